@@ -1,0 +1,449 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (pyro2) itself.
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container (the reference does not
+exist on the GPU box):
+
+    cd /tmp && MPLBACKEND=Agg \
+      PYTHONPATH=/root/repo/oracle/shim:/root/reference \
+      /opt/conda/bin/python3.9 /root/repo/oracle/gen_golden.py
+
+The shim replaces numba.njit by the identity (numba is not importable here;
+the decorated functions are plain Python/NumPy) and stubs
+the setuptools_scm-generated pyro/_version.py.  Nothing is copied from the
+reference: its functions are *called* and their inputs/outputs are stored.
+"""
+import os
+import sys
+import tempfile
+
+import h5py
+import numpy as np
+
+os.chdir(tempfile.mkdtemp())  # Pyro writes inputs.auto into cwd
+
+import pyro.compressible as comp                       # noqa: E402
+import pyro.compressible.interface as ifc              # noqa: E402
+import pyro.compressible.unsplit_fluxes as flx         # noqa: E402
+import pyro.mesh.array_indexer as ai                   # noqa: E402
+import pyro.mesh.boundary as bnd                       # noqa: E402
+import pyro.multigrid.MG as MG                         # noqa: E402
+from pyro.advection import advective_fluxes            # noqa: E402
+from pyro.advection.interface import linear_interface  # noqa: E402
+from pyro.compressible import riemann                  # noqa: E402
+from pyro.mesh import patch, reconstruction            # noqa: E402
+from pyro.pyro_sim import Pyro                         # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+REF = "/root/reference/pyro"
+os.makedirs(OUT, exist_ok=True)
+
+
+def save(name, **kw):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+# --------------------------------------------------------------------------
+# ghost fill (a1): every BC type, ng = 4 and ng = 1, non-square grid
+# --------------------------------------------------------------------------
+def gen_fill_bc():
+    rng = np.random.default_rng(1)
+    out = {}
+    cases = [("outflow",) * 4, ("periodic",) * 4,
+             ("reflect-even", "reflect-odd", "reflect-odd", "reflect-even"),
+             ("outflow", "reflect-even", "periodic", "periodic"),
+             ("reflect-odd", "outflow", "reflect-even", "outflow")]
+    for ng in (4, 1):
+        for k, bcs in enumerate(cases):
+            g = patch.Grid2d(6 if ng == 1 else 9, 8 if ng == 1 else 7, ng=ng)
+            d = patch.CellCenterData2d(g)
+            bc = bnd.BC(xlb=bcs[0], xrb=bcs[1], ylb=bcs[2], yrb=bcs[3])
+            d.register_var("a", bc)
+            d.create()
+            a = d.get_var("a")
+            a[:, :] = rng.standard_normal(a.shape)
+            out[f"in_ng{ng}_{k}"] = np.array(a)
+            d.fill_BC("a")
+            out[f"out_ng{ng}_{k}"] = np.array(d.get_var("a"))
+            out[f"bc_ng{ng}_{k}"] = np.array(bcs)
+    save("fill_bc", **out)
+
+
+# --------------------------------------------------------------------------
+# advection (a2, a4-a6)
+# --------------------------------------------------------------------------
+def gen_advection():
+    # (i) stage dumps of one step on small grids, all velocity sign combos
+    out = {}
+    rng = np.random.default_rng(2)
+    k = 0
+    for (nx, ny) in ((12, 9), (8, 16)):
+        for (u, v) in ((1.0, 1.0), (-0.7, 0.4), (0.3, -1.2), (-1.0, -0.5), (0.0, 1.0)):
+            for limiter in (0, 1, 2):
+                if limiter != 2 and (u, v) != (-0.7, 0.4):
+                    continue
+                p = Pyro("advection")
+                p.initialize_problem("smooth", inputs_dict={
+                    "mesh.nx": nx, "mesh.ny": ny, "advection.u": u,
+                    "advection.v": v, "advection.limiter": limiter,
+                    "particles.do_particles": 0,
+                    "mesh.xlboundary": "outflow" if k % 2 else "periodic",
+                    "mesh.xrboundary": "outflow" if k % 2 else "periodic"})
+                sim = p.sim
+                dens = sim.cc_data.get_var("density")
+                dens[:, :] += 0.3 * rng.standard_normal(dens.shape)  # kinks
+                sim.cc_data.fill_BC_all()
+                sim.compute_timestep()
+                myg = sim.cc_data.grid
+                a0 = np.array(dens)
+                lx = reconstruction.limit(dens, myg, 1, limiter)
+                ly = reconstruction.limit(dens, myg, 2, limiter)
+                _, _, a_x, a_y = linear_interface(dens, myg, sim.rp, sim.dt)
+                Fx, Fy = advective_fluxes.unsplit_fluxes(
+                    sim.cc_data, sim.rp, sim.dt, "density", linear_interface)
+                sim.evolve()
+                pre = f"s{k}_"
+                out[pre + "meta"] = np.array([nx, ny, 4, myg.dx, myg.dy, u, v,
+                                              sim.dt, limiter])
+                out[pre + "a0"] = a0
+                out[pre + "ldx"] = np.array(lx)
+                out[pre + "ldy"] = np.array(ly)
+                out[pre + "ax"] = np.array(a_x)
+                out[pre + "ay"] = np.array(a_y)
+                out[pre + "Fx"] = np.array(Fx)
+                out[pre + "Fy"] = np.array(Fy)
+                out[pre + "a1"] = np.array(sim.cc_data.get_var("density"))
+                k += 1
+    out["ncases"] = np.array(k)
+    save("adv_stages", **out)
+
+    # (ii) the reference's own regression: advection smooth inputs.smooth
+    # (32^2, 40 steps) vs pyro/advection/tests/smooth_0040.h5 (test.py:93)
+    p = Pyro("advection")
+    p.initialize_problem("smooth", inputs_dict={"particles.do_particles": 0})
+    ic = np.array(p.sim.cc_data.get_var("density"))
+    dts = []
+    while not p.sim.finished():
+        p.single_step()
+        dts.append(p.sim.dt)
+    with h5py.File(REF + "/advection/tests/smooth_0040.h5", "r") as f:
+        gold = f["state/density/data"][...]
+        assert f.attrs["nsteps"] == p.sim.n == 40
+        tgold = f.attrs["time"]
+    mine = p.sim.cc_data.get_var("density").v()
+    err = np.abs(mine - gold).max()
+    print("advection smooth 32^2 x40: reference-run vs stored golden, max abs err", err)
+    assert err < 1e-13
+    save("adv_smooth_0040", ic=ic, gold=gold, run=np.array(mine),
+         dts=np.array(dts), t=np.array(tgold))
+
+    # (iii) 64^2 run to tmax (81 steps): convergence-table known answer
+    # pyro/advection/tests/advection_convergence.txt:8
+    p = Pyro("advection")
+    p.initialize_problem("smooth", inputs_dict={"mesh.nx": 64, "mesh.ny": 64,
+                                                "particles.do_particles": 0})
+    ic = np.array(p.sim.cc_data.get_var("density"))
+    dts = []
+    while not p.sim.finished():
+        p.single_step()
+        dts.append(p.sim.dt)
+    fin = np.array(p.sim.cc_data.get_var("density"))
+    save("adv_smooth_64", ic=ic, final=fin, dts=np.array(dts), n=np.array(p.sim.n))
+
+
+# --------------------------------------------------------------------------
+# compressible (a3, a7-a12)
+# --------------------------------------------------------------------------
+def comp_stage_dump(sim):
+    """replicate Simulation.evolve (compressible/simulation.py:290-450) by
+    CALLING the reference's functions, keeping every intermediate array."""
+    rp, ivars, myg, tc = sim.rp, sim.ivars, sim.cc_data.grid, sim.tc
+    dt = sim.dt
+    gamma = rp.get_param("eos.gamma")
+    st = {}
+    sim.clean_state(sim.cc_data.data)
+    U0 = np.array(sim.cc_data.data)
+    st["U0"] = U0
+    q = comp.cons_to_prim(sim.cc_data.data, gamma, ivars, myg)
+    st["q"] = np.array(q)
+    if rp.get_param("compressible.use_flattening"):
+        xi_x = reconstruction.flatten(myg, q, 1, ivars, rp)
+        xi_y = reconstruction.flatten(myg, q, 2, ivars, rp)
+        xi = reconstruction.flatten_multid(myg, q, xi_x, xi_y, ivars)
+        st["xi"] = np.array(xi)
+    else:
+        xi = 1.0
+        st["xi"] = np.ones((myg.qx, myg.qy))
+    limiter = rp.get_param("compressible.limiter")
+    ldx = myg.scratch_array(nvar=ivars.nvar)
+    ldy = myg.scratch_array(nvar=ivars.nvar)
+    for n in range(ivars.nvar):
+        ldx[:, :, n] = xi * reconstruction.limit(q[:, :, n], myg, 1, limiter)
+        ldy[:, :, n] = xi * reconstruction.limit(q[:, :, n], myg, 2, limiter)
+    st["ldx"], st["ldy"] = np.array(ldx), np.array(ldy)
+
+    U_xl, U_xr, U_yl, U_yr = flx.interface_states(sim.cc_data, rp, ivars, tc, dt)
+    U_xl, U_xr, U_yl, U_yr = flx.apply_source_terms(
+        U_xl, U_xr, U_yl, U_yr, sim.cc_data, sim.aux_data, rp, ivars, tc, dt,
+        problem_source=sim.problem_source)
+    for nm, a in (("Uxl0", U_xl), ("Uxr0", U_xr), ("Uyl0", U_yl), ("Uyr0", U_yr)):
+        st[nm] = np.array(a)
+    FxT = riemann.riemann_flux(1, U_xl, U_xr, sim.cc_data, rp, ivars,
+                               sim.solid.xl, sim.solid.xr, tc)
+    FyT = riemann.riemann_flux(2, U_yl, U_yr, sim.cc_data, rp, ivars,
+                               sim.solid.yl, sim.solid.yr, tc)
+    st["FxT"], st["FyT"] = np.array(FxT), np.array(FyT)
+    U_xl, U_xr, U_yl, U_yr = flx.apply_transverse_flux(
+        U_xl, U_xr, U_yl, U_yr, sim.cc_data, rp, ivars, sim.solid, tc, dt)
+    for nm, a in (("Uxl", U_xl), ("Uxr", U_xr), ("Uyl", U_yl), ("Uyr", U_yr)):
+        st[nm] = np.array(a)
+    F_x = riemann.riemann_flux(1, U_xl, U_xr, sim.cc_data, rp, ivars,
+                               sim.solid.xl, sim.solid.xr, tc)
+    F_y = riemann.riemann_flux(2, U_yl, U_yr, sim.cc_data, rp, ivars,
+                               sim.solid.yl, sim.solid.yr, tc)
+    st["Fx0"], st["Fy0"] = np.array(F_x), np.array(F_y)
+    cvisc = rp.get_param("compressible.cvisc")
+    _ax, _ay = ifc.artificial_viscosity(
+        myg.ng, myg.dx, myg.dy, myg.Lx, myg.Ly, myg.xmin, myg.ymin,
+        myg.coord_type, cvisc, q.v(n=ivars.iu, buf=myg.ng),
+        q.v(n=ivars.iv, buf=myg.ng))
+    st["avx"], st["avy"] = np.array(_ax), np.array(_ay)
+    F_x, F_y = flx.apply_artificial_viscosity(F_x, F_y, q, sim.cc_data, rp, ivars)
+    st["Fx"], st["Fy"] = np.array(F_x), np.array(F_y)
+    # and now the reference's own evolve for the end state
+    sim.evolve()
+    st["U1"] = np.array(sim.cc_data.data)
+    return st
+
+
+def bc_names(rp):
+    return np.array([rp.get_param("mesh." + k) for k in
+                     ("xlboundary", "xrboundary", "ylboundary", "yrboundary")])
+
+
+def comp_meta(sim):
+    rp, g = sim.rp, sim.cc_data.grid
+    return np.array([g.nx, g.ny, g.ng, g.dx, g.dy, rp.get_param("eos.gamma"),
+                     rp.get_param("compressible.limiter"),
+                     rp.get_param("compressible.use_flattening"),
+                     rp.get_param("compressible.z0"), rp.get_param("compressible.z1"),
+                     rp.get_param("compressible.delta"),
+                     rp.get_param("compressible.cvisc"),
+                     rp.get_param("compressible.grav"),
+                     rp.get_param("driver.cfl")])
+
+
+def gen_compressible_stages():
+    cases = [
+        ("sedov", None, {"mesh.nx": 24, "mesh.ny": 24, "sedov.r_init": 0.12}, 9),
+        ("sedov", None, {"mesh.nx": 20, "mesh.ny": 28, "sedov.r_init": 0.15,
+                         "compressible.limiter": 1}, 7),
+        ("quad", None, {"mesh.nx": 24, "mesh.ny": 20}, 12),
+        ("quad", None, {"mesh.nx": 16, "mesh.ny": 16,
+                        "compressible.use_flattening": 0,
+                        "compressible.limiter": 0}, 6),
+        ("sod", "inputs.sod.x", {"mesh.nx": 32, "mesh.ny": 8}, 10),
+        ("sod", "inputs.sod.y", {"mesh.nx": 8, "mesh.ny": 32,
+                                 "compressible.limiter": 2}, 10),
+        ("kh", None, {"mesh.nx": 16, "mesh.ny": 24}, 8),
+        ("sedov", None, {"mesh.nx": 16, "mesh.ny": 16, "sedov.r_init": 0.2,
+                         "mesh.xlboundary": "reflect", "mesh.xrboundary": "reflect",
+                         "mesh.ylboundary": "reflect", "mesh.yrboundary": "reflect",
+                         "compressible.grav": -0.5}, 6),
+    ]
+    out = {"ncases": np.array(len(cases))}
+    for k, (prob, inp, d, nsteps) in enumerate(cases):
+        p = Pyro("compressible")
+        p.initialize_problem(prob, inputs_file=inp, inputs_dict=d)
+        sim = p.sim
+        dts = []
+        for _ in range(nsteps):
+            p.single_step()
+            dts.append(sim.dt)
+        sim.cc_data.fill_BC_all()
+        sim.compute_timestep()
+        pre = f"c{k}_"
+        out[pre + "meta"] = comp_meta(sim)
+        out[pre + "bc"] = bc_names(sim.rp)
+        out[pre + "dt"] = np.array(sim.dt)
+        out[pre + "dt_method"] = np.array(_raw_cfl_dt(sim))
+        st = comp_stage_dump(sim)
+        for nm, a in st.items():
+            out[pre + nm] = a
+        print("compressible stage case", k, prob, d, "dt", sim.dt)
+    save("comp_stages", **out)
+
+
+def _raw_cfl_dt(sim):
+    dt_keep, dto_keep = sim.dt, sim.dt_old
+    sim.method_compute_timestep()
+    raw = sim.dt
+    sim.dt, sim.dt_old = dt_keep, dto_keep
+    return raw
+
+
+def gen_compressible_runs():
+    # (i) sedov 64^2, 20 steps: SURVEY 8(c) fingerprint
+    p = Pyro("compressible")
+    p.initialize_problem("sedov", inputs_dict={"mesh.nx": 64, "mesh.ny": 64,
+                                               "driver.max_steps": 20})
+    ic = np.array(p.sim.cc_data.data)
+    dts = []
+    while not p.sim.finished():
+        p.single_step()
+        dts.append(p.sim.dt)
+    save("comp_sedov_64_020", ic=ic, final=np.array(p.sim.cc_data.data),
+         dts=np.array(dts), meta=comp_meta(p.sim), bc=bc_names(p.sim.rp),
+         t=np.array(p.sim.cc_data.t))
+
+    # (ii) reference regression: compressible sod inputs.sod.x (128x10, 76
+    # steps) vs pyro/compressible/tests/sod_x_0076.h5 (test.py:101)
+    p = Pyro("compressible")
+    p.initialize_problem("sod", inputs_file="inputs.sod.x")
+    ic = np.array(p.sim.cc_data.data)
+    dts = []
+    while not p.sim.finished():
+        p.single_step()
+        dts.append(p.sim.dt)
+    gold = {}
+    with h5py.File(REF + "/compressible/tests/sod_x_0076.h5", "r") as f:
+        assert f.attrs["nsteps"] == p.sim.n
+        for nm in ("density", "energy", "x-momentum", "y-momentum"):
+            gold[nm] = f["state/" + nm + "/data"][...]
+    names = ["density", "energy", "x-momentum", "y-momentum"]
+    g = np.stack([gold[nm] for nm in names], axis=-1)
+    run = np.stack([np.array(p.sim.cc_data.get_var(nm).v()) for nm in names], axis=-1)
+    print("sod_x: reference-run vs stored golden, max abs err", np.abs(run - g).max())
+    assert np.abs(run - g).max() < 1e-12
+    save("comp_sod_x_0076", ic=ic, gold=g, run=run, dts=np.array(dts),
+         meta=comp_meta(p.sim), bc=bc_names(p.sim.rp), tmax=np.array(p.sim.tmax))
+
+    # (iii) reference regression: compressible quad inputs.quad (256^2, 606
+    # steps) vs quad_unsplit_0606.h5 (test.py:100).  Too slow to re-run with
+    # interpreted njit kernels; we store the reference's IC (its init_data is
+    # run here) and its stored golden end state.  The C oracle is then
+    # required to reproduce the golden from the IC (tests/test_oracle_golden).
+    p = Pyro("compressible")
+    p.initialize_problem("quad", inputs_file="inputs.quad")
+    ic = np.array(p.sim.cc_data.data)
+    with h5py.File(REF + "/compressible/tests/quad_unsplit_0606.h5", "r") as f:
+        nsteps = int(f.attrs["nsteps"])
+        tfin = float(f.attrs["time"])
+        g = np.stack([f["state/" + nm + "/data"][...] for nm in names], axis=-1)
+    save("comp_quad_0606", ic=ic.astype(np.float64), gold=g, nsteps=np.array(nsteps),
+         t=np.array(tfin), meta=comp_meta(p.sim), bc=bc_names(p.sim.rp),
+         tmax=np.array(p.sim.tmax),
+         drv=np.array([p.rp.get_param("driver.init_tstep_factor"),
+                       p.rp.get_param("driver.max_dt_change")]))
+
+
+# --------------------------------------------------------------------------
+# multigrid (a14-a18)
+# --------------------------------------------------------------------------
+def gen_mg():
+    import pyro.multigrid.examples.mg_test_simple as mts
+
+    # (i) reference regression mg_poisson_dirichlet 256^2 (test.py:138-140)
+    nx = 256
+    a = MG.CellCenterMG2d(nx, nx, xl_BC_type="dirichlet", yl_BC_type="dirichlet",
+                          xr_BC_type="dirichlet", yr_BC_type="dirichlet", verbose=0)
+    a.init_zeros()
+    rhs = mts.f(a.x2d, a.y2d)
+    a.init_RHS(rhs)
+    a.solve(rtol=1.e-11)
+    v = a.get_solution()
+    with h5py.File(REF + "/multigrid/tests/mg_poisson_dirichlet.h5", "r") as f:
+        gv = f["state/v/data"][...]
+    print("mg 256: reference-run vs stored golden max abs", np.abs(v.v() - gv).max(),
+          "cycles", a.num_cycles)
+    assert np.abs(v.v() - gv).max() == 0.0
+    save("mg_poisson_dirichlet_256", rhs=np.array(rhs), gold=gv,
+         ncycles=np.array(a.num_cycles), source_norm=np.array(a.source_norm),
+         residual_error=np.array(a.residual_error),
+         relative_error=np.array(a.relative_error))
+
+    # (ii) per-operator vectors on 16^2 / 32^2 for every BC flavour
+    out = {}
+    rng = np.random.default_rng(3)
+    k = 0
+    for nx in (16, 32):
+        for bcs, inhom in ((("dirichlet",) * 4, False), (("dirichlet",) * 4, True),
+                           (("neumann",) * 4, False), (("neumann", "neumann", "dirichlet", "dirichlet"), True),
+                           (("periodic",) * 4, False),
+                           (("periodic", "periodic", "dirichlet", "neumann"), False)):
+            for (alpha, beta) in ((0.0, -1.0), (2.5, 0.3)):
+                if (alpha, beta) != (0.0, -1.0) and nx != 16:
+                    continue
+                kw = {}
+                if inhom:
+                    kw = dict(xl_BC=lambda y: np.sin(y) + 0.2, xr_BC=lambda y: 0.5 * y - 0.1,
+                              yl_BC=lambda x: x * x, yr_BC=lambda x: np.cos(3 * x))
+                a = MG.CellCenterMG2d(nx, nx, xl_BC_type=bcs[0], xr_BC_type=bcs[1],
+                                      yl_BC_type=bcs[2], yr_BC_type=bcs[3],
+                                      alpha=alpha, beta=beta, nsmooth=3,
+                                      nsmooth_bottom=7, verbose=0, **kw)
+                L = a.nlevels - 1
+                v0 = rng.standard_normal((nx + 2, nx + 2))
+                f0 = rng.standard_normal((nx + 2, nx + 2))
+                a.init_solution(v0)
+                a.init_RHS(f0)
+                pre = f"m{k}_"
+                out[pre + "meta"] = np.array([nx, alpha, beta, 3, 7, int(inhom)])
+                out[pre + "bc"] = np.array(bcs)
+                out[pre + "v0"], out[pre + "f0"] = v0, f0
+                if inhom:
+                    bc_obj = a.grids[L].BCs["v"]
+                    out[pre + "bcvals"] = np.stack([bc_obj.xl_value, bc_obj.xr_value,
+                                                    bc_obj.yl_value, bc_obj.yr_value])
+                a.smooth(L, 2)
+                out[pre + "v_smooth"] = np.array(a.grids[L].get_var("v"))
+                a._compute_residual(L)
+                out[pre + "r"] = np.array(a.grids[L].get_var("r"))
+                out[pre + "rnorm"] = np.array(a.grids[L].get_var("r").norm())
+                out[pre + "restrict"] = np.array(a.grids[L].restrict("r"))
+                # prolong the (filled) fine v of level L-1 source: use coarse grid data
+                cp = a.grids[L - 1]
+                cv = cp.get_var("v")
+                cv[:, :] = rng.standard_normal(cv.shape)
+                cp.fill_BC("v")
+                out[pre + "cv"] = np.array(cv)
+                out[pre + "prolong"] = np.array(cp.prolong("v"))
+                # a full V-cycle and then a solve from a fresh object
+                b = MG.CellCenterMG2d(nx, nx, xl_BC_type=bcs[0], xr_BC_type=bcs[1],
+                                      yl_BC_type=bcs[2], yr_BC_type=bcs[3],
+                                      alpha=alpha, beta=beta, nsmooth=3,
+                                      nsmooth_bottom=7, verbose=0, **kw)
+                b.init_solution(v0)
+                f1 = f0.copy()
+                if bcs[0] in ("periodic", "neumann") and alpha == 0.0 and \
+                        all(x in ("periodic", "neumann") for x in bcs):
+                    f1[1:-1, 1:-1] -= f1[1:-1, 1:-1].mean()   # solvability
+                b.init_RHS(f1)
+                out[pre + "f1"] = f1
+                for lev in range(L):
+                    b.grids[lev].zero("v")
+                b.v_cycle(L)
+                out[pre + "v_vcycle"] = np.array(b.grids[L].get_var("v"))
+                b.max_cycles = 6
+                b.solve(rtol=1.e-10)
+                out[pre + "v_solve"] = np.array(b.grids[L].get_var("v"))
+                out[pre + "solve_info"] = np.array([b.num_cycles, b.residual_error,
+                                                    b.relative_error, b.source_norm])
+                k += 1
+    out["ncases"] = np.array(k)
+    save("mg_ops", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["bc", "adv", "comp_stages", "comp_runs", "mg"]
+    if "bc" in which:
+        gen_fill_bc()
+    if "adv" in which:
+        gen_advection()
+    if "comp_stages" in which:
+        gen_compressible_stages()
+    if "comp_runs" in which:
+        gen_compressible_runs()
+    if "mg" in which:
+        gen_mg()

@@ -1,0 +1,249 @@
+"""ctypes front-end for oracle/pyro_oracle.c.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg as the checker.  The product path (pyro2_amd/)
+never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "liborc.so")
+
+BC_CODES = {"outflow": 0, "neumann": 0, "reflect-even": 1, "reflect-odd": 2,
+            "dirichlet": 2, "periodic": 3}
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "pyro_oracle.c")
+    if force or not os.path.exists(_LIB) or \
+            os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _LIB
+
+
+class CompParams(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("ng", C.c_int),
+                ("dx", C.c_double), ("dy", C.c_double), ("gamma", C.c_double),
+                ("limiter", C.c_int), ("use_flattening", C.c_int),
+                ("z0", C.c_double), ("z1", C.c_double), ("delta", C.c_double),
+                ("cvisc", C.c_double), ("grav", C.c_double),
+                ("small_dens", C.c_double), ("bc", (C.c_int * 4) * 4),
+                ("avisc_xhi_interior", C.c_int),
+                ("avisc_yhi_interior", C.c_int)]
+
+
+_STAGE_NAMES = ["q", "xi", "ldx", "ldy", "Uxl0", "Uxr0", "Uyl0", "Uyr0",
+                "FxT", "FyT", "Uxl", "Uxr", "Uyl", "Uyr", "Fx0", "Fy0",
+                "avx", "avy", "Fx", "Fy"]
+_SCALAR_STAGES = {"xi", "avx", "avy"}
+
+
+class CompStages(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in _STAGE_NAMES]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        _lib.orc_adv_dt.restype = C.c_double
+        _lib.orc_comp_dt.restype = C.c_double
+        _lib.orc_mg_create.restype = C.c_void_p
+        _lib.orc_mg_ptr.restype = C.POINTER(C.c_double)
+        _lib.orc_mg_norm.restype = C.c_double
+        _lib.orc_mg_get_scalar.restype = C.c_double
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ck(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a
+
+
+def bc_codes(bcs):
+    """('outflow','outflow','reflect-even','periodic') -> int32[4]"""
+    return np.array([BC_CODES[b] if isinstance(b, str) else int(b)
+                     for b in bcs], dtype=np.int32)
+
+
+def fill_ghost(a, nx, ny, ng, bcs, n=0):
+    """a: (qx,qy) or (qx,qy,nvar) float64, in place."""
+    _ck(a)
+    nvar = 1 if a.ndim == 2 else a.shape[2]
+    bc = bc_codes(bcs)
+    lib().orc_fill_ghost(_p(a), nx, ny, ng, nvar, n,
+                         bc.ctypes.data_as(C.POINTER(C.c_int)))
+    return a
+
+
+def limit(a, nx, ny, ng, idir, limiter):
+    _ck(a)
+    out = np.zeros_like(a)
+    lib().orc_limit(_p(a), 1, nx, ny, ng, idir, limiter, _p(out))
+    return out
+
+
+def adv_dt(dx, dy, u, v, cfl):
+    return lib().orc_adv_dt(C.c_double(dx), C.c_double(dy), C.c_double(u),
+                            C.c_double(v), C.c_double(cfl))
+
+
+def adv_step(a, nx, ny, ng, dx, dy, u, v, dt, limiter, stages=False):
+    """one advection step in place on a (qx,qy) (ghosts must be filled)."""
+    _ck(a)
+    outs = {}
+    ptrs = []
+    for name in ("ldx", "ldy", "ax", "ay", "Fx", "Fy"):
+        if stages:
+            outs[name] = np.zeros_like(a)
+            ptrs.append(_p(outs[name]))
+        else:
+            ptrs.append(None)
+    lib().orc_adv_step(_p(a), nx, ny, ng, C.c_double(dx), C.c_double(dy),
+                       C.c_double(u), C.c_double(v), C.c_double(dt), limiter,
+                       *ptrs)
+    return outs
+
+
+def comp_params(nx, ny, ng, dx, dy, gamma=1.4, limiter=2, use_flattening=1,
+                z0=0.75, z1=0.85, delta=0.33, cvisc=0.1, grav=0.0,
+                small_dens=-1.e200, bcs=("outflow",) * 4,
+                avisc_xhi_interior=0, avisc_yhi_interior=0):
+    P = CompParams()
+    P.nx, P.ny, P.ng = nx, ny, ng
+    P.dx, P.dy, P.gamma = dx, dy, gamma
+    P.limiter, P.use_flattening = limiter, use_flattening
+    P.z0, P.z1, P.delta = z0, z1, delta
+    P.cvisc, P.grav, P.small_dens = cvisc, grav, small_dens
+    vb = comp_var_bcs(bcs)
+    for n in range(4):
+        for s in range(4):
+            P.bc[n][s] = int(vb[n][s])
+    P.avisc_xhi_interior = avisc_xhi_interior
+    P.avisc_yhi_interior = avisc_yhi_interior
+    return P
+
+
+def comp_var_bcs(bcs):
+    """per-variable BC codes for (dens, ener, xmom, ymom) given the four mesh
+    boundary types; 'reflect' is even except for the normal momentum
+    (simulation_null.py:99-112, compressible/simulation.py:216-226)."""
+    out = np.zeros((4, 4), dtype=np.int32)
+    for n in range(4):
+        for s, b in enumerate(bcs):
+            if b == "reflect":
+                odd = (n == 2 and s < 2) or (n == 3 and s >= 2)
+                out[n, s] = 2 if odd else 1
+            else:
+                out[n, s] = BC_CODES[b]
+    return out
+
+
+def comp_fill_bc(U, nx, ny, ng, bcs):
+    vb = comp_var_bcs(bcs)
+    for n in range(4):
+        lib().orc_fill_ghost(_p(U), nx, ny, ng, 4, n,
+                             vb[n].ctypes.data_as(C.POINTER(C.c_int)))
+    return U
+
+
+def comp_dt(U, nx, ny, ng, dx, dy, gamma, cfl):
+    _ck(U)
+    return lib().orc_comp_dt(_p(U), nx, ny, ng, C.c_double(dx),
+                             C.c_double(dy), C.c_double(gamma),
+                             C.c_double(cfl))
+
+
+def comp_step(U, P, dt, stages=False):
+    """one compressible step in place on U (qx,qy,4) (ghosts filled).
+    returns (rc, stages dict)"""
+    _ck(U)
+    outs = {}
+    st = CompStages()
+    if stages:
+        qx, qy = U.shape[:2]
+        for name in _STAGE_NAMES:
+            shp = (qx, qy) if name in _SCALAR_STAGES else (qx, qy, 4)
+            outs[name] = np.zeros(shp)
+            setattr(st, name, _p(outs[name]))
+    rc = lib().orc_comp_step(_p(U), C.byref(P), C.c_double(dt),
+                             C.byref(st) if stages else None)
+    return rc, outs
+
+
+class MG:
+    """mirror of MG.CellCenterMG2d's numerical core (constant coefficients)"""
+
+    def __init__(self, nx, xmin=0.0, xmax=1.0, ymin=0.0, ymax=1.0,
+                 bcs=("dirichlet",) * 4, alpha=0.0, beta=-1.0, nsmooth=10,
+                 nsmooth_bottom=50):
+        bc = bc_codes(bcs)
+        self._l = lib()
+        self.h = C.c_void_p(self._l.orc_mg_create(
+            nx, C.c_double(xmin), C.c_double(xmax), C.c_double(ymin),
+            C.c_double(ymax), bc.ctypes.data_as(C.POINTER(C.c_int)),
+            C.c_double(alpha), C.c_double(beta), nsmooth, nsmooth_bottom))
+        self.nx = nx
+        self.nlevels = self._l.orc_mg_nlevels(self.h)
+
+    def __del__(self):
+        try:
+            self._l.orc_mg_free(self.h)
+        except Exception:
+            pass
+
+    def arr(self, level, var):
+        """numpy view of a level array; var: 0=v 1=f 2=r"""
+        n = 2 ** (level + 1) + 2
+        p = self._l.orc_mg_ptr(self.h, level, var)
+        return np.ctypeslib.as_array(p, shape=(n, n))
+
+    def set_bcval(self, side, vals):
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        self._l.orc_mg_set_bcval(self.h, side, _p(vals))
+
+    def init_rhs(self, f):
+        self.arr(self.nlevels - 1, 1)[:, :] = f
+        self._l.orc_mg_init_rhs_norm(self.h)
+
+    def smooth(self, level, n):
+        self._l.orc_mg_smooth(self.h, level, n)
+
+    def residual(self, level):
+        self._l.orc_mg_residual(self.h, level)
+
+    def restrict(self, level):
+        self._l.orc_mg_restrict(self.h, level)
+
+    def prolong_add(self, level):
+        self._l.orc_mg_prolong_add(self.h, level)
+
+    def fill_bc_v(self, level):
+        self._l.orc_mg_fill_bc_v(self.h, level)
+
+    def vcycle(self, level=None):
+        self._l.orc_mg_vcycle(self.h, self.nlevels - 1 if level is None else level)
+
+    def norm(self, level, var):
+        return self._l.orc_mg_norm(self.h, level, var)
+
+    def solve(self, rtol=1.e-11, max_cycles=100):
+        self._l.orc_mg_set_max_cycles(self.h, max_cycles)
+        self._l.orc_mg_solve(self.h, C.c_double(rtol))
+        g = self._l.orc_mg_get_scalar
+        self.source_norm = g(self.h, 0)
+        self.num_cycles = int(g(self.h, 1))
+        self.relative_error = g(self.h, 2)
+        self.residual_error = g(self.h, 3)

@@ -1,0 +1,1190 @@
+/*
+ * pyro_oracle.c -- CPU restatement of pyro2's per-timestep hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (pyro2_amd/) may
+ * import, link or call this file; it is the checker used by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ *
+ * It follows the reference statement-by-statement, including the reference's
+ * "full scratch array, zero outside the region that was written" semantics,
+ * so stage arrays can be compared index-for-index (ghost cells included)
+ * with arrays dumped from the reference itself (oracle/gen_golden.py).
+ * Parity is PINNED: tests/test_oracle_golden.py checks this file against
+ * (i) stage dumps of the reference run in this container and (ii) the
+ * reference's own golden files (smooth_0040, sod_x_0076, quad_unsplit_0606,
+ * mg_poisson_dirichlet), exported to tests/golden/ by oracle/gen_golden.py.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).
+ * -ffp-contract=off matters: the reference is NumPy/numba without FMA
+ * contraction and we want bit-level agreement.
+ *
+ * Array conventions (same as the reference, pyro/mesh/patch.py:450-452):
+ *   scalar fields  double a[qx][qy]        C order, j (y) fastest
+ *   vector fields  double U[qx][qy][nvar]  C order, component fastest
+ *   conserved order: density(0) energy(1) x-momentum(2) y-momentum(3)
+ *                    (pyro/compressible/simulation.py:223-226)
+ *   primitive order: rho(0) u(1) v(2) p(3)   (simulation.py:38-41)
+ * Python grid attrs: ilo=ng, ihi=ng+nx-1 (inclusive).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define IDENS 0
+#define IENER 1
+#define IXMOM 2
+#define IYMOM 3
+#define IRHO 0
+#define IU 1
+#define IV 2
+#define IP 3
+
+/* BC codes shared with include/pyrohip.h */
+#define BC_OUTFLOW 0      /* also homogeneous neumann */
+#define BC_REFLECT_EVEN 1
+#define BC_REFLECT_ODD 2  /* also homogeneous dirichlet */
+#define BC_PERIODIC 3
+
+typedef struct {
+    int nx, ny, ng;
+    double dx, dy;
+    double gamma;
+    int limiter;         /* 0 none, 1 MC2, 2 MC4 */
+    int use_flattening;
+    double z0, z1, delta;
+    double cvisc;
+    double grav;
+    double small_dens;
+    /* bc[var][side]: var in conserved order, side = xl,xr,yl,yr.  Only used
+       for the source-term ghost fill when grav != 0. */
+    int bc[4][4];
+    /* domain-decomposition hook: when non-zero the artificial
+       viscosity coefficient on the upper x / y boundary face is computed
+       instead of being left at the reference's 0 (interface.py:366-367),
+       because that face is an interior interface of the global grid. */
+    int avisc_xhi_interior, avisc_yhi_interior;
+} orc_comp_params;
+
+/* optional stage outputs; any pointer may be NULL */
+typedef struct {
+    double *q;                       /* (qx,qy,4) */
+    double *xi;                      /* (qx,qy)   */
+    double *ldx, *ldy;               /* (qx,qy,4) */
+    double *Uxl0, *Uxr0, *Uyl0, *Uyr0; /* states before transverse corr. */
+    double *FxT, *FyT;               /* transverse Riemann fluxes */
+    double *Uxl, *Uxr, *Uyl, *Uyr;   /* corrected states */
+    double *Fx0, *Fy0;               /* final Riemann fluxes before avisc */
+    double *avx, *avy;               /* (qx,qy) */
+    double *Fx, *Fy;                 /* fluxes incl. artificial viscosity */
+} orc_comp_stages;
+
+static double *zalloc(size_t n) { return (double *)calloc(n, sizeof(double)); }
+static inline double dmax(double a, double b) { return a > b ? a : b; }
+static inline double dmin(double a, double b) { return a < b ? a : b; }
+
+/* ------------------------------------------------------------------ */
+/* a1: ghost fill, pyro/mesh/array_indexer.py:150-274                  */
+/* operates on component n of a (qx,qy,nvar) array; bc = xl,xr,yl,yr   */
+/* ------------------------------------------------------------------ */
+void orc_fill_ghost(double *a, int nx, int ny, int ng, int nvar, int n,
+                    const int *bc)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx - 1, jlo = ng, jhi = ng + ny - 1;
+#define A(i, j) a[((size_t)(i) * qy + (j)) * nvar + n]
+    /* -x : all j including ghosts (array_indexer.py:163-190) */
+    for (int i = 0; i < ilo; i++)
+        for (int j = 0; j < qy; j++) {
+            switch (bc[0]) {
+            case BC_OUTFLOW: A(i, j) = A(ilo, j); break;
+            case BC_REFLECT_EVEN: A(i, j) = A(2 * ng - i - 1, j); break;
+            case BC_REFLECT_ODD: A(i, j) = -A(2 * ng - i - 1, j); break;
+            case BC_PERIODIC: A(i, j) = A(ihi - ng + i + 1, j); break;
+            }
+        }
+    /* +x (array_indexer.py:192-221) */
+    for (int k = 0; k < ng; k++)
+        for (int j = 0; j < qy; j++) {
+            int i = ihi + 1 + k;
+            switch (bc[1]) {
+            case BC_OUTFLOW: A(i, j) = A(ihi, j); break;
+            case BC_REFLECT_EVEN: A(i, j) = A(ihi - k, j); break;
+            case BC_REFLECT_ODD: A(i, j) = -A(ihi - k, j); break;
+            case BC_PERIODIC: A(i, j) = A(i - ihi - 1 + ng, j); break;
+            }
+        }
+    /* -y : all i including the x ghosts just filled (:223-244) */
+    for (int i = 0; i < qx; i++)
+        for (int j = 0; j < jlo; j++) {
+            switch (bc[2]) {
+            case BC_OUTFLOW: A(i, j) = A(i, jlo); break;
+            case BC_REFLECT_EVEN: A(i, j) = A(i, 2 * ng - j - 1); break;
+            case BC_REFLECT_ODD: A(i, j) = -A(i, 2 * ng - j - 1); break;
+            case BC_PERIODIC: A(i, j) = A(i, jhi - ng + j + 1); break;
+            }
+        }
+    /* +y (:246-274) */
+    for (int i = 0; i < qx; i++)
+        for (int k = 0; k < ng; k++) {
+            int j = jhi + 1 + k;
+            switch (bc[3]) {
+            case BC_OUTFLOW: A(i, j) = A(i, jhi); break;
+            case BC_REFLECT_EVEN: A(i, j) = A(i, jhi - k); break;
+            case BC_REFLECT_ODD: A(i, j) = -A(i, jhi - k); break;
+            case BC_PERIODIC: A(i, j) = A(i, j - jhi - 1 + ng); break;
+            }
+        }
+#undef A
+}
+
+/* ------------------------------------------------------------------ */
+/* a2: limiters, pyro/mesh/reconstruction.py:56-120                    */
+/* in : a  (qx,qy) with element stride `as` (so a component of a       */
+/*      (qx,qy,nvar) array can be passed)                              */
+/* out: lda (qx,qy) contiguous, zero outside buf=2                     */
+/* ------------------------------------------------------------------ */
+static void limit2_(const double *a, int as, int nx, int ny, int ng,
+                    int idir, double *lda)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx - 1, jlo = ng, jhi = ng + ny - 1;
+    memset(lda, 0, sizeof(double) * qx * qy);
+    const int di = (idir == 1) ? 1 : 0, dj = (idir == 1) ? 0 : 1;
+#define AA(i, j) a[((size_t)(i) * qy + (j)) * as]
+    for (int i = ilo - 2; i <= ihi + 2; i++)
+        for (int j = jlo - 2; j <= jhi + 2; j++) {
+            double ap = AA(i + di, j + dj), am = AA(i - di, j - dj),
+                   a0 = AA(i, j);
+            double dc = 0.5 * (ap - am);
+            double dl = ap - a0;
+            double dr = a0 - am;
+            double d1 = 2.0 * (fabs(dl) < fabs(dr) ? dl : dr);
+            double dt = (fabs(dc) < fabs(d1)) ? dc : d1;
+            lda[(size_t)i * qy + j] = (dl * dr > 0.0) ? dt : 0.0;
+        }
+#undef AA
+}
+
+void orc_limit(const double *a, int as, int nx, int ny, int ng, int idir,
+               int limiter, double *lda)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx - 1, jlo = ng, jhi = ng + ny - 1;
+    const int di = (idir == 1) ? 1 : 0, dj = (idir == 1) ? 0 : 1;
+#define AA(i, j) a[((size_t)(i) * qy + (j)) * as]
+    if (limiter == 0) { /* nolimit, reconstruction.py:56-66 */
+        memset(lda, 0, sizeof(double) * qx * qy);
+        for (int i = ilo - 2; i <= ihi + 2; i++)
+            for (int j = jlo - 2; j <= jhi + 2; j++)
+                lda[(size_t)i * qy + j] =
+                    0.5 * (AA(i + di, j + dj) - AA(i - di, j - dj));
+        return;
+    }
+    if (limiter == 1) {
+        limit2_(a, as, nx, ny, ng, idir, lda);
+        return;
+    }
+    /* limit4, reconstruction.py:94-120 */
+    double *l2 = zalloc((size_t)qx * qy);
+    limit2_(a, as, nx, ny, ng, idir, l2);
+    memset(lda, 0, sizeof(double) * qx * qy);
+    for (int i = ilo - 2; i <= ihi + 2; i++)
+        for (int j = jlo - 2; j <= jhi + 2; j++) {
+            double ap = AA(i + di, j + dj), am = AA(i - di, j - dj),
+                   a0 = AA(i, j);
+            double l2p = l2[(size_t)(i + di) * qy + (j + dj)];
+            double l2m = l2[(size_t)(i - di) * qy + (j - dj)];
+            double dc = (2. / 3.) * (ap - am - 0.25 * (l2p + l2m));
+            double dl = ap - a0;
+            double dr = a0 - am;
+            double d1 = 2.0 * (fabs(dl) < fabs(dr) ? dl : dr);
+            double dt = (fabs(dc) < fabs(d1)) ? dc : d1;
+            lda[(size_t)i * qy + j] = (dl * dr > 0.0) ? dt : 0.0;
+        }
+    free(l2);
+#undef AA
+}
+
+/* ------------------------------------------------------------------ */
+/* a4-a6: advection step, pyro/advection/{interface,advective_fluxes,  */
+/* simulation}.py.  a is (qx,qy) with ghost cells already filled.      */
+/* stage outputs (may be NULL): ldx,ldy,ax,ay,Fx,Fy  all (qx,qy)       */
+/* ------------------------------------------------------------------ */
+void orc_adv_step(double *a, int nx, int ny, int ng, double dx, double dy,
+                  double u, double v, double dt, int limiter, double *o_ldx,
+                  double *o_ldy, double *o_ax, double *o_ay, double *o_Fx,
+                  double *o_Fy)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx - 1, jlo = ng, jhi = ng + ny - 1;
+    const size_t N = (size_t)qx * qy;
+    double *ldx = zalloc(N), *ldy = zalloc(N), *ax = zalloc(N),
+           *ay = zalloc(N), *Fxt = zalloc(N), *Fyt = zalloc(N),
+           *Fx = zalloc(N), *Fy = zalloc(N);
+#define I2(i, j) ((size_t)(i) * qy + (j))
+    /* interface.py:10-21 */
+    double cx = u * dt / dx;
+    double cy = v * dt / dy;
+    orc_limit(a, 1, nx, ny, ng, 1, limiter, ldx);
+    orc_limit(a, 1, nx, ny, ng, 2, limiter, ldy);
+    /* interface.py:25-41, region buf=1 */
+    for (int i = ilo - 1; i <= ihi + 1; i++)
+        for (int j = jlo - 1; j <= jhi + 1; j++) {
+            if (u < 0)
+                ax[I2(i, j)] = a[I2(i, j)] - 0.5 * (1.0 + cx) * ldx[I2(i, j)];
+            else
+                ax[I2(i, j)] =
+                    a[I2(i - 1, j)] + 0.5 * (1.0 - cx) * ldx[I2(i - 1, j)];
+            if (v < 0)
+                ay[I2(i, j)] = a[I2(i, j)] - 0.5 * (1.0 + cy) * ldy[I2(i, j)];
+            else
+                ay[I2(i, j)] =
+                    a[I2(i, j - 1)] + 0.5 * (1.0 - cy) * ldy[I2(i, j - 1)];
+        }
+    /* advective_fluxes.py:62-63, full arrays */
+    for (size_t k = 0; k < N; k++) {
+        Fxt[k] = u * ax[k];
+        Fyt[k] = v * ay[k];
+    }
+    /* advective_fluxes.py:71-90 */
+    int mx = (u <= 0) ? 0 : -1;
+    int my = (v <= 0) ? 0 : -1;
+    double dtdx2 = 0.5 * dt / dx;
+    double dtdy2 = 0.5 * dt / dy;
+    for (int i = ilo - 1; i <= ihi + 1; i++)
+        for (int j = jlo - 1; j <= jhi + 1; j++) {
+            Fx[I2(i, j)] = u * (ax[I2(i, j)] - dtdy2 * (Fyt[I2(i + mx, j + 1)] -
+                                                        Fyt[I2(i + mx, j)]));
+            Fy[I2(i, j)] = v * (ay[I2(i, j)] - dtdx2 * (Fxt[I2(i + 1, j + my)] -
+                                                        Fxt[I2(i, j + my)]));
+        }
+    /* simulation.py:63-80 */
+    double dtdx = dt / dx;
+    double dtdy = dt / dy;
+    for (int i = ilo; i <= ihi; i++)
+        for (int j = jlo; j <= jhi; j++)
+            a[I2(i, j)] = a[I2(i, j)] +
+                          dtdx * (Fx[I2(i, j)] - Fx[I2(i + 1, j)]) +
+                          dtdy * (Fy[I2(i, j)] - Fy[I2(i, j + 1)]);
+#undef I2
+    if (o_ldx) memcpy(o_ldx, ldx, N * 8);
+    if (o_ldy) memcpy(o_ldy, ldy, N * 8);
+    if (o_ax) memcpy(o_ax, ax, N * 8);
+    if (o_ay) memcpy(o_ay, ay, N * 8);
+    if (o_Fx) memcpy(o_Fx, Fx, N * 8);
+    if (o_Fy) memcpy(o_Fy, Fy, N * 8);
+    free(ldx); free(ldy); free(ax); free(ay);
+    free(Fxt); free(Fyt); free(Fx); free(Fy);
+}
+
+/* advection/simulation.py:38-54 */
+double orc_adv_dt(double dx, double dy, double u, double v, double cfl)
+{
+    const double SMALL = 1.e-12;
+    double xtmp = dx / dmax(fabs(u), SMALL);
+    double ytmp = dy / dmax(fabs(v), SMALL);
+    return cfl * dmin(xtmp, ytmp);
+}
+
+/* ------------------------------------------------------------------ */
+/* a7: cons_to_prim / prim_to_cons, compressible/simulation.py:49-102  */
+/* returns 0 ok, 1 if the interior positivity assert (:68-71) fails    */
+/* ------------------------------------------------------------------ */
+int orc_cons_to_prim(const double *U, int nx, int ny, int ng, double gamma,
+                     double *q)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    int bad = 0;
+    for (int i = 0; i < qx; i++)
+        for (int j = 0; j < qy; j++) {
+            const double *Uc = U + ((size_t)i * qy + j) * 4;
+            double *qc = q + ((size_t)i * qy + j) * 4;
+            double rho = Uc[IDENS];
+            double u = 0.0, v = 0.0, e = 0.0;
+            if (rho != 0.0) {
+                u = Uc[IXMOM] / rho;
+                v = Uc[IYMOM] / rho;
+            }
+            if (rho != 0.0)
+                e = (Uc[IENER] - 0.5 * rho * (u * u + v * v)) / rho;
+            qc[IRHO] = rho;
+            qc[IU] = u;
+            qc[IV] = v;
+            qc[IP] = rho * e * (gamma - 1.0); /* eos.py:26 */
+            if (i >= ng && i < ng + nx && j >= ng && j < ng + ny)
+                if (!(e > 0.0 && rho > 0.0)) bad = 1;
+        }
+    return bad;
+}
+
+void orc_prim_to_cons(const double *q, size_t ncell, double gamma, double *U)
+{
+    for (size_t k = 0; k < ncell; k++) {
+        const double *qc = q + k * 4;
+        double *Uc = U + k * 4;
+        Uc[IDENS] = qc[IRHO];
+        Uc[IXMOM] = qc[IU] * Uc[IDENS];
+        Uc[IYMOM] = qc[IV] * Uc[IDENS];
+        double rhoe = qc[IP] / (gamma - 1.0); /* eos.py:72 */
+        Uc[IENER] = rhoe + 0.5 * qc[IRHO] * (qc[IU] * qc[IU] + qc[IV] * qc[IV]);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* a3: flattening, pyro/mesh/reconstruction.py:123-183                 */
+/* ------------------------------------------------------------------ */
+static void flatten_(const double *q, int nx, int ny, int ng, int idir,
+                     double z0, double z1, double delta, double *xi)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx - 1, jlo = ng, jhi = ng + ny - 1;
+    const size_t N = (size_t)qx * qy;
+    const double smallp = 1.e-10;
+    double *z = zalloc(N), *t1 = zalloc(N), *t2 = zalloc(N);
+    const int di = (idir == 1) ? 1 : 0, dj = (idir == 1) ? 0 : 1;
+    const int ivel = (idir == 1) ? IU : IV;
+#define Q(i, j, n) q[((size_t)(i) * qy + (j)) * 4 + (n)]
+#define I2(i, j) ((size_t)(i) * qy + (j))
+    for (int i = ilo - 2; i <= ihi + 2; i++)
+        for (int j = jlo - 2; j <= jhi + 2; j++) {
+            t1[I2(i, j)] = fabs(Q(i + di, j + dj, IP) - Q(i - di, j - dj, IP));
+            t2[I2(i, j)] =
+                fabs(Q(i + 2 * di, j + 2 * dj, IP) - Q(i - 2 * di, j - 2 * dj, IP));
+        }
+    for (size_t k = 0; k < N; k++) z[k] = t1[k] / dmax(t2[k], smallp);
+    for (int i = ilo - 2; i <= ihi + 2; i++)
+        for (int j = jlo - 2; j <= jhi + 2; j++) {
+            t2[I2(i, j)] = t1[I2(i, j)] /
+                           dmin(Q(i + di, j + dj, IP), Q(i - di, j - dj, IP));
+            t1[I2(i, j)] = Q(i - di, j - dj, ivel) - Q(i + di, j + dj, ivel);
+        }
+    for (size_t k = 0; k < N; k++) {
+        double x = dmin(1.0, dmax(0.0, 1.0 - (z[k] - z0) / (z1 - z0)));
+        xi[k] = (t1[k] > 0.0 && t2[k] > delta) ? x : 1.0;
+    }
+#undef Q
+#undef I2
+    free(z); free(t1); free(t2);
+}
+
+void orc_flatten_multid(const double *q, int nx, int ny, int ng, double z0,
+                        double z1, double delta, double *xi)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx - 1, jlo = ng, jhi = ng + ny - 1;
+    const size_t N = (size_t)qx * qy;
+    double *xix = zalloc(N), *xiy = zalloc(N);
+    flatten_(q, nx, ny, ng, 1, z0, z1, delta, xix);
+    flatten_(q, nx, ny, ng, 2, z0, z1, delta, xiy);
+    memset(xi, 0, N * 8);
+#define Q(i, j, n) q[((size_t)(i) * qy + (j)) * 4 + (n)]
+#define I2(i, j) ((size_t)(i) * qy + (j))
+    for (int i = ilo - 2; i <= ihi + 2; i++)
+        for (int j = jlo - 2; j <= jhi + 2; j++) {
+            double px = (Q(i + 1, j, IP) - Q(i - 1, j, IP) > 0)
+                            ? xix[I2(i - 1, j)]
+                            : xix[I2(i + 1, j)];
+            double py = (Q(i, j + 1, IP) - Q(i, j - 1, IP) > 0)
+                            ? xiy[I2(i, j - 1)]
+                            : xiy[I2(i, j + 1)];
+            xi[I2(i, j)] =
+                dmin(dmin(xix[I2(i, j)], px), dmin(xiy[I2(i, j)], py));
+        }
+#undef Q
+#undef I2
+    free(xix); free(xiy);
+}
+
+/* ------------------------------------------------------------------ */
+/* a8: characteristic tracing, pyro/compressible/interface.py:5-236    */
+/* q, dq: (qx,qy,4).  q_l, q_r: (qx,qy,4) zeroed here.                 */
+/* ------------------------------------------------------------------ */
+void orc_states(int idir, int nx, int ny, int ng, double dx, double dt,
+                double gamma, const double *qv, const double *dqv,
+                double *q_l, double *q_r)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx, jlo = ng, jhi = ng + ny; /* njit-local */
+    memset(q_l, 0, sizeof(double) * qx * qy * 4);
+    memset(q_r, 0, sizeof(double) * qx * qy * 4);
+    const double dtdx = dt / dx;       /* interface.py:106 */
+    const double dtdx4 = 0.25 * dtdx;  /* :107 */
+    double lvec[4][4], rvec[4][4], e_val[4], betal[4], betar[4];
+    for (int i = ilo - 2; i < ihi + 2; i++)
+        for (int j = jlo - 2; j < jhi + 2; j++) {
+            const double *dq = dqv + ((size_t)i * qy + j) * 4;
+            const double *q = qv + ((size_t)i * qy + j) * 4;
+            double cs = sqrt(gamma * q[IP] / q[IRHO]);
+            memset(lvec, 0, sizeof lvec);
+            memset(rvec, 0, sizeof rvec);
+            if (idir == 1) {
+                e_val[0] = q[IU] - cs; e_val[1] = q[IU];
+                e_val[2] = q[IU];      e_val[3] = q[IU] + cs;
+                lvec[0][1] = -0.5 * q[IRHO] / cs; lvec[0][3] = 0.5 / (cs * cs);
+                lvec[1][0] = 1.0;                 lvec[1][3] = -1.0 / (cs * cs);
+                lvec[2][2] = 1.0;
+                lvec[3][1] = 0.5 * q[IRHO] / cs;  lvec[3][3] = 0.5 / (cs * cs);
+                rvec[0][0] = 1.0; rvec[0][1] = -cs / q[IRHO]; rvec[0][3] = cs * cs;
+                rvec[1][0] = 1.0;
+                rvec[2][2] = 1.0;
+                rvec[3][0] = 1.0; rvec[3][1] = cs / q[IRHO];  rvec[3][3] = cs * cs;
+            } else {
+                e_val[0] = q[IV] - cs; e_val[1] = q[IV];
+                e_val[2] = q[IV];      e_val[3] = q[IV] + cs;
+                lvec[0][2] = -0.5 * q[IRHO] / cs; lvec[0][3] = 0.5 / (cs * cs);
+                lvec[1][0] = 1.0;                 lvec[1][3] = -1.0 / (cs * cs);
+                lvec[2][1] = 1.0;
+                lvec[3][2] = 0.5 * q[IRHO] / cs;  lvec[3][3] = 0.5 / (cs * cs);
+                rvec[0][0] = 1.0; rvec[0][2] = -cs / q[IRHO]; rvec[0][3] = cs * cs;
+                rvec[1][0] = 1.0;
+                rvec[2][1] = 1.0;
+                rvec[3][0] = 1.0; rvec[3][2] = cs / q[IRHO];  rvec[3][3] = cs * cs;
+            }
+            double *ql = (idir == 1) ? q_l + ((size_t)(i + 1) * qy + j) * 4
+                                     : q_l + ((size_t)i * qy + (j + 1)) * 4;
+            double *qr = q_r + ((size_t)i * qy + j) * 4;
+            /* reference states, interface.py:174-191 */
+            double factor = 0.5 * (1.0 - dtdx * dmax(e_val[3], 0.0));
+            for (int m = 0; m < 4; m++) ql[m] = q[m] + factor * dq[m];
+            factor = 0.5 * (1.0 + dtdx * dmin(e_val[0], 0.0));
+            for (int m = 0; m < 4; m++) qr[m] = q[m] - factor * dq[m];
+            /* :193-201 ; np.dot = in-order 4-term sum */
+            for (int m = 0; m < 4; m++) {
+                double asum = 0.0;
+                for (int k = 0; k < 4; k++) asum += lvec[m][k] * dq[k];
+                betal[m] = dtdx4 * (e_val[3] - e_val[m]) *
+                           (copysign(1.0, e_val[m]) + 1.0) * asum;
+                betar[m] = dtdx4 * (e_val[0] - e_val[m]) *
+                           (1.0 - copysign(1.0, e_val[m])) * asum;
+            }
+            /* :203-213 */
+            for (int m = 0; m < 4; m++) {
+                double sum_l = 0.0, sum_r = 0.0;
+                for (int k = 0; k < 4; k++) {
+                    sum_l += betal[k] * rvec[k][m];
+                    sum_r += betar[k] * rvec[k][m];
+                }
+                ql[m] = ql[m] + sum_l;
+                qr[m] = qr[m] + sum_r;
+            }
+            /* geometric source (:216-234) vanishes for Cartesian: dloga=0 */
+        }
+}
+
+/* ------------------------------------------------------------------ */
+/* a10: HLLC, pyro/compressible/riemann.py:596-860, 1104-1179          */
+/* ------------------------------------------------------------------ */
+static void estimate_wave_speed(double rho_l, double u_l, double p_l,
+                                double c_l, double rho_r, double u_r,
+                                double p_r, double c_r, double gamma,
+                                double *S_l, double *S_r)
+{
+    double p_max = dmax(p_l, p_r);
+    double p_min = dmin(p_l, p_r);
+    double Q = p_max / p_min;
+    double rho_avg = 0.5 * (rho_l + rho_r);
+    double c_avg = 0.5 * (c_l + c_r);
+    double factor = rho_avg * c_avg;
+    double pstar = 0.5 * (p_l + p_r) + 0.5 * (u_l - u_r) * factor;
+    double ustar = 0.5 * (u_l + u_r) + 0.5 * (p_l - p_r) / factor;
+    if (Q > 2 && (pstar < p_min || pstar > p_max)) {
+        if (pstar < p_min) { /* two-rarefaction, riemann.py:626-638 */
+            double z = (gamma - 1.0) / (2.0 * gamma);
+            double p_lr = pow(p_l / p_r, z);
+            ustar = (p_lr * u_l / c_l + u_r / c_r +
+                     2.0 * (p_lr - 1.0) / (gamma - 1.0)) /
+                    (p_lr / c_l + 1.0 / c_r);
+            pstar = 0.5 * (p_l * pow(1.0 + (gamma - 1.0) * (u_l - ustar) /
+                                               (2.0 * c_l),
+                                     1.0 / z) +
+                           p_r * pow(1.0 + (gamma - 1.0) * (ustar - u_r) /
+                                               (2.0 * c_r),
+                                     1.0 / z));
+        } else { /* two-shock, :640-658 */
+            double A_r = 2.0 / ((gamma + 1.0) * rho_r);
+            double B_r = p_r * (gamma - 1.0) / (gamma + 1.0);
+            double A_l = 2.0 / ((gamma + 1.0) * rho_l);
+            double B_l = p_l * (gamma - 1.0) / (gamma + 1.0);
+            double p_guess = dmax(0.0, pstar);
+            double g_l = sqrt(A_l / (p_guess + B_l));
+            double g_r = sqrt(A_r / (p_guess + B_r));
+            pstar = (g_l * p_l + g_r * p_r - (u_r - u_l)) / (g_l + g_r);
+            ustar = 0.5 * (u_l + u_r) +
+                    0.5 * ((pstar - p_r) * g_r - (pstar - p_l) * g_l);
+        }
+    }
+    (void)ustar;
+    if (pstar <= p_l)
+        *S_l = u_l - c_l;
+    else
+        *S_l = u_l - c_l * sqrt(1.0 + ((gamma + 1.0) / (2.0 * gamma)) *
+                                          (pstar / p_l - 1.0));
+    if (pstar <= p_r)
+        *S_r = u_r + c_r;
+    else /* sic: (gamma+1)/(2/gamma), riemann.py:675 */
+        *S_r = u_r + c_r * sqrt(1.0 + ((gamma + 1.0) / (2.0 / gamma)) *
+                                          (pstar / p_r - 1.0));
+}
+
+static void cons_flux(int idir, double gamma, const double *Us, double *F)
+{
+    double u = 0.0, v = 0.0;
+    if (Us[IDENS] != 0.0) {
+        u = Us[IXMOM] / Us[IDENS];
+        v = Us[IYMOM] / Us[IDENS];
+    }
+    double p = (Us[IENER] - 0.5 * Us[IDENS] * (u * u + v * v)) * (gamma - 1.0);
+    if (idir == 1) {
+        F[IDENS] = Us[IDENS] * u;
+        F[IXMOM] = Us[IXMOM] * u;
+        F[IXMOM] += p;
+        F[IYMOM] = Us[IYMOM] * u;
+        F[IENER] = (Us[IENER] + p) * u;
+    } else {
+        F[IDENS] = Us[IDENS] * v;
+        F[IXMOM] = Us[IXMOM] * v;
+        F[IYMOM] = Us[IYMOM] * v;
+        F[IYMOM] += p;
+        F[IENER] = (Us[IENER] + p) * v;
+    }
+}
+
+void orc_riemann_hllc(int idir, int nx, int ny, int ng, double gamma,
+                      const double *U_l, const double *U_r, double *F)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx, jlo = ng, jhi = ng + ny; /* njit-local */
+    const double smallc = 1.e-10, smallp = 1.e-10;
+    memset(F, 0, sizeof(double) * qx * qy * 4);
+    double U_state[4];
+    for (int i = ilo - 1; i < ihi + 1; i++)
+        for (int j = jlo - 1; j < jhi + 1; j++) {
+            const double *Ul = U_l + ((size_t)i * qy + j) * 4;
+            const double *Ur = U_r + ((size_t)i * qy + j) * 4;
+            double *Fc = F + ((size_t)i * qy + j) * 4;
+            double rho_l = Ul[IDENS];
+            double un_l, ut_l;
+            if (idir == 1) {
+                un_l = Ul[IXMOM] / rho_l;
+                ut_l = Ul[IYMOM] / rho_l;
+            } else {
+                un_l = Ul[IYMOM] / rho_l;
+                ut_l = Ul[IXMOM] / rho_l;
+            }
+            double rhoe_l = Ul[IENER] - 0.5 * rho_l * (un_l * un_l + ut_l * ut_l);
+            double p_l = rhoe_l * (gamma - 1.0);
+            p_l = dmax(p_l, smallp);
+            double rho_r = Ur[IDENS];
+            double un_r, ut_r;
+            if (idir == 1) {
+                un_r = Ur[IXMOM] / rho_r;
+                ut_r = Ur[IYMOM] / rho_r;
+            } else {
+                un_r = Ur[IYMOM] / rho_r;
+                ut_r = Ur[IXMOM] / rho_r;
+            }
+            double rhoe_r = Ur[IENER] - 0.5 * rho_r * (un_r * un_r + ut_r * ut_r);
+            double p_r = rhoe_r * (gamma - 1.0);
+            p_r = dmax(p_r, smallp);
+            double c_l = dmax(smallc, sqrt(gamma * p_l / rho_l));
+            double c_r = dmax(smallc, sqrt(gamma * p_r / rho_r));
+            double S_l, S_r;
+            estimate_wave_speed(rho_l, un_l, p_l, c_l, rho_r, un_r, p_r, c_r,
+                                gamma, &S_l, &S_r);
+            double S_c = (p_r - p_l + rho_l * un_l * (S_l - un_l) -
+                          rho_r * un_r * (S_r - un_r)) /
+                         (rho_l * (S_l - un_l) - rho_r * (S_r - un_r));
+            if (S_r <= 0.0) {
+                cons_flux(idir, gamma, Ur, Fc);
+            } else if (S_c <= 0.0 && 0.0 < S_r) {
+                double f = rho_r * (S_r - un_r) / (S_r - S_c);
+                U_state[IDENS] = f;
+                if (idir == 1) {
+                    U_state[IXMOM] = f * S_c;
+                    U_state[IYMOM] = f * ut_r;
+                } else {
+                    U_state[IXMOM] = f * ut_r;
+                    U_state[IYMOM] = f * S_c;
+                }
+                U_state[IENER] =
+                    f * (Ur[IENER] / rho_r +
+                         (S_c - un_r) * (S_c + p_r / (rho_r * (S_r - un_r))));
+                cons_flux(idir, gamma, Ur, Fc);
+                for (int n = 0; n < 4; n++)
+                    Fc[n] = Fc[n] + S_r * (U_state[n] - Ur[n]);
+            } else if (S_l < 0.0 && 0.0 < S_c) {
+                double f = rho_l * (S_l - un_l) / (S_l - S_c);
+                U_state[IDENS] = f;
+                if (idir == 1) {
+                    U_state[IXMOM] = f * S_c;
+                    U_state[IYMOM] = f * ut_l;
+                } else {
+                    U_state[IXMOM] = f * ut_l;
+                    U_state[IYMOM] = f * S_c;
+                }
+                U_state[IENER] =
+                    f * (Ul[IENER] / rho_l +
+                         (S_c - un_l) * (S_c + p_l / (rho_l * (S_l - un_l))));
+                cons_flux(idir, gamma, Ul, Fc);
+                for (int n = 0; n < 4; n++)
+                    Fc[n] = Fc[n] + S_l * (U_state[n] - Ul[n]);
+            } else {
+                cons_flux(idir, gamma, Ul, Fc);
+            }
+        }
+}
+
+/* ------------------------------------------------------------------ */
+/* a11: artificial viscosity, compressible/interface.py:239-378        */
+/* u, v: components IU, IV of q (qx,qy,4)                              */
+/* ------------------------------------------------------------------ */
+void orc_artificial_viscosity(int nx, int ny, int ng, double dx, double dy,
+                              double cvisc, const double *q, int xhi_interior,
+                              int yhi_interior, double *avx, double *avy)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx, jlo = ng, jhi = ng + ny; /* njit-local */
+    const size_t N = (size_t)qx * qy;
+    double *divU = zalloc(N);
+    memset(avx, 0, N * 8);
+    memset(avy, 0, N * 8);
+#define UU(i, j) q[((size_t)(i) * qy + (j)) * 4 + IU]
+#define VV(i, j) q[((size_t)(i) * qy + (j)) * 4 + IV]
+#define I2(i, j) ((size_t)(i) * qy + (j))
+    for (int i = ilo - 1; i < ihi + 1; i++)
+        for (int j = jlo - 1; j < jhi + 1; j++) {
+            double ur = 0.5 * (UU(i, j) + UU(i, j - 1));
+            double ul = 0.5 * (UU(i - 1, j) + UU(i - 1, j - 1));
+            double vt = 0.5 * (VV(i, j) + VV(i - 1, j));
+            double vb = 0.5 * (VV(i, j - 1) + VV(i - 1, j - 1));
+            double ux = (ur - ul) / dx;
+            double vy = (vt - vb) / dy;
+            divU[I2(i, j)] = ux + vy;
+        }
+    /* interface.py:366-376: i in [ilo,ihi), j in [jlo,jhi).  With the
+       decomposition hooks the x (y) face loop runs one face further. */
+    for (int i = ilo; i < ihi + (xhi_interior ? 1 : 0); i++)
+        for (int j = jlo; j < jhi; j++) {
+            double divU_x = 0.5 * (divU[I2(i, j)] + divU[I2(i, j + 1)]);
+            avx[I2(i, j)] = cvisc * dmax(-divU_x * dx, 0.0);
+        }
+    for (int i = ilo; i < ihi; i++)
+        for (int j = jlo; j < jhi + (yhi_interior ? 1 : 0); j++) {
+            double divU_y = 0.5 * (divU[I2(i, j)] + divU[I2(i + 1, j)]);
+            avy[I2(i, j)] = cvisc * dmax(-divU_y * dy, 0.0);
+        }
+#undef UU
+#undef VV
+#undef I2
+    free(divU);
+}
+
+/* compressible/simulation.py:105-161, Cartesian branch, no problem_source */
+static void ext_sources(const double *U, const double *U_old, size_t ncell,
+                        double grav, double dt, double *S)
+{
+    memset(S, 0, ncell * 4 * 8);
+    for (size_t k = 0; k < ncell; k++) {
+        const double *Uc = U + k * 4;
+        double *Sc = S + k * 4;
+        if (!U_old) {
+            Sc[IYMOM] = Uc[IDENS] * grav;
+            Sc[IENER] = Uc[IYMOM] * grav;
+        } else {
+            Sc[IYMOM] = Uc[IDENS] * grav;
+            double S_old_ymom = U_old[k * 4 + IDENS] * grav;
+            double ymom_new = Uc[IYMOM] + 0.5 * dt * (Sc[IYMOM] - S_old_ymom);
+            Sc[IENER] = ymom_new * grav;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* a12: CFL time step, compressible/simulation.py:267-288 +            */
+/* derives.py:19-25,59; min over the FULL array including ghosts       */
+/* ------------------------------------------------------------------ */
+double orc_comp_dt(const double *U, int nx, int ny, int ng, double dx,
+                   double dy, double gamma, double cfl)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    double xmin = INFINITY, ymin = INFINITY;
+    for (size_t k = 0; k < (size_t)qx * qy; k++) {
+        const double *Uc = U + k * 4;
+        double dens = Uc[IDENS];
+        double u = Uc[IXMOM] / dens;
+        double v = Uc[IYMOM] / dens;
+        double e = (Uc[IENER] - 0.5 * dens * (u * u + v * v)) / dens;
+        double p = dens * e * (gamma - 1.0);
+        double cs = sqrt(gamma * p / dens);
+        double xt = dx / (fabs(u) + cs);
+        double yt = dy / (fabs(v) + cs);
+        if (xt < xmin) xmin = xt;
+        if (yt < ymin) ymin = yt;
+    }
+    return cfl * dmin(xmin, ymin);
+}
+
+/* ------------------------------------------------------------------ */
+/* a9+a12: one compressible step, compressible/simulation.py:290-450   */
+/* + unsplit_fluxes.py:134-549.  U: (qx,qy,4), ghost cells filled.     */
+/* returns 0 ok, 1 = positivity assert would have fired                */
+/* ------------------------------------------------------------------ */
+int orc_comp_step(double *U, const orc_comp_params *P, double dt,
+                  orc_comp_stages *st)
+{
+    const int nx = P->nx, ny = P->ny, ng = P->ng;
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx - 1, jlo = ng, jhi = ng + ny - 1;
+    const size_t N = (size_t)qx * qy;
+    const double gamma = P->gamma, dx = P->dx, dy = P->dy;
+    int rc = 0;
+#define U4(a, i, j, n) a[((size_t)(i) * qy + (j)) * 4 + (n)]
+#define I2(i, j) ((size_t)(i) * qy + (j))
+
+    /* clean_state, simulation.py:452-456 */
+    for (int i = ilo; i <= ihi; i++)
+        for (int j = jlo; j <= jhi; j++)
+            U4(U, i, j, IDENS) = dmax(U4(U, i, j, IDENS), P->small_dens);
+
+    double *q = zalloc(N * 4), *xi = zalloc(N), *ldx = zalloc(N * 4),
+           *ldy = zalloc(N * 4), *tmp = zalloc(N);
+    double *V_l = zalloc(N * 4), *V_r = zalloc(N * 4);
+    double *Uxl = zalloc(N * 4), *Uxr = zalloc(N * 4), *Uyl = zalloc(N * 4),
+           *Uyr = zalloc(N * 4);
+    double *Fx = zalloc(N * 4), *Fy = zalloc(N * 4);
+    double *avx = zalloc(N), *avy = zalloc(N);
+
+    /* unsplit_fluxes.py:160-197 */
+    rc |= orc_cons_to_prim(U, nx, ny, ng, gamma, q);
+    if (P->use_flattening)
+        orc_flatten_multid(q, nx, ny, ng, P->z0, P->z1, P->delta, xi);
+    else
+        for (size_t k = 0; k < N; k++) xi[k] = 1.0;
+    for (int n = 0; n < 4; n++) {
+        orc_limit(q + n, 4, nx, ny, ng, 1, P->limiter, tmp);
+        for (size_t k = 0; k < N; k++) ldx[k * 4 + n] = xi[k] * tmp[k];
+        orc_limit(q + n, 4, nx, ny, ng, 2, P->limiter, tmp);
+        for (size_t k = 0; k < N; k++) ldy[k * 4 + n] = xi[k] * tmp[k];
+    }
+    if (st && st->q) memcpy(st->q, q, N * 32);
+    if (st && st->xi) memcpy(st->xi, xi, N * 8);
+    if (st && st->ldx) memcpy(st->ldx, ldx, N * 32);
+    if (st && st->ldy) memcpy(st->ldy, ldy, N * 32);
+
+    /* unsplit_fluxes.py:207-242 */
+    orc_states(1, nx, ny, ng, dx, dt, gamma, q, ldx, V_l, V_r);
+    orc_prim_to_cons(V_l, N, gamma, Uxl);
+    orc_prim_to_cons(V_r, N, gamma, Uxr);
+    orc_states(2, nx, ny, ng, dy, dt, gamma, q, ldy, V_l, V_r);
+    orc_prim_to_cons(V_l, N, gamma, Uyl);
+    orc_prim_to_cons(V_r, N, gamma, Uyr);
+
+    /* apply_source_terms, unsplit_fluxes.py:247-330 (gravity only) */
+    if (P->grav != 0.0) {
+        double *S = zalloc(N * 4);
+        ext_sources(U, NULL, N, P->grav, dt, S);
+        for (int n = 0; n < 4; n++) orc_fill_ghost(S, nx, ny, ng, 4, n, P->bc[n]);
+        const int comps[3] = {IXMOM, IYMOM, IENER};
+        for (int c = 0; c < 3; c++) {
+            int n = comps[c];
+            for (int i = ilo - 1; i <= ihi + 1; i++)
+                for (int j = jlo - 1; j <= jhi + 1; j++) {
+                    U4(Uxl, i, j, n) += 0.5 * dt * U4(S, i - 1, j, n);
+                    U4(Uxr, i, j, n) += 0.5 * dt * U4(S, i, j, n);
+                    U4(Uyl, i, j, n) += 0.5 * dt * U4(S, i, j - 1, n);
+                    U4(Uyr, i, j, n) += 0.5 * dt * U4(S, i, j, n);
+                }
+        }
+        free(S);
+    }
+    if (st && st->Uxl0) memcpy(st->Uxl0, Uxl, N * 32);
+    if (st && st->Uxr0) memcpy(st->Uxr0, Uxr, N * 32);
+    if (st && st->Uyl0) memcpy(st->Uyl0, Uyl, N * 32);
+    if (st && st->Uyr0) memcpy(st->Uyr0, Uyr, N * 32);
+
+    /* apply_transverse_flux, unsplit_fluxes.py:333-494 */
+    orc_riemann_hllc(1, nx, ny, ng, gamma, Uxl, Uxr, Fx);
+    orc_riemann_hllc(2, nx, ny, ng, gamma, Uyl, Uyr, Fy);
+    if (st && st->FxT) memcpy(st->FxT, Fx, N * 32);
+    if (st && st->FyT) memcpy(st->FyT, Fy, N * 32);
+    {
+        const double hdt = 0.5 * dt;
+        const double V = dx * dy;     /* patch.py:232 */
+        const double hdtV = hdt / V;
+        const double Ax = dy, Ay = dx; /* patch.py:219-222 */
+        for (int n = 0; n < 4; n++)
+            for (int i = ilo - 2; i <= ihi + 1; i++)
+                for (int j = jlo - 2; j <= jhi + 1; j++) {
+                    U4(Uxl, i, j, n) += -hdtV * (U4(Fy, i - 1, j + 1, n) * Ay -
+                                                 U4(Fy, i - 1, j, n) * Ay);
+                    U4(Uxr, i, j, n) += -hdtV * (U4(Fy, i, j + 1, n) * Ay -
+                                                 U4(Fy, i, j, n) * Ay);
+                    U4(Uyl, i, j, n) += -hdtV * (U4(Fx, i + 1, j - 1, n) * Ax -
+                                                 U4(Fx, i, j - 1, n) * Ax);
+                    U4(Uyr, i, j, n) += -hdtV * (U4(Fx, i + 1, j, n) * Ax -
+                                                 U4(Fx, i, j, n) * Ax);
+                }
+    }
+    if (st && st->Uxl) memcpy(st->Uxl, Uxl, N * 32);
+    if (st && st->Uxr) memcpy(st->Uxr, Uxr, N * 32);
+    if (st && st->Uyl) memcpy(st->Uyl, Uyl, N * 32);
+    if (st && st->Uyr) memcpy(st->Uyr, Uyr, N * 32);
+
+    /* final Riemann solves, simulation.py:349-357 */
+    orc_riemann_hllc(1, nx, ny, ng, gamma, Uxl, Uxr, Fx);
+    orc_riemann_hllc(2, nx, ny, ng, gamma, Uyl, Uyr, Fy);
+    if (st && st->Fx0) memcpy(st->Fx0, Fx, N * 32);
+    if (st && st->Fy0) memcpy(st->Fy0, Fy, N * 32);
+
+    /* artificial viscosity, simulation.py:361-365, unsplit_fluxes.py:525-547 */
+    orc_artificial_viscosity(nx, ny, ng, dx, dy, P->cvisc, q,
+                             P->avisc_xhi_interior, P->avisc_yhi_interior, avx,
+                             avy);
+    for (int n = 0; n < 4; n++)
+        for (int i = ilo - 2; i <= ihi + 1; i++)
+            for (int j = jlo - 2; j <= jhi + 1; j++) {
+                U4(Fx, i, j, n) +=
+                    avx[I2(i, j)] * (U4(U, i - 1, j, n) - U4(U, i, j, n));
+                U4(Fy, i, j, n) +=
+                    avy[I2(i, j)] * (U4(U, i, j - 1, n) - U4(U, i, j, n));
+            }
+    if (st && st->avx) memcpy(st->avx, avx, N * 8);
+    if (st && st->avy) memcpy(st->avy, avy, N * 8);
+    if (st && st->Fx) memcpy(st->Fx, Fx, N * 32);
+    if (st && st->Fy) memcpy(st->Fy, Fy, N * 32);
+
+    /* conservative update, simulation.py:367-384 */
+    double *U_old = NULL;
+    if (P->grav != 0.0) {
+        U_old = zalloc(N * 4);
+        memcpy(U_old, U, N * 32);
+    }
+    {
+        const double dtdV = dt / (dx * dy);
+        const double Ax = dy, Ay = dx;
+        for (int n = 0; n < 4; n++)
+            for (int i = ilo; i <= ihi; i++)
+                for (int j = jlo; j <= jhi; j++)
+                    U4(U, i, j, n) +=
+                        dtdV * (U4(Fx, i, j, n) * Ax - U4(Fx, i + 1, j, n) * Ax +
+                                U4(Fy, i, j, n) * Ay - U4(Fy, i, j + 1, n) * Ay);
+    }
+    /* source predictor-corrector, simulation.py:406-423 */
+    if (P->grav != 0.0) {
+        double *S_old = zalloc(N * 4), *S_new = zalloc(N * 4);
+        ext_sources(U_old, NULL, N, P->grav, dt, S_old);
+        for (int n = 0; n < 4; n++)
+            for (int i = ilo; i <= ihi; i++)
+                for (int j = jlo; j <= jhi; j++)
+                    U4(U, i, j, n) += dt * U4(S_old, i, j, n);
+        ext_sources(U, U_old, N, P->grav, dt, S_new);
+        for (int n = 0; n < 4; n++)
+            for (int i = ilo; i <= ihi; i++)
+                for (int j = jlo; j <= jhi; j++)
+                    U4(U, i, j, n) +=
+                        0.5 * dt * (U4(S_new, i, j, n) - U4(S_old, i, j, n));
+        free(S_old); free(S_new); free(U_old);
+    }
+#undef U4
+#undef I2
+    free(q); free(xi); free(ldx); free(ldy); free(tmp); free(V_l); free(V_r);
+    free(Uxl); free(Uxr); free(Uyl); free(Uyr); free(Fx); free(Fy);
+    free(avx); free(avy);
+    return rc;
+}
+
+/* ================================================================== */
+/* Multigrid, pyro/multigrid/MG.py + pyro/mesh/patch.py:640-736        */
+/* Levels are planar (n+2)x(n+2) arrays with ng = 1.                   */
+/* MG BC codes: BC_REFLECT_ODD = dirichlet, BC_OUTFLOW = neumann,      */
+/* BC_PERIODIC.  Inhomogeneous values (finest-level v only) follow     */
+/* array_indexer.py:166-183,196-215: first ghost cell only.            */
+/* ================================================================== */
+#define MG_MAXLEV 20
+typedef struct {
+    int nlevels, nx;       /* finest is nx x nx */
+    double xmin, xmax, ymin, ymax;
+    double alpha, beta;
+    int nsmooth, nsmooth_bottom;
+    int bc[4];
+    int n[MG_MAXLEV];
+    double dx[MG_MAXLEV];
+    double *v[MG_MAXLEV], *f[MG_MAXLEV], *r[MG_MAXLEV];
+    double *bcval[4];      /* NULL or length n+2 on the finest level */
+    double source_norm;
+    int num_cycles;
+    double relative_error, residual_error;
+    int max_cycles;
+} orc_mg;
+
+orc_mg *orc_mg_create(int nx, double xmin, double xmax, double ymin,
+                      double ymax, const int *bc, double alpha, double beta,
+                      int nsmooth, int nsmooth_bottom)
+{
+    orc_mg *m = (orc_mg *)calloc(1, sizeof(orc_mg));
+    m->nx = nx;
+    m->xmin = xmin; m->xmax = xmax; m->ymin = ymin; m->ymax = ymax;
+    m->alpha = alpha; m->beta = beta;
+    m->nsmooth = nsmooth; m->nsmooth_bottom = nsmooth_bottom;
+    m->max_cycles = 100;
+    memcpy(m->bc, bc, sizeof(int) * 4);
+    m->nlevels = (int)(log((double)nx) / log(2.0)); /* MG.py:207 */
+    int nt = 2;
+    for (int l = 0; l < m->nlevels; l++) {
+        m->n[l] = nt;
+        m->dx[l] = (xmax - xmin) / nt; /* patch.py:121 */
+        size_t N = (size_t)(nt + 2) * (nt + 2);
+        m->v[l] = zalloc(N); m->f[l] = zalloc(N); m->r[l] = zalloc(N);
+        nt *= 2;
+    }
+    m->residual_error = 1.e33; m->relative_error = 1.e33;
+    return m;
+}
+
+void orc_mg_free(orc_mg *m)
+{
+    for (int l = 0; l < m->nlevels; l++) { free(m->v[l]); free(m->f[l]); free(m->r[l]); }
+    for (int s = 0; s < 4; s++) free(m->bcval[s]);
+    free(m);
+}
+
+int orc_mg_nlevels(const orc_mg *m) { return m->nlevels; }
+double *orc_mg_ptr(orc_mg *m, int level, int var)
+{
+    return var == 0 ? m->v[level] : var == 1 ? m->f[level] : m->r[level];
+}
+void orc_mg_set_bcval(orc_mg *m, int side, const double *vals)
+{
+    int n = m->n[m->nlevels - 1] + 2;
+    free(m->bcval[side]);
+    m->bcval[side] = (double *)malloc(sizeof(double) * n);
+    memcpy(m->bcval[side], vals, sizeof(double) * n);
+}
+void orc_mg_set_max_cycles(orc_mg *m, int mc) { m->max_cycles = mc; }
+double orc_mg_get_scalar(const orc_mg *m, int which)
+{
+    switch (which) {
+    case 0: return m->source_norm;
+    case 1: return (double)m->num_cycles;
+    case 2: return m->relative_error;
+    case 3: return m->residual_error;
+    }
+    return 0.0;
+}
+
+/* fill_BC for an ng=1 level array; vals[side] optional inhomogeneous data */
+static void mg_fill_bc(double *a, int n, double dx, const int *bc,
+                       double *const *vals)
+{
+    const int q = n + 2, lo = 1, hi = n;
+#define A(i, j) a[(size_t)(i) * q + (j)]
+    for (int j = 0; j < q; j++) {
+        switch (bc[0]) {
+        case BC_OUTFLOW:
+            A(0, j) = (vals && vals[0]) ? A(lo, j) - dx * vals[0][j] : A(lo, j);
+            break;
+        case BC_REFLECT_ODD:
+            A(0, j) = (vals && vals[0]) ? 2 * vals[0][j] - A(lo, j) : -A(lo, j);
+            break;
+        case BC_REFLECT_EVEN: A(0, j) = A(lo, j); break;
+        case BC_PERIODIC: A(0, j) = A(hi, j); break;
+        }
+    }
+    for (int j = 0; j < q; j++) {
+        switch (bc[1]) {
+        case BC_OUTFLOW:
+            A(hi + 1, j) = (vals && vals[1]) ? A(hi, j) + dx * vals[1][j] : A(hi, j);
+            break;
+        case BC_REFLECT_ODD:
+            A(hi + 1, j) = (vals && vals[1]) ? 2 * vals[1][j] - A(hi, j) : -A(hi, j);
+            break;
+        case BC_REFLECT_EVEN: A(hi + 1, j) = A(hi, j); break;
+        case BC_PERIODIC: A(hi + 1, j) = A(lo, j); break;
+        }
+    }
+    for (int i = 0; i < q; i++) {
+        switch (bc[2]) {
+        case BC_OUTFLOW:
+            A(i, 0) = (vals && vals[2]) ? A(i, lo) - dx * vals[2][i] : A(i, lo);
+            break;
+        case BC_REFLECT_ODD:
+            A(i, 0) = (vals && vals[2]) ? 2 * vals[2][i] - A(i, lo) : -A(i, lo);
+            break;
+        case BC_REFLECT_EVEN: A(i, 0) = A(i, lo); break;
+        case BC_PERIODIC: A(i, 0) = A(i, hi); break;
+        }
+    }
+    for (int i = 0; i < q; i++) {
+        switch (bc[3]) {
+        case BC_OUTFLOW:
+            A(i, hi + 1) = (vals && vals[3]) ? A(i, hi) + dx * vals[3][i] : A(i, hi);
+            break;
+        case BC_REFLECT_ODD:
+            A(i, hi + 1) = (vals && vals[3]) ? 2 * vals[3][i] - A(i, hi) : -A(i, hi);
+            break;
+        case BC_REFLECT_EVEN: A(i, hi + 1) = A(i, hi); break;
+        case BC_PERIODIC: A(i, hi + 1) = A(i, lo); break;
+        }
+    }
+#undef A
+}
+
+void orc_mg_fill_bc_v(orc_mg *m, int level)
+{
+    double *const *vals = (level == m->nlevels - 1) ? m->bcval : NULL;
+    mg_fill_bc(m->v[level], m->n[level], m->dx[level], m->bc, vals);
+}
+
+/* array_indexer.py:98-111 (plain left-to-right sum; NumPy uses pairwise
+   summation, so norms agree to ~1e-15 relative, not bitwise) */
+static double mg_norm(const double *a, int n, double dx)
+{
+    const int q = n + 2;
+    double s = 0.0;
+    for (int i = 1; i <= n; i++)
+        for (int j = 1; j <= n; j++) s += a[(size_t)i * q + j] * a[(size_t)i * q + j];
+    return sqrt(dx * dx * s);
+}
+double orc_mg_norm(orc_mg *m, int level, int var)
+{
+    return mg_norm(orc_mg_ptr(m, level, var), m->n[level], m->dx[level]);
+}
+
+/* MG.py:529-542 */
+void orc_mg_residual(orc_mg *m, int level)
+{
+    const int n = m->n[level], q = n + 2;
+    const double dx = m->dx[level], dx2 = dx * dx;
+    const double *v = m->v[level], *f = m->f[level];
+    double *r = m->r[level];
+#define I(i, j) ((size_t)(i) * q + (j))
+    for (int i = 1; i <= n; i++)
+        for (int j = 1; j <= n; j++)
+            r[I(i, j)] =
+                f[I(i, j)] - m->alpha * v[I(i, j)] +
+                m->beta * ((v[I(i - 1, j)] + v[I(i + 1, j)] - 2 * v[I(i, j)]) / dx2 +
+                           (v[I(i, j - 1)] + v[I(i, j + 1)] - 2 * v[I(i, j)]) / dx2);
+#undef I
+}
+
+/* MG.py:544-621 */
+void orc_mg_smooth(orc_mg *m, int level, int nsmooth)
+{
+    const int n = m->n[level], q = n + 2;
+    const double dx = m->dx[level];
+    double *v = m->v[level];
+    const double *f = m->f[level];
+    orc_mg_fill_bc_v(m, level);
+    const double xcoeff = m->beta / (dx * dx);
+    const double ycoeff = m->beta / (dx * dx);
+    const double denom = m->alpha + 2.0 * xcoeff + 2.0 * ycoeff;
+    static const int grp[4][2] = {{0, 0}, {1, 1}, {1, 0}, {0, 1}};
+#define I(i, j) ((size_t)(i) * q + (j))
+    for (int it = 0; it < nsmooth; it++)
+        for (int g = 0; g < 4; g++) {
+            int ix = grp[g][0], iy = grp[g][1];
+            for (int i = 1 + ix; i <= n; i += 2)
+                for (int j = 1 + iy; j <= n; j += 2)
+                    v[I(i, j)] = (f[I(i, j)] +
+                                  xcoeff * (v[I(i + 1, j)] + v[I(i - 1, j)]) +
+                                  ycoeff * (v[I(i, j + 1)] + v[I(i, j - 1)])) /
+                                 denom;
+            if (g == 1 || g == 3) orc_mg_fill_bc_v(m, level);
+        }
+#undef I
+}
+
+/* patch.py:640-676 : f_coarse.v() = restrict(r_fine).v() */
+void orc_mg_restrict(orc_mg *m, int level /* fine */)
+{
+    const int nc = m->n[level - 1], qc = nc + 2, qf = m->n[level] + 2;
+    const double *fd = m->r[level];
+    double *cd = m->f[level - 1];
+    for (int i = 0; i < nc; i++)
+        for (int j = 0; j < nc; j++) {
+            int fi = 1 + 2 * i, fj = 1 + 2 * j;
+            cd[(size_t)(1 + i) * qc + (1 + j)] =
+                0.25 * (fd[(size_t)fi * qf + fj] + fd[(size_t)(fi + 1) * qf + fj] +
+                        fd[(size_t)fi * qf + fj + 1] +
+                        fd[(size_t)(fi + 1) * qf + fj + 1]);
+        }
+}
+
+/* patch.py:678-736 + MG.py:745-751: v_fine.v() += prolong(v_coarse).v() */
+void orc_mg_prolong_add(orc_mg *m, int level /* fine */)
+{
+    const int nc = m->n[level - 1], qc = nc + 2, qf = m->n[level] + 2;
+    const double *c = m->v[level - 1];
+    double *v = m->v[level];
+    for (int i = 1; i <= nc; i++)
+        for (int j = 1; j <= nc; j++) {
+            double c0 = c[(size_t)i * qc + j];
+            double m_x = 0.5 * (c[(size_t)(i + 1) * qc + j] - c[(size_t)(i - 1) * qc + j]);
+            double m_y = 0.5 * (c[(size_t)i * qc + j + 1] - c[(size_t)i * qc + j - 1]);
+            int fi = 1 + 2 * (i - 1), fj = 1 + 2 * (j - 1);
+            v[(size_t)fi * qf + fj] += c0 - 0.25 * m_x - 0.25 * m_y;
+            v[(size_t)(fi + 1) * qf + fj] += c0 + 0.25 * m_x - 0.25 * m_y;
+            v[(size_t)fi * qf + fj + 1] += c0 - 0.25 * m_x + 0.25 * m_y;
+            v[(size_t)(fi + 1) * qf + fj + 1] += c0 + 0.25 * m_x + 0.25 * m_y;
+        }
+}
+
+/* MG.py:699-778 */
+void orc_mg_vcycle(orc_mg *m, int level)
+{
+    if (level > 0) {
+        orc_mg_smooth(m, level, m->nsmooth);
+        orc_mg_residual(m, level);
+        orc_mg_restrict(m, level);
+        orc_mg_vcycle(m, level - 1);
+        orc_mg_prolong_add(m, level);
+        orc_mg_fill_bc_v(m, level);
+        orc_mg_smooth(m, level, m->nsmooth);
+    } else {
+        orc_mg_smooth(m, level, m->nsmooth_bottom);
+        orc_mg_fill_bc_v(m, level);
+    }
+}
+
+void orc_mg_init_rhs_norm(orc_mg *m)
+{
+    m->source_norm = orc_mg_norm(m, m->nlevels - 1, 1);
+}
+
+/* MG.py:623-697 */
+void orc_mg_solve(orc_mg *m, double rtol)
+{
+    const int L = m->nlevels - 1;
+    const int n = m->n[L], q = n + 2;
+    const size_t N = (size_t)q * q;
+    double *old_phi = (double *)malloc(N * 8);
+    memcpy(old_phi, m->v[L], N * 8);
+    double residual_error = 1.e33, relative_error = 1.e33;
+    int cycle = 1;
+    while (residual_error > rtol && cycle <= m->max_cycles) {
+        for (int l = 0; l < L; l++) {
+            size_t Nl = (size_t)(m->n[l] + 2) * (m->n[l] + 2);
+            memset(m->v[l], 0, Nl * 8);
+        }
+        orc_mg_vcycle(m, L);
+        /* diff = (v - old)/(v + small); relative_error = diff.norm() */
+        double s = 0.0;
+        for (int i = 1; i <= n; i++)
+            for (int j = 1; j <= n; j++) {
+                size_t k = (size_t)i * q + j;
+                double d = (m->v[L][k] - old_phi[k]) / (m->v[L][k] + 1.e-16);
+                s += d * d;
+            }
+        relative_error = sqrt(m->dx[L] * m->dx[L] * s);
+        memcpy(old_phi, m->v[L], N * 8);
+        orc_mg_residual(m, L);
+        double rn = orc_mg_norm(m, L, 2);
+        residual_error = (m->source_norm != 0.0) ? rn / m->source_norm : rn;
+        cycle++;
+    }
+    m->num_cycles = cycle - 1;
+    m->relative_error = relative_error;
+    m->residual_error = residual_error;
+    orc_mg_fill_bc_v(m, L);
+    free(old_phi);
+}

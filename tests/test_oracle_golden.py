@@ -1,0 +1,212 @@
+"""Pin the C oracle (oracle/pyro_oracle.c) against the reference.
+
+The fixtures under tests/golden/ were produced by oracle/gen_golden.py, which
+RUNS the reference (pyro2) in the build container, and include the
+reference's own regression goldens (pyro/test.py:93,100-101,138-140).
+"""
+import numpy as np
+import pytest
+
+from oracle import orc
+
+
+# ---------------------------------------------------------------- ghost fill
+@pytest.mark.parametrize("ng", [4, 1])
+@pytest.mark.parametrize("k", range(5))
+def test_fill_ghost(golden, ng, k):
+    g = golden("fill_bc")
+    a = g[f"in_ng{ng}_{k}"].copy()
+    bcs = [str(b) for b in g[f"bc_ng{ng}_{k}"]]
+    nx, ny = a.shape[0] - 2 * ng, a.shape[1] - 2 * ng
+    orc.fill_ghost(a, nx, ny, ng, bcs)
+    assert np.array_equal(a, g[f"out_ng{ng}_{k}"])
+
+
+# ----------------------------------------------------------------- advection
+def test_adv_stages(golden):
+    g = golden("adv_stages")
+    n = int(g["ncases"])
+    assert n >= 10
+    for k in range(n):
+        nx, ny, ng, dx, dy, u, v, dt, lim = g[f"s{k}_meta"]
+        nx, ny, ng, lim = int(nx), int(ny), int(ng), int(lim)
+        a = g[f"s{k}_a0"].copy()
+        assert np.array_equal(orc.limit(a, nx, ny, ng, 1, lim), g[f"s{k}_ldx"])
+        assert np.array_equal(orc.limit(a, nx, ny, ng, 2, lim), g[f"s{k}_ldy"])
+        st = orc.adv_step(a, nx, ny, ng, dx, dy, u, v, dt, lim, stages=True)
+        for nm in ("ldx", "ldy", "ax", "ay", "Fx", "Fy"):
+            assert np.array_equal(st[nm], g[f"s{k}_{nm}"]), (k, nm)
+        assert np.array_equal(a, g[f"s{k}_a1"]), k
+
+
+def _run_adv(ic, dts, nx, ng=4, u=1.0, v=1.0, limiter=2):
+    a = ic.copy()
+    dx = 1.0 / nx
+    for dt in dts:
+        orc.fill_ghost(a, nx, nx, ng, ("periodic",) * 4)
+        orc.adv_step(a, nx, nx, ng, dx, dx, u, v, dt, limiter)
+    return a
+
+
+def test_adv_reference_regression_smooth_0040(golden):
+    """pyro/test.py:93 : advection smooth vs smooth_0040.h5, rtol 1e-12"""
+    g = golden("adv_smooth_0040")
+    a = _run_adv(g["ic"], g["dts"], 32)
+    assert np.array_equal(a[4:-4, 4:-4], g["run"])          # reference run here
+    np.testing.assert_allclose(a[4:-4, 4:-4], g["gold"], rtol=1e-12, atol=0)
+
+
+def test_adv_dt_and_64_known_answer(golden):
+    """64^2 to tmax: 81 steps, L2 error 0.00327229868007
+    (pyro/advection/tests/advection_convergence.txt:8)"""
+    g = golden("adv_smooth_64")
+    dts = g["dts"]
+    assert len(dts) == 81
+    assert orc.adv_dt(1 / 64, 1 / 64, 1.0, 1.0, 0.8) == dts[0]
+    a = _run_adv(g["ic"], dts, 64)
+    assert np.array_equal(a[4:-4, 4:-4], g["final"][4:-4, 4:-4])
+    err = a[4:-4, 4:-4] - g["ic"][4:-4, 4:-4]
+    l2 = np.sqrt((1 / 64) ** 2 * np.sum(err ** 2))
+    assert abs(l2 - 0.00327229868007) < 1e-13
+
+
+# ---------------------------------------------------------------- multigrid
+_MGBC = {"dirichlet": "dirichlet", "neumann": "neumann", "periodic": "periodic"}
+
+
+def _mk_mg(g, k):
+    nx, alpha, beta, ns, nb, inhom = g[f"m{k}_meta"]
+    bcs = [str(b) for b in g[f"m{k}_bc"]]
+    m = orc.MG(int(nx), bcs=bcs, alpha=alpha, beta=beta, nsmooth=int(ns),
+               nsmooth_bottom=int(nb))
+    if int(inhom):
+        for s in range(4):
+            m.set_bcval(s, g[f"m{k}_bcvals"][s])
+    return m
+
+
+def test_mg_ops(golden):
+    g = golden("mg_ops")
+    n = int(g["ncases"])
+    assert n >= 12
+    for k in range(n):
+        m = _mk_mg(g, k)
+        L = m.nlevels - 1
+        m.arr(L, 0)[:, :] = g[f"m{k}_v0"]
+        m.init_rhs(g[f"m{k}_f0"])
+        m.smooth(L, 2)
+        assert np.array_equal(m.arr(L, 0), g[f"m{k}_v_smooth"]), k
+        m.residual(L)
+        assert np.array_equal(m.arr(L, 2), g[f"m{k}_r"]), k
+        np.testing.assert_allclose(m.norm(L, 2), g[f"m{k}_rnorm"], rtol=1e-14)
+        m.restrict(L)
+        assert np.array_equal(m.arr(L - 1, 1)[1:-1, 1:-1],
+                              g[f"m{k}_restrict"][1:-1, 1:-1]), k
+        # prolong: v_fine := 0; v_fine += prolong(cv)
+        m.arr(L - 1, 0)[:, :] = g[f"m{k}_cv"]
+        m.arr(L, 0)[:, :] = 0.0
+        m.prolong_add(L)
+        assert np.array_equal(m.arr(L, 0)[1:-1, 1:-1],
+                              g[f"m{k}_prolong"][1:-1, 1:-1]), k
+
+        m = _mk_mg(g, k)
+        m.arr(L, 0)[:, :] = g[f"m{k}_v0"]
+        m.init_rhs(g[f"m{k}_f1"])
+        m.vcycle()
+        assert np.array_equal(m.arr(L, 0), g[f"m{k}_v_vcycle"]), k
+        m.solve(rtol=1e-10, max_cycles=6)
+        info = g[f"m{k}_solve_info"]
+        assert m.num_cycles == int(info[0])
+        assert np.array_equal(m.arr(L, 0), g[f"m{k}_v_solve"]), k
+        np.testing.assert_allclose(m.residual_error, info[1], rtol=1e-10)
+        np.testing.assert_allclose(m.source_norm, info[3], rtol=1e-13)
+
+
+def test_mg_reference_regression_poisson_dirichlet(golden):
+    """pyro/test.py:138-140: mg_test_simple 256^2 vs mg_poisson_dirichlet.h5;
+    7 V-cycles, L2 error 1.60408e-06 (multigrid/tests/mg_convergence.txt:7)"""
+    g = golden("mg_poisson_dirichlet_256")
+    m = orc.MG(256)
+    L = m.nlevels - 1
+    m.init_rhs(g["rhs"])
+    m.solve(rtol=1e-11)
+    assert m.num_cycles == int(g["ncycles"]) == 7
+    assert np.array_equal(m.arr(L, 0)[1:-1, 1:-1], g["gold"])
+    x = (np.arange(258) - 0.5) / 256
+    X, Y = np.meshgrid(x, x, indexing="ij")
+    true = (X ** 2 - X ** 4) * (Y ** 4 - Y ** 2)
+    e = (m.arr(L, 0) - true)[1:-1, 1:-1]
+    l2 = np.sqrt(np.sum(e ** 2) / 256 ** 2)
+    assert abs(l2 - 1.60408e-06) < 1e-11
+
+
+# -------------------------------------------------------------- compressible
+from helpers import meta_to_params, oracle_comp_run  # noqa: E402
+from conftest import max_rel_err  # noqa: E402
+
+_STAGES = ["q", "xi", "ldx", "ldy", "Uxl0", "Uxr0", "Uyl0", "Uyr0", "FxT",
+           "FyT", "Uxl", "Uxr", "Uyl", "Uyr", "Fx0", "Fy0", "avx", "avy",
+           "Fx", "Fy"]
+
+
+@pytest.mark.parametrize("k", range(8))
+def test_comp_stage_dumps(golden, k):
+    """every intermediate array of one step, ghost cells included, against
+    arrays dumped from the reference's own functions"""
+    g = golden("comp_stages")
+    bcs = [str(b) for b in g[f"c{k}_bc"]]
+    P, cfl = meta_to_params(g[f"c{k}_meta"], bcs)
+    U = g[f"c{k}_U0"].copy()
+    dtm = orc.comp_dt(U, P.nx, P.ny, P.ng, P.dx, P.dy, P.gamma, cfl)
+    assert dtm == float(g[f"c{k}_dt_method"])
+    rc, st = orc.comp_step(U, P, float(g[f"c{k}_dt"]), stages=True)
+    assert rc == 0
+    worst = 0.0
+    for nm in _STAGES:
+        e = max_rel_err(st[nm], g[f"c{k}_{nm}"])
+        worst = max(worst, e)
+        assert e < 1e-13, (k, nm, e)
+    e = max_rel_err(U, g[f"c{k}_U1"])
+    assert e < 1e-14, (k, "U1", e)
+
+
+def test_comp_sedov_64_fingerprint(golden):
+    """sedov 64^2, 20 steps"""
+    g = golden("comp_sedov_64_020")
+    bcs = [str(b) for b in g["bc"]]
+    U, dts, t = oracle_comp_run(g["ic"], g["meta"], bcs, tmax=0.1, max_steps=20)
+    np.testing.assert_allclose(dts, g["dts"], rtol=1e-13, atol=0)
+    assert abs(t - 0.009286102192696327) < 1e-15
+    assert max_rel_err(U[4:-4, 4:-4], g["final"][4:-4, 4:-4]) < 1e-12
+    assert abs(U[4:-4, 4:-4, 1].sum() - 4774.750655256859) < 1e-8
+
+
+def test_comp_reference_regression_sod_x(golden):
+    """pyro/test.py:101: compressible sod inputs.sod.x vs sod_x_0076.h5
+    (128x10, limiter 1, reflecting y walls), rtol 1e-12"""
+    g = golden("comp_sod_x_0076")
+    bcs = [str(b) for b in g["bc"]]
+    U, dts, t = oracle_comp_run(g["ic"], g["meta"], bcs, tmax=float(g["tmax"]),
+                                max_steps=200)
+    assert len(dts) == 76
+    np.testing.assert_allclose(dts, g["dts"], rtol=1e-12, atol=0)
+    for n in range(4):
+        assert max_rel_err(U[4:-4, 4:-4, n], g["gold"][..., n]) < 1e-12 or \
+            np.abs(g["gold"][..., n]).max() == 0.0
+
+
+def test_comp_reference_regression_quad(golden):
+    """pyro/test.py:100: compressible quad inputs.quad vs
+    quad_unsplit_0606.h5 (256^2, 606 steps, HLLC, limiter 2).  The reference
+    itself cannot be re-run at this size here (interpreted njit loops), so
+    this is the oracle reproducing the reference's STORED golden from the
+    reference's IC."""
+    g = golden("comp_quad_0606")
+    bcs = [str(b) for b in g["bc"]]
+    U, dts, t = oracle_comp_run(g["ic"], g["meta"], bcs, tmax=float(g["tmax"]),
+                                max_steps=1000)
+    assert len(dts) == int(g["nsteps"]) == 606
+    assert abs(t - float(g["t"])) < 1e-14
+    for n in range(4):
+        e = max_rel_err(U[4:-4, 4:-4, n], g["gold"][..., n])
+        assert e < 1e-10, (n, e)
