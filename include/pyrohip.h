@@ -1,0 +1,192 @@
+/*
+ * pyrohip.h -- C ABI of libpyrohip.so, the MI355X (gfx950) implementation of
+ * pyro2's per-timestep hot path.
+ *
+ * pyro2 has no FFI/plugin layer of its own: its operator API
+ * is the Python class surface that pyro_sim.py drives.  Each entry point below
+ * therefore cites the reference method whose arithmetic it replaces; the
+ * Python-side binding (ctypes) that keeps pyro's class surface lives in
+ * pyro2_amd/ and is described in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, otherwise a hipError_t / own code;
+ *     pyrohip_last_error() returns the text of the last failure (per thread).
+ *   - opaque handles; the library owns all device memory.
+ *   - host pointers are borrowed for the duration of the call only.
+ *   - all floating point data is IEEE double (the reference is float64).
+ *   - host arrays use the reference layouts: scalar fields (qx,qy) C order
+ *     (j fastest); cell data (qx,qy,nvar) C order (patch.py:450-452).  On the
+ *     device every variable is a separate plane (SoA), j fastest.
+ *   - calls on one context are serialised by the caller (one stream per ctx).
+ *   - no torch types, no C++ types: plain pointers and sizes.
+ */
+#ifndef PYROHIP_H
+#define PYROHIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pyrohip_ctx pyrohip_ctx;
+typedef struct pyrohip_state pyrohip_state;
+typedef struct pyrohip_mg pyrohip_mg;
+
+/* boundary-condition codes (pyro/mesh/boundary.py:10-17 names) */
+enum {
+    PYROHIP_BC_OUTFLOW = 0,      /* "outflow", homogeneous "neumann"          */
+    PYROHIP_BC_REFLECT_EVEN = 1, /* "reflect-even"                            */
+    PYROHIP_BC_REFLECT_ODD = 2,  /* "reflect-odd", homogeneous "dirichlet"    */
+    PYROHIP_BC_PERIODIC = 3,     /* "periodic"                                */
+    PYROHIP_BC_HALO = 4          /* interior slab interface: filled by        */
+                                 /* pyrohip_halo_exchange, not by fill_bc     */
+};
+
+/* own status codes (hipError_t values are passed through unchanged) */
+enum {
+    PYROHIP_OK = 0,
+    PYROHIP_ERR_ARG = 10001,
+    PYROHIP_ERR_STATE = 10002,    /* e.g. negative density / internal energy */
+    PYROHIP_ERR_UNSUPPORTED = 10003,
+    PYROHIP_ERR_COMM = 10004
+};
+
+/* ---- context ---------------------------------------------------------- */
+int pyrohip_init(int device_id, pyrohip_ctx **out);
+int pyrohip_shutdown(pyrohip_ctx *ctx);
+int pyrohip_sync(pyrohip_ctx *ctx);
+const char *pyrohip_last_error(void);
+/* "hip-gfx950" for the real library.  The host-side binding refuses anything
+   else unless a test explicitly injects another backend. */
+const char *pyrohip_backend(void);
+int pyrohip_device_info(pyrohip_ctx *ctx, char *name, int name_len,
+                        size_t *free_bytes, size_t *total_bytes,
+                        int *compute_units);
+/* HIP-event timing on the context's stream (bench.py roofline leg) */
+int pyrohip_timer_start(pyrohip_ctx *ctx);
+int pyrohip_timer_stop(pyrohip_ctx *ctx, double *elapsed_ms);
+
+/* ---- cell-centred data: CellCenterData2d storage (patch.py:315-794) ---- */
+/* bc: nvar*4 codes, order per variable: xl, xr, yl, yr                     */
+int pyrohip_state_create(pyrohip_ctx *ctx, int nx, int ny, int ng, int nvar,
+                         const int *bc, pyrohip_state **out);
+int pyrohip_state_destroy(pyrohip_state *s);
+/* whole (qx,qy,nvar) array, reference layout (CellCenterData2d.data) */
+int pyrohip_state_upload(pyrohip_state *s, const double *host_aos);
+int pyrohip_state_download(pyrohip_state *s, double *host_aos);
+/* one variable, (qx,qy) */
+int pyrohip_state_upload_var(pyrohip_state *s, int n, const double *host);
+int pyrohip_state_download_var(pyrohip_state *s, int n, double *host);
+/* rows [i0, i0+ni) of every variable <-> host (ni,qy,nvar); used to stream
+   large initial conditions and slab gathers */
+int pyrohip_state_upload_rows(pyrohip_state *s, int i0, int ni,
+                              const double *host_aos);
+int pyrohip_state_download_rows(pyrohip_state *s, int i0, int ni,
+                                double *host_aos);
+/* ArrayIndexer.fill_ghost / CellCenterData2d.fill_BC(_all)
+   (array_indexer.py:150-274, patch.py:575-624); n = -1: all variables */
+int pyrohip_fill_bc(pyrohip_state *s, int n);
+/* min / max over the valid region grown by buf (patch.py:626-638) */
+int pyrohip_state_minmax(pyrohip_state *s, int n, int buf, double *vmin,
+                         double *vmax);
+
+/* ---- advection: Simulation.evolve (advection/simulation.py:56-94) with
+        advective_fluxes.unsplit_fluxes (:1-92), interface.linear_interface
+        (:4-43) and reconstruction.limit (reconstruction.py:9-120) fused ---- */
+int pyrohip_adv_step(pyrohip_state *s, int n, double dx, double dy, double u,
+                     double v, double dt, int limiter);
+
+/* ---- compressible ---------------------------------------------------- */
+/* conserved order: density(0) energy(1) x-momentum(2) y-momentum(3)
+   (compressible/simulation.py:223-226)                                    */
+typedef struct {
+    double dx, dy;
+    double gamma;          /* eos.gamma                                     */
+    int limiter;           /* compressible.limiter 0/1/2                    */
+    int use_flattening;    /* compressible.use_flattening                   */
+    double z0, z1, delta;  /* compressible.z0/z1/delta                      */
+    double cvisc;          /* compressible.cvisc                            */
+    double grav;           /* compressible.grav (y direction)               */
+    double small_dens;     /* compressible.small_dens                       */
+    /* slab decomposition: compute the artificial-viscosity
+       coefficient on the upper x (y) boundary face because it is an interior
+       interface of the global grid (reference leaves the physical one 0,
+       compressible/interface.py:366-367) */
+    int avisc_xhi_interior, avisc_yhi_interior;
+    /* 0 = bit-faithful arithmetic (no FMA contraction, true divisions);
+       1 = contracted / reciprocal arithmetic, parity-tested to 1e-10      */
+    int fast_math;
+    /* kernel set: 0 = staged kernels with global intermediates (debuggable,
+       supports pyrohip_comp_stage_dump); 1 = fused LDS-tiled kernels       */
+    int kernel_set;
+} pyrohip_comp_params;
+
+/* method_compute_timestep (compressible/simulation.py:267-288 +
+   derives.py:19-25,59): cfl * min over the whole array incl. ghost cells */
+int pyrohip_comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl,
+                    double *dt_out);
+/* Simulation.evolve (compressible/simulation.py:290-450) = interface_states,
+   apply_source_terms, apply_transverse_flux, riemann_flux x4 (HLLC),
+   apply_artificial_viscosity, conservative update, source corrector
+   (unsplit_fluxes.py:134-549, interface.py:5-378, riemann.py:596-860).
+   Ghost cells must be filled.  PYROHIP_ERR_STATE mirrors the reference's
+   positivity assert (simulation.py:68-71). */
+int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p,
+                      double dt);
+/* debug: copy an intermediate of the LAST staged step to the host.
+   stage ids: 0 q(4) 1 xi(1) 2 XM(4) 3 XP(4) 4 YM(4) 5 YP(4) 6 FxT(4)
+   7 FyT(4) 8 Fx(4) 9 Fy(4).  out: (qx,qy,ncomp) reference layout.
+   XM/XP (YM/YP) are the lower/upper face states of each CELL:
+   XM[i,j] = U_xr[i,j], XP[i,j] = U_xl[i+1,j] before the transverse
+   correction (unsplit_fluxes.py:207-242). */
+int pyrohip_comp_stage_dump(pyrohip_state *s, int stage_id, double *out);
+
+/* ---- multigrid: MG.CellCenterMG2d (multigrid/MG.py:85-778) ------------- */
+/* bc: xl,xr,yl,yr with PYROHIP_BC_REFLECT_ODD = dirichlet,
+   PYROHIP_BC_OUTFLOW = neumann, PYROHIP_BC_PERIODIC                        */
+int pyrohip_mg_create(pyrohip_ctx *ctx, int nx, double xmin, double xmax,
+                      double ymin, double ymax, const int *bc, double alpha,
+                      double beta, int nsmooth, int nsmooth_bottom,
+                      pyrohip_mg **out);
+int pyrohip_mg_destroy(pyrohip_mg *m);
+int pyrohip_mg_nlevels(pyrohip_mg *m, int *nlevels);
+/* var: 0 = v, 1 = f, 2 = r; arrays are (n+2, n+2) with ng = 1 */
+int pyrohip_mg_set(pyrohip_mg *m, int level, int var, const double *host);
+int pyrohip_mg_get(pyrohip_mg *m, int level, int var, double *host);
+/* inhomogeneous boundary values on the finest level (boundary.py:196-211);
+   side 0..3 = xl,xr,yl,yr; vals has n+2 entries; NULL clears */
+int pyrohip_mg_set_bcval(pyrohip_mg *m, int side, const double *vals);
+int pyrohip_mg_zero(pyrohip_mg *m, int level, int var);        /* patch.py:562 */
+int pyrohip_mg_fill_bc(pyrohip_mg *m, int level, int var);
+int pyrohip_mg_smooth(pyrohip_mg *m, int level, int nsmooth);  /* MG.py:544-621 */
+int pyrohip_mg_residual(pyrohip_mg *m, int level);             /* MG.py:529-542 */
+int pyrohip_mg_restrict(pyrohip_mg *m, int fine_level);        /* patch.py:640-676 */
+int pyrohip_mg_prolong_add(pyrohip_mg *m, int fine_level);     /* patch.py:678-736 */
+int pyrohip_mg_norm(pyrohip_mg *m, int level, int var, double *out); /* array_indexer.py:98-111 */
+int pyrohip_mg_vcycle(pyrohip_mg *m, int level);               /* MG.py:699-778 */
+/* init_RHS bookkeeping: source_norm = ||f|| on the finest level (MG.py:521) */
+int pyrohip_mg_init_rhs_norm(pyrohip_mg *m, double *source_norm);
+/* MG.py:623-697 */
+int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles,
+                     int *num_cycles, double *residual_error,
+                     double *relative_error);
+
+/* ---- multi-GPU: x-slab decomposition, one process per GPU, RCCL -------- */
+#define PYROHIP_UNIQUE_ID_BYTES 128
+int pyrohip_comm_unique_id(char *out_id /* PYROHIP_UNIQUE_ID_BYTES */);
+int pyrohip_comm_init(pyrohip_ctx *ctx, int nranks, int rank,
+                      const char *unique_id);
+int pyrohip_comm_destroy(pyrohip_ctx *ctx);
+/* exchange ng ghost rows of every variable with the x neighbours
+   (rank_lo / rank_hi, -1 = none).  Replaces the single-domain x ghost fill
+   for PYROHIP_BC_HALO sides; y ghost fill must follow (fill order of
+   array_indexer.py:150-274). */
+int pyrohip_halo_exchange(pyrohip_state *s, int rank_lo, int rank_hi);
+int pyrohip_allreduce_min(pyrohip_ctx *ctx, double *value);
+int pyrohip_allreduce_max(pyrohip_ctx *ctx, double *value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYROHIP_H */

@@ -1,0 +1,163 @@
+"""ctypes binding of libpyrohip.so (include/pyrohip.h).
+
+The product path has NO CPU fallback: if the HIP library cannot be loaded, or
+it is not the gfx950 build, importing a device object fails loudly.  (Tests
+that run on the GPU-less build container inject the host-emulated build of the
+same kernel sources explicitly through `use_library`.)
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "lib", "libpyrohip.so")
+
+BC_OUTFLOW, BC_REFLECT_EVEN, BC_REFLECT_ODD, BC_PERIODIC, BC_HALO = range(5)
+BC_CODE = {"outflow": BC_OUTFLOW, "neumann": BC_OUTFLOW,
+           "reflect-even": BC_REFLECT_EVEN, "reflect-odd": BC_REFLECT_ODD,
+           "dirichlet": BC_REFLECT_ODD, "periodic": BC_PERIODIC,
+           "halo": BC_HALO}
+
+ERR_STATE = 10002
+UNIQUE_ID_BYTES = 128
+
+
+class PyroHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libpyrohip error {code}: {msg}")
+        self.code = code
+
+
+class CompParams(C.Structure):
+    _fields_ = [("dx", C.c_double), ("dy", C.c_double), ("gamma", C.c_double),
+                ("limiter", C.c_int), ("use_flattening", C.c_int),
+                ("z0", C.c_double), ("z1", C.c_double), ("delta", C.c_double),
+                ("cvisc", C.c_double), ("grav", C.c_double),
+                ("small_dens", C.c_double),
+                ("avisc_xhi_interior", C.c_int),
+                ("avisc_yhi_interior", C.c_int),
+                ("fast_math", C.c_int), ("kernel_set", C.c_int)]
+
+
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int)
+_VP = C.c_void_p
+
+_PROTOS = {
+    "pyrohip_init": [C.c_int, C.POINTER(_VP)],
+    "pyrohip_shutdown": [_VP],
+    "pyrohip_sync": [_VP],
+    "pyrohip_device_info": [_VP, C.c_char_p, C.c_int, C.POINTER(C.c_size_t),
+                            C.POINTER(C.c_size_t), _IP],
+    "pyrohip_timer_start": [_VP],
+    "pyrohip_timer_stop": [_VP, _DP],
+    "pyrohip_state_create": [_VP, C.c_int, C.c_int, C.c_int, C.c_int, _IP,
+                             C.POINTER(_VP)],
+    "pyrohip_state_destroy": [_VP],
+    "pyrohip_state_upload": [_VP, _DP],
+    "pyrohip_state_download": [_VP, _DP],
+    "pyrohip_state_upload_var": [_VP, C.c_int, _DP],
+    "pyrohip_state_download_var": [_VP, C.c_int, _DP],
+    "pyrohip_state_upload_rows": [_VP, C.c_int, C.c_int, _DP],
+    "pyrohip_state_download_rows": [_VP, C.c_int, C.c_int, _DP],
+    "pyrohip_fill_bc": [_VP, C.c_int],
+    "pyrohip_state_minmax": [_VP, C.c_int, C.c_int, _DP, _DP],
+    "pyrohip_adv_step": [_VP, C.c_int, C.c_double, C.c_double, C.c_double,
+                         C.c_double, C.c_double, C.c_int],
+    "pyrohip_comp_dt": [_VP, C.POINTER(CompParams), C.c_double, _DP],
+    "pyrohip_comp_step": [_VP, C.POINTER(CompParams), C.c_double],
+    "pyrohip_comp_stage_dump": [_VP, C.c_int, _DP],
+    "pyrohip_mg_create": [_VP, C.c_int, C.c_double, C.c_double, C.c_double,
+                          C.c_double, _IP, C.c_double, C.c_double, C.c_int,
+                          C.c_int, C.POINTER(_VP)],
+    "pyrohip_mg_destroy": [_VP],
+    "pyrohip_mg_nlevels": [_VP, _IP],
+    "pyrohip_mg_set": [_VP, C.c_int, C.c_int, _DP],
+    "pyrohip_mg_get": [_VP, C.c_int, C.c_int, _DP],
+    "pyrohip_mg_set_bcval": [_VP, C.c_int, _DP],
+    "pyrohip_mg_zero": [_VP, C.c_int, C.c_int],
+    "pyrohip_mg_fill_bc": [_VP, C.c_int, C.c_int],
+    "pyrohip_mg_smooth": [_VP, C.c_int, C.c_int],
+    "pyrohip_mg_residual": [_VP, C.c_int],
+    "pyrohip_mg_restrict": [_VP, C.c_int],
+    "pyrohip_mg_prolong_add": [_VP, C.c_int],
+    "pyrohip_mg_norm": [_VP, C.c_int, C.c_int, _DP],
+    "pyrohip_mg_vcycle": [_VP, C.c_int],
+    "pyrohip_mg_init_rhs_norm": [_VP, _DP],
+    "pyrohip_mg_solve": [_VP, C.c_double, C.c_int, _IP, _DP, _DP],
+    "pyrohip_comm_unique_id": [C.c_char_p],
+    "pyrohip_comm_init": [_VP, C.c_int, C.c_int, C.c_char_p],
+    "pyrohip_comm_destroy": [_VP],
+    "pyrohip_halo_exchange": [_VP, C.c_int, C.c_int],
+    "pyrohip_allreduce_min": [_VP, _DP],
+    "pyrohip_allreduce_max": [_VP, _DP],
+}
+
+EXPORTS = sorted(list(_PROTOS) + ["pyrohip_last_error", "pyrohip_backend"])
+
+_lock = threading.Lock()
+_lib = None
+_lib_path = None
+_allow_backend = ("hip-gfx950",)
+
+
+def use_library(path, allow_backends=("hip-gfx950",)):
+    """Select the shared library to bind (call before the first device op).
+    Only tests pass anything but the defaults."""
+    global _lib, _lib_path, _allow_backend
+    with _lock:
+        _lib = None
+        _lib_path = path
+        _allow_backend = tuple(allow_backends)
+
+
+def _load():
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = _lib_path or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} is missing: the HIP extension has not been built "
+                "(run `python -m pyro2_amd.build` or __graft_entry__.build()). "
+                "pyro2_amd has no CPU fallback.")
+        lib = C.CDLL(path)
+        lib.pyrohip_last_error.restype = C.c_char_p
+        lib.pyrohip_backend.restype = C.c_char_p
+        backend = lib.pyrohip_backend().decode()
+        if backend not in _allow_backend:
+            raise ImportError(f"{path} reports backend '{backend}', expected "
+                              f"one of {_allow_backend}")
+        for name, args in _PROTOS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        _lib = lib
+        return lib
+
+
+def lib():
+    return _lib if _lib is not None else _load()
+
+
+def backend_name():
+    return lib().pyrohip_backend().decode()
+
+
+def check(rc):
+    if rc != 0:
+        raise PyroHipError(rc, lib().pyrohip_last_error().decode())
+
+
+def dptr(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"], \
+        "need a C-contiguous float64 array"
+    return a.ctypes.data_as(_DP)
+
+
+def iptr(a):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_IP)

@@ -1,0 +1,100 @@
+// Internal declarations shared by the libpyrohip.so translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pyrohip.h"
+
+namespace pyro {
+
+void set_error(const std::string &msg);
+
+#define PYRO_CHECK_HIP(expr)                                                  \
+    do {                                                                      \
+        hipError_t _e = (expr);                                               \
+        if (_e != hipSuccess) {                                               \
+            ::pyro::set_error(std::string(#expr) + ": " +                     \
+                              hipGetErrorString(_e));                         \
+            return (int)_e;                                                   \
+        }                                                                     \
+    } while (0)
+
+#define PYRO_REQUIRE(cond, msg)                                               \
+    do {                                                                      \
+        if (!(cond)) {                                                        \
+            ::pyro::set_error(std::string(__func__) + ": " + (msg));          \
+            return PYROHIP_ERR_ARG;                                           \
+        }                                                                     \
+    } while (0)
+
+#define PYRO_TRY(expr)                                                        \
+    do {                                                                      \
+        int _rc = (expr);                                                     \
+        if (_rc != 0) return _rc;                                             \
+    } while (0)
+
+// Geometry of one plane.  Rows are 128-B aligned at the FIRST INTERIOR cell
+// (j = ng), so interior row loads/stores of a wave are aligned; `pitch` is a
+// multiple of 16 doubles.
+struct Geom {
+    int nx, ny, ng;
+    int qx, qy;
+    int pitch;        // doubles between consecutive i rows
+    size_t plane;     // doubles between consecutive variables
+    int ilo, ihi, jlo, jhi;
+};
+
+inline Geom make_geom(int nx, int ny, int ng)
+{
+    Geom g;
+    g.nx = nx; g.ny = ny; g.ng = ng;
+    g.qx = nx + 2 * ng; g.qy = ny + 2 * ng;
+    int lead = (16 - ng % 16) % 16;            // pad so that j = ng is aligned
+    g.pitch = ((lead + g.qy + 15) / 16) * 16;
+    g.plane = (size_t)g.qx * g.pitch;
+    g.ilo = ng; g.ihi = ng + nx - 1; g.jlo = ng; g.jhi = ng + ny - 1;
+    return g;
+}
+inline int geom_lead(const Geom &g) { return (16 - g.ng % 16) % 16; }
+
+// scratch buffer grown on demand (device)
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need);
+    void release();
+};
+
+}  // namespace pyro
+
+struct pyrohip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    pyro::DevBuf staging;     // AoS <-> planar staging
+    pyro::DevBuf reduce;      // reduction scratch (device)
+    void *reduce_host = nullptr;  // pinned host words for scalar results
+    void *comm = nullptr;     // ncclComm_t
+    int nranks = 1, rank = 0;
+    int num_cus = 0;
+};
+
+struct pyrohip_state {
+    pyrohip_ctx *ctx = nullptr;
+    pyro::Geom g;
+    int nvar = 0;
+    std::vector<int> bc;      // nvar*4
+    double *base = nullptr;   // allocation
+    double *d = nullptr;      // base + lead: plane n, row i: d + n*plane + i*pitch
+    int *d_bc = nullptr;      // device copy of bc
+    // compressible work space (allocated on first use)
+    double *work = nullptr;
+    size_t work_planes = 0;
+    int *d_flag = nullptr;    // positivity flag
+    double next_cfl_min = -1.0;  // min over interior of dx/(|u|+c) etc. of the
+                                 // state after the last step (-1: unknown)
+};

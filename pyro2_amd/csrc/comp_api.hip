@@ -1,0 +1,61 @@
+// extern "C" entry points of the compressible solver: argument checking and
+// dispatch between the bit-faithful (exact) and contracted (fastm) builds of
+// compressible.hip / comp_fused.hip.
+#include "common.h"
+
+namespace pyro {
+namespace exact {
+int comp_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
+int comp_step_staged(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_stage_dump(pyrohip_state *, int, double *);
+}
+namespace fastm {
+int comp_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
+int comp_step_staged(pyrohip_state *, const pyrohip_comp_params *, double);
+}
+}  // namespace pyro
+
+using namespace pyro;
+
+static int check_comp(pyrohip_state *s, const pyrohip_comp_params *p)
+{
+    PYRO_REQUIRE(s && p, "NULL argument");
+    PYRO_REQUIRE(s->nvar == 4, "compressible state must have 4 variables "
+                               "(density, energy, x-momentum, y-momentum)");
+    PYRO_REQUIRE(s->g.ng >= 4, "compressible needs ng >= 4 (compressible/simulation.py:194)");
+    PYRO_REQUIRE(p->limiter >= 0 && p->limiter <= 2, "limiter must be 0, 1 or 2");
+    PYRO_REQUIRE(p->dx > 0 && p->dy > 0 && p->gamma > 1.0, "bad dx/dy/gamma");
+    if (p->grav != 0.0) {
+        set_error("compressible.grav != 0 is not implemented on the device yet");
+        return PYROHIP_ERR_UNSUPPORTED;
+    }
+    return 0;
+}
+
+extern "C" {
+
+int pyrohip_comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, double *dt_out)
+{
+    PYRO_TRY(check_comp(s, p));
+    PYRO_REQUIRE(dt_out, "dt_out is NULL");
+    return p->fast_math ? fastm::comp_dt(s, p, cfl, dt_out) : exact::comp_dt(s, p, cfl, dt_out);
+}
+
+int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+{
+    PYRO_TRY(check_comp(s, p));
+    PYRO_REQUIRE(dt > 0.0, "dt must be positive");
+    if (p->kernel_set != 0) {
+        set_error("kernel_set != 0 not available in this build");
+        return PYROHIP_ERR_UNSUPPORTED;
+    }
+    return p->fast_math ? fastm::comp_step_staged(s, p, dt) : exact::comp_step_staged(s, p, dt);
+}
+
+int pyrohip_comp_stage_dump(pyrohip_state *s, int stage_id, double *out)
+{
+    PYRO_REQUIRE(s && out, "NULL argument");
+    return exact::comp_stage_dump(s, stage_id, out);
+}
+
+}  // extern "C"

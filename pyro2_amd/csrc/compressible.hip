@@ -1,0 +1,442 @@
+// Compressible Euler, unsplit CTU (Colella 1990) step with HLLC fluxes.
+//
+// Replaces (reference file:line)
+//   pyro/compressible/simulation.py:267-288   method_compute_timestep
+//   pyro/compressible/simulation.py:290-450   Simulation.evolve
+//   pyro/compressible/unsplit_fluxes.py:134-549
+//   pyro/compressible/interface.py:5-378      states, artificial_viscosity
+//   pyro/compressible/riemann.py:596-860,1104-1179  HLLC
+//   pyro/mesh/reconstruction.py:9-183         limiters, flattening
+//
+// kernel_set 0 ("staged"): one kernel per algorithm stage with planar global
+// intermediates; every stage can be dumped (pyrohip_comp_stage_dump) and
+// compared with the oracle.  Only the cells/faces inside the interior's
+// domain of dependence are computed (SURVEY.md 7 "stencil radius 4").
+//
+// This file is compiled twice: PYRO_FAST=0 (-ffp-contract=off, the
+// bit-faithful build) and PYRO_FAST=1 (-ffp-contract=fast); the entry points
+// dispatch on pyrohip_comp_params.fast_math.
+#include "common.h"
+#include "hydro.h"
+#include "reduce.h"
+
+#ifndef PYRO_FAST
+#define PYRO_FAST 0
+#endif
+#if PYRO_FAST
+#define PYRO_NS fastm
+#else
+#define PYRO_NS exact
+#endif
+
+namespace pyro {
+namespace PYRO_NS {
+
+// work-space plane indices
+enum {
+    W_Q = 0,      // 4: rho u v p
+    W_XI = 4,     // 1
+    W_XM = 5,     // 4: lower x-face state of the cell  (= U_xr[i,j])
+    W_XP = 9,     // 4: upper x-face state of the cell  (= U_xl[i+1,j])
+    W_YM = 13,    // 4
+    W_YP = 17,    // 4
+    W_FXT = 21,   // 4: transverse Riemann flux on x faces
+    W_FYT = 25,   // 4
+    W_FX = 29,    // 4: final fluxes incl. artificial viscosity
+    W_FY = 33,    // 4
+    W_NPLANES = 37
+};
+
+struct CP {   // kernel-side parameters
+    double gamma, dx, dy, dt;
+    double z0, z1, delta, cvisc, small_dens;
+    int limiter, use_flattening;
+    int avx_hi, avy_hi;   // compute avisc on the upper boundary face
+};
+
+__device__ __forceinline__ Cons load_cons(const double *__restrict__ a, size_t plane, size_t k)
+{
+    Cons U;
+    U.d = a[k]; U.E = a[plane + k]; U.mx = a[2 * plane + k]; U.my = a[3 * plane + k];
+    return U;
+}
+__device__ __forceinline__ void store_cons(double *__restrict__ a, size_t plane, size_t k,
+                                           const Cons &U)
+{
+    a[k] = U.d; a[plane + k] = U.E; a[2 * plane + k] = U.mx; a[3 * plane + k] = U.my;
+}
+
+// ---- stage 0: clean_state + cons_to_prim over the whole array ------------
+// simulation.py:452-456 and :49-80.  flag[0] |= 1 when the interior
+// positivity assert (:68-71) would fire.
+__global__ __launch_bounds__(256) void k_prim(double *__restrict__ U, double *__restrict__ W,
+                                              Geom g, CP P, int *__restrict__ flag)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= g.qy) return;
+    const size_t k = (size_t)i * g.pitch + j;
+    const bool interior = (i >= g.ilo && i <= g.ihi && j >= g.jlo && j <= g.jhi);
+    Cons Uc = load_cons(U, g.plane, k);
+    if (interior) {
+        double dn = fmax(Uc.d, P.small_dens);
+        if (dn != Uc.d) U[k] = dn;
+        Uc.d = dn;
+    }
+    bool ok;
+    Prim q = cons_to_prim(Uc, P.gamma, &ok);
+    double *Q = W + (size_t)W_Q * g.plane;
+    Q[k] = q.r; Q[g.plane + k] = q.u; Q[2 * g.plane + k] = q.v; Q[3 * g.plane + k] = q.p;
+    if (interior && !ok) atomicOr(flag, 1);
+}
+
+// ---- stage 1: multi-dimensional flattening coefficient on R(1) -----------
+// reconstruction.py:123-183
+__global__ __launch_bounds__(256) void k_xi(const double *__restrict__ W_, double *__restrict__ XI,
+                                            Geom g, CP P)
+{
+    const int j = g.jlo - 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = g.ilo - 1 + blockIdx.y;
+    if (j > g.jhi + 1) return;
+    const int p = g.pitch;
+    const size_t k = (size_t)i * p + j;
+    if (!P.use_flattening) { XI[k] = 1.0; return; }
+    const double *u = W_ + (size_t)(W_Q + 1) * g.plane;
+    const double *v = W_ + (size_t)(W_Q + 2) * g.plane;
+    const double *pr = W_ + (size_t)(W_Q + 3) * g.plane;
+    // xi_x at i-1, i, i+1 ; xi_y at j-1, j, j+1
+    double xix[3], xiy[3];
+#pragma unroll
+    for (int s = -1; s <= 1; s++) {
+        size_t c = k + (ptrdiff_t)s * p;
+        xix[s + 1] = flatten_1d(pr[c - 2 * p], pr[c - p], pr[c + p], pr[c + 2 * p], u[c - p],
+                                u[c + p], P.z0, P.z1, P.delta);
+        size_t d = k + s;
+        xiy[s + 1] = flatten_1d(pr[d - 2], pr[d - 1], pr[d + 1], pr[d + 2], v[d - 1], v[d + 1],
+                                P.z0, P.z1, P.delta);
+    }
+    double px = (pr[k + p] - pr[k - p] > 0) ? xix[0] : xix[2];
+    double py = (pr[k + 1] - pr[k - 1] > 0) ? xiy[0] : xiy[2];
+    XI[k] = fmin(fmin(xix[1], px), fmin(xiy[1], py));
+}
+
+// ---- stage 2: limited slopes + characteristic tracing on R(1) ------------
+// unsplit_fluxes.py:186-242, interface.py:5-236, simulation.py:83-102
+__global__ __launch_bounds__(256) void k_states(const double *__restrict__ W_,
+                                                double *__restrict__ Wout, Geom g, CP P)
+{
+    const int j = g.jlo - 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = g.ilo - 1 + blockIdx.y;
+    if (j > g.jhi + 1) return;
+    const int p = g.pitch;
+    const size_t k = (size_t)i * p + j;
+    const size_t pl = g.plane;
+    const double *Q = W_ + (size_t)W_Q * pl;
+    const double xi = W_[(size_t)W_XI * pl + k];
+    double q0[4], dqx[4], dqy[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const double *a = Q + (size_t)n * pl;
+        q0[n] = a[k];
+        dqx[n] = xi * limited_slope(a[k - 2 * p], a[k - p], a[k], a[k + p], a[k + 2 * p],
+                                    P.limiter);
+        dqy[n] = xi * limited_slope(a[k - 2], a[k - 1], a[k], a[k + 1], a[k + 2], P.limiter);
+    }
+    Trace lo, hi;
+    // x: normal velocity u (1), transverse v (2)
+    trace_states(q0[0], q0[1], q0[2], q0[3], dqx[0], dqx[1], dqx[2], dqx[3], P.gamma,
+                 P.dt / P.dx, lo, hi);
+    store_cons(Wout + (size_t)W_XM * pl, pl, k, prim_to_cons(Prim{lo.r, lo.un, lo.ut, lo.p}, P.gamma));
+    store_cons(Wout + (size_t)W_XP * pl, pl, k, prim_to_cons(Prim{hi.r, hi.un, hi.ut, hi.p}, P.gamma));
+    // y: normal velocity v, transverse u
+    trace_states(q0[0], q0[2], q0[1], q0[3], dqy[0], dqy[2], dqy[1], dqy[3], P.gamma,
+                 P.dt / P.dy, lo, hi);
+    store_cons(Wout + (size_t)W_YM * pl, pl, k, prim_to_cons(Prim{lo.r, lo.ut, lo.un, lo.p}, P.gamma));
+    store_cons(Wout + (size_t)W_YP * pl, pl, k, prim_to_cons(Prim{hi.r, hi.ut, hi.un, hi.p}, P.gamma));
+}
+
+__device__ __forceinline__ ConsN to_n(const Cons &U, bool x)
+{
+    return x ? ConsN{U.d, U.E, U.mx, U.my} : ConsN{U.d, U.E, U.my, U.mx};
+}
+__device__ __forceinline__ Cons from_n(const ConsN &F, bool x)
+{
+    return x ? Cons{F.d, F.E, F.mn, F.mt} : Cons{F.d, F.E, F.mt, F.mn};
+}
+
+// ---- stage 3: transverse Riemann problems --------------------------------
+// unsplit_fluxes.py:412-440 -> riemann.py:681-860
+// thread (i,j) in [ilo-1, ihi+1] x [jlo-1, jhi+1] solves its lower x face
+// (needs i >= ilo) and its lower y face (needs j >= jlo)
+__global__ __launch_bounds__(256) void k_riemann_t(const double *__restrict__ W_,
+                                                   double *__restrict__ Wout, Geom g, CP P)
+{
+    const int j = g.jlo - 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = g.ilo - 1 + blockIdx.y;
+    if (j > g.jhi + 1) return;
+    const int p = g.pitch;
+    const size_t k = (size_t)i * p + j;
+    const size_t pl = g.plane;
+    if (i >= g.ilo) {
+        Cons Ul = load_cons(W_ + (size_t)W_XP * pl, pl, k - p);
+        Cons Ur = load_cons(W_ + (size_t)W_XM * pl, pl, k);
+        ConsN F = hllc_flux(to_n(Ul, true), to_n(Ur, true), P.gamma, true);
+        store_cons(Wout + (size_t)W_FXT * pl, pl, k, from_n(F, true));
+    }
+    if (j >= g.jlo) {
+        Cons Ul = load_cons(W_ + (size_t)W_YP * pl, pl, k - 1);
+        Cons Ur = load_cons(W_ + (size_t)W_YM * pl, pl, k);
+        ConsN F = hllc_flux(to_n(Ul, false), to_n(Ur, false), P.gamma, false);
+        store_cons(Wout + (size_t)W_FYT * pl, pl, k, from_n(F, false));
+    }
+}
+
+__device__ __forceinline__ Cons corrected(const Cons &U, const Cons &Fhi, const Cons &Flo,
+                                          double hdtV, double A)
+{
+    // U += -hdtV*(F_hi*A - F_lo*A), unsplit_fluxes.py:447-471
+    Cons r;
+    r.d = U.d + (-hdtV * (Fhi.d * A - Flo.d * A));
+    r.E = U.E + (-hdtV * (Fhi.E * A - Flo.E * A));
+    r.mx = U.mx + (-hdtV * (Fhi.mx * A - Flo.mx * A));
+    r.my = U.my + (-hdtV * (Fhi.my * A - Flo.my * A));
+    return r;
+}
+
+// ---- stage 4: transverse correction + final Riemann + art. viscosity ----
+// unsplit_fluxes.py:442-471, simulation.py:349-365, interface.py:239-378,
+// unsplit_fluxes.py:525-547.
+// thread (i,j) in [ilo, ihi+1] x [jlo, jhi+1]: F_x on its lower x face when
+// j <= jhi, F_y on its lower y face when i <= ihi.
+__global__ __launch_bounds__(256) void k_final(const double *__restrict__ U,
+                                               const double *__restrict__ W_,
+                                               double *__restrict__ Wout, Geom g, CP P)
+{
+    const int j = g.jlo + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = g.ilo + blockIdx.y;
+    if (j > g.jhi + 1) return;
+    const int p = g.pitch;
+    const size_t k = (size_t)i * p + j;
+    const size_t pl = g.plane;
+    const double hdt = 0.5 * P.dt;
+    const double hdtV = hdt / (P.dx * P.dy);   // hdt / V, patch.py:232
+    const double Ax = P.dy, Ay = P.dx;         // patch.py:219-222
+    const double *FXT = W_ + (size_t)W_FXT * pl, *FYT = W_ + (size_t)W_FYT * pl;
+    const double *u = W_ + (size_t)(W_Q + 1) * pl, *v = W_ + (size_t)(W_Q + 2) * pl;
+
+    // vertex divergences needed by this thread: divU[i,j], [i,j+1], [i+1,j]
+    const double d00 = div_u_vertex(u[k], u[k - 1], u[k - p], u[k - p - 1], v[k], v[k - p],
+                                    v[k - 1], v[k - p - 1], P.dx, P.dy);
+    const Cons Uc = load_cons(U, pl, k);
+
+    if (j <= g.jhi) {   // x face (i,j)
+        Cons Uxl = corrected(load_cons(W_ + (size_t)W_XP * pl, pl, k - p),
+                             load_cons(FYT, pl, k - p + 1), load_cons(FYT, pl, k - p), hdtV, Ay);
+        Cons Uxr = corrected(load_cons(W_ + (size_t)W_XM * pl, pl, k), load_cons(FYT, pl, k + 1),
+                             load_cons(FYT, pl, k), hdtV, Ay);
+        Cons F = from_n(hllc_flux(to_n(Uxl, true), to_n(Uxr, true), P.gamma, true), true);
+        double avx = 0.0;
+        if (i <= g.ihi || P.avx_hi) {
+            size_t kk = k + 1;
+            double d01 = div_u_vertex(u[kk], u[kk - 1], u[kk - p], u[kk - p - 1], v[kk],
+                                      v[kk - p], v[kk - 1], v[kk - p - 1], P.dx, P.dy);
+            double divU_x = 0.5 * (d00 + d01);
+            avx = P.cvisc * fmax(-divU_x * P.dx, 0.0);
+        }
+        const Cons Um = load_cons(U, pl, k - p);
+        F.d += avx * (Um.d - Uc.d);
+        F.E += avx * (Um.E - Uc.E);
+        F.mx += avx * (Um.mx - Uc.mx);
+        F.my += avx * (Um.my - Uc.my);
+        store_cons(Wout + (size_t)W_FX * pl, pl, k, F);
+    }
+    if (i <= g.ihi) {   // y face (i,j)
+        Cons Uyl = corrected(load_cons(W_ + (size_t)W_YP * pl, pl, k - 1),
+                             load_cons(FXT, pl, k + p - 1), load_cons(FXT, pl, k - 1), hdtV, Ax);
+        Cons Uyr = corrected(load_cons(W_ + (size_t)W_YM * pl, pl, k), load_cons(FXT, pl, k + p),
+                             load_cons(FXT, pl, k), hdtV, Ax);
+        Cons F = from_n(hllc_flux(to_n(Uyl, false), to_n(Uyr, false), P.gamma, false), false);
+        double avy = 0.0;
+        if (j <= g.jhi || P.avy_hi) {
+            size_t kk = k + p;
+            double d10 = div_u_vertex(u[kk], u[kk - 1], u[kk - p], u[kk - p - 1], v[kk],
+                                      v[kk - p], v[kk - 1], v[kk - p - 1], P.dx, P.dy);
+            double divU_y = 0.5 * (d00 + d10);
+            avy = P.cvisc * fmax(-divU_y * P.dy, 0.0);
+        }
+        const Cons Um = load_cons(U, pl, k - 1);
+        F.d += avy * (Um.d - Uc.d);
+        F.E += avy * (Um.E - Uc.E);
+        F.mx += avy * (Um.mx - Uc.mx);
+        F.my += avy * (Um.my - Uc.my);
+        store_cons(Wout + (size_t)W_FY * pl, pl, k, F);
+    }
+}
+
+// ---- stage 5: conservative update + CFL minimum of the new state ---------
+// simulation.py:377-384; the per-block minimum of dx/(|u|+c), dy/(|v|+c) of
+// the UPDATED cells is the next step's method_compute_timestep (interior min
+// == full-array min for outflow / reflect / periodic ghost fills).
+__global__ __launch_bounds__(256) void k_update(double *__restrict__ U,
+                                                const double *__restrict__ W_, Geom g, CP P,
+                                                double *__restrict__ partial)
+{
+    const int j = g.jlo + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = g.ilo + blockIdx.y;
+    const int p = g.pitch;
+    const size_t pl = g.plane;
+    double cfl = INFINITY;
+    if (j <= g.jhi) {
+        const size_t k = (size_t)i * p + j;
+        const double dtdV = P.dt / (P.dx * P.dy);
+        const double Ax = P.dy, Ay = P.dx;
+        const double *FX = W_ + (size_t)W_FX * pl, *FY = W_ + (size_t)W_FY * pl;
+        double Un[4];
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const double *fx = FX + (size_t)n * pl, *fy = FY + (size_t)n * pl;
+            Un[n] = U[(size_t)n * pl + k] +
+                    dtdV * (fx[k] * Ax - fx[k + p] * Ax + fy[k] * Ay - fy[k + 1] * Ay);
+            U[(size_t)n * pl + k] = Un[n];
+        }
+        cfl = cfl_cell(Cons{Un[0], Un[1], Un[2], Un[3]}, P.gamma, P.dx, P.dy);
+    }
+    cfl = block_reduce_min(cfl);
+    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = cfl;
+}
+
+// ---- CFL over the whole array (ghost cells included), derives.py ---------
+__global__ __launch_bounds__(256) void k_cfl(const double *__restrict__ U, Geom g, double gamma,
+                                             double dx, double dy, double *__restrict__ partial)
+{
+    double m = INFINITY;
+    for (int i = blockIdx.y; i < g.qx; i += gridDim.y)
+        for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < g.qy; j += gridDim.x * blockDim.x)
+            m = fmin(m, cfl_cell(load_cons(U, g.plane, (size_t)i * g.pitch + j), gamma, dx, dy));
+    m = block_reduce_min(m);
+    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = m;
+}
+
+__global__ void k_min_final(const double *__restrict__ partial, int nb, double *__restrict__ out)
+{
+    double m = INFINITY;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) m = fmin(m, partial[b]);
+    m = block_reduce_min(m);
+    if (threadIdx.x == 0) out[0] = m;
+}
+
+static CP make_cp(const pyrohip_comp_params *p, double dt)
+{
+    CP c;
+    c.gamma = p->gamma; c.dx = p->dx; c.dy = p->dy; c.dt = dt;
+    c.z0 = p->z0; c.z1 = p->z1; c.delta = p->delta; c.cvisc = p->cvisc;
+    c.small_dens = p->small_dens;
+    c.limiter = p->limiter; c.use_flattening = p->use_flattening;
+    c.avx_hi = p->avisc_xhi_interior; c.avy_hi = p->avisc_yhi_interior;
+    return c;
+}
+
+static int ensure_work(pyrohip_state *s, size_t planes)
+{
+    if (s->work_planes >= planes) return 0;
+    if (s->work) PYRO_CHECK_HIP(hipFree(s->work));
+    s->work = nullptr; s->work_planes = 0;
+    size_t n = s->g.plane * planes + 16;
+    PYRO_CHECK_HIP(hipMalloc((void **)&s->work, n * sizeof(double)));
+    // zero once: stage dumps of never-written cells then read as 0
+    PYRO_CHECK_HIP(hipMemsetAsync(s->work, 0, n * sizeof(double), s->ctx->stream));
+    s->work_planes = planes;
+    return 0;
+}
+
+int comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, double *dt_out)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    if (s->next_cfl_min > 0.0) {   // cached by the last k_update
+        *dt_out = cfl * s->next_cfl_min;
+        return 0;
+    }
+    dim3 grid(8, 128), block(256);
+    const int nb = grid.x * grid.y;
+    PYRO_TRY(c->reduce.ensure((nb + 2) * sizeof(double)));
+    double *part = (double *)c->reduce.p;
+    hipLaunchKernelGGL(k_cfl, grid, block, 0, c->stream, (const double *)s->d, g, p->gamma, p->dx,
+                       p->dy, part);
+    hipLaunchKernelGGL(k_min_final, dim3(1), dim3(256), 0, c->stream, (const double *)part, nb,
+                       part + nb);
+    PYRO_CHECK_HIP(hipGetLastError());
+    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, part + nb, sizeof(double),
+                                  hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    *dt_out = cfl * ((double *)c->reduce_host)[0];
+    return 0;
+}
+
+int comp_step_staged(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    PYRO_TRY(ensure_work(s, W_NPLANES));
+    const CP P = make_cp(p, dt);
+    double *U = s->d;
+    double *W = s->work + geom_lead(g);
+    const dim3 block(256);
+    PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_prim, dim3((g.qy + 255) / 256, g.qx), block, 0, c->stream, U, W, g, P,
+                       s->d_flag);
+    const dim3 gridR1((g.ny + 2 + 255) / 256, g.nx + 2);
+    hipLaunchKernelGGL(k_xi, gridR1, block, 0, c->stream, (const double *)W,
+                       W + (size_t)W_XI * g.plane, g, P);
+    hipLaunchKernelGGL(k_states, gridR1, block, 0, c->stream, (const double *)W, W, g, P);
+    hipLaunchKernelGGL(k_riemann_t, gridR1, block, 0, c->stream, (const double *)W, W, g, P);
+    const dim3 gridF((g.ny + 1 + 255) / 256, g.nx + 1);
+    hipLaunchKernelGGL(k_final, gridF, block, 0, c->stream, (const double *)U, (const double *)W,
+                       W, g, P);
+    const dim3 gridU((g.ny + 255) / 256, g.nx);
+    const int nb = gridU.x * gridU.y;
+    PYRO_TRY(c->reduce.ensure((nb + 2) * sizeof(double)));
+    double *part = (double *)c->reduce.p;
+    hipLaunchKernelGGL(k_update, gridU, block, 0, c->stream, U, (const double *)W, g, P, part);
+    hipLaunchKernelGGL(k_min_final, dim3(1), dim3(256), 0, c->stream, (const double *)part, nb,
+                       part + nb);
+    PYRO_CHECK_HIP(hipGetLastError());
+    // one 16-byte D2H per step: next step's CFL minimum + positivity flag
+    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, part + nb, sizeof(double),
+                                  hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipMemcpyAsync((char *)c->reduce_host + 8, s->d_flag, sizeof(int),
+                                  hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    s->next_cfl_min = ((double *)c->reduce_host)[0];
+    int flag = *(int *)((char *)c->reduce_host + 8);
+    if (flag & 1) {
+        s->next_cfl_min = -1.0;
+        set_error("invalid state: min(rho) <= 0 or min(e) <= 0 on the interior "
+                  "(compressible/simulation.py:68-71)");
+        return PYROHIP_ERR_STATE;
+    }
+    return 0;
+}
+
+int comp_stage_dump(pyrohip_state *s, int stage_id, double *out)
+{
+    static const int first[10] = {W_Q, W_XI, W_XM, W_XP, W_YM, W_YP, W_FXT, W_FYT, W_FX, W_FY};
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    PYRO_REQUIRE(stage_id >= 0 && stage_id < 10, "stage id out of range");
+    PYRO_REQUIRE(s->work_planes >= W_NPLANES, "no staged step has been run");
+    const int ncomp = (stage_id == 1) ? 1 : 4;
+    const double *W = s->work + geom_lead(g) + (size_t)first[stage_id] * g.plane;
+    std::vector<double> tmp((size_t)g.qx * g.qy);
+    for (int n = 0; n < ncomp; n++) {
+        PYRO_CHECK_HIP(hipMemcpy2DAsync(tmp.data(), g.qy * sizeof(double), W + (size_t)n * g.plane,
+                                        g.pitch * sizeof(double), g.qy * sizeof(double), g.qx,
+                                        hipMemcpyDeviceToHost, c->stream));
+        PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+        for (size_t k = 0; k < tmp.size(); k++) out[k * ncomp + n] = tmp[k];
+    }
+    return 0;
+}
+
+}  // namespace PYRO_NS
+}  // namespace pyro

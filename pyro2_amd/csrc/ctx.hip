@@ -1,0 +1,445 @@
+// Context, cell-centred data storage, host<->device transfers, ghost fill,
+// reductions.  Replaces the storage / data-movement half of
+// pyro/mesh/patch.py (CellCenterData2d) and ArrayIndexer.fill_ghost
+// (pyro/mesh/array_indexer.py:150-274).
+#include "common.h"
+#include "reduce.h"
+
+namespace pyro {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+int DevBuf::ensure(size_t need)
+{
+    if (need <= bytes) return 0;
+    if (p) PYRO_CHECK_HIP(hipFree(p));
+    p = nullptr; bytes = 0;
+    PYRO_CHECK_HIP(hipMalloc(&p, need));
+    bytes = need;
+    return 0;
+}
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr; bytes = 0;
+}
+
+// ---------------------------------------------------------------------------
+// AoS (rows, qy, nvar) staging  <->  planar SoA
+// one thread per (row, j); it moves the nvar contiguous doubles of a cell
+// ---------------------------------------------------------------------------
+__global__ void k_aos_to_planar(const double *__restrict__ aos, double *__restrict__ d,
+                                int i0, int ni, int qy, int nvar, int pitch, size_t plane)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = blockIdx.y;
+    if (j >= qy || r >= ni) return;
+    const double *src = aos + ((size_t)r * qy + j) * nvar;
+    double *dst = d + (size_t)(i0 + r) * pitch + j;
+    for (int n = 0; n < nvar; n++) dst[n * plane] = src[n];
+}
+
+__global__ void k_planar_to_aos(const double *__restrict__ d, double *__restrict__ aos,
+                                int i0, int ni, int qy, int nvar, int pitch, size_t plane)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = blockIdx.y;
+    if (j >= qy || r >= ni) return;
+    double *dst = aos + ((size_t)r * qy + j) * nvar;
+    const double *src = d + (size_t)(i0 + r) * pitch + j;
+    for (int n = 0; n < nvar; n++) dst[n] = src[n * plane];
+}
+
+// ---------------------------------------------------------------------------
+// ghost fill.  x pass: rows i < ilo and i > ihi over ALL j (ghost columns
+// included); y pass afterwards over ALL i, so corners come from x-filled data
+// exactly as in array_indexer.py:163-274.
+// grid.z = variable.  bc = nvar*4 codes on the device.
+// ---------------------------------------------------------------------------
+__global__ void k_fill_x(double *__restrict__ d, Geom g, const int *__restrict__ bc, int n0)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = n0 + blockIdx.z;
+    if (j >= g.qy) return;
+    double *a = d + (size_t)n * g.plane;
+    const int bl = bc[n * 4 + 0], br = bc[n * 4 + 1];
+    const int ng = g.ng, ilo = g.ilo, ihi = g.ihi;
+    const int p = g.pitch;
+    if (bl != PYROHIP_BC_HALO)
+        for (int i = 0; i < ilo; i++) {
+            double v;
+            switch (bl) {
+            case PYROHIP_BC_OUTFLOW: v = a[(size_t)ilo * p + j]; break;
+            case PYROHIP_BC_REFLECT_EVEN: v = a[(size_t)(2 * ng - i - 1) * p + j]; break;
+            case PYROHIP_BC_REFLECT_ODD: v = -a[(size_t)(2 * ng - i - 1) * p + j]; break;
+            default: v = a[(size_t)(ihi - ng + i + 1) * p + j]; break;  // periodic
+            }
+            a[(size_t)i * p + j] = v;
+        }
+    if (br != PYROHIP_BC_HALO)
+        for (int k = 0; k < ng; k++) {
+            int i = ihi + 1 + k;
+            double v;
+            switch (br) {
+            case PYROHIP_BC_OUTFLOW: v = a[(size_t)ihi * p + j]; break;
+            case PYROHIP_BC_REFLECT_EVEN: v = a[(size_t)(ihi - k) * p + j]; break;
+            case PYROHIP_BC_REFLECT_ODD: v = -a[(size_t)(ihi - k) * p + j]; break;
+            default: v = a[(size_t)(i - ihi - 1 + ng) * p + j]; break;  // periodic
+            }
+            a[(size_t)i * p + j] = v;
+        }
+}
+
+// threads: x = ghost index k in [0, 2*ng) (contiguous in memory per side),
+//          y = row i
+__global__ void k_fill_y(double *__restrict__ d, Geom g, const int *__restrict__ bc, int n0)
+{
+    int k = threadIdx.x;
+    int i = blockIdx.x * blockDim.y + threadIdx.y;
+    int n = n0 + blockIdx.z;
+    if (i >= g.qx || k >= 2 * g.ng) return;
+    double *a = d + (size_t)n * g.plane + (size_t)i * g.pitch;
+    const int ng = g.ng, jlo = g.jlo, jhi = g.jhi;
+    if (k < ng) {
+        int j = k;
+        double v;
+        switch (bc[n * 4 + 2]) {
+        case PYROHIP_BC_OUTFLOW: v = a[jlo]; break;
+        case PYROHIP_BC_REFLECT_EVEN: v = a[2 * ng - j - 1]; break;
+        case PYROHIP_BC_REFLECT_ODD: v = -a[2 * ng - j - 1]; break;
+        case PYROHIP_BC_PERIODIC: v = a[jhi - ng + j + 1]; break;
+        default: return;
+        }
+        a[j] = v;
+    } else {
+        int kk = k - ng, j = jhi + 1 + kk;
+        double v;
+        switch (bc[n * 4 + 3]) {
+        case PYROHIP_BC_OUTFLOW: v = a[jhi]; break;
+        case PYROHIP_BC_REFLECT_EVEN: v = a[jhi - kk]; break;
+        case PYROHIP_BC_REFLECT_ODD: v = -a[jhi - kk]; break;
+        case PYROHIP_BC_PERIODIC: v = a[j - jhi - 1 + ng]; break;
+        default: return;
+        }
+        a[j] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// min / max over a rectangular region of one plane (two-pass, deterministic)
+// ---------------------------------------------------------------------------
+__global__ void k_minmax(const double *__restrict__ a, int pitch, int i0, int i1, int j0, int j1,
+                         double *__restrict__ partial)
+{
+    double mn = INFINITY, mx = -INFINITY;
+    for (int i = i0 + blockIdx.y; i <= i1; i += gridDim.y)
+        for (int j = j0 + blockIdx.x * blockDim.x + threadIdx.x; j <= j1;
+             j += gridDim.x * blockDim.x) {
+            double v = a[(size_t)i * pitch + j];
+            mn = fmin(mn, v);
+            mx = fmax(mx, v);
+        }
+    mn = block_reduce_min(mn);
+    mx = block_reduce_max(mx);
+    if (threadIdx.x == 0) {
+        int b = blockIdx.y * gridDim.x + blockIdx.x;
+        partial[2 * b] = mn;
+        partial[2 * b + 1] = mx;
+    }
+}
+
+__global__ void k_minmax_final(const double *__restrict__ partial, int nb, double *__restrict__ out)
+{
+    double mn = INFINITY, mx = -INFINITY;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+        mn = fmin(mn, partial[2 * b]);
+        mx = fmax(mx, partial[2 * b + 1]);
+    }
+    mn = block_reduce_min(mn);
+    mx = block_reduce_max(mx);
+    if (threadIdx.x == 0) { out[0] = mn; out[1] = mx; }
+}
+
+}  // namespace pyro
+
+using namespace pyro;
+
+extern "C" {
+
+const char *pyrohip_last_error(void) { return g_last_error.c_str(); }
+
+#ifndef PYRO_BACKEND_NAME
+#define PYRO_BACKEND_NAME "hip-gfx950"
+#endif
+const char *pyrohip_backend(void) { return PYRO_BACKEND_NAME; }
+
+int pyrohip_init(int device_id, pyrohip_ctx **out)
+{
+    PYRO_REQUIRE(out != nullptr, "out is NULL");
+    int ndev = 0;
+    PYRO_CHECK_HIP(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) { set_error("no HIP device visible"); return PYROHIP_ERR_UNSUPPORTED; }
+    PYRO_REQUIRE(device_id >= 0 && device_id < ndev, "device_id out of range");
+    PYRO_CHECK_HIP(hipSetDevice(device_id));
+    pyrohip_ctx *c = new pyrohip_ctx();
+    c->device = device_id;
+    PYRO_CHECK_HIP(hipStreamCreate(&c->stream));
+    PYRO_CHECK_HIP(hipEventCreate(&c->ev0));
+    PYRO_CHECK_HIP(hipEventCreate(&c->ev1));
+    PYRO_CHECK_HIP(hipHostMalloc(&c->reduce_host, 256, 0));
+    hipDeviceProp_t prop;
+    PYRO_CHECK_HIP(hipGetDeviceProperties(&prop, device_id));
+    c->num_cus = prop.multiProcessorCount;
+    *out = c;
+    return 0;
+}
+
+int pyrohip_shutdown(pyrohip_ctx *c)
+{
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    pyrohip_comm_destroy(c);
+    c->staging.release();
+    c->reduce.release();
+    if (c->reduce_host) (void)hipHostFree(c->reduce_host);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int pyrohip_sync(pyrohip_ctx *c)
+{
+    PYRO_REQUIRE(c, "ctx is NULL");
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pyrohip_device_info(pyrohip_ctx *c, char *name, int name_len, size_t *free_bytes,
+                        size_t *total_bytes, int *compute_units)
+{
+    PYRO_REQUIRE(c, "ctx is NULL");
+    hipDeviceProp_t prop;
+    PYRO_CHECK_HIP(hipGetDeviceProperties(&prop, c->device));
+    if (name && name_len > 0) {
+        std::string s = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+        strncpy(name, s.c_str(), name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    size_t f = 0, t = 0;
+    PYRO_CHECK_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    return 0;
+}
+
+int pyrohip_timer_start(pyrohip_ctx *c)
+{
+    PYRO_REQUIRE(c, "ctx is NULL");
+    PYRO_CHECK_HIP(hipEventRecord(c->ev0, c->stream));
+    return 0;
+}
+
+int pyrohip_timer_stop(pyrohip_ctx *c, double *elapsed_ms)
+{
+    PYRO_REQUIRE(c && elapsed_ms, "NULL argument");
+    PYRO_CHECK_HIP(hipEventRecord(c->ev1, c->stream));
+    PYRO_CHECK_HIP(hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    PYRO_CHECK_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *elapsed_ms = (double)ms;
+    return 0;
+}
+
+// --------------------------------------------------------------------------
+int pyrohip_state_create(pyrohip_ctx *c, int nx, int ny, int ng, int nvar, const int *bc,
+                         pyrohip_state **out)
+{
+    PYRO_REQUIRE(c && out && bc, "NULL argument");
+    PYRO_REQUIRE(nx > 0 && ny > 0 && ng >= 1 && ng <= 8 && nvar >= 1, "bad dimensions");
+    PYRO_REQUIRE(nx >= ng && ny >= ng, "grid smaller than the ghost width");
+    for (int k = 0; k < nvar * 4; k++)
+        PYRO_REQUIRE(bc[k] >= 0 && bc[k] <= PYROHIP_BC_HALO, "bad BC code");
+    PYRO_CHECK_HIP(hipSetDevice(c->device));
+    pyrohip_state *s = new pyrohip_state();
+    s->ctx = c;
+    s->g = make_geom(nx, ny, ng);
+    s->nvar = nvar;
+    s->bc.assign(bc, bc + nvar * 4);
+    size_t n = s->g.plane * nvar + 16;
+    PYRO_CHECK_HIP(hipMalloc((void **)&s->base, n * sizeof(double)));
+    PYRO_CHECK_HIP(hipMemsetAsync(s->base, 0, n * sizeof(double), c->stream));
+    s->d = s->base + geom_lead(s->g);
+    PYRO_CHECK_HIP(hipMalloc((void **)&s->d_bc, sizeof(int) * nvar * 4));
+    PYRO_CHECK_HIP(hipMemcpy(s->d_bc, bc, sizeof(int) * nvar * 4, hipMemcpyHostToDevice));
+    PYRO_CHECK_HIP(hipMalloc((void **)&s->d_flag, sizeof(int) * 4));
+    PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int) * 4, c->stream));
+    *out = s;
+    return 0;
+}
+
+int pyrohip_state_destroy(pyrohip_state *s)
+{
+    if (!s) return 0;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->base) (void)hipFree(s->base);
+    if (s->d_bc) (void)hipFree(s->d_bc);
+    if (s->d_flag) (void)hipFree(s->d_flag);
+    if (s->work) (void)hipFree(s->work);
+    delete s;
+    return 0;
+}
+
+static const size_t kStageBytes = (size_t)256 << 20;
+
+static int rows_per_chunk(const pyrohip_state *s)
+{
+    size_t row = (size_t)s->g.qy * s->nvar * sizeof(double);
+    size_t r = kStageBytes / row;
+    if (r < 1) r = 1;
+    return (int)r;
+}
+
+int pyrohip_state_upload_rows(pyrohip_state *s, int i0, int ni, const double *host)
+{
+    PYRO_REQUIRE(s && host, "NULL argument");
+    PYRO_REQUIRE(i0 >= 0 && ni >= 0 && i0 + ni <= s->g.qx, "row range out of bounds");
+    pyrohip_ctx *c = s->ctx;
+    PYRO_CHECK_HIP(hipSetDevice(c->device));
+    const Geom &g = s->g;
+    const int chunk = rows_per_chunk(s);
+    const size_t row = (size_t)g.qy * s->nvar;
+    for (int r0 = 0; r0 < ni; r0 += chunk) {
+        int nr = (ni - r0 < chunk) ? ni - r0 : chunk;
+        PYRO_TRY(c->staging.ensure(nr * row * sizeof(double)));
+        PYRO_CHECK_HIP(hipMemcpyAsync(c->staging.p, host + (size_t)r0 * row,
+                                      nr * row * sizeof(double), hipMemcpyHostToDevice,
+                                      c->stream));
+        dim3 grid((g.qy + 255) / 256, nr), block(256);
+        hipLaunchKernelGGL(k_aos_to_planar, grid, block, 0, c->stream,
+                           (const double *)c->staging.p, s->d, i0 + r0, nr, g.qy, s->nvar,
+                           g.pitch, g.plane);
+        PYRO_CHECK_HIP(hipGetLastError());
+        PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    }
+    s->next_cfl_min = -1.0;
+    return 0;
+}
+
+int pyrohip_state_download_rows(pyrohip_state *s, int i0, int ni, double *host)
+{
+    PYRO_REQUIRE(s && host, "NULL argument");
+    PYRO_REQUIRE(i0 >= 0 && ni >= 0 && i0 + ni <= s->g.qx, "row range out of bounds");
+    pyrohip_ctx *c = s->ctx;
+    PYRO_CHECK_HIP(hipSetDevice(c->device));
+    const Geom &g = s->g;
+    const int chunk = rows_per_chunk(s);
+    const size_t row = (size_t)g.qy * s->nvar;
+    for (int r0 = 0; r0 < ni; r0 += chunk) {
+        int nr = (ni - r0 < chunk) ? ni - r0 : chunk;
+        PYRO_TRY(c->staging.ensure(nr * row * sizeof(double)));
+        dim3 grid((g.qy + 255) / 256, nr), block(256);
+        hipLaunchKernelGGL(k_planar_to_aos, grid, block, 0, c->stream, (const double *)s->d,
+                           (double *)c->staging.p, i0 + r0, nr, g.qy, s->nvar, g.pitch,
+                           g.plane);
+        PYRO_CHECK_HIP(hipGetLastError());
+        PYRO_CHECK_HIP(hipMemcpyAsync(host + (size_t)r0 * row, c->staging.p,
+                                      nr * row * sizeof(double), hipMemcpyDeviceToHost,
+                                      c->stream));
+        PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int pyrohip_state_upload(pyrohip_state *s, const double *host)
+{
+    PYRO_REQUIRE(s, "NULL state");
+    return pyrohip_state_upload_rows(s, 0, s->g.qx, host);
+}
+
+int pyrohip_state_download(pyrohip_state *s, double *host)
+{
+    PYRO_REQUIRE(s, "NULL state");
+    return pyrohip_state_download_rows(s, 0, s->g.qx, host);
+}
+
+int pyrohip_state_upload_var(pyrohip_state *s, int n, const double *host)
+{
+    PYRO_REQUIRE(s && host, "NULL argument");
+    PYRO_REQUIRE(n >= 0 && n < s->nvar, "variable index out of range");
+    pyrohip_ctx *c = s->ctx;
+    PYRO_CHECK_HIP(hipSetDevice(c->device));
+    const Geom &g = s->g;
+    PYRO_CHECK_HIP(hipMemcpy2DAsync(s->d + (size_t)n * g.plane, g.pitch * sizeof(double), host,
+                                    g.qy * sizeof(double), g.qy * sizeof(double), g.qx,
+                                    hipMemcpyHostToDevice, c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    s->next_cfl_min = -1.0;
+    return 0;
+}
+
+int pyrohip_state_download_var(pyrohip_state *s, int n, double *host)
+{
+    PYRO_REQUIRE(s && host, "NULL argument");
+    PYRO_REQUIRE(n >= 0 && n < s->nvar, "variable index out of range");
+    pyrohip_ctx *c = s->ctx;
+    PYRO_CHECK_HIP(hipSetDevice(c->device));
+    const Geom &g = s->g;
+    PYRO_CHECK_HIP(hipMemcpy2DAsync(host, g.qy * sizeof(double), s->d + (size_t)n * g.plane,
+                                    g.pitch * sizeof(double), g.qy * sizeof(double), g.qx,
+                                    hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pyrohip_fill_bc(pyrohip_state *s, int n)
+{
+    PYRO_REQUIRE(s, "NULL state");
+    PYRO_REQUIRE(n >= -1 && n < s->nvar, "variable index out of range");
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    int n0 = (n < 0) ? 0 : n, cnt = (n < 0) ? s->nvar : 1;
+    {
+        dim3 grid((g.qy + 255) / 256, 1, cnt), block(256);
+        hipLaunchKernelGGL(k_fill_x, grid, block, 0, c->stream, s->d, g, (const int *)s->d_bc, n0);
+    }
+    {
+        dim3 block(16, 16);
+        dim3 grid((g.qx + 15) / 16, 1, cnt);
+        hipLaunchKernelGGL(k_fill_y, grid, block, 0, c->stream, s->d, g, (const int *)s->d_bc, n0);
+    }
+    PYRO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int pyrohip_state_minmax(pyrohip_state *s, int n, int buf, double *vmin, double *vmax)
+{
+    PYRO_REQUIRE(s, "NULL state");
+    PYRO_REQUIRE(n >= 0 && n < s->nvar, "variable index out of range");
+    PYRO_REQUIRE(buf >= 0 && buf <= s->g.ng, "buf out of range");
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    dim3 grid(8, 64), block(256);
+    int nb = grid.x * grid.y;
+    PYRO_TRY(c->reduce.ensure((2 * nb + 2) * sizeof(double)));
+    double *part = (double *)c->reduce.p;
+    hipLaunchKernelGGL(k_minmax, grid, block, 0, c->stream,
+                       (const double *)(s->d + (size_t)n * g.plane), g.pitch, g.ilo - buf,
+                       g.ihi + buf, g.jlo - buf, g.jhi + buf, part);
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, c->stream, (const double *)part, nb,
+                       part + 2 * nb);
+    PYRO_CHECK_HIP(hipGetLastError());
+    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, part + 2 * nb, 2 * sizeof(double),
+                                  hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (vmin) *vmin = ((double *)c->reduce_host)[0];
+    if (vmax) *vmax = ((double *)c->reduce_host)[1];
+    return 0;
+}
+
+}  // extern "C"

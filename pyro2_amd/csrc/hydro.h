@@ -1,0 +1,270 @@
+// Per-cell / per-face Euler arithmetic for the compressible CTU update.
+// Written once, used by the staged kernels and by the fused LDS kernels.
+// Operation order follows the reference expression by expression (cited
+// below) so that the -ffp-contract=off build is bit-identical to it.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "stencil.h"
+
+namespace pyro {
+
+struct Cons { double d, E, mx, my; };   // density, energy, x-mom, y-mom
+struct Prim { double r, u, v, p; };     // rho, u, v, p
+
+// compressible/simulation.py:49-80 (cons_to_prim) + eos.py:26
+// `ok` is cleared when e <= 0 or rho <= 0 (the reference's interior assert)
+__device__ __forceinline__ Prim cons_to_prim(const Cons &U, double gamma, bool *ok = nullptr)
+{
+    Prim q;
+    q.r = U.d;
+    double u = 0.0, v = 0.0, e = 0.0;
+    if (U.d != 0.0) {
+        u = U.mx / U.d;
+        v = U.my / U.d;
+        e = (U.E - 0.5 * U.d * (u * u + v * v)) / U.d;
+    }
+    q.u = u;
+    q.v = v;
+    q.p = U.d * e * (gamma - 1.0);
+    if (ok) *ok = (e > 0.0) && (U.d > 0.0);
+    return q;
+}
+
+// compressible/simulation.py:83-102 (prim_to_cons) + eos.py:72
+__device__ __forceinline__ Cons prim_to_cons(const Prim &q, double gamma)
+{
+    Cons U;
+    U.d = q.r;
+    U.mx = q.u * U.d;
+    U.my = q.v * U.d;
+    double rhoe = q.p / (gamma - 1.0);
+    U.E = rhoe + 0.5 * q.r * (q.u * q.u + q.v * q.v);
+    return U;
+}
+
+// CFL quantities, compressible/derives.py:19-25,59 + simulation.py:284-288
+// returns min(dx/(|u|+c), dy/(|v|+c)) for one cell
+__device__ __forceinline__ double cfl_cell(const Cons &U, double gamma, double dx, double dy)
+{
+    double u = U.mx / U.d;
+    double v = U.my / U.d;
+    double e = (U.E - 0.5 * U.d * (u * u + v * v)) / U.d;
+    double p = U.d * e * (gamma - 1.0);
+    double cs = sqrt(gamma * p / U.d);
+    double xt = dx / (fabs(u) + cs);
+    double yt = dy / (fabs(v) + cs);
+    return fmin(xt, yt);
+}
+
+// 1-d flattening coefficient, pyro/mesh/reconstruction.py:123-164
+//   pm2..pp2 : pressure at -2..+2,  um1/up1 : normal velocity at -1/+1
+__device__ __forceinline__ double flatten_1d(double pm2, double pm1, double pp1, double pp2,
+                                             double um1, double up1, double z0, double z1,
+                                             double delta)
+{
+    const double smallp = 1.e-10;
+    double t1 = fabs(pp1 - pm1);
+    double t2 = fabs(pp2 - pm2);
+    double z = t1 / fmax(t2, smallp);
+    double t2b = t1 / fmin(pp1, pm1);
+    double t1b = um1 - up1;
+    double xi = fmin(1.0, fmax(0.0, 1.0 - (z - z0) / (z1 - z0)));
+    return (t1b > 0.0 && t2b > delta) ? xi : 1.0;
+}
+
+// Characteristic tracing of one cell in one direction,
+// compressible/interface.py:5-236.  `un`/`ut` are the normal / transverse
+// velocity (u,v for idir=1; v,u for idir=2); d* the limited slopes.
+// Outputs primitive states on the cell's lower face (q_r[face-]) and upper
+// face (q_l[face+]) with the same (rho, un, ut, p) convention.
+struct Trace { double r, un, ut, p; };
+
+__device__ __forceinline__ void trace_states(double r, double un, double ut, double p,
+                                             double dr, double dun, double dut, double dp,
+                                             double gamma, double dtdx, Trace &lo, Trace &hi)
+{
+    const double dtdx4 = 0.25 * dtdx;                // interface.py:107
+    const double cs = sqrt(gamma * p / r);           // :122
+    const double e0 = un - cs, e1 = un, e3 = un + cs;  // :129 / :151  (e2 == e1)
+
+    // reference states, :174-191
+    double fl = 0.5 * (1.0 - dtdx * fmax(e3, 0.0));
+    double fr = 0.5 * (1.0 + dtdx * fmin(e0, 0.0));
+    hi.r = r + fl * dr;   hi.un = un + fl * dun;
+    hi.ut = ut + fl * dut; hi.p = p + fl * dp;
+    lo.r = r - fr * dr;   lo.un = un - fr * dun;
+    lo.ut = ut - fr * dut; lo.p = p - fr * dp;
+
+    // l_m . dq as 4-term in-order sums with the zero entries dropped
+    // (adding 0*x terms never changes a finite sum), :131-139 / :153-161
+    const double a0 = (-0.5 * r / cs) * dun + (0.5 / (cs * cs)) * dp;
+    const double a1 = dr + (-1.0 / (cs * cs)) * dp;
+    const double a2 = dut;
+    const double a3 = (0.5 * r / cs) * dun + (0.5 / (cs * cs)) * dp;
+
+    // :193-201
+    const double s0 = copysign(1.0, e0), s1 = copysign(1.0, e1), s3 = copysign(1.0, e3);
+    const double bl0 = dtdx4 * (e3 - e0) * (s0 + 1.0) * a0;
+    const double bl1 = dtdx4 * (e3 - e1) * (s1 + 1.0) * a1;
+    const double bl2 = dtdx4 * (e3 - e1) * (s1 + 1.0) * a2;
+    const double bl3 = dtdx4 * (e3 - e3) * (s3 + 1.0) * a3;
+    const double br0 = dtdx4 * (e0 - e0) * (1.0 - s0) * a0;
+    const double br1 = dtdx4 * (e0 - e1) * (1.0 - s1) * a1;
+    const double br2 = dtdx4 * (e0 - e1) * (1.0 - s1) * a2;
+    const double br3 = dtdx4 * (e0 - e3) * (1.0 - s3) * a3;
+
+    // sum_m beta_m r_m, in index order with the structural zeros kept where
+    // they sit between non-zero terms, :203-213; r_m from :141-144 / :163-166
+    const double cr = cs / r, c2 = cs * cs;
+    hi.r = hi.r + ((bl0 + bl1) + bl3);
+    hi.un = hi.un + (bl0 * (-cr) + bl3 * cr);
+    hi.ut = hi.ut + bl2;
+    hi.p = hi.p + (bl0 * c2 + bl3 * c2);
+    lo.r = lo.r + ((br0 + br1) + br3);
+    lo.un = lo.un + (br0 * (-cr) + br3 * cr);
+    lo.ut = lo.ut + br2;
+    lo.p = lo.p + (br0 * c2 + br3 * c2);
+}
+
+// Wave-speed estimate, compressible/riemann.py:596-678 (quirk: S_r uses
+// (gamma+1)/(2/gamma), :675)
+__device__ __forceinline__ void estimate_wave_speed(double rho_l, double u_l, double p_l,
+                                                    double c_l, double rho_r, double u_r,
+                                                    double p_r, double c_r, double gamma,
+                                                    double &S_l, double &S_r)
+{
+    double p_max = fmax(p_l, p_r);
+    double p_min = fmin(p_l, p_r);
+    double Q = p_max / p_min;
+    double rho_avg = 0.5 * (rho_l + rho_r);
+    double c_avg = 0.5 * (c_l + c_r);
+    double factor = rho_avg * c_avg;
+    double pstar = 0.5 * (p_l + p_r) + 0.5 * (u_l - u_r) * factor;
+    if (Q > 2 && (pstar < p_min || pstar > p_max)) {
+        if (pstar < p_min) {   // two-rarefaction, :626-638
+            double z = (gamma - 1.0) / (2.0 * gamma);
+            double p_lr = pow(p_l / p_r, z);
+            double ustar = (p_lr * u_l / c_l + u_r / c_r + 2.0 * (p_lr - 1.0) / (gamma - 1.0)) /
+                           (p_lr / c_l + 1.0 / c_r);
+            pstar = 0.5 * (p_l * pow(1.0 + (gamma - 1.0) * (u_l - ustar) / (2.0 * c_l), 1.0 / z) +
+                           p_r * pow(1.0 + (gamma - 1.0) * (ustar - u_r) / (2.0 * c_r), 1.0 / z));
+        } else {               // two-shock, :640-658
+            double A_r = 2.0 / ((gamma + 1.0) * rho_r);
+            double B_r = p_r * (gamma - 1.0) / (gamma + 1.0);
+            double A_l = 2.0 / ((gamma + 1.0) * rho_l);
+            double B_l = p_l * (gamma - 1.0) / (gamma + 1.0);
+            double p_guess = fmax(0.0, pstar);
+            double g_l = sqrt(A_l / (p_guess + B_l));
+            double g_r = sqrt(A_r / (p_guess + B_r));
+            pstar = (g_l * p_l + g_r * p_r - (u_r - u_l)) / (g_l + g_r);
+        }
+    }
+    if (pstar <= p_l)
+        S_l = u_l - c_l;
+    else
+        S_l = u_l - c_l * sqrt(1.0 + ((gamma + 1.0) / (2.0 * gamma)) * (pstar / p_l - 1.0));
+    if (pstar <= p_r)
+        S_r = u_r + c_r;
+    else
+        S_r = u_r + c_r * sqrt(1.0 + ((gamma + 1.0) / (2.0 / gamma)) * (pstar / p_r - 1.0));
+}
+
+// consFlux in the (normal, transverse) frame, riemann.py:1104-1179.
+// State and flux components: d, E, mn (normal momentum), mt (transverse).
+struct ConsN { double d, E, mn, mt; };
+
+__device__ __forceinline__ ConsN cons_flux_n(const ConsN &U, double gamma, bool normal_is_x)
+{
+    // u, v in the reference are x/y velocities; (u*u + v*v) is evaluated as
+    // written there, i.e. x-velocity squared first
+    double un = 0.0, ut = 0.0;
+    if (U.d != 0.0) {
+        un = U.mn / U.d;
+        ut = U.mt / U.d;
+    }
+    double ke = normal_is_x ? (un * un + ut * ut) : (ut * ut + un * un);
+    double p = (U.E - 0.5 * U.d * ke) * (gamma - 1.0);
+    ConsN F;
+    F.d = U.d * un;
+    F.mn = U.mn * un;
+    F.mn += p;
+    F.mt = U.mt * un;
+    F.E = (U.E + p) * un;
+    return F;
+}
+
+// HLLC flux for one face, riemann.py:681-860, in the (normal, transverse)
+// frame.  normal_is_x only fixes the order of the two squares in the kinetic
+// energy of consFlux.
+__device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, double gamma,
+                                           bool normal_is_x)
+{
+    const double smallc = 1.e-10, smallp = 1.e-10;
+    double rho_l = Ul.d;
+    double un_l = Ul.mn / rho_l;
+    double ut_l = Ul.mt / rho_l;
+    double rhoe_l = Ul.E - 0.5 * rho_l * (un_l * un_l + ut_l * ut_l);
+    double p_l = rhoe_l * (gamma - 1.0);
+    p_l = fmax(p_l, smallp);
+    double rho_r = Ur.d;
+    double un_r = Ur.mn / rho_r;
+    double ut_r = Ur.mt / rho_r;
+    double rhoe_r = Ur.E - 0.5 * rho_r * (un_r * un_r + ut_r * ut_r);
+    double p_r = rhoe_r * (gamma - 1.0);
+    p_r = fmax(p_r, smallp);
+    double c_l = fmax(smallc, sqrt(gamma * p_l / rho_l));
+    double c_r = fmax(smallc, sqrt(gamma * p_r / rho_r));
+    double S_l, S_r;
+    estimate_wave_speed(rho_l, un_l, p_l, c_l, rho_r, un_r, p_r, c_r, gamma, S_l, S_r);
+    double S_c = (p_r - p_l + rho_l * un_l * (S_l - un_l) - rho_r * un_r * (S_r - un_r)) /
+                 (rho_l * (S_l - un_l) - rho_r * (S_r - un_r));
+    ConsN F;
+    if (S_r <= 0.0) {
+        F = cons_flux_n(Ur, gamma, normal_is_x);
+    } else if (S_c <= 0.0 && 0.0 < S_r) {
+        double f = rho_r * (S_r - un_r) / (S_r - S_c);
+        ConsN Us;
+        Us.d = f;
+        Us.mn = f * S_c;
+        Us.mt = f * ut_r;
+        Us.E = f * (Ur.E / rho_r + (S_c - un_r) * (S_c + p_r / (rho_r * (S_r - un_r))));
+        F = cons_flux_n(Ur, gamma, normal_is_x);
+        F.d = F.d + S_r * (Us.d - Ur.d);
+        F.mn = F.mn + S_r * (Us.mn - Ur.mn);
+        F.mt = F.mt + S_r * (Us.mt - Ur.mt);
+        F.E = F.E + S_r * (Us.E - Ur.E);
+    } else if (S_l < 0.0 && 0.0 < S_c) {
+        double f = rho_l * (S_l - un_l) / (S_l - S_c);
+        ConsN Us;
+        Us.d = f;
+        Us.mn = f * S_c;
+        Us.mt = f * ut_l;
+        Us.E = f * (Ul.E / rho_l + (S_c - un_l) * (S_c + p_l / (rho_l * (S_l - un_l))));
+        F = cons_flux_n(Ul, gamma, normal_is_x);
+        F.d = F.d + S_l * (Us.d - Ul.d);
+        F.mn = F.mn + S_l * (Us.mn - Ul.mn);
+        F.mt = F.mt + S_l * (Us.mt - Ul.mt);
+        F.E = F.E + S_l * (Us.E - Ul.E);
+    } else {
+        F = cons_flux_n(Ul, gamma, normal_is_x);
+    }
+    return F;
+}
+
+// vertex-centred velocity divergence at (i-1/2, j-1/2),
+// compressible/interface.py:312-330 (Cartesian branch)
+__device__ __forceinline__ double div_u_vertex(double u_ij, double u_ijm, double u_imj,
+                                               double u_imjm, double v_ij, double v_imj,
+                                               double v_ijm, double v_imjm, double dx, double dy)
+{
+    double ur = 0.5 * (u_ij + u_ijm);
+    double ul = 0.5 * (u_imj + u_imjm);
+    double vt = 0.5 * (v_ij + v_imj);
+    double vb = 0.5 * (v_ijm + v_imjm);
+    double ux = (ur - ul) / dx;
+    double vy = (vt - vb) / dy;
+    return ux + vy;
+}
+
+}  // namespace pyro

@@ -1,0 +1,54 @@
+// Block reductions for CDNA4: wave64 shuffle tree, then one LDS slot per wave.
+// min/max are order independent, so the results are bit-exact vs NumPy.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pyro {
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+__device__ inline double wave_reduce_min(double v)
+{
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, kWave));
+    return v;
+}
+__device__ inline double wave_reduce_max(double v)
+{
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, kWave));
+    return v;
+}
+__device__ inline double wave_reduce_sum(double v)
+{
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+// All threads of the block must call.  Result valid in thread 0.
+// blockDim (flattened) must be a multiple of 64 and <= 1024.
+template <int OP>  // 0 min, 1 max, 2 sum
+__device__ inline double block_reduce(double v)
+{
+    __shared__ double slot[16];
+    const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    const int nthr = blockDim.x * blockDim.y * blockDim.z;
+    const int lane = tid & (kWave - 1), wave = tid >> 6;
+    v = (OP == 0) ? wave_reduce_min(v) : (OP == 1) ? wave_reduce_max(v) : wave_reduce_sum(v);
+    __syncthreads();  // protect slot[] against a previous call
+    if (lane == 0) slot[wave] = v;
+    __syncthreads();
+    if (wave == 0) {
+        const int nw = nthr >> 6;
+        double w = (lane < nw) ? slot[lane] : (OP == 0 ? INFINITY : OP == 1 ? -INFINITY : 0.0);
+        w = (OP == 0) ? wave_reduce_min(w) : (OP == 1) ? wave_reduce_max(w) : wave_reduce_sum(w);
+        v = w;
+    }
+    return v;
+}
+__device__ inline double block_reduce_min(double v) { return block_reduce<0>(v); }
+__device__ inline double block_reduce_max(double v) { return block_reduce<1>(v); }
+__device__ inline double block_reduce_sum(double v) { return block_reduce<2>(v); }
+
+}  // namespace pyro

@@ -1,0 +1,53 @@
+// Per-cell stencil arithmetic shared by the advection and compressible
+// kernels.  Every expression keeps the reference's operation order so that,
+// compiled with -ffp-contract=off, results are bit-identical to NumPy/numba
+// (SURVEY.md 8(a) "arithmetic-order rules").
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pyro {
+
+// MC limiter building block, pyro/mesh/reconstruction.py:84-91 / 113-120
+__device__ __forceinline__ double mc_select(double dc, double dl, double dr)
+{
+    double d1 = 2.0 * ((fabs(dl) < fabs(dr)) ? dl : dr);
+    double dt = (fabs(dc) < fabs(d1)) ? dc : d1;
+    return (dl * dr > 0.0) ? dt : 0.0;
+}
+
+// limit2 (reconstruction.py:69-91) at the centre of (am, a0, ap)
+__device__ __forceinline__ double limit2(double am, double a0, double ap)
+{
+    double dc = 0.5 * (ap - am);
+    double dl = ap - a0;
+    double dr = a0 - am;
+    return mc_select(dc, dl, dr);
+}
+
+// limited slope at the centre of the 5-point stencil (reconstruction.py:9-120)
+//   limiter 0: nolimit, 1: limit2, otherwise limit4
+__device__ __forceinline__ double limited_slope(double am2, double am1, double a0, double ap1,
+                                                double ap2, int limiter)
+{
+    if (limiter == 0) return 0.5 * (ap1 - am1);
+    if (limiter == 1) return limit2(am1, a0, ap1);
+    double l2p = limit2(a0, ap1, ap2);
+    double l2m = limit2(am2, am1, a0);
+    double dc = (2. / 3.) * (ap1 - am1 - 0.25 * (l2p + l2m));
+    double dl = ap1 - a0;
+    double dr = a0 - am1;
+    return mc_select(dc, dl, dr);
+}
+
+// blockIdx -> logical tile id such that each XCD (blocks are dealt round-robin
+// to the 8 XCDs, MI355X_MICROARCH.md "block b runs on XCD b % 8") works on a
+// contiguous band of tiles and halo re-reads hit its own L2.  Performance
+// only: any mapping is correct.
+__device__ __forceinline__ int xcd_tile(int b, int nb)
+{
+    const int nxcd = 8;
+    if (nb % nxcd != 0) return b;
+    return (b % nxcd) * (nb / nxcd) + b / nxcd;
+}
+
+}  // namespace pyro

@@ -1,0 +1,318 @@
+"""Thin object layer over the C ABI (include/pyrohip.h): handles + NumPy I/O.
+
+These classes own opaque library handles; all arithmetic happens in the HIP
+kernels.  The pyro-facing API (Grid2d / CellCenterData2d / Simulation /
+CellCenterMG2d mirrors) is built on top of them in pyro2_amd.mesh,
+pyro2_amd.advection, pyro2_amd.compressible and pyro2_amd.multigrid.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import BC_CODE, CompParams, check, dptr, iptr
+
+
+class Context:
+    """One HIP device + stream.  Calls are serialised with a lock because
+    ctypes releases the GIL (include/pyrohip.h conventions)."""
+
+    _default = None
+
+    def __init__(self, device_id=0):
+        self._l = _lib.lib()
+        self.h = C.c_void_p()
+        check(self._l.pyrohip_init(int(device_id), C.byref(self.h)))
+        self.device_id = int(device_id)
+        self.lock = threading.RLock()
+
+    @classmethod
+    def default(cls, device_id=None):
+        import os
+        if cls._default is None:
+            if device_id is None:
+                device_id = int(os.environ.get("PYRO2_AMD_DEVICE",
+                                               os.environ.get("LOCAL_RANK", "0")))
+            cls._default = cls(device_id)
+        return cls._default
+
+    def close(self):
+        if self.h:
+            self._l.pyrohip_shutdown(self.h)
+            self.h = C.c_void_p()
+            if Context._default is self:
+                Context._default = None
+
+    def sync(self):
+        with self.lock:
+            check(self._l.pyrohip_sync(self.h))
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        fr, tot, cus = C.c_size_t(), C.c_size_t(), C.c_int()
+        with self.lock:
+            check(self._l.pyrohip_device_info(self.h, name, 256, C.byref(fr),
+                                              C.byref(tot), C.byref(cus)))
+        return {"name": name.value.decode(), "free": fr.value,
+                "total": tot.value, "compute_units": cus.value,
+                "backend": _lib.backend_name()}
+
+    def timer_start(self):
+        with self.lock:
+            check(self._l.pyrohip_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_double()
+        with self.lock:
+            check(self._l.pyrohip_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    # ---- multi-GPU plumbing (RCCL) ------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        check(_lib.lib().pyrohip_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id):
+        with self.lock:
+            check(self._l.pyrohip_comm_init(self.h, nranks, rank, unique_id))
+
+    def allreduce_min(self, x):
+        v = C.c_double(x)
+        with self.lock:
+            check(self._l.pyrohip_allreduce_min(self.h, C.byref(v)))
+        return v.value
+
+    def allreduce_max(self, x):
+        v = C.c_double(x)
+        with self.lock:
+            check(self._l.pyrohip_allreduce_max(self.h, C.byref(v)))
+        return v.value
+
+
+def bc_table(bcs_per_var):
+    """[[xl,xr,yl,yr] per variable] of names or codes -> int32 (nvar,4)"""
+    out = np.zeros((len(bcs_per_var), 4), dtype=np.int32)
+    for n, row in enumerate(bcs_per_var):
+        for s, b in enumerate(row):
+            out[n, s] = BC_CODE[b] if isinstance(b, str) else int(b)
+    return out
+
+
+class DeviceState:
+    """planar SoA copy of a CellCenterData2d.data array on the device"""
+
+    def __init__(self, ctx, nx, ny, ng, bcs_per_var):
+        self.ctx = ctx
+        self._l = ctx._l
+        self.nx, self.ny, self.ng = int(nx), int(ny), int(ng)
+        self.qx, self.qy = self.nx + 2 * self.ng, self.ny + 2 * self.ng
+        self.bc = np.ascontiguousarray(bc_table(bcs_per_var))
+        self.nvar = self.bc.shape[0]
+        self.h = C.c_void_p()
+        with ctx.lock:
+            check(self._l.pyrohip_state_create(ctx.h, self.nx, self.ny, self.ng,
+                                               self.nvar, iptr(self.bc.reshape(-1)),
+                                               C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self._l.pyrohip_state_destroy(self.h)
+        except Exception:
+            pass
+
+    def _aos(self, a, rows=None):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        want = (self.qx if rows is None else rows, self.qy, self.nvar)
+        if self.nvar == 1 and a.ndim == 2:
+            a = a.reshape(a.shape + (1,))
+        assert a.shape == want, (a.shape, want)
+        return a
+
+    def upload(self, data):
+        a = self._aos(data)
+        with self.ctx.lock:
+            check(self._l.pyrohip_state_upload(self.h, dptr(a)))
+
+    def download(self, out=None):
+        if out is None:
+            out = np.empty((self.qx, self.qy, self.nvar))
+        a = out if out.ndim == 3 else out.reshape(out.shape + (1,))
+        with self.ctx.lock:
+            check(self._l.pyrohip_state_download(self.h, dptr(a)))
+        return out
+
+    def upload_rows(self, i0, data):
+        a = self._aos(data, rows=data.shape[0])
+        with self.ctx.lock:
+            check(self._l.pyrohip_state_upload_rows(self.h, int(i0), a.shape[0], dptr(a)))
+
+    def download_rows(self, i0, ni):
+        out = np.empty((ni, self.qy, self.nvar))
+        with self.ctx.lock:
+            check(self._l.pyrohip_state_download_rows(self.h, int(i0), int(ni), dptr(out)))
+        return out
+
+    def upload_var(self, n, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.shape == (self.qx, self.qy)
+        with self.ctx.lock:
+            check(self._l.pyrohip_state_upload_var(self.h, int(n), dptr(a)))
+
+    def download_var(self, n):
+        out = np.empty((self.qx, self.qy))
+        with self.ctx.lock:
+            check(self._l.pyrohip_state_download_var(self.h, int(n), dptr(out)))
+        return out
+
+    def fill_bc(self, n=-1):
+        with self.ctx.lock:
+            check(self._l.pyrohip_fill_bc(self.h, int(n)))
+
+    def minmax(self, n, buf=0):
+        mn, mx = C.c_double(), C.c_double()
+        with self.ctx.lock:
+            check(self._l.pyrohip_state_minmax(self.h, int(n), int(buf),
+                                               C.byref(mn), C.byref(mx)))
+        return mn.value, mx.value
+
+    # ---- solvers ------------------------------------------------------
+    def adv_step(self, n, dx, dy, u, v, dt, limiter):
+        with self.ctx.lock:
+            check(self._l.pyrohip_adv_step(self.h, int(n), dx, dy, u, v, dt, int(limiter)))
+
+    def comp_dt(self, params, cfl):
+        dt = C.c_double()
+        with self.ctx.lock:
+            check(self._l.pyrohip_comp_dt(self.h, C.byref(params), cfl, C.byref(dt)))
+        return dt.value
+
+    def comp_step(self, params, dt):
+        with self.ctx.lock:
+            check(self._l.pyrohip_comp_step(self.h, C.byref(params), dt))
+
+    STAGES = {"q": 0, "xi": 1, "XM": 2, "XP": 3, "YM": 4, "YP": 5, "FxT": 6,
+              "FyT": 7, "Fx": 8, "Fy": 9}
+
+    def comp_stage(self, name):
+        sid = self.STAGES[name]
+        ncomp = 1 if name == "xi" else 4
+        out = np.empty((self.qx, self.qy, ncomp))
+        with self.ctx.lock:
+            check(self._l.pyrohip_comp_stage_dump(self.h, sid, dptr(out)))
+        return out[:, :, 0] if ncomp == 1 else out
+
+    def halo_exchange(self, rank_lo, rank_hi):
+        with self.ctx.lock:
+            check(self._l.pyrohip_halo_exchange(self.h, int(rank_lo), int(rank_hi)))
+
+
+def make_comp_params(dx, dy, gamma=1.4, limiter=2, use_flattening=1, z0=0.75,
+                     z1=0.85, delta=0.33, cvisc=0.1, grav=0.0,
+                     small_dens=-1.e200, avisc_xhi_interior=0,
+                     avisc_yhi_interior=0, fast_math=0, kernel_set=0):
+    p = CompParams()
+    p.dx, p.dy, p.gamma = dx, dy, gamma
+    p.limiter, p.use_flattening = int(limiter), int(use_flattening)
+    p.z0, p.z1, p.delta, p.cvisc = z0, z1, delta, cvisc
+    p.grav, p.small_dens = grav, small_dens
+    p.avisc_xhi_interior = int(avisc_xhi_interior)
+    p.avisc_yhi_interior = int(avisc_yhi_interior)
+    p.fast_math, p.kernel_set = int(fast_math), int(kernel_set)
+    return p
+
+
+class DeviceMG:
+    """device-resident level hierarchy of MG.CellCenterMG2d"""
+
+    def __init__(self, ctx, nx, xmin=0.0, xmax=1.0, ymin=0.0, ymax=1.0,
+                 bcs=("dirichlet",) * 4, alpha=0.0, beta=-1.0, nsmooth=10,
+                 nsmooth_bottom=50):
+        self.ctx = ctx
+        self._l = ctx._l
+        bc = np.array([BC_CODE[b] if isinstance(b, str) else int(b) for b in bcs],
+                      dtype=np.int32)
+        self.h = C.c_void_p()
+        with ctx.lock:
+            check(self._l.pyrohip_mg_create(ctx.h, int(nx), xmin, xmax, ymin, ymax,
+                                            iptr(bc), alpha, beta, int(nsmooth),
+                                            int(nsmooth_bottom), C.byref(self.h)))
+            nl = C.c_int()
+            check(self._l.pyrohip_mg_nlevels(self.h, C.byref(nl)))
+        self.nx = int(nx)
+        self.nlevels = nl.value
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self._l.pyrohip_mg_destroy(self.h)
+        except Exception:
+            pass
+
+    def _n(self, level):
+        return 2 ** (level + 1) + 2
+
+    def set(self, level, var, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.shape == (self._n(level),) * 2
+        with self.ctx.lock:
+            check(self._l.pyrohip_mg_set(self.h, level, var, dptr(a)))
+
+    def get(self, level, var):
+        out = np.empty((self._n(level),) * 2)
+        with self.ctx.lock:
+            check(self._l.pyrohip_mg_get(self.h, level, var, dptr(out)))
+        return out
+
+    def set_bcval(self, side, vals):
+        with self.ctx.lock:
+            if vals is None:
+                check(self._l.pyrohip_mg_set_bcval(self.h, side, None))
+            else:
+                v = np.ascontiguousarray(vals, dtype=np.float64)
+                assert v.shape == (self.nx + 2,)
+                check(self._l.pyrohip_mg_set_bcval(self.h, side, dptr(v)))
+
+    def _call(self, fn, *args):
+        with self.ctx.lock:
+            check(getattr(self._l, fn)(self.h, *args))
+
+    def zero(self, level, var):
+        self._call("pyrohip_mg_zero", level, var)
+
+    def fill_bc(self, level, var=0):
+        self._call("pyrohip_mg_fill_bc", level, var)
+
+    def smooth(self, level, n):
+        self._call("pyrohip_mg_smooth", level, n)
+
+    def residual(self, level):
+        self._call("pyrohip_mg_residual", level)
+
+    def restrict(self, fine):
+        self._call("pyrohip_mg_restrict", fine)
+
+    def prolong_add(self, fine):
+        self._call("pyrohip_mg_prolong_add", fine)
+
+    def vcycle(self, level=None):
+        self._call("pyrohip_mg_vcycle", self.nlevels - 1 if level is None else level)
+
+    def norm(self, level, var):
+        out = C.c_double()
+        self._call("pyrohip_mg_norm", level, var, C.byref(out))
+        return out.value
+
+    def init_rhs_norm(self):
+        out = C.c_double()
+        self._call("pyrohip_mg_init_rhs_norm", C.byref(out))
+        return out.value
+
+    def solve(self, rtol=1.e-11, max_cycles=100):
+        nc, res, rel = C.c_int(), C.c_double(), C.c_double()
+        self._call("pyrohip_mg_solve", rtol, int(max_cycles), C.byref(nc),
+                   C.byref(res), C.byref(rel))
+        return nc.value, res.value, rel.value

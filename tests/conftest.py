@@ -36,3 +36,43 @@ def max_rel_err(a, b):
     if scale == 0.0:
         return float(np.abs(a).max())
     return float(np.abs(a - b).max() / scale)
+
+
+# ---------------------------------------------------------------------------
+# device backends.  "hip" = the product library on a real MI355X (marked gpu);
+# "emu" = the same kernel sources compiled for the host by tests/emu (so the
+# GPU-less container can still execute them).  The emulated build is test
+# infrastructure and is injected explicitly here -- pyro2_amd never loads it
+# on its own.
+# ---------------------------------------------------------------------------
+_CTX = {}
+
+
+def _get_ctx(kind):
+    from pyro2_amd import _lib, device
+    if kind not in _CTX:
+        if kind == "emu":
+            sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+            import build_emu
+            _lib.use_library(build_emu.build(), allow_backends=("host-emu",))
+        else:
+            _lib.use_library(None)
+        _CTX[kind] = device.Context(0)
+    return _CTX[kind]
+
+
+@pytest.fixture(params=[pytest.param("emu"),
+                        pytest.param("hip", marks=pytest.mark.gpu)])
+def dev(request):
+    """a pyro2_amd.device.Context on the requested backend"""
+    ctx = _get_ctx(request.param)
+    ctx.kind = request.param
+    return ctx
+
+
+@pytest.fixture
+def hip():
+    """real-GPU context (use together with @pytest.mark.gpu)"""
+    ctx = _get_ctx("hip")
+    ctx.kind = "hip"
+    return ctx

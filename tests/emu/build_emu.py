@@ -1,0 +1,52 @@
+"""Build the host-emulated libpyrohip (TEST INFRASTRUCTURE ONLY).
+
+Compiles the *same* pyro2_amd/csrc/*.hip kernel sources with g++ against
+tests/emu/hip/hip_runtime.h into tests/_emu_build/libpyrohip_emu.so, so the
+GPU-less build container can execute the kernels (slowly) and compare them
+with the oracle before GPU time is spent.  The library identifies itself as
+backend "host-emu"; pyro2_amd._lib refuses it unless a test injects it.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(ROOT, "tests", "_emu_build")
+LIB = os.path.join(OUT, "libpyrohip_emu.so")
+
+sys.path.insert(0, ROOT)
+from pyro2_amd import build as hb  # noqa: E402
+
+
+def build(force=False):
+    os.makedirs(OUT, exist_ok=True)
+    deps = hb._deps() + [os.path.join(HERE, "hipemu.cpp"),
+                         os.path.join(HERE, "hip", "hip_runtime.h")]
+    if not force and not hb._stale(LIB, deps):
+        return LIB
+    flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off",
+             "-I" + HERE, "-DPYRO_EMU=1", '-DPYRO_BACKEND_NAME="host-emu"']
+    units = [u for u in hb.units() if u[1] not in ("comm",)]
+    if not any(u[1] == "comm_stub" for u in units):
+        units.append(("comm_stub.hip", "comm_stub", []))
+
+    def cc(u):
+        src, name, extra = u
+        defs = [f for f in extra if f.startswith("-D")]
+        obj = os.path.join(OUT, name + ".o")
+        subprocess.check_call(["g++"] + flags + defs + ["-x", "c++", "-c",
+                              os.path.join(hb.CSRC, src), "-o", obj])
+        return obj
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(cc, units))
+    rt = os.path.join(OUT, "hipemu.o")
+    subprocess.check_call(["g++"] + flags + ["-c", os.path.join(HERE, "hipemu.cpp"), "-o", rt])
+    subprocess.check_call(["g++", "-shared", "-o", LIB] + objs + [rt])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,176 @@
+"""HIP compressible (CTU + HLLC) step vs the reference's stage dumps, its
+golden files and the oracle.
+
+Tolerance: north_star asks 1e-10 rtol.  exact build (fast_math=0, no FMA
+contraction, reference operation order): bit-identical on the emulated
+backend, <= 1e-13 per step on the GPU (TOL_EXACT; the only expected source of
+difference is libm pow in the rare two-rarefaction branch).  fast build
+(fast_math=1): <= 1e-10 (TOL_FAST).
+"""
+import numpy as np
+import pytest
+
+from conftest import max_rel_err
+from helpers import DtPolicy, meta_to_params
+from oracle import orc
+from pyro2_amd import device
+
+TOL_EXACT = 1e-13
+TOL_FAST = 1e-10
+
+
+def dev_params(meta, **kw):
+    nx, ny, ng, dx, dy, gamma, lim, flat, z0, z1, delta, cvisc, grav, cfl = meta
+    return device.make_comp_params(dx, dy, gamma=gamma, limiter=int(lim),
+                                   use_flattening=int(flat), z0=z0, z1=z1,
+                                   delta=delta, cvisc=cvisc, grav=grav, **kw), cfl
+
+
+def comp_state(dev, nx, ny, bcs, ng=4):
+    vb = orc.comp_var_bcs(bcs)
+    return device.DeviceState(dev, nx, ny, ng, [list(r) for r in vb])
+
+
+def R(a, ng, lo, hi=None):
+    """valid region grown by (lo, hi)"""
+    hi = lo if hi is None else hi
+    return a[ng - lo:a.shape[0] - ng + hi, ng - lo:a.shape[1] - ng + hi]
+
+
+@pytest.mark.parametrize("k", range(7))
+def test_comp_stages_vs_reference(dev, golden, k):
+    """one step from a reference state; every device stage array is compared
+    with the array dumped from the reference's own functions on the cells /
+    faces inside the interior's domain of dependence"""
+    g = golden("comp_stages")
+    bcs = [str(b) for b in g[f"c{k}_bc"]]
+    meta = g[f"c{k}_meta"]
+    P, cfl = dev_params(meta)
+    nx, ny, ng = int(meta[0]), int(meta[1]), int(meta[2])
+    s = comp_state(dev, nx, ny, bcs)
+    U0 = g[f"c{k}_U0"]
+    s.upload(U0)
+    tol = 0.0 if dev.kind == "emu" else TOL_EXACT
+    dt_raw = s.comp_dt(P, cfl)
+    assert abs(dt_raw - float(g[f"c{k}_dt_method"])) <= tol * dt_raw
+    s.comp_step(P, float(g[f"c{k}_dt"]))
+
+    def chk(name, dev_arr, ref_arr):
+        e = max_rel_err(dev_arr, ref_arr)
+        assert e <= tol, (k, name, e)
+
+    chk("q", s.comp_stage("q"), g[f"c{k}_q"])
+    chk("xi", R(s.comp_stage("xi"), ng, 1), R(g[f"c{k}_xi"], ng, 1))
+    # cell-indexed face states: XM[i,j] = U_xr[i,j]; XP[i,j] = U_xl[i+1,j]
+    chk("XM", R(s.comp_stage("XM"), ng, 1), R(g[f"c{k}_Uxr0"], ng, 1))
+    chk("XP", R(s.comp_stage("XP"), ng, 1), g[f"c{k}_Uxl0"][ng:ng + nx + 2, ng - 1:ng + ny + 1])
+    chk("YM", R(s.comp_stage("YM"), ng, 1), R(g[f"c{k}_Uyr0"], ng, 1))
+    chk("YP", R(s.comp_stage("YP"), ng, 1), g[f"c{k}_Uyl0"][ng - 1:ng + nx + 1, ng:ng + ny + 2])
+    # transverse fluxes: x faces i in [ilo, ihi+1], j in [jlo-1, jhi+1]
+    chk("FxT", s.comp_stage("FxT")[ng:ng + nx + 1, ng - 1:ng + ny + 1],
+        g[f"c{k}_FxT"][ng:ng + nx + 1, ng - 1:ng + ny + 1])
+    chk("FyT", s.comp_stage("FyT")[ng - 1:ng + nx + 1, ng:ng + ny + 1],
+        g[f"c{k}_FyT"][ng - 1:ng + nx + 1, ng:ng + ny + 1])
+    # final fluxes incl. artificial viscosity on the faces of interior cells
+    chk("Fx", s.comp_stage("Fx")[ng:ng + nx + 1, ng:ng + ny],
+        g[f"c{k}_Fx"][ng:ng + nx + 1, ng:ng + ny])
+    chk("Fy", s.comp_stage("Fy")[ng:ng + nx, ng:ng + ny + 1],
+        g[f"c{k}_Fy"][ng:ng + nx, ng:ng + ny + 1])
+    U1 = s.download()
+    chk("U1", R(U1, ng, 0), R(g[f"c{k}_U1"], ng, 0))
+    # ghost cells untouched by the step (in-place semantics of the reference)
+    m = np.ones(U1.shape[:2], bool)
+    m[ng:-ng, ng:-ng] = False
+    assert np.array_equal(U1[m], g[f"c{k}_U1"][m])
+
+
+def device_comp_run(dev, ic, meta, bcs, tmax, max_steps, **kw):
+    """Pyro.run_sim loop (pyro_sim.py:219-256) with the device kernels"""
+    P, cfl = dev_params(meta, **kw)
+    nx, ny = int(meta[0]), int(meta[1])
+    s = comp_state(dev, nx, ny, bcs)
+    s.upload(ic)
+    pol = DtPolicy(tmax)
+    dts = []
+    while not (pol.t >= tmax or pol.n >= max_steps):
+        s.fill_bc()
+        dt = pol(s.comp_dt(P, cfl))
+        s.comp_step(P, dt)
+        pol.advance(dt)
+        dts.append(dt)
+    return s.download(), np.array(dts), pol.t
+
+
+def test_comp_sedov_64(dev, golden):
+    """sedov 64^2 (SURVEY 8(c) fingerprint): 20 steps on the GPU, 6 on emu"""
+    g = golden("comp_sedov_64_020")
+    bcs = [str(b) for b in g["bc"]]
+    nsteps = 20 if dev.kind == "hip" else 6
+    U, dts, t = device_comp_run(dev, g["ic"], g["meta"], bcs, 0.1, nsteps)
+    tol = 0.0 if dev.kind == "emu" else TOL_EXACT * nsteps
+    assert max_rel_err(dts, g["dts"][:nsteps]) <= tol
+    if nsteps == 20:
+        assert max_rel_err(U[4:-4, 4:-4], g["final"][4:-4, 4:-4]) <= 1e-12
+    else:
+        from helpers import oracle_comp_run
+        Uo, _, _ = oracle_comp_run(g["ic"], g["meta"], bcs, 0.1, nsteps)
+        assert max_rel_err(U[4:-4, 4:-4], Uo[4:-4, 4:-4]) <= tol
+
+
+def test_comp_positivity_error(dev, golden):
+    """negative internal energy -> PYROHIP_ERR_STATE, like the reference's
+    assert (compressible/simulation.py:68-71)"""
+    from pyro2_amd._lib import ERR_STATE, PyroHipError
+    g = golden("comp_sedov_64_020")
+    U = g["ic"].copy()
+    U[30, 30, 1] = -1.0
+    P, cfl = dev_params(g["meta"])
+    s = comp_state(dev, 64, 64, [str(b) for b in g["bc"]])
+    s.upload(U)
+    with pytest.raises(PyroHipError) as ei:
+        s.comp_step(P, 1e-6)
+    assert ei.value.code == ERR_STATE
+
+
+@pytest.mark.gpu
+def test_comp_reference_regression_sod_x(hip, golden):
+    """pyro/test.py:101 -- sod_x_0076.h5 (128x10, limiter 1, reflect y)"""
+    g = golden("comp_sod_x_0076")
+    bcs = [str(b) for b in g["bc"]]
+    U, dts, t = device_comp_run(hip, g["ic"], g["meta"], bcs, float(g["tmax"]), 200)
+    assert len(dts) == 76
+    for n in range(3):
+        assert max_rel_err(U[4:-4, 4:-4, n], g["gold"][..., n]) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fast", [0, 1])
+def test_comp_reference_regression_quad(hip, golden, fast):
+    """pyro/test.py:100 -- quad_unsplit_0606.h5 (256^2, 606 steps)"""
+    g = golden("comp_quad_0606")
+    bcs = [str(b) for b in g["bc"]]
+    U, dts, t = device_comp_run(hip, g["ic"], g["meta"], bcs, float(g["tmax"]), 1000,
+                                fast_math=fast)
+    assert len(dts) == 606
+    for n in range(4):
+        e = max_rel_err(U[4:-4, 4:-4, n], g["gold"][..., n])
+        assert e < (1e-11 if not fast else TOL_FAST), (n, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fast", [0, 1])
+def test_comp_sedov_512_vs_oracle(hip, fast):
+    """sedov at 512^2 (inputs.sedov physics), 30 steps, against the oracle on
+    identical inputs; 1e-10 is the north_star tolerance"""
+    from sedov_ic import sedov_ic
+    nx = 512
+    ic, meta, bcs = sedov_ic(nx)
+    from helpers import oracle_comp_run
+    Uo, dto, _ = oracle_comp_run(ic, meta, bcs, 0.1, 30)
+    U, dts, _ = device_comp_run(hip, ic, meta, bcs, 0.1, 30, fast_math=fast)
+    tol = TOL_FAST if fast else 1e-12
+    assert max_rel_err(dts, dto) <= tol
+    for n in range(4):
+        assert max_rel_err(U[4:-4, 4:-4, n], Uo[4:-4, 4:-4, n]) <= tol
+    # conservation of mass and energy away from the (outflow) boundary
+    assert abs(U[4:-4, 4:-4, 0].sum() - ic[4:-4, 4:-4, 0].sum()) < 1e-9 * nx * nx
