@@ -1,0 +1,316 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the pyro2 hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Headline workload (BASELINE.json metric "cell-updates/s ... at 1/2/4/8 GPUs",
+configs[4]): compressible Sedov, inputs.sedov physics, 16384 x 16384, x-slab
+decomposed over the N GPUs of one node (strong scaling), one process per GPU
+(torch.distributed.run launches us; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from
+the env), halo exchange + dt all-reduce over RCCL inside libpyrohip.
+
+A "step" is one full Pyro.single_step of the hot path: ghost fill (halo
+exchange), CFL time step (device reduction + driver dt policy), evolve.
+State is resident in HBM before the timed region starts.
+
+Rank 0 prints ONE JSON line.  At N=1 it also carries
+  roofline      HBM roofline of the update kernels (HIP events, per launch)
+  cpu_baseline  the oracle (CPU port of the reference) on a bounded sample
+  also          advection 2048^2 (configs[1]) and multigrid 4096^2 V-cycles/s
+                (configs[3]), measured the same way
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+SEDOV_BYTES_PER_CELL = 64   # read 4 + write 4 conserved doubles
+ADV_BYTES_PER_CELL = 16     # read a + write a
+MG_BYTES_PER_CELL_VCYCLE = 720
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nx", type=int, default=16384)
+    ap.add_argument("--fast-math", type=int, default=None,
+                    help="1: contracted arithmetic (parity 1e-10), 0: bit-faithful")
+    ap.add_argument("--kernel-set", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true")
+    ap.add_argument("--cpu-sample-nx", type=int, default=1024)
+    return ap.parse_args()
+
+
+class Dist:
+    """process-group plumbing (torch.distributed, gloo on CPU tensors);
+    the data path (halos, dt) goes through RCCL inside libpyrohip."""
+
+    def __init__(self, world):
+        self.world = world
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.td = None
+        if world > 1:
+            import torch.distributed as td
+            td.init_process_group("gloo", rank=self.rank, world_size=world)
+            self.td = td
+
+    def barrier(self):
+        if self.td:
+            self.td.barrier()
+
+    def max(self, x):
+        if not self.td:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
+        return float(t[0])
+
+    def bcast_bytes(self, b, n):
+        if not self.td:
+            return b
+        import torch
+        t = torch.zeros(n, dtype=torch.uint8)
+        if self.rank == 0:
+            t = torch.frombuffer(bytearray(b), dtype=torch.uint8).clone()
+        self.td.broadcast(t, 0)
+        return bytes(t.numpy().tobytes())
+
+
+def kernel_table(prof, nlaunch_unit):
+    return {k: {"launches": n, "avg_ms": ms / max(n, 1)} for k, (n, ms) in prof.items()}
+
+
+def bench_sedov(args, dist, ctx, device, defaults):
+    from pyro2_amd.decomp import SlabDecomp
+    from helpers import DtPolicy
+    from sedov_ic import sedov_ic
+    nx = ny = args.nx
+    ng = 4
+    dec = SlabDecomp(nx, dist.world, dist.rank, periodic=False)
+    bcs = ["outflow"] * 4
+    st = device.DeviceState(ctx, dec.nx_local, ny, ng, dec.comp_var_bcs(bcs))
+    # initial condition: generated slab by slab on the host (never more than
+    # 512 rows in memory), uploaded before the timed region
+    chunk = 512
+    meta = None
+    for r0 in range(0, dec.nx_local + 2 * ng, chunk):
+        nr = min(chunk, dec.nx_local + 2 * ng - r0)
+        U, meta, _ = sedov_ic(nx, ny, ng=ng, i0=dec.i0 + r0, ni=nr)
+        st.upload_rows(r0, U)
+    dx, dy = meta[3], meta[4]
+    P = device.make_comp_params(dx, dy, fast_math=defaults["fast_math"],
+                                kernel_set=defaults["kernel_set"],
+                                avisc_xhi_interior=int(dec.hi >= 0))
+    pol = DtPolicy(tmax=0.1)
+
+    def step():
+        if dist.world > 1:
+            st.halo_exchange(dec.lo, dec.hi)
+        st.fill_bc()
+        dtm = st.comp_dt(P, 0.8)
+        if dist.world > 1:
+            dtm = ctx.allreduce_min(dtm)
+        dt = pol(dtm)
+        st.comp_step(P, dt)
+        pol.advance(dt)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    dist.barrier()
+    ctx.prof_enable(True)
+    ctx.timer_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    t1 = time.perf_counter()
+    ev_ms = ctx.timer_stop()
+    prof = ctx.prof_report()
+    ctx.prof_enable(False)
+    dist.barrier()
+    elapsed = dist.max(t1 - t0)
+    cells = float(nx) * ny
+    res = {"elapsed": elapsed, "cells": cells, "prof": prof, "event_ms": ev_ms,
+           "t": pol.t, "dt": pol.dt_old, "local_cells": float(dec.nx_local) * ny}
+    del st
+    return res
+
+
+def bench_advection(ctx, device, nx=2048, steps=100, warmup=10):
+    from oracle import orc
+    x = (np.arange(nx + 8) - 3.5) / nx
+    X, Y = np.meshgrid(x, x, indexing="ij")
+    ic = 1.0 + np.exp(-60.0 * ((X - 0.5) ** 2 + (Y - 0.5) ** 2))
+    st = device.DeviceState(ctx, nx, nx, 4, [["periodic"] * 4])
+    st.upload(ic)
+    dt = orc.adv_dt(1 / nx, 1 / nx, 1.0, 1.0, 0.8)
+
+    def step():
+        st.fill_bc()
+        st.adv_step(0, 1 / nx, 1 / nx, 1.0, 1.0, dt, 2)
+    for _ in range(warmup):
+        step()
+    ctx.sync()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    t1 = time.perf_counter()
+    prof = ctx.prof_report()
+    ctx.prof_enable(False)
+    n, ms = prof["k_adv_step"]
+    kern_s = ms / n * 1e-3
+    return {"workload": f"advection smooth {nx}x{nx} periodic, limiter 2",
+            "value": nx * nx * steps / (t1 - t0), "unit": "cell-updates/s",
+            "ms_per_step": (t1 - t0) / steps * 1e3, "steps": steps,
+            "roofline": {"bound": "hbm", "kernel": "k_adv_step",
+                         "achieved": ADV_BYTES_PER_CELL * nx * nx / kern_s / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ADV_BYTES_PER_CELL * nx * nx / kern_s / 1e9 / HBM_PEAK_GBS,
+                         "kernel_avg_ms": ms / n, "traffic": None}}
+
+
+def bench_mg(ctx, device, nx=4096, cycles=10):
+    x = (np.arange(nx + 2) - 0.5) / nx
+    X, Y = np.meshgrid(x, x, indexing="ij")
+    rhs = -2.0 * ((1.0 - 6.0 * X ** 2) * Y ** 2 * (1.0 - Y ** 2) +
+                  (1.0 - 6.0 * Y ** 2) * X ** 2 * (1.0 - X ** 2))
+    m = device.DeviceMG(ctx, nx)
+    L = m.nlevels - 1
+    m.zero(L, 0)
+    m.set(L, 1, rhs)
+    m.init_rhs_norm()
+    m.solve(rtol=0.0, max_cycles=2)     # warm-up
+    m.zero(L, 0)
+    ctx.sync()
+    t0 = time.perf_counter()
+    nc, res, rel = m.solve(rtol=0.0, max_cycles=cycles)
+    ctx.sync()
+    t1 = time.perf_counter()
+    vps = cycles / (t1 - t0)
+    gbs = MG_BYTES_PER_CELL_VCYCLE * nx * nx * vps / 1e9
+    return {"workload": f"multigrid constant-coeff Poisson {nx}x{nx} dirichlet, "
+                        f"{cycles} V-cycles (nsmooth 10, bottom 50)",
+            "value": vps, "unit": "V-cycles/s", "ms_per_vcycle": (t1 - t0) / cycles * 1e3,
+            "residual_error_after": res,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
+
+
+def cpu_baseline_sedov(sample_nx, max_seconds=25.0):
+    """the oracle (single-threaded C port of the reference) on a bounded sample
+    of the same workload: Sedov, same physics, sample_nx^2, from t = 0"""
+    from oracle import orc
+    from helpers import DtPolicy, meta_to_params
+    from sedov_ic import sedov_ic
+    ic, meta, bcs = sedov_ic(sample_nx)
+    P, cfl = meta_to_params(meta, bcs)
+    U = ic.copy()
+    pol = DtPolicy(0.1)
+    n = 0
+    t0 = time.perf_counter()
+    while n < 50:
+        orc.comp_fill_bc(U, P.nx, P.ny, P.ng, bcs)
+        dt = pol(orc.comp_dt(U, P.nx, P.ny, P.ng, P.dx, P.dy, P.gamma, cfl))
+        orc.comp_step(U, P, dt)
+        pol.advance(dt)
+        n += 1
+        if time.perf_counter() - t0 > max_seconds:
+            break
+    el = time.perf_counter() - t0
+    return {"value": sample_nx * sample_nx * n / el, "unit": "cell-updates/s",
+            "cores": 1, "kind": "port",
+            "sample": f"oracle/pyro_oracle.c (gcc -O2, 1 thread), compressible sedov "
+                      f"{sample_nx}x{sample_nx}, {n} steps from t=0, {el:.1f} s; host has "
+                      f"{os.cpu_count()} cores; the reference itself is single-threaded "
+                      f"NumPy/numba (SURVEY 8(d))"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    if world != args.gpus:
+        if "RANK" not in os.environ and args.gpus > 1:
+            sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run "
+                     "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
+                     "--master-port P bench.py --gpus N ...")
+    dist = Dist(world)
+    from pyro2_amd import device
+    ctx = device.Context(dist.local_rank)
+    if world > 1:
+        uid = device.Context.comm_unique_id() if dist.rank == 0 else b""
+        uid = dist.bcast_bytes(uid, 128)
+        ctx.comm_init(world, dist.rank, uid)
+    defaults = {"fast_math": 1 if args.fast_math is None else args.fast_math,
+                "kernel_set": 0 if args.kernel_set is None else args.kernel_set}
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+
+    r = bench_sedov(args, dist, ctx, device, defaults)
+    value = r["cells"] * args.steps / r["elapsed"]
+    out = {
+        "metric": "cell-updates/s", "value": value, "unit": "cell-updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": r["elapsed"] / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"compressible sedov {args.nx}x{args.nx} (inputs.sedov physics: "
+                               "HLLC, limiter 2, flattening, cvisc 0.1, cfl 0.8, outflow), "
+                               f"x-slab decomposed over {world} GPU(s), RCCL halo exchange",
+                   "parallelism": f"slab{world}", "fast_math": defaults["fast_math"],
+                   "kernel_set": defaults["kernel_set"], "sim_time": r["t"]},
+    }
+    if dist.rank == 0:
+        # roofline of the update kernels: algorithmic bytes of ONE rank's slab
+        # per step / HIP-event time of that rank's kernels per step
+        prof = r["prof"]
+        upd = {k: v for k, v in prof.items()}
+        tot_ms = sum(ms for (_, ms) in upd.values()) / args.steps
+        dom = max(upd, key=lambda k: upd[k][1]) if upd else None
+        gbs = SEDOV_BYTES_PER_CELL * r["local_cells"] / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0
+        out["roofline"] = {
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            "basis": "64 B/cell-update (SURVEY 8(d)) x cells of this rank / sum of the "
+                     "update kernels' HIP-event durations per step",
+            "update_kernels_ms_per_step": tot_ms, "dominant_kernel": dom,
+            "kernels": {k: {"launches": n, "avg_ms": ms / n} for k, (n, ms) in upd.items()},
+            "stream_event_ms_per_step": r["event_ms"] / args.steps,
+        }
+        tr = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tr):
+            try:
+                out["roofline"]["traffic"] = json.load(open(tr))
+            except Exception:
+                pass
+        if world == 1:
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_sedov(args.cpu_sample_nx)
+            if not args.no_also:
+                out["also"] = {"advection": bench_advection(ctx, device),
+                               "multigrid": bench_mg(ctx, device)}
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,12 @@ int pyrohip_device_info(pyrohip_ctx *ctx, char *name, int name_len,
 int pyrohip_timer_start(pyrohip_ctx *ctx);
 int pyrohip_timer_stop(pyrohip_ctx *ctx, double *elapsed_ms);
 
+/* per-kernel HIP-event timing of the solver kernels.  enable(1) starts
+   recording one event pair per launch; report() synchronises and writes
+   lines "kernel_name launches total_ms\n" into buf, then clears. */
+int pyrohip_prof_enable(pyrohip_ctx *ctx, int on);
+int pyrohip_prof_report(pyrohip_ctx *ctx, char *buf, int buf_len);
+
 /* ---- cell-centred data: CellCenterData2d storage (patch.py:315-794) ---- */
 /* bc: nvar*4 codes, order per variable: xl, xr, yl, yr                     */
 int pyrohip_state_create(pyrohip_ctx *ctx, int nx, int ny, int ng, int nvar,

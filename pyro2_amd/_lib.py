@@ -51,6 +51,8 @@ _PROTOS = {
     "pyrohip_sync": [_VP],
     "pyrohip_device_info": [_VP, C.c_char_p, C.c_int, C.POINTER(C.c_size_t),
                             C.POINTER(C.c_size_t), _IP],
+    "pyrohip_prof_enable": [_VP, C.c_int],
+    "pyrohip_prof_report": [_VP, C.c_char_p, C.c_int],
     "pyrohip_timer_start": [_VP],
     "pyrohip_timer_stop": [_VP, _DP],
     "pyrohip_state_create": [_VP, C.c_int, C.c_int, C.c_int, C.c_int, _IP,

@@ -28,7 +28,6 @@ UNITS = [
     ("comp_api.hip", "comp_api", ["-ffp-contract=off"]),
     ("multigrid.hip", "multigrid", ["-ffp-contract=off"]),
     ("comm.hip", "comm", ["-ffp-contract=off"]),
-    ("comm_stub.hip", "comm_stub", ["-ffp-contract=off"]),
 ]
 
 
@@ -53,8 +52,6 @@ def _stale(target, deps):
 
 def units():
     us = [u for u in UNITS if os.path.exists(os.path.join(CSRC, u[0]))]
-    if any(u[1] == "comm" for u in us):
-        us = [u for u in us if u[1] != "comm_stub"]
     return us
 
 

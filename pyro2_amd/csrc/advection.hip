@@ -166,7 +166,7 @@ extern "C" int pyrohip_adv_step(pyrohip_state *s, int n, double dx, double dy, d
     AdvParams P{u, v, dt, dx, dy, limiter};
     const int nti = (g.nx + ADV_TI - 1) / ADV_TI, ntj = (g.ny + ADV_TJ - 1) / ADV_TJ;
     const int ntiles = nti * ntj;
-    hipLaunchKernelGGL(k_adv_step, dim3(ntiles), dim3(ADV_THREADS), 0, c->stream,
+    PYRO_LAUNCH(c, "k_adv_step", k_adv_step, dim3(ntiles), dim3(ADV_THREADS), 0,
                        (const double *)cur, nxt, g, P, ntj, ntiles);
     // interior back into the state plane: swap roles by copying the interior
     // is avoided -- instead copy the (tiny) ghost frame into the new buffer

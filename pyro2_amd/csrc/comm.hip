@@ -1,0 +1,130 @@
+// Multi-GPU plumbing: x-slab halo exchange and scalar all-reduce over RCCL
+// (xGMI), one process per GPU.  The reference has no distributed path at all
+// (SURVEY.md 5, 8(e)); this is the spatial domain decomposition of the
+// explicit update: ng ghost rows per variable are exchanged with the two x
+// neighbours once per time step and dt is min-reduced.
+//
+// Per-link sizing: 4 variables x ng(4) rows x 16400 doubles = 2.1 MB per
+// neighbour per direction at 16384^2 -- one grouped send/recv per neighbour,
+// not a ring collective, so each transfer rides a single xGMI link.
+#include <rccl/rccl.h>
+
+#include "common.h"
+
+namespace pyro {
+
+#define PYRO_CHECK_NCCL(expr)                                                  \
+    do {                                                                       \
+        ncclResult_t _r = (expr);                                              \
+        if (_r != ncclSuccess) {                                               \
+            ::pyro::set_error(std::string(#expr) + ": " + ncclGetErrorString(_r)); \
+            return PYROHIP_ERR_COMM;                                           \
+        }                                                                      \
+    } while (0)
+
+}  // namespace pyro
+
+using namespace pyro;
+
+extern "C" {
+
+int pyrohip_comm_unique_id(char *out_id)
+{
+    PYRO_REQUIRE(out_id, "out_id is NULL");
+    static_assert(sizeof(ncclUniqueId) <= PYROHIP_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    PYRO_CHECK_NCCL(ncclGetUniqueId(&id));
+    memset(out_id, 0, PYROHIP_UNIQUE_ID_BYTES);
+    memcpy(out_id, &id, sizeof(id));
+    return 0;
+}
+
+int pyrohip_comm_init(pyrohip_ctx *c, int nranks, int rank, const char *unique_id)
+{
+    PYRO_REQUIRE(c && unique_id, "NULL argument");
+    PYRO_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank / nranks");
+    PYRO_REQUIRE(c->comm == nullptr, "communicator already initialised");
+    PYRO_CHECK_HIP(hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t comm;
+    PYRO_CHECK_NCCL(ncclCommInitRank(&comm, nranks, id, rank));
+    c->comm = (void *)comm;
+    c->nranks = nranks;
+    c->rank = rank;
+    return 0;
+}
+
+int pyrohip_comm_destroy(pyrohip_ctx *c)
+{
+    if (!c || !c->comm) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    ncclCommDestroy((ncclComm_t)c->comm);
+    c->comm = nullptr;
+    return 0;
+}
+
+int pyrohip_halo_exchange(pyrohip_state *s, int rank_lo, int rank_hi)
+{
+    PYRO_REQUIRE(s, "NULL state");
+    pyrohip_ctx *c = s->ctx;
+    PYRO_REQUIRE(c->comm != nullptr, "communicator not initialised");
+    PYRO_REQUIRE(rank_lo >= -1 && rank_lo < c->nranks && rank_hi >= -1 && rank_hi < c->nranks,
+                 "neighbour rank out of range");
+    if (rank_lo < 0 && rank_hi < 0) return 0;
+    const Geom &g = s->g;
+    PYRO_REQUIRE(g.nx >= g.ng, "slab thinner than the ghost width");
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    const size_t cnt = (size_t)g.ng * g.pitch;   // ng whole rows, contiguous
+    PYRO_CHECK_NCCL(ncclGroupStart());
+    // order (per variable): send low rows -> lo, recv hi ghosts <- hi,
+    // send high rows -> hi, recv lo ghosts <- lo.  With lo == hi (two ranks,
+    // periodic) the per-peer FIFO matching pairs my hi ghosts with the peer's
+    // low rows and my lo ghosts with its high rows, as required.
+    for (int n = 0; n < s->nvar; n++) {
+        double *a = s->d + (size_t)n * g.plane;
+        if (rank_lo >= 0)
+            PYRO_CHECK_NCCL(ncclSend(a + (size_t)g.ilo * g.pitch, cnt, ncclDouble, rank_lo, comm,
+                                     c->stream));
+        if (rank_hi >= 0)
+            PYRO_CHECK_NCCL(ncclRecv(a + (size_t)(g.ihi + 1) * g.pitch, cnt, ncclDouble, rank_hi,
+                                     comm, c->stream));
+        if (rank_hi >= 0)
+            PYRO_CHECK_NCCL(ncclSend(a + (size_t)(g.ihi - g.ng + 1) * g.pitch, cnt, ncclDouble,
+                                     rank_hi, comm, c->stream));
+        if (rank_lo >= 0)
+            PYRO_CHECK_NCCL(ncclRecv(a, cnt, ncclDouble, rank_lo, comm, c->stream));
+    }
+    PYRO_CHECK_NCCL(ncclGroupEnd());
+    return 0;
+}
+
+static int allreduce_scalar(pyrohip_ctx *c, double *value, ncclRedOp_t op)
+{
+    PYRO_REQUIRE(c && value, "NULL argument");
+    if (c->comm == nullptr) return 0;   // single process, no communicator
+    PYRO_TRY(c->reduce.ensure(64));
+    double *d = (double *)c->reduce.p;
+    *(double *)c->reduce_host = *value;
+    PYRO_CHECK_HIP(hipMemcpyAsync(d, c->reduce_host, sizeof(double), hipMemcpyHostToDevice,
+                                  c->stream));
+    PYRO_CHECK_NCCL(ncclAllReduce(d, d + 1, 1, ncclDouble, op, (ncclComm_t)c->comm, c->stream));
+    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, d + 1, sizeof(double), hipMemcpyDeviceToHost,
+                                  c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    *value = *(double *)c->reduce_host;
+    return 0;
+}
+
+int pyrohip_allreduce_min(pyrohip_ctx *c, double *value)
+{
+    return allreduce_scalar(c, value, ncclMin);
+}
+
+int pyrohip_allreduce_max(pyrohip_ctx *c, double *value)
+{
+    return allreduce_scalar(c, value, ncclMax);
+}
+
+}  // extern "C"

@@ -71,8 +71,18 @@ struct DevBuf {
 
 }  // namespace pyro
 
+namespace pyro {
+// per-kernel HIP-event timing (bench.py roofline leg); off by default
+struct ProfRec { const char *name; hipEvent_t a, b; };
+struct Prof {
+    bool on = false;
+    std::vector<ProfRec> recs;
+};
+}  // namespace pyro
+
 struct pyrohip_ctx {
     int device = 0;
+    pyro::Prof prof;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     pyro::DevBuf staging;     // AoS <-> planar staging
@@ -82,6 +92,29 @@ struct pyrohip_ctx {
     int nranks = 1, rank = 0;
     int num_cus = 0;
 };
+
+namespace pyro {
+struct ProfScope {
+    pyrohip_ctx *c;
+    hipEvent_t b = nullptr;
+    ProfScope(pyrohip_ctx *c_, const char *name) : c(c_)
+    {
+        if (!c->prof.on) return;
+        hipEvent_t a;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { b = nullptr; return; }
+        (void)hipEventRecord(a, c->stream);
+        c->prof.recs.push_back(ProfRec{name, a, b});
+    }
+    ~ProfScope() { if (b) (void)hipEventRecord(b, c->stream); }
+};
+}  // namespace pyro
+
+// launch on the context's stream, bracketed by events when profiling is on
+#define PYRO_LAUNCH(c, name, kern, grid, block, shmem, ...)                       \
+    do {                                                                          \
+        ::pyro::ProfScope _ps((c), (name));                                       \
+        hipLaunchKernelGGL(kern, (grid), (block), (shmem), (c)->stream, __VA_ARGS__); \
+    } while (0)
 
 struct pyrohip_state {
     pyrohip_ctx *ctx = nullptr;

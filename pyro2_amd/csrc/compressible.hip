@@ -383,21 +383,21 @@ int comp_step_staged(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     double *W = s->work + geom_lead(g);
     const dim3 block(256);
     PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(k_prim, dim3((g.qy + 255) / 256, g.qx), block, 0, c->stream, U, W, g, P,
+    PYRO_LAUNCH(c, "k_prim", k_prim, dim3((g.qy + 255) / 256, g.qx), block, 0, U, W, g, P,
                        s->d_flag);
     const dim3 gridR1((g.ny + 2 + 255) / 256, g.nx + 2);
-    hipLaunchKernelGGL(k_xi, gridR1, block, 0, c->stream, (const double *)W,
+    PYRO_LAUNCH(c, "k_xi", k_xi, gridR1, block, 0, (const double *)W,
                        W + (size_t)W_XI * g.plane, g, P);
-    hipLaunchKernelGGL(k_states, gridR1, block, 0, c->stream, (const double *)W, W, g, P);
-    hipLaunchKernelGGL(k_riemann_t, gridR1, block, 0, c->stream, (const double *)W, W, g, P);
+    PYRO_LAUNCH(c, "k_states", k_states, gridR1, block, 0, (const double *)W, W, g, P);
+    PYRO_LAUNCH(c, "k_riemann_t", k_riemann_t, gridR1, block, 0, (const double *)W, W, g, P);
     const dim3 gridF((g.ny + 1 + 255) / 256, g.nx + 1);
-    hipLaunchKernelGGL(k_final, gridF, block, 0, c->stream, (const double *)U, (const double *)W,
+    PYRO_LAUNCH(c, "k_final", k_final, gridF, block, 0, (const double *)U, (const double *)W,
                        W, g, P);
     const dim3 gridU((g.ny + 255) / 256, g.nx);
     const int nb = gridU.x * gridU.y;
     PYRO_TRY(c->reduce.ensure((nb + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
-    hipLaunchKernelGGL(k_update, gridU, block, 0, c->stream, U, (const double *)W, g, P, part);
+    PYRO_LAUNCH(c, "k_update", k_update, gridU, block, 0, U, (const double *)W, g, P, part);
     hipLaunchKernelGGL(k_min_final, dim3(1), dim3(256), 0, c->stream, (const double *)part, nb,
                        part + nb);
     PYRO_CHECK_HIP(hipGetLastError());

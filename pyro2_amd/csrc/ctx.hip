@@ -255,6 +255,41 @@ int pyrohip_timer_stop(pyrohip_ctx *c, double *elapsed_ms)
     return 0;
 }
 
+int pyrohip_prof_enable(pyrohip_ctx *c, int on)
+{
+    PYRO_REQUIRE(c, "ctx is NULL");
+    c->prof.on = (on != 0);
+    return 0;
+}
+
+int pyrohip_prof_report(pyrohip_ctx *c, char *buf, int buf_len)
+{
+    PYRO_REQUIRE(c && buf && buf_len > 0, "bad argument");
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    struct Agg { const char *name; int n; double ms; };
+    std::vector<Agg> agg;
+    for (auto &r : c->prof.recs) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+        bool found = false;
+        for (auto &a : agg)
+            if (strcmp(a.name, r.name) == 0) { a.n++; a.ms += ms; found = true; break; }
+        if (!found) agg.push_back(Agg{r.name, 1, (double)ms});
+    }
+    c->prof.recs.clear();
+    std::string out;
+    char line[256];
+    for (auto &a : agg) {
+        snprintf(line, sizeof line, "%s %d %.6f\n", a.name, a.n, a.ms);
+        out += line;
+    }
+    strncpy(buf, out.c_str(), buf_len - 1);
+    buf[buf_len - 1] = 0;
+    return 0;
+}
+
 // --------------------------------------------------------------------------
 int pyrohip_state_create(pyrohip_ctx *c, int nx, int ny, int ng, int nvar, const int *bc,
                          pyrohip_state **out)

@@ -252,7 +252,7 @@ static int mg_smooth(pyrohip_mg *m, int level, int nsmooth)
     dim3 grid((half + bx - 1) / bx, L.n), block(bx);
     for (int it = 0; it < nsmooth; it++)
         for (int colour = 0; colour < 2; colour++)
-            hipLaunchKernelGGL(k_mg_smooth, grid, block, 0, m->ctx->stream, L.v,
+            PYRO_LAUNCH(m->ctx, "k_mg_smooth", k_mg_smooth, grid, block, 0, L.v,
                                (const double *)L.f, L.n, L.pitch, L.dx, xcoeff, ycoeff, denom,
                                colour, bc);
     return 0;
@@ -272,8 +272,7 @@ static int mg_restrict(pyrohip_mg *m, int fine)
 {
     MGLevel &F = m->lev[fine], &Cc = m->lev[fine - 1];
     const int bx = (Cc.n >= 256) ? 256 : 64;
-    hipLaunchKernelGGL(k_mg_restrict, dim3((Cc.n + bx - 1) / bx, Cc.n), dim3(bx), 0,
-                       m->ctx->stream, (const double *)F.r, F.pitch, Cc.f, Cc.pitch, Cc.n);
+    PYRO_LAUNCH(m->ctx, "k_mg_restrict", k_mg_restrict, dim3((Cc.n + bx - 1) / bx, Cc.n), dim3(bx), 0, (const double *)F.r, F.pitch, Cc.f, Cc.pitch, Cc.n);
     return 0;
 }
 
@@ -281,8 +280,7 @@ static int mg_prolong_add(pyrohip_mg *m, int fine)
 {
     MGLevel &F = m->lev[fine], &Cc = m->lev[fine - 1];
     const int bx = (F.n >= 256) ? 256 : 64;
-    hipLaunchKernelGGL(k_mg_prolong_add, dim3((F.n + bx - 1) / bx, F.n), dim3(bx), 0,
-                       m->ctx->stream, (const double *)Cc.v, Cc.pitch, F.v, F.pitch, F.n);
+    PYRO_LAUNCH(m->ctx, "k_mg_prolong_add", k_mg_prolong_add, dim3((F.n + bx - 1) / bx, F.n), dim3(bx), 0, (const double *)Cc.v, Cc.pitch, F.v, F.pitch, F.n);
     return 0;
 }
 

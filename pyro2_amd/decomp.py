@@ -1,0 +1,62 @@
+"""x-slab domain decomposition of a Grid2d across the GPUs of one node.
+
+The reference is single-block (pyro/mesh/array_indexer.py:157-158 "there is
+only a single grid"); the explicit finite-volume update has a dependence
+radius of ng = 4 cells, so slabs of whole rows (i is the slow axis: each halo
+is ng contiguous rows per variable) with one halo exchange per time step and a
+min all-reduce of dt reproduce the single-domain result bit for bit, provided
+the artificial-viscosity coefficient is also computed on slab faces that are
+interior to the global grid.
+"""
+import numpy as np
+
+from ._lib import BC_CODE, BC_HALO
+
+
+class SlabDecomp:
+    def __init__(self, nx, nranks, rank, periodic=False):
+        if nranks < 1 or not 0 <= rank < nranks:
+            raise ValueError("bad rank / nranks")
+        base, rem = divmod(int(nx), nranks)
+        counts = [base + (1 if r < rem else 0) for r in range(nranks)]
+        if min(counts) < 4:
+            raise ValueError("slab thinner than the ghost width")
+        self.nx, self.nranks, self.rank = int(nx), nranks, rank
+        self.counts = counts
+        self.nx_local = counts[rank]
+        # local array row r  <->  global array row i0 + r (both carry ng ghosts)
+        self.i0 = sum(counts[:rank])
+        self.lo = rank - 1 if rank > 0 else (nranks - 1 if periodic and nranks > 1 else -1)
+        self.hi = rank + 1 if rank < nranks - 1 else (0 if periodic and nranks > 1 else -1)
+
+    def var_bcs(self, per_var):
+        """per-variable [xl,xr,yl,yr] names/codes -> int table with HALO on the
+        slab faces that have a neighbour"""
+        out = np.zeros((len(per_var), 4), dtype=np.int32)
+        for n, row in enumerate(per_var):
+            for s, b in enumerate(row):
+                out[n, s] = BC_CODE[b] if isinstance(b, str) else int(b)
+            if self.lo >= 0:
+                out[n, 0] = BC_HALO
+            if self.hi >= 0:
+                out[n, 1] = BC_HALO
+        return [list(r) for r in out]
+
+    def comp_var_bcs(self, bcs):
+        """mesh boundary names -> table for (dens, ener, xmom, ymom);
+        'reflect' is odd for the normal momentum (simulation_null.py:99-112)"""
+        rows = []
+        for n in range(4):
+            row = []
+            for s, b in enumerate(bcs):
+                if b == "reflect":
+                    odd = (n == 2 and s < 2) or (n == 3 and s >= 2)
+                    row.append("reflect-odd" if odd else "reflect-even")
+                else:
+                    row.append(b)
+            rows.append(row)
+        return self.var_bcs(rows)
+
+    def local_rows(self, ng):
+        """global array rows [a, b) held by this rank incl. ghosts"""
+        return self.i0, self.i0 + self.nx_local + 2 * ng

@@ -68,6 +68,21 @@ class Context:
             check(self._l.pyrohip_timer_stop(self.h, C.byref(ms)))
         return ms.value
 
+    def prof_enable(self, on=True):
+        with self.lock:
+            check(self._l.pyrohip_prof_enable(self.h, 1 if on else 0))
+
+    def prof_report(self):
+        """{kernel: (launches, total_ms)} since the last report"""
+        buf = C.create_string_buffer(1 << 16)
+        with self.lock:
+            check(self._l.pyrohip_prof_report(self.h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, n, ms = line.split()
+            out[name] = (int(n), float(ms))
+        return out
+
     # ---- multi-GPU plumbing (RCCL) ------------------------------------
     @staticmethod
     def comm_unique_id():

@@ -22,15 +22,13 @@ from pyro2_amd import build as hb  # noqa: E402
 
 def build(force=False):
     os.makedirs(OUT, exist_ok=True)
-    deps = hb._deps() + [os.path.join(HERE, "hipemu.cpp"),
+    deps = hb._deps() + [os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "comm_emu.cpp"),
                          os.path.join(HERE, "hip", "hip_runtime.h")]
     if not force and not hb._stale(LIB, deps):
         return LIB
     flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off",
              "-I" + HERE, "-DPYRO_EMU=1", '-DPYRO_BACKEND_NAME="host-emu"']
     units = [u for u in hb.units() if u[1] not in ("comm",)]
-    if not any(u[1] == "comm_stub" for u in units):
-        units.append(("comm_stub.hip", "comm_stub", []))
 
     def cc(u):
         src, name, extra = u
@@ -44,7 +42,9 @@ def build(force=False):
         objs = list(ex.map(cc, units))
     rt = os.path.join(OUT, "hipemu.o")
     subprocess.check_call(["g++"] + flags + ["-c", os.path.join(HERE, "hipemu.cpp"), "-o", rt])
-    subprocess.check_call(["g++", "-shared", "-o", LIB] + objs + [rt])
+    cm = os.path.join(OUT, "comm_emu.o")
+    subprocess.check_call(["g++"] + flags + ["-c", os.path.join(HERE, "comm_emu.cpp"), "-o", cm])
+    subprocess.check_call(["g++", "-shared", "-o", LIB] + objs + [rt, cm])
     return LIB
 
 

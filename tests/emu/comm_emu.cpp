@@ -1,0 +1,12 @@
+// host-emu build has no RCCL: the comm entry points report "unsupported".
+// (CPU multi-process tests exchange halos over torch.distributed/gloo through
+// download_rows / upload_rows instead -- tests/test_decomp_gloo.py.)
+#include "../../pyro2_amd/csrc/common.h"
+extern "C" {
+int pyrohip_comm_unique_id(char *) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
+int pyrohip_comm_init(pyrohip_ctx *, int, int, const char *) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
+int pyrohip_comm_destroy(pyrohip_ctx *) { return 0; }
+int pyrohip_halo_exchange(pyrohip_state *, int, int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
+int pyrohip_allreduce_min(pyrohip_ctx *, double *) { return 0; }
+int pyrohip_allreduce_max(pyrohip_ctx *, double *) { return 0; }
+}
