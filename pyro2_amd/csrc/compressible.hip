@@ -70,10 +70,13 @@ __device__ __forceinline__ void store_cons(double *__restrict__ a, size_t plane,
 // simulation.py:452-456 and :49-80.  flag[0] |= 1 when the interior
 // positivity assert (:68-71) would fire.
 __global__ __launch_bounds__(256) void k_prim(double *__restrict__ U, double *__restrict__ W,
-                                              Geom g, CP P, int *__restrict__ flag)
+                                              Geom g, CP P, int *__restrict__ flag,
+                                              int gx, int gy)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
+    int bx, by;
+    if (!xcd_block_2d(gx, gy, bx, by)) return;
+    const int j = bx * blockDim.x + threadIdx.x;
+    const int i = by;
     if (j >= g.qy) return;
     const size_t k = (size_t)i * g.pitch + j;
     const bool interior = (i >= g.ilo && i <= g.ihi && j >= g.jlo && j <= g.jhi);
@@ -93,10 +96,12 @@ __global__ __launch_bounds__(256) void k_prim(double *__restrict__ U, double *__
 // ---- stage 1: multi-dimensional flattening coefficient on R(1) -----------
 // reconstruction.py:123-183
 __global__ __launch_bounds__(256) void k_xi(const double *__restrict__ W_, double *__restrict__ XI,
-                                            Geom g, CP P)
+                                            Geom g, CP P, int gx, int gy)
 {
-    const int j = g.jlo - 1 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = g.ilo - 1 + blockIdx.y;
+    int bx, by;
+    if (!xcd_block_2d(gx, gy, bx, by)) return;
+    const int j = g.jlo - 1 + bx * blockDim.x + threadIdx.x;
+    const int i = g.ilo - 1 + by;
     if (j > g.jhi + 1) return;
     const int p = g.pitch;
     const size_t k = (size_t)i * p + j;
@@ -123,10 +128,13 @@ __global__ __launch_bounds__(256) void k_xi(const double *__restrict__ W_, doubl
 // ---- stage 2: limited slopes + characteristic tracing on R(1) ------------
 // unsplit_fluxes.py:186-242, interface.py:5-236, simulation.py:83-102
 __global__ __launch_bounds__(256) void k_states(const double *__restrict__ W_,
-                                                double *__restrict__ Wout, Geom g, CP P)
+                                                double *__restrict__ Wout, Geom g, CP P,
+                                                int gx, int gy)
 {
-    const int j = g.jlo - 1 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = g.ilo - 1 + blockIdx.y;
+    int bx, by;
+    if (!xcd_block_2d(gx, gy, bx, by)) return;
+    const int j = g.jlo - 1 + bx * blockDim.x + threadIdx.x;
+    const int i = g.ilo - 1 + by;
     if (j > g.jhi + 1) return;
     const int p = g.pitch;
     const size_t k = (size_t)i * p + j;
@@ -169,10 +177,13 @@ __device__ __forceinline__ Cons from_n(const ConsN &F, bool x)
 // thread (i,j) in [ilo-1, ihi+1] x [jlo-1, jhi+1] solves its lower x face
 // (needs i >= ilo) and its lower y face (needs j >= jlo)
 __global__ __launch_bounds__(256) void k_riemann_t(const double *__restrict__ W_,
-                                                   double *__restrict__ Wout, Geom g, CP P)
+                                                   double *__restrict__ Wout, Geom g, CP P,
+                                                   int gx, int gy)
 {
-    const int j = g.jlo - 1 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = g.ilo - 1 + blockIdx.y;
+    int bx, by;
+    if (!xcd_block_2d(gx, gy, bx, by)) return;
+    const int j = g.jlo - 1 + bx * blockDim.x + threadIdx.x;
+    const int i = g.ilo - 1 + by;
     if (j > g.jhi + 1) return;
     const int p = g.pitch;
     const size_t k = (size_t)i * p + j;
@@ -210,10 +221,13 @@ __device__ __forceinline__ Cons corrected(const Cons &U, const Cons &Fhi, const 
 // j <= jhi, F_y on its lower y face when i <= ihi.
 __global__ __launch_bounds__(256) void k_final(const double *__restrict__ U,
                                                const double *__restrict__ W_,
-                                               double *__restrict__ Wout, Geom g, CP P)
+                                               double *__restrict__ Wout, Geom g, CP P,
+                                               int gx, int gy)
 {
-    const int j = g.jlo + blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = g.ilo + blockIdx.y;
+    int bx, by;
+    if (!xcd_block_2d(gx, gy, bx, by)) return;
+    const int j = g.jlo + bx * blockDim.x + threadIdx.x;
+    const int i = g.ilo + by;
     if (j > g.jhi + 1) return;
     const int p = g.pitch;
     const size_t k = (size_t)i * p + j;
@@ -279,10 +293,12 @@ __global__ __launch_bounds__(256) void k_final(const double *__restrict__ U,
 // == full-array min for outflow / reflect / periodic ghost fills).
 __global__ __launch_bounds__(256) void k_update(double *__restrict__ U,
                                                 const double *__restrict__ W_, Geom g, CP P,
-                                                double *__restrict__ partial)
+                                                double *__restrict__ partial, int gx, int gy)
 {
-    const int j = g.jlo + blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = g.ilo + blockIdx.y;
+    int bx, by;
+    if (!xcd_block_2d(gx, gy, bx, by)) return;   // whole block leaves together
+    const int j = g.jlo + bx * blockDim.x + threadIdx.x;
+    const int i = g.ilo + by;
     const int p = g.pitch;
     const size_t pl = g.plane;
     double cfl = INFINITY;
@@ -302,7 +318,7 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ U,
         cfl = cfl_cell(Cons{Un[0], Un[1], Un[2], Un[3]}, P.gamma, P.dx, P.dy);
     }
     cfl = block_reduce_min(cfl);
-    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = cfl;
+    if (threadIdx.x == 0) partial[by * gx + bx] = cfl;
 }
 
 // ---- CFL over the whole array (ghost cells included), derives.py ---------
@@ -383,21 +399,27 @@ int comp_step_staged(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     double *W = s->work + geom_lead(g);
     const dim3 block(256);
     PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
-    PYRO_LAUNCH(c, "k_prim", k_prim, dim3((g.qy + 255) / 256, g.qx), block, 0, U, W, g, P,
-                       s->d_flag);
-    const dim3 gridR1((g.ny + 2 + 255) / 256, g.nx + 2);
+    // all stage kernels: one block = 256 consecutive j of one row; 1-d launch
+    // with the XCD-band remap of stencil.h
+    int gx = (g.qy + 255) / 256, gy = g.qx;
+    PYRO_LAUNCH(c, "k_prim", k_prim, dim3(xcd_grid_1d(gx, gy)), block, 0, U, W, g, P, s->d_flag,
+                gx, gy);
+    gx = (g.ny + 2 + 255) / 256; gy = g.nx + 2;
+    const dim3 gridR1(xcd_grid_1d(gx, gy));
     PYRO_LAUNCH(c, "k_xi", k_xi, gridR1, block, 0, (const double *)W,
-                       W + (size_t)W_XI * g.plane, g, P);
-    PYRO_LAUNCH(c, "k_states", k_states, gridR1, block, 0, (const double *)W, W, g, P);
-    PYRO_LAUNCH(c, "k_riemann_t", k_riemann_t, gridR1, block, 0, (const double *)W, W, g, P);
-    const dim3 gridF((g.ny + 1 + 255) / 256, g.nx + 1);
-    PYRO_LAUNCH(c, "k_final", k_final, gridF, block, 0, (const double *)U, (const double *)W,
-                       W, g, P);
-    const dim3 gridU((g.ny + 255) / 256, g.nx);
-    const int nb = gridU.x * gridU.y;
+                W + (size_t)W_XI * g.plane, g, P, gx, gy);
+    PYRO_LAUNCH(c, "k_states", k_states, gridR1, block, 0, (const double *)W, W, g, P, gx, gy);
+    PYRO_LAUNCH(c, "k_riemann_t", k_riemann_t, gridR1, block, 0, (const double *)W, W, g, P, gx,
+                gy);
+    gx = (g.ny + 1 + 255) / 256; gy = g.nx + 1;
+    PYRO_LAUNCH(c, "k_final", k_final, dim3(xcd_grid_1d(gx, gy)), block, 0, (const double *)U,
+                (const double *)W, W, g, P, gx, gy);
+    gx = (g.ny + 255) / 256; gy = g.nx;
+    const int nb = gx * gy;
     PYRO_TRY(c->reduce.ensure((nb + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
-    PYRO_LAUNCH(c, "k_update", k_update, gridU, block, 0, U, (const double *)W, g, P, part);
+    PYRO_LAUNCH(c, "k_update", k_update, dim3(xcd_grid_1d(gx, gy)), block, 0, U,
+                (const double *)W, g, P, part, gx, gy);
     hipLaunchKernelGGL(k_min_final, dim3(1), dim3(256), 0, c->stream, (const double *)part, nb,
                        part + nb);
     PYRO_CHECK_HIP(hipGetLastError());

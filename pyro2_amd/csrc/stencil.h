@@ -50,4 +50,23 @@ __device__ __forceinline__ int xcd_tile(int b, int nb)
     return (b % nxcd) * (nb / nxcd) + b / nxcd;
 }
 
+// 2-d version for row-per-block kernels launched as a 1-d grid of
+// 8*ceil(gx*gy/8) blocks: returns false for the padding blocks, otherwise the
+// logical (bx, by) with by = row index.  XCD k then owns a contiguous band of
+// rows, walked in order, so the +-1..4 neighbour rows of a stencil are L2 hits
+// instead of being re-fetched by every XCD (measured 4-7x FETCH_SIZE
+// amplification without it, profiles/r01_*).
+__device__ __forceinline__ bool xcd_block_2d(int gx, int gy, int &bx, int &by)
+{
+    const int N = gx * gy;
+    const int per = (N + 7) / 8;
+    const int L = blockIdx.x;
+    const int Lp = (L % 8) * per + L / 8;
+    if (Lp >= N) return false;
+    bx = Lp % gx;
+    by = Lp / gx;
+    return true;
+}
+inline int xcd_grid_1d(int gx, int gy) { return 8 * ((gx * gy + 7) / 8); }
+
 }  // namespace pyro

@@ -1,0 +1,377 @@
+"""Grid2d / Cartesian2d / CellCenterData2d with the call surface of
+pyro/mesh/patch.py:42-794, cell data resident on the GPU.
+
+Differences in mechanism (not in behaviour):
+  * 2-d coordinate arrays (x2d, y2d, ..., Lx, Ly, Ax, Ay, V) are built lazily
+    on first access -- the reference builds 11 full (qx,qy) arrays eagerly
+    (patch.py:137-147, 210-233), which does not fit host memory at 16384^2.
+  * CellCenterData2d keeps a planar copy of `data` on the device.  Host and
+    device copies carry validity flags: touching `.data` / `get_var()`
+    downloads if the device is newer and (because writes through NumPy views
+    cannot be observed) marks the device copy stale; the next device
+    operation uploads first.  In Pyro.run_sim's steady loop nothing touches
+    the host copy, so the state never leaves HBM.
+"""
+import numpy as np
+
+from .. import device
+from .._lib import BC_CODE
+from ..util import msg
+from . import boundary as bnd
+from .array_indexer import ArrayIndexer
+
+
+class Grid2d:
+    """the discretisation: nx x ny zones plus ng ghost cells per side on
+    [xmin,xmax] x [ymin,ymax]  (patch.py:42-189)"""
+
+    coord_type = None
+
+    def __init__(self, nx, ny, *, ng=1, xmin=0.0, xmax=1.0, ymin=0.0, ymax=1.0):
+        self.nx, self.ny, self.ng = int(nx), int(ny), int(ng)
+        self.qx, self.qy = int(2 * ng + nx), int(2 * ng + ny)
+        self.xmin, self.xmax, self.ymin, self.ymax = xmin, xmax, ymin, ymax
+        self.ilo, self.ihi = self.ng, self.ng + self.nx - 1
+        self.jlo, self.jhi = self.ng, self.ng + self.ny - 1
+        self.ic = self.ilo + self.nx // 2 - 1
+        self.jc = self.jlo + self.ny // 2 - 1
+        # 1-d coordinates, same expressions as patch.py:121-134
+        self.dx = (xmax - xmin) / nx
+        self.xl = (np.arange(self.qx) - ng) * self.dx + xmin
+        self.xr = (np.arange(self.qx) + 1.0 - ng) * self.dx + xmin
+        self.x = 0.5 * (self.xl + self.xr)
+        self.dy = (ymax - ymin) / ny
+        self.yl = (np.arange(self.qy) - ng) * self.dy + ymin
+        self.yr = (np.arange(self.qy) + 1.0 - ng) * self.dy + ymin
+        self.y = 0.5 * (self.yl + self.yr)
+        self._lazy = {}
+
+    # ---- lazily built 2-d coordinate arrays ----------------------------
+    def _mesh(self, key, a, b, which):
+        if key not in self._lazy:
+            aa, bb = np.meshgrid(a, b, indexing="ij")
+            self._lazy[key] = ArrayIndexer(d=aa if which == 0 else bb, grid=self)
+        return self._lazy[key]
+
+    x2d = property(lambda self: self._mesh("x2d", self.x, self.y, 0))
+    y2d = property(lambda self: self._mesh("y2d", self.x, self.y, 1))
+    xl2d = property(lambda self: self._mesh("xl2d", self.xl, self.yl, 0))
+    yl2d = property(lambda self: self._mesh("yl2d", self.xl, self.yl, 1))
+    xr2d = property(lambda self: self._mesh("xr2d", self.xr, self.yr, 0))
+    yr2d = property(lambda self: self._mesh("yr2d", self.xr, self.yr, 1))
+
+    def scratch_array(self, *, nvar=1, dtype=np.float64):
+        shape = (self.qx, self.qy) if nvar == 1 else (self.qx, self.qy, nvar)
+        return ArrayIndexer(d=np.zeros(shape, dtype=dtype), grid=self)
+
+    def coarse_like(self, N):
+        return Grid2d(self.nx // N, self.ny // N, ng=self.ng, xmin=self.xmin,
+                      xmax=self.xmax, ymin=self.ymin, ymax=self.ymax)
+
+    def fine_like(self, N):
+        return Grid2d(self.nx * N, self.ny * N, ng=self.ng, xmin=self.xmin,
+                      xmax=self.xmax, ymin=self.ymin, ymax=self.ymax)
+
+    def __str__(self):
+        return f"2-d grid: nx = {self.nx}, ny = {self.ny}, ng = {self.ng}"
+
+    def __eq__(self, other):
+        keys = ("nx", "ny", "ng", "xmin", "xmax", "ymin", "ymax")
+        return all(getattr(self, k) == getattr(other, k) for k in keys)
+
+    __hash__ = None
+
+
+class Cartesian2d(Grid2d):
+    """Cartesian geometry: Lx = dx, Ly = dy, Ax = Ly, Ay = Lx, V = dx dy
+    (patch.py:192-239); the constant 2-d arrays are built on demand"""
+
+    def __init__(self, nx, ny, *, ng=1, xmin=0.0, xmax=1.0, ymin=0.0, ymax=1.0):
+        super().__init__(nx, ny, ng=ng, xmin=xmin, xmax=xmax, ymin=ymin, ymax=ymax)
+        self.coord_type = 0
+
+    def _const(self, key, value):
+        if key not in self._lazy:
+            self._lazy[key] = ArrayIndexer(np.full((self.qx, self.qy), value), grid=self)
+        return self._lazy[key]
+
+    Lx = property(lambda self: self._const("Lx", self.dx))
+    Ly = property(lambda self: self._const("Ly", self.dy))
+    Ax = property(lambda self: self.Ly)
+    Ay = property(lambda self: self.Lx)
+    dlogAx = property(lambda self: self._const("dlogAx", 0.0))
+    dlogAy = property(lambda self: self._const("dlogAy", 0.0))
+    V = property(lambda self: self._const("V", self.dx * self.dy))
+
+    def __str__(self):
+        return (f"Cartesian 2D Grid: xmin = {self.xmin}, xmax = {self.xmax}, "
+                f"ymin = {self.ymin}, ymax = {self.ymax}, "
+                f"nx = {self.nx}, ny = {self.ny}, ng = {self.ng}")
+
+
+def _bc_row(bc):
+    return [BC_CODE.get(b, 0) for b in bc.sides()]
+
+
+def _fill_host_array(ctx, arr, n, bc):
+    """ArrayIndexer.fill_ghost for a stand-alone host array: one round trip
+    through the device ghost-fill kernel"""
+    g = arr.g
+    plane = np.ascontiguousarray(arr if arr.ndim == 2 else arr[:, :, n], dtype=np.float64)
+    st = device.DeviceState(ctx, g.nx, g.ny, g.ng, [_bc_row(bc)])
+    st.upload_var(0, plane)
+    st.fill_bc(0)
+    out = st.download_var(0)
+    _apply_inhomogeneous(out, g, bc)
+    if arr.ndim == 2:
+        arr[:, :] = out
+    else:
+        arr[:, :, n] = out
+
+
+def _apply_inhomogeneous(a, g, bc):
+    """first-ghost-cell values for inhomogeneous Dirichlet / Neumann data
+    (array_indexer.py:166-183,196-215); host side, O(perimeter)"""
+    xl, xr, yl, yr = bc.values()
+    if xl is not None:
+        a[g.ilo - 1, :] = a[g.ilo, :] - g.dx * xl if bc.xlb in ("outflow", "neumann") \
+            else 2 * xl - a[g.ilo, :]
+    if xr is not None:
+        a[g.ihi + 1, :] = a[g.ihi, :] + g.dx * xr if bc.xrb in ("outflow", "neumann") \
+            else 2 * xr - a[g.ihi, :]
+    if yl is not None:
+        a[:, g.jlo - 1] = a[:, g.jlo] - g.dy * yl if bc.ylb in ("outflow", "neumann") \
+            else 2 * yl - a[:, g.jlo]
+    if yr is not None:
+        a[:, g.jhi + 1] = a[:, g.jhi] + g.dy * yr if bc.yrb in ("outflow", "neumann") \
+            else 2 * yr - a[:, g.jhi]
+
+
+class CellCenterData2d:
+    """cell-centred state on a grid: register_var()* -> create() -> use
+    (patch.py:315-794).  Storage order of `data` is (qx, qy, nvar)."""
+
+    def __init__(self, grid, *, dtype=np.float64, ctx=None):
+        if dtype != np.float64:
+            raise ValueError("the device path is float64 only (like the reference's defaults)")
+        self.grid = grid
+        self.dtype = dtype
+        self.names = []
+        self.vars = self.names   # same alias as the reference
+        self.nvar = 0
+        self.ivars = []
+        self.aux = {}
+        self.derives = []
+        self.BCs = {}
+        self.t = -1.0
+        self.initialized = 0
+        self._ctx = ctx
+        self._host = None
+        self._dev = None
+        self._host_valid = True
+        self._dev_valid = False
+
+    # ---- construction ---------------------------------------------------
+    def register_var(self, name, bc):
+        if self.initialized == 1:
+            msg.fail("ERROR: grid already initialized")
+        self.names.append(name)
+        self.nvar += 1
+        self.BCs[name] = bc
+
+    def set_aux(self, keyword, value):
+        self.aux[keyword] = value
+
+    def get_aux(self, keyword):
+        return self.aux.get(keyword)
+
+    def add_derived(self, func):
+        self.derives.append(func)
+
+    def add_ivars(self, ivars):
+        self.ivars = ivars
+
+    def create(self):
+        if self.initialized == 1:
+            msg.fail("ERROR: grid already initialized")
+        g = self.grid
+        self._host = ArrayIndexer(np.zeros((g.qx, g.qy, self.nvar)), grid=g)
+        self._host_valid, self._dev_valid = True, False
+        self.initialized = 1
+
+    # ---- host / device coherence ---------------------------------------
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = device.Context.default()
+        return self._ctx
+
+    def device_state(self):
+        """the DeviceState with a current copy of the data (uploads if the host
+        copy was touched since the last device operation)"""
+        if self._dev is None:
+            g = self.grid
+            rows = [_bc_row(self.BCs[n]) for n in self.names]
+            self._dev = device.DeviceState(self.ctx, g.nx, g.ny, g.ng, rows)
+        if not self._dev_valid:
+            self._dev.upload(np.asarray(self._host))
+            self._dev_valid = True
+        return self._dev
+
+    def device_modified(self):
+        """to be called after a kernel changed the device copy"""
+        self._dev_valid = True
+        self._host_valid = False
+
+    def _host_rw(self):
+        if not self._host_valid:
+            self._dev.download(np.asarray(self._host))
+            self._host_valid = True
+        # views handed out may be written through: the device copy is stale
+        self._dev_valid = False
+        return self._host
+
+    @property
+    def data(self):
+        return self._host_rw()
+
+    @data.setter
+    def data(self, value):
+        self._host = ArrayIndexer(np.ascontiguousarray(value, dtype=np.float64), grid=self.grid)
+        self._host_valid, self._dev_valid = True, False
+
+    # ---- variable access ------------------------------------------------
+    def get_var(self, name):
+        """stored variable: writable view into `data`; otherwise the first
+        derived-variable function that knows the name (patch.py:476-508)"""
+        if name in self.names:
+            return self.get_var_by_index(self.names.index(name))
+        for f in self.derives:
+            try:
+                var = f(self, name)
+            except TypeError:
+                var = f(self, name, self.ivars, self.grid)
+            if len(var) > 0:
+                return var
+        raise KeyError(f"name {name} is not valid") from None
+
+    def get_var_by_index(self, n):
+        return ArrayIndexer(d=self._host_rw()[:, :, n], grid=self.grid)
+
+    def get_vars(self):
+        return ArrayIndexer(d=self._host_rw(), grid=self.grid)
+
+    def zero(self, name):
+        self._host_rw()[:, :, self.names.index(name)] = 0.0
+
+    def min(self, name, *, ng=0):
+        n = self.names.index(name)
+        if self._dev_valid and self._dev is not None:
+            return self._dev.minmax(n, buf=ng)[0]
+        return np.min(self._host.v(buf=ng, n=n))
+
+    def max(self, name, *, ng=0):
+        n = self.names.index(name)
+        if self._dev_valid and self._dev is not None:
+            return self._dev.minmax(n, buf=ng)[1]
+        return np.max(self._host.v(buf=ng, n=n))
+
+    # ---- boundary conditions -------------------------------------------
+    def _has_host_bc(self, name):
+        bc = self.BCs[name]
+        return any(b in bnd.ext_bcs for b in bc.sides()) or \
+            any(v is not None for v in bc.values())
+
+    def fill_BC_all(self):
+        if not any(self._has_host_bc(n) for n in self.names):
+            self.device_state().fill_bc(-1)     # one launch pair for all variables
+            self.device_modified()
+            return
+        for name in self.names:
+            self.fill_BC(name)
+
+    def fill_BC(self, name):
+        """device ghost fill (ArrayIndexer.fill_ghost semantics), then any
+        user-defined boundary callbacks on the host copy (patch.py:582-624)"""
+        n = self.names.index(name)
+        bc = self.BCs[name]
+        self.device_state().fill_bc(n)
+        self.device_modified()
+        if not self._has_host_bc(name):
+            return
+        host = self._host_rw()
+        _apply_inhomogeneous(host[:, :, n], self.grid, bc)
+        for side, tag in zip(bc.sides(), ("xlb", "xrb", "ylb", "yrb")):
+            if side in bnd.ext_bcs:
+                try:
+                    bnd.ext_bcs[side](side, tag, name, self, self.ivars)
+                except TypeError:
+                    bnd.ext_bcs[side](side, tag, name, self)
+
+    # ---- grid transfer (patch.py:640-736) ------------------------------
+    def restrict(self, varname, N=2):
+        """4-cell average onto a grid coarser by N = 2 (device kernel shared
+        with the multigrid solver)"""
+        if N != 2:
+            raise ValueError("restriction on the device is implemented for N = 2")
+        from ..multigrid import _transfer
+        return _transfer.restrict(self, varname)
+
+    def prolong(self, varname):
+        from ..multigrid import _transfer
+        return _transfer.prolong(self, varname)
+
+    # ---- output ---------------------------------------------------------
+    def write(self, filename):
+        import h5py
+        if not filename.endswith(".h5"):
+            filename += ".h5"
+        with h5py.File(filename, "w") as f:
+            self.write_data(f)
+
+    def write_data(self, f):
+        """HDF5 layout of patch.py:750-788: groups aux / grid / state/<var>"""
+        gaux = f.create_group("aux")
+        for k, v in self.aux.items():
+            gaux.attrs[k] = v
+        g = self.grid
+        ggrid = f.create_group("grid")
+        for k in ("nx", "ny", "ng", "xmin", "xmax", "ymin", "ymax"):
+            ggrid.attrs[k] = getattr(g, k)
+        if g.coord_type is not None:
+            ggrid.attrs["coord_type"] = g.coord_type
+        gstate = f.create_group("state")
+        for n, name in enumerate(self.names):
+            gvar = gstate.create_group(name)
+            gvar.create_dataset("data", data=self.get_var_by_index(n).v())
+            bc = self.BCs[name]
+            for tag, val in zip(("xlb", "xrb", "ylb", "yrb"), bc.sides()):
+                gvar.attrs[tag] = val
+
+    def pretty_print(self, var, fmt=None):
+        self.get_var(var).pretty_print(fmt=fmt)
+
+    def __str__(self):
+        if self.initialized == 0:
+            return "CellCenterData2d object not yet initialized"
+        g = self.grid
+        s = f"cc data: nx = {g.nx}, ny = {g.ny}, ng = {g.ng}\n"
+        s += f"         nvars = {self.nvar}\n         variables:\n"
+        for name in self.names:
+            bc = self.BCs[name]
+            s += f"{name:>16s}: min: {self.min(name):15.10f}    max: {self.max(name):15.10f}\n"
+            s += f"{' ':>16s}  BCs: -x: {bc.xlb:12s} +x: {bc.xrb:12s} -y: {bc.ylb:12s} +y: {bc.yrb:12s}\n"
+        return s
+
+
+def cell_center_data_clone(old):
+    """a new CellCenterData2d with the same grid, variables, BCs and aux data
+    and a copy of the data (patch.py:951-980)"""
+    new = CellCenterData2d(old.grid, dtype=old.dtype, ctx=old._ctx)
+    for name in old.names:
+        new.register_var(name, old.BCs[name])
+    new.aux = dict(old.aux)
+    new.derives = list(old.derives)
+    new.create()
+    new.data[:, :, :] = np.asarray(old.data)
+    return new

@@ -137,8 +137,9 @@ def test_mg_4096_vcycle_properties(hip):
         rn = m.norm(L, 2)
         assert rn < prev / 5.0, (c, rn, prev)
         prev = rn
-    nc, res, rel = m.solve(rtol=1e-11)
-    assert res <= 1e-11 and nc <= 10
+    # (round-off floor of the residual at 4096^2 is ~1e-10 of the source norm)
+    nc, res, rel = m.solve(rtol=1e-9)
+    assert res <= 1e-9 and nc <= 6
     v = m.get(L, 0)
     e = (v - (X ** 2 - X ** 4) * (Y ** 4 - Y ** 2))[1:-1, 1:-1]
     l2 = np.sqrt(np.sum(e ** 2) / nx ** 2)
