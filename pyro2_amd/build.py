@@ -25,6 +25,8 @@ UNITS = [
     ("advection.hip", "advection", ["-ffp-contract=off"]),
     ("compressible.hip", "comp_exact", ["-ffp-contract=off", "-DPYRO_FAST=0"]),
     ("compressible.hip", "comp_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1"]),
+    ("comp_fused.hip", "fused_exact", ["-ffp-contract=off", "-DPYRO_FAST=0"]),
+    ("comp_fused.hip", "fused_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1"]),
     ("comp_api.hip", "comp_api", ["-ffp-contract=off"]),
     ("multigrid.hip", "multigrid", ["-ffp-contract=off"]),
     ("comm.hip", "comm", ["-ffp-contract=off"]),

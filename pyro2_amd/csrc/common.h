@@ -123,6 +123,8 @@ struct pyrohip_state {
     std::vector<int> bc;      // nvar*4
     double *base = nullptr;   // allocation
     double *d = nullptr;      // base + lead: plane n, row i: d + n*plane + i*pitch
+    double *alt_base = nullptr;  // second buffer (fused kernels write the new
+                                 // time level here, then the two are swapped)
     int *d_bc = nullptr;      // device copy of bc
     // compressible work space (allocated on first use)
     double *work = nullptr;

@@ -7,11 +7,13 @@ namespace pyro {
 namespace exact {
 int comp_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_step_staged(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_step_fused(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_stage_dump(pyrohip_state *, int, double *);
 }
 namespace fastm {
 int comp_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_step_staged(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_step_fused(pyrohip_state *, const pyrohip_comp_params *, double);
 }
 }  // namespace pyro
 
@@ -45,10 +47,9 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
 {
     PYRO_TRY(check_comp(s, p));
     PYRO_REQUIRE(dt > 0.0, "dt must be positive");
-    if (p->kernel_set != 0) {
-        set_error("kernel_set != 0 not available in this build");
-        return PYROHIP_ERR_UNSUPPORTED;
-    }
+    PYRO_REQUIRE(p->kernel_set == 0 || p->kernel_set == 1, "kernel_set must be 0 or 1");
+    if (p->kernel_set == 1)
+        return p->fast_math ? fastm::comp_step_fused(s, p, dt) : exact::comp_step_fused(s, p, dt);
     return p->fast_math ? fastm::comp_step_staged(s, p, dt) : exact::comp_step_staged(s, p, dt);
 }
 

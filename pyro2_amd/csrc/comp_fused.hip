@@ -1,0 +1,356 @@
+// Compressible CTU + HLLC step as ONE kernel per time step (kernel_set 1).
+//
+// Same arithmetic as the staged kernels of compressible.hip (shared per-cell
+// functions in hydro.h), but every intermediate lives in LDS or registers:
+// HBM traffic per cell update is the algorithmic 64 B (read 4 + write 4
+// conserved doubles) plus apron re-reads that hit L2.
+//
+// Decomposition: a workgroup of BI x BJ threads owns the (BI-2) x (BJ-2)
+// interior cells of its tile; thread (ti,tj) is cell (i0-1+ti, j0-1+tj), i.e.
+// the tile grown by one cell (the region on which face states are needed,
+// SURVEY.md 7).  Phases, separated by workgroup barriers:
+//   0  stage U (tile + 4-cell apron) -> primitives Q in LDS
+//   1  per cell: flattening, limited slopes, characteristic tracing ->
+//      4 conserved face states in registers; upper states + vertex div(U)
+//      -> LDS
+//   2  transverse Riemann problems on the cell's lower faces -> LDS
+//   3  per cell: transverse correction of its own 4 states; upper states
+//      -> LDS
+//   4  final Riemann problems + artificial viscosity on the lower faces
+//      -> LDS
+//   5  conservative update of the interior cells into the second state
+//      buffer + CFL minimum of the new state
+// LDS: max(Q, fluxes) + upper states + div(U); for 16x32 threads
+// 32 + 32 + 4 KiB = 68 KiB, two workgroups (16 waves) per CU.
+//
+// Compiled twice like compressible.hip (PYRO_FAST = 0 / 1).
+#include "common.h"
+#include "hydro.h"
+#include "reduce.h"
+
+#ifndef PYRO_FAST
+#define PYRO_FAST 0
+#endif
+#if PYRO_FAST
+#define PYRO_NS fastm
+#else
+#define PYRO_NS exact
+#endif
+
+namespace pyro {
+namespace PYRO_NS {
+
+constexpr int FBI = 16;                 // threads along i (rows)
+constexpr int FBJ = 32;                 // threads along j (fast axis)
+constexpr int FNT = FBI * FBJ;          // 512
+constexpr int FTI = FBI - 2;            // interior cells per tile
+constexpr int FTJ = FBJ - 2;
+constexpr int FQH = FBI + 6;            // Q tile rows  (tile + 4 apron)
+constexpr int FQW = FBJ + 6;
+constexpr int FQN = FQH * FQW;          // cells in the Q tile
+constexpr int FBUF0 = (4 * FQN > 8 * FNT) ? 4 * FQN : 8 * FNT;   // Q | FT | F
+constexpr int FLDS_DOUBLES = FBUF0 + 8 * FNT + FNT;
+constexpr size_t FLDS_BYTES = (size_t)FLDS_DOUBLES * sizeof(double);
+
+struct FP {   // kernel parameters
+    double gamma, dx, dy, dt;
+    double z0, z1, delta, cvisc, small_dens;
+    int limiter, use_flattening;
+    int avx_hi, avy_hi;
+    int ntj, ntiles;
+};
+
+__device__ __forceinline__ ConsN to_nf(const Cons &U, bool x)
+{
+    return x ? ConsN{U.d, U.E, U.mx, U.my} : ConsN{U.d, U.E, U.my, U.mx};
+}
+__device__ __forceinline__ Cons from_nf(const ConsN &F, bool x)
+{
+    return x ? Cons{F.d, F.E, F.mn, F.mt} : Cons{F.d, F.E, F.mt, F.mn};
+}
+__device__ __forceinline__ Cons lds_get(const double *b, int t)
+{
+    return Cons{b[t], b[FNT + t], b[2 * FNT + t], b[3 * FNT + t]};
+}
+__device__ __forceinline__ void lds_put(double *b, int t, const Cons &U)
+{
+    b[t] = U.d; b[FNT + t] = U.E; b[2 * FNT + t] = U.mx; b[3 * FNT + t] = U.my;
+}
+__device__ __forceinline__ Cons corr(const Cons &U, const Cons &Fhi, const Cons &Flo, double hdtV,
+                                     double A)
+{
+    Cons r;   // U += -hdtV*(F_hi*A - F_lo*A), unsplit_fluxes.py:447-471
+    r.d = U.d + (-hdtV * (Fhi.d * A - Flo.d * A));
+    r.E = U.E + (-hdtV * (Fhi.E * A - Flo.E * A));
+    r.mx = U.mx + (-hdtV * (Fhi.mx * A - Flo.mx * A));
+    r.my = U.my + (-hdtV * (Fhi.my * A - Flo.my * A));
+    return r;
+}
+
+__global__ __launch_bounds__(FNT) void k_ctu_fused(const double *__restrict__ Uin,
+                                                   double *__restrict__ Uout, Geom g, FP P,
+                                                   int *__restrict__ flag,
+                                                   double *__restrict__ partial)
+{
+    HIP_DYNAMIC_SHARED(double, lds)
+    double *B0 = lds;                 // Q (phase 0-1) | FT (2-3) | F (4-5)
+    double *S = lds + FBUF0;          // upper face states XP(0..3), YP(4..7)
+    double *D = S + 8 * FNT;          // vertex div(U)
+
+    const int tile = xcd_tile(blockIdx.x, P.ntiles);
+    const int i0 = g.ilo + (tile / P.ntj) * FTI;
+    const int j0 = g.jlo + (tile % P.ntj) * FTJ;
+    const int tj = threadIdx.x, ti = threadIdx.y;
+    const int t = ti * FBJ + tj;
+    const int i = i0 - 1 + ti, j = j0 - 1 + tj;
+    const int p = g.pitch;
+    const size_t pl = g.plane;
+    const double gamma = P.gamma;
+
+    // ---- phase 0: U -> Q (rho,u,v,p) for the tile + 4-cell apron --------
+    bool bad = false;
+    for (int idx = t; idx < FQN; idx += FNT) {
+        const int r = idx / FQW, c = idx - r * FQW;
+        int gi = i0 - 4 + r, gj = j0 - 4 + c;
+        gi = (gi < g.qx) ? gi : g.qx - 1;   // ragged last tiles: clamp, unused
+        gj = (gj < g.qy) ? gj : g.qy - 1;
+        const size_t k = (size_t)gi * p + gj;
+        Cons U{Uin[k], Uin[pl + k], Uin[2 * pl + k], Uin[3 * pl + k]};
+        const bool interior = (gi >= g.ilo && gi <= g.ihi && gj >= g.jlo && gj <= g.jhi);
+        if (interior) U.d = fmax(U.d, P.small_dens);      // clean_state
+        bool ok;
+        const Prim q = cons_to_prim(U, gamma, &ok);
+        if (interior && !ok) bad = true;
+        B0[idx] = q.r; B0[FQN + idx] = q.u; B0[2 * FQN + idx] = q.v; B0[3 * FQN + idx] = q.p;
+    }
+    if (bad) atomicOr(flag, 1);
+    __syncthreads();
+
+    // ---- phase 1: xi, slopes, tracing for the thread's own cell --------
+    Cons XM, XP, YM, YP;
+    {
+        const int qc = (ti + 3) * FQW + (tj + 3);   // own cell in the Q tile
+        const double *Qr = B0, *Qu = B0 + FQN, *Qv = B0 + 2 * FQN, *Qp = B0 + 3 * FQN;
+        double xi = 1.0;
+        if (P.use_flattening) {
+            double xix[3], xiy[3];
+#pragma unroll
+            for (int s = -1; s <= 1; s++) {
+                const int c = qc + s * FQW;
+                xix[s + 1] = flatten_1d(Qp[c - 2 * FQW], Qp[c - FQW], Qp[c + FQW], Qp[c + 2 * FQW],
+                                        Qu[c - FQW], Qu[c + FQW], P.z0, P.z1, P.delta);
+                const int d = qc + s;
+                xiy[s + 1] = flatten_1d(Qp[d - 2], Qp[d - 1], Qp[d + 1], Qp[d + 2], Qv[d - 1],
+                                        Qv[d + 1], P.z0, P.z1, P.delta);
+            }
+            const double px = (Qp[qc + FQW] - Qp[qc - FQW] > 0) ? xix[0] : xix[2];
+            const double py = (Qp[qc + 1] - Qp[qc - 1] > 0) ? xiy[0] : xiy[2];
+            xi = fmin(fmin(xix[1], px), fmin(xiy[1], py));
+        }
+        double q0[4], dqx[4], dqy[4];
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const double *a = B0 + n * FQN;
+            q0[n] = a[qc];
+            dqx[n] = xi * limited_slope(a[qc - 2 * FQW], a[qc - FQW], a[qc], a[qc + FQW],
+                                        a[qc + 2 * FQW], P.limiter);
+            dqy[n] = xi * limited_slope(a[qc - 2], a[qc - 1], a[qc], a[qc + 1], a[qc + 2],
+                                        P.limiter);
+        }
+        Trace lo, hi;
+        trace_states(q0[0], q0[1], q0[2], q0[3], dqx[0], dqx[1], dqx[2], dqx[3], gamma,
+                     P.dt / P.dx, lo, hi);
+        XM = prim_to_cons(Prim{lo.r, lo.un, lo.ut, lo.p}, gamma);
+        XP = prim_to_cons(Prim{hi.r, hi.un, hi.ut, hi.p}, gamma);
+        trace_states(q0[0], q0[2], q0[1], q0[3], dqy[0], dqy[2], dqy[1], dqy[3], gamma,
+                     P.dt / P.dy, lo, hi);
+        YM = prim_to_cons(Prim{lo.r, lo.ut, lo.un, lo.p}, gamma);
+        YP = prim_to_cons(Prim{hi.r, hi.ut, hi.un, hi.p}, gamma);
+        // vertex divergence at (i-1/2, j-1/2), interface.py:312-330
+        D[t] = div_u_vertex(Qu[qc], Qu[qc - 1], Qu[qc - FQW], Qu[qc - FQW - 1], Qv[qc],
+                            Qv[qc - FQW], Qv[qc - 1], Qv[qc - FQW - 1], P.dx, P.dy);
+        lds_put(S, t, XP);
+        lds_put(S + 4 * FNT, t, YP);
+    }
+    __syncthreads();   // Q is dead from here on; B0 becomes the flux buffer
+
+    // ---- phase 2: transverse Riemann problems on the lower faces --------
+    Cons FxT{0, 0, 0, 0}, FyT{0, 0, 0, 0};
+    if (ti >= 1)
+        FxT = from_nf(hllc_flux(to_nf(lds_get(S, t - FBJ), true), to_nf(XM, true), gamma, true),
+                      true);
+    if (tj >= 1)
+        FyT = from_nf(hllc_flux(to_nf(lds_get(S + 4 * FNT, t - 1), false), to_nf(YM, false), gamma,
+                                false), false);
+    lds_put(B0, t, FxT);
+    lds_put(B0 + 4 * FNT, t, FyT);
+    __syncthreads();
+
+    // ---- phase 3: transverse correction of the cell's own states --------
+    const double hdtV = (0.5 * P.dt) / (P.dx * P.dy);   // hdt / V
+    const double Ax = P.dy, Ay = P.dx;
+    if (tj >= 1 && tj <= FBJ - 2) {
+        const Cons Fhi = lds_get(B0 + 4 * FNT, t + 1);   // F_yT at (i, j+1)
+        XM = corr(XM, Fhi, FyT, hdtV, Ay);
+        XP = corr(XP, Fhi, FyT, hdtV, Ay);
+    }
+    if (ti >= 1 && ti <= FBI - 2) {
+        const Cons Fhi = lds_get(B0, t + FBJ);           // F_xT at (i+1, j)
+        YM = corr(YM, Fhi, FxT, hdtV, Ax);
+        YP = corr(YP, Fhi, FxT, hdtV, Ax);
+    }
+    // (all reads of the uncorrected upper states happened before the barrier
+    // that closed phase 2; phase 3 itself only reads the flux buffer)
+    lds_put(S, t, XP);
+    lds_put(S + 4 * FNT, t, YP);
+    __syncthreads();
+
+    // ---- phase 4: final Riemann problems + artificial viscosity ---------
+    const bool in_arr = (i < g.qx && j < g.qy);
+    const size_t k = (size_t)(in_arr ? i : g.qx - 1) * p + (in_arr ? j : g.qy - 1);
+    Cons Uc{Uin[k], Uin[pl + k], Uin[2 * pl + k], Uin[3 * pl + k]};
+    const bool cell_interior = (i >= g.ilo && i <= g.ihi && j >= g.jlo && j <= g.jhi);
+    if (cell_interior) Uc.d = fmax(Uc.d, P.small_dens);
+    Cons Fx{0, 0, 0, 0}, Fy{0, 0, 0, 0};
+    const double d00 = D[t];
+    if (ti >= 1 && tj >= 1 && tj <= FBJ - 2) {           // x face (i, j)
+        Fx = from_nf(hllc_flux(to_nf(lds_get(S, t - FBJ), true), to_nf(XM, true), gamma, true),
+                     true);
+        double avx = 0.0;
+        // interface.py:366-376: only faces i in [ilo, ihi], j in [jlo, jhi]
+        if (i >= g.ilo && (i <= g.ihi || (P.avx_hi && i == g.ihi + 1)) && j >= g.jlo &&
+            j <= g.jhi) {
+            const double divU_x = 0.5 * (d00 + D[t + 1]);
+            avx = P.cvisc * fmax(-divU_x * P.dx, 0.0);
+        }
+        Cons Um{Uin[k - p], Uin[pl + k - p], Uin[2 * pl + k - p], Uin[3 * pl + k - p]};
+        if (i - 1 >= g.ilo && i - 1 <= g.ihi && j >= g.jlo && j <= g.jhi)
+            Um.d = fmax(Um.d, P.small_dens);
+        Fx.d += avx * (Um.d - Uc.d);
+        Fx.E += avx * (Um.E - Uc.E);
+        Fx.mx += avx * (Um.mx - Uc.mx);
+        Fx.my += avx * (Um.my - Uc.my);
+    }
+    if (tj >= 1 && ti >= 1 && ti <= FBI - 2) {           // y face (i, j)
+        Fy = from_nf(hllc_flux(to_nf(lds_get(S + 4 * FNT, t - 1), false), to_nf(YM, false), gamma,
+                               false), false);
+        double avy = 0.0;
+        if (j >= g.jlo && (j <= g.jhi || (P.avy_hi && j == g.jhi + 1)) && i >= g.ilo &&
+            i <= g.ihi) {
+            const double divU_y = 0.5 * (d00 + D[t + FBJ]);
+            avy = P.cvisc * fmax(-divU_y * P.dy, 0.0);
+        }
+        Cons Um{Uin[k - 1], Uin[pl + k - 1], Uin[2 * pl + k - 1], Uin[3 * pl + k - 1]};
+        if (i >= g.ilo && i <= g.ihi && j - 1 >= g.jlo && j - 1 <= g.jhi)
+            Um.d = fmax(Um.d, P.small_dens);
+        Fy.d += avy * (Um.d - Uc.d);
+        Fy.E += avy * (Um.E - Uc.E);
+        Fy.mx += avy * (Um.mx - Uc.mx);
+        Fy.my += avy * (Um.my - Uc.my);
+    }
+    lds_put(B0, t, Fx);            // FT was last read before the barrier above
+    lds_put(B0 + 4 * FNT, t, Fy);
+    __syncthreads();
+
+    // ---- phase 5: conservative update + CFL of the new state -----------
+    double cfl = INFINITY;
+    if (ti >= 1 && ti <= FBI - 2 && tj >= 1 && tj <= FBJ - 2 && cell_interior) {
+        const double dtdV = P.dt / (P.dx * P.dy);
+        const Cons Fxh = lds_get(B0, t + FBJ);
+        const Cons Fyh = lds_get(B0 + 4 * FNT, t + 1);
+        Cons Un;   // simulation.py:377-384
+        Un.d = Uc.d + dtdV * (Fx.d * Ax - Fxh.d * Ax + Fy.d * Ay - Fyh.d * Ay);
+        Un.E = Uc.E + dtdV * (Fx.E * Ax - Fxh.E * Ax + Fy.E * Ay - Fyh.E * Ay);
+        Un.mx = Uc.mx + dtdV * (Fx.mx * Ax - Fxh.mx * Ax + Fy.mx * Ay - Fyh.mx * Ay);
+        Un.my = Uc.my + dtdV * (Fx.my * Ax - Fxh.my * Ax + Fy.my * Ay - Fyh.my * Ay);
+        Uout[k] = Un.d; Uout[pl + k] = Un.E; Uout[2 * pl + k] = Un.mx; Uout[3 * pl + k] = Un.my;
+        cfl = cfl_cell(Un, gamma, P.dx, P.dy);
+    }
+    cfl = block_reduce_min(cfl);
+    if (t == 0) partial[tile] = cfl;
+}
+
+// ghost frame of all 4 planes old -> new (the reference updates in place, so
+// ghost cells keep their pre-step values)
+__global__ void k_copy_frame4(const double *__restrict__ src, double *__restrict__ dst, Geom g)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= g.qy || i >= g.qx) return;
+    if (i >= g.ilo && i <= g.ihi && j >= g.jlo && j <= g.jhi) return;
+    const size_t k = (size_t)i * g.pitch + j;
+#pragma unroll
+    for (int n = 0; n < 4; n++) dst[n * g.plane + k] = src[n * g.plane + k];
+}
+
+__global__ void k_min_final_f(const double *__restrict__ partial, int nb, double *__restrict__ out)
+{
+    double m = INFINITY;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) m = fmin(m, partial[b]);
+    m = block_reduce_min(m);
+    if (threadIdx.x == 0) out[0] = m;
+}
+
+int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    // second state buffer
+    if (!s->alt_base) {
+        size_t n = g.plane * 4 + 16;
+        PYRO_CHECK_HIP(hipMalloc((void **)&s->alt_base, n * sizeof(double)));
+        PYRO_CHECK_HIP(hipMemsetAsync(s->alt_base, 0, n * sizeof(double), c->stream));
+    }
+    double *Uin = s->d;
+    double *Uout = s->alt_base + geom_lead(g);
+    FP P;
+    P.gamma = p->gamma; P.dx = p->dx; P.dy = p->dy; P.dt = dt;
+    P.z0 = p->z0; P.z1 = p->z1; P.delta = p->delta; P.cvisc = p->cvisc;
+    P.small_dens = p->small_dens;
+    P.limiter = p->limiter; P.use_flattening = p->use_flattening;
+    P.avx_hi = p->avisc_xhi_interior; P.avy_hi = p->avisc_yhi_interior;
+    const int nti = (g.nx + FTI - 1) / FTI;
+    P.ntj = (g.ny + FTJ - 1) / FTJ;
+    P.ntiles = nti * P.ntj;
+    PYRO_TRY(c->reduce.ensure((P.ntiles + 2) * sizeof(double)));
+    double *part = (double *)c->reduce.p;
+    PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
+#ifndef PYRO_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_ctu_fused,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)FLDS_BYTES));
+        attr_set = true;
+    }
+#endif
+    PYRO_LAUNCH(c, "k_ctu_fused", k_ctu_fused, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
+                (const double *)Uin, Uout, g, P, s->d_flag, part);
+    hipLaunchKernelGGL(k_copy_frame4, dim3((g.qy + 255) / 256, g.qx), dim3(256), 0, c->stream,
+                       (const double *)Uin, Uout, g);
+    hipLaunchKernelGGL(k_min_final_f, dim3(1), dim3(256), 0, c->stream, (const double *)part,
+                       P.ntiles, part + P.ntiles);
+    PYRO_CHECK_HIP(hipGetLastError());
+    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, part + P.ntiles, sizeof(double),
+                                  hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipMemcpyAsync((char *)c->reduce_host + 8, s->d_flag, sizeof(int),
+                                  hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    const int flagv = *(int *)((char *)c->reduce_host + 8);
+    if (flagv & 1) {   // like the reference's assert: the state is left untouched
+        s->next_cfl_min = -1.0;
+        set_error("invalid state: min(rho) <= 0 or min(e) <= 0 on the interior "
+                  "(compressible/simulation.py:68-71)");
+        return PYROHIP_ERR_STATE;
+    }
+    // swap the two state buffers
+    double *old_base = s->base;
+    s->base = s->alt_base;
+    s->alt_base = old_base;
+    s->d = s->base + geom_lead(g);
+    s->next_cfl_min = ((double *)c->reduce_host)[0];
+    return 0;
+}
+
+}  // namespace PYRO_NS
+}  // namespace pyro

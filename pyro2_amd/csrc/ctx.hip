@@ -323,6 +323,7 @@ int pyrohip_state_destroy(pyrohip_state *s)
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->base) (void)hipFree(s->base);
+    if (s->alt_base) (void)hipFree(s->alt_base);
     if (s->d_bc) (void)hipFree(s->d_bc);
     if (s->d_flag) (void)hipFree(s->d_flag);
     if (s->work) (void)hipFree(s->work);

@@ -84,6 +84,34 @@ def test_comp_stages_vs_reference(dev, golden, k):
     assert np.array_equal(U1[m], g[f"c{k}_U1"][m])
 
 
+@pytest.mark.parametrize("k", range(7))
+def test_comp_fused_vs_reference(dev, golden, k):
+    """kernel_set 1 (single fused LDS kernel): one step from a reference
+    state, end state against the reference's own evolve(); then the cached
+    CFL minimum against the oracle's next time step"""
+    g = golden("comp_stages")
+    bcs = [str(b) for b in g[f"c{k}_bc"]]
+    meta = g[f"c{k}_meta"]
+    P, cfl = dev_params(meta, kernel_set=1)
+    nx, ny, ng = int(meta[0]), int(meta[1]), int(meta[2])
+    s = comp_state(dev, nx, ny, bcs)
+    s.upload(g[f"c{k}_U0"])
+    tol = 0.0 if dev.kind == "emu" else TOL_EXACT
+    s.comp_step(P, float(g[f"c{k}_dt"]))
+    U1 = s.download()
+    ref = g[f"c{k}_U1"]
+    assert max_rel_err(R(U1, ng, 0), R(ref, ng, 0)) <= tol, k
+    m = np.ones(U1.shape[:2], bool)
+    m[ng:-ng, ng:-ng] = False
+    assert np.array_equal(U1[m], ref[m])
+    # next dt: cached interior minimum == full-array minimum after a fill
+    Uo = ref.copy()
+    orc.comp_fill_bc(Uo, nx, ny, ng, bcs)
+    dto = orc.comp_dt(Uo, nx, ny, ng, meta[3], meta[4], meta[5], cfl)
+    s.fill_bc()
+    assert abs(s.comp_dt(P, cfl) - dto) <= tol * dto
+
+
 def device_comp_run(dev, ic, meta, bcs, tmax, max_steps, **kw):
     """Pyro.run_sim loop (pyro_sim.py:219-256) with the device kernels"""
     P, cfl = dev_params(meta, **kw)
@@ -101,12 +129,13 @@ def device_comp_run(dev, ic, meta, bcs, tmax, max_steps, **kw):
     return s.download(), np.array(dts), pol.t
 
 
-def test_comp_sedov_64(dev, golden):
+@pytest.mark.parametrize("kset", [0, 1])
+def test_comp_sedov_64(dev, golden, kset):
     """sedov 64^2 (SURVEY 8(c) fingerprint): 20 steps on the GPU, 6 on emu"""
     g = golden("comp_sedov_64_020")
     bcs = [str(b) for b in g["bc"]]
     nsteps = 20 if dev.kind == "hip" else 6
-    U, dts, t = device_comp_run(dev, g["ic"], g["meta"], bcs, 0.1, nsteps)
+    U, dts, t = device_comp_run(dev, g["ic"], g["meta"], bcs, 0.1, nsteps, kernel_set=kset)
     tol = 0.0 if dev.kind == "emu" else TOL_EXACT * nsteps
     assert max_rel_err(dts, g["dts"][:nsteps]) <= tol
     if nsteps == 20:
@@ -117,14 +146,15 @@ def test_comp_sedov_64(dev, golden):
         assert max_rel_err(U[4:-4, 4:-4], Uo[4:-4, 4:-4]) <= tol
 
 
-def test_comp_positivity_error(dev, golden):
+@pytest.mark.parametrize("kset", [0, 1])
+def test_comp_positivity_error(dev, golden, kset):
     """negative internal energy -> PYROHIP_ERR_STATE, like the reference's
     assert (compressible/simulation.py:68-71)"""
     from pyro2_amd._lib import ERR_STATE, PyroHipError
     g = golden("comp_sedov_64_020")
     U = g["ic"].copy()
     U[30, 30, 1] = -1.0
-    P, cfl = dev_params(g["meta"])
+    P, cfl = dev_params(g["meta"], kernel_set=kset)
     s = comp_state(dev, 64, 64, [str(b) for b in g["bc"]])
     s.upload(U)
     with pytest.raises(PyroHipError) as ei:
@@ -133,24 +163,27 @@ def test_comp_positivity_error(dev, golden):
 
 
 @pytest.mark.gpu
-def test_comp_reference_regression_sod_x(hip, golden):
+@pytest.mark.parametrize("kset", [0, 1])
+def test_comp_reference_regression_sod_x(hip, golden, kset):
     """pyro/test.py:101 -- sod_x_0076.h5 (128x10, limiter 1, reflect y)"""
     g = golden("comp_sod_x_0076")
     bcs = [str(b) for b in g["bc"]]
-    U, dts, t = device_comp_run(hip, g["ic"], g["meta"], bcs, float(g["tmax"]), 200)
+    U, dts, t = device_comp_run(hip, g["ic"], g["meta"], bcs, float(g["tmax"]), 200,
+                                kernel_set=kset)
     assert len(dts) == 76
     for n in range(3):
         assert max_rel_err(U[4:-4, 4:-4, n], g["gold"][..., n]) < 1e-12
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kset", [0, 1])
 @pytest.mark.parametrize("fast", [0, 1])
-def test_comp_reference_regression_quad(hip, golden, fast):
+def test_comp_reference_regression_quad(hip, golden, fast, kset):
     """pyro/test.py:100 -- quad_unsplit_0606.h5 (256^2, 606 steps)"""
     g = golden("comp_quad_0606")
     bcs = [str(b) for b in g["bc"]]
     U, dts, t = device_comp_run(hip, g["ic"], g["meta"], bcs, float(g["tmax"]), 1000,
-                                fast_math=fast)
+                                fast_math=fast, kernel_set=kset)
     assert len(dts) == 606
     for n in range(4):
         e = max_rel_err(U[4:-4, 4:-4, n], g["gold"][..., n])
@@ -158,8 +191,9 @@ def test_comp_reference_regression_quad(hip, golden, fast):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kset", [0, 1])
 @pytest.mark.parametrize("fast", [0, 1])
-def test_comp_sedov_512_vs_oracle(hip, fast):
+def test_comp_sedov_512_vs_oracle(hip, fast, kset):
     """sedov at 512^2 (inputs.sedov physics), 30 steps, against the oracle on
     identical inputs; 1e-10 is the north_star tolerance"""
     from sedov_ic import sedov_ic
@@ -167,7 +201,7 @@ def test_comp_sedov_512_vs_oracle(hip, fast):
     ic, meta, bcs = sedov_ic(nx)
     from helpers import oracle_comp_run
     Uo, dto, _ = oracle_comp_run(ic, meta, bcs, 0.1, 30)
-    U, dts, _ = device_comp_run(hip, ic, meta, bcs, 0.1, 30, fast_math=fast)
+    U, dts, _ = device_comp_run(hip, ic, meta, bcs, 0.1, 30, fast_math=fast, kernel_set=kset)
     tol = TOL_FAST if fast else 1e-12
     assert max_rel_err(dts, dto) <= tol
     for n in range(4):
