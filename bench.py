@@ -94,48 +94,33 @@ def kernel_table(prof, nlaunch_unit):
 
 
 def bench_sedov(args, dist, ctx, device, defaults):
-    from pyro2_amd.decomp import SlabDecomp
-    from helpers import DtPolicy
-    from sedov_ic import sedov_ic
+    from pyro2_amd.compressible.problems.sedov import sedov_state
+    from pyro2_amd.decomp import DtPolicy, NoComm, RcclComm, SlabCompressible, SlabDecomp
     nx = ny = args.nx
     ng = 4
     dec = SlabDecomp(nx, dist.world, dist.rank, periodic=False)
-    bcs = ["outflow"] * 4
-    st = device.DeviceState(ctx, dec.nx_local, ny, ng, dec.comp_var_bcs(bcs))
-    # initial condition: generated slab by slab on the host (never more than
-    # 512 rows in memory), uploaded before the timed region
+    comm = RcclComm(ctx) if dist.world > 1 else NoComm()
+    kw = dict(dx=1.0 / nx, dy=1.0 / ny, fast_math=defaults["fast_math"],
+              kernel_set=defaults["kernel_set"])
+    slab = SlabCompressible(ctx, dec, ny, ["outflow"] * 4, kw, comm, ng=ng)
+    st = slab.state
+    # initial condition (inputs.sedov): generated slab by slab on the host (never
+    # more than 512 rows in memory), resident in HBM before the timed region
     chunk = 512
-    meta = None
     for r0 in range(0, dec.nx_local + 2 * ng, chunk):
         nr = min(chunk, dec.nx_local + 2 * ng - r0)
-        U, meta, _ = sedov_ic(nx, ny, ng=ng, i0=dec.i0 + r0, ni=nr)
-        st.upload_rows(r0, U)
-    dx, dy = meta[3], meta[4]
-    P = device.make_comp_params(dx, dy, fast_math=defaults["fast_math"],
-                                kernel_set=defaults["kernel_set"],
-                                avisc_xhi_interior=int(dec.hi >= 0))
+        st.upload_rows(r0, sedov_state(nx, ny, ng, 0.0, 1.0, 0.0, 1.0, 1.4, 0.01, 4,
+                                       i0=dec.i0 + r0, ni=nr))
     pol = DtPolicy(tmax=0.1)
-
-    def step():
-        if dist.world > 1:
-            st.halo_exchange(dec.lo, dec.hi)
-        st.fill_bc()
-        dtm = st.comp_dt(P, 0.8)
-        if dist.world > 1:
-            dtm = ctx.allreduce_min(dtm)
-        dt = pol(dtm)
-        st.comp_step(P, dt)
-        pol.advance(dt)
-
     for _ in range(args.warmup):
-        step()
+        slab.step(pol, 0.8)
     ctx.sync()
     dist.barrier()
     ctx.prof_enable(True)
     ctx.timer_start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        slab.step(pol, 0.8)
     ctx.sync()
     t1 = time.perf_counter()
     ev_ms = ctx.timer_stop()
@@ -143,10 +128,9 @@ def bench_sedov(args, dist, ctx, device, defaults):
     ctx.prof_enable(False)
     dist.barrier()
     elapsed = dist.max(t1 - t0)
-    cells = float(nx) * ny
-    res = {"elapsed": elapsed, "cells": cells, "prof": prof, "event_ms": ev_ms,
+    res = {"elapsed": elapsed, "cells": float(nx) * ny, "prof": prof, "event_ms": ev_ms,
            "t": pol.t, "dt": pol.dt_old, "local_cells": float(dec.nx_local) * ny}
-    del st
+    del slab, st
     return res
 
 
@@ -256,8 +240,8 @@ def main():
         uid = device.Context.comm_unique_id() if dist.rank == 0 else b""
         uid = dist.bcast_bytes(uid, 128)
         ctx.comm_init(world, dist.rank, uid)
-    defaults = {"fast_math": 1 if args.fast_math is None else args.fast_math,
-                "kernel_set": 0 if args.kernel_set is None else args.kernel_set}
+    defaults = {"fast_math": 0 if args.fast_math is None else args.fast_math,
+                "kernel_set": 1 if args.kernel_set is None else args.kernel_set}
     try:
         import torch
         if torch.cuda.is_available():

@@ -1,0 +1,65 @@
+"""advection.Simulation with the call surface of
+pyro/advection/simulation.py:12-94; evolve() is one launch of the fused
+LDS-tiled kernel (pyrohip_adv_step)."""
+from ..mesh import patch
+from ..simulation_null import NullSimulation, bc_setup, grid_setup
+from ..util import msg
+
+
+class Simulation(NullSimulation):
+    def initialize(self):
+        """grid (ng = 4, advection/simulation.py:20), the single variable
+        "density", then the problem's initial condition"""
+        my_grid = grid_setup(self.rp, ng=4)
+        my_data = patch.CellCenterData2d(my_grid)
+        bc = bc_setup(self.rp)[0]
+        my_data.register_var("density", bc)
+        my_data.create()
+        self.cc_data = my_data
+        if self.rp.get_param("particles.do_particles") == 1:
+            msg.warning("particles are host-side post-processing in pyro and are not "
+                        "carried by the device path; ignoring particles.do_particles")
+        self.problem_func(self.cc_data, self.rp)
+
+    def method_compute_timestep(self):
+        """closed-form advective CFL step (advection/simulation.py:38-54);
+        nothing to reduce"""
+        cfl = self.rp.get_param("driver.cfl")
+        u = self.rp.get_param("advection.u")
+        v = self.rp.get_param("advection.v")
+        g = self.cc_data.grid
+        xtmp = g.dx / max(abs(u), self.SMALL)
+        ytmp = g.dy / max(abs(v), self.SMALL)
+        self.dt = cfl * min(xtmp, ytmp)
+
+    def evolve(self):
+        """one time step of "density" on the device"""
+        tm = self.tc.timer("evolve")
+        tm.begin()
+        g = self.cc_data.grid
+        st = self.cc_data.device_state()
+        st.adv_step(self.cc_data.names.index("density"), g.dx, g.dy,
+                    float(self.rp.get_param("advection.u")),
+                    float(self.rp.get_param("advection.v")), float(self.dt),
+                    int(self.rp.get_param("advection.limiter")))
+        self.cc_data.device_modified()
+        self.cc_data.t += self.dt
+        self.n += 1
+        tm.end()
+
+    def dovis(self):
+        """runtime plot of the density (same picture as the reference's dovis)"""
+        import matplotlib.pyplot as plt
+        import numpy as np
+        plt.clf()
+        dens = self.cc_data.get_var("density")
+        g = self.cc_data.grid
+        img = plt.imshow(np.transpose(dens.v()), interpolation="nearest", origin="lower",
+                         extent=[g.xmin, g.xmax, g.ymin, g.ymax], cmap=self.cm)
+        plt.xlabel("x")
+        plt.ylabel("y")
+        plt.colorbar(img)
+        plt.title("density")
+        plt.figtext(0.05, 0.0125, f"t = {self.cc_data.t:10.5f}")
+        plt.pause(0.001)
+        plt.draw()

@@ -1,0 +1,15 @@
+"""uniform state for unit tests (reference: compressible/problems/test.py)"""
+DEFAULT_INPUTS = None
+PROBLEM_PARAMS = {}
+
+
+def init_data(my_data, rp):
+    del rp
+    my_data.get_var("density")[:, :] = 1.0
+    my_data.get_var("x-momentum")[:, :] = 0.0
+    my_data.get_var("y-momentum")[:, :] = 0.0
+    my_data.get_var("energy")[:, :] = 2.5
+
+
+def finalize():
+    pass

@@ -1,0 +1,150 @@
+"""compressible.Simulation with the call surface of
+pyro/compressible/simulation.py:12-553.
+
+evolve() = pyrohip_comp_step (interface states, HLLC Riemann problems,
+transverse correction, artificial viscosity, conservative update in HIP);
+method_compute_timestep() = pyrohip_comp_dt (device min-reduction, 8 bytes
+D2H).  Scope of the device path: Cartesian
+grid, HLLC, gamma-law gas, limiter 0/1/2, flattening, artificial viscosity,
+grav = 0, standard boundary types.
+"""
+import numpy as np
+
+from .. import device
+from ..mesh import boundary as bnd
+from ..simulation_null import NullSimulation, bc_setup, grid_setup
+from ..util import msg
+from . import derives, eos
+
+
+class Variables:
+    """integer keys of the conserved / primitive components
+    (compressible/simulation.py:12-46)"""
+
+    def __init__(self, myd):
+        self.nvar = len(myd.names)
+        self.idens = myd.names.index("density")
+        self.ixmom = myd.names.index("x-momentum")
+        self.iymom = myd.names.index("y-momentum")
+        self.iener = myd.names.index("energy")
+        self.naux = self.nvar - 4
+        self.irhox = 4 if self.naux > 0 else -1
+        self.nq = 4 + self.naux
+        self.irho, self.iu, self.iv, self.ip = 0, 1, 2, 3
+        self.ix = 4 if self.naux > 0 else -1
+
+
+def cons_to_prim(U, gamma, ivars, myg):
+    """host-side conversion for analysis scripts (the device kernels do their
+    own); same formulas as compressible/simulation.py:49-80"""
+    q = myg.scratch_array(nvar=ivars.nq)
+    rho = U[:, :, ivars.idens]
+    ok = rho != 0.0
+    q[:, :, ivars.irho] = rho
+    q[:, :, ivars.iu] = np.divide(U[:, :, ivars.ixmom], rho, out=np.zeros_like(rho), where=ok)
+    q[:, :, ivars.iv] = np.divide(U[:, :, ivars.iymom], rho, out=np.zeros_like(rho), where=ok)
+    e = np.divide(U[:, :, ivars.iener] - 0.5 * rho * (q[:, :, ivars.iu]**2 + q[:, :, ivars.iv]**2),
+                  rho, out=np.zeros_like(rho), where=ok)
+    q[:, :, ivars.ip] = eos.pres(gamma, rho, e)
+    return q
+
+
+def prim_to_cons(q, gamma, ivars, myg):
+    U = myg.scratch_array(nvar=ivars.nvar)
+    U[:, :, ivars.idens] = q[:, :, ivars.irho]
+    U[:, :, ivars.ixmom] = q[:, :, ivars.iu] * U[:, :, ivars.idens]
+    U[:, :, ivars.iymom] = q[:, :, ivars.iv] * U[:, :, ivars.idens]
+    U[:, :, ivars.iener] = eos.rhoe(gamma, q[:, :, ivars.ip]) + \
+        0.5 * q[:, :, ivars.irho] * (q[:, :, ivars.iu]**2 + q[:, :, ivars.iv]**2)
+    return U
+
+
+class Simulation(NullSimulation):
+    def initialize(self, *, extra_vars=None, ng=4):
+        my_grid = grid_setup(self.rp, ng=ng)
+        my_data = self.data_class(my_grid)
+        riemann_method = self.rp.get_param("compressible.riemann")
+        if riemann_method != "HLLC":
+            msg.fail("ERROR: the device path implements compressible.riemann = HLLC only "
+                     "(CGF / HLLC_lm: SURVEY.md 8 row f2)")
+        bc, bc_xodd, bc_yodd = bc_setup(self.rp)
+        self.solid = bnd.bc_is_solid(bc)
+        # same registration order as compressible/simulation.py:223-226
+        my_data.register_var("density", bc)
+        my_data.register_var("energy", bc)
+        my_data.register_var("x-momentum", bc_xodd)
+        my_data.register_var("y-momentum", bc_yodd)
+        if extra_vars:
+            msg.fail("ERROR: passive scalars are not carried by the device path yet")
+        my_data.set_aux("gamma", self.rp.get_param("eos.gamma"))
+        my_data.set_aux("grav", self.rp.get_param("compressible.grav"))
+        my_data.create()
+        self.cc_data = my_data
+        self.ivars = Variables(my_data)
+        self.cc_data.add_derived(derives.derive_primitives)
+        self.problem_func(self.cc_data, self.rp)
+        if self.verbose > 0:
+            print(my_data)
+
+    def _params(self):
+        rp, g = self.rp, self.cc_data.grid
+
+        def opt(key, default):
+            try:
+                return rp.get_param(key)
+            except KeyError:
+                return default
+        return device.make_comp_params(
+            g.dx, g.dy, gamma=rp.get_param("eos.gamma"),
+            limiter=rp.get_param("compressible.limiter"),
+            use_flattening=rp.get_param("compressible.use_flattening"),
+            z0=rp.get_param("compressible.z0"), z1=rp.get_param("compressible.z1"),
+            delta=rp.get_param("compressible.delta"), cvisc=rp.get_param("compressible.cvisc"),
+            grav=rp.get_param("compressible.grav"),
+            small_dens=rp.get_param("compressible.small_dens"),
+            fast_math=opt("gpu.fast_math", 0), kernel_set=opt("gpu.kernel_set", 1))
+
+    def method_compute_timestep(self):
+        """cfl * min(dx/(|u|+c), dy/(|v|+c)) over the whole array
+        (compressible/simulation.py:267-288), reduced on the device"""
+        cfl = self.rp.get_param("driver.cfl")
+        self.dt = self.cc_data.device_state().comp_dt(self._params(), float(cfl))
+
+    def evolve(self):
+        tm = self.tc.timer("evolve")
+        tm.begin()
+        if self.rp.get_param("sponge.do_sponge"):
+            msg.fail("ERROR: sponge.do_sponge is not implemented on the device path")
+        st = self.cc_data.device_state()
+        st.comp_step(self._params(), float(self.dt))
+        self.cc_data.device_modified()
+        self.cc_data.t += self.dt
+        self.n += 1
+        tm.end()
+
+    def clean_state(self, U):
+        """density floor on a host array (the device step applies it itself)"""
+        U.v(n=self.ivars.idens)[:, :] = np.maximum(U.v(n=self.ivars.idens),
+                                                   self.rp.get_param("compressible.small_dens"))
+
+    def write_extras(self, f):
+        """the BC group of compressible/simulation.py:543-553"""
+        gb = f.create_group("BC")
+        gb.create_dataset("hse", data=np.array([], dtype=np.float64))
+
+    def dovis(self):
+        import matplotlib.pyplot as plt
+        plt.clf()
+        g = self.cc_data.grid
+        rho, u, v, p = self.cc_data.get_var("primitive")
+        fields = [rho, np.sqrt(u**2 + v**2), p, p / ((self.rp.get_param("eos.gamma") - 1.0) * rho)]
+        names = [r"$\rho$", "U", "p", "e"]
+        for n, (f, nm) in enumerate(zip(fields, names)):
+            ax = plt.subplot(2, 2, n + 1)
+            img = ax.imshow(np.transpose(f.v()), interpolation="nearest", origin="lower",
+                            extent=[g.xmin, g.xmax, g.ymin, g.ymax], cmap=self.cm)
+            ax.set_title(nm)
+            plt.colorbar(img, ax=ax)
+        plt.figtext(0.05, 0.0125, f"t = {self.cc_data.t:10.5f}")
+        plt.pause(0.001)
+        plt.draw()

@@ -60,3 +60,77 @@ class SlabDecomp:
     def local_rows(self, ng):
         """global array rows [a, b) held by this rank incl. ghosts"""
         return self.i0, self.i0 + self.nx_local + 2 * ng
+
+
+class RcclComm:
+    """data-path communication of the product: RCCL inside libpyrohip
+    (csrc/comm.hip) on the context's stream"""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def halo_exchange(self, state, lo, hi):
+        state.halo_exchange(lo, hi)
+
+    def allreduce_min(self, x):
+        return self.ctx.allreduce_min(x)
+
+
+class NoComm:
+    """single rank"""
+
+    def halo_exchange(self, state, lo, hi):
+        pass
+
+    def allreduce_min(self, x):
+        return x
+
+
+class SlabCompressible:
+    """Pyro.single_step for one x-slab of a decomposed compressible run:
+    halo exchange -> y / physical ghost fill -> global CFL dt -> evolve.
+
+    The driver's dt policy (simulation_null.py:222-244) is applied to the
+    GLOBAL minimum, so every rank takes the same step."""
+
+    def __init__(self, ctx, decomp, ny, bcs, params_kw, comm, ng=4):
+        from . import device
+        self.dec, self.comm = decomp, comm
+        self.state = device.DeviceState(ctx, decomp.nx_local, ny, ng, decomp.comp_var_bcs(bcs))
+        kw = dict(params_kw)
+        kw["avisc_xhi_interior"] = int(decomp.hi >= 0)
+        self.params = device.make_comp_params(**kw)
+
+    def step(self, policy, cfl):
+        self.comm.halo_exchange(self.state, self.dec.lo, self.dec.hi)
+        self.state.fill_bc()
+        dt = policy(self.comm.allreduce_min(self.state.comp_dt(self.params, cfl)))
+        self.state.comp_step(self.params, dt)
+        policy.advance(dt)
+        return dt
+
+
+class DtPolicy:
+    """driver time-step policy, pyro/simulation_null.py:222-244: first step
+    scaled by init_tstep_factor, growth capped by max_dt_change, last step
+    clipped to land on tmax"""
+
+    def __init__(self, tmax, init_tstep_factor=0.01, max_dt_change=2.0, fix_dt=-1.0):
+        self.tmax, self.f0, self.mx, self.fix = tmax, init_tstep_factor, max_dt_change, fix_dt
+        self.n, self.t, self.dt_old = 0, 0.0, -1.e33
+
+    def __call__(self, dt_method):
+        if self.fix > 0.0:
+            dt = self.fix
+        else:
+            dt = dt_method if self.n else self.f0 * dt_method
+            if self.n:
+                dt = min(self.mx * self.dt_old, dt)
+            self.dt_old = dt
+        if self.t + dt > self.tmax:
+            dt = self.tmax - self.t
+        return dt
+
+    def advance(self, dt):
+        self.t += dt
+        self.n += 1

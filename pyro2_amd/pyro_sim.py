@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""The driver: `Pyro(solver).initialize_problem(problem, ...)`, `run_sim()`,
+`single_step()` and the `pyro_sim.py solver problem inputs` command line, with
+the surface of pyro/pyro_sim.py:33-456.
+
+single_step() is the hot path (pyro_sim.py:241-281):
+    cc_data.fill_BC_all()  ->  compute_timestep()  ->  evolve()
+all three run on the GPU; only dt (8 bytes) comes back per step.
+"""
+import argparse
+import importlib
+import os
+
+from .util import msg
+from .util import profile_pyro as profile
+from .util.runparams import RuntimeParameters, _get_val
+
+# solvers with a device implementation in this package; the reference's other
+# solvers are out of scope
+valid_solvers = ["advection", "compressible"]
+
+
+class Pyro:
+    def __init__(self, solver_name, *, from_commandline=False):
+        if from_commandline:
+            msg.bold("pyro ...")
+        if solver_name.startswith("pyro2_amd."):
+            solver_name = solver_name[len("pyro2_amd."):]
+        if solver_name not in valid_solvers:
+            msg.fail(f"ERROR: {solver_name} is not a valid solver")
+        self.from_commandline = from_commandline
+        self.pyro_home = os.path.dirname(os.path.realpath(__file__)) + "/"
+        self.solver = importlib.import_module("pyro2_amd." + solver_name)
+        self.solver_name = solver_name
+        self.problem_name = None
+        self.problem_func = None
+        self.problem_source = None
+        self.problem_params = None
+        self.problem_finalize = None
+        self.custom_problems = {}
+        self.rp = RuntimeParameters()
+        self.rp.load_params(self.pyro_home + "_defaults")
+        self.rp.load_params(self.pyro_home + self.solver_name + "/_defaults")
+        self.tc = profile.TimerCollection()
+        self.is_initialized = False
+
+    def add_problem(self, name, problem_func, *, problem_params=None):
+        """register a user problem: problem_func(cc_data, rp) fills the state"""
+        self.custom_problems[name] = (problem_func, problem_params or {})
+
+    def initialize_problem(self, problem_name, *, inputs_file=None, inputs_dict=None):
+        if problem_name in self.custom_problems:
+            self.problem_func, self.problem_params = self.custom_problems[problem_name]
+            self.problem_finalize = None
+            self.problem_source = None
+        else:
+            problem = importlib.import_module(
+                f"pyro2_amd.{self.solver_name}.problems.{problem_name}")
+            self.problem_func = problem.init_data
+            self.problem_params = problem.PROBLEM_PARAMS
+            self.problem_finalize = problem.finalize
+            self.problem_source = getattr(problem, "source_terms", None)
+            if inputs_file is None:
+                inputs_file = problem.DEFAULT_INPUTS
+        self.problem_name = problem_name
+        if self.problem_source is not None:
+            msg.fail("ERROR: problem source terms are not carried by the device path")
+
+        for k, v in self.problem_params.items():
+            self.rp.set_param(k, v, no_new=False)
+        if inputs_file is not None:
+            if not os.path.isfile(inputs_file):
+                inputs_file = self.pyro_home + self.solver_name + "/problems/" + inputs_file
+                if not os.path.isfile(inputs_file):
+                    msg.fail("ERROR: inputs file does not exist")
+            self.rp.load_params(inputs_file, no_new=1)
+        if not self.from_commandline:
+            # library / notebook use: quiet, no files, no windows
+            self.rp.set_param("vis.dovis", 0)
+            self.rp.set_param("driver.verbose", 0)
+            self.rp.set_param("io.do_io", 0)
+        if inputs_dict is not None:
+            for k, v in inputs_dict.items():
+                self.rp.set_param(k, v)
+        self.rp.print_paramfile()
+        self.verbose = self.rp.get_param("driver.verbose")
+        self.dovis = self.rp.get_param("vis.dovis")
+
+        self.sim = self.solver.Simulation(
+            self.solver_name, self.problem_name, self.problem_func, self.rp,
+            problem_finalize_func=self.problem_finalize,
+            problem_source_func=self.problem_source, timers=self.tc)
+        self.sim.initialize()
+        self.sim.preevolve()
+        self.sim.cc_data.t = 0.0
+        self.is_initialized = True
+
+    def run_sim(self):
+        if not self.is_initialized:
+            msg.fail("ERROR: problem has not been initialized")
+        tm_main = self.tc.timer("main")
+        tm_main.begin()
+        basename = self.rp.get_param("io.basename")
+        do_io = self.rp.get_param("io.do_io")
+        if do_io:
+            self.sim.write(f"{basename}{self.sim.n:04d}")
+        if self.dovis:
+            import matplotlib.pyplot as plt
+            plt.ion()
+            plt.figure(num=1, figsize=(8, 6), dpi=100, facecolor="w")
+            self.sim.dovis()
+        while not self.sim.finished():
+            self.single_step()
+        if do_io or self.rp.get_param("io.force_final_output"):
+            if self.verbose > 0:
+                msg.warning("outputting...")
+            self.sim.write(f"{basename}{self.sim.n:04d}")
+        tm_main.end()
+        if self.verbose > 0:
+            self.rp.print_unused_params()
+            self.tc.report()
+        self.sim.finalize()
+
+    def single_step(self):
+        if not self.is_initialized:
+            msg.fail("ERROR: problem has not been initialized")
+        self.sim.cc_data.fill_BC_all()
+        self.sim.compute_timestep()
+        self.sim.evolve()
+        if self.verbose > 0:
+            print("%5d %10.5f %10.5f" % (self.sim.n, self.sim.cc_data.t, self.sim.dt))
+        if self.sim.do_output():
+            if self.verbose > 0:
+                msg.warning("outputting...")
+            basename = self.rp.get_param("io.basename")
+            self.sim.write(f"{basename}{self.sim.n:04d}")
+        if self.dovis:
+            tm_vis = self.tc.timer("vis")
+            tm_vis.begin()
+            self.sim.dovis()
+            if self.rp.get_param("vis.store_images") == 1:
+                import matplotlib.pyplot as plt
+                basename = self.rp.get_param("io.basename")
+                plt.savefig(f"{basename}{self.sim.n:04d}.png")
+            tm_vis.end()
+
+    def __repr__(self):
+        return f"Pyro('{self.solver_name}')"
+
+    def __str__(self):
+        s = f"Solver = {self.solver_name}\n"
+        if self.is_initialized:
+            s += f"Problem = {self.sim.problem_name}\n"
+            s += f"Simulation time = {self.sim.cc_data.t}\n"
+            s += f"Simulation step number = {self.sim.n}\n"
+        return s + "\nRuntime Parameters\n------------------\n" + str(self.rp)
+
+    def get_var(self, v):
+        if not self.is_initialized:
+            msg.fail("ERROR: problem has not been initialized")
+        return self.sim.cc_data.get_var(v)
+
+    def get_grid(self):
+        if not self.is_initialized:
+            msg.fail("ERROR: problem has not been initialized")
+        return self.sim.cc_data.grid
+
+    def get_sim(self):
+        return self.sim
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description="pyro hot path on MI355X")
+    p.add_argument("--make_benchmark", action="store_true",
+                   help="(accepted for command-line compatibility)")
+    p.add_argument("--compare_benchmark", action="store_true",
+                   help="(accepted for command-line compatibility)")
+    p.add_argument("solver", metavar="solver-name", choices=valid_solvers)
+    p.add_argument("problem", metavar="problem-name")
+    p.add_argument("param", metavar="inputs-file")
+    p.add_argument("other", metavar="runtime-parameters", nargs="*",
+                   help="section.option=value overrides")
+    return p.parse_args()
+
+
+def main():
+    args = parse_args()
+    other = {}
+    for param_string in args.other:
+        k, v = param_string.split("=")
+        other[k] = _get_val(v)
+    pyro = Pyro(args.solver, from_commandline=True)
+    pyro.initialize_problem(args.problem, inputs_file=args.param, inputs_dict=other)
+    pyro.run_sim()
+
+
+if __name__ == "__main__":
+    main()

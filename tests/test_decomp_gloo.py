@@ -1,0 +1,154 @@
+"""N > 1 path on CPU: world_size-2 gloo processes, each driving its x-slab on
+the emulated backend; halos travel over torch.distributed (the product uses
+RCCL for the same exchange, csrc/comm.hip -- covered on one GPU by
+tests/test_zz_comm.py).  The decomposed runs must be BIT-IDENTICAL to the
+single-domain oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class GlooComm:
+    """same contract as pyro2_amd.decomp.RcclComm, over gloo + host staging"""
+
+    def __init__(self, td):
+        self.td = td
+
+    def halo_exchange(self, state, lo, hi):
+        import torch
+        ng, nxl = state.ng, state.nx
+        reqs, recvs = [], []
+        # same pairing as csrc/comm.hip: low rows -> lo, hi ghosts <- hi,
+        # high rows -> hi, lo ghosts <- lo
+        if lo >= 0:
+            t = torch.from_numpy(state.download_rows(ng, ng).copy())
+            reqs.append(self.td.isend(t, lo, tag=1))
+        if hi >= 0:
+            buf = torch.empty((ng, state.qy, state.nvar), dtype=torch.float64)
+            reqs.append(self.td.irecv(buf, hi, tag=1))
+            recvs.append((nxl + ng, buf))
+        if hi >= 0:
+            t = torch.from_numpy(state.download_rows(nxl, ng).copy())
+            reqs.append(self.td.isend(t, hi, tag=2))
+        if lo >= 0:
+            buf = torch.empty((ng, state.qy, state.nvar), dtype=torch.float64)
+            reqs.append(self.td.irecv(buf, lo, tag=2))
+            recvs.append((0, buf))
+        for r in reqs:
+            r.wait()
+        for row, buf in recvs:
+            state.upload_rows(row, buf.numpy())
+
+    def allreduce_min(self, x):
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self.td.all_reduce(t, op=self.td.ReduceOp.MIN)
+        return float(t[0])
+
+
+def _worker(rank, world, port, case, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import torch.distributed as td
+    td.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank,
+                          world_size=world)
+    import build_emu
+    from pyro2_amd import _lib, device
+    from pyro2_amd.decomp import DtPolicy, SlabCompressible, SlabDecomp
+    _lib.use_library(build_emu.LIB, allow_backends=("host-emu",))
+    ctx = device.Context(0)
+    comm = GlooComm(td)
+    if case == "sedov":
+        from sedov_ic import sedov_ic
+        nx, ny, nsteps = 40, 24, 12
+        ic, meta, bcs = sedov_ic(nx, ny, r_init=0.12)
+        dec = SlabDecomp(nx, world, rank)
+        kw = dict(dx=meta[3], dy=meta[4], kernel_set=rank % 2)   # mix staged / fused
+        sl = SlabCompressible(ctx, dec, ny, bcs, kw, comm)
+        a, b = dec.local_rows(4)
+        sl.state.upload(np.ascontiguousarray(ic[a:b]))
+        pol = DtPolicy(0.1)
+        dts = [sl.step(pol, 0.8) for _ in range(nsteps)]
+        res = sl.state.download()
+        np.savez(os.path.join(out_dir, f"sedov_{rank}.npz"), U=res, dts=np.array(dts),
+                 rows=np.array([a, b]))
+    else:   # periodic advection, lo == hi for two ranks
+        nx, ny, nsteps = 32, 16, 10
+        dec = SlabDecomp(nx, world, rank, periodic=True)
+        rng = np.random.default_rng(7)
+        ic = 1.0 + rng.random((nx + 8, ny + 8))
+        st = device.DeviceState(ctx, dec.nx_local, ny, 4, dec.var_bcs([["periodic"] * 4]))
+        a, b = dec.local_rows(4)
+        st.upload(np.ascontiguousarray(ic[a:b]))
+        dt = 0.8 * min((1 / nx) / 1.0, (1 / ny) / 0.5)
+        for _ in range(nsteps):
+            comm.halo_exchange(st, dec.lo, dec.hi)
+            st.fill_bc()
+            st.adv_step(0, 1 / nx, 1 / ny, 1.0, -0.5, dt, 2)
+        np.savez(os.path.join(out_dir, f"adv_{rank}.npz"), U=st.download(), rows=np.array([a, b]),
+                 ic=ic, dt=np.array(dt))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn(case, tmp_path, world=2):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    build_emu.build()
+    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+
+
+def test_slab_decomp_indices():
+    from pyro2_amd.decomp import SlabDecomp
+    d = [SlabDecomp(100, 3, r) for r in range(3)]
+    assert [x.nx_local for x in d] == [34, 33, 33] and [x.i0 for x in d] == [0, 34, 67]
+    assert (d[0].lo, d[0].hi, d[2].lo, d[2].hi) == (-1, 1, 1, -1)
+    p = [SlabDecomp(64, 2, r, periodic=True) for r in range(2)]
+    assert (p[0].lo, p[0].hi, p[1].lo, p[1].hi) == (1, 1, 0, 0)
+    t = d[1].comp_var_bcs(["reflect", "outflow", "reflect", "periodic"])
+    assert t[2][:2] == [4, 4] and t[3][2] == 2 and t[0][2] == 1
+    with pytest.raises(ValueError):
+        SlabDecomp(6, 2, 0)
+
+
+def test_two_rank_sedov_bit_identical(tmp_path):
+    from helpers import oracle_comp_run
+    from sedov_ic import sedov_ic
+    _spawn("sedov", tmp_path)
+    ic, meta, bcs = sedov_ic(40, 24, r_init=0.12)
+    Uo, dto, _ = oracle_comp_run(ic, meta, bcs, 0.1, 12)
+    for r in range(2):
+        z = np.load(tmp_path / f"sedov_{r}.npz")
+        a, b = z["rows"]
+        assert np.array_equal(z["dts"], dto)
+        assert np.array_equal(z["U"][4:-4, 4:-4], Uo[a + 4:b - 4, 4:-4]), r
+
+
+def test_two_rank_periodic_advection_bit_identical(tmp_path):
+    from oracle import orc
+    _spawn("adv", tmp_path)
+    z0 = np.load(tmp_path / "adv_0.npz")
+    a = z0["ic"].copy()
+    nx, ny = 32, 16
+    for _ in range(10):
+        orc.fill_ghost(a, nx, ny, 4, ("periodic",) * 4)
+        orc.adv_step(a, nx, ny, 4, 1 / nx, 1 / ny, 1.0, -0.5, float(z0["dt"]), 2)
+    for r in range(2):
+        z = np.load(tmp_path / f"adv_{r}.npz")
+        lo, hi = z["rows"]
+        assert np.array_equal(z["U"][4:-4, 4:-4, 0], a[lo + 4:hi - 4, 4:-4]), r
