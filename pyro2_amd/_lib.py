@@ -120,7 +120,9 @@ def _load():
     with _lock:
         if _lib is not None:
             return _lib
-        path = _lib_path or DEFAULT_LIB
+        # PYRO2_AMD_LIB: developer override to A/B differently built gfx950
+        # libraries; the backend check below still applies
+        path = _lib_path or os.environ.get("PYRO2_AMD_LIB") or DEFAULT_LIB
         if not os.path.exists(path):
             raise ImportError(
                 f"{path} is missing: the HIP extension has not been built "

@@ -13,7 +13,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libpyrohip.so")
+LIB = os.path.join(LIBDIR, os.environ.get("PYRO_LIB_NAME", "libpyrohip.so"))
+EXTRA = os.environ.get("PYRO_EXTRA_FLAGS", "").split()   # developer experiments only
 
 ARCH = "gfx950"
 COMMON = ["-std=c++17", "-fPIC", "-O3"]
@@ -67,8 +68,8 @@ def build(force=False, verbose=False):
 
     def compile_one(u):
         src, name, extra = u
-        obj = os.path.join(LIBDIR, "obj", name + ".o")
-        cmd = [hipcc, f"--offload-arch={ARCH}"] + COMMON + extra + \
+        obj = os.path.join(LIBDIR, "obj", name + os.environ.get("PYRO_OBJ_SUFFIX", "") + ".o")
+        cmd = [hipcc, f"--offload-arch={ARCH}"] + COMMON + extra + EXTRA + \
               ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -21,7 +21,7 @@
 //   5  conservative update of the interior cells into the second state
 //      buffer + CFL minimum of the new state
 // LDS: max(Q, fluxes) + upper states + div(U); for 16x32 threads
-// 32 + 32 + 4 KiB = 68 KiB, two workgroups (16 waves) per CU.
+// 32 + 32 + 4 KiB = 68 KiB, two workgroups (16 waves, 4 per SIMD) per CU.
 //
 // Compiled twice like compressible.hip (PYRO_FAST = 0 / 1).
 #include "common.h"
@@ -58,6 +58,11 @@ struct FP {   // kernel parameters
     int limiter, use_flattening;
     int avx_hi, avy_hi;
     int ntj, ntiles;
+    // uniform quotients, evaluated once on the host with the reference's
+    // expressions (IEEE double on both sides: same bits)
+    double dtdx, dtdy;    // dt/dx, dt/dy          interface.py:106
+    double hdtV;          // (0.5*dt)/(dx*dy)      unsplit_fluxes.py:444-445
+    double dtdV;          // dt/(dx*dy)            simulation.py:375
 };
 
 __device__ __forceinline__ ConsN to_nf(const Cons &U, bool x)
@@ -87,7 +92,15 @@ __device__ __forceinline__ Cons corr(const Cons &U, const Cons &Fhi, const Cons 
     return r;
 }
 
-__global__ __launch_bounds__(FNT) void k_ctu_fused(const double *__restrict__ Uin,
+#ifndef PYRO_FUSED_MINW
+// waves per SIMD the register allocation must allow: 4 = two 512-thread
+// workgroups per CU (128 VGPRs, 48 B/lane scratch).  Measured at 8192^2:
+// 6.75 ms vs 9.48 ms with one workgroup per CU (146 VGPRs, no scratch) -- the
+// second workgroup fills the VALU while the first sits in a barrier.
+#define PYRO_FUSED_MINW 4
+#endif
+
+__global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double *__restrict__ Uin,
                                                    double *__restrict__ Uout, Geom g, FP P,
                                                    int *__restrict__ flag,
                                                    double *__restrict__ partial)
@@ -159,11 +172,11 @@ __global__ __launch_bounds__(FNT) void k_ctu_fused(const double *__restrict__ Ui
         }
         Trace lo, hi;
         trace_states(q0[0], q0[1], q0[2], q0[3], dqx[0], dqx[1], dqx[2], dqx[3], gamma,
-                     P.dt / P.dx, lo, hi);
+                     P.dtdx, lo, hi);
         XM = prim_to_cons(Prim{lo.r, lo.un, lo.ut, lo.p}, gamma);
         XP = prim_to_cons(Prim{hi.r, hi.un, hi.ut, hi.p}, gamma);
         trace_states(q0[0], q0[2], q0[1], q0[3], dqy[0], dqy[2], dqy[1], dqy[3], gamma,
-                     P.dt / P.dy, lo, hi);
+                     P.dtdy, lo, hi);
         YM = prim_to_cons(Prim{lo.r, lo.ut, lo.un, lo.p}, gamma);
         YP = prim_to_cons(Prim{hi.r, hi.ut, hi.un, hi.p}, gamma);
         // vertex divergence at (i-1/2, j-1/2), interface.py:312-330
@@ -187,7 +200,7 @@ __global__ __launch_bounds__(FNT) void k_ctu_fused(const double *__restrict__ Ui
     __syncthreads();
 
     // ---- phase 3: transverse correction of the cell's own states --------
-    const double hdtV = (0.5 * P.dt) / (P.dx * P.dy);   // hdt / V
+    const double hdtV = P.hdtV;                          // hdt / V
     const double Ax = P.dy, Ay = P.dx;
     if (tj >= 1 && tj <= FBJ - 2) {
         const Cons Fhi = lds_get(B0 + 4 * FNT, t + 1);   // F_yT at (i, j+1)
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(FNT) void k_ctu_fused(const double *__restrict__ Ui
     // ---- phase 5: conservative update + CFL of the new state -----------
     double cfl = INFINITY;
     if (ti >= 1 && ti <= FBI - 2 && tj >= 1 && tj <= FBJ - 2 && cell_interior) {
-        const double dtdV = P.dt / (P.dx * P.dy);
+        const double dtdV = P.dtdV;
         const Cons Fxh = lds_get(B0, t + FBJ);
         const Cons Fyh = lds_get(B0 + 4 * FNT, t + 1);
         Cons Un;   // simulation.py:377-384
@@ -309,6 +322,9 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     P.small_dens = p->small_dens;
     P.limiter = p->limiter; P.use_flattening = p->use_flattening;
     P.avx_hi = p->avisc_xhi_interior; P.avy_hi = p->avisc_yhi_interior;
+    P.dtdx = dt / p->dx; P.dtdy = dt / p->dy;
+    P.hdtV = (0.5 * dt) / (p->dx * p->dy);
+    P.dtdV = dt / (p->dx * p->dy);
     const int nti = (g.nx + FTI - 1) / FTI;
     P.ntj = (g.ny + FTJ - 1) / FTJ;
     P.ntiles = nti * P.ntj;

@@ -7,7 +7,34 @@
 
 #include "stencil.h"
 
+#ifndef PYRO_FAST
+#define PYRO_FAST 0
+#endif
+
 namespace pyro {
+
+// Division policy.  Bit-faithful build: IEEE division, exactly as written in
+// the reference.  fast_math build: v_rcp_f64 (~2^-23 relative) + two Newton
+// steps (full double precision, not correctly rounded) and a multiply: 6 VALU
+// instructions instead of the ~12 of the IEEE sequence; divisions are ~40 % of
+// this solver's VALU work (profiles/r01_fused_8192_pmc.json).  Parity of the
+// fast build is tolerance-tested (1e-10), not bit-tested.
+#if PYRO_FAST && !defined(PYRO_EMU)
+__device__ __forceinline__ double prcp(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double pdiv(double a, double b) { return a * prcp(b); }
+// a / b where rb = prcp(b) was computed once for several quotients
+__device__ __forceinline__ double pdivr(double a, double b, double rb) { (void)b; return a * rb; }
+#else
+__device__ __forceinline__ double prcp(double b) { return 1.0 / b; }
+__device__ __forceinline__ double pdiv(double a, double b) { return a / b; }
+__device__ __forceinline__ double pdivr(double a, double b, double rb) { (void)rb; return a / b; }
+#endif
 
 struct Cons { double d, E, mx, my; };   // density, energy, x-mom, y-mom
 struct Prim { double r, u, v, p; };     // rho, u, v, p
@@ -20,9 +47,10 @@ __device__ __forceinline__ Prim cons_to_prim(const Cons &U, double gamma, bool *
     q.r = U.d;
     double u = 0.0, v = 0.0, e = 0.0;
     if (U.d != 0.0) {
-        u = U.mx / U.d;
-        v = U.my / U.d;
-        e = (U.E - 0.5 * U.d * (u * u + v * v)) / U.d;
+        const double rd = PYRO_FAST ? prcp(U.d) : 0.0;
+        u = pdivr(U.mx, U.d, rd);
+        v = pdivr(U.my, U.d, rd);
+        e = pdivr(U.E - 0.5 * U.d * (u * u + v * v), U.d, rd);
     }
     q.u = u;
     q.v = v;
@@ -38,7 +66,7 @@ __device__ __forceinline__ Cons prim_to_cons(const Prim &q, double gamma)
     U.d = q.r;
     U.mx = q.u * U.d;
     U.my = q.v * U.d;
-    double rhoe = q.p / (gamma - 1.0);
+    double rhoe = pdiv(q.p, gamma - 1.0);
     U.E = rhoe + 0.5 * q.r * (q.u * q.u + q.v * q.v);
     return U;
 }
@@ -47,13 +75,14 @@ __device__ __forceinline__ Cons prim_to_cons(const Prim &q, double gamma)
 // returns min(dx/(|u|+c), dy/(|v|+c)) for one cell
 __device__ __forceinline__ double cfl_cell(const Cons &U, double gamma, double dx, double dy)
 {
-    double u = U.mx / U.d;
-    double v = U.my / U.d;
-    double e = (U.E - 0.5 * U.d * (u * u + v * v)) / U.d;
+    const double rd = PYRO_FAST ? prcp(U.d) : 0.0;
+    double u = pdivr(U.mx, U.d, rd);
+    double v = pdivr(U.my, U.d, rd);
+    double e = pdivr(U.E - 0.5 * U.d * (u * u + v * v), U.d, rd);
     double p = U.d * e * (gamma - 1.0);
-    double cs = sqrt(gamma * p / U.d);
-    double xt = dx / (fabs(u) + cs);
-    double yt = dy / (fabs(v) + cs);
+    double cs = sqrt(pdivr(gamma * p, U.d, rd));
+    double xt = pdiv(dx, fabs(u) + cs);
+    double yt = pdiv(dy, fabs(v) + cs);
     return fmin(xt, yt);
 }
 
@@ -66,10 +95,10 @@ __device__ __forceinline__ double flatten_1d(double pm2, double pm1, double pp1,
     const double smallp = 1.e-10;
     double t1 = fabs(pp1 - pm1);
     double t2 = fabs(pp2 - pm2);
-    double z = t1 / fmax(t2, smallp);
-    double t2b = t1 / fmin(pp1, pm1);
+    double z = pdiv(t1, fmax(t2, smallp));
+    double t2b = pdiv(t1, fmin(pp1, pm1));
     double t1b = um1 - up1;
-    double xi = fmin(1.0, fmax(0.0, 1.0 - (z - z0) / (z1 - z0)));
+    double xi = fmin(1.0, fmax(0.0, 1.0 - pdiv(z - z0, z1 - z0)));
     return (t1b > 0.0 && t2b > delta) ? xi : 1.0;
 }
 
@@ -85,7 +114,7 @@ __device__ __forceinline__ void trace_states(double r, double un, double ut, dou
                                              double gamma, double dtdx, Trace &lo, Trace &hi)
 {
     const double dtdx4 = 0.25 * dtdx;                // interface.py:107
-    const double cs = sqrt(gamma * p / r);           // :122
+    const double cs = sqrt(pdiv(gamma * p, r));      // :122
     const double e0 = un - cs, e1 = un, e3 = un + cs;  // :129 / :151  (e2 == e1)
 
     // reference states, :174-191
@@ -98,10 +127,12 @@ __device__ __forceinline__ void trace_states(double r, double un, double ut, dou
 
     // l_m . dq as 4-term in-order sums with the zero entries dropped
     // (adding 0*x terms never changes a finite sum), :131-139 / :153-161
-    const double a0 = (-0.5 * r / cs) * dun + (0.5 / (cs * cs)) * dp;
-    const double a1 = dr + (-1.0 / (cs * cs)) * dp;
+    const double rcs = PYRO_FAST ? prcp(cs) : 0.0;
+    const double rc2 = PYRO_FAST ? rcs * rcs : 0.0;
+    const double a0 = pdivr(-0.5 * r, cs, rcs) * dun + pdivr(0.5, cs * cs, rc2) * dp;
+    const double a1 = dr + pdivr(-1.0, cs * cs, rc2) * dp;
     const double a2 = dut;
-    const double a3 = (0.5 * r / cs) * dun + (0.5 / (cs * cs)) * dp;
+    const double a3 = pdivr(0.5 * r, cs, rcs) * dun + pdivr(0.5, cs * cs, rc2) * dp;
 
     // :193-201
     const double s0 = copysign(1.0, e0), s1 = copysign(1.0, e1), s3 = copysign(1.0, e3);
@@ -116,7 +147,7 @@ __device__ __forceinline__ void trace_states(double r, double un, double ut, dou
 
     // sum_m beta_m r_m, in index order with the structural zeros kept where
     // they sit between non-zero terms, :203-213; r_m from :141-144 / :163-166
-    const double cr = cs / r, c2 = cs * cs;
+    const double cr = pdiv(cs, r), c2 = cs * cs;
     hi.r = hi.r + ((bl0 + bl1) + bl3);
     hi.un = hi.un + (bl0 * (-cr) + bl3 * cr);
     hi.ut = hi.ut + bl2;
@@ -136,38 +167,41 @@ __device__ __forceinline__ void estimate_wave_speed(double rho_l, double u_l, do
 {
     double p_max = fmax(p_l, p_r);
     double p_min = fmin(p_l, p_r);
-    double Q = p_max / p_min;
+    double Q = pdiv(p_max, p_min);
     double rho_avg = 0.5 * (rho_l + rho_r);
     double c_avg = 0.5 * (c_l + c_r);
     double factor = rho_avg * c_avg;
     double pstar = 0.5 * (p_l + p_r) + 0.5 * (u_l - u_r) * factor;
     if (Q > 2 && (pstar < p_min || pstar > p_max)) {
         if (pstar < p_min) {   // two-rarefaction, :626-638
-            double z = (gamma - 1.0) / (2.0 * gamma);
-            double p_lr = pow(p_l / p_r, z);
-            double ustar = (p_lr * u_l / c_l + u_r / c_r + 2.0 * (p_lr - 1.0) / (gamma - 1.0)) /
-                           (p_lr / c_l + 1.0 / c_r);
-            pstar = 0.5 * (p_l * pow(1.0 + (gamma - 1.0) * (u_l - ustar) / (2.0 * c_l), 1.0 / z) +
-                           p_r * pow(1.0 + (gamma - 1.0) * (ustar - u_r) / (2.0 * c_r), 1.0 / z));
+            double z = pdiv(gamma - 1.0, 2.0 * gamma);
+            double p_lr = pow(pdiv(p_l, p_r), z);
+            double ustar = pdiv(pdiv(p_lr * u_l, c_l) + pdiv(u_r, c_r) +
+                                    pdiv(2.0 * (p_lr - 1.0), gamma - 1.0),
+                                pdiv(p_lr, c_l) + pdiv(1.0, c_r));
+            pstar = 0.5 * (p_l * pow(1.0 + pdiv((gamma - 1.0) * (u_l - ustar), 2.0 * c_l),
+                                     pdiv(1.0, z)) +
+                           p_r * pow(1.0 + pdiv((gamma - 1.0) * (ustar - u_r), 2.0 * c_r),
+                                     pdiv(1.0, z)));
         } else {               // two-shock, :640-658
-            double A_r = 2.0 / ((gamma + 1.0) * rho_r);
-            double B_r = p_r * (gamma - 1.0) / (gamma + 1.0);
-            double A_l = 2.0 / ((gamma + 1.0) * rho_l);
-            double B_l = p_l * (gamma - 1.0) / (gamma + 1.0);
+            double A_r = pdiv(2.0, (gamma + 1.0) * rho_r);
+            double B_r = pdiv(p_r * (gamma - 1.0), gamma + 1.0);
+            double A_l = pdiv(2.0, (gamma + 1.0) * rho_l);
+            double B_l = pdiv(p_l * (gamma - 1.0), gamma + 1.0);
             double p_guess = fmax(0.0, pstar);
-            double g_l = sqrt(A_l / (p_guess + B_l));
-            double g_r = sqrt(A_r / (p_guess + B_r));
-            pstar = (g_l * p_l + g_r * p_r - (u_r - u_l)) / (g_l + g_r);
+            double g_l = sqrt(pdiv(A_l, p_guess + B_l));
+            double g_r = sqrt(pdiv(A_r, p_guess + B_r));
+            pstar = pdiv(g_l * p_l + g_r * p_r - (u_r - u_l), g_l + g_r);
         }
     }
     if (pstar <= p_l)
         S_l = u_l - c_l;
     else
-        S_l = u_l - c_l * sqrt(1.0 + ((gamma + 1.0) / (2.0 * gamma)) * (pstar / p_l - 1.0));
+        S_l = u_l - c_l * sqrt(1.0 + pdiv(gamma + 1.0, 2.0 * gamma) * (pdiv(pstar, p_l) - 1.0));
     if (pstar <= p_r)
         S_r = u_r + c_r;
     else
-        S_r = u_r + c_r * sqrt(1.0 + ((gamma + 1.0) / (2.0 / gamma)) * (pstar / p_r - 1.0));
+        S_r = u_r + c_r * sqrt(1.0 + pdiv(gamma + 1.0, pdiv(2.0, gamma)) * (pdiv(pstar, p_r) - 1.0));
 }
 
 // consFlux in the (normal, transverse) frame, riemann.py:1104-1179.
@@ -180,8 +214,9 @@ __device__ __forceinline__ ConsN cons_flux_n(const ConsN &U, double gamma, bool 
     // written there, i.e. x-velocity squared first
     double un = 0.0, ut = 0.0;
     if (U.d != 0.0) {
-        un = U.mn / U.d;
-        ut = U.mt / U.d;
+        const double rd = PYRO_FAST ? prcp(U.d) : 0.0;
+        un = pdivr(U.mn, U.d, rd);
+        ut = pdivr(U.mt, U.d, rd);
     }
     double ke = normal_is_x ? (un * un + ut * ut) : (ut * ut + un * un);
     double p = (U.E - 0.5 * U.d * ke) * (gamma - 1.0);
@@ -202,45 +237,47 @@ __device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, dou
 {
     const double smallc = 1.e-10, smallp = 1.e-10;
     double rho_l = Ul.d;
-    double un_l = Ul.mn / rho_l;
-    double ut_l = Ul.mt / rho_l;
+    const double ril = PYRO_FAST ? prcp(rho_l) : 0.0;
+    double un_l = pdivr(Ul.mn, rho_l, ril);
+    double ut_l = pdivr(Ul.mt, rho_l, ril);
     double rhoe_l = Ul.E - 0.5 * rho_l * (un_l * un_l + ut_l * ut_l);
     double p_l = rhoe_l * (gamma - 1.0);
     p_l = fmax(p_l, smallp);
     double rho_r = Ur.d;
-    double un_r = Ur.mn / rho_r;
-    double ut_r = Ur.mt / rho_r;
+    const double rir = PYRO_FAST ? prcp(rho_r) : 0.0;
+    double un_r = pdivr(Ur.mn, rho_r, rir);
+    double ut_r = pdivr(Ur.mt, rho_r, rir);
     double rhoe_r = Ur.E - 0.5 * rho_r * (un_r * un_r + ut_r * ut_r);
     double p_r = rhoe_r * (gamma - 1.0);
     p_r = fmax(p_r, smallp);
-    double c_l = fmax(smallc, sqrt(gamma * p_l / rho_l));
-    double c_r = fmax(smallc, sqrt(gamma * p_r / rho_r));
+    double c_l = fmax(smallc, sqrt(pdivr(gamma * p_l, rho_l, ril)));
+    double c_r = fmax(smallc, sqrt(pdivr(gamma * p_r, rho_r, rir)));
     double S_l, S_r;
     estimate_wave_speed(rho_l, un_l, p_l, c_l, rho_r, un_r, p_r, c_r, gamma, S_l, S_r);
-    double S_c = (p_r - p_l + rho_l * un_l * (S_l - un_l) - rho_r * un_r * (S_r - un_r)) /
-                 (rho_l * (S_l - un_l) - rho_r * (S_r - un_r));
+    double S_c = pdiv(p_r - p_l + rho_l * un_l * (S_l - un_l) - rho_r * un_r * (S_r - un_r),
+                      rho_l * (S_l - un_l) - rho_r * (S_r - un_r));
     ConsN F;
     if (S_r <= 0.0) {
         F = cons_flux_n(Ur, gamma, normal_is_x);
     } else if (S_c <= 0.0 && 0.0 < S_r) {
-        double f = rho_r * (S_r - un_r) / (S_r - S_c);
+        double f = pdiv(rho_r * (S_r - un_r), S_r - S_c);
         ConsN Us;
         Us.d = f;
         Us.mn = f * S_c;
         Us.mt = f * ut_r;
-        Us.E = f * (Ur.E / rho_r + (S_c - un_r) * (S_c + p_r / (rho_r * (S_r - un_r))));
+        Us.E = f * (pdivr(Ur.E, rho_r, rir) + (S_c - un_r) * (S_c + pdiv(p_r, rho_r * (S_r - un_r))));
         F = cons_flux_n(Ur, gamma, normal_is_x);
         F.d = F.d + S_r * (Us.d - Ur.d);
         F.mn = F.mn + S_r * (Us.mn - Ur.mn);
         F.mt = F.mt + S_r * (Us.mt - Ur.mt);
         F.E = F.E + S_r * (Us.E - Ur.E);
     } else if (S_l < 0.0 && 0.0 < S_c) {
-        double f = rho_l * (S_l - un_l) / (S_l - S_c);
+        double f = pdiv(rho_l * (S_l - un_l), S_l - S_c);
         ConsN Us;
         Us.d = f;
         Us.mn = f * S_c;
         Us.mt = f * ut_l;
-        Us.E = f * (Ul.E / rho_l + (S_c - un_l) * (S_c + p_l / (rho_l * (S_l - un_l))));
+        Us.E = f * (pdivr(Ul.E, rho_l, ril) + (S_c - un_l) * (S_c + pdiv(p_l, rho_l * (S_l - un_l))));
         F = cons_flux_n(Ul, gamma, normal_is_x);
         F.d = F.d + S_l * (Us.d - Ul.d);
         F.mn = F.mn + S_l * (Us.mn - Ul.mn);
@@ -262,8 +299,8 @@ __device__ __forceinline__ double div_u_vertex(double u_ij, double u_ijm, double
     double ul = 0.5 * (u_imj + u_imjm);
     double vt = 0.5 * (v_ij + v_imj);
     double vb = 0.5 * (v_ijm + v_imjm);
-    double ux = (ur - ul) / dx;
-    double vy = (vt - vb) / dy;
+    double ux = pdiv(ur - ul, dx);
+    double vy = pdiv(vt - vb, dy);
     return ux + vy;
 }
 
