@@ -157,6 +157,10 @@ int pyrohip_mg_create(pyrohip_ctx *ctx, int nx, double xmin, double xmax,
                       pyrohip_mg **out);
 int pyrohip_mg_destroy(pyrohip_mg *m);
 int pyrohip_mg_nlevels(pyrohip_mg *m, int *nlevels);
+/* smoother implementation: 1 (default) = LDS tile kernel running up to 5
+   red-black iterations per launch; 0 = one launch per colour.  Results are
+   bit-identical. */
+int pyrohip_mg_set_smoother(pyrohip_mg *m, int kind);
 /* var: 0 = v, 1 = f, 2 = r; arrays are (n+2, n+2) with ng = 1 */
 int pyrohip_mg_set(pyrohip_mg *m, int level, int var, const double *host);
 int pyrohip_mg_get(pyrohip_mg *m, int level, int var, double *host);

@@ -76,6 +76,7 @@ _PROTOS = {
                           C.c_int, C.POINTER(_VP)],
     "pyrohip_mg_destroy": [_VP],
     "pyrohip_mg_nlevels": [_VP, _IP],
+    "pyrohip_mg_set_smoother": [_VP, C.c_int],
     "pyrohip_mg_set": [_VP, C.c_int, C.c_int, _DP],
     "pyrohip_mg_get": [_VP, C.c_int, C.c_int, _DP],
     "pyrohip_mg_set_bcval": [_VP, C.c_int, _DP],

@@ -25,6 +25,7 @@
 // outside the colour loop.
 #include "common.h"
 #include "reduce.h"
+#include "stencil.h"
 
 namespace pyro {
 
@@ -35,6 +36,7 @@ struct MGLevel {
     int pitch;
     double dx;
     double *v, *f, *r;
+    double *v2;     // second solution buffer (tile smoother ping-pong)
 };
 
 struct MGBC {
@@ -55,6 +57,10 @@ struct pyrohip_mg {
     double *old_phi = nullptr;    // finest-level copy for relative_error
     double *bcval[4] = {nullptr, nullptr, nullptr, nullptr};  // device
     double source_norm = 0.0;
+    int smoother = 1;             // 0: one launch per colour, 1: LDS tile smoother
+    int kmax = 3;                 // red-black iterations fused per tile launch
+    int coarse_kernel = 1;        // levels <= 64^2 in one LDS-resident workgroup
+    bool corners_stale[pyro::MG_MAXLEV] = {};   // v: corner ghosts not refreshed yet
 };
 
 namespace pyro {
@@ -133,6 +139,368 @@ __global__ __launch_bounds__(256) void k_mg_smooth(double *__restrict__ v,
     if (j == n) {
         if (bc.code[3] == PYROHIP_BC_PERIODIC) v[(size_t)i * pitch] = vn;
         else v[(size_t)i * pitch + n + 1] = ghost_hi(bc.code[3], vn, bc.val[3], i, dx);
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// LDS tile smoother: K complete red-black iterations per launch.
+//
+// A workgroup stages its TI x TJ tile of v and f plus an apron of H = 2K cells
+// in LDS, runs 2K colour passes there (after pass s the outermost s apron
+// rings are stale and no longer read), and writes the tile to the second
+// solution buffer.  Every cell update uses the reference's expression on the
+// same operands as the one-launch-per-colour kernel, so results are
+// bit-identical; HBM traffic per iteration drops from 48 B/cell to
+// (16*apron_factor + 8)/K B/cell (8.4 B at K = 5).
+//
+// Physical boundaries inside the staged region: the ghost ring is refreshed
+// from its interior neighbour after every colour pass (the reference's
+// fill_BC after groups (1,1) and (0,1), MG.py:598-599), so no ring is lost on
+// that side.  Periodic sides of multi-tile levels are staged through wrapped
+// indices and treated like interior.  Levels that fit one tile (n <= 64) run
+// single = 1: the whole level incl. ghosts is staged once and ANY number of
+// iterations (nsmooth, nsmooth_bottom) runs in one launch.
+// ---------------------------------------------------------------------------
+// Two instantiations:
+//   <256, 0>    generic: region pitch = region width (run time); used for the
+//               levels that fit one tile ("single": any number of iterations).
+//   <512, 128>  wide: the staged region is (TI+4K) x (TJ+4K) <= 32 x 128 cells
+//               with a fixed LDS pitch of 128, so one wave = one row of one
+//               colour (64 cells, stride 2) and no index division is needed.
+constexpr int MGS_CELLS = 66 * 66;                 // single-tile levels: n <= 64
+constexpr size_t MGS_LDS = (size_t)2 * MGS_CELLS * sizeof(double);
+constexpr int MGW_RI = 32, MGW_LP = 128, MGW_NT = 512, MGW_KMAX = 3;
+constexpr size_t MGW_LDS = (size_t)2 * MGW_RI * MGW_LP * sizeof(double);
+
+struct MGTile {
+    const double *vin, *f;
+    double *vout;
+    int n, pitch;
+    double dx, xc, yc, denom;
+    int K, TI, TJ, ntj, ntiles, single;
+    MGBC bc;
+};
+
+__device__ __forceinline__ int mg_wrap(int g, int n)   // periodic image in [1, n]
+{
+    int w = (g - 1) % n;
+    if (w < 0) w += n;
+    return w + 1;
+}
+
+template <int NT, int LPC>
+__global__ __launch_bounds__(NT) void k_mg_smooth_tile(MGTile A)
+{
+    HIP_DYNAMIC_SHARED(double, lds)
+    const int n = A.n;
+    const bool per_i = (A.bc.code[0] == PYROHIP_BC_PERIODIC);
+    const bool per_j = (A.bc.code[2] == PYROHIP_BC_PERIODIC);
+    const int H = A.single ? 0 : 2 * A.K;
+    int ti0, ti1, tj0, tj1, gi0, gi1, gj0, gj1;
+    if (A.single) {
+        ti0 = 1; ti1 = n; tj0 = 1; tj1 = n;
+        gi0 = 0; gi1 = n + 1; gj0 = 0; gj1 = n + 1;
+    } else {
+        const int tile = xcd_tile(blockIdx.x, A.ntiles);
+        ti0 = 1 + (tile / A.ntj) * A.TI; ti1 = min(ti0 + A.TI - 1, n);
+        tj0 = 1 + (tile % A.ntj) * A.TJ; tj1 = min(tj0 + A.TJ - 1, n);
+        gi0 = ti0 - H; gi1 = ti1 + H; gj0 = tj0 - H; gj1 = tj1 + H;
+        if (!per_i) { gi0 = max(gi0, 0); gi1 = min(gi1, n + 1); }
+        if (!per_j) { gj0 = max(gj0, 0); gj1 = min(gj1, n + 1); }
+    }
+    const int RI = gi1 - gi0 + 1, RJ = gj1 - gj0 + 1;
+    const int LP = LPC ? LPC : RJ;                     // LDS row pitch
+    double *V = lds, *F = lds + (LPC ? MGW_RI * LPC : RI * RJ);
+    const int tid = threadIdx.x;
+    const bool wrap_i = per_i && !A.single, wrap_j = per_j && !A.single;
+
+    if (LPC) {   // one thread per column, NT / LPC rows per sweep
+        const int c = tid & (LPC - 1);
+        if (c < RJ) {
+            const int gj = wrap_j ? mg_wrap(gj0 + c, n) : gj0 + c;
+            for (int r = tid / LPC; r < RI; r += NT / LPC) {
+                const int gi = wrap_i ? mg_wrap(gi0 + r, n) : gi0 + r;
+                const size_t k = (size_t)gi * A.pitch + gj;
+                V[r * LP + c] = A.vin[k];
+                F[r * LP + c] = A.f[k];
+            }
+        }
+    } else {
+        for (int idx = tid; idx < RI * RJ; idx += NT) {
+            const int r = idx / RJ, c = idx - r * RJ;
+            const size_t k = (size_t)(gi0 + r) * A.pitch + (gj0 + c);
+            V[idx] = A.vin[k];
+            F[idx] = A.f[k];
+        }
+    }
+    __syncthreads();
+
+    // sides on which the staged region ends at the level's ghost ring
+    const bool plo_i = (gi0 == 0) && !wrap_i, phi_i = (gi1 == n + 1) && !wrap_i;
+    const bool plo_j = (gj0 == 0) && !wrap_j, phi_j = (gj1 == n + 1) && !wrap_j;
+    const bool any_phys = plo_i || phi_i || plo_j || phi_j;   // uniform per workgroup
+    const int npass = 2 * A.K;
+    // pass 0 only refreshes the staged ghost cells from their interior
+    // neighbours (the fill_BC that opens MG.smooth, MG.py:565), so the input
+    // buffer's ghosts need not be current
+    for (int s = 0; s <= npass; s++) {
+        const int colour = (s - 1) & 1;
+        // updatable cells (global indices): all four neighbours still valid
+        const int ulo_i = plo_i ? 1 : gi0 + s, uhi_i = phi_i ? n : gi1 - s;
+        const int ulo_j = plo_j ? 1 : gj0 + s, uhi_j = phi_j ? n : gj1 - s;
+        const int ni = uhi_i - ulo_i + 1, nj = uhi_j - ulo_j + 1;
+        if (s == 0) {
+            // nothing to update
+        } else if (LPC) {   // lane = cell of this colour within the row
+            const int h = tid & 63;
+            for (int ri = tid >> 6; ri < ni; ri += NT >> 6) {
+                const int gi = ulo_i + ri;
+                // colour 0: (gi-1)+(gj-1) even.  first column of that colour:
+                const int off = (gi - 1 + ulo_j - 1 + colour) & 1;
+                const int gj = ulo_j + off + 2 * h;
+                if (gj <= uhi_j) {
+                    const int c = (gi - gi0) * LP + (gj - gj0);
+                    V[c] = (F[c] + A.xc * (V[c + LP] + V[c - LP]) + A.yc * (V[c + 1] + V[c - 1])) /
+                           A.denom;
+                }
+            }
+        } else {
+            const int half = (nj + 1) >> 1;
+            for (int idx = tid; idx < ni * half; idx += NT) {
+                const int ri = idx / half, h = idx - ri * half;
+                const int gi = ulo_i + ri;
+                const int off = (gi - 1 + ulo_j - 1 + colour) & 1;
+                const int gj = ulo_j + off + 2 * h;
+                if (gj > uhi_j) continue;
+                const int c = (gi - gi0) * LP + (gj - gj0);
+                V[c] = (F[c] + A.xc * (V[c + LP] + V[c - LP]) + A.yc * (V[c + 1] + V[c - 1])) /
+                       A.denom;
+            }
+        }
+        if (s > 0) __syncthreads();
+        if (!any_phys) continue;
+        // ghost refresh on the physical sides (edge cells only; corners are
+        // never read by the 5-point stencil)
+        if (plo_i || phi_i)
+            for (int gj = ulo_j + tid; gj <= uhi_j; gj += NT) {
+                const int c = gj - gj0;
+                if (plo_i) {
+                    const double in = V[1 * LP + c];
+                    V[c] = (A.bc.code[0] == PYROHIP_BC_PERIODIC)
+                               ? V[n * LP + c]
+                               : ghost_lo(A.bc.code[0], in, A.bc.val[0], gj, A.dx);
+                }
+                if (phi_i) {
+                    const int rl = (n + 1) - gi0;
+                    const double in = V[(rl - 1) * LP + c];
+                    V[rl * LP + c] = (A.bc.code[1] == PYROHIP_BC_PERIODIC)
+                                         ? V[(1 - gi0) * LP + c]
+                                         : ghost_hi(A.bc.code[1], in, A.bc.val[1], gj, A.dx);
+                }
+            }
+        if (plo_j || phi_j)
+            for (int gi = ulo_i + tid; gi <= uhi_i; gi += NT) {
+                const int r = (gi - gi0) * LP;
+                if (plo_j) {
+                    const double in = V[r + 1];
+                    V[r] = (A.bc.code[2] == PYROHIP_BC_PERIODIC)
+                               ? V[r + n]
+                               : ghost_lo(A.bc.code[2], in, A.bc.val[2], gi, A.dx);
+                }
+                if (phi_j) {
+                    const int cl = (n + 1) - gj0;
+                    const double in = V[r + cl - 1];
+                    V[r + cl] = (A.bc.code[3] == PYROHIP_BC_PERIODIC)
+                                    ? V[r + (1 - gj0)]
+                                    : ghost_hi(A.bc.code[3], in, A.bc.val[3], gi, A.dx);
+                }
+            }
+        __syncthreads();
+    }
+
+    // tile (plus the ghost cells next to it on physical sides) -> vout
+    const int oi0 = (plo_i && ti0 == 1) ? 0 : ti0, oi1 = (phi_i && ti1 == n) ? n + 1 : ti1;
+    const int oj0 = (plo_j && tj0 == 1) ? 0 : tj0, oj1 = (phi_j && tj1 == n) ? n + 1 : tj1;
+    if (LPC) {
+        const int gj = oj0 + (tid & (LPC - 1));
+        if (gj <= oj1)
+            for (int gi = oi0 + tid / LPC; gi <= oi1; gi += NT / LPC)
+                A.vout[(size_t)gi * A.pitch + gj] = V[(gi - gi0) * LP + (gj - gj0)];
+    } else {
+        const int oni = oi1 - oi0 + 1, onj = oj1 - oj0 + 1;
+        for (int idx = tid; idx < oni * onj; idx += NT) {
+            const int r = idx / onj, c = idx - r * onj;
+            const int gi = oi0 + r, gj = oj0 + c;
+            A.vout[(size_t)gi * A.pitch + gj] = V[(gi - gi0) * LP + (gj - gj0)];
+        }
+    }
+    // periodic sides staged through wrapped indices: the tile that owns row /
+    // column n (1) also writes the ghost row / column 0 (n+1), so the other
+    // kernels (residual, prolongation) find current edge ghosts
+    if (wrap_i && (ti1 == n || ti0 == 1))
+        for (int gj = tj0 + tid; gj <= tj1; gj += NT) {
+            if (ti1 == n) A.vout[gj] = V[(n - gi0) * LP + (gj - gj0)];
+            if (ti0 == 1) A.vout[(size_t)(n + 1) * A.pitch + gj] = V[(1 - gi0) * LP + (gj - gj0)];
+        }
+    if (wrap_j && (tj1 == n || tj0 == 1))
+        for (int gi = ti0 + tid; gi <= ti1; gi += NT) {
+            if (tj1 == n) A.vout[(size_t)gi * A.pitch] = V[(gi - gi0) * LP + (n - gj0)];
+            if (tj0 == 1) A.vout[(size_t)gi * A.pitch + n + 1] = V[(gi - gi0) * LP + (1 - gj0)];
+        }
+}
+
+
+// ---------------------------------------------------------------------------
+// Coarse sub-V-cycle: every level with n <= 64 (v and f of 2^2 ... 64^2, 96 KB)
+// lives in the LDS of ONE workgroup, which runs the whole recursion below the
+// 64^2 level -- smoothing, residual, restriction, bottom solve, prolongation --
+// without leaving the kernel.  These levels are pure launch latency otherwise
+// (~550 us of ~100 dependent launches per V-cycle at 4096^2, measured).
+// Arithmetic and operation order are those of the per-level kernels.
+// ---------------------------------------------------------------------------
+constexpr int MGC_TOP = 5;                       // level index of n = 64
+constexpr int MGC_NT = 1024;
+struct MGCoarse {
+    double *v[MGC_TOP + 1], *f[MGC_TOP + 1], *r[MGC_TOP + 1];
+    int pitch[MGC_TOP + 1];
+    double dx[MGC_TOP + 1];
+    int top;                                     // run levels top .. 0
+    int finest;                                  // 1: `top` is the finest level (bc values apply)
+    double alpha, beta;
+    int nsmooth, nsmooth_bottom;
+    MGBC bc;                                     // val[] only meaningful when finest
+};
+__host__ __device__ inline int mgc_off(int l)    // LDS offset (doubles) of level l's v
+{
+    int o = 0;
+    for (int k = 0; k < l; k++) o += 2 * ((2 << k) + 2) * ((2 << k) + 2);
+    return o;
+}
+constexpr int MGC_LDS_DOUBLES = 2 * (16 + 36 + 100 + 324 + 1156 + 4356);
+constexpr size_t MGC_LDS = (size_t)MGC_LDS_DOUBLES * sizeof(double);
+
+__device__ inline void mgc_fill(double *V, int n, double dx, const MGBC &bc, bool use_val, int tid)
+{
+    const int q = n + 2;
+    // x sides over all j, then y sides over all i (corners from x-filled data)
+    for (int j = tid; j < q; j += MGC_NT) {
+        const double *v0 = use_val ? bc.val[0] : nullptr, *v1 = use_val ? bc.val[1] : nullptr;
+        V[j] = (bc.code[0] == PYROHIP_BC_PERIODIC) ? V[n * q + j]
+                                                    : ghost_lo(bc.code[0], V[q + j], v0, j, dx);
+        V[(n + 1) * q + j] = (bc.code[1] == PYROHIP_BC_PERIODIC)
+                                 ? V[q + j]
+                                 : ghost_hi(bc.code[1], V[n * q + j], v1, j, dx);
+    }
+    __syncthreads();
+    for (int i = tid; i < q; i += MGC_NT) {
+        const double *v2 = use_val ? bc.val[2] : nullptr, *v3 = use_val ? bc.val[3] : nullptr;
+        double *row = V + i * q;
+        row[0] = (bc.code[2] == PYROHIP_BC_PERIODIC) ? row[n] : ghost_lo(bc.code[2], row[1], v2, i, dx);
+        row[n + 1] = (bc.code[3] == PYROHIP_BC_PERIODIC) ? row[1]
+                                                          : ghost_hi(bc.code[3], row[n], v3, i, dx);
+    }
+    __syncthreads();
+}
+
+__device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, double dx,
+                                  double alpha, double beta, int iters, const MGBC &bc,
+                                  bool use_val, int tid)
+{
+    const int q = n + 2;
+    const double xc = beta / (dx * dx), yc = beta / (dx * dx);
+    const double denom = alpha + 2.0 * xc + 2.0 * yc;
+    mgc_fill(V, n, dx, bc, use_val, tid);                       // MG.py:565
+    const int half = n >> 1;                                    // cells of one colour per row
+    for (int it = 0; it < 2 * iters; it++) {
+        const int colour = it & 1;
+        for (int idx = tid; idx < n * half; idx += MGC_NT) {
+            const int ri = (lg > 1) ? (idx >> (lg - 1)) : idx, h = idx - ri * half;
+            const int i = 1 + ri;
+            const int j = 1 + 2 * h + ((ri + colour) & 1);
+            const int c = i * q + j;
+            V[c] = (F[c] + xc * (V[c + q] + V[c - q]) + yc * (V[c + 1] + V[c - 1])) / denom;
+        }
+        __syncthreads();
+        mgc_fill(V, n, dx, bc, use_val, tid);                   // MG.py:598-599
+    }
+}
+
+__global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
+{
+    HIP_DYNAMIC_SHARED(double, lds)
+    const int tid = threadIdx.x;
+    // stage v and f of every level
+    for (int l = 0; l <= A.top; l++) {
+        const int n = 2 << l, q = n + 2;
+        double *V = lds + mgc_off(l), *F = V + q * q;
+        for (int idx = tid; idx < q * q; idx += MGC_NT) {
+            const int i = idx / q, j = idx - i * q;
+            V[idx] = A.v[l][(size_t)i * A.pitch[l] + j];
+            F[idx] = A.f[l][(size_t)i * A.pitch[l] + j];
+        }
+    }
+    __syncthreads();
+    // down leg (MG.py:722-735)
+    for (int l = A.top; l >= 1; l--) {
+        const int n = 2 << l, q = n + 2, nc = n >> 1, qc = nc + 2;
+        double *V = lds + mgc_off(l), *F = V + q * q;
+        double *Fc = lds + mgc_off(l - 1) + qc * qc;
+        const bool uv = A.finest && l == A.top;
+        mgc_smooth(V, F, n, l + 1, A.dx[l], A.alpha, A.beta, A.nsmooth, A.bc, uv, tid);
+        const double dx2 = A.dx[l] * A.dx[l];
+        // residual (MG.py:529-542) -> global r; restriction of it -> coarse f
+        for (int idx = tid; idx < nc * nc; idx += MGC_NT) {
+            const int ci = idx / nc, cj = idx - ci * nc;
+            double rr[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = 1 + 2 * ci + (k & 1), j = 1 + 2 * cj + (k >> 1);
+                const int c = i * q + j;
+                rr[k] = F[c] - A.alpha * V[c] +
+                        A.beta * ((V[c - q] + V[c + q] - 2 * V[c]) / dx2 +
+                                  (V[c - 1] + V[c + 1] - 2 * V[c]) / dx2);
+                A.r[l][(size_t)i * A.pitch[l] + j] = rr[k];
+            }
+            // patch.py:660-662: (i,j) + (i+1,j) + (i,j+1) + (i+1,j+1)
+            Fc[(1 + ci) * qc + (1 + cj)] = 0.25 * (rr[0] + rr[1] + rr[2] + rr[3]);
+        }
+        __syncthreads();
+    }
+    {   // bottom solve (MG.py:776-778)
+        double *V = lds + mgc_off(0), *F = V + 16;
+        mgc_smooth(V, F, 2, 1, A.dx[0], A.alpha, A.beta, A.nsmooth_bottom, A.bc,
+                   A.finest && A.top == 0, tid);
+    }
+    // up leg (MG.py:745-758)
+    for (int l = 1; l <= A.top; l++) {
+        const int n = 2 << l, q = n + 2, nc = n >> 1, qc = nc + 2;
+        double *V = lds + mgc_off(l), *F = V + q * q;
+        const double *Vc = lds + mgc_off(l - 1);
+        for (int idx = tid; idx < n * n; idx += MGC_NT) {
+            const int fi = idx / n, fj = idx - fi * n;
+            const int ck = (1 + (fi >> 1)) * qc + 1 + (fj >> 1);
+            const double c0 = Vc[ck];
+            const double m_x = 0.5 * (Vc[ck + qc] - Vc[ck - qc]);
+            const double m_y = 0.5 * (Vc[ck + 1] - Vc[ck - 1]);
+            double e;
+            if (fi & 1) e = (fj & 1) ? c0 + 0.25 * m_x + 0.25 * m_y : c0 + 0.25 * m_x - 0.25 * m_y;
+            else        e = (fj & 1) ? c0 - 0.25 * m_x + 0.25 * m_y : c0 - 0.25 * m_x - 0.25 * m_y;
+            V[(1 + fi) * q + (1 + fj)] += e;
+        }
+        __syncthreads();
+        mgc_smooth(V, F, n, l + 1, A.dx[l], A.alpha, A.beta, A.nsmooth, A.bc,
+                   A.finest && l == A.top, tid);
+    }
+    // write back: v of every level, f of the levels below the top
+    for (int l = 0; l <= A.top; l++) {
+        const int n = 2 << l, q = n + 2;
+        const double *V = lds + mgc_off(l), *F = V + q * q;
+        for (int idx = tid; idx < q * q; idx += MGC_NT) {
+            const int i = idx / q, j = idx - i * q;
+            A.v[l][(size_t)i * A.pitch[l] + j] = V[idx];
+            if (l < A.top) A.f[l][(size_t)i * A.pitch[l] + j] = F[idx];
+        }
     }
 }
 
@@ -239,11 +607,10 @@ static int mg_fill(pyrohip_mg *m, int level, int var)
     return 0;
 }
 
-static int mg_smooth(pyrohip_mg *m, int level, int nsmooth)
+static int mg_smooth_colour_launches(pyrohip_mg *m, int level, int nsmooth)
 {
     MGLevel &L = m->lev[level];
     MGBC bc = make_bc(m, level, true);
-    PYRO_TRY(mg_fill(m, level, 0));                       // MG.py:565
     const double xcoeff = m->beta / (L.dx * L.dx);        // :567-568
     const double ycoeff = m->beta / (L.dx * L.dx);
     const double denom = m->alpha + 2.0 * xcoeff + 2.0 * ycoeff;
@@ -253,9 +620,69 @@ static int mg_smooth(pyrohip_mg *m, int level, int nsmooth)
     for (int it = 0; it < nsmooth; it++)
         for (int colour = 0; colour < 2; colour++)
             PYRO_LAUNCH(m->ctx, "k_mg_smooth", k_mg_smooth, grid, block, 0, L.v,
-                               (const double *)L.f, L.n, L.pitch, L.dx, xcoeff, ycoeff, denom,
-                               colour, bc);
+                        (const double *)L.f, L.n, L.pitch, L.dx, xcoeff, ycoeff, denom, colour, bc);
     return 0;
+}
+
+static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth)
+{
+    MGLevel &L = m->lev[level];
+#ifndef PYRO_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_mg_smooth_tile<256, 0>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)MGS_LDS));
+        PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_mg_smooth_tile<MGW_NT, MGW_LP>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)MGW_LDS));
+        attr_set = true;
+    }
+#endif
+    MGTile A;
+    A.f = L.f; A.n = L.n; A.pitch = L.pitch; A.dx = L.dx;
+    A.xc = m->beta / (L.dx * L.dx);
+    A.yc = m->beta / (L.dx * L.dx);
+    A.denom = m->alpha + 2.0 * A.xc + 2.0 * A.yc;
+    A.bc = make_bc(m, level, true);
+    A.single = ((L.n + 2) * (L.n + 2) <= MGS_CELLS) ? 1 : 0;   // whole level in one tile
+    const int kmax = (m->kmax >= 1 && m->kmax <= MGW_KMAX) ? m->kmax : 2;
+    int left = nsmooth;
+    while (left > 0) {
+        const int K = A.single ? left : (left < kmax ? left : kmax);
+        A.K = K;
+        A.vin = L.v; A.vout = L.v2;
+        if (A.single) {
+            A.TI = L.n; A.TJ = L.n; A.ntj = 1; A.ntiles = 1;
+            PYRO_LAUNCH(m->ctx, "k_mg_smooth_tile", (k_mg_smooth_tile<256, 0>), dim3(1), dim3(256),
+                        MGS_LDS, A);
+        } else {
+            A.TI = MGW_RI - 4 * K; A.TJ = MGW_LP - 4 * K;
+            const int nti = (L.n + A.TI - 1) / A.TI;
+            A.ntj = (L.n + A.TJ - 1) / A.TJ;
+            A.ntiles = nti * A.ntj;
+            PYRO_LAUNCH(m->ctx, "k_mg_smooth_tile", (k_mg_smooth_tile<MGW_NT, MGW_LP>),
+                        dim3(A.ntiles), dim3(MGW_NT), MGW_LDS, A);
+        }
+        double *t = L.v; L.v = L.v2; L.v2 = t;
+        left -= K;
+    }
+    return 0;
+}
+
+// `corners`: also make the corner ghosts exact (needed only when the array is
+// handed to the host; no kernel reads corners)
+static int mg_smooth(pyrohip_mg *m, int level, int nsmooth, bool corners = true)
+{
+    if (m->smoother == 0 || nsmooth <= 0) {
+        PYRO_TRY(mg_fill(m, level, 0));                   // MG.py:565
+        return nsmooth > 0 ? mg_smooth_colour_launches(m, level, nsmooth) : 0;
+    }
+    // the tile kernel refreshes the edge ghosts itself on load (= the fill_BC
+    // of MG.py:565) and leaves them current on exit
+    PYRO_TRY(mg_smooth_tiles(m, level, nsmooth));
+    m->corners_stale[level] = !corners;
+    return corners ? mg_fill(m, level, 0) : 0;
 }
 
 static int mg_residual(pyrohip_mg *m, int level)
@@ -315,19 +742,48 @@ static int mg_sumsq(pyrohip_mg *m, const double *a, const double *b, int level, 
     return 0;
 }
 
+static int mg_coarse_vcycle(pyrohip_mg *m, int top)
+{
+#ifndef PYRO_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_mg_coarse_vcycle,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)MGC_LDS));
+        attr_set = true;
+    }
+#endif
+    MGCoarse A;
+    for (int l = 0; l <= MGC_TOP; l++) {
+        MGLevel &L = m->lev[l <= top ? l : top];
+        A.v[l] = L.v; A.f[l] = L.f; A.r[l] = L.r; A.pitch[l] = L.pitch; A.dx[l] = L.dx;
+    }
+    A.top = top;
+    A.finest = (top == m->nlevels - 1) ? 1 : 0;
+    A.alpha = m->alpha; A.beta = m->beta;
+    A.nsmooth = m->nsmooth; A.nsmooth_bottom = m->nsmooth_bottom;
+    A.bc = make_bc(m, top, true);
+    PYRO_LAUNCH(m->ctx, "k_mg_coarse_vcycle", k_mg_coarse_vcycle, dim3(1), dim3(MGC_NT), MGC_LDS,
+                A);
+    for (int l = 0; l <= top; l++) m->corners_stale[l] = false;   // full fills inside
+    return 0;
+}
+
 static int mg_vcycle(pyrohip_mg *m, int level)
 {
+    if (m->smoother != 0 && m->coarse_kernel && level <= MGC_TOP)
+        return mg_coarse_vcycle(m, level);
     if (level > 0) {
-        PYRO_TRY(mg_smooth(m, level, m->nsmooth));       // MG.py:722
+        PYRO_TRY(mg_smooth(m, level, m->nsmooth, false)); // MG.py:722
         PYRO_TRY(mg_residual(m, level));                  // :724
         PYRO_TRY(mg_restrict(m, level));                  // :731-732
         PYRO_TRY(mg_vcycle(m, level - 1));                // :735
         PYRO_TRY(mg_prolong_add(m, level));               // :745-748
-        PYRO_TRY(mg_fill(m, level, 0));                   // :751
-        PYRO_TRY(mg_smooth(m, level, m->nsmooth));        // :758
+        if (m->smoother == 0) PYRO_TRY(mg_fill(m, level, 0));   // :751 (tile smoother: on load)
+        PYRO_TRY(mg_smooth(m, level, m->nsmooth, false)); // :758
     } else {
-        PYRO_TRY(mg_smooth(m, level, m->nsmooth_bottom)); // :776
-        PYRO_TRY(mg_fill(m, level, 0));                   // :778
+        PYRO_TRY(mg_smooth(m, level, m->nsmooth_bottom, false)); // :776
+        if (m->smoother == 0) PYRO_TRY(mg_fill(m, level, 0));     // :778
     }
     return 0;
 }
@@ -372,7 +828,7 @@ int pyrohip_mg_create(pyrohip_ctx *c, int nx, double xmin, double xmax, double y
     int nt = 2;
     for (int l = 0; l < nl; l++) {
         Geom g = make_geom(nt, nt, 1);
-        total += 3 * g.plane + 16;
+        total += 4 * g.plane + 16;
         nt *= 2;
     }
     Geom gf = make_geom(nx, nx, 1);
@@ -390,6 +846,7 @@ int pyrohip_mg_create(pyrohip_ctx *c, int nx, double xmin, double xmax, double y
         L.v = p + geom_lead(g); p += g.plane;
         L.f = p + geom_lead(g); p += g.plane;
         L.r = p + geom_lead(g); p += g.plane;
+        L.v2 = p + geom_lead(g); p += g.plane;
         p += 16;
         nt *= 2;
     }
@@ -407,6 +864,19 @@ int pyrohip_mg_destroy(pyrohip_mg *m)
     for (int s = 0; s < 4; s++)
         if (m->bcval[s]) (void)hipFree(m->bcval[s]);
     delete m;
+    return 0;
+}
+
+int pyrohip_mg_set_smoother(pyrohip_mg *m, int kind)
+{
+    PYRO_REQUIRE(m, "NULL mg");
+    PYRO_REQUIRE(kind >= 0 && kind <= 23, "smoother must be 0, 1, 10+kmax or 20+kmax");
+    // 10 + k selects the tile smoother with k fused iterations (tuning knob)
+    // 20 + k: the same without the single-workgroup coarse V-cycle kernel
+    m->coarse_kernel = 1;
+    if (kind >= 20) { m->smoother = 1; m->kmax = kind - 20; m->coarse_kernel = 0; }
+    else if (kind >= 10) { m->smoother = 1; m->kmax = kind - 10; }
+    else m->smoother = kind;
     return 0;
 }
 
@@ -434,6 +904,10 @@ int pyrohip_mg_get(pyrohip_mg *m, int level, int var, double *host)
 {
     MG_CHECK_LEVEL(m, level);
     PYRO_REQUIRE(var >= 0 && var <= 2 && host, "bad var / NULL host");
+    if (var == 0 && m->corners_stale[level]) {   // index-for-index incl. corner ghosts
+        PYRO_TRY(mg_fill(m, level, 0));
+        m->corners_stale[level] = false;
+    }
     MGLevel &L = m->lev[level];
     const int q = L.n + 2;
     PYRO_CHECK_HIP(hipMemcpy2DAsync(host, q * sizeof(double), plane(m, level, var),

@@ -295,6 +295,9 @@ class DeviceMG:
         with self.ctx.lock:
             check(getattr(self._l, fn)(self.h, *args))
 
+    def set_smoother(self, kind):
+        self._call("pyrohip_mg_set_smoother", int(kind))
+
     def zero(self, level, var):
         self._call("pyrohip_mg_zero", level, var)
 

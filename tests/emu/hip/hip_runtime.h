@@ -100,6 +100,8 @@ static const hipemu_gdim_proxy gridDim;
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
     ::hipemu::launch((grid), (block), (shmem), [&]() { kern(__VA_ARGS__); })
 
+using std::max;
+using std::min;
 inline void __syncthreads() { hipemu::block_barrier(); }
 inline double __shfl_down(double v, unsigned delta, int width = 64)
 {

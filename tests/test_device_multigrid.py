@@ -144,3 +144,40 @@ def test_mg_4096_vcycle_properties(hip):
     e = (v - (X ** 2 - X ** 4) * (Y ** 4 - Y ** 2))[1:-1, 1:-1]
     l2 = np.sqrt(np.sum(e ** 2) / nx ** 2)
     assert l2 < 1.60408e-06 / 200.0   # (4096/256)^2 = 256x smaller than at 256^2
+
+
+@pytest.mark.parametrize("bcs", [("dirichlet",) * 4, ("periodic",) * 4,
+                                 ("neumann", "dirichlet", "periodic", "periodic"),
+                                 ("periodic", "periodic", "dirichlet", "neumann")])
+def test_mg_tile_smoother_multi_tile(dev, bcs):
+    """128^2 is 4 x 2 tiles of the LDS tile smoother (incl. wrapped staging on
+    periodic sides and the K = 5 + 2 launch split): must equal both the
+    one-launch-per-colour kernel and the oracle bit for bit"""
+    from oracle import orc
+    nx = 128
+    rng = np.random.default_rng(11)
+    v0 = rng.standard_normal((nx + 2, nx + 2))
+    f0 = rng.standard_normal((nx + 2, nx + 2))
+    o = orc.MG(nx, bcs=bcs, alpha=0.3, beta=-1.1)
+    L = o.nlevels - 1
+    o.arr(L, 0)[:, :] = v0
+    o.init_rhs(f0)
+    o.smooth(L, 7)
+    res = {}
+    for kind in (0, 1, 11, 13):     # 10 + k: tile smoother, k iterations / launch
+        m = device.DeviceMG(dev, nx, bcs=bcs, alpha=0.3, beta=-1.1)
+        m.set_smoother(kind)
+        m.set(L, 0, v0)
+        m.set(L, 1, f0)
+        m.smooth(L, 7)
+        m.fill_bc(L, 0)
+        res[kind] = m.get(L, 0)
+    tol = 0.0 if dev.kind == "emu" else TOL
+    assert max_rel_err(res[0], o.arr(L, 0)) <= tol
+    for kind in (1, 11, 13):
+        assert np.array_equal(res[0], res[kind]), kind
+    # and a whole V-cycle through the tile smoother
+    o.vcycle()
+    m.vcycle()
+    m.fill_bc(L, 0)
+    assert max_rel_err(m.get(L, 0), o.arr(L, 0)) <= tol * 10
