@@ -282,10 +282,21 @@ def main():
             "kernels": {k: {"launches": n, "avg_ms": ms / n} for k, (n, ms) in upd.items()},
             "stream_event_ms_per_step": r["event_ms"] / args.steps,
         }
+        # traffic: fabric bytes per launch from the committed rocprofv3 PMC
+        # passes (profiles/traffic.json, measured per cell at 8192^2 with the
+        # same kernel), scaled to this rank's cells; null for other kernel sets
         tr = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tr):
+        if os.path.exists(tr) and defaults["kernel_set"] == 1:
             try:
-                out["roofline"]["traffic"] = json.load(open(tr))
+                t = json.load(open(tr))[f"fast_math_{defaults['fast_math']}"]
+                out["roofline"]["traffic"] = t["bytes_per_cell_update"] * r["local_cells"]
+                out["roofline"]["traffic_source"] = "profiles/traffic.json: " + t["measured_at"]
+                # the binding roof of this kernel is FP64 VALU issue, not HBM
+                # (DESIGN.md 3): report it next to the HBM roofline
+                out["roofline"]["valu"] = {
+                    "valu_insts_per_wave": t["valu_insts_per_wave"],
+                    "valu_busy_frac_of_kernel_time": t["valu_busy_ms"] / t["kernel_ms"],
+                    "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU, same profile"}
             except Exception:
                 pass
         if world == 1:

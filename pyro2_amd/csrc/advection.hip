@@ -35,6 +35,8 @@ struct AdvParams {
     int limiter;
 };
 
+// LIM: limiter (0 none, 1 MC2, 2 MC4); UNEG / VNEG: u < 0 / v < 0 (upwind side)
+template <int LIM, bool UNEG, bool VNEG>
 __global__ __launch_bounds__(ADV_THREADS) void k_adv_step(const double *__restrict__ ain,
                                                           double *__restrict__ aout, Geom g,
                                                           AdvParams P, int ntj, int ntiles)
@@ -42,7 +44,6 @@ __global__ __launch_bounds__(ADV_THREADS) void k_adv_step(const double *__restri
     __shared__ double A[ADV_AH][ADV_AW];
     __shared__ double AX[ADV_XH][ADV_XW];
     __shared__ double AY[ADV_YH][ADV_YW];
-
     const int tile = xcd_tile(blockIdx.x, ntiles);
     const int i0 = g.ilo + (tile / ntj) * ADV_TI;
     const int j0 = g.jlo + (tile % ntj) * ADV_TJ;
@@ -62,43 +63,26 @@ __global__ __launch_bounds__(ADV_THREADS) void k_adv_step(const double *__restri
     const double u = P.u, v = P.v, dt = P.dt;
     const double cx = u * dt / P.dx;   // interface.py:10-11
     const double cy = v * dt / P.dy;
-    const int lim = P.limiter;
 
     // ---- phase 1: upwind interface states (interface.py:25-41) ----------
     // a_x at faces i in [i0, i0+TI], j in [j0-1, j0+TJ]
     for (int idx = tid; idx < ADV_XH * ADV_XW; idx += ADV_THREADS) {
-        int r = idx / ADV_XW, c = idx - r * ADV_XW;
-        // A-tile coordinates of cell (i0 + r, j0 - 1 + c)
-        int ar = r + ADV_H, ac = c - 1 + ADV_H;
-        double val;
-        if (u < 0) {
-            double ld = limited_slope(A[ar - 2][ac], A[ar - 1][ac], A[ar][ac], A[ar + 1][ac],
-                                      A[ar + 2][ac], lim);
-            val = A[ar][ac] - 0.5 * (1.0 + cx) * ld;
-        } else {
-            int br = ar - 1;
-            double ld = limited_slope(A[br - 2][ac], A[br - 1][ac], A[br][ac], A[br + 1][ac],
-                                      A[br + 2][ac], lim);
-            val = A[br][ac] + 0.5 * (1.0 - cx) * ld;
-        }
-        AX[r][c] = val;
+        const int r = idx / ADV_XW, c = idx - r * ADV_XW;
+        // A-tile coordinates of the upwind cell of face (i0 + r, j0 - 1 + c)
+        const int br = r + ADV_H - (UNEG ? 0 : 1), ac = c - 1 + ADV_H;
+        const double a0 = A[br][ac];
+        const double ld = limited_slope(A[br - 2][ac], A[br - 1][ac], a0, A[br + 1][ac],
+                                        A[br + 2][ac], LIM);
+        AX[r][c] = UNEG ? a0 - 0.5 * (1.0 + cx) * ld : a0 + 0.5 * (1.0 - cx) * ld;
     }
     // a_y at faces i in [i0-1, i0+TI], j in [j0, j0+TJ]
     for (int idx = tid; idx < ADV_YH * ADV_YW; idx += ADV_THREADS) {
-        int r = idx / ADV_YW, c = idx - r * ADV_YW;
-        int ar = r - 1 + ADV_H, ac = c + ADV_H;
-        double val;
-        if (v < 0) {
-            double ld = limited_slope(A[ar][ac - 2], A[ar][ac - 1], A[ar][ac], A[ar][ac + 1],
-                                      A[ar][ac + 2], lim);
-            val = A[ar][ac] - 0.5 * (1.0 + cy) * ld;
-        } else {
-            int bc = ac - 1;
-            double ld = limited_slope(A[ar][bc - 2], A[ar][bc - 1], A[ar][bc], A[ar][bc + 1],
-                                      A[ar][bc + 2], lim);
-            val = A[ar][bc] + 0.5 * (1.0 - cy) * ld;
-        }
-        AY[r][c] = val;
+        const int r = idx / ADV_YW, c = idx - r * ADV_YW;
+        const int ar = r - 1 + ADV_H, bc = c + ADV_H - (VNEG ? 0 : 1);
+        const double a0 = A[ar][bc];
+        const double ld = limited_slope(A[ar][bc - 2], A[ar][bc - 1], a0, A[ar][bc + 1],
+                                        A[ar][bc + 2], LIM);
+        AY[r][c] = VNEG ? a0 - 0.5 * (1.0 + cy) * ld : a0 + 0.5 * (1.0 - cy) * ld;
     }
     __syncthreads();
 
@@ -130,15 +114,45 @@ __global__ __launch_bounds__(ADV_THREADS) void k_adv_step(const double *__restri
     }
 }
 
-// copy the ghost frame of plane n from src to dst (keeps the "stale ghost"
-// semantics of the reference's in-place update)
+template <int LIM>
+static void adv_launch(pyrohip_ctx *c, bool uneg, bool vneg, int ntiles, const double *cur,
+                       double *nxt, const Geom &g, const AdvParams &P, int ntj)
+{
+    const dim3 grid(ntiles), block(ADV_THREADS);
+    if (uneg && vneg)
+        PYRO_LAUNCH(c, "k_adv_step", (k_adv_step<LIM, true, true>), grid, block, 0, cur, nxt, g, P, ntj, ntiles);
+    else if (uneg)
+        PYRO_LAUNCH(c, "k_adv_step", (k_adv_step<LIM, true, false>), grid, block, 0, cur, nxt, g, P, ntj, ntiles);
+    else if (vneg)
+        PYRO_LAUNCH(c, "k_adv_step", (k_adv_step<LIM, false, true>), grid, block, 0, cur, nxt, g, P, ntj, ntiles);
+    else
+        PYRO_LAUNCH(c, "k_adv_step", (k_adv_step<LIM, false, false>), grid, block, 0, cur, nxt, g, P, ntj, ntiles);
+}
+
+// copy the ghost frame of one plane from src to dst (keeps the "stale ghost"
+// semantics of the reference's in-place update).  O(perimeter): blockIdx.y
+// enumerates the 2*ng ghost rows (all j), then groups of interior rows (only
+// their 2*ng ghost columns).
 __global__ void k_copy_frame(const double *__restrict__ src, double *__restrict__ dst, Geom g)
 {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    int i = blockIdx.y;
-    if (j >= g.qy || i >= g.qx) return;
-    bool interior = (i >= g.ilo && i <= g.ihi && j >= g.jlo && j <= g.jhi);
-    if (!interior) dst[(size_t)i * g.pitch + j] = src[(size_t)i * g.pitch + j];
+    const int ng = g.ng;
+    const int b = blockIdx.y;
+    int i, j;
+    if (b < 2 * ng) {
+        i = (b < ng) ? b : g.ihi + 1 + (b - ng);
+        j = blockIdx.x * blockDim.x + threadIdx.x;
+        if (j >= g.qy) return;
+    } else {
+        if (blockIdx.x != 0) return;
+        const int t = threadIdx.x;
+        const int rows_per_block = 256 / (2 * ng);
+        const int r = (b - 2 * ng) * rows_per_block + t / (2 * ng);
+        const int kx = t % (2 * ng);
+        if (r >= g.nx || t >= rows_per_block * 2 * ng) return;
+        i = g.ilo + r;
+        j = (kx < ng) ? kx : g.jhi + 1 + (kx - ng);
+    }
+    dst[(size_t)i * g.pitch + j] = src[(size_t)i * g.pitch + j];
 }
 
 }  // namespace pyro
@@ -166,13 +180,19 @@ extern "C" int pyrohip_adv_step(pyrohip_state *s, int n, double dx, double dy, d
     AdvParams P{u, v, dt, dx, dy, limiter};
     const int nti = (g.nx + ADV_TI - 1) / ADV_TI, ntj = (g.ny + ADV_TJ - 1) / ADV_TJ;
     const int ntiles = nti * ntj;
-    PYRO_LAUNCH(c, "k_adv_step", k_adv_step, dim3(ntiles), dim3(ADV_THREADS), 0,
-                       (const double *)cur, nxt, g, P, ntj, ntiles);
+    const bool uneg = (u < 0), vneg = (v < 0);   // interface.py:28,38
+    if (limiter == 0) adv_launch<0>(c, uneg, vneg, ntiles, cur, nxt, g, P, ntj);
+    else if (limiter == 1) adv_launch<1>(c, uneg, vneg, ntiles, cur, nxt, g, P, ntj);
+    else adv_launch<2>(c, uneg, vneg, ntiles, cur, nxt, g, P, ntj);
     // interior back into the state plane: swap roles by copying the interior
     // is avoided -- instead copy the (tiny) ghost frame into the new buffer
     // and exchange the two planes' contents by pointer where possible.
-    hipLaunchKernelGGL(k_copy_frame, dim3((g.qy + 255) / 256, g.qx), dim3(256), 0, c->stream,
-                       (const double *)cur, nxt, g);
+    {
+        const int rows_per_block = 256 / (2 * g.ng);
+        const int nby = 2 * g.ng + (g.nx + rows_per_block - 1) / rows_per_block;
+        hipLaunchKernelGGL(k_copy_frame, dim3((g.qy + 255) / 256, nby), dim3(256), 0, c->stream,
+                           (const double *)cur, nxt, g);
+    }
     PYRO_CHECK_HIP(hipGetLastError());
     if (s->nvar == 1) {
         // single-variable state: swap the two allocations

@@ -285,12 +285,27 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
 
 // ghost frame of all 4 planes old -> new (the reference updates in place, so
 // ghost cells keep their pre-step values)
+// O(perimeter): blockIdx.y enumerates the 2*ng ghost rows (all j) followed by
+// the nx interior rows (only their 2*ng ghost columns)
 __global__ void k_copy_frame4(const double *__restrict__ src, double *__restrict__ dst, Geom g)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
-    if (j >= g.qy || i >= g.qx) return;
-    if (i >= g.ilo && i <= g.ihi && j >= g.jlo && j <= g.jhi) return;
+    const int ng = g.ng;
+    const int b = blockIdx.y;
+    int i, j;
+    if (b < 2 * ng) {                               // a full ghost row
+        i = (b < ng) ? b : g.ihi + 1 + (b - ng);
+        j = blockIdx.x * blockDim.x + threadIdx.x;
+        if (j >= g.qy) return;
+    } else {                                        // ghost columns of interior rows
+        if (blockIdx.x != 0) return;
+        const int t = threadIdx.x;                  // 256 threads: 2*ng columns x rows
+        const int rows_per_block = 256 / (2 * ng);
+        const int r = (b - 2 * ng) * rows_per_block + t / (2 * ng);
+        const int kx = t % (2 * ng);
+        if (r >= g.nx || t >= rows_per_block * 2 * ng) return;
+        i = g.ilo + r;
+        j = (kx < ng) ? kx : g.jhi + 1 + (kx - ng);
+    }
     const size_t k = (size_t)i * g.pitch + j;
 #pragma unroll
     for (int n = 0; n < 4; n++) dst[n * g.plane + k] = src[n * g.plane + k];
@@ -342,8 +357,12 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
 #endif
     PYRO_LAUNCH(c, "k_ctu_fused", k_ctu_fused, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
                 (const double *)Uin, Uout, g, P, s->d_flag, part);
-    hipLaunchKernelGGL(k_copy_frame4, dim3((g.qy + 255) / 256, g.qx), dim3(256), 0, c->stream,
-                       (const double *)Uin, Uout, g);
+    {
+        const int rows_per_block = 256 / (2 * g.ng);
+        const int nby = 2 * g.ng + (g.nx + rows_per_block - 1) / rows_per_block;
+        hipLaunchKernelGGL(k_copy_frame4, dim3((g.qy + 255) / 256, nby), dim3(256), 0, c->stream,
+                           (const double *)Uin, Uout, g);
+    }
     hipLaunchKernelGGL(k_min_final_f, dim3(1), dim3(256), 0, c->stream, (const double *)part,
                        P.ntiles, part + P.ntiles);
     PYRO_CHECK_HIP(hipGetLastError());
