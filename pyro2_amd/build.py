@@ -15,6 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, os.environ.get("PYRO_LIB_NAME", "libpyrohip.so"))
 EXTRA = os.environ.get("PYRO_EXTRA_FLAGS", "").split()   # developer experiments only
+FAST_EXTRA = os.environ.get("PYRO_FAST_EXTRA_FLAGS", "").split()   # ... fast_math units only
 
 ARCH = "gfx950"
 COMMON = ["-std=c++17", "-fPIC", "-O3"]
@@ -69,7 +70,8 @@ def build(force=False, verbose=False):
     def compile_one(u):
         src, name, extra = u
         obj = os.path.join(LIBDIR, "obj", name + os.environ.get("PYRO_OBJ_SUFFIX", "") + ".o")
-        cmd = [hipcc, f"--offload-arch={ARCH}"] + COMMON + extra + EXTRA + \
+        fx = FAST_EXTRA if "-DPYRO_FAST=1" in extra else []
+        cmd = [hipcc, f"--offload-arch={ARCH}"] + COMMON + extra + EXTRA + fx + \
               ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -27,10 +27,6 @@ static int check_comp(pyrohip_state *s, const pyrohip_comp_params *p)
     PYRO_REQUIRE(s->g.ng >= 4, "compressible needs ng >= 4 (compressible/simulation.py:194)");
     PYRO_REQUIRE(p->limiter >= 0 && p->limiter <= 2, "limiter must be 0, 1 or 2");
     PYRO_REQUIRE(p->dx > 0 && p->dy > 0 && p->gamma > 1.0, "bad dx/dy/gamma");
-    if (p->grav != 0.0) {
-        set_error("compressible.grav != 0 is not implemented on the device yet");
-        return PYROHIP_ERR_UNSUPPORTED;
-    }
     return 0;
 }
 

@@ -63,6 +63,8 @@ struct FP {   // kernel parameters
     double dtdx, dtdy;    // dt/dx, dt/dy          interface.py:106
     double hdtV;          // (0.5*dt)/(dx*dy)      unsplit_fluxes.py:444-445
     double dtdV;          // dt/(dx*dy)            simulation.py:375
+    double grav;          // compressible.grav (0: no source terms)
+    int refl_ylo, refl_yhi;   // y-momentum reflects oddly at the lower / upper y wall
 };
 
 __device__ __forceinline__ ConsN to_nf(const Cons &U, bool x)
@@ -182,6 +184,19 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
         // vertex divergence at (i-1/2, j-1/2), interface.py:312-330
         D[t] = div_u_vertex(Qu[qc], Qu[qc - 1], Qu[qc - FQW], Qu[qc - FQW - 1], Qv[qc],
                             Qv[qc - FQW], Qv[qc - 1], Qv[qc - FQW - 1], P.dx, P.dy);
+        if (P.grav != 0.0) {   // apply_source_terms, unsplit_fluxes.py:247-330
+            const bool ina = (i < g.qx && j < g.qy);
+            const size_t kc = (size_t)(ina ? i : g.qx - 1) * p + (ina ? j : g.qy - 1);
+            Cons Ug{Uin[kc], 0.0, 0.0, Uin[3 * pl + kc]};
+            if (i >= g.ilo && i <= g.ihi && j >= g.jlo && j <= g.jhi)
+                Ug.d = fmax(Ug.d, P.small_dens);
+            const double sgn =
+                ((j < g.jlo && P.refl_ylo) || (j > g.jhi && P.refl_yhi)) ? -1.0 : 1.0;
+            add_grav_to_state(XM, Ug, P.grav, P.dt, sgn);
+            add_grav_to_state(XP, Ug, P.grav, P.dt, sgn);
+            add_grav_to_state(YM, Ug, P.grav, P.dt, sgn);
+            add_grav_to_state(YP, Ug, P.grav, P.dt, sgn);
+        }
         lds_put(S, t, XP);
         lds_put(S + 4 * FNT, t, YP);
     }
@@ -276,6 +291,7 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
         Un.E = Uc.E + dtdV * (Fx.E * Ax - Fxh.E * Ax + Fy.E * Ay - Fyh.E * Ay);
         Un.mx = Uc.mx + dtdV * (Fx.mx * Ax - Fxh.mx * Ax + Fy.mx * Ay - Fyh.mx * Ay);
         Un.my = Uc.my + dtdV * (Fx.my * Ax - Fxh.my * Ax + Fy.my * Ay - Fyh.my * Ay);
+        if (P.grav != 0.0) grav_update(Un, Uc, P.grav, P.dt);   // simulation.py:406-423
         Uout[k] = Un.d; Uout[pl + k] = Un.E; Uout[2 * pl + k] = Un.mx; Uout[3 * pl + k] = Un.my;
         cfl = cfl_cell(Un, gamma, P.dx, P.dy);
     }
@@ -340,6 +356,9 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     P.dtdx = dt / p->dx; P.dtdy = dt / p->dy;
     P.hdtV = (0.5 * dt) / (p->dx * p->dy);
     P.dtdV = dt / (p->dx * p->dy);
+    P.grav = p->grav;
+    P.refl_ylo = (s->bc[3 * 4 + 2] == PYROHIP_BC_REFLECT_ODD);
+    P.refl_yhi = (s->bc[3 * 4 + 3] == PYROHIP_BC_REFLECT_ODD);
     const int nti = (g.nx + FTI - 1) / FTI;
     P.ntj = (g.ny + FTJ - 1) / FTJ;
     P.ntiles = nti * P.ntj;

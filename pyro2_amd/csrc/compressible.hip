@@ -52,6 +52,8 @@ struct CP {   // kernel-side parameters
     double z0, z1, delta, cvisc, small_dens;
     int limiter, use_flattening;
     int avx_hi, avy_hi;   // compute avisc on the upper boundary face
+    double grav;          // compressible.grav (0: no source terms)
+    int refl_ylo, refl_yhi;   // y-momentum reflects oddly at the lower / upper y wall
 };
 
 __device__ __forceinline__ Cons load_cons(const double *__restrict__ a, size_t plane, size_t k)
@@ -127,7 +129,8 @@ __global__ __launch_bounds__(256) void k_xi(const double *__restrict__ W_, doubl
 
 // ---- stage 2: limited slopes + characteristic tracing on R(1) ------------
 // unsplit_fluxes.py:186-242, interface.py:5-236, simulation.py:83-102
-__global__ __launch_bounds__(256) void k_states(const double *__restrict__ W_,
+__global__ __launch_bounds__(256) void k_states(const double *__restrict__ U,
+                                                const double *__restrict__ W_,
                                                 double *__restrict__ Wout, Geom g, CP P,
                                                 int gx, int gy)
 {
@@ -154,13 +157,25 @@ __global__ __launch_bounds__(256) void k_states(const double *__restrict__ W_,
     // x: normal velocity u (1), transverse v (2)
     trace_states(q0[0], q0[1], q0[2], q0[3], dqx[0], dqx[1], dqx[2], dqx[3], P.gamma,
                  P.dt / P.dx, lo, hi);
-    store_cons(Wout + (size_t)W_XM * pl, pl, k, prim_to_cons(Prim{lo.r, lo.un, lo.ut, lo.p}, P.gamma));
-    store_cons(Wout + (size_t)W_XP * pl, pl, k, prim_to_cons(Prim{hi.r, hi.un, hi.ut, hi.p}, P.gamma));
+    Cons XM = prim_to_cons(Prim{lo.r, lo.un, lo.ut, lo.p}, P.gamma);
+    Cons XP = prim_to_cons(Prim{hi.r, hi.un, hi.ut, hi.p}, P.gamma);
     // y: normal velocity v, transverse u
     trace_states(q0[0], q0[2], q0[1], q0[3], dqy[0], dqy[2], dqy[1], dqy[3], P.gamma,
                  P.dt / P.dy, lo, hi);
-    store_cons(Wout + (size_t)W_YM * pl, pl, k, prim_to_cons(Prim{lo.r, lo.ut, lo.un, lo.p}, P.gamma));
-    store_cons(Wout + (size_t)W_YP * pl, pl, k, prim_to_cons(Prim{hi.r, hi.ut, hi.un, hi.p}, P.gamma));
+    Cons YM = prim_to_cons(Prim{lo.r, lo.ut, lo.un, lo.p}, P.gamma);
+    Cons YP = prim_to_cons(Prim{hi.r, hi.ut, hi.un, hi.p}, P.gamma);
+    if (P.grav != 0.0) {   // apply_source_terms, unsplit_fluxes.py:247-330
+        const Cons Uc = load_cons(U, pl, k);
+        const double sgn = ((j < g.jlo && P.refl_ylo) || (j > g.jhi && P.refl_yhi)) ? -1.0 : 1.0;
+        add_grav_to_state(XM, Uc, P.grav, P.dt, sgn);
+        add_grav_to_state(XP, Uc, P.grav, P.dt, sgn);
+        add_grav_to_state(YM, Uc, P.grav, P.dt, sgn);
+        add_grav_to_state(YP, Uc, P.grav, P.dt, sgn);
+    }
+    store_cons(Wout + (size_t)W_XM * pl, pl, k, XM);
+    store_cons(Wout + (size_t)W_XP * pl, pl, k, XP);
+    store_cons(Wout + (size_t)W_YM * pl, pl, k, YM);
+    store_cons(Wout + (size_t)W_YP * pl, pl, k, YP);
 }
 
 __device__ __forceinline__ ConsN to_n(const Cons &U, bool x)
@@ -307,15 +322,17 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ U,
         const double dtdV = P.dt / (P.dx * P.dy);
         const double Ax = P.dy, Ay = P.dx;
         const double *FX = W_ + (size_t)W_FX * pl, *FY = W_ + (size_t)W_FY * pl;
-        double Un[4];
+        double Un[4], Uo[4];
 #pragma unroll
         for (int n = 0; n < 4; n++) {
             const double *fx = FX + (size_t)n * pl, *fy = FY + (size_t)n * pl;
-            Un[n] = U[(size_t)n * pl + k] +
-                    dtdV * (fx[k] * Ax - fx[k + p] * Ax + fy[k] * Ay - fy[k + 1] * Ay);
-            U[(size_t)n * pl + k] = Un[n];
+            Uo[n] = U[(size_t)n * pl + k];
+            Un[n] = Uo[n] + dtdV * (fx[k] * Ax - fx[k + p] * Ax + fy[k] * Ay - fy[k + 1] * Ay);
         }
-        cfl = cfl_cell(Cons{Un[0], Un[1], Un[2], Un[3]}, P.gamma, P.dx, P.dy);
+        Cons Uc{Un[0], Un[1], Un[2], Un[3]};
+        if (P.grav != 0.0) grav_update(Uc, Cons{Uo[0], Uo[1], Uo[2], Uo[3]}, P.grav, P.dt);
+        store_cons(U, pl, k, Uc);
+        cfl = cfl_cell(Uc, P.gamma, P.dx, P.dy);
     }
     cfl = block_reduce_min(cfl);
     if (threadIdx.x == 0) partial[by * gx + bx] = cfl;
@@ -341,7 +358,7 @@ __global__ void k_min_final(const double *__restrict__ partial, int nb, double *
     if (threadIdx.x == 0) out[0] = m;
 }
 
-static CP make_cp(const pyrohip_comp_params *p, double dt)
+static CP make_cp(const pyrohip_comp_params *p, double dt, const pyrohip_state *s)
 {
     CP c;
     c.gamma = p->gamma; c.dx = p->dx; c.dy = p->dy; c.dt = dt;
@@ -349,6 +366,9 @@ static CP make_cp(const pyrohip_comp_params *p, double dt)
     c.small_dens = p->small_dens;
     c.limiter = p->limiter; c.use_flattening = p->use_flattening;
     c.avx_hi = p->avisc_xhi_interior; c.avy_hi = p->avisc_yhi_interior;
+    c.grav = p->grav;
+    c.refl_ylo = (s->bc[3 * 4 + 2] == PYROHIP_BC_REFLECT_ODD);
+    c.refl_yhi = (s->bc[3 * 4 + 3] == PYROHIP_BC_REFLECT_ODD);
     return c;
 }
 
@@ -394,7 +414,7 @@ int comp_step_staged(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     pyrohip_ctx *c = s->ctx;
     const Geom &g = s->g;
     PYRO_TRY(ensure_work(s, W_NPLANES));
-    const CP P = make_cp(p, dt);
+    const CP P = make_cp(p, dt, s);
     double *U = s->d;
     double *W = s->work + geom_lead(g);
     const dim3 block(256);
@@ -408,7 +428,8 @@ int comp_step_staged(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     const dim3 gridR1(xcd_grid_1d(gx, gy));
     PYRO_LAUNCH(c, "k_xi", k_xi, gridR1, block, 0, (const double *)W,
                 W + (size_t)W_XI * g.plane, g, P, gx, gy);
-    PYRO_LAUNCH(c, "k_states", k_states, gridR1, block, 0, (const double *)W, W, g, P, gx, gy);
+    PYRO_LAUNCH(c, "k_states", k_states, gridR1, block, 0, (const double *)U, (const double *)W, W, g,
+                P, gx, gy);
     PYRO_LAUNCH(c, "k_riemann_t", k_riemann_t, gridR1, block, 0, (const double *)W, W, g, P, gx,
                 gy);
     gx = (g.ny + 1 + 255) / 256; gy = g.nx + 1;

@@ -289,6 +289,41 @@ __device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, dou
     return F;
 }
 
+// Gravity (Cartesian, acting in y): S[ymom] = rho g, S[E] = ymom g
+// (compressible/simulation.py:131-134).
+//
+// Interface states: every one of the cell's four face states receives
+// +(dt/2) S(cell) on its momentum and energy components
+// (apply_source_terms, unsplit_fluxes.py:308-326; XP(i) = U_xl[i+1] gets
+// S[i], etc.).  The reference ghost-fills S with the BCs of ymom_src
+// (odd across a reflecting y wall) and E_src (even), which for a ghost cell
+// beyond such a wall is minus the value computed from the ghost state itself:
+// pass sgn = -1 there, +1 everywhere else.
+__device__ __forceinline__ void add_grav_to_state(Cons &S, const Cons &Ucell, double grav,
+                                                  double dt, double sgn)
+{
+    const double Sy = sgn * (Ucell.d * grav);
+    const double SE = sgn * (Ucell.my * grav);
+    S.my += 0.5 * dt * Sy;
+    S.E += 0.5 * dt * SE;
+}
+
+// Source predictor-corrector after the conservative update
+// (compressible/simulation.py:406-423 with get_external_sources :105-161):
+// U* = U + dt S(U_old); S_new uses the time-centred momentum; U = U* + dt/2 (S_new - S_old)
+__device__ __forceinline__ void grav_update(Cons &U, const Cons &Uold, double grav, double dt)
+{
+    const double Sy_old = Uold.d * grav;
+    const double SE_old = Uold.my * grav;
+    U.my = U.my + dt * Sy_old;
+    U.E = U.E + dt * SE_old;
+    const double Sy_new = U.d * grav;
+    const double ymom_new = U.my + 0.5 * dt * (Sy_new - Sy_old);
+    const double SE_new = ymom_new * grav;
+    U.my = U.my + 0.5 * dt * (Sy_new - Sy_old);
+    U.E = U.E + 0.5 * dt * (SE_new - SE_old);
+}
+
 // vertex-centred velocity divergence at (i-1/2, j-1/2),
 // compressible/interface.py:312-330 (Cartesian branch)
 __device__ __forceinline__ double div_u_vertex(double u_ij, double u_ijm, double u_imj,

@@ -37,7 +37,7 @@ def R(a, ng, lo, hi=None):
     return a[ng - lo:a.shape[0] - ng + hi, ng - lo:a.shape[1] - ng + hi]
 
 
-@pytest.mark.parametrize("k", range(7))
+@pytest.mark.parametrize("k", range(8))
 def test_comp_stages_vs_reference(dev, golden, k):
     """one step from a reference state; every device stage array is compared
     with the array dumped from the reference's own functions on the cells /
@@ -61,11 +61,15 @@ def test_comp_stages_vs_reference(dev, golden, k):
 
     chk("q", s.comp_stage("q"), g[f"c{k}_q"])
     chk("xi", R(s.comp_stage("xi"), ng, 1), R(g[f"c{k}_xi"], ng, 1))
-    # cell-indexed face states: XM[i,j] = U_xr[i,j]; XP[i,j] = U_xl[i+1,j]
-    chk("XM", R(s.comp_stage("XM"), ng, 1), R(g[f"c{k}_Uxr0"], ng, 1))
-    chk("XP", R(s.comp_stage("XP"), ng, 1), g[f"c{k}_Uxl0"][ng:ng + nx + 2, ng - 1:ng + ny + 1])
-    chk("YM", R(s.comp_stage("YM"), ng, 1), R(g[f"c{k}_Uyr0"], ng, 1))
-    chk("YP", R(s.comp_stage("YP"), ng, 1), g[f"c{k}_Uyl0"][ng - 1:ng + nx + 1, ng:ng + ny + 2])
+    # cell-indexed face states: XM[i,j] = U_xr[i,j]; XP[i,j] = U_xl[i+1,j], compared on
+    # the cells whose state feeds a needed face: x faces i in [ilo, ihi+1] take
+    # XP of cells [ilo-1, ihi] and XM of cells [ilo, ihi+1] (same in y)
+    J1 = slice(ng - 1, ng + ny + 1)
+    I1 = slice(ng - 1, ng + nx + 1)
+    chk("XM", s.comp_stage("XM")[ng:ng + nx + 1, J1], g[f"c{k}_Uxr0"][ng:ng + nx + 1, J1])
+    chk("XP", s.comp_stage("XP")[ng - 1:ng + nx, J1], g[f"c{k}_Uxl0"][ng:ng + nx + 1, J1])
+    chk("YM", s.comp_stage("YM")[I1, ng:ng + ny + 1], g[f"c{k}_Uyr0"][I1, ng:ng + ny + 1])
+    chk("YP", s.comp_stage("YP")[I1, ng - 1:ng + ny], g[f"c{k}_Uyl0"][I1, ng:ng + ny + 1])
     # transverse fluxes: x faces i in [ilo, ihi+1], j in [jlo-1, jhi+1]
     chk("FxT", s.comp_stage("FxT")[ng:ng + nx + 1, ng - 1:ng + ny + 1],
         g[f"c{k}_FxT"][ng:ng + nx + 1, ng - 1:ng + ny + 1])
@@ -84,7 +88,7 @@ def test_comp_stages_vs_reference(dev, golden, k):
     assert np.array_equal(U1[m], g[f"c{k}_U1"][m])
 
 
-@pytest.mark.parametrize("k", range(7))
+@pytest.mark.parametrize("k", range(8))
 def test_comp_fused_vs_reference(dev, golden, k):
     """kernel_set 1 (single fused LDS kernel): one step from a reference
     state, end state against the reference's own evolve(); then the cached
@@ -208,3 +212,34 @@ def test_comp_sedov_512_vs_oracle(hip, fast, kset):
         assert max_rel_err(U[4:-4, 4:-4, n], Uo[4:-4, 4:-4, n]) <= tol
     # conservation of mass and energy away from the (outflow) boundary
     assert abs(U[4:-4, 4:-4, 0].sum() - ic[4:-4, 4:-4, 0].sum()) < 1e-9 * nx * nx
+
+
+@pytest.mark.parametrize("kset", [0, 1])
+def test_comp_gravity_run(dev, kset):
+    """gravity sources (apply_source_terms + predictor-corrector,
+    unsplit_fluxes.py:247-330, simulation.py:406-423): a perturbed stratified
+    atmosphere between reflecting walls, periodic in x, against the oracle"""
+    from helpers import oracle_comp_run
+    nx, ny, ng = 24, 32, 4
+    gamma, grav = 1.4, -1.0
+    dx, dy = 1.0 / nx, 2.0 / ny
+    x = (np.arange(nx + 2 * ng) - ng + 0.5) * dx
+    y = (np.arange(ny + 2 * ng) - ng + 0.5) * dy
+    X, Y = np.meshgrid(x, y, indexing="ij")
+    rho = np.where(Y < 1.0, 1.0, 2.0)
+    p = 5.0 + grav * np.where(Y < 1.0, Y, 1.0 + 2.0 * (Y - 1.0))
+    v = 0.05 * np.cos(2 * np.pi * X) * np.exp(-((Y - 1.0) / 0.2) ** 2)
+    ic = np.zeros((nx + 2 * ng, ny + 2 * ng, 4))
+    ic[..., 0] = rho
+    ic[..., 3] = rho * v
+    ic[..., 1] = p / (gamma - 1.0) + 0.5 * rho * v * v
+    meta = np.array([nx, ny, ng, dx, dy, gamma, 2, 1, 0.75, 0.85, 0.33, 0.1, grav, 0.8])
+    bcs = ["periodic", "periodic", "reflect", "reflect"]
+    nsteps = 8 if dev.kind == "emu" else 40
+    Uo, dto, _ = oracle_comp_run(ic, meta, bcs, 10.0, nsteps)
+    U, dts, _ = device_comp_run(dev, ic, meta, bcs, 10.0, nsteps, kernel_set=kset)
+    tol = 0.0 if dev.kind == "emu" else 1e-12
+    assert max_rel_err(dts, dto) <= tol
+    for n in range(4):
+        assert max_rel_err(U[4:-4, 4:-4, n], Uo[4:-4, 4:-4, n]) <= tol, n
+    assert np.abs(U[4:-4, 4:-4, 3]).max() > 1e-3   # gravity did something
