@@ -177,6 +177,12 @@ int pyrohip_mg_norm(pyrohip_mg *m, int level, int var, double *out); /* array_in
 int pyrohip_mg_vcycle(pyrohip_mg *m, int level);               /* MG.py:699-778 */
 /* init_RHS bookkeeping: source_norm = ||f|| on the finest level (MG.py:521) */
 int pyrohip_mg_init_rhs_norm(pyrohip_mg *m, double *source_norm);
+/* callers that keep their field on the device (pyro/diffusion/simulation.py:
+   92-118): f <- phi + coef * Laplacian(phi) on the finest level from variable
+   n of a (nx, nx, ng = 1) state, and the solution back into that variable */
+int pyrohip_mg_set_rhs_cn(pyrohip_mg *m, pyrohip_state *s, int n, double coef,
+                          double *source_norm);
+int pyrohip_mg_copy_solution(pyrohip_mg *m, pyrohip_state *s, int n);
 /* MG.py:623-697 */
 int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles,
                      int *num_cycles, double *residual_error,

@@ -435,8 +435,50 @@ def gen_mg():
     save("mg_ops", **out)
 
 
+# --------------------------------------------------------------------------
+# diffusion: a caller of MG
+# --------------------------------------------------------------------------
+def gen_diffusion():
+    # (i) reference regression: diffusion gaussian inputs.gaussian (128^2) vs
+    # pyro/diffusion/tests/gaussian_0164.h5 (test.py "diffusion gaussian")
+    p = Pyro("diffusion")
+    p.initialize_problem("gaussian")
+    ic = np.array(p.sim.cc_data.get_var("phi"))
+    dts = []
+    while not p.sim.finished():
+        p.single_step()
+        dts.append(p.sim.dt)
+    with h5py.File(REF + "/diffusion/tests/gaussian_0164.h5", "r") as f:
+        gold = f["state/phi/data"][...]
+        assert int(f.attrs["nsteps"]) == p.sim.n
+    run = np.array(p.sim.cc_data.get_var("phi").v())
+    print("diffusion gaussian: reference-run vs stored golden max abs", np.abs(run - gold).max(),
+          "steps", p.sim.n)
+    save("diff_gaussian_0164", ic=ic, gold=gold, run=run, dts=np.array(dts),
+         n=np.array(p.sim.n))
+    # (ii) small cases with other boundary types, 6 steps
+    out = {}
+    cases = [("periodic",) * 4, ("dirichlet",) * 4, ("neumann", "neumann", "periodic", "periodic")]
+    for k, b in enumerate(cases):
+        p = Pyro("diffusion")
+        p.initialize_problem("gaussian", inputs_dict={
+            "mesh.nx": 32, "mesh.ny": 32, "driver.max_steps": 6, "driver.cfl": 1.5,
+            "mesh.xlboundary": b[0], "mesh.xrboundary": b[1],
+            "mesh.ylboundary": b[2], "mesh.yrboundary": b[3], "gaussian.t_0": 0.002})
+        out[f"d{k}_ic"] = np.array(p.sim.cc_data.get_var("phi"))
+        out[f"d{k}_bc"] = np.array(b)
+        while not p.sim.finished():
+            p.single_step()
+        out[f"d{k}_final"] = np.array(p.sim.cc_data.get_var("phi"))
+        out[f"d{k}_dt"] = np.array(p.sim.dt)
+    out["ncases"] = np.array(len(cases))
+    save("diff_small", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["bc", "adv", "comp_stages", "comp_runs", "mg"]
+    which = sys.argv[1:] or ["bc", "adv", "comp_stages", "comp_runs", "mg", "diffusion"]
+    if "diffusion" in which:
+        gen_diffusion()
     if "bc" in which:
         gen_fill_bc()
     if "adv" in which:

@@ -90,6 +90,8 @@ _PROTOS = {
     "pyrohip_mg_vcycle": [_VP, C.c_int],
     "pyrohip_mg_init_rhs_norm": [_VP, _DP],
     "pyrohip_mg_solve": [_VP, C.c_double, C.c_int, _IP, _DP, _DP],
+    "pyrohip_mg_set_rhs_cn": [_VP, _VP, C.c_int, C.c_double, _DP],
+    "pyrohip_mg_copy_solution": [_VP, _VP, C.c_int],
     "pyrohip_comm_unique_id": [C.c_char_p],
     "pyrohip_comm_init": [_VP, C.c_int, C.c_int, C.c_char_p],
     "pyrohip_comm_destroy": [_VP],

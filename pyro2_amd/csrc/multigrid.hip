@@ -551,6 +551,30 @@ __global__ __launch_bounds__(256) void k_mg_prolong_add(const double *__restrict
     fv[(size_t)(1 + fi) * fpitch + (1 + fj)] += e;
 }
 
+// Crank-Nicolson right-hand side of the diffusion solver,
+// pyro/diffusion/simulation.py:104-110:  f = phi + coef * L(phi)
+__global__ __launch_bounds__(256) void k_mg_rhs_cn(const double *__restrict__ phi,
+                                                   double *__restrict__ f, int n, int pitch,
+                                                   double coef, double dx2, double dy2)
+{
+    const int j = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = 1 + blockIdx.y;
+    if (j > n) return;
+    const size_t k = (size_t)i * pitch + j;
+    f[k] = phi[k] + coef * ((phi[k + pitch] + phi[k - pitch] - 2.0 * phi[k]) / dx2 +
+                            (phi[k + 1] + phi[k - 1] - 2.0 * phi[k]) / dy2);
+}
+
+__global__ __launch_bounds__(256) void k_mg_copy_interior(const double *__restrict__ src,
+                                                          double *__restrict__ dst, int n,
+                                                          int pitch)
+{
+    const int j = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = 1 + blockIdx.y;
+    if (j > n) return;
+    dst[(size_t)i * pitch + j] = src[(size_t)i * pitch + j];
+}
+
 // sum over the interior of a^2 (mode 0) or ((a-b)/(a+small))^2 (mode 1)
 __global__ __launch_bounds__(256) void k_mg_sumsq(const double *__restrict__ a,
                                                   const double *__restrict__ b, int n, int pitch,
@@ -1008,6 +1032,41 @@ int pyrohip_mg_init_rhs_norm(pyrohip_mg *m, double *source_norm)
     PYRO_TRY(pyrohip_mg_norm(m, m->nlevels - 1, 1, &nrm));
     m->source_norm = nrm;
     if (source_norm) *source_norm = nrm;
+    return 0;
+}
+
+int pyrohip_mg_set_rhs_cn(pyrohip_mg *m, pyrohip_state *s, int n, double coef,
+                          double *source_norm)
+{
+    PYRO_REQUIRE(m && s, "NULL argument");
+    PYRO_REQUIRE(n >= 0 && n < s->nvar, "variable index out of range");
+    PYRO_REQUIRE(s->ctx == m->ctx, "state and multigrid live on different contexts");
+    PYRO_REQUIRE(s->g.ng == 1 && s->g.nx == m->nx && s->g.ny == m->nx,
+                 "state must be nx x nx with ng = 1 like the finest multigrid level");
+    MGLevel &F = m->lev[m->nlevels - 1];
+    PYRO_REQUIRE(F.pitch == s->g.pitch, "pitch mismatch");
+    const int bx = (F.n >= 256) ? 256 : 64;
+    hipLaunchKernelGGL(k_mg_rhs_cn, dim3((F.n + bx - 1) / bx, F.n), dim3(bx), 0, m->ctx->stream,
+                       (const double *)(s->d + (size_t)n * s->g.plane), F.f, F.n, F.pitch, coef,
+                       F.dx * F.dx, F.dx * F.dx);
+    PYRO_CHECK_HIP(hipGetLastError());
+    return pyrohip_mg_init_rhs_norm(m, source_norm);
+}
+
+int pyrohip_mg_copy_solution(pyrohip_mg *m, pyrohip_state *s, int n)
+{
+    PYRO_REQUIRE(m && s, "NULL argument");
+    PYRO_REQUIRE(n >= 0 && n < s->nvar, "variable index out of range");
+    PYRO_REQUIRE(s->ctx == m->ctx, "state and multigrid live on different contexts");
+    PYRO_REQUIRE(s->g.ng == 1 && s->g.nx == m->nx && s->g.ny == m->nx,
+                 "state must be nx x nx with ng = 1 like the finest multigrid level");
+    MGLevel &F = m->lev[m->nlevels - 1];
+    const int bx = (F.n >= 256) ? 256 : 64;
+    hipLaunchKernelGGL(k_mg_copy_interior, dim3((F.n + bx - 1) / bx, F.n), dim3(bx), 0,
+                       m->ctx->stream, (const double *)F.v, s->d + (size_t)n * s->g.plane, F.n,
+                       F.pitch);
+    PYRO_CHECK_HIP(hipGetLastError());
+    s->next_cfl_min = -1.0;
     return 0;
 }
 

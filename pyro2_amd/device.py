@@ -329,6 +329,15 @@ class DeviceMG:
         self._call("pyrohip_mg_init_rhs_norm", C.byref(out))
         return out.value
 
+    def set_rhs_cn(self, state, n, coef):
+        """f <- phi + coef * L(phi) from variable n of a device state; returns ||f||"""
+        out = C.c_double()
+        self._call("pyrohip_mg_set_rhs_cn", state.h, int(n), float(coef), C.byref(out))
+        return out.value
+
+    def copy_solution(self, state, n):
+        self._call("pyrohip_mg_copy_solution", state.h, int(n))
+
     def solve(self, rtol=1.e-11, max_cycles=100):
         nc, res, rel = C.c_int(), C.c_double(), C.c_double()
         self._call("pyrohip_mg_solve", rtol, int(max_cycles), C.byref(nc),
