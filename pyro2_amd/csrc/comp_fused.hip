@@ -327,14 +327,6 @@ __global__ void k_copy_frame4(const double *__restrict__ src, double *__restrict
     for (int n = 0; n < 4; n++) dst[n * g.plane + k] = src[n * g.plane + k];
 }
 
-__global__ void k_min_final_f(const double *__restrict__ partial, int nb, double *__restrict__ out)
-{
-    double m = INFINITY;
-    for (int b = threadIdx.x; b < nb; b += blockDim.x) m = fmin(m, partial[b]);
-    m = block_reduce_min(m);
-    if (threadIdx.x == 0) out[0] = m;
-}
-
 int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
 {
     pyrohip_ctx *c = s->ctx;
@@ -362,7 +354,7 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     const int nti = (g.nx + FTI - 1) / FTI;
     P.ntj = (g.ny + FTJ - 1) / FTJ;
     P.ntiles = nti * P.ntj;
-    PYRO_TRY(c->reduce.ensure((P.ntiles + 2) * sizeof(double)));
+    PYRO_TRY(c->reduce.ensure((P.ntiles + kMinStageBlocks + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
     PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
 #ifndef PYRO_EMU
@@ -382,10 +374,9 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
         hipLaunchKernelGGL(k_copy_frame4, dim3((g.qy + 255) / 256, nby), dim3(256), 0, c->stream,
                            (const double *)Uin, Uout, g);
     }
-    hipLaunchKernelGGL(k_min_final_f, dim3(1), dim3(256), 0, c->stream, (const double *)part,
-                       P.ntiles, part + P.ntiles);
+    const double *dmin = launch_min_reduce(c->stream, part, P.ntiles);
     PYRO_CHECK_HIP(hipGetLastError());
-    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, part + P.ntiles, sizeof(double),
+    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, dmin, sizeof(double),
                                   hipMemcpyDeviceToHost, c->stream));
     PYRO_CHECK_HIP(hipMemcpyAsync((char *)c->reduce_host + 8, s->d_flag, sizeof(int),
                                   hipMemcpyDeviceToHost, c->stream));

@@ -350,14 +350,6 @@ __global__ __launch_bounds__(256) void k_cfl(const double *__restrict__ U, Geom 
     if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = m;
 }
 
-__global__ void k_min_final(const double *__restrict__ partial, int nb, double *__restrict__ out)
-{
-    double m = INFINITY;
-    for (int b = threadIdx.x; b < nb; b += blockDim.x) m = fmin(m, partial[b]);
-    m = block_reduce_min(m);
-    if (threadIdx.x == 0) out[0] = m;
-}
-
 static CP make_cp(const pyrohip_comp_params *p, double dt, const pyrohip_state *s)
 {
     CP c;
@@ -395,14 +387,13 @@ int comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, double *
     }
     dim3 grid(8, 128), block(256);
     const int nb = grid.x * grid.y;
-    PYRO_TRY(c->reduce.ensure((nb + 2) * sizeof(double)));
+    PYRO_TRY(c->reduce.ensure((nb + kMinStageBlocks + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
     hipLaunchKernelGGL(k_cfl, grid, block, 0, c->stream, (const double *)s->d, g, p->gamma, p->dx,
                        p->dy, part);
-    hipLaunchKernelGGL(k_min_final, dim3(1), dim3(256), 0, c->stream, (const double *)part, nb,
-                       part + nb);
+    const double *dmin = launch_min_reduce(c->stream, part, nb);
     PYRO_CHECK_HIP(hipGetLastError());
-    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, part + nb, sizeof(double),
+    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, dmin, sizeof(double),
                                   hipMemcpyDeviceToHost, c->stream));
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
     *dt_out = cfl * ((double *)c->reduce_host)[0];
@@ -437,15 +428,14 @@ int comp_step_staged(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
                 (const double *)W, W, g, P, gx, gy);
     gx = (g.ny + 255) / 256; gy = g.nx;
     const int nb = gx * gy;
-    PYRO_TRY(c->reduce.ensure((nb + 2) * sizeof(double)));
+    PYRO_TRY(c->reduce.ensure((nb + kMinStageBlocks + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
     PYRO_LAUNCH(c, "k_update", k_update, dim3(xcd_grid_1d(gx, gy)), block, 0, U,
                 (const double *)W, g, P, part, gx, gy);
-    hipLaunchKernelGGL(k_min_final, dim3(1), dim3(256), 0, c->stream, (const double *)part, nb,
-                       part + nb);
+    const double *dmin = launch_min_reduce(c->stream, part, nb);
     PYRO_CHECK_HIP(hipGetLastError());
     // one 16-byte D2H per step: next step's CFL minimum + positivity flag
-    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, part + nb, sizeof(double),
+    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, dmin, sizeof(double),
                                   hipMemcpyDeviceToHost, c->stream));
     PYRO_CHECK_HIP(hipMemcpyAsync((char *)c->reduce_host + 8, s->d_flag, sizeof(int),
                                   hipMemcpyDeviceToHost, c->stream));

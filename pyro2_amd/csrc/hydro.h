@@ -30,7 +30,22 @@ __device__ __forceinline__ double prcp(double b)
 __device__ __forceinline__ double pdiv(double a, double b) { return a * prcp(b); }
 // a / b where rb = prcp(b) was computed once for several quotients
 __device__ __forceinline__ double pdivr(double a, double b, double rb) { (void)b; return a * rb; }
+// sqrt of a strictly positive, normal argument (sound speeds, 1 + ...):
+// v_rsq_f64 + one Goldschmidt step + a residual correction, without the
+// denormal scaling / special-case code of the IEEE expansion
+__device__ __forceinline__ double psqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return (x > 0.0) ? g : 0.0;
+}
 #else
+__device__ __forceinline__ double psqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ double prcp(double b) { return 1.0 / b; }
 __device__ __forceinline__ double pdiv(double a, double b) { return a / b; }
 __device__ __forceinline__ double pdivr(double a, double b, double rb) { (void)rb; return a / b; }
@@ -80,7 +95,7 @@ __device__ __forceinline__ double cfl_cell(const Cons &U, double gamma, double d
     double v = pdivr(U.my, U.d, rd);
     double e = pdivr(U.E - 0.5 * U.d * (u * u + v * v), U.d, rd);
     double p = U.d * e * (gamma - 1.0);
-    double cs = sqrt(pdivr(gamma * p, U.d, rd));
+    double cs = psqrt(pdivr(gamma * p, U.d, rd));
     double xt = pdiv(dx, fabs(u) + cs);
     double yt = pdiv(dy, fabs(v) + cs);
     return fmin(xt, yt);
@@ -114,7 +129,7 @@ __device__ __forceinline__ void trace_states(double r, double un, double ut, dou
                                              double gamma, double dtdx, Trace &lo, Trace &hi)
 {
     const double dtdx4 = 0.25 * dtdx;                // interface.py:107
-    const double cs = sqrt(pdiv(gamma * p, r));      // :122
+    const double cs = psqrt(pdiv(gamma * p, r));     // :122
     const double e0 = un - cs, e1 = un, e3 = un + cs;  // :129 / :151  (e2 == e1)
 
     // reference states, :174-191
@@ -136,11 +151,13 @@ __device__ __forceinline__ void trace_states(double r, double un, double ut, dou
 
     // :193-201
     const double s0 = copysign(1.0, e0), s1 = copysign(1.0, e1), s3 = copysign(1.0, e3);
+    (void)s3; (void)s0;
     const double bl0 = dtdx4 * (e3 - e0) * (s0 + 1.0) * a0;
     const double bl1 = dtdx4 * (e3 - e1) * (s1 + 1.0) * a1;
     const double bl2 = dtdx4 * (e3 - e1) * (s1 + 1.0) * a2;
-    const double bl3 = dtdx4 * (e3 - e3) * (s3 + 1.0) * a3;
-    const double br0 = dtdx4 * (e0 - e0) * (1.0 - s0) * a0;
+    // bl3 carries the factor (e3 - e3) and br0 the factor (e0 - e0): both are
+    // exactly zero, and adding a zero never changes the sums below, so the two
+    // terms are dropped (bitwise neutral for finite states)
     const double br1 = dtdx4 * (e0 - e1) * (1.0 - s1) * a1;
     const double br2 = dtdx4 * (e0 - e1) * (1.0 - s1) * a2;
     const double br3 = dtdx4 * (e0 - e3) * (1.0 - s3) * a3;
@@ -148,14 +165,14 @@ __device__ __forceinline__ void trace_states(double r, double un, double ut, dou
     // sum_m beta_m r_m, in index order with the structural zeros kept where
     // they sit between non-zero terms, :203-213; r_m from :141-144 / :163-166
     const double cr = pdiv(cs, r), c2 = cs * cs;
-    hi.r = hi.r + ((bl0 + bl1) + bl3);
-    hi.un = hi.un + (bl0 * (-cr) + bl3 * cr);
+    hi.r = hi.r + (bl0 + bl1);
+    hi.un = hi.un + bl0 * (-cr);
     hi.ut = hi.ut + bl2;
-    hi.p = hi.p + (bl0 * c2 + bl3 * c2);
-    lo.r = lo.r + ((br0 + br1) + br3);
-    lo.un = lo.un + (br0 * (-cr) + br3 * cr);
+    hi.p = hi.p + bl0 * c2;
+    lo.r = lo.r + (br1 + br3);
+    lo.un = lo.un + br3 * cr;
     lo.ut = lo.ut + br2;
-    lo.p = lo.p + (br0 * c2 + br3 * c2);
+    lo.p = lo.p + br3 * c2;
 }
 
 // Wave-speed estimate, compressible/riemann.py:596-678 (quirk: S_r uses
@@ -189,19 +206,19 @@ __device__ __forceinline__ void estimate_wave_speed(double rho_l, double u_l, do
             double A_l = pdiv(2.0, (gamma + 1.0) * rho_l);
             double B_l = pdiv(p_l * (gamma - 1.0), gamma + 1.0);
             double p_guess = fmax(0.0, pstar);
-            double g_l = sqrt(pdiv(A_l, p_guess + B_l));
-            double g_r = sqrt(pdiv(A_r, p_guess + B_r));
+            double g_l = psqrt(pdiv(A_l, p_guess + B_l));
+            double g_r = psqrt(pdiv(A_r, p_guess + B_r));
             pstar = pdiv(g_l * p_l + g_r * p_r - (u_r - u_l), g_l + g_r);
         }
     }
     if (pstar <= p_l)
         S_l = u_l - c_l;
     else
-        S_l = u_l - c_l * sqrt(1.0 + pdiv(gamma + 1.0, 2.0 * gamma) * (pdiv(pstar, p_l) - 1.0));
+        S_l = u_l - c_l * psqrt(1.0 + pdiv(gamma + 1.0, 2.0 * gamma) * (pdiv(pstar, p_l) - 1.0));
     if (pstar <= p_r)
         S_r = u_r + c_r;
     else
-        S_r = u_r + c_r * sqrt(1.0 + pdiv(gamma + 1.0, pdiv(2.0, gamma)) * (pdiv(pstar, p_r) - 1.0));
+        S_r = u_r + c_r * psqrt(1.0 + pdiv(gamma + 1.0, pdiv(2.0, gamma)) * (pdiv(pstar, p_r) - 1.0));
 }
 
 // consFlux in the (normal, transverse) frame, riemann.py:1104-1179.
@@ -250,8 +267,8 @@ __device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, dou
     double rhoe_r = Ur.E - 0.5 * rho_r * (un_r * un_r + ut_r * ut_r);
     double p_r = rhoe_r * (gamma - 1.0);
     p_r = fmax(p_r, smallp);
-    double c_l = fmax(smallc, sqrt(pdivr(gamma * p_l, rho_l, ril)));
-    double c_r = fmax(smallc, sqrt(pdivr(gamma * p_r, rho_r, rir)));
+    double c_l = fmax(smallc, psqrt(pdivr(gamma * p_l, rho_l, ril)));
+    double c_r = fmax(smallc, psqrt(pdivr(gamma * p_r, rho_r, rir)));
     double S_l, S_r;
     estimate_wave_speed(rho_l, un_l, p_l, c_l, rho_r, un_r, p_r, c_r, gamma, S_l, S_r);
     double S_c = pdiv(p_r - p_l + rho_l * un_l * (S_l - un_l) - rho_r * un_r * (S_r - un_r),

@@ -51,4 +51,35 @@ __device__ inline double block_reduce_min(double v) { return block_reduce<0>(v);
 __device__ inline double block_reduce_max(double v) { return block_reduce<1>(v); }
 __device__ inline double block_reduce_sum(double v) { return block_reduce<2>(v); }
 
+// Minimum of nb per-workgroup partials (one per tile: 640k at 16384^2).
+// One workgroup reading them all costs ~1 ms there, so: 256 workgroups reduce
+// strided chunks into `stage`, then one workgroup finishes.
+static __global__ void k_min_stage(const double *__restrict__ partial, int nb,
+                                   double *__restrict__ stage)
+{
+    double m = INFINITY;
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x)
+        m = fmin(m, partial[b]);
+    m = block_reduce_min(m);
+    if (threadIdx.x == 0) stage[blockIdx.x] = m;
+}
+
+constexpr int kMinStageBlocks = 256;
+// scratch needed behind the nb partials: kMinStageBlocks + 1 doubles; the
+// result lands in part[nb + kMinStageBlocks]
+inline double *launch_min_reduce(hipStream_t stream, double *part, int nb)
+{
+    double *stage = part + nb, *out = part + nb + kMinStageBlocks;
+    if (nb > 4 * kMinStageBlocks) {
+        hipLaunchKernelGGL(k_min_stage, dim3(kMinStageBlocks), dim3(256), 0, stream,
+                           (const double *)part, nb, stage);
+        hipLaunchKernelGGL(k_min_stage, dim3(1), dim3(256), 0, stream, (const double *)stage,
+                           kMinStageBlocks, out);
+    } else {
+        hipLaunchKernelGGL(k_min_stage, dim3(1), dim3(256), 0, stream, (const double *)part, nb,
+                           out);
+    }
+    return out;
+}
+
 }  // namespace pyro
