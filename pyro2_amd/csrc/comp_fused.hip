@@ -148,19 +148,23 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
         const double *Qr = B0, *Qu = B0 + FQN, *Qv = B0 + 2 * FQN, *Qp = B0 + 3 * FQN;
         double xi = 1.0;
         if (P.use_flattening) {
-            double xix[3], xiy[3];
-#pragma unroll
-            for (int s = -1; s <= 1; s++) {
-                const int c = qc + s * FQW;
-                xix[s + 1] = flatten_1d(Qp[c - 2 * FQW], Qp[c - FQW], Qp[c + FQW], Qp[c + 2 * FQW],
-                                        Qu[c - FQW], Qu[c + FQW], P.z0, P.z1, P.delta);
-                const int d = qc + s;
-                xiy[s + 1] = flatten_1d(Qp[d - 2], Qp[d - 1], Qp[d + 1], Qp[d + 2], Qv[d - 1],
-                                        Qv[d + 1], P.z0, P.z1, P.delta);
-            }
-            const double px = (Qp[qc + FQW] - Qp[qc - FQW] > 0) ? xix[0] : xix[2];
-            const double py = (Qp[qc + 1] - Qp[qc - 1] > 0) ? xiy[0] : xiy[2];
-            xi = fmin(fmin(xix[1], px), fmin(xiy[1], py));
+            // flatten_multid (reconstruction.py:167-183): own coefficient and
+            // the one of the UPWIND neighbour (w.r.t. the pressure gradient)
+            // in each direction -- the downwind one is never selected
+            const int sx = (Qp[qc + FQW] - Qp[qc - FQW] > 0) ? -FQW : FQW;
+            const int sy = (Qp[qc + 1] - Qp[qc - 1] > 0) ? -1 : 1;
+            const int cx = qc + sx, cy = qc + sy;
+            const double xix = flatten_1d(Qp[qc - 2 * FQW], Qp[qc - FQW], Qp[qc + FQW],
+                                          Qp[qc + 2 * FQW], Qu[qc - FQW], Qu[qc + FQW], P.z0, P.z1,
+                                          P.delta);
+            const double px = flatten_1d(Qp[cx - 2 * FQW], Qp[cx - FQW], Qp[cx + FQW],
+                                         Qp[cx + 2 * FQW], Qu[cx - FQW], Qu[cx + FQW], P.z0, P.z1,
+                                         P.delta);
+            const double xiy = flatten_1d(Qp[qc - 2], Qp[qc - 1], Qp[qc + 1], Qp[qc + 2],
+                                          Qv[qc - 1], Qv[qc + 1], P.z0, P.z1, P.delta);
+            const double py = flatten_1d(Qp[cy - 2], Qp[cy - 1], Qp[cy + 1], Qp[cy + 2],
+                                         Qv[cy - 1], Qv[cy + 1], P.z0, P.z1, P.delta);
+            xi = fmin(fmin(xix, px), fmin(xiy, py));
         }
         double q0[4], dqx[4], dqy[4];
 #pragma unroll

@@ -111,20 +111,20 @@ __global__ __launch_bounds__(256) void k_xi(const double *__restrict__ W_, doubl
     const double *u = W_ + (size_t)(W_Q + 1) * g.plane;
     const double *v = W_ + (size_t)(W_Q + 2) * g.plane;
     const double *pr = W_ + (size_t)(W_Q + 3) * g.plane;
-    // xi_x at i-1, i, i+1 ; xi_y at j-1, j, j+1
-    double xix[3], xiy[3];
-#pragma unroll
-    for (int s = -1; s <= 1; s++) {
-        size_t c = k + (ptrdiff_t)s * p;
-        xix[s + 1] = flatten_1d(pr[c - 2 * p], pr[c - p], pr[c + p], pr[c + 2 * p], u[c - p],
-                                u[c + p], P.z0, P.z1, P.delta);
-        size_t d = k + s;
-        xiy[s + 1] = flatten_1d(pr[d - 2], pr[d - 1], pr[d + 1], pr[d + 2], v[d - 1], v[d + 1],
-                                P.z0, P.z1, P.delta);
-    }
-    double px = (pr[k + p] - pr[k - p] > 0) ? xix[0] : xix[2];
-    double py = (pr[k + 1] - pr[k - 1] > 0) ? xiy[0] : xiy[2];
-    XI[k] = fmin(fmin(xix[1], px), fmin(xiy[1], py));
+    // own coefficient and the one of the UPWIND neighbour (w.r.t. the pressure
+    // gradient) in each direction; the downwind one is never selected
+    const ptrdiff_t sx = (pr[k + p] - pr[k - p] > 0) ? -(ptrdiff_t)p : (ptrdiff_t)p;
+    const ptrdiff_t sy = (pr[k + 1] - pr[k - 1] > 0) ? -1 : 1;
+    const size_t cx = k + sx, cy = k + sy;
+    const double xix = flatten_1d(pr[k - 2 * p], pr[k - p], pr[k + p], pr[k + 2 * p], u[k - p],
+                                  u[k + p], P.z0, P.z1, P.delta);
+    const double px = flatten_1d(pr[cx - 2 * p], pr[cx - p], pr[cx + p], pr[cx + 2 * p],
+                                 u[cx - p], u[cx + p], P.z0, P.z1, P.delta);
+    const double xiy = flatten_1d(pr[k - 2], pr[k - 1], pr[k + 1], pr[k + 2], v[k - 1], v[k + 1],
+                                  P.z0, P.z1, P.delta);
+    const double py = flatten_1d(pr[cy - 2], pr[cy - 1], pr[cy + 1], pr[cy + 2], v[cy - 1],
+                                 v[cy + 1], P.z0, P.z1, P.delta);
+    XI[k] = fmin(fmin(xix, px), fmin(xiy, py));
 }
 
 // ---- stage 2: limited slopes + characteristic tracing on R(1) ------------

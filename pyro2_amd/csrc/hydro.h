@@ -107,14 +107,20 @@ __device__ __forceinline__ double flatten_1d(double pm2, double pm1, double pp1,
                                              double um1, double up1, double z0, double z1,
                                              double delta)
 {
+    // The reference evaluates z and xi everywhere and then selects with
+    // np.where(t1 > 0 and t2 > delta, xi, 1).  The selected value only depends
+    // on z where the condition holds, so the divisions are evaluated lazily:
+    // no compression (u_{-1} - u_{+1} <= 0) -> 1 without any division -- the
+    // common case away from shocks.  Same result, bit for bit.
+    const double t1b = um1 - up1;
+    if (!(t1b > 0.0)) return 1.0;
     const double smallp = 1.e-10;
-    double t1 = fabs(pp1 - pm1);
-    double t2 = fabs(pp2 - pm2);
-    double z = pdiv(t1, fmax(t2, smallp));
-    double t2b = pdiv(t1, fmin(pp1, pm1));
-    double t1b = um1 - up1;
-    double xi = fmin(1.0, fmax(0.0, 1.0 - pdiv(z - z0, z1 - z0)));
-    return (t1b > 0.0 && t2b > delta) ? xi : 1.0;
+    const double t1 = fabs(pp1 - pm1);
+    const double t2b = pdiv(t1, fmin(pp1, pm1));
+    if (!(t2b > delta)) return 1.0;
+    const double t2 = fabs(pp2 - pm2);
+    const double z = pdiv(t1, fmax(t2, smallp));
+    return fmin(1.0, fmax(0.0, 1.0 - pdiv(z - z0, z1 - z0)));
 }
 
 // Characteristic tracing of one cell in one direction,
