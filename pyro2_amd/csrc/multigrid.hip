@@ -59,6 +59,7 @@ struct pyrohip_mg {
     double source_norm = 0.0;
     int smoother = 1;             // 0: one launch per colour, 1: LDS tile smoother
     int kmax = 3;                 // red-black iterations fused per tile launch
+    int kmax_small = 5;           // ... on levels <= 1024^2 (latency bound)
     int coarse_kernel = 1;        // levels <= 64^2 in one LDS-resident workgroup
     bool corners_stale[pyro::MG_MAXLEV] = {};   // v: corner ghosts not refreshed yet
 };
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void k_mg_smooth(double *__restrict__ v,
 //               colour (64 cells, stride 2) and no index division is needed.
 constexpr int MGS_CELLS = 66 * 66;                 // single-tile levels: n <= 64
 constexpr size_t MGS_LDS = (size_t)2 * MGS_CELLS * sizeof(double);
-constexpr int MGW_RI = 32, MGW_LP = 128, MGW_NT = 512, MGW_KMAX = 3;
+constexpr int MGW_RI = 32, MGW_LP = 128, MGW_NT = 512, MGW_KMAX = 5;
 constexpr size_t MGW_LDS = (size_t)2 * MGW_RI * MGW_LP * sizeof(double);
 
 struct MGTile {
@@ -670,7 +671,10 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth)
     A.denom = m->alpha + 2.0 * A.xc + 2.0 * A.yc;
     A.bc = make_bc(m, level, true);
     A.single = ((L.n + 2) * (L.n + 2) <= MGS_CELLS) ? 1 : 0;   // whole level in one tile
-    const int kmax = (m->kmax >= 1 && m->kmax <= MGW_KMAX) ? m->kmax : 2;
+    int kmax = (m->kmax >= 1 && m->kmax <= MGW_KMAX) ? m->kmax : 3;
+    // levels up to 1024^2 live in L2 / Infinity Cache and are launch-latency
+    // bound: fuse as many iterations per launch as the 32-row region allows
+    if (L.n <= 1024 && m->kmax_small > kmax) kmax = m->kmax_small;
     int left = nsmooth;
     while (left > 0) {
         const int K = A.single ? left : (left < kmax ? left : kmax);
@@ -898,7 +902,8 @@ int pyrohip_mg_set_smoother(pyrohip_mg *m, int kind)
     // 10 + k selects the tile smoother with k fused iterations (tuning knob)
     // 20 + k: the same without the single-workgroup coarse V-cycle kernel
     m->coarse_kernel = 1;
-    if (kind >= 20) { m->smoother = 1; m->kmax = kind - 20; m->coarse_kernel = 0; }
+    m->kmax_small = 5;
+    if (kind >= 20) { m->smoother = 1; m->kmax = kind - 20; m->coarse_kernel = 0; m->kmax_small = 0; }
     else if (kind >= 10) { m->smoother = 1; m->kmax = kind - 10; }
     else m->smoother = kind;
     return 0;
