@@ -177,6 +177,13 @@ int pyrohip_mg_norm(pyrohip_mg *m, int level, int var, double *out); /* array_in
 int pyrohip_mg_vcycle(pyrohip_mg *m, int level);               /* MG.py:699-778 */
 /* init_RHS bookkeeping: source_norm = ||f|| on the finest level (MG.py:521) */
 int pyrohip_mg_init_rhs_norm(pyrohip_mg *m, double *source_norm);
+/* variable-coefficient mode, VarCoeffCCMG2d (multigrid/variable_coeff_MG.py:
+   23-213): solve div(eta grad phi) = f.  coeffs: (n+2, n+2) cell-centred eta on
+   the finest level (interior is used), coeffs_bc: its 4 BC codes.  Builds the
+   edge coefficients on every level (edge_coeffs.py:1-54); smoothing and the
+   residual then use them.  pyrohip_mg_get accepts var 3 = eta, 4 = eta_x,
+   5 = eta_y afterwards. */
+int pyrohip_mg_set_coeffs(pyrohip_mg *m, const double *coeffs, const int *coeffs_bc);
 /* callers that keep their field on the device (pyro/diffusion/simulation.py:
    92-118): f <- phi + coef * Laplacian(phi) on the finest level from variable
    n of a (nx, nx, ng = 1) state, and the solution back into that variable */

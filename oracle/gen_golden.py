@@ -475,7 +475,69 @@ def gen_diffusion():
     save("diff_small", **out)
 
 
+# --------------------------------------------------------------------------
+# variable-coefficient multigrid.  The reference's stored
+# goldens mg_vc_poisson_*.h5 are missing from this checkout
+# (.MISSING_LARGE_BLOBS), so the reference itself is run.
+# --------------------------------------------------------------------------
+def gen_mg_vc():
+    import pyro.multigrid.variable_coeff_MG as VC
+    out = {}
+    cases = [(("dirichlet",) * 4, ("neumann",) * 4, 32),
+             (("periodic",) * 4, ("periodic",) * 4, 32),
+             (("neumann", "dirichlet", "periodic", "periodic"),
+              ("neumann", "neumann", "periodic", "periodic"), 16)]
+    rng = np.random.default_rng(5)
+    for k, (bcs, cbcs, nx) in enumerate(cases):
+        g = patch.Grid2d(nx, nx, ng=1)
+        d = patch.CellCenterData2d(g)
+        bc_c = bnd.BC(xlb=cbcs[0], xrb=cbcs[1], ylb=cbcs[2], yrb=cbcs[3])
+        d.register_var("c", bc_c)
+        d.create()
+        c = d.get_var("c")
+        c[:, :] = 2.0 + np.cos(2.0 * np.pi * g.x2d) * np.cos(2.0 * np.pi * g.y2d) + \
+            0.1 * rng.random(c.shape)
+        a = VC.VarCoeffCCMG2d(nx, nx, xl_BC_type=bcs[0], xr_BC_type=bcs[1],
+                              yl_BC_type=bcs[2], yr_BC_type=bcs[3], nsmooth=4,
+                              nsmooth_bottom=9, coeffs=c, coeffs_bc=bc_c, verbose=0)
+        L = a.nlevels - 1
+        pre = f"v{k}_"
+        out[pre + "bc"] = np.array(bcs)
+        out[pre + "cbc"] = np.array(cbcs)
+        out[pre + "nx"] = np.array(nx)
+        out[pre + "c"] = np.array(c)
+        for lev in (L, L - 1, 0):
+            out[pre + f"c_l{lev}"] = np.array(a.grids[lev].get_var("coeffs"))
+            out[pre + f"ex_l{lev}"] = np.array(a.edge_coeffs[lev].x)
+            out[pre + f"ey_l{lev}"] = np.array(a.edge_coeffs[lev].y)
+        v0 = rng.standard_normal((nx + 2, nx + 2))
+        f0 = rng.standard_normal((nx + 2, nx + 2))
+        if all(b in ("periodic", "neumann") for b in bcs):
+            f0[1:-1, 1:-1] -= f0[1:-1, 1:-1].mean()
+        out[pre + "v0"], out[pre + "f0"] = v0, f0
+        a.init_solution(v0)
+        a.init_RHS(f0)
+        a.smooth(L, 3)
+        out[pre + "v_smooth"] = np.array(a.grids[L].get_var("v"))
+        a._compute_residual(L)
+        out[pre + "r"] = np.array(a.grids[L].get_var("r"))
+        b = VC.VarCoeffCCMG2d(nx, nx, xl_BC_type=bcs[0], xr_BC_type=bcs[1],
+                              yl_BC_type=bcs[2], yr_BC_type=bcs[3], nsmooth=4,
+                              nsmooth_bottom=9, coeffs=c, coeffs_bc=bc_c, verbose=0)
+        b.init_solution(v0)
+        b.init_RHS(f0)
+        b.max_cycles = 5
+        b.solve(rtol=1.e-10)
+        out[pre + "v_solve"] = np.array(b.grids[L].get_var("v"))
+        out[pre + "info"] = np.array([b.num_cycles, b.residual_error, b.relative_error,
+                                      b.source_norm])
+    out["ncases"] = np.array(len(cases))
+    save("mg_vc", **out)
+
+
 if __name__ == "__main__":
+    if "mg_vc" in sys.argv[1:]:
+        gen_mg_vc()
     which = sys.argv[1:] or ["bc", "adv", "comp_stages", "comp_runs", "mg", "diffusion"]
     if "diffusion" in which:
         gen_diffusion()

@@ -60,6 +60,9 @@ def lib():
         _lib.orc_mg_ptr.restype = C.POINTER(C.c_double)
         _lib.orc_mg_norm.restype = C.c_double
         _lib.orc_mg_get_scalar.restype = C.c_double
+        _lib.orc_vcmg_create.restype = C.c_void_p
+        _lib.orc_vcmg_base.restype = C.c_void_p
+        _lib.orc_vcmg_ptr.restype = C.POINTER(C.c_double)
     return _lib
 
 
@@ -242,6 +245,53 @@ class MG:
     def solve(self, rtol=1.e-11, max_cycles=100):
         self._l.orc_mg_set_max_cycles(self.h, max_cycles)
         self._l.orc_mg_solve(self.h, C.c_double(rtol))
+        g = self._l.orc_mg_get_scalar
+        self.source_norm = g(self.h, 0)
+        self.num_cycles = int(g(self.h, 1))
+        self.relative_error = g(self.h, 2)
+        self.residual_error = g(self.h, 3)
+
+
+class VCMG(MG):
+    """variable-coefficient subclass (variable_coeff_MG.VarCoeffCCMG2d core)"""
+
+    def __init__(self, nx, coeffs, xmin=0.0, xmax=1.0, ymin=0.0, ymax=1.0,
+                 bcs=("dirichlet",) * 4, coeffs_bcs=("neumann",) * 4, nsmooth=10,
+                 nsmooth_bottom=50):
+        bc, cbc = bc_codes(bcs), bc_codes(coeffs_bcs)
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)
+        self._l = lib()
+        self.vh = C.c_void_p(self._l.orc_vcmg_create(
+            nx, C.c_double(xmin), C.c_double(xmax), C.c_double(ymin), C.c_double(ymax),
+            bc.ctypes.data_as(C.POINTER(C.c_int)), cbc.ctypes.data_as(C.POINTER(C.c_int)),
+            _p(coeffs), nsmooth, nsmooth_bottom))
+        self.h = C.c_void_p(self._l.orc_vcmg_base(self.vh))
+        self.nx = nx
+        self.nlevels = self._l.orc_mg_nlevels(self.h)
+
+    def __del__(self):
+        try:
+            self._l.orc_vcmg_free(self.vh)
+        except Exception:
+            pass
+
+    def coef(self, level, which):
+        """0 = cell coefficient, 1 = eta_x, 2 = eta_y"""
+        n = 2 ** (level + 1) + 2
+        return np.ctypeslib.as_array(self._l.orc_vcmg_ptr(self.vh, level, which), shape=(n, n))
+
+    def smooth(self, level, n):
+        self._l.orc_vcmg_smooth(self.vh, level, n)
+
+    def residual(self, level):
+        self._l.orc_vcmg_residual(self.vh, level)
+
+    def vcycle(self, level=None):
+        self._l.orc_vcmg_vcycle(self.vh, self.nlevels - 1 if level is None else level)
+
+    def solve(self, rtol=1.e-11, max_cycles=100):
+        self._l.orc_mg_set_max_cycles(self.h, max_cycles)
+        self._l.orc_vcmg_solve(self.vh, C.c_double(rtol))
         g = self._l.orc_mg_get_scalar
         self.source_norm = g(self.h, 0)
         self.num_cycles = int(g(self.h, 1))

@@ -1188,3 +1188,181 @@ void orc_mg_solve(orc_mg *m, double rtol)
     orc_mg_fill_bc_v(m, L);
     free(old_phi);
 }
+
+/* ================================================================== */
+/* Variable-coefficient multigrid  div(eta grad phi) = f               */
+/* pyro/multigrid/variable_coeff_MG.py:23-213, edge_coeffs.py:1-54     */
+/* (SURVEY 8 row f1).  Uses the level arrays of orc_mg plus per-level  */
+/* edge coefficients eta_x[i,j] = eta_{i-1/2,j}, eta_y[i,j] = eta_{i,j-1/2} */
+/* ================================================================== */
+typedef struct {
+    orc_mg *mg;
+    double *c[MG_MAXLEV];     /* cell-centred coefficient, ghost filled */
+    double *ex[MG_MAXLEV], *ey[MG_MAXLEV];
+    int cbc[4];
+} orc_vcmg;
+
+orc_vcmg *orc_vcmg_create(int nx, double xmin, double xmax, double ymin, double ymax,
+                          const int *bc, const int *coeffs_bc, const double *coeffs,
+                          int nsmooth, int nsmooth_bottom)
+{
+    orc_vcmg *V = (orc_vcmg *)calloc(1, sizeof(orc_vcmg));
+    V->mg = orc_mg_create(nx, xmin, xmax, ymin, ymax, bc, 0.0, 0.0, nsmooth, nsmooth_bottom);
+    memcpy(V->cbc, coeffs_bc, sizeof(int) * 4);
+    orc_mg *m = V->mg;
+    const int L = m->nlevels - 1;
+    for (int l = 0; l <= L; l++) {
+        size_t N = (size_t)(m->n[l] + 2) * (m->n[l] + 2);
+        V->c[l] = zalloc(N); V->ex[l] = zalloc(N); V->ey[l] = zalloc(N);
+    }
+    {   /* finest: c.v() = coeffs.v(); fill_BC; EdgeCoeffs (edge_coeffs.py:8-27) */
+        const int n = m->n[L], q = n + 2;
+        for (int i = 1; i <= n; i++)
+            for (int j = 1; j <= n; j++) V->c[L][(size_t)i * q + j] = coeffs[(size_t)i * q + j];
+        mg_fill_bc(V->c[L], n, m->dx[L], V->cbc, NULL);
+        const double dx2 = m->dx[L] * m->dx[L];
+        for (int i = 1; i <= n + 1; i++)
+            for (int j = 1; j <= n + 1; j++) {
+                V->ex[L][(size_t)i * q + j] =
+                    0.5 * (V->c[L][(size_t)(i - 1) * q + j] + V->c[L][(size_t)i * q + j]);
+                V->ey[L][(size_t)i * q + j] =
+                    0.5 * (V->c[L][(size_t)i * q + j - 1] + V->c[L][(size_t)i * q + j]);
+            }
+        for (size_t k = 0; k < (size_t)q * q; k++) { V->ex[L][k] /= dx2; V->ey[L][k] /= dx2; }
+    }
+    for (int l = L - 1; l >= 0; l--) {   /* variable_coeff_MG.py:86-99 */
+        const int nc = m->n[l], qc = nc + 2, qf = m->n[l + 1] + 2;
+        const double *fc = V->c[l + 1];
+        for (int i = 0; i < nc; i++)
+            for (int j = 0; j < nc; j++) {
+                int fi = 1 + 2 * i, fj = 1 + 2 * j;
+                V->c[l][(size_t)(1 + i) * qc + 1 + j] =
+                    0.25 * (fc[(size_t)fi * qf + fj] + fc[(size_t)(fi + 1) * qf + fj] +
+                            fc[(size_t)fi * qf + fj + 1] + fc[(size_t)(fi + 1) * qf + fj + 1]);
+            }
+        mg_fill_bc(V->c[l], nc, m->dx[l], V->cbc, NULL);
+        /* EdgeCoeffs.restrict, edge_coeffs.py:29-54 */
+        const double *fx = V->ex[l + 1], *fy = V->ey[l + 1];
+        const double fdx2 = m->dx[l + 1] * m->dx[l + 1], cdx2 = m->dx[l] * m->dx[l];
+        for (int i = 0; i <= nc; i++)        /* x edges: i in [ilo, ihi+1], j interior */
+            for (int j = 0; j < nc; j++) {
+                int fi = 1 + 2 * i, fj = 1 + 2 * j;
+                double e = 0.5 * (fx[(size_t)fi * qf + fj] + fx[(size_t)fi * qf + fj + 1]);
+                V->ex[l][(size_t)(1 + i) * qc + 1 + j] = e * fdx2 / cdx2;
+            }
+        for (int i = 0; i < nc; i++)         /* y edges: j in [jlo, jhi+1], i interior */
+            for (int j = 0; j <= nc; j++) {
+                int fi = 1 + 2 * i, fj = 1 + 2 * j;
+                double e = 0.5 * (fy[(size_t)fi * qf + fj] + fy[(size_t)(fi + 1) * qf + fj]);
+                V->ey[l][(size_t)(1 + i) * qc + 1 + j] = e * fdx2 / cdx2;
+            }
+    }
+    return V;
+}
+
+void orc_vcmg_free(orc_vcmg *V)
+{
+    for (int l = 0; l < V->mg->nlevels; l++) { free(V->c[l]); free(V->ex[l]); free(V->ey[l]); }
+    orc_mg_free(V->mg);
+    free(V);
+}
+orc_mg *orc_vcmg_base(orc_vcmg *V) { return V->mg; }
+double *orc_vcmg_ptr(orc_vcmg *V, int level, int which)
+{
+    return which == 0 ? V->c[level] : which == 1 ? V->ex[level] : V->ey[level];
+}
+
+/* variable_coeff_MG.py:103-168 */
+void orc_vcmg_smooth(orc_vcmg *V, int level, int nsmooth)
+{
+    orc_mg *m = V->mg;
+    const int n = m->n[level], q = n + 2;
+    double *v = m->v[level];
+    const double *f = m->f[level], *ex = V->ex[level], *ey = V->ey[level];
+    orc_mg_fill_bc_v(m, level);
+    static const int grp[4][2] = {{0, 0}, {1, 1}, {1, 0}, {0, 1}};
+#define I(i, j) ((size_t)(i) * q + (j))
+    for (int it = 0; it < nsmooth; it++)
+        for (int g = 0; g < 4; g++) {
+            for (int i = 1 + grp[g][0]; i <= n; i += 2)
+                for (int j = 1 + grp[g][1]; j <= n; j += 2) {
+                    double denom = ex[I(i + 1, j)] + ex[I(i, j)] + ey[I(i, j + 1)] + ey[I(i, j)];
+                    v[I(i, j)] = (-f[I(i, j)] + ex[I(i + 1, j)] * v[I(i + 1, j)] +
+                                  ex[I(i, j)] * v[I(i - 1, j)] + ey[I(i, j + 1)] * v[I(i, j + 1)] +
+                                  ey[I(i, j)] * v[I(i, j - 1)]) / denom;
+                }
+            if (g == 1 || g == 3) orc_mg_fill_bc_v(m, level);
+        }
+#undef I
+}
+
+/* variable_coeff_MG.py:191-213 */
+void orc_vcmg_residual(orc_vcmg *V, int level)
+{
+    orc_mg *m = V->mg;
+    const int n = m->n[level], q = n + 2;
+    const double *v = m->v[level], *f = m->f[level], *ex = V->ex[level], *ey = V->ey[level];
+    double *r = m->r[level];
+#define I(i, j) ((size_t)(i) * q + (j))
+    for (int i = 1; i <= n; i++)
+        for (int j = 1; j <= n; j++) {
+            double L = ex[I(i + 1, j)] * (v[I(i + 1, j)] - v[I(i, j)]) -
+                       ex[I(i, j)] * (v[I(i, j)] - v[I(i - 1, j)]) +
+                       ey[I(i, j + 1)] * (v[I(i, j + 1)] - v[I(i, j)]) -
+                       ey[I(i, j)] * (v[I(i, j)] - v[I(i, j - 1)]);
+            r[I(i, j)] = f[I(i, j)] - L;
+        }
+#undef I
+}
+
+void orc_vcmg_vcycle(orc_vcmg *V, int level)
+{
+    orc_mg *m = V->mg;
+    if (level > 0) {
+        orc_vcmg_smooth(V, level, m->nsmooth);
+        orc_vcmg_residual(V, level);
+        orc_mg_restrict(m, level);
+        orc_vcmg_vcycle(V, level - 1);
+        orc_mg_prolong_add(m, level);
+        orc_mg_fill_bc_v(m, level);
+        orc_vcmg_smooth(V, level, m->nsmooth);
+    } else {
+        orc_vcmg_smooth(V, level, m->nsmooth_bottom);
+        orc_mg_fill_bc_v(m, level);
+    }
+}
+
+void orc_vcmg_solve(orc_vcmg *V, double rtol)
+{
+    orc_mg *m = V->mg;
+    const int L = m->nlevels - 1;
+    const int n = m->n[L], q = n + 2;
+    const size_t N = (size_t)q * q;
+    double *old_phi = (double *)malloc(N * 8);
+    memcpy(old_phi, m->v[L], N * 8);
+    double residual_error = 1.e33, relative_error = 1.e33;
+    int cycle = 1;
+    while (residual_error > rtol && cycle <= m->max_cycles) {
+        for (int l = 0; l < L; l++)
+            memset(m->v[l], 0, (size_t)(m->n[l] + 2) * (m->n[l] + 2) * 8);
+        orc_vcmg_vcycle(V, L);
+        double s = 0.0;
+        for (int i = 1; i <= n; i++)
+            for (int j = 1; j <= n; j++) {
+                size_t k = (size_t)i * q + j;
+                double d = (m->v[L][k] - old_phi[k]) / (m->v[L][k] + 1.e-16);
+                s += d * d;
+            }
+        relative_error = sqrt(m->dx[L] * m->dx[L] * s);
+        memcpy(old_phi, m->v[L], N * 8);
+        orc_vcmg_residual(V, L);
+        double rn = orc_mg_norm(m, L, 2);
+        residual_error = (m->source_norm != 0.0) ? rn / m->source_norm : rn;
+        cycle++;
+    }
+    m->num_cycles = cycle - 1;
+    m->relative_error = relative_error;
+    m->residual_error = residual_error;
+    orc_mg_fill_bc_v(m, L);
+    free(old_phi);
+}

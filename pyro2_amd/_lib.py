@@ -90,6 +90,7 @@ _PROTOS = {
     "pyrohip_mg_vcycle": [_VP, C.c_int],
     "pyrohip_mg_init_rhs_norm": [_VP, _DP],
     "pyrohip_mg_solve": [_VP, C.c_double, C.c_int, _IP, _DP, _DP],
+    "pyrohip_mg_set_coeffs": [_VP, _DP, _IP],
     "pyrohip_mg_set_rhs_cn": [_VP, _VP, C.c_int, C.c_double, _DP],
     "pyrohip_mg_copy_solution": [_VP, _VP, C.c_int],
     "pyrohip_comm_unique_id": [C.c_char_p],

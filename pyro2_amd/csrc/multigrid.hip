@@ -37,6 +37,7 @@ struct MGLevel {
     double dx;
     double *v, *f, *r;
     double *v2;     // second solution buffer (tile smoother ping-pong)
+    double *c = nullptr, *ex = nullptr, *ey = nullptr;   // variable-coefficient mode
 };
 
 struct MGBC {
@@ -61,6 +62,8 @@ struct pyrohip_mg {
     int kmax = 3;                 // red-black iterations fused per tile launch
     int kmax_small = 5;           // ... on levels <= 1024^2 (latency bound)
     int coarse_kernel = 1;        // levels <= 64^2 in one LDS-resident workgroup
+    int vc = 0;                   // variable-coefficient mode (div(eta grad phi) = f)
+    double *vc_pool = nullptr;
     bool corners_stale[pyro::MG_MAXLEV] = {};   // v: corner ghosts not refreshed yet
 };
 
@@ -505,6 +508,89 @@ __global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Variable-coefficient mode  div(eta grad phi) = f
+// pyro/multigrid/variable_coeff_MG.py:23-213, edge_coeffs.py:1-54.
+// eta_x[i,j] = eta_{i-1/2,j}/dx^2, eta_y[i,j] = eta_{i,j-1/2}/dy^2.
+// ---------------------------------------------------------------------------
+__global__ void k_vc_edges(const double *__restrict__ c, double *__restrict__ ex,
+                           double *__restrict__ ey, int n, int pitch, double dx2)
+{
+    const int j = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = 1 + blockIdx.y;
+    if (j > n + 1 || i > n + 1) return;
+    const size_t k = (size_t)i * pitch + j;
+    double e = 0.5 * (c[k - pitch] + c[k]);   // edge_coeffs.py:21-25
+    ex[k] = e / dx2;
+    e = 0.5 * (c[k - 1] + c[k]);
+    ey[k] = e / dx2;
+}
+
+// EdgeCoeffs.restrict, edge_coeffs.py:29-54
+__global__ void k_vc_edges_restrict(const double *__restrict__ fx, const double *__restrict__ fy,
+                                    int fpitch, double *__restrict__ cx, double *__restrict__ cy,
+                                    int cpitch, int nc, double fdx2, double cdx2)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;   // 0 .. nc
+    const int i = blockIdx.y;                              // 0 .. nc
+    if (j > nc || i > nc) return;
+    const size_t fk = (size_t)(1 + 2 * i) * fpitch + (1 + 2 * j);
+    const size_t ck = (size_t)(1 + i) * cpitch + (1 + j);
+    if (j < nc) cx[ck] = 0.5 * (fx[fk] + fx[fk + 1]) * fdx2 / cdx2;
+    if (i < nc) cy[ck] = 0.5 * (fy[fk] + fy[fk + fpitch]) * fdx2 / cdx2;
+}
+
+// one colour of the variable-coefficient smoother, variable_coeff_MG.py:131-147
+__global__ __launch_bounds__(256) void k_vc_smooth(double *__restrict__ v,
+                                                   const double *__restrict__ f,
+                                                   const double *__restrict__ ex,
+                                                   const double *__restrict__ ey, int n, int pitch,
+                                                   double dx, int colour, MGBC bc)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = 1 + blockIdx.y;
+    const int j = 1 + 2 * t + ((i - 1 + colour) & 1);
+    if (j > n) return;
+    const size_t k = (size_t)i * pitch + j;
+    const double denom = ex[k + pitch] + ex[k] + ey[k + 1] + ey[k];
+    const double vn = (-f[k] + ex[k + pitch] * v[k + pitch] + ex[k] * v[k - pitch] +
+                       ey[k + 1] * v[k + 1] + ey[k] * v[k - 1]) / denom;
+    v[k] = vn;
+    if (i == 1) {
+        if (bc.code[0] == PYROHIP_BC_PERIODIC) v[(size_t)(n + 1) * pitch + j] = vn;
+        else v[j] = ghost_lo(bc.code[0], vn, bc.val[0], j, dx);
+    }
+    if (i == n) {
+        if (bc.code[1] == PYROHIP_BC_PERIODIC) v[j] = vn;
+        else v[(size_t)(n + 1) * pitch + j] = ghost_hi(bc.code[1], vn, bc.val[1], j, dx);
+    }
+    if (j == 1) {
+        if (bc.code[2] == PYROHIP_BC_PERIODIC) v[(size_t)i * pitch + n + 1] = vn;
+        else v[(size_t)i * pitch] = ghost_lo(bc.code[2], vn, bc.val[2], i, dx);
+    }
+    if (j == n) {
+        if (bc.code[3] == PYROHIP_BC_PERIODIC) v[(size_t)i * pitch] = vn;
+        else v[(size_t)i * pitch + n + 1] = ghost_hi(bc.code[3], vn, bc.val[3], i, dx);
+    }
+}
+
+// variable_coeff_MG.py:191-213
+__global__ __launch_bounds__(256) void k_vc_residual(const double *__restrict__ v,
+                                                     const double *__restrict__ f,
+                                                     const double *__restrict__ ex,
+                                                     const double *__restrict__ ey,
+                                                     double *__restrict__ r, int n, int pitch)
+{
+    const int j = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = 1 + blockIdx.y;
+    if (j > n) return;
+    const size_t k = (size_t)i * pitch + j;
+    const double L = ex[k + pitch] * (v[k + pitch] - v[k]) - ex[k] * (v[k] - v[k - pitch]) +
+                     ey[k + 1] * (v[k + 1] - v[k]) - ey[k] * (v[k] - v[k - 1]);
+    r[k] = f[k] - L;
+}
+
 // MG.py:529-542
 __global__ __launch_bounds__(256) void k_mg_residual(const double *__restrict__ v,
                                                      const double *__restrict__ f,
@@ -616,7 +702,14 @@ static MGBC make_bc(const pyrohip_mg *m, int level, bool for_v)
 static double *plane(pyrohip_mg *m, int level, int var)
 {
     MGLevel &L = m->lev[level];
-    return var == 0 ? L.v : var == 1 ? L.f : L.r;
+    switch (var) {
+    case 0: return L.v;
+    case 1: return L.f;
+    case 2: return L.r;
+    case 3: return L.c;
+    case 4: return L.ex;
+    default: return L.ey;
+    }
 }
 
 static int mg_fill(pyrohip_mg *m, int level, int var)
@@ -702,6 +795,20 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth)
 // handed to the host; no kernel reads corners)
 static int mg_smooth(pyrohip_mg *m, int level, int nsmooth, bool corners = true)
 {
+    if (m->vc) {   // variable coefficients: one launch per colour
+        PYRO_TRY(mg_fill(m, level, 0));
+        MGLevel &L = m->lev[level];
+        MGBC bc = make_bc(m, level, true);
+        const int half = (L.n + 1) / 2;
+        const int bx = (half >= 256) ? 256 : 64;
+        dim3 grid((half + bx - 1) / bx, L.n), block(bx);
+        for (int it = 0; it < nsmooth; it++)
+            for (int colour = 0; colour < 2; colour++)
+                PYRO_LAUNCH(m->ctx, "k_vc_smooth", k_vc_smooth, grid, block, 0, L.v,
+                            (const double *)L.f, (const double *)L.ex, (const double *)L.ey, L.n,
+                            L.pitch, L.dx, colour, bc);
+        return 0;
+    }
     if (m->smoother == 0 || nsmooth <= 0) {
         PYRO_TRY(mg_fill(m, level, 0));                   // MG.py:565
         return nsmooth > 0 ? mg_smooth_colour_launches(m, level, nsmooth) : 0;
@@ -717,6 +824,12 @@ static int mg_residual(pyrohip_mg *m, int level)
 {
     MGLevel &L = m->lev[level];
     const int bx = (L.n >= 256) ? 256 : 64;
+    if (m->vc) {
+        hipLaunchKernelGGL(k_vc_residual, dim3((L.n + bx - 1) / bx, L.n), dim3(bx), 0,
+                           m->ctx->stream, (const double *)L.v, (const double *)L.f,
+                           (const double *)L.ex, (const double *)L.ey, L.r, L.n, L.pitch);
+        return 0;
+    }
     hipLaunchKernelGGL(k_mg_residual, dim3((L.n + bx - 1) / bx, L.n), dim3(bx), 0, m->ctx->stream,
                        (const double *)L.v, (const double *)L.f, L.r, L.n, L.pitch, m->alpha,
                        m->beta, L.dx * L.dx);
@@ -799,7 +912,7 @@ static int mg_coarse_vcycle(pyrohip_mg *m, int top)
 
 static int mg_vcycle(pyrohip_mg *m, int level)
 {
-    if (m->smoother != 0 && m->coarse_kernel && level <= MGC_TOP)
+    if (!m->vc && m->smoother != 0 && m->coarse_kernel && level <= MGC_TOP)
         return mg_coarse_vcycle(m, level);
     if (level > 0) {
         PYRO_TRY(mg_smooth(m, level, m->nsmooth, false)); // MG.py:722
@@ -807,11 +920,11 @@ static int mg_vcycle(pyrohip_mg *m, int level)
         PYRO_TRY(mg_restrict(m, level));                  // :731-732
         PYRO_TRY(mg_vcycle(m, level - 1));                // :735
         PYRO_TRY(mg_prolong_add(m, level));               // :745-748
-        if (m->smoother == 0) PYRO_TRY(mg_fill(m, level, 0));   // :751 (tile smoother: on load)
+        if (m->smoother == 0 || m->vc) PYRO_TRY(mg_fill(m, level, 0));   // :751 (tile smoother: on load)
         PYRO_TRY(mg_smooth(m, level, m->nsmooth, false)); // :758
     } else {
         PYRO_TRY(mg_smooth(m, level, m->nsmooth_bottom, false)); // :776
-        if (m->smoother == 0) PYRO_TRY(mg_fill(m, level, 0));     // :778
+        if (m->smoother == 0 || m->vc) PYRO_TRY(mg_fill(m, level, 0));     // :778
     }
     return 0;
 }
@@ -889,6 +1002,7 @@ int pyrohip_mg_destroy(pyrohip_mg *m)
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     if (m->pool) (void)hipFree(m->pool);
+    if (m->vc_pool) (void)hipFree(m->vc_pool);
     for (int s = 0; s < 4; s++)
         if (m->bcval[s]) (void)hipFree(m->bcval[s]);
     delete m;
@@ -932,7 +1046,7 @@ int pyrohip_mg_set(pyrohip_mg *m, int level, int var, const double *host)
 int pyrohip_mg_get(pyrohip_mg *m, int level, int var, double *host)
 {
     MG_CHECK_LEVEL(m, level);
-    PYRO_REQUIRE(var >= 0 && var <= 2 && host, "bad var / NULL host");
+    PYRO_REQUIRE(var >= 0 && var <= (m->vc ? 5 : 2) && host, "bad var / NULL host");
     if (var == 0 && m->corners_stale[level]) {   // index-for-index incl. corner ghosts
         PYRO_TRY(mg_fill(m, level, 0));
         m->corners_stale[level] = false;
@@ -1037,6 +1151,68 @@ int pyrohip_mg_init_rhs_norm(pyrohip_mg *m, double *source_norm)
     PYRO_TRY(pyrohip_mg_norm(m, m->nlevels - 1, 1, &nrm));
     m->source_norm = nrm;
     if (source_norm) *source_norm = nrm;
+    return 0;
+}
+
+int pyrohip_mg_set_coeffs(pyrohip_mg *m, const double *coeffs, const int *coeffs_bc)
+{
+    PYRO_REQUIRE(m && coeffs && coeffs_bc, "NULL argument");
+    pyrohip_ctx *c = m->ctx;
+    PYRO_CHECK_HIP(hipSetDevice(c->device));
+    if (!m->vc_pool) {
+        size_t total = 16;
+        for (int l = 0; l < m->nlevels; l++) {
+            Geom g = make_geom(m->lev[l].n, m->lev[l].n, 1);
+            total += 3 * g.plane + 16;
+        }
+        PYRO_CHECK_HIP(hipMalloc((void **)&m->vc_pool, total * sizeof(double)));
+        PYRO_CHECK_HIP(hipMemsetAsync(m->vc_pool, 0, total * sizeof(double), c->stream));
+        double *p = m->vc_pool;
+        for (int l = 0; l < m->nlevels; l++) {
+            Geom g = make_geom(m->lev[l].n, m->lev[l].n, 1);
+            MGLevel &L = m->lev[l];
+            L.c = p + geom_lead(g); p += g.plane;
+            L.ex = p + geom_lead(g); p += g.plane;
+            L.ey = p + geom_lead(g); p += g.plane;
+            p += 16;
+        }
+    }
+    MGBC cbc;
+    for (int s = 0; s < 4; s++) { cbc.code[s] = coeffs_bc[s]; cbc.val[s] = nullptr; }
+    const int Lf = m->nlevels - 1;
+    {   // finest: c.v() = coeffs.v(); fill_BC; EdgeCoeffs (variable_coeff_MG.py:72-84)
+        MGLevel &F = m->lev[Lf];
+        const int q = F.n + 2;
+        PYRO_CHECK_HIP(hipMemcpy2DAsync(F.c, F.pitch * sizeof(double), coeffs, q * sizeof(double),
+                                        q * sizeof(double), q, hipMemcpyHostToDevice, c->stream));
+    }
+    for (int l = Lf; l >= 0; l--) {
+        MGLevel &L = m->lev[l];
+        if (l < Lf) {   // coeffs_c.v() = f_patch.restrict("coeffs").v()  (:86-93)
+            MGLevel &F = m->lev[l + 1];
+            const int bx = (L.n >= 256) ? 256 : 64;
+            hipLaunchKernelGGL(k_mg_restrict, dim3((L.n + bx - 1) / bx, L.n), dim3(bx), 0,
+                               c->stream, (const double *)F.c, F.pitch, L.c, L.pitch, L.n);
+        }
+        const int nt = L.n + 2;
+        hipLaunchKernelGGL(k_mg_fill_x, dim3((nt + 255) / 256), dim3(256), 0, c->stream, L.c, L.n,
+                           L.pitch, L.dx, cbc);
+        hipLaunchKernelGGL(k_mg_fill_y, dim3((nt + 255) / 256), dim3(256), 0, c->stream, L.c, L.n,
+                           L.pitch, L.dx, cbc);
+        if (l == Lf) {
+            hipLaunchKernelGGL(k_vc_edges, dim3((L.n + 1 + 63) / 64, L.n + 1), dim3(64), 0,
+                               c->stream, (const double *)L.c, L.ex, L.ey, L.n, L.pitch,
+                               L.dx * L.dx);
+        } else {
+            MGLevel &F = m->lev[l + 1];
+            hipLaunchKernelGGL(k_vc_edges_restrict, dim3((L.n + 1 + 63) / 64, L.n + 1), dim3(64), 0,
+                               c->stream, (const double *)F.ex, (const double *)F.ey, F.pitch,
+                               L.ex, L.ey, L.pitch, L.n, F.dx * F.dx, L.dx * L.dx);
+        }
+    }
+    PYRO_CHECK_HIP(hipGetLastError());
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    m->vc = 1;
     return 0;
 }
 

@@ -329,6 +329,14 @@ class DeviceMG:
         self._call("pyrohip_mg_init_rhs_norm", C.byref(out))
         return out.value
 
+    def set_coeffs(self, coeffs, coeffs_bcs):
+        """switch to variable-coefficient mode (VarCoeffCCMG2d)"""
+        a = np.ascontiguousarray(coeffs, dtype=np.float64)
+        assert a.shape == (self.nx + 2,) * 2
+        bc = np.array([BC_CODE[b] if isinstance(b, str) else int(b) for b in coeffs_bcs],
+                      dtype=np.int32)
+        self._call("pyrohip_mg_set_coeffs", dptr(a), iptr(bc))
+
     def set_rhs_cn(self, state, n, coef):
         """f <- phi + coef * L(phi) from variable n of a device state; returns ||f||"""
         out = C.c_double()

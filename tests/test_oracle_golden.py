@@ -210,3 +210,31 @@ def test_comp_reference_regression_quad(golden):
     for n in range(4):
         e = max_rel_err(U[4:-4, 4:-4, n], g["gold"][..., n])
         assert e < 1e-12, (n, e)   # measured 1.0e-13 (golden made with real numba)
+
+
+def test_mg_variable_coefficient(golden):
+    """variable_coeff_MG.VarCoeffCCMG2d: edge coefficients on three levels,
+    smoother, residual and a 5-cycle solve against the reference"""
+    g = golden("mg_vc")
+    for k in range(int(g["ncases"])):
+        nx = int(g[f"v{k}_nx"])
+        m = orc.VCMG(nx, g[f"v{k}_c"], bcs=[str(b) for b in g[f"v{k}_bc"]],
+                     coeffs_bcs=[str(b) for b in g[f"v{k}_cbc"]], nsmooth=4, nsmooth_bottom=9)
+        L = m.nlevels - 1
+        for lev in (L, L - 1, 0):
+            n = 2 ** (lev + 1)
+            assert np.array_equal(m.coef(lev, 0), g[f"v{k}_c_l{lev}"]), (k, lev)
+            # x edges valid for i in [1, n+1], j interior (and vice versa)
+            assert np.array_equal(m.coef(lev, 1)[1:n + 2, 1:n + 1], g[f"v{k}_ex_l{lev}"][1:n + 2, 1:n + 1])
+            assert np.array_equal(m.coef(lev, 2)[1:n + 1, 1:n + 2], g[f"v{k}_ey_l{lev}"][1:n + 1, 1:n + 2])
+        m.arr(L, 0)[:, :] = g[f"v{k}_v0"]
+        m.init_rhs(g[f"v{k}_f0"])
+        m.smooth(L, 3)
+        assert np.array_equal(m.arr(L, 0), g[f"v{k}_v_smooth"]), k
+        m.residual(L)
+        assert np.array_equal(m.arr(L, 2)[1:-1, 1:-1], g[f"v{k}_r"][1:-1, 1:-1]), k
+        m.arr(L, 0)[:, :] = g[f"v{k}_v0"]
+        m.solve(rtol=1e-10, max_cycles=5)
+        info = g[f"v{k}_info"]
+        assert m.num_cycles == int(info[0])
+        assert np.array_equal(m.arr(L, 0), g[f"v{k}_v_solve"]), k
