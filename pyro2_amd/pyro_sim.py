@@ -169,6 +169,54 @@ class Pyro:
         return self.sim
 
 
+class PyroBenchmark(Pyro):
+    """Pyro that compares its end state with a stored HDF5 output / stores one
+    (pyro/pyro_sim.py:322-408)"""
+
+    def __init__(self, solver_name, *, comp_bench=False, reset_bench_on_fail=False,
+                 make_bench=False, bench_dir=None):
+        super().__init__(solver_name)
+        self.comp_bench = comp_bench
+        self.reset_bench_on_fail = reset_bench_on_fail
+        self.make_bench = make_bench
+        self.bench_dir = bench_dir or (self.pyro_home + self.solver_name + "/tests/")
+
+    def _bench_file(self):
+        basename = self.rp.get_param("io.basename")
+        return f"{self.bench_dir}{basename}{self.sim.n:04d}"
+
+    def run_sim(self, rtol=1.e-12):
+        super().run_sim()
+        result = 0
+        if self.comp_bench:
+            result = self.compare_to_benchmark(rtol)
+        if self.make_bench or (result != 0 and self.reset_bench_on_fail):
+            self.store_as_benchmark()
+        return result if self.comp_bench else self.sim
+
+    def compare_to_benchmark(self, rtol):
+        from .util import compare, io_pyro
+        compare_file = self._bench_file()
+        msg.warning(f"comparing to: {compare_file} ")
+        try:
+            sim_bench = io_pyro.read(compare_file)
+        except OSError:
+            msg.warning("ERROR opening compare file")
+            return "ERROR opening compare file"
+        result = compare.compare(self.sim.cc_data, sim_bench.cc_data, rtol)
+        if result == 0:
+            msg.success(f"results match benchmark to within relative tolerance of {rtol}\n")
+        else:
+            msg.warning("ERROR: " + compare.errors[result] + "\n")
+        return result
+
+    def store_as_benchmark(self):
+        os.makedirs(self.bench_dir, exist_ok=True)
+        bench_file = self._bench_file()
+        msg.warning(f"storing new benchmark: {bench_file}\n")
+        self.sim.write(bench_file)
+
+
 def parse_args():
     p = argparse.ArgumentParser(description="pyro hot path on MI355X")
     p.add_argument("--make_benchmark", action="store_true",

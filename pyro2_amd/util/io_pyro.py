@@ -1,0 +1,57 @@
+"""Read the HDF5 output files (layout of pyro/simulation_null.py:270-290 and
+pyro/mesh/patch.py:750-788) back into a Simulation / CellCenterData2d, API of
+pyro/util/io_pyro.py:27-148.  Files written by pyro itself are readable too
+(same layout).  Host-side I/O: needs h5py."""
+import importlib
+
+from ..mesh import boundary as bnd
+from ..mesh.patch import Cartesian2d, CellCenterData2d
+
+
+def read(filename):
+    import h5py
+    if not filename.endswith(".h5"):
+        filename += ".h5"
+    with h5py.File(filename, "r") as f:
+        solver_name = f.attrs.get("solver")
+        problem_name = f.attrs.get("problem")
+        t = f.attrs.get("time")
+        nsteps = f.attrs.get("nsteps")
+        g = f["grid"].attrs
+        if g.get("coord_type", 0) == 1:
+            raise ValueError("SphericalPolar output cannot be read by the device package")
+        myg = Cartesian2d(int(g["nx"]), int(g["ny"]), ng=int(g["ng"]), xmin=g["xmin"],
+                          xmax=g["xmax"], ymin=g["ymin"], ymax=g["ymax"])
+        names = list(f["state"])
+        myd = CellCenterData2d(myg)
+        for n in names:
+            a = f["state"][n].attrs
+            known = {k: (a[k] if a[k] in bnd.bc_solid else "outflow")
+                     for k in ("xlb", "xrb", "ylb", "yrb")}   # custom BC types: not filled here
+            myd.register_var(n, bnd.BC(**known))
+        myd.create()
+        for k in f["aux"].attrs:
+            myd.set_aux(k, f["aux"].attrs[k])
+        for n in names:
+            myd.get_var(n).v()[:, :] = f["state"][n]["data"][:, :]
+    if solver_name is None:
+        return myd
+    if isinstance(solver_name, bytes):
+        solver_name = solver_name.decode()
+    base = {"compressible_rk": "compressible", "compressible_fv4": "compressible",
+            "compressible_sdc": "compressible"}.get(solver_name, solver_name)
+    try:
+        solver = importlib.import_module("pyro2_amd." + base)
+        sim = solver.Simulation(solver_name, problem_name, None, None)
+    except ModuleNotFoundError:
+        from ..simulation_null import NullSimulation
+        sim = NullSimulation(solver_name, problem_name, None, None)
+    sim.n = nsteps
+    sim.cc_data = myd
+    sim.cc_data.t = t
+    try:
+        derives = importlib.import_module(f"pyro2_amd.{base}.derives")
+        sim.cc_data.add_derived(derives.derive_primitives)
+    except ModuleNotFoundError:
+        pass
+    return sim

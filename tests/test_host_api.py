@@ -155,3 +155,19 @@ def test_custom_problem_and_fill_bc(api):
     assert d[6, 0] == d[6, 8] and d[6, 15] == d[6, 7]          # periodic in y
     p.single_step()
     assert p.sim.n == 1 and p.sim.cc_data.t == p.sim.dt
+
+
+def test_hdf5_roundtrip_and_benchmark_compare(api, tmp_path):
+    """write() / io_pyro.read() / compare / PyroBenchmark (needs h5py, which the
+    default interpreter of this image lacks: skipped there, runs under conda)"""
+    pytest.importorskip("h5py")
+    from pyro2_amd.pyro_sim import PyroBenchmark
+    from pyro2_amd.util import compare, io_pyro
+    p = PyroBenchmark("advection", make_bench=True, bench_dir=str(tmp_path) + "/bench/")
+    p.initialize_problem("smooth", inputs_dict={"driver.max_steps": 3})
+    p.run_sim()
+    s = io_pyro.read(str(tmp_path) + "/bench/smooth_0003")
+    assert s.n == 3 and compare.compare(p.sim.cc_data, s.cc_data, rtol=0.0, atol=0.0) == 0
+    q = PyroBenchmark("advection", comp_bench=True, bench_dir=str(tmp_path) + "/bench/")
+    q.initialize_problem("smooth", inputs_dict={"driver.max_steps": 3})
+    assert q.run_sim() == 0
