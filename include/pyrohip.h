@@ -126,6 +126,13 @@ typedef struct {
     /* kernel set: 0 = staged kernels with global intermediates (debuggable,
        supports pyrohip_comp_stage_dump); 1 = fused LDS-tiled kernels       */
     int kernel_set;
+    /* compressible.riemann: 0 = HLLC (riemann.py:681-860), 1 = CGF (:8-310).
+       solid_xl / solid_yl: the lower x / y mesh boundary is a solid wall
+       (boundary.bc_is_solid), used by CGF only */
+    int riemann, solid_xl, solid_yl;
+    /* sponge (compressible/simulation.py:164-184,427-441) */
+    int do_sponge;
+    double sponge_rho_begin, sponge_rho_full, sponge_timescale;
 } pyrohip_comp_params;
 
 /* method_compute_timestep (compressible/simulation.py:267-288 +

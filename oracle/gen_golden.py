@@ -275,6 +275,47 @@ def gen_compressible_stages():
     save("comp_stages", **out)
 
 
+def gen_compressible_f2():
+    """rows f2: CGF Riemann solver and sponge; same dump format as comp_stages"""
+    sp = {"sponge.do_sponge": 1, "sponge.sponge_rho_begin": 1.05,
+          "sponge.sponge_rho_full": 0.3, "sponge.sponge_timescale": 0.02}
+    cases = [
+        ("sedov", None, {"mesh.nx": 20, "mesh.ny": 24, "sedov.r_init": 0.15,
+                         "compressible.riemann": "CGF"}, 8),
+        ("sod", "inputs.sod.x", {"mesh.nx": 32, "mesh.ny": 8, "compressible.riemann": "CGF",
+                                 "mesh.xlboundary": "reflect", "mesh.xrboundary": "reflect"}, 12),
+        ("sod", "inputs.sod.y", {"mesh.nx": 8, "mesh.ny": 32, "compressible.riemann": "CGF",
+                                 "compressible.limiter": 2}, 9),
+        ("kh", None, {"mesh.nx": 16, "mesh.ny": 24, "compressible.riemann": "CGF"}, 7),
+        ("sedov", None, dict({"mesh.nx": 20, "mesh.ny": 20, "sedov.r_init": 0.15}, **sp), 8),
+        ("quad", None, dict({"mesh.nx": 16, "mesh.ny": 24, "compressible.riemann": "CGF"}, **sp), 10),
+    ]
+    out = {"ncases": np.array(len(cases))}
+    for k, (prob, inp, d, nsteps) in enumerate(cases):
+        p = Pyro("compressible")
+        p.initialize_problem(prob, inputs_file=inp, inputs_dict=d)
+        sim = p.sim
+        for _ in range(nsteps):
+            p.single_step()
+        sim.cc_data.fill_BC_all()
+        sim.compute_timestep()
+        pre = f"c{k}_"
+        out[pre + "meta"] = comp_meta(sim)
+        out[pre + "bc"] = bc_names(sim.rp)
+        out[pre + "riemann"] = np.array(sim.rp.get_param("compressible.riemann"))
+        out[pre + "sponge"] = np.array([sim.rp.get_param("sponge.do_sponge"),
+                                        sim.rp.get_param("sponge.sponge_rho_begin"),
+                                        sim.rp.get_param("sponge.sponge_rho_full"),
+                                        sim.rp.get_param("sponge.sponge_timescale")])
+        out[pre + "dt"] = np.array(sim.dt)
+        st = comp_stage_dump(sim)
+        for nm in ("U0", "FxT", "FyT", "Fx0", "Fy0", "Fx", "Fy", "U1"):
+            out[pre + nm] = st[nm]
+        print("f2 case", k, prob, d.get("compressible.riemann", "HLLC"),
+              "sponge" if d.get("sponge.do_sponge") else "", "dt", sim.dt)
+    save("comp_stages_f2", **out)
+
+
 def _raw_cfl_dt(sim):
     dt_keep, dto_keep = sim.dt, sim.dt_old
     sim.method_compute_timestep()
@@ -538,6 +579,8 @@ def gen_mg_vc():
 if __name__ == "__main__":
     if "mg_vc" in sys.argv[1:]:
         gen_mg_vc()
+    if "comp_f2" in sys.argv[1:]:
+        gen_compressible_f2()
     which = sys.argv[1:] or ["bc", "adv", "comp_stages", "comp_runs", "mg", "diffusion"]
     if "diffusion" in which:
         gen_diffusion()

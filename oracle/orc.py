@@ -33,7 +33,11 @@ class CompParams(C.Structure):
                 ("cvisc", C.c_double), ("grav", C.c_double),
                 ("small_dens", C.c_double), ("bc", (C.c_int * 4) * 4),
                 ("avisc_xhi_interior", C.c_int),
-                ("avisc_yhi_interior", C.c_int)]
+                ("avisc_yhi_interior", C.c_int),
+                ("riemann", C.c_int), ("solid_xl", C.c_int), ("solid_xr", C.c_int),
+                ("solid_yl", C.c_int), ("solid_yr", C.c_int), ("do_sponge", C.c_int),
+                ("sponge_rho_begin", C.c_double), ("sponge_rho_full", C.c_double),
+                ("sponge_timescale", C.c_double)]
 
 
 _STAGE_NAMES = ["q", "xi", "ldx", "ldy", "Uxl0", "Uxr0", "Uyl0", "Uyr0",
@@ -123,7 +127,8 @@ def adv_step(a, nx, ny, ng, dx, dy, u, v, dt, limiter, stages=False):
 def comp_params(nx, ny, ng, dx, dy, gamma=1.4, limiter=2, use_flattening=1,
                 z0=0.75, z1=0.85, delta=0.33, cvisc=0.1, grav=0.0,
                 small_dens=-1.e200, bcs=("outflow",) * 4,
-                avisc_xhi_interior=0, avisc_yhi_interior=0):
+                avisc_xhi_interior=0, avisc_yhi_interior=0, riemann="HLLC",
+                sponge=None):
     P = CompParams()
     P.nx, P.ny, P.ng = nx, ny, ng
     P.dx, P.dy, P.gamma = dx, dy, gamma
@@ -136,6 +141,12 @@ def comp_params(nx, ny, ng, dx, dy, gamma=1.4, limiter=2, use_flattening=1,
             P.bc[n][s] = int(vb[n][s])
     P.avisc_xhi_interior = avisc_xhi_interior
     P.avisc_yhi_interior = avisc_yhi_interior
+    P.riemann = {"HLLC": 0, "CGF": 1}[riemann]
+    solid = [int(b in ("reflect", "reflect-even", "reflect-odd", "dirichlet")) for b in bcs]
+    P.solid_xl, P.solid_xr, P.solid_yl, P.solid_yr = solid
+    if sponge is not None:
+        P.do_sponge = 1
+        P.sponge_rho_begin, P.sponge_rho_full, P.sponge_timescale = sponge
     return P
 
 

@@ -63,6 +63,13 @@ typedef struct {
        instead of being left at the reference's 0 (interface.py:366-367),
        because that face is an interior interface of the global grid. */
     int avisc_xhi_interior, avisc_yhi_interior;
+    /* 0 = HLLC, 1 = CGF (compressible.riemann); solid_*: bc_is_solid of the
+       mesh boundaries, used by CGF only (riemann.py:274-286) */
+    int riemann;
+    int solid_xl, solid_xr, solid_yl, solid_yr;
+    /* sponge (compressible/simulation.py:164-184, 427-441) */
+    int do_sponge;
+    double sponge_rho_begin, sponge_rho_full, sponge_timescale;
 } orc_comp_params;
 
 /* optional stage outputs; any pointer may be NULL */
@@ -634,6 +641,118 @@ void orc_riemann_hllc(int idir, int nx, int ny, int ng, double gamma,
         }
 }
 
+
+/* ------------------------------------------------------------------ */
+/* riemann_cgf, pyro/compressible/riemann.py:8-310 + consFlux          */
+/* (riemann_flux :1083-1090).  Solid-wall quirk: the njit-local ihi is */
+/* ng+nx, so "i == ihi + 1" never fires.          */
+/* ------------------------------------------------------------------ */
+void orc_riemann_cgf(int idir, int nx, int ny, int ng, double gamma, int lower_solid,
+                     int upper_solid, const double *U_l, const double *U_r, double *F)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx, jlo = ng, jhi = ng + ny; /* njit-local */
+    const double smallc = 1.e-10, smallrho = 1.e-10, smallp = 1.e-10;
+    (void)upper_solid;
+    memset(F, 0, sizeof(double) * qx * qy * 4);
+    for (int i = ilo - 1; i < ihi + 1; i++)
+        for (int j = jlo - 1; j < jhi + 1; j++) {
+            const double *Ul = U_l + ((size_t)i * qy + j) * 4;
+            const double *Ur = U_r + ((size_t)i * qy + j) * 4;
+            double rho_l = Ul[IDENS], un_l, ut_l;
+            if (idir == 1) { un_l = Ul[IXMOM] / rho_l; ut_l = Ul[IYMOM] / rho_l; }
+            else           { un_l = Ul[IYMOM] / rho_l; ut_l = Ul[IXMOM] / rho_l; }
+            double rhoe_l = Ul[IENER] - 0.5 * rho_l * (un_l * un_l + ut_l * ut_l);
+            double p_l = dmax(rhoe_l * (gamma - 1.0), smallp);
+            double rho_r = Ur[IDENS], un_r, ut_r;
+            if (idir == 1) { un_r = Ur[IXMOM] / rho_r; ut_r = Ur[IYMOM] / rho_r; }
+            else           { un_r = Ur[IYMOM] / rho_r; ut_r = Ur[IXMOM] / rho_r; }
+            double rhoe_r = Ur[IENER] - 0.5 * rho_r * (un_r * un_r + ut_r * ut_r);
+            double p_r = dmax(rhoe_r * (gamma - 1.0), smallp);
+            double W_l = dmax(smallrho * smallc, sqrt(gamma * p_l * rho_l));
+            double W_r = dmax(smallrho * smallc, sqrt(gamma * p_r * rho_r));
+            double c_l = dmax(smallc, sqrt(gamma * p_l / rho_l));
+            double c_r = dmax(smallc, sqrt(gamma * p_r / rho_r));
+            double pstar = (W_l * p_r + W_r * p_l + W_l * W_r * (un_l - un_r)) / (W_l + W_r);
+            pstar = dmax(pstar, smallp);
+            double ustar = (W_l * un_l + W_r * un_r + (p_l - p_r)) / (W_l + W_r);
+            double rhostar_l = rho_l + (pstar - p_l) / (c_l * c_l);
+            double rhostar_r = rho_r + (pstar - p_r) / (c_r * c_r);
+            double rhoestar_l = rhoe_l + (pstar - p_l) * (rhoe_l / rho_l + p_l / rho_l) / (c_l * c_l);
+            double rhoestar_r = rhoe_r + (pstar - p_r) * (rhoe_r / rho_r + p_r / rho_r) / (c_r * c_r);
+            double cstar_l = dmax(smallc, sqrt(gamma * pstar / rhostar_l));
+            double cstar_r = dmax(smallc, sqrt(gamma * pstar / rhostar_r));
+            double rho_s, un_s, ut_s, p_s, rhoe_s;
+            if (ustar > 0.0) {
+                ut_s = ut_l;
+                double lambda_l = un_l - c_l, lambdastar_l = ustar - cstar_l;
+                if (pstar > p_l) {
+                    double sigma = (lambda_l + lambdastar_l) / 2.0;
+                    if (sigma > 0.0) { rho_s = rho_l; un_s = un_l; p_s = p_l; rhoe_s = rhoe_l; }
+                    else { rho_s = rhostar_l; un_s = ustar; p_s = pstar; rhoe_s = rhoestar_l; }
+                } else {
+                    if (lambda_l < 0.0 && lambdastar_l < 0.0) {
+                        rho_s = rhostar_l; un_s = ustar; p_s = pstar; rhoe_s = rhoestar_l;
+                    } else if (lambda_l > 0.0 && lambdastar_l > 0.0) {
+                        rho_s = rho_l; un_s = un_l; p_s = p_l; rhoe_s = rhoe_l;
+                    } else {
+                        double alpha = lambda_l / (lambda_l - lambdastar_l);
+                        rho_s = alpha * rhostar_l + (1.0 - alpha) * rho_l;
+                        un_s = alpha * ustar + (1.0 - alpha) * un_l;
+                        p_s = alpha * pstar + (1.0 - alpha) * p_l;
+                        rhoe_s = alpha * rhoestar_l + (1.0 - alpha) * rhoe_l;
+                    }
+                }
+            } else if (ustar < 0) {
+                ut_s = ut_r;
+                double lambda_r = un_r + c_r, lambdastar_r = ustar + cstar_r;
+                if (pstar > p_r) {
+                    double sigma = (lambda_r + lambdastar_r) / 2.0;
+                    if (sigma > 0.0) { rho_s = rhostar_r; un_s = ustar; p_s = pstar; rhoe_s = rhoestar_r; }
+                    else { rho_s = rho_r; un_s = un_r; p_s = p_r; rhoe_s = rhoe_r; }
+                } else {
+                    if (lambda_r < 0.0 && lambdastar_r < 0.0) {
+                        rho_s = rho_r; un_s = un_r; p_s = p_r; rhoe_s = rhoe_r;
+                    } else if (lambda_r > 0.0 && lambdastar_r > 0.0) {
+                        rho_s = rhostar_r; un_s = ustar; p_s = pstar; rhoe_s = rhoestar_r;
+                    } else {
+                        double alpha = lambda_r / (lambda_r - lambdastar_r);
+                        rho_s = alpha * rhostar_r + (1.0 - alpha) * rho_r;
+                        un_s = alpha * ustar + (1.0 - alpha) * un_r;
+                        p_s = alpha * pstar + (1.0 - alpha) * p_r;
+                        rhoe_s = alpha * rhoestar_r + (1.0 - alpha) * rhoe_r;
+                    }
+                }
+            } else {
+                rho_s = 0.5 * (rhostar_l + rhostar_r);
+                un_s = ustar;
+                ut_s = 0.5 * (ut_l + ut_r);
+                p_s = pstar;
+                rhoe_s = 0.5 * (rhoestar_l + rhoestar_r);
+            }
+            (void)p_s;
+            if (idir == 1) { if (i == ilo && lower_solid == 1) un_s = 0.0; }
+            else           { if (j == jlo && lower_solid == 1) un_s = 0.0; }
+            double Uo[4];
+            Uo[IDENS] = rho_s;
+            if (idir == 1) { Uo[IXMOM] = rho_s * un_s; Uo[IYMOM] = rho_s * ut_s; }
+            else           { Uo[IXMOM] = rho_s * ut_s; Uo[IYMOM] = rho_s * un_s; }
+            Uo[IENER] = rhoe_s + 0.5 * rho_s * (un_s * un_s + ut_s * ut_s);
+            cons_flux(idir, gamma, Uo, F + ((size_t)i * qy + j) * 4);
+        }
+}
+
+static void riemann_dispatch(const orc_comp_params *P, int idir, const double *U_l,
+                             const double *U_r, double *F)
+{
+    if (P->riemann == 1)
+        orc_riemann_cgf(idir, P->nx, P->ny, P->ng, P->gamma,
+                        idir == 1 ? P->solid_xl : P->solid_yl,
+                        idir == 1 ? P->solid_xr : P->solid_yr, U_l, U_r, F);
+    else
+        orc_riemann_hllc(idir, P->nx, P->ny, P->ng, P->gamma, U_l, U_r, F);
+}
+
 /* ------------------------------------------------------------------ */
 /* a11: artificial viscosity, compressible/interface.py:239-378        */
 /* u, v: components IU, IV of q (qx,qy,4)                              */
@@ -803,8 +922,8 @@ int orc_comp_step(double *U, const orc_comp_params *P, double dt,
     if (st && st->Uyr0) memcpy(st->Uyr0, Uyr, N * 32);
 
     /* apply_transverse_flux, unsplit_fluxes.py:333-494 */
-    orc_riemann_hllc(1, nx, ny, ng, gamma, Uxl, Uxr, Fx);
-    orc_riemann_hllc(2, nx, ny, ng, gamma, Uyl, Uyr, Fy);
+    riemann_dispatch(P, 1, Uxl, Uxr, Fx);
+    riemann_dispatch(P, 2, Uyl, Uyr, Fy);
     if (st && st->FxT) memcpy(st->FxT, Fx, N * 32);
     if (st && st->FyT) memcpy(st->FyT, Fy, N * 32);
     {
@@ -831,8 +950,8 @@ int orc_comp_step(double *U, const orc_comp_params *P, double dt,
     if (st && st->Uyr) memcpy(st->Uyr, Uyr, N * 32);
 
     /* final Riemann solves, simulation.py:349-357 */
-    orc_riemann_hllc(1, nx, ny, ng, gamma, Uxl, Uxr, Fx);
-    orc_riemann_hllc(2, nx, ny, ng, gamma, Uyl, Uyr, Fy);
+    riemann_dispatch(P, 1, Uxl, Uxr, Fx);
+    riemann_dispatch(P, 2, Uyl, Uyr, Fy);
     if (st && st->Fx0) memcpy(st->Fx0, Fx, N * 32);
     if (st && st->Fy0) memcpy(st->Fy0, Fy, N * 32);
 
@@ -884,6 +1003,25 @@ int orc_comp_step(double *U, const orc_comp_params *P, double dt,
                     U4(U, i, j, n) +=
                         0.5 * dt * (U4(S_new, i, j, n) - U4(S_old, i, j, n));
         free(S_old); free(S_new); free(U_old);
+    }
+    /* sponge, simulation.py:164-184, 427-441: the WHOLE array incl. ghosts */
+    if (P->do_sponge) {
+        const double PI = 3.14159265358979323846;
+        for (size_t k = 0; k < N; k++) {
+            double *Uc = U + k * 4;
+            double rho = Uc[IDENS], f;
+            if (rho > P->sponge_rho_begin) f = 0.0;
+            else if (rho < P->sponge_rho_full) f = 1.0;
+            else f = 0.5 * (1.0 - cos(PI * (rho - P->sponge_rho_begin) /
+                                      (P->sponge_rho_full - P->sponge_rho_begin)));
+            double kappa = f / P->sponge_timescale;
+            double xo = Uc[IXMOM], yo = Uc[IYMOM];
+            Uc[IXMOM] = xo / (1.0 + dt * kappa);
+            Uc[IYMOM] = yo / (1.0 + dt * kappa);
+            double dke = 0.5 * ((Uc[IXMOM] * Uc[IXMOM] + Uc[IYMOM] * Uc[IYMOM]) -
+                                (xo * xo + yo * yo)) / Uc[IDENS];
+            Uc[IENER] += dke;
+        }
     }
 #undef U4
 #undef I2

@@ -38,7 +38,10 @@ class CompParams(C.Structure):
                 ("small_dens", C.c_double),
                 ("avisc_xhi_interior", C.c_int),
                 ("avisc_yhi_interior", C.c_int),
-                ("fast_math", C.c_int), ("kernel_set", C.c_int)]
+                ("fast_math", C.c_int), ("kernel_set", C.c_int),
+                ("riemann", C.c_int), ("solid_xl", C.c_int), ("solid_yl", C.c_int),
+                ("do_sponge", C.c_int), ("sponge_rho_begin", C.c_double),
+                ("sponge_rho_full", C.c_double), ("sponge_timescale", C.c_double)]
 
 
 _DP = C.POINTER(C.c_double)

@@ -5,8 +5,8 @@ evolve() = pyrohip_comp_step (interface states, HLLC Riemann problems,
 transverse correction, artificial viscosity, conservative update in HIP);
 method_compute_timestep() = pyrohip_comp_dt (device min-reduction, 8 bytes
 D2H).  Scope of the device path: Cartesian
-grid, HLLC, gamma-law gas, limiter 0/1/2, flattening, artificial viscosity,
-grav = 0, standard boundary types.
+grid, HLLC or CGF Riemann solver, gamma-law gas, limiter 0/1/2, flattening,
+artificial viscosity, gravity, sponge, standard boundary types.
 """
 import numpy as np
 
@@ -64,9 +64,9 @@ class Simulation(NullSimulation):
         my_grid = grid_setup(self.rp, ng=ng)
         my_data = self.data_class(my_grid)
         riemann_method = self.rp.get_param("compressible.riemann")
-        if riemann_method != "HLLC":
-            msg.fail("ERROR: the device path implements compressible.riemann = HLLC only "
-                     "(CGF / HLLC_lm: SURVEY.md 8 row f2)")
+        if riemann_method not in ("HLLC", "CGF"):
+            msg.fail("ERROR: the device path implements compressible.riemann = HLLC or CGF "
+                     "(HLLC_lm: SURVEY.md 8 row f2)")
         bc, bc_xodd, bc_yodd = bc_setup(self.rp)
         self.solid = bnd.bc_is_solid(bc)
         # same registration order as compressible/simulation.py:223-226
@@ -102,7 +102,12 @@ class Simulation(NullSimulation):
             delta=rp.get_param("compressible.delta"), cvisc=rp.get_param("compressible.cvisc"),
             grav=rp.get_param("compressible.grav"),
             small_dens=rp.get_param("compressible.small_dens"),
-            fast_math=opt("gpu.fast_math", 0), kernel_set=opt("gpu.kernel_set", 1))
+            fast_math=opt("gpu.fast_math", 0), kernel_set=opt("gpu.kernel_set", 1),
+            riemann=rp.get_param("compressible.riemann"),
+            solid_xl=self.solid.xl, solid_yl=self.solid.yl,
+            sponge=(rp.get_param("sponge.sponge_rho_begin"), rp.get_param("sponge.sponge_rho_full"),
+                    rp.get_param("sponge.sponge_timescale"))
+            if rp.get_param("sponge.do_sponge") else None)
 
     def method_compute_timestep(self):
         """cfl * min(dx/(|u|+c), dy/(|v|+c)) over the whole array
@@ -113,8 +118,6 @@ class Simulation(NullSimulation):
     def evolve(self):
         tm = self.tc.timer("evolve")
         tm.begin()
-        if self.rp.get_param("sponge.do_sponge"):
-            msg.fail("ERROR: sponge.do_sponge is not implemented on the device path")
         st = self.cc_data.device_state()
         st.comp_step(self._params(), float(self.dt))
         self.cc_data.device_modified()

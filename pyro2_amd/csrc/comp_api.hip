@@ -9,6 +9,7 @@ int comp_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_step_staged(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_fused(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_stage_dump(pyrohip_state *, int, double *);
+int comp_sponge(pyrohip_state *, const pyrohip_comp_params *, double);
 }
 namespace fastm {
 int comp_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
@@ -44,9 +45,18 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     PYRO_TRY(check_comp(s, p));
     PYRO_REQUIRE(dt > 0.0, "dt must be positive");
     PYRO_REQUIRE(p->kernel_set == 0 || p->kernel_set == 1, "kernel_set must be 0 or 1");
+    PYRO_REQUIRE(p->riemann == 0 || p->riemann == 1, "riemann must be 0 (HLLC) or 1 (CGF)");
+    int rc;
     if (p->kernel_set == 1)
-        return p->fast_math ? fastm::comp_step_fused(s, p, dt) : exact::comp_step_fused(s, p, dt);
-    return p->fast_math ? fastm::comp_step_staged(s, p, dt) : exact::comp_step_staged(s, p, dt);
+        rc = p->fast_math ? fastm::comp_step_fused(s, p, dt) : exact::comp_step_fused(s, p, dt);
+    else
+        rc = p->fast_math ? fastm::comp_step_staged(s, p, dt) : exact::comp_step_staged(s, p, dt);
+    if (rc == 0 && p->do_sponge) {
+        PYRO_REQUIRE(p->sponge_rho_begin > p->sponge_rho_full,
+                     "sponge_rho_begin must exceed sponge_rho_full (simulation.py:172)");
+        rc = exact::comp_sponge(s, p, dt);
+    }
+    return rc;
 }
 
 int pyrohip_comp_stage_dump(pyrohip_state *s, int stage_id, double *out)

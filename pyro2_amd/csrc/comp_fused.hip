@@ -65,6 +65,7 @@ struct FP {   // kernel parameters
     double dtdV;          // dt/(dx*dy)            simulation.py:375
     double grav;          // compressible.grav (0: no source terms)
     int refl_ylo, refl_yhi;   // y-momentum reflects oddly at the lower / upper y wall
+    int solid_xl, solid_yl;   // CGF wall rule (riemann.py:274-286)
 };
 
 __device__ __forceinline__ ConsN to_nf(const Cons &U, bool x)
@@ -102,6 +103,7 @@ __device__ __forceinline__ Cons corr(const Cons &U, const Cons &Fhi, const Cons 
 #define PYRO_FUSED_MINW 4
 #endif
 
+template <int SOLVER>   // compressible.riemann: 0 HLLC, 1 CGF
 __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double *__restrict__ Uin,
                                                    double *__restrict__ Uout, Geom g, FP P,
                                                    int *__restrict__ flag,
@@ -209,11 +211,12 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
     // ---- phase 2: transverse Riemann problems on the lower faces --------
     Cons FxT{0, 0, 0, 0}, FyT{0, 0, 0, 0};
     if (ti >= 1)
-        FxT = from_nf(hllc_flux(to_nf(lds_get(S, t - FBJ), true), to_nf(XM, true), gamma, true),
-                      true);
+        FxT = from_nf(riemann_face<SOLVER>(to_nf(lds_get(S, t - FBJ), true), to_nf(XM, true), gamma,
+                                           true, P.solid_xl && i == g.ilo), true);
     if (tj >= 1)
-        FyT = from_nf(hllc_flux(to_nf(lds_get(S + 4 * FNT, t - 1), false), to_nf(YM, false), gamma,
-                                false), false);
+        FyT = from_nf(riemann_face<SOLVER>(to_nf(lds_get(S + 4 * FNT, t - 1), false),
+                                           to_nf(YM, false), gamma, false,
+                                           P.solid_yl && j == g.jlo), false);
     lds_put(B0, t, FxT);
     lds_put(B0 + 4 * FNT, t, FyT);
     __syncthreads();
@@ -246,8 +249,8 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
     Cons Fx{0, 0, 0, 0}, Fy{0, 0, 0, 0};
     const double d00 = D[t];
     if (ti >= 1 && tj >= 1 && tj <= FBJ - 2) {           // x face (i, j)
-        Fx = from_nf(hllc_flux(to_nf(lds_get(S, t - FBJ), true), to_nf(XM, true), gamma, true),
-                     true);
+        Fx = from_nf(riemann_face<SOLVER>(to_nf(lds_get(S, t - FBJ), true), to_nf(XM, true), gamma,
+                                          true, P.solid_xl && i == g.ilo), true);
         double avx = 0.0;
         // interface.py:366-376: only faces i in [ilo, ihi], j in [jlo, jhi]
         if (i >= g.ilo && (i <= g.ihi || (P.avx_hi && i == g.ihi + 1)) && j >= g.jlo &&
@@ -264,8 +267,9 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
         Fx.my += avx * (Um.my - Uc.my);
     }
     if (tj >= 1 && ti >= 1 && ti <= FBI - 2) {           // y face (i, j)
-        Fy = from_nf(hllc_flux(to_nf(lds_get(S + 4 * FNT, t - 1), false), to_nf(YM, false), gamma,
-                               false), false);
+        Fy = from_nf(riemann_face<SOLVER>(to_nf(lds_get(S + 4 * FNT, t - 1), false),
+                                          to_nf(YM, false), gamma, false,
+                                          P.solid_yl && j == g.jlo), false);
         double avy = 0.0;
         if (j >= g.jlo && (j <= g.jhi || (P.avy_hi && j == g.jhi + 1)) && i >= g.ilo &&
             i <= g.ihi) {
@@ -355,6 +359,7 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     P.grav = p->grav;
     P.refl_ylo = (s->bc[3 * 4 + 2] == PYROHIP_BC_REFLECT_ODD);
     P.refl_yhi = (s->bc[3 * 4 + 3] == PYROHIP_BC_REFLECT_ODD);
+    P.solid_xl = p->solid_xl; P.solid_yl = p->solid_yl;
     const int nti = (g.nx + FTI - 1) / FTI;
     P.ntj = (g.ny + FTJ - 1) / FTJ;
     P.ntiles = nti * P.ntj;
@@ -364,14 +369,21 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
 #ifndef PYRO_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_ctu_fused,
+        PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_ctu_fused<0>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)FLDS_BYTES));
+        PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_ctu_fused<1>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)FLDS_BYTES));
         attr_set = true;
     }
 #endif
-    PYRO_LAUNCH(c, "k_ctu_fused", k_ctu_fused, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
-                (const double *)Uin, Uout, g, P, s->d_flag, part);
+    if (p->riemann == 1)
+        PYRO_LAUNCH(c, "k_ctu_fused", k_ctu_fused<1>, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
+                    (const double *)Uin, Uout, g, P, s->d_flag, part);
+    else
+        PYRO_LAUNCH(c, "k_ctu_fused", k_ctu_fused<0>, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
+                    (const double *)Uin, Uout, g, P, s->d_flag, part);
     {
         const int rows_per_block = 256 / (2 * g.ng);
         const int nby = 2 * g.ng + (g.nx + rows_per_block - 1) / rows_per_block;

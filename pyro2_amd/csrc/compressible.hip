@@ -54,7 +54,15 @@ struct CP {   // kernel-side parameters
     int avx_hi, avy_hi;   // compute avisc on the upper boundary face
     double grav;          // compressible.grav (0: no source terms)
     int refl_ylo, refl_yhi;   // y-momentum reflects oddly at the lower / upper y wall
+    int riemann, solid_xl, solid_yl;   // 0 HLLC / 1 CGF; CGF wall rule
 };
+
+__device__ __forceinline__ ConsN riemann_rt(const ConsN &Ul, const ConsN &Ur, const CP &P, bool x,
+                                            bool wall)
+{
+    return P.riemann == 1 ? riemann_face<1>(Ul, Ur, P.gamma, x, wall)
+                          : riemann_face<0>(Ul, Ur, P.gamma, x, wall);
+}
 
 __device__ __forceinline__ Cons load_cons(const double *__restrict__ a, size_t plane, size_t k)
 {
@@ -206,13 +214,13 @@ __global__ __launch_bounds__(256) void k_riemann_t(const double *__restrict__ W_
     if (i >= g.ilo) {
         Cons Ul = load_cons(W_ + (size_t)W_XP * pl, pl, k - p);
         Cons Ur = load_cons(W_ + (size_t)W_XM * pl, pl, k);
-        ConsN F = hllc_flux(to_n(Ul, true), to_n(Ur, true), P.gamma, true);
+        ConsN F = riemann_rt(to_n(Ul, true), to_n(Ur, true), P, true, P.solid_xl && i == g.ilo);
         store_cons(Wout + (size_t)W_FXT * pl, pl, k, from_n(F, true));
     }
     if (j >= g.jlo) {
         Cons Ul = load_cons(W_ + (size_t)W_YP * pl, pl, k - 1);
         Cons Ur = load_cons(W_ + (size_t)W_YM * pl, pl, k);
-        ConsN F = hllc_flux(to_n(Ul, false), to_n(Ur, false), P.gamma, false);
+        ConsN F = riemann_rt(to_n(Ul, false), to_n(Ur, false), P, false, P.solid_yl && j == g.jlo);
         store_cons(Wout + (size_t)W_FYT * pl, pl, k, from_n(F, false));
     }
 }
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(256) void k_final(const double *__restrict__ U,
                              load_cons(FYT, pl, k - p + 1), load_cons(FYT, pl, k - p), hdtV, Ay);
         Cons Uxr = corrected(load_cons(W_ + (size_t)W_XM * pl, pl, k), load_cons(FYT, pl, k + 1),
                              load_cons(FYT, pl, k), hdtV, Ay);
-        Cons F = from_n(hllc_flux(to_n(Uxl, true), to_n(Uxr, true), P.gamma, true), true);
+        Cons F = from_n(riemann_rt(to_n(Uxl, true), to_n(Uxr, true), P, true, P.solid_xl && i == g.ilo), true);
         double avx = 0.0;
         if (i <= g.ihi || P.avx_hi) {
             size_t kk = k + 1;
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(256) void k_final(const double *__restrict__ U,
                              load_cons(FXT, pl, k + p - 1), load_cons(FXT, pl, k - 1), hdtV, Ax);
         Cons Uyr = corrected(load_cons(W_ + (size_t)W_YM * pl, pl, k), load_cons(FXT, pl, k + p),
                              load_cons(FXT, pl, k), hdtV, Ax);
-        Cons F = from_n(hllc_flux(to_n(Uyl, false), to_n(Uyr, false), P.gamma, false), false);
+        Cons F = from_n(riemann_rt(to_n(Uyl, false), to_n(Uyr, false), P, false, P.solid_yl && j == g.jlo), false);
         double avy = 0.0;
         if (j <= g.jhi || P.avy_hi) {
             size_t kk = k + p;
@@ -338,6 +346,30 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ U,
     if (threadIdx.x == 0) partial[by * gx + bx] = cfl;
 }
 
+// ---- sponge over the whole array (simulation.py:427-441) -----------------
+__global__ __launch_bounds__(256) void k_sponge(double *__restrict__ U, Geom g, double dt,
+                                                double rho_begin, double rho_full, double tau)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= g.qy) return;
+    const size_t k = (size_t)i * g.pitch + j;
+    Cons Uc = load_cons(U, g.plane, k);
+    sponge_cell(Uc, dt, rho_begin, rho_full, tau);
+    store_cons(U, g.plane, k, Uc);
+}
+
+int comp_sponge(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+{
+    const Geom &g = s->g;
+    hipLaunchKernelGGL(k_sponge, dim3((g.qy + 255) / 256, g.qx), dim3(256), 0, s->ctx->stream,
+                       s->d, g, dt, p->sponge_rho_begin, p->sponge_rho_full,
+                       p->sponge_timescale);
+    PYRO_CHECK_HIP(hipGetLastError());
+    s->next_cfl_min = -1.0;   // the cached minimum is from before the sponge
+    return 0;
+}
+
 // ---- CFL over the whole array (ghost cells included), derives.py ---------
 __global__ __launch_bounds__(256) void k_cfl(const double *__restrict__ U, Geom g, double gamma,
                                              double dx, double dy, double *__restrict__ partial)
@@ -361,6 +393,7 @@ static CP make_cp(const pyrohip_comp_params *p, double dt, const pyrohip_state *
     c.grav = p->grav;
     c.refl_ylo = (s->bc[3 * 4 + 2] == PYROHIP_BC_REFLECT_ODD);
     c.refl_yhi = (s->bc[3 * 4 + 3] == PYROHIP_BC_REFLECT_ODD);
+    c.riemann = p->riemann; c.solid_xl = p->solid_xl; c.solid_yl = p->solid_yl;
     return c;
 }
 

@@ -312,6 +312,120 @@ __device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, dou
     return F;
 }
 
+
+// Two-shock Colella-Glaz-Ferguson solver on one face, riemann.py:8-310,
+// followed by consFlux of the resulting interface state (riemann_flux
+// :1083-1090), in the (normal, transverse) frame.  wall_zero: this is the
+// lower boundary face of a solid wall (riemann.py:274-286; the upper-wall
+// test of the reference can never fire).
+__device__ __forceinline__ ConsN cgf_flux(const ConsN &Ul, const ConsN &Ur, double gamma,
+                                          bool normal_is_x, bool wall_zero)
+{
+    const double smallc = 1.e-10, smallrho = 1.e-10, smallp = 1.e-10;
+    const double rho_l = Ul.d;
+    const double ril = PYRO_FAST ? prcp(rho_l) : 0.0;
+    const double un_l = pdivr(Ul.mn, rho_l, ril), ut_l = pdivr(Ul.mt, rho_l, ril);
+    const double rhoe_l = Ul.E - 0.5 * rho_l * (un_l * un_l + ut_l * ut_l);
+    const double p_l = fmax(rhoe_l * (gamma - 1.0), smallp);
+    const double rho_r = Ur.d;
+    const double rir = PYRO_FAST ? prcp(rho_r) : 0.0;
+    const double un_r = pdivr(Ur.mn, rho_r, rir), ut_r = pdivr(Ur.mt, rho_r, rir);
+    const double rhoe_r = Ur.E - 0.5 * rho_r * (un_r * un_r + ut_r * ut_r);
+    const double p_r = fmax(rhoe_r * (gamma - 1.0), smallp);
+    const double W_l = fmax(smallrho * smallc, psqrt(gamma * p_l * rho_l));
+    const double W_r = fmax(smallrho * smallc, psqrt(gamma * p_r * rho_r));
+    const double c_l = fmax(smallc, psqrt(pdivr(gamma * p_l, rho_l, ril)));
+    const double c_r = fmax(smallc, psqrt(pdivr(gamma * p_r, rho_r, rir)));
+    const double rW = PYRO_FAST ? prcp(W_l + W_r) : 0.0;
+    double pstar = pdivr(W_l * p_r + W_r * p_l + W_l * W_r * (un_l - un_r), W_l + W_r, rW);
+    pstar = fmax(pstar, smallp);
+    const double ustar = pdivr(W_l * un_l + W_r * un_r + (p_l - p_r), W_l + W_r, rW);
+    const double rhostar_l = rho_l + pdiv(pstar - p_l, c_l * c_l);
+    const double rhostar_r = rho_r + pdiv(pstar - p_r, c_r * c_r);
+    const double rhoestar_l =
+        rhoe_l + pdiv((pstar - p_l) * (pdivr(rhoe_l, rho_l, ril) + pdivr(p_l, rho_l, ril)), c_l * c_l);
+    const double rhoestar_r =
+        rhoe_r + pdiv((pstar - p_r) * (pdivr(rhoe_r, rho_r, rir) + pdivr(p_r, rho_r, rir)), c_r * c_r);
+    double rho_s, un_s, ut_s, rhoe_s;
+    if (ustar > 0.0) {
+        ut_s = ut_l;
+        const double cstar_l = fmax(smallc, psqrt(pdiv(gamma * pstar, rhostar_l)));
+        const double lambda_l = un_l - c_l, lambdastar_l = ustar - cstar_l;
+        if (pstar > p_l) {
+            const double sigma = (lambda_l + lambdastar_l) / 2.0;
+            if (sigma > 0.0) { rho_s = rho_l; un_s = un_l; rhoe_s = rhoe_l; }
+            else { rho_s = rhostar_l; un_s = ustar; rhoe_s = rhoestar_l; }
+        } else if (lambda_l < 0.0 && lambdastar_l < 0.0) {
+            rho_s = rhostar_l; un_s = ustar; rhoe_s = rhoestar_l;
+        } else if (lambda_l > 0.0 && lambdastar_l > 0.0) {
+            rho_s = rho_l; un_s = un_l; rhoe_s = rhoe_l;
+        } else {
+            const double alpha = pdiv(lambda_l, lambda_l - lambdastar_l);
+            rho_s = alpha * rhostar_l + (1.0 - alpha) * rho_l;
+            un_s = alpha * ustar + (1.0 - alpha) * un_l;
+            rhoe_s = alpha * rhoestar_l + (1.0 - alpha) * rhoe_l;
+        }
+    } else if (ustar < 0) {
+        ut_s = ut_r;
+        const double cstar_r = fmax(smallc, psqrt(pdiv(gamma * pstar, rhostar_r)));
+        const double lambda_r = un_r + c_r, lambdastar_r = ustar + cstar_r;
+        if (pstar > p_r) {
+            const double sigma = (lambda_r + lambdastar_r) / 2.0;
+            if (sigma > 0.0) { rho_s = rhostar_r; un_s = ustar; rhoe_s = rhoestar_r; }
+            else { rho_s = rho_r; un_s = un_r; rhoe_s = rhoe_r; }
+        } else if (lambda_r < 0.0 && lambdastar_r < 0.0) {
+            rho_s = rho_r; un_s = un_r; rhoe_s = rhoe_r;
+        } else if (lambda_r > 0.0 && lambdastar_r > 0.0) {
+            rho_s = rhostar_r; un_s = ustar; rhoe_s = rhoestar_r;
+        } else {
+            const double alpha = pdiv(lambda_r, lambda_r - lambdastar_r);
+            rho_s = alpha * rhostar_r + (1.0 - alpha) * rho_r;
+            un_s = alpha * ustar + (1.0 - alpha) * un_r;
+            rhoe_s = alpha * rhoestar_r + (1.0 - alpha) * rhoe_r;
+        }
+    } else {   // ustar == 0
+        rho_s = 0.5 * (rhostar_l + rhostar_r);
+        un_s = ustar;
+        ut_s = 0.5 * (ut_l + ut_r);
+        rhoe_s = 0.5 * (rhoestar_l + rhoestar_r);
+    }
+    if (wall_zero) un_s = 0.0;
+    ConsN Uo;
+    Uo.d = rho_s;
+    Uo.mn = rho_s * un_s;
+    Uo.mt = rho_s * ut_s;
+    Uo.E = rhoe_s + 0.5 * rho_s * (un_s * un_s + ut_s * ut_s);
+    return cons_flux_n(Uo, gamma, normal_is_x);
+}
+
+// compressible.riemann dispatch: SOLVER 0 = HLLC, 1 = CGF
+template <int SOLVER>
+__device__ __forceinline__ ConsN riemann_face(const ConsN &Ul, const ConsN &Ur, double gamma,
+                                              bool normal_is_x, bool wall_zero)
+{
+    if (SOLVER == 1) return cgf_flux(Ul, Ur, gamma, normal_is_x, wall_zero);
+    return hllc_flux(Ul, Ur, gamma, normal_is_x);
+}
+
+// Sponge, compressible/simulation.py:164-184 and :427-441 (acts on every
+// cell of the array, ghost cells included)
+__device__ __forceinline__ void sponge_cell(Cons &U, double dt, double rho_begin, double rho_full,
+                                            double tau)
+{
+    const double PI = 3.14159265358979323846;
+    const double rho = U.d;
+    double f;
+    if (rho > rho_begin) f = 0.0;
+    else if (rho < rho_full) f = 1.0;
+    else f = 0.5 * (1.0 - cos(PI * (rho - rho_begin) / (rho_full - rho_begin)));
+    const double kappa = f / tau;
+    const double xo = U.mx, yo = U.my;
+    U.mx = xo / (1.0 + dt * kappa);
+    U.my = yo / (1.0 + dt * kappa);
+    const double dke = 0.5 * ((U.mx * U.mx + U.my * U.my) - (xo * xo + yo * yo)) / U.d;
+    U.E += dke;
+}
+
 // Gravity (Cartesian, acting in y): S[ymom] = rho g, S[E] = ymom g
 // (compressible/simulation.py:131-134).
 //

@@ -228,7 +228,8 @@ class DeviceState:
 def make_comp_params(dx, dy, gamma=1.4, limiter=2, use_flattening=1, z0=0.75,
                      z1=0.85, delta=0.33, cvisc=0.1, grav=0.0,
                      small_dens=-1.e200, avisc_xhi_interior=0,
-                     avisc_yhi_interior=0, fast_math=0, kernel_set=0):
+                     avisc_yhi_interior=0, fast_math=0, kernel_set=0, riemann="HLLC",
+                     solid_xl=0, solid_yl=0, sponge=None):
     p = CompParams()
     p.dx, p.dy, p.gamma = dx, dy, gamma
     p.limiter, p.use_flattening = int(limiter), int(use_flattening)
@@ -237,6 +238,11 @@ def make_comp_params(dx, dy, gamma=1.4, limiter=2, use_flattening=1, z0=0.75,
     p.avisc_xhi_interior = int(avisc_xhi_interior)
     p.avisc_yhi_interior = int(avisc_yhi_interior)
     p.fast_math, p.kernel_set = int(fast_math), int(kernel_set)
+    p.riemann = {"HLLC": 0, "CGF": 1}[riemann] if isinstance(riemann, str) else int(riemann)
+    p.solid_xl, p.solid_yl = int(solid_xl), int(solid_yl)
+    if sponge is not None:   # (rho_begin, rho_full, timescale)
+        p.do_sponge = 1
+        p.sponge_rho_begin, p.sponge_rho_full, p.sponge_timescale = sponge
     return p
 
 

@@ -243,3 +243,35 @@ def test_comp_gravity_run(dev, kset):
     for n in range(4):
         assert max_rel_err(U[4:-4, 4:-4, n], Uo[4:-4, 4:-4, n]) <= tol, n
     assert np.abs(U[4:-4, 4:-4, 3]).max() > 1e-3   # gravity did something
+
+
+@pytest.mark.parametrize("kset", [0, 1])
+@pytest.mark.parametrize("k", range(6))
+def test_comp_cgf_and_sponge(dev, golden, k, kset):
+    """SURVEY 8 row f2 on the device: CGF Riemann solver (incl. the solid-wall
+    rule) and the sponge, one step from reference states"""
+    g = golden("comp_stages_f2")
+    bcs = [str(b) for b in g[f"c{k}_bc"]]
+    meta = g[f"c{k}_meta"]
+    sp = g[f"c{k}_sponge"]
+    solid = [int(b == "reflect") for b in bcs]
+    P, cfl = dev_params(meta, kernel_set=kset, riemann=str(g[f"c{k}_riemann"]),
+                        solid_xl=solid[0], solid_yl=solid[2],
+                        sponge=tuple(sp[1:]) if sp[0] else None)
+    nx, ny, ng = int(meta[0]), int(meta[1]), int(meta[2])
+    s = comp_state(dev, nx, ny, bcs)
+    s.upload(g[f"c{k}_U0"])
+    s.comp_step(P, float(g[f"c{k}_dt"]))
+    tol = (1e-15 if sp[0] else 0.0) if dev.kind == "emu" else TOL_EXACT
+    if kset == 0:
+        for nm, sl in (("FxT", (slice(ng, ng + nx + 1), slice(ng - 1, ng + ny + 1))),
+                       ("FyT", (slice(ng - 1, ng + nx + 1), slice(ng, ng + ny + 1))),
+                       ("Fx", (slice(ng, ng + nx + 1), slice(ng, ng + ny))),
+                       ("Fy", (slice(ng, ng + nx), slice(ng, ng + ny + 1)))):
+            assert max_rel_err(s.comp_stage(nm)[sl], g[f"c{k}_{nm}"][sl]) <= (0.0 if dev.kind == "emu" else TOL_EXACT), (k, nm)
+    U1 = s.download()
+    ref = g[f"c{k}_U1"]
+    if sp[0]:   # the sponge also acts on the ghost cells
+        assert max_rel_err(U1, ref) <= tol, k
+    else:
+        assert max_rel_err(R(U1, ng, 0), R(ref, ng, 0)) <= tol, k

@@ -238,3 +238,23 @@ def test_mg_variable_coefficient(golden):
         info = g[f"v{k}_info"]
         assert m.num_cycles == int(info[0])
         assert np.array_equal(m.arr(L, 0), g[f"v{k}_v_solve"]), k
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_comp_cgf_and_sponge(golden, k):
+    """riemann_cgf (riemann.py:8-310) incl. the solid-wall
+    rule, and the sponge (simulation.py:164-184,427-441), against dumps of
+    the reference's own functions"""
+    g = golden("comp_stages_f2")
+    bcs = [str(b) for b in g[f"c{k}_bc"]]
+    sp = g[f"c{k}_sponge"]
+    P, cfl = meta_to_params(g[f"c{k}_meta"], bcs, riemann=str(g[f"c{k}_riemann"]),
+                            sponge=tuple(sp[1:]) if sp[0] else None)
+    U = g[f"c{k}_U0"].copy()
+    rc, st = orc.comp_step(U, P, float(g[f"c{k}_dt"]), stages=True)
+    assert rc == 0
+    for nm in ("FxT", "FyT", "Fx0", "Fy0", "Fx", "Fy"):
+        assert max_rel_err(st[nm], g[f"c{k}_{nm}"]) == 0.0, (k, nm)
+    # the sponge evaluates cos(): libm vs NumPy may differ in the last bit
+    tol = 1e-15 if sp[0] else 0.0
+    assert max_rel_err(U, g[f"c{k}_U1"]) <= tol, k
