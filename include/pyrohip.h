@@ -39,8 +39,10 @@ enum {
     PYROHIP_BC_REFLECT_EVEN = 1, /* "reflect-even"                            */
     PYROHIP_BC_REFLECT_ODD = 2,  /* "reflect-odd", homogeneous "dirichlet"    */
     PYROHIP_BC_PERIODIC = 3,     /* "periodic"                                */
-    PYROHIP_BC_HALO = 4          /* interior slab interface: filled by        */
+    PYROHIP_BC_HALO = 4,         /* interior slab interface: filled by        */
                                  /* pyrohip_halo_exchange, not by fill_bc     */
+    PYROHIP_BC_HSE = 5,          /* compressible "hse" user boundary, y sides */
+    PYROHIP_BC_AMBIENT = 6       /* compressible "ambient" user boundary, yr  */
 };
 
 /* own status codes (hipError_t values are passed through unchanged) */
@@ -93,6 +95,15 @@ int pyrohip_state_download_rows(pyrohip_state *s, int i0, int ni,
 /* ArrayIndexer.fill_ghost / CellCenterData2d.fill_BC(_all)
    (array_indexer.py:150-274, patch.py:575-624); n = -1: all variables */
 int pyrohip_fill_bc(pyrohip_state *s, int n);
+/* Parameters of the compressible solver's user boundaries, compressible/BC.py:
+   21-176 ("hse": hydrostatic pressure integrated into the y ghost cells at
+   constant density; "ambient": fixed rho,u,v,p above the upper y boundary).
+   The state must hold the 4 conserved variables in pyro's order.  With these
+   codes fill_bc(-1) fills variable after variable like fill_BC_all
+   (patch.py:575-624): the hse energy ghosts are computed from the momenta's x
+   ghost columns as the PREVIOUS fill left them.  ambient = rho,u,v,p or NULL */
+int pyrohip_state_set_user_bc(pyrohip_state *s, double gamma, double grav,
+                              double dy, const double *ambient);
 /* min / max over the valid region grown by buf (patch.py:626-638) */
 int pyrohip_state_minmax(pyrohip_state *s, int n, int buf, double *vmin,
                          double *vmax);

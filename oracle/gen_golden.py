@@ -316,6 +316,60 @@ def gen_compressible_f2():
     save("comp_stages_f2", **out)
 
 
+def gen_compressible_hse():
+    """row f2: gravity with the hse / ambient user boundaries
+    (compressible/BC.py).  Whole short runs (IC -> final, dt sequence) plus a
+    stage dump of the step after the last one."""
+    cases = [
+        ("rt", None, {"mesh.nx": 16, "mesh.ny": 48}, 25, None),
+        ("rt", None, {"mesh.nx": 12, "mesh.ny": 40, "mesh.xlboundary": "outflow",
+                      "mesh.xrboundary": "reflect", "rt.amp": 0.4,
+                      "compressible.riemann": "CGF"}, 20, None),
+        ("hse", None, {"mesh.nx": 8, "mesh.ny": 32}, 12, None),
+        ("rt", None, {"mesh.nx": 16, "mesh.ny": 32, "mesh.yrboundary": "ambient",
+                      "rt.amp": 0.5}, 20, (0.8, 0.1, -0.2, 6.0)),
+    ]
+    out = {"ncases": np.array(len(cases))}
+    for k, (prob, inp, d, nsteps, amb) in enumerate(cases):
+        p = Pyro("compressible")
+        if amb is not None:
+            # the aux values must exist before the first fill_BC_all
+            import pyro.mesh.patch as _patch
+            orig = _patch.CellCenterData2d.create
+
+            def create(self, _orig=orig, _amb=amb):
+                _orig(self)
+                for nm, v in zip(("ambient_rho", "ambient_u", "ambient_v", "ambient_p"), _amb):
+                    self.set_aux(nm, v)
+            _patch.CellCenterData2d.create = create
+        p.initialize_problem(prob, inputs_file=inp, inputs_dict=d)
+        if amb is not None:
+            _patch.CellCenterData2d.create = orig
+        sim = p.sim
+        pre = f"c{k}_"
+        out[pre + "ic"] = np.array(sim.cc_data.data)
+        dts = []
+        for _ in range(nsteps):
+            p.single_step()
+            dts.append(sim.dt)
+        out[pre + "final"] = np.array(sim.cc_data.data)
+        out[pre + "dts"] = np.array(dts)
+        sim.cc_data.fill_BC_all()
+        out[pre + "filled"] = np.array(sim.cc_data.data)
+        sim.compute_timestep()
+        out[pre + "meta"] = comp_meta(sim)
+        out[pre + "bc"] = bc_names(sim.rp)
+        out[pre + "ambient"] = np.array(amb if amb is not None else (0.0,) * 4)
+        out[pre + "drv"] = np.array([p.rp.get_param("driver.init_tstep_factor"),
+                                     p.rp.get_param("driver.max_dt_change")])
+        out[pre + "dt"] = np.array(sim.dt)
+        st = comp_stage_dump(sim)
+        for nm in ("U0", "FxT", "FyT", "Fx", "Fy", "U1"):
+            out[pre + nm] = st[nm]
+        print("hse case", k, prob, d, "dt", sim.dt)
+    save("comp_hse", **out)
+
+
 def _raw_cfl_dt(sim):
     dt_keep, dto_keep = sim.dt, sim.dt_old
     sim.method_compute_timestep()
@@ -581,6 +635,8 @@ if __name__ == "__main__":
         gen_mg_vc()
     if "comp_f2" in sys.argv[1:]:
         gen_compressible_f2()
+    if "comp_hse" in sys.argv[1:]:
+        gen_compressible_hse()
     which = sys.argv[1:] or ["bc", "adv", "comp_stages", "comp_runs", "mg", "diffusion"]
     if "diffusion" in which:
         gen_diffusion()

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "_build", "liborc.so")
 
 BC_CODES = {"outflow": 0, "neumann": 0, "reflect-even": 1, "reflect-odd": 2,
-            "dirichlet": 2, "periodic": 3}
+            "dirichlet": 2, "periodic": 3, "hse": 5, "ambient": 6}
 
 
 def build(force=False):
@@ -165,11 +165,22 @@ def comp_var_bcs(bcs):
     return out
 
 
-def comp_fill_bc(U, nx, ny, ng, bcs):
-    vb = comp_var_bcs(bcs)
-    for n in range(4):
-        lib().orc_fill_ghost(_p(U), nx, ny, ng, 4, n,
-                             vb[n].ctypes.data_as(C.POINTER(C.c_int)))
+def set_scalar_pow(on):
+    """evaluate the reference's scalar `x**2` with libm pow (what the
+    interpreted shim run does) instead of x*x (what numba compiles)."""
+    lib().orc_set_scalar_pow(int(on))
+
+
+def comp_fill_bc(U, nx, ny, ng, bcs, gamma=1.4, grav=0.0, dy=0.0,
+                 ambient=(0.0, 0.0, 0.0, 0.0)):
+    """CellCenterData2d.fill_BC_all on the conserved state, including the
+    hse / ambient user boundaries (compressible/BC.py)."""
+    vb = np.ascontiguousarray(comp_var_bcs(bcs))
+    amb = np.asarray(ambient, dtype=np.float64)
+    f = lib().orc_comp_fill_bc
+    f.restype = None
+    f(_p(U), nx, ny, ng, vb.ctypes.data_as(C.POINTER(C.c_int)),
+      C.c_double(gamma), C.c_double(grav), C.c_double(dy), _p(amb))
     return U
 
 

@@ -44,6 +44,8 @@
 #define BC_REFLECT_EVEN 1
 #define BC_REFLECT_ODD 2  /* also homogeneous dirichlet */
 #define BC_PERIODIC 3
+#define BC_HSE 5          /* compressible/BC.py "hse" (y sides only)   */
+#define BC_AMBIENT 6      /* compressible/BC.py "ambient" (yr only)    */
 
 typedef struct {
     int nx, ny, ng;
@@ -124,6 +126,7 @@ void orc_fill_ghost(double *a, int nx, int ny, int ng, int nvar, int n,
     for (int i = 0; i < qx; i++)
         for (int j = 0; j < jlo; j++) {
             switch (bc[2]) {
+            case BC_HSE: /* BC.py:54-62: plain copy for everything but energy */
             case BC_OUTFLOW: A(i, j) = A(i, jlo); break;
             case BC_REFLECT_EVEN: A(i, j) = A(i, 2 * ng - j - 1); break;
             case BC_REFLECT_ODD: A(i, j) = -A(i, 2 * ng - j - 1); break;
@@ -135,6 +138,7 @@ void orc_fill_ghost(double *a, int nx, int ny, int ng, int nvar, int n,
         for (int k = 0; k < ng; k++) {
             int j = jhi + 1 + k;
             switch (bc[3]) {
+            case BC_HSE: case BC_AMBIENT: /* BC.py:87-93, 159-160 */
             case BC_OUTFLOW: A(i, j) = A(i, jhi); break;
             case BC_REFLECT_EVEN: A(i, j) = A(i, jhi - k); break;
             case BC_REFLECT_ODD: A(i, j) = -A(i, jhi - k); break;
@@ -647,6 +651,16 @@ void orc_riemann_hllc(int idir, int nx, int ny, int ng, double gamma,
 /* (riemann_flux :1083-1090).  Solid-wall quirk: the njit-local ihi is */
 /* ng+nx, so "i == ihi + 1" never fires.          */
 /* ------------------------------------------------------------------ */
+/* `x**2` on a scalar: numba compiles it to x*x (the real reference), the
+   interpreted identity-njit shim used by gen_golden.py evaluates it with
+   libm pow(x, 2.0), which is not always the correctly rounded square.
+   orc_set_scalar_pow(1) selects the shim's arithmetic so that goldens
+   generated through the shim can be pinned bit for bit; default 0. */
+static int g_scalar_pow = 0;
+void orc_set_scalar_pow(int on) { g_scalar_pow = on; }
+static volatile double g_two = 2.0; /* volatile: gcc would fold pow(x, 2.0) into x*x */
+static inline double sq_ref(double x) { return g_scalar_pow ? pow(x, g_two) : x * x; }
+#define SQ(x) sq_ref(x)
 void orc_riemann_cgf(int idir, int nx, int ny, int ng, double gamma, int lower_solid,
                      int upper_solid, const double *U_l, const double *U_r, double *F)
 {
@@ -662,12 +676,12 @@ void orc_riemann_cgf(int idir, int nx, int ny, int ng, double gamma, int lower_s
             double rho_l = Ul[IDENS], un_l, ut_l;
             if (idir == 1) { un_l = Ul[IXMOM] / rho_l; ut_l = Ul[IYMOM] / rho_l; }
             else           { un_l = Ul[IYMOM] / rho_l; ut_l = Ul[IXMOM] / rho_l; }
-            double rhoe_l = Ul[IENER] - 0.5 * rho_l * (un_l * un_l + ut_l * ut_l);
+            double rhoe_l = Ul[IENER] - 0.5 * rho_l * (SQ(un_l) + SQ(ut_l));
             double p_l = dmax(rhoe_l * (gamma - 1.0), smallp);
             double rho_r = Ur[IDENS], un_r, ut_r;
             if (idir == 1) { un_r = Ur[IXMOM] / rho_r; ut_r = Ur[IYMOM] / rho_r; }
             else           { un_r = Ur[IYMOM] / rho_r; ut_r = Ur[IXMOM] / rho_r; }
-            double rhoe_r = Ur[IENER] - 0.5 * rho_r * (un_r * un_r + ut_r * ut_r);
+            double rhoe_r = Ur[IENER] - 0.5 * rho_r * (SQ(un_r) + SQ(ut_r));
             double p_r = dmax(rhoe_r * (gamma - 1.0), smallp);
             double W_l = dmax(smallrho * smallc, sqrt(gamma * p_l * rho_l));
             double W_r = dmax(smallrho * smallc, sqrt(gamma * p_r * rho_r));
@@ -676,10 +690,10 @@ void orc_riemann_cgf(int idir, int nx, int ny, int ng, double gamma, int lower_s
             double pstar = (W_l * p_r + W_r * p_l + W_l * W_r * (un_l - un_r)) / (W_l + W_r);
             pstar = dmax(pstar, smallp);
             double ustar = (W_l * un_l + W_r * un_r + (p_l - p_r)) / (W_l + W_r);
-            double rhostar_l = rho_l + (pstar - p_l) / (c_l * c_l);
-            double rhostar_r = rho_r + (pstar - p_r) / (c_r * c_r);
-            double rhoestar_l = rhoe_l + (pstar - p_l) * (rhoe_l / rho_l + p_l / rho_l) / (c_l * c_l);
-            double rhoestar_r = rhoe_r + (pstar - p_r) * (rhoe_r / rho_r + p_r / rho_r) / (c_r * c_r);
+            double rhostar_l = rho_l + (pstar - p_l) / SQ(c_l);
+            double rhostar_r = rho_r + (pstar - p_r) / SQ(c_r);
+            double rhoestar_l = rhoe_l + (pstar - p_l) * (rhoe_l / rho_l + p_l / rho_l) / SQ(c_l);
+            double rhoestar_r = rhoe_r + (pstar - p_r) * (rhoe_r / rho_r + p_r / rho_r) / SQ(c_r);
             double cstar_l = dmax(smallc, sqrt(gamma * pstar / rhostar_l));
             double cstar_r = dmax(smallc, sqrt(gamma * pstar / rhostar_r));
             double rho_s, un_s, ut_s, p_s, rhoe_s;
@@ -737,11 +751,12 @@ void orc_riemann_cgf(int idir, int nx, int ny, int ng, double gamma, int lower_s
             Uo[IDENS] = rho_s;
             if (idir == 1) { Uo[IXMOM] = rho_s * un_s; Uo[IYMOM] = rho_s * ut_s; }
             else           { Uo[IXMOM] = rho_s * ut_s; Uo[IYMOM] = rho_s * un_s; }
-            Uo[IENER] = rhoe_s + 0.5 * rho_s * (un_s * un_s + ut_s * ut_s);
+            Uo[IENER] = rhoe_s + 0.5 * rho_s * (SQ(un_s) + SQ(ut_s));
             cons_flux(idir, gamma, Uo, F + ((size_t)i * qy + j) * 4);
         }
 }
 
+#undef SQ
 static void riemann_dispatch(const orc_comp_params *P, int idir, const double *U_l,
                              const double *U_r, double *F)
 {
@@ -817,6 +832,62 @@ static void ext_sources(const double *U, const double *U_old, size_t ncell,
         }
     }
 }
+
+/* ------------------------------------------------------------------ */
+/* f2: CellCenterData2d.fill_BC_all for the compressible state with the */
+/* user boundaries of compressible/BC.py:21-176 ("hse", "ambient").      */
+/* Variables are filled one after the other in registration order       */
+/* (density, energy, x-momentum, y-momentum; patch.py:575-624), so the   */
+/* hse energy fill sees the x ghosts of the momenta as the PREVIOUS      */
+/* fill left them.  ambient = rho, u, v, p.                              */
+/* ------------------------------------------------------------------ */
+#define U4(a, i, j, n) a[((size_t)(i) * qy + (j)) * 4 + (n)]
+void orc_comp_fill_bc(double *U, int nx, int ny, int ng, const int *bc /*[4][4]*/,
+                      double gamma, double grav, double dy, const double *ambient)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int jlo = ng, jhi = ng + ny - 1;
+    for (int n = 0; n < 4; n++) {
+        const int *b = bc + 4 * n;
+        orc_fill_ghost(U, nx, ny, ng, 4, n, b);
+        if (n == IENER && (b[2] == BC_HSE || b[3] == BC_HSE)) {
+            for (int side = 0; side < 2; side++) {
+                if (b[2 + side] != BC_HSE) continue;
+                const int jb = side ? jhi : jlo;
+                for (int i = 0; i < qx; i++) {
+                    /* BC.py:64-84 (ylb), 95-115 (yrb) */
+                    double dens_base = U4(U, i, jb, IDENS);
+                    double xm = U4(U, i, jb, IXMOM), ym = U4(U, i, jb, IYMOM);
+                    double ke_base = 0.5 * (xm * xm + ym * ym) / dens_base;
+                    double eint_base = (U4(U, i, jb, IENER) - ke_base) / dens_base;
+                    double pres_base = dens_base * eint_base * (gamma - 1.0); /* eos.py pres */
+                    for (int k = 1; k <= ng; k++) {
+                        int j = side ? jhi + k : jlo - k;
+                        double pres_next = side ? pres_base + grav * dens_base * dy
+                                                : pres_base - grav * dens_base * dy;
+                        double rhoe = pres_next / (gamma - 1.0);
+                        U4(U, i, j, IENER) = rhoe + ke_base;
+                        pres_base = pres_next;
+                    }
+                }
+            }
+        }
+        if (b[3] == BC_AMBIENT) { /* BC.py:147-176 */
+            double val;
+            if (n == IDENS) val = ambient[0];
+            else if (n == IXMOM) val = ambient[0] * ambient[1];
+            else if (n == IYMOM) val = ambient[0] * ambient[2];
+            else {
+                double ke = 0.5 * ambient[0] * (ambient[1] * ambient[1] + ambient[2] * ambient[2]);
+                val = ambient[3] / (gamma - 1.0) + ke;
+            }
+            for (int i = 0; i < qx; i++)
+                for (int j = jhi + 1; j < qy; j++) U4(U, i, j, n) = val;
+        }
+    }
+}
+
+#undef U4
 
 /* ------------------------------------------------------------------ */
 /* a12: CFL time step, compressible/simulation.py:267-288 +            */

@@ -6,15 +6,17 @@ transverse correction, artificial viscosity, conservative update in HIP);
 method_compute_timestep() = pyrohip_comp_dt (device min-reduction, 8 bytes
 D2H).  Scope of the device path: Cartesian
 grid, HLLC or CGF Riemann solver, gamma-law gas, limiter 0/1/2, flattening,
-artificial viscosity, gravity, sponge, standard boundary types.
+artificial viscosity, gravity, sponge, standard boundary types plus the
+hse / ambient user boundaries.
 """
 import numpy as np
 
 from .. import device
+from .._lib import BC_CODE
 from ..mesh import boundary as bnd
 from ..simulation_null import NullSimulation, bc_setup, grid_setup
 from ..util import msg
-from . import derives, eos
+from . import BC, derives, eos
 
 
 class Variables:
@@ -67,6 +69,9 @@ class Simulation(NullSimulation):
         if riemann_method not in ("HLLC", "CGF"):
             msg.fail("ERROR: the device path implements compressible.riemann = HLLC or CGF "
                      "(HLLC_lm: SURVEY.md 8 row f2)")
+        # compressible/simulation.py:212-214; both have device kernels
+        bnd.define_bc("hse", BC.user, is_solid=False, device_code=BC_CODE["hse"])
+        bnd.define_bc("ambient", BC.user, is_solid=False, device_code=BC_CODE["ambient"])
         bc, bc_xodd, bc_yodd = bc_setup(self.rp)
         self.solid = bnd.bc_is_solid(bc)
         # same registration order as compressible/simulation.py:223-226

@@ -126,6 +126,10 @@ struct pyrohip_state {
     double *alt_base = nullptr;  // second buffer (fused kernels write the new
                                  // time level here, then the two are swapped)
     int *d_bc = nullptr;      // device copy of bc
+    // compressible user boundaries (pyrohip_state_set_user_bc)
+    bool user_bc = false;     // any HSE / AMBIENT code in bc
+    bool user_bc_set = false;
+    double ubc_gamma = 0.0, ubc_grav = 0.0, ubc_dy = 0.0, ubc_amb[4] = {0, 0, 0, 0};
     // compressible work space (allocated on first use)
     double *work = nullptr;
     size_t work_planes = 0;

@@ -65,6 +65,7 @@ struct FP {   // kernel parameters
     double dtdV;          // dt/(dx*dy)            simulation.py:375
     double grav;          // compressible.grav (0: no source terms)
     int refl_ylo, refl_yhi;   // y-momentum reflects oddly at the lower / upper y wall
+    int amb_yhi;              // "ambient" boundary on the upper y side
     int solid_xl, solid_yl;   // CGF wall rule (riemann.py:274-286)
 };
 
@@ -192,9 +193,12 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
                             Qv[qc - FQW], Qv[qc - 1], Qv[qc - FQW - 1], P.dx, P.dy);
         if (P.grav != 0.0) {   // apply_source_terms, unsplit_fluxes.py:247-330
             const bool ina = (i < g.qx && j < g.qy);
-            const size_t kc = (size_t)(ina ? i : g.qx - 1) * p + (ina ? j : g.qy - 1);
+            // "ambient" upper boundary: the source ghosts are copies of row jhi
+            // (BC.py:159-160), not the sources of the ambient ghost state
+            const int js = (P.amb_yhi && j > g.jhi) ? g.jhi : j;
+            const size_t kc = (size_t)(ina ? i : g.qx - 1) * p + (ina ? js : g.qy - 1);
             Cons Ug{Uin[kc], 0.0, 0.0, Uin[3 * pl + kc]};
-            if (i >= g.ilo && i <= g.ihi && j >= g.jlo && j <= g.jhi)
+            if (i >= g.ilo && i <= g.ihi && js >= g.jlo && js <= g.jhi)
                 Ug.d = fmax(Ug.d, P.small_dens);
             const double sgn =
                 ((j < g.jlo && P.refl_ylo) || (j > g.jhi && P.refl_yhi)) ? -1.0 : 1.0;
@@ -359,6 +363,7 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     P.grav = p->grav;
     P.refl_ylo = (s->bc[3 * 4 + 2] == PYROHIP_BC_REFLECT_ODD);
     P.refl_yhi = (s->bc[3 * 4 + 3] == PYROHIP_BC_REFLECT_ODD);
+    P.amb_yhi = (s->bc[3 * 4 + 3] == PYROHIP_BC_AMBIENT);
     P.solid_xl = p->solid_xl; P.solid_yl = p->solid_yl;
     const int nti = (g.nx + FTI - 1) / FTI;
     P.ntj = (g.ny + FTJ - 1) / FTJ;

@@ -54,6 +54,7 @@ struct CP {   // kernel-side parameters
     int avx_hi, avy_hi;   // compute avisc on the upper boundary face
     double grav;          // compressible.grav (0: no source terms)
     int refl_ylo, refl_yhi;   // y-momentum reflects oddly at the lower / upper y wall
+    int amb_yhi;              // "ambient" boundary on the upper y side
     int riemann, solid_xl, solid_yl;   // 0 HLLC / 1 CGF; CGF wall rule
 };
 
@@ -173,7 +174,9 @@ __global__ __launch_bounds__(256) void k_states(const double *__restrict__ U,
     Cons YM = prim_to_cons(Prim{lo.r, lo.ut, lo.un, lo.p}, P.gamma);
     Cons YP = prim_to_cons(Prim{hi.r, hi.ut, hi.un, hi.p}, P.gamma);
     if (P.grav != 0.0) {   // apply_source_terms, unsplit_fluxes.py:247-330
-        const Cons Uc = load_cons(U, pl, k);
+        // "ambient" upper boundary: the source ghosts are copies of row jhi
+        // (BC.py:159-160), not the sources of the ambient ghost state
+        const Cons Uc = load_cons(U, pl, (P.amb_yhi && j > g.jhi) ? k - (j - g.jhi) : k);
         const double sgn = ((j < g.jlo && P.refl_ylo) || (j > g.jhi && P.refl_yhi)) ? -1.0 : 1.0;
         add_grav_to_state(XM, Uc, P.grav, P.dt, sgn);
         add_grav_to_state(XP, Uc, P.grav, P.dt, sgn);
@@ -393,6 +396,7 @@ static CP make_cp(const pyrohip_comp_params *p, double dt, const pyrohip_state *
     c.grav = p->grav;
     c.refl_ylo = (s->bc[3 * 4 + 2] == PYROHIP_BC_REFLECT_ODD);
     c.refl_yhi = (s->bc[3 * 4 + 3] == PYROHIP_BC_REFLECT_ODD);
+    c.amb_yhi = (s->bc[3 * 4 + 3] == PYROHIP_BC_AMBIENT);
     c.riemann = p->riemann; c.solid_xl = p->solid_xl; c.solid_yl = p->solid_yl;
     return c;
 }

@@ -105,6 +105,7 @@ __global__ void k_fill_y(double *__restrict__ d, Geom g, const int *__restrict__
         int j = k;
         double v;
         switch (bc[n * 4 + 2]) {
+        case PYROHIP_BC_HSE:   // BC.py:54-62 (energy is overwritten by k_fill_y_user)
         case PYROHIP_BC_OUTFLOW: v = a[jlo]; break;
         case PYROHIP_BC_REFLECT_EVEN: v = a[2 * ng - j - 1]; break;
         case PYROHIP_BC_REFLECT_ODD: v = -a[2 * ng - j - 1]; break;
@@ -116,6 +117,8 @@ __global__ void k_fill_y(double *__restrict__ d, Geom g, const int *__restrict__
         int kk = k - ng, j = jhi + 1 + kk;
         double v;
         switch (bc[n * 4 + 3]) {
+        case PYROHIP_BC_HSE:      // BC.py:87-93
+        case PYROHIP_BC_AMBIENT:  // BC.py:159-160
         case PYROHIP_BC_OUTFLOW: v = a[jhi]; break;
         case PYROHIP_BC_REFLECT_EVEN: v = a[jhi - kk]; break;
         case PYROHIP_BC_REFLECT_ODD: v = -a[jhi - kk]; break;
@@ -123,6 +126,45 @@ __global__ void k_fill_y(double *__restrict__ d, Geom g, const int *__restrict__
         default: return;
         }
         a[j] = v;
+    }
+}
+
+// User boundaries of the compressible solver (compressible/BC.py:21-176) for
+// variable n of a 4-plane conserved state; one thread per row i and side.
+//   hse, energy only (:64-84 lower, :95-115 upper): integrate dp = rho g dy
+//   away from the last interior cell at constant density, keep its kinetic
+//   energy.  ambient (:147-176, upper side): constant state.
+struct UserBc {
+    double gamma, grav, dy, amb_val;
+};
+__global__ void k_fill_y_user(double *__restrict__ d, Geom g, const int *__restrict__ bc, int n,
+                              UserBc ub)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int side = blockIdx.y;
+    if (i >= g.qx) return;
+    const int code = bc[n * 4 + 2 + side];
+    const size_t row = (size_t)i * g.pitch;
+    if (code == PYROHIP_BC_AMBIENT && side == 1) {
+        double *a = d + (size_t)n * g.plane + row;
+        for (int j = g.jhi + 1; j < g.qy; j++) a[j] = ub.amb_val;
+        return;
+    }
+    if (code != PYROHIP_BC_HSE || n != 1) return;
+    const int jb = side ? g.jhi : g.jlo;
+    const double dens_base = d[row + jb];
+    const double ener = d[(size_t)g.plane + row + jb];
+    const double xm = d[2 * (size_t)g.plane + row + jb], ym = d[3 * (size_t)g.plane + row + jb];
+    const double ke_base = 0.5 * (xm * xm + ym * ym) / dens_base;
+    const double eint_base = (ener - ke_base) / dens_base;
+    double pres_base = dens_base * eint_base * (ub.gamma - 1.0);   // eos.pres
+    double *e = d + (size_t)g.plane + row;
+    for (int k = 1; k <= g.ng; k++) {
+        const int j = side ? g.jhi + k : g.jlo - k;
+        const double pres_next = side ? pres_base + ub.grav * dens_base * ub.dy
+                                      : pres_base - ub.grav * dens_base * ub.dy;
+        e[j] = pres_next / (ub.gamma - 1.0) + ke_base;             // eos.rhoe
+        pres_base = pres_next;
     }
 }
 
@@ -298,9 +340,20 @@ int pyrohip_state_create(pyrohip_ctx *c, int nx, int ny, int ng, int nvar, const
     PYRO_REQUIRE(nx > 0 && ny > 0 && ng >= 1 && ng <= 8 && nvar >= 1, "bad dimensions");
     PYRO_REQUIRE(nx >= ng && ny >= ng, "grid smaller than the ghost width");
     for (int k = 0; k < nvar * 4; k++)
-        PYRO_REQUIRE(bc[k] >= 0 && bc[k] <= PYROHIP_BC_HALO, "bad BC code");
+        PYRO_REQUIRE(bc[k] >= 0 && bc[k] <= PYROHIP_BC_AMBIENT, "bad BC code");
+    bool user_bc = false;
+    for (int k = 0; k < nvar * 4; k++) {
+        if (bc[k] != PYROHIP_BC_HSE && bc[k] != PYROHIP_BC_AMBIENT) continue;
+        // BC.py:116-117, 176-177: hse on the y sides only, ambient on the upper y side only
+        PYRO_REQUIRE(nvar == 4, "hse / ambient boundaries need the 4-variable compressible state");
+        PYRO_REQUIRE((k & 3) >= 2, "hse / ambient boundaries are not supported on the x sides");
+        PYRO_REQUIRE(bc[k] == PYROHIP_BC_HSE || (k & 3) == 3,
+                     "the ambient boundary is only supported on the upper y side");
+        user_bc = true;
+    }
     PYRO_CHECK_HIP(hipSetDevice(c->device));
     pyrohip_state *s = new pyrohip_state();
+    s->user_bc = user_bc;
     s->ctx = c;
     s->g = make_geom(nx, ny, ng);
     s->nvar = nvar;
@@ -433,10 +486,71 @@ int pyrohip_state_download_var(pyrohip_state *s, int n, double *host)
     return 0;
 }
 
+int pyrohip_state_set_user_bc(pyrohip_state *s, double gamma, double grav, double dy,
+                              const double *ambient)
+{
+    PYRO_REQUIRE(s, "NULL state");
+    PYRO_REQUIRE(s->nvar == 4, "user boundaries need the 4-variable compressible state");
+    s->ubc_gamma = gamma;
+    s->ubc_grav = grav;
+    s->ubc_dy = dy;
+    for (int k = 0; k < 4; k++) s->ubc_amb[k] = ambient ? ambient[k] : 0.0;
+    s->user_bc_set = true;
+    return 0;
+}
+
+// fill_BC for variables n0 .. n0+cnt-1: x sides, then y sides, then the
+// user boundaries of each variable
+static int fill_bc_range(pyrohip_state *s, int n0, int cnt)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    {
+        dim3 grid((g.qy + 255) / 256, 1, cnt), block(256);
+        hipLaunchKernelGGL(k_fill_x, grid, block, 0, c->stream, s->d, g, (const int *)s->d_bc, n0);
+    }
+    {
+        dim3 block(16, 16);
+        dim3 grid((g.qx + 15) / 16, 1, cnt);
+        hipLaunchKernelGGL(k_fill_y, grid, block, 0, c->stream, s->d, g, (const int *)s->d_bc, n0);
+    }
+    if (s->user_bc) {
+        for (int n = n0; n < n0 + cnt; n++) {
+            const int yl = s->bc[n * 4 + 2], yr = s->bc[n * 4 + 3];
+            const bool hse = (n == 1) && (yl == PYROHIP_BC_HSE || yr == PYROHIP_BC_HSE);
+            const bool amb = (yr == PYROHIP_BC_AMBIENT);
+            if (!hse && !amb) continue;
+            const double *A = s->ubc_amb;   // rho, u, v, p
+            UserBc ub{s->ubc_gamma, s->ubc_grav, s->ubc_dy, 0.0};
+            // BC.py:162-176; n: density, energy, x-momentum, y-momentum
+            if (n == 0) ub.amb_val = A[0];
+            else if (n == 2) ub.amb_val = A[0] * A[1];
+            else if (n == 3) ub.amb_val = A[0] * A[2];
+            else {
+                const double ke = 0.5 * A[0] * (A[1] * A[1] + A[2] * A[2]);
+                ub.amb_val = A[3] / (s->ubc_gamma - 1.0) + ke;
+            }
+            hipLaunchKernelGGL(k_fill_y_user, dim3((g.qx + 63) / 64, 2), dim3(64), 0, c->stream,
+                               s->d, g, (const int *)s->d_bc, n, ub);
+        }
+    }
+    PYRO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int pyrohip_fill_bc(pyrohip_state *s, int n)
 {
     PYRO_REQUIRE(s, "NULL state");
     PYRO_REQUIRE(n >= -1 && n < s->nvar, "variable index out of range");
+    if (s->user_bc) {
+        PYRO_REQUIRE(s->user_bc_set, "hse / ambient boundary: call pyrohip_state_set_user_bc first");
+        if (n >= 0) return fill_bc_range(s, n, 1);
+        // variable after variable, like fill_BC_all: the hse energy (variable 1)
+        // must see the momenta's x ghosts of the previous fill.  (0,1) and (2,3)
+        // can still share launches: energy only reads row jlo/jhi of the others.
+        PYRO_TRY(fill_bc_range(s, 0, 2));
+        return fill_bc_range(s, 2, 2);
+    }
     pyrohip_ctx *c = s->ctx;
     const Geom &g = s->g;
     int n0 = (n < 0) ? 0 : n, cnt = (n < 0) ? s->nvar : 1;

@@ -187,6 +187,15 @@ class DeviceState:
         with self.ctx.lock:
             check(self._l.pyrohip_fill_bc(self.h, int(n)))
 
+    def set_user_bc(self, gamma, grav, dy, ambient=None):
+        """parameters of the hse / ambient boundaries (compressible/BC.py);
+        ambient = (rho, u, v, p)"""
+        amb = None if ambient is None else np.ascontiguousarray(ambient, dtype=np.float64)
+        with self.ctx.lock:
+            check(self._l.pyrohip_state_set_user_bc(
+                self.h, float(gamma), float(grav), float(dy),
+                None if amb is None else dptr(amb)))
+
     def minmax(self, n, buf=0):
         mn, mx = C.c_double(), C.c_double()
         with self.ctx.lock:

@@ -15,10 +15,19 @@ bc_solid = {"outflow": False, "periodic": False, "reflect": True,
 ext_bcs = {}
 
 
-def define_bc(bc_type, function, is_solid=False):
-    """register a solver-specific boundary type (boundary.py:19-32)"""
+# user boundary types that the device ghost fill implements itself
+# {name: PYROHIP_BC_* code}; their Python callbacks are then not needed for the
+# 4-variable compressible state
+device_bcs = {}
+
+
+def define_bc(bc_type, function, is_solid=False, device_code=None):
+    """register a solver-specific boundary type (boundary.py:19-32).
+    device_code: the type has a kernel in csrc/ctx.hip (pyrohip.h BC codes)"""
     bc_solid[bc_type] = is_solid
     ext_bcs[bc_type] = function
+    if device_code is not None:
+        device_bcs[bc_type] = device_code
 
 
 class BCProp:

@@ -109,8 +109,12 @@ class Cartesian2d(Grid2d):
                 f"nx = {self.nx}, ny = {self.ny}, ng = {self.ng}")
 
 
-def _bc_row(bc):
-    return [BC_CODE.get(b, 0) for b in bc.sides()]
+def _bc_row(bc, device_user_bc=False):
+    """BC codes of one variable; user types without a device kernel get 0
+    (their callback overwrites the ghost cells afterwards)"""
+    return [bnd.device_bcs[b] if (device_user_bc and b in bnd.device_bcs)
+            else BC_CODE.get(b, 0) if b not in bnd.ext_bcs else 0
+            for b in bc.sides()]
 
 
 def _fill_host_array(ctx, arr, n, bc):
@@ -211,7 +215,8 @@ class CellCenterData2d:
         copy was touched since the last device operation)"""
         if self._dev is None:
             g = self.grid
-            rows = [_bc_row(self.BCs[n]) for n in self.names]
+            dub = self._device_user_bc()
+            rows = [_bc_row(self.BCs[n], dub) for n in self.names]
             self._dev = device.DeviceState(self.ctx, g.nx, g.ny, g.ng, rows)
         if not self._dev_valid:
             self._dev.upload(np.asarray(self._host))
@@ -277,14 +282,34 @@ class CellCenterData2d:
         return np.max(self._host.v(buf=ng, n=n))
 
     # ---- boundary conditions -------------------------------------------
+    def _device_user_bc(self):
+        """the hse / ambient boundaries run on the device for the compressible
+        state (4 variables in pyro's order, y sides only)"""
+        return self.names == ["density", "energy", "x-momentum", "y-momentum"] and \
+            all(b not in bnd.device_bcs for n in self.names
+                for b in self.BCs[n].sides()[:2])
+
     def _has_host_bc(self, name):
         bc = self.BCs[name]
-        return any(b in bnd.ext_bcs for b in bc.sides()) or \
+        dev_ok = self._device_user_bc()
+        return any(b in bnd.ext_bcs and not (dev_ok and b in bnd.device_bcs)
+                   for b in bc.sides()) or \
             any(v is not None for v in bc.values())
+
+    def _push_user_bc(self, st):
+        """hand gamma, grav and the ambient state (aux data, set by the solver
+        and the problem setup) to the device ghost fill"""
+        if not any(b in bnd.device_bcs for n in self.names for b in self.BCs[n].sides()):
+            return
+        amb = [self.aux.get(k, 0.0) for k in
+               ("ambient_rho", "ambient_u", "ambient_v", "ambient_p")]
+        st.set_user_bc(self.get_aux("gamma"), self.get_aux("grav"), self.grid.dy, amb)
 
     def fill_BC_all(self):
         if not any(self._has_host_bc(n) for n in self.names):
-            self.device_state().fill_bc(-1)     # one launch pair for all variables
+            st = self.device_state()
+            self._push_user_bc(st)
+            st.fill_bc(-1)     # one launch pair for all variables
             self.device_modified()
             return
         for name in self.names:
@@ -295,7 +320,9 @@ class CellCenterData2d:
         user-defined boundary callbacks on the host copy (patch.py:582-624)"""
         n = self.names.index(name)
         bc = self.BCs[name]
-        self.device_state().fill_bc(n)
+        st = self.device_state()
+        self._push_user_bc(st)
+        st.fill_bc(n)
         self.device_modified()
         if not self._has_host_bc(name):
             return

@@ -42,14 +42,14 @@ class DtPolicy:
 
 
 def oracle_comp_run(ic, meta, bcs, tmax, max_steps, init_tstep_factor=0.01,
-                    max_dt_change=2.0):
+                    max_dt_change=2.0, ambient=(0.0,) * 4, **over):
     """run the C oracle like Pyro.run_sim (pyro_sim.py:219-256)"""
-    P, cfl = meta_to_params(meta, bcs)
+    P, cfl = meta_to_params(meta, bcs, **over)
     U = np.ascontiguousarray(ic, dtype=np.float64).copy()
     pol = DtPolicy(tmax, init_tstep_factor, max_dt_change)
     dts = []
     while not (pol.t >= tmax or pol.n >= max_steps):
-        orc.comp_fill_bc(U, P.nx, P.ny, P.ng, bcs)
+        orc.comp_fill_bc(U, P.nx, P.ny, P.ng, bcs, P.gamma, P.grav, P.dy, ambient)
         dtm = orc.comp_dt(U, P.nx, P.ny, P.ng, P.dx, P.dy, P.gamma, cfl)
         dt = pol(dtm)
         rc, _ = orc.comp_step(U, P, dt)

@@ -13,7 +13,7 @@ import pytest
 from conftest import max_rel_err
 from helpers import DtPolicy, meta_to_params
 from oracle import orc
-from pyro2_amd import device
+from pyro2_amd import _lib, device
 
 TOL_EXACT = 1e-13
 TOL_FAST = 1e-10
@@ -275,3 +275,55 @@ def test_comp_cgf_and_sponge(dev, golden, k, kset):
         assert max_rel_err(U1, ref) <= tol, k
     else:
         assert max_rel_err(R(U1, ng, 0), R(ref, ng, 0)) <= tol, k
+
+
+@pytest.mark.parametrize("kset", [0, 1])
+@pytest.mark.parametrize("k", range(4))
+def test_comp_hse_ambient_runs(dev, golden, k, kset):
+    """gravity with the hse / ambient user boundaries
+    (compressible/BC.py) filled on the device, whole runs of the reference
+    (rt / hse problems, periodic / outflow / reflecting x sides, HLLC and CGF)"""
+    g = golden("comp_hse")
+    pre = f"c{k}_"
+    meta, bcs = g[pre + "meta"], [str(b) for b in g[pre + "bc"]]
+    riemann = "CGF" if k == 1 else "HLLC"
+    solid = [int(b == "reflect") for b in bcs]
+    P, cfl = dev_params(meta, kernel_set=kset, riemann=riemann, solid_xl=solid[0],
+                        solid_yl=solid[2])
+    nx, ny, ng = int(meta[0]), int(meta[1]), int(meta[2])
+    s = comp_state(dev, nx, ny, bcs)
+    with pytest.raises(_lib.PyroHipError):
+        s.fill_bc()                      # parameters of the user boundary missing
+    s.set_user_bc(meta[5], meta[12], meta[4], g[pre + "ambient"])
+    s.upload(np.nan_to_num(g[pre + "ic"]))   # NaNs only in never-read y ghost rows
+    dts_ref = g[pre + "dts"]
+    nsteps = len(dts_ref) if dev.kind == "hip" else 5
+    f0, mx = g[pre + "drv"]
+    pol = DtPolicy(1.e30, f0, mx)
+    dts = []
+    for _ in range(nsteps):
+        s.fill_bc()
+        dt = pol(s.comp_dt(P, cfl))
+        s.comp_step(P, dt)
+        pol.advance(dt)
+        dts.append(dt)
+    # the CGF run holds one face where the shim's libm pow differs from x*x
+    # by an ulp (tests/test_oracle_golden.py::test_oracle_hse_runs): compare
+    # with the oracle's default arithmetic there
+    from helpers import oracle_comp_run
+    Uo, dto, _ = oracle_comp_run(g[pre + "ic"], meta, bcs, 1.e30, nsteps, f0, mx,
+                                 ambient=tuple(g[pre + "ambient"]), riemann=riemann)
+    tol = 0.0 if dev.kind == "emu" else TOL_EXACT * nsteps
+    assert max_rel_err(np.array(dts), dto) <= tol
+    if k != 1:
+        assert max_rel_err(np.array(dts), dts_ref[:nsteps]) <= tol
+    U = s.download()
+    scale = np.abs(Uo[ng:-ng, ng:-ng]).max(axis=(0, 1))
+    err = (np.abs(U - Uo)[ng:-ng, ng:-ng] / scale).max()
+    assert err <= tol, err
+    # ghost cells: as the last fill left them
+    assert np.abs(np.nan_to_num(U) - np.nan_to_num(Uo)).max() <= tol * scale.max()
+    # and one more fill against the reference's filled state
+    if nsteps == len(dts_ref) and k != 1:
+        s.fill_bc()
+        assert (np.abs(s.download() - g[pre + "filled"]) / scale).max() <= tol

@@ -258,3 +258,52 @@ def test_comp_cgf_and_sponge(golden, k):
     # the sponge evaluates cos(): libm vs NumPy may differ in the last bit
     tol = 1e-15 if sp[0] else 0.0
     assert max_rel_err(U, g[f"c{k}_U1"]) <= tol, k
+
+
+# ---------------------------------------------------------------------------
+# row f2: gravity + the hse / ambient user boundaries (compressible/BC.py)
+# ---------------------------------------------------------------------------
+HSE_RIEMANN = {1: "CGF"}
+
+
+@pytest.mark.parametrize("k", range(4))
+def test_oracle_hse_runs(golden, k):
+    from helpers import meta_to_params, oracle_comp_run
+    g = golden("comp_hse")
+    pre = f"c{k}_"
+    meta, bcs = g[pre + "meta"], [str(b) for b in g[pre + "bc"]]
+    amb = tuple(g[pre + "ambient"])
+    f0, mx = g[pre + "drv"]
+    dts_ref = g[pre + "dts"]
+    over = {"riemann": HSE_RIEMANN.get(k, "HLLC")}
+    if k == 1:
+        # numba turns the scalar `x**2` of riemann_cgf into x*x (the oracle's
+        # default); the goldens come from the interpreted shim, where it is
+        # libm pow(x, 2.0).  One face of this run is a case where the two
+        # differ by an ulp: default arithmetic agrees to round-off ...
+        U, dts, _ = oracle_comp_run(g[pre + "ic"], meta, bcs, 1.e30, len(dts_ref), f0, mx,
+                                    ambient=amb, **over)
+        assert np.array_equal(dts, dts_ref)
+        assert np.allclose(U, g[pre + "final"], rtol=1e-13, atol=1e-12)
+        # ... and the shim's arithmetic reproduces them bit for bit
+        orc.set_scalar_pow(1)
+    try:
+        U, dts, _ = oracle_comp_run(g[pre + "ic"], meta, bcs, 1.e30, len(dts_ref), f0, mx,
+                                    ambient=amb, **over)
+    finally:
+        orc.set_scalar_pow(0)
+    assert np.array_equal(dts, dts_ref)
+    fin = g[pre + "final"]
+    ng = int(meta[2])
+    assert np.array_equal(U[ng:-ng, ng:-ng], fin[ng:-ng, ng:-ng])
+    # ghost cells are whatever the last fill left, also in the reference
+    assert np.array_equal(U, fin, equal_nan=True)
+    # one more fill + stage dump
+    P, _ = meta_to_params(meta, bcs, **over)
+    orc.comp_fill_bc(U, P.nx, P.ny, P.ng, bcs, P.gamma, P.grav, P.dy, amb)
+    assert np.array_equal(U, g[pre + "filled"])
+    rc, st = orc.comp_step(U, P, float(g[pre + "dt"]), stages=True)
+    assert rc == 0
+    for nm in ("FxT", "FyT", "Fx", "Fy"):
+        assert np.array_equal(st[nm], g[pre + nm]), nm
+    assert np.array_equal(U[ng:-ng, ng:-ng], g[pre + "U1"][ng:-ng, ng:-ng])
