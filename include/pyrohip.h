@@ -55,6 +55,7 @@ enum {
 };
 
 /* ---- context ---------------------------------------------------------- */
+int pyrohip_device_count(int *count);   /* visible HIP devices */
 int pyrohip_init(int device_id, pyrohip_ctx **out);
 int pyrohip_shutdown(pyrohip_ctx *ctx);
 int pyrohip_sync(pyrohip_ctx *ctx);

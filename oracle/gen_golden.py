@@ -370,6 +370,24 @@ def gen_compressible_hse():
     save("comp_hse", **out)
 
 
+def gen_compressible_rt():
+    """reference regression compressible rt (inputs.rt, 64x192, 945 steps) vs
+    pyro/compressible/tests/rt_0945.h5 (test.py:102): the reference's IC and
+    its stored end state (like quad: too slow to re-run interpreted)."""
+    names = ["density", "energy", "x-momentum", "y-momentum"]
+    p = Pyro("compressible")
+    p.initialize_problem("rt", inputs_file="inputs.rt")
+    ic = np.array(p.sim.cc_data.data)
+    with h5py.File(REF + "/compressible/tests/rt_0945.h5", "r") as f:
+        nsteps = int(f.attrs["nsteps"])
+        tfin = float(f.attrs["time"])
+        g = np.stack([f["state/" + nm + "/data"][...] for nm in names], axis=-1)
+    save("comp_rt_0945", ic=ic, gold=g, nsteps=np.array(nsteps), t=np.array(tfin),
+         meta=comp_meta(p.sim), bc=bc_names(p.sim.rp), tmax=np.array(p.sim.tmax),
+         drv=np.array([p.rp.get_param("driver.init_tstep_factor"),
+                       p.rp.get_param("driver.max_dt_change")]))
+
+
 def _raw_cfl_dt(sim):
     dt_keep, dto_keep = sim.dt, sim.dt_old
     sim.method_compute_timestep()
@@ -637,6 +655,8 @@ if __name__ == "__main__":
         gen_compressible_f2()
     if "comp_hse" in sys.argv[1:]:
         gen_compressible_hse()
+    if "comp_rt" in sys.argv[1:]:
+        gen_compressible_rt()
     which = sys.argv[1:] or ["bc", "adv", "comp_stages", "comp_runs", "mg", "diffusion"]
     if "diffusion" in which:
         gen_diffusion()

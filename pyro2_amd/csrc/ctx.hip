@@ -216,6 +216,13 @@ const char *pyrohip_last_error(void) { return g_last_error.c_str(); }
 #endif
 const char *pyrohip_backend(void) { return PYRO_BACKEND_NAME; }
 
+int pyrohip_device_count(int *count)
+{
+    PYRO_REQUIRE(count != nullptr, "count is NULL");
+    PYRO_CHECK_HIP(hipGetDeviceCount(count));
+    return 0;
+}
+
 int pyrohip_init(int device_id, pyrohip_ctx **out)
 {
     PYRO_REQUIRE(out != nullptr, "out is NULL");

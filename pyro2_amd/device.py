@@ -14,6 +14,12 @@ from . import _lib
 from ._lib import BC_CODE, CompParams, check, dptr, iptr
 
 
+def device_count():
+    n = C.c_int()
+    check(_lib.lib().pyrohip_device_count(C.byref(n)))
+    return n.value
+
+
 class Context:
     """One HIP device + stream.  Calls are serialised with a lock because
     ctypes releases the GIL (include/pyrohip.h conventions)."""

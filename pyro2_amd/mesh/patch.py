@@ -350,10 +350,10 @@ class CellCenterData2d:
 
     # ---- output ---------------------------------------------------------
     def write(self, filename):
-        import h5py
-        if not filename.endswith(".h5"):
-            filename += ".h5"
-        with h5py.File(filename, "w") as f:
+        """pyro's HDF5 layout; an .npz container with the same tree when h5py
+        is not installed (util/h5lite.py)"""
+        from ..util import h5lite
+        with h5lite.open_file(filename, "w") as f:
             self.write_data(f)
 
     def write_data(self, f):

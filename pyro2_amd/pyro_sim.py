@@ -95,6 +95,47 @@ class Pyro:
         self.sim.cc_data.t = 0.0
         self.is_initialized = True
 
+    def restart_problem(self, filename, *, inputs_dict=None):
+        """continue a run from an output file written by Simulation.write()
+        (the reference has no restart path).  The runtime
+        parameters stored in the file are re-applied (inputs_dict overrides,
+        e.g. driver.max_steps / driver.tmax), the problem is set up as usual
+        and the interior of every variable, the time, the step count and the
+        previous time step are taken from the file.  Ghost cells are refilled
+        by the first step, so with the standard boundary types the continued
+        run is bit-identical to the uninterrupted one."""
+        from .util import io_pyro
+        chk = io_pyro.read(filename)
+        info = getattr(chk, "restart_info", None)
+        if info is None or chk.solver_name != self.solver_name:
+            msg.fail(f"ERROR: {filename} is not an output file of the {self.solver_name} solver")
+        params = {}
+        for k, v in info["params"].items():
+            if isinstance(v, bytes):
+                v = v.decode()
+            params[k] = v.item() if hasattr(v, "item") else v
+        params.update(inputs_dict or {})
+        problem = chk.problem_name.decode() if isinstance(chk.problem_name, bytes) \
+            else chk.problem_name
+        for k, v in list(params.items()):      # parameters of the problem module come first
+            try:
+                self.rp.get_param(k)
+            except (KeyError, RuntimeError):
+                self.rp.set_param(k, v, no_new=False)
+        self.initialize_problem(problem, inputs_dict=params)
+        dst, src = self.sim.cc_data, chk.cc_data
+        if (dst.grid.nx, dst.grid.ny) != (src.grid.nx, src.grid.ny):
+            msg.fail("ERROR: the grid of the restart file does not match the inputs")
+        for name in src.names:
+            dst.get_var(name).v()[:, :] = src.get_var(name).v()
+        dst.t = float(src.t)
+        self.sim.n = int(chk.n)
+        if info["dt"] is not None:
+            self.sim.dt, self.sim.dt_old = float(info["dt"]), float(info["dt_old"])
+        else:       # a file written by pyro itself: no dt history
+            self.sim.n = max(self.sim.n, 1)
+            self.sim.dt_old = 1.e33
+
     def run_sim(self):
         if not self.is_initialized:
             msg.fail("ERROR: problem has not been initialized")

@@ -132,14 +132,16 @@ class NullSimulation:
     def write(self, filename):
         """HDF5 dump in the reference layout (simulation_null.py:270-290);
         this is a device -> host synchronisation point"""
-        import h5py
-        if not filename.endswith(".h5"):
-            filename += ".h5"
-        with h5py.File(filename, "w") as f:
+        from .util import h5lite
+        with h5lite.open_file(filename, "w") as f:
             f.attrs["solver"] = self.solver_name
             f.attrs["problem"] = self.problem_name
             f.attrs["time"] = self.cc_data.t
             f.attrs["nsteps"] = self.n
+            # not in the reference's files: lets a restart reproduce the
+            # max_dt_change limiter of the next step exactly
+            f.attrs["dt"] = self.dt
+            f.attrs["dt_old"] = self.dt_old
             self.cc_data.write_data(f)
             if self.particles is not None:
                 self.particles.write_particles(f)

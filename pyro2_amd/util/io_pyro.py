@@ -1,7 +1,8 @@
 """Read the HDF5 output files (layout of pyro/simulation_null.py:270-290 and
 pyro/mesh/patch.py:750-788) back into a Simulation / CellCenterData2d, API of
 pyro/util/io_pyro.py:27-148.  Files written by pyro itself are readable too
-(same layout).  Host-side I/O: needs h5py."""
+(same layout).  Host-side I/O through h5py, or through the .npz container of
+util/h5lite.py (same tree) when h5py is not installed."""
 import importlib
 
 from ..mesh import boundary as bnd
@@ -9,10 +10,8 @@ from ..mesh.patch import Cartesian2d, CellCenterData2d
 
 
 def read(filename):
-    import h5py
-    if not filename.endswith(".h5"):
-        filename += ".h5"
-    with h5py.File(filename, "r") as f:
+    from . import h5lite
+    with h5lite.open_file(filename, "r") as f:
         solver_name = f.attrs.get("solver")
         problem_name = f.attrs.get("problem")
         t = f.attrs.get("time")
@@ -23,6 +22,9 @@ def read(filename):
         myg = Cartesian2d(int(g["nx"]), int(g["ny"]), ng=int(g["ng"]), xmin=g["xmin"],
                           xmax=g["xmax"], ymin=g["ymin"], ymax=g["ymax"])
         names = list(f["state"])
+        dt, dt_old = f.attrs.get("dt"), f.attrs.get("dt_old")
+        params = dict(f["runtime parameters"].attrs.items()) \
+            if "runtime parameters" in f else {}
         myd = CellCenterData2d(myg)
         for n in names:
             a = f["state"][n].attrs
@@ -47,6 +49,8 @@ def read(filename):
         from ..simulation_null import NullSimulation
         sim = NullSimulation(solver_name, problem_name, None, None)
     sim.n = nsteps
+    # what a restart needs beyond the state (Pyro.restart_problem)
+    sim.restart_info = {"dt": dt, "dt_old": dt_old, "params": params}
     sim.cc_data = myd
     sim.cc_data.t = t
     try:

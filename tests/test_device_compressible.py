@@ -116,12 +116,14 @@ def test_comp_fused_vs_reference(dev, golden, k):
     assert abs(s.comp_dt(P, cfl) - dto) <= tol * dto
 
 
-def device_comp_run(dev, ic, meta, bcs, tmax, max_steps, **kw):
+def device_comp_run(dev, ic, meta, bcs, tmax, max_steps, ambient=None, **kw):
     """Pyro.run_sim loop (pyro_sim.py:219-256) with the device kernels"""
     P, cfl = dev_params(meta, **kw)
     nx, ny = int(meta[0]), int(meta[1])
     s = comp_state(dev, nx, ny, bcs)
-    s.upload(ic)
+    if any(b in ("hse", "ambient") for b in bcs):
+        s.set_user_bc(meta[5], meta[12], meta[4], ambient)
+    s.upload(np.nan_to_num(ic))
     pol = DtPolicy(tmax)
     dts = []
     while not (pol.t >= tmax or pol.n >= max_steps):
@@ -192,6 +194,22 @@ def test_comp_reference_regression_quad(hip, golden, fast, kset):
     for n in range(4):
         e = max_rel_err(U[4:-4, 4:-4, n], g["gold"][..., n])
         assert e < (1e-11 if not fast else TOL_FAST), (n, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kset", [0, 1])
+@pytest.mark.parametrize("fast", [0, 1])
+def test_comp_reference_regression_rt(hip, golden, fast, kset):
+    """pyro/test.py:102 -- rt_0945.h5 (64x192, 945 steps, gravity, hse
+    boundaries, periodic in x); momenta relative to the largest momentum"""
+    g = golden("comp_rt_0945")
+    bcs = [str(b) for b in g["bc"]]
+    U, dts, t = device_comp_run(hip, g["ic"], g["meta"], bcs, float(g["tmax"]), 10000,
+                                fast_math=fast, kernel_set=kset)
+    assert len(dts) == 945
+    scale = np.abs(g["gold"]).max(axis=(0, 1))
+    err = np.abs(U[4:-4, 4:-4] - g["gold"]).max(axis=(0, 1)) / scale
+    assert err.max() < (1e-11 if not fast else TOL_FAST), err
 
 
 @pytest.mark.gpu

@@ -198,9 +198,8 @@ def test_custom_problem_and_fill_bc(api):
 
 
 def test_hdf5_roundtrip_and_benchmark_compare(api, tmp_path):
-    """write() / io_pyro.read() / compare / PyroBenchmark (needs h5py, which the
-    default interpreter of this image lacks: skipped there, runs under conda)"""
-    pytest.importorskip("h5py")
+    """write() / io_pyro.read() / compare / PyroBenchmark: HDF5 through h5py when
+    it is installed, the .npz container with the same tree otherwise"""
     from pyro2_amd.pyro_sim import PyroBenchmark
     from pyro2_amd.util import compare, io_pyro
     p = PyroBenchmark("advection", make_bench=True, bench_dir=str(tmp_path) + "/bench/")
@@ -211,3 +210,41 @@ def test_hdf5_roundtrip_and_benchmark_compare(api, tmp_path):
     q = PyroBenchmark("advection", comp_bench=True, bench_dir=str(tmp_path) + "/bench/")
     q.initialize_problem("smooth", inputs_dict={"driver.max_steps": 3})
     assert q.run_sim() == 0
+
+
+def test_restart_is_bit_identical(api, tmp_path):
+    """row f3: write() -> Pyro.restart_problem() continues bit-identically
+    (state interior, t, n and the dt history come from the file)"""
+    from pyro2_amd.pyro_sim import Pyro
+    d = {"mesh.nx": 32, "mesh.ny": 24, "sedov.r_init": 0.12}
+    a = Pyro("compressible")
+    a.initialize_problem("sedov", inputs_dict=dict(d, **{"driver.max_steps": 6}))
+    a.run_sim()
+    b = Pyro("compressible")
+    b.initialize_problem("sedov", inputs_dict=dict(d, **{"driver.max_steps": 3}))
+    b.run_sim()
+    b.sim.write(str(tmp_path / "chk_0003"))
+    c = Pyro("compressible")
+    c.restart_problem(str(tmp_path / "chk_0003"), inputs_dict={"driver.max_steps": 6})
+    assert c.sim.n == 3 and c.sim.cc_data.t == b.sim.cc_data.t
+    assert c.rp.get_param("sedov.r_init") == 0.12 and c.sim.cc_data.grid.ny == 24
+    c.run_sim()
+    assert c.sim.n == 6 and c.sim.cc_data.t == a.sim.cc_data.t
+    assert np.array_equal(np.asarray(c.sim.cc_data.data)[4:-4, 4:-4],
+                          np.asarray(a.sim.cc_data.data)[4:-4, 4:-4])
+
+
+def test_h5lite_tree(tmp_path):
+    from pyro2_amd.util import h5lite
+    with h5lite.NpzFile(str(tmp_path / "t.pyro.npz"), "w") as f:
+        f.attrs["solver"] = "advection"
+        g = f.create_group("state").create_group("density")
+        g.create_dataset("data", data=np.arange(6.0).reshape(2, 3))
+        g.attrs["xlb"] = "periodic"
+        f.create_group("aux")
+    with h5lite.NpzFile(str(tmp_path / "t.pyro.npz"), "r") as f:
+        assert f.attrs["solver"] == "advection" and f.attrs.get("nope") is None
+        assert list(f["state"]) == ["density"] and "aux" in f and "nope" not in f
+        assert f["state"]["density"].attrs["xlb"] == "periodic"
+        assert f["state/density/data"][1, 2] == 5.0
+        assert list(f["aux"].attrs) == []

@@ -212,6 +212,23 @@ def test_comp_reference_regression_quad(golden):
         assert e < 1e-12, (n, e)   # measured 1.0e-13 (golden made with real numba)
 
 
+def test_comp_reference_regression_rt(golden):
+    """pyro/test.py:102: compressible rt inputs.rt vs rt_0945.h5 (64x192, 945
+    steps; gravity + hse boundaries): the oracle reproducing the reference's
+    STORED golden from the reference's IC.  RT growth amplifies round-off, so
+    the momenta are compared relative to the largest momentum."""
+    g = golden("comp_rt_0945")
+    bcs = [str(b) for b in g["bc"]]
+    f0, mx = g["drv"]
+    U, dts, t = oracle_comp_run(g["ic"], g["meta"], bcs, float(g["tmax"]), 10000, f0, mx)
+    assert len(dts) == int(g["nsteps"]) == 945
+    assert abs(t - float(g["t"])) < 1e-13
+    gold = g["gold"]
+    scale = np.abs(gold).max(axis=(0, 1))
+    err = np.abs(U[4:-4, 4:-4] - gold).max(axis=(0, 1)) / scale
+    assert err.max() < 1e-11, err
+
+
 def test_mg_variable_coefficient(golden):
     """variable_coeff_MG.VarCoeffCCMG2d: edge coefficients on three levels,
     smoother, residual and a 5-cycle solve against the reference"""
