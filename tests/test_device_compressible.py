@@ -315,7 +315,11 @@ def test_comp_hse_ambient_runs(dev, golden, k, kset):
     s.set_user_bc(meta[5], meta[12], meta[4], g[pre + "ambient"])
     s.upload(np.nan_to_num(g[pre + "ic"]))   # NaNs only in never-read y ghost rows
     dts_ref = g[pre + "dts"]
-    nsteps = len(dts_ref) if dev.kind == "hip" else 5
+    if dev.kind == "emu" and kset == 0 and k != 2:
+        pytest.skip("emulated backend: staged set on the smallest case only (time)")
+    # from step 8 on the CFL limit takes over, and its minimum sits in the hse
+    # ghost rows; the emulated backend runs that far on the smallest case only
+    nsteps = len(dts_ref) if dev.kind == "hip" else (9 if (k == 2 and kset == 1) else 4)
     f0, mx = g[pre + "drv"]
     pol = DtPolicy(1.e30, f0, mx)
     dts = []
