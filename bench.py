@@ -318,8 +318,9 @@ def main():
             "stream_event_ms_per_step": r["event_ms"] / args.steps,
         }
         # traffic: fabric bytes per launch from the committed rocprofv3 PMC
-        # passes (profiles/traffic.json, measured per cell at 8192^2 with the
-        # same kernel), scaled to this rank's cells; null for other kernel sets
+        # passes of this same default command (profiles/traffic.json, written by
+        # tools/gpu_round.sh + tools/make_traffic.py), scaled to this rank's
+        # cells; null for other kernel sets
         tr = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr) and defaults["kernel_set"] == 1:
             try:
