@@ -214,6 +214,40 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles,
                      int *num_cycles, double *residual_error,
                      double *relative_error);
 
+/* ---- burgers / incompressible (the solvers on top of the multigrid solver;
+        SURVEY.md 8 rows f1, f4) ------------------------------------------- */
+/* burgers Simulation.evolve (pyro/burgers/simulation.py:53-117 with
+   burgers_interface.py:4-312): one unsplit CTU step of (u, v) = variables
+   iu, iv of the state (ng >= 4, ghost cells filled)                        */
+int pyrohip_bg_step(pyrohip_state *s, int iu, int iv, double dx, double dy,
+                    double dt, int limiter);
+/* incompressible Simulation.evolve (pyro/incompressible/simulation.py:200-
+   330), the four device pieces around the two MG solves.  mg: a
+   pyrohip_mg with the state's nx (= ny) and the BCs of phi.
+   1. mac_rhs: edge states (incomp_interface.mac_vels :4-63), MAC velocities,
+      mg.f = div(U_MAC), mg.v = 0 (init_zeros), source norm (init_RHS)      */
+int pyrohip_inc_mac_rhs(pyrohip_state *s, pyrohip_mg *mg, int iu, int iv,
+                        int igpx, int igpy, double dx, double dy, double dt,
+                        int limiter, double *source_norm);
+/* 2. after mg solve: phi-MAC <- solution (buf 1), MAC correction, states()
+      (:66-136), advective terms and provisional velocity update (:286-304) */
+int pyrohip_inc_advect(pyrohip_state *s, pyrohip_mg *mg, int iu, int iv,
+                       int iphimac, int igpx, int igpy, double dx, double dy,
+                       double dt, int proj_type);
+/* 3. mg.f = cell-centred div(U) [/ dt], mg.v = phi on buf 1 (iphi >= 0) or 0
+      (:306-325; :99-103 for the initial projection of preevolve)           */
+int pyrohip_inc_proj_rhs(pyrohip_state *s, pyrohip_mg *mg, int iu, int iv,
+                         int iphi, double dx, double dy, double dt,
+                         int divide_by_dt, double *source_norm);
+/* 4. after mg solve: phi <- solution (buf 1, 0 elsewhere), (u,v) -= fac *
+      grad(solution); gp_mode 0: grad p untouched, 1: +=, 2: = (:327-339)   */
+int pyrohip_inc_proj_update(pyrohip_state *s, pyrohip_mg *mg, int iu, int iv,
+                            int iphi, int igpx, int igpy, double dx, double dy,
+                            double fac, int gp_mode);
+/* test hook: which 0-7 edge states u_xl u_xr u_yl u_yr v_xl v_xr v_yl v_yr,
+   8 u_MAC, 9 v_MAC, 10 advect_x, 11 advect_y -> host (qx, qy)              */
+int pyrohip_inc_stage_dump(pyrohip_state *s, int which, double *host);
+
 /* ---- multi-GPU: x-slab decomposition, one process per GPU, RCCL -------- */
 #define PYROHIP_UNIQUE_ID_BYTES 128
 int pyrohip_comm_unique_id(char *out_id /* PYROHIP_UNIQUE_ID_BYTES */);

@@ -388,6 +388,125 @@ def gen_compressible_rt():
                        p.rp.get_param("driver.max_dt_change")]))
 
 
+def _planes(cc):
+    """(nvar, qx, qy) planar copy of a CellCenterData2d"""
+    return np.ascontiguousarray(np.moveaxis(np.array(cc.data), -1, 0))
+
+
+def gen_incompressible():
+    """rows f1/f4: burgers (the CTU predictor shared with incompressible) and
+    the incompressible projection solver on top of the multigrid solver."""
+    import pyro.burgers.burgers_interface as bi
+    import pyro.incompressible.incomp_interface as ii
+    import pyro.incompressible.simulation as isim
+    from pyro.mesh import reconstruction as rec
+
+    out = {}
+    # ---- burgers: test problem (diagonal shock, outflow), no particles
+    for k, (nx, ny, lim, nsteps) in enumerate([(24, 24, 2, 10), (20, 28, 1, 8)]):
+        p = Pyro("burgers")
+        p.initialize_problem("test", inputs_dict={"mesh.nx": nx, "mesh.ny": ny,
+                                                  "advection.limiter": lim,
+                                                  "particles.do_particles": 0})
+        sim = p.sim
+        pre = f"b{k}_"
+        out[pre + "ic"] = _planes(sim.cc_data)
+        dts = []
+        for _ in range(nsteps):
+            p.single_step()
+            dts.append(sim.dt)
+        out[pre + "final"] = _planes(sim.cc_data)
+        out[pre + "dts"] = np.array(dts)
+        g = sim.cc_data.grid
+        out[pre + "meta"] = np.array([g.nx, g.ny, g.ng, g.dx, g.dy, lim,
+                                      sim.rp.get_param("driver.cfl")])
+        out[pre + "bc"] = bc_names(sim.rp)
+        # edge states of the next step
+        sim.cc_data.fill_BC_all()
+        sim.compute_timestep()
+        u, v = sim.cc_data.get_var("x-velocity"), sim.cc_data.get_var("y-velocity")
+        ld = [rec.limit(a, g, d, lim) for a, d in ((u, 1), (v, 1), (u, 2), (v, 2))]
+        E = bi.get_interface_states(g, sim.dt, u, v, *ld)
+        E = bi.apply_transverse_corrections(g, sim.dt, *E)
+        out[pre + "U0"] = _planes(sim.cc_data)
+        out[pre + "dt"] = np.array(sim.dt)
+        out[pre + "E"] = np.array([np.array(e) for e in E])
+        print("burgers case", k, nx, ny, "dt", sim.dt)
+    out["nburgers"] = np.array(2)
+
+    # ---- incompressible shear: IC before preevolve, state after it, a run,
+    #      and the pieces of one more step
+    store = {}
+    orig_pre = isim.Simulation.preevolve
+
+    def preevolve(self):
+        store["ic"] = _planes(self.cc_data)
+        orig_pre(self)
+        store["after_pre"] = _planes(self.cc_data)
+    isim.Simulation.preevolve = preevolve
+    for k, (nx, lim, proj, nsteps) in enumerate([(32, 2, 2, 6), (16, 1, 1, 5)]):
+        p = Pyro("incompressible")
+        p.initialize_problem("shear", inputs_dict={"mesh.nx": nx, "mesh.ny": nx,
+                                                   "incompressible.limiter": lim,
+                                                   "incompressible.proj_type": proj})
+        sim = p.sim
+        pre = f"i{k}_"
+        out[pre + "ic"] = store["ic"]
+        out[pre + "after_pre"] = store["after_pre"]
+        dts = []
+        for _ in range(nsteps):
+            p.single_step()
+            dts.append(sim.dt)
+        out[pre + "final"] = _planes(sim.cc_data)
+        out[pre + "dts"] = np.array(dts)
+        g = sim.cc_data.grid
+        out[pre + "meta"] = np.array([g.nx, g.ng, lim, proj, sim.rp.get_param("driver.cfl"),
+                                      sim.rp.get_param("driver.init_tstep_factor"),
+                                      sim.rp.get_param("driver.max_dt_change")])
+        # one more step with the MAC velocities captured
+        sim.cc_data.fill_BC_all()
+        sim.compute_timestep()
+        out[pre + "U0"] = _planes(sim.cc_data)
+        out[pre + "dt"] = np.array(sim.dt)
+        cap = {}
+        orig_states = ii.states
+
+        def states(grid, dt, u, v, a, b, c, d, gx, gy, u_MAC, v_MAC, sx=None, sy=None):
+            cap["umac"], cap["vmac"] = np.array(u_MAC), np.array(v_MAC)
+            return orig_states(grid, dt, u, v, a, b, c, d, gx, gy, u_MAC, v_MAC, sx, sy)
+        ii.states = states
+        sim.evolve()
+        ii.states = orig_states
+        out[pre + "umac"], out[pre + "vmac"] = cap["umac"], cap["vmac"]
+        out[pre + "U1"] = _planes(sim.cc_data)
+        print("incompressible case", k, nx, "dt", sim.dt)
+    out["nincomp"] = np.array(2)
+    save("incomp", **out)
+
+    # ---- reference regression: incompressible shear inputs.shear (128^2, 216
+    # steps) vs pyro/incompressible/tests/shear_128_0216.h5 (test.py:110)
+    p = Pyro("incompressible")
+    p.initialize_problem("shear", inputs_file="inputs.shear")
+    ic = store["ic"]
+    while not p.sim.finished():
+        p.single_step()
+    names = ["x-velocity", "y-velocity", "phi-MAC", "phi", "gradp_x", "gradp_y"]
+    with h5py.File(REF + "/incompressible/tests/shear_128_0216.h5", "r") as f:
+        assert int(f.attrs["nsteps"]) == p.sim.n, (f.attrs["nsteps"], p.sim.n)
+        gold = np.array([f["state/" + nm + "/data"][...] for nm in names])
+        tfin = float(f.attrs["time"])
+    run = np.array([np.array(p.sim.cc_data.get_var(nm).v()) for nm in names])
+    print("shear_128: reference-run vs stored golden, max abs err per var",
+          np.abs(run - gold).max(axis=(1, 2)))
+    isim.Simulation.preevolve = orig_pre
+    save("incomp_shear_128_0216", ic=ic[:2], gold=gold[:2].astype(np.float64),
+         gold_gp=gold[4:6], run=run[:2], run_gp=run[4:6], nsteps=np.array(p.sim.n),
+         t=np.array(tfin), tmax=np.array(p.sim.tmax),
+         meta=np.array([128, 4, 2, 2, p.rp.get_param("driver.cfl"),
+                        p.rp.get_param("driver.init_tstep_factor"),
+                        p.rp.get_param("driver.max_dt_change")]))
+
+
 def _raw_cfl_dt(sim):
     dt_keep, dto_keep = sim.dt, sim.dt_old
     sim.method_compute_timestep()
@@ -657,6 +776,8 @@ if __name__ == "__main__":
         gen_compressible_hse()
     if "comp_rt" in sys.argv[1:]:
         gen_compressible_rt()
+    if "incomp" in sys.argv[1:]:
+        gen_incompressible()
     which = sys.argv[1:] or ["bc", "adv", "comp_stages", "comp_runs", "mg", "diffusion"]
     if "diffusion" in which:
         gen_diffusion()

@@ -319,3 +319,65 @@ class VCMG(MG):
         self.num_cycles = int(g(self.h, 1))
         self.relative_error = g(self.h, 2)
         self.residual_error = g(self.h, 3)
+
+
+# ---- burgers / incompressible (rows f1, f4) ------------------------------
+def bg_edge_states(u, v, gpx, gpy, nx, ny, ng, dx, dy, dt, limiter):
+    """8 planes u_xl,u_xr,u_yl,u_yr,v_xl,v_xr,v_yl,v_yr"""
+    E = np.zeros((8,) + u.shape)
+    lib().orc_bg_edge_states(_p(u), _p(v), None if gpx is None else _p(gpx),
+                             None if gpy is None else _p(gpy), nx, ny, ng,
+                             C.c_double(dx), C.c_double(dy), C.c_double(dt), limiter, _p(E))
+    return E
+
+
+def bg_dt(u, v, nx, ny, ng, dx, dy, cfl):
+    f = lib().orc_bg_dt
+    f.restype = C.c_double
+    return f(_p(u), _p(v), nx, ny, ng, C.c_double(dx), C.c_double(dy), C.c_double(cfl))
+
+
+def bg_step(u, v, nx, ny, ng, dx, dy, dt, limiter):
+    lib().orc_bg_step(_p(u), _p(v), nx, ny, ng, C.c_double(dx), C.c_double(dy),
+                      C.c_double(dt), limiter)
+
+
+def _bc4(bcs):
+    return np.ascontiguousarray(bc_codes(bcs))
+
+
+def incomp_step(D, nx, ng, dt, limiter=2, proj_type=2, bc_u=("periodic",) * 4,
+                bc_v=("periodic",) * 4, bc_phi=("periodic",) * 4,
+                xmin=0.0, xmax=1.0, ymin=0.0, ymax=1.0, stages=False):
+    """one incompressible evolve() on D = (6, qx, qy) planes u, v, phi-MAC,
+    phi, gradp_x, gradp_y.  Returns dict(ncyc=..., [umac, vmac, adv])"""
+    _ck(D)
+    N = D.shape[1:]
+    um = np.zeros(N) if stages else None
+    vm = np.zeros(N) if stages else None
+    adv = np.zeros((2,) + N) if stages else None
+    ncyc = (C.c_int * 2)()
+    bu, bv, bp = _bc4(bc_u), _bc4(bc_v), _bc4(bc_phi)
+    ip = C.POINTER(C.c_int)
+    lib().orc_incomp_step(_p(D), nx, ng, C.c_double(xmin), C.c_double(xmax), C.c_double(ymin),
+                          C.c_double(ymax), C.c_double(dt), limiter, proj_type,
+                          bu.ctypes.data_as(ip), bv.ctypes.data_as(ip), bp.ctypes.data_as(ip), 0,
+                          None if um is None else _p(um), None if vm is None else _p(vm),
+                          None if adv is None else _p(adv), ncyc)
+    out = {"ncyc": (ncyc[0], ncyc[1])}
+    if stages:
+        out.update(umac=um, vmac=vm, adv=adv)
+    return out
+
+
+def incomp_preevolve(D, nx, ng, cfl, limiter=2, proj_type=2, bc_u=("periodic",) * 4,
+                     bc_v=("periodic",) * 4, bc_phi=("periodic",) * 4,
+                     xmin=0.0, xmax=1.0, ymin=0.0, ymax=1.0):
+    _ck(D)
+    bu, bv, bp = _bc4(bc_u), _bc4(bc_v), _bc4(bc_phi)
+    ip = C.POINTER(C.c_int)
+    f = lib().orc_incomp_preevolve
+    f.restype = C.c_double
+    return f(_p(D), nx, ng, C.c_double(xmin), C.c_double(xmax), C.c_double(ymin),
+             C.c_double(ymax), C.c_double(cfl), limiter, proj_type,
+             bu.ctypes.data_as(ip), bv.ctypes.data_as(ip), bp.ctypes.data_as(ip))

@@ -1575,3 +1575,329 @@ void orc_vcmg_solve(orc_vcmg *V, double rtol)
     orc_mg_fill_bc_v(m, L);
     free(old_phi);
 }
+
+/* ================================================================== */
+/* Burgers / incompressible: the callers of the  */
+/* multigrid solver named in north_star.                                */
+/*   pyro/burgers/burgers_interface.py:4-312                            */
+/*   pyro/incompressible/incomp_interface.py:4-254                      */
+/*   pyro/incompressible/simulation.py:77-330                           */
+/* Planar arrays (qx,qy).  Region "B2" = valid region grown by 2; the   */
+/* reference works on zero-initialised scratch arrays and never writes  */
+/* outside the stated regions, so reads just outside them see 0.        */
+/* ================================================================== */
+enum { E_UXL, E_UXR, E_UYL, E_UYR, E_VXL, E_VXR, E_VYL, E_VYR };
+
+/* burgers_interface.py:265-290 */
+static inline double bg_riemann(double ql, double qr)
+{
+    if (ql <= 0.0 && qr >= 0.0) return 0.0;
+    return (ql > 0.0 && ql + qr > 0.0) ? ql : qr;
+}
+/* burgers_interface.py:236-262 */
+static inline double bg_upwind(double ql, double qr, double s)
+{
+    if (s == 0.0) return 0.5 * (ql + qr);
+    return (s > 0.0) ? ql : qr;
+}
+
+/* get_interface_states (:4-86) + apply_transverse_corrections (:89-175) +
+   apply_gradp_corrections (incomp_interface.py:139-183; gpx == NULL: burgers).
+   E: 8 planes, zeroed here.  */
+void orc_bg_edge_states(const double *u, const double *v, const double *gpx,
+                        const double *gpy, int nx, int ny, int ng, double dx,
+                        double dy, double dt, int limiter, double *E)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx - 1, jlo = ng, jhi = ng + ny - 1;
+    const size_t N = (size_t)qx * qy;
+#define I2(i, j) ((size_t)(i) * qy + (j))
+    double *ldux = zalloc(N), *ldvx = zalloc(N), *lduy = zalloc(N), *ldvy = zalloc(N);
+    orc_limit(u, 1, nx, ny, ng, 1, limiter, ldux);
+    orc_limit(v, 1, nx, ny, ng, 1, limiter, ldvx);
+    orc_limit(u, 1, nx, ny, ng, 2, limiter, lduy);
+    orc_limit(v, 1, nx, ny, ng, 2, limiter, ldvy);
+    memset(E, 0, 8 * N * sizeof(double));
+    double *uxl = E + E_UXL * N, *uxr = E + E_UXR * N, *uyl = E + E_UYL * N,
+           *uyr = E + E_UYR * N, *vxl = E + E_VXL * N, *vxr = E + E_VXR * N,
+           *vyl = E + E_VYL * N, *vyr = E + E_VYR * N;
+    const double dtdx = dt / dx, dtdy = dt / dy;
+    for (int i = ilo - 2; i <= ihi + 2; i++)
+        for (int j = jlo - 2; j <= jhi + 2; j++) {
+            const size_t k = I2(i, j);
+            const double uc = u[k], vc = v[k];
+            uxl[I2(i + 1, j)] = uc + 0.5 * (1.0 - dtdx * uc) * ldux[k];
+            uxr[k] = uc - 0.5 * (1.0 + dtdx * uc) * ldux[k];
+            vxl[I2(i + 1, j)] = vc + 0.5 * (1.0 - dtdx * uc) * ldvx[k];
+            vxr[k] = vc - 0.5 * (1.0 + dtdx * uc) * ldvx[k];
+            uyl[I2(i, j + 1)] = uc + 0.5 * (1.0 - dtdy * vc) * lduy[k];
+            uyr[k] = uc - 0.5 * (1.0 + dtdy * vc) * lduy[k];
+            vyl[I2(i, j + 1)] = vc + 0.5 * (1.0 - dtdy * vc) * ldvy[k];
+            vyr[k] = vc - 0.5 * (1.0 + dtdy * vc) * ldvy[k];
+        }
+    /* transverse terms from the uncorrected states */
+    double *uhat = zalloc(N), *vhat = zalloc(N), *uxi = zalloc(N), *vxi = zalloc(N),
+           *uyi = zalloc(N), *vyi = zalloc(N);
+    for (int i = ilo - 2; i <= ihi + 2; i++)
+        for (int j = jlo - 2; j <= jhi + 2; j++) {
+            const size_t k = I2(i, j);
+            uhat[k] = bg_riemann(uxl[k], uxr[k]);
+            vhat[k] = bg_riemann(vyl[k], vyr[k]);
+            uxi[k] = bg_upwind(uxl[k], uxr[k], uhat[k]);
+            vxi[k] = bg_upwind(vxl[k], vxr[k], uhat[k]);
+            uyi[k] = bg_upwind(uyl[k], uyr[k], vhat[k]);
+            vyi[k] = bg_upwind(vyl[k], vyr[k], vhat[k]);
+        }
+    for (int i = ilo - 2; i <= ihi + 2; i++)
+        for (int j = jlo - 2; j <= jhi + 2; j++) {
+            const size_t k = I2(i, j);
+            const double ubar = 0.5 * (uhat[k] + uhat[I2(i + 1, j)]);
+            const double vbar = 0.5 * (vhat[k] + vhat[I2(i, j + 1)]);
+            const double tu = -0.5 * dtdy * vbar * (uyi[I2(i, j + 1)] - uyi[k]);
+            const double tv = -0.5 * dtdy * vbar * (vyi[I2(i, j + 1)] - vyi[k]);
+            uxl[I2(i + 1, j)] += tu;  uxr[k] += tu;
+            vxl[I2(i + 1, j)] += tv;  vxr[k] += tv;
+            const double sv = -0.5 * dtdx * ubar * (vxi[I2(i + 1, j)] - vxi[k]);
+            const double su = -0.5 * dtdx * ubar * (uxi[I2(i + 1, j)] - uxi[k]);
+            vyl[I2(i, j + 1)] += sv;  vyr[k] += sv;
+            uyl[I2(i, j + 1)] += su;  uyr[k] += su;
+            if (gpx) {
+                const double gx = -0.5 * dt * gpx[k], gy = -0.5 * dt * gpy[k];
+                uxl[I2(i + 1, j)] += gx;  uxr[k] += gx;
+                vxl[I2(i + 1, j)] += gy;  vxr[k] += gy;
+                vyl[I2(i, j + 1)] += gy;  vyr[k] += gy;
+                uyl[I2(i, j + 1)] += gx;  uyr[k] += gx;
+            }
+        }
+    free(ldux); free(ldvx); free(lduy); free(ldvy);
+    free(uhat); free(vhat); free(uxi); free(vxi); free(uyi); free(vyi);
+#undef I2
+}
+
+/* burgers/simulation.py:37-51 (SMALL = 1e-12, simulation_null.py) */
+double orc_bg_dt(const double *u, const double *v, int nx, int ny, int ng,
+                 double dx, double dy, double cfl)
+{
+    const size_t N = (size_t)(nx + 2 * ng) * (ny + 2 * ng);
+    double um = 0.0, vm = 0.0;
+    for (size_t k = 0; k < N; k++) { um = dmax(um, fabs(u[k])); vm = dmax(vm, fabs(v[k])); }
+    return cfl * dmin(dx / dmax(um, 1.e-12), dy / dmax(vm, 1.e-12));
+}
+
+/* burgers/simulation.py:53-117 + construct_unsplit_fluxes (:178-233) */
+void orc_bg_step(double *u, double *v, int nx, int ny, int ng, double dx,
+                 double dy, double dt, int limiter)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx - 1, jlo = ng, jhi = ng + ny - 1;
+    const size_t N = (size_t)qx * qy;
+#define I2(i, j) ((size_t)(i) * qy + (j))
+    double *E = zalloc(8 * N);
+    orc_bg_edge_states(u, v, NULL, NULL, nx, ny, ng, dx, dy, dt, limiter, E);
+    double *fux = zalloc(N), *fvx = zalloc(N), *fuy = zalloc(N), *fvy = zalloc(N);
+    for (int i = ilo - 2; i <= ihi + 2; i++)
+        for (int j = jlo - 2; j <= jhi + 2; j++) {
+            const size_t k = I2(i, j);
+            const double um = bg_upwind(E[E_UXL * N + k], E[E_UXR * N + k],
+                                        bg_riemann(E[E_UXL * N + k], E[E_UXR * N + k]));
+            const double vm = bg_upwind(E[E_VYL * N + k], E[E_VYR * N + k],
+                                        bg_riemann(E[E_VYL * N + k], E[E_VYR * N + k]));
+            fux[k] = 0.5 * bg_upwind(E[E_UXL * N + k], E[E_UXR * N + k], um) * um;
+            fvx[k] = 0.5 * bg_upwind(E[E_VXL * N + k], E[E_VXR * N + k], um) * um;
+            fuy[k] = 0.5 * bg_upwind(E[E_UYL * N + k], E[E_UYR * N + k], vm) * vm;
+            fvy[k] = 0.5 * bg_upwind(E[E_VYL * N + k], E[E_VYR * N + k], vm) * vm;
+        }
+    const double dtdx = dt / dx, dtdy = dt / dy;
+    for (int i = ilo; i <= ihi; i++)
+        for (int j = jlo; j <= jhi; j++) {
+            const size_t k = I2(i, j);
+            u[k] = u[k] + dtdx * (fux[k] - fux[I2(i + 1, j)]) + dtdy * (fuy[k] - fuy[I2(i, j + 1)]);
+            v[k] = v[k] + dtdx * (fvx[k] - fvx[I2(i + 1, j)]) + dtdy * (fvy[k] - fvy[I2(i, j + 1)]);
+        }
+    free(E); free(fux); free(fvx); free(fuy); free(fvy);
+#undef I2
+}
+
+/* copy (qx,qy) interior [+buf] <-> MG level array (n+2)^2 */
+static inline size_t mgk(int n, int i, int j) { return (size_t)i * (n + 2) + j; }
+
+/* incompressible/simulation.py:200-330, one evolve().  D: 6 planes
+   u, v, phi-MAC, phi, gradp_x, gradp_y (registration order :35-55); ghost
+   cells of u, v filled on entry and on exit.  bc_u/bc_v/bc_phi: 4 codes each.
+   Optional stage outputs (any may be NULL): o_umac/o_vmac (after the MAC
+   projection), o_adv (2 planes).  Returns the number of V-cycles of the two
+   solves in ncyc[2]. */
+void orc_incomp_step(double *D, int nx, int ng, double xmin, double xmax,
+                     double ymin, double ymax, double dt, int limiter,
+                     int proj_type, const int *bc_u, const int *bc_v,
+                     const int *bc_phi, int in_preevolve_unused,
+                     double *o_umac, double *o_vmac, double *o_adv, int *ncyc)
+{
+    (void)in_preevolve_unused;
+    const int ny = nx;
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx - 1, jlo = ng, jhi = ng + ny - 1;
+    const size_t N = (size_t)qx * qy;
+    const double dx = (xmax - xmin) / nx, dy = (ymax - ymin) / ny;
+    double *u = D, *v = D + N, *phiM = D + 2 * N, *phi = D + 3 * N, *gpx = D + 4 * N,
+           *gpy = D + 5 * N;
+#define I2(i, j) ((size_t)(i) * qy + (j))
+    double *E = zalloc(8 * N);
+    orc_bg_edge_states(u, v, gpx, gpy, nx, ny, ng, dx, dy, dt, limiter, E);
+    /* mac_vels: riemann_and_upwind on B2 (incomp_interface.py:62-63) */
+    double *um = zalloc(N), *vm = zalloc(N);
+    for (int i = ilo - 2; i <= ihi + 2; i++)
+        for (int j = jlo - 2; j <= jhi + 2; j++) {
+            const size_t k = I2(i, j);
+            um[k] = bg_upwind(E[E_UXL * N + k], E[E_UXR * N + k],
+                              bg_riemann(E[E_UXL * N + k], E[E_UXR * N + k]));
+            vm[k] = bg_upwind(E[E_VYL * N + k], E[E_VYR * N + k],
+                              bg_riemann(E[E_VYL * N + k], E[E_VYR * N + k]));
+        }
+    /* MAC projection (:232-262) */
+    orc_mg *m = orc_mg_create(nx, xmin, xmax, ymin, ymax, bc_phi, 0.0, -1.0, 10, 50);
+    const int L = m->nlevels - 1, n = nx;
+    for (int i = 0; i < nx; i++)
+        for (int j = 0; j < ny; j++)
+            m->f[L][mgk(n, i + 1, j + 1)] =
+                (um[I2(ilo + i + 1, jlo + j)] - um[I2(ilo + i, jlo + j)]) / dx +
+                (vm[I2(ilo + i, jlo + j + 1)] - vm[I2(ilo + i, jlo + j)]) / dy;
+    orc_mg_init_rhs_norm(m);
+    orc_mg_solve(m, 1.e-12);
+    if (ncyc) ncyc[0] = m->num_cycles;
+    for (int i = -1; i <= nx; i++)
+        for (int j = -1; j <= ny; j++)
+            phiM[I2(ilo + i, jlo + j)] = m->v[L][mgk(n, i + 1, j + 1)];
+    for (int i = ilo; i <= ihi + 1; i++)
+        for (int j = jlo; j <= jhi; j++)
+            um[I2(i, j)] -= (phiM[I2(i, j)] - phiM[I2(i - 1, j)]) / dx;
+    for (int i = ilo; i <= ihi; i++)
+        for (int j = jlo; j <= jhi + 1; j++)
+            vm[I2(i, j)] -= (phiM[I2(i, j)] - phiM[I2(i, j - 1)]) / dy;
+    if (o_umac) memcpy(o_umac, um, N * 8);
+    if (o_vmac) memcpy(o_vmac, vm, N * 8);
+    /* states (:264-277) + provisional update (:286-304) */
+    double *ax = zalloc(N), *ay = zalloc(N);
+    {
+        double *uxi = zalloc(N), *vxi = zalloc(N), *uyi = zalloc(N), *vyi = zalloc(N);
+        for (int i = ilo - 2; i <= ihi + 2; i++)
+            for (int j = jlo - 2; j <= jhi + 2; j++) {
+                const size_t k = I2(i, j);
+                uxi[k] = bg_upwind(E[E_UXL * N + k], E[E_UXR * N + k], um[k]);
+                vxi[k] = bg_upwind(E[E_VXL * N + k], E[E_VXR * N + k], um[k]);
+                uyi[k] = bg_upwind(E[E_UYL * N + k], E[E_UYR * N + k], vm[k]);
+                vyi[k] = bg_upwind(E[E_VYL * N + k], E[E_VYR * N + k], vm[k]);
+            }
+        for (int i = ilo; i <= ihi; i++)
+            for (int j = jlo; j <= jhi; j++) {
+                const size_t k = I2(i, j), ki = I2(i + 1, j), kj = I2(i, j + 1);
+                ax[k] = 0.5 * (um[k] + um[ki]) * (uxi[ki] - uxi[k]) / dx +
+                        0.5 * (vm[k] + vm[kj]) * (uyi[kj] - uyi[k]) / dy;
+                ay[k] = 0.5 * (um[k] + um[ki]) * (vxi[ki] - vxi[k]) / dx +
+                        0.5 * (vm[k] + vm[kj]) * (vyi[kj] - vyi[k]) / dy;
+            }
+        free(uxi); free(vxi); free(uyi); free(vyi);
+    }
+    if (o_adv) { memcpy(o_adv, ax, N * 8); memcpy(o_adv + N, ay, N * 8); }
+    for (size_t k = 0; k < N; k++) {
+        if (proj_type == 1) {
+            u[k] -= (dt * ax[k] + dt * gpx[k]);
+            v[k] -= (dt * ay[k] + dt * gpy[k]);
+        } else {
+            u[k] -= dt * ax[k];
+            v[k] -= dt * ay[k];
+        }
+    }
+    orc_fill_ghost(u, nx, ny, ng, 1, 0, bc_u);
+    orc_fill_ghost(v, nx, ny, ng, 1, 0, bc_v);
+    /* final projection (:306-330) */
+    for (int l = 0; l <= L; l++) {
+        size_t Nl = (size_t)(m->n[l] + 2) * (m->n[l] + 2);
+        memset(m->v[l], 0, Nl * 8); memset(m->f[l], 0, Nl * 8); memset(m->r[l], 0, Nl * 8);
+    }
+    for (int i = 0; i < nx; i++)
+        for (int j = 0; j < ny; j++) {
+            const int gi = ilo + i, gj = jlo + j;
+            const double d = 0.5 * (u[I2(gi + 1, gj)] - u[I2(gi - 1, gj)]) / dx +
+                             0.5 * (v[I2(gi, gj + 1)] - v[I2(gi, gj - 1)]) / dy;
+            m->f[L][mgk(n, i + 1, j + 1)] = d / dt;
+        }
+    orc_mg_init_rhs_norm(m);
+    for (int i = -1; i <= nx; i++)
+        for (int j = -1; j <= ny; j++)
+            m->v[L][mgk(n, i + 1, j + 1)] = phi[I2(ilo + i, jlo + j)];
+    orc_mg_solve(m, 1.e-12);
+    if (ncyc) ncyc[1] = m->num_cycles;
+    memset(phi, 0, N * 8);
+    for (int i = -1; i <= nx; i++)
+        for (int j = -1; j <= ny; j++)
+            phi[I2(ilo + i, jlo + j)] = m->v[L][mgk(n, i + 1, j + 1)];
+    if (proj_type == 2) { memset(gpx, 0, N * 8); memset(gpy, 0, N * 8); }
+    for (int i = 0; i < nx; i++)
+        for (int j = 0; j < ny; j++) {
+            const size_t k = I2(ilo + i, jlo + j);
+            const double gx = 0.5 * (m->v[L][mgk(n, i + 2, j + 1)] - m->v[L][mgk(n, i, j + 1)]) / dx;
+            const double gy = 0.5 * (m->v[L][mgk(n, i + 1, j + 2)] - m->v[L][mgk(n, i + 1, j)]) / dy;
+            u[k] -= dt * gx;
+            v[k] -= dt * gy;
+            if (proj_type == 1) { gpx[k] += gx; gpy[k] += gy; }
+            else { gpx[k] = gx; gpy[k] = gy; }
+        }
+    orc_fill_ghost(u, nx, ny, ng, 1, 0, bc_u);
+    orc_fill_ghost(v, nx, ny, ng, 1, 0, bc_v);
+    orc_mg_free(m);
+    free(E); free(um); free(vm); free(ax); free(ay);
+#undef I2
+}
+
+/* incompressible/simulation.py:77-143: initial projection of (u, v), then one
+   throw-away evolve() whose only surviving product is gradp.  Returns the dt
+   used for that evolve. */
+double orc_incomp_preevolve(double *D, int nx, int ng, double xmin, double xmax,
+                            double ymin, double ymax, double cfl, int limiter,
+                            int proj_type, const int *bc_u, const int *bc_v,
+                            const int *bc_phi)
+{
+    const int ny = nx;
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, jlo = ng;
+    const size_t N = (size_t)qx * qy;
+    const double dx = (xmax - xmin) / nx, dy = (ymax - ymin) / ny;
+    double *u = D, *v = D + N, *phi = D + 3 * N;
+#define I2(i, j) ((size_t)(i) * qy + (j))
+    orc_fill_ghost(u, nx, ny, ng, 1, 0, bc_u);
+    orc_fill_ghost(v, nx, ny, ng, 1, 0, bc_v);
+    const int per[4] = {BC_PERIODIC, BC_PERIODIC, BC_PERIODIC, BC_PERIODIC}; /* :90-97 */
+    orc_mg *m = orc_mg_create(nx, xmin, xmax, ymin, ymax, per, 0.0, -1.0, 10, 50);
+    const int L = m->nlevels - 1, n = nx;
+    for (int i = 0; i < nx; i++)
+        for (int j = 0; j < ny; j++) {
+            const int gi = ilo + i, gj = jlo + j;
+            m->f[L][mgk(n, i + 1, j + 1)] = 0.5 * (u[I2(gi + 1, gj)] - u[I2(gi - 1, gj)]) / dx +
+                                            0.5 * (v[I2(gi, gj + 1)] - v[I2(gi, gj - 1)]) / dy;
+        }
+    orc_mg_init_rhs_norm(m);
+    orc_mg_solve(m, 1.e-10);
+    memset(phi, 0, N * 8);
+    for (int i = -1; i <= nx; i++)
+        for (int j = -1; j <= ny; j++)
+            phi[I2(ilo + i, jlo + j)] = m->v[L][mgk(n, i + 1, j + 1)];
+    for (int i = 0; i < nx; i++)
+        for (int j = 0; j < ny; j++) {
+            const size_t k = I2(ilo + i, jlo + j);
+            u[k] -= 0.5 * (m->v[L][mgk(n, i + 2, j + 1)] - m->v[L][mgk(n, i, j + 1)]) / dx;
+            v[k] -= 0.5 * (m->v[L][mgk(n, i + 1, j + 2)] - m->v[L][mgk(n, i + 1, j)]) / dy;
+        }
+    orc_mg_free(m);
+    orc_fill_ghost(u, nx, ny, ng, 1, 0, bc_u);
+    orc_fill_ghost(v, nx, ny, ng, 1, 0, bc_v);
+    double *T = (double *)malloc(6 * N * 8);
+    memcpy(T, D, 6 * N * 8);
+    const double dt = orc_bg_dt(T, T + N, nx, ny, ng, dx, dy, cfl);
+    orc_incomp_step(T, nx, ng, xmin, xmax, ymin, ymax, dt, limiter, proj_type, bc_u, bc_v,
+                    bc_phi, 1, NULL, NULL, NULL, NULL);
+    memcpy(D + 4 * N, T + 4 * N, 2 * N * 8);   /* gradp_x, gradp_y */
+    free(T);
+#undef I2
+    return dt;
+}

@@ -68,6 +68,16 @@ _PROTOS = {
     "pyrohip_state_upload_rows": [_VP, C.c_int, C.c_int, _DP],
     "pyrohip_state_download_rows": [_VP, C.c_int, C.c_int, _DP],
     "pyrohip_device_count": [C.POINTER(C.c_int)],
+    "pyrohip_bg_step": [_VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int],
+    "pyrohip_inc_mac_rhs": [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                            C.c_double, C.c_double, C.c_int, _DP],
+    "pyrohip_inc_advect": [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                           C.c_double, C.c_double, C.c_int],
+    "pyrohip_inc_proj_rhs": [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                             C.c_double, C.c_int, _DP],
+    "pyrohip_inc_proj_update": [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_double, C.c_double, C.c_double, C.c_int],
+    "pyrohip_inc_stage_dump": [_VP, C.c_int, _DP],
     "pyrohip_fill_bc": [_VP, C.c_int],
     "pyrohip_state_set_user_bc": [_VP, C.c_double, C.c_double, C.c_double, _DP],
     "pyrohip_state_minmax": [_VP, C.c_int, C.c_int, _DP, _DP],

@@ -31,6 +31,7 @@ UNITS = [
     ("comp_fused.hip", "fused_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1"]),
     ("comp_api.hip", "comp_api", ["-ffp-contract=off"]),
     ("multigrid.hip", "multigrid", ["-ffp-contract=off"]),
+    ("incompressible.hip", "incompressible", ["-ffp-contract=off"]),
     ("comm.hip", "comm", ["-ffp-contract=off"]),
 ]
 

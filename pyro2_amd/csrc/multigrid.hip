@@ -24,6 +24,7 @@
 // explicit fill kernel, which runs wherever the reference calls fill_BC
 // outside the colour loop.
 #include "common.h"
+#include "mg_internal.h"
 #include "reduce.h"
 #include "stencil.h"
 
@@ -1277,6 +1278,7 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
         cycle++;
     }
     PYRO_TRY(mg_fill(m, Lf, 0));                          // :697
+    m->corners_stale[Lf] = false;
     PYRO_CHECK_HIP(hipGetLastError());
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
     if (num_cycles) *num_cycles = cycle - 1;
@@ -1286,3 +1288,36 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
 }
 
 }  // extern "C"
+
+// ---- mg_internal.h ----------------------------------------------------------
+namespace pyro {
+
+int mg_finest(pyrohip_mg *m, MgFinest *out)
+{
+    PYRO_REQUIRE(m && out, "NULL argument");
+    const int Lf = m->nlevels - 1;
+    const MGLevel &F = m->lev[Lf];
+    *out = MgFinest{m->ctx, Lf, F.n, F.pitch, F.dx, F.v, F.f, F.r};
+    return 0;
+}
+
+int mg_solution_written(pyrohip_mg *m)
+{
+    PYRO_REQUIRE(m, "NULL mg");
+    m->corners_stale[m->nlevels - 1] = false;
+    return 0;
+}
+
+int mg_solution_ghosts(pyrohip_mg *m)
+{
+    PYRO_REQUIRE(m, "NULL mg");
+    const int Lf = m->nlevels - 1;
+    if (m->corners_stale[Lf]) {
+        PYRO_TRY(mg_fill(m, Lf, 0));
+        m->corners_stale[Lf] = false;
+        PYRO_CHECK_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+}  // namespace pyro

@@ -193,6 +193,49 @@ class DeviceState:
         with self.ctx.lock:
             check(self._l.pyrohip_fill_bc(self.h, int(n)))
 
+    # ---- burgers / incompressible (csrc/incompressible.hip) ----------------
+    def bg_step(self, iu, iv, dx, dy, dt, limiter):
+        with self.ctx.lock:
+            check(self._l.pyrohip_bg_step(self.h, int(iu), int(iv), float(dx), float(dy),
+                                          float(dt), int(limiter)))
+
+    def inc_mac_rhs(self, mg, iu, iv, igpx, igpy, dx, dy, dt, limiter):
+        out = C.c_double()
+        with self.ctx.lock:
+            check(self._l.pyrohip_inc_mac_rhs(self.h, mg.h, int(iu), int(iv), int(igpx), int(igpy),
+                                              float(dx), float(dy), float(dt), int(limiter),
+                                              C.byref(out)))
+        return out.value
+
+    def inc_advect(self, mg, iu, iv, iphimac, igpx, igpy, dx, dy, dt, proj_type):
+        with self.ctx.lock:
+            check(self._l.pyrohip_inc_advect(self.h, mg.h, int(iu), int(iv), int(iphimac),
+                                             int(igpx), int(igpy), float(dx), float(dy), float(dt),
+                                             int(proj_type)))
+
+    def inc_proj_rhs(self, mg, iu, iv, iphi, dx, dy, dt, divide_by_dt):
+        out = C.c_double()
+        with self.ctx.lock:
+            check(self._l.pyrohip_inc_proj_rhs(self.h, mg.h, int(iu), int(iv), int(iphi),
+                                               float(dx), float(dy), float(dt), int(divide_by_dt),
+                                               C.byref(out)))
+        return out.value
+
+    def inc_proj_update(self, mg, iu, iv, iphi, igpx, igpy, dx, dy, fac, gp_mode):
+        with self.ctx.lock:
+            check(self._l.pyrohip_inc_proj_update(self.h, mg.h, int(iu), int(iv), int(iphi),
+                                                  int(igpx), int(igpy), float(dx), float(dy),
+                                                  float(fac), int(gp_mode)))
+
+    def inc_stage(self, which):
+        names = ("u_xl", "u_xr", "u_yl", "u_yr", "v_xl", "v_xr", "v_yl", "v_yr",
+                 "u_MAC", "v_MAC", "advect_x", "advect_y")
+        k = names.index(which) if isinstance(which, str) else int(which)
+        out = np.zeros((self.qx, self.qy))
+        with self.ctx.lock:
+            check(self._l.pyrohip_inc_stage_dump(self.h, k, dptr(out)))
+        return out
+
     def set_user_bc(self, gamma, grav, dy, ambient=None):
         """parameters of the hse / ambient boundaries (compressible/BC.py);
         ambient = (rho, u, v, p)"""

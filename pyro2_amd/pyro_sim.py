@@ -17,7 +17,7 @@ from .util.runparams import RuntimeParameters, _get_val
 
 # solvers with a device implementation in this package; the reference's other
 # solvers are out of scope
-valid_solvers = ["advection", "compressible", "diffusion"]
+valid_solvers = ["advection", "burgers", "compressible", "diffusion", "incompressible"]
 
 
 class Pyro:

@@ -324,3 +324,118 @@ def test_oracle_hse_runs(golden, k):
     for nm in ("FxT", "FyT", "Fx", "Fy"):
         assert np.array_equal(st[nm], g[pre + nm]), nm
     assert np.array_equal(U[ng:-ng, ng:-ng], g[pre + "U1"][ng:-ng, ng:-ng])
+
+
+# ---------------------------------------------------------------------------
+# rows f1 / f4: burgers and the incompressible projection solver
+# ---------------------------------------------------------------------------
+def _bg_run(ic, meta, bcs, nsteps, tmax=0.1):
+    nx, ny, ng, dx, dy, lim, cfl = meta
+    nx, ny, ng, lim = int(nx), int(ny), int(ng), int(lim)
+    u, v = ic[0].copy(), ic[1].copy()
+    t, dts = 0.0, []
+    for _ in range(nsteps):
+        orc.fill_ghost(u, nx, ny, ng, bcs)
+        orc.fill_ghost(v, nx, ny, ng, bcs)
+        dt = orc.bg_dt(u, v, nx, ny, ng, dx, dy, cfl)   # inputs.test: no start-up limiter
+        if t + dt > tmax:
+            dt = tmax - t
+        orc.bg_step(u, v, nx, ny, ng, dx, dy, dt, lim)
+        t += dt
+        dts.append(dt)
+    return u, v, np.array(dts)
+
+
+@pytest.mark.parametrize("k", range(2))
+def test_oracle_burgers(golden, k):
+    g = golden("incomp")
+    pre = f"b{k}_"
+    meta, bcs = g[pre + "meta"], [str(b) for b in g[pre + "bc"]]
+    dts_ref = g[pre + "dts"]
+    u, v, dts = _bg_run(g[pre + "ic"], meta, bcs, len(dts_ref))
+    assert np.array_equal(dts, dts_ref)
+    ng = int(meta[2])
+    fin = g[pre + "final"]
+    assert np.array_equal(u[ng:-ng, ng:-ng], fin[0][ng:-ng, ng:-ng])
+    assert np.array_equal(v[ng:-ng, ng:-ng], fin[1][ng:-ng, ng:-ng])
+    # edge states of one more step: everything the update can reach (B1)
+    U0 = g[pre + "U0"]
+    nx, ny = int(meta[0]), int(meta[1])
+    E = orc.bg_edge_states(U0[0].copy(), U0[1].copy(), None, None, nx, ny, ng, meta[3], meta[4],
+                           float(g[pre + "dt"]), int(meta[5]))
+    assert np.array_equal(E, g[pre + "E"])
+
+
+def _inc_bcs():
+    return dict(bc_u=("periodic",) * 4, bc_v=("periodic",) * 4, bc_phi=("periodic",) * 4)
+
+
+@pytest.mark.parametrize("k", range(2))
+def test_oracle_incompressible(golden, k):
+    """preevolve, a short run and the MAC velocities of one more step against
+    the reference (bit-identical up to the solves: the oracle's norms are
+    plain sums, NumPy's are pairwise -- see orc_mg_norm -- so the V-cycle
+    count at the rtol threshold could differ; it does not in these cases)"""
+    from helpers import DtPolicy
+    g = golden("incomp")
+    pre = f"i{k}_"
+    nx, ng, lim, proj, cfl, f0, mx = g[pre + "meta"]
+    nx, ng, lim, proj = int(nx), int(ng), int(lim), int(proj)
+    dx = 1.0 / nx
+    D = np.ascontiguousarray(g[pre + "ic"])
+    orc.incomp_preevolve(D, nx, ng, cfl, lim, proj, **_inc_bcs())
+    assert np.abs(D - g[pre + "after_pre"]).max() < 1e-13
+    pol = DtPolicy(1.e30, f0, mx)
+    dts = []
+    for _ in g[pre + "dts"]:
+        for n in range(6):     # Pyro.single_step: fill_BC_all, also phi and grad p
+            orc.fill_ghost(D[n], nx, nx, ng, ("periodic",) * 4)
+        dt = pol(orc.bg_dt(D[0], D[1], nx, nx, ng, dx, dx, cfl))
+        orc.incomp_step(D, nx, ng, dt, lim, proj, **_inc_bcs())
+        pol.advance(dt)
+        dts.append(dt)
+    assert np.abs(np.array(dts) / g[pre + "dts"] - 1).max() < 1e-12
+    fin = g[pre + "final"]
+    I = (slice(None), slice(ng, -ng), slice(ng, -ng))
+    assert np.abs(D[I] - fin[I]).max() < 1e-11
+    # one step from the reference's state, with its dt
+    D = np.ascontiguousarray(g[pre + "U0"])
+    st = orc.incomp_step(D, nx, ng, float(g[pre + "dt"]), lim, proj, stages=True, **_inc_bcs())
+    F = (slice(ng, ng + nx + 1), slice(ng, ng + nx))
+    assert np.abs(st["umac"][F] - g[pre + "umac"][F]).max() < 1e-12
+    F = (slice(ng, ng + nx), slice(ng, ng + nx + 1))
+    assert np.abs(st["vmac"][F] - g[pre + "vmac"][F]).max() < 1e-12
+    assert np.abs(D[I] - g[pre + "U1"][I]).max() < 1e-11
+
+
+def _oracle_shear_run(g):
+    from helpers import DtPolicy
+    nx, ng, lim, proj, cfl, f0, mx = g["meta"]
+    nx, ng, lim, proj = int(nx), int(ng), int(lim), int(proj)
+    q = nx + 2 * ng
+    D = np.zeros((6, q, q))
+    D[:2] = g["ic"]
+    orc.incomp_preevolve(D, nx, ng, cfl, lim, proj, **_inc_bcs())
+    pol = DtPolicy(float(g["tmax"]), f0, mx)
+    while pol.t < float(g["tmax"]) and pol.n < 2000:
+        for n in range(6):
+            orc.fill_ghost(D[n], nx, nx, ng, ("periodic",) * 4)
+        dt = pol(orc.bg_dt(D[0], D[1], nx, nx, ng, 1.0 / nx, 1.0 / nx, cfl))
+        orc.incomp_step(D, nx, ng, dt, lim, proj, **_inc_bcs())
+        pol.advance(dt)
+    return D, pol
+
+
+def test_incompressible_reference_regression_shear(golden):
+    """pyro/test.py:110: incompressible shear inputs.shear vs
+    shear_128_0216.h5 (128^2, 216 steps, two MG solves per step): the oracle
+    from the reference's IC against the reference's stored golden"""
+    g = golden("incomp_shear_128_0216")
+    D, pol = _oracle_shear_run(g)
+    assert pol.n == int(g["nsteps"]) == 216
+    assert abs(pol.t - float(g["t"])) < 1e-13
+    ng = int(g["meta"][1])
+    I = (slice(ng, -ng), slice(ng, -ng))
+    assert np.abs(D[0][I] - g["gold"][0]).max() < 1e-10
+    assert np.abs(D[1][I] - g["gold"][1]).max() < 1e-10
+    assert np.abs(D[4][I] - g["gold_gp"][0]).max() < 1e-9
