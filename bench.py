@@ -202,6 +202,40 @@ def bench_mg(ctx, device, nx=4096, cycles=10):
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
 
 
+def bench_incompressible(ctx, device, nx=2048, steps=5):
+    """the solver north_star names as the caller of the multigrid V-cycle:
+    incompressible shear layer, two MG solves (rtol 1e-12) per step"""
+    import contextlib
+    import io
+    import tempfile
+    from pyro2_amd.pyro_sim import Pyro
+    cwd = os.getcwd()
+    os.chdir(tempfile.mkdtemp())          # Pyro writes inputs.auto
+    try:
+        old = device.Context._default
+        device.Context._default = ctx
+        with contextlib.redirect_stdout(io.StringIO()):
+            p = Pyro("incompressible")
+            p.initialize_problem("shear", inputs_dict={"mesh.nx": nx, "mesh.ny": nx,
+                                                       "driver.max_steps": steps + 1})
+            p.single_step()
+        ctx.sync()
+        t0 = time.perf_counter()
+        cyc = []
+        for _ in range(steps):
+            p.single_step()
+            cyc.append(sum(p.sim.mg_cycles))
+        ctx.sync()
+        t1 = time.perf_counter()
+    finally:
+        device.Context._default = old
+        os.chdir(cwd)
+    ms = (t1 - t0) / steps * 1e3
+    return {"workload": f"incompressible shear {nx}x{nx} (limiter 2, proj_type 2), {steps} steps",
+            "value": nx * nx / (ms * 1e-3), "unit": "cell-updates/s", "ms_per_step": ms,
+            "vcycles_per_step": sum(cyc) / steps}
+
+
 def cpu_baseline_sedov(sample_nx, max_seconds=25.0):
     """the oracle (single-threaded C port of the reference) on a bounded sample
     of the same workload: Sedov, same physics, sample_nx^2, from t = 0"""
@@ -340,7 +374,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_sedov(args.cpu_sample_nx)
             if not args.no_also:
                 out["also"] = {"advection": bench_advection(ctx, device),
-                               "multigrid": bench_mg(ctx, device)}
+                               "multigrid": bench_mg(ctx, device),
+                               "incompressible": bench_incompressible(ctx, device)}
         print(json.dumps(out), flush=True)
     dist.barrier()
 

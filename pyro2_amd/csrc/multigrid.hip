@@ -60,7 +60,7 @@ struct pyrohip_mg {
     double *bcval[4] = {nullptr, nullptr, nullptr, nullptr};  // device
     double source_norm = 0.0;
     int smoother = 1;             // 0: one launch per colour, 1: LDS tile smoother
-    int kmax = 3;                 // red-black iterations fused per tile launch
+    int kmax = 5;                 // red-black iterations fused per tile launch
     int kmax_small = 5;           // ... on levels <= 1024^2 (latency bound)
     int coarse_kernel = 1;        // levels <= 64^2 in one LDS-resident workgroup
     int vc = 0;                   // variable-coefficient mode (div(eta grad phi) = f)
@@ -170,13 +170,21 @@ __global__ __launch_bounds__(256) void k_mg_smooth(double *__restrict__ v,
 // Two instantiations:
 //   <256, 0>    generic: region pitch = region width (run time); used for the
 //               levels that fit one tile ("single": any number of iterations).
-//   <512, 128>  wide: the staged region is (TI+4K) x (TJ+4K) <= 32 x 128 cells
-//               with a fixed LDS pitch of 128, so one wave = one row of one
-//               colour (64 cells, stride 2) and no index division is needed.
+//   <1024, 128> wide: the staged region is (TI+4K) x (TJ+4K) <= 64 x 128 cells
+//               with a fixed LDS pitch of 128.  Thread (wave w, lane h) owns
+//               the region cells (w + 16 m, 2h + q), m < 4, q < 2 for the whole
+//               launch; their right-hand sides stay in registers, so LDS holds
+//               v only (64 KB: two 16-wave workgroups = 8 waves/SIMD per CU).
+//               Measured at 4096^2, smooth(10): 651 us with v and f in LDS
+//               (32 x 128 region, K = 3) -> 491 us with f in registers
+//               -> ~350 us with the 64-row region and K = 5 (two launches).
 constexpr int MGS_CELLS = 66 * 66;                 // single-tile levels: n <= 64
 constexpr size_t MGS_LDS = (size_t)2 * MGS_CELLS * sizeof(double);
-constexpr int MGW_RI = 32, MGW_LP = 128, MGW_NT = 512, MGW_KMAX = 5;
-constexpr size_t MGW_LDS = (size_t)2 * MGW_RI * MGW_LP * sizeof(double);
+#ifndef PYRO_MGW_RI
+#define PYRO_MGW_RI 64
+#endif
+constexpr int MGW_RI = PYRO_MGW_RI, MGW_LP = 128, MGW_NT = 16 * MGW_RI, MGW_KMAX = 5;
+constexpr size_t MGW_LDS = (size_t)MGW_RI * MGW_LP * sizeof(double);   // v only; f in registers
 
 struct MGTile {
     const double *vin, *f;
@@ -195,7 +203,7 @@ __device__ __forceinline__ int mg_wrap(int g, int n)   // periodic image in [1, 
 }
 
 template <int NT, int LPC>
-__global__ __launch_bounds__(NT) void k_mg_smooth_tile(MGTile A)
+__global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
 {
     HIP_DYNAMIC_SHARED(double, lds)
     const int n = A.n;
@@ -220,17 +228,33 @@ __global__ __launch_bounds__(NT) void k_mg_smooth_tile(MGTile A)
     const int tid = threadIdx.x;
     const bool wrap_i = per_i && !A.single, wrap_j = per_j && !A.single;
 
-    if (LPC) {   // one thread per column, NT / LPC rows per sweep
-        const int c = tid & (LPC - 1);
-        if (c < RJ) {
-            const int gj = wrap_j ? mg_wrap(gj0 + c, n) : gj0 + c;
-            for (int r = tid / LPC; r < RI; r += NT / LPC) {
-                const int gi = wrap_i ? mg_wrap(gi0 + r, n) : gi0 + r;
-                const size_t k = (size_t)gi * A.pitch + gj;
-                V[r * LP + c] = A.vin[k];
-                F[r * LP + c] = A.f[k];
+    // wide variant: thread (wave w, lane h) owns the region cells (w + 8m, 2h + q),
+    // m < 4, q < 2, for the whole launch; their right-hand sides stay in
+    // registers, so LDS only holds v (32 KB: four workgroups per CU instead of two)
+    static_assert(LPC == 0 || (MGW_RI * 64) / NT == 4, "four region rows per wave");
+    constexpr int WSTEP = NT >> 6;             // waves per workgroup = row stride
+    double f00 = 0, f01 = 0, f10 = 0, f11 = 0, f20 = 0, f21 = 0, f30 = 0, f31 = 0;
+    const int wv = tid >> 6, ln = tid & 63;
+    if (LPC) {
+        // explicit scalars (not an array): they must live in VGPRs
+        auto stage = [&](int m, double &fa, double &fb) {
+            const int r = wv + WSTEP * m;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int c = 2 * ln + q;
+                double vv = 0.0, ff = 0.0;
+                if (r < RI && c < RJ) {
+                    const int gi = wrap_i ? mg_wrap(gi0 + r, n) : gi0 + r;
+                    const int gj = wrap_j ? mg_wrap(gj0 + c, n) : gj0 + c;
+                    const size_t k = (size_t)gi * A.pitch + gj;
+                    vv = A.vin[k];
+                    ff = A.f[k];
+                }
+                V[r * LP + c] = vv;
+                if (q) fb = ff; else fa = ff;
             }
-        }
+        };
+        stage(0, f00, f01); stage(1, f10, f11); stage(2, f20, f21); stage(3, f30, f31);
     } else {
         for (int idx = tid; idx < RI * RJ; idx += NT) {
             const int r = idx / RJ, c = idx - r * RJ;
@@ -257,19 +281,21 @@ __global__ __launch_bounds__(NT) void k_mg_smooth_tile(MGTile A)
         const int ni = uhi_i - ulo_i + 1, nj = uhi_j - ulo_j + 1;
         if (s == 0) {
             // nothing to update
-        } else if (LPC) {   // lane = cell of this colour within the row
-            const int h = tid & 63;
-            for (int ri = tid >> 6; ri < ni; ri += NT >> 6) {
-                const int gi = ulo_i + ri;
-                // colour 0: (gi-1)+(gj-1) even.  first column of that colour:
-                const int off = (gi - 1 + ulo_j - 1 + colour) & 1;
-                const int gj = ulo_j + off + 2 * h;
-                if (gj <= uhi_j) {
-                    const int c = (gi - gi0) * LP + (gj - gj0);
-                    V[c] = (F[c] + A.xc * (V[c + LP] + V[c - LP]) + A.yc * (V[c + 1] + V[c - 1])) /
+        } else if (LPC) {   // the thread's cell of this colour in each of its rows
+            auto relax = [&](int m, double fa, double fb) {
+                const int r = wv + WSTEP * m;
+                const int gi = gi0 + r;
+                // colour 0: (gi-1)+(gj-1) even
+                const int q = (colour + gi + gj0) & 1;
+                const int gj = gj0 + 2 * ln + q;
+                if (gi >= ulo_i && gi <= uhi_i && gj >= ulo_j && gj <= uhi_j) {
+                    const int c = r * LP + 2 * ln + q;
+                    const double fc = q ? fb : fa;
+                    V[c] = (fc + A.xc * (V[c + LP] + V[c - LP]) + A.yc * (V[c + 1] + V[c - 1])) /
                            A.denom;
                 }
-            }
+            };
+            relax(0, f00, f01); relax(1, f10, f11); relax(2, f20, f21); relax(3, f30, f31);
         } else {
             const int half = (nj + 1) >> 1;
             for (int idx = tid; idx < ni * half; idx += NT) {
@@ -328,10 +354,17 @@ __global__ __launch_bounds__(NT) void k_mg_smooth_tile(MGTile A)
     const int oi0 = (plo_i && ti0 == 1) ? 0 : ti0, oi1 = (phi_i && ti1 == n) ? n + 1 : ti1;
     const int oj0 = (plo_j && tj0 == 1) ? 0 : tj0, oj1 = (phi_j && tj1 == n) ? n + 1 : tj1;
     if (LPC) {
-        const int gj = oj0 + (tid & (LPC - 1));
-        if (gj <= oj1)
-            for (int gi = oi0 + tid / LPC; gi <= oi1; gi += NT / LPC)
-                A.vout[(size_t)gi * A.pitch + gj] = V[(gi - gi0) * LP + (gj - gj0)];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int r = wv + WSTEP * m;
+            const int gi = gi0 + r;
+            if (gi < oi0 || gi > oi1) continue;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int gj = gj0 + 2 * ln + q;
+                if (gj >= oj0 && gj <= oj1) A.vout[(size_t)gi * A.pitch + gj] = V[r * LP + 2 * ln + q];
+            }
+        }
     } else {
         const int oni = oi1 - oi0 + 1, onj = oj1 - oj0 + 1;
         for (int idx = tid; idx < oni * onj; idx += NT) {
@@ -765,7 +798,7 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth)
     A.denom = m->alpha + 2.0 * A.xc + 2.0 * A.yc;
     A.bc = make_bc(m, level, true);
     A.single = ((L.n + 2) * (L.n + 2) <= MGS_CELLS) ? 1 : 0;   // whole level in one tile
-    int kmax = (m->kmax >= 1 && m->kmax <= MGW_KMAX) ? m->kmax : 3;
+    int kmax = (m->kmax >= 1 && m->kmax <= MGW_KMAX) ? m->kmax : MGW_KMAX;
     // levels up to 1024^2 live in L2 / Infinity Cache and are launch-latency
     // bound: fuse as many iterations per launch as the 32-row region allows
     if (L.n <= 1024 && m->kmax_small > kmax) kmax = m->kmax_small;
@@ -1013,7 +1046,7 @@ int pyrohip_mg_destroy(pyrohip_mg *m)
 int pyrohip_mg_set_smoother(pyrohip_mg *m, int kind)
 {
     PYRO_REQUIRE(m, "NULL mg");
-    PYRO_REQUIRE(kind >= 0 && kind <= 23, "smoother must be 0, 1, 10+kmax or 20+kmax");
+    PYRO_REQUIRE(kind >= 0 && kind <= 25, "smoother must be 0, 1, 10+kmax or 20+kmax");
     // 10 + k selects the tile smoother with k fused iterations (tuning knob)
     // 20 + k: the same without the single-workgroup coarse V-cycle kernel
     m->coarse_kernel = 1;

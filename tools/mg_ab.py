@@ -10,7 +10,7 @@ for nx in (4096,):
     x = (np.arange(nx + 2) - 0.5) / nx
     X, Y = np.meshgrid(x, x, indexing="ij")
     rhs = -2.0 * ((1 - 6 * X**2) * Y**2 * (1 - Y**2) + (1 - 6 * Y**2) * X**2 * (1 - X**2))
-    for kind in (23, 13):
+    for kind in [int(k) for k in os.environ.get('MG_KINDS', '23,13').split(',')]:
         m = device.DeviceMG(ctx, nx)
         m.set_smoother(kind)
         L = m.nlevels - 1
