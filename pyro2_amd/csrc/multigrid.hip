@@ -190,10 +190,24 @@ struct MGTile {
     const double *vin, *f;
     double *vout;
     int n, pitch;
-    double dx, xc, yc, denom;
+    double dx, xc, yc, denom, rdenom;   // rdenom = RN(1 / denom), see div_by
     int K, TI, TJ, ntj, ntiles, single;
     MGBC bc;
 };
+
+// a / b for a divisor that is the same in every cell, with rb = RN(1 / b)
+// evaluated once on the host: Markstein's sequence q = a rb; e = a - b q
+// (exact, one FMA); q + e rb.  With a correctly rounded reciprocal and a
+// faithful first quotient the result is the correctly rounded quotient, i.e.
+// the same bits as the IEEE division of the reference (barring over/underflow
+// of the intermediates, far from the values on these grids), at 3 instead of
+// ~14 VALU instructions -- the smoother is VALU bound (profiles/r01c_mg4096).
+__device__ __forceinline__ double div_by(double a, double b, double rb)
+{
+    const double q = a * rb;
+    const double e = fma(-b, q, a);
+    return fma(e, rb, q);
+}
 
 __device__ __forceinline__ int mg_wrap(int g, int n)   // periodic image in [1, n]
 {
@@ -223,8 +237,18 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
         if (!per_j) { gj0 = max(gj0, 0); gj1 = min(gj1, n + 1); }
     }
     const int RI = gi1 - gi0 + 1, RJ = gj1 - gj0 + 1;
-    const int LP = LPC ? LPC : RJ;                     // LDS row pitch
+    const int LP = LPC ? LPC : RJ;                     // LDS row pitch (generic variant)
     double *V = lds, *F = lds + (LPC ? MGW_RI * LPC : RI * RJ);
+    // LDS index of region cell (r, c).  Wide variant: the two checkerboard
+    // classes of the region are stored separately (class, row, c/2), so the 64
+    // lanes of a wave, which work on ONE class of one row, touch consecutive
+    // doubles -- and so do their four neighbours, which all belong to the other
+    // class.  The plain row-major layout made every access stride-2 (measured:
+    // 2.2 bank-conflict cycles per LDS-active cycle).
+    constexpr int HALF = LPC ? MGW_RI * (LPC / 2) : 0;
+    auto at = [&](int r, int c) -> int {
+        return LPC ? ((r + c) & 1) * HALF + r * (LPC / 2) + (c >> 1) : r * LP + c;
+    };
     const int tid = threadIdx.x;
     const bool wrap_i = per_i && !A.single, wrap_j = per_j && !A.single;
 
@@ -250,7 +274,7 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
                     vv = A.vin[k];
                     ff = A.f[k];
                 }
-                V[r * LP + c] = vv;
+                V[at(r, c)] = vv;
                 if (q) fb = ff; else fa = ff;
             }
         };
@@ -282,17 +306,26 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
         if (s == 0) {
             // nothing to update
         } else if (LPC) {   // the thread's cell of this colour in each of its rows
+            // a colour is one checkerboard class of the region: class P is
+            // written, its neighbours are all read from class 1 - P; which of
+            // the thread's two columns belongs to P is the same for all of a
+            // wave's rows (they are 16 apart)
+            constexpr int HP = LPC / 2;                     // row pitch of one class
+            const int P = (colour + gi0 + gj0) & 1;         // colour 0: (gi-1)+(gj-1) even
+            const int q = (P + wv) & 1;
+            double *Vo = V + P * HALF;
+            const double *Vn = V + (P ^ 1) * HALF;
+            const int gj = gj0 + 2 * ln + q;
+            const bool jin = (gj >= ulo_j && gj <= uhi_j);
             auto relax = [&](int m, double fa, double fb) {
                 const int r = wv + WSTEP * m;
                 const int gi = gi0 + r;
-                // colour 0: (gi-1)+(gj-1) even
-                const int q = (colour + gi + gj0) & 1;
-                const int gj = gj0 + 2 * ln + q;
-                if (gi >= ulo_i && gi <= uhi_i && gj >= ulo_j && gj <= uhi_j) {
-                    const int c = r * LP + 2 * ln + q;
+                if (jin && gi >= ulo_i && gi <= uhi_i) {
+                    const int b = r * HP + ln;
                     const double fc = q ? fb : fa;
-                    V[c] = (fc + A.xc * (V[c + LP] + V[c - LP]) + A.yc * (V[c + 1] + V[c - 1])) /
-                           A.denom;
+                    // neighbours: (r+1, c), (r-1, c), (r, c+1), (r, c-1)
+                    Vo[b] = div_by(fc + A.xc * (Vn[b + HP] + Vn[b - HP]) +
+                                   A.yc * (Vn[b + q] + Vn[b + q - 1]), A.denom, A.rdenom);
                 }
             };
             relax(0, f00, f01); relax(1, f10, f11); relax(2, f20, f21); relax(3, f30, f31);
@@ -317,34 +350,34 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
             for (int gj = ulo_j + tid; gj <= uhi_j; gj += NT) {
                 const int c = gj - gj0;
                 if (plo_i) {
-                    const double in = V[1 * LP + c];
-                    V[c] = (A.bc.code[0] == PYROHIP_BC_PERIODIC)
-                               ? V[n * LP + c]
-                               : ghost_lo(A.bc.code[0], in, A.bc.val[0], gj, A.dx);
+                    const double in = V[at(1, c)];
+                    V[at(0, c)] = (A.bc.code[0] == PYROHIP_BC_PERIODIC)
+                                      ? V[at(n, c)]
+                                      : ghost_lo(A.bc.code[0], in, A.bc.val[0], gj, A.dx);
                 }
                 if (phi_i) {
                     const int rl = (n + 1) - gi0;
-                    const double in = V[(rl - 1) * LP + c];
-                    V[rl * LP + c] = (A.bc.code[1] == PYROHIP_BC_PERIODIC)
-                                         ? V[(1 - gi0) * LP + c]
-                                         : ghost_hi(A.bc.code[1], in, A.bc.val[1], gj, A.dx);
+                    const double in = V[at(rl - 1, c)];
+                    V[at(rl, c)] = (A.bc.code[1] == PYROHIP_BC_PERIODIC)
+                                       ? V[at(1 - gi0, c)]
+                                       : ghost_hi(A.bc.code[1], in, A.bc.val[1], gj, A.dx);
                 }
             }
         if (plo_j || phi_j)
             for (int gi = ulo_i + tid; gi <= uhi_i; gi += NT) {
-                const int r = (gi - gi0) * LP;
+                const int r = gi - gi0;
                 if (plo_j) {
-                    const double in = V[r + 1];
-                    V[r] = (A.bc.code[2] == PYROHIP_BC_PERIODIC)
-                               ? V[r + n]
-                               : ghost_lo(A.bc.code[2], in, A.bc.val[2], gi, A.dx);
+                    const double in = V[at(r, 1)];
+                    V[at(r, 0)] = (A.bc.code[2] == PYROHIP_BC_PERIODIC)
+                                      ? V[at(r, n)]
+                                      : ghost_lo(A.bc.code[2], in, A.bc.val[2], gi, A.dx);
                 }
                 if (phi_j) {
                     const int cl = (n + 1) - gj0;
-                    const double in = V[r + cl - 1];
-                    V[r + cl] = (A.bc.code[3] == PYROHIP_BC_PERIODIC)
-                                    ? V[r + (1 - gj0)]
-                                    : ghost_hi(A.bc.code[3], in, A.bc.val[3], gi, A.dx);
+                    const double in = V[at(r, cl - 1)];
+                    V[at(r, cl)] = (A.bc.code[3] == PYROHIP_BC_PERIODIC)
+                                       ? V[at(r, 1 - gj0)]
+                                       : ghost_hi(A.bc.code[3], in, A.bc.val[3], gi, A.dx);
                 }
             }
         __syncthreads();
@@ -362,7 +395,7 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const int gj = gj0 + 2 * ln + q;
-                if (gj >= oj0 && gj <= oj1) A.vout[(size_t)gi * A.pitch + gj] = V[r * LP + 2 * ln + q];
+                if (gj >= oj0 && gj <= oj1) A.vout[(size_t)gi * A.pitch + gj] = V[at(r, 2 * ln + q)];
             }
         }
     } else {
@@ -370,7 +403,7 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
         for (int idx = tid; idx < oni * onj; idx += NT) {
             const int r = idx / onj, c = idx - r * onj;
             const int gi = oi0 + r, gj = oj0 + c;
-            A.vout[(size_t)gi * A.pitch + gj] = V[(gi - gi0) * LP + (gj - gj0)];
+            A.vout[(size_t)gi * A.pitch + gj] = V[at(gi - gi0, gj - gj0)];
         }
     }
     // periodic sides staged through wrapped indices: the tile that owns row /
@@ -378,13 +411,13 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
     // kernels (residual, prolongation) find current edge ghosts
     if (wrap_i && (ti1 == n || ti0 == 1))
         for (int gj = tj0 + tid; gj <= tj1; gj += NT) {
-            if (ti1 == n) A.vout[gj] = V[(n - gi0) * LP + (gj - gj0)];
-            if (ti0 == 1) A.vout[(size_t)(n + 1) * A.pitch + gj] = V[(1 - gi0) * LP + (gj - gj0)];
+            if (ti1 == n) A.vout[gj] = V[at(n - gi0, gj - gj0)];
+            if (ti0 == 1) A.vout[(size_t)(n + 1) * A.pitch + gj] = V[at(1 - gi0, gj - gj0)];
         }
     if (wrap_j && (tj1 == n || tj0 == 1))
         for (int gi = ti0 + tid; gi <= ti1; gi += NT) {
-            if (tj1 == n) A.vout[(size_t)gi * A.pitch] = V[(gi - gi0) * LP + (n - gj0)];
-            if (tj0 == 1) A.vout[(size_t)gi * A.pitch + n + 1] = V[(gi - gi0) * LP + (1 - gj0)];
+            if (tj1 == n) A.vout[(size_t)gi * A.pitch] = V[at(gi - gi0, n - gj0)];
+            if (tj0 == 1) A.vout[(size_t)gi * A.pitch + n + 1] = V[at(gi - gi0, 1 - gj0)];
         }
 }
 
@@ -796,6 +829,7 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth)
     A.xc = m->beta / (L.dx * L.dx);
     A.yc = m->beta / (L.dx * L.dx);
     A.denom = m->alpha + 2.0 * A.xc + 2.0 * A.yc;
+    A.rdenom = 1.0 / A.denom;
     A.bc = make_bc(m, level, true);
     A.single = ((L.n + 2) * (L.n + 2) <= MGS_CELLS) ? 1 : 0;   // whole level in one tile
     int kmax = (m->kmax >= 1 && m->kmax <= MGW_KMAX) ? m->kmax : MGW_KMAX;
