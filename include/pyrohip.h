@@ -214,6 +214,22 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles,
                      int *num_cycles, double *residual_error,
                      double *relative_error);
 
+/* ---- compressible_rk (method of lines) -------------
+   Simulation.substep (pyro/compressible_rk/simulation.py:10-44) with
+   fluxes.fluxes (compressible_rk/fluxes.py:28-180): k = -div F + S of the
+   stage state y (ghost cells filled; the density floor is applied to y in
+   place) into planes 4*slot .. 4*slot+3 of the state k (same nx, ny, ng).   */
+int pyrohip_comp_rk_rhs(pyrohip_state *y, const pyrohip_comp_params *p,
+                        pyrohip_state *k, int slot);
+/* its CFL step (compressible_rk/simulation.py:46-56)                        */
+int pyrohip_comp_rk_dt(pyrohip_state *s, const pyrohip_comp_params *p,
+                       double cfl, double *dt_out);
+/* RKIntegrator.get_stage_start / compute_final_update (pyro/mesh/
+   integration.py:84-113): dst <- src everywhere (clone), then on the interior
+   dst += coef[0] k_0; dst += coef[1] k_1; ... in this order.  dst may be src. */
+int pyrohip_state_lincomb(pyrohip_state *dst, const pyrohip_state *src,
+                          const pyrohip_state *k, const double *coef, int ncoef);
+
 /* ---- burgers / incompressible (the solvers on top of the multigrid solver;
         SURVEY.md 8 rows f1, f4) ------------------------------------------- */
 /* burgers Simulation.evolve (pyro/burgers/simulation.py:53-117 with

@@ -507,6 +507,53 @@ def gen_incompressible():
                         p.rp.get_param("driver.max_dt_change")]))
 
 
+def gen_compressible_rk():
+    """row f4: compressible_rk (method of lines + RK integrators): short runs
+    and the right-hand side k = -div F + S of the state after them"""
+    sp = {"sponge.do_sponge": 1, "sponge.sponge_rho_begin": 1.05,
+          "sponge.sponge_rho_full": 0.3, "sponge.sponge_timescale": 0.02}
+    cases = [
+        ("sedov", None, {"mesh.nx": 16, "mesh.ny": 16, "sedov.r_init": 0.2}, 4),
+        ("rt", None, {"mesh.nx": 12, "mesh.ny": 36, "rt.amp": 0.4,
+                      "compressible.temporal_method": "TVD3"}, 5),
+        ("sod", "inputs.sod.x", {"mesh.nx": 32, "mesh.ny": 8, "compressible.riemann": "CGF",
+                                 "compressible.temporal_method": "RK2"}, 6),
+        ("quad", None, dict({"mesh.nx": 16, "mesh.ny": 16,
+                             "compressible.temporal_method": "TVD2",
+                             "compressible.limiter": 1}, **sp), 5),
+    ]
+    out = {"ncases": np.array(len(cases))}
+    for k, (prob, inp, d, nsteps) in enumerate(cases):
+        p = Pyro("compressible_rk")
+        p.initialize_problem(prob, inputs_file=inp, inputs_dict=d)
+        sim = p.sim
+        pre = f"c{k}_"
+        out[pre + "ic"] = np.array(sim.cc_data.data)
+        dts = []
+        for _ in range(nsteps):
+            p.single_step()
+            dts.append(sim.dt)
+        out[pre + "final"] = np.array(sim.cc_data.data)
+        out[pre + "dts"] = np.array(dts)
+        out[pre + "meta"] = comp_meta(sim)
+        out[pre + "bc"] = bc_names(sim.rp)
+        out[pre + "method"] = np.array(sim.rp.get_param("compressible.temporal_method"))
+        out[pre + "riemann"] = np.array(sim.rp.get_param("compressible.riemann"))
+        out[pre + "sponge"] = np.array([sim.rp.get_param("sponge.do_sponge"),
+                                        sim.rp.get_param("sponge.sponge_rho_begin"),
+                                        sim.rp.get_param("sponge.sponge_rho_full"),
+                                        sim.rp.get_param("sponge.sponge_timescale")])
+        out[pre + "drv"] = np.array([p.rp.get_param("driver.init_tstep_factor"),
+                                     p.rp.get_param("driver.max_dt_change")])
+        sim.cc_data.fill_BC_all()
+        sim.compute_timestep()
+        out[pre + "U0"] = np.array(sim.cc_data.data)
+        out[pre + "dt"] = np.array(sim.dt)
+        out[pre + "k"] = np.array(sim.substep(sim.cc_data))
+        print("compressible_rk case", k, prob, d, "dt", sim.dt)
+    save("comp_rk", **out)
+
+
 def _raw_cfl_dt(sim):
     dt_keep, dto_keep = sim.dt, sim.dt_old
     sim.method_compute_timestep()
@@ -778,6 +825,8 @@ if __name__ == "__main__":
         gen_compressible_rt()
     if "incomp" in sys.argv[1:]:
         gen_incompressible()
+    if "comp_rk" in sys.argv[1:]:
+        gen_compressible_rk()
     which = sys.argv[1:] or ["bc", "adv", "comp_stages", "comp_runs", "mg", "diffusion"]
     if "diffusion" in which:
         gen_diffusion()

@@ -381,3 +381,23 @@ def incomp_preevolve(D, nx, ng, cfl, limiter=2, proj_type=2, bc_u=("periodic",) 
     return f(_p(D), nx, ng, C.c_double(xmin), C.c_double(xmax), C.c_double(ymin),
              C.c_double(ymax), C.c_double(cfl), limiter, proj_type,
              bu.ctypes.data_as(ip), bv.ctypes.data_as(ip), bp.ctypes.data_as(ip))
+
+
+# ---- compressible_rk (row f4) ---------------------------------------------
+def comp_rk_rhs(U, P, fluxes=False):
+    """k = -div F + S of the stage state U (qx,qy,4), ghost cells filled; U's
+    density is floored in place.  Returns (rc, k[, Fx, Fy])"""
+    _ck(U)
+    k = np.zeros_like(U)
+    Fx = np.zeros_like(U) if fluxes else None
+    Fy = np.zeros_like(U) if fluxes else None
+    rc = lib().orc_comp_rk_rhs(_p(U), C.byref(P), _p(k), None if Fx is None else _p(Fx),
+                               None if Fy is None else _p(Fy))
+    return (rc, k, Fx, Fy) if fluxes else (rc, k)
+
+
+def comp_rk_dt(U, nx, ny, ng, dx, dy, gamma, cfl):
+    f = lib().orc_comp_rk_dt
+    f.restype = C.c_double
+    return f(_p(U), nx, ny, ng, C.c_double(dx), C.c_double(dy), C.c_double(gamma),
+             C.c_double(cfl))

@@ -1901,3 +1901,121 @@ double orc_incomp_preevolve(double *D, int nx, int ng, double xmin, double xmax,
 #undef I2
     return dt;
 }
+
+/* ================================================================== */
+/* compressible_rk: method-of-lines right-hand side  */
+/*   pyro/compressible_rk/fluxes.py:28-180 (no well-balancing)         */
+/*   pyro/compressible_rk/simulation.py:10-44  substep                 */
+/* U: (qx,qy,4) stage state with ghost cells filled; density floor is  */
+/* applied in place like clean_state.  k: (qx,qy,4), interior written. */
+/* Optional dumps Fx, Fy (with artificial viscosity).  Returns 1 when  */
+/* the positivity assert of cons_to_prim would fire.                   */
+/* ================================================================== */
+int orc_comp_rk_rhs(double *U, const orc_comp_params *P, double *kout,
+                    double *o_Fx, double *o_Fy)
+{
+    const int nx = P->nx, ny = P->ny, ng = P->ng;
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx - 1, jlo = ng, jhi = ng + ny - 1;
+    const size_t N = (size_t)qx * qy;
+    const double gamma = P->gamma, dx = P->dx, dy = P->dy;
+    int rc = 0;
+#define U4(a, i, j, n) a[((size_t)(i) * qy + (j)) * 4 + (n)]
+#define I2(i, j) ((size_t)(i) * qy + (j))
+    for (int i = ilo; i <= ihi; i++)            /* clean_state */
+        for (int j = jlo; j <= jhi; j++)
+            U4(U, i, j, IDENS) = dmax(U4(U, i, j, IDENS), P->small_dens);
+    double *S = zalloc(N * 4);                  /* simulation.py:16-19 */
+    ext_sources(U, NULL, N, P->grav, 0.0, S);
+
+    double *q = zalloc(N * 4), *xi = zalloc(N), *ldx = zalloc(N * 4), *ldy = zalloc(N * 4),
+           *tmp = zalloc(N);
+    double *V_l = zalloc(N * 4), *V_r = zalloc(N * 4);
+    double *Uxl = zalloc(N * 4), *Uxr = zalloc(N * 4), *Uyl = zalloc(N * 4), *Uyr = zalloc(N * 4);
+    double *Fx = zalloc(N * 4), *Fy = zalloc(N * 4), *avx = zalloc(N), *avy = zalloc(N);
+    rc |= orc_cons_to_prim(U, nx, ny, ng, gamma, q);           /* fluxes.py:63-88 */
+    if (P->use_flattening)
+        orc_flatten_multid(q, nx, ny, ng, P->z0, P->z1, P->delta, xi);
+    else
+        for (size_t k = 0; k < N; k++) xi[k] = 1.0;
+    for (int n = 0; n < 4; n++) {
+        orc_limit(q + n, 4, nx, ny, ng, 1, P->limiter, tmp);
+        for (size_t k = 0; k < N; k++) ldx[k * 4 + n] = xi[k] * tmp[k];
+        orc_limit(q + n, 4, nx, ny, ng, 2, P->limiter, tmp);
+        for (size_t k = 0; k < N; k++) ldy[k * 4 + n] = xi[k] * tmp[k];
+    }
+    /* piecewise-linear face states on B2, fluxes.py:107-140 */
+    for (int d = 1; d <= 2; d++) {
+        const double *ld = (d == 1) ? ldx : ldy;
+        memset(V_l, 0, N * 32); memset(V_r, 0, N * 32);
+        for (int i = ilo - 2; i <= ihi + 2; i++)
+            for (int j = jlo - 2; j <= jhi + 2; j++)
+                for (int n = 0; n < 4; n++) {
+                    const double qc = U4(q, i, j, n), l = U4(ld, i, j, n);
+                    if (d == 1) U4(V_l, i + 1, j, n) = qc + 0.5 * l;
+                    else        U4(V_l, i, j + 1, n) = qc + 0.5 * l;
+                    U4(V_r, i, j, n) = qc - 0.5 * l;
+                }
+        orc_prim_to_cons(V_l, N, gamma, d == 1 ? Uxl : Uyl);
+        orc_prim_to_cons(V_r, N, gamma, d == 1 ? Uxr : Uyr);
+    }
+    riemann_dispatch(P, 1, Uxl, Uxr, Fx);                      /* fluxes.py:145-160 */
+    riemann_dispatch(P, 2, Uyl, Uyr, Fy);
+    orc_artificial_viscosity(nx, ny, ng, dx, dy, P->cvisc, q, P->avisc_xhi_interior,
+                             P->avisc_yhi_interior, avx, avy);
+    for (int n = 0; n < 4; n++)
+        for (int i = ilo - 2; i <= ihi + 1; i++)
+            for (int j = jlo - 2; j <= jhi + 1; j++) {
+                U4(Fx, i, j, n) += avx[I2(i, j)] * (U4(U, i - 1, j, n) - U4(U, i, j, n));
+                U4(Fy, i, j, n) += avy[I2(i, j)] * (U4(U, i, j - 1, n) - U4(U, i, j, n));
+            }
+    if (o_Fx) memcpy(o_Fx, Fx, N * 32);
+    if (o_Fy) memcpy(o_Fy, Fy, N * 32);
+    memset(kout, 0, N * 32);
+    for (int i = ilo; i <= ihi; i++)            /* simulation.py:26-30 */
+        for (int j = jlo; j <= jhi; j++)
+            for (int n = 0; n < 4; n++)
+                U4(kout, i, j, n) = (U4(Fx, i, j, n) - U4(Fx, i + 1, j, n)) / dx +
+                                    (U4(Fy, i, j, n) - U4(Fy, i, j + 1, n)) / dy +
+                                    U4(S, i, j, n);
+    if (P->do_sponge) {                         /* simulation.py:33-42 */
+        const double PI = 3.14159265358979323846;
+        for (int i = ilo; i <= ihi; i++)
+            for (int j = jlo; j <= jhi; j++) {
+                const double rho = U4(U, i, j, IDENS);
+                double f;
+                if (rho > P->sponge_rho_begin) f = 0.0;
+                else if (rho < P->sponge_rho_full) f = 1.0;
+                else f = 0.5 * (1.0 - cos(PI * (rho - P->sponge_rho_begin) /
+                                          (P->sponge_rho_full - P->sponge_rho_begin)));
+                const double kap = f / P->sponge_timescale;
+                const double mx = U4(U, i, j, IXMOM), my = U4(U, i, j, IYMOM);
+                U4(kout, i, j, IXMOM) -= kap * mx;
+                U4(kout, i, j, IYMOM) -= kap * my;
+                U4(kout, i, j, IENER) -= kap * (mx * mx / rho + my * my / rho);
+            }
+    }
+    free(S); free(q); free(xi); free(ldx); free(ldy); free(tmp); free(V_l); free(V_r);
+    free(Uxl); free(Uxr); free(Uyl); free(Uyr); free(Fx); free(Fy); free(avx); free(avy);
+#undef U4
+#undef I2
+    return rc;
+}
+
+/* compressible_rk/simulation.py:46-56 (the dt is NOT the CTU one) */
+double orc_comp_rk_dt(const double *U, int nx, int ny, int ng, double dx,
+                      double dy, double gamma, double cfl)
+{
+    const size_t N = (size_t)(nx + 2 * ng) * (ny + 2 * ng);
+    double m = INFINITY;
+    for (size_t k = 0; k < N; k++) {
+        const double *Uc = U + k * 4;
+        const double rho = Uc[IDENS], u = Uc[IXMOM] / rho, v = Uc[IYMOM] / rho;
+        const double e = (Uc[IENER] - 0.5 * rho * (u * u + v * v)) / rho;
+        const double p = rho * e * (gamma - 1.0);
+        const double cs = sqrt(gamma * p / rho);
+        const double xtmp = (fabs(u) + cs) / dx, ytmp = (fabs(v) + cs) / dy;
+        m = dmin(m, 1.0 / (xtmp + ytmp));
+    }
+    return cfl * m;
+}

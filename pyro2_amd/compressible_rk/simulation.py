@@ -1,0 +1,53 @@
+"""compressible_rk.Simulation with the call surface of
+pyro/compressible_rk/simulation.py:8-104: the compressible solver's state,
+problems and boundaries with a method-of-lines update.  Per stage: ghost fill,
+pyrohip_comp_rk_rhs (density floor, primitives, flattening, limited slopes,
+face states, Riemann fluxes, artificial viscosity, flux divergence, gravity and
+sponge sources); stage starts and the final update are
+pyrohip_state_lincomb launches (pyro2_amd/mesh/integration.py)."""
+from ..compressible.simulation import Simulation as CompressibleSimulation
+from ..mesh import integration
+from ..util import msg
+
+
+class Simulation(CompressibleSimulation):
+    def initialize(self, *, extra_vars=None, ng=4):
+        if self.rp.get_param("compressible.well_balanced"):
+            msg.fail("ERROR: compressible.well_balanced is not carried by the device path")
+        super().initialize(extra_vars=extra_vars, ng=ng)
+        self._rk_scratch = None
+
+    def substep(self, st, kstate, slot):
+        """k of the device state `st` into slot `slot` of `kstate`"""
+        st.comp_rk_rhs(self._params(), kstate, slot)
+
+    def method_compute_timestep(self):
+        """cfl * min 1 / ((|u|+c)/dx + (|v|+c)/dy) over the whole array
+        (compressible_rk/simulation.py:46-56)"""
+        cfl = self.rp.get_param("driver.cfl")
+        self.dt = self.cc_data.device_state().comp_rk_dt(self._params(), float(cfl))
+
+    def evolve(self):
+        tm = self.tc.timer("evolve")
+        tm.begin()
+        cc = self.cc_data
+        method = self.rp.get_param("compressible.temporal_method")
+        rk = integration.RKIntegrator(cc.t, self.dt, method=method)
+        start = cc.device_state()
+        if self._rk_scratch is not None and self._rk_scratch[1].nvar != 4 * rk.nstages():
+            self._rk_scratch = None
+        self._rk_scratch = rk.set_start(start, self._rk_scratch)
+        for s in range(rk.nstages()):
+            ytmp = rk.get_stage_start(s)
+            if s == 0:
+                cc.fill_BC_all()
+            else:
+                cc._push_user_bc(ytmp)
+                ytmp.fill_bc(-1)
+            self.substep(ytmp, rk.k, s)
+            rk.store_increment(s)
+        rk.compute_final_update()
+        cc.device_modified()
+        cc.t += self.dt
+        self.n += 1
+        tm.end()

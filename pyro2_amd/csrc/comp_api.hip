@@ -10,8 +10,11 @@ int comp_step_staged(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_fused(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_stage_dump(pyrohip_state *, int, double *);
 int comp_sponge(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_rk_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
+int comp_rk_rhs(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, int);
 }
 namespace fastm {
+int comp_rk_rhs(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, int);
 int comp_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_step_staged(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_fused(pyrohip_state *, const pyrohip_comp_params *, double);
@@ -57,6 +60,27 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
         rc = exact::comp_sponge(s, p, dt);
     }
     return rc;
+}
+
+int pyrohip_comp_rk_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, double *dt_out)
+{
+    PYRO_TRY(check_comp(s, p));
+    PYRO_REQUIRE(dt_out, "dt_out is NULL");
+    return exact::comp_rk_dt(s, p, cfl, dt_out);
+}
+
+int pyrohip_comp_rk_rhs(pyrohip_state *y, const pyrohip_comp_params *p, pyrohip_state *k, int slot)
+{
+    PYRO_TRY(check_comp(y, p));
+    PYRO_REQUIRE(k && k->ctx == y->ctx, "k state missing or on another context");
+    PYRO_REQUIRE(k->g.nx == y->g.nx && k->g.ny == y->g.ny && k->g.ng == y->g.ng,
+                 "k state must have the geometry of the stage state");
+    PYRO_REQUIRE(slot >= 0 && 4 * (slot + 1) <= k->nvar, "slot outside the k state");
+    PYRO_REQUIRE(p->riemann == 0 || p->riemann == 1, "riemann must be 0 (HLLC) or 1 (CGF)");
+    if (p->do_sponge)
+        PYRO_REQUIRE(p->sponge_rho_begin > p->sponge_rho_full,
+                     "sponge_rho_begin must exceed sponge_rho_full (simulation.py:172)");
+    return p->fast_math ? fastm::comp_rk_rhs(y, p, k, slot) : exact::comp_rk_rhs(y, p, k, slot);
 }
 
 int pyrohip_comp_stage_dump(pyrohip_state *s, int stage_id, double *out)

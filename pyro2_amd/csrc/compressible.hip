@@ -490,6 +490,227 @@ int comp_step_staged(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     return 0;
 }
 
+// ===========================================================================
+// compressible_rk: method-of-lines right-hand side k = -div F + S
+// (pyro/compressible_rk/fluxes.py:28-180, simulation.py:10-44).  Reuses
+// k_prim / k_xi; the face states are piecewise linear (no characteristic
+// tracing, no transverse terms), then one Riemann problem per face plus the
+// artificial viscosity, then the flux divergence.
+// ===========================================================================
+// R1: face states of the cells of R(1) (the faces of the interior need no more)
+__global__ __launch_bounds__(256) void k_rk_states(const double *__restrict__ W_,
+                                                   double *__restrict__ Wout, Geom g, CP P,
+                                                   int gx, int gy)
+{
+    int bx, by;
+    if (!xcd_block_2d(gx, gy, bx, by)) return;
+    const int j = g.jlo - 1 + bx * blockDim.x + threadIdx.x;
+    const int i = g.ilo - 1 + by;
+    if (j > g.jhi + 1) return;
+    const int p = g.pitch;
+    const size_t k = (size_t)i * p + j;
+    const size_t pl = g.plane;
+    const double *Q = W_ + (size_t)W_Q * pl;
+    const double xi = W_[(size_t)W_XI * pl + k];
+    double q0[4], dqx[4], dqy[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const double *a = Q + (size_t)n * pl;
+        q0[n] = a[k];
+        dqx[n] = xi * limited_slope(a[k - 2 * p], a[k - p], a[k], a[k + p], a[k + 2 * p],
+                                    P.limiter);
+        dqy[n] = xi * limited_slope(a[k - 2], a[k - 1], a[k], a[k + 1], a[k + 2], P.limiter);
+    }
+    // fluxes.py:107-140: V_l[i+1] = q + ld/2 (the cell's upper face), V_r[i] = q - ld/2
+    auto face = [&](const double *d, double sgn) {
+        return prim_to_cons(Prim{q0[0] + sgn * 0.5 * d[0], q0[1] + sgn * 0.5 * d[1],
+                                 q0[2] + sgn * 0.5 * d[2], q0[3] + sgn * 0.5 * d[3]}, P.gamma);
+    };
+    store_cons(Wout + (size_t)W_XM * pl, pl, k, face(dqx, -1.0));
+    store_cons(Wout + (size_t)W_XP * pl, pl, k, face(dqx, 1.0));
+    store_cons(Wout + (size_t)W_YM * pl, pl, k, face(dqy, -1.0));
+    store_cons(Wout + (size_t)W_YP * pl, pl, k, face(dqy, 1.0));
+}
+
+// R2: Riemann problems (fluxes.py:145-160) + artificial viscosity (:162-168,
+// unsplit_fluxes.py:525-547) on the lower faces of thread (i,j) in
+// [ilo, ihi+1] x [jlo, jhi+1]
+__global__ __launch_bounds__(256) void k_rk_flux(const double *__restrict__ U,
+                                                 const double *__restrict__ W_,
+                                                 double *__restrict__ Wout, Geom g, CP P, int gx,
+                                                 int gy)
+{
+    int bx, by;
+    if (!xcd_block_2d(gx, gy, bx, by)) return;
+    const int j = g.jlo + bx * blockDim.x + threadIdx.x;
+    const int i = g.ilo + by;
+    if (j > g.jhi + 1) return;
+    const int p = g.pitch;
+    const size_t k = (size_t)i * p + j;
+    const size_t pl = g.plane;
+    const double *u = W_ + (size_t)(W_Q + 1) * pl, *v = W_ + (size_t)(W_Q + 2) * pl;
+    const double d00 = div_u_vertex(u[k], u[k - 1], u[k - p], u[k - p - 1], v[k], v[k - p],
+                                    v[k - 1], v[k - p - 1], P.dx, P.dy);
+    const Cons Uc = load_cons(U, pl, k);
+    if (j <= g.jhi) {
+        const Cons Ul = load_cons(W_ + (size_t)W_XP * pl, pl, k - p);
+        const Cons Ur = load_cons(W_ + (size_t)W_XM * pl, pl, k);
+        Cons F = from_n(riemann_rt(to_n(Ul, true), to_n(Ur, true), P, true,
+                                   P.solid_xl && i == g.ilo), true);
+        double avx = 0.0;
+        if (i <= g.ihi || P.avx_hi) {
+            const size_t kk = k + 1;
+            const double d01 = div_u_vertex(u[kk], u[kk - 1], u[kk - p], u[kk - p - 1], v[kk],
+                                            v[kk - p], v[kk - 1], v[kk - p - 1], P.dx, P.dy);
+            avx = P.cvisc * fmax(-(0.5 * (d00 + d01)) * P.dx, 0.0);
+        }
+        const Cons Um = load_cons(U, pl, k - p);
+        F.d += avx * (Um.d - Uc.d);
+        F.E += avx * (Um.E - Uc.E);
+        F.mx += avx * (Um.mx - Uc.mx);
+        F.my += avx * (Um.my - Uc.my);
+        store_cons(Wout + (size_t)W_FX * pl, pl, k, F);
+    }
+    if (i <= g.ihi) {
+        const Cons Ul = load_cons(W_ + (size_t)W_YP * pl, pl, k - 1);
+        const Cons Ur = load_cons(W_ + (size_t)W_YM * pl, pl, k);
+        Cons F = from_n(riemann_rt(to_n(Ul, false), to_n(Ur, false), P, false,
+                                   P.solid_yl && j == g.jlo), false);
+        double avy = 0.0;
+        if (j <= g.jhi || P.avy_hi) {
+            const size_t kk = k + p;
+            const double d10 = div_u_vertex(u[kk], u[kk - 1], u[kk - p], u[kk - p - 1], v[kk],
+                                            v[kk - p], v[kk - 1], v[kk - p - 1], P.dx, P.dy);
+            avy = P.cvisc * fmax(-(0.5 * (d00 + d10)) * P.dy, 0.0);
+        }
+        const Cons Um = load_cons(U, pl, k - 1);
+        F.d += avy * (Um.d - Uc.d);
+        F.E += avy * (Um.E - Uc.E);
+        F.mx += avy * (Um.mx - Uc.mx);
+        F.my += avy * (Um.my - Uc.my);
+        store_cons(Wout + (size_t)W_FY * pl, pl, k, F);
+    }
+}
+
+// R3: k = (Fx[i] - Fx[i+1])/dx + (Fy[j] - Fy[j+1])/dy + S (gravity) - sponge
+// (compressible_rk/simulation.py:16-42) into 4 planes of the k state
+struct RkSponge { int on; double rho_begin, rho_full, tau; };
+__global__ __launch_bounds__(256) void k_rk_rhs(const double *__restrict__ U,
+                                                const double *__restrict__ W_,
+                                                double *__restrict__ K, Geom g, CP P,
+                                                RkSponge sp)
+{
+    const int j = g.jlo + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = g.ilo + blockIdx.y;
+    if (j > g.jhi) return;
+    const int p = g.pitch;
+    const size_t pl = g.plane;
+    const size_t k = (size_t)i * p + j;
+    const double *FX = W_ + (size_t)W_FX * pl, *FY = W_ + (size_t)W_FY * pl;
+    const Cons Uc = load_cons(U, pl, k);
+    double kk[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const double *fx = FX + (size_t)n * pl, *fy = FY + (size_t)n * pl;
+        kk[n] = (fx[k] - fx[k + p]) / P.dx + (fy[k] - fy[k + 1]) / P.dy;
+    }
+    // planes: density, energy, x-momentum, y-momentum; S = (0, ymom g, 0, rho g)
+    kk[0] = kk[0] + 0.0;
+    kk[1] = kk[1] + Uc.my * P.grav;
+    kk[2] = kk[2] + 0.0;
+    kk[3] = kk[3] + Uc.d * P.grav;
+    if (sp.on) {
+        const double PI = 3.14159265358979323846;
+        double f;
+        if (Uc.d > sp.rho_begin) f = 0.0;
+        else if (Uc.d < sp.rho_full) f = 1.0;
+        else f = 0.5 * (1.0 - cos(PI * (Uc.d - sp.rho_begin) / (sp.rho_full - sp.rho_begin)));
+        const double kap = f / sp.tau;
+        kk[2] -= kap * Uc.mx;
+        kk[3] -= kap * Uc.my;
+        kk[1] -= kap * (Uc.mx * Uc.mx / Uc.d + Uc.my * Uc.my / Uc.d);
+    }
+#pragma unroll
+    for (int n = 0; n < 4; n++) K[(size_t)n * pl + k] = kk[n];
+}
+
+// compressible_rk/simulation.py:46-56: cfl * min 1 / ((|u|+c)/dx + (|v|+c)/dy)
+__global__ __launch_bounds__(256) void k_rk_cfl(const double *__restrict__ U, Geom g, double gamma,
+                                                double dx, double dy, double *__restrict__ partial)
+{
+    double m = INFINITY;
+    for (int i = blockIdx.y; i < g.qx; i += gridDim.y)
+        for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < g.qy; j += gridDim.x * blockDim.x) {
+            const Cons Uc = load_cons(U, g.plane, (size_t)i * g.pitch + j);
+            const double u = Uc.mx / Uc.d, v = Uc.my / Uc.d;
+            const double e = (Uc.E - 0.5 * Uc.d * (u * u + v * v)) / Uc.d;
+            const double pr = Uc.d * e * (gamma - 1.0);
+            const double cs = sqrt(gamma * pr / Uc.d);
+            m = fmin(m, 1.0 / ((fabs(u) + cs) / dx + (fabs(v) + cs) / dy));
+        }
+    m = block_reduce_min(m);
+    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = m;
+}
+
+int comp_rk_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, double *dt_out)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    dim3 grid(8, 128), block(256);
+    const int nb = grid.x * grid.y;
+    PYRO_TRY(c->reduce.ensure((nb + kMinStageBlocks + 2) * sizeof(double)));
+    double *part = (double *)c->reduce.p;
+    hipLaunchKernelGGL(k_rk_cfl, grid, block, 0, c->stream, (const double *)s->d, g, p->gamma, p->dx,
+                       p->dy, part);
+    const double *dmin = launch_min_reduce(c->stream, part, nb);
+    PYRO_CHECK_HIP(hipGetLastError());
+    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, dmin, sizeof(double), hipMemcpyDeviceToHost,
+                                  c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    *dt_out = cfl * ((double *)c->reduce_host)[0];
+    return 0;
+}
+
+// y: stage state (ghost cells filled; the density floor is applied in place
+// like clean_state); kst / slot: where the 4 planes of k go
+int comp_rk_rhs(pyrohip_state *s, const pyrohip_comp_params *p, pyrohip_state *kst, int slot)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    PYRO_TRY(ensure_work(s, W_NPLANES));
+    const CP P = make_cp(p, 0.0, s);
+    double *U = s->d;
+    double *W = s->work + geom_lead(g);
+    const dim3 block(256);
+    PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
+    int gx = (g.qy + 255) / 256, gy = g.qx;
+    PYRO_LAUNCH(c, "k_prim", k_prim, dim3(xcd_grid_1d(gx, gy)), block, 0, U, W, g, P, s->d_flag,
+                gx, gy);
+    gx = (g.ny + 2 + 255) / 256; gy = g.nx + 2;
+    const dim3 gridR1(xcd_grid_1d(gx, gy));
+    PYRO_LAUNCH(c, "k_xi", k_xi, gridR1, block, 0, (const double *)W, W + (size_t)W_XI * g.plane, g,
+                P, gx, gy);
+    PYRO_LAUNCH(c, "k_rk_states", k_rk_states, gridR1, block, 0, (const double *)W, W, g, P, gx, gy);
+    gx = (g.ny + 1 + 255) / 256; gy = g.nx + 1;
+    PYRO_LAUNCH(c, "k_rk_flux", k_rk_flux, dim3(xcd_grid_1d(gx, gy)), block, 0, (const double *)U,
+                (const double *)W, W, g, P, gx, gy);
+    const RkSponge sp{p->do_sponge, p->sponge_rho_begin, p->sponge_rho_full, p->sponge_timescale};
+    PYRO_LAUNCH(c, "k_rk_rhs", k_rk_rhs, dim3((g.ny + 255) / 256, g.nx), block, 0,
+                (const double *)U, (const double *)W, kst->d + (size_t)(4 * slot) * g.plane, g, P,
+                sp);
+    PYRO_CHECK_HIP(hipGetLastError());
+    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, s->d_flag, sizeof(int), hipMemcpyDeviceToHost,
+                                  c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    s->next_cfl_min = -1.0;
+    if (*(int *)c->reduce_host & 1) {
+        set_error("invalid state: min(rho) <= 0 or min(e) <= 0 on the interior "
+                  "(compressible/simulation.py:68-71)");
+        return PYROHIP_ERR_STATE;
+    }
+    return 0;
+}
+
 int comp_stage_dump(pyrohip_state *s, int stage_id, double *out)
 {
     static const int first[10] = {W_Q, W_XI, W_XM, W_XP, W_YM, W_YP, W_FXT, W_FYT, W_FX, W_FY};

@@ -168,6 +168,26 @@ __global__ void k_fill_y_user(double *__restrict__ d, Geom g, const int *__restr
     }
 }
 
+// Runge-Kutta stage combination (pyro/mesh/integration.py:84-113): dst <- src
+// on the whole array (cell_center_data_clone), then on the interior
+// dst += c[0] k_0; dst += c[1] k_1; ... in this order, k_s = planes
+// nvar*s .. nvar*s + nvar - 1 of the k state.  dst may be src.
+struct LinComb { double c[8]; int n; };
+__global__ __launch_bounds__(256) void k_lincomb(double *__restrict__ dst,
+                                                 const double *__restrict__ src,
+                                                 const double *__restrict__ K, Geom g, int nvar,
+                                                 LinComb lc)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y, n = blockIdx.z;
+    if (j >= g.qy) return;
+    const size_t k = (size_t)i * g.pitch + j;
+    double v = src[(size_t)n * g.plane + k];
+    if (i >= g.ilo && i <= g.ihi && j >= g.jlo && j <= g.jhi)
+        for (int s = 0; s < lc.n; s++) v += lc.c[s] * K[(size_t)(nvar * s + n) * g.plane + k];
+    dst[(size_t)n * g.plane + k] = v;
+}
+
 // ---------------------------------------------------------------------------
 // min / max over a rectangular region of one plane (two-pass, deterministic)
 // ---------------------------------------------------------------------------
@@ -571,6 +591,28 @@ int pyrohip_fill_bc(pyrohip_state *s, int n)
         hipLaunchKernelGGL(k_fill_y, grid, block, 0, c->stream, s->d, g, (const int *)s->d_bc, n0);
     }
     PYRO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int pyrohip_state_lincomb(pyrohip_state *dst, const pyrohip_state *src, const pyrohip_state *k,
+                          const double *coef, int ncoef)
+{
+    PYRO_REQUIRE(dst && src && k && coef, "NULL argument");
+    PYRO_REQUIRE(ncoef >= 0 && ncoef <= 8, "at most 8 increments");
+    PYRO_REQUIRE(dst->nvar == src->nvar && k->nvar >= ncoef * src->nvar, "variable counts differ");
+    PYRO_REQUIRE(dst->g.plane == src->g.plane && dst->g.plane == k->g.plane &&
+                     dst->g.nx == src->g.nx && dst->g.ny == src->g.ny && dst->g.ng == src->g.ng,
+                 "geometries differ");
+    PYRO_REQUIRE(dst->ctx == src->ctx && dst->ctx == k->ctx, "states live on different contexts");
+    LinComb lc;
+    lc.n = ncoef;
+    for (int s = 0; s < ncoef; s++) lc.c[s] = coef[s];
+    const Geom &g = dst->g;
+    hipLaunchKernelGGL(k_lincomb, dim3((g.qy + 255) / 256, g.qx, dst->nvar), dim3(256), 0,
+                       dst->ctx->stream, dst->d, (const double *)src->d, (const double *)k->d, g,
+                       dst->nvar, lc);
+    PYRO_CHECK_HIP(hipGetLastError());
+    dst->next_cfl_min = -1.0;
     return 0;
 }
 

@@ -193,6 +193,24 @@ class DeviceState:
         with self.ctx.lock:
             check(self._l.pyrohip_fill_bc(self.h, int(n)))
 
+    # ---- compressible_rk -----------------------------------------------------
+    def comp_rk_rhs(self, params, kstate, slot):
+        with self.ctx.lock:
+            check(self._l.pyrohip_comp_rk_rhs(self.h, C.byref(params), kstate.h, int(slot)))
+
+    def comp_rk_dt(self, params, cfl):
+        out = C.c_double()
+        with self.ctx.lock:
+            check(self._l.pyrohip_comp_rk_dt(self.h, C.byref(params), float(cfl), C.byref(out)))
+        return out.value
+
+    def lincomb(self, src, kstate, coefs):
+        """self <- src (whole array); interior += coefs[s] * k_s in order"""
+        c = np.ascontiguousarray(coefs, dtype=np.float64)
+        with self.ctx.lock:
+            check(self._l.pyrohip_state_lincomb(self.h, src.h, kstate.h, dptr(c) if len(c) else
+                                                dptr(np.zeros(1)), len(c)))
+
     # ---- burgers / incompressible (csrc/incompressible.hip) ----------------
     def bg_step(self, iu, iv, dx, dy, dt, limiter):
         with self.ctx.lock:

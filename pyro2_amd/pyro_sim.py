@@ -17,7 +17,10 @@ from .util.runparams import RuntimeParameters, _get_val
 
 # solvers with a device implementation in this package; the reference's other
 # solvers are out of scope
-valid_solvers = ["advection", "burgers", "compressible", "diffusion", "incompressible"]
+valid_solvers = ["advection", "burgers", "compressible", "compressible_rk", "diffusion",
+                 "incompressible"]
+# solvers that share another solver's problem directory (inputs files)
+problem_home = {"compressible_rk": "compressible"}
 
 
 class Pyro:
@@ -70,7 +73,8 @@ class Pyro:
             self.rp.set_param(k, v, no_new=False)
         if inputs_file is not None:
             if not os.path.isfile(inputs_file):
-                inputs_file = self.pyro_home + self.solver_name + "/problems/" + inputs_file
+                base = problem_home.get(self.solver_name, self.solver_name)
+                inputs_file = self.pyro_home + base + "/problems/" + inputs_file
                 if not os.path.isfile(inputs_file):
                     msg.fail("ERROR: inputs file does not exist")
             self.rp.load_params(inputs_file, no_new=1)

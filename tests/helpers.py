@@ -57,3 +57,49 @@ def oracle_comp_run(ic, meta, bcs, tmax, max_steps, init_tstep_factor=0.01,
         pol.advance(dt)
         dts.append(dt)
     return U, np.array(dts), pol.t
+
+
+# Butcher tableaus of pyro/mesh/integration.py:27-60 (a, b)
+RK_TABLEAU = {
+    "RK2": ([[0.0, 0.0], [0.5, 0.0]], [0.0, 1.0]),
+    "TVD2": ([[0.0, 0.0], [1.0, 0.0]], [0.5, 0.5]),
+    "TVD3": ([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.25, 0.25, 0.0]], [1. / 6., 1. / 6., 2. / 3.]),
+    "RK4": ([[0.0, 0.0, 0.0, 0.0], [0.5, 0.0, 0.0, 0.0], [0.0, 0.5, 0.0, 0.0],
+             [0.0, 0.0, 1.0, 0.0]], [1. / 6., 1. / 3., 1. / 3., 1. / 6.]),
+}
+
+
+def oracle_rk_step(U, P, bcs, dt, method, ambient=(0.0,) * 4):
+    """compressible_rk Simulation.evolve (simulation.py:58-95) with the
+    RKIntegrator of mesh/integration.py:63-113 on the oracle"""
+    a, b = RK_TABLEAU[method]
+    ng = P.ng
+    I = (slice(ng, -ng), slice(ng, -ng))
+    ks = []
+    for s in range(len(b)):
+        if s == 0:
+            y = U                      # the state itself: filled and floored in place
+        else:
+            y = U.copy()
+            for j in range(s):
+                y[I] += dt * a[s][j] * ks[j][I]
+        orc.comp_fill_bc(y, P.nx, P.ny, P.ng, bcs, P.gamma, P.grav, P.dy, ambient)
+        rc, k = orc.comp_rk_rhs(y, P)
+        assert rc == 0
+        ks.append(k)
+    for s in range(len(b)):
+        U[I] += dt * b[s] * ks[s][I]
+
+
+def oracle_rk_run(ic, meta, bcs, nsteps, method, f0=0.01, mx=2.0, **over):
+    P, cfl = meta_to_params(meta, bcs, **over)
+    U = np.nan_to_num(np.ascontiguousarray(ic, dtype=np.float64))
+    pol = DtPolicy(1.e30, f0, mx)
+    dts = []
+    for _ in range(nsteps):
+        orc.comp_fill_bc(U, P.nx, P.ny, P.ng, bcs, P.gamma, P.grav, P.dy)
+        dt = pol(orc.comp_rk_dt(U, P.nx, P.ny, P.ng, P.dx, P.dy, P.gamma, cfl))
+        oracle_rk_step(U, P, bcs, dt, method)
+        pol.advance(dt)
+        dts.append(dt)
+    return U, np.array(dts)

@@ -349,3 +349,96 @@ def test_comp_hse_ambient_runs(dev, golden, k, kset):
     if nsteps == len(dts_ref) and k != 1:
         s.fill_bc()
         assert (np.abs(s.download() - g[pre + "filled"]) / scale).max() <= tol
+
+
+@pytest.mark.parametrize("k", range(4))
+def test_compressible_rk(dev, golden, k):
+    """compressible_rk right-hand side and RK2 / TVD2 / TVD3 /
+    RK4 runs (HLLC + CGF, gravity + hse, sponge) against the reference"""
+    from helpers import RK_TABLEAU, oracle_rk_run
+    g = golden("comp_rk")
+    pre = f"c{k}_"
+    meta, bcs = g[pre + "meta"], [str(b) for b in g[pre + "bc"]]
+    method, riemann, sp = str(g[pre + "method"]), str(g[pre + "riemann"]), g[pre + "sponge"]
+    solid = [int(b == "reflect") for b in bcs]
+    kw = dict(riemann=riemann, solid_xl=solid[0], solid_yl=solid[2],
+              sponge=tuple(sp[1:]) if sp[0] else None)
+    P, cfl = dev_params(meta, **kw)
+    nx, ny, ng = int(meta[0]), int(meta[1]), int(meta[2])
+    I = (slice(ng, -ng), slice(ng, -ng))
+    a, b = RK_TABLEAU[method]
+    ns = len(b)
+
+    def states():
+        s = comp_state(dev, nx, ny, bcs)
+        y = comp_state(dev, nx, ny, bcs)
+        kst = device.DeviceState(dev, nx, ny, ng, [["outflow"] * 4] * (4 * ns))
+        for t in (s, y):
+            if "hse" in bcs:
+                t.set_user_bc(meta[5], meta[12], meta[4], None)
+        return s, y, kst
+    tol = 0.0 if dev.kind == "emu" else TOL_EXACT
+    # right-hand side of a reference state (CGF: against the oracle's default
+    # arithmetic, see test_oracle_hse_runs)
+    s, y, kst = states()
+    s.upload(g[pre + "U0"])
+    s.comp_rk_rhs(P, kst, 0)
+    kd = kst.download()[:, :, :4]
+    kref = g[pre + "k"] if riemann != "CGF" else orc.comp_rk_rhs(
+        g[pre + "U0"].copy(), meta_to_params(meta, bcs, **{k_: v for k_, v in kw.items()
+                                                            if k_ in ("riemann", "sponge")})[0])[1]
+    scale = np.maximum(np.abs(kref[I]).max(axis=(0, 1)), 1e-3)
+    assert (np.abs(kd[I] - kref[I]) / scale).max() <= tol * 10
+    # runs
+    dts_ref = g[pre + "dts"]
+    nsteps = len(dts_ref) if dev.kind == "hip" else 2
+    f0, mx = g[pre + "drv"]
+    s, y, kst = states()
+    s.upload(np.nan_to_num(g[pre + "ic"]))
+    pol = DtPolicy(1.e30, f0, mx)
+    for n in range(nsteps):
+        s.fill_bc()
+        dt = pol(s.comp_rk_dt(P, cfl))
+        assert abs(dt / dts_ref[n] - 1) <= max(tol * nsteps * 10, 1e-13)
+        for st in range(ns):
+            if st == 0:
+                cur = s
+            else:
+                y.lincomb(s, kst, [dt * a[st][j] for j in range(st)])
+                y.fill_bc()
+                cur = y
+            cur.comp_rk_rhs(P, kst, st)
+        s.lincomb(s, kst, [dt * b[st] for st in range(ns)])
+        pol.advance(dt)
+    over = {"riemann": riemann}
+    if sp[0]:
+        over["sponge"] = tuple(sp[1:])
+    Uo, _ = oracle_rk_run(g[pre + "ic"], meta, bcs, nsteps, method, f0, mx, **over)
+    U = s.download()
+    scale = np.maximum(np.abs(Uo[I]).max(axis=(0, 1)), 1e-3)
+    assert (np.abs(U[I] - Uo[I]) / scale).max() <= tol * nsteps * 10
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_pyro_compressible_rk(dev, golden, k, tmp_path, monkeypatch):
+    monkeypatch.setattr(device.Context, "_default", dev)
+    monkeypatch.chdir(tmp_path)
+    from pyro2_amd.pyro_sim import Pyro
+    g = golden("comp_rk")
+    pre = f"c{k}_"
+    prob, d = [("sedov", {"mesh.nx": 16, "mesh.ny": 16, "sedov.r_init": 0.2}),
+               ("rt", {"mesh.nx": 12, "mesh.ny": 36, "rt.amp": 0.4,
+                       "compressible.temporal_method": "TVD3"})][k]
+    nsteps = len(g[pre + "dts"]) if dev.kind == "hip" else 2
+    p = Pyro("compressible_rk")
+    p.initialize_problem(prob, inputs_dict=dict(d, **{"driver.max_steps": nsteps}))
+    dts = []
+    while not p.sim.finished():
+        p.single_step()
+        dts.append(p.sim.dt)
+    assert max_rel_err(np.array(dts), g[pre + "dts"][:nsteps]) < 1e-12
+    if nsteps == len(g[pre + "dts"]):
+        U = np.asarray(p.sim.cc_data.data)
+        fin = g[pre + "final"]
+        scale = np.maximum(np.abs(fin[4:-4, 4:-4]).max(axis=(0, 1)), 1e-3)
+        assert (np.abs(U - fin)[4:-4, 4:-4] / scale).max() < 1e-11

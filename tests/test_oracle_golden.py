@@ -439,3 +439,43 @@ def test_incompressible_reference_regression_shear(golden):
     assert np.abs(D[0][I] - g["gold"][0]).max() < 1e-10
     assert np.abs(D[1][I] - g["gold"][1]).max() < 1e-10
     assert np.abs(D[4][I] - g["gold_gp"][0]).max() < 1e-9
+
+
+# ---------------------------------------------------------------------------
+# row f4: compressible_rk (method of lines, RK2 / TVD2 / TVD3 / RK4)
+# ---------------------------------------------------------------------------
+def _rk_case(g, k):
+    pre = f"c{k}_"
+    sp = g[pre + "sponge"]
+    over = {"riemann": str(g[pre + "riemann"])}
+    if sp[0]:
+        over["sponge"] = tuple(sp[1:])
+    return pre, g[pre + "meta"], [str(b) for b in g[pre + "bc"]], str(g[pre + "method"]), over
+
+
+@pytest.mark.parametrize("k", range(4))
+def test_oracle_compressible_rk(golden, k):
+    from helpers import meta_to_params, oracle_rk_run
+    g = golden("comp_rk")
+    pre, meta, bcs, method, over = _rk_case(g, k)
+    ng = int(meta[2])
+    I = (slice(ng, -ng), slice(ng, -ng))
+    # right-hand side of a reference state
+    P, _ = meta_to_params(meta, bcs, **over)
+    U0 = g[pre + "U0"].copy()
+    rc, kk = orc.comp_rk_rhs(U0, P)
+    assert rc == 0
+    if str(g[pre + "riemann"]) == "CGF":      # shim: scalar x**2 is libm pow there
+        orc.set_scalar_pow(1)
+        try:
+            rc, kk = orc.comp_rk_rhs(g[pre + "U0"].copy(), P)
+        finally:
+            orc.set_scalar_pow(0)
+    assert np.array_equal(kk[I], g[pre + "k"][I])
+    # whole run
+    f0, mx = g[pre + "drv"]
+    dts_ref = g[pre + "dts"]
+    U, dts = oracle_rk_run(g[pre + "ic"], meta, bcs, len(dts_ref), method, f0, mx, **over)
+    scale = np.maximum(np.abs(g[pre + "final"][I]).max(axis=(0, 1)), 1e-3)
+    assert np.abs(dts / dts_ref - 1).max() < 1e-13
+    assert (np.abs(U[I] - g[pre + "final"][I]) / scale).max() < 1e-12
