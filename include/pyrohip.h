@@ -230,6 +230,20 @@ int pyrohip_comp_rk_dt(pyrohip_state *s, const pyrohip_comp_params *p,
 int pyrohip_state_lincomb(pyrohip_state *dst, const pyrohip_state *src,
                           const pyrohip_state *k, const double *coef, int ncoef);
 
+/* ---- shallow water (pyro/swe) -------------------------
+   state: 4 variables height, x-momentum, y-momentum, fuel (ng >= 4).
+   riemann: 0 Roe, 1 HLLC (swe/interface.py:216-554).
+   swe_dt: Simulation.method_compute_timestep (swe/simulation.py:143-153);
+   swe_step: Simulation.evolve (:155-193) with unsplit_fluxes.unsplit_fluxes
+   (swe/unsplit_fluxes.py:132-380) and interface.states (:5-213)            */
+int pyrohip_swe_dt(pyrohip_state *s, double dx, double dy, double grav,
+                   double cfl, double *dt_out);
+int pyrohip_swe_step(pyrohip_state *s, double dx, double dy, double grav,
+                     int limiter, int riemann, double dt);
+/* test hook: 0-3 U_xl U_xr U_yl U_yr before the transverse terms, 4 FxT 5 FyT
+   (transverse fluxes), 6 Fx 7 Fy -> host (qx, qy, 4)                        */
+int pyrohip_swe_stage_dump(pyrohip_state *s, int stage, double *out);
+
 /* ---- burgers / incompressible (the solvers on top of the multigrid solver;
         SURVEY.md 8 rows f1, f4) ------------------------------------------- */
 /* burgers Simulation.evolve (pyro/burgers/simulation.py:53-117 with

@@ -554,6 +554,98 @@ def gen_compressible_rk():
     save("comp_rk", **out)
 
 
+def gen_swe():
+    """row f4: shallow-water solver (pyro/swe): short runs and the stages of
+    one more step (face states before / after the transverse terms, fluxes)"""
+    import pyro.swe as swe
+    import pyro.swe.interface as sifc
+    from pyro.mesh import reconstruction as rec
+    cases = [
+        ("dam", "inputs.dam.x", {"mesh.nx": 32, "mesh.ny": 8}, 10),
+        ("dam", "inputs.dam.y", {"mesh.nx": 8, "mesh.ny": 32, "swe.riemann": "HLLC",
+                                 "swe.limiter": 2}, 10),
+        ("quad", None, {"mesh.nx": 16, "mesh.ny": 16, "swe.riemann": "HLLC"}, 8),
+        ("quad", None, {"mesh.nx": 16, "mesh.ny": 20, "swe.riemann": "Roe",
+                        "swe.limiter": 0, "swe.grav": 2.0}, 6),
+        ("kh", None, {"mesh.nx": 16, "mesh.ny": 16}, 6),
+    ]
+    out = {"ncases": np.array(len(cases))}
+    for k, (prob, inp, d, nsteps) in enumerate(cases):
+        p = Pyro("swe")
+        p.initialize_problem(prob, inputs_file=inp, inputs_dict=d)
+        sim = p.sim
+        rp, ivars, myg = sim.rp, sim.ivars, sim.cc_data.grid
+        pre = f"c{k}_"
+        out[pre + "ic"] = np.array(sim.cc_data.data)
+        dts = []
+        for _ in range(nsteps):
+            p.single_step()
+            dts.append(sim.dt)
+        out[pre + "final"] = np.array(sim.cc_data.data)
+        out[pre + "dts"] = np.array(dts)
+        g = rp.get_param("swe.grav")
+        limiter = rp.get_param("swe.limiter")
+        out[pre + "meta"] = np.array([myg.nx, myg.ny, myg.ng, myg.dx, myg.dy, g, limiter,
+                                      rp.get_param("driver.cfl")])
+        out[pre + "riemann"] = np.array(rp.get_param("swe.riemann"))
+        out[pre + "bc"] = bc_names(rp)
+        out[pre + "drv"] = np.array([p.rp.get_param("driver.init_tstep_factor"),
+                                     p.rp.get_param("driver.max_dt_change")])
+        # stages of one more step
+        sim.cc_data.fill_BC_all()
+        sim.compute_timestep()
+        dt = sim.dt
+        out[pre + "U0"] = np.array(sim.cc_data.data)
+        out[pre + "dt"] = np.array(dt)
+        q = swe.cons_to_prim(sim.cc_data.data, ivars, myg)
+        ldx = myg.scratch_array(nvar=ivars.nvar)
+        ldy = myg.scratch_array(nvar=ivars.nvar)
+        for n in range(ivars.nvar):
+            ldx[:, :, n] = rec.limit(q[:, :, n], myg, 1, limiter)
+            ldy[:, :, n] = rec.limit(q[:, :, n], myg, 2, limiter)
+        args = (ivars.ih, ivars.iu, ivars.iv, ivars.ix, ivars.naux, g)
+        V_l, V_r = sifc.states(1, myg.ng, myg.dx, dt, *args, q, ldx)
+        out[pre + "Uxl0"] = np.array(swe.prim_to_cons(V_l, ivars, myg))
+        out[pre + "Uxr0"] = np.array(swe.prim_to_cons(V_r, ivars, myg))
+        V_l, V_r = sifc.states(2, myg.ng, myg.dy, dt, *args, q, ldy)
+        out[pre + "Uyl0"] = np.array(swe.prim_to_cons(ai.ArrayIndexer(d=V_l, grid=myg), ivars, myg))
+        out[pre + "Uyr0"] = np.array(swe.prim_to_cons(ai.ArrayIndexer(d=V_r, grid=myg), ivars, myg))
+        rf = sifc.riemann_hllc if rp.get_param("swe.riemann") == "HLLC" else sifc.riemann_roe
+        rargs = (ivars.ih, ivars.ixmom, ivars.iymom, ivars.ihx, ivars.naux)
+        out[pre + "FxT"] = np.array(rf(1, myg.ng, *rargs, sim.solid.xl, sim.solid.xr, g,
+                                       out[pre + "Uxl0"], out[pre + "Uxr0"]))
+        out[pre + "FyT"] = np.array(rf(2, myg.ng, *rargs, sim.solid.yl, sim.solid.yr, g,
+                                       out[pre + "Uyl0"], out[pre + "Uyr0"]))
+        import pyro.swe.unsplit_fluxes as sflx
+        Fx, Fy = sflx.unsplit_fluxes(sim.cc_data, rp, ivars, sim.solid, sim.tc, dt)
+        out[pre + "Fx"], out[pre + "Fy"] = np.array(Fx), np.array(Fy)
+        sim.evolve()
+        out[pre + "U1"] = np.array(sim.cc_data.data)
+        print("swe case", k, prob, d, "dt", dt)
+    save("swe", **out)
+
+    # reference regression: swe dam inputs.dam.x (128x10, 81 steps) vs
+    # pyro/swe/tests/dam_x_0081.h5 (test.py:113)
+    p = Pyro("swe")
+    p.initialize_problem("dam", inputs_file="inputs.dam.x")
+    ic = np.array(p.sim.cc_data.data)
+    dts = []
+    while not p.sim.finished():
+        p.single_step()
+        dts.append(p.sim.dt)
+    names = ["height", "x-momentum", "y-momentum", "fuel"]
+    with h5py.File(REF + "/swe/tests/dam_x_0081.h5", "r") as f:
+        assert int(f.attrs["nsteps"]) == p.sim.n, (f.attrs["nsteps"], p.sim.n)
+        gold = np.stack([f["state/" + nm + "/data"][...] for nm in names], axis=-1)
+    run = np.stack([np.array(p.sim.cc_data.get_var(nm).v()) for nm in names], axis=-1)
+    print("dam_x: reference-run vs stored golden, max abs err", np.abs(run - gold).max())
+    myg = p.sim.cc_data.grid
+    save("swe_dam_x_0081", ic=ic, gold=gold, run=run, dts=np.array(dts),
+         meta=np.array([myg.nx, myg.ny, myg.ng, myg.dx, myg.dy, p.rp.get_param("swe.grav"),
+                        p.rp.get_param("swe.limiter"), p.rp.get_param("driver.cfl")]),
+         bc=bc_names(p.rp), tmax=np.array(p.sim.tmax), riemann=np.array("Roe"))
+
+
 def _raw_cfl_dt(sim):
     dt_keep, dto_keep = sim.dt, sim.dt_old
     sim.method_compute_timestep()
@@ -827,6 +919,8 @@ if __name__ == "__main__":
         gen_incompressible()
     if "comp_rk" in sys.argv[1:]:
         gen_compressible_rk()
+    if "swe" in sys.argv[1:]:
+        gen_swe()
     which = sys.argv[1:] or ["bc", "adv", "comp_stages", "comp_runs", "mg", "diffusion"]
     if "diffusion" in which:
         gen_diffusion()

@@ -401,3 +401,39 @@ def comp_rk_dt(U, nx, ny, ng, dx, dy, gamma, cfl):
     f.restype = C.c_double
     return f(_p(U), nx, ny, ng, C.c_double(dx), C.c_double(dy), C.c_double(gamma),
              C.c_double(cfl))
+
+
+# ---- shallow water (row f4) -------------------------------------------------
+class SweParams(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("ng", C.c_int), ("dx", C.c_double),
+                ("dy", C.c_double), ("g", C.c_double), ("limiter", C.c_int),
+                ("riemann", C.c_int)]
+
+
+class SweStages(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in
+                ("Uxl0", "Uxr0", "Uyl0", "Uyr0", "FxT", "FyT", "Fx", "Fy")]
+
+
+def swe_params(nx, ny, ng, dx, dy, g, limiter, riemann):
+    return SweParams(int(nx), int(ny), int(ng), dx, dy, g, int(limiter),
+                     {"Roe": 0, "HLLC": 1}[riemann])
+
+
+def swe_dt(U, P, cfl):
+    f = lib().orc_swe_dt
+    f.restype = C.c_double
+    return f(_p(U), P.nx, P.ny, P.ng, C.c_double(P.dx), C.c_double(P.dy), C.c_double(P.g),
+             C.c_double(cfl))
+
+
+def swe_step(U, P, dt, stages=False):
+    _ck(U)
+    st = SweStages()
+    outs = {}
+    if stages:
+        for n, _t in SweStages._fields_:
+            outs[n] = np.zeros_like(U)
+            setattr(st, n, _p(outs[n]))
+    lib().orc_swe_step(_p(U), C.byref(P), C.c_double(dt), C.byref(st) if stages else None)
+    return outs

@@ -2019,3 +2019,317 @@ double orc_comp_rk_dt(const double *U, int nx, int ny, int ng, double dx,
     }
     return cfl * m;
 }
+
+/* ================================================================== */
+/* Shallow water: pyro/swe                           */
+/*   simulation.py:48-80 (cons/prim), :143-193 (dt, evolve)            */
+/*   unsplit_fluxes.py:132-380                                         */
+/*   interface.py:5-578 (states, riemann_roe, riemann_hllc, consFlux)  */
+/* 4 variables: height, x-momentum, y-momentum, fuel (h X); primitive  */
+/* h, u, v, X.  (qx,qy,4) AoS arrays.                                  */
+/* ================================================================== */
+#define SQ(x) sq_ref(x)
+enum { SH = 0, SMX = 1, SMY = 2, SHX = 3 };
+
+typedef struct {
+    int nx, ny, ng;
+    double dx, dy, g;
+    int limiter;
+    int riemann;     /* 0 Roe, 1 HLLC */
+} orc_swe_params;
+
+/* interface.py:557-578 */
+static void swe_cons_flux(int idir, double g, const double *U, double *F)
+{
+    const double u = U[SMX] / U[SH], v = U[SMY] / U[SH];
+    if (idir == 1) {
+        F[SH] = U[SH] * u;
+        F[SMX] = U[SMX] * u + 0.5 * g * SQ(U[SH]);
+        F[SMY] = U[SMY] * u;
+        F[SHX] = U[SHX] * u;
+    } else {
+        F[SH] = U[SH] * v;
+        F[SMX] = U[SMX] * v;
+        F[SMY] = U[SMY] * v + 0.5 * g * SQ(U[SH]);
+        F[SHX] = U[SHX] * v;
+    }
+}
+
+/* interface.py:5-213 */
+static void swe_states(int idir, int nx, int ny, int ng, double dx, double dt, double g,
+                       const double *qv, const double *dqv, double *q_l, double *q_r)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx, jlo = ng, jhi = ng + ny; /* njit-local */
+    memset(q_l, 0, sizeof(double) * qx * qy * 4);
+    memset(q_r, 0, sizeof(double) * qx * qy * 4);
+    const double dtdx = dt / dx;
+    const double dtdx3 = 0.33333 * dtdx;   /* sic, interface.py:100 */
+    const int in = (idir == 1) ? 1 : 2;    /* normal velocity */
+    double lvec[4][4], rvec[4][4], e_val[4], betal[4], betar[4];
+    for (int i = ilo - 2; i < ihi + 2; i++)
+        for (int j = jlo - 2; j < jhi + 2; j++) {
+            const double *dq = dqv + ((size_t)i * qy + j) * 4;
+            const double *q = qv + ((size_t)i * qy + j) * 4;
+            const double cs = sqrt(g * q[0]);
+            memset(lvec, 0, sizeof lvec);
+            memset(rvec, 0, sizeof rvec);
+            e_val[0] = q[in] - cs; e_val[1] = q[in]; e_val[2] = q[in] + cs; e_val[3] = q[in];
+            if (idir == 1) {
+                lvec[0][0] = cs;   lvec[0][1] = -q[0];
+                lvec[1][2] = 1.0;
+                lvec[2][0] = cs;   lvec[2][1] = q[0];
+                rvec[0][0] = q[0]; rvec[0][1] = -cs;
+                rvec[1][2] = 1.0;
+                rvec[2][0] = q[0]; rvec[2][1] = cs;
+            } else {
+                lvec[0][0] = cs;   lvec[0][2] = -q[0];
+                lvec[1][1] = 1.0;
+                lvec[2][0] = cs;   lvec[2][2] = q[0];
+                rvec[0][0] = q[0]; rvec[0][2] = -cs;
+                rvec[1][1] = 1.0;
+                rvec[2][0] = q[0]; rvec[2][2] = cs;
+            }
+            lvec[3][3] = 1.0; rvec[3][3] = 1.0;
+            for (int k = 0; k < 4; k++) {
+                lvec[0][k] = lvec[0][k] * 0.50 / (cs * q[0]);
+                lvec[2][k] = -lvec[2][k] * 0.50 / (cs * q[0]);
+            }
+            double *ql = (idir == 1) ? q_l + ((size_t)(i + 1) * qy + j) * 4
+                                     : q_l + ((size_t)i * qy + (j + 1)) * 4;
+            double *qr = q_r + ((size_t)i * qy + j) * 4;
+            double factor = 0.5 * (1.0 - dtdx * dmax(e_val[2], 0.0));
+            for (int m = 0; m < 4; m++) ql[m] = q[m] + factor * dq[m];
+            factor = 0.5 * (1.0 + dtdx * dmin(e_val[0], 0.0));
+            for (int m = 0; m < 4; m++) qr[m] = q[m] - factor * dq[m];
+            for (int m = 0; m < 4; m++) {
+                double asum = 0.0;
+                for (int k = 0; k < 4; k++) asum += lvec[m][k] * dq[k];
+                betal[m] = dtdx3 * (e_val[2] - e_val[m]) * (copysign(1.0, e_val[m]) + 1.0) * asum;
+                betar[m] = dtdx3 * (e_val[0] - e_val[m]) * (1.0 - copysign(1.0, e_val[m])) * asum;
+            }
+            for (int m = 0; m < 4; m++) {
+                double sum_l = 0.0, sum_r = 0.0;
+                for (int k = 0; k < 4; k++) {
+                    sum_l += betal[k] * rvec[k][m];
+                    sum_r += betar[k] * rvec[k][m];
+                }
+                ql[m] = ql[m] + sum_l;
+                qr[m] = qr[m] + sum_r;
+            }
+        }
+}
+
+/* interface.py:216-385 */
+static void swe_riemann_roe(int idir, int nx, int ny, int ng, double g, const double *U_l,
+                            const double *U_r, double *F)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx, jlo = ng, jhi = ng + ny;
+    const double smallc = 1.e-10, tol = 0.1e-1;
+    const int im = (idir == 1) ? SMX : SMY;
+    memset(F, 0, sizeof(double) * qx * qy * 4);
+    for (int i = ilo - 1; i < ihi + 1; i++)
+        for (int j = jlo - 1; j < jhi + 1; j++) {
+            const double *Ul = U_l + ((size_t)i * qy + j) * 4, *Ur = U_r + ((size_t)i * qy + j) * 4;
+            double *Fo = F + ((size_t)i * qy + j) * 4;
+            const double h_l = Ul[SH], un_l = Ul[im] / h_l;
+            const double h_r = Ur[SH], un_r = Ur[im] / h_r;
+            const double c_l = dmax(smallc, sqrt(g * h_l)), c_r = dmax(smallc, sqrt(g * h_r));
+            double U_roe[4], delta[4], lambda[4], alpha[4], K[4][4];
+            for (int n = 0; n < 4; n++) {
+                U_roe[n] = (Ul[n] / sqrt(h_l) + Ur[n] / sqrt(h_r)) / (sqrt(h_l) + sqrt(h_r));
+                delta[n] = Ur[n] / h_r - Ul[n] / h_l;
+            }
+            U_roe[SH] = sqrt(h_l * h_r);
+            const double c_roe = sqrt(0.5 * (SQ(c_l) + SQ(c_r)));
+            delta[SH] = h_r - h_l;
+            const double un_roe = U_roe[im];
+            memset(K, 0, sizeof K);
+            lambda[0] = un_roe - c_roe; lambda[1] = un_roe; lambda[2] = un_roe + c_roe;
+            if (idir == 1) {
+                alpha[0] = 0.5 * (delta[SH] - U_roe[SH] / c_roe * delta[SMX]);
+                alpha[1] = U_roe[SH] * delta[SMY];
+                alpha[2] = 0.5 * (delta[SH] + U_roe[SH] / c_roe * delta[SMX]);
+                K[0][0] = 1.0; K[0][1] = un_roe - c_roe; K[0][2] = U_roe[SMY];
+                K[1][2] = 1.0;
+                K[2][0] = 1.0; K[2][1] = un_roe + c_roe; K[2][2] = U_roe[SMY];
+            } else {
+                alpha[0] = 0.5 * (delta[SH] - U_roe[SH] / c_roe * delta[SMY]);
+                alpha[1] = U_roe[SH] * delta[SMX];
+                alpha[2] = 0.5 * (delta[SH] + U_roe[SH] / c_roe * delta[SMY]);
+                K[0][0] = 1.0; K[0][1] = U_roe[SMX]; K[0][2] = un_roe - c_roe;
+                K[1][1] = 1.0;
+                K[2][0] = 1.0; K[2][1] = U_roe[SMX]; K[2][2] = un_roe + c_roe;
+            }
+            lambda[3] = un_roe;
+            alpha[3] = U_roe[SH] * delta[3];
+            K[3][3] = 1.0;
+            double Fl[4], Fr[4];
+            swe_cons_flux(idir, g, Ul, Fl);
+            swe_cons_flux(idir, g, Ur, Fr);
+            for (int n = 0; n < 4; n++) Fo[n] = 0.5 * (Fl[n] + Fr[n]);
+            const double h_star = 1.0 / g * SQ(0.5 * (c_l + c_r) + 0.25 * (un_l - un_r));
+            const double u_star = 0.5 * (un_l + un_r) + c_l - c_r;
+            const double c_star = sqrt(g * h_star);
+            if (fabs(lambda[0]) < tol)
+                lambda[0] = lambda[0] * (u_star - c_star - lambda[0]) /
+                            (u_star - c_star - (un_l - c_l));
+            if (fabs(lambda[2]) < tol)
+                lambda[2] = lambda[2] * (u_star + c_star - lambda[2]) /
+                            (u_star + c_star - (un_r + c_r));
+            for (int n = 0; n < 4; n++)
+                for (int m = 0; m < 4; m++)
+                    Fo[n] -= 0.5 * alpha[m] * fabs(lambda[m]) * K[m][n];
+        }
+}
+
+/* interface.py:388-554 */
+static void swe_riemann_hllc(int idir, int nx, int ny, int ng, double g, const double *U_l,
+                             const double *U_r, double *F)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx, jlo = ng, jhi = ng + ny;
+    const double smallc = 1.e-10;
+    const int im = (idir == 1) ? SMX : SMY, it = (idir == 1) ? SMY : SMX;
+    memset(F, 0, sizeof(double) * qx * qy * 4);
+    for (int i = ilo - 1; i < ihi + 1; i++)
+        for (int j = jlo - 1; j < jhi + 1; j++) {
+            const double *Ul = U_l + ((size_t)i * qy + j) * 4, *Ur = U_r + ((size_t)i * qy + j) * 4;
+            double *Fo = F + ((size_t)i * qy + j) * 4;
+            const double h_l = Ul[SH], un_l = Ul[im] / h_l, ut_l = Ul[it] / h_l;
+            const double h_r = Ur[SH], un_r = Ur[im] / h_r, ut_r = Ur[it] / h_r;
+            const double c_l = dmax(smallc, sqrt(g * h_l)), c_r = dmax(smallc, sqrt(g * h_r));
+            const double h_avg = 0.5 * (h_l + h_r), c_avg = 0.5 * (c_l + c_r);
+            const double hstar = h_avg - 0.25 * (un_r - un_l) * h_avg / c_avg;
+            const double S_l = (hstar <= h_l) ? un_l - c_l
+                                              : un_l - c_l * sqrt(0.5 * (hstar + h_l) * hstar) / h_l;
+            const double S_r = (hstar <= h_r) ? un_r + c_r
+                                              : un_r + c_r * sqrt(0.5 * (hstar + h_r) * hstar) / h_r;
+            const double S_c = (S_l * h_r * (un_r - S_r) - S_r * h_l * (un_l - S_l)) /
+                               (h_r * (un_r - S_r) - h_l * (un_l - S_l));
+            double Us[4];
+            if (S_r <= 0.0) {
+                swe_cons_flux(idir, g, Ur, Fo);
+            } else if (S_c <= 0.0 && 0.0 < S_r) {
+                const double fac = h_r * (S_r - un_r) / (S_r - S_c);
+                Us[SH] = fac; Us[im] = fac * S_c; Us[it] = fac * ut_r;
+                Us[SHX] = fac * Ur[SHX] / h_r;
+                swe_cons_flux(idir, g, Ur, Fo);
+                for (int n = 0; n < 4; n++) Fo[n] = Fo[n] + S_r * (Us[n] - Ur[n]);
+            } else if (S_l < 0.0 && 0.0 < S_c) {
+                const double fac = h_l * (S_l - un_l) / (S_l - S_c);
+                Us[SH] = fac; Us[im] = fac * S_c; Us[it] = fac * ut_l;
+                Us[SHX] = fac * Ul[SHX] / h_l;
+                swe_cons_flux(idir, g, Ul, Fo);
+                for (int n = 0; n < 4; n++) Fo[n] = Fo[n] + S_l * (Us[n] - Ul[n]);
+            } else {
+                swe_cons_flux(idir, g, Ul, Fo);
+            }
+        }
+}
+
+static void swe_riemann(const orc_swe_params *P, int idir, const double *Ul, const double *Ur,
+                        double *F)
+{
+    if (P->riemann == 1) swe_riemann_hllc(idir, P->nx, P->ny, P->ng, P->g, Ul, Ur, F);
+    else swe_riemann_roe(idir, P->nx, P->ny, P->ng, P->g, Ul, Ur, F);
+}
+
+/* simulation.py:48-80 */
+static void swe_prim_to_cons(const double *q, size_t N, double *U)
+{
+    for (size_t k = 0; k < N; k++) {
+        const double *qc = q + k * 4;
+        double *Uc = U + k * 4;
+        Uc[SH] = qc[0];
+        Uc[SMX] = qc[1] * Uc[SH];
+        Uc[SMY] = qc[2] * Uc[SH];
+        Uc[SHX] = qc[3] * qc[0];
+    }
+}
+
+/* simulation.py:143-153 + derives.py */
+double orc_swe_dt(const double *U, int nx, int ny, int ng, double dx, double dy, double g,
+                  double cfl)
+{
+    const size_t N = (size_t)(nx + 2 * ng) * (ny + 2 * ng);
+    double xm = INFINITY, ym = INFINITY;
+    for (size_t k = 0; k < N; k++) {
+        const double h = U[k * 4 + SH], u = U[k * 4 + SMX] / h, v = U[k * 4 + SMY] / h;
+        const double cs = sqrt(g * h);
+        xm = dmin(xm, dx / (fabs(u) + cs));
+        ym = dmin(ym, dy / (fabs(v) + cs));
+    }
+    return cfl * dmin(xm, ym);
+}
+
+typedef struct {
+    double *Uxl0, *Uxr0, *Uyl0, *Uyr0, *FxT, *FyT, *Fx, *Fy;   /* any may be NULL */
+} orc_swe_stages;
+
+/* Simulation.evolve (simulation.py:155-193) with unsplit_fluxes.py:132-380 */
+void orc_swe_step(double *U, const orc_swe_params *P, double dt, orc_swe_stages *st)
+{
+    const int nx = P->nx, ny = P->ny, ng = P->ng;
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx - 1, jlo = ng, jhi = ng + ny - 1;
+    const size_t N = (size_t)qx * qy;
+    const double dx = P->dx, dy = P->dy;
+#define U4(a, i, j, n) a[((size_t)(i) * qy + (j)) * 4 + (n)]
+    double *q = zalloc(N * 4), *ldx = zalloc(N * 4), *ldy = zalloc(N * 4), *tmp = zalloc(N);
+    double *V_l = zalloc(N * 4), *V_r = zalloc(N * 4);
+    double *Uxl = zalloc(N * 4), *Uxr = zalloc(N * 4), *Uyl = zalloc(N * 4), *Uyr = zalloc(N * 4);
+    double *Fx = zalloc(N * 4), *Fy = zalloc(N * 4);
+    for (size_t k = 0; k < N; k++) {            /* cons_to_prim over the whole array */
+        q[k * 4 + 0] = U[k * 4 + SH];
+        q[k * 4 + 1] = U[k * 4 + SMX] / U[k * 4 + SH];
+        q[k * 4 + 2] = U[k * 4 + SMY] / U[k * 4 + SH];
+        q[k * 4 + 3] = U[k * 4 + SHX] / q[k * 4 + 0];
+    }
+    for (int n = 0; n < 4; n++) {               /* xi = 1 (no flattening) */
+        orc_limit(q + n, 4, nx, ny, ng, 1, P->limiter, tmp);
+        for (size_t k = 0; k < N; k++) ldx[k * 4 + n] = 1.0 * tmp[k];
+        orc_limit(q + n, 4, nx, ny, ng, 2, P->limiter, tmp);
+        for (size_t k = 0; k < N; k++) ldy[k * 4 + n] = 1.0 * tmp[k];
+    }
+    swe_states(1, nx, ny, ng, dx, dt, P->g, q, ldx, V_l, V_r);
+    swe_prim_to_cons(V_l, N, Uxl); swe_prim_to_cons(V_r, N, Uxr);
+    swe_states(2, nx, ny, ng, dy, dt, P->g, q, ldy, V_l, V_r);
+    swe_prim_to_cons(V_l, N, Uyl); swe_prim_to_cons(V_r, N, Uyr);
+    if (st && st->Uxl0) memcpy(st->Uxl0, Uxl, N * 32);
+    if (st && st->Uxr0) memcpy(st->Uxr0, Uxr, N * 32);
+    if (st && st->Uyl0) memcpy(st->Uyl0, Uyl, N * 32);
+    if (st && st->Uyr0) memcpy(st->Uyr0, Uyr, N * 32);
+    swe_riemann(P, 1, Uxl, Uxr, Fx);
+    swe_riemann(P, 2, Uyl, Uyr, Fy);
+    if (st && st->FxT) memcpy(st->FxT, Fx, N * 32);
+    if (st && st->FyT) memcpy(st->FyT, Fy, N * 32);
+    {   /* transverse flux differences, unsplit_fluxes.py:331-352, b = (2, 1) */
+        const double dtdx = dt / dx, dtdy = dt / dy;
+        for (int n = 0; n < 4; n++)
+            for (int i = ilo - 2; i <= ihi + 1; i++)
+                for (int j = jlo - 2; j <= jhi + 1; j++) {
+                    U4(Uxl, i, j, n) += -0.5 * dtdy * (U4(Fy, i - 1, j + 1, n) - U4(Fy, i - 1, j, n));
+                    U4(Uxr, i, j, n) += -0.5 * dtdy * (U4(Fy, i, j + 1, n) - U4(Fy, i, j, n));
+                    U4(Uyl, i, j, n) += -0.5 * dtdx * (U4(Fx, i + 1, j - 1, n) - U4(Fx, i, j - 1, n));
+                    U4(Uyr, i, j, n) += -0.5 * dtdx * (U4(Fx, i + 1, j, n) - U4(Fx, i, j, n));
+                }
+    }
+    swe_riemann(P, 1, Uxl, Uxr, Fx);
+    swe_riemann(P, 2, Uyl, Uyr, Fy);
+    if (st && st->Fx) memcpy(st->Fx, Fx, N * 32);
+    if (st && st->Fy) memcpy(st->Fy, Fy, N * 32);
+    {
+        const double dtdx = dt / dx, dtdy = dt / dy;
+        for (int n = 0; n < 4; n++)
+            for (int i = ilo; i <= ihi; i++)
+                for (int j = jlo; j <= jhi; j++)
+                    U4(U, i, j, n) += dtdx * (U4(Fx, i, j, n) - U4(Fx, i + 1, j, n)) +
+                                      dtdy * (U4(Fy, i, j, n) - U4(Fy, i, j + 1, n));
+    }
+#undef U4
+    free(q); free(ldx); free(ldy); free(tmp); free(V_l); free(V_r);
+    free(Uxl); free(Uxr); free(Uyl); free(Uyr); free(Fx); free(Fy);
+}
+#undef SQ

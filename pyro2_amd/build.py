@@ -32,6 +32,7 @@ UNITS = [
     ("comp_api.hip", "comp_api", ["-ffp-contract=off"]),
     ("multigrid.hip", "multigrid", ["-ffp-contract=off"]),
     ("incompressible.hip", "incompressible", ["-ffp-contract=off"]),
+    ("swe.hip", "swe", ["-ffp-contract=off"]),
     ("comm.hip", "comm", ["-ffp-contract=off"]),
 ]
 

@@ -211,6 +211,29 @@ class DeviceState:
             check(self._l.pyrohip_state_lincomb(self.h, src.h, kstate.h, dptr(c) if len(c) else
                                                 dptr(np.zeros(1)), len(c)))
 
+    # ---- shallow water (csrc/swe.hip) ------------------------------------------
+    SWE_RIEMANN = {"Roe": 0, "HLLC": 1}
+
+    def swe_dt(self, dx, dy, grav, cfl):
+        out = C.c_double()
+        with self.ctx.lock:
+            check(self._l.pyrohip_swe_dt(self.h, float(dx), float(dy), float(grav), float(cfl),
+                                         C.byref(out)))
+        return out.value
+
+    def swe_step(self, dx, dy, grav, limiter, riemann, dt):
+        r = self.SWE_RIEMANN[riemann] if isinstance(riemann, str) else int(riemann)
+        with self.ctx.lock:
+            check(self._l.pyrohip_swe_step(self.h, float(dx), float(dy), float(grav), int(limiter),
+                                           r, float(dt)))
+
+    def swe_stage(self, name):
+        names = ("Uxl0", "Uxr0", "Uyl0", "Uyr0", "FxT", "FyT", "Fx", "Fy")
+        out = np.zeros((self.qx, self.qy, 4))
+        with self.ctx.lock:
+            check(self._l.pyrohip_swe_stage_dump(self.h, names.index(name), dptr(out)))
+        return out
+
     # ---- burgers / incompressible (csrc/incompressible.hip) ----------------
     def bg_step(self, iu, iv, dx, dy, dt, limiter):
         with self.ctx.lock:

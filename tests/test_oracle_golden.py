@@ -479,3 +479,73 @@ def test_oracle_compressible_rk(golden, k):
     scale = np.maximum(np.abs(g[pre + "final"][I]).max(axis=(0, 1)), 1e-3)
     assert np.abs(dts / dts_ref - 1).max() < 1e-13
     assert (np.abs(U[I] - g[pre + "final"][I]) / scale).max() < 1e-12
+
+
+# ---------------------------------------------------------------------------
+# row f4: shallow water (pyro/swe), Roe and HLLC
+# ---------------------------------------------------------------------------
+def _swe_params(g, pre):
+    nx, ny, ng, dx, dy, grav, lim, cfl = g[pre + "meta"]
+    return orc.swe_params(nx, ny, ng, dx, dy, grav, lim, str(g[pre + "riemann"])), cfl
+
+
+def swe_fill(U, P, bcs):
+    from oracle.orc import comp_var_bcs
+    vb = comp_var_bcs(bcs)      # rows for (even, even, x-odd, y-odd)
+    rows = [vb[0], vb[2], vb[3], vb[0]]     # height, x-momentum, y-momentum, fuel
+    for n in range(4):
+        orc.fill_ghost(U, P.nx, P.ny, P.ng, rows[n], n=n)
+
+
+def oracle_swe_run(ic, P, cfl, bcs, nsteps, tmax=1.e30, f0=0.01, mx=2.0):
+    from helpers import DtPolicy
+    U = np.ascontiguousarray(ic, dtype=np.float64).copy()
+    pol = DtPolicy(tmax, f0, mx)
+    dts = []
+    while pol.n < nsteps and pol.t < tmax:
+        swe_fill(U, P, bcs)
+        dt = pol(orc.swe_dt(U, P, cfl))
+        orc.swe_step(U, P, dt)
+        pol.advance(dt)
+        dts.append(dt)
+    return U, np.array(dts), pol
+
+
+@pytest.mark.parametrize("k", range(5))
+def test_oracle_swe(golden, k):
+    """the interpreted shim evaluates the scalar x**2 of consFlux / riemann_roe
+    with libm pow (numba: x*x): goldens are pinned bit for bit in that mode and
+    to round-off in the default one"""
+    g = golden("swe")
+    pre = f"c{k}_"
+    P, cfl = _swe_params(g, pre)
+    bcs = [str(b) for b in g[pre + "bc"]]
+    ng = P.ng
+    I = (slice(ng, -ng), slice(ng, -ng))
+    orc.set_scalar_pow(1)
+    try:
+        U = g[pre + "U0"].copy()
+        st = orc.swe_step(U, P, float(g[pre + "dt"]), stages=True)
+        for nm in ("Uxl0", "Uxr0", "Uyl0", "Uyr0", "FxT", "FyT", "Fx", "Fy"):
+            assert np.array_equal(st[nm], g[pre + nm]), nm
+        assert np.array_equal(U[I], g[pre + "U1"][I])
+        f0, mx = g[pre + "drv"]
+        U, dts, _ = oracle_swe_run(g[pre + "ic"], P, cfl, bcs, len(g[pre + "dts"]), f0=f0, mx=mx)
+        assert np.array_equal(dts, g[pre + "dts"])
+        assert np.array_equal(U[I], g[pre + "final"][I])
+    finally:
+        orc.set_scalar_pow(0)
+    U, dts, _ = oracle_swe_run(g[pre + "ic"], P, cfl, bcs, len(g[pre + "dts"]), f0=f0, mx=mx)
+    assert np.abs(U[I] - g[pre + "final"][I]).max() < 1e-13
+
+
+def test_swe_reference_regression_dam(golden):
+    """pyro/test.py:113: swe dam inputs.dam.x vs dam_x_0081.h5 (128x10, 81
+    steps, Roe): oracle from the reference's IC against the stored golden"""
+    g = golden("swe_dam_x_0081")
+    P, cfl = _swe_params(g, "")
+    bcs = [str(b) for b in g["bc"]]
+    U, dts, pol = oracle_swe_run(g["ic"], P, cfl, bcs, 10000, tmax=float(g["tmax"]))
+    assert pol.n == 81
+    ng = P.ng
+    assert np.abs(U[ng:-ng, ng:-ng] - g["gold"]).max() < 1e-12
