@@ -232,6 +232,40 @@ def test_comp_sedov_512_vs_oracle(hip, fast, kset):
     assert abs(U[4:-4, 4:-4, 0].sum() - ic[4:-4, 4:-4, 0].sum()) < 1e-9 * nx * nx
 
 
+@pytest.mark.gpu
+def test_comp_sedov_4096_properties(hip):
+    """BASELINE config 2 size (sedov 4096^2): the oracle cannot run this in
+    test time, so size-independent properties after 12 steps -- (i) the fused
+    and the staged kernel sets (independent code paths, bit-faithful build)
+    agree to 1e-12, (ii) the default fast build stays within 1e-10 of them,
+    (iii) mass and energy are conserved to round-off (the blast is far from the
+    outflow boundary), (iv) the solution keeps the x <-> y symmetry of the
+    problem, (v) the time steps of all three runs agree"""
+    from sedov_ic import sedov_ic
+    nx = 4096
+    ic, meta, bcs = sedov_ic(nx)
+    runs = {}
+    for name, kw in (("fused", dict(fast_math=0, kernel_set=1)),
+                     ("staged", dict(fast_math=0, kernel_set=0)),
+                     ("fast", dict(fast_math=1, kernel_set=1))):
+        U, dts, _ = device_comp_run(hip, ic, meta, bcs, 0.1, 12, **kw)
+        runs[name] = (U[4:-4, 4:-4].copy(), dts)
+        del U
+    Uf, df = runs["fused"]
+    for other, tol in (("staged", 1e-12), ("fast", TOL_FAST)):
+        Uo, do = runs[other]
+        assert max_rel_err(do, df) <= tol
+        for n in range(4):
+            scale = np.abs(Uf[..., n]).max()
+            assert np.abs(Uo[..., n] - Uf[..., n]).max() <= tol * max(scale, 1.0), (other, n)
+    I0 = ic[4:-4, 4:-4]
+    for n in (0, 1):   # density, energy
+        assert abs(Uf[..., n].sum() - I0[..., n].sum()) <= 1e-12 * np.abs(I0[..., n]).sum()
+    # transpose symmetry: rho, E symmetric; x-momentum(i,j) = y-momentum(j,i)
+    assert np.abs(Uf[..., 0] - Uf[..., 0].T).max() <= 1e-10 * np.abs(Uf[..., 0]).max()
+    assert np.abs(Uf[..., 2] - Uf[..., 3].T).max() <= 1e-10 * np.abs(Uf[..., 2]).max()
+
+
 @pytest.mark.parametrize("kset", [0, 1])
 def test_comp_gravity_run(dev, kset):
     """gravity sources (apply_source_terms + predictor-corrector,
