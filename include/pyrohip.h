@@ -284,6 +284,13 @@ int pyrohip_comm_unique_id(char *out_id /* PYROHIP_UNIQUE_ID_BYTES */);
 int pyrohip_comm_init(pyrohip_ctx *ctx, int nranks, int rank,
                       const char *unique_id);
 int pyrohip_comm_destroy(pyrohip_ctx *ctx);
+/* on: pyrohip_comp_step all-reduces (min) the CFL minimum of the new state
+   over the communicator on the device, inside the step -- every rank must then
+   call comp_step in lock step.  pyrohip_comp_dt_is_global tells whether the next
+   pyrohip_comp_dt comes from that reduced value (no pyrohip_allreduce_min
+   needed) or from a local reduction (first step, after an upload).          */
+int pyrohip_comm_set_global_dt(pyrohip_ctx *ctx, int on);
+int pyrohip_comp_dt_is_global(pyrohip_state *s, int *flag);
 /* exchange ng ghost rows of every variable with the x neighbours
    (rank_lo / rank_hi, -1 = none).  Replaces the single-domain x ghost fill
    for PYROHIP_BC_HALO sides; y ghost fill must follow (fill order of

@@ -68,6 +68,8 @@ _PROTOS = {
     "pyrohip_state_upload_rows": [_VP, C.c_int, C.c_int, _DP],
     "pyrohip_state_download_rows": [_VP, C.c_int, C.c_int, _DP],
     "pyrohip_device_count": [C.POINTER(C.c_int)],
+    "pyrohip_comm_set_global_dt": [_VP, C.c_int],
+    "pyrohip_comp_dt_is_global": [_VP, C.POINTER(C.c_int)],
     "pyrohip_comp_rk_rhs": [_VP, C.POINTER(CompParams), _VP, C.c_int],
     "pyrohip_comp_rk_dt": [_VP, C.POINTER(CompParams), C.c_double, _DP],
     "pyrohip_state_lincomb": [_VP, _VP, _VP, _DP, C.c_int],

@@ -100,6 +100,14 @@ int pyrohip_halo_exchange(pyrohip_state *s, int rank_lo, int rank_hi)
     return 0;
 }
 
+int pyrohip_comm_set_global_dt(pyrohip_ctx *c, int on)
+{
+    PYRO_REQUIRE(c, "NULL context");
+    PYRO_REQUIRE(!on || c->comm != nullptr, "communicator not initialised");
+    c->global_cfl = on != 0;
+    return 0;
+}
+
 static int allreduce_scalar(pyrohip_ctx *c, double *value, ncclRedOp_t op)
 {
     PYRO_REQUIRE(c && value, "NULL argument");
@@ -128,3 +136,12 @@ int pyrohip_allreduce_max(pyrohip_ctx *c, double *value)
 }
 
 }  // extern "C"
+
+namespace pyro {
+int comm_allreduce_min_device(pyrohip_ctx *c, double *d)
+{
+    if (c->comm == nullptr) return 0;
+    PYRO_CHECK_NCCL(ncclAllReduce(d, d, 1, ncclDouble, ncclMin, (ncclComm_t)c->comm, c->stream));
+    return 0;
+}
+}  // namespace pyro

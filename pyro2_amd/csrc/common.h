@@ -90,6 +90,7 @@ struct pyrohip_ctx {
     void *reduce_host = nullptr;  // pinned host words for scalar results
     void *comm = nullptr;     // ncclComm_t
     int nranks = 1, rank = 0;
+    bool global_cfl = false;  // all-reduce the step kernels' CFL minimum on the device
     int num_cus = 0;
 };
 
@@ -107,6 +108,12 @@ struct ProfScope {
     }
     ~ProfScope() { if (b) (void)hipEventRecord(b, c->stream); }
 };
+}  // namespace pyro
+
+namespace pyro {
+// in-place min all-reduce of one device double over the context's communicator
+// on its stream; no-op without a communicator (comm.hip / tests/emu/comm_emu.cpp)
+int comm_allreduce_min_device(pyrohip_ctx *c, double *d);
 }  // namespace pyro
 
 // launch on the context's stream, bracketed by events when profiling is on
@@ -136,4 +143,5 @@ struct pyrohip_state {
     int *d_flag = nullptr;    // positivity flag
     double next_cfl_min = -1.0;  // min over interior of dx/(|u|+c) etc. of the
                                  // state after the last step (-1: unknown)
+    bool cfl_is_global = false;  // ... already reduced over all ranks
 };

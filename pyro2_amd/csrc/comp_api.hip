@@ -43,6 +43,13 @@ int pyrohip_comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, 
     return p->fast_math ? fastm::comp_dt(s, p, cfl, dt_out) : exact::comp_dt(s, p, cfl, dt_out);
 }
 
+int pyrohip_comp_dt_is_global(pyrohip_state *s, int *flag)
+{
+    PYRO_REQUIRE(s && flag, "NULL argument");
+    *flag = (s->next_cfl_min > 0.0 && s->cfl_is_global && !s->user_bc) ? 1 : 0;
+    return 0;
+}
+
 int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
 {
     PYRO_TRY(check_comp(s, p));

@@ -396,6 +396,11 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
                            (const double *)Uin, Uout, g);
     }
     const double *dmin = launch_min_reduce(c->stream, part, P.ntiles);
+    s->cfl_is_global = false;
+    if (c->global_cfl) {   // multi-GPU: the next dt needs the minimum over all slabs
+        PYRO_TRY(comm_allreduce_min_device(c, const_cast<double *>(dmin)));
+        s->cfl_is_global = true;
+    }
     PYRO_CHECK_HIP(hipGetLastError());
     PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, dmin, sizeof(double),
                                   hipMemcpyDeviceToHost, c->stream));

@@ -472,6 +472,11 @@ int comp_step_staged(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     PYRO_LAUNCH(c, "k_update", k_update, dim3(xcd_grid_1d(gx, gy)), block, 0, U,
                 (const double *)W, g, P, part, gx, gy);
     const double *dmin = launch_min_reduce(c->stream, part, nb);
+    s->cfl_is_global = false;
+    if (c->global_cfl) {   // multi-GPU: the next dt needs the minimum over all slabs
+        PYRO_TRY(comm_allreduce_min_device(c, const_cast<double *>(dmin)));
+        s->cfl_is_global = true;
+    }
     PYRO_CHECK_HIP(hipGetLastError());
     // one 16-byte D2H per step: next step's CFL minimum + positivity flag
     PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, dmin, sizeof(double),

@@ -66,14 +66,23 @@ class RcclComm:
     """data-path communication of the product: RCCL inside libpyrohip
     (csrc/comm.hip) on the context's stream"""
 
-    def __init__(self, ctx):
+    def __init__(self, ctx, global_dt=True):
         self.ctx = ctx
+        # the step kernel's CFL minimum is all-reduced on the device inside
+        # comp_step: one host round trip per step less
+        ctx.comm_set_global_dt(global_dt)
 
     def halo_exchange(self, state, lo, hi):
         state.halo_exchange(lo, hi)
 
     def allreduce_min(self, x):
         return self.ctx.allreduce_min(x)
+
+    def dt_min(self, state, params, cfl):
+        """global CFL time step of a decomposed state"""
+        if state.comp_dt_is_global():
+            return state.comp_dt(params, cfl)
+        return self.allreduce_min(state.comp_dt(params, cfl))
 
 
 class HostStagedComm:
@@ -151,7 +160,10 @@ class SlabCompressible:
     def step(self, policy, cfl):
         self.comm.halo_exchange(self.state, self.dec.lo, self.dec.hi)
         self.state.fill_bc()
-        dt = policy(self.comm.allreduce_min(self.state.comp_dt(self.params, cfl)))
+        if hasattr(self.comm, "dt_min"):
+            dt = policy(self.comm.dt_min(self.state, self.params, cfl))
+        else:
+            dt = policy(self.comm.allreduce_min(self.state.comp_dt(self.params, cfl)))
         self.state.comp_step(self.params, dt)
         policy.advance(dt)
         return dt

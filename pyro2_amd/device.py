@@ -100,6 +100,11 @@ class Context:
         with self.lock:
             check(self._l.pyrohip_comm_init(self.h, nranks, rank, unique_id))
 
+    def comm_set_global_dt(self, on=True):
+        """let comp_step all-reduce the next CFL minimum on the device"""
+        with self.lock:
+            check(self._l.pyrohip_comm_set_global_dt(self.h, int(bool(on))))
+
     def allreduce_min(self, x):
         v = C.c_double(x)
         with self.lock:
@@ -303,6 +308,11 @@ class DeviceState:
         with self.ctx.lock:
             check(self._l.pyrohip_comp_dt(self.h, C.byref(params), cfl, C.byref(dt)))
         return dt.value
+
+    def comp_dt_is_global(self):
+        f = C.c_int()
+        check(self._l.pyrohip_comp_dt_is_global(self.h, C.byref(f)))
+        return bool(f.value)
 
     def comp_step(self, params, dt):
         with self.ctx.lock:

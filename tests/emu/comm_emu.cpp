@@ -9,4 +9,12 @@ int pyrohip_comm_destroy(pyrohip_ctx *) { return 0; }
 int pyrohip_halo_exchange(pyrohip_state *, int, int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
 int pyrohip_allreduce_min(pyrohip_ctx *, double *) { return 0; }
 int pyrohip_allreduce_max(pyrohip_ctx *, double *) { return 0; }
+int pyrohip_comm_set_global_dt(pyrohip_ctx *, int on)
+{
+    if (on) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
+    return 0;
+}
+}
+namespace pyro {
+int comm_allreduce_min_device(pyrohip_ctx *, double *) { return 0; }
 }
