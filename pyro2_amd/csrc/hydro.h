@@ -14,24 +14,28 @@
 namespace pyro {
 
 // Division policy.  Bit-faithful build: IEEE division, exactly as written in
-// the reference.  fast_math build: v_rcp_f64 (~2^-23 relative) + two Newton
-// steps (full double precision, not correctly rounded) and a multiply: 6 VALU
-// instructions instead of the ~12 of the IEEE sequence; divisions are ~40 % of
-// this solver's VALU work (profiles/r01_fused_8192_pmc.json).  Parity of the
-// fast build is tolerance-tested (1e-10), not bit-tested.
+// the reference.  fast_math build: v_rcp_f64 (~2^-23 relative) + ONE Newton
+// step (~2^-45 = 3e-14 relative) and a multiply: 4 VALU instructions instead of
+// the ~12 of the IEEE sequence; divisions are ~40 % of this solver's VALU work
+// (profiles/r01_fused_8192_pmc.json).  Parity of the fast build is
+// tolerance-tested (north_star: 1e-10; 606-step quad and 945-step rt
+// regressions included), not bit-tested.  A second Newton step (full double
+// precision) costs 3 % of the step time: -DPYRO_RCP_NEWTON2.
 #if PYRO_FAST && !defined(PYRO_EMU)
 __device__ __forceinline__ double prcp(double b)
 {
     double r = __builtin_amdgcn_rcp(b);
     r = fma(fma(-b, r, 1.0), r, r);
+#ifdef PYRO_RCP_NEWTON2
     r = fma(fma(-b, r, 1.0), r, r);
+#endif
     return r;
 }
 __device__ __forceinline__ double pdiv(double a, double b) { return a * prcp(b); }
 // a / b where rb = prcp(b) was computed once for several quotients
 __device__ __forceinline__ double pdivr(double a, double b, double rb) { (void)b; return a * rb; }
 // sqrt of a strictly positive, normal argument (sound speeds, 1 + ...):
-// v_rsq_f64 + one Goldschmidt step + a residual correction, without the
+// v_rsq_f64 + one Goldschmidt step (~2^-45 relative, like prcp), without the
 // denormal scaling / special-case code of the IEEE expansion
 __device__ __forceinline__ double psqrt(double x)
 {
@@ -40,8 +44,10 @@ __device__ __forceinline__ double psqrt(double x)
     const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
-    const double d = fma(-g, g, x);
+#ifdef PYRO_RCP_NEWTON2
+    const double d = fma(-g, g, x);   // residual correction: full double precision
     g = fma(d, h, g);
+#endif
     return (x > 0.0) ? g : 0.0;
 }
 #else
