@@ -31,7 +31,7 @@ def _worker(rank, world, port, case, out_dir):
     comm = GlooComm(td)
     if case == "sedov":
         from sedov_ic import sedov_ic
-        nx, ny, nsteps = 40, 24, 12
+        nx, ny, nsteps = 40, 24, 6
         ic, meta, bcs = sedov_ic(nx, ny, r_init=0.12)
         dec = SlabDecomp(nx, world, rank)
         kw = dict(dx=meta[3], dy=meta[4], kernel_set=rank % 2)   # mix staged / fused
@@ -96,7 +96,7 @@ def test_two_rank_sedov_bit_identical(tmp_path):
     from sedov_ic import sedov_ic
     _spawn("sedov", tmp_path)
     ic, meta, bcs = sedov_ic(40, 24, r_init=0.12)
-    Uo, dto, _ = oracle_comp_run(ic, meta, bcs, 0.1, 12)
+    Uo, dto, _ = oracle_comp_run(ic, meta, bcs, 0.1, 6)
     for r in range(2):
         z = np.load(tmp_path / f"sedov_{r}.npz")
         a, b = z["rows"]
