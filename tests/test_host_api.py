@@ -249,3 +249,21 @@ def test_h5lite_tree(tmp_path):
         assert f["state"]["density"].attrs["xlb"] == "periodic"
         assert f["state/density/data"][1, 2] == 5.0
         assert list(f["aux"].attrs) == []
+
+
+def test_pyro_import_alias():
+    """code written against pyro2's module paths resolves to this package"""
+    import pyro.multigrid.MG as MG
+    from pyro.compressible import Simulation
+    from pyro.mesh import patch
+    from pyro.pyro_sim import Pyro
+    import pyro2_amd.compressible
+    import pyro2_amd.mesh.patch
+    import pyro2_amd.multigrid.MG
+    import pyro2_amd.pyro_sim
+    assert Pyro is pyro2_amd.pyro_sim.Pyro
+    assert patch is pyro2_amd.mesh.patch
+    assert MG.CellCenterMG2d is pyro2_amd.multigrid.MG.CellCenterMG2d
+    assert Simulation is pyro2_amd.compressible.Simulation
+    with pytest.raises(ImportError):
+        import pyro.no_such_solver  # noqa: F401
