@@ -549,3 +549,19 @@ def test_swe_reference_regression_dam(golden):
     assert pol.n == 81
     ng = P.ng
     assert np.abs(U[ng:-ng, ng:-ng] - g["gold"]).max() < 1e-12
+
+
+def test_survey_fingerprints(golden):
+    """the fingerprints SURVEY.md 8(c) lists for a fresh reference set-up are the
+    ones of the runs behind the fixtures (conda py3.9 / NumPy 1.26)"""
+    g = golden("comp_sedov_64_020")
+    f = g["final"][4:-4, 4:-4]
+    assert float(g["t"]) == 0.009286102192696327
+    assert g["dts"][-1] == 0.000788786465650361
+    assert abs(f[..., 1].sum() - 4774.750655256859) < 1e-9
+    assert f[..., 0].max() == 1.9139231351538135 and f[..., 0].min() == 0.051270183038480036
+    a = golden("adv_smooth_64")
+    fa = a["final"][4:-4, 4:-4]
+    fa = fa[..., 0] if fa.ndim == 3 else fa
+    assert int(a["n"]) == 81
+    assert abs(fa.sum() - 4310.466040637316) < 1e-9 and abs(fa.max() - 1.9600687314173393) < 1e-14
