@@ -646,6 +646,30 @@ def gen_swe():
          bc=bc_names(p.rp), tmax=np.array(p.sim.tmax), riemann=np.array("Roe"))
 
 
+def gen_mg_4096():
+    """BASELINE config 4 at full size: the reference's CellCenterMG2d(4096^2),
+    10 V-cycles.  The solution does not fit a fixture, so
+    a 64x64 lattice of samples, row / column checksums and the norms are kept."""
+    nx = 4096
+    a = MG.CellCenterMG2d(nx, nx, xl_BC_type="dirichlet", yl_BC_type="dirichlet",
+                          xr_BC_type="dirichlet", yr_BC_type="dirichlet", verbose=0)
+    a.init_zeros()
+    x, y = a.x2d, a.y2d
+    rhs = -2.0 * ((1.0 - 6.0 * x**2) * y**2 * (1.0 - y**2) +
+                  (1.0 - 6.0 * y**2) * x**2 * (1.0 - x**2))
+    a.init_RHS(rhs)
+    a.max_cycles = 10
+    a.solve(rtol=0.0)
+    v = np.array(a.get_solution())
+    step = nx // 64
+    save("mg_4096_samples", samples=v[1:-1:step, 1:-1:step].copy(),
+         row_sums=v[1:-1, 1:-1].sum(axis=1), col_sums=v[1:-1, 1:-1].sum(axis=0),
+         source_norm=np.array(a.source_norm), residual_error=np.array(a.residual_error),
+         relative_error=np.array(a.relative_error), num_cycles=np.array(a.num_cycles),
+         vnorm=np.array(a.get_solution().norm()))
+    print("mg 4096: residual_error", a.residual_error, "cycles", a.num_cycles)
+
+
 def _raw_cfl_dt(sim):
     dt_keep, dto_keep = sim.dt, sim.dt_old
     sim.method_compute_timestep()
@@ -921,6 +945,8 @@ if __name__ == "__main__":
         gen_compressible_rk()
     if "swe" in sys.argv[1:]:
         gen_swe()
+    if "mg_4096" in sys.argv[1:]:
+        gen_mg_4096()
     which = sys.argv[1:] or ["bc", "adv", "comp_stages", "comp_runs", "mg", "diffusion"]
     if "diffusion" in which:
         gen_diffusion()

@@ -266,6 +266,29 @@ def test_comp_sedov_4096_properties(hip):
     assert np.abs(Uf[..., 2] - Uf[..., 3].T).max() <= 1e-10 * np.abs(Uf[..., 2]).max()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("fast", [0, 1])
+def test_comp_sedov_4096_vs_oracle_samples(hip, golden, fast):
+    """BASELINE config 2 at full size against the C oracle (oracle/
+    gen_fullsize.py: sedov 4096^2, 25 steps, ~10 min of CPU): dt sequence, a
+    64x64 lattice of the state and its row / column sums per variable"""
+    from sedov_ic import sedov_ic
+    g = golden("comp_sedov_4096_samples")
+    nx, nsteps = 4096, int(g["nsteps"])
+    ic, meta, bcs = sedov_ic(nx)
+    U, dts, t = device_comp_run(hip, ic, meta, bcs, 0.1, nsteps, fast_math=fast, kernel_set=1)
+    tol = TOL_FAST if fast else 1e-12
+    assert max_rel_err(dts, g["dts"]) <= tol
+    I = U[4:-4, 4:-4]
+    step = nx // 64
+    umax = g["umax"]
+    for n in range(4):
+        assert np.abs(I[::step, ::step, n] - g["samples"][..., n]).max() <= tol * umax[n]
+        for ax, key in ((1, "row_sums"), (0, "col_sums")):
+            ref = g[key][:, n]
+            assert np.abs(I[..., n].sum(axis=ax) - ref).max() <= tol * max(np.abs(ref).max(), nx * umax[n] * 1e-3)
+
+
 @pytest.mark.parametrize("kset", [0, 1])
 def test_comp_gravity_run(dev, kset):
     """gravity sources (apply_source_terms + predictor-corrector,

@@ -241,3 +241,32 @@ def test_vc_class_surface(dev, tmp_path, monkeypatch):
     e = v - np.sin(2.0 * np.pi * a.x2d) * np.sin(2.0 * np.pi * a.y2d)
     assert e.norm() < (3e-3 if nx == 32 else 8e-4) and a.residual_error < 1e-11
     assert a.edge_coeffs[a.nlevels - 1].x.shape == v.shape
+
+
+@pytest.mark.gpu
+def test_mg_4096_vs_reference_samples(hip, golden):
+    """BASELINE config 4 at full size against the REFERENCE itself
+    (CellCenterMG2d(4096^2), 10 V-cycles; oracle/gen_golden.py mg_4096): a 64x64
+    lattice of the solution, its row / column sums and the residual norm,
+    north_star tolerance 1e-10 (measured ~1e-14)"""
+    g = golden("mg_4096_samples")
+    nx = 4096
+    x = (np.arange(nx + 2) - 0.5) / nx
+    X, Y = np.meshgrid(x, x, indexing="ij")
+    rhs = -2.0 * ((1.0 - 6.0 * X ** 2) * Y ** 2 * (1.0 - Y ** 2) +
+                  (1.0 - 6.0 * Y ** 2) * X ** 2 * (1.0 - X ** 2))
+    m = device.DeviceMG(hip, nx)
+    L = m.nlevels - 1
+    m.zero(L, 0)
+    m.set(L, 1, rhs)
+    src = m.init_rhs_norm()
+    nc, res, rel = m.solve(rtol=0.0, max_cycles=10)
+    v = m.get(L, 0)[1:-1, 1:-1]
+    assert abs(src / float(g["source_norm"]) - 1) < 1e-13
+    assert nc == int(g["num_cycles"]) == 10
+    assert abs(res / float(g["residual_error"]) - 1) < 1e-10
+    scale = np.abs(g["samples"]).max()
+    step = nx // 64
+    assert np.abs(v[::step, ::step] - g["samples"]).max() <= 1e-10 * scale
+    assert np.abs(v.sum(axis=1) - g["row_sums"]).max() <= 1e-10 * np.abs(g["row_sums"]).max()
+    assert np.abs(v.sum(axis=0) - g["col_sums"]).max() <= 1e-10 * np.abs(g["col_sums"]).max()
