@@ -20,6 +20,8 @@ for fm in 1 0; do
   timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/prof_${TAG}_write_fm$fm -- $B >> $O/rocprof_${TAG}_fm$fm.log 2>&1
   timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/prof_${TAG}_sq_fm$fm -- $B >> $O/rocprof_${TAG}_fm$fm.log 2>&1
 done
+# multigrid (10 V-cycles at 4096^2) and advection kernels: kernel stats of the `also` legs
+MG_KINDS=15 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_mg_stats -- python $R/tools/mg_ab.py > $O/rocprof_${TAG}_mg.log 2>&1
 cd $R
 # launcher / N>1 plumbing on a 1-GPU box: two ranks share GPU 0 (debug only)
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
