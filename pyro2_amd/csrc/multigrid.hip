@@ -748,6 +748,50 @@ __global__ __launch_bounds__(256) void k_mg_sumsq(const double *__restrict__ a,
     if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
 
+// The per-cycle diagnostics of MG.solve (MG.py:670-686) in ONE pass over the
+// finest level: relative change of the solution (sum of ((v-old)/(v+small))^2,
+// then old <- v) and the residual r = f - (alpha - beta L) v with the sum of
+// r^2.  Replaces four kernels / two host syncs per V-cycle by two / one.
+__global__ __launch_bounds__(256) void k_mg_solve_diag(const double *__restrict__ v,
+                                                       const double *__restrict__ f,
+                                                       double *__restrict__ r,
+                                                       double *__restrict__ old, int n, int pitch,
+                                                       double alpha, double beta, double dx2,
+                                                       double small, double *__restrict__ partial)
+{
+    double srel = 0.0, sres = 0.0;
+    for (int i = 1 + blockIdx.y; i <= n; i += gridDim.y)
+        for (int j = 1 + blockIdx.x * blockDim.x + threadIdx.x; j <= n;
+             j += gridDim.x * blockDim.x) {
+            const size_t k = (size_t)i * pitch + j;
+            const double vk = v[k];
+            const double d = (vk - old[k]) / (vk + small);
+            srel += d * d;
+            old[k] = vk;
+            const double rr = f[k] - alpha * vk +
+                              beta * ((v[k - pitch] + v[k + pitch] - 2 * vk) / dx2 +
+                                      (v[k - 1] + v[k + 1] - 2 * vk) / dx2);
+            r[k] = rr;
+            sres += rr * rr;
+        }
+    srel = block_reduce_sum(srel);
+    sres = block_reduce_sum(sres);
+    if (threadIdx.x == 0) {
+        const int b = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.x * gridDim.y;
+        partial[b] = srel;
+        partial[nb + b] = sres;
+    }
+}
+
+__global__ void k_sum_final2(const double *__restrict__ partial, int nb, double *__restrict__ out)
+{
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) { a += partial[k]; b += partial[nb + k]; }
+    a = block_reduce_sum(a);
+    b = block_reduce_sum(b);
+    if (threadIdx.x == 0) { out[0] = a; out[1] = b; }
+}
+
 __global__ void k_sum_final(const double *__restrict__ partial, int nb, double *__restrict__ out)
 {
     double s = 0.0;
@@ -1333,14 +1377,32 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
     while (res > rtol && cycle <= max_cycles) {           // MG.py:652
         for (int l = 0; l < Lf; l++) PYRO_TRY(mg_zero(m, l, 0));   // :658-659
         PYRO_TRY(mg_vcycle(m, Lf));
-        double s = 0.0;                                   // :673-676
-        PYRO_TRY(mg_sumsq(m, F.v, m->old_phi, Lf, 1, &s));
+        double s = 0.0, s2 = 0.0;                         // :673-678
+        if (m->vc) {
+            PYRO_TRY(mg_sumsq(m, F.v, m->old_phi, Lf, 1, &s));
+            PYRO_CHECK_HIP(hipMemcpyAsync(m->old_phi, F.v, fbytes, hipMemcpyDeviceToDevice,
+                                          c->stream));
+            PYRO_TRY(mg_residual(m, Lf));
+            PYRO_TRY(mg_sumsq(m, F.r, nullptr, Lf, 0, &s2));
+        } else {   // fused: relative change, old <- v, residual and its norm in one pass
+            const dim3 grid(F.n >= 2048 ? 16 : 1, F.n >= 64 ? 128 : 1), block(256);
+            const int nb = grid.x * grid.y;
+            PYRO_TRY(c->reduce.ensure((2 * nb + 2) * sizeof(double)));
+            double *part = (double *)c->reduce.p;
+            PYRO_LAUNCH(c, "k_mg_solve_diag", k_mg_solve_diag, grid, block, 0, (const double *)F.v,
+                        (const double *)F.f, F.r, m->old_phi, F.n, F.pitch, m->alpha, m->beta,
+                        F.dx * F.dx, 1.e-16, part);
+            hipLaunchKernelGGL(k_sum_final2, dim3(1), dim3(256), 0, c->stream,
+                               (const double *)part, nb, part + 2 * nb);
+            PYRO_CHECK_HIP(hipGetLastError());
+            PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, part + 2 * nb, 2 * sizeof(double),
+                                          hipMemcpyDeviceToHost, c->stream));
+            PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+            s = ((double *)c->reduce_host)[0];
+            s2 = ((double *)c->reduce_host)[1];
+        }
         rel = sqrt(F.dx * F.dx * s);
-        PYRO_CHECK_HIP(hipMemcpyAsync(m->old_phi, F.v, fbytes, hipMemcpyDeviceToDevice,
-                                      c->stream));
-        PYRO_TRY(mg_residual(m, Lf));                     // :678
-        PYRO_TRY(mg_sumsq(m, F.r, nullptr, Lf, 0, &s));
-        double rn = sqrt(F.dx * F.dx * s);
+        double rn = sqrt(F.dx * F.dx * s2);
         res = (m->source_norm != 0.0) ? rn / m->source_norm : rn;   // :682-685
         cycle++;
     }
