@@ -203,6 +203,14 @@ int pyrohip_mg_init_rhs_norm(pyrohip_mg *m, double *source_norm);
    residual then use them.  pyrohip_mg_get accepts var 3 = eta, 4 = eta_x,
    5 = eta_y afterwards. */
 int pyrohip_mg_set_coeffs(pyrohip_mg *m, const double *coeffs, const int *coeffs_bc);
+/* general mode, GeneralMG2d (multigrid/general_MG.py:22-242): solve
+   alpha phi + div(beta grad phi) + gamma . grad phi = f.  Four (n+2, n+2)
+   cell-centred arrays on the finest level and their BC codes (alpha, beta,
+   gamma_x, gamma_y; 4 each).  pyrohip_mg_get then also accepts var 6 = alpha,
+   7 = gamma_x, 8 = gamma_y (3..5 = beta, beta_x, beta_y).                    */
+int pyrohip_mg_set_general_coeffs(pyrohip_mg *m, const double *alpha,
+                                  const double *beta, const double *gamma_x,
+                                  const double *gamma_y, const int *coeffs_bc);
 /* callers that keep their field on the device (pyro/diffusion/simulation.py:
    92-118): f <- phi + coef * Laplacian(phi) on the finest level from variable
    n of a (nx, nx, ng = 1) state, and the solution back into that variable */

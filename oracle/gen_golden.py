@@ -930,7 +930,69 @@ def gen_mg_vc():
     save("mg_vc", **out)
 
 
+def gen_mg_general():
+    """row f1: general_MG.GeneralMG2d (alpha phi + div(beta grad phi) +
+    gamma . grad phi = f): coefficient hierarchy, smoother, residual, solve"""
+    import pyro.multigrid.general_MG as GM
+    out = {}
+    cases = [(("dirichlet",) * 4, ("neumann",) * 4, 32),
+             (("periodic",) * 4, ("periodic",) * 4, 32),
+             (("neumann", "dirichlet", "periodic", "periodic"),
+              ("neumann", "neumann", "periodic", "periodic"), 16)]
+    rng = np.random.default_rng(11)
+    for k, (bcs, cbcs, nx) in enumerate(cases):
+        g = patch.Grid2d(nx, nx, ng=1)
+        d = patch.CellCenterData2d(g)
+        bc_c = bnd.BC(xlb=cbcs[0], xrb=cbcs[1], ylb=cbcs[2], yrb=cbcs[3])
+        for nm in ("alpha", "beta", "gamma_x", "gamma_y"):
+            d.register_var(nm, bc_c)
+        d.create()
+        X, Y = 2.0 * np.pi * g.x2d, 2.0 * np.pi * g.y2d
+        d.get_var("alpha")[:, :] = -(8.0 + np.cos(X) + 0.1 * rng.random(X.shape))
+        d.get_var("beta")[:, :] = 2.0 + np.cos(X) * np.cos(Y) + 0.1 * rng.random(X.shape)
+        d.get_var("gamma_x")[:, :] = 0.5 * np.sin(X) + 0.05 * rng.random(X.shape)
+        d.get_var("gamma_y")[:, :] = 0.5 * np.sin(Y) + 0.05 * rng.random(X.shape)
+
+        def make():
+            return GM.GeneralMG2d(nx, nx, xl_BC_type=bcs[0], xr_BC_type=bcs[1],
+                                  yl_BC_type=bcs[2], yr_BC_type=bcs[3], nsmooth=4,
+                                  nsmooth_bottom=9, coeffs=d, verbose=0)
+        a = make()
+        L = a.nlevels - 1
+        pre = f"g{k}_"
+        out[pre + "bc"], out[pre + "cbc"], out[pre + "nx"] = np.array(bcs), np.array(cbcs), np.array(nx)
+        for nm in ("alpha", "beta", "gamma_x", "gamma_y"):
+            out[pre + nm] = np.array(d.get_var(nm))
+        for lev in (L, L - 1, 0):
+            for nm in ("alpha", "gamma_x", "gamma_y"):
+                out[pre + f"{nm}_l{lev}"] = np.array(a.grids[lev].get_var(nm))
+            out[pre + f"ex_l{lev}"] = np.array(a.beta_edge[lev].x)
+            out[pre + f"ey_l{lev}"] = np.array(a.beta_edge[lev].y)
+        v0 = rng.standard_normal((nx + 2, nx + 2))
+        f0 = rng.standard_normal((nx + 2, nx + 2))
+        out[pre + "v0"], out[pre + "f0"] = v0, f0
+        a.init_solution(v0)
+        a.init_RHS(f0)
+        a.smooth(L, 3)
+        out[pre + "v_smooth"] = np.array(a.grids[L].get_var("v"))
+        a._compute_residual(L)
+        out[pre + "r"] = np.array(a.grids[L].get_var("r"))
+        b = make()
+        b.init_solution(v0)
+        b.init_RHS(f0)
+        b.max_cycles = 5
+        b.solve(rtol=1.e-10)
+        out[pre + "v_solve"] = np.array(b.grids[L].get_var("v"))
+        out[pre + "info"] = np.array([b.num_cycles, b.residual_error, b.relative_error,
+                                      b.source_norm])
+        print("general MG case", k, bcs, "cycles", b.num_cycles, "res", b.residual_error)
+    out["ncases"] = np.array(len(cases))
+    save("mg_general", **out)
+
+
 if __name__ == "__main__":
+    if "mg_general" in sys.argv[1:]:
+        gen_mg_general()
     if "mg_vc" in sys.argv[1:]:
         gen_mg_vc()
     if "comp_f2" in sys.argv[1:]:

@@ -437,3 +437,25 @@ def swe_step(U, P, dt, stages=False):
             setattr(st, n, _p(outs[n]))
     lib().orc_swe_step(_p(U), C.byref(P), C.c_double(dt), C.byref(st) if stages else None)
     return outs
+
+
+class GenMG(VCMG):
+    """general_MG.GeneralMG2d core: alpha phi + div(beta grad phi) + gamma . grad phi = f.
+    coef(level, which): 0 beta, 1 beta_x, 2 beta_y, 3 alpha, 4 gamma_x, 5 gamma_y"""
+
+    def __init__(self, nx, alpha, beta, gamma_x, gamma_y, xmin=0.0, xmax=1.0, ymin=0.0, ymax=1.0,
+                 bcs=("dirichlet",) * 4, coeffs_bcs=("neumann",) * 4, nsmooth=10,
+                 nsmooth_bottom=50):
+        bc = bc_codes(bcs)
+        cb = np.ascontiguousarray(np.tile(bc_codes(coeffs_bcs), 4))
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (alpha, beta, gamma_x, gamma_y)]
+        self._l = lib()
+        self._l.orc_genmg_create.restype = C.c_void_p
+        ip = C.POINTER(C.c_int)
+        self.vh = C.c_void_p(self._l.orc_genmg_create(
+            nx, C.c_double(xmin), C.c_double(xmax), C.c_double(ymin), C.c_double(ymax),
+            bc.ctypes.data_as(ip), cb.ctypes.data_as(ip), *[_p(a) for a in arrs],
+            nsmooth, nsmooth_bottom))
+        self.h = C.c_void_p(self._l.orc_vcmg_base(self.vh))
+        self.nx = nx
+        self.nlevels = self._l.orc_mg_nlevels(self.h)

@@ -1409,6 +1409,10 @@ typedef struct {
     double *c[MG_MAXLEV];     /* cell-centred coefficient, ghost filled */
     double *ex[MG_MAXLEV], *ey[MG_MAXLEV];
     int cbc[4];
+    /* general mode (general_MG.py): alpha phi + div(beta grad phi) + gamma . grad phi = f;
+       c / ex / ey then hold beta */
+    int general;
+    double *a[MG_MAXLEV], *gx[MG_MAXLEV], *gy[MG_MAXLEV];
 } orc_vcmg;
 
 orc_vcmg *orc_vcmg_create(int nx, double xmin, double xmax, double ymin, double ymax,
@@ -1469,16 +1473,63 @@ orc_vcmg *orc_vcmg_create(int nx, double xmin, double xmax, double ymin, double 
     return V;
 }
 
+/* general_MG.py:44-105: alpha, gamma_x, gamma_y (cell centred, own BCs) are
+   restricted down the hierarchy like beta; beta goes to the edges as in the
+   variable-coefficient solver.  cbcs: BC codes of alpha, beta, gamma_x, gamma_y */
+orc_vcmg *orc_genmg_create(int nx, double xmin, double xmax, double ymin, double ymax,
+                           const int *bc, const int *cbcs, const double *alpha,
+                           const double *beta, const double *gamma_x, const double *gamma_y,
+                           int nsmooth, int nsmooth_bottom)
+{
+    orc_vcmg *V = orc_vcmg_create(nx, xmin, xmax, ymin, ymax, bc, cbcs + 4, beta, nsmooth,
+                                  nsmooth_bottom);
+    orc_mg *m = V->mg;
+    const int L = m->nlevels - 1;
+    V->general = 1;
+    const double *src[3] = {alpha, gamma_x, gamma_y};
+    const int *sbc[3] = {cbcs, cbcs + 8, cbcs + 12};
+    double **dst[3] = {V->a, V->gx, V->gy};
+    for (int w = 0; w < 3; w++) {
+        for (int l = 0; l <= L; l++) dst[w][l] = zalloc((size_t)(m->n[l] + 2) * (m->n[l] + 2));
+        const int n = m->n[L], q = n + 2;
+        for (int i = 1; i <= n; i++)
+            for (int j = 1; j <= n; j++) dst[w][L][(size_t)i * q + j] = src[w][(size_t)i * q + j];
+        mg_fill_bc(dst[w][L], n, m->dx[L], sbc[w], NULL);
+        for (int l = L - 1; l >= 0; l--) {
+            const int nc = m->n[l], qc = nc + 2, qf = m->n[l + 1] + 2;
+            const double *fc = dst[w][l + 1];
+            for (int i = 0; i < nc; i++)
+                for (int j = 0; j < nc; j++) {
+                    const int fi = 1 + 2 * i, fj = 1 + 2 * j;
+                    dst[w][l][(size_t)(1 + i) * qc + 1 + j] =
+                        0.25 * (fc[(size_t)fi * qf + fj] + fc[(size_t)(fi + 1) * qf + fj] +
+                                fc[(size_t)fi * qf + fj + 1] + fc[(size_t)(fi + 1) * qf + fj + 1]);
+                }
+            mg_fill_bc(dst[w][l], nc, m->dx[l], sbc[w], NULL);
+        }
+    }
+    return V;
+}
+
 void orc_vcmg_free(orc_vcmg *V)
 {
     for (int l = 0; l < V->mg->nlevels; l++) { free(V->c[l]); free(V->ex[l]); free(V->ey[l]); }
+    if (V->general)
+        for (int l = 0; l < V->mg->nlevels; l++) { free(V->a[l]); free(V->gx[l]); free(V->gy[l]); }
     orc_mg_free(V->mg);
     free(V);
 }
 orc_mg *orc_vcmg_base(orc_vcmg *V) { return V->mg; }
 double *orc_vcmg_ptr(orc_vcmg *V, int level, int which)
 {
-    return which == 0 ? V->c[level] : which == 1 ? V->ex[level] : V->ey[level];
+    switch (which) {
+    case 0: return V->c[level];
+    case 1: return V->ex[level];
+    case 2: return V->ey[level];
+    case 3: return V->a[level];
+    case 4: return V->gx[level];
+    default: return V->gy[level];
+    }
 }
 
 /* variable_coeff_MG.py:103-168 */
@@ -1491,10 +1542,22 @@ void orc_vcmg_smooth(orc_vcmg *V, int level, int nsmooth)
     orc_mg_fill_bc_v(m, level);
     static const int grp[4][2] = {{0, 0}, {1, 1}, {1, 0}, {0, 1}};
 #define I(i, j) ((size_t)(i) * q + (j))
+    const double dxl = m->dx[level];
     for (int it = 0; it < nsmooth; it++)
         for (int g = 0; g < 4; g++) {
             for (int i = 1 + grp[g][0]; i <= n; i += 2)
                 for (int j = 1 + grp[g][1]; j <= n; j += 2) {
+                    if (V->general) {   /* general_MG.py:130-160 */
+                        const double gxc = 0.5 * V->gx[level][I(i, j)] / dxl;
+                        const double gyc = 0.5 * V->gy[level][I(i, j)] / dxl;
+                        const double den = V->a[level][I(i, j)] - ex[I(i + 1, j)] - ex[I(i, j)] -
+                                           ey[I(i, j + 1)] - ey[I(i, j)];
+                        v[I(i, j)] = (f[I(i, j)] - (ex[I(i + 1, j)] + gxc) * v[I(i + 1, j)] -
+                                      (ex[I(i, j)] - gxc) * v[I(i - 1, j)] -
+                                      (ey[I(i, j + 1)] + gyc) * v[I(i, j + 1)] -
+                                      (ey[I(i, j)] - gyc) * v[I(i, j - 1)]) / den;
+                        continue;
+                    }
                     double denom = ex[I(i + 1, j)] + ex[I(i, j)] + ey[I(i, j + 1)] + ey[I(i, j)];
                     v[I(i, j)] = (-f[I(i, j)] + ex[I(i + 1, j)] * v[I(i + 1, j)] +
                                   ex[I(i, j)] * v[I(i - 1, j)] + ey[I(i, j + 1)] * v[I(i, j + 1)] +
@@ -1513,8 +1576,22 @@ void orc_vcmg_residual(orc_vcmg *V, int level)
     const double *v = m->v[level], *f = m->f[level], *ex = V->ex[level], *ey = V->ey[level];
     double *r = m->r[level];
 #define I(i, j) ((size_t)(i) * q + (j))
+    const double dxl = m->dx[level];
     for (int i = 1; i <= n; i++)
         for (int j = 1; j <= n; j++) {
+            if (V->general) {   /* general_MG.py:196-242 */
+                const double gxc = 0.5 * V->gx[level][I(i, j)] / dxl;
+                const double gyc = 0.5 * V->gy[level][I(i, j)] / dxl;
+                const double Lg = V->a[level][I(i, j)] * v[I(i, j)] +
+                                  ex[I(i + 1, j)] * (v[I(i + 1, j)] - v[I(i, j)]) -
+                                  ex[I(i, j)] * (v[I(i, j)] - v[I(i - 1, j)]) +
+                                  ey[I(i, j + 1)] * (v[I(i, j + 1)] - v[I(i, j)]) -
+                                  ey[I(i, j)] * (v[I(i, j)] - v[I(i, j - 1)]) +
+                                  gxc * (v[I(i + 1, j)] - v[I(i - 1, j)]) +
+                                  gyc * (v[I(i, j + 1)] - v[I(i, j - 1)]);
+                r[I(i, j)] = f[I(i, j)] - Lg;
+                continue;
+            }
             double L = ex[I(i + 1, j)] * (v[I(i + 1, j)] - v[I(i, j)]) -
                        ex[I(i, j)] * (v[I(i, j)] - v[I(i - 1, j)]) +
                        ey[I(i, j + 1)] * (v[I(i, j + 1)] - v[I(i, j)]) -

@@ -39,6 +39,7 @@ struct MGLevel {
     double *v, *f, *r;
     double *v2;     // second solution buffer (tile smoother ping-pong)
     double *c = nullptr, *ex = nullptr, *ey = nullptr;   // variable-coefficient mode
+    double *a = nullptr, *gx = nullptr, *gy = nullptr;   // general mode: alpha, gamma_x, gamma_y
 };
 
 struct MGBC {
@@ -63,8 +64,9 @@ struct pyrohip_mg {
     int kmax = 5;                 // red-black iterations fused per tile launch
     int kmax_small = 5;           // ... on levels <= 1024^2 (latency bound)
     int coarse_kernel = 1;        // levels <= 64^2 in one LDS-resident workgroup
-    int vc = 0;                   // variable-coefficient mode (div(eta grad phi) = f)
+    int vc = 0;                   // 1: div(eta grad phi) = f; 2: general (alpha, beta, gamma)
     double *vc_pool = nullptr;
+    double *gen_pool = nullptr;
     bool corners_stale[pyro::MG_MAXLEV] = {};   // v: corner ghosts not refreshed yet
 };
 
@@ -608,21 +610,36 @@ __global__ void k_vc_edges_restrict(const double *__restrict__ fx, const double 
     if (i < nc) cy[ck] = 0.5 * (fy[fk] + fy[fk + fpitch]) * fdx2 / cdx2;
 }
 
+// general mode (general_MG.py:107-242): alpha phi + div(beta grad phi) +
+// gamma . grad phi = f with beta on the edges (ex, ey) and cell-centred alpha,
+// gamma_x, gamma_y
+struct MGGen { const double *a, *gx, *gy; };
+
 // one colour of the variable-coefficient smoother, variable_coeff_MG.py:131-147
+// (GEN: general_MG.py:130-160)
+template <bool GEN>
 __global__ __launch_bounds__(256) void k_vc_smooth(double *__restrict__ v,
                                                    const double *__restrict__ f,
                                                    const double *__restrict__ ex,
                                                    const double *__restrict__ ey, int n, int pitch,
-                                                   double dx, int colour, MGBC bc)
+                                                   double dx, int colour, MGBC bc, MGGen G)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = 1 + blockIdx.y;
     const int j = 1 + 2 * t + ((i - 1 + colour) & 1);
     if (j > n) return;
     const size_t k = (size_t)i * pitch + j;
-    const double denom = ex[k + pitch] + ex[k] + ey[k + 1] + ey[k];
-    const double vn = (-f[k] + ex[k + pitch] * v[k + pitch] + ex[k] * v[k - pitch] +
-                       ey[k + 1] * v[k + 1] + ey[k] * v[k - 1]) / denom;
+    double vn;
+    if (GEN) {
+        const double gxc = 0.5 * G.gx[k] / dx, gyc = 0.5 * G.gy[k] / dx;
+        const double denom = G.a[k] - ex[k + pitch] - ex[k] - ey[k + 1] - ey[k];
+        vn = (f[k] - (ex[k + pitch] + gxc) * v[k + pitch] - (ex[k] - gxc) * v[k - pitch] -
+              (ey[k + 1] + gyc) * v[k + 1] - (ey[k] - gyc) * v[k - 1]) / denom;
+    } else {
+        const double denom = ex[k + pitch] + ex[k] + ey[k + 1] + ey[k];
+        vn = (-f[k] + ex[k + pitch] * v[k + pitch] + ex[k] * v[k - pitch] +
+              ey[k + 1] * v[k + 1] + ey[k] * v[k - 1]) / denom;
+    }
     v[k] = vn;
     if (i == 1) {
         if (bc.code[0] == PYROHIP_BC_PERIODIC) v[(size_t)(n + 1) * pitch + j] = vn;
@@ -642,19 +659,29 @@ __global__ __launch_bounds__(256) void k_vc_smooth(double *__restrict__ v,
     }
 }
 
-// variable_coeff_MG.py:191-213
+// variable_coeff_MG.py:191-213 (GEN: general_MG.py:196-242)
+template <bool GEN>
 __global__ __launch_bounds__(256) void k_vc_residual(const double *__restrict__ v,
                                                      const double *__restrict__ f,
                                                      const double *__restrict__ ex,
                                                      const double *__restrict__ ey,
-                                                     double *__restrict__ r, int n, int pitch)
+                                                     double *__restrict__ r, int n, int pitch,
+                                                     double dx, MGGen G)
 {
     const int j = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int i = 1 + blockIdx.y;
     if (j > n) return;
     const size_t k = (size_t)i * pitch + j;
-    const double L = ex[k + pitch] * (v[k + pitch] - v[k]) - ex[k] * (v[k] - v[k - pitch]) +
-                     ey[k + 1] * (v[k + 1] - v[k]) - ey[k] * (v[k] - v[k - 1]);
+    double L;
+    if (GEN) {
+        const double gxc = 0.5 * G.gx[k] / dx, gyc = 0.5 * G.gy[k] / dx;
+        L = G.a[k] * v[k] + ex[k + pitch] * (v[k + pitch] - v[k]) - ex[k] * (v[k] - v[k - pitch]) +
+            ey[k + 1] * (v[k + 1] - v[k]) - ey[k] * (v[k] - v[k - 1]) +
+            gxc * (v[k + pitch] - v[k - pitch]) + gyc * (v[k + 1] - v[k - 1]);
+    } else {
+        L = ex[k + pitch] * (v[k + pitch] - v[k]) - ex[k] * (v[k] - v[k - pitch]) +
+            ey[k + 1] * (v[k + 1] - v[k]) - ey[k] * (v[k] - v[k - 1]);
+    }
     r[k] = f[k] - L;
 }
 
@@ -819,7 +846,10 @@ static double *plane(pyrohip_mg *m, int level, int var)
     case 2: return L.r;
     case 3: return L.c;
     case 4: return L.ex;
-    default: return L.ey;
+    case 5: return L.ey;
+    case 6: return L.a;
+    case 7: return L.gx;
+    default: return L.gy;
     }
 }
 
@@ -914,11 +944,18 @@ static int mg_smooth(pyrohip_mg *m, int level, int nsmooth, bool corners = true)
         const int half = (L.n + 1) / 2;
         const int bx = (half >= 256) ? 256 : 64;
         dim3 grid((half + bx - 1) / bx, L.n), block(bx);
+        const MGGen G{L.a, L.gx, L.gy};
         for (int it = 0; it < nsmooth; it++)
-            for (int colour = 0; colour < 2; colour++)
-                PYRO_LAUNCH(m->ctx, "k_vc_smooth", k_vc_smooth, grid, block, 0, L.v,
-                            (const double *)L.f, (const double *)L.ex, (const double *)L.ey, L.n,
-                            L.pitch, L.dx, colour, bc);
+            for (int colour = 0; colour < 2; colour++) {
+                if (m->vc == 2)
+                    PYRO_LAUNCH(m->ctx, "k_vc_smooth", k_vc_smooth<true>, grid, block, 0, L.v,
+                                (const double *)L.f, (const double *)L.ex, (const double *)L.ey,
+                                L.n, L.pitch, L.dx, colour, bc, G);
+                else
+                    PYRO_LAUNCH(m->ctx, "k_vc_smooth", k_vc_smooth<false>, grid, block, 0, L.v,
+                                (const double *)L.f, (const double *)L.ex, (const double *)L.ey,
+                                L.n, L.pitch, L.dx, colour, bc, G);
+            }
         return 0;
     }
     if (m->smoother == 0 || nsmooth <= 0) {
@@ -937,9 +974,17 @@ static int mg_residual(pyrohip_mg *m, int level)
     MGLevel &L = m->lev[level];
     const int bx = (L.n >= 256) ? 256 : 64;
     if (m->vc) {
-        hipLaunchKernelGGL(k_vc_residual, dim3((L.n + bx - 1) / bx, L.n), dim3(bx), 0,
-                           m->ctx->stream, (const double *)L.v, (const double *)L.f,
-                           (const double *)L.ex, (const double *)L.ey, L.r, L.n, L.pitch);
+        const MGGen G{L.a, L.gx, L.gy};
+        if (m->vc == 2)
+            hipLaunchKernelGGL(k_vc_residual<true>, dim3((L.n + bx - 1) / bx, L.n), dim3(bx), 0,
+                               m->ctx->stream, (const double *)L.v, (const double *)L.f,
+                               (const double *)L.ex, (const double *)L.ey, L.r, L.n, L.pitch, L.dx,
+                               G);
+        else
+            hipLaunchKernelGGL(k_vc_residual<false>, dim3((L.n + bx - 1) / bx, L.n), dim3(bx), 0,
+                               m->ctx->stream, (const double *)L.v, (const double *)L.f,
+                               (const double *)L.ex, (const double *)L.ey, L.r, L.n, L.pitch, L.dx,
+                               G);
         return 0;
     }
     hipLaunchKernelGGL(k_mg_residual, dim3((L.n + bx - 1) / bx, L.n), dim3(bx), 0, m->ctx->stream,
@@ -1115,6 +1160,7 @@ int pyrohip_mg_destroy(pyrohip_mg *m)
     (void)hipStreamSynchronize(m->ctx->stream);
     if (m->pool) (void)hipFree(m->pool);
     if (m->vc_pool) (void)hipFree(m->vc_pool);
+    if (m->gen_pool) (void)hipFree(m->gen_pool);
     for (int s = 0; s < 4; s++)
         if (m->bcval[s]) (void)hipFree(m->bcval[s]);
     delete m;
@@ -1158,7 +1204,8 @@ int pyrohip_mg_set(pyrohip_mg *m, int level, int var, const double *host)
 int pyrohip_mg_get(pyrohip_mg *m, int level, int var, double *host)
 {
     MG_CHECK_LEVEL(m, level);
-    PYRO_REQUIRE(var >= 0 && var <= (m->vc ? 5 : 2) && host, "bad var / NULL host");
+    PYRO_REQUIRE(var >= 0 && var <= (m->vc == 2 ? 8 : m->vc ? 5 : 2) && host,
+                 "bad var / NULL host");
     if (var == 0 && m->corners_stale[level]) {   // index-for-index incl. corner ghosts
         PYRO_TRY(mg_fill(m, level, 0));
         m->corners_stale[level] = false;
@@ -1325,6 +1372,66 @@ int pyrohip_mg_set_coeffs(pyrohip_mg *m, const double *coeffs, const int *coeffs
     PYRO_CHECK_HIP(hipGetLastError());
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
     m->vc = 1;
+    return 0;
+}
+
+int pyrohip_mg_set_general_coeffs(pyrohip_mg *m, const double *alpha, const double *beta,
+                                  const double *gamma_x, const double *gamma_y,
+                                  const int *coeffs_bc)
+{
+    PYRO_REQUIRE(m && alpha && beta && gamma_x && gamma_y && coeffs_bc, "NULL argument");
+    // beta: cell values restricted down the hierarchy, then onto the edges,
+    // exactly like the variable-coefficient solver (general_MG.py:84-105)
+    PYRO_TRY(pyrohip_mg_set_coeffs(m, beta, coeffs_bc + 4));
+    pyrohip_ctx *c = m->ctx;
+    if (!m->gen_pool) {
+        size_t total = 16;
+        for (int l = 0; l < m->nlevels; l++) total += 3 * make_geom(m->lev[l].n, m->lev[l].n, 1).plane + 16;
+        PYRO_CHECK_HIP(hipMalloc((void **)&m->gen_pool, total * sizeof(double)));
+        PYRO_CHECK_HIP(hipMemsetAsync(m->gen_pool, 0, total * sizeof(double), c->stream));
+        double *p = m->gen_pool;
+        for (int l = 0; l < m->nlevels; l++) {
+            Geom g = make_geom(m->lev[l].n, m->lev[l].n, 1);
+            MGLevel &L = m->lev[l];
+            L.a = p + geom_lead(g); p += g.plane;
+            L.gx = p + geom_lead(g); p += g.plane;
+            L.gy = p + geom_lead(g); p += g.plane;
+            p += 16;
+        }
+    }
+    const int Lf = m->nlevels - 1;
+    const double *src[3] = {alpha, gamma_x, gamma_y};
+    const int *sbc[3] = {coeffs_bc, coeffs_bc + 8, coeffs_bc + 12};
+    for (int w = 0; w < 3; w++) {   // general_MG.py:66-82
+        MGBC cbc;
+        for (int s = 0; s < 4; s++) { cbc.code[s] = sbc[w][s]; cbc.val[s] = nullptr; }
+        auto arr = [&](int l) { MGLevel &L = m->lev[l]; return w == 0 ? L.a : w == 1 ? L.gx : L.gy; };
+        {
+            MGLevel &F = m->lev[Lf];
+            const int q = F.n + 2;
+            PYRO_CHECK_HIP(hipMemcpy2DAsync(arr(Lf), F.pitch * sizeof(double), src[w],
+                                            q * sizeof(double), q * sizeof(double), q,
+                                            hipMemcpyHostToDevice, c->stream));
+        }
+        for (int l = Lf; l >= 0; l--) {
+            MGLevel &L = m->lev[l];
+            if (l < Lf) {
+                MGLevel &F = m->lev[l + 1];
+                const int bx = (L.n >= 256) ? 256 : 64;
+                hipLaunchKernelGGL(k_mg_restrict, dim3((L.n + bx - 1) / bx, L.n), dim3(bx), 0,
+                                   c->stream, (const double *)arr(l + 1), F.pitch, arr(l), L.pitch,
+                                   L.n);
+            }
+            const int nt = L.n + 2;
+            hipLaunchKernelGGL(k_mg_fill_x, dim3((nt + 255) / 256), dim3(256), 0, c->stream, arr(l),
+                               L.n, L.pitch, L.dx, cbc);
+            hipLaunchKernelGGL(k_mg_fill_y, dim3((nt + 255) / 256), dim3(256), 0, c->stream, arr(l),
+                               L.n, L.pitch, L.dx, cbc);
+        }
+    }
+    PYRO_CHECK_HIP(hipGetLastError());
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    m->vc = 2;
     return 0;
 }
 

@@ -452,6 +452,17 @@ class DeviceMG:
                       dtype=np.int32)
         self._call("pyrohip_mg_set_coeffs", dptr(a), iptr(bc))
 
+    def set_general_coeffs(self, alpha, beta, gamma_x, gamma_y, coeffs_bcs):
+        """switch to general mode (GeneralMG2d); coeffs_bcs: 4 BC names per
+        coefficient in the order alpha, beta, gamma_x, gamma_y"""
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (alpha, beta, gamma_x, gamma_y)]
+        for a in arrs:
+            assert a.shape == (self.nx + 2,) * 2
+        bc = np.array([BC_CODE[b] if isinstance(b, str) else int(b)
+                       for row in coeffs_bcs for b in row], dtype=np.int32)
+        assert bc.size == 16
+        self._call("pyrohip_mg_set_general_coeffs", *[dptr(a) for a in arrs], iptr(bc))
+
     def set_rhs_cn(self, state, n, coef):
         """f <- phi + coef * L(phi) from variable n of a device state; returns ||f||"""
         out = C.c_double()

@@ -270,3 +270,67 @@ def test_mg_4096_vs_reference_samples(hip, golden):
     assert np.abs(v[::step, ::step] - g["samples"]).max() <= 1e-10 * scale
     assert np.abs(v.sum(axis=1) - g["row_sums"]).max() <= 1e-10 * np.abs(g["row_sums"]).max()
     assert np.abs(v.sum(axis=0) - g["col_sums"]).max() <= 1e-10 * np.abs(g["col_sums"]).max()
+
+
+def test_mg_general(dev, golden, tmp_path, monkeypatch):
+    """GeneralMG2d (alpha phi + div(beta grad phi) + gamma . grad phi = f) on the
+    device against the reference: coefficient hierarchy, smoother, residual,
+    5-cycle solve -- through the C ABI and through the GeneralMG2d class"""
+    from pyro2_amd import device as devmod
+    from pyro2_amd.mesh import boundary as bnd
+    from pyro2_amd.mesh import patch
+    from pyro2_amd.multigrid import general_MG as GM
+    monkeypatch.setattr(devmod.Context, "_default", dev)
+    g = golden("mg_general")
+    tol = 0.0 if dev.kind == "emu" else TOL
+    for k in range(int(g["ncases"])):
+        pre = f"g{k}_"
+        nx = int(g[pre + "nx"])
+        bcs = [str(b) for b in g[pre + "bc"]]
+        cbcs = [str(b) for b in g[pre + "cbc"]]
+        m = device.DeviceMG(dev, nx, bcs=bcs, alpha=0.0, beta=0.0, nsmooth=4, nsmooth_bottom=9)
+        m.set_general_coeffs(g[pre + "alpha"], g[pre + "beta"], g[pre + "gamma_x"],
+                             g[pre + "gamma_y"], [cbcs] * 4)
+        L = m.nlevels - 1
+        for lev in (L, L - 1, 0):
+            n = 2 ** (lev + 1)
+            for var, nm in ((6, "alpha"), (7, "gamma_x"), (8, "gamma_y")):
+                assert max_rel_err(m.get(lev, var), g[pre + f"{nm}_l{lev}"]) <= tol, (k, lev, nm)
+            assert max_rel_err(m.get(lev, 4)[1:n + 2, 1:n + 1],
+                               g[pre + f"ex_l{lev}"][1:n + 2, 1:n + 1]) <= tol
+            assert max_rel_err(m.get(lev, 5)[1:n + 1, 1:n + 2],
+                               g[pre + f"ey_l{lev}"][1:n + 1, 1:n + 2]) <= tol
+        m.set(L, 0, g[pre + "v0"])
+        m.set(L, 1, g[pre + "f0"])
+        m.init_rhs_norm()
+        m.smooth(L, 3)
+        m.fill_bc(L, 0)
+        assert max_rel_err(m.get(L, 0), g[pre + "v_smooth"]) <= tol, k
+        m.residual(L)
+        assert max_rel_err(m.get(L, 2)[1:-1, 1:-1], g[pre + "r"][1:-1, 1:-1]) <= tol, k
+        m.set(L, 0, g[pre + "v0"])
+        nc, res, rel = m.solve(rtol=1e-10, max_cycles=5)
+        info = g[pre + "info"]
+        assert nc == int(info[0])
+        assert max_rel_err(m.get(L, 0), g[pre + "v_solve"]) <= tol * 100, k
+        np.testing.assert_allclose(res, info[1], rtol=1e-8)
+    # class surface (last case): coeffs as a CellCenterData2d
+    gr = patch.Grid2d(nx, nx, ng=1)
+    d = patch.CellCenterData2d(gr)
+    bc_c = bnd.BC(xlb=cbcs[0], xrb=cbcs[1], ylb=cbcs[2], yrb=cbcs[3])
+    for nm in ("alpha", "beta", "gamma_x", "gamma_y"):
+        d.register_var(nm, bc_c)
+    d.create()
+    for nm in ("alpha", "beta", "gamma_x", "gamma_y"):
+        d.get_var(nm)[:, :] = g[pre + nm]
+    a = GM.GeneralMG2d(nx, nx, xl_BC_type=bcs[0], xr_BC_type=bcs[1], yl_BC_type=bcs[2],
+                       yr_BC_type=bcs[3], nsmooth=4, nsmooth_bottom=9, coeffs=d, verbose=0)
+    a.init_solution(g[pre + "v0"])
+    a.init_RHS(g[pre + "f0"])
+    a.max_cycles = 5
+    a.solve(rtol=1.e-10)
+    assert a.num_cycles == int(g[pre + "info"][0])
+    assert max_rel_err(np.asarray(a.get_solution()), g[pre + "v_solve"]) <= tol * 100
+    assert max_rel_err(np.asarray(a.beta_edge[L].x)[1:nx + 2, 1:nx + 1],
+                       g[pre + f"ex_l{L}"][1:nx + 2, 1:nx + 1]) <= tol
+    assert max_rel_err(np.asarray(a.grids[L].get_var("alpha")), g[pre + f"alpha_l{L}"]) <= tol

@@ -257,6 +257,35 @@ def test_mg_variable_coefficient(golden):
         assert np.array_equal(m.arr(L, 0), g[f"v{k}_v_solve"]), k
 
 
+def test_mg_general(golden):
+    """general_MG.GeneralMG2d: coefficient hierarchy (alpha, gamma restricted,
+    beta on edges), smoother, residual and a 5-cycle solve against the reference"""
+    g = golden("mg_general")
+    for k in range(int(g["ncases"])):
+        pre = f"g{k}_"
+        nx = int(g[pre + "nx"])
+        m = orc.GenMG(nx, g[pre + "alpha"], g[pre + "beta"], g[pre + "gamma_x"], g[pre + "gamma_y"],
+                      bcs=[str(b) for b in g[pre + "bc"]],
+                      coeffs_bcs=[str(b) for b in g[pre + "cbc"]], nsmooth=4, nsmooth_bottom=9)
+        L = m.nlevels - 1
+        for lev in (L, L - 1, 0):
+            n = 2 ** (lev + 1)
+            for which, nm in ((3, "alpha"), (4, "gamma_x"), (5, "gamma_y")):
+                assert np.array_equal(m.coef(lev, which), g[pre + f"{nm}_l{lev}"]), (k, lev, nm)
+            assert np.array_equal(m.coef(lev, 1)[1:n + 2, 1:n + 1], g[pre + f"ex_l{lev}"][1:n + 2, 1:n + 1])
+            assert np.array_equal(m.coef(lev, 2)[1:n + 1, 1:n + 2], g[pre + f"ey_l{lev}"][1:n + 1, 1:n + 2])
+        m.arr(L, 0)[:, :] = g[pre + "v0"]
+        m.init_rhs(g[pre + "f0"])
+        m.smooth(L, 3)
+        assert np.array_equal(m.arr(L, 0), g[pre + "v_smooth"]), k
+        m.residual(L)
+        assert np.array_equal(m.arr(L, 2)[1:-1, 1:-1], g[pre + "r"][1:-1, 1:-1]), k
+        m.arr(L, 0)[:, :] = g[pre + "v0"]
+        m.solve(rtol=1e-10, max_cycles=5)
+        assert m.num_cycles == int(g[pre + "info"][0])
+        assert np.array_equal(m.arr(L, 0), g[pre + "v_solve"]), k
+
+
 @pytest.mark.parametrize("k", range(6))
 def test_comp_cgf_and_sponge(golden, k):
     """riemann_cgf (riemann.py:8-310) incl. the solid-wall
