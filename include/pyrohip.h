@@ -138,7 +138,8 @@ typedef struct {
     /* kernel set: 0 = staged kernels with global intermediates (debuggable,
        supports pyrohip_comp_stage_dump); 1 = fused LDS-tiled kernels       */
     int kernel_set;
-    /* compressible.riemann: 0 = HLLC (riemann.py:681-860), 1 = CGF (:8-310).
+    /* compressible.riemann: 0 = HLLC (riemann.py:681-860), 1 = CGF (:8-310),
+       2 = HLLC_lm (riemann_hllc_lowspeed, :863-1020).
        solid_xl / solid_yl: the lower x / y mesh boundary is a solid wall
        (boundary.bc_is_solid), used by CGF only */
     int riemann, solid_xl, solid_yl;

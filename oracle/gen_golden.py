@@ -670,6 +670,38 @@ def gen_mg_4096():
     print("mg 4096: residual_error", a.residual_error, "cycles", a.num_cycles)
 
 
+def gen_compressible_lm():
+    """row f2: the low-Mach HLLC variant (compressible.riemann = HLLC_lm,
+    riemann_hllc_lowspeed); same dump format as comp_stages_f2"""
+    cases = [
+        ("sedov", None, {"mesh.nx": 20, "mesh.ny": 24, "sedov.r_init": 0.15,
+                         "compressible.riemann": "HLLC_lm"}, 8),
+        ("kh", None, {"mesh.nx": 16, "mesh.ny": 24, "compressible.riemann": "HLLC_lm"}, 7),
+        ("sod", "inputs.sod.y", {"mesh.nx": 8, "mesh.ny": 32, "compressible.riemann": "HLLC_lm",
+                                 "compressible.limiter": 2}, 9),
+        ("rt", None, {"mesh.nx": 12, "mesh.ny": 36, "rt.amp": 0.4,
+                      "compressible.riemann": "HLLC_lm"}, 10),
+    ]
+    out = {"ncases": np.array(len(cases))}
+    for k, (prob, inp, d, nsteps) in enumerate(cases):
+        p = Pyro("compressible")
+        p.initialize_problem(prob, inputs_file=inp, inputs_dict=d)
+        sim = p.sim
+        for _ in range(nsteps):
+            p.single_step()
+        sim.cc_data.fill_BC_all()
+        sim.compute_timestep()
+        pre = f"c{k}_"
+        out[pre + "meta"] = comp_meta(sim)
+        out[pre + "bc"] = bc_names(sim.rp)
+        out[pre + "dt"] = np.array(sim.dt)
+        st = comp_stage_dump(sim)
+        for nm in ("U0", "FxT", "FyT", "Fx0", "Fy0", "Fx", "Fy", "U1"):
+            out[pre + nm] = st[nm]
+        print("HLLC_lm case", k, prob, "dt", sim.dt)
+    save("comp_stages_lm", **out)
+
+
 def _raw_cfl_dt(sim):
     dt_keep, dto_keep = sim.dt, sim.dt_old
     sim.method_compute_timestep()
@@ -993,6 +1025,8 @@ def gen_mg_general():
 if __name__ == "__main__":
     if "mg_general" in sys.argv[1:]:
         gen_mg_general()
+    if "comp_lm" in sys.argv[1:]:
+        gen_compressible_lm()
     if "mg_vc" in sys.argv[1:]:
         gen_mg_vc()
     if "comp_f2" in sys.argv[1:]:

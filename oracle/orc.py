@@ -141,7 +141,7 @@ def comp_params(nx, ny, ng, dx, dy, gamma=1.4, limiter=2, use_flattening=1,
             P.bc[n][s] = int(vb[n][s])
     P.avisc_xhi_interior = avisc_xhi_interior
     P.avisc_yhi_interior = avisc_yhi_interior
-    P.riemann = {"HLLC": 0, "CGF": 1}[riemann]
+    P.riemann = {"HLLC": 0, "CGF": 1, "HLLC_lm": 2}[riemann]
     solid = [int(b in ("reflect", "reflect-even", "reflect-odd", "dirichlet")) for b in bcs]
     P.solid_xl, P.solid_xr, P.solid_yl, P.solid_yr = solid
     if sponge is not None:

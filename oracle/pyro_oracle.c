@@ -756,11 +756,64 @@ void orc_riemann_cgf(int idir, int nx, int ny, int ng, double gamma, int lower_s
         }
 }
 
+/* riemann_hllc_lowspeed ("HLLC_lm"), compressible/riemann.py:863-1020: HLLC
+   with the low-Mach pressure fix  p* = (p_l+p_r)/2 + phi/2 (...),
+   phi = chi (2 - chi), chi = min(1, max|v| / max c)                          */
+void orc_riemann_hllc_lm(int idir, int nx, int ny, int ng, double gamma, const double *U_l,
+                         const double *U_r, double *F)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx, jlo = ng, jhi = ng + ny; /* njit-local */
+    const double smallc = 1.e-10, smallp = 1.e-10;
+    const int iun = (idir == 1) ? IXMOM : IYMOM, iut = (idir == 1) ? IYMOM : IXMOM;
+    memset(F, 0, sizeof(double) * qx * qy * 4);
+    for (int i = ilo - 1; i < ihi + 1; i++)
+        for (int j = jlo - 1; j < jhi + 1; j++) {
+            const double *Ul = U_l + ((size_t)i * qy + j) * 4, *Ur = U_r + ((size_t)i * qy + j) * 4;
+            double *Fc = F + ((size_t)i * qy + j) * 4;
+            const double rho_l = Ul[IDENS], un_l = Ul[iun] / rho_l, ut_l = Ul[iut] / rho_l;
+            const double rhoe_l = Ul[IENER] - 0.5 * rho_l * (SQ(un_l) + SQ(ut_l));
+            const double p_l = dmax(rhoe_l * (gamma - 1.0), smallp);
+            const double rho_r = Ur[IDENS], un_r = Ur[iun] / rho_r, ut_r = Ur[iut] / rho_r;
+            const double rhoe_r = Ur[IENER] - 0.5 * rho_r * (SQ(un_r) + SQ(ut_r));
+            const double p_r = dmax(rhoe_r * (gamma - 1.0), smallp);
+            const double c_l = dmax(smallc, sqrt(gamma * p_l / rho_l));
+            const double c_r = dmax(smallc, sqrt(gamma * p_r / rho_r));
+            double S_l, S_r;
+            estimate_wave_speed(rho_l, un_l, p_l, c_l, rho_r, un_r, p_r, c_r, gamma, &S_l, &S_r);
+            const double S_c = (p_r - p_l + rho_l * un_l * (S_l - un_l) - rho_r * un_r * (S_r - un_r)) /
+                               (rho_l * (S_l - un_l) - rho_r * (S_r - un_r));
+            double D[4] = {0.0, 0.0, 0.0, 0.0};
+            D[iun] = 1.0;
+            D[IENER] = S_c;
+            double F_l[4], F_r[4];
+            cons_flux(idir, gamma, Ul, F_l);
+            cons_flux(idir, gamma, Ur, F_r);
+            const double vmag_l = sqrt(SQ(un_l) + SQ(ut_l)), vmag_r = sqrt(SQ(un_r) + SQ(ut_r));
+            const double cs_max = dmax(c_l, c_r);
+            const double chi = dmin(1.0, dmax(vmag_l, vmag_r) / cs_max);
+            const double phi = chi * (2.0 - chi);
+            const double pstar = 0.5 * (p_l + p_r) +
+                                 0.5 * phi * (rho_l * (S_l - un_l) * (S_c - un_l) +
+                                              rho_r * (S_r - un_r) * (S_c - un_r));
+            for (int n = 0; n < 4; n++) {
+                if (S_r <= 0.0) Fc[n] = F_r[n];
+                else if (S_c <= 0.0 && 0.0 < S_r)
+                    Fc[n] = (S_c * (S_r * Ur[n] - F_r[n]) + S_r * pstar * D[n]) / (S_r - S_c);
+                else if (S_l < 0.0 && 0.0 < S_c)
+                    Fc[n] = (S_c * (S_l * Ul[n] - F_l[n]) + S_l * pstar * D[n]) / (S_l - S_c);
+                else Fc[n] = F_l[n];
+            }
+        }
+}
+
 #undef SQ
 static void riemann_dispatch(const orc_comp_params *P, int idir, const double *U_l,
                              const double *U_r, double *F)
 {
-    if (P->riemann == 1)
+    if (P->riemann == 2)
+        orc_riemann_hllc_lm(idir, P->nx, P->ny, P->ng, P->gamma, U_l, U_r, F);
+    else if (P->riemann == 1)
         orc_riemann_cgf(idir, P->nx, P->ny, P->ng, P->gamma,
                         idir == 1 ? P->solid_xl : P->solid_yl,
                         idir == 1 ? P->solid_xr : P->solid_yr, U_l, U_r, F);

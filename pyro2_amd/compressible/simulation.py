@@ -66,9 +66,8 @@ class Simulation(NullSimulation):
         my_grid = grid_setup(self.rp, ng=ng)
         my_data = self.data_class(my_grid)
         riemann_method = self.rp.get_param("compressible.riemann")
-        if riemann_method not in ("HLLC", "CGF"):
-            msg.fail("ERROR: the device path implements compressible.riemann = HLLC or CGF "
-                     "(HLLC_lm: SURVEY.md 8 row f2)")
+        if riemann_method not in ("HLLC", "CGF", "HLLC_lm"):
+            msg.fail("ERROR: Riemann solver undefined")
         # compressible/simulation.py:212-214; both have device kernels
         bnd.define_bc("hse", BC.user, is_solid=False, device_code=BC_CODE["hse"])
         bnd.define_bc("ambient", BC.user, is_solid=False, device_code=BC_CODE["ambient"])

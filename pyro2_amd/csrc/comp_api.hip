@@ -55,7 +55,7 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     PYRO_TRY(check_comp(s, p));
     PYRO_REQUIRE(dt > 0.0, "dt must be positive");
     PYRO_REQUIRE(p->kernel_set == 0 || p->kernel_set == 1, "kernel_set must be 0 or 1");
-    PYRO_REQUIRE(p->riemann == 0 || p->riemann == 1, "riemann must be 0 (HLLC) or 1 (CGF)");
+    PYRO_REQUIRE(p->riemann >= 0 && p->riemann <= 2, "riemann must be 0 (HLLC), 1 (CGF) or 2 (HLLC_lm)");
     int rc;
     if (p->kernel_set == 1)
         rc = p->fast_math ? fastm::comp_step_fused(s, p, dt) : exact::comp_step_fused(s, p, dt);
@@ -83,7 +83,7 @@ int pyrohip_comp_rk_rhs(pyrohip_state *y, const pyrohip_comp_params *p, pyrohip_
     PYRO_REQUIRE(k->g.nx == y->g.nx && k->g.ny == y->g.ny && k->g.ng == y->g.ng,
                  "k state must have the geometry of the stage state");
     PYRO_REQUIRE(slot >= 0 && 4 * (slot + 1) <= k->nvar, "slot outside the k state");
-    PYRO_REQUIRE(p->riemann == 0 || p->riemann == 1, "riemann must be 0 (HLLC) or 1 (CGF)");
+    PYRO_REQUIRE(p->riemann >= 0 && p->riemann <= 2, "riemann must be 0 (HLLC), 1 (CGF) or 2 (HLLC_lm)");
     if (p->do_sponge)
         PYRO_REQUIRE(p->sponge_rho_begin > p->sponge_rho_full,
                      "sponge_rho_begin must exceed sponge_rho_full (simulation.py:172)");

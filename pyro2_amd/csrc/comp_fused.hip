@@ -104,7 +104,7 @@ __device__ __forceinline__ Cons corr(const Cons &U, const Cons &Fhi, const Cons 
 #define PYRO_FUSED_MINW 4
 #endif
 
-template <int SOLVER>   // compressible.riemann: 0 HLLC, 1 CGF
+template <int SOLVER>   // compressible.riemann: 0 HLLC, 1 CGF, 2 HLLC_lm
 __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double *__restrict__ Uin,
                                                    double *__restrict__ Uout, Geom g, FP P,
                                                    int *__restrict__ flag,
@@ -380,10 +380,16 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
         PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_ctu_fused<1>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)FLDS_BYTES));
+        PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_ctu_fused<2>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)FLDS_BYTES));
         attr_set = true;
     }
 #endif
-    if (p->riemann == 1)
+    if (p->riemann == 2)
+        PYRO_LAUNCH(c, "k_ctu_fused", k_ctu_fused<2>, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
+                    (const double *)Uin, Uout, g, P, s->d_flag, part);
+    else if (p->riemann == 1)
         PYRO_LAUNCH(c, "k_ctu_fused", k_ctu_fused<1>, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
                     (const double *)Uin, Uout, g, P, s->d_flag, part);
     else

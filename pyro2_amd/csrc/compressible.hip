@@ -55,12 +55,13 @@ struct CP {   // kernel-side parameters
     double grav;          // compressible.grav (0: no source terms)
     int refl_ylo, refl_yhi;   // y-momentum reflects oddly at the lower / upper y wall
     int amb_yhi;              // "ambient" boundary on the upper y side
-    int riemann, solid_xl, solid_yl;   // 0 HLLC / 1 CGF; CGF wall rule
+    int riemann, solid_xl, solid_yl;   // 0 HLLC / 1 CGF / 2 HLLC_lm; CGF wall rule
 };
 
 __device__ __forceinline__ ConsN riemann_rt(const ConsN &Ul, const ConsN &Ur, const CP &P, bool x,
                                             bool wall)
 {
+    if (P.riemann == 2) return riemann_face<2>(Ul, Ur, P.gamma, x, wall);
     return P.riemann == 1 ? riemann_face<1>(Ul, Ur, P.gamma, x, wall)
                           : riemann_face<0>(Ul, Ur, P.gamma, x, wall);
 }

@@ -50,7 +50,11 @@ __device__ __forceinline__ double psqrt(double x)
 #endif
     return (x > 0.0) ? g : 0.0;
 }
+// same for arguments that may be exactly 0 (velocity magnitudes): psqrt already
+// returns 0 there
+__device__ __forceinline__ double psqrt0(double x) { return psqrt(x); }
 #else
+__device__ __forceinline__ double psqrt0(double x) { return sqrt(x); }
 __device__ __forceinline__ double psqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ double prcp(double b) { return 1.0 / b; }
 __device__ __forceinline__ double pdiv(double a, double b) { return a / b; }
@@ -319,6 +323,58 @@ __device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, dou
 }
 
 
+// Low-Mach HLLC variant ("HLLC_lm", riemann_hllc_lowspeed, riemann.py:863-1020):
+// the star-region pressure is blended with phi = chi (2 - chi),
+// chi = min(1, max|v| / max c), and the star fluxes are written in the
+// (S_c (S U - F) + S p* D) / (S - S_c) form with D = (0, S_c, 1, 0) in
+// (density, energy, normal momentum, transverse momentum).
+__device__ __forceinline__ ConsN hllc_lm_flux(const ConsN &Ul, const ConsN &Ur, double gamma,
+                                              bool normal_is_x)
+{
+    const double smallc = 1.e-10, smallp = 1.e-10;
+    const double rho_l = Ul.d;
+    const double ril = PYRO_FAST ? prcp(rho_l) : 0.0;
+    const double un_l = pdivr(Ul.mn, rho_l, ril), ut_l = pdivr(Ul.mt, rho_l, ril);
+    const double rhoe_l = Ul.E - 0.5 * rho_l * (un_l * un_l + ut_l * ut_l);
+    const double p_l = fmax(rhoe_l * (gamma - 1.0), smallp);
+    const double rho_r = Ur.d;
+    const double rir = PYRO_FAST ? prcp(rho_r) : 0.0;
+    const double un_r = pdivr(Ur.mn, rho_r, rir), ut_r = pdivr(Ur.mt, rho_r, rir);
+    const double rhoe_r = Ur.E - 0.5 * rho_r * (un_r * un_r + ut_r * ut_r);
+    const double p_r = fmax(rhoe_r * (gamma - 1.0), smallp);
+    const double c_l = fmax(smallc, psqrt(pdivr(gamma * p_l, rho_l, ril)));
+    const double c_r = fmax(smallc, psqrt(pdivr(gamma * p_r, rho_r, rir)));
+    double S_l, S_r;
+    estimate_wave_speed(rho_l, un_l, p_l, c_l, rho_r, un_r, p_r, c_r, gamma, S_l, S_r);
+    const double S_c = pdiv(p_r - p_l + rho_l * un_l * (S_l - un_l) - rho_r * un_r * (S_r - un_r),
+                            rho_l * (S_l - un_l) - rho_r * (S_r - un_r));
+    const double vmag_l = psqrt0(un_l * un_l + ut_l * ut_l);
+    const double vmag_r = psqrt0(un_r * un_r + ut_r * ut_r);
+    const double cs_max = fmax(c_l, c_r);
+    const double chi = fmin(1.0, pdiv(fmax(vmag_l, vmag_r), cs_max));
+    const double phi = chi * (2.0 - chi);
+    const double pstar = 0.5 * (p_l + p_r) + 0.5 * phi * (rho_l * (S_l - un_l) * (S_c - un_l) +
+                                                          rho_r * (S_r - un_r) * (S_c - un_r));
+    if (S_r <= 0.0) return cons_flux_n(Ur, gamma, normal_is_x);
+    if (S_c <= 0.0 && 0.0 < S_r) {
+        const ConsN Fr = cons_flux_n(Ur, gamma, normal_is_x);
+        const double den = S_r - S_c, sp = S_r * pstar;
+        return ConsN{pdiv(S_c * (S_r * Ur.d - Fr.d) + sp * 0.0, den),
+                     pdiv(S_c * (S_r * Ur.E - Fr.E) + sp * S_c, den),
+                     pdiv(S_c * (S_r * Ur.mn - Fr.mn) + sp * 1.0, den),
+                     pdiv(S_c * (S_r * Ur.mt - Fr.mt) + sp * 0.0, den)};
+    }
+    if (S_l < 0.0 && 0.0 < S_c) {
+        const ConsN Fl = cons_flux_n(Ul, gamma, normal_is_x);
+        const double den = S_l - S_c, sp = S_l * pstar;
+        return ConsN{pdiv(S_c * (S_l * Ul.d - Fl.d) + sp * 0.0, den),
+                     pdiv(S_c * (S_l * Ul.E - Fl.E) + sp * S_c, den),
+                     pdiv(S_c * (S_l * Ul.mn - Fl.mn) + sp * 1.0, den),
+                     pdiv(S_c * (S_l * Ul.mt - Fl.mt) + sp * 0.0, den)};
+    }
+    return cons_flux_n(Ul, gamma, normal_is_x);
+}
+
 // Two-shock Colella-Glaz-Ferguson solver on one face, riemann.py:8-310,
 // followed by consFlux of the resulting interface state (riemann_flux
 // :1083-1090), in the (normal, transverse) frame.  wall_zero: this is the
@@ -410,6 +466,7 @@ __device__ __forceinline__ ConsN riemann_face(const ConsN &Ul, const ConsN &Ur, 
                                               bool normal_is_x, bool wall_zero)
 {
     if (SOLVER == 1) return cgf_flux(Ul, Ur, gamma, normal_is_x, wall_zero);
+    if (SOLVER == 2) return hllc_lm_flux(Ul, Ur, gamma, normal_is_x);
     return hllc_flux(Ul, Ur, gamma, normal_is_x);
 }
 

@@ -347,7 +347,7 @@ def make_comp_params(dx, dy, gamma=1.4, limiter=2, use_flattening=1, z0=0.75,
     p.avisc_xhi_interior = int(avisc_xhi_interior)
     p.avisc_yhi_interior = int(avisc_yhi_interior)
     p.fast_math, p.kernel_set = int(fast_math), int(kernel_set)
-    p.riemann = {"HLLC": 0, "CGF": 1}[riemann] if isinstance(riemann, str) else int(riemann)
+    p.riemann = {"HLLC": 0, "CGF": 1, "HLLC_lm": 2}[riemann] if isinstance(riemann, str) else int(riemann)
     p.solid_xl, p.solid_yl = int(solid_xl), int(solid_yl)
     if sponge is not None:   # (rho_begin, rho_full, timescale)
         p.do_sponge = 1
