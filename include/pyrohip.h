@@ -42,7 +42,9 @@ enum {
     PYROHIP_BC_HALO = 4,         /* interior slab interface: filled by        */
                                  /* pyrohip_halo_exchange, not by fill_bc     */
     PYROHIP_BC_HSE = 5,          /* compressible "hse" user boundary, y sides */
-    PYROHIP_BC_AMBIENT = 6       /* compressible "ambient" user boundary, yr  */
+    PYROHIP_BC_AMBIENT = 6,      /* compressible "ambient" user boundary, yr  */
+    PYROHIP_BC_RAMP = 7          /* compressible "ramp" (double Mach           */
+                                 /* reflection) user boundary: xl, yl, yr     */
 };
 
 /* own status codes (hipError_t values are passed through unchanged) */
@@ -105,6 +107,17 @@ int pyrohip_fill_bc(pyrohip_state *s, int n);
    ghost columns as the PREVIOUS fill left them.  ambient = rho,u,v,p or NULL */
 int pyrohip_state_set_user_bc(pyrohip_state *s, double gamma, double grav,
                               double dy, const double *ambient);
+/* Parameters of the "ramp" boundary of the double Mach reflection problem
+   (compressible/BC.py:178-296).  x: the qx cell-centre coordinates of the grid
+   (copied); cxoff = 0.5 dx sqrt(3); post / pre: post- and pre-shock values of
+   the 4 conserved variables in the state's order; sf_down / sf_up: the shock
+   front positions (BC.py:240-243) of the ng ghost rows above the upper y
+   boundary at the CURRENT time -- call again whenever t changes.  All
+   transcendental factors are evaluated by the caller, so the fill is
+   bit-identical to the reference.                                          */
+int pyrohip_state_set_ramp_bc(pyrohip_state *s, const double *x, double cxoff,
+                              const double *post, const double *pre,
+                              const double *sf_down, const double *sf_up);
 /* min / max over the valid region grown by buf (patch.py:626-638) */
 int pyrohip_state_minmax(pyrohip_state *s, int n, int buf, double *vmin,
                          double *vmax);

@@ -702,6 +702,33 @@ def gen_compressible_lm():
     save("comp_stages_lm", **out)
 
 
+def gen_compressible_ramp():
+    """row f2: the double Mach reflection problem with its time-dependent
+    "ramp" boundary (compressible/BC.py:178-296): a short run, and the ghost
+    fill at the end time"""
+    p = Pyro("compressible")
+    p.initialize_problem("ramp", inputs_dict={"mesh.nx": 48, "mesh.ny": 12})
+    sim = p.sim
+    out = {"ic": np.array(sim.cc_data.data)}
+    dts = []
+    for _ in range(12):
+        p.single_step()
+        dts.append(sim.dt)
+    out["final"] = np.array(sim.cc_data.data)
+    out["dts"] = np.array(dts)
+    out["t"] = np.array(sim.cc_data.t)
+    sim.cc_data.fill_BC_all()
+    out["filled"] = np.array(sim.cc_data.data)
+    out["meta"] = comp_meta(sim)
+    out["bc"] = bc_names(sim.rp)
+    g = sim.cc_data.grid
+    out["domain"] = np.array([g.xmin, g.xmax, g.ymin, g.ymax])
+    out["drv"] = np.array([p.rp.get_param("driver.init_tstep_factor"),
+                           p.rp.get_param("driver.max_dt_change")])
+    print("ramp: t", sim.cc_data.t, "dt", sim.dt)
+    save("comp_ramp", **out)
+
+
 def _raw_cfl_dt(sim):
     dt_keep, dto_keep = sim.dt, sim.dt_old
     sim.method_compute_timestep()
@@ -1027,6 +1054,8 @@ if __name__ == "__main__":
         gen_mg_general()
     if "comp_lm" in sys.argv[1:]:
         gen_compressible_lm()
+    if "comp_ramp" in sys.argv[1:]:
+        gen_compressible_ramp()
     if "mg_vc" in sys.argv[1:]:
         gen_mg_vc()
     if "comp_f2" in sys.argv[1:]:

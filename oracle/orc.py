@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "_build", "liborc.so")
 
 BC_CODES = {"outflow": 0, "neumann": 0, "reflect-even": 1, "reflect-odd": 2,
-            "dirichlet": 2, "periodic": 3, "hse": 5, "ambient": 6}
+            "dirichlet": 2, "periodic": 3, "hse": 5, "ambient": 6, "ramp": 7}
 
 
 def build(force=False):
@@ -459,3 +459,44 @@ class GenMG(VCMG):
         self.h = C.c_void_p(self._l.orc_vcmg_base(self.vh))
         self.nx = nx
         self.nlevels = self._l.orc_mg_nlevels(self.h)
+
+
+# ---- "ramp" boundary of the double Mach reflection problem ------------------
+def ramp_params(nx, ny, ng, xmin, xmax, ymin, ymax, gamma, t):
+    """everything compressible/BC.py:178-296 evaluates with math.*: cell centres,
+    sub-sampling offset, inflow states (inflow_post_bc / inflow_pre_bc, :254-296,
+    in the state's order density, energy, x-momentum, y-momentum) and the shock
+    front of the ghost rows above the upper y boundary (:240-243) at time t"""
+    import math
+    dx, dy = (xmax - xmin) / nx, (ymax - ymin) / ny
+    qx, qy = nx + 2 * ng, ny + 2 * ng
+    xl = (np.arange(qx) - ng) * dx + xmin
+    xr = (np.arange(qx) + 1.0 - ng) * dx + xmin
+    x = 0.5 * (xl + xr)
+    yl = (np.arange(qy) - ng) * dy + ymin
+    yr = (np.arange(qy) + 1.0 - ng) * dy + ymin
+    y = 0.5 * (yl + yr)
+    r_l, u_l, v_l, p_l = 8.0, 7.1447096, -4.125, 116.5
+    r_r, u_r, v_r, p_r = 1.4, 0.0, 0.0, 1.0
+    post = np.array([r_l, p_l / (gamma - 1.0) + 0.5 * r_l * (u_l * u_l + v_l * v_l), r_l * u_l,
+                     r_l * v_l])
+    pre = np.array([r_r, p_r / (gamma - 1.0) + 0.5 * r_r * (u_r * u_r + v_r * v_r), r_r * u_r,
+                    r_r * v_r])
+    jhi = ng + ny - 1
+    sfd, sfu = np.zeros(8), np.zeros(8)
+    for k in range(ng):
+        yj = float(y[jhi + 1 + k])
+        sfu[k] = 1.0 / 6.0 + (yj + 0.5 * dy * math.sqrt(3)) / math.tan(math.pi / 3.0) + \
+            (10.0 / math.sin(math.pi / 3.0)) * t
+        sfd[k] = 1.0 / 6.0 + (yj - 0.5 * dy * math.sqrt(3)) / math.tan(math.pi / 3.0) + \
+            (10.0 / math.sin(math.pi / 3.0)) * t
+    return dict(x=np.ascontiguousarray(x), cxoff=0.5 * dx * math.sqrt(3), post=post, pre=pre,
+                sf_down=sfd, sf_up=sfu)
+
+
+def comp_fill_bc_ramp(U, nx, ny, ng, bcs, rp):
+    vb = np.ascontiguousarray(comp_var_bcs(bcs))
+    f = lib().orc_comp_fill_bc_ramp
+    f.restype = None
+    f(_p(U), nx, ny, ng, vb.ctypes.data_as(C.POINTER(C.c_int)), _p(rp["x"]),
+      C.c_double(rp["cxoff"]), _p(rp["post"]), _p(rp["pre"]), _p(rp["sf_down"]), _p(rp["sf_up"]))

@@ -46,6 +46,7 @@
 #define BC_PERIODIC 3
 #define BC_HSE 5          /* compressible/BC.py "hse" (y sides only)   */
 #define BC_AMBIENT 6      /* compressible/BC.py "ambient" (yr only)    */
+#define BC_RAMP 7         /* compressible/BC.py "ramp" (xl, yl, yr)    */
 
 typedef struct {
     int nx, ny, ng;
@@ -940,6 +941,48 @@ void orc_comp_fill_bc(double *U, int nx, int ny, int ng, const int *bc /*[4][4]*
     }
 }
 
+/* "ramp" boundary of the double Mach reflection problem, BC.py:178-296, as
+   part of fill_BC_all: per variable the standard fill (which knows nothing
+   about "ramp"), then xlb, ylb, yrb.  x: cell centres (qx); cxoff = 0.5 dx
+   sqrt(3); post/pre: inflow values per variable; sfd/sfu: shock front of the
+   ng ghost rows above the upper boundary at the current time (evaluated by
+   the caller with the reference's math.* expressions). */
+void orc_comp_fill_bc_ramp(double *U, int nx, int ny, int ng, const int *bc,
+                           const double *x, double cxoff, const double *post,
+                           const double *pre, const double *sfd, const double *sfu)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, jlo = ng, jhi = ng + ny - 1;
+    for (int n = 0; n < 4; n++) {
+        const int *b = bc + 4 * n;
+        orc_fill_ghost(U, nx, ny, ng, 4, n, b);
+        if (b[0] == BC_RAMP)                     /* :186-191 */
+            for (int i = ilo - 1; i >= 0; i--)
+                for (int j = 0; j < qy; j++) U4(U, i, j, n) = post[n];
+        if (b[2] == BC_RAMP) {                   /* :199-214 */
+            int jj = 0;
+            for (int j = jlo - 1; j >= 0; j--, jj++)
+                for (int i = 0; i < qx; i++) {
+                    if (x[i] < 1.0 / 6.0) U4(U, i, j, n) = post[n];
+                    else if (n == IYMOM) U4(U, i, j, n) = -1.0 * U4(U, i, jlo + jj, n);
+                    else U4(U, i, j, n) = U4(U, i, jlo + jj, n);
+                }
+        }
+        if (b[3] == BC_RAMP)                     /* :224-246 */
+            for (int k = 0; k < ng; k++) {
+                const int j = jhi + 1 + k;
+                const double sf[2] = {sfd[k], sfu[k]};
+                for (int i = 0; i < qx; i++) {
+                    const double cx[2] = {x[i] - cxoff, x[i] + cxoff};
+                    double v = 0.0;
+                    for (int s = 0; s < 2; s++)
+                        for (int c = 0; c < 2; c++)
+                            v = v + 0.25 * ((cx[c] < sf[s]) ? post[n] : pre[n]);
+                    U4(U, i, j, n) = v;
+                }
+            }
+    }
+}
 #undef U4
 
 /* ------------------------------------------------------------------ */

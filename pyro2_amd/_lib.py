@@ -14,11 +14,11 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "lib", "libpyrohip.so")
 
-BC_OUTFLOW, BC_REFLECT_EVEN, BC_REFLECT_ODD, BC_PERIODIC, BC_HALO, BC_HSE, BC_AMBIENT = range(7)
+BC_OUTFLOW, BC_REFLECT_EVEN, BC_REFLECT_ODD, BC_PERIODIC, BC_HALO, BC_HSE, BC_AMBIENT, BC_RAMP = range(8)
 BC_CODE = {"outflow": BC_OUTFLOW, "neumann": BC_OUTFLOW,
            "reflect-even": BC_REFLECT_EVEN, "reflect-odd": BC_REFLECT_ODD,
            "dirichlet": BC_REFLECT_ODD, "periodic": BC_PERIODIC,
-           "halo": BC_HALO, "hse": BC_HSE, "ambient": BC_AMBIENT}
+           "halo": BC_HALO, "hse": BC_HSE, "ambient": BC_AMBIENT, "ramp": BC_RAMP}
 
 ERR_STATE = 10002
 UNIQUE_ID_BYTES = 128
@@ -89,6 +89,7 @@ _PROTOS = {
     "pyrohip_inc_stage_dump": [_VP, C.c_int, _DP],
     "pyrohip_fill_bc": [_VP, C.c_int],
     "pyrohip_state_set_user_bc": [_VP, C.c_double, C.c_double, C.c_double, _DP],
+    "pyrohip_state_set_ramp_bc": [_VP, _DP, C.c_double, _DP, _DP, _DP, _DP],
     "pyrohip_state_minmax": [_VP, C.c_int, C.c_int, _DP, _DP],
     "pyrohip_adv_step": [_VP, C.c_int, C.c_double, C.c_double, C.c_double,
                          C.c_double, C.c_double, C.c_int],

@@ -71,6 +71,7 @@ class Simulation(NullSimulation):
         # compressible/simulation.py:212-214; both have device kernels
         bnd.define_bc("hse", BC.user, is_solid=False, device_code=BC_CODE["hse"])
         bnd.define_bc("ambient", BC.user, is_solid=False, device_code=BC_CODE["ambient"])
+        bnd.define_bc("ramp", BC.user, is_solid=False, device_code=BC_CODE["ramp"])
         bc, bc_xodd, bc_yodd = bc_setup(self.rp)
         self.solid = bnd.bc_is_solid(bc)
         # same registration order as compressible/simulation.py:223-226

@@ -137,6 +137,11 @@ struct pyrohip_state {
     bool user_bc = false;     // any HSE / AMBIENT code in bc
     bool user_bc_set = false;
     double ubc_gamma = 0.0, ubc_grav = 0.0, ubc_dy = 0.0, ubc_amb[4] = {0, 0, 0, 0};
+    // "ramp" boundary (pyrohip_state_set_ramp_bc)
+    bool ramp_bc = false, ramp_set = false;
+    double *d_x = nullptr;    // cell-centre x coordinates (qx)
+    double r_cxoff = 0.0, r_post[4] = {0, 0, 0, 0}, r_pre[4] = {0, 0, 0, 0};
+    double r_sfd[8] = {0}, r_sfu[8] = {0};
     // compressible work space (allocated on first use)
     double *work = nullptr;
     size_t work_planes = 0;

@@ -46,7 +46,7 @@ int pyrohip_comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, 
 int pyrohip_comp_dt_is_global(pyrohip_state *s, int *flag)
 {
     PYRO_REQUIRE(s && flag, "NULL argument");
-    *flag = (s->next_cfl_min > 0.0 && s->cfl_is_global && !s->user_bc) ? 1 : 0;
+    *flag = (s->next_cfl_min > 0.0 && s->cfl_is_global && !s->user_bc && !s->ramp_bc) ? 1 : 0;
     return 0;
 }
 

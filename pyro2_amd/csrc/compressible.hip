@@ -421,7 +421,7 @@ int comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, double *
     const Geom &g = s->g;
     // the hse / ambient boundaries put states into the y ghost rows that no
     // interior cell holds (they do enter the reference's full-array minimum)
-    if (s->next_cfl_min > 0.0 && !s->user_bc) {   // cached by the last k_update
+    if (s->next_cfl_min > 0.0 && !s->user_bc && !s->ramp_bc) {   // cached by the last k_update
         *dt_out = cfl * s->next_cfl_min;
         return 0;
     }

@@ -66,7 +66,7 @@ __global__ void k_fill_x(double *__restrict__ d, Geom g, const int *__restrict__
     const int bl = bc[n * 4 + 0], br = bc[n * 4 + 1];
     const int ng = g.ng, ilo = g.ilo, ihi = g.ihi;
     const int p = g.pitch;
-    if (bl != PYROHIP_BC_HALO)
+    if (bl != PYROHIP_BC_HALO && bl != PYROHIP_BC_RAMP)   // ramp: k_fill_ramp
         for (int i = 0; i < ilo; i++) {
             double v;
             switch (bl) {
@@ -186,6 +186,50 @@ __global__ __launch_bounds__(256) void k_lincomb(double *__restrict__ dst,
     if (i >= g.ilo && i <= g.ihi && j >= g.jlo && j <= g.jhi)
         for (int s = 0; s < lc.n; s++) v += lc.c[s] * K[(size_t)(nvar * s + n) * g.plane + k];
     dst[(size_t)n * g.plane + k] = v;
+}
+
+// "ramp" boundary of the double Mach reflection problem, compressible/BC.py:
+// 178-296, for conserved variable n.  pass 0: lower x side = post-shock inflow
+// for all j (:186-191).  pass 1: lower y side (:199-214: inflow for x < 1/6,
+// reflecting wall beyond -- odd for the y-momentum) and upper y side (:224-246:
+// the moving shock, sub-sampled at four points per cell), for all i.
+struct RampBc {
+    double post, pre, cxoff;
+    double sfd[8], sfu[8];
+    int odd;   // variable is the y-momentum
+};
+__global__ void k_fill_ramp(double *__restrict__ a, Geom g, const double *__restrict__ x,
+                            int bxl, int byl, int byr, int pass, RampBc rb)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pass == 0) {
+        if (bxl != PYROHIP_BC_RAMP || t >= g.qy) return;
+        for (int i = 0; i < g.ilo; i++) a[(size_t)i * g.pitch + t] = rb.post;
+        return;
+    }
+    if (t >= g.qx) return;
+    double *row = a + (size_t)t * g.pitch;
+    const double xc = x[t];
+    if (byl == PYROHIP_BC_RAMP)
+        for (int j = g.jlo - 1; j >= 0; j--) {
+            if (xc < 1.0 / 6.0) row[j] = rb.post;
+            else {
+                const double m = row[2 * g.ng - j - 1];   // row jlo + jj
+                row[j] = rb.odd ? -1.0 * m : m;
+            }
+        }
+    if (byr == PYROHIP_BC_RAMP) {
+        const double cx[2] = {xc - rb.cxoff, xc + rb.cxoff};
+        for (int k = 0; k < g.ng; k++) {
+            const double sf[2] = {rb.sfd[k], rb.sfu[k]};
+            double v = 0.0;
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) v = v + 0.25 * ((cx[c] < sf[s]) ? rb.post : rb.pre);
+            row[g.jhi + 1 + k] = v;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -367,8 +411,14 @@ int pyrohip_state_create(pyrohip_ctx *c, int nx, int ny, int ng, int nvar, const
     PYRO_REQUIRE(nx > 0 && ny > 0 && ng >= 1 && ng <= 8 && nvar >= 1, "bad dimensions");
     PYRO_REQUIRE(nx >= ng && ny >= ng, "grid smaller than the ghost width");
     for (int k = 0; k < nvar * 4; k++)
-        PYRO_REQUIRE(bc[k] >= 0 && bc[k] <= PYROHIP_BC_AMBIENT, "bad BC code");
-    bool user_bc = false;
+        PYRO_REQUIRE(bc[k] >= 0 && bc[k] <= PYROHIP_BC_RAMP, "bad BC code");
+    bool user_bc = false, ramp_bc = false;
+    for (int k = 0; k < nvar * 4; k++) {
+        if (bc[k] != PYROHIP_BC_RAMP) continue;
+        PYRO_REQUIRE(nvar == 4, "the ramp boundary needs the 4-variable compressible state");
+        PYRO_REQUIRE((k & 3) != 1, "the ramp boundary is not defined on the upper x side");
+        ramp_bc = true;
+    }
     for (int k = 0; k < nvar * 4; k++) {
         if (bc[k] != PYROHIP_BC_HSE && bc[k] != PYROHIP_BC_AMBIENT) continue;
         // BC.py:116-117, 176-177: hse on the y sides only, ambient on the upper y side only
@@ -381,6 +431,7 @@ int pyrohip_state_create(pyrohip_ctx *c, int nx, int ny, int ng, int nvar, const
     PYRO_CHECK_HIP(hipSetDevice(c->device));
     pyrohip_state *s = new pyrohip_state();
     s->user_bc = user_bc;
+    s->ramp_bc = ramp_bc;
     s->ctx = c;
     s->g = make_geom(nx, ny, ng);
     s->nvar = nvar;
@@ -405,6 +456,7 @@ int pyrohip_state_destroy(pyrohip_state *s)
     if (s->base) (void)hipFree(s->base);
     if (s->alt_base) (void)hipFree(s->alt_base);
     if (s->d_bc) (void)hipFree(s->d_bc);
+    if (s->d_x) (void)hipFree(s->d_x);
     if (s->d_flag) (void)hipFree(s->d_flag);
     if (s->work) (void)hipFree(s->work);
     delete s;
@@ -526,6 +578,35 @@ int pyrohip_state_set_user_bc(pyrohip_state *s, double gamma, double grav, doubl
     return 0;
 }
 
+int pyrohip_state_set_ramp_bc(pyrohip_state *s, const double *x, double cxoff, const double *post,
+                              const double *pre, const double *sf_down, const double *sf_up)
+{
+    PYRO_REQUIRE(s && x && post && pre && sf_down && sf_up, "NULL argument");
+    PYRO_REQUIRE(s->nvar == 4, "the ramp boundary needs the 4-variable compressible state");
+    if (!s->d_x) PYRO_CHECK_HIP(hipMalloc((void **)&s->d_x, sizeof(double) * s->g.qx));
+    PYRO_CHECK_HIP(hipMemcpyAsync(s->d_x, x, sizeof(double) * s->g.qx, hipMemcpyHostToDevice,
+                                  s->ctx->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(s->ctx->stream));   // x is borrowed for the call only
+    s->r_cxoff = cxoff;
+    for (int n = 0; n < 4; n++) { s->r_post[n] = post[n]; s->r_pre[n] = pre[n]; }
+    for (int k = 0; k < s->g.ng; k++) { s->r_sfd[k] = sf_down[k]; s->r_sfu[k] = sf_up[k]; }
+    s->ramp_set = true;
+    return 0;
+}
+
+static void launch_ramp(pyrohip_state *s, int n, int pass)
+{
+    const Geom &g = s->g;
+    RampBc rb;
+    rb.post = s->r_post[n]; rb.pre = s->r_pre[n]; rb.cxoff = s->r_cxoff;
+    for (int k = 0; k < 8; k++) { rb.sfd[k] = s->r_sfd[k]; rb.sfu[k] = s->r_sfu[k]; }
+    rb.odd = (n == 3);
+    const int len = pass == 0 ? g.qy : g.qx;
+    hipLaunchKernelGGL(k_fill_ramp, dim3((len + 63) / 64), dim3(64), 0, s->ctx->stream,
+                       s->d + (size_t)n * g.plane, g, (const double *)s->d_x, s->bc[n * 4 + 0],
+                       s->bc[n * 4 + 2], s->bc[n * 4 + 3], pass, rb);
+}
+
 // fill_BC for variables n0 .. n0+cnt-1: x sides, then y sides, then the
 // user boundaries of each variable
 static int fill_bc_range(pyrohip_state *s, int n0, int cnt)
@@ -536,11 +617,15 @@ static int fill_bc_range(pyrohip_state *s, int n0, int cnt)
         dim3 grid((g.qy + 255) / 256, 1, cnt), block(256);
         hipLaunchKernelGGL(k_fill_x, grid, block, 0, c->stream, s->d, g, (const int *)s->d_bc, n0);
     }
+    if (s->ramp_bc)
+        for (int n = n0; n < n0 + cnt; n++) launch_ramp(s, n, 0);
     {
         dim3 block(16, 16);
         dim3 grid((g.qx + 15) / 16, 1, cnt);
         hipLaunchKernelGGL(k_fill_y, grid, block, 0, c->stream, s->d, g, (const int *)s->d_bc, n0);
     }
+    if (s->ramp_bc)
+        for (int n = n0; n < n0 + cnt; n++) launch_ramp(s, n, 1);
     if (s->user_bc) {
         for (int n = n0; n < n0 + cnt; n++) {
             const int yl = s->bc[n * 4 + 2], yr = s->bc[n * 4 + 3];
@@ -569,6 +654,10 @@ int pyrohip_fill_bc(pyrohip_state *s, int n)
 {
     PYRO_REQUIRE(s, "NULL state");
     PYRO_REQUIRE(n >= -1 && n < s->nvar, "variable index out of range");
+    if (s->ramp_bc) {
+        PYRO_REQUIRE(s->ramp_set, "ramp boundary: call pyrohip_state_set_ramp_bc first");
+        if (!s->user_bc) return fill_bc_range(s, n < 0 ? 0 : n, n < 0 ? s->nvar : 1);
+    }
     if (s->user_bc) {
         PYRO_REQUIRE(s->user_bc_set, "hse / ambient boundary: call pyrohip_state_set_user_bc first");
         if (n >= 0) return fill_bc_range(s, n, 1);

@@ -282,6 +282,15 @@ class DeviceState:
             check(self._l.pyrohip_inc_stage_dump(self.h, k, dptr(out)))
         return out
 
+    def set_ramp_bc(self, x, cxoff, post, pre, sf_down, sf_up):
+        """parameters of the "ramp" boundary (compressible/BC.py ramp_params)"""
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (x, post, pre, sf_down, sf_up)]
+        assert arrs[0].size == self.qx and arrs[3].size >= self.ng and arrs[4].size >= self.ng
+        with self.ctx.lock:
+            check(self._l.pyrohip_state_set_ramp_bc(self.h, dptr(arrs[0]), float(cxoff),
+                                                    dptr(arrs[1]), dptr(arrs[2]), dptr(arrs[3]),
+                                                    dptr(arrs[4])))
+
     def set_user_bc(self, gamma, grav, dy, ambient=None):
         """parameters of the hse / ambient boundaries (compressible/BC.py);
         ambient = (rho, u, v, p)"""

@@ -283,11 +283,16 @@ class CellCenterData2d:
 
     # ---- boundary conditions -------------------------------------------
     def _device_user_bc(self):
-        """the hse / ambient boundaries run on the device for the compressible
-        state (4 variables in pyro's order, y sides only)"""
-        return self.names == ["density", "energy", "x-momentum", "y-momentum"] and \
-            all(b not in bnd.device_bcs for n in self.names
-                for b in self.BCs[n].sides()[:2])
+        """the hse / ambient / ramp boundaries run on the device for the
+        compressible state (4 variables in pyro's order; hse and ambient on the
+        y sides only, ramp anywhere but the upper x side)"""
+        if self.names != ["density", "energy", "x-momentum", "y-momentum"]:
+            return False
+        for n in self.names:
+            xl, xr = self.BCs[n].sides()[:2]
+            if xr in bnd.device_bcs or (xl in bnd.device_bcs and xl != "ramp"):
+                return False
+        return True
 
     def _has_host_bc(self, name):
         bc = self.BCs[name]
@@ -299,11 +304,16 @@ class CellCenterData2d:
     def _push_user_bc(self, st):
         """hand gamma, grav and the ambient state (aux data, set by the solver
         and the problem setup) to the device ghost fill"""
-        if not any(b in bnd.device_bcs for n in self.names for b in self.BCs[n].sides()):
+        used = {b for n in self.names for b in self.BCs[n].sides() if b in bnd.device_bcs}
+        if not used:
             return
-        amb = [self.aux.get(k, 0.0) for k in
-               ("ambient_rho", "ambient_u", "ambient_v", "ambient_p")]
-        st.set_user_bc(self.get_aux("gamma"), self.get_aux("grav"), self.grid.dy, amb)
+        if used & {"hse", "ambient"}:
+            amb = [self.aux.get(k, 0.0) for k in
+                   ("ambient_rho", "ambient_u", "ambient_v", "ambient_p")]
+            st.set_user_bc(self.get_aux("gamma"), self.get_aux("grav"), self.grid.dy, amb)
+        if "ramp" in used:      # time dependent: the shock front moves with t
+            from ..compressible import BC as comp_bc
+            st.set_ramp_bc(**comp_bc.ramp_params(self.grid, self.get_aux("gamma"), self.t))
 
     def fill_BC_all(self):
         if not any(self._has_host_bc(n) for n in self.names):

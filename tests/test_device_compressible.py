@@ -531,3 +531,41 @@ def test_comp_hllc_lm(dev, golden, k, kset):
     scale = np.maximum(np.abs(Uo[ng:-ng, ng:-ng]).max(axis=(0, 1)), 1e-3)
     assert (np.abs(U1 - Uo)[ng:-ng, ng:-ng] / scale).max() <= tol
     assert (np.abs(U1 - g[f"c{k}_U1"])[ng:-ng, ng:-ng] / scale).max() <= 1e-13
+
+
+@pytest.mark.parametrize("kset", [0, 1])
+def test_comp_ramp_boundary(dev, golden, kset):
+    """the time-dependent "ramp" boundary of the double Mach
+    reflection problem (compressible/BC.py:178-296) filled on the device; run
+    and final ghost fill against the reference"""
+    from test_oracle_golden import oracle_ramp_run
+    g = golden("comp_ramp")
+    meta, bcs, dom = g["meta"], [str(b) for b in g["bc"]], g["domain"]
+    P, cfl = dev_params(meta, kernel_set=kset)
+    nx, ny, ng = int(meta[0]), int(meta[1]), int(meta[2])
+    s = comp_state(dev, nx, ny, bcs)
+    with pytest.raises(_lib.PyroHipError):
+        s.fill_bc()
+    s.upload(g["ic"])
+    nsteps = len(g["dts"]) if dev.kind == "hip" else 4
+    f0, mx = g["drv"]
+    pol = DtPolicy(1.e30, f0, mx)
+
+    def push(t):
+        s.set_ramp_bc(**orc.ramp_params(nx, ny, ng, dom[0], dom[1], dom[2], dom[3], meta[5], t))
+    for n in range(nsteps):
+        push(pol.t)
+        s.fill_bc()
+        dt = pol(s.comp_dt(P, cfl))
+        assert abs(dt / g["dts"][n] - 1) <= 1e-12
+        s.comp_step(P, dt)
+        pol.advance(dt)
+    Uo, _, t, _, _ = oracle_ramp_run(g, nsteps)
+    tol = 0.0 if dev.kind == "emu" else TOL_EXACT * nsteps
+    U = s.download()
+    scale = np.abs(Uo).max(axis=(0, 1))
+    assert (np.abs(U - Uo) / scale).max() <= tol
+    if nsteps == len(g["dts"]):
+        push(pol.t)
+        s.fill_bc()
+        assert (np.abs(s.download() - g["filled"]) / scale).max() <= tol

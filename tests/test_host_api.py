@@ -267,3 +267,22 @@ def test_pyro_import_alias():
     assert Simulation is pyro2_amd.compressible.Simulation
     with pytest.raises(ImportError):
         import pyro.no_such_solver  # noqa: F401
+
+
+def test_pyro_ramp_problem(api, golden):
+    """double Mach reflection through Pyro: IC and the time-dependent boundary"""
+    from pyro2_amd.pyro_sim import Pyro
+    g = golden("comp_ramp")
+    nsteps = len(g["dts"]) if api.kind == "hip" else 3
+    p = Pyro("compressible")
+    p.initialize_problem("ramp", inputs_dict={"mesh.nx": 48, "mesh.ny": 12,
+                                              "driver.max_steps": nsteps})
+    assert np.array_equal(np.asarray(p.sim.cc_data.data), g["ic"])
+    dts = []
+    while not p.sim.finished():
+        p.single_step()
+        dts.append(p.sim.dt)
+    assert max_rel_err(np.array(dts), g["dts"][:nsteps]) < 1e-12
+    if nsteps == len(g["dts"]):
+        scale = np.abs(g["final"]).max(axis=(0, 1))
+        assert (np.abs(np.asarray(p.sim.cc_data.data) - g["final"]) / scale).max() < 1e-12

@@ -617,3 +617,37 @@ def test_comp_hllc_lm(golden, k):
         assert max_rel_err(st[nm], g[f"c{k}_{nm}"]) == 0.0, (k, nm)
     ng = int(g[f"c{k}_meta"][2])
     assert np.array_equal(U[ng:-ng, ng:-ng], g[f"c{k}_U1"][ng:-ng, ng:-ng])
+
+
+def _ramp_fill(U, P, bcs, dom, t):
+    rp = orc.ramp_params(P.nx, P.ny, P.ng, dom[0], dom[1], dom[2], dom[3], P.gamma, t)
+    orc.comp_fill_bc_ramp(U, P.nx, P.ny, P.ng, bcs, rp)
+
+
+def oracle_ramp_run(g, nsteps):
+    from helpers import DtPolicy
+    bcs = [str(b) for b in g["bc"]]
+    P, cfl = meta_to_params(g["meta"], bcs)
+    f0, mx = g["drv"]
+    U = g["ic"].copy()
+    pol = DtPolicy(1.e30, f0, mx)
+    dts = []
+    for _ in range(nsteps):
+        _ramp_fill(U, P, bcs, g["domain"], pol.t)
+        dt = pol(orc.comp_dt(U, P.nx, P.ny, P.ng, P.dx, P.dy, P.gamma, cfl))
+        rc, _ = orc.comp_step(U, P, dt)
+        assert rc == 0
+        pol.advance(dt)
+        dts.append(dt)
+    return U, np.array(dts), pol.t, P, bcs
+
+
+def test_oracle_ramp(golden):
+    """double Mach reflection with the time-dependent "ramp" boundary
+    (compressible/BC.py:178-296): run and final ghost fill vs the reference"""
+    g = golden("comp_ramp")
+    U, dts, t, P, bcs = oracle_ramp_run(g, len(g["dts"]))
+    assert np.array_equal(dts, g["dts"]) and t == float(g["t"])
+    assert np.array_equal(U, g["final"])
+    _ramp_fill(U, P, bcs, g["domain"], t)
+    assert np.array_equal(U, g["filled"])
