@@ -107,6 +107,11 @@ int pyrohip_fill_bc(pyrohip_state *s, int n);
    ghost columns as the PREVIOUS fill left them.  ambient = rho,u,v,p or NULL */
 int pyrohip_state_set_user_bc(pyrohip_state *s, double gamma, double grav,
                               double dy, const double *ambient);
+/* Heating profile exp(-(dist/r)^2) of the problem source above: (qx, qy) host
+   array on the whole grid (ghost coordinates included), or NULL to remove it.
+   The ghost cells of the device copy are refilled like the reference's E_src
+   (the boundary types of the energy, plain copies for hse / ambient).        */
+int pyrohip_state_set_heating(pyrohip_state *s, const double *profile);
 /* Parameters of the "ramp" boundary of the double Mach reflection problem
    (compressible/BC.py:178-296).  x: the qx cell-centre coordinates of the grid
    (copied); cxoff = 0.5 dx sqrt(3); post / pre: post- and pre-shock values of
@@ -159,6 +164,11 @@ typedef struct {
     /* sponge (compressible/simulation.py:164-184,427-441) */
     int do_sponge;
     double sponge_rho_begin, sponge_rho_full, sponge_timescale;
+    /* e_rate of the problem source S[energy] += rho e_rate profile(x, y) of the
+       heating / plume / convection problems (compressible/simulation.py:156-159,
+       problems/{heating,plume,convection}.py source_terms); only used when the
+       state carries a profile (pyrohip_state_set_heating) */
+    double heat_rate;
 } pyrohip_comp_params;
 
 /* method_compute_timestep (compressible/simulation.py:267-288 +

@@ -729,6 +729,71 @@ def gen_compressible_ramp():
     save("comp_ramp", **out)
 
 
+def gen_compressible_heating():
+    """row f2: problem source terms of the heating / plume / convection
+    problems (S[energy] += rho * e_rate * exp(-(dist/r)^2)): short runs, the
+    profile the reference evaluates, and the stages of one more step"""
+    cases = [
+        ("heating", {"mesh.nx": 24, "mesh.ny": 24, "heating.r_src": 0.15, "heating.e_rate": 5.0}, 12),
+        ("plume", {"mesh.nx": 16, "mesh.ny": 32, "plume.r_pert": 0.6}, 12),
+        ("convection", {"mesh.nx": 16, "mesh.ny": 48, "convection.thickness": 0.5}, 12),
+    ]
+    out = {"ncases": np.array(len(cases))}
+    for k, (prob, d, nsteps) in enumerate(cases):
+        p = Pyro("compressible")
+        p.initialize_problem(prob, inputs_dict=d)
+        sim = p.sim
+        rp, myg = sim.rp, sim.cc_data.grid
+        pre = f"c{k}_"
+        out[pre + "ic"] = np.array(sim.cc_data.data)
+        dts = []
+        for _ in range(nsteps):
+            p.single_step()
+            dts.append(sim.dt)
+        out[pre + "final"] = np.array(sim.cc_data.data)
+        out[pre + "dts"] = np.array(dts)
+        out[pre + "meta"] = comp_meta(sim)
+        out[pre + "bc"] = bc_names(rp)
+        out[pre + "small_dens"] = np.array(rp.get_param("compressible.small_dens"))
+        out[pre + "sponge"] = np.array([rp.get_param("sponge.do_sponge"),
+                                        rp.get_param("sponge.sponge_rho_begin"),
+                                        rp.get_param("sponge.sponge_rho_full"),
+                                        rp.get_param("sponge.sponge_timescale")])
+        amb = [sim.cc_data.aux.get(nm, 0.0) for nm in
+               ("ambient_rho", "ambient_u", "ambient_v", "ambient_p")]
+        out[pre + "ambient"] = np.array(amb, dtype=np.float64)
+        out[pre + "drv"] = np.array([p.rp.get_param("driver.init_tstep_factor"),
+                                     p.rp.get_param("driver.max_dt_change")])
+        # the source of a unit-density state: rate * profile as the reference evaluates it
+        ones = myg.scratch_array(nvar=sim.ivars.nvar)
+        ones[:, :, sim.ivars.idens] = 1.0
+        out[pre + "unit_source"] = np.array(sim.problem_source(myg, ones, sim.ivars, rp)[:, :, sim.ivars.iener])
+        out[pre + "e_rate"] = np.array(rp.get_param(prob + ".e_rate"))
+        # the bare profile exp(-(dist/r)^2), evaluated with this NumPy build's exp
+        if prob == "heating":
+            dist = np.sqrt((myg.x2d - 0.5 * (myg.xmin + myg.xmax))**2 +
+                           (myg.y2d - 0.5 * (myg.ymin + myg.ymax))**2)
+            r = rp.get_param("heating.r_src")
+        elif prob == "plume":
+            dist = np.sqrt((myg.x2d - rp.get_param("plume.x_pert"))**2 +
+                           (myg.y2d - rp.get_param("plume.y_pert"))**2)
+            r = rp.get_param("plume.r_pert")
+        else:
+            dist = np.abs(myg.y2d - rp.get_param("convection.y_height"))
+            r = rp.get_param("convection.thickness")
+        prof = np.exp(-(dist / r)**2)
+        assert np.array_equal(1.0 * out[pre + "e_rate"] * prof, out[pre + "unit_source"])
+        out[pre + "prof"] = np.array(prof)
+        sim.cc_data.fill_BC_all()
+        sim.compute_timestep()
+        out[pre + "dt"] = np.array(sim.dt)
+        st = comp_stage_dump(sim)
+        for nm in ("U0", "Uxl0", "Uyr0", "Fx", "Fy", "U1"):
+            out[pre + nm] = st[nm]
+        print("source case", k, prob, "dt", sim.dt)
+    save("comp_heating", **out)
+
+
 def _raw_cfl_dt(sim):
     dt_keep, dto_keep = sim.dt, sim.dt_old
     sim.method_compute_timestep()
@@ -1056,6 +1121,8 @@ if __name__ == "__main__":
         gen_compressible_lm()
     if "comp_ramp" in sys.argv[1:]:
         gen_compressible_ramp()
+    if "comp_heating" in sys.argv[1:]:
+        gen_compressible_heating()
     if "mg_vc" in sys.argv[1:]:
         gen_mg_vc()
     if "comp_f2" in sys.argv[1:]:

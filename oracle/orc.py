@@ -37,7 +37,8 @@ class CompParams(C.Structure):
                 ("riemann", C.c_int), ("solid_xl", C.c_int), ("solid_xr", C.c_int),
                 ("solid_yl", C.c_int), ("solid_yr", C.c_int), ("do_sponge", C.c_int),
                 ("sponge_rho_begin", C.c_double), ("sponge_rho_full", C.c_double),
-                ("sponge_timescale", C.c_double)]
+                ("sponge_timescale", C.c_double),
+                ("heat_rate", C.c_double), ("heat_prof", C.POINTER(C.c_double))]
 
 
 _STAGE_NAMES = ["q", "xi", "ldx", "ldy", "Uxl0", "Uxr0", "Uyl0", "Uyr0",
@@ -128,7 +129,7 @@ def comp_params(nx, ny, ng, dx, dy, gamma=1.4, limiter=2, use_flattening=1,
                 z0=0.75, z1=0.85, delta=0.33, cvisc=0.1, grav=0.0,
                 small_dens=-1.e200, bcs=("outflow",) * 4,
                 avisc_xhi_interior=0, avisc_yhi_interior=0, riemann="HLLC",
-                sponge=None):
+                sponge=None, heating=None):
     P = CompParams()
     P.nx, P.ny, P.ng = nx, ny, ng
     P.dx, P.dy, P.gamma = dx, dy, gamma
@@ -147,6 +148,11 @@ def comp_params(nx, ny, ng, dx, dy, gamma=1.4, limiter=2, use_flattening=1,
     if sponge is not None:
         P.do_sponge = 1
         P.sponge_rho_begin, P.sponge_rho_full, P.sponge_timescale = sponge
+    if heating is not None:      # (rate, profile (qx,qy) incl. ghost coordinates)
+        rate, prof = heating
+        P._heat_keep = np.ascontiguousarray(prof, dtype=np.float64)   # keep alive
+        P.heat_rate = rate
+        P.heat_prof = _p(P._heat_keep)
     return P
 
 

@@ -73,6 +73,12 @@ typedef struct {
     /* sponge (compressible/simulation.py:164-184, 427-441) */
     int do_sponge;
     double sponge_rho_begin, sponge_rho_full, sponge_timescale;
+    /* problem source of the heating / plume / convection problems
+       (compressible/problems/{heating,plume,convection}.py source_terms):
+       S[energy] += rho * heat_rate * heat_prof[i,j]; heat_prof: (qx,qy) profile
+       exp(-(dist/r)^2) on the whole grid incl. ghost coordinates, or NULL */
+    double heat_rate;
+    const double *heat_prof;
 } orc_comp_params;
 
 /* optional stage outputs; any pointer may be NULL */
@@ -867,9 +873,10 @@ void orc_artificial_viscosity(int nx, int ny, int ng, double dx, double dy,
     free(divU);
 }
 
-/* compressible/simulation.py:105-161, Cartesian branch, no problem_source */
-static void ext_sources(const double *U, const double *U_old, size_t ncell,
-                        double grav, double dt, double *S)
+/* compressible/simulation.py:105-161, Cartesian branch; problem_source of the
+   form rho * rate * prof (:156-159) */
+static void ext_sources_h(const double *U, const double *U_old, size_t ncell, double grav,
+                          double dt, double *S, double rate, const double *prof)
 {
     memset(S, 0, ncell * 4 * 8);
     for (size_t k = 0; k < ncell; k++) {
@@ -884,6 +891,7 @@ static void ext_sources(const double *U, const double *U_old, size_t ncell,
             double ymom_new = Uc[IYMOM] + 0.5 * dt * (Sc[IYMOM] - S_old_ymom);
             Sc[IENER] = ymom_new * grav;
         }
+        if (prof) Sc[IENER] += Uc[IDENS] * rate * prof[k];
     }
 }
 
@@ -1065,10 +1073,11 @@ int orc_comp_step(double *U, const orc_comp_params *P, double dt,
     orc_prim_to_cons(V_l, N, gamma, Uyl);
     orc_prim_to_cons(V_r, N, gamma, Uyr);
 
-    /* apply_source_terms, unsplit_fluxes.py:247-330 (gravity only) */
-    if (P->grav != 0.0) {
+    /* apply_source_terms, unsplit_fluxes.py:247-330 */
+    const int have_src = (P->grav != 0.0 || P->heat_prof != NULL);
+    if (have_src) {
         double *S = zalloc(N * 4);
-        ext_sources(U, NULL, N, P->grav, dt, S);
+        ext_sources_h(U, NULL, N, P->grav, dt, S, P->heat_rate, P->heat_prof);
         for (int n = 0; n < 4; n++) orc_fill_ghost(S, nx, ny, ng, 4, n, P->bc[n]);
         const int comps[3] = {IXMOM, IYMOM, IENER};
         for (int c = 0; c < 3; c++) {
@@ -1141,7 +1150,7 @@ int orc_comp_step(double *U, const orc_comp_params *P, double dt,
 
     /* conservative update, simulation.py:367-384 */
     double *U_old = NULL;
-    if (P->grav != 0.0) {
+    if (have_src) {
         U_old = zalloc(N * 4);
         memcpy(U_old, U, N * 32);
     }
@@ -1156,14 +1165,14 @@ int orc_comp_step(double *U, const orc_comp_params *P, double dt,
                                 U4(Fy, i, j, n) * Ay - U4(Fy, i, j + 1, n) * Ay);
     }
     /* source predictor-corrector, simulation.py:406-423 */
-    if (P->grav != 0.0) {
+    if (have_src) {
         double *S_old = zalloc(N * 4), *S_new = zalloc(N * 4);
-        ext_sources(U_old, NULL, N, P->grav, dt, S_old);
+        ext_sources_h(U_old, NULL, N, P->grav, dt, S_old, P->heat_rate, P->heat_prof);
         for (int n = 0; n < 4; n++)
             for (int i = ilo; i <= ihi; i++)
                 for (int j = jlo; j <= jhi; j++)
                     U4(U, i, j, n) += dt * U4(S_old, i, j, n);
-        ext_sources(U, U_old, N, P->grav, dt, S_new);
+        ext_sources_h(U, U_old, N, P->grav, dt, S_new, P->heat_rate, P->heat_prof);
         for (int n = 0; n < 4; n++)
             for (int i = ilo; i <= ihi; i++)
                 for (int j = jlo; j <= jhi; j++)
@@ -2099,7 +2108,7 @@ int orc_comp_rk_rhs(double *U, const orc_comp_params *P, double *kout,
         for (int j = jlo; j <= jhi; j++)
             U4(U, i, j, IDENS) = dmax(U4(U, i, j, IDENS), P->small_dens);
     double *S = zalloc(N * 4);                  /* simulation.py:16-19 */
-    ext_sources(U, NULL, N, P->grav, 0.0, S);
+    ext_sources_h(U, NULL, N, P->grav, 0.0, S, P->heat_rate, P->heat_prof);
 
     double *q = zalloc(N * 4), *xi = zalloc(N), *ldx = zalloc(N * 4), *ldy = zalloc(N * 4),
            *tmp = zalloc(N);

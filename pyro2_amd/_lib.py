@@ -41,7 +41,8 @@ class CompParams(C.Structure):
                 ("fast_math", C.c_int), ("kernel_set", C.c_int),
                 ("riemann", C.c_int), ("solid_xl", C.c_int), ("solid_yl", C.c_int),
                 ("do_sponge", C.c_int), ("sponge_rho_begin", C.c_double),
-                ("sponge_rho_full", C.c_double), ("sponge_timescale", C.c_double)]
+                ("sponge_rho_full", C.c_double), ("sponge_timescale", C.c_double),
+                ("heat_rate", C.c_double)]
 
 
 _DP = C.POINTER(C.c_double)
@@ -89,6 +90,7 @@ _PROTOS = {
     "pyrohip_inc_stage_dump": [_VP, C.c_int, _DP],
     "pyrohip_fill_bc": [_VP, C.c_int],
     "pyrohip_state_set_user_bc": [_VP, C.c_double, C.c_double, C.c_double, _DP],
+    "pyrohip_state_set_heating": [_VP, _DP],
     "pyrohip_state_set_ramp_bc": [_VP, _DP, C.c_double, _DP, _DP, _DP, _DP],
     "pyrohip_state_minmax": [_VP, C.c_int, C.c_int, _DP, _DP],
     "pyrohip_adv_step": [_VP, C.c_int, C.c_double, C.c_double, C.c_double,

@@ -112,18 +112,39 @@ class Simulation(NullSimulation):
             solid_xl=self.solid.xl, solid_yl=self.solid.yl,
             sponge=(rp.get_param("sponge.sponge_rho_begin"), rp.get_param("sponge.sponge_rho_full"),
                     rp.get_param("sponge.sponge_timescale"))
-            if rp.get_param("sponge.do_sponge") else None)
+            if rp.get_param("sponge.do_sponge") else None,
+            heat_rate=self._heating()[0] if self._heating() else 0.0)
+
+    def _heating(self):
+        """(e_rate, profile) of the problem source rho * e_rate * profile(x, y)
+        (problems heating / plume / convection), evaluated once; None without"""
+        fn = getattr(self, "problem_heating", None)
+        if fn is None:
+            return None
+        if getattr(self, "_heat_cache", None) is None:
+            rate, prof = fn(self.cc_data.grid, self.rp)
+            self._heat_cache = (float(rate), np.ascontiguousarray(prof, dtype=np.float64))
+        return self._heat_cache
+
+    def _device_state(self):
+        """the state on the device, carrying the heating profile if there is one"""
+        st = self.cc_data.device_state()
+        h = self._heating()
+        if h is not None and getattr(st, "_heating_set", False) is False:
+            st.set_heating(h[1])
+            st._heating_set = True
+        return st
 
     def method_compute_timestep(self):
         """cfl * min(dx/(|u|+c), dy/(|v|+c)) over the whole array
         (compressible/simulation.py:267-288), reduced on the device"""
         cfl = self.rp.get_param("driver.cfl")
-        self.dt = self.cc_data.device_state().comp_dt(self._params(), float(cfl))
+        self.dt = self._device_state().comp_dt(self._params(), float(cfl))
 
     def evolve(self):
         tm = self.tc.timer("evolve")
         tm.begin()
-        st = self.cc_data.device_state()
+        st = self._device_state()
         st.comp_step(self._params(), float(self.dt))
         self.cc_data.device_modified()
         self.cc_data.t += self.dt

@@ -25,7 +25,7 @@ class Simulation(CompressibleSimulation):
         """cfl * min 1 / ((|u|+c)/dx + (|v|+c)/dy) over the whole array
         (compressible_rk/simulation.py:46-56)"""
         cfl = self.rp.get_param("driver.cfl")
-        self.dt = self.cc_data.device_state().comp_rk_dt(self._params(), float(cfl))
+        self.dt = self._device_state().comp_rk_dt(self._params(), float(cfl))
 
     def evolve(self):
         tm = self.tc.timer("evolve")
@@ -33,10 +33,14 @@ class Simulation(CompressibleSimulation):
         cc = self.cc_data
         method = self.rp.get_param("compressible.temporal_method")
         rk = integration.RKIntegrator(cc.t, self.dt, method=method)
-        start = cc.device_state()
+        start = self._device_state()
         if self._rk_scratch is not None and self._rk_scratch[1].nvar != 4 * rk.nstages():
             self._rk_scratch = None
         self._rk_scratch = rk.set_start(start, self._rk_scratch)
+        h = self._heating()
+        if h is not None and not getattr(rk.stage, "_heating_set", False):
+            rk.stage.set_heating(h[1])
+            rk.stage._heating_set = True
         for s in range(rk.nstages()):
             ytmp = rk.get_stage_start(s)
             if s == 0:

@@ -137,6 +137,7 @@ struct pyrohip_state {
     bool user_bc = false;     // any HSE / AMBIENT code in bc
     bool user_bc_set = false;
     double ubc_gamma = 0.0, ubc_grav = 0.0, ubc_dy = 0.0, ubc_amb[4] = {0, 0, 0, 0};
+    double *heat_base = nullptr, *heat = nullptr;   // heating profile plane (set_heating)
     // "ramp" boundary (pyrohip_state_set_ramp_bc)
     bool ramp_bc = false, ramp_set = false;
     double *d_x = nullptr;    // cell-centre x coordinates (qx)

@@ -66,6 +66,9 @@ struct FP {   // kernel parameters
     double grav;          // compressible.grav (0: no source terms)
     int refl_ylo, refl_yhi;   // y-momentum reflects oddly at the lower / upper y wall
     int amb_yhi;              // "ambient" boundary on the upper y side
+    int have_src;             // gravity and / or a heating source
+    double heat_rate;         // S[E] += rho * heat_rate * heat[i,j] (ghost-filled plane)
+    const double *heat;
     int solid_xl, solid_yl;   // CGF wall rule (riemann.py:274-286)
 };
 
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
         // vertex divergence at (i-1/2, j-1/2), interface.py:312-330
         D[t] = div_u_vertex(Qu[qc], Qu[qc - 1], Qu[qc - FQW], Qu[qc - FQW - 1], Qv[qc],
                             Qv[qc - FQW], Qv[qc - 1], Qv[qc - FQW - 1], P.dx, P.dy);
-        if (P.grav != 0.0) {   // apply_source_terms, unsplit_fluxes.py:247-330
+        if (P.have_src) {   // apply_source_terms, unsplit_fluxes.py:247-330
             const bool ina = (i < g.qx && j < g.qy);
             // "ambient" upper boundary: the source ghosts are copies of row jhi
             // (BC.py:159-160), not the sources of the ambient ghost state
@@ -202,10 +205,12 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
                 Ug.d = fmax(Ug.d, P.small_dens);
             const double sgn =
                 ((j < g.jlo && P.refl_ylo) || (j > g.jhi && P.refl_yhi)) ? -1.0 : 1.0;
-            add_grav_to_state(XM, Ug, P.grav, P.dt, sgn);
-            add_grav_to_state(XP, Ug, P.grav, P.dt, sgn);
-            add_grav_to_state(YM, Ug, P.grav, P.dt, sgn);
-            add_grav_to_state(YP, Ug, P.grav, P.dt, sgn);
+            const double hp = P.heat ? P.heat[(size_t)(ina ? i : g.qx - 1) * p + (ina ? j : g.qy - 1)]
+                                     : 0.0;
+            add_grav_to_state(XM, Ug, P.grav, P.dt, sgn, P.heat_rate, hp);
+            add_grav_to_state(XP, Ug, P.grav, P.dt, sgn, P.heat_rate, hp);
+            add_grav_to_state(YM, Ug, P.grav, P.dt, sgn, P.heat_rate, hp);
+            add_grav_to_state(YP, Ug, P.grav, P.dt, sgn, P.heat_rate, hp);
         }
         lds_put(S, t, XP);
         lds_put(S + 4 * FNT, t, YP);
@@ -303,7 +308,8 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
         Un.E = Uc.E + dtdV * (Fx.E * Ax - Fxh.E * Ax + Fy.E * Ay - Fyh.E * Ay);
         Un.mx = Uc.mx + dtdV * (Fx.mx * Ax - Fxh.mx * Ax + Fy.mx * Ay - Fyh.mx * Ay);
         Un.my = Uc.my + dtdV * (Fx.my * Ax - Fxh.my * Ax + Fy.my * Ay - Fyh.my * Ay);
-        if (P.grav != 0.0) grav_update(Un, Uc, P.grav, P.dt);   // simulation.py:406-423
+        if (P.have_src)   // simulation.py:406-423
+            grav_update(Un, Uc, P.grav, P.dt, P.heat_rate, P.heat ? P.heat[k] : 0.0);
         Uout[k] = Un.d; Uout[pl + k] = Un.E; Uout[2 * pl + k] = Un.mx; Uout[3 * pl + k] = Un.my;
         cfl = cfl_cell(Un, gamma, P.dx, P.dy);
     }
@@ -364,6 +370,8 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     P.refl_ylo = (s->bc[3 * 4 + 2] == PYROHIP_BC_REFLECT_ODD);
     P.refl_yhi = (s->bc[3 * 4 + 3] == PYROHIP_BC_REFLECT_ODD);
     P.amb_yhi = (s->bc[3 * 4 + 3] == PYROHIP_BC_AMBIENT);
+    P.heat = s->heat; P.heat_rate = s->heat ? p->heat_rate : 0.0;
+    P.have_src = (p->grav != 0.0 || s->heat != nullptr);
     P.solid_xl = p->solid_xl; P.solid_yl = p->solid_yl;
     const int nti = (g.nx + FTI - 1) / FTI;
     P.ntj = (g.ny + FTJ - 1) / FTJ;

@@ -55,6 +55,9 @@ struct CP {   // kernel-side parameters
     double grav;          // compressible.grav (0: no source terms)
     int refl_ylo, refl_yhi;   // y-momentum reflects oddly at the lower / upper y wall
     int amb_yhi;              // "ambient" boundary on the upper y side
+    int have_src;             // gravity and / or a heating source
+    double heat_rate;         // S[E] += rho * heat_rate * heat[i,j] (ghost-filled plane)
+    const double *heat;
     int riemann, solid_xl, solid_yl;   // 0 HLLC / 1 CGF / 2 HLLC_lm; CGF wall rule
 };
 
@@ -174,15 +177,16 @@ __global__ __launch_bounds__(256) void k_states(const double *__restrict__ U,
                  P.dt / P.dy, lo, hi);
     Cons YM = prim_to_cons(Prim{lo.r, lo.ut, lo.un, lo.p}, P.gamma);
     Cons YP = prim_to_cons(Prim{hi.r, hi.ut, hi.un, hi.p}, P.gamma);
-    if (P.grav != 0.0) {   // apply_source_terms, unsplit_fluxes.py:247-330
+    if (P.have_src) {   // apply_source_terms, unsplit_fluxes.py:247-330
         // "ambient" upper boundary: the source ghosts are copies of row jhi
         // (BC.py:159-160), not the sources of the ambient ghost state
         const Cons Uc = load_cons(U, pl, (P.amb_yhi && j > g.jhi) ? k - (j - g.jhi) : k);
         const double sgn = ((j < g.jlo && P.refl_ylo) || (j > g.jhi && P.refl_yhi)) ? -1.0 : 1.0;
-        add_grav_to_state(XM, Uc, P.grav, P.dt, sgn);
-        add_grav_to_state(XP, Uc, P.grav, P.dt, sgn);
-        add_grav_to_state(YM, Uc, P.grav, P.dt, sgn);
-        add_grav_to_state(YP, Uc, P.grav, P.dt, sgn);
+        const double hp = P.heat ? P.heat[k] : 0.0;
+        add_grav_to_state(XM, Uc, P.grav, P.dt, sgn, P.heat_rate, hp);
+        add_grav_to_state(XP, Uc, P.grav, P.dt, sgn, P.heat_rate, hp);
+        add_grav_to_state(YM, Uc, P.grav, P.dt, sgn, P.heat_rate, hp);
+        add_grav_to_state(YP, Uc, P.grav, P.dt, sgn, P.heat_rate, hp);
     }
     store_cons(Wout + (size_t)W_XM * pl, pl, k, XM);
     store_cons(Wout + (size_t)W_XP * pl, pl, k, XP);
@@ -342,7 +346,9 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ U,
             Un[n] = Uo[n] + dtdV * (fx[k] * Ax - fx[k + p] * Ax + fy[k] * Ay - fy[k + 1] * Ay);
         }
         Cons Uc{Un[0], Un[1], Un[2], Un[3]};
-        if (P.grav != 0.0) grav_update(Uc, Cons{Uo[0], Uo[1], Uo[2], Uo[3]}, P.grav, P.dt);
+        if (P.have_src)
+            grav_update(Uc, Cons{Uo[0], Uo[1], Uo[2], Uo[3]}, P.grav, P.dt, P.heat_rate,
+                        P.heat ? P.heat[k] : 0.0);
         store_cons(U, pl, k, Uc);
         cfl = cfl_cell(Uc, P.gamma, P.dx, P.dy);
     }
@@ -398,6 +404,8 @@ static CP make_cp(const pyrohip_comp_params *p, double dt, const pyrohip_state *
     c.refl_ylo = (s->bc[3 * 4 + 2] == PYROHIP_BC_REFLECT_ODD);
     c.refl_yhi = (s->bc[3 * 4 + 3] == PYROHIP_BC_REFLECT_ODD);
     c.amb_yhi = (s->bc[3 * 4 + 3] == PYROHIP_BC_AMBIENT);
+    c.heat = s->heat; c.heat_rate = s->heat ? p->heat_rate : 0.0;
+    c.have_src = (p->grav != 0.0 || s->heat != nullptr);
     c.riemann = p->riemann; c.solid_xl = p->solid_xl; c.solid_yl = p->solid_yl;
     return c;
 }
@@ -622,7 +630,7 @@ __global__ __launch_bounds__(256) void k_rk_rhs(const double *__restrict__ U,
     }
     // planes: density, energy, x-momentum, y-momentum; S = (0, ymom g, 0, rho g)
     kk[0] = kk[0] + 0.0;
-    kk[1] = kk[1] + Uc.my * P.grav;
+    kk[1] = kk[1] + (Uc.my * P.grav + Uc.d * P.heat_rate * (P.heat ? P.heat[k] : 0.0));
     kk[2] = kk[2] + 0.0;
     kk[3] = kk[3] + Uc.d * P.grav;
     if (sp.on) {

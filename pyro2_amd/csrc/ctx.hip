@@ -457,6 +457,7 @@ int pyrohip_state_destroy(pyrohip_state *s)
     if (s->alt_base) (void)hipFree(s->alt_base);
     if (s->d_bc) (void)hipFree(s->d_bc);
     if (s->d_x) (void)hipFree(s->d_x);
+    if (s->heat_base) (void)hipFree(s->heat_base);
     if (s->d_flag) (void)hipFree(s->d_flag);
     if (s->work) (void)hipFree(s->work);
     delete s;
@@ -575,6 +576,38 @@ int pyrohip_state_set_user_bc(pyrohip_state *s, double gamma, double grav, doubl
     s->ubc_dy = dy;
     for (int k = 0; k < 4; k++) s->ubc_amb[k] = ambient ? ambient[k] : 0.0;
     s->user_bc_set = true;
+    return 0;
+}
+
+int pyrohip_state_set_heating(pyrohip_state *s, const double *profile)
+{
+    PYRO_REQUIRE(s, "NULL state");
+    PYRO_REQUIRE(s->nvar == 4, "the heating source needs the 4-variable compressible state");
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    if (!profile) {
+        PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+        if (s->heat_base) PYRO_CHECK_HIP(hipFree(s->heat_base));
+        s->heat_base = s->heat = nullptr;
+        return 0;
+    }
+    if (!s->heat_base) {
+        PYRO_CHECK_HIP(hipMalloc((void **)&s->heat_base, (g.plane + 16) * sizeof(double)));
+        PYRO_CHECK_HIP(hipMemsetAsync(s->heat_base, 0, (g.plane + 16) * sizeof(double), c->stream));
+        s->heat = s->heat_base + geom_lead(g);
+    }
+    PYRO_CHECK_HIP(hipMemcpy2DAsync(s->heat, g.pitch * sizeof(double), profile,
+                                    g.qy * sizeof(double), g.qy * sizeof(double), g.qx,
+                                    hipMemcpyHostToDevice, c->stream));
+    // ghost cells like my_aux.fill_BC("E_src") (unsplit_fluxes.py:303-306):
+    // the boundary types of the energy = row 1 of the BC table, used as "variable 0"
+    // of this one-plane array
+    hipLaunchKernelGGL(k_fill_x, dim3((g.qy + 255) / 256, 1, 1), dim3(256), 0, c->stream, s->heat, g,
+                       (const int *)(s->d_bc + 4), 0);
+    hipLaunchKernelGGL(k_fill_y, dim3((g.qx + 15) / 16, 1, 1), dim3(16, 16), 0, c->stream, s->heat,
+                       g, (const int *)(s->d_bc + 4), 0);
+    PYRO_CHECK_HIP(hipGetLastError());
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));   // profile is borrowed for the call only
     return 0;
 }
 

@@ -499,11 +499,16 @@ __device__ __forceinline__ void sponge_cell(Cons &U, double dt, double rho_begin
 // (odd across a reflecting y wall) and E_src (even), which for a ghost cell
 // beyond such a wall is minus the value computed from the ghost state itself:
 // pass sgn = -1 there, +1 everywhere else.
+// hrate / hprof: problem source S[E] += rho * e_rate * profile of the heating /
+// plume / convection problems (simulation.py:156-159); its ghost values are
+// the even BC fill of the interior ones, i.e. the profile plane is ghost-filled
+// and no sign applies.  0 / 0 when there is no such source.
 __device__ __forceinline__ void add_grav_to_state(Cons &S, const Cons &Ucell, double grav,
-                                                  double dt, double sgn)
+                                                  double dt, double sgn, double hrate = 0.0,
+                                                  double hprof = 0.0)
 {
     const double Sy = sgn * (Ucell.d * grav);
-    const double SE = sgn * (Ucell.my * grav);
+    const double SE = sgn * (Ucell.my * grav) + Ucell.d * hrate * hprof;
     S.my += 0.5 * dt * Sy;
     S.E += 0.5 * dt * SE;
 }
@@ -511,15 +516,16 @@ __device__ __forceinline__ void add_grav_to_state(Cons &S, const Cons &Ucell, do
 // Source predictor-corrector after the conservative update
 // (compressible/simulation.py:406-423 with get_external_sources :105-161):
 // U* = U + dt S(U_old); S_new uses the time-centred momentum; U = U* + dt/2 (S_new - S_old)
-__device__ __forceinline__ void grav_update(Cons &U, const Cons &Uold, double grav, double dt)
+__device__ __forceinline__ void grav_update(Cons &U, const Cons &Uold, double grav, double dt,
+                                            double hrate = 0.0, double hprof = 0.0)
 {
     const double Sy_old = Uold.d * grav;
-    const double SE_old = Uold.my * grav;
+    const double SE_old = Uold.my * grav + Uold.d * hrate * hprof;
     U.my = U.my + dt * Sy_old;
     U.E = U.E + dt * SE_old;
     const double Sy_new = U.d * grav;
     const double ymom_new = U.my + 0.5 * dt * (Sy_new - Sy_old);
-    const double SE_new = ymom_new * grav;
+    const double SE_new = ymom_new * grav + U.d * hrate * hprof;
     U.my = U.my + 0.5 * dt * (Sy_new - Sy_old);
     U.E = U.E + 0.5 * dt * (SE_new - SE_old);
 }

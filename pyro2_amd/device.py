@@ -282,6 +282,17 @@ class DeviceState:
             check(self._l.pyrohip_inc_stage_dump(self.h, k, dptr(out)))
         return out
 
+    def set_heating(self, profile):
+        """heating profile (qx, qy) of the problem source S[E] += rho e_rate profile
+        (None removes it); e_rate travels in the comp params (heat_rate)"""
+        with self.ctx.lock:
+            if profile is None:
+                check(self._l.pyrohip_state_set_heating(self.h, None))
+            else:
+                a = np.ascontiguousarray(profile, dtype=np.float64)
+                assert a.shape == (self.qx, self.qy)
+                check(self._l.pyrohip_state_set_heating(self.h, dptr(a)))
+
     def set_ramp_bc(self, x, cxoff, post, pre, sf_down, sf_up):
         """parameters of the "ramp" boundary (compressible/BC.py ramp_params)"""
         arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (x, post, pre, sf_down, sf_up)]
@@ -347,7 +358,7 @@ def make_comp_params(dx, dy, gamma=1.4, limiter=2, use_flattening=1, z0=0.75,
                      z1=0.85, delta=0.33, cvisc=0.1, grav=0.0,
                      small_dens=-1.e200, avisc_xhi_interior=0,
                      avisc_yhi_interior=0, fast_math=0, kernel_set=0, riemann="HLLC",
-                     solid_xl=0, solid_yl=0, sponge=None):
+                     solid_xl=0, solid_yl=0, sponge=None, heat_rate=0.0):
     p = CompParams()
     p.dx, p.dy, p.gamma = dx, dy, gamma
     p.limiter, p.use_flattening = int(limiter), int(use_flattening)
@@ -361,6 +372,7 @@ def make_comp_params(dx, dy, gamma=1.4, limiter=2, use_flattening=1, z0=0.75,
     if sponge is not None:   # (rho_begin, rho_full, timescale)
         p.do_sponge = 1
         p.sponge_rho_begin, p.sponge_rho_full, p.sponge_timescale = sponge
+    p.heat_rate = float(heat_rate)     # used when the state carries a heating profile
     return p
 
 

@@ -10,6 +10,7 @@ all three run on the GPU; only dt (8 bytes) comes back per step.
 import argparse
 import importlib
 import os
+import sys
 
 from .util import msg
 from .util import profile_pyro as profile
@@ -66,8 +67,19 @@ class Pyro:
             if inputs_file is None:
                 inputs_file = problem.DEFAULT_INPUTS
         self.problem_name = problem_name
+        # Problem sources run on the device when they have the form of the
+        # reference's three heating problems, S[energy] = rho * e_rate *
+        # profile(x, y): the problem module then also provides
+        # heating_profile(grid, rp) -> (e_rate, profile).  Arbitrary Python
+        # source callbacks would need the state on the host twice per step.
+        self.problem_heating = None
         if self.problem_source is not None:
-            msg.fail("ERROR: problem source terms are not carried by the device path")
+            self.problem_heating = getattr(
+                sys.modules.get(self.problem_source.__module__), "heating_profile", None)
+            if self.problem_heating is None:
+                msg.fail("ERROR: this problem's source_terms() has no heating_profile() "
+                         "companion; only sources of the form rho * e_rate * profile(x, y) "
+                         "are carried by the device path")
 
         for k, v in self.problem_params.items():
             self.rp.set_param(k, v, no_new=False)
@@ -94,6 +106,7 @@ class Pyro:
             self.solver_name, self.problem_name, self.problem_func, self.rp,
             problem_finalize_func=self.problem_finalize,
             problem_source_func=self.problem_source, timers=self.tc)
+        self.sim.problem_heating = getattr(self, "problem_heating", None)
         self.sim.initialize()
         self.sim.preevolve()
         self.sim.cc_data.t = 0.0

@@ -569,3 +569,59 @@ def test_comp_ramp_boundary(dev, golden, kset):
         push(pol.t)
         s.fill_bc()
         assert (np.abs(s.download() - g["filled"]) / scale).max() <= tol
+
+
+@pytest.mark.parametrize("kset", [0, 1])
+@pytest.mark.parametrize("k", range(3))
+def test_comp_problem_sources(dev, golden, k, kset):
+    """the heating source of the heating / plume / convection
+    problems on the device (convection: + gravity, sponge, reflecting wall,
+    ambient boundary, density floor); one step from a reference state and a
+    short run against the reference"""
+    from test_oracle_golden import _heat_case
+    from helpers import oracle_comp_run
+    g = golden("comp_heating")
+    pre, bcs, over = _heat_case(g, k)
+    meta = g[pre + "meta"]
+    nx, ny, ng = int(meta[0]), int(meta[1]), int(meta[2])
+    I = (slice(ng, -ng), slice(ng, -ng))
+    solid = [int(b == "reflect") for b in bcs]
+    P, cfl = dev_params(meta, kernel_set=kset, solid_xl=solid[0], solid_yl=solid[2],
+                        small_dens=over["small_dens"], sponge=over.get("sponge"),
+                        heat_rate=over["heating"][0])
+
+    def state():
+        s = comp_state(dev, nx, ny, bcs)
+        if any(b in ("hse", "ambient") for b in bcs):
+            s.set_user_bc(meta[5], meta[12], meta[4], g[pre + "ambient"])
+        s.set_heating(g[pre + "prof"])
+        return s
+    tol = 0.0 if dev.kind == "emu" else TOL_EXACT
+    s = state()
+    s.upload(g[pre + "U0"])
+    s.comp_step(P, float(g[pre + "dt"]))
+    ref = g[pre + "U1"]
+    scale = np.maximum(np.abs(ref[I]).max(axis=(0, 1)), 1e-3)
+    U1 = s.download()
+    sel = slice(None) if g[pre + "sponge"][0] else I      # the sponge also acts on ghost cells
+    tol1 = max(tol, 1e-15) if g[pre + "sponge"][0] else tol      # cos() in the sponge
+    assert (np.abs(U1 - ref)[sel] / scale).max() <= tol1
+    if kset == 0:
+        for nm, sl in (("Fx", (slice(ng, ng + nx + 1), slice(ng, ng + ny))),
+                       ("Fy", (slice(ng, ng + nx), slice(ng, ng + ny + 1)))):
+            assert max_rel_err(s.comp_stage(nm)[sl], g[pre + nm][sl]) <= tol, nm
+    # run
+    nsteps = len(g[pre + "dts"]) if dev.kind == "hip" else 4
+    f0, mx = g[pre + "drv"]
+    s = state()
+    s.upload(np.nan_to_num(g[pre + "ic"]))
+    pol = DtPolicy(1.e30, f0, mx)
+    for n in range(nsteps):
+        s.fill_bc()
+        dt = pol(s.comp_dt(P, cfl))
+        assert abs(dt / g[pre + "dts"][n] - 1) <= 1e-12
+        s.comp_step(P, dt)
+        pol.advance(dt)
+    Uo, _, _ = oracle_comp_run(g[pre + "ic"], meta, bcs, 1.e30, nsteps, f0, mx,
+                               ambient=tuple(g[pre + "ambient"]), **over)
+    assert (np.abs(s.download() - Uo)[I] / scale).max() <= max(tol * nsteps, 1e-14 if g[pre + "sponge"][0] else 0.0)

@@ -286,3 +286,33 @@ def test_pyro_ramp_problem(api, golden):
     if nsteps == len(g["dts"]):
         scale = np.abs(g["final"]).max(axis=(0, 1))
         assert (np.abs(np.asarray(p.sim.cc_data.data) - g["final"]) / scale).max() < 1e-12
+
+
+@pytest.mark.parametrize("k,prob,d", [
+    (0, "heating", {"mesh.nx": 24, "mesh.ny": 24, "heating.r_src": 0.15, "heating.e_rate": 5.0}),
+    (1, "plume", {"mesh.nx": 16, "mesh.ny": 32, "plume.r_pert": 0.6}),
+    (2, "convection", {"mesh.nx": 16, "mesh.ny": 48, "convection.thickness": 0.5}),
+])
+def test_pyro_problem_sources(api, golden, k, prob, d):
+    """heating / plume / convection through Pyro: IC, heating profile, run"""
+    from pyro2_amd.pyro_sim import Pyro
+    g = golden("comp_heating")
+    pre = f"c{k}_"
+    nsteps = len(g[pre + "dts"]) if api.kind == "hip" else 3
+    p = Pyro("compressible")
+    p.initialize_problem(prob, inputs_dict=dict(d, **{"driver.max_steps": nsteps}))
+    ic = np.asarray(p.sim.cc_data.data)
+    assert np.array_equal(np.isnan(ic), np.isnan(g[pre + "ic"]))
+    # sqrt / exp / pow differ in the last bit between NumPy builds
+    assert np.allclose(ic, g[pre + "ic"], rtol=2e-15, atol=1e-30, equal_nan=True)
+    rate, prof = p.sim._heating()
+    assert rate == float(g[pre + "e_rate"]) and np.allclose(prof, g[pre + "prof"], rtol=4e-16, atol=0)
+    dts = []
+    while not p.sim.finished():
+        p.single_step()
+        dts.append(p.sim.dt)
+    assert max_rel_err(np.array(dts), g[pre + "dts"][:nsteps]) < 1e-12
+    if nsteps == len(g[pre + "dts"]):
+        fin = g[pre + "final"][4:-4, 4:-4]
+        scale = np.maximum(np.abs(fin).max(axis=(0, 1)), 1e-3)
+        assert (np.abs(np.asarray(p.sim.cc_data.data)[4:-4, 4:-4] - fin) / scale).max() < 1e-11

@@ -651,3 +651,40 @@ def test_oracle_ramp(golden):
     assert np.array_equal(U, g["final"])
     _ramp_fill(U, P, bcs, g["domain"], t)
     assert np.array_equal(U, g["filled"])
+
+
+def _heat_case(g, k):
+    pre = f"c{k}_"
+    bcs = [str(b) for b in g[pre + "bc"]]
+    sp = g[pre + "sponge"]
+    over = dict(heating=(float(g[pre + "e_rate"]), g[pre + "prof"]),
+                small_dens=float(g[pre + "small_dens"]))
+    if sp[0]:
+        over["sponge"] = tuple(sp[1:])
+    return pre, bcs, over
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_oracle_problem_sources(golden, k):
+    """the problem source of heating / plume / convection
+    (S[E] += rho e_rate exp(-(dist/r)^2); convection also has gravity, the
+    sponge, a reflecting wall and the ambient boundary): stages of one step
+    and a short run against the reference"""
+    from helpers import oracle_comp_run
+    g = golden("comp_heating")
+    pre, bcs, over = _heat_case(g, k)
+    meta = g[pre + "meta"]
+    ng = int(meta[2])
+    I = (slice(ng, -ng), slice(ng, -ng))
+    P, cfl = meta_to_params(meta, bcs, **over)
+    U = g[pre + "U0"].copy()
+    rc, st = orc.comp_step(U, P, float(g[pre + "dt"]), stages=True)
+    assert rc == 0
+    for nm in ("Uxl0", "Uyr0", "Fx", "Fy"):
+        assert np.array_equal(st[nm], g[pre + nm]), nm
+    assert np.array_equal(U[I], g[pre + "U1"][I])
+    f0, mx = g[pre + "drv"]
+    U, dts, _ = oracle_comp_run(g[pre + "ic"], meta, bcs, 1.e30, len(g[pre + "dts"]), f0, mx,
+                                ambient=tuple(g[pre + "ambient"]), **over)
+    assert np.array_equal(dts, g[pre + "dts"])
+    assert np.array_equal(U[I], g[pre + "final"][I])
