@@ -794,6 +794,24 @@ def gen_compressible_heating():
     save("comp_heating", **out)
 
 
+def gen_problem_ics():
+    """initial conditions of the remaining compressible problem set-ups"""
+    cases = {"acoustic_pulse": {"mesh.nx": 24, "mesh.ny": 24},
+             "advect": {"mesh.nx": 16, "mesh.ny": 20},
+             "bubble": {"mesh.nx": 32, "mesh.ny": 64},
+             "gresho": {"mesh.nx": 20, "mesh.ny": 20},
+             "rt2": {"mesh.nx": 24, "mesh.ny": 48},
+             "rt_multimode": {"mesh.nx": 24, "mesh.ny": 48}}
+    out = {}
+    for prob, d in cases.items():
+        p = Pyro("compressible")
+        p.initialize_problem(prob, inputs_dict=d)
+        out[prob] = np.array(p.sim.cc_data.data)
+        out[prob + "_bc"] = bc_names(p.sim.rp)
+        print("ic", prob, out[prob].shape)
+    save("comp_problem_ics", **out)
+
+
 def _raw_cfl_dt(sim):
     dt_keep, dto_keep = sim.dt, sim.dt_old
     sim.method_compute_timestep()
@@ -1123,6 +1141,8 @@ if __name__ == "__main__":
         gen_compressible_ramp()
     if "comp_heating" in sys.argv[1:]:
         gen_compressible_heating()
+    if "problem_ics" in sys.argv[1:]:
+        gen_problem_ics()
     if "mg_vc" in sys.argv[1:]:
         gen_mg_vc()
     if "comp_f2" in sys.argv[1:]:

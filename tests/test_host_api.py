@@ -316,3 +316,27 @@ def test_pyro_problem_sources(api, golden, k, prob, d):
         fin = g[pre + "final"][4:-4, 4:-4]
         scale = np.maximum(np.abs(fin).max(axis=(0, 1)), 1e-3)
         assert (np.abs(np.asarray(p.sim.cc_data.data)[4:-4, 4:-4] - fin) / scale).max() < 1e-11
+
+
+@pytest.mark.parametrize("prob,d", [
+    ("acoustic_pulse", {"mesh.nx": 24, "mesh.ny": 24}),
+    ("advect", {"mesh.nx": 16, "mesh.ny": 20}),
+    ("bubble", {"mesh.nx": 32, "mesh.ny": 64}),
+    ("gresho", {"mesh.nx": 20, "mesh.ny": 20}),
+    ("rt2", {"mesh.nx": 24, "mesh.ny": 48}),
+    ("rt_multimode", {"mesh.nx": 24, "mesh.ny": 48}),
+])
+def test_problem_initial_conditions(api, golden, prob, d):
+    """the remaining compressible problem set-ups produce the reference's initial
+    state (to the last bits of exp / cos / log between NumPy builds) and boundaries"""
+    from pyro2_amd.pyro_sim import Pyro
+    g = golden("comp_problem_ics")
+    p = Pyro("compressible")
+    p.initialize_problem(prob, inputs_dict=dict(d, **{"driver.max_steps": 0}))
+    ic = np.asarray(p.sim.cc_data.data)
+    assert np.array_equal(np.isnan(ic), np.isnan(g[prob]))
+    assert np.allclose(ic, g[prob], rtol=4e-15, atol=1e-18, equal_nan=True)
+    bc = p.sim.cc_data.BCs["density"]
+    assert [bc.xlb, bc.xrb, bc.ylb, bc.yrb] == [str(b).replace("reflect", "reflect-even")
+                                                  if str(b) == "reflect" else str(b)
+                                                  for b in g[prob + "_bc"]]
