@@ -340,3 +340,7 @@ def test_problem_initial_conditions(api, golden, prob, d):
     assert [bc.xlb, bc.xrb, bc.ylb, bc.yrb] == [str(b).replace("reflect", "reflect-even")
                                                   if str(b) == "reflect" else str(b)
                                                   for b in g[prob + "_bc"]]
+    if api.kind == "hip" and prob != "bubble":   # bubble is under-resolved at this size
+        p.sim.max_steps = 5                          # (the reference fails on it too)
+        p.run_sim()
+        assert p.sim.n == 5 and np.isfinite(np.asarray(p.sim.cc_data.data)[4:-4, 4:-4]).all()
