@@ -13,6 +13,32 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    _parallel_cpu_suite(config)
+
+
+def _parallel_cpu_suite(config):
+    """The CPU suite (-m "not gpu") executes the HIP kernels on a single-threaded
+    emulator; spread it over a few pytest-xdist workers so that it stays within
+    a few minutes.  The GPU suite is never parallelised (one context, one GPU).
+    PYRO_TEST_WORKERS=0 disables, an explicit -n wins."""
+    if hasattr(config, "workerinput"):          # we are a worker already
+        return
+    if (config.getoption("markexpr", "") or "").replace(" ", "") != "notgpu":
+        return
+    n = int(os.environ.get("PYRO_TEST_WORKERS", "4"))
+    if n <= 1 or not config.pluginmanager.hasplugin("xdist"):
+        return
+    if getattr(config.option, "numprocesses", None) or getattr(config.option, "dist", "no") != "no":
+        return
+    # build the shared test libraries once, before the workers race for them
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    build_emu.build()
+    from oracle import orc
+    orc.build()
+    config.option.numprocesses = n
+    config.option.tx = ["popen"] * n
+    config.option.dist = "load"
 
 
 @pytest.fixture(scope="session")
