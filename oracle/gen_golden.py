@@ -812,6 +812,85 @@ def gen_problem_ics():
     save("comp_problem_ics", **out)
 
 
+def gen_incompressible_viscous():
+    """row f4: incompressible_viscous (lid-driven cavity, moving_lid boundary,
+    two Helmholtz solves per step) -- short runs, one instrumented step, and
+    the reference regression cavity_n64_Re400_0025.h5 (test.py:111)"""
+    import pyro.incompressible.incomp_interface as ii
+    import pyro.incompressible.simulation as isim
+    store = {}
+    orig_pre = isim.Simulation.preevolve
+
+    def preevolve(self):
+        store["ic"] = _planes(self.cc_data)
+        orig_pre(self)
+        store["after_pre"] = _planes(self.cc_data)
+    isim.Simulation.preevolve = preevolve
+    out = {}
+    cases = [("cavity", {"mesh.nx": 16, "mesh.ny": 16}, 5),
+             ("cavity", {"mesh.nx": 32, "mesh.ny": 32, "incompressible.proj_type": 1,
+                         "incompressible_viscous.viscosity": 0.01}, 4),
+             ("shear", {"mesh.nx": 16, "mesh.ny": 16, "incompressible.limiter": 1}, 4)]
+    for k, (prob, d, nsteps) in enumerate(cases):
+        p = Pyro("incompressible_viscous")
+        p.initialize_problem(prob, inputs_dict=d)
+        sim = p.sim
+        pre = f"i{k}_"
+        out[pre + "ic"], out[pre + "after_pre"] = store["ic"], store["after_pre"]
+        dts = []
+        for _ in range(nsteps):
+            p.single_step()
+            dts.append(sim.dt)
+        out[pre + "final"] = _planes(sim.cc_data)
+        out[pre + "dts"] = np.array(dts)
+        g = sim.cc_data.grid
+        out[pre + "meta"] = np.array([g.nx, g.ng, sim.rp.get_param("incompressible.limiter"),
+                                      sim.rp.get_param("incompressible.proj_type"),
+                                      sim.rp.get_param("driver.cfl"),
+                                      sim.rp.get_param("driver.init_tstep_factor"),
+                                      sim.rp.get_param("driver.max_dt_change"),
+                                      sim.rp.get_param("incompressible_viscous.viscosity")])
+        out[pre + "bc"] = bc_names(sim.rp)
+        sim.cc_data.fill_BC_all()
+        sim.compute_timestep()
+        out[pre + "U0"] = _planes(sim.cc_data)
+        out[pre + "dt"] = np.array(sim.dt)
+        cap = {}
+        orig_states = ii.states
+
+        def states(grid, dt, u, v, a, b, c, dd, gx, gy, u_MAC, v_MAC, sx=None, sy=None):
+            cap["umac"], cap["vmac"] = np.array(u_MAC), np.array(v_MAC)
+            return orig_states(grid, dt, u, v, a, b, c, dd, gx, gy, u_MAC, v_MAC, sx, sy)
+        ii.states = states
+        sim.evolve()
+        ii.states = orig_states
+        out[pre + "umac"], out[pre + "vmac"] = cap["umac"], cap["vmac"]
+        out[pre + "U1"] = _planes(sim.cc_data)
+        print("viscous case", k, prob, d, "dt", sim.dt)
+    out["ncases"] = np.array(len(cases))
+    save("incomp_viscous", **out)
+
+    p = Pyro("incompressible_viscous")
+    p.initialize_problem("cavity", inputs_file="inputs.cavity")
+    ic = store["ic"]
+    while not p.sim.finished():
+        p.single_step()
+    names = ["x-velocity", "y-velocity"]
+    with h5py.File(REF + "/incompressible_viscous/tests/cavity_n64_Re400_0025.h5", "r") as f:
+        assert int(f.attrs["nsteps"]) == p.sim.n, (f.attrs["nsteps"], p.sim.n)
+        gold = np.array([f["state/" + nm + "/data"][...] for nm in names])
+        tfin = float(f.attrs["time"])
+    run = np.array([np.array(p.sim.cc_data.get_var(nm).v()) for nm in names])
+    print("cavity: reference-run vs stored golden, max abs err", np.abs(run - gold).max(axis=(1, 2)))
+    isim.Simulation.preevolve = orig_pre
+    save("incomp_cavity_0025", ic=ic[:2], gold=gold, run=run, nsteps=np.array(p.sim.n),
+         t=np.array(tfin), tmax=np.array(p.sim.tmax), bc=bc_names(p.rp),
+         meta=np.array([64, 4, 2, 2, p.rp.get_param("driver.cfl"),
+                        p.rp.get_param("driver.init_tstep_factor"),
+                        p.rp.get_param("driver.max_dt_change"),
+                        p.rp.get_param("incompressible_viscous.viscosity")]))
+
+
 def _raw_cfl_dt(sim):
     dt_keep, dto_keep = sim.dt, sim.dt_old
     sim.method_compute_timestep()
@@ -1143,6 +1222,8 @@ if __name__ == "__main__":
         gen_compressible_heating()
     if "problem_ics" in sys.argv[1:]:
         gen_problem_ics()
+    if "incomp_viscous" in sys.argv[1:]:
+        gen_incompressible_viscous()
     if "mg_vc" in sys.argv[1:]:
         gen_mg_vc()
     if "comp_f2" in sys.argv[1:]:

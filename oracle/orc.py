@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "_build", "liborc.so")
 
 BC_CODES = {"outflow": 0, "neumann": 0, "reflect-even": 1, "reflect-odd": 2,
-            "dirichlet": 2, "periodic": 3, "hse": 5, "ambient": 6, "ramp": 7}
+            "dirichlet": 2, "periodic": 3, "hse": 5, "ambient": 6, "ramp": 7, "moving_lid": 8}
 
 
 def build(force=False):
@@ -362,7 +362,7 @@ def incomp_step(D, nx, ng, dt, limiter=2, proj_type=2, bc_u=("periodic",) * 4,
     um = np.zeros(N) if stages else None
     vm = np.zeros(N) if stages else None
     adv = np.zeros((2,) + N) if stages else None
-    ncyc = (C.c_int * 2)()
+    ncyc = (C.c_int * 4)()
     bu, bv, bp = _bc4(bc_u), _bc4(bc_v), _bc4(bc_phi)
     ip = C.POINTER(C.c_int)
     lib().orc_incomp_step(_p(D), nx, ng, C.c_double(xmin), C.c_double(xmax), C.c_double(ymin),
@@ -370,10 +370,16 @@ def incomp_step(D, nx, ng, dt, limiter=2, proj_type=2, bc_u=("periodic",) * 4,
                           bu.ctypes.data_as(ip), bv.ctypes.data_as(ip), bp.ctypes.data_as(ip), 0,
                           None if um is None else _p(um), None if vm is None else _p(vm),
                           None if adv is None else _p(adv), ncyc)
-    out = {"ncyc": (ncyc[0], ncyc[1])}
+    out = {"ncyc": (ncyc[0], ncyc[1]), "ncyc_visc": (ncyc[2], ncyc[3])}
     if stages:
         out.update(umac=um, vmac=vm, adv=adv)
     return out
+
+
+def incomp_set_viscous(nu=None, lid_u=1.0, lid_v=0.0):
+    """nu = None: inviscid incompressible solver; else incompressible_viscous"""
+    lib().orc_incomp_set_viscous(int(nu is not None), C.c_double(0.0 if nu is None else nu),
+                                 C.c_double(lid_u), C.c_double(lid_v))
 
 
 def incomp_preevolve(D, nx, ng, cfl, limiter=2, proj_type=2, bc_u=("periodic",) * 4,

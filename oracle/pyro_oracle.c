@@ -47,6 +47,8 @@
 #define BC_HSE 5          /* compressible/BC.py "hse" (y sides only)   */
 #define BC_AMBIENT 6      /* compressible/BC.py "ambient" (yr only)    */
 #define BC_RAMP 7         /* compressible/BC.py "ramp" (xl, yl, yr)    */
+#define BC_CONST 8        /* ghost cells = a constant ("moving_lid" of  */
+                          /* incompressible_viscous/BC.py; 0 in the MG) */
 
 typedef struct {
     int nx, ny, ng;
@@ -1302,6 +1304,7 @@ static void mg_fill_bc(double *a, int n, double dx, const int *bc,
             break;
         case BC_REFLECT_EVEN: A(0, j) = A(lo, j); break;
         case BC_PERIODIC: A(0, j) = A(hi, j); break;
+        case BC_CONST: A(0, j) = 0.0; break;
         }
     }
     for (int j = 0; j < q; j++) {
@@ -1314,6 +1317,7 @@ static void mg_fill_bc(double *a, int n, double dx, const int *bc,
             break;
         case BC_REFLECT_EVEN: A(hi + 1, j) = A(hi, j); break;
         case BC_PERIODIC: A(hi + 1, j) = A(lo, j); break;
+        case BC_CONST: A(hi + 1, j) = 0.0; break;
         }
     }
     for (int i = 0; i < q; i++) {
@@ -1326,6 +1330,7 @@ static void mg_fill_bc(double *a, int n, double dx, const int *bc,
             break;
         case BC_REFLECT_EVEN: A(i, 0) = A(i, lo); break;
         case BC_PERIODIC: A(i, 0) = A(i, hi); break;
+        case BC_CONST: A(i, 0) = 0.0; break;
         }
     }
     for (int i = 0; i < q; i++) {
@@ -1338,6 +1343,7 @@ static void mg_fill_bc(double *a, int n, double dx, const int *bc,
             break;
         case BC_REFLECT_EVEN: A(i, hi + 1) = A(i, hi); break;
         case BC_PERIODIC: A(i, hi + 1) = A(i, lo); break;
+        case BC_CONST: A(i, hi + 1) = 0.0; break; /* BC.user on the MG variable "v" */
         }
     }
 #undef A
@@ -1786,9 +1792,21 @@ static inline double bg_upwind(double ql, double qr, double s)
 /* get_interface_states (:4-86) + apply_transverse_corrections (:89-175) +
    apply_gradp_corrections (incomp_interface.py:139-183; gpx == NULL: burgers).
    E: 8 planes, zeroed here.  */
+static void bg_edge_states_src(const double *u, const double *v, const double *gpx,
+                               const double *gpy, const double *sx, const double *sy, int nx,
+                               int ny, int ng, double dx, double dy, double dt, int limiter,
+                               double *E);
 void orc_bg_edge_states(const double *u, const double *v, const double *gpx,
                         const double *gpy, int nx, int ny, int ng, double dx,
                         double dy, double dt, int limiter, double *E)
+{
+    bg_edge_states_src(u, v, gpx, gpy, NULL, NULL, nx, ny, ng, dx, dy, dt, limiter, E);
+}
+/* sx, sy: other source terms (apply_other_source_terms, incomp_interface.py:186-254) */
+static void bg_edge_states_src(const double *u, const double *v, const double *gpx,
+                               const double *gpy, const double *sx, const double *sy, int nx,
+                               int ny, int ng, double dx, double dy, double dt, int limiter,
+                               double *E)
 {
     const int qx = nx + 2 * ng, qy = ny + 2 * ng;
     const int ilo = ng, ihi = ng + nx - 1, jlo = ng, jhi = ng + ny - 1;
@@ -1850,6 +1868,13 @@ void orc_bg_edge_states(const double *u, const double *v, const double *gpx,
                 vyl[I2(i, j + 1)] += gy;  vyr[k] += gy;
                 uyl[I2(i, j + 1)] += gx;  uyr[k] += gx;
             }
+            if (sx) {
+                const double ax = 0.5 * dt * sx[k], ay = 0.5 * dt * sy[k];
+                uxl[I2(i + 1, j)] += ax;  uxr[k] += ax;
+                uyl[I2(i, j + 1)] += ax;  uyr[k] += ax;
+                vxl[I2(i + 1, j)] += ay;  vxr[k] += ay;
+                vyl[I2(i, j + 1)] += ay;  vyr[k] += ay;
+            }
         }
     free(ldux); free(ldvx); free(lduy); free(ldvy);
     free(uhat); free(vhat); free(uxi); free(vxi); free(uyi); free(vyi);
@@ -1900,6 +1925,60 @@ void orc_bg_step(double *u, double *v, int nx, int ny, int ng, double dx,
 #undef I2
 }
 
+/* incompressible_viscous (pyro/incompressible_viscous/simulation.py:8-190):
+   viscosity nu >= 0 switches orc_incomp_step to the viscous update; lid_u /
+   lid_v: ghost values of u / v on sides with code BC_CONST ("moving_lid",
+   incompressible_viscous/BC.py:9-50) */
+static struct { int on; double nu, lid_u, lid_v; } g_visc = {0, 0.0, 1.0, 0.0};
+void orc_incomp_set_viscous(int on, double nu, double lid_u, double lid_v)
+{
+    g_visc.on = on; g_visc.nu = nu; g_visc.lid_u = lid_u; g_visc.lid_v = lid_v;
+}
+static void inc_fill(double *a, int nx, int ny, int ng, const int *bc, double cval)
+{
+    orc_fill_ghost(a, nx, ny, ng, 1, 0, bc);
+    if (bc[3] == BC_CONST) {
+        const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+        for (int i = 0; i < qx; i++)
+            for (int j = ng + ny; j < qy; j++) a[(size_t)i * qy + j] = cval;
+    }
+}
+/* Helmholtz solve of one velocity component, incompressible_viscous/
+   simulation.py:78-123: (1 - dt nu/2 L) w = w + dt nu/2 L w - dt (advect [+ gradp]) */
+static int visc_solve(double *w, const double *adv, const double *gp, int nx, int ng,
+                      double xmin, double xmax, double ymin, double ymax, double dt, double nu,
+                      int proj_type, const int *bc)
+{
+    const int ny = nx, qy = ny + 2 * ng, ilo = ng, jlo = ng;
+    const double dx = (xmax - xmin) / nx, dy = (ymax - ymin) / ny;
+#define I2(i, j) ((size_t)(i) * qy + (j))
+    orc_mg *m = orc_mg_create(nx, xmin, xmax, ymin, ymax, bc, 1.0, 0.5 * dt * nu, 10, 50);
+    const int L = m->nlevels - 1, n = nx;
+    for (int i = 0; i < nx; i++)
+        for (int j = 0; j < ny; j++) {
+            const int gi = ilo + i, gj = jlo + j;
+            const size_t k = I2(gi, gj);
+            double f = w[k] + 0.5 * dt * nu *
+                                  ((w[I2(gi + 1, gj)] + w[I2(gi - 1, gj)] - 2.0 * w[k]) / (dx * dx) +
+                                   (w[I2(gi, gj + 1)] + w[I2(gi, gj - 1)] - 2.0 * w[k]) / (dy * dy));
+            if (proj_type == 1) f -= dt * (adv[k] + gp[k]);
+            else f -= dt * adv[k];
+            m->f[L][(size_t)(i + 1) * (n + 2) + j + 1] = f;
+        }
+    orc_mg_init_rhs_norm(m);
+    for (int i = -1; i <= nx; i++)
+        for (int j = -1; j <= ny; j++)
+            m->v[L][(size_t)(i + 1) * (n + 2) + j + 1] = w[I2(ilo + i, jlo + j)];
+    orc_mg_solve(m, 1.e-12);
+    const int nc = m->num_cycles;
+    for (int i = 0; i < nx; i++)
+        for (int j = 0; j < ny; j++)
+            w[I2(ilo + i, jlo + j)] = m->v[L][(size_t)(i + 1) * (n + 2) + j + 1];
+    orc_mg_free(m);
+#undef I2
+    return nc;
+}
+
 /* copy (qx,qy) interior [+buf] <-> MG level array (n+2)^2 */
 static inline size_t mgk(int n, int i, int j) { return (size_t)i * (n + 2) + j; }
 
@@ -1925,7 +2004,20 @@ void orc_incomp_step(double *D, int nx, int ng, double xmin, double xmax,
            *gpy = D + 5 * N;
 #define I2(i, j) ((size_t)(i) * qy + (j))
     double *E = zalloc(8 * N);
-    orc_bg_edge_states(u, v, gpx, gpy, nx, ny, ng, dx, dy, dt, limiter, E);
+    double *srcx = NULL, *srcy = NULL;
+    if (g_visc.on) {   /* other_source_term, incompressible_viscous/simulation.py:24-41 */
+        srcx = zalloc(N); srcy = zalloc(N);
+        for (int i = ilo; i <= ihi; i++)
+            for (int j = jlo; j <= jhi; j++) {
+                const size_t k = I2(i, j);
+                srcx[k] = g_visc.nu * ((u[I2(i + 1, j)] + u[I2(i - 1, j)] - 2.0 * u[k]) / (dx * dx) +
+                                       (u[I2(i, j + 1)] + u[I2(i, j - 1)] - 2.0 * u[k]) / (dy * dy));
+                srcy[k] = g_visc.nu * ((v[I2(i + 1, j)] + v[I2(i - 1, j)] - 2.0 * v[k]) / (dx * dx) +
+                                       (v[I2(i, j + 1)] + v[I2(i, j - 1)] - 2.0 * v[k]) / (dy * dy));
+            }
+    }
+    bg_edge_states_src(u, v, gpx, gpy, srcx, srcy, nx, ny, ng, dx, dy, dt, limiter, E);
+    free(srcx); free(srcy);
     /* mac_vels: riemann_and_upwind on B2 (incomp_interface.py:62-63) */
     double *um = zalloc(N), *vm = zalloc(N);
     for (int i = ilo - 2; i <= ihi + 2; i++)
@@ -1981,6 +2073,13 @@ void orc_incomp_step(double *D, int nx, int ng, double xmin, double xmax,
         free(uxi); free(vxi); free(uyi); free(vyi);
     }
     if (o_adv) { memcpy(o_adv, ax, N * 8); memcpy(o_adv + N, ay, N * 8); }
+    if (g_visc.on) {   /* do_other_update_velocity: two parabolic solves */
+        const int nu_c = visc_solve(u, ax, gpx, nx, ng, xmin, xmax, ymin, ymax, dt, g_visc.nu,
+                                    proj_type, bc_u);
+        const int nv_c = visc_solve(v, ay, gpy, nx, ng, xmin, xmax, ymin, ymax, dt, g_visc.nu,
+                                    proj_type, bc_v);
+        if (ncyc) { ncyc[2] = nu_c; ncyc[3] = nv_c; }
+    } else
     for (size_t k = 0; k < N; k++) {
         if (proj_type == 1) {
             u[k] -= (dt * ax[k] + dt * gpx[k]);
@@ -1990,8 +2089,8 @@ void orc_incomp_step(double *D, int nx, int ng, double xmin, double xmax,
             v[k] -= dt * ay[k];
         }
     }
-    orc_fill_ghost(u, nx, ny, ng, 1, 0, bc_u);
-    orc_fill_ghost(v, nx, ny, ng, 1, 0, bc_v);
+    inc_fill(u, nx, ny, ng, bc_u, g_visc.lid_u);
+    inc_fill(v, nx, ny, ng, bc_v, g_visc.lid_v);
     /* final projection (:306-330) */
     for (int l = 0; l <= L; l++) {
         size_t Nl = (size_t)(m->n[l] + 2) * (m->n[l] + 2);
@@ -2025,8 +2124,8 @@ void orc_incomp_step(double *D, int nx, int ng, double xmin, double xmax,
             if (proj_type == 1) { gpx[k] += gx; gpy[k] += gy; }
             else { gpx[k] = gx; gpy[k] = gy; }
         }
-    orc_fill_ghost(u, nx, ny, ng, 1, 0, bc_u);
-    orc_fill_ghost(v, nx, ny, ng, 1, 0, bc_v);
+    inc_fill(u, nx, ny, ng, bc_u, g_visc.lid_u);
+    inc_fill(v, nx, ny, ng, bc_v, g_visc.lid_v);
     orc_mg_free(m);
     free(E); free(um); free(vm); free(ax); free(ay);
 #undef I2
@@ -2047,8 +2146,8 @@ double orc_incomp_preevolve(double *D, int nx, int ng, double xmin, double xmax,
     const double dx = (xmax - xmin) / nx, dy = (ymax - ymin) / ny;
     double *u = D, *v = D + N, *phi = D + 3 * N;
 #define I2(i, j) ((size_t)(i) * qy + (j))
-    orc_fill_ghost(u, nx, ny, ng, 1, 0, bc_u);
-    orc_fill_ghost(v, nx, ny, ng, 1, 0, bc_v);
+    inc_fill(u, nx, ny, ng, bc_u, g_visc.lid_u);
+    inc_fill(v, nx, ny, ng, bc_v, g_visc.lid_v);
     const int per[4] = {BC_PERIODIC, BC_PERIODIC, BC_PERIODIC, BC_PERIODIC}; /* :90-97 */
     orc_mg *m = orc_mg_create(nx, xmin, xmax, ymin, ymax, per, 0.0, -1.0, 10, 50);
     const int L = m->nlevels - 1, n = nx;
@@ -2071,8 +2170,8 @@ double orc_incomp_preevolve(double *D, int nx, int ng, double xmin, double xmax,
             v[k] -= 0.5 * (m->v[L][mgk(n, i + 1, j + 2)] - m->v[L][mgk(n, i + 1, j)]) / dy;
         }
     orc_mg_free(m);
-    orc_fill_ghost(u, nx, ny, ng, 1, 0, bc_u);
-    orc_fill_ghost(v, nx, ny, ng, 1, 0, bc_v);
+    inc_fill(u, nx, ny, ng, bc_u, g_visc.lid_u);
+    inc_fill(v, nx, ny, ng, bc_v, g_visc.lid_v);
     double *T = (double *)malloc(6 * N * 8);
     memcpy(T, D, 6 * N * 8);
     const double dt = orc_bg_dt(T, T + N, nx, ny, ng, dx, dy, cfl);

@@ -688,3 +688,82 @@ def test_oracle_problem_sources(golden, k):
                                 ambient=tuple(g[pre + "ambient"]), **over)
     assert np.array_equal(dts, g[pre + "dts"])
     assert np.array_equal(U[I], g[pre + "final"][I])
+
+
+# ---------------------------------------------------------------------------
+# row f4: incompressible_viscous (lid-driven cavity)
+# ---------------------------------------------------------------------------
+def visc_bcs(names):
+    """(bc_u, bc_v, bc_phi) names for the mesh boundary names of a viscous run
+    (incompressible/simulation.py:33-48)"""
+    names = [str(b) for b in names]
+    phi = names if names[0] == "periodic" else ["neumann"] * 4
+    return dict(bc_u=names, bc_v=names, bc_phi=phi)
+
+
+def oracle_visc_run(ic2, meta, bcnames, nsteps=None, tmax=1.e30):
+    from helpers import DtPolicy
+    nx, ng, lim, proj, cfl, f0, mx, nu = meta
+    nx, ng, lim, proj = int(nx), int(ng), int(lim), int(proj)
+    bcs = visc_bcs(bcnames)
+    q = nx + 2 * ng
+    D = np.zeros((6, q, q))
+    D[:2] = ic2
+    orc.incomp_set_viscous(nu)
+    try:
+        orc.incomp_preevolve(D, nx, ng, cfl, lim, proj, **bcs)
+        after_pre = D.copy()
+        pol = DtPolicy(tmax, f0, mx)
+        dts = []
+        while pol.t < tmax and (nsteps is None or pol.n < nsteps):
+            for n in range(6):
+                codes = orc.bc_codes(bcs["bc_u"] if n < 2 else bcs["bc_phi"])
+                orc.fill_ghost(D[n], nx, nx, ng, codes)
+                if n < 2 and codes[3] == 8:
+                    D[n][:, ng + nx:] = 1.0 if n == 0 else 0.0     # moving lid
+            dt = pol(orc.bg_dt(D[0], D[1], nx, nx, ng, 1.0 / nx, 1.0 / nx, cfl))
+            orc.incomp_step(D, nx, ng, dt, lim, proj, **bcs)
+            pol.advance(dt)
+            dts.append(dt)
+    finally:
+        orc.incomp_set_viscous(None)
+    return D, after_pre, np.array(dts), pol
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_oracle_incompressible_viscous(golden, k):
+    g = golden("incomp_viscous")
+    pre = f"i{k}_"
+    meta = g[pre + "meta"]
+    nx, ng = int(meta[0]), int(meta[1])
+    D, after_pre, dts, _ = oracle_visc_run(g[pre + "ic"][:2], meta, g[pre + "bc"],
+                                           nsteps=len(g[pre + "dts"]))
+    assert np.abs(after_pre - g[pre + "after_pre"]).max() < 1e-13
+    assert np.abs(dts / g[pre + "dts"] - 1).max() < 1e-12
+    I = (slice(None), slice(ng, -ng), slice(ng, -ng))
+    assert np.abs(D[I] - g[pre + "final"][I]).max() < 1e-11
+    # one step from the reference's state with its dt: bit-identical pieces
+    D = np.ascontiguousarray(g[pre + "U0"])
+    orc.incomp_set_viscous(meta[7])
+    try:
+        st = orc.incomp_step(D, nx, ng, float(g[pre + "dt"]), int(meta[2]), int(meta[3]),
+                             stages=True, **visc_bcs(g[pre + "bc"]))
+    finally:
+        orc.incomp_set_viscous(None)
+    F = (slice(ng, ng + nx + 1), slice(ng, ng + nx))
+    assert np.abs(st["umac"][F] - g[pre + "umac"][F]).max() < 1e-12
+    assert np.abs(D[I] - g[pre + "U1"][I]).max() < 1e-11
+
+
+def test_incompressible_viscous_reference_regression_cavity(golden):
+    """pyro/test.py:111: incompressible_viscous cavity inputs.cavity vs
+    cavity_n64_Re400_0025.h5 (64^2, Re 400, 25 steps, 4 MG solves per step)"""
+    g = golden("incomp_cavity_0025")
+    D, _, dts, pol = oracle_visc_run(g["ic"], g["meta"], g["bc"], nsteps=25,
+                                     tmax=float(g["tmax"]))
+    assert pol.n == int(g["nsteps"]) == 25 and abs(pol.t - float(g["t"])) < 1e-13
+    ng = int(g["meta"][1])
+    I = (slice(ng, -ng), slice(ng, -ng))
+    assert np.abs(D[0][I] - g["gold"][0]).max() < 1e-10
+    assert np.abs(D[1][I] - g["gold"][1]).max() < 1e-10
+    assert np.abs(D[0][I] - g["run"][0]).max() < 1e-11
