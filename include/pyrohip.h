@@ -43,8 +43,11 @@ enum {
                                  /* pyrohip_halo_exchange, not by fill_bc     */
     PYROHIP_BC_HSE = 5,          /* compressible "hse" user boundary, y sides */
     PYROHIP_BC_AMBIENT = 6,      /* compressible "ambient" user boundary, yr  */
-    PYROHIP_BC_RAMP = 7          /* compressible "ramp" (double Mach           */
+    PYROHIP_BC_RAMP = 7,         /* compressible "ramp" (double Mach           */
                                  /* reflection) user boundary: xl, yl, yr     */
+    PYROHIP_BC_CONST = 8         /* ghost cells = a constant: "moving_lid" of */
+                                 /* incompressible_viscous/BC.py:9-50 (yr);   */
+                                 /* in a pyrohip_mg the constant is 0         */
 };
 
 /* own status codes (hipError_t values are passed through unchanged) */
@@ -112,6 +115,9 @@ int pyrohip_state_set_user_bc(pyrohip_state *s, double gamma, double grav,
    The ghost cells of the device copy are refilled like the reference's E_src
    (the boundary types of the energy, plain copies for hse / ambient).        */
 int pyrohip_state_set_heating(pyrohip_state *s, const double *profile);
+/* ghost value of variable n on its PYROHIP_BC_CONST side (upper y side only:
+   "moving_lid", incompressible_viscous/BC.py:31-42; default 0)             */
+int pyrohip_state_set_const_bc(pyrohip_state *s, int n, double value);
 /* Parameters of the "ramp" boundary of the double Mach reflection problem
    (compressible/BC.py:178-296).  x: the qx cell-centre coordinates of the grid
    (copied); cxoff = 0.5 dx sqrt(3); post / pre: post- and pre-shock values of
@@ -193,12 +199,18 @@ int pyrohip_comp_stage_dump(pyrohip_state *s, int stage_id, double *out);
 
 /* ---- multigrid: MG.CellCenterMG2d (multigrid/MG.py:85-778) ------------- */
 /* bc: xl,xr,yl,yr with PYROHIP_BC_REFLECT_ODD = dirichlet,
-   PYROHIP_BC_OUTFLOW = neumann, PYROHIP_BC_PERIODIC                        */
+   PYROHIP_BC_OUTFLOW = neumann, PYROHIP_BC_PERIODIC; PYROHIP_BC_CONST: ghost
+   cells = 0 (what incompressible_viscous/BC.py:39-42 does to the variable "v"
+   of the velocity solves)                                                   */
 int pyrohip_mg_create(pyrohip_ctx *ctx, int nx, double xmin, double xmax,
                       double ymin, double ymax, const int *bc, double alpha,
                       double beta, int nsmooth, int nsmooth_bottom,
                       pyrohip_mg **out);
 int pyrohip_mg_destroy(pyrohip_mg *m);
+/* new alpha, beta of (alpha - beta L) phi = f for an existing solver: the
+   reference builds a new MG object for every solve with beta = dt nu / 2
+   (incompressible_viscous/simulation.py:103-111); the levels are reused here */
+int pyrohip_mg_set_helmholtz(pyrohip_mg *m, double alpha, double beta);
 int pyrohip_mg_nlevels(pyrohip_mg *m, int *nlevels);
 /* smoother implementation: 1 (default) = LDS tile kernel running up to 5
    red-black iterations per launch; 0 = one launch per colour.  Results are
@@ -287,12 +299,16 @@ int pyrohip_bg_step(pyrohip_state *s, int iu, int iv, double dx, double dy,
    330), the four device pieces around the two MG solves.  mg: a
    pyrohip_mg with the state's nx (= ny) and the BCs of phi.
    1. mac_rhs: edge states (incomp_interface.mac_vels :4-63), MAC velocities,
-      mg.f = div(U_MAC), mg.v = 0 (init_zeros), source norm (init_RHS)      */
+      mg.f = div(U_MAC), mg.v = 0 (init_zeros), source norm (init_RHS).
+      nu > 0: the viscous source nu L(U) of incompressible_viscous
+      (simulation.py:24-41, incomp_interface.py:186-254) enters the edge
+      states                                                                */
 int pyrohip_inc_mac_rhs(pyrohip_state *s, pyrohip_mg *mg, int iu, int iv,
                         int igpx, int igpy, double dx, double dy, double dt,
-                        int limiter, double *source_norm);
+                        int limiter, double nu, double *source_norm);
 /* 2. after mg solve: phi-MAC <- solution (buf 1), MAC correction, states()
-      (:66-136), advective terms and provisional velocity update (:286-304) */
+      (:66-136), advective terms and provisional velocity update (:286-304);
+      proj_type 0: advective terms only (the viscous update follows)        */
 int pyrohip_inc_advect(pyrohip_state *s, pyrohip_mg *mg, int iu, int iv,
                        int iphimac, int igpx, int igpy, double dx, double dy,
                        double dt, int proj_type);
@@ -306,6 +322,16 @@ int pyrohip_inc_proj_rhs(pyrohip_state *s, pyrohip_mg *mg, int iu, int iv,
 int pyrohip_inc_proj_update(pyrohip_state *s, pyrohip_mg *mg, int iu, int iv,
                             int iphi, int igpx, int igpy, double dx, double dy,
                             double fac, int gp_mode);
+/* incompressible_viscous do_other_update_velocity (pyro/incompressible_viscous/
+   simulation.py:43-176), one velocity component w = variable iw (comp 0: u,
+   1: v) per call.  visc_rhs: mg.f = w + dt nu / 2 L(w) - dt (advect [+ grad p,
+   proj_type 1]), mg.v = w on buf 1 (the guess); mg must have the BCs of w and
+   alpha = 1, beta = dt nu / 2 (pyrohip_mg_set_helmholtz).  visc_store after the
+   solve: interior of w <- solution                                          */
+int pyrohip_inc_visc_rhs(pyrohip_state *s, pyrohip_mg *mg, int iw, int comp,
+                         int igp, double dx, double dy, double dt, double nu,
+                         int proj_type, double *source_norm);
+int pyrohip_inc_visc_store(pyrohip_state *s, pyrohip_mg *mg, int iw);
 /* test hook: which 0-7 edge states u_xl u_xr u_yl u_yr v_xl v_xr v_yl v_yr,
    8 u_MAC, 9 v_MAC, 10 advect_x, 11 advect_y -> host (qx, qy)              */
 int pyrohip_inc_stage_dump(pyrohip_state *s, int which, double *host);

@@ -14,11 +14,13 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "lib", "libpyrohip.so")
 
-BC_OUTFLOW, BC_REFLECT_EVEN, BC_REFLECT_ODD, BC_PERIODIC, BC_HALO, BC_HSE, BC_AMBIENT, BC_RAMP = range(8)
+BC_OUTFLOW, BC_REFLECT_EVEN, BC_REFLECT_ODD, BC_PERIODIC, BC_HALO, BC_HSE, BC_AMBIENT, BC_RAMP, \
+    BC_CONST = range(9)
 BC_CODE = {"outflow": BC_OUTFLOW, "neumann": BC_OUTFLOW,
            "reflect-even": BC_REFLECT_EVEN, "reflect-odd": BC_REFLECT_ODD,
            "dirichlet": BC_REFLECT_ODD, "periodic": BC_PERIODIC,
-           "halo": BC_HALO, "hse": BC_HSE, "ambient": BC_AMBIENT, "ramp": BC_RAMP}
+           "halo": BC_HALO, "hse": BC_HSE, "ambient": BC_AMBIENT, "ramp": BC_RAMP,
+           "moving_lid": BC_CONST}
 
 ERR_STATE = 10002
 UNIQUE_ID_BYTES = 128
@@ -80,7 +82,12 @@ _PROTOS = {
     "pyrohip_swe_stage_dump": [_VP, C.c_int, _DP],
     "pyrohip_bg_step": [_VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int],
     "pyrohip_inc_mac_rhs": [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
-                            C.c_double, C.c_double, C.c_int, _DP],
+                            C.c_double, C.c_double, C.c_int, C.c_double, _DP],
+    "pyrohip_inc_visc_rhs": [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                             C.c_double, C.c_double, C.c_int, _DP],
+    "pyrohip_inc_visc_store": [_VP, _VP, C.c_int],
+    "pyrohip_state_set_const_bc": [_VP, C.c_int, C.c_double],
+    "pyrohip_mg_set_helmholtz": [_VP, C.c_double, C.c_double],
     "pyrohip_inc_advect": [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                            C.c_double, C.c_double, C.c_int],
     "pyrohip_inc_proj_rhs": [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,

@@ -147,6 +147,7 @@ struct pyrohip_state {
     double *work = nullptr;
     size_t work_planes = 0;
     int *d_flag = nullptr;    // positivity flag
+    double *d_cval = nullptr; // per-variable ghost value of PYROHIP_BC_CONST sides
     double next_cfl_min = -1.0;  // min over interior of dx/(|u|+c) etc. of the
                                  // state after the last step (-1: unknown)
     bool cfl_is_global = false;  // ... already reduced over all ranks

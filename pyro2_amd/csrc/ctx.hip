@@ -93,7 +93,8 @@ __global__ void k_fill_x(double *__restrict__ d, Geom g, const int *__restrict__
 
 // threads: x = ghost index k in [0, 2*ng) (contiguous in memory per side),
 //          y = row i
-__global__ void k_fill_y(double *__restrict__ d, Geom g, const int *__restrict__ bc, int n0)
+__global__ void k_fill_y(double *__restrict__ d, Geom g, const int *__restrict__ bc, int n0,
+                         const double *__restrict__ cval)
 {
     int k = threadIdx.x;
     int i = blockIdx.x * blockDim.y + threadIdx.y;
@@ -123,6 +124,7 @@ __global__ void k_fill_y(double *__restrict__ d, Geom g, const int *__restrict__
         case PYROHIP_BC_REFLECT_EVEN: v = a[jhi - kk]; break;
         case PYROHIP_BC_REFLECT_ODD: v = -a[jhi - kk]; break;
         case PYROHIP_BC_PERIODIC: v = a[j - jhi - 1 + ng]; break;
+        case PYROHIP_BC_CONST: v = cval[n]; break;   // incompressible_viscous/BC.py:31-42
         default: return;
         }
         a[j] = v;
@@ -411,7 +413,10 @@ int pyrohip_state_create(pyrohip_ctx *c, int nx, int ny, int ng, int nvar, const
     PYRO_REQUIRE(nx > 0 && ny > 0 && ng >= 1 && ng <= 8 && nvar >= 1, "bad dimensions");
     PYRO_REQUIRE(nx >= ng && ny >= ng, "grid smaller than the ghost width");
     for (int k = 0; k < nvar * 4; k++)
-        PYRO_REQUIRE(bc[k] >= 0 && bc[k] <= PYROHIP_BC_RAMP, "bad BC code");
+        PYRO_REQUIRE(bc[k] >= 0 && bc[k] <= PYROHIP_BC_CONST, "bad BC code");
+    for (int k = 0; k < nvar * 4; k++)   // incompressible_viscous/BC.py:44-45
+        PYRO_REQUIRE(bc[k] != PYROHIP_BC_CONST || (k & 3) == 3,
+                     "the constant-value boundary is only defined on the upper y side");
     bool user_bc = false, ramp_bc = false;
     for (int k = 0; k < nvar * 4; k++) {
         if (bc[k] != PYROHIP_BC_RAMP) continue;
@@ -442,6 +447,8 @@ int pyrohip_state_create(pyrohip_ctx *c, int nx, int ny, int ng, int nvar, const
     s->d = s->base + geom_lead(s->g);
     PYRO_CHECK_HIP(hipMalloc((void **)&s->d_bc, sizeof(int) * nvar * 4));
     PYRO_CHECK_HIP(hipMemcpy(s->d_bc, bc, sizeof(int) * nvar * 4, hipMemcpyHostToDevice));
+    PYRO_CHECK_HIP(hipMalloc((void **)&s->d_cval, sizeof(double) * nvar));
+    PYRO_CHECK_HIP(hipMemsetAsync(s->d_cval, 0, sizeof(double) * nvar, c->stream));
     PYRO_CHECK_HIP(hipMalloc((void **)&s->d_flag, sizeof(int) * 4));
     PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int) * 4, c->stream));
     *out = s;
@@ -459,6 +466,7 @@ int pyrohip_state_destroy(pyrohip_state *s)
     if (s->d_x) (void)hipFree(s->d_x);
     if (s->heat_base) (void)hipFree(s->heat_base);
     if (s->d_flag) (void)hipFree(s->d_flag);
+    if (s->d_cval) (void)hipFree(s->d_cval);
     if (s->work) (void)hipFree(s->work);
     delete s;
     return 0;
@@ -605,7 +613,7 @@ int pyrohip_state_set_heating(pyrohip_state *s, const double *profile)
     hipLaunchKernelGGL(k_fill_x, dim3((g.qy + 255) / 256, 1, 1), dim3(256), 0, c->stream, s->heat, g,
                        (const int *)(s->d_bc + 4), 0);
     hipLaunchKernelGGL(k_fill_y, dim3((g.qx + 15) / 16, 1, 1), dim3(16, 16), 0, c->stream, s->heat,
-                       g, (const int *)(s->d_bc + 4), 0);
+                       g, (const int *)(s->d_bc + 4), 0, (const double *)nullptr);
     PYRO_CHECK_HIP(hipGetLastError());
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));   // profile is borrowed for the call only
     return 0;
@@ -655,7 +663,8 @@ static int fill_bc_range(pyrohip_state *s, int n0, int cnt)
     {
         dim3 block(16, 16);
         dim3 grid((g.qx + 15) / 16, 1, cnt);
-        hipLaunchKernelGGL(k_fill_y, grid, block, 0, c->stream, s->d, g, (const int *)s->d_bc, n0);
+        hipLaunchKernelGGL(k_fill_y, grid, block, 0, c->stream, s->d, g, (const int *)s->d_bc, n0,
+                           (const double *)s->d_cval);
     }
     if (s->ramp_bc)
         for (int n = n0; n < n0 + cnt; n++) launch_ramp(s, n, 1);
@@ -710,9 +719,21 @@ int pyrohip_fill_bc(pyrohip_state *s, int n)
     {
         dim3 block(16, 16);
         dim3 grid((g.qx + 15) / 16, 1, cnt);
-        hipLaunchKernelGGL(k_fill_y, grid, block, 0, c->stream, s->d, g, (const int *)s->d_bc, n0);
+        hipLaunchKernelGGL(k_fill_y, grid, block, 0, c->stream, s->d, g, (const int *)s->d_bc, n0,
+                           (const double *)s->d_cval);
     }
     PYRO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int pyrohip_state_set_const_bc(pyrohip_state *s, int n, double value)
+{
+    PYRO_REQUIRE(s, "NULL state");
+    PYRO_REQUIRE(n >= 0 && n < s->nvar, "variable index out of range");
+    PYRO_CHECK_HIP(hipSetDevice(s->ctx->device));
+    PYRO_CHECK_HIP(hipMemcpyAsync(s->d_cval + n, &value, sizeof(double), hipMemcpyHostToDevice,
+                                  s->ctx->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(s->ctx->stream));   // value is a stack temporary
     return 0;
 }
 

@@ -47,6 +47,7 @@ __device__ __forceinline__ double bg_upwind(double ql, double qr, double s)
 struct BP {   // kernel parameters
     double dx, dy, dt, dtdx, dtdy;
     int limiter;
+    double nu;   // > 0: viscous source in the predictor (incompressible_viscous)
 };
 
 // one thread per cell of B1
@@ -83,7 +84,12 @@ __global__ __launch_bounds__(256) void k_bg_hat(const double *__restrict__ u,
 // apply_gradp_corrections (incomp_interface.py:139-183) for the states that
 // belong to cell (i, j): x states for j interior, y states for i interior
 // (the others would need hat states outside B1 and are never used).
-__global__ __launch_bounds__(256) void k_bg_trans(const double *__restrict__ gpx,
+// With P.nu > 0 the other source terms follow (apply_other_source_terms,
+// incomp_interface.py:186-254): + dt/2 nu L(u) with the source evaluated on
+// the interior only (incompressible_viscous/simulation.py:24-41).
+__global__ __launch_bounds__(256) void k_bg_trans(const double *__restrict__ u,
+                                                  const double *__restrict__ v,
+                                                  const double *__restrict__ gpx,
                                                   const double *__restrict__ gpy,
                                                   double *__restrict__ W, Geom g, BP P)
 {
@@ -94,6 +100,17 @@ __global__ __launch_bounds__(256) void k_bg_trans(const double *__restrict__ gpx
     const bool jin = (j >= g.jlo && j <= g.jhi), iin = (i >= g.ilo && i <= g.ihi);
     double gx = 0.0, gy = 0.0;
     if (gpx) { gx = -0.5 * P.dt * gpx[k]; gy = -0.5 * P.dt * gpy[k]; }
+    const bool src = (P.nu > 0.0) && jin && iin;
+    double sx = 0.0, sy = 0.0;
+    if (src) {
+        const double dx2 = P.dx * P.dx, dy2 = P.dy * P.dy;
+        const double lu = P.nu * ((u[k + p] + u[k - p] - 2.0 * u[k]) / dx2 +
+                                  (u[k + 1] + u[k - 1] - 2.0 * u[k]) / dy2);
+        const double lv = P.nu * ((v[k + p] + v[k - p] - 2.0 * v[k]) / dx2 +
+                                  (v[k + 1] + v[k - 1] - 2.0 * v[k]) / dy2);
+        sx = 0.5 * P.dt * lu;
+        sy = 0.5 * P.dt * lv;
+    }
     if (jin) {   // x states: transverse (y) derivative over the cell
         const double vh0 = bg_riemann(vyl[k], vyr[k]), vh1 = bg_riemann(vyl[k + 1], vyr[k + 1]);
         const double vbar = 0.5 * (vh0 + vh1);
@@ -103,6 +120,7 @@ __global__ __launch_bounds__(256) void k_bg_trans(const double *__restrict__ gpx
         const double tv = -0.5 * P.dtdy * vbar * (vy1 - vy0);
         double a = uxl[k + p] + tu, b = uxr[k] + tu, c = vxl[k + p] + tv, d = vxr[k] + tv;
         if (gpx) { a += gx; b += gx; c += gy; d += gy; }
+        if (src) { a += sx; b += sx; c += sy; d += sy; }
         W[C_UXL * pl + k + p] = a; W[C_UXR * pl + k] = b;
         W[C_VXL * pl + k + p] = c; W[C_VXR * pl + k] = d;
     }
@@ -115,6 +133,7 @@ __global__ __launch_bounds__(256) void k_bg_trans(const double *__restrict__ gpx
         const double su = -0.5 * P.dtdx * ubar * (ux1 - ux0);
         double a = vyl[k + 1] + sv, b = vyr[k] + sv, c = uyl[k + 1] + su, d = uyr[k] + su;
         if (gpx) { a += gy; b += gy; c += gx; d += gx; }
+        if (src) { a += sy; b += sy; c += sx; d += sx; }
         W[C_VYL * pl + k + 1] = a; W[C_VYR * pl + k] = b;
         W[C_UYL * pl + k + 1] = c; W[C_UYR * pl + k] = d;
     }
@@ -231,6 +250,7 @@ __global__ __launch_bounds__(256) void k_inc_advect(double *__restrict__ u, doub
                       vbar * (ys(C_VYL, C_VYR, k + 1) - ys(C_VYL, C_VYR, k)) / P.dy;
     W[W_ADVX * pl + k] = ax;
     W[W_ADVY * pl + k] = ay;
+    if (proj_type == 0) return;   // viscous: the parabolic solves do the update
     if (proj_type == 1) {
         u[k] -= (P.dt * ax + P.dt * gpx[k]);
         v[k] -= (P.dt * ay + P.dt * gpy[k]);
@@ -258,6 +278,42 @@ __global__ __launch_bounds__(256) void k_inc_div_cc(const double *__restrict__ u
         if (divide_by_dt) d = d / P.dt;
         f[mk] = d;
     }
+}
+
+// incompressible_viscous/simulation.py:113-135 (and :152-170 for v): RHS and
+// guess of the Helmholtz solve of one velocity component w
+__global__ __launch_bounds__(256) void k_inc_visc_rhs(const double *__restrict__ w,
+                                                      const double *__restrict__ adv,
+                                                      const double *__restrict__ gp, Geom g,
+                                                      double *__restrict__ f,
+                                                      double *__restrict__ mv, int mpitch, BP P,
+                                                      int proj_type)
+{
+    const int jj = blockIdx.x * blockDim.x + threadIdx.x, ii = blockIdx.y;   // MG indices
+    if (jj > g.ny + 1) return;
+    const size_t mk = (size_t)ii * mpitch + jj;
+    const int p = g.pitch;
+    const size_t k = (size_t)(g.ilo + ii - 1) * p + g.jlo + jj - 1;
+    const double wc = w[k];
+    mv[mk] = wc;
+    if (ii >= 1 && ii <= g.nx && jj >= 1 && jj <= g.ny) {
+        double r = wc + 0.5 * P.dt * P.nu *
+                            ((w[k + p] + w[k - p] - 2.0 * wc) / (P.dx * P.dx) +
+                             (w[k + 1] + w[k - 1] - 2.0 * wc) / (P.dy * P.dy));
+        if (proj_type == 1) r -= P.dt * (adv[k] + gp[k]);
+        else r -= P.dt * adv[k];
+        f[mk] = r;
+    }
+}
+
+// u.v()[:, :] = mg.get_solution().v()  (:141, :176)
+__global__ __launch_bounds__(256) void k_inc_visc_store(double *__restrict__ w,
+                                                        const double *__restrict__ mv, int mpitch,
+                                                        Geom g)
+{
+    const int jj = blockIdx.x * blockDim.x + threadIdx.x, ii = blockIdx.y;
+    if (jj >= g.ny) return;
+    w[(size_t)(g.ilo + ii) * g.pitch + g.jlo + jj] = mv[(size_t)(ii + 1) * mpitch + jj + 1];
 }
 
 // solution gradient (MG.py:439-469) and the velocity / grad p update
@@ -300,10 +356,11 @@ static int bg_work(pyrohip_state *s)
     return 0;
 }
 
-static BP make_bp(double dx, double dy, double dt, int limiter)
+static BP make_bp(double dx, double dy, double dt, int limiter, double nu = 0.0)
 {
     BP P;
     P.dx = dx; P.dy = dy; P.dt = dt; P.dtdx = dt / dx; P.dtdy = dt / dy; P.limiter = limiter;
+    P.nu = nu;
     return P;
 }
 
@@ -321,7 +378,7 @@ static int bg_predict(pyrohip_state *s, int iu, int iv, int igpx, int igpy, cons
     const dim3 block(256);
     const dim3 gridB1((g.ny + 2 + 255) / 256, g.nx + 2), gridF((g.ny + 1 + 255) / 256, g.nx + 1);
     PYRO_LAUNCH(c, "k_bg_hat", k_bg_hat, gridB1, block, 0, u, v, W, g, P);
-    PYRO_LAUNCH(c, "k_bg_trans", k_bg_trans, gridB1, block, 0, gpx, gpy, W, g, P);
+    PYRO_LAUNCH(c, "k_bg_trans", k_bg_trans, gridB1, block, 0, u, v, gpx, gpy, W, g, P);
     PYRO_LAUNCH(c, "k_bg_mac", k_bg_mac, gridF, block, 0, W, g);
     PYRO_CHECK_HIP(hipGetLastError());
     return 0;
@@ -361,11 +418,13 @@ int pyrohip_bg_step(pyrohip_state *s, int iu, int iv, double dx, double dy, doub
 }
 
 int pyrohip_inc_mac_rhs(pyrohip_state *s, pyrohip_mg *m, int iu, int iv, int igpx, int igpy,
-                        double dx, double dy, double dt, int limiter, double *source_norm)
+                        double dx, double dy, double dt, int limiter, double nu,
+                        double *source_norm)
 {
     INC_CHECK_MG(s, m, F);
     BG_CHECK_VARS(s, iu, iv, igpx, igpy);
-    const BP P = make_bp(dx, dy, dt, limiter);
+    PYRO_REQUIRE(nu >= 0.0, "negative viscosity");
+    const BP P = make_bp(dx, dy, dt, limiter, nu);
     PYRO_TRY(bg_predict(s, iu, iv, igpx, igpy, P));
     const Geom &g = s->g;
     PYRO_TRY(pyrohip_mg_zero(m, F.level, 0));   // init_zeros
@@ -439,6 +498,40 @@ int pyrohip_inc_proj_update(pyrohip_state *s, pyrohip_mg *m, int iu, int iv, int
                 gp_mode ? s->d + (size_t)igpx * g.plane : nullptr,
                 gp_mode ? s->d + (size_t)igpy * g.plane : nullptr, (const double *)F.v, F.pitch, g,
                 P, fac, gp_mode);
+    PYRO_CHECK_HIP(hipGetLastError());
+    s->next_cfl_min = -1.0;
+    return 0;
+}
+
+int pyrohip_inc_visc_rhs(pyrohip_state *s, pyrohip_mg *m, int iw, int comp, int igp, double dx,
+                         double dy, double dt, double nu, int proj_type, double *source_norm)
+{
+    INC_CHECK_MG(s, m, F);
+    BG_CHECK_VARS(s, iw, igp);
+    PYRO_REQUIRE(comp == 0 || comp == 1, "comp: 0 = u, 1 = v");
+    PYRO_REQUIRE(proj_type == 1 || proj_type == 2, "proj_type must be 1 or 2");
+    PYRO_REQUIRE(s->work_planes >= (size_t)W_NPL, "call pyrohip_inc_advect first");
+    const BP P = make_bp(dx, dy, dt, 0, nu);
+    const Geom &g = s->g;
+    PYRO_TRY(pyrohip_mg_zero(m, F.level, 1));
+    PYRO_LAUNCH(s->ctx, "k_inc_visc_rhs", k_inc_visc_rhs, dim3((g.ny + 2 + 255) / 256, g.nx + 2),
+                dim3(256), 0, (const double *)(s->d + (size_t)iw * g.plane),
+                (const double *)(s->work + geom_lead(g) +
+                                 (size_t)(comp ? W_ADVY : W_ADVX) * g.plane),
+                (const double *)(s->d + (size_t)igp * g.plane), g, F.f, F.v, F.pitch, P,
+                proj_type);
+    PYRO_CHECK_HIP(hipGetLastError());
+    PYRO_TRY(mg_solution_written(m));
+    return pyrohip_mg_init_rhs_norm(m, source_norm);
+}
+
+int pyrohip_inc_visc_store(pyrohip_state *s, pyrohip_mg *m, int iw)
+{
+    INC_CHECK_MG(s, m, F);
+    BG_CHECK_VARS(s, iw);
+    const Geom &g = s->g;
+    PYRO_LAUNCH(s->ctx, "k_inc_visc_store", k_inc_visc_store, dim3((g.ny + 255) / 256, g.nx),
+                dim3(256), 0, s->d + (size_t)iw * g.plane, (const double *)F.v, F.pitch, g);
     PYRO_CHECK_HIP(hipGetLastError());
     s->next_cfl_min = -1.0;
     return 0;

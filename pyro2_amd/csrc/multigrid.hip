@@ -78,6 +78,7 @@ __device__ __forceinline__ double ghost_lo(int code, double inner, const double 
     switch (code) {
     case PYROHIP_BC_OUTFLOW: return val ? inner - dx * val[idx] : inner;          // neumann
     case PYROHIP_BC_REFLECT_ODD: return val ? 2 * val[idx] - inner : -inner;      // dirichlet
+    case PYROHIP_BC_CONST: return 0.0;   // incompressible_viscous/BC.py:39-42 on "v"
     default: return inner;                                                       // reflect-even
     }
 }
@@ -87,6 +88,7 @@ __device__ __forceinline__ double ghost_hi(int code, double inner, const double 
     switch (code) {
     case PYROHIP_BC_OUTFLOW: return val ? inner + dx * val[idx] : inner;
     case PYROHIP_BC_REFLECT_ODD: return val ? 2 * val[idx] - inner : -inner;
+    case PYROHIP_BC_CONST: return 0.0;
     default: return inner;
     }
 }
@@ -1106,7 +1108,8 @@ int pyrohip_mg_create(pyrohip_ctx *c, int nx, double xmin, double xmax, double y
                  "multigrid requires a square domain (MG.py:197-198)");
     for (int s = 0; s < 4; s++)
         PYRO_REQUIRE(bc[s] == PYROHIP_BC_OUTFLOW || bc[s] == PYROHIP_BC_REFLECT_ODD ||
-                         bc[s] == PYROHIP_BC_PERIODIC || bc[s] == PYROHIP_BC_REFLECT_EVEN,
+                         bc[s] == PYROHIP_BC_PERIODIC || bc[s] == PYROHIP_BC_REFLECT_EVEN ||
+                         bc[s] == PYROHIP_BC_CONST,
                      "bad BC code");
     PYRO_REQUIRE((bc[0] == PYROHIP_BC_PERIODIC) == (bc[1] == PYROHIP_BC_PERIODIC) &&
                      (bc[2] == PYROHIP_BC_PERIODIC) == (bc[3] == PYROHIP_BC_PERIODIC),
@@ -1164,6 +1167,14 @@ int pyrohip_mg_destroy(pyrohip_mg *m)
     for (int s = 0; s < 4; s++)
         if (m->bcval[s]) (void)hipFree(m->bcval[s]);
     delete m;
+    return 0;
+}
+
+int pyrohip_mg_set_helmholtz(pyrohip_mg *m, double alpha, double beta)
+{
+    PYRO_REQUIRE(m, "NULL mg");
+    PYRO_REQUIRE(m->vc == 0, "constant-coefficient solvers only");
+    m->alpha = alpha; m->beta = beta;   // read at every launch
     return 0;
 }
 

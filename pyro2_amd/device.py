@@ -245,13 +245,32 @@ class DeviceState:
             check(self._l.pyrohip_bg_step(self.h, int(iu), int(iv), float(dx), float(dy),
                                           float(dt), int(limiter)))
 
-    def inc_mac_rhs(self, mg, iu, iv, igpx, igpy, dx, dy, dt, limiter):
+    def inc_mac_rhs(self, mg, iu, iv, igpx, igpy, dx, dy, dt, limiter, nu=0.0):
         out = C.c_double()
         with self.ctx.lock:
             check(self._l.pyrohip_inc_mac_rhs(self.h, mg.h, int(iu), int(iv), int(igpx), int(igpy),
                                               float(dx), float(dy), float(dt), int(limiter),
-                                              C.byref(out)))
+                                              float(nu), C.byref(out)))
         return out.value
+
+    def inc_visc_rhs(self, mg, iw, comp, igp, dx, dy, dt, nu, proj_type):
+        """RHS + guess of the Helmholtz solve of velocity component comp
+        (incompressible_viscous do_other_update_velocity); returns ||f||"""
+        out = C.c_double()
+        with self.ctx.lock:
+            check(self._l.pyrohip_inc_visc_rhs(self.h, mg.h, int(iw), int(comp), int(igp),
+                                               float(dx), float(dy), float(dt), float(nu),
+                                               int(proj_type), C.byref(out)))
+        return out.value
+
+    def inc_visc_store(self, mg, iw):
+        with self.ctx.lock:
+            check(self._l.pyrohip_inc_visc_store(self.h, mg.h, int(iw)))
+
+    def set_const_bc(self, n, value):
+        """ghost value of variable n on its PYROHIP_BC_CONST ("moving_lid") side"""
+        with self.ctx.lock:
+            check(self._l.pyrohip_state_set_const_bc(self.h, int(n), float(value)))
 
     def inc_advect(self, mg, iu, iv, iphimac, igpx, igpy, dx, dy, dt, proj_type):
         with self.ctx.lock:
@@ -433,6 +452,11 @@ class DeviceMG:
 
     def set_smoother(self, kind):
         self._call("pyrohip_mg_set_smoother", int(kind))
+
+    def set_helmholtz(self, alpha, beta):
+        """new constant coefficients of (alpha - beta L) phi = f"""
+        self._call("pyrohip_mg_set_helmholtz", float(alpha), float(beta))
+        self.alpha, self.beta = float(alpha), float(beta)
 
     def zero(self, level, var):
         self._call("pyrohip_mg_zero", level, var)

@@ -104,7 +104,10 @@ class Simulation(burgers_simulation):
             print("done with the pre-evolution")
         self.in_preevolve = False
 
-    def evolve(self):
+    def evolve(self, other_update_velocity=False, other_source_term=False):
+        """other_source_term: the derived solver's viscosity() enters the edge
+        states; other_update_velocity: its do_other_update_velocity replaces the
+        provisional update (incompressible/simulation.py:159, :174-176, :305-308)"""
         tm = self.tc.timer("evolve")
         tm.begin()
         cc, g = self.cc_data, self.cc_data.grid
@@ -116,13 +119,17 @@ class Simulation(burgers_simulation):
 
         if self.verbose > 0:
             print("  making MAC velocities")
-        st.inc_mac_rhs(mg, iu, iv, igx, igy, g.dx, g.dy, self.dt, limiter)
+        nu = self.viscosity() if other_source_term else 0.0
+        st.inc_mac_rhs(mg, iu, iv, igx, igy, g.dx, g.dy, self.dt, limiter, nu)
         if self.verbose > 0:
             print("  MAC projection")
         nc1 = mg.solve(rtol=1.e-12)[0]
         if self.verbose > 0:
             print("  making u, v edge states; provisional update of u, v")
-        st.inc_advect(mg, iu, iv, iphim, igx, igy, g.dx, g.dy, self.dt, proj_type)
+        st.inc_advect(mg, iu, iv, iphim, igx, igy, g.dx, g.dy, self.dt,
+                      0 if other_update_velocity else proj_type)
+        if other_update_velocity:
+            self.do_other_update_velocity(st)
         cc.device_modified()
         self._fill_velocity()
 

@@ -19,15 +19,20 @@ ext_bcs = {}
 # {name: PYROHIP_BC_* code}; their Python callbacks are then not needed for the
 # 4-variable compressible state
 device_bcs = {}
+# constant-value types (PYROHIP_BC_CONST): {name: function(variable) -> value}
+const_bcs = {}
 
 
-def define_bc(bc_type, function, is_solid=False, device_code=None):
+def define_bc(bc_type, function, is_solid=False, device_code=None, const_value=None):
     """register a solver-specific boundary type (boundary.py:19-32).
-    device_code: the type has a kernel in csrc/ctx.hip (pyrohip.h BC codes)"""
+    device_code: the type has a kernel in csrc/ctx.hip (pyrohip.h BC codes);
+    const_value(variable): ghost value of a constant-value type"""
     bc_solid[bc_type] = is_solid
     ext_bcs[bc_type] = function
     if device_code is not None:
         device_bcs[bc_type] = device_code
+    if const_value is not None:
+        const_bcs[bc_type] = const_value
 
 
 class BCProp:

@@ -286,6 +286,11 @@ class CellCenterData2d:
         """the hse / ambient / ramp boundaries run on the device for the
         compressible state (4 variables in pyro's order; hse and ambient on the
         y sides only, ramp anywhere but the upper x side)"""
+        used = {b for n in self.names for b in self.BCs[n].sides() if b in bnd.device_bcs}
+        if used and used <= set(bnd.const_bcs):
+            # constant-value ghost cells ("moving_lid"): any state, upper y side only
+            return all(b not in bnd.const_bcs for n in self.names
+                       for b in self.BCs[n].sides()[:3])
         if self.names != ["density", "energy", "x-momentum", "y-momentum"]:
             return False
         for n in self.names:
@@ -307,6 +312,12 @@ class CellCenterData2d:
         used = {b for n in self.names for b in self.BCs[n].sides() if b in bnd.device_bcs}
         if not used:
             return
+        if used & set(bnd.const_bcs) and not getattr(st, "_const_bc_pushed", False):
+            for n, name in enumerate(self.names):
+                b = self.BCs[name].yrb
+                if b in bnd.const_bcs:
+                    st.set_const_bc(n, bnd.const_bcs[b](name))
+            st._const_bc_pushed = True
         if used & {"hse", "ambient"}:
             amb = [self.aux.get(k, 0.0) for k in
                    ("ambient_rho", "ambient_u", "ambient_v", "ambient_p")]

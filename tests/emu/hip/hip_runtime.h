@@ -48,7 +48,8 @@ struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcess
 
 namespace hipemu {
 struct Fiber {
-    ucontext_t ctx;
+    ucontext_t ctx;        // generic fallback
+    void *sp = nullptr;    // x86-64: saved stack pointer of the hand-written switch
     char *stack = nullptr;
     bool done = false;
     unsigned long bar_gen_seen = 0;
@@ -60,6 +61,7 @@ struct BlockState {
     int cur = 0;
     std::vector<Fiber> fib;
     ucontext_t sched;
+    void *sched_sp = nullptr;
     // block barrier
     int bar_arrived = 0;
     unsigned long bar_gen = 0;

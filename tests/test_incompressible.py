@@ -186,3 +186,129 @@ def test_pyro_burgers(api, golden):
     if nsteps == 10:
         got = np.moveaxis(np.asarray(p.sim.cc_data.data), -1, 0)
         assert np.array_equal(got[:, 4:-4, 4:-4], g["b0_final"][:, 4:-4, 4:-4])
+
+
+# ---------------------------------------------------------------------------
+# incompressible_viscous: viscous predictor source, two Helmholtz solves per
+# step, "moving_lid" boundary
+# ---------------------------------------------------------------------------
+def visc_step(s, mgs, nx, dt, lim, proj, nu):
+    """incompressible_viscous evolve() through the C ABI; mgs = (phi, u, v)"""
+    dx = 1.0 / nx
+    mg, mgu, mgv = mgs
+    s.inc_mac_rhs(mg, 0, 1, 4, 5, dx, dx, dt, lim, nu)
+    n1 = mg.solve(rtol=1.e-12)[0]
+    s.inc_advect(mg, 0, 1, 2, 4, 5, dx, dx, dt, 0)
+    nv = []
+    for comp, m in enumerate((mgu, mgv)):
+        m.set_helmholtz(1.0, 0.5 * dt * nu)
+        s.inc_visc_rhs(m, comp, comp, 4 + comp, dx, dx, dt, nu, proj)
+        nv.append(m.solve(rtol=1.e-12)[0])
+        s.inc_visc_store(m, comp)
+    s.fill_bc(0)
+    s.fill_bc(1)
+    s.inc_proj_rhs(mg, 0, 1, 3, dx, dx, dt, 1)
+    n2 = mg.solve(rtol=1.e-12)[0]
+    s.inc_proj_update(mg, 0, 1, 3, 4, 5, dx, dx, dt, proj)
+    s.fill_bc(0)
+    s.fill_bc(1)
+    return n1, n2, nv[0], nv[1]
+
+
+def _visc_names(g, pre):
+    names = [str(b) for b in g[pre + "bc"]]
+    phi = names if names[0] == "periodic" else ["neumann"] * 4
+    return names, phi
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_viscous_step_vs_reference(dev, golden, k):
+    """one evolve() of incompressible_viscous from a reference state"""
+    g = golden("incomp_viscous")
+    pre = f"i{k}_"
+    meta = g[pre + "meta"]
+    nx, ng, lim, proj = (int(x) for x in meta[:4])
+    nu = float(meta[7])
+    names, phi = _visc_names(g, pre)
+    s = planar_state(dev, g[pre + "U0"], [names, names] + [phi] * 4)
+    s.set_const_bc(0, 1.0)
+    mk = lambda b, a, be: device.DeviceMG(dev, nx, bcs=b, alpha=a, beta=be, nsmooth=10,
+                                          nsmooth_bottom=50)
+    dt = float(g[pre + "dt"])
+    mgs = (mk(phi, 0.0, -1.0), mk(names, 1.0, 0.5 * dt * nu), mk(names, 1.0, 1.0))
+    D = np.ascontiguousarray(g[pre + "U0"])
+    orc.incomp_set_viscous(nu)
+    try:
+        so = orc.incomp_step(D, nx, ng, dt, lim, proj, stages=True, bc_u=names, bc_v=names,
+                             bc_phi=phi)
+    finally:
+        orc.incomp_set_viscous(None)
+    ncyc = visc_step(s, mgs, nx, dt, lim, proj, nu)
+    assert ncyc == tuple(so["ncyc"]) + tuple(so["ncyc_visc"])
+    F = (slice(ng, ng + nx + 1), slice(ng, ng + nx))
+    assert np.abs(s.inc_stage("u_MAC")[F] - so["umac"][F]).max() < 1e-13
+    assert np.abs(s.inc_stage("u_MAC")[F] - g[pre + "umac"][F]).max() < 1e-12
+    got = planes_of(s)
+    ref = g[pre + "U1"]
+    for n in range(6):
+        tol = 1e-12 if n < 2 else 1e-10
+        assert np.abs(got[n] - D[n]).max() < tol, (n, np.abs(got[n] - D[n]).max())
+        assert np.abs(got[n] - ref[n]).max() < 10 * tol, (n, np.abs(got[n] - ref[n]).max())
+    if names[3] == "moving_lid":     # the lid: u = 1, v = 0 in the ghost rows
+        assert np.all(got[0][:, ng + nx:] == 1.0) and np.all(got[1][:, ng + nx:] == 0.0)
+
+
+def _pyro_visc(problem, nx, lim, proj, nu, nsteps):
+    from pyro2_amd.pyro_sim import Pyro
+    p = Pyro("incompressible_viscous")
+    p.initialize_problem(problem, inputs_dict={"mesh.nx": nx, "mesh.ny": nx,
+                                               "incompressible.limiter": lim,
+                                               "incompressible.proj_type": proj,
+                                               "incompressible_viscous.viscosity": nu,
+                                               "driver.max_steps": nsteps})
+    return p
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_pyro_incompressible_viscous(api, golden, k):
+    """Pyro("incompressible_viscous"): cavity (moving lid) and shear set-ups,
+    preevolve and a short run against the reference"""
+    g = golden("incomp_viscous")
+    pre = f"i{k}_"
+    meta = g[pre + "meta"]
+    nx, ng, lim, proj = (int(x) for x in meta[:4])
+    if api.kind == "emu" and k == 1:
+        pytest.skip("emulated backend: the 16^2 cases only (time)")
+    nsteps = len(g[pre + "dts"]) if api.kind == "hip" else 1
+    problem = "cavity" if str(g[pre + "bc"][3]) == "moving_lid" else "shear"
+    p = _pyro_visc(problem, nx, lim, proj, float(meta[7]), nsteps)
+    got = np.moveaxis(np.asarray(p.sim.cc_data.data), -1, 0)
+    assert np.abs(got - g[pre + "after_pre"]).max() < 1e-12
+    dts = []
+    while not p.sim.finished():
+        p.single_step()
+        dts.append(p.sim.dt)
+    assert np.abs(np.array(dts) / g[pre + "dts"][:nsteps] - 1).max() < 1e-12
+    if nsteps == len(g[pre + "dts"]):
+        got = np.moveaxis(np.asarray(p.sim.cc_data.data), -1, 0)
+        I = (slice(None), slice(ng, -ng), slice(ng, -ng))
+        assert np.abs(got[I] - g[pre + "final"][I]).max() < 1e-10
+
+
+@pytest.mark.gpu
+def test_incompressible_viscous_reference_regression_cavity(hip, golden, tmp_path, monkeypatch):
+    """pyro/test.py:111 -- cavity_n64_Re400_0025.h5 (64^2, Re 400, 25 steps, 100
+    MG solves) through Pyro on the GPU"""
+    monkeypatch.setattr(device.Context, "_default", hip)
+    monkeypatch.chdir(tmp_path)
+    from pyro2_amd.pyro_sim import Pyro
+    g = golden("incomp_cavity_0025")
+    p = Pyro("incompressible_viscous")
+    p.initialize_problem("cavity")
+    p.run_sim()
+    assert p.sim.n == int(g["nsteps"]) == 25
+    assert abs(p.sim.cc_data.t - float(g["t"])) < 1e-13
+    u = np.asarray(p.sim.cc_data.get_var("x-velocity").v())
+    v = np.asarray(p.sim.cc_data.get_var("y-velocity").v())
+    assert np.abs(u - g["gold"][0]).max() < 1e-10
+    assert np.abs(v - g["gold"][1]).max() < 1e-10
