@@ -1211,7 +1211,64 @@ def gen_mg_general():
     save("mg_general", **out)
 
 
+def sph_geometry(g):
+    """the arrays of patch.SphericalPolar + the sines artificial_viscosity
+    evaluates (interface.py:345-347), with the reference's own expressions"""
+    out = {n: np.array(getattr(g, n)) for n in ("Lx", "Ly", "Ax", "Ay", "V", "dlogAx", "dlogAy",
+                                                 "x2d", "y2d")}
+    j = np.arange(g.qy)
+    out["sint"] = np.array([np.sin((jj + 0.5 - g.ng) * g.dy + g.ymin) for jj in j])
+    out["sinb"] = np.array([np.sin((jj - 0.5 - g.ng) * g.dy + g.ymin) for jj in j])
+    out["sinc"] = np.array([np.sin((jj - g.ng) * g.dy + g.ymin) for jj in j])
+    out["domain"] = np.array([g.xmin, g.xmax, g.ymin, g.ymax])
+    return out
+
+
+def gen_compressible_spherical():
+    """row f4: the compressible solver on a SphericalPolar grid (mesh.grid_type
+    = SphericalPolar; CGF solver): short runs of the reference's two spherical
+    set-ups and the stages of one more step"""
+    cases = [
+        ("sedov", "inputs.sedov.spherical", {"mesh.nx": 48, "mesh.ny": 24}, 8),
+        ("advect", "inputs.advect.spherical.64", {"mesh.nx": 40, "mesh.ny": 20}, 6),
+        ("sedov", "inputs.sedov.spherical", {"mesh.nx": 40, "mesh.ny": 16, "compressible.grav": -0.3,
+                                             "compressible.limiter": 1, "mesh.ymin": 0.4,
+                                             "mesh.ymax": 1.2}, 7),
+    ]
+    out = {"ncases": np.array(len(cases))}
+    for k, (prob, inp, d, nsteps) in enumerate(cases):
+        p = Pyro("compressible")
+        p.initialize_problem(prob, inputs_file=inp, inputs_dict=d)
+        sim = p.sim
+        pre = f"c{k}_"
+        out[pre + "ic"] = np.array(sim.cc_data.data)
+        dts = []
+        for _ in range(nsteps):
+            p.single_step()
+            dts.append(sim.dt)
+        out[pre + "dts"] = np.array(dts)
+        out[pre + "after"] = np.array(sim.cc_data.data)
+        sim.cc_data.fill_BC_all()
+        sim.compute_timestep()
+        out[pre + "meta"] = comp_meta(sim)
+        out[pre + "bc"] = bc_names(sim.rp)
+        out[pre + "problem"] = np.array(prob)
+        out[pre + "dt"] = np.array(sim.dt)
+        out[pre + "drv"] = np.array([p.rp.get_param("driver.init_tstep_factor"),
+                                     p.rp.get_param("driver.max_dt_change")])
+        for nm, a in sph_geometry(sim.cc_data.grid).items():
+            out[pre + "g_" + nm] = a
+        st = comp_stage_dump(sim)
+        for nm in ("U0", "q", "ldx", "Uxl0", "Uxr0", "Uyl0", "Uyr0", "FxT", "FyT", "Uxl", "Uxr",
+                   "Uyl", "Uyr", "Fx0", "Fy0", "avx", "avy", "Fx", "Fy", "U1"):
+            out[pre + nm] = st[nm]
+        print("spherical case", k, prob, "dt", sim.dt, type(sim.cc_data.grid).__name__)
+    save("comp_spherical", **out)
+
+
 if __name__ == "__main__":
+    if "comp_spherical" in sys.argv[1:]:
+        gen_compressible_spherical()
     if "mg_general" in sys.argv[1:]:
         gen_mg_general()
     if "comp_lm" in sys.argv[1:]:

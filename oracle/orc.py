@@ -38,7 +38,24 @@ class CompParams(C.Structure):
                 ("solid_yl", C.c_int), ("solid_yr", C.c_int), ("do_sponge", C.c_int),
                 ("sponge_rho_begin", C.c_double), ("sponge_rho_full", C.c_double),
                 ("sponge_timescale", C.c_double),
-                ("heat_rate", C.c_double), ("heat_prof", C.POINTER(C.c_double))]
+                ("heat_rate", C.c_double), ("heat_prof", C.POINTER(C.c_double)),
+                ("geom", C.c_void_p)]
+
+
+class Geom(C.Structure):
+    """orc_geom: the arrays of patch.SphericalPolar"""
+    _NAMES = ("Lx", "Ly", "Ax", "Ay", "V", "dlogAx", "dlogAy", "x2d", "sint", "sinb", "sinc")
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in _NAMES] + \
+               [("xmin", C.c_double), ("ymin", C.c_double)]
+
+    def __init__(self, arrays, xmin, ymin):
+        super().__init__()
+        self._keep = {}
+        for n in self._NAMES:
+            a = np.ascontiguousarray(arrays[n], dtype=np.float64)
+            self._keep[n] = a
+            setattr(self, n, _p(a))
+        self.xmin, self.ymin = float(xmin), float(ymin)
 
 
 _STAGE_NAMES = ["q", "xi", "ldx", "ldy", "Uxl0", "Uxr0", "Uyl0", "Uyr0",
@@ -197,10 +214,19 @@ def comp_dt(U, nx, ny, ng, dx, dy, gamma, cfl):
                              C.c_double(cfl))
 
 
-def comp_step(U, P, dt, stages=False):
-    """one compressible step in place on U (qx,qy,4) (ghosts filled).
-    returns (rc, stages dict)"""
+def comp_dt_geom(U, nx, ny, ng, geom, gamma, cfl):
+    """method_compute_timestep with the Lx, Ly arrays of a curvilinear grid"""
     _ck(U)
+    f = lib().orc_comp_dt_geom
+    f.restype = C.c_double
+    return f(_p(U), nx, ny, ng, geom.Lx, geom.Ly, C.c_double(gamma), C.c_double(cfl))
+
+
+def comp_step(U, P, dt, stages=False, geom=None):
+    """one compressible step in place on U (qx,qy,4) (ghosts filled).
+    geom: a Geom (SphericalPolar grid) or None.  returns (rc, stages dict)"""
+    _ck(U)
+    P.geom = C.cast(C.pointer(geom), C.c_void_p) if geom is not None else None
     outs = {}
     st = CompStages()
     if stages:

@@ -81,7 +81,21 @@ typedef struct {
        exp(-(dist/r)^2) on the whole grid incl. ghost coordinates, or NULL */
     double heat_rate;
     const double *heat_prof;
+    /* SphericalPolar grid (mesh/patch.py:242-312; x = r, y = theta), NULL for
+       Cartesian2d: see orc_geom */
+    const struct orc_geom_s *geom;
 } orc_comp_params;
+
+/* geometry arrays of patch.SphericalPolar, all (qx,qy) and evaluated by the
+   caller with the reference's NumPy expressions (cos / sin / tan included), so
+   that restatement and product see the same bits.  sint/sinb/sinc: (qy) sines
+   of artificial_viscosity (interface.py:345-347): sin((j +- 1/2 - ng) dy + ymin)
+   and sin((j - ng) dy + ymin). */
+typedef struct orc_geom_s {
+    const double *Lx, *Ly, *Ax, *Ay, *V, *dlogAx, *dlogAy, *x2d;
+    const double *sint, *sinb, *sinc;
+    double xmin, ymin;
+} orc_geom;
 
 /* optional stage outputs; any pointer may be NULL */
 typedef struct {
@@ -99,6 +113,13 @@ typedef struct {
 static double *zalloc(size_t n) { return (double *)calloc(n, sizeof(double)); }
 static inline double dmax(double a, double b) { return a > b ? a : b; }
 static inline double dmin(double a, double b) { return a < b ? a : b; }
+/* Python's builtin max(a, b) / min(a, b) on scalars, as the njit kernels of
+   the reference call them: the first argument wins unless the second one is
+   strictly larger / smaller, so max(smallc, nan) = smallc but max(nan, small)
+   = nan.  Only matters in ghost faces whose states are not physical (the
+   reflect-odd density ghosts of inputs.sedov.spherical). */
+static inline double pymax(double a, double b) { return b > a ? b : a; }
+static inline double pymin(double a, double b) { return b < a ? b : a; }
 
 /* ------------------------------------------------------------------ */
 /* a1: ghost fill, pyro/mesh/array_indexer.py:150-274                  */
@@ -419,19 +440,31 @@ void orc_flatten_multid(const double *q, int nx, int ny, int ng, double z0,
 /* a8: characteristic tracing, pyro/compressible/interface.py:5-236    */
 /* q, dq: (qx,qy,4).  q_l, q_r: (qx,qy,4) zeroed here.                 */
 /* ------------------------------------------------------------------ */
+static void states_impl(int idir, int nx, int ny, int ng, double dx, const double *L,
+                        const double *dloga, double dt, double gamma, const double *qv,
+                        const double *dqv, double *q_l, double *q_r);
 void orc_states(int idir, int nx, int ny, int ng, double dx, double dt,
                 double gamma, const double *qv, const double *dqv,
                 double *q_l, double *q_r)
+{
+    states_impl(idir, nx, ny, ng, dx, NULL, NULL, dt, gamma, qv, dqv, q_l, q_r);
+}
+/* L, dloga: the 2-d cell-size and dlog(area) arrays of a curvilinear grid
+   (interface.py:106 dtdx = dt / dx with dx an array; :215-234), NULL: uniform */
+static void states_impl(int idir, int nx, int ny, int ng, double dx, const double *L,
+                        const double *dloga, double dt, double gamma, const double *qv,
+                        const double *dqv, double *q_l, double *q_r)
 {
     const int qx = nx + 2 * ng, qy = ny + 2 * ng;
     const int ilo = ng, ihi = ng + nx, jlo = ng, jhi = ng + ny; /* njit-local */
     memset(q_l, 0, sizeof(double) * qx * qy * 4);
     memset(q_r, 0, sizeof(double) * qx * qy * 4);
-    const double dtdx = dt / dx;       /* interface.py:106 */
-    const double dtdx4 = 0.25 * dtdx;  /* :107 */
+    double dtdx = dt / dx;       /* interface.py:106 */
+    double dtdx4 = 0.25 * dtdx;  /* :107 */
     double lvec[4][4], rvec[4][4], e_val[4], betal[4], betar[4];
     for (int i = ilo - 2; i < ihi + 2; i++)
         for (int j = jlo - 2; j < jhi + 2; j++) {
+            if (L) { dtdx = dt / L[(size_t)i * qy + j]; dtdx4 = 0.25 * dtdx; }
             const double *dq = dqv + ((size_t)i * qy + j) * 4;
             const double *q = qv + ((size_t)i * qy + j) * 4;
             double cs = sqrt(gamma * q[IP] / q[IRHO]);
@@ -464,9 +497,9 @@ void orc_states(int idir, int nx, int ny, int ng, double dx, double dt,
                                      : q_l + ((size_t)i * qy + (j + 1)) * 4;
             double *qr = q_r + ((size_t)i * qy + j) * 4;
             /* reference states, interface.py:174-191 */
-            double factor = 0.5 * (1.0 - dtdx * dmax(e_val[3], 0.0));
+            double factor = 0.5 * (1.0 - dtdx * pymax(e_val[3], 0.0));
             for (int m = 0; m < 4; m++) ql[m] = q[m] + factor * dq[m];
-            factor = 0.5 * (1.0 + dtdx * dmin(e_val[0], 0.0));
+            factor = 0.5 * (1.0 + dtdx * pymin(e_val[0], 0.0));
             for (int m = 0; m < 4; m++) qr[m] = q[m] - factor * dq[m];
             /* :193-201 ; np.dot = in-order 4-term sum */
             for (int m = 0; m < 4; m++) {
@@ -487,7 +520,15 @@ void orc_states(int idir, int nx, int ny, int ng, double dx, double dt,
                 ql[m] = ql[m] + sum_l;
                 qr[m] = qr[m] + sum_r;
             }
-            /* geometric source (:216-234) vanishes for Cartesian: dloga=0 */
+            /* geometric source (:216-234); vanishes for Cartesian: dloga = 0 */
+            if (dloga) {
+                const double rho_source = -0.5 * dt * dloga[(size_t)i * qy + j] * q[IRHO] *
+                                          q[idir == 1 ? IU : IV];
+                ql[IRHO] += rho_source;
+                qr[IRHO] += rho_source;
+                ql[IP] += rho_source * cs * cs;
+                qr[IP] += rho_source * cs * cs;
+            }
         }
 }
 
@@ -499,8 +540,8 @@ static void estimate_wave_speed(double rho_l, double u_l, double p_l,
                                 double p_r, double c_r, double gamma,
                                 double *S_l, double *S_r)
 {
-    double p_max = dmax(p_l, p_r);
-    double p_min = dmin(p_l, p_r);
+    double p_max = pymax(p_l, p_r);
+    double p_min = pymin(p_l, p_r);
     double Q = p_max / p_min;
     double rho_avg = 0.5 * (rho_l + rho_r);
     double c_avg = 0.5 * (c_l + c_r);
@@ -525,7 +566,7 @@ static void estimate_wave_speed(double rho_l, double u_l, double p_l,
             double B_r = p_r * (gamma - 1.0) / (gamma + 1.0);
             double A_l = 2.0 / ((gamma + 1.0) * rho_l);
             double B_l = p_l * (gamma - 1.0) / (gamma + 1.0);
-            double p_guess = dmax(0.0, pstar);
+            double p_guess = pymax(0.0, pstar);
             double g_l = sqrt(A_l / (p_guess + B_l));
             double g_r = sqrt(A_r / (p_guess + B_r));
             pstar = (g_l * p_l + g_r * p_r - (u_r - u_l)) / (g_l + g_r);
@@ -546,6 +587,12 @@ static void estimate_wave_speed(double rho_l, double u_l, double p_l,
                                           (pstar / p_r - 1.0));
 }
 
+/* SphericalPolar: consFlux leaves the pressure out of the momentum flux
+   (riemann.py:1156, 1171) and riemann_flux(return_cons=True) also hands back the
+   CGF interface state (:1092-1096): g_sph / g_cgf_state are set by
+   orc_comp_step around riemann_dispatch */
+static int g_sph = 0;
+static double *g_cgf_state = NULL;
 static void cons_flux(int idir, double gamma, const double *Us, double *F)
 {
     double u = 0.0, v = 0.0;
@@ -557,14 +604,14 @@ static void cons_flux(int idir, double gamma, const double *Us, double *F)
     if (idir == 1) {
         F[IDENS] = Us[IDENS] * u;
         F[IXMOM] = Us[IXMOM] * u;
-        F[IXMOM] += p;
+        if (!g_sph) F[IXMOM] += p;
         F[IYMOM] = Us[IYMOM] * u;
         F[IENER] = (Us[IENER] + p) * u;
     } else {
         F[IDENS] = Us[IDENS] * v;
         F[IXMOM] = Us[IXMOM] * v;
         F[IYMOM] = Us[IYMOM] * v;
-        F[IYMOM] += p;
+        if (!g_sph) F[IYMOM] += p;
         F[IENER] = (Us[IENER] + p) * v;
     }
 }
@@ -593,7 +640,7 @@ void orc_riemann_hllc(int idir, int nx, int ny, int ng, double gamma,
             }
             double rhoe_l = Ul[IENER] - 0.5 * rho_l * (un_l * un_l + ut_l * ut_l);
             double p_l = rhoe_l * (gamma - 1.0);
-            p_l = dmax(p_l, smallp);
+            p_l = pymax(p_l, smallp);
             double rho_r = Ur[IDENS];
             double un_r, ut_r;
             if (idir == 1) {
@@ -605,9 +652,9 @@ void orc_riemann_hllc(int idir, int nx, int ny, int ng, double gamma,
             }
             double rhoe_r = Ur[IENER] - 0.5 * rho_r * (un_r * un_r + ut_r * ut_r);
             double p_r = rhoe_r * (gamma - 1.0);
-            p_r = dmax(p_r, smallp);
-            double c_l = dmax(smallc, sqrt(gamma * p_l / rho_l));
-            double c_r = dmax(smallc, sqrt(gamma * p_r / rho_r));
+            p_r = pymax(p_r, smallp);
+            double c_l = pymax(smallc, sqrt(gamma * p_l / rho_l));
+            double c_r = pymax(smallc, sqrt(gamma * p_r / rho_r));
             double S_l, S_r;
             estimate_wave_speed(rho_l, un_l, p_l, c_l, rho_r, un_r, p_r, c_r,
                                 gamma, &S_l, &S_r);
@@ -678,6 +725,7 @@ void orc_riemann_cgf(int idir, int nx, int ny, int ng, double gamma, int lower_s
     const double smallc = 1.e-10, smallrho = 1.e-10, smallp = 1.e-10;
     (void)upper_solid;
     memset(F, 0, sizeof(double) * qx * qy * 4);
+    if (g_cgf_state) memset(g_cgf_state, 0, sizeof(double) * qx * qy * 4);
     for (int i = ilo - 1; i < ihi + 1; i++)
         for (int j = jlo - 1; j < jhi + 1; j++) {
             const double *Ul = U_l + ((size_t)i * qy + j) * 4;
@@ -686,25 +734,25 @@ void orc_riemann_cgf(int idir, int nx, int ny, int ng, double gamma, int lower_s
             if (idir == 1) { un_l = Ul[IXMOM] / rho_l; ut_l = Ul[IYMOM] / rho_l; }
             else           { un_l = Ul[IYMOM] / rho_l; ut_l = Ul[IXMOM] / rho_l; }
             double rhoe_l = Ul[IENER] - 0.5 * rho_l * (SQ(un_l) + SQ(ut_l));
-            double p_l = dmax(rhoe_l * (gamma - 1.0), smallp);
+            double p_l = pymax(rhoe_l * (gamma - 1.0), smallp);
             double rho_r = Ur[IDENS], un_r, ut_r;
             if (idir == 1) { un_r = Ur[IXMOM] / rho_r; ut_r = Ur[IYMOM] / rho_r; }
             else           { un_r = Ur[IYMOM] / rho_r; ut_r = Ur[IXMOM] / rho_r; }
             double rhoe_r = Ur[IENER] - 0.5 * rho_r * (SQ(un_r) + SQ(ut_r));
-            double p_r = dmax(rhoe_r * (gamma - 1.0), smallp);
-            double W_l = dmax(smallrho * smallc, sqrt(gamma * p_l * rho_l));
-            double W_r = dmax(smallrho * smallc, sqrt(gamma * p_r * rho_r));
-            double c_l = dmax(smallc, sqrt(gamma * p_l / rho_l));
-            double c_r = dmax(smallc, sqrt(gamma * p_r / rho_r));
+            double p_r = pymax(rhoe_r * (gamma - 1.0), smallp);
+            double W_l = pymax(smallrho * smallc, sqrt(gamma * p_l * rho_l));
+            double W_r = pymax(smallrho * smallc, sqrt(gamma * p_r * rho_r));
+            double c_l = pymax(smallc, sqrt(gamma * p_l / rho_l));
+            double c_r = pymax(smallc, sqrt(gamma * p_r / rho_r));
             double pstar = (W_l * p_r + W_r * p_l + W_l * W_r * (un_l - un_r)) / (W_l + W_r);
-            pstar = dmax(pstar, smallp);
+            pstar = pymax(pstar, smallp);
             double ustar = (W_l * un_l + W_r * un_r + (p_l - p_r)) / (W_l + W_r);
             double rhostar_l = rho_l + (pstar - p_l) / SQ(c_l);
             double rhostar_r = rho_r + (pstar - p_r) / SQ(c_r);
             double rhoestar_l = rhoe_l + (pstar - p_l) * (rhoe_l / rho_l + p_l / rho_l) / SQ(c_l);
             double rhoestar_r = rhoe_r + (pstar - p_r) * (rhoe_r / rho_r + p_r / rho_r) / SQ(c_r);
-            double cstar_l = dmax(smallc, sqrt(gamma * pstar / rhostar_l));
-            double cstar_r = dmax(smallc, sqrt(gamma * pstar / rhostar_r));
+            double cstar_l = pymax(smallc, sqrt(gamma * pstar / rhostar_l));
+            double cstar_r = pymax(smallc, sqrt(gamma * pstar / rhostar_r));
             double rho_s, un_s, ut_s, p_s, rhoe_s;
             if (ustar > 0.0) {
                 ut_s = ut_l;
@@ -761,6 +809,7 @@ void orc_riemann_cgf(int idir, int nx, int ny, int ng, double gamma, int lower_s
             if (idir == 1) { Uo[IXMOM] = rho_s * un_s; Uo[IYMOM] = rho_s * ut_s; }
             else           { Uo[IXMOM] = rho_s * ut_s; Uo[IYMOM] = rho_s * un_s; }
             Uo[IENER] = rhoe_s + 0.5 * rho_s * (SQ(un_s) + SQ(ut_s));
+            if (g_cgf_state) memcpy(g_cgf_state + ((size_t)i * qy + j) * 4, Uo, 32);
             cons_flux(idir, gamma, Uo, F + ((size_t)i * qy + j) * 4);
         }
 }
@@ -782,12 +831,12 @@ void orc_riemann_hllc_lm(int idir, int nx, int ny, int ng, double gamma, const d
             double *Fc = F + ((size_t)i * qy + j) * 4;
             const double rho_l = Ul[IDENS], un_l = Ul[iun] / rho_l, ut_l = Ul[iut] / rho_l;
             const double rhoe_l = Ul[IENER] - 0.5 * rho_l * (SQ(un_l) + SQ(ut_l));
-            const double p_l = dmax(rhoe_l * (gamma - 1.0), smallp);
+            const double p_l = pymax(rhoe_l * (gamma - 1.0), smallp);
             const double rho_r = Ur[IDENS], un_r = Ur[iun] / rho_r, ut_r = Ur[iut] / rho_r;
             const double rhoe_r = Ur[IENER] - 0.5 * rho_r * (SQ(un_r) + SQ(ut_r));
-            const double p_r = dmax(rhoe_r * (gamma - 1.0), smallp);
-            const double c_l = dmax(smallc, sqrt(gamma * p_l / rho_l));
-            const double c_r = dmax(smallc, sqrt(gamma * p_r / rho_r));
+            const double p_r = pymax(rhoe_r * (gamma - 1.0), smallp);
+            const double c_l = pymax(smallc, sqrt(gamma * p_l / rho_l));
+            const double c_r = pymax(smallc, sqrt(gamma * p_r / rho_r));
             double S_l, S_r;
             estimate_wave_speed(rho_l, un_l, p_l, c_l, rho_r, un_r, p_r, c_r, gamma, &S_l, &S_r);
             const double S_c = (p_r - p_l + rho_l * un_l * (S_l - un_l) - rho_r * un_r * (S_r - un_r)) /
@@ -799,8 +848,8 @@ void orc_riemann_hllc_lm(int idir, int nx, int ny, int ng, double gamma, const d
             cons_flux(idir, gamma, Ul, F_l);
             cons_flux(idir, gamma, Ur, F_r);
             const double vmag_l = sqrt(SQ(un_l) + SQ(ut_l)), vmag_r = sqrt(SQ(un_r) + SQ(ut_r));
-            const double cs_max = dmax(c_l, c_r);
-            const double chi = dmin(1.0, dmax(vmag_l, vmag_r) / cs_max);
+            const double cs_max = pymax(c_l, c_r);
+            const double chi = pymin(1.0, pymax(vmag_l, vmag_r) / cs_max);
             const double phi = chi * (2.0 - chi);
             const double pstar = 0.5 * (p_l + p_r) +
                                  0.5 * phi * (rho_l * (S_l - un_l) * (S_c - un_l) +
@@ -873,6 +922,93 @@ void orc_artificial_viscosity(int nx, int ny, int ng, double dx, double dy,
 #undef VV
 #undef I2
     free(divU);
+}
+
+/* artificial_viscosity on a SphericalPolar grid, interface.py:331-376 */
+static void avisc_sph(int nx, int ny, int ng, double dx, double dy, double cvisc,
+                      const double *q, const orc_geom *G, double *avx, double *avy)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx, jlo = ng, jhi = ng + ny; /* njit-local */
+    const size_t N = (size_t)qx * qy;
+    double *divU = zalloc(N);
+    memset(avx, 0, N * 8);
+    memset(avy, 0, N * 8);
+#define UU(i, j) q[((size_t)(i) * qy + (j)) * 4 + IU]
+#define VV(i, j) q[((size_t)(i) * qy + (j)) * 4 + IV]
+#define I2(i, j) ((size_t)(i) * qy + (j))
+    for (int i = ilo - 1; i < ihi + 1; i++)
+        for (int j = jlo - 1; j < jhi + 1; j++) {
+            const double rr = (i + 0.5 - ng) * dx + G->xmin;
+            const double rl = (i - 0.5 - ng) * dx + G->xmin;
+            const double rc = (i - ng) * dx + G->xmin;
+            const double ur = 0.5 * (UU(i, j) + UU(i, j - 1));
+            const double ul = 0.5 * (UU(i - 1, j) + UU(i - 1, j - 1));
+            const double ux = (ur * rr * rr - ul * rl * rl) / (rc * rc * dx);
+            const double sint = G->sint[j], sinb = G->sinb[j], sinc = G->sinc[j];
+            double vy;
+            if (sinc == 0.0) vy = 0.0;
+            else {
+                const double vt = 0.5 * (VV(i, j) + VV(i - 1, j));
+                const double vb = 0.5 * (VV(i, j - 1) + VV(i - 1, j - 1));
+                vy = (sint * vt - sinb * vb) / (rc * sinc * dy);
+            }
+            divU[I2(i, j)] = ux + vy;
+        }
+    for (int i = ilo; i < ihi; i++)
+        for (int j = jlo; j < jhi; j++) {
+            const double divU_x = 0.5 * (divU[I2(i, j)] + divU[I2(i, j + 1)]);
+            const double divU_y = 0.5 * (divU[I2(i, j)] + divU[I2(i + 1, j)]);
+            avx[I2(i, j)] = cvisc * dmax(-divU_x * G->Lx[I2(i, j)], 0.0);
+            avy[I2(i, j)] = cvisc * dmax(-divU_y * G->Ly[I2(i, j)], 0.0);
+        }
+#undef UU
+#undef VV
+#undef I2
+    free(divU);
+}
+
+/* get_external_sources on a SphericalPolar grid (compressible/simulation.py:
+   117-124, 135-147): radial gravity and the geometric terms */
+static void ext_sources_sph(const double *U, const double *U_old, size_t ncell, double grav,
+                            double dt, double *S, const double *x2d)
+{
+    memset(S, 0, ncell * 4 * 8);
+    for (size_t k = 0; k < ncell; k++) {
+        const double *Uc = U + k * 4;
+        double *Sc = S + k * 4;
+        Sc[IXMOM] = Uc[IDENS] * grav;
+        if (!U_old) Sc[IENER] = Uc[IXMOM] * grav;
+        else {
+            const double S_old_xmom = U_old[k * 4 + IDENS] * grav;
+            const double xmom_new = Uc[IXMOM] + 0.5 * dt * (Sc[IXMOM] - S_old_xmom);
+            Sc[IENER] = xmom_new * grav;
+        }
+        Sc[IXMOM] += Uc[IYMOM] * Uc[IYMOM] / (Uc[IDENS] * x2d[k]);
+        Sc[IYMOM] += -Uc[IXMOM] * Uc[IYMOM] / Uc[IDENS];
+    }
+}
+
+/* method_compute_timestep with the grid's Lx, Ly arrays (simulation.py:284-288) */
+double orc_comp_dt_geom(const double *U, int nx, int ny, int ng, const double *Lx,
+                        const double *Ly, double gamma, double cfl)
+{
+    const int qx = nx + 2 * ng, qy = ny + 2 * ng;
+    double xmin = INFINITY, ymin = INFINITY;
+    for (size_t k = 0; k < (size_t)qx * qy; k++) {
+        const double *Uc = U + k * 4;
+        double dens = Uc[IDENS];
+        double u = Uc[IXMOM] / dens;
+        double v = Uc[IYMOM] / dens;
+        double e = (Uc[IENER] - 0.5 * dens * (u * u + v * v)) / dens;
+        double p = dens * e * (gamma - 1.0);
+        double cs = sqrt(gamma * p / dens);
+        double xt = Lx[k] / (fabs(u) + cs);
+        double yt = Ly[k] / (fabs(v) + cs);
+        if (xt < xmin) xmin = xt;
+        if (yt < ymin) ymin = yt;
+    }
+    return cfl * dmin(xmin, ymin);
 }
 
 /* compressible/simulation.py:105-161, Cartesian branch; problem_source of the
@@ -1033,6 +1169,7 @@ int orc_comp_step(double *U, const orc_comp_params *P, double dt,
     const int ilo = ng, ihi = ng + nx - 1, jlo = ng, jhi = ng + ny - 1;
     const size_t N = (size_t)qx * qy;
     const double gamma = P->gamma, dx = P->dx, dy = P->dy;
+    const orc_geom *G = P->geom;   /* SphericalPolar when set */
     int rc = 0;
 #define U4(a, i, j, n) a[((size_t)(i) * qy + (j)) * 4 + (n)]
 #define I2(i, j) ((size_t)(i) * qy + (j))
@@ -1049,6 +1186,9 @@ int orc_comp_step(double *U, const orc_comp_params *P, double dt,
            *Uyr = zalloc(N * 4);
     double *Fx = zalloc(N * 4), *Fy = zalloc(N * 4);
     double *avx = zalloc(N), *avy = zalloc(N);
+    /* SphericalPolar: CGF interface states and their primitives (pressure) */
+    double *Ux = NULL, *Uy = NULL, *qfx = NULL, *qfy = NULL;
+    if (G) { Ux = zalloc(N * 4); Uy = zalloc(N * 4); qfx = zalloc(N * 4); qfy = zalloc(N * 4); }
 
     /* unsplit_fluxes.py:160-197 */
     rc |= orc_cons_to_prim(U, nx, ny, ng, gamma, q);
@@ -1068,18 +1208,21 @@ int orc_comp_step(double *U, const orc_comp_params *P, double dt,
     if (st && st->ldy) memcpy(st->ldy, ldy, N * 32);
 
     /* unsplit_fluxes.py:207-242 */
-    orc_states(1, nx, ny, ng, dx, dt, gamma, q, ldx, V_l, V_r);
+    states_impl(1, nx, ny, ng, dx, G ? G->Lx : NULL, G ? G->dlogAx : NULL, dt, gamma, q, ldx,
+                V_l, V_r);
     orc_prim_to_cons(V_l, N, gamma, Uxl);
     orc_prim_to_cons(V_r, N, gamma, Uxr);
-    orc_states(2, nx, ny, ng, dy, dt, gamma, q, ldy, V_l, V_r);
+    states_impl(2, nx, ny, ng, dy, G ? G->Ly : NULL, G ? G->dlogAy : NULL, dt, gamma, q, ldy,
+                V_l, V_r);
     orc_prim_to_cons(V_l, N, gamma, Uyl);
     orc_prim_to_cons(V_r, N, gamma, Uyr);
 
     /* apply_source_terms, unsplit_fluxes.py:247-330 */
-    const int have_src = (P->grav != 0.0 || P->heat_prof != NULL);
+    const int have_src = (P->grav != 0.0 || P->heat_prof != NULL || G != NULL);
     if (have_src) {
         double *S = zalloc(N * 4);
-        ext_sources_h(U, NULL, N, P->grav, dt, S, P->heat_rate, P->heat_prof);
+        if (G) ext_sources_sph(U, NULL, N, P->grav, dt, S, G->x2d);
+        else ext_sources_h(U, NULL, N, P->grav, dt, S, P->heat_rate, P->heat_prof);
         for (int n = 0; n < 4; n++) orc_fill_ghost(S, nx, ny, ng, 4, n, P->bc[n]);
         const int comps[3] = {IXMOM, IYMOM, IENER};
         for (int c = 0; c < 3; c++) {
@@ -1100,8 +1243,16 @@ int orc_comp_step(double *U, const orc_comp_params *P, double dt,
     if (st && st->Uyr0) memcpy(st->Uyr0, Uyr, N * 32);
 
     /* apply_transverse_flux, unsplit_fluxes.py:333-494 */
+    g_sph = (G != NULL);
+    g_cgf_state = Ux;
     riemann_dispatch(P, 1, Uxl, Uxr, Fx);
+    g_cgf_state = Uy;
     riemann_dispatch(P, 2, Uyl, Uyr, Fy);
+    g_cgf_state = NULL;
+    if (G) {   /* :421-423; the interior assert of cons_to_prim is not an issue on faces */
+        orc_cons_to_prim(Ux, nx, ny, ng, gamma, qfx);
+        orc_cons_to_prim(Uy, nx, ny, ng, gamma, qfy);
+    }
     if (st && st->FxT) memcpy(st->FxT, Fx, N * 32);
     if (st && st->FyT) memcpy(st->FyT, Fy, N * 32);
     {
@@ -1109,6 +1260,32 @@ int orc_comp_step(double *U, const orc_comp_params *P, double dt,
         const double V = dx * dy;     /* patch.py:232 */
         const double hdtV = hdt / V;
         const double Ax = dy, Ay = dx; /* patch.py:219-222 */
+        if (G) {   /* area / volume arrays and the pressure-gradient terms, :442-488 */
+            for (int n = 0; n < 4; n++)
+                for (int i = ilo - 2; i <= ihi + 1; i++)
+                    for (int j = jlo - 2; j <= jhi + 1; j++) {
+                        const double hv = hdt / G->V[I2(i, j)];
+                        U4(Uxl, i, j, n) += -hv * (U4(Fy, i - 1, j + 1, n) * G->Ay[I2(i - 1, j + 1)] -
+                                                   U4(Fy, i - 1, j, n) * G->Ay[I2(i - 1, j)]);
+                        U4(Uxr, i, j, n) += -hv * (U4(Fy, i, j + 1, n) * G->Ay[I2(i, j + 1)] -
+                                                   U4(Fy, i, j, n) * G->Ay[I2(i, j)]);
+                        U4(Uyl, i, j, n) += -hv * (U4(Fx, i + 1, j - 1, n) * G->Ax[I2(i + 1, j - 1)] -
+                                                   U4(Fx, i, j - 1, n) * G->Ax[I2(i, j - 1)]);
+                        U4(Uyr, i, j, n) += -hv * (U4(Fx, i + 1, j, n) * G->Ax[I2(i + 1, j)] -
+                                                   U4(Fx, i, j, n) * G->Ax[I2(i, j)]);
+                    }
+            for (int i = ilo - 2; i <= ihi + 1; i++)
+                for (int j = jlo - 2; j <= jhi + 1; j++) {
+                    U4(Uxl, i, j, IYMOM) += -hdt * (U4(qfy, i - 1, j + 1, IP) - U4(qfy, i - 1, j, IP)) /
+                                            G->Ly[I2(i, j)];
+                    U4(Uxr, i, j, IYMOM) += -hdt * (U4(qfy, i, j + 1, IP) - U4(qfy, i, j, IP)) /
+                                            G->Ly[I2(i, j)];
+                    U4(Uyl, i, j, IXMOM) += -hdt * (U4(qfx, i + 1, j - 1, IP) - U4(qfx, i, j - 1, IP)) /
+                                            G->Lx[I2(i, j)];
+                    U4(Uyr, i, j, IXMOM) += -hdt * (U4(qfx, i + 1, j, IP) - U4(qfx, i, j, IP)) /
+                                            G->Lx[I2(i, j)];
+                }
+        } else
         for (int n = 0; n < 4; n++)
             for (int i = ilo - 2; i <= ihi + 1; i++)
                 for (int j = jlo - 2; j <= jhi + 1; j++) {
@@ -1127,13 +1304,23 @@ int orc_comp_step(double *U, const orc_comp_params *P, double dt,
     if (st && st->Uyl) memcpy(st->Uyl, Uyl, N * 32);
     if (st && st->Uyr) memcpy(st->Uyr, Uyr, N * 32);
 
-    /* final Riemann solves, simulation.py:349-357 */
+    /* final Riemann solves, simulation.py:330-357 */
+    g_cgf_state = Ux;
     riemann_dispatch(P, 1, Uxl, Uxr, Fx);
+    g_cgf_state = Uy;
     riemann_dispatch(P, 2, Uyl, Uyr, Fy);
+    g_cgf_state = NULL;
+    g_sph = 0;
+    if (G) {
+        orc_cons_to_prim(Ux, nx, ny, ng, gamma, qfx);
+        orc_cons_to_prim(Uy, nx, ny, ng, gamma, qfy);
+    }
     if (st && st->Fx0) memcpy(st->Fx0, Fx, N * 32);
     if (st && st->Fy0) memcpy(st->Fy0, Fy, N * 32);
 
     /* artificial viscosity, simulation.py:361-365, unsplit_fluxes.py:525-547 */
+    if (G) avisc_sph(nx, ny, ng, dx, dy, P->cvisc, q, G, avx, avy);
+    else
     orc_artificial_viscosity(nx, ny, ng, dx, dy, P->cvisc, q,
                              P->avisc_xhi_interior, P->avisc_yhi_interior, avx,
                              avy);
@@ -1159,6 +1346,19 @@ int orc_comp_step(double *U, const orc_comp_params *P, double dt,
     {
         const double dtdV = dt / (dx * dy);
         const double Ax = dy, Ay = dx;
+        if (G) {   /* :375-398: area / volume arrays, then the pressure gradients */
+            for (int n = 0; n < 4; n++)
+                for (int i = ilo; i <= ihi; i++)
+                    for (int j = jlo; j <= jhi; j++)
+                        U4(U, i, j, n) += (dt / G->V[I2(i, j)]) *
+                            (U4(Fx, i, j, n) * G->Ax[I2(i, j)] - U4(Fx, i + 1, j, n) * G->Ax[I2(i + 1, j)] +
+                             U4(Fy, i, j, n) * G->Ay[I2(i, j)] - U4(Fy, i, j + 1, n) * G->Ay[I2(i, j + 1)]);
+            for (int i = ilo; i <= ihi; i++)
+                for (int j = jlo; j <= jhi; j++) {
+                    U4(U, i, j, IXMOM) -= dt * (U4(qfx, i + 1, j, IP) - U4(qfx, i, j, IP)) / G->Lx[I2(i, j)];
+                    U4(U, i, j, IYMOM) -= dt * (U4(qfy, i, j + 1, IP) - U4(qfy, i, j, IP)) / G->Ly[I2(i, j)];
+                }
+        } else
         for (int n = 0; n < 4; n++)
             for (int i = ilo; i <= ihi; i++)
                 for (int j = jlo; j <= jhi; j++)
@@ -1169,11 +1369,15 @@ int orc_comp_step(double *U, const orc_comp_params *P, double dt,
     /* source predictor-corrector, simulation.py:406-423 */
     if (have_src) {
         double *S_old = zalloc(N * 4), *S_new = zalloc(N * 4);
+        if (G) ext_sources_sph(U_old, NULL, N, P->grav, dt, S_old, G->x2d);
+        else
         ext_sources_h(U_old, NULL, N, P->grav, dt, S_old, P->heat_rate, P->heat_prof);
         for (int n = 0; n < 4; n++)
             for (int i = ilo; i <= ihi; i++)
                 for (int j = jlo; j <= jhi; j++)
                     U4(U, i, j, n) += dt * U4(S_old, i, j, n);
+        if (G) ext_sources_sph(U, U_old, N, P->grav, dt, S_new, G->x2d);
+        else
         ext_sources_h(U, U_old, N, P->grav, dt, S_new, P->heat_rate, P->heat_prof);
         for (int n = 0; n < 4; n++)
             for (int i = ilo; i <= ihi; i++)
@@ -1206,6 +1410,7 @@ int orc_comp_step(double *U, const orc_comp_params *P, double dt,
     free(q); free(xi); free(ldx); free(ldy); free(tmp); free(V_l); free(V_r);
     free(Uxl); free(Uxr); free(Uyl); free(Uyr); free(Fx); free(Fy);
     free(avx); free(avy);
+    free(Ux); free(Uy); free(qfx); free(qfy);
     return rc;
 }
 

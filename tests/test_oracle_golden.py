@@ -767,3 +767,72 @@ def test_incompressible_viscous_reference_regression_cavity(golden):
     assert np.abs(D[0][I] - g["gold"][0]).max() < 1e-10
     assert np.abs(D[1][I] - g["gold"][1]).max() < 1e-10
     assert np.abs(D[0][I] - g["run"][0]).max() < 1e-11
+
+
+# ---------------------------------------------------------------------------
+# row f4: compressible solver on a SphericalPolar grid
+# ---------------------------------------------------------------------------
+def nan_rel_err(a, b):
+    """max relative error where both are finite; NaNs (the reflect-odd ghost
+    faces of the reference hold sqrt(negative)) must sit at the same places"""
+    a, b = np.asarray(a), np.asarray(b)
+    na, nb = np.isnan(a), np.isnan(b)
+    assert np.array_equal(na, nb)
+    return max_rel_err(np.where(na, 0.0, a), np.where(nb, 0.0, b))
+
+
+def sph_geom(g, pre):
+    names = ("Lx", "Ly", "Ax", "Ay", "V", "dlogAx", "dlogAy", "x2d", "sint", "sinb", "sinc")
+    dom = g[pre + "g_domain"]
+    return orc.Geom({n: g[pre + "g_" + n] for n in names}, dom[0], dom[2])
+
+
+def oracle_sph_run(g, pre, nsteps):
+    from helpers import DtPolicy
+    bcs = [str(b) for b in g[pre + "bc"]]
+    P, cfl = meta_to_params(g[pre + "meta"], bcs, riemann="CGF")
+    geom = sph_geom(g, pre)
+    f0, mx = g[pre + "drv"]
+    fix = 0.005 if str(g[pre + "problem"]) == "advect" else -1.0
+    U = g[pre + "ic"].copy()
+    pol = DtPolicy(1.e30, f0, mx, fix_dt=fix)
+    dts = []
+    for _ in range(nsteps):
+        orc.comp_fill_bc(U, P.nx, P.ny, P.ng, bcs, P.gamma, P.grav, P.dy, (0.0,) * 4)
+        dt = pol(orc.comp_dt_geom(U, P.nx, P.ny, P.ng, geom, P.gamma, cfl))
+        rc, _ = orc.comp_step(U, P, dt, geom=geom)
+        assert rc == 0
+        pol.advance(dt)
+        dts.append(dt)
+    return U, np.array(dts)
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_oracle_spherical(golden, k):
+    """SphericalPolar geometry (mesh/patch.py:242-312): area / volume weighted
+    update, geometric terms in the tracing and the sources, pressure gradients
+    outside the fluxes, CGF interface states -- against dumps of the reference's
+    own functions and a short run"""
+    g = golden("comp_spherical")
+    pre = f"c{k}_"
+    bcs = [str(b) for b in g[pre + "bc"]]
+    P, cfl = meta_to_params(g[pre + "meta"], bcs, riemann="CGF")
+    geom = sph_geom(g, pre)
+    ng = P.ng
+    I = (slice(ng, -ng), slice(ng, -ng))
+    orc.set_scalar_pow(1)
+    try:
+        U = g[pre + "U0"].copy()
+        assert abs(orc.comp_dt_geom(U, P.nx, P.ny, ng, geom, P.gamma, cfl) /
+                   float(g[pre + "dt"]) - 1) < 1e-14 or str(g[pre + "problem"]) == "advect"
+        rc, st = orc.comp_step(U, P, float(g[pre + "dt"]), stages=True, geom=geom)
+        assert rc == 0
+        for nm in ("Uxl0", "Uxr0", "Uyl0", "Uyr0", "FxT", "FyT", "Uxl", "Uxr", "Uyl", "Uyr",
+                   "Fx0", "Fy0", "avx", "avy", "Fx", "Fy"):
+            assert nan_rel_err(st[nm], g[pre + nm]) < 1e-13, (k, nm, nan_rel_err(st[nm], g[pre + nm]))
+        assert max_rel_err(U[I], g[pre + "U1"][I]) < 1e-13
+        U, dts = oracle_sph_run(g, pre, len(g[pre + "dts"]))
+    finally:
+        orc.set_scalar_pow(0)
+    assert np.abs(dts / g[pre + "dts"] - 1).max() < 1e-12
+    assert max_rel_err(U[I], g[pre + "after"][I]) < 1e-11
