@@ -118,6 +118,22 @@ int pyrohip_state_set_heating(pyrohip_state *s, const double *profile);
 /* ghost value of variable n on its PYROHIP_BC_CONST side (upper y side only:
    "moving_lid", incompressible_viscous/BC.py:31-42; default 0)             */
 int pyrohip_state_set_const_bc(pyrohip_state *s, int n, double value);
+/* SphericalPolar grid (pyro/mesh/patch.py:242-312; x = r, y = theta) for the
+   compressible solver: the grid's arrays Lx, Ly, Ax, Ay, V, dlogAx, dlogAy, x2d,
+   each (qx, qy) row-major and evaluated by the caller with the reference's
+   expressions, and the qy sines that artificial_viscosity evaluates
+   (compressible/interface.py:345-347): sint[j] = sin((j + 1/2 - ng) dy + ymin),
+   sinb[j] = sin((j - 1/2 - ng) dy + ymin), sinc[j] = sin((j - ng) dy + ymin).
+   All arrays are copied.  With a geometry set, pyrohip_comp_dt / _step follow the
+   coord_type == 1 branches of compressible/simulation.py:117-147, 284-288,
+   330-398, unsplit_fluxes.py:411-488, interface.py:215-234, 331-376 and
+   riemann.py:1156-1171 (CGF solver only, like the reference); NULL removes it. */
+typedef struct pyrohip_geom {
+    const double *Lx, *Ly, *Ax, *Ay, *V, *dlogAx, *dlogAy, *x2d;
+    const double *sint, *sinb, *sinc;
+    double xmin, ymin;
+} pyrohip_geom;
+int pyrohip_state_set_geometry(pyrohip_state *s, const pyrohip_geom *g);
 /* Parameters of the "ramp" boundary of the double Mach reflection problem
    (compressible/BC.py:178-296).  x: the qx cell-centre coordinates of the grid
    (copied); cxoff = 0.5 dx sqrt(3); post / pre: post- and pre-shock values of

@@ -22,6 +22,13 @@ BC_CODE = {"outflow": BC_OUTFLOW, "neumann": BC_OUTFLOW,
            "halo": BC_HALO, "hse": BC_HSE, "ambient": BC_AMBIENT, "ramp": BC_RAMP,
            "moving_lid": BC_CONST}
 
+class GeomArrays(C.Structure):
+    """pyrohip_geom: the arrays of a SphericalPolar grid (include/pyrohip.h)"""
+    NAMES = ("Lx", "Ly", "Ax", "Ay", "V", "dlogAx", "dlogAy", "x2d", "sint", "sinb", "sinc")
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in NAMES] + \
+               [("xmin", C.c_double), ("ymin", C.c_double)]
+
+
 ERR_STATE = 10002
 UNIQUE_ID_BYTES = 128
 
@@ -87,6 +94,7 @@ _PROTOS = {
                              C.c_double, C.c_double, C.c_int, _DP],
     "pyrohip_inc_visc_store": [_VP, _VP, C.c_int],
     "pyrohip_state_set_const_bc": [_VP, C.c_int, C.c_double],
+    "pyrohip_state_set_geometry": [_VP, C.c_void_p],
     "pyrohip_mg_set_helmholtz": [_VP, C.c_double, C.c_double],
     "pyrohip_inc_advect": [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                            C.c_double, C.c_double, C.c_int],

@@ -114,6 +114,9 @@ namespace pyro {
 // in-place min all-reduce of one device double over the context's communicator
 // on its stream; no-op without a communicator (comm.hip / tests/emu/comm_emu.cpp)
 int comm_allreduce_min_device(pyrohip_ctx *c, double *d);
+// plain ghost fill (x sides, then y sides) of cnt planes laid out like the
+// state's planes n0.. with the boundary types of those variables (ctx.hip)
+int fill_bc_planes(pyrohip_state *s, double *planes, int n0, int cnt);
 }  // namespace pyro
 
 // launch on the context's stream, bracketed by events when profiling is on
@@ -122,6 +125,17 @@ int comm_allreduce_min_device(pyrohip_ctx *c, double *d);
         ::pyro::ProfScope _ps((c), (name));                                       \
         hipLaunchKernelGGL(kern, (grid), (block), (shmem), (c)->stream, __VA_ARGS__); \
     } while (0)
+
+namespace pyro {
+// device copy of a SphericalPolar grid's geometry (pyrohip_state_set_geometry):
+// 8 planes laid out like a state plane, 3 arrays of qy sines
+struct SphGeom {
+    double *base = nullptr;
+    const double *Lx, *Ly, *Ax, *Ay, *V, *dlAx, *dlAy, *x2d;
+    const double *sint, *sinb, *sinc;
+    double xmin, ymin;
+};
+}  // namespace pyro
 
 struct pyrohip_state {
     pyrohip_ctx *ctx = nullptr;
@@ -148,6 +162,7 @@ struct pyrohip_state {
     size_t work_planes = 0;
     int *d_flag = nullptr;    // positivity flag
     double *d_cval = nullptr; // per-variable ghost value of PYROHIP_BC_CONST sides
+    pyro::SphGeom *sph = nullptr;   // SphericalPolar geometry (compressible solver)
     double next_cfl_min = -1.0;  // min over interior of dx/(|u|+c) etc. of the
                                  // state after the last step (-1: unknown)
     bool cfl_is_global = false;  // ... already reduced over all ranks

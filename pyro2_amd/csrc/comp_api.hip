@@ -8,6 +8,8 @@ namespace exact {
 int comp_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_step_staged(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_fused(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_step_sph(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_dt_sph(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_stage_dump(pyrohip_state *, int, double *);
 int comp_sponge(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_rk_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
@@ -18,6 +20,8 @@ int comp_rk_rhs(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, i
 int comp_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_step_staged(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_fused(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_step_sph(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_dt_sph(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 }
 }  // namespace pyro
 
@@ -40,6 +44,9 @@ int pyrohip_comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, 
 {
     PYRO_TRY(check_comp(s, p));
     PYRO_REQUIRE(dt_out, "dt_out is NULL");
+    if (s->sph)
+        return p->fast_math ? fastm::comp_dt_sph(s, p, cfl, dt_out)
+                            : exact::comp_dt_sph(s, p, cfl, dt_out);
     return p->fast_math ? fastm::comp_dt(s, p, cfl, dt_out) : exact::comp_dt(s, p, cfl, dt_out);
 }
 
@@ -57,7 +64,13 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     PYRO_REQUIRE(p->kernel_set == 0 || p->kernel_set == 1, "kernel_set must be 0 or 1");
     PYRO_REQUIRE(p->riemann >= 0 && p->riemann <= 2, "riemann must be 0 (HLLC), 1 (CGF) or 2 (HLLC_lm)");
     int rc;
-    if (p->kernel_set == 1)
+    if (s->sph) {
+        // compressible/simulation.py:206-208: no HLLC on a SphericalPolar grid
+        PYRO_REQUIRE(p->riemann == 1, "a SphericalPolar grid needs the CGF Riemann solver");
+        PYRO_REQUIRE(!s->user_bc && !s->ramp_bc && !s->heat,
+                     "hse / ambient / ramp boundaries and heating are Cartesian-only");
+        rc = p->fast_math ? fastm::comp_step_sph(s, p, dt) : exact::comp_step_sph(s, p, dt);
+    } else if (p->kernel_set == 1)
         rc = p->fast_math ? fastm::comp_step_fused(s, p, dt) : exact::comp_step_fused(s, p, dt);
     else
         rc = p->fast_math ? fastm::comp_step_staged(s, p, dt) : exact::comp_step_staged(s, p, dt);

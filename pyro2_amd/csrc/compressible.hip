@@ -505,6 +505,386 @@ int comp_step_staged(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
 }
 
 // ===========================================================================
+// SphericalPolar grids (x = r, y = theta; mesh/patch.py:242-312): the
+// coord_type == 1 branches of the reference.  Reuses k_prim / k_xi; the other
+// stages get the geometry arrays: per-cell dt/Lx, dt/Ly and the geometric
+// source in the tracing (interface.py:106, 215-234), radial gravity and the
+// geometric source terms (simulation.py:117-124, 135-147), CGF interface
+// states whose pressure enters as a gradient outside the area-weighted flux
+// difference (riemann.py:1092-1096, 1156-1171; unsplit_fluxes.py:411-488;
+// simulation.py:330-398), the divergence of interface.py:331-364.
+// ===========================================================================
+enum {
+    W_PXT = W_NPLANES,   // pressure of the CGF interface state, transverse solve, x faces
+    W_PYT,
+    W_PX,                // ... final solve
+    W_PY,
+    W_SRC,               // 4: external sources in the state's order (density unused)
+    W_NPLANES_SPH = W_SRC + 4
+};
+
+struct SG {   // kernel-side geometry
+    const double *Lx, *Ly, *Ax, *Ay, *V, *dlAx, *dlAy, *x2d, *sint, *sinb, *sinc;
+    double xmin, ymin;
+};
+
+// get_external_sources, simulation.py:117-124 (U_old is None) on the interior
+__global__ __launch_bounds__(256) void k_sph_src(const double *__restrict__ U,
+                                                 double *__restrict__ S, Geom g, CP P, SG G)
+{
+    const int j = g.jlo + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = g.ilo + blockIdx.y;
+    if (j > g.jhi) return;
+    const size_t k = (size_t)i * g.pitch + j, pl = g.plane;
+    Cons Uc = load_cons(U, pl, k);
+    Uc.d = fmax(Uc.d, P.small_dens);   // clean_state ran before (k_prim stores it too)
+    double Sx = Uc.d * P.grav;
+    const double SE = Uc.mx * P.grav;
+    Sx += pdiv(Uc.my * Uc.my, Uc.d * G.x2d[k]);
+    const double Sy = pdiv(-Uc.mx * Uc.my, Uc.d);
+    S[k] = 0.0; S[pl + k] = SE; S[2 * pl + k] = Sx; S[3 * pl + k] = Sy;
+}
+
+__global__ __launch_bounds__(256) void k_sph_states(const double *__restrict__ W_,
+                                                    double *__restrict__ Wout, Geom g, CP P, SG G,
+                                                    int gx, int gy)
+{
+    int bx, by;
+    if (!xcd_block_2d(gx, gy, bx, by)) return;
+    const int j = g.jlo - 1 + bx * blockDim.x + threadIdx.x;
+    const int i = g.ilo - 1 + by;
+    if (j > g.jhi + 1) return;
+    const int p = g.pitch;
+    const size_t k = (size_t)i * p + j;
+    const size_t pl = g.plane;
+    const double *Q = W_ + (size_t)W_Q * pl;
+    const double xi = W_[(size_t)W_XI * pl + k];
+    double q0[4], dqx[4], dqy[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const double *a = Q + (size_t)n * pl;
+        q0[n] = a[k];
+        dqx[n] = xi * limited_slope(a[k - 2 * p], a[k - p], a[k], a[k + p], a[k + 2 * p],
+                                    P.limiter);
+        dqy[n] = xi * limited_slope(a[k - 2], a[k - 1], a[k], a[k + 1], a[k + 2], P.limiter);
+    }
+    const double cs = psqrt(pdiv(P.gamma * q0[3], q0[0]));   // interface.py:122
+    Trace lo, hi;
+    trace_states(q0[0], q0[1], q0[2], q0[3], dqx[0], dqx[1], dqx[2], dqx[3], P.gamma,
+                 pdiv(P.dt, G.Lx[k]), lo, hi);
+    {   // :216-224
+        const double rs = -0.5 * P.dt * G.dlAx[k] * q0[0] * q0[1];
+        hi.r += rs; lo.r += rs;
+        hi.p += rs * cs * cs; lo.p += rs * cs * cs;
+    }
+    Cons XM = prim_to_cons(Prim{lo.r, lo.un, lo.ut, lo.p}, P.gamma);
+    Cons XP = prim_to_cons(Prim{hi.r, hi.un, hi.ut, hi.p}, P.gamma);
+    trace_states(q0[0], q0[2], q0[1], q0[3], dqy[0], dqy[2], dqy[1], dqy[3], P.gamma,
+                 pdiv(P.dt, G.Ly[k]), lo, hi);
+    {   // :226-234
+        const double rs = -0.5 * P.dt * G.dlAy[k] * q0[0] * q0[2];
+        hi.r += rs; lo.r += rs;
+        hi.p += rs * cs * cs; lo.p += rs * cs * cs;
+    }
+    Cons YM = prim_to_cons(Prim{lo.r, lo.ut, lo.un, lo.p}, P.gamma);
+    Cons YP = prim_to_cons(Prim{hi.r, hi.ut, hi.un, hi.p}, P.gamma);
+    // apply_source_terms with the ghost-filled source planes, unsplit_fluxes.py:308-326
+    const double *S = W_ + (size_t)W_SRC * pl;
+    const double h = 0.5 * P.dt;
+    const double sE = h * S[pl + k], sx = h * S[2 * pl + k], sy = h * S[3 * pl + k];
+    XM.mx += sx; XM.my += sy; XM.E += sE;
+    XP.mx += sx; XP.my += sy; XP.E += sE;
+    YM.mx += sx; YM.my += sy; YM.E += sE;
+    YP.mx += sx; YP.my += sy; YP.E += sE;
+    store_cons(Wout + (size_t)W_XM * pl, pl, k, XM);
+    store_cons(Wout + (size_t)W_XP * pl, pl, k, XP);
+    store_cons(Wout + (size_t)W_YM * pl, pl, k, YM);
+    store_cons(Wout + (size_t)W_YP * pl, pl, k, YP);
+}
+
+// CGF interface state, its flux without the pressure and its pressure
+// (riemann_flux(return_cons=True) + cons_to_prim, unsplit_fluxes.py:411-423)
+__device__ __forceinline__ Cons sph_face(const Cons &Ul, const Cons &Ur, const CP &P, bool x,
+                                         bool wall, double &pface)
+{
+    const ConsN Uo = cgf_state(to_n(Ul, x), to_n(Ur, x), P.gamma, wall);
+    pface = cons_to_prim(from_n(Uo, x), P.gamma).p;
+    return from_n(cons_flux_n(Uo, P.gamma, x, false), x);
+}
+
+__global__ __launch_bounds__(256) void k_sph_riemann_t(const double *__restrict__ W_,
+                                                       double *__restrict__ Wout, Geom g, CP P,
+                                                       int gx, int gy)
+{
+    int bx, by;
+    if (!xcd_block_2d(gx, gy, bx, by)) return;
+    const int j = g.jlo - 1 + bx * blockDim.x + threadIdx.x;
+    const int i = g.ilo - 1 + by;
+    if (j > g.jhi + 1) return;
+    const int p = g.pitch;
+    const size_t k = (size_t)i * p + j;
+    const size_t pl = g.plane;
+    if (i >= g.ilo) {
+        double pf;
+        const Cons F = sph_face(load_cons(W_ + (size_t)W_XP * pl, pl, k - p),
+                                load_cons(W_ + (size_t)W_XM * pl, pl, k), P, true,
+                                P.solid_xl && i == g.ilo, pf);
+        store_cons(Wout + (size_t)W_FXT * pl, pl, k, F);
+        Wout[(size_t)W_PXT * pl + k] = pf;
+    }
+    if (j >= g.jlo) {
+        double pf;
+        const Cons F = sph_face(load_cons(W_ + (size_t)W_YP * pl, pl, k - 1),
+                                load_cons(W_ + (size_t)W_YM * pl, pl, k), P, false,
+                                P.solid_yl && j == g.jlo, pf);
+        store_cons(Wout + (size_t)W_FYT * pl, pl, k, F);
+        Wout[(size_t)W_PYT * pl + k] = pf;
+    }
+}
+
+__device__ __forceinline__ Cons corrected_g(const Cons &U, const Cons &Fhi, double Ahi,
+                                            const Cons &Flo, double Alo, double hv)
+{
+    Cons r;   // U += -hdtV*(F_hi*A_hi - F_lo*A_lo), unsplit_fluxes.py:447-471
+    r.d = U.d + (-hv * (Fhi.d * Ahi - Flo.d * Alo));
+    r.E = U.E + (-hv * (Fhi.E * Ahi - Flo.E * Alo));
+    r.mx = U.mx + (-hv * (Fhi.mx * Ahi - Flo.mx * Alo));
+    r.my = U.my + (-hv * (Fhi.my * Ahi - Flo.my * Alo));
+    return r;
+}
+
+// vertex divergence at (i-1/2, j-1/2) on the spherical grid, interface.py:331-364
+__device__ __forceinline__ double div_u_vertex_sph(const double *__restrict__ u,
+                                                   const double *__restrict__ v, size_t k, int p,
+                                                   int i, int j, const Geom &g, const CP &P,
+                                                   const SG &G)
+{
+    const double rr = (i + 0.5 - g.ng) * P.dx + G.xmin;
+    const double rl = (i - 0.5 - g.ng) * P.dx + G.xmin;
+    const double rc = (i - g.ng) * P.dx + G.xmin;
+    const double ur = 0.5 * (u[k] + u[k - 1]);
+    const double ul = 0.5 * (u[k - p] + u[k - p - 1]);
+    const double ux = pdiv(ur * rr * rr - ul * rl * rl, rc * rc * P.dx);
+    const double sint = G.sint[j], sinb = G.sinb[j], sinc = G.sinc[j];
+    double vy = 0.0;
+    if (sinc != 0.0) {
+        const double vt = 0.5 * (v[k] + v[k - p]);
+        const double vb = 0.5 * (v[k - 1] + v[k - p - 1]);
+        vy = pdiv(sint * vt - sinb * vb, rc * sinc * P.dy);
+    }
+    return ux + vy;
+}
+
+__global__ __launch_bounds__(256) void k_sph_final(const double *__restrict__ U,
+                                                   const double *__restrict__ W_,
+                                                   double *__restrict__ Wout, Geom g, CP P, SG G,
+                                                   int gx, int gy)
+{
+    int bx, by;
+    if (!xcd_block_2d(gx, gy, bx, by)) return;
+    const int j = g.jlo + bx * blockDim.x + threadIdx.x;
+    const int i = g.ilo + by;
+    if (j > g.jhi + 1) return;
+    const int p = g.pitch;
+    const size_t k = (size_t)i * p + j;
+    const size_t pl = g.plane;
+    const double hdt = 0.5 * P.dt;
+    const double hv = pdiv(hdt, G.V[k]);
+    const double *FXT = W_ + (size_t)W_FXT * pl, *FYT = W_ + (size_t)W_FYT * pl;
+    const double *PXT = W_ + (size_t)W_PXT * pl, *PYT = W_ + (size_t)W_PYT * pl;
+    const double *u = W_ + (size_t)(W_Q + 1) * pl, *v = W_ + (size_t)(W_Q + 2) * pl;
+    const double d00 = div_u_vertex_sph(u, v, k, p, i, j, g, P, G);
+    const Cons Uc = load_cons(U, pl, k);
+
+    if (j <= g.jhi) {   // x face (i,j)
+        Cons Uxl = corrected_g(load_cons(W_ + (size_t)W_XP * pl, pl, k - p),
+                               load_cons(FYT, pl, k - p + 1), G.Ay[k - p + 1],
+                               load_cons(FYT, pl, k - p), G.Ay[k - p], hv);
+        Cons Uxr = corrected_g(load_cons(W_ + (size_t)W_XM * pl, pl, k), load_cons(FYT, pl, k + 1),
+                               G.Ay[k + 1], load_cons(FYT, pl, k), G.Ay[k], hv);
+        // pressure gradient on the transverse momentum, :476-481 (Ly of cell (i,j))
+        Uxl.my += pdiv(-hdt * (PYT[k - p + 1] - PYT[k - p]), G.Ly[k]);
+        Uxr.my += pdiv(-hdt * (PYT[k + 1] - PYT[k]), G.Ly[k]);
+        double pf;
+        Cons F = sph_face(Uxl, Uxr, P, true, P.solid_xl && i == g.ilo, pf);
+        double avx = 0.0;
+        if (i <= g.ihi) {
+            const double d01 = div_u_vertex_sph(u, v, k + 1, p, i, j + 1, g, P, G);
+            const double divU_x = 0.5 * (d00 + d01);
+            avx = P.cvisc * fmax(-divU_x * G.Lx[k], 0.0);
+        }
+        const Cons Um = load_cons(U, pl, k - p);
+        F.d += avx * (Um.d - Uc.d);
+        F.E += avx * (Um.E - Uc.E);
+        F.mx += avx * (Um.mx - Uc.mx);
+        F.my += avx * (Um.my - Uc.my);
+        store_cons(Wout + (size_t)W_FX * pl, pl, k, F);
+        Wout[(size_t)W_PX * pl + k] = pf;
+    }
+    if (i <= g.ihi) {   // y face (i,j)
+        Cons Uyl = corrected_g(load_cons(W_ + (size_t)W_YP * pl, pl, k - 1),
+                               load_cons(FXT, pl, k + p - 1), G.Ax[k + p - 1],
+                               load_cons(FXT, pl, k - 1), G.Ax[k - 1], hv);
+        Cons Uyr = corrected_g(load_cons(W_ + (size_t)W_YM * pl, pl, k), load_cons(FXT, pl, k + p),
+                               G.Ax[k + p], load_cons(FXT, pl, k), G.Ax[k], hv);
+        Uyl.mx += pdiv(-hdt * (PXT[k + p - 1] - PXT[k - 1]), G.Lx[k]);
+        Uyr.mx += pdiv(-hdt * (PXT[k + p] - PXT[k]), G.Lx[k]);
+        double pf;
+        Cons F = sph_face(Uyl, Uyr, P, false, P.solid_yl && j == g.jlo, pf);
+        double avy = 0.0;
+        if (j <= g.jhi) {
+            const double d10 = div_u_vertex_sph(u, v, k + p, p, i + 1, j, g, P, G);
+            const double divU_y = 0.5 * (d00 + d10);
+            avy = P.cvisc * fmax(-divU_y * G.Ly[k], 0.0);
+        }
+        const Cons Um = load_cons(U, pl, k - 1);
+        F.d += avy * (Um.d - Uc.d);
+        F.E += avy * (Um.E - Uc.E);
+        F.mx += avy * (Um.mx - Uc.mx);
+        F.my += avy * (Um.my - Uc.my);
+        store_cons(Wout + (size_t)W_FY * pl, pl, k, F);
+        Wout[(size_t)W_PY * pl + k] = pf;
+    }
+}
+
+// conservative update with the area / volume arrays, the pressure gradients
+// and the source predictor-corrector, simulation.py:375-423
+__global__ __launch_bounds__(256) void k_sph_update(double *__restrict__ U,
+                                                    const double *__restrict__ W_, Geom g, CP P,
+                                                    SG G, int gx, int gy)
+{
+    int bx, by;
+    if (!xcd_block_2d(gx, gy, bx, by)) return;
+    const int j = g.jlo + bx * blockDim.x + threadIdx.x;
+    const int i = g.ilo + by;
+    if (j > g.jhi) return;
+    const int p = g.pitch;
+    const size_t pl = g.plane;
+    const size_t k = (size_t)i * p + j;
+    const double dtdV = pdiv(P.dt, G.V[k]);
+    const double *FX = W_ + (size_t)W_FX * pl, *FY = W_ + (size_t)W_FY * pl;
+    const double *PX = W_ + (size_t)W_PX * pl, *PY = W_ + (size_t)W_PY * pl;
+    double Un[4], Uo[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const double *fx = FX + (size_t)n * pl, *fy = FY + (size_t)n * pl;
+        Uo[n] = U[(size_t)n * pl + k];
+        Un[n] = Uo[n] + dtdV * (fx[k] * G.Ax[k] - fx[k + p] * G.Ax[k + p] + fy[k] * G.Ay[k] -
+                                fy[k + 1] * G.Ay[k + 1]);
+    }
+    Un[2] -= pdiv(P.dt * (PX[k + p] - PX[k]), G.Lx[k]);
+    Un[3] -= pdiv(P.dt * (PY[k + 1] - PY[k]), G.Ly[k]);
+    // S_old = S(U_old); U += dt S_old; S_new (time-centred x-momentum); U += dt/2 (S_new - S_old)
+    const double r = G.x2d[k], grav = P.grav, dt = P.dt;
+    const double Sx_g_old = Uo[0] * grav;
+    const double SE_old = Uo[2] * grav;
+    const double Sx_old = Sx_g_old + pdiv(Uo[3] * Uo[3], Uo[0] * r);
+    const double Sy_old = pdiv(-Uo[2] * Uo[3], Uo[0]);
+    Un[1] = Un[1] + dt * SE_old;
+    Un[2] = Un[2] + dt * Sx_old;
+    Un[3] = Un[3] + dt * Sy_old;
+    const double Sx_g_new = Un[0] * grav;
+    const double xmom_new = Un[2] + 0.5 * dt * (Sx_g_new - Sx_g_old);
+    const double SE_new = xmom_new * grav;
+    const double Sx_new = Sx_g_new + pdiv(Un[3] * Un[3], Un[0] * r);
+    const double Sy_new = pdiv(-Un[2] * Un[3], Un[0]);
+    U[k] = Un[0];   // the density source is zero: U += dt * 0, U += dt/2 * (0 - 0)
+    U[pl + k] = Un[1] + 0.5 * dt * (SE_new - SE_old);
+    U[2 * pl + k] = Un[2] + 0.5 * dt * (Sx_new - Sx_old);
+    U[3 * pl + k] = Un[3] + 0.5 * dt * (Sy_new - Sy_old);
+}
+
+// method_compute_timestep with Lx, Ly arrays (simulation.py:284-288), whole array
+__global__ __launch_bounds__(256) void k_sph_cfl(const double *__restrict__ U, Geom g,
+                                                 double gamma, const double *__restrict__ Lx,
+                                                 const double *__restrict__ Ly,
+                                                 double *__restrict__ partial)
+{
+    double m = INFINITY;
+    for (int i = blockIdx.y; i < g.qx; i += gridDim.y)
+        for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < g.qy; j += gridDim.x * blockDim.x) {
+            const size_t k = (size_t)i * g.pitch + j;
+            m = fmin(m, cfl_cell(load_cons(U, g.plane, k), gamma, Lx[k], Ly[k]));
+        }
+    m = block_reduce_min(m);
+    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = m;
+}
+
+static SG make_sg(const pyrohip_state *s)
+{
+    const SphGeom &h = *s->sph;
+    return SG{h.Lx, h.Ly, h.Ax, h.Ay, h.V, h.dlAx, h.dlAy, h.x2d, h.sint, h.sinb, h.sinc, h.xmin,
+              h.ymin};
+}
+
+int comp_dt_sph(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, double *dt_out)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    dim3 grid(8, 128), block(256);
+    const int nb = grid.x * grid.y;
+    PYRO_TRY(c->reduce.ensure((nb + kMinStageBlocks + 2) * sizeof(double)));
+    double *part = (double *)c->reduce.p;
+    hipLaunchKernelGGL(k_sph_cfl, grid, block, 0, c->stream, (const double *)s->d, g, p->gamma,
+                       s->sph->Lx, s->sph->Ly, part);
+    const double *dmin = launch_min_reduce(c->stream, part, nb);
+    PYRO_CHECK_HIP(hipGetLastError());
+    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, dmin, sizeof(double), hipMemcpyDeviceToHost,
+                                  c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    *dt_out = cfl * ((double *)c->reduce_host)[0];
+    return 0;
+}
+
+int comp_step_sph(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    PYRO_TRY(ensure_work(s, W_NPLANES_SPH));
+    const CP P = make_cp(p, dt, s);
+    const SG G = make_sg(s);
+    double *U = s->d;
+    double *W = s->work + geom_lead(g);
+    const dim3 block(256);
+    PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
+    int gx = (g.qy + 255) / 256, gy = g.qx;
+    PYRO_LAUNCH(c, "k_prim", k_prim, dim3(xcd_grid_1d(gx, gy)), block, 0, U, W, g, P, s->d_flag,
+                gx, gy);
+    // external sources on the interior, then their ghost cells like the
+    // reference's dens_src .. E_src variables (boundary types of the state)
+    double *S = W + (size_t)W_SRC * g.plane;
+    PYRO_LAUNCH(c, "k_sph_src", k_sph_src, dim3((g.ny + 255) / 256, g.nx), block, 0,
+                (const double *)U, S, g, P, G);
+    PYRO_TRY(fill_bc_planes(s, S, 0, 4));
+    gx = (g.ny + 2 + 255) / 256; gy = g.nx + 2;
+    const dim3 gridR1(xcd_grid_1d(gx, gy));
+    PYRO_LAUNCH(c, "k_xi", k_xi, gridR1, block, 0, (const double *)W,
+                W + (size_t)W_XI * g.plane, g, P, gx, gy);
+    PYRO_LAUNCH(c, "k_sph_states", k_sph_states, gridR1, block, 0, (const double *)W, W, g, P, G,
+                gx, gy);
+    PYRO_LAUNCH(c, "k_sph_riemann_t", k_sph_riemann_t, gridR1, block, 0, (const double *)W, W, g,
+                P, gx, gy);
+    gx = (g.ny + 1 + 255) / 256; gy = g.nx + 1;
+    PYRO_LAUNCH(c, "k_sph_final", k_sph_final, dim3(xcd_grid_1d(gx, gy)), block, 0,
+                (const double *)U, (const double *)W, W, g, P, G, gx, gy);
+    gx = (g.ny + 255) / 256; gy = g.nx;
+    PYRO_LAUNCH(c, "k_sph_update", k_sph_update, dim3(xcd_grid_1d(gx, gy)), block, 0, U,
+                (const double *)W, g, P, G, gx, gy);
+    PYRO_CHECK_HIP(hipGetLastError());
+    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, s->d_flag, sizeof(int), hipMemcpyDeviceToHost,
+                                  c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    s->next_cfl_min = -1.0;
+    s->cfl_is_global = false;
+    if (*(int *)c->reduce_host & 1) {
+        set_error("invalid state: min(rho) <= 0 or min(e) <= 0 on the interior "
+                  "(compressible/simulation.py:68-71)");
+        return PYROHIP_ERR_STATE;
+    }
+    return 0;
+}
+
+// ===========================================================================
 // compressible_rk: method-of-lines right-hand side k = -div F + S
 // (pyro/compressible_rk/fluxes.py:28-180, simulation.py:10-44).  Reuses
 // k_prim / k_xi; the face states are piecewise linear (no characteristic

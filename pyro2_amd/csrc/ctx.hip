@@ -269,6 +269,18 @@ __global__ void k_minmax_final(const double *__restrict__ partial, int nb, doubl
     if (threadIdx.x == 0) { out[0] = mn; out[1] = mx; }
 }
 
+int fill_bc_planes(pyrohip_state *s, double *planes, int n0, int cnt)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    hipLaunchKernelGGL(k_fill_x, dim3((g.qy + 255) / 256, 1, cnt), dim3(256), 0, c->stream, planes,
+                       g, (const int *)s->d_bc, n0);
+    hipLaunchKernelGGL(k_fill_y, dim3((g.qx + 15) / 16, 1, cnt), dim3(16, 16), 0, c->stream,
+                       planes, g, (const int *)s->d_bc, n0, (const double *)s->d_cval);
+    PYRO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace pyro
 
 using namespace pyro;
@@ -467,6 +479,7 @@ int pyrohip_state_destroy(pyrohip_state *s)
     if (s->heat_base) (void)hipFree(s->heat_base);
     if (s->d_flag) (void)hipFree(s->d_flag);
     if (s->d_cval) (void)hipFree(s->d_cval);
+    if (s->sph) { if (s->sph->base) (void)hipFree(s->sph->base); delete s->sph; }
     if (s->work) (void)hipFree(s->work);
     delete s;
     return 0;
@@ -723,6 +736,48 @@ int pyrohip_fill_bc(pyrohip_state *s, int n)
                            (const double *)s->d_cval);
     }
     PYRO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int pyrohip_state_set_geometry(pyrohip_state *s, const pyrohip_geom *hg)
+{
+    PYRO_REQUIRE(s, "NULL state");
+    pyrohip_ctx *c = s->ctx;
+    PYRO_CHECK_HIP(hipSetDevice(c->device));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (s->sph) {
+        if (s->sph->base) PYRO_CHECK_HIP(hipFree(s->sph->base));
+        delete s->sph;
+        s->sph = nullptr;
+    }
+    s->next_cfl_min = -1.0;
+    if (!hg) return 0;
+    const double *src[8] = {hg->Lx, hg->Ly, hg->Ax, hg->Ay, hg->V, hg->dlogAx, hg->dlogAy, hg->x2d};
+    for (int k = 0; k < 8; k++) PYRO_REQUIRE(src[k], "NULL geometry array");
+    PYRO_REQUIRE(hg->sint && hg->sinb && hg->sinc, "NULL geometry array");
+    const Geom &g = s->g;
+    const size_t qyp = ((size_t)g.qy + 7) & ~(size_t)7;
+    SphGeom *G = new SphGeom();
+    const size_t n = 8 * g.plane + 3 * qyp + 16;
+    PYRO_CHECK_HIP(hipMalloc((void **)&G->base, n * sizeof(double)));
+    PYRO_CHECK_HIP(hipMemsetAsync(G->base, 0, n * sizeof(double), c->stream));
+    double *planes = G->base + geom_lead(g);
+    for (int k = 0; k < 8; k++)
+        PYRO_CHECK_HIP(hipMemcpy2DAsync(planes + (size_t)k * g.plane, g.pitch * sizeof(double), src[k],
+                                        g.qy * sizeof(double), g.qy * sizeof(double), g.qx,
+                                        hipMemcpyHostToDevice, c->stream));
+    double *sines = G->base + 8 * g.plane;
+    const double *ssrc[3] = {hg->sint, hg->sinb, hg->sinc};
+    for (int k = 0; k < 3; k++)
+        PYRO_CHECK_HIP(hipMemcpyAsync(sines + k * qyp, ssrc[k], g.qy * sizeof(double),
+                                      hipMemcpyHostToDevice, c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));   // the host arrays are borrowed
+    G->Lx = planes; G->Ly = planes + g.plane; G->Ax = planes + 2 * g.plane;
+    G->Ay = planes + 3 * g.plane; G->V = planes + 4 * g.plane; G->dlAx = planes + 5 * g.plane;
+    G->dlAy = planes + 6 * g.plane; G->x2d = planes + 7 * g.plane;
+    G->sint = sines; G->sinb = sines + qyp; G->sinc = sines + 2 * qyp;
+    G->xmin = hg->xmin; G->ymin = hg->ymin;
+    s->sph = G;
     return 0;
 }
 

@@ -241,7 +241,10 @@ __device__ __forceinline__ void estimate_wave_speed(double rho_l, double u_l, do
 // State and flux components: d, E, mn (normal momentum), mt (transverse).
 struct ConsN { double d, E, mn, mt; };
 
-__device__ __forceinline__ ConsN cons_flux_n(const ConsN &U, double gamma, bool normal_is_x)
+// with_p = false: SphericalPolar grids keep the pressure out of the momentum
+// flux (riemann.py:1156, 1171)
+__device__ __forceinline__ ConsN cons_flux_n(const ConsN &U, double gamma, bool normal_is_x,
+                                             bool with_p = true)
 {
     // u, v in the reference are x/y velocities; (u*u + v*v) is evaluated as
     // written there, i.e. x-velocity squared first
@@ -256,7 +259,7 @@ __device__ __forceinline__ ConsN cons_flux_n(const ConsN &U, double gamma, bool 
     ConsN F;
     F.d = U.d * un;
     F.mn = U.mn * un;
-    F.mn += p;
+    if (with_p) F.mn += p;
     F.mt = U.mt * un;
     F.E = (U.E + p) * un;
     return F;
@@ -380,8 +383,8 @@ __device__ __forceinline__ ConsN hllc_lm_flux(const ConsN &Ul, const ConsN &Ur, 
 // :1083-1090), in the (normal, transverse) frame.  wall_zero: this is the
 // lower boundary face of a solid wall (riemann.py:274-286; the upper-wall
 // test of the reference can never fire).
-__device__ __forceinline__ ConsN cgf_flux(const ConsN &Ul, const ConsN &Ur, double gamma,
-                                          bool normal_is_x, bool wall_zero)
+__device__ __forceinline__ ConsN cgf_state(const ConsN &Ul, const ConsN &Ur, double gamma,
+                                           bool wall_zero)
 {
     const double smallc = 1.e-10, smallrho = 1.e-10, smallp = 1.e-10;
     const double rho_l = Ul.d;
@@ -457,7 +460,12 @@ __device__ __forceinline__ ConsN cgf_flux(const ConsN &Ul, const ConsN &Ur, doub
     Uo.mn = rho_s * un_s;
     Uo.mt = rho_s * ut_s;
     Uo.E = rhoe_s + 0.5 * rho_s * (un_s * un_s + ut_s * ut_s);
-    return cons_flux_n(Uo, gamma, normal_is_x);
+    return Uo;
+}
+__device__ __forceinline__ ConsN cgf_flux(const ConsN &Ul, const ConsN &Ur, double gamma,
+                                          bool normal_is_x, bool wall_zero)
+{
+    return cons_flux_n(cgf_state(Ul, Ur, gamma, wall_zero), gamma, normal_is_x);
 }
 
 // compressible.riemann dispatch: SOLVER 0 = HLLC, 1 = CGF

@@ -267,6 +267,26 @@ class DeviceState:
         with self.ctx.lock:
             check(self._l.pyrohip_inc_visc_store(self.h, mg.h, int(iw)))
 
+    def set_geometry(self, arrays, xmin, ymin):
+        """SphericalPolar geometry for the compressible solver: arrays = dict of
+        the grid's Lx, Ly, Ax, Ay, V, dlogAx, dlogAy, x2d (qx, qy) and the sines
+        sint, sinb, sinc (qy) of artificial_viscosity; None removes it"""
+        from ._lib import GeomArrays
+        with self.ctx.lock:
+            if arrays is None:
+                check(self._l.pyrohip_state_set_geometry(self.h, None))
+                return
+            G = GeomArrays()
+            keep = []
+            for n in GeomArrays.NAMES:
+                a = np.ascontiguousarray(arrays[n], dtype=np.float64)
+                want = (self.qy,) if n.startswith("sin") else (self.qx, self.qy)
+                assert a.shape == want, (n, a.shape, want)
+                keep.append(a)
+                setattr(G, n, dptr(a))
+            G.xmin, G.ymin = float(xmin), float(ymin)
+            check(self._l.pyrohip_state_set_geometry(self.h, C.byref(G)))
+
     def set_const_bc(self, n, value):
         """ghost value of variable n on its PYROHIP_BC_CONST ("moving_lid") side"""
         with self.ctx.lock:
