@@ -58,7 +58,15 @@ def init_data(my_data, rp):
         msg.bold("initializing the sedov problem...")
     g = my_data.grid
     if g.coord_type != 0:
-        msg.fail("ERROR: the device path implements the Cartesian sedov problem only")
+        # SphericalPolar branch (sedov.py:84-93): a hot sphere r < r_init
+        gamma = rp.get_param("eos.gamma")
+        my_data.get_var("density")[:, :] = 1.0
+        my_data.get_var("x-momentum")[:, :] = 0.0
+        my_data.get_var("y-momentum")[:, :] = 0.0
+        ener = my_data.get_var("energy")
+        ener[:, :] = 1.e-6 / (gamma - 1.0)
+        ener[np.asarray(g.x2d) < rp.get_param("sedov.r_init")] = 1.e6
+        return
     U = sedov_state(g.nx, g.ny, g.ng, rp.get_param("mesh.xmin"), rp.get_param("mesh.xmax"),
                     rp.get_param("mesh.ymin"), rp.get_param("mesh.ymax"),
                     rp.get_param("eos.gamma"), rp.get_param("sedov.r_init"),

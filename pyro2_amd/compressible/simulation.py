@@ -62,12 +62,17 @@ def prim_to_cons(q, gamma, ivars, myg):
 
 
 class Simulation(NullSimulation):
+    spherical_ok = True   # derived solvers without the geometry terms clear this
+
     def initialize(self, *, extra_vars=None, ng=4):
-        my_grid = grid_setup(self.rp, ng=ng)
+        my_grid = grid_setup(self.rp, ng=ng, spherical_ok=type(self).spherical_ok)
         my_data = self.data_class(my_grid)
         riemann_method = self.rp.get_param("compressible.riemann")
         if riemann_method not in ("HLLC", "CGF", "HLLC_lm"):
             msg.fail("ERROR: Riemann solver undefined")
+        if my_grid.coord_type == 1 and riemann_method != "CGF":   # simulation.py:206-208
+            msg.fail("ERROR: only the CGF Riemann solver is supported "
+                     "with SphericalPolar geometry")
         # compressible/simulation.py:212-214; both have device kernels
         bnd.define_bc("hse", BC.user, is_solid=False, device_code=BC_CODE["hse"])
         bnd.define_bc("ambient", BC.user, is_solid=False, device_code=BC_CODE["ambient"])
@@ -129,6 +134,10 @@ class Simulation(NullSimulation):
     def _device_state(self):
         """the state on the device, carrying the heating profile if there is one"""
         st = self.cc_data.device_state()
+        g = self.cc_data.grid
+        if g.coord_type == 1 and getattr(st, "_geometry_set", False) is False:
+            st.set_geometry(g.device_geometry(), g.xmin, g.ymin)
+            st._geometry_set = True
         h = self._heating()
         if h is not None and getattr(st, "_heating_set", False) is False:
             st.set_heating(h[1])

@@ -11,6 +11,8 @@ from ..util import msg
 
 
 class Simulation(CompressibleSimulation):
+    spherical_ok = False   # compressible_rk/fluxes.py has no geometry terms
+
     def initialize(self, *, extra_vars=None, ng=4):
         if self.rp.get_param("compressible.well_balanced"):
             msg.fail("ERROR: compressible.well_balanced is not carried by the device path")

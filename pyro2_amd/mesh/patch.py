@@ -109,6 +109,54 @@ class Cartesian2d(Grid2d):
                 f"nx = {self.nx}, ny = {self.ny}, ng = {self.ng}")
 
 
+class SphericalPolar(Grid2d):
+    """Spherical polar grid with azimuthal symmetry, x = r and y = theta
+    (patch.py:242-318): cell sizes, face areas, volumes and the dlog(area)
+    factors as 2-d arrays, built with the reference's expressions.  The
+    compressible solver hands them to the device once
+    (pyrohip_state_set_geometry); `device_geometry()` also carries the sines
+    that artificial_viscosity evaluates (compressible/interface.py:345-347)."""
+
+    def __init__(self, nx, ny, *, ng=1, xmin=0.2, xmax=1.0, ymin=0.0, ymax=1.0):
+        super().__init__(nx, ny, ng=ng, xmin=xmin, xmax=xmax, ymin=ymin, ymax=ymax)
+        assert ymin >= 0.0 and ymax <= np.pi, "y or \u03b8 should be within [0, \u03c0]."
+        assert xmin - ng * self.dx >= 0.0, \
+            "xmin (r-direction), must be large enough so ghost cell doesn't have negative x."
+        self.coord_type = 1
+        self.Lx = ArrayIndexer(np.full((self.qx, self.qy), self.dx), grid=self)   # dr
+        self.Ly = ArrayIndexer(self.x2d * self.dy, grid=self)                     # r dtheta
+        # |r_{i-1/2}^2 2 pi (cos(theta_{j+1/2}) - cos(theta_{j-1/2}))|
+        self.Ax = np.abs(-2.0 * np.pi * self.xl2d**2 * (np.cos(self.yr2d) - np.cos(self.yl2d)))
+        # |pi sin(theta_{j-1/2}) (r_{i+1/2}^2 - r_{i-1/2}^2)|
+        self.Ay = np.abs(np.pi * np.sin(self.yl2d) * (self.xr2d**2 - self.xl2d**2))
+        self.dlogAx = 2.0 / self.x2d
+        self.dlogAy = 1.0 / (np.tan(self.y2d) * self.x2d)
+        self.V = np.abs(-2.0 * np.pi / 3.0 * (np.cos(self.yr2d) - np.cos(self.yl2d)) *
+                        (self.xr2d - self.xl2d) *
+                        (self.xr2d**2 + self.xl2d**2 + self.xr2d * self.xl2d))
+
+    def device_geometry(self):
+        j = np.arange(self.qy)
+        out = {n: np.ascontiguousarray(getattr(self, n)) for n in
+               ("Lx", "Ly", "Ax", "Ay", "V", "dlogAx", "dlogAy", "x2d")}
+        # scalar by scalar like the reference's loop body
+        out["sint"] = np.array([np.sin((jj + 0.5 - self.ng) * self.dy + self.ymin) for jj in j])
+        out["sinb"] = np.array([np.sin((jj - 0.5 - self.ng) * self.dy + self.ymin) for jj in j])
+        out["sinc"] = np.array([np.sin((jj - self.ng) * self.dy + self.ymin) for jj in j])
+        return out
+
+    def coarse_like(self, N):
+        raise NotImplementedError("multigrid hierarchies are Cartesian")
+
+    fine_like = coarse_like
+
+    def __str__(self):
+        return ("Spherical Polar 2D Grid: Define x : r, y : \u03b8. "
+                f"xmin (r) = {self.xmin}, xmax= {self.xmax}, "
+                f"ymin = {self.ymin}, ymax = {self.ymax}, "
+                f"nx = {self.nx}, ny = {self.ny}, ng = {self.ng}")
+
+
 def _bc_row(bc, device_user_bc=False):
     """BC codes of one variable; user types without a device kernel get 0
     (their callback overwrites the ghost cells afterwards)"""

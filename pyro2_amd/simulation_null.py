@@ -18,9 +18,10 @@ def _param(rp, key, default, what):
         return default
 
 
-def grid_setup(rp, ng=1):
+def grid_setup(rp, ng=1, spherical_ok=False):
     """build the Grid2d described by the [mesh] parameters
-    (simulation_null.py:10-69)"""
+    (simulation_null.py:10-69).  spherical_ok: the calling solver has the
+    geometry terms (only the compressible solver does, as in the reference)"""
     nx = rp.get_param("mesh.nx")
     ny = rp.get_param("mesh.ny")
     xmin = _param(rp, "mesh.xmin", 0.0, "0.0")
@@ -28,9 +29,13 @@ def grid_setup(rp, ng=1):
     ymin = _param(rp, "mesh.ymin", 0.0, "0.0")
     ymax = _param(rp, "mesh.ymax", 1.0, "1.0")
     grid_type = _param(rp, "mesh.grid_type", "Cartesian2d", "Cartesian2D")
+    if grid_type == "SphericalPolar":
+        if not spherical_ok:
+            raise ValueError("mesh.grid_type = SphericalPolar is implemented by the "
+                             "compressible solver only")
+        return patch.SphericalPolar(nx, ny, xmin=xmin, xmax=xmax, ymin=ymin, ymax=ymax, ng=ng)
     if grid_type != "Cartesian2d":
-        raise ValueError("Unsupported grid type! (the device path implements Cartesian2d; "
-                         "SphericalPolar is out of scope, SURVEY.md 2 row 3)")
+        raise ValueError("Unsupported grid type!")
     return patch.Cartesian2d(nx, ny, xmin=xmin, xmax=xmax, ymin=ymin, ymax=ymax, ng=ng)
 
 

@@ -6,7 +6,7 @@ util/h5lite.py (same tree) when h5py is not installed."""
 import importlib
 
 from ..mesh import boundary as bnd
-from ..mesh.patch import Cartesian2d, CellCenterData2d
+from ..mesh.patch import Cartesian2d, CellCenterData2d, SphericalPolar
 
 
 def read(filename):
@@ -17,10 +17,9 @@ def read(filename):
         t = f.attrs.get("time")
         nsteps = f.attrs.get("nsteps")
         g = f["grid"].attrs
-        if g.get("coord_type", 0) == 1:
-            raise ValueError("SphericalPolar output cannot be read by the device package")
-        myg = Cartesian2d(int(g["nx"]), int(g["ny"]), ng=int(g["ng"]), xmin=g["xmin"],
-                          xmax=g["xmax"], ymin=g["ymin"], ymax=g["ymax"])
+        grid_class = SphericalPolar if g.get("coord_type", 0) == 1 else Cartesian2d   # io_pyro.py:52-60
+        myg = grid_class(int(g["nx"]), int(g["ny"]), ng=int(g["ng"]), xmin=g["xmin"],
+                         xmax=g["xmax"], ymin=g["ymin"], ymax=g["ymax"])
         names = list(f["state"])
         dt, dt_old = f.attrs.get("dt"), f.attrs.get("dt_old")
         params = dict(f["runtime parameters"].attrs.items()) \
