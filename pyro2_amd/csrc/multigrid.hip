@@ -182,6 +182,9 @@ __global__ __launch_bounds__(256) void k_mg_smooth(double *__restrict__ v,
 //               Measured at 4096^2, smooth(10): 651 us with v and f in LDS
 //               (32 x 128 region, K = 3) -> 491 us with f in registers
 //               -> ~350 us with the 64-row region and K = 5 (two launches).
+constexpr int MG_SMALL_TILES_DEFAULT = 128;         // workgroups aimed at on small levels (0: off;
+                                                   // env PYRO_MG_SMALL_TILES; measured 0 / 128 / 256 / 512:
+                                                   // 655 / 591 / 600 / 640 us per V-cycle at 512^2)
 constexpr int MGS_CELLS = 66 * 66;                 // single-tile levels: n <= 64
 constexpr size_t MGS_LDS = (size_t)2 * MGS_CELLS * sizeof(double);
 #ifndef PYRO_MGW_RI
@@ -455,11 +458,36 @@ __host__ __device__ inline int mgc_off(int l)    // LDS offset (doubles) of leve
 constexpr int MGC_LDS_DOUBLES = 2 * (16 + 36 + 100 + 324 + 1156 + 4356);
 constexpr size_t MGC_LDS = (size_t)MGC_LDS_DOUBLES * sizeof(double);
 
+// Synchronisation inside the coarse kernel: levels up to 16^2 (and the bottom
+// solve) are run by wave 0 alone -- a colour sweep there is a few LDS round
+// trips, and a workgroup barrier of 16 waves after every one of its three
+// phases costs more than the arithmetic.  Within one wave LDS operations
+// complete in program order, so a wave-level barrier (plus a fence that keeps
+// the compiler from moving LDS accesses across it) is all that is needed.
+#ifdef PYRO_EMU
+__device__ inline void mgc_wave_sync() { hipemu::wave_barrier(); }
+#else
+__device__ __forceinline__ void mgc_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#endif
+template <int NT>
+__device__ __forceinline__ void mgc_sync()
+{
+    if (NT == 64) mgc_wave_sync();
+    else __syncthreads();
+}
+constexpr int MGC_WAVE_TOP = 3;   // levels 0 .. 3 (n <= 16): wave 0 only
+
+template <int NT>
 __device__ inline void mgc_fill(double *V, int n, double dx, const MGBC &bc, bool use_val, int tid)
 {
     const int q = n + 2;
     // x sides over all j, then y sides over all i (corners from x-filled data)
-    for (int j = tid; j < q; j += MGC_NT) {
+    for (int j = tid; j < q; j += NT) {
         const double *v0 = use_val ? bc.val[0] : nullptr, *v1 = use_val ? bc.val[1] : nullptr;
         V[j] = (bc.code[0] == PYROHIP_BC_PERIODIC) ? V[n * q + j]
                                                     : ghost_lo(bc.code[0], V[q + j], v0, j, dx);
@@ -467,17 +495,18 @@ __device__ inline void mgc_fill(double *V, int n, double dx, const MGBC &bc, boo
                                  ? V[q + j]
                                  : ghost_hi(bc.code[1], V[n * q + j], v1, j, dx);
     }
-    __syncthreads();
-    for (int i = tid; i < q; i += MGC_NT) {
+    mgc_sync<NT>();
+    for (int i = tid; i < q; i += NT) {
         const double *v2 = use_val ? bc.val[2] : nullptr, *v3 = use_val ? bc.val[3] : nullptr;
         double *row = V + i * q;
         row[0] = (bc.code[2] == PYROHIP_BC_PERIODIC) ? row[n] : ghost_lo(bc.code[2], row[1], v2, i, dx);
         row[n + 1] = (bc.code[3] == PYROHIP_BC_PERIODIC) ? row[1]
                                                           : ghost_hi(bc.code[3], row[n], v3, i, dx);
     }
-    __syncthreads();
+    mgc_sync<NT>();
 }
 
+template <int NT>
 __device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, double dx,
                                   double alpha, double beta, int iters, const MGBC &bc,
                                   bool use_val, int tid)
@@ -485,20 +514,74 @@ __device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, dou
     const int q = n + 2;
     const double xc = beta / (dx * dx), yc = beta / (dx * dx);
     const double denom = alpha + 2.0 * xc + 2.0 * yc;
-    mgc_fill(V, n, dx, bc, use_val, tid);                       // MG.py:565
+    const double rdenom = 1.0 / denom;                          // correctly rounded: div_by
+    mgc_fill<NT>(V, n, dx, bc, use_val, tid);                   // MG.py:565
     const int half = n >> 1;                                    // cells of one colour per row
     for (int it = 0; it < 2 * iters; it++) {
         const int colour = it & 1;
-        for (int idx = tid; idx < n * half; idx += MGC_NT) {
+        for (int idx = tid; idx < n * half; idx += NT) {
             const int ri = (lg > 1) ? (idx >> (lg - 1)) : idx, h = idx - ri * half;
             const int i = 1 + ri;
             const int j = 1 + 2 * h + ((ri + colour) & 1);
             const int c = i * q + j;
-            V[c] = (F[c] + xc * (V[c + q] + V[c - q]) + yc * (V[c + 1] + V[c - 1])) / denom;
+            V[c] = div_by(F[c] + xc * (V[c + q] + V[c - q]) + yc * (V[c + 1] + V[c - 1]), denom,
+                          rdenom);
         }
-        __syncthreads();
-        mgc_fill(V, n, dx, bc, use_val, tid);                   // MG.py:598-599
+        mgc_sync<NT>();
+        mgc_fill<NT>(V, n, dx, bc, use_val, tid);               // MG.py:598-599
     }
+}
+
+// one level of the down leg (MG.py:722-735): smooth, residual -> global r,
+// its restriction -> f of the next coarser level
+template <int NT>
+__device__ inline void mgc_down(const MGCoarse &A, int l, double *lds, int tid)
+{
+    const int n = 2 << l, q = n + 2, nc = n >> 1, qc = nc + 2;
+    double *V = lds + mgc_off(l), *F = V + q * q;
+    double *Fc = lds + mgc_off(l - 1) + qc * qc;
+    const bool uv = A.finest && l == A.top;
+    mgc_smooth<NT>(V, F, n, l + 1, A.dx[l], A.alpha, A.beta, A.nsmooth, A.bc, uv, tid);
+    const double dx2 = A.dx[l] * A.dx[l];
+    for (int idx = tid; idx < nc * nc; idx += NT) {
+        const int ci = idx / nc, cj = idx - ci * nc;
+        double rr[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = 1 + 2 * ci + (k & 1), j = 1 + 2 * cj + (k >> 1);
+            const int c = i * q + j;
+            rr[k] = F[c] - A.alpha * V[c] +
+                    A.beta * ((V[c - q] + V[c + q] - 2 * V[c]) / dx2 +
+                              (V[c - 1] + V[c + 1] - 2 * V[c]) / dx2);
+            A.r[l][(size_t)i * A.pitch[l] + j] = rr[k];
+        }
+        // patch.py:660-662: (i,j) + (i+1,j) + (i,j+1) + (i+1,j+1)
+        Fc[(1 + ci) * qc + (1 + cj)] = 0.25 * (rr[0] + rr[1] + rr[2] + rr[3]);
+    }
+    mgc_sync<NT>();
+}
+
+// one level of the up leg (MG.py:745-758): prolong the coarse correction, smooth
+template <int NT>
+__device__ inline void mgc_up(const MGCoarse &A, int l, double *lds, int tid)
+{
+    const int n = 2 << l, q = n + 2, nc = n >> 1, qc = nc + 2;
+    double *V = lds + mgc_off(l), *F = V + q * q;
+    const double *Vc = lds + mgc_off(l - 1);
+    for (int idx = tid; idx < n * n; idx += NT) {
+        const int fi = idx / n, fj = idx - fi * n;
+        const int ck = (1 + (fi >> 1)) * qc + 1 + (fj >> 1);
+        const double c0 = Vc[ck];
+        const double m_x = 0.5 * (Vc[ck + qc] - Vc[ck - qc]);
+        const double m_y = 0.5 * (Vc[ck + 1] - Vc[ck - 1]);
+        double e;
+        if (fi & 1) e = (fj & 1) ? c0 + 0.25 * m_x + 0.25 * m_y : c0 + 0.25 * m_x - 0.25 * m_y;
+        else        e = (fj & 1) ? c0 - 0.25 * m_x + 0.25 * m_y : c0 - 0.25 * m_x - 0.25 * m_y;
+        V[(1 + fi) * q + (1 + fj)] += e;
+    }
+    mgc_sync<NT>();
+    mgc_smooth<NT>(V, F, n, l + 1, A.dx[l], A.alpha, A.beta, A.nsmooth, A.bc,
+                   A.finest && l == A.top, tid);
 }
 
 __global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
@@ -516,57 +599,21 @@ __global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
         }
     }
     __syncthreads();
-    // down leg (MG.py:722-735)
-    for (int l = A.top; l >= 1; l--) {
-        const int n = 2 << l, q = n + 2, nc = n >> 1, qc = nc + 2;
-        double *V = lds + mgc_off(l), *F = V + q * q;
-        double *Fc = lds + mgc_off(l - 1) + qc * qc;
-        const bool uv = A.finest && l == A.top;
-        mgc_smooth(V, F, n, l + 1, A.dx[l], A.alpha, A.beta, A.nsmooth, A.bc, uv, tid);
-        const double dx2 = A.dx[l] * A.dx[l];
-        // residual (MG.py:529-542) -> global r; restriction of it -> coarse f
-        for (int idx = tid; idx < nc * nc; idx += MGC_NT) {
-            const int ci = idx / nc, cj = idx - ci * nc;
-            double rr[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int i = 1 + 2 * ci + (k & 1), j = 1 + 2 * cj + (k >> 1);
-                const int c = i * q + j;
-                rr[k] = F[c] - A.alpha * V[c] +
-                        A.beta * ((V[c - q] + V[c + q] - 2 * V[c]) / dx2 +
-                                  (V[c - 1] + V[c + 1] - 2 * V[c]) / dx2);
-                A.r[l][(size_t)i * A.pitch[l] + j] = rr[k];
-            }
-            // patch.py:660-662: (i,j) + (i+1,j) + (i,j+1) + (i+1,j+1)
-            Fc[(1 + ci) * qc + (1 + cj)] = 0.25 * (rr[0] + rr[1] + rr[2] + rr[3]);
+    const int wtop = (A.top < MGC_WAVE_TOP) ? A.top : MGC_WAVE_TOP;
+    // down leg, levels 64^2 and 32^2: the whole workgroup
+    for (int l = A.top; l > wtop; l--) mgc_down<MGC_NT>(A, l, lds, tid);
+    // levels <= 16^2: wave 0, no workgroup barriers
+    if (tid < 64) {
+        for (int l = wtop; l >= 1; l--) mgc_down<64>(A, l, lds, tid);
+        {   // bottom solve (MG.py:776-778)
+            double *V = lds + mgc_off(0), *F = V + 16;
+            mgc_smooth<64>(V, F, 2, 1, A.dx[0], A.alpha, A.beta, A.nsmooth_bottom, A.bc,
+                           A.finest && A.top == 0, tid);
         }
-        __syncthreads();
+        for (int l = 1; l <= wtop; l++) mgc_up<64>(A, l, lds, tid);
     }
-    {   // bottom solve (MG.py:776-778)
-        double *V = lds + mgc_off(0), *F = V + 16;
-        mgc_smooth(V, F, 2, 1, A.dx[0], A.alpha, A.beta, A.nsmooth_bottom, A.bc,
-                   A.finest && A.top == 0, tid);
-    }
-    // up leg (MG.py:745-758)
-    for (int l = 1; l <= A.top; l++) {
-        const int n = 2 << l, q = n + 2, nc = n >> 1, qc = nc + 2;
-        double *V = lds + mgc_off(l), *F = V + q * q;
-        const double *Vc = lds + mgc_off(l - 1);
-        for (int idx = tid; idx < n * n; idx += MGC_NT) {
-            const int fi = idx / n, fj = idx - fi * n;
-            const int ck = (1 + (fi >> 1)) * qc + 1 + (fj >> 1);
-            const double c0 = Vc[ck];
-            const double m_x = 0.5 * (Vc[ck + qc] - Vc[ck - qc]);
-            const double m_y = 0.5 * (Vc[ck + 1] - Vc[ck - 1]);
-            double e;
-            if (fi & 1) e = (fj & 1) ? c0 + 0.25 * m_x + 0.25 * m_y : c0 + 0.25 * m_x - 0.25 * m_y;
-            else        e = (fj & 1) ? c0 - 0.25 * m_x + 0.25 * m_y : c0 - 0.25 * m_x - 0.25 * m_y;
-            V[(1 + fi) * q + (1 + fj)] += e;
-        }
-        __syncthreads();
-        mgc_smooth(V, F, n, l + 1, A.dx[l], A.alpha, A.beta, A.nsmooth, A.bc,
-                   A.finest && l == A.top, tid);
-    }
+    __syncthreads();
+    for (int l = wtop + 1; l <= A.top; l++) mgc_up<MGC_NT>(A, l, lds, tid);
     // write back: v of every level, f of the levels below the top
     for (int l = 0; l <= A.top; l++) {
         const int n = 2 << l, q = n + 2;
@@ -923,8 +970,22 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth)
                         MGS_LDS, A);
         } else {
             A.TI = MGW_RI - 4 * K; A.TJ = MGW_LP - 4 * K;
-            const int nti = (L.n + A.TI - 1) / A.TI;
             A.ntj = (L.n + A.TJ - 1) / A.TJ;
+            // Small levels: a launch lasts as long as ONE workgroup needs for its
+            // region (2K sweeps over up to 64 x 128 cells on one CU), while most of
+            // the 256 CUs idle.  Shorter tiles (fewer region rows per workgroup,
+            // more workgroups) cut that latency; the extra apron rows are free here.
+            static const int target = [] {
+                const char *e = getenv("PYRO_MG_SMALL_TILES");
+                return e ? atoi(e) : MG_SMALL_TILES_DEFAULT;
+            }();
+            if (target > 0) {
+                const int want = (target + A.ntj - 1) / A.ntj;
+                int ti = (L.n + want - 1) / want;
+                if (ti < 4) ti = 4;
+                if (ti < A.TI) A.TI = ti;
+            }
+            const int nti = (L.n + A.TI - 1) / A.TI;
             A.ntiles = nti * A.ntj;
             PYRO_LAUNCH(m->ctx, "k_mg_smooth_tile", (k_mg_smooth_tile<MGW_NT, MGW_LP>),
                         dim3(A.ntiles), dim3(MGW_NT), MGW_LDS, A);
