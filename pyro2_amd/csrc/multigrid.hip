@@ -200,6 +200,10 @@ struct MGTile {
     double dx, xc, yc, denom, rdenom;   // rdenom = RN(1 / denom), see div_by
     int K, TI, TJ, ntj, ntiles, single;
     MGBC bc;
+    // up leg: v += prolong(coarse v) while staging (patch.py:678-736 + MG.py:
+    // 745-748), instead of a separate pass over the level; nullptr: plain smooth
+    const double *cv;
+    int cpitch;
 };
 
 // a / b for a divisor that is the same in every cell, with rb = RN(1 / b)
@@ -280,6 +284,18 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
                     const size_t k = (size_t)gi * A.pitch + gj;
                     vv = A.vin[k];
                     ff = A.f[k];
+                    if (A.cv && gi >= 1 && gi <= n && gj >= 1 && gj <= n) {
+                        // k_mg_prolong_add's expression for fine cell (gi-1, gj-1)
+                        const int fi = gi - 1, fj = gj - 1;
+                        const size_t ck = (size_t)(1 + (fi >> 1)) * A.cpitch + 1 + (fj >> 1);
+                        const double c0 = A.cv[ck];
+                        const double m_x = 0.5 * (A.cv[ck + A.cpitch] - A.cv[ck - A.cpitch]);
+                        const double m_y = 0.5 * (A.cv[ck + 1] - A.cv[ck - 1]);
+                        double e;
+                        if (fi & 1) e = (fj & 1) ? c0 + 0.25 * m_x + 0.25 * m_y : c0 + 0.25 * m_x - 0.25 * m_y;
+                        else        e = (fj & 1) ? c0 - 0.25 * m_x + 0.25 * m_y : c0 - 0.25 * m_x - 0.25 * m_y;
+                        vv += e;
+                    }
                 }
                 V[at(r, c)] = vv;
                 if (q) fb = ff; else fa = ff;
@@ -932,7 +948,16 @@ static int mg_smooth_colour_launches(pyrohip_mg *m, int level, int nsmooth)
     return 0;
 }
 
-static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth)
+// can the prolongation of level-1's correction ride on the first smoothing
+// launch of `level`?  (wide tile kernel only)
+static bool mg_prolong_fusable(pyrohip_mg *m, int level, int nsmooth)
+{
+    const MGLevel &L = m->lev[level];
+    return !m->vc && m->smoother != 0 && nsmooth > 0 && level > 0 &&
+           (L.n + 2) * (L.n + 2) > MGS_CELLS;
+}
+
+static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong = false)
 {
     MGLevel &L = m->lev[level];
 #ifndef PYRO_EMU
@@ -955,6 +980,8 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth)
     A.rdenom = 1.0 / A.denom;
     A.bc = make_bc(m, level, true);
     A.single = ((L.n + 2) * (L.n + 2) <= MGS_CELLS) ? 1 : 0;   // whole level in one tile
+    A.cv = nullptr; A.cpitch = 0;
+    if (prolong) { A.cv = m->lev[level - 1].v; A.cpitch = m->lev[level - 1].pitch; }
     int kmax = (m->kmax >= 1 && m->kmax <= MGW_KMAX) ? m->kmax : MGW_KMAX;
     // levels up to 1024^2 live in L2 / Infinity Cache and are launch-latency
     // bound: fuse as many iterations per launch as the 32-row region allows
@@ -992,13 +1019,15 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth)
         }
         double *t = L.v; L.v = L.v2; L.v2 = t;
         left -= K;
+        A.cv = nullptr;   // only the first launch carries the prolongation
     }
     return 0;
 }
 
 // `corners`: also make the corner ghosts exact (needed only when the array is
 // handed to the host; no kernel reads corners)
-static int mg_smooth(pyrohip_mg *m, int level, int nsmooth, bool corners = true)
+static int mg_smooth(pyrohip_mg *m, int level, int nsmooth, bool corners = true,
+                     bool prolong = false)
 {
     if (m->vc) {   // variable coefficients: one launch per colour
         PYRO_TRY(mg_fill(m, level, 0));
@@ -1027,7 +1056,7 @@ static int mg_smooth(pyrohip_mg *m, int level, int nsmooth, bool corners = true)
     }
     // the tile kernel refreshes the edge ghosts itself on load (= the fill_BC
     // of MG.py:565) and leaves them current on exit
-    PYRO_TRY(mg_smooth_tiles(m, level, nsmooth));
+    PYRO_TRY(mg_smooth_tiles(m, level, nsmooth, prolong));
     m->corners_stale[level] = !corners;
     return corners ? mg_fill(m, level, 0) : 0;
 }
@@ -1139,9 +1168,10 @@ static int mg_vcycle(pyrohip_mg *m, int level)
         PYRO_TRY(mg_residual(m, level));                  // :724
         PYRO_TRY(mg_restrict(m, level));                  // :731-732
         PYRO_TRY(mg_vcycle(m, level - 1));                // :735
-        PYRO_TRY(mg_prolong_add(m, level));               // :745-748
+        const bool fuse = mg_prolong_fusable(m, level, m->nsmooth);
+        if (!fuse) PYRO_TRY(mg_prolong_add(m, level));    // :745-748 (else: while staging below)
         if (m->smoother == 0 || m->vc) PYRO_TRY(mg_fill(m, level, 0));   // :751 (tile smoother: on load)
-        PYRO_TRY(mg_smooth(m, level, m->nsmooth, false)); // :758
+        PYRO_TRY(mg_smooth(m, level, m->nsmooth, false, fuse)); // :758
     } else {
         PYRO_TRY(mg_smooth(m, level, m->nsmooth_bottom, false)); // :776
         if (m->smoother == 0 || m->vc) PYRO_TRY(mg_fill(m, level, 0));     // :778
