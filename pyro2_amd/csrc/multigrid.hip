@@ -464,6 +464,7 @@ struct MGCoarse {
     double alpha, beta;
     int nsmooth, nsmooth_bottom;
     MGBC bc;                                     // val[] only meaningful when finest
+    int wave_top;                                // levels 0 .. wave_top: wave 0 only (-1: none)
 };
 __host__ __device__ inline int mgc_off(int l)    // LDS offset (doubles) of level l's v
 {
@@ -474,12 +475,14 @@ __host__ __device__ inline int mgc_off(int l)    // LDS offset (doubles) of leve
 constexpr int MGC_LDS_DOUBLES = 2 * (16 + 36 + 100 + 324 + 1156 + 4356);
 constexpr size_t MGC_LDS = (size_t)MGC_LDS_DOUBLES * sizeof(double);
 
-// Synchronisation inside the coarse kernel: levels up to 16^2 (and the bottom
-// solve) are run by wave 0 alone -- a colour sweep there is a few LDS round
-// trips, and a workgroup barrier of 16 waves after every one of its three
-// phases costs more than the arithmetic.  Within one wave LDS operations
-// complete in program order, so a wave-level barrier (plus a fence that keeps
-// the compiler from moving LDS accesses across it) is all that is needed.
+// Synchronisation inside the coarse kernel.  The levels up to wave_top can be
+// run by wave 0 alone with wave-level barriers instead of workgroup barriers
+// (within one wave LDS operations complete in program order).  Measured on
+// MI355X (gpurun_out/mgc_wave.log, V-cycle of a 64^2 grid = this kernel):
+// 325 / 333 / 329 / 320 / 333 / 353 us for wave_top = -1 / 0 / 1 / 2 / 3 / 4 --
+// no gain: the kernel is bound by the dependent LDS round trips of the ~300
+// colour sweeps (update, x fill, y fill), not by the barriers, whose other 15
+// waves arrive at once.  Default: off (-1); env PYRO_MGC_WAVE_TOP.
 #ifdef PYRO_EMU
 __device__ inline void mgc_wave_sync() { hipemu::wave_barrier(); }
 #else
@@ -496,7 +499,7 @@ __device__ __forceinline__ void mgc_sync()
     if (NT == 64) mgc_wave_sync();
     else __syncthreads();
 }
-constexpr int MGC_WAVE_TOP = 3;   // levels 0 .. 3 (n <= 16): wave 0 only
+constexpr int MGC_WAVE_TOP = -1;   // default: every level by the whole workgroup
 
 template <int NT>
 __device__ inline void mgc_fill(double *V, int n, double dx, const MGBC &bc, bool use_val, int tid)
@@ -615,21 +618,27 @@ __global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
         }
     }
     __syncthreads();
-    const int wtop = (A.top < MGC_WAVE_TOP) ? A.top : MGC_WAVE_TOP;
-    // down leg, levels 64^2 and 32^2: the whole workgroup
-    for (int l = A.top; l > wtop; l--) mgc_down<MGC_NT>(A, l, lds, tid);
-    // levels <= 16^2: wave 0, no workgroup barriers
-    if (tid < 64) {
-        for (int l = wtop; l >= 1; l--) mgc_down<64>(A, l, lds, tid);
-        {   // bottom solve (MG.py:776-778)
-            double *V = lds + mgc_off(0), *F = V + 16;
-            mgc_smooth<64>(V, F, 2, 1, A.dx[0], A.alpha, A.beta, A.nsmooth_bottom, A.bc,
-                           A.finest && A.top == 0, tid);
+    const int wtop = (A.top < A.wave_top) ? A.top : A.wave_top;
+    // down leg of the larger levels: the whole workgroup
+    for (int l = A.top; l > wtop && l >= 1; l--) mgc_down<MGC_NT>(A, l, lds, tid);
+    if (wtop >= 0) {
+        // the smallest levels: wave 0, no workgroup barriers
+        if (tid < 64) {
+            for (int l = wtop; l >= 1; l--) mgc_down<64>(A, l, lds, tid);
+            {   // bottom solve (MG.py:776-778)
+                double *V = lds + mgc_off(0), *F = V + 16;
+                mgc_smooth<64>(V, F, 2, 1, A.dx[0], A.alpha, A.beta, A.nsmooth_bottom, A.bc,
+                               A.finest && A.top == 0, tid);
+            }
+            for (int l = 1; l <= wtop; l++) mgc_up<64>(A, l, lds, tid);
         }
-        for (int l = 1; l <= wtop; l++) mgc_up<64>(A, l, lds, tid);
+        __syncthreads();
+    } else {
+        double *V = lds + mgc_off(0), *F = V + 16;
+        mgc_smooth<MGC_NT>(V, F, 2, 1, A.dx[0], A.alpha, A.beta, A.nsmooth_bottom, A.bc,
+                           A.finest && A.top == 0, tid);
     }
-    __syncthreads();
-    for (int l = wtop + 1; l <= A.top; l++) mgc_up<MGC_NT>(A, l, lds, tid);
+    for (int l = (wtop > 0 ? wtop : 0) + 1; l <= A.top; l++) mgc_up<MGC_NT>(A, l, lds, tid);
     // write back: v of every level, f of the levels below the top
     for (int l = 0; l <= A.top; l++) {
         const int n = 2 << l, q = n + 2;
@@ -1152,6 +1161,11 @@ static int mg_coarse_vcycle(pyrohip_mg *m, int top)
     A.finest = (top == m->nlevels - 1) ? 1 : 0;
     A.alpha = m->alpha; A.beta = m->beta;
     A.nsmooth = m->nsmooth; A.nsmooth_bottom = m->nsmooth_bottom;
+    static const int wave_top = [] {
+        const char *e = getenv("PYRO_MGC_WAVE_TOP");
+        return e ? atoi(e) : MGC_WAVE_TOP;
+    }();
+    A.wave_top = wave_top;
     A.bc = make_bc(m, top, true);
     PYRO_LAUNCH(m->ctx, "k_mg_coarse_vcycle", k_mg_coarse_vcycle, dim3(1), dim3(MGC_NT), MGC_LDS,
                 A);
