@@ -525,6 +525,20 @@ __device__ inline void mgc_fill(double *V, int n, double dx, const MGBC &bc, boo
     mgc_sync<NT>();
 }
 
+// Red-black sweeps of one LDS-resident level.  The thread that updates a cell
+// next to a boundary also refreshes the ghost cell(s) that mirror it (like
+// k_mg_smooth): during a colour sweep a ghost cell is only read by the cell it
+// mirrors (or, on periodic sides, by a cell of the other colour), so this is
+// the reference's fill_BC after the sweep (MG.py:598-599) without a separate
+// pass and its two extra synchronisations.  Corner ghosts are not read by the
+// 5-point stencil; the closing fill makes them exact again.
+// Measured (tools/mgc_probe.py, gpurun_out/mgc_probe*.log): a colour sweep
+// costs ~0.6 us on the 2 x 2 level and ~0.8 us averaged over the levels,
+// whether ghosts are refreshed here or in two extra passes and whether one
+// wave or the workgroup runs it -- the kernel (~250 us of the V-cycle, 300
+// sweeps at nsmooth 10 / bottom 50) is bound by the dependent chain LDS read
+// -> 8 fp64 operations -> LDS write -> barrier of each sweep, not by the
+// number of barriers.
 template <int NT>
 __device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, double dx,
                                   double alpha, double beta, int iters, const MGBC &bc,
@@ -535,7 +549,11 @@ __device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, dou
     const double denom = alpha + 2.0 * xc + 2.0 * yc;
     const double rdenom = 1.0 / denom;                          // correctly rounded: div_by
     mgc_fill<NT>(V, n, dx, bc, use_val, tid);                   // MG.py:565
+    if (iters <= 0) return;
     const int half = n >> 1;                                    // cells of one colour per row
+    const int c0 = bc.code[0], c1 = bc.code[1], c2 = bc.code[2], c3 = bc.code[3];
+    const double *v0 = use_val ? bc.val[0] : nullptr, *v1 = use_val ? bc.val[1] : nullptr;
+    const double *v2 = use_val ? bc.val[2] : nullptr, *v3 = use_val ? bc.val[3] : nullptr;
     for (int it = 0; it < 2 * iters; it++) {
         const int colour = it & 1;
         for (int idx = tid; idx < n * half; idx += NT) {
@@ -543,12 +561,29 @@ __device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, dou
             const int i = 1 + ri;
             const int j = 1 + 2 * h + ((ri + colour) & 1);
             const int c = i * q + j;
-            V[c] = div_by(F[c] + xc * (V[c + q] + V[c - q]) + yc * (V[c + 1] + V[c - 1]), denom,
-                          rdenom);
+            const double vn = div_by(F[c] + xc * (V[c + q] + V[c - q]) + yc * (V[c + 1] + V[c - 1]),
+                                     denom, rdenom);
+            V[c] = vn;
+            if (i == 1) {
+                if (c0 == PYROHIP_BC_PERIODIC) V[(n + 1) * q + j] = vn;
+                else V[j] = ghost_lo(c0, vn, v0, j, dx);
+            }
+            if (i == n) {
+                if (c1 == PYROHIP_BC_PERIODIC) V[j] = vn;
+                else V[(n + 1) * q + j] = ghost_hi(c1, vn, v1, j, dx);
+            }
+            if (j == 1) {
+                if (c2 == PYROHIP_BC_PERIODIC) V[i * q + n + 1] = vn;
+                else V[i * q] = ghost_lo(c2, vn, v2, i, dx);
+            }
+            if (j == n) {
+                if (c3 == PYROHIP_BC_PERIODIC) V[i * q] = vn;
+                else V[i * q + n + 1] = ghost_hi(c3, vn, v3, i, dx);
+            }
         }
         mgc_sync<NT>();
-        mgc_fill<NT>(V, n, dx, bc, use_val, tid);               // MG.py:598-599
     }
+    mgc_fill<NT>(V, n, dx, bc, use_val, tid);                   // corners
 }
 
 // one level of the down leg (MG.py:722-735): smooth, residual -> global r,
