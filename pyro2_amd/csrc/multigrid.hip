@@ -586,6 +586,47 @@ __device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, dou
     mgc_fill<NT>(V, n, dx, bc, use_val, tid);                   // corners
 }
 
+// Bottom solve (the 2 x 2 level, nsmooth_bottom = 50 iterations = 100 colour
+// sweeps, MG.py:776-778) by ONE thread with the 4 x 4 array in registers: the
+// same updates in the same order as mgc_smooth (within a colour the two cells
+// do not read anything the other one writes), without 100 LDS round trips.
+__device__ inline void mgc_bottom_regs(double *V, const double *F, double dx, double alpha,
+                                       double beta, int iters, const MGBC &bc, bool use_val)
+{
+    const double xc = beta / (dx * dx), yc = beta / (dx * dx);
+    const double denom = alpha + 2.0 * xc + 2.0 * yc;
+    const double rdenom = 1.0 / denom;
+    const int c0 = bc.code[0], c1 = bc.code[1], c2 = bc.code[2], c3 = bc.code[3];
+    const double *v0 = use_val ? bc.val[0] : nullptr, *v1 = use_val ? bc.val[1] : nullptr;
+    const double *v2 = use_val ? bc.val[2] : nullptr, *v3 = use_val ? bc.val[3] : nullptr;
+    double v[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[i][j] = V[i * 4 + j];
+    const double f11 = F[5], f12 = F[6], f21 = F[9], f22 = F[10];
+    // cell (I, J) with literal indices; ghost refresh as in mgc_smooth (n = 2)
+#define MGC_RELAX(I, J, FF)                                                                  \
+    {                                                                                        \
+        const double vn = div_by(FF + xc * (v[I + 1][J] + v[I - 1][J]) +                     \
+                                     yc * (v[I][J + 1] + v[I][J - 1]), denom, rdenom);        \
+        v[I][J] = vn;                                                                        \
+        if (I == 1) { if (c0 == PYROHIP_BC_PERIODIC) v[3][J] = vn; else v[0][J] = ghost_lo(c0, vn, v0, J, dx); } \
+        if (I == 2) { if (c1 == PYROHIP_BC_PERIODIC) v[0][J] = vn; else v[3][J] = ghost_hi(c1, vn, v1, J, dx); } \
+        if (J == 1) { if (c2 == PYROHIP_BC_PERIODIC) v[I][3] = vn; else v[I][0] = ghost_lo(c2, vn, v2, I, dx); } \
+        if (J == 2) { if (c3 == PYROHIP_BC_PERIODIC) v[I][0] = vn; else v[I][3] = ghost_hi(c3, vn, v3, I, dx); } \
+    }
+    for (int it = 0; it < iters; it++) {
+        MGC_RELAX(1, 1, f11) MGC_RELAX(2, 2, f22)   // colour 0
+        MGC_RELAX(1, 2, f12) MGC_RELAX(2, 1, f21)   // colour 1
+    }
+#undef MGC_RELAX
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) V[i * 4 + j] = v[i][j];
+}
+
 // one level of the down leg (MG.py:722-735): smooth, residual -> global r,
 // its restriction -> f of the next coarser level
 template <int NT>
@@ -669,9 +710,14 @@ __global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
         }
         __syncthreads();
     } else {
+        // MG.py:565 fill, the sweeps in registers of thread 0, closing fill (corners)
         double *V = lds + mgc_off(0), *F = V + 16;
-        mgc_smooth<MGC_NT>(V, F, 2, 1, A.dx[0], A.alpha, A.beta, A.nsmooth_bottom, A.bc,
-                           A.finest && A.top == 0, tid);
+        const bool uv = A.finest && A.top == 0;
+        mgc_fill<MGC_NT>(V, 2, A.dx[0], A.bc, uv, tid);
+        if (tid == 0 && A.nsmooth_bottom > 0)
+            mgc_bottom_regs(V, F, A.dx[0], A.alpha, A.beta, A.nsmooth_bottom, A.bc, uv);
+        __syncthreads();
+        if (A.nsmooth_bottom > 0) mgc_fill<MGC_NT>(V, 2, A.dx[0], A.bc, uv, tid);
     }
     for (int l = (wtop > 0 ? wtop : 0) + 1; l <= A.top; l++) mgc_up<MGC_NT>(A, l, lds, tid);
     // write back: v of every level, f of the levels below the top
