@@ -695,3 +695,44 @@ def test_comp_spherical(dev, golden, k):
     # a Cartesian solver on this state would be a different algorithm: HLLC is refused
     with pytest.raises(Exception):
         s.comp_step(dev_params(meta, kernel_set=1)[0], dt)
+
+
+@pytest.mark.gpu
+def test_comp_spherical_512_vs_oracle(hip):
+    """SphericalPolar Sedov at 512 x 256 (the set-up of inputs.sedov.spherical),
+    12 steps with the driver's dt policy: device vs the C oracle, geometry from
+    pyro2_amd.mesh.patch.SphericalPolar"""
+    from helpers import DtPolicy
+    from pyro2_amd.mesh import patch
+    nx, ny, ng, gamma, cfl = 512, 256, 4, 1.4, 0.8
+    grid = patch.SphericalPolar(nx, ny, ng=ng, xmin=0.1, xmax=1.0, ymin=0.785, ymax=2.355)
+    geo = grid.device_geometry()
+    bcs = ["reflect-odd", "outflow", "outflow", "outflow"]
+    U0 = np.zeros((grid.qx, grid.qy, 4))
+    U0[:, :, 0] = 1.0
+    U0[:, :, 1] = 1.e-6 / (gamma - 1.0)
+    U0[:, :, 1][np.asarray(grid.x2d) < 0.13] = 1.e6
+    meta = [nx, ny, ng, grid.dx, grid.dy, gamma, 2, 1, 0.75, 0.85, 0.33, 0.1, 0.0, cfl]
+    P, _ = dev_params(meta, kernel_set=0, riemann="CGF", solid_xl=1, solid_yl=0)
+    Po, _ = meta_to_params(meta, bcs, riemann="CGF")
+    og = orc.Geom(geo, grid.xmin, grid.ymin)
+    s = comp_state(hip, nx, ny, bcs)
+    s.set_geometry(geo, grid.xmin, grid.ymin)
+    s.upload(U0)
+    Uo = U0.copy()
+    pol_d, pol_o = DtPolicy(1.e30), DtPolicy(1.e30)
+    for _ in range(12):
+        s.fill_bc()
+        dt = pol_d(s.comp_dt(P, cfl))
+        s.comp_step(P, dt)
+        pol_d.advance(dt)
+        orc.comp_fill_bc(Uo, nx, ny, ng, bcs, gamma, 0.0, grid.dy, (0.0,) * 4)
+        dto = pol_o(orc.comp_dt_geom(Uo, nx, ny, ng, og, gamma, cfl))
+        assert orc.comp_step(Uo, Po, dto, geom=og)[0] == 0
+        pol_o.advance(dto)
+        assert abs(dt / dto - 1) < 1e-12
+    U1 = s.download()
+    I = (slice(ng, -ng), slice(ng, -ng))
+    scale = np.maximum(np.abs(Uo[I]).max(axis=(0, 1)), 1e-3)
+    assert (np.abs(U1 - Uo)[I] / scale).max() <= TOL_EXACT
+    assert np.isfinite(U1[I]).all() and U1[I][:, :, 0].min() > 0

@@ -312,3 +312,42 @@ def test_incompressible_viscous_reference_regression_cavity(hip, golden, tmp_pat
     v = np.asarray(p.sim.cc_data.get_var("y-velocity").v())
     assert np.abs(u - g["gold"][0]).max() < 1e-10
     assert np.abs(v - g["gold"][1]).max() < 1e-10
+
+
+@pytest.mark.gpu
+def test_viscous_cavity_256_vs_oracle(hip):
+    """lid-driven cavity at 256^2 (Re 400): 3 steps from rest on the device
+    against the C oracle (12 multigrid solves, the lid boundary in the state
+    fill and in the velocity solves)"""
+    nx, ng, lim, proj, cfl, nu = 256, 4, 2, 2, 0.8, 0.0025
+    names = ["dirichlet", "dirichlet", "dirichlet", "moving_lid"]
+    phi = ["neumann"] * 4
+    q = nx + 2 * ng
+    D = np.zeros((6, q, q))
+    s = planar_state(hip, D, [names, names] + [phi] * 4)
+    s.set_const_bc(0, 1.0)
+    mk = lambda b, a, be: device.DeviceMG(hip, nx, bcs=b, alpha=a, beta=be, nsmooth=10,
+                                          nsmooth_bottom=50)
+    mgs = (mk(phi, 0.0, -1.0), mk(names, 1.0, 1.0), mk(names, 1.0, 1.0))
+    orc.incomp_set_viscous(nu)
+    try:
+        for n in range(3):
+            for k in (0, 1):
+                s.fill_bc(k)
+                codes = orc.bc_codes(names)
+                orc.fill_ghost(D[k], nx, nx, ng, codes)
+                D[k][:, ng + nx:] = 1.0 if k == 0 else 0.0
+            (ulo, uhi), (vlo, vhi) = s.minmax(0, buf=ng), s.minmax(1, buf=ng)
+            dt = cfl * min((1.0 / nx) / max(-ulo, uhi, 1e-12), (1.0 / nx) / max(-vlo, vhi, 1e-12))
+            assert abs(dt / orc.bg_dt(D[0], D[1], nx, nx, ng, 1.0 / nx, 1.0 / nx, cfl) - 1) < 1e-12
+            if n == 0:
+                dt *= 0.01
+            visc_step(s, mgs, nx, dt, lim, proj, nu)
+            orc.incomp_step(D, nx, ng, dt, lim, proj, bc_u=names, bc_v=names, bc_phi=phi)
+    finally:
+        orc.incomp_set_viscous(None)
+    got = planes_of(s)
+    I = (slice(ng, -ng), slice(ng, -ng))
+    assert np.abs(got[0][I] - D[0][I]).max() < 1e-11
+    assert np.abs(got[1][I] - D[1][I]).max() < 1e-11
+    assert np.abs(got[0][I]).max() > 1e-3     # the lid drives a flow
