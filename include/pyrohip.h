@@ -348,6 +348,17 @@ int pyrohip_inc_visc_rhs(pyrohip_state *s, pyrohip_mg *mg, int iw, int comp,
                          int igp, double dx, double dy, double dt, double nu,
                          int proj_type, double *source_norm);
 int pyrohip_inc_visc_store(pyrohip_state *s, pyrohip_mg *mg, int iw);
+/* burgers_viscous Simulation.evolve (pyro/burgers_viscous/simulation.py:9-89):
+   bgv_predict: edge states with the diffusion correction eps dt / 2 L(U) applied
+   before the transverse terms (burgers_viscous/interface.py:94-171), MAC
+   velocities.  bgv_rhs, once per component (comp 0: u, 1: v; iw its variable):
+   mg.f = w + dt eps / 2 L(w) - dt A with A from the unsplit fluxes, mg.v = 0
+   (interface.diffuse :27-91; mg: BCs of w, alpha = 1, beta = dt eps / 2); after
+   the solve pyrohip_inc_visc_store writes the solution back                  */
+int pyrohip_bgv_predict(pyrohip_state *s, int iu, int iv, double dx, double dy,
+                        double dt, int limiter, double eps);
+int pyrohip_bgv_rhs(pyrohip_state *s, pyrohip_mg *mg, int iw, int comp, double dx,
+                    double dy, double dt, double eps, double *source_norm);
 /* test hook: which 0-7 edge states u_xl u_xr u_yl u_yr v_xl v_xr v_yl v_yr,
    8 u_MAC, 9 v_MAC, 10 advect_x, 11 advect_y -> host (qx, qy)              */
 int pyrohip_inc_stage_dump(pyrohip_state *s, int which, double *host);

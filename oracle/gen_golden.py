@@ -1211,6 +1211,56 @@ def gen_mg_general():
     save("mg_general", **out)
 
 
+def gen_burgers_viscous():
+    """burgers_viscous (another multigrid caller: unsplit Burgers fluxes + one
+    Crank-Nicolson Helmholtz solve per velocity component): short runs of its
+    three problems and one more step from the end state"""
+    cases = [
+        ("converge", "inputs.converge.32", {"mesh.nx": 16, "mesh.ny": 16}, 5),
+        ("test", None, {"mesh.nx": 32, "mesh.ny": 32, "driver.max_dt_change": 2.0,
+                        "driver.init_tstep_factor": 0.5}, 5),
+        ("tophat", None, {"mesh.nx": 16, "mesh.ny": 16, "advection.limiter": 1,
+                          "diffusion.eps": 0.01}, 6),
+    ]
+    out = {"ncases": np.array(len(cases))}
+    for k, (prob, inp, d, nsteps) in enumerate(cases):
+        p = Pyro("burgers_viscous")
+        import importlib
+        mod = importlib.import_module(f"pyro.burgers_viscous.problems.{prob}")
+        if not hasattr(mod, "PROBLEM_PARAMS"):
+            # shipped without it (converge, tophat): register init_data by hand
+            p.add_problem(prob, mod.init_data)
+        p.initialize_problem(prob, inputs_file=inp or f"inputs.{prob}",
+                             inputs_dict=dict(d, **{"particles.do_particles": 0}))
+        sim = p.sim
+        pre = f"v{k}_"
+        out[pre + "ic"] = np.moveaxis(np.array(sim.cc_data.data), -1, 0)
+        dts = []
+        for _ in range(nsteps):
+            p.single_step()
+            dts.append(sim.dt)
+        out[pre + "dts"] = np.array(dts)
+        out[pre + "final"] = np.moveaxis(np.array(sim.cc_data.data), -1, 0)
+        sim.cc_data.fill_BC_all()
+        sim.compute_timestep()
+        out[pre + "U0"] = np.moveaxis(np.array(sim.cc_data.data), -1, 0)
+        out[pre + "dt"] = np.array(sim.dt)
+        sim.evolve()
+        out[pre + "U1"] = np.moveaxis(np.array(sim.cc_data.data), -1, 0)
+        g = sim.cc_data.grid
+        out[pre + "meta"] = np.array([g.nx, g.ng, sim.rp.get_param("advection.limiter"),
+                                      sim.rp.get_param("diffusion.eps"),
+                                      sim.rp.get_param("driver.cfl"),
+                                      sim.rp.get_param("driver.init_tstep_factor"),
+                                      sim.rp.get_param("driver.max_dt_change"),
+                                      sim.rp.get_param("driver.fix_dt"),
+                                      sim.rp.get_param("driver.tmax")])
+        out[pre + "bc"] = bc_names(sim.rp)
+        out[pre + "problem"] = np.array(prob)
+        print("burgers_viscous case", k, prob, "dt", sim.dt, "max u", np.abs(out[pre + "U1"][0]).max())
+    save("burgers_viscous", **out)
+
+
 def sph_geometry(g):
     """the arrays of patch.SphericalPolar + the sines artificial_viscosity
     evaluates (interface.py:345-347), with the reference's own expressions"""
@@ -1267,6 +1317,8 @@ def gen_compressible_spherical():
 
 
 if __name__ == "__main__":
+    if "burgers_viscous" in sys.argv[1:]:
+        gen_burgers_viscous()
     if "comp_spherical" in sys.argv[1:]:
         gen_compressible_spherical()
     if "mg_general" in sys.argv[1:]:

@@ -378,6 +378,20 @@ def _bc4(bcs):
     return np.ascontiguousarray(bc_codes(bcs))
 
 
+def bgv_step(u, v, nx, ng, dt, limiter, eps, bc_u=("periodic",) * 4, bc_v=("periodic",) * 4,
+             xmin=0.0, xmax=1.0, ymin=0.0, ymax=1.0):
+    """one burgers_viscous evolve() in place on u, v (qx, qy), ghost cells filled;
+    returns the V-cycle counts of the two Helmholtz solves"""
+    bu, bv = _bc4(bc_u), _bc4(bc_v)
+    ncyc = np.zeros(2, dtype=np.int32)
+    lib().orc_bgv_step(_p(u), _p(v), nx, ng, C.c_double(xmin), C.c_double(xmax),
+                       C.c_double(ymin), C.c_double(ymax), C.c_double(dt), limiter,
+                       C.c_double(eps), bu.ctypes.data_as(C.POINTER(C.c_int)),
+                       bv.ctypes.data_as(C.POINTER(C.c_int)),
+                       ncyc.ctypes.data_as(C.POINTER(C.c_int)))
+    return tuple(int(x) for x in ncyc)
+
+
 def incomp_step(D, nx, ng, dt, limiter=2, proj_type=2, bc_u=("periodic",) * 4,
                 bc_v=("periodic",) * 4, bc_phi=("periodic",) * 4,
                 xmin=0.0, xmax=1.0, ymin=0.0, ymax=1.0, stages=False):

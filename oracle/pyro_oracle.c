@@ -2007,6 +2007,9 @@ void orc_bg_edge_states(const double *u, const double *v, const double *gpx,
 {
     bg_edge_states_src(u, v, gpx, gpy, NULL, NULL, nx, ny, ng, dx, dy, dt, limiter, E);
 }
+/* burgers_viscous: + eps dt / 2 * Laplacian on the uncorrected states BEFORE the
+   transverse terms (burgers_viscous/interface.py:94-171); 0: off */
+static double g_bgv_eps = 0.0;
 /* sx, sy: other source terms (apply_other_source_terms, incomp_interface.py:186-254) */
 static void bg_edge_states_src(const double *u, const double *v, const double *gpx,
                                const double *gpy, const double *sx, const double *sy, int nx,
@@ -2040,6 +2043,20 @@ static void bg_edge_states_src(const double *u, const double *v, const double *g
             vyl[I2(i, j + 1)] = vc + 0.5 * (1.0 - dtdy * vc) * ldvy[k];
             vyr[k] = vc - 0.5 * (1.0 + dtdy * vc) * ldvy[k];
         }
+    if (g_bgv_eps != 0.0) {   /* apply_diffusion_corrections, get_lap (buf = 2) */
+        const double eps = g_bgv_eps;
+        for (int i = ilo - 2; i <= ihi + 2; i++)
+            for (int j = jlo - 2; j <= jhi + 2; j++) {
+                const size_t k = I2(i, j);
+                const double lu = (u[I2(i + 1, j)] - 2.0 * u[k] + u[I2(i - 1, j)]) / (dx * dx) +
+                                  (u[I2(i, j + 1)] - 2.0 * u[k] + u[I2(i, j - 1)]) / (dy * dy);
+                const double lv = (v[I2(i + 1, j)] - 2.0 * v[k] + v[I2(i - 1, j)]) / (dx * dx) +
+                                  (v[I2(i, j + 1)] - 2.0 * v[k] + v[I2(i, j - 1)]) / (dy * dy);
+                const double cu = 0.5 * eps * dt * lu, cv = 0.5 * eps * dt * lv;
+                uxl[I2(i + 1, j)] += cu;  uyl[I2(i, j + 1)] += cu;  uxr[k] += cu;  uyr[k] += cu;
+                vxl[I2(i + 1, j)] += cv;  vyl[I2(i, j + 1)] += cv;  vxr[k] += cv;  vyr[k] += cv;
+            }
+    }
     /* transverse terms from the uncorrected states */
     double *uhat = zalloc(N), *vhat = zalloc(N), *uxi = zalloc(N), *vxi = zalloc(N),
            *uyi = zalloc(N), *vyi = zalloc(N);
@@ -2127,6 +2144,70 @@ void orc_bg_step(double *u, double *v, int nx, int ny, int ng, double dx,
             v[k] = v[k] + dtdx * (fvx[k] - fvx[I2(i + 1, j)]) + dtdy * (fvy[k] - fvy[I2(i, j + 1)]);
         }
     free(E); free(fux); free(fvx); free(fuy); free(fvy);
+#undef I2
+}
+
+/* burgers_viscous Simulation.evolve (pyro/burgers_viscous/simulation.py:9-89) with
+   interface.diffuse (burgers_viscous/interface.py:27-91): advective terms from
+   the unsplit fluxes, then one Crank-Nicolson Helmholtz solve per component.
+   u, v: ghost cells filled; bc_u / bc_v: their boundary codes.  ncyc[2]: V-cycles */
+void orc_bgv_step(double *u, double *v, int nx, int ng, double xmin, double xmax, double ymin,
+                  double ymax, double dt, int limiter, double eps, const int *bc_u,
+                  const int *bc_v, int *ncyc)
+{
+    const int ny = nx, qx = nx + 2 * ng, qy = ny + 2 * ng;
+    const int ilo = ng, ihi = ng + nx - 1, jlo = ng, jhi = ng + ny - 1;
+    const size_t N = (size_t)qx * qy;
+    const double dx = (xmax - xmin) / nx, dy = (ymax - ymin) / ny;
+#define I2(i, j) ((size_t)(i) * qy + (j))
+    double *E = zalloc(8 * N);
+    g_bgv_eps = eps;
+    orc_bg_edge_states(u, v, NULL, NULL, nx, ny, ng, dx, dy, dt, limiter, E);
+    g_bgv_eps = 0.0;
+    /* construct_unsplit_fluxes, burgers_interface.py:178-233 */
+    double *fux = zalloc(N), *fvx = zalloc(N), *fuy = zalloc(N), *fvy = zalloc(N);
+    for (int i = ilo - 2; i <= ihi + 2; i++)
+        for (int j = jlo - 2; j <= jhi + 2; j++) {
+            const size_t k = I2(i, j);
+            const double um = bg_upwind(E[E_UXL * N + k], E[E_UXR * N + k],
+                                        bg_riemann(E[E_UXL * N + k], E[E_UXR * N + k]));
+            const double vm = bg_upwind(E[E_VYL * N + k], E[E_VYR * N + k],
+                                        bg_riemann(E[E_VYL * N + k], E[E_VYR * N + k]));
+            fux[k] = 0.5 * bg_upwind(E[E_UXL * N + k], E[E_UXR * N + k], um) * um;
+            fvx[k] = 0.5 * bg_upwind(E[E_VXL * N + k], E[E_VXR * N + k], um) * um;
+            fuy[k] = 0.5 * bg_upwind(E[E_UYL * N + k], E[E_UYR * N + k], vm) * vm;
+            fvy[k] = 0.5 * bg_upwind(E[E_VYL * N + k], E[E_VYR * N + k], vm) * vm;
+        }
+    double *Au = zalloc(N), *Av = zalloc(N);
+    for (int i = ilo; i <= ihi; i++)
+        for (int j = jlo; j <= jhi; j++) {
+            const size_t k = I2(i, j);
+            Au[k] = (fux[I2(i + 1, j)] - fux[k]) / dx + (fuy[I2(i, j + 1)] - fuy[k]) / dy;
+            Av[k] = (fvx[I2(i + 1, j)] - fvx[k]) / dx + (fvy[I2(i, j + 1)] - fvy[k]) / dy;
+        }
+    for (int comp = 0; comp < 2; comp++) {   /* diffuse(), x-velocity first */
+        double *a = comp ? v : u;
+        const double *A = comp ? Av : Au;
+        orc_mg *m = orc_mg_create(nx, xmin, xmax, ymin, ymax, comp ? bc_v : bc_u, 1.0,
+                                  0.5 * dt * eps, 10, 50);
+        const int L = m->nlevels - 1, n = nx;
+        for (int i = 0; i < nx; i++)
+            for (int j = 0; j < ny; j++) {
+                const int gi = ilo + i, gj = jlo + j;
+                const size_t k = I2(gi, gj);
+                const double lap = (a[I2(gi + 1, gj)] - 2.0 * a[k] + a[I2(gi - 1, gj)]) / (dx * dx) +
+                                   (a[I2(gi, gj + 1)] - 2.0 * a[k] + a[I2(gi, gj - 1)]) / (dy * dy);
+                m->f[L][(size_t)(i + 1) * (n + 2) + j + 1] = a[k] + 0.5 * dt * eps * lap - dt * A[k];
+            }
+        orc_mg_init_rhs_norm(m);
+        orc_mg_solve(m, 1.e-12);   /* init_zeros: the guess is 0 */
+        if (ncyc) ncyc[comp] = m->num_cycles;
+        for (int i = 0; i < nx; i++)
+            for (int j = 0; j < ny; j++)
+                a[I2(ilo + i, jlo + j)] = m->v[L][(size_t)(i + 1) * (n + 2) + j + 1];
+        orc_mg_free(m);
+    }
+    free(E); free(fux); free(fvx); free(fuy); free(fvy); free(Au); free(Av);
 #undef I2
 }
 

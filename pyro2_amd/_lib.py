@@ -93,6 +93,10 @@ _PROTOS = {
     "pyrohip_inc_visc_rhs": [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                              C.c_double, C.c_double, C.c_int, _DP],
     "pyrohip_inc_visc_store": [_VP, _VP, C.c_int],
+    "pyrohip_bgv_predict": [_VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
+                            C.c_double],
+    "pyrohip_bgv_rhs": [_VP, _VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                        _DP],
     "pyrohip_state_set_const_bc": [_VP, C.c_int, C.c_double],
     "pyrohip_state_set_geometry": [_VP, C.c_void_p],
     "pyrohip_mg_set_helmholtz": [_VP, C.c_double, C.c_double],

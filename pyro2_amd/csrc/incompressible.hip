@@ -48,6 +48,7 @@ struct BP {   // kernel parameters
     double dx, dy, dt, dtdx, dtdy;
     int limiter;
     double nu;   // > 0: viscous source in the predictor (incompressible_viscous)
+    double eps;  // != 0: diffusion correction of the uncorrected states (burgers_viscous)
 };
 
 // one thread per cell of B1
@@ -70,14 +71,30 @@ __global__ __launch_bounds__(256) void k_bg_hat(const double *__restrict__ u,
     const double ldvx = limited_slope(v[k - 2 * p], v[k - p], vc, v[k + p], v[k + 2 * p], P.limiter);
     const double lduy = limited_slope(u[k - 2], u[k - 1], uc, u[k + 1], u[k + 2], P.limiter);
     const double ldvy = limited_slope(v[k - 2], v[k - 1], vc, v[k + 1], v[k + 2], P.limiter);
-    W[W_UXL * pl + k + p] = uc + 0.5 * (1.0 - P.dtdx * uc) * ldux;
-    W[W_UXR * pl + k] = uc - 0.5 * (1.0 + P.dtdx * uc) * ldux;
-    W[W_VXL * pl + k + p] = vc + 0.5 * (1.0 - P.dtdx * uc) * ldvx;
-    W[W_VXR * pl + k] = vc - 0.5 * (1.0 + P.dtdx * uc) * ldvx;
-    W[W_UYL * pl + k + 1] = uc + 0.5 * (1.0 - P.dtdy * vc) * lduy;
-    W[W_UYR * pl + k] = uc - 0.5 * (1.0 + P.dtdy * vc) * lduy;
-    W[W_VYL * pl + k + 1] = vc + 0.5 * (1.0 - P.dtdy * vc) * ldvy;
-    W[W_VYR * pl + k] = vc - 0.5 * (1.0 + P.dtdy * vc) * ldvy;
+    double uxl = uc + 0.5 * (1.0 - P.dtdx * uc) * ldux;
+    double uxr = uc - 0.5 * (1.0 + P.dtdx * uc) * ldux;
+    double vxl = vc + 0.5 * (1.0 - P.dtdx * uc) * ldvx;
+    double vxr = vc - 0.5 * (1.0 + P.dtdx * uc) * ldvx;
+    double uyl = uc + 0.5 * (1.0 - P.dtdy * vc) * lduy;
+    double uyr = uc - 0.5 * (1.0 + P.dtdy * vc) * lduy;
+    double vyl = vc + 0.5 * (1.0 - P.dtdy * vc) * ldvy;
+    double vyr = vc - 0.5 * (1.0 + P.dtdy * vc) * ldvy;
+    if (P.eps != 0.0) {   // apply_diffusion_corrections, burgers_viscous/interface.py:94-171
+        const double dx2 = P.dx * P.dx, dy2 = P.dy * P.dy;
+        const double lu = (u[k + p] - 2.0 * uc + u[k - p]) / dx2 + (u[k + 1] - 2.0 * uc + u[k - 1]) / dy2;
+        const double lv = (v[k + p] - 2.0 * vc + v[k - p]) / dx2 + (v[k + 1] - 2.0 * vc + v[k - 1]) / dy2;
+        const double cu = 0.5 * P.eps * P.dt * lu, cv = 0.5 * P.eps * P.dt * lv;
+        uxl += cu; uyl += cu; uxr += cu; uyr += cu;
+        vxl += cv; vyl += cv; vxr += cv; vyr += cv;
+    }
+    W[W_UXL * pl + k + p] = uxl;
+    W[W_UXR * pl + k] = uxr;
+    W[W_VXL * pl + k + p] = vxl;
+    W[W_VXR * pl + k] = vxr;
+    W[W_UYL * pl + k + 1] = uyl;
+    W[W_UYR * pl + k] = uyr;
+    W[W_VYL * pl + k + 1] = vyl;
+    W[W_VYR * pl + k] = vyr;
 }
 
 // apply_transverse_corrections (burgers_interface.py:89-175) and
@@ -316,6 +333,30 @@ __global__ __launch_bounds__(256) void k_inc_visc_store(double *__restrict__ w,
     w[(size_t)(g.ilo + ii) * g.pitch + g.jlo + jj] = mv[(size_t)(ii + 1) * mpitch + jj + 1];
 }
 
+// burgers_viscous: advective term from the unsplit fluxes (simulation.py:64-73,
+// construct_unsplit_fluxes burgers_interface.py:178-233) and the right-hand side
+// of interface.diffuse (burgers_viscous/interface.py:66-72) for component w
+__global__ __launch_bounds__(256) void k_bgv_rhs(const double *__restrict__ w,
+                                                 const double *__restrict__ W, Geom g,
+                                                 double *__restrict__ f, int mpitch, BP P, int comp)
+{
+    const int jj = blockIdx.x * blockDim.x + threadIdx.x, ii = blockIdx.y;
+    if (jj >= g.ny) return;
+    const int p = g.pitch;
+    const size_t pl = g.plane;
+    const size_t k = (size_t)(g.ilo + ii) * p + g.jlo + jj;
+    const double *um = W + W_UMAC * pl, *vm = W + W_VMAC * pl;
+    const int XL = comp ? C_VXL : C_UXL, XR = comp ? C_VXR : C_UXR;
+    const int YL = comp ? C_VYL : C_UYL, YR = comp ? C_VYR : C_UYR;
+    auto fx = [&](size_t kk) { return 0.5 * bg_upwind(W[XL * pl + kk], W[XR * pl + kk], um[kk]) * um[kk]; };
+    auto fy = [&](size_t kk) { return 0.5 * bg_upwind(W[YL * pl + kk], W[YR * pl + kk], vm[kk]) * vm[kk]; };
+    const double A = (fx(k + p) - fx(k)) / P.dx + (fy(k + 1) - fy(k)) / P.dy;
+    const double a = w[k];
+    const double lap = (w[k + p] - 2.0 * a + w[k - p]) / (P.dx * P.dx) +
+                       (w[k + 1] - 2.0 * a + w[k - 1]) / (P.dy * P.dy);
+    f[(size_t)(ii + 1) * mpitch + jj + 1] = a + 0.5 * P.dt * P.eps * lap - P.dt * A;
+}
+
 // solution gradient (MG.py:439-469) and the velocity / grad p update
 // (simulation.py:329-339; :108-109 with fac = 1 and gp_mode 0)
 __global__ __launch_bounds__(256) void k_inc_proj_update(double *__restrict__ u,
@@ -356,11 +397,11 @@ static int bg_work(pyrohip_state *s)
     return 0;
 }
 
-static BP make_bp(double dx, double dy, double dt, int limiter, double nu = 0.0)
+static BP make_bp(double dx, double dy, double dt, int limiter, double nu = 0.0, double eps = 0.0)
 {
     BP P;
     P.dx = dx; P.dy = dy; P.dt = dt; P.dtdx = dt / dx; P.dtdy = dt / dy; P.limiter = limiter;
-    P.nu = nu;
+    P.nu = nu; P.eps = eps;
     return P;
 }
 
@@ -522,6 +563,32 @@ int pyrohip_inc_visc_rhs(pyrohip_state *s, pyrohip_mg *m, int iw, int comp, int 
                 proj_type);
     PYRO_CHECK_HIP(hipGetLastError());
     PYRO_TRY(mg_solution_written(m));
+    return pyrohip_mg_init_rhs_norm(m, source_norm);
+}
+
+int pyrohip_bgv_predict(pyrohip_state *s, int iu, int iv, double dx, double dy, double dt,
+                        int limiter, double eps)
+{
+    PYRO_REQUIRE(s, "NULL state");
+    BG_CHECK_VARS(s, iu, iv);
+    return bg_predict(s, iu, iv, -1, -1, make_bp(dx, dy, dt, limiter, 0.0, eps));
+}
+
+int pyrohip_bgv_rhs(pyrohip_state *s, pyrohip_mg *m, int iw, int comp, double dx, double dy,
+                    double dt, double eps, double *source_norm)
+{
+    INC_CHECK_MG(s, m, F);
+    BG_CHECK_VARS(s, iw);
+    PYRO_REQUIRE(comp == 0 || comp == 1, "comp: 0 = u, 1 = v");
+    PYRO_REQUIRE(s->work_planes >= (size_t)W_NPL, "call pyrohip_bgv_predict first");
+    const BP P = make_bp(dx, dy, dt, 0, 0.0, eps);
+    const Geom &g = s->g;
+    PYRO_TRY(pyrohip_mg_zero(m, F.level, 0));   // init_zeros
+    PYRO_TRY(pyrohip_mg_zero(m, F.level, 1));
+    PYRO_LAUNCH(s->ctx, "k_bgv_rhs", k_bgv_rhs, dim3((g.ny + 255) / 256, g.nx), dim3(256), 0,
+                (const double *)(s->d + (size_t)iw * g.plane),
+                (const double *)(s->work + geom_lead(g)), g, F.f, F.pitch, P, comp);
+    PYRO_CHECK_HIP(hipGetLastError());
     return pyrohip_mg_init_rhs_norm(m, source_norm);
 }
 

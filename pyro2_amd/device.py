@@ -263,6 +263,20 @@ class DeviceState:
                                                int(proj_type), C.byref(out)))
         return out.value
 
+    def bgv_predict(self, iu, iv, dx, dy, dt, limiter, eps):
+        """burgers_viscous: diffusion-corrected edge states + MAC velocities"""
+        with self.ctx.lock:
+            check(self._l.pyrohip_bgv_predict(self.h, int(iu), int(iv), float(dx), float(dy),
+                                              float(dt), int(limiter), float(eps)))
+
+    def bgv_rhs(self, mg, iw, comp, dx, dy, dt, eps):
+        """burgers_viscous: RHS of the Helmholtz solve of component comp; returns ||f||"""
+        out = C.c_double()
+        with self.ctx.lock:
+            check(self._l.pyrohip_bgv_rhs(self.h, mg.h, int(iw), int(comp), float(dx), float(dy),
+                                          float(dt), float(eps), C.byref(out)))
+        return out.value
+
     def inc_visc_store(self, mg, iw):
         with self.ctx.lock:
             check(self._l.pyrohip_inc_visc_store(self.h, mg.h, int(iw)))

@@ -19,7 +19,7 @@ from .util.runparams import RuntimeParameters, _get_val
 # solvers with a device implementation in this package; the reference's other
 # solvers are out of scope
 valid_solvers = ["advection", "burgers", "compressible", "compressible_rk", "diffusion", "swe",
-                 "incompressible", "incompressible_viscous"]
+                 "incompressible", "incompressible_viscous", "burgers_viscous"]
 # solvers that share another solver's problem directory (inputs files)
 problem_home = {"compressible_rk": "compressible"}
 

@@ -351,3 +351,63 @@ def test_viscous_cavity_256_vs_oracle(hip):
     assert np.abs(got[0][I] - D[0][I]).max() < 1e-11
     assert np.abs(got[1][I] - D[1][I]).max() < 1e-11
     assert np.abs(got[0][I]).max() > 1e-3     # the lid drives a flow
+
+
+# ---------------------------------------------------------------------------
+# burgers_viscous: diffusion-corrected Burgers predictor + Helmholtz solves
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("k", range(3))
+def test_burgers_viscous_step_vs_reference(dev, golden, k):
+    """one evolve() of burgers_viscous through the C ABI from a reference
+    state: against the oracle (V-cycle counts included) and the reference"""
+    g = golden("burgers_viscous")
+    pre = f"v{k}_"
+    nx, ng, lim, eps = (g[pre + "meta"][i] for i in range(4))
+    nx, ng, lim = int(nx), int(ng), int(lim)
+    bcs = [str(b) for b in g[pre + "bc"]]
+    mgbc = ["neumann" if b == "outflow" else b for b in bcs]
+    dt, dx = float(g[pre + "dt"]), 1.0 / nx
+    s = planar_state(dev, g[pre + "U0"], [bcs, bcs])
+    mg = device.DeviceMG(dev, nx, bcs=mgbc, alpha=1.0, beta=0.5 * dt * eps, nsmooth=10,
+                         nsmooth_bottom=50)
+    s.bgv_predict(0, 1, dx, dx, dt, lim, eps)
+    ncyc = []
+    for comp in (0, 1):
+        s.bgv_rhs(mg, comp, comp, dx, dx, dt, eps)
+        ncyc.append(mg.solve(rtol=1.e-12)[0])
+        s.inc_visc_store(mg, comp)
+    U = g[pre + "U0"].copy()
+    assert tuple(ncyc) == orc.bgv_step(U[0], U[1], nx, ng, dt, lim, eps, bc_u=bcs, bc_v=bcs)
+    got = planes_of(s)
+    I = (slice(None), slice(ng, -ng), slice(ng, -ng))
+    assert np.abs(got[I] - U[I]).max() < 1e-13
+    assert np.abs(got[I] - g[pre + "U1"][I]).max() < 1e-12
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_pyro_burgers_viscous(api, golden, k):
+    """Pyro("burgers_viscous"): problem set-up and a short run against the reference"""
+    from pyro2_amd.pyro_sim import Pyro
+    g = golden("burgers_viscous")
+    pre = f"v{k}_"
+    meta = g[pre + "meta"]
+    nx, ng, lim, eps = int(meta[0]), int(meta[1]), int(meta[2]), float(meta[3])
+    prob = str(g[pre + "problem"])
+    nsteps = len(g[pre + "dts"]) if (api.kind == "hip" or k != 1) else 2
+    over = {"mesh.nx": nx, "mesh.ny": nx, "advection.limiter": lim, "diffusion.eps": eps,
+            "driver.max_steps": nsteps, "driver.init_tstep_factor": float(meta[5]),
+            "driver.max_dt_change": float(meta[6]), "particles.do_particles": 0}
+    p = Pyro("burgers_viscous")
+    p.initialize_problem(prob, inputs_file="inputs.converge.32" if prob == "converge" else None,
+                         inputs_dict=over)
+    got = np.moveaxis(np.asarray(p.sim.cc_data.data), -1, 0)
+    assert np.allclose(got, g[pre + "ic"], rtol=4e-15, atol=0.0)
+    dts = []
+    while not p.sim.finished():
+        p.single_step()
+        dts.append(p.sim.dt)
+    assert np.abs(np.array(dts) / g[pre + "dts"][:nsteps] - 1).max() < 1e-11
+    if nsteps == len(g[pre + "dts"]):
+        got = np.moveaxis(np.asarray(p.sim.cc_data.data), -1, 0)
+        I = (slice(None), slice(ng, -ng), slice(ng, -ng))
+        assert np.abs(got[I] - g[pre + "final"][I]).max() < 1e-10

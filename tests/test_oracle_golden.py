@@ -836,3 +836,43 @@ def test_oracle_spherical(golden, k):
         orc.set_scalar_pow(0)
     assert np.abs(dts / g[pre + "dts"] - 1).max() < 1e-12
     assert max_rel_err(U[I], g[pre + "after"][I]) < 1e-11
+
+
+# ---------------------------------------------------------------------------
+# burgers_viscous: unsplit Burgers fluxes + one Helmholtz solve per component
+# ---------------------------------------------------------------------------
+def oracle_bgv_run(g, pre, nsteps):
+    from helpers import DtPolicy
+    nx, ng, lim, eps, cfl, f0, mx, fix, tmax = g[pre + "meta"]
+    nx, ng, lim = int(nx), int(ng), int(lim)
+    bcs = [str(b) for b in g[pre + "bc"]]
+    codes = orc.bc_codes(bcs)
+    U = g[pre + "ic"].copy()
+    pol = DtPolicy(tmax, f0, mx, fix_dt=fix)
+    dts = []
+    for _ in range(nsteps):
+        for n in range(2):
+            orc.fill_ghost(U[n], nx, nx, ng, codes)
+        dt = pol(orc.bg_dt(U[0], U[1], nx, nx, ng, 1.0 / nx, 1.0 / nx, cfl))
+        orc.bgv_step(U[0], U[1], nx, ng, dt, lim, eps, bc_u=bcs, bc_v=bcs)
+        pol.advance(dt)
+        dts.append(dt)
+    return U, np.array(dts)
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_oracle_burgers_viscous(golden, k):
+    """pyro/burgers_viscous/simulation.py:9-89 + interface.py:27-171 against runs
+    of the reference: one step from a reference state and a short run"""
+    g = golden("burgers_viscous")
+    pre = f"v{k}_"
+    nx, ng, lim, eps = (g[pre + "meta"][i] for i in range(4))
+    nx, ng, lim = int(nx), int(ng), int(lim)
+    bcs = [str(b) for b in g[pre + "bc"]]
+    U = g[pre + "U0"].copy()
+    orc.bgv_step(U[0], U[1], nx, ng, float(g[pre + "dt"]), lim, eps, bc_u=bcs, bc_v=bcs)
+    I = (slice(None), slice(ng, -ng), slice(ng, -ng))
+    assert np.abs(U[I] - g[pre + "U1"][I]).max() < 1e-13
+    U, dts = oracle_bgv_run(g, pre, len(g[pre + "dts"]))
+    assert np.abs(dts / g[pre + "dts"] - 1).max() < 1e-12
+    assert np.abs(U[I] - g[pre + "final"][I]).max() < 1e-12
