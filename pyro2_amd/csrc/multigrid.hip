@@ -93,6 +93,16 @@ __device__ __forceinline__ double ghost_hi(int code, double inner, const double 
     }
 }
 
+// homogeneous ghost value (val == nullptr above) as a select, not a branch:
+// +inner, -inner or 0.  A taken branch costs more than the dozen fp64
+// operations of a cell update (no branch prediction); measured on the bottom
+// solve: 0.48 -> 0.17 us per colour sweep (gpurun_out/mgc_probe3/4.log).
+__device__ __forceinline__ double ghost_h(int code, double inner)
+{
+    const double g = (code == PYROHIP_BC_REFLECT_ODD) ? -inner : inner;
+    return (code == PYROHIP_BC_CONST) ? 0.0 : g;
+}
+
 // explicit ghost fill, x sides (all j) -- array_indexer.py:163-221 with ng=1
 __global__ void k_mg_fill_x(double *__restrict__ a, int n, int pitch, double dx, MGBC bc)
 {
@@ -368,22 +378,25 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
         if (s > 0) __syncthreads();
         if (!any_phys) continue;
         // ghost refresh on the physical sides (edge cells only; corners are
-        // never read by the 5-point stencil)
+        // never read by the 5-point stencil).  Homogeneous boundaries (every
+        // level but a finest one with boundary values): selects instead of the
+        // switch of ghost_lo / ghost_hi -- branches are what this phase costs.
+        const bool hom = !(A.bc.val[0] || A.bc.val[1] || A.bc.val[2] || A.bc.val[3]);
         if (plo_i || phi_i)
             for (int gj = ulo_j + tid; gj <= uhi_j; gj += NT) {
                 const int c = gj - gj0;
                 if (plo_i) {
                     const double in = V[at(1, c)];
-                    V[at(0, c)] = (A.bc.code[0] == PYROHIP_BC_PERIODIC)
-                                      ? V[at(n, c)]
-                                      : ghost_lo(A.bc.code[0], in, A.bc.val[0], gj, A.dx);
+                    V[at(0, c)] = (A.bc.code[0] == PYROHIP_BC_PERIODIC) ? V[at(n, c)]
+                                  : hom ? ghost_h(A.bc.code[0], in)
+                                        : ghost_lo(A.bc.code[0], in, A.bc.val[0], gj, A.dx);
                 }
                 if (phi_i) {
                     const int rl = (n + 1) - gi0;
                     const double in = V[at(rl - 1, c)];
-                    V[at(rl, c)] = (A.bc.code[1] == PYROHIP_BC_PERIODIC)
-                                       ? V[at(1 - gi0, c)]
-                                       : ghost_hi(A.bc.code[1], in, A.bc.val[1], gj, A.dx);
+                    V[at(rl, c)] = (A.bc.code[1] == PYROHIP_BC_PERIODIC) ? V[at(1 - gi0, c)]
+                                   : hom ? ghost_h(A.bc.code[1], in)
+                                         : ghost_hi(A.bc.code[1], in, A.bc.val[1], gj, A.dx);
                 }
             }
         if (plo_j || phi_j)
@@ -391,16 +404,16 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
                 const int r = gi - gi0;
                 if (plo_j) {
                     const double in = V[at(r, 1)];
-                    V[at(r, 0)] = (A.bc.code[2] == PYROHIP_BC_PERIODIC)
-                                      ? V[at(r, n)]
-                                      : ghost_lo(A.bc.code[2], in, A.bc.val[2], gi, A.dx);
+                    V[at(r, 0)] = (A.bc.code[2] == PYROHIP_BC_PERIODIC) ? V[at(r, n)]
+                                  : hom ? ghost_h(A.bc.code[2], in)
+                                        : ghost_lo(A.bc.code[2], in, A.bc.val[2], gi, A.dx);
                 }
                 if (phi_j) {
                     const int cl = (n + 1) - gj0;
                     const double in = V[at(r, cl - 1)];
-                    V[at(r, cl)] = (A.bc.code[3] == PYROHIP_BC_PERIODIC)
-                                       ? V[at(r, 1 - gj0)]
-                                       : ghost_hi(A.bc.code[3], in, A.bc.val[3], gi, A.dx);
+                    V[at(r, cl)] = (A.bc.code[3] == PYROHIP_BC_PERIODIC) ? V[at(r, 1 - gj0)]
+                                   : hom ? ghost_h(A.bc.code[3], in)
+                                         : ghost_hi(A.bc.code[3], in, A.bc.val[3], gi, A.dx);
                 }
             }
         __syncthreads();
@@ -554,6 +567,9 @@ __device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, dou
     const int c0 = bc.code[0], c1 = bc.code[1], c2 = bc.code[2], c3 = bc.code[3];
     const double *v0 = use_val ? bc.val[0] : nullptr, *v1 = use_val ? bc.val[1] : nullptr;
     const double *v2 = use_val ? bc.val[2] : nullptr, *v3 = use_val ? bc.val[3] : nullptr;
+    const bool p0 = (c0 == PYROHIP_BC_PERIODIC), p1 = (c1 == PYROHIP_BC_PERIODIC);
+    const bool p2 = (c2 == PYROHIP_BC_PERIODIC), p3 = (c3 == PYROHIP_BC_PERIODIC);
+    const bool hom = !(v0 || v1 || v2 || v3);   // boundary values only on a finest level <= 64^2
     for (int it = 0; it < 2 * iters; it++) {
         const int colour = it & 1;
         for (int idx = tid; idx < n * half; idx += NT) {
@@ -564,21 +580,31 @@ __device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, dou
             const double vn = div_by(F[c] + xc * (V[c + q] + V[c - q]) + yc * (V[c + 1] + V[c - 1]),
                                      denom, rdenom);
             V[c] = vn;
-            if (i == 1) {
-                if (c0 == PYROHIP_BC_PERIODIC) V[(n + 1) * q + j] = vn;
-                else V[j] = ghost_lo(c0, vn, v0, j, dx);
-            }
-            if (i == n) {
-                if (c1 == PYROHIP_BC_PERIODIC) V[j] = vn;
-                else V[(n + 1) * q + j] = ghost_hi(c1, vn, v1, j, dx);
-            }
-            if (j == 1) {
-                if (c2 == PYROHIP_BC_PERIODIC) V[i * q + n + 1] = vn;
-                else V[i * q] = ghost_lo(c2, vn, v2, i, dx);
-            }
-            if (j == n) {
-                if (c3 == PYROHIP_BC_PERIODIC) V[i * q] = vn;
-                else V[i * q + n + 1] = ghost_hi(c3, vn, v3, i, dx);
+            if (hom) {
+                // four unconditional stores with selected target and value (the
+                // cell itself again when it is not on that side): no branches
+                const bool a0 = (i == 1), a1 = (i == n), a2 = (j == 1), a3 = (j == n);
+                V[a0 ? (p0 ? (n + 1) * q + j : j) : c] = a0 ? (p0 ? vn : ghost_h(c0, vn)) : vn;
+                V[a1 ? (p1 ? j : (n + 1) * q + j) : c] = a1 ? (p1 ? vn : ghost_h(c1, vn)) : vn;
+                V[a2 ? (p2 ? i * q + n + 1 : i * q) : c] = a2 ? (p2 ? vn : ghost_h(c2, vn)) : vn;
+                V[a3 ? (p3 ? i * q : i * q + n + 1) : c] = a3 ? (p3 ? vn : ghost_h(c3, vn)) : vn;
+            } else {
+                if (i == 1) {
+                    if (p0) V[(n + 1) * q + j] = vn;
+                    else V[j] = ghost_lo(c0, vn, v0, j, dx);
+                }
+                if (i == n) {
+                    if (p1) V[j] = vn;
+                    else V[(n + 1) * q + j] = ghost_hi(c1, vn, v1, j, dx);
+                }
+                if (j == 1) {
+                    if (p2) V[i * q + n + 1] = vn;
+                    else V[i * q] = ghost_lo(c2, vn, v2, i, dx);
+                }
+                if (j == n) {
+                    if (p3) V[i * q] = vn;
+                    else V[i * q + n + 1] = ghost_hi(c3, vn, v3, i, dx);
+                }
             }
         }
         mgc_sync<NT>();
@@ -597,30 +623,47 @@ __device__ inline void mgc_bottom_regs(double *V, const double *F, double dx, do
     const double denom = alpha + 2.0 * xc + 2.0 * yc;
     const double rdenom = 1.0 / denom;
     const int c0 = bc.code[0], c1 = bc.code[1], c2 = bc.code[2], c3 = bc.code[3];
+    const bool p0 = (c0 == PYROHIP_BC_PERIODIC), p1 = (c1 == PYROHIP_BC_PERIODIC);
+    const bool p2 = (c2 == PYROHIP_BC_PERIODIC), p3 = (c3 == PYROHIP_BC_PERIODIC);
     const double *v0 = use_val ? bc.val[0] : nullptr, *v1 = use_val ? bc.val[1] : nullptr;
     const double *v2 = use_val ? bc.val[2] : nullptr, *v3 = use_val ? bc.val[3] : nullptr;
+    const bool inhom = v0 || v1 || v2 || v3;   // boundary values: only if this is the finest level
     double v[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) v[i][j] = V[i * 4 + j];
     const double f11 = F[5], f12 = F[6], f21 = F[9], f22 = F[10];
-    // cell (I, J) with literal indices; ghost refresh as in mgc_smooth (n = 2)
-#define MGC_RELAX(I, J, FF)                                                                  \
+    // cell (I, J) with literal indices; ghost refresh as in mgc_smooth (n = 2).
+    // The boundary rules are selects, not branches: a taken branch costs more
+    // than the dozen fp64 operations of the update (no branch prediction).
+#define MGC_RELAX(I, J, FF, GLO, GHI)                                                        \
     {                                                                                        \
         const double vn = div_by(FF + xc * (v[I + 1][J] + v[I - 1][J]) +                     \
                                      yc * (v[I][J + 1] + v[I][J - 1]), denom, rdenom);        \
         v[I][J] = vn;                                                                        \
-        if (I == 1) { if (c0 == PYROHIP_BC_PERIODIC) v[3][J] = vn; else v[0][J] = ghost_lo(c0, vn, v0, J, dx); } \
-        if (I == 2) { if (c1 == PYROHIP_BC_PERIODIC) v[0][J] = vn; else v[3][J] = ghost_hi(c1, vn, v1, J, dx); } \
-        if (J == 1) { if (c2 == PYROHIP_BC_PERIODIC) v[I][3] = vn; else v[I][0] = ghost_lo(c2, vn, v2, I, dx); } \
-        if (J == 2) { if (c3 == PYROHIP_BC_PERIODIC) v[I][0] = vn; else v[I][3] = ghost_hi(c3, vn, v3, I, dx); } \
+        if (I == 1) { v[3][J] = p0 ? vn : v[3][J]; v[0][J] = p0 ? v[0][J] : GLO(c0, vn, v0, J); } \
+        if (I == 2) { v[0][J] = p1 ? vn : v[0][J]; v[3][J] = p1 ? v[3][J] : GHI(c1, vn, v1, J); } \
+        if (J == 1) { v[I][3] = p2 ? vn : v[I][3]; v[I][0] = p2 ? v[I][0] : GLO(c2, vn, v2, I); } \
+        if (J == 2) { v[I][0] = p3 ? vn : v[I][0]; v[I][3] = p3 ? v[I][3] : GHI(c3, vn, v3, I); } \
     }
-    for (int it = 0; it < iters; it++) {
-        MGC_RELAX(1, 1, f11) MGC_RELAX(2, 2, f22)   // colour 0
-        MGC_RELAX(1, 2, f12) MGC_RELAX(2, 1, f21)   // colour 1
-    }
+#define MGC_GH(code, x, val, idx) ghost_h(code, x)
+#define MGC_GLO(code, x, val, idx) ghost_lo(code, x, val, idx, dx)
+#define MGC_GHI(code, x, val, idx) ghost_hi(code, x, val, idx, dx)
+    if (!inhom)
+        for (int it = 0; it < iters; it++) {
+            MGC_RELAX(1, 1, f11, MGC_GH, MGC_GH) MGC_RELAX(2, 2, f22, MGC_GH, MGC_GH)   // colour 0
+            MGC_RELAX(1, 2, f12, MGC_GH, MGC_GH) MGC_RELAX(2, 1, f21, MGC_GH, MGC_GH)   // colour 1
+        }
+    else
+        for (int it = 0; it < iters; it++) {
+            MGC_RELAX(1, 1, f11, MGC_GLO, MGC_GHI) MGC_RELAX(2, 2, f22, MGC_GLO, MGC_GHI)
+            MGC_RELAX(1, 2, f12, MGC_GLO, MGC_GHI) MGC_RELAX(2, 1, f21, MGC_GLO, MGC_GHI)
+        }
 #undef MGC_RELAX
+#undef MGC_GH
+#undef MGC_GLO
+#undef MGC_GHI
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
