@@ -538,38 +538,17 @@ __device__ inline void mgc_fill(double *V, int n, double dx, const MGBC &bc, boo
     mgc_sync<NT>();
 }
 
-// Red-black sweeps of one LDS-resident level.  The thread that updates a cell
-// next to a boundary also refreshes the ghost cell(s) that mirror it (like
-// k_mg_smooth): during a colour sweep a ghost cell is only read by the cell it
-// mirrors (or, on periodic sides, by a cell of the other colour), so this is
-// the reference's fill_BC after the sweep (MG.py:598-599) without a separate
-// pass and its two extra synchronisations.  Corner ghosts are not read by the
-// 5-point stencil; the closing fill makes them exact again.
-// Measured (tools/mgc_probe.py, gpurun_out/mgc_probe*.log): a colour sweep
-// costs ~0.6 us on the 2 x 2 level and ~0.8 us averaged over the levels,
-// whether ghosts are refreshed here or in two extra passes and whether one
-// wave or the workgroup runs it -- the kernel (~250 us of the V-cycle, 300
-// sweeps at nsmooth 10 / bottom 50) is bound by the dependent chain LDS read
-// -> 8 fp64 operations -> LDS write -> barrier of each sweep, not by the
-// number of barriers.
-template <int NT>
-__device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, double dx,
-                                  double alpha, double beta, int iters, const MGBC &bc,
-                                  bool use_val, int tid)
+// colour sweeps of mgc_smooth (below); HOM: homogeneous boundaries, branch-free
+template <int NT, bool HOM>
+__device__ __forceinline__ void mgc_sweeps(double *V, const double *F, int n, int lg, double dx,
+                                           double xc, double yc, double denom, double rdenom,
+                                           int iters, int c0, int c1, int c2, int c3,
+                                           const double *v0, const double *v1, const double *v2,
+                                           const double *v3, int tid)
 {
-    const int q = n + 2;
-    const double xc = beta / (dx * dx), yc = beta / (dx * dx);
-    const double denom = alpha + 2.0 * xc + 2.0 * yc;
-    const double rdenom = 1.0 / denom;                          // correctly rounded: div_by
-    mgc_fill<NT>(V, n, dx, bc, use_val, tid);                   // MG.py:565
-    if (iters <= 0) return;
-    const int half = n >> 1;                                    // cells of one colour per row
-    const int c0 = bc.code[0], c1 = bc.code[1], c2 = bc.code[2], c3 = bc.code[3];
-    const double *v0 = use_val ? bc.val[0] : nullptr, *v1 = use_val ? bc.val[1] : nullptr;
-    const double *v2 = use_val ? bc.val[2] : nullptr, *v3 = use_val ? bc.val[3] : nullptr;
+    const int q = n + 2, half = n >> 1;
     const bool p0 = (c0 == PYROHIP_BC_PERIODIC), p1 = (c1 == PYROHIP_BC_PERIODIC);
     const bool p2 = (c2 == PYROHIP_BC_PERIODIC), p3 = (c3 == PYROHIP_BC_PERIODIC);
-    const bool hom = !(v0 || v1 || v2 || v3);   // boundary values only on a finest level <= 64^2
     for (int it = 0; it < 2 * iters; it++) {
         const int colour = it & 1;
         for (int idx = tid; idx < n * half; idx += NT) {
@@ -580,7 +559,7 @@ __device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, dou
             const double vn = div_by(F[c] + xc * (V[c + q] + V[c - q]) + yc * (V[c + 1] + V[c - 1]),
                                      denom, rdenom);
             V[c] = vn;
-            if (hom) {
+            if (HOM) {
                 // four unconditional stores with selected target and value (the
                 // cell itself again when it is not on that side): no branches
                 const bool a0 = (i == 1), a1 = (i == n), a2 = (j == 1), a3 = (j == n);
@@ -609,6 +588,42 @@ __device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, dou
         }
         mgc_sync<NT>();
     }
+}
+
+// Red-black sweeps of one LDS-resident level.  The thread that updates a cell
+// next to a boundary also refreshes the ghost cell(s) that mirror it (like
+// k_mg_smooth): during a colour sweep a ghost cell is only read by the cell it
+// mirrors (or, on periodic sides, by a cell of the other colour), so this is
+// the reference's fill_BC after the sweep (MG.py:598-599) without a separate
+// pass and its two extra synchronisations.  Corner ghosts are not read by the
+// 5-point stencil; the closing fill makes them exact again.
+// Measured (tools/mgc_probe.py, gpurun_out/mgc_probe*.log): a colour sweep
+// costs ~0.6 us on the 2 x 2 level and ~0.8 us averaged over the levels,
+// whether ghosts are refreshed here or in two extra passes and whether one
+// wave or the workgroup runs it -- the kernel (~250 us of the V-cycle, 300
+// sweeps at nsmooth 10 / bottom 50) is bound by the dependent chain LDS read
+// -> 8 fp64 operations -> LDS write -> barrier of each sweep, not by the
+// number of barriers.
+template <int NT>
+__device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, double dx,
+                                  double alpha, double beta, int iters, const MGBC &bc,
+                                  bool use_val, int tid)
+{
+    const int q = n + 2;
+    const double xc = beta / (dx * dx), yc = beta / (dx * dx);
+    const double denom = alpha + 2.0 * xc + 2.0 * yc;
+    const double rdenom = 1.0 / denom;                          // correctly rounded: div_by
+    mgc_fill<NT>(V, n, dx, bc, use_val, tid);                   // MG.py:565
+    if (iters <= 0) return;
+    const int c0 = bc.code[0], c1 = bc.code[1], c2 = bc.code[2], c3 = bc.code[3];
+    const double *v0 = use_val ? bc.val[0] : nullptr, *v1 = use_val ? bc.val[1] : nullptr;
+    const double *v2 = use_val ? bc.val[2] : nullptr, *v3 = use_val ? bc.val[3] : nullptr;
+    if (!(v0 || v1 || v2 || v3))   // boundary values only on a finest level <= 64^2
+        mgc_sweeps<NT, true>(V, F, n, lg, dx, xc, yc, denom, rdenom, iters, c0, c1, c2, c3, v0, v1,
+                             v2, v3, tid);
+    else
+        mgc_sweeps<NT, false>(V, F, n, lg, dx, xc, yc, denom, rdenom, iters, c0, c1, c2, c3, v0, v1,
+                              v2, v3, tid);
     mgc_fill<NT>(V, n, dx, bc, use_val, tid);                   // corners
 }
 
