@@ -68,6 +68,9 @@ struct pyrohip_mg {
     double *vc_pool = nullptr;
     double *gen_pool = nullptr;
     bool corners_stale[pyro::MG_MAXLEV] = {};   // v: corner ghosts not refreshed yet
+    // v of the level is to be taken as 0 by its next smoothing launch (set by
+    // the solve loop instead of a memset, consumed inside the same V-cycle)
+    bool v_is_zero[pyro::MG_MAXLEV] = {};
 };
 
 namespace pyro {
@@ -214,6 +217,7 @@ struct MGTile {
     // 745-748), instead of a separate pass over the level; nullptr: plain smooth
     const double *cv;
     int cpitch;
+    int vin_zero;   // 1: take vin as 0 (down leg: MG.py:658-659 zeroes the coarse solutions)
 };
 
 // a / b for a divisor that is the same in every cell, with rb = RN(1 / b)
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
                     const int gi = wrap_i ? mg_wrap(gi0 + r, n) : gi0 + r;
                     const int gj = wrap_j ? mg_wrap(gj0 + c, n) : gj0 + c;
                     const size_t k = (size_t)gi * A.pitch + gj;
-                    vv = A.vin[k];
+                    if (!A.vin_zero) vv = A.vin[k];
                     ff = A.f[k];
                     if (A.cv && gi >= 1 && gi <= n && gj >= 1 && gj <= n) {
                         // k_mg_prolong_add's expression for fine cell (gi-1, gj-1)
@@ -478,6 +482,7 @@ struct MGCoarse {
     int nsmooth, nsmooth_bottom;
     MGBC bc;                                     // val[] only meaningful when finest
     int wave_top;                                // levels 0 .. wave_top: wave 0 only (-1: none)
+    unsigned zero_mask;                          // bit l: take v of level l as 0 (no memset before)
 };
 __host__ __device__ inline int mgc_off(int l)    // LDS offset (doubles) of level l's v
 {
@@ -745,9 +750,10 @@ __global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
     for (int l = 0; l <= A.top; l++) {
         const int n = 2 << l, q = n + 2;
         double *V = lds + mgc_off(l), *F = V + q * q;
+        const bool vz = (A.zero_mask >> l) & 1u;
         for (int idx = tid; idx < q * q; idx += MGC_NT) {
             const int i = idx / q, j = idx - i * q;
-            V[idx] = A.v[l][(size_t)i * A.pitch[l] + j];
+            V[idx] = vz ? 0.0 : A.v[l][(size_t)i * A.pitch[l] + j];
             F[idx] = A.f[l][(size_t)i * A.pitch[l] + j];
         }
     }
@@ -1096,6 +1102,8 @@ static int mg_smooth_colour_launches(pyrohip_mg *m, int level, int nsmooth)
     return 0;
 }
 
+static int mg_zero(pyrohip_mg *m, int level, int var);
+
 // can the prolongation of level-1's correction ride on the first smoothing
 // launch of `level`?  (wide tile kernel only)
 static bool mg_prolong_fusable(pyrohip_mg *m, int level, int nsmooth)
@@ -1130,6 +1138,12 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
     A.single = ((L.n + 2) * (L.n + 2) <= MGS_CELLS) ? 1 : 0;   // whole level in one tile
     A.cv = nullptr; A.cpitch = 0;
     if (prolong) { A.cv = m->lev[level - 1].v; A.cpitch = m->lev[level - 1].pitch; }
+    A.vin_zero = 0;
+    if (m->v_is_zero[level]) {
+        if (A.single) PYRO_TRY(mg_zero(m, level, 0));   // generic variant: materialise
+        else A.vin_zero = 1;
+        m->v_is_zero[level] = false;
+    }
     int kmax = (m->kmax >= 1 && m->kmax <= MGW_KMAX) ? m->kmax : MGW_KMAX;
     // levels up to 1024^2 live in L2 / Infinity Cache and are launch-latency
     // bound: fuse as many iterations per launch as the 32-row region allows
@@ -1168,6 +1182,7 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
         double *t = L.v; L.v = L.v2; L.v2 = t;
         left -= K;
         A.cv = nullptr;   // only the first launch carries the prolongation
+        A.vin_zero = 0;
     }
     return 0;
 }
@@ -1305,6 +1320,9 @@ static int mg_coarse_vcycle(pyrohip_mg *m, int top)
         return e ? atoi(e) : MGC_WAVE_TOP;
     }();
     A.wave_top = wave_top;
+    A.zero_mask = 0;
+    for (int l = 0; l <= top; l++)
+        if (m->v_is_zero[l]) { A.zero_mask |= 1u << l; m->v_is_zero[l] = false; }
     A.bc = make_bc(m, top, true);
     PYRO_LAUNCH(m->ctx, "k_mg_coarse_vcycle", k_mg_coarse_vcycle, dim3(1), dim3(MGC_NT), MGC_LDS,
                 A);
@@ -1737,7 +1755,16 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
     double res = 1.e33, rel = 1.e33;
     int cycle = 1;
     while (res > rtol && cycle <= max_cycles) {           // MG.py:652
-        for (int l = 0; l < Lf; l++) PYRO_TRY(mg_zero(m, l, 0));   // :658-659
+        for (int l = 0; l < Lf; l++) {                    // :658-659 (zero the coarse solutions)
+            // levels the wide tile smoother visits first: no memset (hipMemset runs
+            // at ~270 GB/s: 123 us for the 2048^2 level), the staging takes v = 0
+            const MGLevel &Lc = m->lev[l];
+            const bool lazy = !m->vc && m->smoother != 0 && m->nsmooth > 0 &&
+                              ((Lc.n + 2) * (Lc.n + 2) > MGS_CELLS ||
+                               (m->coarse_kernel && l <= MGC_TOP));   // staged as 0 there
+            if (lazy) m->v_is_zero[l] = true;
+            else PYRO_TRY(mg_zero(m, l, 0));
+        }
         PYRO_TRY(mg_vcycle(m, Lf));
         double s = 0.0, s2 = 0.0;                         // :673-678
         if (m->vc) {
