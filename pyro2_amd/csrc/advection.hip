@@ -19,7 +19,10 @@
 
 namespace pyro {
 
-constexpr int ADV_TI = 16;   // tile rows   (i, slow axis)
+#ifndef PYRO_ADV_TI
+#define PYRO_ADV_TI 16
+#endif
+constexpr int ADV_TI = PYRO_ADV_TI;   // tile rows   (i, slow axis)
 constexpr int ADV_TJ = 64;   // tile columns (j, fast axis) = one wave
 constexpr int ADV_H = 3;     // apron
 constexpr int ADV_AW = ADV_TJ + 2 * ADV_H;       // 70
@@ -28,74 +31,97 @@ constexpr int ADV_XW = ADV_TJ + 2;               // a_x: j in [j0-1, j0+TJ]
 constexpr int ADV_XH = ADV_TI + 1;               //      i in [i0, i0+TI]
 constexpr int ADV_YW = ADV_TJ + 1;               // a_y: j in [j0, j0+TJ]
 constexpr int ADV_YH = ADV_TI + 2;               //      i in [i0-1, i0+TI]
-constexpr int ADV_THREADS = 256;
+#ifndef PYRO_ADV_THREADS
+#define PYRO_ADV_THREADS 256
+#endif
+constexpr int ADV_THREADS = PYRO_ADV_THREADS;
 
 struct AdvParams {
     double u, v, dt, dx, dy;
     int limiter;
+    // uniform quotients, evaluated once on the host with the reference's
+    // expressions (IEEE double on both sides: same bits); a division is ~14
+    // VALU instructions per thread otherwise
+    double cx, cy;          // u*dt/dx, v*dt/dy          interface.py:10-11
+    double dtdx2, dtdy2;    // 0.5*dt/dx, 0.5*dt/dy      advective_fluxes.py:60-61
+    double dtdx, dtdy;      // dt/dx, dt/dy              simulation.py:63-64
 };
 
 // LIM: limiter (0 none, 1 MC2, 2 MC4); UNEG / VNEG: u < 0 / v < 0 (upwind side)
+//
+// Thread layout: 4 waves; wave w, lane l.  Every phase walks rows w, w+4, ...
+// with the lane as the column (no integer division, one LDS address add per
+// row); the few columns beyond 64 (apron of A, the two extra face columns of
+// a_x, the extra one of a_y) are a short second pass of a partial wave.
 template <int LIM, bool UNEG, bool VNEG>
 __global__ __launch_bounds__(ADV_THREADS) void k_adv_step(const double *__restrict__ ain,
                                                           double *__restrict__ aout, Geom g,
                                                           AdvParams P, int ntj, int ntiles)
 {
+    static_assert(ADV_THREADS == 256 && ADV_TJ == 64, "4 waves, lane = column");
     __shared__ double A[ADV_AH][ADV_AW];
     __shared__ double AX[ADV_XH][ADV_XW];
     __shared__ double AY[ADV_YH][ADV_YW];
     const int tile = xcd_tile(blockIdx.x, ntiles);
     const int i0 = g.ilo + (tile / ntj) * ADV_TI;
     const int j0 = g.jlo + (tile % ntj) * ADV_TJ;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int p = g.pitch;
 
     // ---- phase 0: stage a (tile + apron) in LDS -------------------------
-    for (int idx = tid; idx < ADV_AH * ADV_AW; idx += ADV_THREADS) {
-        int r = idx / ADV_AW, c = idx - r * ADV_AW;
-        int i = i0 - ADV_H + r, j = j0 - ADV_H + c;
+    // columns H .. H+63 (the tile's own, 512-byte aligned rows) by all lanes
+    for (int r = w; r < ADV_AH; r += 4) {
+        int i = i0 - ADV_H + r, j = j0 + l;
         i = (i < g.qx) ? i : g.qx - 1;   // partial tiles: clamp (values unused)
+        j = (j < g.qy) ? j : g.qy - 1;
+        A[r][ADV_H + l] = ain[(size_t)i * p + j];
+    }
+    // the 2 x H apron columns: ADV_AH rows x 6 columns
+    for (int idx = tid; idx < ADV_AH * 2 * ADV_H; idx += ADV_THREADS) {
+        const int r = idx / (2 * ADV_H), k = idx - r * (2 * ADV_H);
+        const int c = (k < ADV_H) ? k : ADV_TJ + k;          // 0..2, 67..69
+        int i = i0 - ADV_H + r, j = j0 - ADV_H + c;
+        i = (i < g.qx) ? i : g.qx - 1;
         j = (j < g.qy) ? j : g.qy - 1;
         A[r][c] = ain[(size_t)i * p + j];
     }
     __syncthreads();
 
-    const double u = P.u, v = P.v, dt = P.dt;
-    const double cx = u * dt / P.dx;   // interface.py:10-11
-    const double cy = v * dt / P.dy;
+    const double u = P.u, v = P.v;
+    const double cx = P.cx, cy = P.cy;
 
     // ---- phase 1: upwind interface states (interface.py:25-41) ----------
-    // a_x at faces i in [i0, i0+TI], j in [j0-1, j0+TJ]
-    for (int idx = tid; idx < ADV_XH * ADV_XW; idx += ADV_THREADS) {
-        const int r = idx / ADV_XW, c = idx - r * ADV_XW;
+    // a_x at faces i in [i0, i0+TI], j in [j0-1, j0+TJ]: AX[r][c], c = 0..65
+    auto ax_state = [&](int r, int c) {
         // A-tile coordinates of the upwind cell of face (i0 + r, j0 - 1 + c)
         const int br = r + ADV_H - (UNEG ? 0 : 1), ac = c - 1 + ADV_H;
         const double a0 = A[br][ac];
         const double ld = limited_slope(A[br - 2][ac], A[br - 1][ac], a0, A[br + 1][ac],
                                         A[br + 2][ac], LIM);
         AX[r][c] = UNEG ? a0 - 0.5 * (1.0 + cx) * ld : a0 + 0.5 * (1.0 - cx) * ld;
-    }
-    // a_y at faces i in [i0-1, i0+TI], j in [j0, j0+TJ]
-    for (int idx = tid; idx < ADV_YH * ADV_YW; idx += ADV_THREADS) {
-        const int r = idx / ADV_YW, c = idx - r * ADV_YW;
+    };
+    for (int r = w; r < ADV_XH; r += 4) ax_state(r, l + 1);          // columns 1..64
+    if (tid < 2 * ADV_XH) ax_state(tid >> 1, (tid & 1) ? ADV_XW - 1 : 0);   // columns 0, 65
+    // a_y at faces i in [i0-1, i0+TI], j in [j0, j0+TJ]: AY[r][c], c = 0..64
+    auto ay_state = [&](int r, int c) {
         const int ar = r - 1 + ADV_H, bc = c + ADV_H - (VNEG ? 0 : 1);
         const double a0 = A[ar][bc];
         const double ld = limited_slope(A[ar][bc - 2], A[ar][bc - 1], a0, A[ar][bc + 1],
                                         A[ar][bc + 2], LIM);
         AY[r][c] = VNEG ? a0 - 0.5 * (1.0 + cy) * ld : a0 + 0.5 * (1.0 - cy) * ld;
-    }
+    };
+    for (int r = w; r < ADV_YH; r += 4) ay_state(r, l);              // columns 0..63
+    if (tid >= 64 && tid < 64 + ADV_YH) ay_state(tid - 64, ADV_YW - 1);   // column 64
     __syncthreads();
 
     // ---- phase 2: transverse-corrected fluxes + conservative update -----
     const int mx = (u <= 0) ? 0 : -1;   // advective_fluxes.py:71-79
     const int my = (v <= 0) ? 0 : -1;
-    const double dtdx2 = 0.5 * dt / P.dx;
-    const double dtdy2 = 0.5 * dt / P.dy;
-    const double dtdx = dt / P.dx;      // simulation.py:63-64
-    const double dtdy = dt / P.dy;
+    const double dtdx2 = P.dtdx2, dtdy2 = P.dtdy2;
+    const double dtdx = P.dtdx, dtdy = P.dtdy;      // simulation.py:63-64
 
-    const int c = tid & (ADV_TJ - 1);
-    for (int r = tid / ADV_TJ; r < ADV_TI; r += ADV_THREADS / ADV_TJ) {
+    const int c = l;
+    for (int r = w; r < ADV_TI; r += 4) {
         const int i = i0 + r, j = j0 + c;
         if (i > g.ihi || j > g.jhi) continue;
         // AX[r][c+1] is a_x at (i, j);  AY[r+1][c] is a_y at (i, j)
@@ -177,7 +203,11 @@ extern "C" int pyrohip_adv_step(pyrohip_state *s, int n, double dx, double dy, d
     }
     double *cur = s->d + (size_t)n * g.plane;
     double *nxt = s->work + geom_lead(g);
-    AdvParams P{u, v, dt, dx, dy, limiter};
+    AdvParams P;
+    P.u = u; P.v = v; P.dt = dt; P.dx = dx; P.dy = dy; P.limiter = limiter;
+    P.cx = u * dt / dx; P.cy = v * dt / dy;
+    P.dtdx2 = 0.5 * dt / dx; P.dtdy2 = 0.5 * dt / dy;
+    P.dtdx = dt / dx; P.dtdy = dt / dy;
     const int nti = (g.nx + ADV_TI - 1) / ADV_TI, ntj = (g.ny + ADV_TJ - 1) / ADV_TJ;
     const int ntiles = nti * ntj;
     const bool uneg = (u < 0), vneg = (v < 0);   // interface.py:28,38
