@@ -331,6 +331,50 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
     const bool plo_j = (gj0 == 0) && !wrap_j, phi_j = (gj1 == n + 1) && !wrap_j;
     const bool any_phys = plo_i || phi_i || plo_j || phi_j;   // uniform per workgroup
     const int npass = 2 * A.K;
+    // Wide variant, per-thread sweep schedule (all of it fixed for the launch):
+    // odd passes (colour 0) write checkerboard class P1, even passes the other
+    // one; of the thread's two columns 2*ln + q the one in the written class is
+    // qA on odd and qB = 1 - qA on even passes, the same for its four rows.  A
+    // cell may be relaxed in pass s while all four neighbours are still valid,
+    // i.e. while s <= its distance to the nearest non-physical edge of the
+    // staged region (and only inside the level on physical sides): one integer
+    // per cell, compared with s -- instead of re-deriving the updatable
+    // rectangle and the lane predicates in every pass (that bookkeeping was
+    // ~40 % of the VALU instructions of a pass, and the smoother is VALU bound).
+    constexpr int HP = LPC ? LPC / 2 : 1;                   // row pitch of one class
+    const int P1 = (gi0 + gj0) & 1;
+    const int qA = (P1 + wv) & 1, qB = qA ^ 1;
+    int sA0 = -1, sA1 = -1, sA2 = -1, sA3 = -1, sB0 = -1, sB1 = -1, sB2 = -1, sB3 = -1;
+    int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    double fA0 = 0, fA1 = 0, fA2 = 0, fA3 = 0, fB0 = 0, fB1 = 0, fB2 = 0, fB3 = 0;
+    if (LPC) {
+        constexpr int BIG = 1 << 20;
+        auto last_j = [&](int q) {
+            const int c = 2 * ln + q, gj = gj0 + c;
+            if (c >= RJ) return -1;
+            const int lo = plo_j ? (gj >= 1 ? BIG : -1) : c;
+            const int hi = phi_j ? (gj <= n ? BIG : -1) : gj1 - gj;
+            return min(lo, hi);
+        };
+        const int sjA = last_j(qA), sjB = last_j(qB);
+        auto plan = [&](int m, double fa, double fb, int &sa, int &sb, int &b, double &ga,
+                        double &gb) {
+            const int r = wv + WSTEP * m, gi = gi0 + r;
+            int si = -1;
+            if (r < RI) {
+                const int lo = plo_i ? (gi >= 1 ? BIG : -1) : r;
+                const int hi = phi_i ? (gi <= n ? BIG : -1) : gi1 - gi;
+                si = min(lo, hi);
+            }
+            sa = min(si, sjA); sb = min(si, sjB);
+            b = r * HP + ln;
+            ga = qA ? fb : fa; gb = qA ? fa : fb;
+        };
+        plan(0, f00, f01, sA0, sB0, b0, fA0, fB0);
+        plan(1, f10, f11, sA1, sB1, b1, fA1, fB1);
+        plan(2, f20, f21, sA2, sB2, b2, fA2, fB2);
+        plan(3, f30, f31, sA3, sB3, b3, fA3, fB3);
+    }
     // pass 0 only refreshes the staged ghost cells from their interior
     // neighbours (the fill_BC that opens MG.smooth, MG.py:565), so the input
     // buffer's ghosts need not be current
@@ -342,30 +386,20 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
         const int ni = uhi_i - ulo_i + 1, nj = uhi_j - ulo_j + 1;
         if (s == 0) {
             // nothing to update
-        } else if (LPC) {   // the thread's cell of this colour in each of its rows
-            // a colour is one checkerboard class of the region: class P is
-            // written, its neighbours are all read from class 1 - P; which of
-            // the thread's two columns belongs to P is the same for all of a
-            // wave's rows (they are 16 apart)
-            constexpr int HP = LPC / 2;                     // row pitch of one class
-            const int P = (colour + gi0 + gj0) & 1;         // colour 0: (gi-1)+(gj-1) even
-            const int q = (P + wv) & 1;
-            double *Vo = V + P * HALF;
-            const double *Vn = V + (P ^ 1) * HALF;
-            const int gj = gj0 + 2 * ln + q;
-            const bool jin = (gj >= ulo_j && gj <= uhi_j);
-            auto relax = [&](int m, double fa, double fb) {
-                const int r = wv + WSTEP * m;
-                const int gi = gi0 + r;
-                if (jin && gi >= ulo_i && gi <= uhi_i) {
-                    const int b = r * HP + ln;
-                    const double fc = q ? fb : fa;
-                    // neighbours: (r+1, c), (r-1, c), (r, c+1), (r, c-1)
+        } else if (LPC) {
+            // class written / read in this pass; neighbours of (r, c): (r+-1, c)
+            // at b +- HP and (r, c+1), (r, c-1) at b + q, b + q - 1 of the other class
+            const bool odd = s & 1;
+            double *Vo = V + (odd ? P1 : P1 ^ 1) * HALF;
+            const double *Vn = V + (odd ? P1 ^ 1 : P1) * HALF;
+            const double *Vq = Vn + (odd ? qA : qB);
+            auto relax = [&](int b, int last, double fc) {
+                if (s <= last)
                     Vo[b] = div_by(fc + A.xc * (Vn[b + HP] + Vn[b - HP]) +
-                                   A.yc * (Vn[b + q] + Vn[b + q - 1]), A.denom, A.rdenom);
-                }
+                                   A.yc * (Vq[b] + Vq[b - 1]), A.denom, A.rdenom);
             };
-            relax(0, f00, f01); relax(1, f10, f11); relax(2, f20, f21); relax(3, f30, f31);
+            if (odd) { relax(b0, sA0, fA0); relax(b1, sA1, fA1); relax(b2, sA2, fA2); relax(b3, sA3, fA3); }
+            else     { relax(b0, sB0, fB0); relax(b1, sB1, fB1); relax(b2, sB2, fB2); relax(b3, sB3, fB3); }
         } else {
             const int half = (nj + 1) >> 1;
             for (int idx = tid; idx < ni * half; idx += NT) {
