@@ -419,8 +419,8 @@ class CellCenterData2d:
 
     # ---- output ---------------------------------------------------------
     def write(self, filename):
-        """pyro's HDF5 layout; an .npz container with the same tree when h5py
-        is not installed (util/h5lite.py)"""
+        """pyro's HDF5 layout (through h5py, or util/h5pure.py when h5py is
+        not installed: util/h5lite.py picks)"""
         from ..util import h5lite
         with h5lite.open_file(filename, "w") as f:
             self.write_data(f)

@@ -1,15 +1,16 @@
-"""Output container with the (tiny) h5py surface the writers/readers of this
-package use -- File / groups / attrs / create_dataset / item access -- so the
-on-disk LAYOUT of pyro's HDF5 files (simulation_null.py:270-290,
-patch.py:750-788) is kept when h5py is not installed.
+"""Output files of the package: pyro's HDF5 layout (simulation_null.py:270-290,
+patch.py:750-788), SURVEY.md 8 row f3.
 
-`open_file(name, mode)` returns an h5py.File when h5py is importable and the
-name ends in .h5; otherwise an `NpzFile`, which keeps the same tree in ONE
-NumPy .npz archive:
-    dataset  "state/density/data"      -> entry  "d:state/density/data"
-    attribute ("grid", "nx")           -> entry  "a:grid@nx"
-    (empty groups are remembered as     -> entry  "g:<path>")
-File name convention: "<base>.h5" with h5py, "<base>.pyro.npz" without.
+`open_file(name, mode)` returns
+  * an h5py.File when h5py is importable,
+  * otherwise a util/h5pure.File: a pure Python + NumPy reader / writer of the
+    HDF5 subset pyro uses.  Files it writes are real HDF5 (libhdf5 / h5py and
+    therefore pyro's own io_pyro / compare.py / plot.py read them); it reads
+    the files pyro writes, including the regression benchmarks pyro ships.
+Both expose the same small surface (groups, attrs, create_dataset, item
+access).  The `NpzFile` class below is the container earlier versions of this
+package wrote when h5py was missing ("<base>.pyro.npz"); it is kept so that
+those files stay readable.
 """
 import os
 
@@ -27,14 +28,9 @@ def have_h5py():
 def resolve(filename, for_write):
     """full file name for a base name (with or without extension)"""
     if filename.endswith(".h5") or filename.endswith(".pyro.npz"):
-        if filename.endswith(".h5") and not have_h5py():
-            if for_write:
-                return filename[:-3] + ".pyro.npz"
-            alt = filename[:-3] + ".pyro.npz"
-            return alt if os.path.exists(alt) else filename
         return filename
     if for_write:
-        return filename + (".h5" if have_h5py() else ".pyro.npz")
+        return filename + ".h5"
     for ext in (".h5", ".pyro.npz"):
         if os.path.exists(filename + ext):
             return filename + ext
@@ -43,10 +39,13 @@ def resolve(filename, for_write):
 
 def open_file(filename, mode="r"):
     name = resolve(filename, for_write=mode != "r")
-    if name.endswith(".h5"):
-        import h5py    # raises ImportError with a clear message when missing
+    if name.endswith(".pyro.npz"):
+        return NpzFile(name, mode)
+    if have_h5py() and not os.environ.get("PYRO_H5PURE"):
+        import h5py
         return h5py.File(name, mode)
-    return NpzFile(name, mode)
+    from . import h5pure
+    return h5pure.File(name, mode)
 
 
 class _Attrs:

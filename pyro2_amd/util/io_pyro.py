@@ -1,8 +1,8 @@
 """Read the HDF5 output files (layout of pyro/simulation_null.py:270-290 and
 pyro/mesh/patch.py:750-788) back into a Simulation / CellCenterData2d, API of
 pyro/util/io_pyro.py:27-148.  Files written by pyro itself are readable too
-(same layout).  Host-side I/O through h5py, or through the .npz container of
-util/h5lite.py (same tree) when h5py is not installed."""
+(same layout).  Host-side I/O through h5py, or through the pure-Python HDF5 code of
+util/h5pure.py when h5py is not installed (util/h5lite.py picks)."""
 import importlib
 
 from ..mesh import boundary as bnd

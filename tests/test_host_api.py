@@ -200,7 +200,7 @@ def test_custom_problem_and_fill_bc(api):
 
 def test_hdf5_roundtrip_and_benchmark_compare(api, tmp_path):
     """write() / io_pyro.read() / compare / PyroBenchmark: HDF5 through h5py when
-    it is installed, the .npz container with the same tree otherwise"""
+    it is installed, util/h5pure.py (pure Python HDF5) otherwise"""
     from pyro2_amd.pyro_sim import PyroBenchmark
     from pyro2_amd.util import compare, io_pyro
     p = PyroBenchmark("advection", make_bench=True, bench_dir=str(tmp_path) + "/bench/")
