@@ -3,7 +3,6 @@ pyro/advection/simulation.py:12-94; evolve() is one launch of the fused
 LDS-tiled kernel (pyrohip_adv_step)."""
 from ..mesh import patch
 from ..simulation_null import NullSimulation, bc_setup, grid_setup
-from ..util import msg
 
 
 class Simulation(NullSimulation):
@@ -16,9 +15,7 @@ class Simulation(NullSimulation):
         my_data.register_var("density", bc)
         my_data.create()
         self.cc_data = my_data
-        if self.rp.get_param("particles.do_particles") == 1:
-            msg.warning("particles are host-side post-processing in pyro and are not "
-                        "carried by the device path; ignoring particles.do_particles")
+        self.setup_particles(bc)         # advection/simulation.py:30-33
         self.problem_func(self.cc_data, self.rp)
 
     def method_compute_timestep(self):
@@ -43,6 +40,9 @@ class Simulation(NullSimulation):
                     float(self.rp.get_param("advection.v")), float(self.dt),
                     int(self.rp.get_param("advection.limiter")))
         self.cc_data.device_modified()
+        if self.particles is not None:   # constant velocity field, advection/simulation.py:82-90
+            self.advance_particles(g.scratch_array() + self.rp.get_param("advection.u"),
+                                   g.scratch_array() + self.rp.get_param("advection.v"))
         self.cc_data.t += self.dt
         self.n += 1
         tm.end()

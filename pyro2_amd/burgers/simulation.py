@@ -7,7 +7,6 @@ import numpy as np
 
 from ..mesh import patch
 from ..simulation_null import NullSimulation, bc_setup, grid_setup
-from ..util import msg
 
 
 class Simulation(NullSimulation):
@@ -19,8 +18,7 @@ class Simulation(NullSimulation):
         my_data.register_var("y-velocity", bc)
         my_data.create()
         self.cc_data = my_data
-        if self.rp.get_param("particles.do_particles") == 1:
-            msg.warning("particles are host-side tracers of the reference; not carried here")
+        self.setup_particles(bc)
         self.problem_func(self.cc_data, self.rp)
 
     def _max_abs(self, name):
@@ -45,6 +43,7 @@ class Simulation(NullSimulation):
         st.bg_step(cc.names.index("x-velocity"), cc.names.index("y-velocity"), g.dx, g.dy,
                    self.dt, self.rp.get_param("advection.limiter"))
         cc.device_modified()
+        self.advance_particles()         # burgers/simulation.py:128-133 (updated u, v)
         cc.t += self.dt
         self.n += 1
         tm.end()

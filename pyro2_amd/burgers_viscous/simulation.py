@@ -57,6 +57,7 @@ class Simulation(burgers_simulation):
             st.inc_visc_store(mg, iw)
         self.mg_cycles = tuple(cycles)
         cc.device_modified()
+        self.advance_particles()         # burgers_viscous/simulation.py:80-85
         cc.t += self.dt
         self.n += 1
         tm.end()

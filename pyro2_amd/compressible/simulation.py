@@ -92,6 +92,10 @@ class Simulation(NullSimulation):
         self.cc_data = my_data
         self.ivars = Variables(my_data)
         self.cc_data.add_derived(derives.derive_primitives)
+        # compressible/simulation.py:243-244 hands the parameter object over as
+        # the particle count (TypeError in the reference); the count and the
+        # generator of the [particles] section are what is meant
+        self.setup_particles(bc)
         self.problem_func(self.cc_data, self.rp)
         if self.verbose > 0:
             print(my_data)
@@ -156,6 +160,7 @@ class Simulation(NullSimulation):
         st = self._device_state()
         st.comp_step(self._params(), float(self.dt))
         self.cc_data.device_modified()
+        self.advance_particles()         # compressible/simulation.py:443-444
         self.cc_data.t += self.dt
         self.n += 1
         tm.end()

@@ -54,6 +54,7 @@ class Simulation(CompressibleSimulation):
             rk.store_increment(s)
         rk.compute_final_update()
         cc.device_modified()
+        self.advance_particles()         # compressible_rk/simulation.py:97-98
         cc.t += self.dt
         self.n += 1
         tm.end()

@@ -51,8 +51,7 @@ class Simulation(burgers_simulation):
             my_data.set_aux(keyword=k, value=v)
         my_data.create()
         self.cc_data = my_data
-        if self.rp.get_param("particles.do_particles") == 1:
-            msg.warning("particles are host-side tracers of the reference; not carried here")
+        self.setup_particles(bc)         # incompressible/simulation.py:57-60
         self.in_preevolve = False
         self._mgs = {}
         self.mg_cycles = (0, 0)
@@ -142,6 +141,9 @@ class Simulation(burgers_simulation):
         cc.device_modified()
         self._fill_velocity()
         self.mg_cycles = (nc1, nc2)
+        # incompressible/simulation.py:398-399 asks for a derived "velocity" the
+        # solver does not define; the stored x-/y-velocity is what is meant
+        self.advance_particles()
 
         if not self.in_preevolve:
             cc.t += self.dt

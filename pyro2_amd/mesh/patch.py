@@ -308,6 +308,15 @@ class CellCenterData2d:
                 return var
         raise KeyError(f"name {name} is not valid") from None
 
+    def get_var_readonly(self, name):
+        """like get_var for callers that only READ (host-side diagnostics such
+        as the tracer particles): the device copy stays current"""
+        keep = self._dev_valid
+        try:
+            return self.get_var(name)
+        finally:
+            self._dev_valid = keep
+
     def get_var_by_index(self, n):
         return ArrayIndexer(d=self._host_rw()[:, :, n], grid=self.grid)
 

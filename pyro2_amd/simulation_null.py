@@ -82,6 +82,30 @@ class NullSimulation:
     def __str__(self):
         return f"pyro Simulation:\n  solver: {self.solver_name}\n  problem: {self.problem_name}\n"
 
+    # ---- tracer particles (pyro/particles; host-side diagnostic) ---------
+    def setup_particles(self, bc):
+        """particles.do_particles = 1: seed the tracers the way every solver's
+        initialize() does (e.g. advection/simulation.py:30-33)"""
+        if self.rp.get_param("particles.do_particles") == 1:
+            from .particles import particles
+            self.particles = particles.Particles(
+                self.cc_data, bc, self.rp.get_param("particles.n_particles"),
+                self.rp.get_param("particles.particle_generator"))
+
+    def advance_particles(self, u=None, v=None):
+        """move the tracers over self.dt with the cell-centred velocity: the
+        arrays given, else the stored x-/y-velocity, else the derived
+        "velocity" (read from the device once, only when particles exist)"""
+        if self.particles is None:
+            return
+        cc = self.cc_data
+        if u is None and v is None:
+            if "x-velocity" in cc.names:
+                u, v = cc.get_var_readonly("x-velocity"), cc.get_var_readonly("y-velocity")
+            else:
+                u, v = cc.get_var_readonly("velocity")
+        self.particles.update_particles(self.dt, u, v)
+
     def finished(self):
         return self.cc_data.t >= self.tmax or self.n >= self.max_steps
 

@@ -69,8 +69,7 @@ class Simulation(NullSimulation):
         my_data.set_aux("g", self.rp.get_param("swe.grav"))
         my_data.create()
         self.cc_data = my_data
-        if self.rp.get_param("particles.do_particles") == 1:
-            msg.warning("particles are host-side tracers of the reference; not carried here")
+        self.setup_particles(bc)         # swe/simulation.py:129-132
         self.ivars = Variables(my_data)
         self.cc_data.add_derived(derives.derive_primitives)
         self.problem_func(self.cc_data, self.rp)
@@ -92,6 +91,7 @@ class Simulation(NullSimulation):
                                    self.rp.get_param("swe.limiter"),
                                    self.rp.get_param("swe.riemann"), self.dt)
         cc.device_modified()
+        self.advance_particles()         # swe/simulation.py:198-199 (derived "velocity")
         cc.t += self.dt
         self.n += 1
         tm.end()

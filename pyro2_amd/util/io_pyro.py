@@ -35,6 +35,12 @@ def read(filename):
             myd.set_aux(k, f["aux"].attrs[k])
         for n in names:
             myd.get_var(n).v()[:, :] = f["state"][n]["data"][:, :]
+        my_particles = None              # io_pyro.py:108-117
+        if "particles" in f:
+            from ..particles import particles
+            pos = f["particles"]["particle_positions"][...]
+            my_particles = particles.Particles(myd, None, len(pos), "array", pos,
+                                               f["particles"]["init_particle_positions"][...])
     if solver_name is None:
         return myd
     if isinstance(solver_name, bytes):
@@ -51,6 +57,7 @@ def read(filename):
     # what a restart needs beyond the state (Pyro.restart_problem)
     sim.restart_info = {"dt": dt, "dt_old": dt_old, "params": params}
     sim.cc_data = myd
+    sim.particles = my_particles
     sim.cc_data.t = t
     try:
         derives = importlib.import_module(f"pyro2_amd.{base}.derives")
