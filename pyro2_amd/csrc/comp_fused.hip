@@ -99,6 +99,26 @@ __device__ __forceinline__ Cons corr(const Cons &U, const Cons &Fhi, const Cons 
     return r;
 }
 
+// cons_to_prim (hydro.h) without the branch on rho != 0: same operations on
+// the same operands when rho != 0 (bit-identical), zeros otherwise
+__device__ __forceinline__ Prim cons_to_prim_nb(const Cons &U, double gamma, bool &ok)
+{
+    const bool nz = (U.d != 0.0);
+    const double ds = nz ? U.d : 1.0;
+    const double rd = PYRO_FAST ? prcp(ds) : 0.0;
+    const double u = pdivr(U.mx, ds, rd);
+    const double v = pdivr(U.my, ds, rd);
+    const double e = pdivr(U.E - 0.5 * U.d * (u * u + v * v), ds, rd);
+    Prim q;
+    q.r = U.d;
+    q.u = nz ? u : 0.0;
+    q.v = nz ? v : 0.0;
+    const double es = nz ? e : 0.0;
+    q.p = U.d * es * (gamma - 1.0);
+    ok = (es > 0.0) && (U.d > 0.0);
+    return q;
+}
+
 #ifndef PYRO_FUSED_MINW
 // waves per SIMD the register allocation must allow: 4 = two 512-thread
 // workgroups per CU (128 VGPRs, 48 B/lane scratch).  Measured at 8192^2:
@@ -129,20 +149,41 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
     const double gamma = P.gamma;
 
     // ---- phase 0: U -> Q (rho,u,v,p) for the tile + 4-cell apron --------
+    // All global loads of the thread (2 cells x 4 planes) are issued before the
+    // first use and the conversion is branch-free: with the `if (U.d != 0)` of
+    // cons_to_prim the compiler sank the loads of E, mx, my into the branch, so
+    // a workgroup went through four dependent HBM round trips here (density,
+    // rest, density, rest) instead of one.
     bool bad = false;
-    for (int idx = t; idx < FQN; idx += FNT) {
-        const int r = idx / FQW, c = idx - r * FQW;
-        int gi = i0 - 4 + r, gj = j0 - 4 + c;
-        gi = (gi < g.qx) ? gi : g.qx - 1;   // ragged last tiles: clamp, unused
-        gj = (gj < g.qy) ? gj : g.qy - 1;
-        const size_t k = (size_t)gi * p + gj;
-        Cons U{Uin[k], Uin[pl + k], Uin[2 * pl + k], Uin[3 * pl + k]};
-        const bool interior = (gi >= g.ilo && gi <= g.ihi && gj >= g.jlo && gj <= g.jhi);
-        if (interior) U.d = fmax(U.d, P.small_dens);      // clean_state
-        bool ok;
-        const Prim q = cons_to_prim(U, gamma, &ok);
-        if (interior && !ok) bad = true;
-        B0[idx] = q.r; B0[FQN + idx] = q.u; B0[2 * FQN + idx] = q.v; B0[3 * FQN + idx] = q.p;
+    {
+        constexpr int NIT = (FQN + FNT - 1) / FNT;
+        Cons Ul[NIT];
+        bool act[NIT], interior[NIT];
+#pragma unroll
+        for (int n = 0; n < NIT; n++) {
+            const int idx = t + n * FNT;
+            act[n] = idx < FQN;
+            const int ii = act[n] ? idx : t;       // idle lanes re-read their first cell
+            const int r = ii / FQW, c = ii - r * FQW;
+            int gi = i0 - 4 + r, gj = j0 - 4 + c;
+            gi = (gi < g.qx) ? gi : g.qx - 1;   // ragged last tiles: clamp, unused
+            gj = (gj < g.qy) ? gj : g.qy - 1;
+            const size_t k = (size_t)gi * p + gj;
+            Ul[n] = Cons{Uin[k], Uin[pl + k], Uin[2 * pl + k], Uin[3 * pl + k]};
+            interior[n] = (gi >= g.ilo && gi <= g.ihi && gj >= g.jlo && gj <= g.jhi);
+        }
+#pragma unroll
+        for (int n = 0; n < NIT; n++) {
+            const int idx = t + n * FNT;
+            Cons U = Ul[n];
+            if (interior[n]) U.d = fmax(U.d, P.small_dens);      // clean_state
+            bool ok;
+            const Prim q = cons_to_prim_nb(U, gamma, ok);
+            if (act[n] && interior[n] && !ok) bad = true;
+            if (act[n]) {
+                B0[idx] = q.r; B0[FQN + idx] = q.u; B0[2 * FQN + idx] = q.v; B0[3 * FQN + idx] = q.p;
+            }
+        }
     }
     if (bad) atomicOr(flag, 1);
     __syncthreads();
@@ -257,41 +298,43 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
     if (cell_interior) Uc.d = fmax(Uc.d, P.small_dens);
     Cons Fx{0, 0, 0, 0}, Fy{0, 0, 0, 0};
     const double d00 = D[t];
+    // the lower neighbours' old states for the artificial-viscosity terms:
+    // loaded (L2 hits) before the Riemann problems so that the latency is
+    // covered by them.  k - p / k - 1 are inside the array for every thread.
+    Cons Umx{Uin[k - p], Uin[pl + k - p], Uin[2 * pl + k - p], Uin[3 * pl + k - p]};
+    Cons Umy{Uin[k - 1], Uin[pl + k - 1], Uin[2 * pl + k - 1], Uin[3 * pl + k - 1]};
+    double avx = 0.0, avy = 0.0;
+    // interface.py:366-376: only faces i in [ilo, ihi], j in [jlo, jhi]
+    if (ti >= 1 && tj >= 1 && tj <= FBJ - 2 && i >= g.ilo &&
+        (i <= g.ihi || (P.avx_hi && i == g.ihi + 1)) && j >= g.jlo && j <= g.jhi) {
+        const double divU_x = 0.5 * (d00 + D[t + 1]);
+        avx = P.cvisc * fmax(-divU_x * P.dx, 0.0);
+    }
+    if (tj >= 1 && ti >= 1 && ti <= FBI - 2 && j >= g.jlo &&
+        (j <= g.jhi || (P.avy_hi && j == g.jhi + 1)) && i >= g.ilo && i <= g.ihi) {
+        const double divU_y = 0.5 * (d00 + D[t + FBJ]);
+        avy = P.cvisc * fmax(-divU_y * P.dy, 0.0);
+    }
+    if (i - 1 >= g.ilo && i - 1 <= g.ihi && j >= g.jlo && j <= g.jhi)
+        Umx.d = fmax(Umx.d, P.small_dens);
+    if (i >= g.ilo && i <= g.ihi && j - 1 >= g.jlo && j - 1 <= g.jhi)
+        Umy.d = fmax(Umy.d, P.small_dens);
     if (ti >= 1 && tj >= 1 && tj <= FBJ - 2) {           // x face (i, j)
         Fx = from_nf(riemann_face<SOLVER>(to_nf(lds_get(S, t - FBJ), true), to_nf(XM, true), gamma,
                                           true, P.solid_xl && i == g.ilo), true);
-        double avx = 0.0;
-        // interface.py:366-376: only faces i in [ilo, ihi], j in [jlo, jhi]
-        if (i >= g.ilo && (i <= g.ihi || (P.avx_hi && i == g.ihi + 1)) && j >= g.jlo &&
-            j <= g.jhi) {
-            const double divU_x = 0.5 * (d00 + D[t + 1]);
-            avx = P.cvisc * fmax(-divU_x * P.dx, 0.0);
-        }
-        Cons Um{Uin[k - p], Uin[pl + k - p], Uin[2 * pl + k - p], Uin[3 * pl + k - p]};
-        if (i - 1 >= g.ilo && i - 1 <= g.ihi && j >= g.jlo && j <= g.jhi)
-            Um.d = fmax(Um.d, P.small_dens);
-        Fx.d += avx * (Um.d - Uc.d);
-        Fx.E += avx * (Um.E - Uc.E);
-        Fx.mx += avx * (Um.mx - Uc.mx);
-        Fx.my += avx * (Um.my - Uc.my);
+        Fx.d += avx * (Umx.d - Uc.d);
+        Fx.E += avx * (Umx.E - Uc.E);
+        Fx.mx += avx * (Umx.mx - Uc.mx);
+        Fx.my += avx * (Umx.my - Uc.my);
     }
     if (tj >= 1 && ti >= 1 && ti <= FBI - 2) {           // y face (i, j)
         Fy = from_nf(riemann_face<SOLVER>(to_nf(lds_get(S + 4 * FNT, t - 1), false),
                                           to_nf(YM, false), gamma, false,
                                           P.solid_yl && j == g.jlo), false);
-        double avy = 0.0;
-        if (j >= g.jlo && (j <= g.jhi || (P.avy_hi && j == g.jhi + 1)) && i >= g.ilo &&
-            i <= g.ihi) {
-            const double divU_y = 0.5 * (d00 + D[t + FBJ]);
-            avy = P.cvisc * fmax(-divU_y * P.dy, 0.0);
-        }
-        Cons Um{Uin[k - 1], Uin[pl + k - 1], Uin[2 * pl + k - 1], Uin[3 * pl + k - 1]};
-        if (i >= g.ilo && i <= g.ihi && j - 1 >= g.jlo && j - 1 <= g.jhi)
-            Um.d = fmax(Um.d, P.small_dens);
-        Fy.d += avy * (Um.d - Uc.d);
-        Fy.E += avy * (Um.E - Uc.E);
-        Fy.mx += avy * (Um.mx - Uc.mx);
-        Fy.my += avy * (Um.my - Uc.my);
+        Fy.d += avy * (Umy.d - Uc.d);
+        Fy.E += avy * (Umy.E - Uc.E);
+        Fy.mx += avy * (Umy.mx - Uc.mx);
+        Fy.my += avy * (Umy.my - Uc.my);
     }
     lds_put(B0, t, Fx);            // FT was last read before the barrier above
     lds_put(B0 + 4 * FNT, t, Fy);
