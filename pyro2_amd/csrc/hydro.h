@@ -50,6 +50,18 @@ __device__ __forceinline__ double psqrt(double x)
 #endif
     return (x > 0.0) ? g : 0.0;
 }
+// sqrt(x) and 1/sqrt(x) of a strictly positive, normal argument from ONE
+// v_rsq_f64 (a transcendental issues at quarter rate: 16 cycles per wave)
+__device__ __forceinline__ double psqrt_r(double x, double &rinv)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    rinv = h + h;
+    return g;
+}
 // same for arguments that may be exactly 0 (velocity magnitudes): psqrt already
 // returns 0 there
 __device__ __forceinline__ double psqrt0(double x) { return psqrt(x); }
@@ -145,7 +157,13 @@ __device__ __forceinline__ void trace_states(double r, double un, double ut, dou
                                              double gamma, double dtdx, Trace &lo, Trace &hi)
 {
     const double dtdx4 = 0.25 * dtdx;                // interface.py:107
+#if PYRO_FAST && !defined(PYRO_EMU)
+    const double rr = prcp(r);
+    double rcs_f;
+    const double cs = psqrt_r(gamma * p * rr, rcs_f);   // :122
+#else
     const double cs = psqrt(pdiv(gamma * p, r));     // :122
+#endif
     const double e0 = un - cs, e1 = un, e3 = un + cs;  // :129 / :151  (e2 == e1)
 
     // reference states, :174-191
@@ -158,7 +176,11 @@ __device__ __forceinline__ void trace_states(double r, double un, double ut, dou
 
     // l_m . dq as 4-term in-order sums with the zero entries dropped
     // (adding 0*x terms never changes a finite sum), :131-139 / :153-161
+#if PYRO_FAST && !defined(PYRO_EMU)
+    const double rcs = rcs_f;
+#else
     const double rcs = PYRO_FAST ? prcp(cs) : 0.0;
+#endif
     const double rc2 = PYRO_FAST ? rcs * rcs : 0.0;
     const double a0 = pdivr(-0.5 * r, cs, rcs) * dun + pdivr(0.5, cs * cs, rc2) * dp;
     const double a1 = dr + pdivr(-1.0, cs * cs, rc2) * dp;
@@ -180,7 +202,11 @@ __device__ __forceinline__ void trace_states(double r, double un, double ut, dou
 
     // sum_m beta_m r_m, in index order with the structural zeros kept where
     // they sit between non-zero terms, :203-213; r_m from :141-144 / :163-166
+#if PYRO_FAST && !defined(PYRO_EMU)
+    const double cr = cs * rr, c2 = cs * cs;
+#else
     const double cr = pdiv(cs, r), c2 = cs * cs;
+#endif
     hi.r = hi.r + (bl0 + bl1);
     hi.un = hi.un + bl0 * (-cr);
     hi.ut = hi.ut + bl2;
@@ -200,7 +226,11 @@ __device__ __forceinline__ void estimate_wave_speed(double rho_l, double u_l, do
 {
     double p_max = fmax(p_l, p_r);
     double p_min = fmin(p_l, p_r);
+#if PYRO_FAST && !defined(PYRO_EMU)
+    const double Q = (p_max > 2.0 * p_min) ? 3.0 : 1.0;   // only "Q > 2" is used below
+#else
     double Q = pdiv(p_max, p_min);
+#endif
     double rho_avg = 0.5 * (rho_l + rho_r);
     double c_avg = 0.5 * (c_l + c_r);
     double factor = rho_avg * c_avg;
@@ -296,24 +326,38 @@ __device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, dou
     if (S_r <= 0.0) {
         F = cons_flux_n(Ur, gamma, normal_is_x);
     } else if (S_c <= 0.0 && 0.0 < S_r) {
+#if PYRO_FAST && !defined(PYRO_EMU)
+        const double a = rho_r * (S_r - un_r), b = S_r - S_c;
+        const double w = prcp(a * b);          // a/b = a*a*w,  p_r/a = p_r*b*w
+        const double f = a * a * w, pa = p_r * b * w;
+#else
         double f = pdiv(rho_r * (S_r - un_r), S_r - S_c);
+        const double pa = pdiv(p_r, rho_r * (S_r - un_r));
+#endif
         ConsN Us;
         Us.d = f;
         Us.mn = f * S_c;
         Us.mt = f * ut_r;
-        Us.E = f * (pdivr(Ur.E, rho_r, rir) + (S_c - un_r) * (S_c + pdiv(p_r, rho_r * (S_r - un_r))));
+        Us.E = f * (pdivr(Ur.E, rho_r, rir) + (S_c - un_r) * (S_c + pa));
         F = cons_flux_n(Ur, gamma, normal_is_x);
         F.d = F.d + S_r * (Us.d - Ur.d);
         F.mn = F.mn + S_r * (Us.mn - Ur.mn);
         F.mt = F.mt + S_r * (Us.mt - Ur.mt);
         F.E = F.E + S_r * (Us.E - Ur.E);
     } else if (S_l < 0.0 && 0.0 < S_c) {
+#if PYRO_FAST && !defined(PYRO_EMU)
+        const double a = rho_l * (S_l - un_l), b = S_l - S_c;
+        const double w = prcp(a * b);
+        const double f = a * a * w, pa = p_l * b * w;
+#else
         double f = pdiv(rho_l * (S_l - un_l), S_l - S_c);
+        const double pa = pdiv(p_l, rho_l * (S_l - un_l));
+#endif
         ConsN Us;
         Us.d = f;
         Us.mn = f * S_c;
         Us.mt = f * ut_l;
-        Us.E = f * (pdivr(Ul.E, rho_l, ril) + (S_c - un_l) * (S_c + pdiv(p_l, rho_l * (S_l - un_l))));
+        Us.E = f * (pdivr(Ul.E, rho_l, ril) + (S_c - un_l) * (S_c + pa));
         F = cons_flux_n(Ul, gamma, normal_is_x);
         F.d = F.d + S_l * (Us.d - Ul.d);
         F.mn = F.mn + S_l * (Us.mn - Ul.mn);
