@@ -59,7 +59,9 @@ __global__ __launch_bounds__(ADV_THREADS) void k_adv_step(const double *__restri
                                                           AdvParams P, int ntj, int ntiles)
 {
     static_assert(ADV_THREADS == 256 && ADV_TJ == 64, "4 waves, lane = column");
-    __shared__ double A[ADV_AH][ADV_AW];
+    // rows padded to 4 * NR so that every wave stores all the rows it loaded
+    // (no predicate the compiler could sink a load under)
+    __shared__ double A[((ADV_AH + 3) / 4) * 4][ADV_AW];
     __shared__ double AX[ADV_XH][ADV_XW];
     __shared__ double AY[ADV_YH][ADV_YW];
     const int tile = xcd_tile(blockIdx.x, ntiles);
@@ -69,22 +71,39 @@ __global__ __launch_bounds__(ADV_THREADS) void k_adv_step(const double *__restri
     const int p = g.pitch;
 
     // ---- phase 0: stage a (tile + apron) in LDS -------------------------
-    // columns H .. H+63 (the tile's own, 512-byte aligned rows) by all lanes
-    for (int r = w; r < ADV_AH; r += 4) {
-        int i = i0 - ADV_H + r, j = j0 + l;
-        i = (i < g.qx) ? i : g.qx - 1;   // partial tiles: clamp (values unused)
+    // Every load of the thread (up to 6 tile rows + 1 apron cell) is issued
+    // before the first LDS store: written as load/store loops, each iteration
+    // waited for its own load -- seven dependent HBM round trips per workgroup.
+    constexpr int NR = (ADV_AH + 3) / 4;          // rows per wave
+    double av[NR];
+#pragma unroll
+    for (int n = 0; n < NR; n++) {
+        // columns H .. H+63 (the tile's own, 512-byte aligned rows) by all lanes
+        int i = i0 - ADV_H + w + 4 * n, j = j0 + l;
+        i = (i < g.qx) ? i : g.qx - 1;   // partial tiles / rows beyond the apron: clamp (unused)
         j = (j < g.qy) ? j : g.qy - 1;
-        A[r][ADV_H + l] = ain[(size_t)i * p + j];
+        av[n] = ain[(size_t)i * p + j];
     }
-    // the 2 x H apron columns: ADV_AH rows x 6 columns
-    for (int idx = tid; idx < ADV_AH * 2 * ADV_H; idx += ADV_THREADS) {
-        const int r = idx / (2 * ADV_H), k = idx - r * (2 * ADV_H);
-        const int c = (k < ADV_H) ? k : ADV_TJ + k;          // 0..2, 67..69
-        int i = i0 - ADV_H + r, j = j0 - ADV_H + c;
+    // the 2 x H apron columns: ADV_AH rows x 6 columns, one cell per thread
+    static_assert(ADV_AH * 2 * ADV_H <= ADV_THREADS, "one apron cell per thread");
+    static_assert(ADV_THREADS <= 2 * ADV_AH * 2 * ADV_H, "apron cell index wraps once");
+    // threads beyond the apron cells repeat one of them (same value to the same
+    // LDS word): no predicate the compiler could sink the load under
+    const int at = (tid < ADV_AH * 2 * ADV_H) ? tid : tid - ADV_AH * 2 * ADV_H;
+    const int apr = at / (2 * ADV_H), apk = at - apr * (2 * ADV_H);
+    const int apc = (apk < ADV_H) ? apk : ADV_TJ + apk;          // 0..2, 67..69
+    double apv;
+    {
+        int i = i0 - ADV_H + apr, j = j0 - ADV_H + apc;
         i = (i < g.qx) ? i : g.qx - 1;
         j = (j < g.qy) ? j : g.qy - 1;
-        A[r][c] = ain[(size_t)i * p + j];
+        apv = ain[(size_t)i * p + j];
     }
+#pragma unroll
+    for (int n = 0; n < NR; n++) {
+        A[w + 4 * n][ADV_H + l] = av[n];
+    }
+    A[apr][apc] = apv;
     __syncthreads();
 
     const double u = P.u, v = P.v;
