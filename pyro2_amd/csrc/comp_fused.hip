@@ -119,6 +119,17 @@ __device__ __forceinline__ Prim cons_to_prim_nb(const Cons &U, double gamma, boo
     return q;
 }
 
+// developer timing aid (tools/fused_phases.sh): -DPYRO_FUSED_STOP=k ends the
+// kernel after phase k, storing one value that depends on the phase's results
+#ifndef PYRO_FUSED_STOP
+#define PYRO_FUSED_STOP 99
+#endif
+#define PYRO_PHASE_END(k, val)                                                   \
+    if (PYRO_FUSED_STOP == (k)) {                                                \
+        if (i < g.qx && j < g.qy) Uout[(size_t)i * p + j] = (val);               \
+        return;                                                                  \
+    }
+
 #ifndef PYRO_FUSED_MINW
 // waves per SIMD the register allocation must allow: 4 = two 512-thread
 // workgroups per CU (128 VGPRs, 48 B/lane scratch).  Measured at 8192^2:
@@ -138,6 +149,11 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
     double *S = lds + FBUF0;          // upper face states XP(0..3), YP(4..7)
     double *D = S + 8 * FNT;          // vertex div(U)
 
+    // (a walk that keeps every XCD on a contiguous band of tiles for ANY tile
+    // count -- xcd_tile falls back to the identity when it is not divisible by
+    // 8, as at 8192^2 and 16384^2 -- and goes through super-columns of 8..64
+    // tiles was measured: 3.85 vs 3.82 ms at 8192^2.  The apron re-reads are
+    // served by the MALL; phase 0 is bound by latency, not by fabric traffic.)
     const int tile = xcd_tile(blockIdx.x, P.ntiles);
     const int i0 = g.ilo + (tile / P.ntj) * FTI;
     const int j0 = g.jlo + (tile % P.ntj) * FTJ;
@@ -187,6 +203,7 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
     }
     if (bad) atomicOr(flag, 1);
     __syncthreads();
+    PYRO_PHASE_END(0, B0[(ti + 3) * FQW + (tj + 3)] + B0[3 * FQN + (ti + 3) * FQW + (tj + 3)])
 
     // ---- phase 1: xi, slopes, tracing for the thread's own cell --------
     Cons XM, XP, YM, YP;
@@ -257,6 +274,7 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
         lds_put(S + 4 * FNT, t, YP);
     }
     __syncthreads();   // Q is dead from here on; B0 becomes the flux buffer
+    PYRO_PHASE_END(1, XM.d + XM.E + XM.mx + XM.my + YM.d + YM.E + YM.mx + YM.my + S[t] + S[7 * FNT + t] + D[t])
 
     // ---- phase 2: transverse Riemann problems on the lower faces --------
     Cons FxT{0, 0, 0, 0}, FyT{0, 0, 0, 0};
@@ -270,6 +288,7 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
     lds_put(B0, t, FxT);
     lds_put(B0 + 4 * FNT, t, FyT);
     __syncthreads();
+    PYRO_PHASE_END(2, FxT.d + FxT.E + FxT.mx + FxT.my + FyT.d + FyT.E + FyT.mx + FyT.my + XM.d + YM.E)
 
     // ---- phase 3: transverse correction of the cell's own states --------
     const double hdtV = P.hdtV;                          // hdt / V
@@ -289,6 +308,7 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
     lds_put(S, t, XP);
     lds_put(S + 4 * FNT, t, YP);
     __syncthreads();
+    PYRO_PHASE_END(3, XM.d + XM.E + XM.mx + XM.my + YM.d + YM.E + YM.mx + YM.my + S[t] + S[7 * FNT + t])
 
     // ---- phase 4: final Riemann problems + artificial viscosity ---------
     const bool in_arr = (i < g.qx && j < g.qy);
@@ -339,6 +359,7 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
     lds_put(B0, t, Fx);            // FT was last read before the barrier above
     lds_put(B0 + 4 * FNT, t, Fy);
     __syncthreads();
+    PYRO_PHASE_END(4, Fx.d + Fx.E + Fx.mx + Fx.my + Fy.d + Fy.E + Fy.mx + Fy.my)
 
     // ---- phase 5: conservative update + CFL of the new state -----------
     double cfl = INFINITY;
