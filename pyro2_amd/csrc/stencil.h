@@ -25,17 +25,14 @@ __device__ __forceinline__ double limit2(double am, double a0, double ap)
     double dc = 0.5 * (ap - am);
     double dl = ap - a0;
     double dr = a0 - am;
-#if PYRO_FAST && !defined(PYRO_EMU)
     // where dl*dr > 0 the three candidates share their sign (dc is their
-    // mean), so the selects by magnitude are two v_min_f64 with |.| operand
-    // modifiers and a sign copy: the same value as mc_select, 8 instead of 11
-    // VALU instructions (3 compares + 6 v_cndmask_b32 there)
+    // mean), so the selects by magnitude of mc_select are two minima of
+    // absolute values (v_min_f64 with |.| operand modifiers) and a sign copy:
+    // the SAME candidate is chosen, bit for bit (ties have equal values), at 8
+    // instead of 11 VALU instructions (3 compares + 6 v_cndmask_b32 there)
     const double m = fmin(fabs(dl), fabs(dr));
     const double r = copysign(fmin(fabs(dc), m + m), dl);
     return (dl * dr > 0.0) ? r : 0.0;
-#else
-    return mc_select(dc, dl, dr);
-#endif
 }
 
 // limited slope at the centre of the 5-point stencil (reconstruction.py:9-120)
