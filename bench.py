@@ -267,6 +267,13 @@ def cpu_baseline_sedov(sample_nx, max_seconds=25.0):
 
 def main():
     args = parse()
+    # multi-process GPU work on this image: dmabuf IPC only (already exported on
+    # the GPU boxes; kept here so that a bare environment behaves the same), and
+    # all ranks of this bench live on ONE node: let RCCL's bootstrap use the
+    # loopback interface unless the caller chose one
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
     if world != args.gpus:
         if "RANK" not in os.environ and args.gpus > 1:
