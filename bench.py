@@ -141,13 +141,12 @@ def bench_sedov(args, dist, ctx, device, defaults):
 
 
 def bench_advection(ctx, device, nx=2048, steps=100, warmup=10):
-    from oracle import orc
     x = (np.arange(nx + 8) - 3.5) / nx
     X, Y = np.meshgrid(x, x, indexing="ij")
     ic = 1.0 + np.exp(-60.0 * ((X - 0.5) ** 2 + (Y - 0.5) ** 2))
     st = device.DeviceState(ctx, nx, nx, 4, [["periodic"] * 4])
     st.upload(ic)
-    dt = orc.adv_dt(1 / nx, 1 / nx, 1.0, 1.0, 0.8)
+    dt = 0.8 * min((1 / nx) / 1.0, (1 / nx) / 1.0)     # advection/simulation.py:38-54, u = v = 1, cfl 0.8
 
     def step():
         st.fill_bc()
