@@ -138,7 +138,11 @@ __device__ __forceinline__ Prim cons_to_prim_nb(const Cons &U, double gamma, boo
 #define PYRO_FUSED_MINW 4
 #endif
 
-template <int SOLVER>   // compressible.riemann: 0 HLLC, 1 CGF, 2 HLLC_lm
+// STD: the default physics (limiter 2 = 4th-order MC, flattening on, no
+// gravity / heating sources) as compile-time constants: straight-line code the
+// compiler schedules across the eight limited slopes (3.84 -> 3.61 ms at
+// 8192^2); STD = false reads all of it from the parameters
+template <int SOLVER, bool STD = false>   // compressible.riemann: 0 HLLC, 1 CGF, 2 HLLC_lm
 __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double *__restrict__ Uin,
                                                    double *__restrict__ Uout, Geom g, FP P,
                                                    int *__restrict__ flag,
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
         const int qc = (ti + 3) * FQW + (tj + 3);   // own cell in the Q tile
         const double *Qr = B0, *Qu = B0 + FQN, *Qv = B0 + 2 * FQN, *Qp = B0 + 3 * FQN;
         double xi = 1.0;
-        if (P.use_flattening) {
+        if (STD || P.use_flattening) {
             // flatten_multid (reconstruction.py:167-183): own coefficient and
             // the one of the UPWIND neighbour (w.r.t. the pressure gradient)
             // in each direction -- the downwind one is never selected
@@ -236,9 +240,9 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
             const double *a = B0 + n * FQN;
             q0[n] = a[qc];
             dqx[n] = xi * limited_slope(a[qc - 2 * FQW], a[qc - FQW], a[qc], a[qc + FQW],
-                                        a[qc + 2 * FQW], P.limiter);
+                                        a[qc + 2 * FQW], STD ? 2 : P.limiter);
             dqy[n] = xi * limited_slope(a[qc - 2], a[qc - 1], a[qc], a[qc + 1], a[qc + 2],
-                                        P.limiter);
+                                        STD ? 2 : P.limiter);
         }
         Trace lo, hi;
         trace_states(q0[0], q0[1], q0[2], q0[3], dqx[0], dqx[1], dqx[2], dqx[3], gamma,
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
         // vertex divergence at (i-1/2, j-1/2), interface.py:312-330
         D[t] = div_u_vertex(Qu[qc], Qu[qc - 1], Qu[qc - FQW], Qu[qc - FQW - 1], Qv[qc],
                             Qv[qc - FQW], Qv[qc - 1], Qv[qc - FQW - 1], P.dx, P.dy);
-        if (P.have_src) {   // apply_source_terms, unsplit_fluxes.py:247-330
+        if (!STD && P.have_src) {   // apply_source_terms, unsplit_fluxes.py:247-330
             const bool ina = (i < g.qx && j < g.qy);
             // "ambient" upper boundary: the source ghosts are copies of row jhi
             // (BC.py:159-160), not the sources of the ambient ghost state
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
         Un.E = Uc.E + dtdV * (Fx.E * Ax - Fxh.E * Ax + Fy.E * Ay - Fyh.E * Ay);
         Un.mx = Uc.mx + dtdV * (Fx.mx * Ax - Fxh.mx * Ax + Fy.mx * Ay - Fyh.mx * Ay);
         Un.my = Uc.my + dtdV * (Fx.my * Ax - Fxh.my * Ax + Fy.my * Ay - Fyh.my * Ay);
-        if (P.have_src)   // simulation.py:406-423
+        if (!STD && P.have_src)   // simulation.py:406-423
             grav_update(Un, Uc, P.grav, P.dt, P.heat_rate, P.heat ? P.heat[k] : 0.0);
         Uout[k] = Un.d; Uout[pl + k] = Un.E; Uout[2 * pl + k] = Un.mx; Uout[3 * pl + k] = Un.my;
         cfl = cfl_cell(Un, gamma, P.dx, P.dy);
@@ -446,6 +450,9 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
 #ifndef PYRO_EMU
     static bool attr_set = false;
     if (!attr_set) {
+        PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_ctu_fused<0, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)FLDS_BYTES));
         PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_ctu_fused<0>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)FLDS_BYTES));
@@ -463,6 +470,9 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
                     (const double *)Uin, Uout, g, P, s->d_flag, part);
     else if (p->riemann == 1)
         PYRO_LAUNCH(c, "k_ctu_fused", k_ctu_fused<1>, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
+                    (const double *)Uin, Uout, g, P, s->d_flag, part);
+    else if (p->limiter == 2 && p->use_flattening && !P.have_src)
+        PYRO_LAUNCH(c, "k_ctu_fused", (k_ctu_fused<0, true>), dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
                     (const double *)Uin, Uout, g, P, s->d_flag, part);
     else
         PYRO_LAUNCH(c, "k_ctu_fused", k_ctu_fused<0>, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
