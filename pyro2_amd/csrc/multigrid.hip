@@ -64,6 +64,7 @@ struct pyrohip_mg {
     int kmax = 5;                 // red-black iterations fused per tile launch
     int kmax_small = 5;           // ... on levels <= 1024^2 (latency bound)
     int coarse_kernel = 1;        // levels <= 64^2 in one LDS-resident workgroup
+    int fuse_res_restrict = getenv("PYRO_MG_NOFUSE_RR") ? 0 : 1;   // down leg: residual + restriction in one pass
     int vc = 0;                   // 1: div(eta grad phi) = f; 2: general (alpha, beta, gamma)
     double *vc_pool = nullptr;
     double *gen_pool = nullptr;
@@ -965,6 +966,31 @@ __global__ __launch_bounds__(256) void k_mg_restrict(const double *__restrict__ 
         0.25 * (fr[fk] + fr[fk + fpitch] + fr[fk + 1] + fr[fk + fpitch + 1]);
 }
 
+// Down leg of the V-cycle, constant coefficients: residual of the fine level
+// (MG.py:529-542) AND its restriction into the coarse right-hand side
+// (patch.py:640-676) in one pass -- one thread per COARSE cell evaluates the
+// residual of its 2 x 2 fine cells with k_mg_residual's expression, stores
+// them (r stays observable) and averages them in k_mg_restrict's order.  Saves
+// re-reading r and one launch per level.
+__global__ __launch_bounds__(256) void k_mg_residual_restrict(
+    const double *__restrict__ v, const double *__restrict__ f, double *__restrict__ r, int fpitch,
+    double *__restrict__ cf, int cpitch, int nc, double alpha, double beta, double dx2)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= nc) return;
+    const size_t k00 = (size_t)(1 + 2 * i) * fpitch + (1 + 2 * j);
+    auto res = [&](size_t k) {
+        return f[k] - alpha * v[k] +
+               beta * ((v[k - fpitch] + v[k + fpitch] - 2 * v[k]) / dx2 +
+                       (v[k - 1] + v[k + 1] - 2 * v[k]) / dx2);
+    };
+    const double r00 = res(k00), r10 = res(k00 + fpitch), r01 = res(k00 + 1),
+                 r11 = res(k00 + fpitch + 1);
+    r[k00] = r00; r[k00 + fpitch] = r10; r[k00 + 1] = r01; r[k00 + fpitch + 1] = r11;
+    cf[(size_t)(1 + i) * cpitch + (1 + j)] = 0.25 * (r00 + r10 + r01 + r11);
+}
+
 // patch.py:678-736 + MG.py:745-748: fine v += prolong(coarse v)
 // one thread per FINE cell
 __global__ __launch_bounds__(256) void k_mg_prolong_add(const double *__restrict__ cv, int cpitch,
@@ -1370,8 +1396,17 @@ static int mg_vcycle(pyrohip_mg *m, int level)
         return mg_coarse_vcycle(m, level);
     if (level > 0) {
         PYRO_TRY(mg_smooth(m, level, m->nsmooth, false)); // MG.py:722
-        PYRO_TRY(mg_residual(m, level));                  // :724
-        PYRO_TRY(mg_restrict(m, level));                  // :731-732
+        if (!m->vc && m->fuse_res_restrict) {             // :724 + :731-732 in one pass
+            MGLevel &F = m->lev[level], &Cc = m->lev[level - 1];
+            const int bx = (Cc.n >= 256) ? 256 : 64;
+            PYRO_LAUNCH(m->ctx, "k_mg_residual_restrict", k_mg_residual_restrict,
+                        dim3((Cc.n + bx - 1) / bx, Cc.n), dim3(bx), 0, (const double *)F.v,
+                        (const double *)F.f, F.r, F.pitch, Cc.f, Cc.pitch, Cc.n, m->alpha, m->beta,
+                        F.dx * F.dx);
+        } else {
+            PYRO_TRY(mg_residual(m, level));              // :724
+            PYRO_TRY(mg_restrict(m, level));              // :731-732
+        }
         PYRO_TRY(mg_vcycle(m, level - 1));                // :735
         const bool fuse = mg_prolong_fusable(m, level, m->nsmooth);
         if (!fuse) PYRO_TRY(mg_prolong_add(m, level));    // :745-748 (else: while staging below)
