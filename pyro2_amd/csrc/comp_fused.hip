@@ -138,10 +138,11 @@ __device__ __forceinline__ Prim cons_to_prim_nb(const Cons &U, double gamma, boo
 #define PYRO_FUSED_MINW 4
 #endif
 
-// STD: the default physics (limiter 2 = 4th-order MC, flattening on, no
-// gravity / heating sources) as compile-time constants: straight-line code the
-// compiler schedules across the eight limited slopes (3.84 -> 3.61 ms at
-// 8192^2); STD = false reads all of it from the parameters
+// STD: the default reconstruction (limiter 2 = 4th-order MC, flattening on) as
+// compile-time constants: straight-line code the compiler schedules across the
+// eight limited slopes (3.84 -> 3.61 ms at 8192^2; also making "no sources" a
+// constant gave 3.59 and was not kept: problems with gravity use this instance
+// too); STD = false reads both from the parameters
 template <int SOLVER, bool STD = false>   // compressible.riemann: 0 HLLC, 1 CGF, 2 HLLC_lm
 __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double *__restrict__ Uin,
                                                    double *__restrict__ Uout, Geom g, FP P,
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
         // vertex divergence at (i-1/2, j-1/2), interface.py:312-330
         D[t] = div_u_vertex(Qu[qc], Qu[qc - 1], Qu[qc - FQW], Qu[qc - FQW - 1], Qv[qc],
                             Qv[qc - FQW], Qv[qc - 1], Qv[qc - FQW - 1], P.dx, P.dy);
-        if (!STD && P.have_src) {   // apply_source_terms, unsplit_fluxes.py:247-330
+        if (P.have_src) {   // apply_source_terms, unsplit_fluxes.py:247-330
             const bool ina = (i < g.qx && j < g.qy);
             // "ambient" upper boundary: the source ghosts are copies of row jhi
             // (BC.py:159-160), not the sources of the ambient ghost state
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
         Un.E = Uc.E + dtdV * (Fx.E * Ax - Fxh.E * Ax + Fy.E * Ay - Fyh.E * Ay);
         Un.mx = Uc.mx + dtdV * (Fx.mx * Ax - Fxh.mx * Ax + Fy.mx * Ay - Fyh.mx * Ay);
         Un.my = Uc.my + dtdV * (Fx.my * Ax - Fxh.my * Ax + Fy.my * Ay - Fyh.my * Ay);
-        if (!STD && P.have_src)   // simulation.py:406-423
+        if (P.have_src)   // simulation.py:406-423
             grav_update(Un, Uc, P.grav, P.dt, P.heat_rate, P.heat ? P.heat[k] : 0.0);
         Uout[k] = Un.d; Uout[pl + k] = Un.E; Uout[2 * pl + k] = Un.mx; Uout[3 * pl + k] = Un.my;
         cfl = cfl_cell(Un, gamma, P.dx, P.dy);
@@ -471,7 +472,7 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     else if (p->riemann == 1)
         PYRO_LAUNCH(c, "k_ctu_fused", k_ctu_fused<1>, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
                     (const double *)Uin, Uout, g, P, s->d_flag, part);
-    else if (p->limiter == 2 && p->use_flattening && !P.have_src)
+    else if (p->limiter == 2 && p->use_flattening)
         PYRO_LAUNCH(c, "k_ctu_fused", (k_ctu_fused<0, true>), dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
                     (const double *)Uin, Uout, g, P, s->d_flag, part);
     else
