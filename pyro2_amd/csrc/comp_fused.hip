@@ -448,36 +448,30 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     PYRO_TRY(c->reduce.ensure((P.ntiles + kMinStageBlocks + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
     PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
+    // instances: Riemann solver x (default reconstruction as constants | generic)
+    using KernelT = void (*)(const double *, double *, Geom, FP, int *, double *);
+    static const KernelT kernels[3][2] = {
+        {k_ctu_fused<0, false>, k_ctu_fused<0, true>},
+        {k_ctu_fused<1, false>, k_ctu_fused<1, true>},
+        {k_ctu_fused<2, false>, k_ctu_fused<2, true>}};
 #ifndef PYRO_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_ctu_fused<0, true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)FLDS_BYTES));
-        PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_ctu_fused<0>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)FLDS_BYTES));
-        PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_ctu_fused<1>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)FLDS_BYTES));
-        PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_ctu_fused<2>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)FLDS_BYTES));
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 2; b++)
+                PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)kernels[a][b],
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)FLDS_BYTES));
         attr_set = true;
     }
 #endif
-    if (p->riemann == 2)
-        PYRO_LAUNCH(c, "k_ctu_fused", k_ctu_fused<2>, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
+    {
+        const int solver = (p->riemann == 1 || p->riemann == 2) ? p->riemann : 0;
+        const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
+        const KernelT kern = kernels[solver][std_rec];
+        PYRO_LAUNCH(c, "k_ctu_fused", kern, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
                     (const double *)Uin, Uout, g, P, s->d_flag, part);
-    else if (p->riemann == 1)
-        PYRO_LAUNCH(c, "k_ctu_fused", k_ctu_fused<1>, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
-                    (const double *)Uin, Uout, g, P, s->d_flag, part);
-    else if (p->limiter == 2 && p->use_flattening)
-        PYRO_LAUNCH(c, "k_ctu_fused", (k_ctu_fused<0, true>), dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
-                    (const double *)Uin, Uout, g, P, s->d_flag, part);
-    else
-        PYRO_LAUNCH(c, "k_ctu_fused", k_ctu_fused<0>, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
-                    (const double *)Uin, Uout, g, P, s->d_flag, part);
+    }
     {
         const int rows_per_block = 256 / (2 * g.ng);
         const int nby = 2 * g.ng + (g.nx + rows_per_block - 1) / rows_per_block;
