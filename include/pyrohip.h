@@ -176,7 +176,9 @@ typedef struct {
        1 = contracted / reciprocal arithmetic, parity-tested to 1e-10      */
     int fast_math;
     /* kernel set: 0 = staged kernels with global intermediates (debuggable,
-       supports pyrohip_comp_stage_dump); 1 = fused LDS-tiled kernels       */
+       supports pyrohip_comp_stage_dump); 1 = one fused kernel on 2-d LDS
+       tiles; 2 = one fused kernel marching along the rows (x windows in
+       registers, y exchange through LDS rings; the fastest)                */
     int kernel_set;
     /* compressible.riemann: 0 = HLLC (riemann.py:681-860), 1 = CGF (:8-310),
        2 = HLLC_lm (riemann_hllc_lowspeed, :863-1020).
@@ -191,6 +193,9 @@ typedef struct {
        problems/{heating,plume,convection}.py source_terms); only used when the
        state carries a profile (pyrohip_state_set_heating) */
     double heat_rate;
+    /* kernel_set 2: rows per strip of the row-marching kernel; 0 = chosen by
+       the library from the grid size and the CU count (tuning / test knob)  */
+    int march_rows;
 } pyrohip_comp_params;
 
 /* method_compute_timestep (compressible/simulation.py:267-288 +

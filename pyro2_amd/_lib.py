@@ -51,7 +51,7 @@ class CompParams(C.Structure):
                 ("riemann", C.c_int), ("solid_xl", C.c_int), ("solid_yl", C.c_int),
                 ("do_sponge", C.c_int), ("sponge_rho_begin", C.c_double),
                 ("sponge_rho_full", C.c_double), ("sponge_timescale", C.c_double),
-                ("heat_rate", C.c_double)]
+                ("heat_rate", C.c_double), ("march_rows", C.c_int)]
 
 
 _DP = C.POINTER(C.c_double)

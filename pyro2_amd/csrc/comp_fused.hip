@@ -52,34 +52,8 @@ constexpr int FBUF0 = (4 * FQN > 8 * FNT) ? 4 * FQN : 8 * FNT;   // Q | FT | F
 constexpr int FLDS_DOUBLES = FBUF0 + 8 * FNT + FNT;
 constexpr size_t FLDS_BYTES = (size_t)FLDS_DOUBLES * sizeof(double);
 
-struct FP {   // kernel parameters
-    double gamma, dx, dy, dt;
-    double z0, z1, delta, cvisc, small_dens;
-    int limiter, use_flattening;
-    int avx_hi, avy_hi;
-    int ntj, ntiles;
-    // uniform quotients, evaluated once on the host with the reference's
-    // expressions (IEEE double on both sides: same bits)
-    double dtdx, dtdy;    // dt/dx, dt/dy          interface.py:106
-    double hdtV;          // (0.5*dt)/(dx*dy)      unsplit_fluxes.py:444-445
-    double dtdV;          // dt/(dx*dy)            simulation.py:375
-    double grav;          // compressible.grav (0: no source terms)
-    int refl_ylo, refl_yhi;   // y-momentum reflects oddly at the lower / upper y wall
-    int amb_yhi;              // "ambient" boundary on the upper y side
-    int have_src;             // gravity and / or a heating source
-    double heat_rate;         // S[E] += rho * heat_rate * heat[i,j] (ghost-filled plane)
-    const double *heat;
-    int solid_xl, solid_yl;   // CGF wall rule (riemann.py:274-286)
-};
+#include "fused_common.h"
 
-__device__ __forceinline__ ConsN to_nf(const Cons &U, bool x)
-{
-    return x ? ConsN{U.d, U.E, U.mx, U.my} : ConsN{U.d, U.E, U.my, U.mx};
-}
-__device__ __forceinline__ Cons from_nf(const ConsN &F, bool x)
-{
-    return x ? Cons{F.d, F.E, F.mn, F.mt} : Cons{F.d, F.E, F.mt, F.mn};
-}
 __device__ __forceinline__ Cons lds_get(const double *b, int t)
 {
     return Cons{b[t], b[FNT + t], b[2 * FNT + t], b[3 * FNT + t]};
@@ -88,37 +62,6 @@ __device__ __forceinline__ void lds_put(double *b, int t, const Cons &U)
 {
     b[t] = U.d; b[FNT + t] = U.E; b[2 * FNT + t] = U.mx; b[3 * FNT + t] = U.my;
 }
-__device__ __forceinline__ Cons corr(const Cons &U, const Cons &Fhi, const Cons &Flo, double hdtV,
-                                     double A)
-{
-    Cons r;   // U += -hdtV*(F_hi*A - F_lo*A), unsplit_fluxes.py:447-471
-    r.d = U.d + (-hdtV * (Fhi.d * A - Flo.d * A));
-    r.E = U.E + (-hdtV * (Fhi.E * A - Flo.E * A));
-    r.mx = U.mx + (-hdtV * (Fhi.mx * A - Flo.mx * A));
-    r.my = U.my + (-hdtV * (Fhi.my * A - Flo.my * A));
-    return r;
-}
-
-// cons_to_prim (hydro.h) without the branch on rho != 0: same operations on
-// the same operands when rho != 0 (bit-identical), zeros otherwise
-__device__ __forceinline__ Prim cons_to_prim_nb(const Cons &U, double gamma, bool &ok)
-{
-    const bool nz = (U.d != 0.0);
-    const double ds = nz ? U.d : 1.0;
-    const double rd = PYRO_FAST ? prcp(ds) : 0.0;
-    const double u = pdivr(U.mx, ds, rd);
-    const double v = pdivr(U.my, ds, rd);
-    const double e = pdivr(U.E - 0.5 * U.d * (u * u + v * v), ds, rd);
-    Prim q;
-    q.r = U.d;
-    q.u = nz ? u : 0.0;
-    q.v = nz ? v : 0.0;
-    const double es = nz ? e : 0.0;
-    q.p = U.d * es * (gamma - 1.0);
-    ok = (es > 0.0) && (U.d > 0.0);
-    return q;
-}
-
 // developer timing aid (tools/fused_phases.sh): -DPYRO_FUSED_STOP=k ends the
 // kernel after phase k, storing one value that depends on the phase's results
 #ifndef PYRO_FUSED_STOP
@@ -414,19 +357,19 @@ __global__ void k_copy_frame4(const double *__restrict__ src, double *__restrict
     for (int n = 0; n < 4; n++) dst[n * g.plane + k] = src[n * g.plane + k];
 }
 
-int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+// second state buffer + the kernel parameters both single-launch kernels share
+int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP &P, double *&Uin,
+                  double *&Uout)
 {
     pyrohip_ctx *c = s->ctx;
     const Geom &g = s->g;
-    // second state buffer
     if (!s->alt_base) {
         size_t n = g.plane * 4 + 16;
         PYRO_CHECK_HIP(hipMalloc((void **)&s->alt_base, n * sizeof(double)));
         PYRO_CHECK_HIP(hipMemsetAsync(s->alt_base, 0, n * sizeof(double), c->stream));
     }
-    double *Uin = s->d;
-    double *Uout = s->alt_base + geom_lead(g);
-    FP P;
+    Uin = s->d;
+    Uout = s->alt_base + geom_lead(g);
     P.gamma = p->gamma; P.dx = p->dx; P.dy = p->dy; P.dt = dt;
     P.z0 = p->z0; P.z1 = p->z1; P.delta = p->delta; P.cvisc = p->cvisc;
     P.small_dens = p->small_dens;
@@ -442,43 +385,28 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     P.heat = s->heat; P.heat_rate = s->heat ? p->heat_rate : 0.0;
     P.have_src = (p->grav != 0.0 || s->heat != nullptr);
     P.solid_xl = p->solid_xl; P.solid_yl = p->solid_yl;
-    const int nti = (g.nx + FTI - 1) / FTI;
-    P.ntj = (g.ny + FTJ - 1) / FTJ;
-    P.ntiles = nti * P.ntj;
-    PYRO_TRY(c->reduce.ensure((P.ntiles + kMinStageBlocks + 2) * sizeof(double)));
-    double *part = (double *)c->reduce.p;
+    P.ntj = P.ntiles = 0;
+    P.L = P.ncb = 0;
     PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
-    // instances: Riemann solver x (default reconstruction as constants | generic)
-    using KernelT = void (*)(const double *, double *, Geom, FP, int *, double *);
-    static const KernelT kernels[3][2] = {
-        {k_ctu_fused<0, false>, k_ctu_fused<0, true>},
-        {k_ctu_fused<1, false>, k_ctu_fused<1, true>},
-        {k_ctu_fused<2, false>, k_ctu_fused<2, true>}};
-#ifndef PYRO_EMU
-    static bool attr_set = false;
-    if (!attr_set) {
-        for (int a = 0; a < 3; a++)
-            for (int b = 0; b < 2; b++)
-                PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)kernels[a][b],
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   (int)FLDS_BYTES));
-        attr_set = true;
-    }
-#endif
-    {
-        const int solver = (p->riemann == 1 || p->riemann == 2) ? p->riemann : 0;
-        const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
-        const KernelT kern = kernels[solver][std_rec];
-        PYRO_LAUNCH(c, "k_ctu_fused", kern, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
-                    (const double *)Uin, Uout, g, P, s->d_flag, part);
-    }
+    return 0;
+}
+
+// after the step kernel: ghost frame old -> new, minimum of the per-workgroup
+// CFL partials (all-reduced over the slabs when decomposed), positivity flag,
+// swap of the two state buffers
+int fused_finish(pyrohip_state *s, double *part, int nparts)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    double *Uin = s->d;
+    double *Uout = s->alt_base + geom_lead(g);
     {
         const int rows_per_block = 256 / (2 * g.ng);
         const int nby = 2 * g.ng + (g.nx + rows_per_block - 1) / rows_per_block;
         hipLaunchKernelGGL(k_copy_frame4, dim3((g.qy + 255) / 256, nby), dim3(256), 0, c->stream,
                            (const double *)Uin, Uout, g);
     }
-    const double *dmin = launch_min_reduce(c->stream, part, P.ntiles);
+    const double *dmin = launch_min_reduce(c->stream, part, nparts);
     s->cfl_is_global = false;
     if (c->global_cfl) {   // multi-GPU: the next dt needs the minimum over all slabs
         PYRO_TRY(comm_allreduce_min_device(c, const_cast<double *>(dmin)));
@@ -504,6 +432,45 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     s->d = s->base + geom_lead(g);
     s->next_cfl_min = ((double *)c->reduce_host)[0];
     return 0;
+}
+
+int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    FP P;
+    double *Uin, *Uout;
+    PYRO_TRY(fused_prepare(s, p, dt, P, Uin, Uout));
+    const int nti = (g.nx + FTI - 1) / FTI;
+    P.ntj = (g.ny + FTJ - 1) / FTJ;
+    P.ntiles = nti * P.ntj;
+    PYRO_TRY(c->reduce.ensure((P.ntiles + kMinStageBlocks + 2) * sizeof(double)));
+    double *part = (double *)c->reduce.p;
+    // instances: Riemann solver x (default reconstruction as constants | generic)
+    using KernelT = void (*)(const double *, double *, Geom, FP, int *, double *);
+    static const KernelT kernels[3][2] = {
+        {k_ctu_fused<0, false>, k_ctu_fused<0, true>},
+        {k_ctu_fused<1, false>, k_ctu_fused<1, true>},
+        {k_ctu_fused<2, false>, k_ctu_fused<2, true>}};
+#ifndef PYRO_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 2; b++)
+                PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)kernels[a][b],
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)FLDS_BYTES));
+        attr_set = true;
+    }
+#endif
+    {
+        const int solver = (p->riemann == 1 || p->riemann == 2) ? p->riemann : 0;
+        const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
+        const KernelT kern = kernels[solver][std_rec];
+        PYRO_LAUNCH(c, "k_ctu_fused", kern, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
+                    (const double *)Uin, Uout, g, P, s->d_flag, part);
+    }
+    return fused_finish(s, part, P.ntiles);
 }
 
 }  // namespace PYRO_NS

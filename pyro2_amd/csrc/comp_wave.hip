@@ -1,0 +1,452 @@
+// Compressible CTU + Riemann step as ONE kernel per time step: autonomous
+// wavefronts marching along the rows (kernel_set 3).
+//
+// Same arithmetic as the other kernel sets (per-cell functions of hydro.h /
+// stencil.h in the reference's operation order).  One wavefront = 64 columns
+// (lane = column j, 512-B row loads per plane), of which the inner 56 are
+// updated; it walks down a strip of L rows on its own:
+//
+//   * x direction (rows, index i): rolling windows in REGISTERS.  limit2_x,
+//     flatten_x, the x face states, FxT and Fx of a row are computed once and
+//     handed from one iteration to the next.
+//   * y direction (neighbouring lanes): ds_bpermute lane shuffles.  No LDS
+//     memory, no workgroup barrier -- a value is read from the neighbour lane's
+//     register at the point of use, so nothing has to be published a pipeline
+//     stage ahead and a row goes through ALL stages of the algorithm in two
+//     consecutive iterations.
+//
+// Iteration k of the strip [i0, i1):
+//   S0  load row k -> primitives (window rows k-4..k); flatten_x, limit2_x of
+//       row k-2
+//   S2  row c = k-3: limit2_y / flatten_y (+ neighbours'), xi, limited slopes,
+//       characteristic tracing -> XM XP YM YP; FxT(c) (XP of row c-1 carried),
+//       FyT(c) (YP of lane j-1); transverse correction of the x states (FyT of
+//       lane j+1); final x flux Fx(c) + artificial viscosity
+//   S4  row c-1 = k-4: transverse correction of the y states (FxT of rows c-1, c),
+//       final y flux Fy (YP of lane j-1) + artificial viscosity, conservative
+//       update (Fy of lane j+1), store, CFL
+//
+// Lanes 0-3 and 60-63 are apron (87.5 % of the lanes produce output; a strip
+// costs L + 8 iterations for L rows), which buys: no barriers, no LDS, the
+// shortest possible carried state (70 doubles per lane).  HBM traffic: every
+// row is read once per column strip (x 64/56) and written once; the second
+// read of a row three iterations later (old state for the update and the
+// viscosity terms) is an L1/L2 hit.
+//
+// Compiled twice like the other compressible units (PYRO_FAST = 0 / 1).
+#include "common.h"
+#include "hydro.h"
+#include "reduce.h"
+
+#ifndef PYRO_FAST
+#define PYRO_FAST 0
+#endif
+#if PYRO_FAST
+#define PYRO_NS fastm
+#else
+#define PYRO_NS exact
+#endif
+
+namespace pyro {
+namespace PYRO_NS {
+
+#include "fused_common.h"
+
+constexpr int WOUT = 56;          // columns a wavefront updates
+// stage boundary: the scheduler may not move instructions across it.  The
+// stages are written in the order that keeps the live ranges short (a value is
+// produced right before the Riemann problem that consumes it); left alone, the
+// scheduler interleaves the stages for ILP and pushes the kernel over 256 VGPRs.
+#if defined(PYRO_EMU) || defined(PYRO_WAVE_NO_SCHED_BARRIER)
+#define STAGE_FENCE() do {} while (0)
+#else
+#define STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef PYRO_WAVE_MINW
+#define PYRO_WAVE_MINW 2          // waves per SIMD the register allocation must allow
+#endif
+
+// value of the same variable in lane l-1 / l+1 (own value at the ends of the
+// wavefront).  gfx950 keeps the GFX9 whole-wave DPP shifts (wave_shr:1 /
+// wave_shl:1 move data across all 64 lanes, tools/dpp_probe.hip): two
+// v_mov_b32_dpp per double, a register-to-register VALU move without the
+// LDS-crossbar round trip of ds_bpermute (__shfl_up / __shfl_down).
+#if !defined(PYRO_EMU) && !defined(PYRO_WAVE_BPERMUTE)
+template <int CTRL> __device__ __forceinline__ double lane_dpp(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_m1(double v) { return lane_dpp<0x138>(v); }   // wave_shr:1
+__device__ __forceinline__ double lane_p1(double v) { return lane_dpp<0x130>(v); }   // wave_shl:1
+__device__ __forceinline__ double lane_m2(double v) { return lane_m1(lane_m1(v)); }
+__device__ __forceinline__ double lane_p2(double v) { return lane_p1(lane_p1(v)); }
+#else
+__device__ __forceinline__ double lane_m1(double v) { return __shfl_up(v, 1, 64); }
+__device__ __forceinline__ double lane_p1(double v) { return __shfl_down(v, 1, 64); }
+__device__ __forceinline__ double lane_m2(double v) { return __shfl_up(v, 2, 64); }
+__device__ __forceinline__ double lane_p2(double v) { return __shfl_down(v, 2, 64); }
+#endif
+__device__ __forceinline__ Cons lane_m1(const Cons &U)
+{
+    return Cons{lane_m1(U.d), lane_m1(U.E), lane_m1(U.mx), lane_m1(U.my)};
+}
+__device__ __forceinline__ Cons lane_p1(const Cons &U)
+{
+    return Cons{lane_p1(U.d), lane_p1(U.E), lane_p1(U.mx), lane_p1(U.my)};
+}
+
+// Per-lane stash in LDS for the values a row hands to the next iteration
+// (slot s of lane l at doubles s*64 + l: conflict-free 512-B rows).  Own-lane
+// data only, so no barrier: LDS operations of one wavefront complete in order.
+// Every slot is read (old row) before it is written (new row) within an
+// iteration, so one slot per value is enough.
+constexpr int ST_YM = 0, ST_YP = 4, ST_FXT = 8, ST_XP = 12, ST_XPC = 16, ST_FX = 20;
+constexpr int ST_L2 = 24;         // limit2_x of two rows: 2 x 4 slots, the older row at (k & 1)
+constexpr int ST_CFL = 32;        // running CFL minimum of the lane
+constexpr int ST_SLOTS = 33;
+// Uniform doubles (kernel parameters) live in a table behind the stash and are
+// read with a broadcast ds_read where a stage needs them.  Left in the argument
+// registers they do not fit: ~50 uniform doubles (parameters, x / y variants,
+// VALU-derived quotients) exceed the 102 SGPRs, the overflow is parked in VGPRs
+// and scratch as loop invariants and reloaded every iteration through vmcnt,
+// i.e. behind the HBM prefetch of the next row.  `volatile` keeps the compiler
+// from hoisting the reads (and what is derived from them) out of the row loop.
+enum { C_GAMMA, C_DX, C_DY, C_DT, C_Z0, C_Z1, C_DELTA, C_CVISC, C_SMALLD, C_DTDX, C_DTDY, C_HDTV,
+       C_DTDV, C_GRAV, C_HEATR, C_GM1, C_RGM1, C_RDX, C_RDY, C_KSL, C_KSR, C_RGP1, C_N };
+constexpr size_t WLDS_BYTES = (size_t)(ST_SLOTS * 64 + C_N) * sizeof(double);
+#define UC(name) (ct[C_##name])
+#define UC_GASK() GasK{UC(GAMMA), UC(KSL), UC(KSR), UC(RGP1)}
+// (an explicit LDS pointer type: a plain `volatile double *` is a generic pointer
+// that the address-space inference leaves alone, i.e. flat loads through vmcnt)
+#if defined(PYRO_EMU)
+typedef volatile double *UniformTab;
+#else
+typedef volatile __attribute__((address_space(3))) double *UniformTab;
+#endif
+
+__device__ __forceinline__ Cons st_get(const double *st, int s)
+{
+    return Cons{st[s * 64], st[(s + 1) * 64], st[(s + 2) * 64], st[(s + 3) * 64]};
+}
+__device__ __forceinline__ void st_put(double *st, int s, const Cons &U)
+{
+    st[s * 64] = U.d; st[(s + 1) * 64] = U.E; st[(s + 2) * 64] = U.mx; st[(s + 3) * 64] = U.my;
+}
+
+template <int SOLVER, bool STD>   // as k_ctu_fused
+__global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *__restrict__ Uin,
+                                                                 double *__restrict__ Uout, Geom g,
+                                                                 FP P, int *__restrict__ flag,
+                                                                 double *__restrict__ partial)
+{
+    HIP_DYNAMIC_SHARED(double, lds)
+    const int l = threadIdx.x;
+    double *st = lds + l;
+    const int cb = blockIdx.x % P.ncb, sb = blockIdx.x / P.ncb;
+    const int i0 = g.ilo + sb * P.L;                       // strip rows [i0, i1)
+    const int i1 = (i0 + P.L < g.ihi + 1) ? i0 + P.L : g.ihi + 1;
+    const int j = g.jlo + cb * WOUT - 4 + l;               // this lane's column
+    const int jc = (j < g.qy) ? j : g.qy - 1;              // ragged last strip: clamp, unused
+    const bool jin = (j >= g.jlo && j <= g.jhi);
+    const bool jout = jin && l >= 4 && l <= 59;
+    const int p = g.pitch;
+    const size_t pl = g.plane;
+    const int limiter = STD ? 2 : P.limiter;
+    const bool flat = STD || P.use_flattening;
+    UniformTab ct = (UniformTab)(lds + ST_SLOTS * 64);
+    if (l == 0) {     // one wavefront, LDS operations complete in order: no barrier needed
+        ct[C_GAMMA] = P.gamma; ct[C_DX] = P.dx; ct[C_DY] = P.dy; ct[C_DT] = P.dt;
+        ct[C_Z0] = P.z0; ct[C_Z1] = P.z1; ct[C_DELTA] = P.delta; ct[C_CVISC] = P.cvisc;
+        ct[C_SMALLD] = P.small_dens; ct[C_DTDX] = P.dtdx; ct[C_DTDY] = P.dtdy;
+        ct[C_HDTV] = P.hdtV; ct[C_DTDV] = P.dtdV; ct[C_GRAV] = P.grav; ct[C_HEATR] = P.heat_rate;
+        ct[C_GM1] = P.gamma - 1.0; ct[C_RGM1] = prcp(P.gamma - 1.0);
+        ct[C_RDX] = prcp(P.dx); ct[C_RDY] = prcp(P.dy);
+        const GasK K0 = make_gask(P.gamma);
+        ct[C_KSL] = K0.ksl; ct[C_KSR] = K0.ksr; ct[C_RGP1] = K0.rgp1;
+    }
+
+    auto loadU = [&](int row) {
+        row = row < 0 ? 0 : (row > g.qx - 1 ? g.qx - 1 : row);
+        const size_t kk = (size_t)row * p + jc;
+        return Cons{Uin[kk], Uin[pl + kk], Uin[2 * pl + kk], Uin[3 * pl + kk]};
+    };
+    auto row_in = [&](int r) { return r >= g.ilo && r <= g.ihi; };
+
+    // state carried from one iteration to the next in registers (rows relative
+    // to the iteration k that is about to start) ...
+    double wr[5] = {1, 1, 1, 1, 1}, wu[5] = {0, 0, 0, 0, 0};   // Q window, rows k-4..k
+    double wv[5] = {0, 0, 0, 0, 0}, wp[5] = {1, 1, 1, 1, 1};
+    double fxa = 1.0, fxb = 1.0;                               // flatten_x of rows k-4, k-3
+    Cons Ue{1.0, 1.0, 0.0, 0.0}, Uem = Ue;                     // old state, rows k-3 / k-4
+    double Dp = 0.0;                                           // vertex div(U) of row k-4
+    double up = 0.0, vp = 0.0;                                 // u, v at (k-4, j-1)
+    Cons Upre = loadU(i0 - 4);                                 // row k, in flight
+    Cons Urep = loadU(i0 - 7);                                 // row k-3 again, in flight
+    bool bad = false;
+    // ... and in the stash: uncorrected YM, YP, XP, FxT, corrected XP and Fx of row k-4
+    {
+        const Cons one{1.0, 1.0, 0.0, 0.0};
+        st_put(st, ST_YM, one); st_put(st, ST_YP, one); st_put(st, ST_XP, one);
+        st_put(st, ST_XPC, one); st_put(st, ST_FXT, one); st_put(st, ST_FX, one);
+        st_put(st, ST_L2, one); st_put(st, ST_L2 + 4, one);
+        st[ST_CFL * 64] = INFINITY;
+    }
+
+    for (int k = i0 - 4; k <= i1 + 3; k++) {
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            wr[n] = wr[n + 1]; wu[n] = wu[n + 1]; wv[n] = wv[n + 1]; wp[n] = wp[n + 1];
+        }
+        Uem = Ue;
+        Ue = Urep;
+        if (row_in(k - 3) && jin) Ue.d = fmax(Ue.d, UC(SMALLD));      // clean_state
+        Urep = loadU(k - 2);
+        // ---- S0: row k -> primitives
+        {
+            Cons U = Upre;
+            Upre = loadU(k + 1);
+            const bool interior = row_in(k) && jin;
+            if (interior) U.d = fmax(U.d, UC(SMALLD));
+            bool ok;
+            const Prim q = cons_to_prim_nb(U, UC(GAMMA), ok);
+            if (interior && !ok) bad = true;
+            wr[4] = q.r; wu[4] = q.u; wv[4] = q.v; wp[4] = q.p;
+        }
+        // ---- flatten_x and limit2_x of row k-2 (window index 2)
+        double fxn = 1.0, l2n[4] = {0, 0, 0, 0};
+        if (k >= i0) {
+            if (flat)
+                fxn = flatten_1d(wp[0], wp[1], wp[3], wp[4], wu[1], wu[3], UC(Z0), UC(Z1), UC(DELTA));
+            if (limiter != 0) {
+                l2n[0] = limit2(wr[1], wr[2], wr[3]);
+                l2n[1] = limit2(wu[1], wu[2], wu[3]);
+                l2n[2] = limit2(wv[1], wv[2], wv[3]);
+                l2n[3] = limit2(wp[1], wp[2], wp[3]);
+            }
+        }
+        // limit2_x of rows k-4 (slot k & 1) and k-3 from the stash; row k-2 takes the
+        // older one's place
+        double l2a[4], l2b[4];
+        {
+            double *sa = st + (ST_L2 + 4 * (k & 1)) * 64, *sb = st + (ST_L2 + 4 * ((k + 1) & 1)) * 64;
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                l2a[n] = sa[n * 64]; l2b[n] = sb[n * 64];
+                sa[n * 64] = l2n[n];
+            }
+        }
+        double Dn = 0.0, um = 0.0, vm = 0.0;
+        // ---- rows c = k-3 (window index 1: slopes, states, x flux) and f = k-4
+        // (y flux, update)
+        if (k >= i0 + 2) {
+            const int i = k - 3;
+            const bool xface = (k >= i0 + 3);          // row c has a lower x face in the strip
+            const bool frow = (k >= i0 + 4);           // row f is updated by this strip
+            const double q0[4] = {wr[1], wu[1], wv[1], wp[1]};
+            const double qm[4] = {wr[0], wu[0], wv[0], wp[0]};
+            const double qp[4] = {wr[2], wu[2], wv[2], wp[2]};
+            double ym[4], yp[4], l2y[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                ym[n] = lane_m1(q0[n]);
+                yp[n] = lane_p1(q0[n]);
+                if (limiter != 0) l2y[n] = limit2(ym[n], q0[n], yp[n]);
+            }
+            um = ym[1]; vm = ym[2];
+            double xi = 1.0;
+            if (flat) {
+                // flatten_multid (reconstruction.py:167-183): own coefficient and the
+                // one of the UPWIND neighbour (w.r.t. the pressure gradient)
+                const double fy = flatten_1d(lane_m2(q0[3]), ym[3], yp[3], lane_p2(q0[3]), ym[2],
+                                             yp[2], UC(Z0), UC(Z1), UC(DELTA));
+                const double fym = lane_m1(fy), fyp = lane_p1(fy);
+                const double px = (qp[3] - qm[3] > 0) ? fxa : fxn;
+                const double py = (yp[3] - ym[3] > 0) ? fym : fyp;
+                xi = fmin(fmin(fxb, px), fmin(fy, py));
+            }
+            double dqx[4], dqy[4];
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                dqx[n] = xi * slope_shared(l2a[n], l2b[n], l2n[n], qm[n], q0[n], qp[n], limiter);
+                const double l2m = (limiter == 2) ? lane_m1(l2y[n]) : 0.0;
+                const double l2p = (limiter == 2) ? lane_p1(l2y[n]) : 0.0;
+                dqy[n] = xi * slope_shared(l2m, l2y[n], l2p, ym[n], q0[n], yp[n], limiter);
+            }
+            STAGE_FENCE();
+            // source terms of the face states (apply_source_terms, unsplit_fluxes.py:247-330)
+            Cons Ug{0.0, 0.0, 0.0, 0.0};
+            double sgn = 1.0, hp = 0.0;
+            if (P.have_src) {
+                const bool ina = (j < g.qy);
+                // "ambient" upper boundary: the source ghosts are copies of row jhi
+                // (BC.py:159-160), not the sources of the ambient ghost state
+                const int js = (P.amb_yhi && j > g.jhi) ? g.jhi : j;
+                const size_t kc = (size_t)(ina ? i : g.qx - 1) * p + (ina ? js : g.qy - 1);
+                Ug.d = Uin[kc]; Ug.my = Uin[3 * pl + kc];
+                if (i >= g.ilo && i <= g.ihi && js >= g.jlo && js <= g.jhi)
+                    Ug.d = fmax(Ug.d, UC(SMALLD));
+                sgn = ((j < g.jlo && P.refl_ylo) || (j > g.jhi && P.refl_yhi)) ? -1.0 : 1.0;
+                hp = P.heat ? P.heat[(size_t)(ina ? i : g.qx - 1) * p + (ina ? j : g.qy - 1)] : 0.0;
+            }
+            // vertex divergence at (i-1/2, j-1/2), interface.py:312-330, and the
+            // artificial viscosity coefficients of the faces (i, j) in x and (i-1, j)
+            // in y (interface.py:366-376: only faces i in [ilo, ihi], j in [jlo, jhi])
+            Dn = div_u_vertex_r(q0[1], um, qm[1], up, q0[2], qm[2], vm, vp, UC(DX), UC(DY), UC(RDX),
+                                UC(RDY));
+            const double Dn_p = lane_p1(Dn);
+            double avx = 0.0, avy = 0.0;
+            if (i >= g.ilo && (i <= g.ihi || (P.avx_hi && i == g.ihi + 1)) && jin) {
+                const double divU_x = 0.5 * (Dn + Dn_p);
+                avx = UC(CVISC) * fmax(-divU_x * UC(DX), 0.0);
+            }
+            if (j >= g.jlo && (j <= g.jhi || (P.avy_hi && j == g.jhi + 1)) && row_in(i - 1)) {
+                const double divU_y = 0.5 * (Dp + Dn);
+                avy = UC(CVISC) * fmax(-divU_y * UC(DY), 0.0);
+            }
+            STAGE_FENCE();
+            // -- x states of row c, transverse x flux on its lower face
+            Trace lo, hi;
+            double gamma = UC(GAMMA);
+            trace_states(q0[0], q0[1], q0[2], q0[3], dqx[0], dqx[1], dqx[2], dqx[3], gamma,
+                         UC(DTDX), lo, hi);
+            double gm1 = UC(GM1), rgm1 = UC(RGM1);
+            Cons XMn = prim_to_cons_g(Prim{lo.r, lo.un, lo.ut, lo.p}, gm1, rgm1);
+            Cons XPn = prim_to_cons_g(Prim{hi.r, hi.un, hi.ut, hi.p}, gm1, rgm1);
+            if (P.have_src) {
+                add_grav_to_state(XMn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
+                add_grav_to_state(XPn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
+            }
+            Cons FxTn{0.0, 0.0, 0.0, 0.0};
+            if (xface)
+                FxTn = from_nf(riemann_face<SOLVER>(to_nf(st_get(st, ST_XP), true), to_nf(XMn, true),
+                                                    UC_GASK(), true, P.solid_xl && i == g.ilo), true);
+            STAGE_FENCE();
+            // -- row f: y states corrected with FxT of rows f, f+1; final y flux
+            Cons Fy{0.0, 0.0, 0.0, 0.0}, Fyh = Fy;
+            if (frow) {
+                const Cons FxTp = st_get(st, ST_FXT);
+                const double hdtV = UC(HDTV), Ax = UC(DY);
+                const Cons YMc = corr(st_get(st, ST_YM), FxTn, FxTp, hdtV, Ax);
+                const Cons YPc = corr(st_get(st, ST_YP), FxTn, FxTp, hdtV, Ax);
+                Fy = from_nf(riemann_face<SOLVER>(to_nf(lane_m1(YPc), false), to_nf(YMc, false),
+                                                  UC_GASK(), false, P.solid_yl && j == g.jlo), false);
+                const Cons Umy = lane_m1(Uem);
+                Fy.d += avy * (Umy.d - Uem.d);
+                Fy.E += avy * (Umy.E - Uem.E);
+                Fy.mx += avy * (Umy.mx - Uem.mx);
+                Fy.my += avy * (Umy.my - Uem.my);
+                Fyh = lane_p1(Fy);
+            }
+            st_put(st, ST_FXT, FxTn);
+            STAGE_FENCE();
+            // -- y states of row c, transverse y flux on its lower face
+            gamma = UC(GAMMA);
+            trace_states(q0[0], q0[2], q0[1], q0[3], dqy[0], dqy[2], dqy[1], dqy[3], gamma,
+                         UC(DTDY), lo, hi);
+            gm1 = UC(GM1); rgm1 = UC(RGM1);
+            Cons YMn = prim_to_cons_g(Prim{lo.r, lo.ut, lo.un, lo.p}, gm1, rgm1);
+            Cons YPn = prim_to_cons_g(Prim{hi.r, hi.ut, hi.un, hi.p}, gm1, rgm1);
+            if (P.have_src) {
+                add_grav_to_state(YMn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
+                add_grav_to_state(YPn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
+            }
+            st_put(st, ST_YM, YMn);
+            st_put(st, ST_YP, YPn);
+            const Cons FyT = from_nf(riemann_face<SOLVER>(to_nf(lane_m1(YPn), false),
+                                                          to_nf(YMn, false), UC_GASK(), false,
+                                                          P.solid_yl && j == g.jlo), false);
+            STAGE_FENCE();
+            // -- transverse correction of the x states of row c, final x flux
+            const Cons FyTh = lane_p1(FyT);            // FyT at (i, j+1)
+            const double hdtV = UC(HDTV), Ay = UC(DX);
+            const Cons XMc = corr(XMn, FyTh, FyT, hdtV, Ay);
+            const Cons XPc = corr(XPn, FyTh, FyT, hdtV, Ay);
+            st_put(st, ST_XP, XPn);
+            Cons Fxn{0.0, 0.0, 0.0, 0.0};
+            if (xface) {
+                Fxn = from_nf(riemann_face<SOLVER>(to_nf(st_get(st, ST_XPC), true), to_nf(XMc, true),
+                                                   UC_GASK(), true, P.solid_xl && i == g.ilo), true);
+                Fxn.d += avx * (Uem.d - Ue.d);
+                Fxn.E += avx * (Uem.E - Ue.E);
+                Fxn.mx += avx * (Uem.mx - Ue.mx);
+                Fxn.my += avx * (Uem.my - Ue.my);
+            }
+            st_put(st, ST_XPC, XPc);
+            STAGE_FENCE();
+            // -- conservative update of row f + CFL of the new state
+            if (frow && jout) {
+                const double dtdV = UC(DTDV), Ax = UC(DY);
+                const Cons Fxp = st_get(st, ST_FX);
+                const Cons &Uc = Uem;
+                Cons Un;   // simulation.py:377-384
+                Un.d = Uc.d + dtdV * (Fxp.d * Ax - Fxn.d * Ax + Fy.d * Ay - Fyh.d * Ay);
+                Un.E = Uc.E + dtdV * (Fxp.E * Ax - Fxn.E * Ax + Fy.E * Ay - Fyh.E * Ay);
+                Un.mx = Uc.mx + dtdV * (Fxp.mx * Ax - Fxn.mx * Ax + Fy.mx * Ay - Fyh.mx * Ay);
+                Un.my = Uc.my + dtdV * (Fxp.my * Ax - Fxn.my * Ax + Fy.my * Ay - Fyh.my * Ay);
+                const size_t ko = (size_t)(i - 1) * p + j;
+                if (P.have_src)   // simulation.py:406-423
+                    grav_update(Un, Uc, UC(GRAV), UC(DT), UC(HEATR), P.heat ? P.heat[ko] : 0.0);
+                Uout[ko] = Un.d; Uout[pl + ko] = Un.E; Uout[2 * pl + ko] = Un.mx;
+                Uout[3 * pl + ko] = Un.my;
+                st[ST_CFL * 64] = fmin(st[ST_CFL * 64], cfl_cell(Un, UC(GAMMA), UC(DX), UC(DY)));
+            }
+            st_put(st, ST_FX, Fxn);
+        }
+        // hand the rows on
+        fxa = fxb; fxb = fxn;
+        Dp = Dn; up = um; vp = vm;
+    }
+    if (bad) atomicOr(flag, 1);
+    const double cfl = wave_reduce_min(st[ST_CFL * 64]);
+    if (l == 0) partial[blockIdx.x] = cfl;
+}
+
+// rows per strip: the strip count that minimises (rounds of resident
+// wavefronts) x (iterations per strip)
+static int wave_rows(int nx, int ncb, int slots)
+{
+    int bestL = nx;
+    long best = 1L << 60;
+    for (int nsb = 1; nsb <= nx; nsb++) {
+        const int L = (nx + nsb - 1) / nsb;
+        if (L < 32 && nsb > 1) break;
+        const long wgs = (long)ncb * ((nx + L - 1) / L);
+        const long rounds = (wgs + slots - 1) / slots;
+        const long cost = rounds * (L + 8);
+        if (cost < best) { best = cost; bestL = L; }
+    }
+    return bestL;
+}
+
+int comp_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    FP P;
+    double *Uin, *Uout;
+    PYRO_TRY(fused_prepare(s, p, dt, P, Uin, Uout));
+    P.ncb = (g.ny + WOUT - 1) / WOUT;
+    const int cus = c->num_cus > 0 ? c->num_cus : 256;
+    P.L = wave_rows(g.nx, P.ncb, 4 * PYRO_WAVE_MINW * cus);
+    if (p->march_rows > 0) P.L = p->march_rows < g.nx ? p->march_rows : g.nx;
+    const int nsb = (g.nx + P.L - 1) / P.L;
+    const int nwg = P.ncb * nsb;
+    PYRO_TRY(c->reduce.ensure((nwg + kMinStageBlocks + 2) * sizeof(double)));
+    double *part = (double *)c->reduce.p;
+    using KernelT = void (*)(const double *, double *, Geom, FP, int *, double *);
+    static const KernelT kernels[3][2] = {
+        {k_ctu_wave<0, false>, k_ctu_wave<0, true>},
+        {k_ctu_wave<1, false>, k_ctu_wave<1, true>},
+        {k_ctu_wave<2, false>, k_ctu_wave<2, true>}};
+    const int solver = (p->riemann == 1 || p->riemann == 2) ? p->riemann : 0;
+    const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
+    PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(nwg), dim3(64), WLDS_BYTES,
+                (const double *)Uin, Uout, g, P, s->d_flag, part);
+    return fused_finish(s, part, nwg);
+}
+
+}  // namespace PYRO_NS
+}  // namespace pyro

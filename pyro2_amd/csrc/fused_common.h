@@ -1,0 +1,85 @@
+// Definitions shared by the two single-launch CTU kernels: the 2-d LDS tile
+// kernel (comp_fused.hip, kernel_set 1) and the row-marching kernel
+// (comp_march.hip, kernel_set 2).  Included inside namespace pyro::PYRO_NS.
+#pragma once
+
+struct FP {   // kernel parameters
+    double gamma, dx, dy, dt;
+    double z0, z1, delta, cvisc, small_dens;
+    int limiter, use_flattening;
+    int avx_hi, avy_hi;
+    int ntj, ntiles;
+    // uniform quotients, evaluated once on the host with the reference's
+    // expressions (IEEE double on both sides: same bits)
+    double dtdx, dtdy;    // dt/dx, dt/dy          interface.py:106
+    double hdtV;          // (0.5*dt)/(dx*dy)      unsplit_fluxes.py:444-445
+    double dtdV;          // dt/(dx*dy)            simulation.py:375
+    double grav;          // compressible.grav (0: no source terms)
+    int refl_ylo, refl_yhi;   // y-momentum reflects oddly at the lower / upper y wall
+    int amb_yhi;              // "ambient" boundary on the upper y side
+    int have_src;             // gravity and / or a heating source
+    double heat_rate;         // S[E] += rho * heat_rate * heat[i,j] (ghost-filled plane)
+    const double *heat;
+    int solid_xl, solid_yl;   // CGF wall rule (riemann.py:274-286)
+    int L, ncb;               // row-marching kernel: rows per strip, column blocks
+};
+
+// host side, defined in comp_fused.hip
+__global__ void k_copy_frame4(const double *__restrict__ src, double *__restrict__ dst, Geom g);
+int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP &P, double *&Uin,
+                  double *&Uout);
+int fused_finish(pyrohip_state *s, double *part, int nparts);
+
+__device__ __forceinline__ ConsN to_nf(const Cons &U, bool x)
+{
+    return x ? ConsN{U.d, U.E, U.mx, U.my} : ConsN{U.d, U.E, U.my, U.mx};
+}
+__device__ __forceinline__ Cons from_nf(const ConsN &F, bool x)
+{
+    return x ? Cons{F.d, F.E, F.mn, F.mt} : Cons{F.d, F.E, F.mt, F.mn};
+}
+__device__ __forceinline__ Cons corr(const Cons &U, const Cons &Fhi, const Cons &Flo, double hdtV,
+                                     double A)
+{
+    Cons r;   // U += -hdtV*(F_hi*A - F_lo*A), unsplit_fluxes.py:447-471
+    r.d = U.d + (-hdtV * (Fhi.d * A - Flo.d * A));
+    r.E = U.E + (-hdtV * (Fhi.E * A - Flo.E * A));
+    r.mx = U.mx + (-hdtV * (Fhi.mx * A - Flo.mx * A));
+    r.my = U.my + (-hdtV * (Fhi.my * A - Flo.my * A));
+    return r;
+}
+
+// limited slope from the limit2 values of the two neighbours (limiter 2), the
+// cell's own limit2 (limiter 1) or none: the expressions of limited_slope()
+// (stencil.h, reconstruction.py:9-120) with the shared limit2 passed in
+__device__ __forceinline__ double slope_shared(double l2m, double l20, double l2p, double am1,
+                                               double a0, double ap1, int limiter)
+{
+    if (limiter == 0) return 0.5 * (ap1 - am1);
+    if (limiter == 1) return l20;
+    const double dc = (2. / 3.) * (ap1 - am1 - 0.25 * (l2p + l2m));
+    const double dl = ap1 - a0;
+    const double dr = a0 - am1;
+    return mc_select(dc, dl, dr);
+}
+
+// cons_to_prim (hydro.h) without the branch on rho != 0: same operations on
+// the same operands when rho != 0 (bit-identical), zeros otherwise
+__device__ __forceinline__ Prim cons_to_prim_nb(const Cons &U, double gamma, bool &ok)
+{
+    const bool nz = (U.d != 0.0);
+    const double ds = nz ? U.d : 1.0;
+    const double rd = PYRO_FAST ? prcp(ds) : 0.0;
+    const double u = pdivr(U.mx, ds, rd);
+    const double v = pdivr(U.my, ds, rd);
+    const double e = pdivr(U.E - 0.5 * U.d * (u * u + v * v), ds, rd);
+    Prim q;
+    q.r = U.d;
+    q.u = nz ? u : 0.0;
+    q.v = nz ? v : 0.0;
+    const double es = nz ? e : 0.0;
+    q.p = U.d * es * (gamma - 1.0);
+    ok = (es > 0.0) && (U.d > 0.0);
+    return q;
+}
+

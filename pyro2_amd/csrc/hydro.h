@@ -50,6 +50,23 @@ __device__ __forceinline__ double psqrt(double x)
 #endif
     return (x > 0.0) ? g : 0.0;
 }
+// the same without the x > 0 select, for arguments that are positive by
+// construction (1 + positive, A / (p + B)) or whose result goes through
+// fmax(smallc, .) anyway: fmax returns smallc for the NaN a zero / negative
+// argument produces, exactly what the selected 0 gives
+__device__ __forceinline__ double psqrt_nc(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+#ifdef PYRO_RCP_NEWTON2
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+#endif
+    return g;
+}
 // sqrt(x) and 1/sqrt(x) of a strictly positive, normal argument from ONE
 // v_rsq_f64 (a transcendental issues at quarter rate: 16 cycles per wave)
 __device__ __forceinline__ double psqrt_r(double x, double &rinv)
@@ -68,6 +85,7 @@ __device__ __forceinline__ double psqrt0(double x) { return psqrt(x); }
 #else
 __device__ __forceinline__ double psqrt0(double x) { return sqrt(x); }
 __device__ __forceinline__ double psqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double psqrt_nc(double x) { return sqrt(x); }
 __device__ __forceinline__ double prcp(double b) { return 1.0 / b; }
 __device__ __forceinline__ double pdiv(double a, double b) { return a / b; }
 __device__ __forceinline__ double pdivr(double a, double b, double rb) { (void)rb; return a / b; }
@@ -104,6 +122,19 @@ __device__ __forceinline__ Cons prim_to_cons(const Prim &q, double gamma)
     U.mx = q.u * U.d;
     U.my = q.v * U.d;
     double rhoe = pdiv(q.p, gamma - 1.0);
+    U.E = rhoe + 0.5 * q.r * (q.u * q.u + q.v * q.v);
+    return U;
+}
+
+// the same with gamma - 1 (and, fast build, its reciprocal) passed in: kernels
+// that cannot keep derived uniforms in registers read them from a table
+__device__ __forceinline__ Cons prim_to_cons_g(const Prim &q, double gm1, double rgm1)
+{
+    Cons U;
+    U.d = q.r;
+    U.mx = q.u * U.d;
+    U.my = q.v * U.d;
+    double rhoe = pdivr(q.p, gm1, rgm1);
     U.E = rhoe + 0.5 * q.r * (q.u * q.u + q.v * q.v);
     return U;
 }
@@ -219,11 +250,31 @@ __device__ __forceinline__ void trace_states(double r, double un, double ut, dou
 
 // Wave-speed estimate, compressible/riemann.py:596-678 (quirk: S_r uses
 // (gamma+1)/(2/gamma), :675)
+// gamma and the uniform quotients of it the HLLC solver uses, evaluated once
+// with the reference's expressions (kernels that keep their uniforms in a table
+// pass them in; make_gask() is the inline equivalent)
+struct GasK {
+    double gamma;
+    double ksl;    // (gamma + 1) / (2 gamma)        riemann.py:665
+    double ksr;    // (gamma + 1) / (2 / gamma)      riemann.py:675 (the quirk)
+    double rgp1;   // fast build: 1 / (gamma + 1)
+};
+__device__ __forceinline__ GasK make_gask(double gamma)
+{
+    GasK k;
+    k.gamma = gamma;
+    k.ksl = pdiv(gamma + 1.0, 2.0 * gamma);
+    k.ksr = pdiv(gamma + 1.0, pdiv(2.0, gamma));
+    k.rgp1 = PYRO_FAST ? prcp(gamma + 1.0) : 0.0;
+    return k;
+}
+
 __device__ __forceinline__ void estimate_wave_speed(double rho_l, double u_l, double p_l,
                                                     double c_l, double rho_r, double u_r,
-                                                    double p_r, double c_r, double gamma,
+                                                    double p_r, double c_r, const GasK &K,
                                                     double &S_l, double &S_r)
 {
+    const double gamma = K.gamma;
     double p_max = fmax(p_l, p_r);
     double p_min = fmin(p_l, p_r);
 #if PYRO_FAST && !defined(PYRO_EMU)
@@ -237,6 +288,8 @@ __device__ __forceinline__ void estimate_wave_speed(double rho_l, double u_l, do
     double pstar = 0.5 * (p_l + p_r) + 0.5 * (u_l - u_r) * factor;
     if (Q > 2 && (pstar < p_min || pstar > p_max)) {
         if (pstar < p_min) {   // two-rarefaction, :626-638
+            // (kept inline: as an out-of-line function the call's clobber rules
+            // spill more registers around it than the three pow() bodies cost)
             double z = pdiv(gamma - 1.0, 2.0 * gamma);
             double p_lr = pow(pdiv(p_l, p_r), z);
             double ustar = pdiv(pdiv(p_lr * u_l, c_l) + pdiv(u_r, c_r) +
@@ -248,23 +301,23 @@ __device__ __forceinline__ void estimate_wave_speed(double rho_l, double u_l, do
                                      pdiv(1.0, z)));
         } else {               // two-shock, :640-658
             double A_r = pdiv(2.0, (gamma + 1.0) * rho_r);
-            double B_r = pdiv(p_r * (gamma - 1.0), gamma + 1.0);
+            double B_r = pdivr(p_r * (gamma - 1.0), gamma + 1.0, K.rgp1);
             double A_l = pdiv(2.0, (gamma + 1.0) * rho_l);
-            double B_l = pdiv(p_l * (gamma - 1.0), gamma + 1.0);
+            double B_l = pdivr(p_l * (gamma - 1.0), gamma + 1.0, K.rgp1);
             double p_guess = fmax(0.0, pstar);
-            double g_l = psqrt(pdiv(A_l, p_guess + B_l));
-            double g_r = psqrt(pdiv(A_r, p_guess + B_r));
+            double g_l = psqrt_nc(pdiv(A_l, p_guess + B_l));
+            double g_r = psqrt_nc(pdiv(A_r, p_guess + B_r));
             pstar = pdiv(g_l * p_l + g_r * p_r - (u_r - u_l), g_l + g_r);
         }
     }
     if (pstar <= p_l)
         S_l = u_l - c_l;
     else
-        S_l = u_l - c_l * psqrt(1.0 + pdiv(gamma + 1.0, 2.0 * gamma) * (pdiv(pstar, p_l) - 1.0));
+        S_l = u_l - c_l * psqrt_nc(1.0 + K.ksl * (pdiv(pstar, p_l) - 1.0));
     if (pstar <= p_r)
         S_r = u_r + c_r;
     else
-        S_r = u_r + c_r * psqrt(1.0 + pdiv(gamma + 1.0, pdiv(2.0, gamma)) * (pdiv(pstar, p_r) - 1.0));
+        S_r = u_r + c_r * psqrt_nc(1.0 + K.ksr * (pdiv(pstar, p_r) - 1.0));
 }
 
 // consFlux in the (normal, transverse) frame, riemann.py:1104-1179.
@@ -298,9 +351,10 @@ __device__ __forceinline__ ConsN cons_flux_n(const ConsN &U, double gamma, bool 
 // HLLC flux for one face, riemann.py:681-860, in the (normal, transverse)
 // frame.  normal_is_x only fixes the order of the two squares in the kinetic
 // energy of consFlux.
-__device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, double gamma,
+__device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, const GasK &K,
                                            bool normal_is_x)
 {
+    const double gamma = K.gamma;
     const double smallc = 1.e-10, smallp = 1.e-10;
     double rho_l = Ul.d;
     const double ril = PYRO_FAST ? prcp(rho_l) : 0.0;
@@ -316,10 +370,10 @@ __device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, dou
     double rhoe_r = Ur.E - 0.5 * rho_r * (un_r * un_r + ut_r * ut_r);
     double p_r = rhoe_r * (gamma - 1.0);
     p_r = fmax(p_r, smallp);
-    double c_l = fmax(smallc, psqrt(pdivr(gamma * p_l, rho_l, ril)));
-    double c_r = fmax(smallc, psqrt(pdivr(gamma * p_r, rho_r, rir)));
+    double c_l = fmax(smallc, psqrt_nc(pdivr(gamma * p_l, rho_l, ril)));
+    double c_r = fmax(smallc, psqrt_nc(pdivr(gamma * p_r, rho_r, rir)));
     double S_l, S_r;
-    estimate_wave_speed(rho_l, un_l, p_l, c_l, rho_r, un_r, p_r, c_r, gamma, S_l, S_r);
+    estimate_wave_speed(rho_l, un_l, p_l, c_l, rho_r, un_r, p_r, c_r, K, S_l, S_r);
     double S_c = pdiv(p_r - p_l + rho_l * un_l * (S_l - un_l) - rho_r * un_r * (S_r - un_r),
                       rho_l * (S_l - un_l) - rho_r * (S_r - un_r));
     ConsN F;
@@ -375,9 +429,10 @@ __device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, dou
 // chi = min(1, max|v| / max c), and the star fluxes are written in the
 // (S_c (S U - F) + S p* D) / (S - S_c) form with D = (0, S_c, 1, 0) in
 // (density, energy, normal momentum, transverse momentum).
-__device__ __forceinline__ ConsN hllc_lm_flux(const ConsN &Ul, const ConsN &Ur, double gamma,
+__device__ __forceinline__ ConsN hllc_lm_flux(const ConsN &Ul, const ConsN &Ur, const GasK &K,
                                               bool normal_is_x)
 {
+    const double gamma = K.gamma;
     const double smallc = 1.e-10, smallp = 1.e-10;
     const double rho_l = Ul.d;
     const double ril = PYRO_FAST ? prcp(rho_l) : 0.0;
@@ -392,7 +447,7 @@ __device__ __forceinline__ ConsN hllc_lm_flux(const ConsN &Ul, const ConsN &Ur, 
     const double c_l = fmax(smallc, psqrt(pdivr(gamma * p_l, rho_l, ril)));
     const double c_r = fmax(smallc, psqrt(pdivr(gamma * p_r, rho_r, rir)));
     double S_l, S_r;
-    estimate_wave_speed(rho_l, un_l, p_l, c_l, rho_r, un_r, p_r, c_r, gamma, S_l, S_r);
+    estimate_wave_speed(rho_l, un_l, p_l, c_l, rho_r, un_r, p_r, c_r, K, S_l, S_r);
     const double S_c = pdiv(p_r - p_l + rho_l * un_l * (S_l - un_l) - rho_r * un_r * (S_r - un_r),
                             rho_l * (S_l - un_l) - rho_r * (S_r - un_r));
     const double vmag_l = psqrt0(un_l * un_l + ut_l * ut_l);
@@ -512,14 +567,20 @@ __device__ __forceinline__ ConsN cgf_flux(const ConsN &Ul, const ConsN &Ur, doub
     return cons_flux_n(cgf_state(Ul, Ur, gamma, wall_zero), gamma, normal_is_x);
 }
 
-// compressible.riemann dispatch: SOLVER 0 = HLLC, 1 = CGF
+// compressible.riemann dispatch: SOLVER 0 = HLLC, 1 = CGF, 2 = HLLC_lm
+template <int SOLVER>
+__device__ __forceinline__ ConsN riemann_face(const ConsN &Ul, const ConsN &Ur, const GasK &K,
+                                              bool normal_is_x, bool wall_zero)
+{
+    if (SOLVER == 1) return cgf_flux(Ul, Ur, K.gamma, normal_is_x, wall_zero);
+    if (SOLVER == 2) return hllc_lm_flux(Ul, Ur, K, normal_is_x);
+    return hllc_flux(Ul, Ur, K, normal_is_x);
+}
 template <int SOLVER>
 __device__ __forceinline__ ConsN riemann_face(const ConsN &Ul, const ConsN &Ur, double gamma,
                                               bool normal_is_x, bool wall_zero)
 {
-    if (SOLVER == 1) return cgf_flux(Ul, Ur, gamma, normal_is_x, wall_zero);
-    if (SOLVER == 2) return hllc_lm_flux(Ul, Ur, gamma, normal_is_x);
-    return hllc_flux(Ul, Ur, gamma, normal_is_x);
+    return riemann_face<SOLVER>(Ul, Ur, make_gask(gamma), normal_is_x, wall_zero);
 }
 
 // Sponge, compressible/simulation.py:164-184 and :427-441 (acts on every
@@ -594,6 +655,21 @@ __device__ __forceinline__ double div_u_vertex(double u_ij, double u_ijm, double
     double vb = 0.5 * (v_ijm + v_imjm);
     double ux = pdiv(ur - ul, dx);
     double vy = pdiv(vt - vb, dy);
+    return ux + vy;
+}
+
+// div_u_vertex with the reciprocals of dx, dy passed in (fast build)
+__device__ __forceinline__ double div_u_vertex_r(double u_ij, double u_ijm, double u_imj,
+                                                 double u_imjm, double v_ij, double v_imj,
+                                                 double v_ijm, double v_imjm, double dx, double dy,
+                                                 double rdx, double rdy)
+{
+    double ur = 0.5 * (u_ij + u_ijm);
+    double ul = 0.5 * (u_imj + u_imjm);
+    double vt = 0.5 * (v_ij + v_imj);
+    double vb = 0.5 * (v_ijm + v_imjm);
+    double ux = pdivr(ur - ul, dx, rdx);
+    double vy = pdivr(vt - vb, dy, rdy);
     return ux + vy;
 }
 

@@ -18,6 +18,18 @@ from pyro2_amd import _lib, device
 TOL_EXACT = 1e-13
 TOL_FAST = 1e-10
 
+# kernel sets under test: 0 staged, 1 fused 2-d tile kernel, 2 fused row-marching
+# kernel (workgroup pipeline through LDS), 3 fused row-marching kernel (autonomous
+# wavefronts), both with the library's strip length; 4 / 5 = 2 / 3 with 11-row
+# strips (several strips and ragged last strips on the small test grids)
+KSETS = [0, 1, 2, 3, 4, 5]
+FUSED_KSETS = [1, 2, 3, 4, 5]
+
+
+def kset_kw(kset):
+    """test id -> parameters: 4 / 5 = kernel_set 2 / 3 with short strips"""
+    return dict(kernel_set=kset - 2, march_rows=11) if kset >= 4 else dict(kernel_set=kset)
+
 
 def dev_params(meta, **kw):
     nx, ny, ng, dx, dy, gamma, lim, flat, z0, z1, delta, cvisc, grav, cfl = meta
@@ -88,15 +100,16 @@ def test_comp_stages_vs_reference(dev, golden, k):
     assert np.array_equal(U1[m], g[f"c{k}_U1"][m])
 
 
+@pytest.mark.parametrize("kset", FUSED_KSETS)
 @pytest.mark.parametrize("k", range(8))
-def test_comp_fused_vs_reference(dev, golden, k):
-    """kernel_set 1 (single fused LDS kernel): one step from a reference
+def test_comp_fused_vs_reference(dev, golden, k, kset):
+    """kernel_set 1 / 2 (single fused kernel per step): one step from a reference
     state, end state against the reference's own evolve(); then the cached
     CFL minimum against the oracle's next time step"""
     g = golden("comp_stages")
     bcs = [str(b) for b in g[f"c{k}_bc"]]
     meta = g[f"c{k}_meta"]
-    P, cfl = dev_params(meta, kernel_set=1)
+    P, cfl = dev_params(meta, **kset_kw(kset))
     nx, ny, ng = int(meta[0]), int(meta[1]), int(meta[2])
     s = comp_state(dev, nx, ny, bcs)
     s.upload(g[f"c{k}_U0"])
@@ -135,13 +148,13 @@ def device_comp_run(dev, ic, meta, bcs, tmax, max_steps, ambient=None, **kw):
     return s.download(), np.array(dts), pol.t
 
 
-@pytest.mark.parametrize("kset", [0, 1])
+@pytest.mark.parametrize("kset", KSETS)
 def test_comp_sedov_64(dev, golden, kset):
     """sedov 64^2 (SURVEY 8(c) fingerprint): 20 steps on the GPU, 6 on emu"""
     g = golden("comp_sedov_64_020")
     bcs = [str(b) for b in g["bc"]]
     nsteps = 20 if dev.kind == "hip" else 6
-    U, dts, t = device_comp_run(dev, g["ic"], g["meta"], bcs, 0.1, nsteps, kernel_set=kset)
+    U, dts, t = device_comp_run(dev, g["ic"], g["meta"], bcs, 0.1, nsteps, **kset_kw(kset))
     tol = 0.0 if dev.kind == "emu" else TOL_EXACT * nsteps
     assert max_rel_err(dts, g["dts"][:nsteps]) <= tol
     if nsteps == 20:
@@ -152,7 +165,7 @@ def test_comp_sedov_64(dev, golden, kset):
         assert max_rel_err(U[4:-4, 4:-4], Uo[4:-4, 4:-4]) <= tol
 
 
-@pytest.mark.parametrize("kset", [0, 1])
+@pytest.mark.parametrize("kset", KSETS)
 def test_comp_positivity_error(dev, golden, kset):
     """negative internal energy -> PYROHIP_ERR_STATE, like the reference's
     assert (compressible/simulation.py:68-71)"""
@@ -160,7 +173,7 @@ def test_comp_positivity_error(dev, golden, kset):
     g = golden("comp_sedov_64_020")
     U = g["ic"].copy()
     U[30, 30, 1] = -1.0
-    P, cfl = dev_params(g["meta"], kernel_set=kset)
+    P, cfl = dev_params(g["meta"], **kset_kw(kset))
     s = comp_state(dev, 64, 64, [str(b) for b in g["bc"]])
     s.upload(U)
     with pytest.raises(PyroHipError) as ei:
@@ -169,27 +182,27 @@ def test_comp_positivity_error(dev, golden, kset):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kset", [0, 1])
+@pytest.mark.parametrize("kset", KSETS)
 def test_comp_reference_regression_sod_x(hip, golden, kset):
     """pyro/test.py:101 -- sod_x_0076.h5 (128x10, limiter 1, reflect y)"""
     g = golden("comp_sod_x_0076")
     bcs = [str(b) for b in g["bc"]]
     U, dts, t = device_comp_run(hip, g["ic"], g["meta"], bcs, float(g["tmax"]), 200,
-                                kernel_set=kset)
+                                **kset_kw(kset))
     assert len(dts) == 76
     for n in range(3):
         assert max_rel_err(U[4:-4, 4:-4, n], g["gold"][..., n]) < 1e-12
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kset", [0, 1])
+@pytest.mark.parametrize("kset", KSETS)
 @pytest.mark.parametrize("fast", [0, 1])
 def test_comp_reference_regression_quad(hip, golden, fast, kset):
     """pyro/test.py:100 -- quad_unsplit_0606.h5 (256^2, 606 steps)"""
     g = golden("comp_quad_0606")
     bcs = [str(b) for b in g["bc"]]
     U, dts, t = device_comp_run(hip, g["ic"], g["meta"], bcs, float(g["tmax"]), 1000,
-                                fast_math=fast, kernel_set=kset)
+                                fast_math=fast, **kset_kw(kset))
     assert len(dts) == 606
     for n in range(4):
         e = max_rel_err(U[4:-4, 4:-4, n], g["gold"][..., n])
@@ -197,7 +210,7 @@ def test_comp_reference_regression_quad(hip, golden, fast, kset):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kset", [0, 1])
+@pytest.mark.parametrize("kset", KSETS)
 @pytest.mark.parametrize("fast", [0, 1])
 def test_comp_reference_regression_rt(hip, golden, fast, kset):
     """pyro/test.py:102 -- rt_0945.h5 (64x192, 945 steps, gravity, hse
@@ -205,15 +218,46 @@ def test_comp_reference_regression_rt(hip, golden, fast, kset):
     g = golden("comp_rt_0945")
     bcs = [str(b) for b in g["bc"]]
     U, dts, t = device_comp_run(hip, g["ic"], g["meta"], bcs, float(g["tmax"]), 10000,
-                                fast_math=fast, kernel_set=kset)
+                                fast_math=fast, **kset_kw(kset))
     assert len(dts) == 945
     scale = np.abs(g["gold"]).max(axis=(0, 1))
     err = np.abs(U[4:-4, 4:-4] - g["gold"]).max(axis=(0, 1)) / scale
     assert err.max() < (1e-11 if not fast else TOL_FAST), err
 
 
+@pytest.mark.parametrize("kset", [2, 3])
+@pytest.mark.parametrize("rows", [0, 7])
+def test_comp_march_wide_grid(dev, rows, kset):
+    """kernel_set 2 on a grid wider than one column block (248 columns per
+    workgroup): 20 x 530 cells = 3 column blocks, the last one ragged, short
+    strips; an off-centre blast so that no symmetry hides a mix-up of columns.
+    Against the staged kernels (validated stage by stage above): bit-identical
+    in the bit-faithful build"""
+    from sedov_ic import sedov_ic
+    nx, ny = 20, 530
+    ic, meta, bcs = sedov_ic(nx, ny, r_init=0.02, xmin=0.0, xmax=0.2, ymin=0.0, ymax=5.3)
+    # move the energy peak off the centre, add a smooth density / velocity field
+    ic = np.nan_to_num(ic)
+    x = (np.arange(nx + 8) - 3.5)[:, None] / nx
+    y = (np.arange(ny + 8) - 3.5)[None, :] / ny
+    ic[..., 0] = 1.0 + 0.3 * np.sin(7 * x + 3) * np.cos(23 * y)
+    ic[..., 2] = 0.1 * ic[..., 0] * np.cos(11 * y + x)
+    ic[..., 3] = -0.2 * ic[..., 0] * np.sin(5 * x) * np.sin(17 * y)
+    ic[..., 1] += 0.5 * (ic[..., 2] ** 2 + ic[..., 3] ** 2) / ic[..., 0]
+    ic[..., 1] += 0.4 * np.exp(-((x - 0.3) ** 2 + (y - 0.47) ** 2) * 4000.0)
+    ic[..., 1] += 0.7 * np.exp(-((x - 0.8) ** 2 + (y - 0.935) ** 2) * 4000.0)
+    nsteps = 3
+    Us, dts_s, _ = device_comp_run(dev, ic, meta, bcs, 10.0, nsteps, kernel_set=0)
+    Um, dts_m, _ = device_comp_run(dev, ic, meta, bcs, 10.0, nsteps, kernel_set=kset,
+                                   march_rows=rows)
+    tol = 0.0 if dev.kind == "emu" else TOL_EXACT * nsteps
+    assert max_rel_err(dts_m, dts_s) <= tol
+    for n in range(4):
+        assert max_rel_err(Um[..., n], Us[..., n]) <= tol, n
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("kset", [0, 1])
+@pytest.mark.parametrize("kset", KSETS)
 @pytest.mark.parametrize("fast", [0, 1])
 def test_comp_sedov_512_vs_oracle(hip, fast, kset):
     """sedov at 512^2 (inputs.sedov physics), 30 steps, against the oracle on
@@ -223,7 +267,7 @@ def test_comp_sedov_512_vs_oracle(hip, fast, kset):
     ic, meta, bcs = sedov_ic(nx)
     from helpers import oracle_comp_run
     Uo, dto, _ = oracle_comp_run(ic, meta, bcs, 0.1, 30)
-    U, dts, _ = device_comp_run(hip, ic, meta, bcs, 0.1, 30, fast_math=fast, kernel_set=kset)
+    U, dts, _ = device_comp_run(hip, ic, meta, bcs, 0.1, 30, fast_math=fast, **kset_kw(kset))
     tol = TOL_FAST if fast else 1e-12
     assert max_rel_err(dts, dto) <= tol
     for n in range(4):
@@ -289,7 +333,7 @@ def test_comp_sedov_4096_vs_oracle_samples(hip, golden, fast):
             assert np.abs(I[..., n].sum(axis=ax) - ref).max() <= tol * max(np.abs(ref).max(), nx * umax[n] * 1e-3)
 
 
-@pytest.mark.parametrize("kset", [0, 1])
+@pytest.mark.parametrize("kset", KSETS)
 def test_comp_gravity_run(dev, kset):
     """gravity sources (apply_source_terms + predictor-corrector,
     unsplit_fluxes.py:247-330, simulation.py:406-423): a perturbed stratified
@@ -312,7 +356,7 @@ def test_comp_gravity_run(dev, kset):
     bcs = ["periodic", "periodic", "reflect", "reflect"]
     nsteps = 8 if dev.kind == "emu" else 40
     Uo, dto, _ = oracle_comp_run(ic, meta, bcs, 10.0, nsteps)
-    U, dts, _ = device_comp_run(dev, ic, meta, bcs, 10.0, nsteps, kernel_set=kset)
+    U, dts, _ = device_comp_run(dev, ic, meta, bcs, 10.0, nsteps, **kset_kw(kset))
     tol = 0.0 if dev.kind == "emu" else 1e-12
     assert max_rel_err(dts, dto) <= tol
     for n in range(4):
@@ -320,7 +364,7 @@ def test_comp_gravity_run(dev, kset):
     assert np.abs(U[4:-4, 4:-4, 3]).max() > 1e-3   # gravity did something
 
 
-@pytest.mark.parametrize("kset", [0, 1])
+@pytest.mark.parametrize("kset", KSETS)
 @pytest.mark.parametrize("k", range(6))
 def test_comp_cgf_and_sponge(dev, golden, k, kset):
     """SURVEY 8 row f2 on the device: CGF Riemann solver (incl. the solid-wall
@@ -330,7 +374,7 @@ def test_comp_cgf_and_sponge(dev, golden, k, kset):
     meta = g[f"c{k}_meta"]
     sp = g[f"c{k}_sponge"]
     solid = [int(b == "reflect") for b in bcs]
-    P, cfl = dev_params(meta, kernel_set=kset, riemann=str(g[f"c{k}_riemann"]),
+    P, cfl = dev_params(meta, **kset_kw(kset), riemann=str(g[f"c{k}_riemann"]),
                         solid_xl=solid[0], solid_yl=solid[2],
                         sponge=tuple(sp[1:]) if sp[0] else None)
     nx, ny, ng = int(meta[0]), int(meta[1]), int(meta[2])
@@ -352,7 +396,7 @@ def test_comp_cgf_and_sponge(dev, golden, k, kset):
         assert max_rel_err(R(U1, ng, 0), R(ref, ng, 0)) <= tol, k
 
 
-@pytest.mark.parametrize("kset", [0, 1])
+@pytest.mark.parametrize("kset", KSETS)
 @pytest.mark.parametrize("k", range(4))
 def test_comp_hse_ambient_runs(dev, golden, k, kset):
     """gravity with the hse / ambient user boundaries
@@ -363,7 +407,7 @@ def test_comp_hse_ambient_runs(dev, golden, k, kset):
     meta, bcs = g[pre + "meta"], [str(b) for b in g[pre + "bc"]]
     riemann = "CGF" if k == 1 else "HLLC"
     solid = [int(b == "reflect") for b in bcs]
-    P, cfl = dev_params(meta, kernel_set=kset, riemann=riemann, solid_xl=solid[0],
+    P, cfl = dev_params(meta, **kset_kw(kset), riemann=riemann, solid_xl=solid[0],
                         solid_yl=solid[2])
     nx, ny, ng = int(meta[0]), int(meta[1]), int(meta[2])
     s = comp_state(dev, nx, ny, bcs)
@@ -501,7 +545,7 @@ def test_pyro_compressible_rk(dev, golden, k, tmp_path, monkeypatch):
         assert (np.abs(U - fin)[4:-4, 4:-4] / scale).max() < 1e-11
 
 
-@pytest.mark.parametrize("kset", [0, 1])
+@pytest.mark.parametrize("kset", KSETS)
 @pytest.mark.parametrize("k", range(4))
 def test_comp_hllc_lm(dev, golden, k, kset):
     """low-Mach HLLC (compressible.riemann = HLLC_lm) on the
@@ -510,7 +554,7 @@ def test_comp_hllc_lm(dev, golden, k, kset):
     g = golden("comp_stages_lm")
     bcs = [str(b) for b in g[f"c{k}_bc"]]
     meta = g[f"c{k}_meta"]
-    P, cfl = dev_params(meta, kernel_set=kset, riemann="HLLC_lm")
+    P, cfl = dev_params(meta, **kset_kw(kset), riemann="HLLC_lm")
     nx, ny, ng = int(meta[0]), int(meta[1]), int(meta[2])
     s = comp_state(dev, nx, ny, bcs)
     if "hse" in bcs:
@@ -533,7 +577,7 @@ def test_comp_hllc_lm(dev, golden, k, kset):
     assert (np.abs(U1 - g[f"c{k}_U1"])[ng:-ng, ng:-ng] / scale).max() <= 1e-13
 
 
-@pytest.mark.parametrize("kset", [0, 1])
+@pytest.mark.parametrize("kset", KSETS)
 def test_comp_ramp_boundary(dev, golden, kset):
     """the time-dependent "ramp" boundary of the double Mach
     reflection problem (compressible/BC.py:178-296) filled on the device; run
@@ -541,7 +585,7 @@ def test_comp_ramp_boundary(dev, golden, kset):
     from test_oracle_golden import oracle_ramp_run
     g = golden("comp_ramp")
     meta, bcs, dom = g["meta"], [str(b) for b in g["bc"]], g["domain"]
-    P, cfl = dev_params(meta, kernel_set=kset)
+    P, cfl = dev_params(meta, **kset_kw(kset))
     nx, ny, ng = int(meta[0]), int(meta[1]), int(meta[2])
     s = comp_state(dev, nx, ny, bcs)
     with pytest.raises(_lib.PyroHipError):
@@ -571,7 +615,7 @@ def test_comp_ramp_boundary(dev, golden, kset):
         assert (np.abs(s.download() - g["filled"]) / scale).max() <= tol
 
 
-@pytest.mark.parametrize("kset", [0, 1])
+@pytest.mark.parametrize("kset", KSETS)
 @pytest.mark.parametrize("k", range(3))
 def test_comp_problem_sources(dev, golden, k, kset):
     """the heating source of the heating / plume / convection
@@ -586,7 +630,7 @@ def test_comp_problem_sources(dev, golden, k, kset):
     nx, ny, ng = int(meta[0]), int(meta[1]), int(meta[2])
     I = (slice(ng, -ng), slice(ng, -ng))
     solid = [int(b == "reflect") for b in bcs]
-    P, cfl = dev_params(meta, kernel_set=kset, solid_xl=solid[0], solid_yl=solid[2],
+    P, cfl = dev_params(meta, **kset_kw(kset), solid_xl=solid[0], solid_yl=solid[2],
                         small_dens=over["small_dens"], sponge=over.get("sponge"),
                         heat_rate=over["heating"][0])
 
