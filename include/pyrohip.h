@@ -177,8 +177,9 @@ typedef struct {
     int fast_math;
     /* kernel set: 0 = staged kernels with global intermediates (debuggable,
        supports pyrohip_comp_stage_dump); 1 = one fused kernel on 2-d LDS
-       tiles; 2 = one fused kernel marching along the rows (x windows in
-       registers, y exchange through LDS rings; the fastest)                */
+       tiles (best below ~1024^2); 2 = one fused kernel of autonomous
+       wavefronts marching along the rows (x windows in registers, y exchange
+       by DPP lane rotation; the fastest on large grids)                     */
     int kernel_set;
     /* compressible.riemann: 0 = HLLC (riemann.py:681-860), 1 = CGF (:8-310),
        2 = HLLC_lm (riemann_hllc_lowspeed, :863-1020).

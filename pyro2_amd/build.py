@@ -29,8 +29,6 @@ UNITS = [
     ("compressible.hip", "comp_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1"]),
     ("comp_fused.hip", "fused_exact", ["-ffp-contract=off", "-DPYRO_FAST=0"]),
     ("comp_fused.hip", "fused_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1"]),
-    ("comp_march.hip", "march_exact", ["-ffp-contract=off", "-DPYRO_FAST=0"]),
-    ("comp_march.hip", "march_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1"]),
     ("comp_wave.hip", "wave_exact", ["-ffp-contract=off", "-DPYRO_FAST=0"]),
     ("comp_wave.hip", "wave_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1"]),
     ("comp_api.hip", "comp_api", ["-ffp-contract=off"]),

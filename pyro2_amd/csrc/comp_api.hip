@@ -8,7 +8,6 @@ namespace exact {
 int comp_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_step_staged(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_fused(pyrohip_state *, const pyrohip_comp_params *, double);
-int comp_step_march(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_wave(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_sph(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_dt_sph(pyrohip_state *, const pyrohip_comp_params *, double, double *);
@@ -22,7 +21,6 @@ int comp_rk_rhs(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, i
 int comp_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_step_staged(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_fused(pyrohip_state *, const pyrohip_comp_params *, double);
-int comp_step_march(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_wave(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_sph(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_dt_sph(pyrohip_state *, const pyrohip_comp_params *, double, double *);
@@ -65,7 +63,7 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
 {
     PYRO_TRY(check_comp(s, p));
     PYRO_REQUIRE(dt > 0.0, "dt must be positive");
-    PYRO_REQUIRE(p->kernel_set >= 0 && p->kernel_set <= 3, "kernel_set must be 0, 1, 2 or 3");
+    PYRO_REQUIRE(p->kernel_set >= 0 && p->kernel_set <= 2, "kernel_set must be 0, 1 or 2");
     PYRO_REQUIRE(p->riemann >= 0 && p->riemann <= 2, "riemann must be 0 (HLLC), 1 (CGF) or 2 (HLLC_lm)");
     int rc;
     if (s->sph) {
@@ -74,10 +72,8 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
         PYRO_REQUIRE(!s->user_bc && !s->ramp_bc && !s->heat,
                      "hse / ambient / ramp boundaries and heating are Cartesian-only");
         rc = p->fast_math ? fastm::comp_step_sph(s, p, dt) : exact::comp_step_sph(s, p, dt);
-    } else if (p->kernel_set == 3)
+    } else if (p->kernel_set == 2)
         rc = p->fast_math ? fastm::comp_step_wave(s, p, dt) : exact::comp_step_wave(s, p, dt);
-    else if (p->kernel_set == 2)
-        rc = p->fast_math ? fastm::comp_step_march(s, p, dt) : exact::comp_step_march(s, p, dt);
     else if (p->kernel_set == 1)
         rc = p->fast_math ? fastm::comp_step_fused(s, p, dt) : exact::comp_step_fused(s, p, dt);
     else

@@ -1,5 +1,5 @@
 // Compressible CTU + Riemann step as ONE kernel per time step: autonomous
-// wavefronts marching along the rows (kernel_set 3).
+// wavefronts marching along the rows (kernel_set 2).
 //
 // Same arithmetic as the other kernel sets (per-cell functions of hydro.h /
 // stencil.h in the reference's operation order).  One wavefront = 64 columns
@@ -66,8 +66,16 @@ constexpr int WOUT = 56;          // columns a wavefront updates
 #define PYRO_WAVE_MINW 2          // waves per SIMD the register allocation must allow
 #endif
 
-// value of the same variable in lane l-1 / l+1 (own value at the ends of the
-// wavefront).  gfx950 keeps the GFX9 whole-wave DPP shifts (wave_shr:1 /
+// value of the same variable in lane l-1 / l+1.  The ends of the wavefront are
+// apron lanes whose results are never stored, but what they compute matters
+// for speed: a wavefront executes every lazily evaluated branch (flattening,
+// the shock branches of the wave-speed estimate) that ANY lane takes.  The DPP
+// moves therefore ROTATE (lane 0 reads lane 63: a finite physical state, equal
+// to its own in uniform regions) -- with shifts + bound_ctrl the end lanes read
+// 0, went to NaN and dragged the wavefront through the slow paths (+8 v_rsq /
+// v_rcp per row, PMC); shifts that keep the own value need a register copy in
+// front of every move (the `old` operand is tied to the destination).  The
+// shuffle variant (emulator, -DPYRO_WAVE_BPERMUTE) keeps the own value.  gfx950 keeps the GFX9 whole-wave DPP shifts (wave_shr:1 /
 // wave_shl:1 move data across all 64 lanes, tools/dpp_probe.hip): two
 // v_mov_b32_dpp per double, a register-to-register VALU move without the
 // LDS-crossbar round trip of ds_bpermute (__shfl_up / __shfl_down).
@@ -75,12 +83,12 @@ constexpr int WOUT = 56;          // columns a wavefront updates
 template <int CTRL> __device__ __forceinline__ double lane_dpp(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double lane_m1(double v) { return lane_dpp<0x138>(v); }   // wave_shr:1
-__device__ __forceinline__ double lane_p1(double v) { return lane_dpp<0x130>(v); }   // wave_shl:1
+__device__ __forceinline__ double lane_m1(double v) { return lane_dpp<0x13C>(v); }   // wave_ror:1
+__device__ __forceinline__ double lane_p1(double v) { return lane_dpp<0x134>(v); }   // wave_rol:1
 __device__ __forceinline__ double lane_m2(double v) { return lane_m1(lane_m1(v)); }
 __device__ __forceinline__ double lane_p2(double v) { return lane_p1(lane_p1(v)); }
 #else
@@ -105,8 +113,9 @@ __device__ __forceinline__ Cons lane_p1(const Cons &U)
 // iteration, so one slot per value is enough.
 constexpr int ST_YM = 0, ST_YP = 4, ST_FXT = 8, ST_XP = 12, ST_XPC = 16, ST_FX = 20;
 constexpr int ST_L2 = 24;         // limit2_x of two rows: 2 x 4 slots, the older row at (k & 1)
-constexpr int ST_CFL = 32;        // running CFL minimum of the lane
-constexpr int ST_SLOTS = 33;
+constexpr int ST_AX = 32, ST_AY = 33;   // running maxima of |u| + c, |v| + c of the lane's new cells
+constexpr int ST_XPQ = 34;        // (un, ut, p) of the uncorrected XP (fast build)
+constexpr int ST_SLOTS = 37;
 // Uniform doubles (kernel parameters) live in a table behind the stash and are
 // read with a broadcast ds_read where a stage needs them.  Left in the argument
 // registers they do not fit: ~50 uniform doubles (parameters, x / y variants,
@@ -156,6 +165,9 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     const size_t pl = g.plane;
     const int limiter = STD ? 2 : P.limiter;
     const bool flat = STD || P.use_flattening;
+    // fast build, HLLC: the transverse Riemann problems take the traced primitive
+    // face states as they are (hllc_flux_impl<true>)
+    constexpr bool TQ = (PYRO_FAST != 0) && (SOLVER == 0);
     UniformTab ct = (UniformTab)(lds + ST_SLOTS * 64);
     if (l == 0) {     // one wavefront, LDS operations complete in order: no barrier needed
         ct[C_GAMMA] = P.gamma; ct[C_DX] = P.dx; ct[C_DY] = P.dy; ct[C_DT] = P.dt;
@@ -174,6 +186,12 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         return Cons{Uin[kk], Uin[pl + kk], Uin[2 * pl + kk], Uin[3 * pl + kk]};
     };
     auto row_in = [&](int r) { return r >= g.ilo && r <= g.ihi; };
+    // (un, ut, p) of a conserved face state in the normal frame, as HLLC derives them
+    auto faceq = [&](const ConsN &U, double gamma) {
+        const double ri = prcp(U.d);
+        const double un = U.mn * ri, ut = U.mt * ri;
+        return FaceQ{un, ut, (U.E - 0.5 * U.d * (un * un + ut * ut)) * (gamma - 1.0)};
+    };
 
     // state carried from one iteration to the next in registers (rows relative
     // to the iteration k that is about to start) ...
@@ -192,7 +210,8 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         st_put(st, ST_YM, one); st_put(st, ST_YP, one); st_put(st, ST_XP, one);
         st_put(st, ST_XPC, one); st_put(st, ST_FXT, one); st_put(st, ST_FX, one);
         st_put(st, ST_L2, one); st_put(st, ST_L2 + 4, one);
-        st[ST_CFL * 64] = INFINITY;
+        st[ST_AX * 64] = 0.0; st[ST_AY * 64] = 0.0;
+        st[ST_XPQ * 64] = 0.0; st[(ST_XPQ + 1) * 64] = 0.0; st[(ST_XPQ + 2) * 64] = 1.0;
     }
 
     for (int k = i0 - 4; k <= i1 + 3; k++) {
@@ -315,14 +334,26 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             double gm1 = UC(GM1), rgm1 = UC(RGM1);
             Cons XMn = prim_to_cons_g(Prim{lo.r, lo.un, lo.ut, lo.p}, gm1, rgm1);
             Cons XPn = prim_to_cons_g(Prim{hi.r, hi.un, hi.ut, hi.p}, gm1, rgm1);
+            FaceQ qxm{lo.un, lo.ut, lo.p}, qxp{hi.un, hi.ut, hi.p};
             if (P.have_src) {
                 add_grav_to_state(XMn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
                 add_grav_to_state(XPn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
+                if (TQ) { qxm = faceq(to_nf(XMn, true), gamma); qxp = faceq(to_nf(XPn, true), gamma); }
             }
             Cons FxTn{0.0, 0.0, 0.0, 0.0};
-            if (xface)
-                FxTn = from_nf(riemann_face<SOLVER>(to_nf(st_get(st, ST_XP), true), to_nf(XMn, true),
-                                                    UC_GASK(), true, P.solid_xl && i == g.ilo), true);
+            if (xface) {
+                if (TQ) {
+                    const FaceQ ql{st[ST_XPQ * 64], st[(ST_XPQ + 1) * 64], st[(ST_XPQ + 2) * 64]};
+                    FxTn = from_nf(hllc_flux_impl<true>(to_nf(st_get(st, ST_XP), true), to_nf(XMn, true),
+                                                        ql, qxm, UC_GASK(), true), true);
+                } else
+                    FxTn = from_nf(riemann_face<SOLVER>(to_nf(st_get(st, ST_XP), true),
+                                                        to_nf(XMn, true), UC_GASK(), true,
+                                                        P.solid_xl && i == g.ilo), true);
+            }
+            if (TQ) {
+                st[ST_XPQ * 64] = qxp.un; st[(ST_XPQ + 1) * 64] = qxp.ut; st[(ST_XPQ + 2) * 64] = qxp.p;
+            }
             STAGE_FENCE();
             // -- row f: y states corrected with FxT of rows f, f+1; final y flux
             Cons Fy{0.0, 0.0, 0.0, 0.0}, Fyh = Fy;
@@ -349,15 +380,22 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             gm1 = UC(GM1); rgm1 = UC(RGM1);
             Cons YMn = prim_to_cons_g(Prim{lo.r, lo.ut, lo.un, lo.p}, gm1, rgm1);
             Cons YPn = prim_to_cons_g(Prim{hi.r, hi.ut, hi.un, hi.p}, gm1, rgm1);
+            FaceQ qym{lo.un, lo.ut, lo.p}, qyp{hi.un, hi.ut, hi.p};
             if (P.have_src) {
                 add_grav_to_state(YMn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
                 add_grav_to_state(YPn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
+                if (TQ) { qym = faceq(to_nf(YMn, false), gamma); qyp = faceq(to_nf(YPn, false), gamma); }
             }
             st_put(st, ST_YM, YMn);
             st_put(st, ST_YP, YPn);
-            const Cons FyT = from_nf(riemann_face<SOLVER>(to_nf(lane_m1(YPn), false),
-                                                          to_nf(YMn, false), UC_GASK(), false,
-                                                          P.solid_yl && j == g.jlo), false);
+            Cons FyT;
+            if (TQ) {
+                const FaceQ ql{lane_m1(qyp.un), lane_m1(qyp.ut), lane_m1(qyp.p)};
+                FyT = from_nf(hllc_flux_impl<true>(to_nf(lane_m1(YPn), false), to_nf(YMn, false), ql,
+                                                   qym, UC_GASK(), false), false);
+            } else
+                FyT = from_nf(riemann_face<SOLVER>(to_nf(lane_m1(YPn), false), to_nf(YMn, false),
+                                                   UC_GASK(), false, P.solid_yl && j == g.jlo), false);
             STAGE_FENCE();
             // -- transverse correction of the x states of row c, final x flux
             const Cons FyTh = lane_p1(FyT);            // FyT at (i, j+1)
@@ -391,7 +429,10 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                     grav_update(Un, Uc, UC(GRAV), UC(DT), UC(HEATR), P.heat ? P.heat[ko] : 0.0);
                 Uout[ko] = Un.d; Uout[pl + ko] = Un.E; Uout[2 * pl + ko] = Un.mx;
                 Uout[3 * pl + ko] = Un.my;
-                st[ST_CFL * 64] = fmin(st[ST_CFL * 64], cfl_cell(Un, UC(GAMMA), UC(DX), UC(DY)));
+                double ax, ay;   // CFL: running maxima of the divisors, one division at the end
+                cfl_speeds(Un, UC(GAMMA), ax, ay);
+                st[ST_AX * 64] = fmax(st[ST_AX * 64], ax);
+                st[ST_AY * 64] = fmax(st[ST_AY * 64], ay);
             }
             st_put(st, ST_FX, Fxn);
         }
@@ -400,7 +441,10 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         Dp = Dn; up = um; vp = vm;
     }
     if (bad) atomicOr(flag, 1);
-    const double cfl = wave_reduce_min(st[ST_CFL * 64]);
+    // min over the lane's cells of min(dx / (|u| + c), dy / (|v| + c)), cfl_cell()
+    const double ax = st[ST_AX * 64], ay = st[ST_AY * 64];
+    double cfl = fmin(ax > 0.0 ? pdiv(P.dx, ax) : INFINITY, ay > 0.0 ? pdiv(P.dy, ay) : INFINITY);
+    cfl = wave_reduce_min(cfl);
     if (l == 0) partial[blockIdx.x] = cfl;
 }
 

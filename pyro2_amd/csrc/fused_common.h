@@ -1,6 +1,6 @@
 // Definitions shared by the two single-launch CTU kernels: the 2-d LDS tile
 // kernel (comp_fused.hip, kernel_set 1) and the row-marching kernel
-// (comp_march.hip, kernel_set 2).  Included inside namespace pyro::PYRO_NS.
+// (comp_wave.hip, kernel_set 2).  Included inside namespace pyro::PYRO_NS.
 #pragma once
 
 struct FP {   // kernel parameters

@@ -154,6 +154,21 @@ __device__ __forceinline__ double cfl_cell(const Cons &U, double gamma, double d
     return fmin(xt, yt);
 }
 
+// |u| + c and |v| + c of one cell: the divisors of cfl_cell.  A kernel may keep
+// the running maxima and divide once at the end: min_i fl(dx / a_i) =
+// fl(dx / max_i a_i) because a correctly rounded quotient is monotone in the divisor
+__device__ __forceinline__ void cfl_speeds(const Cons &U, double gamma, double &ax, double &ay)
+{
+    const double rd = PYRO_FAST ? prcp(U.d) : 0.0;
+    double u = pdivr(U.mx, U.d, rd);
+    double v = pdivr(U.my, U.d, rd);
+    double e = pdivr(U.E - 0.5 * U.d * (u * u + v * v), U.d, rd);
+    double p = U.d * e * (gamma - 1.0);
+    double cs = psqrt(pdivr(gamma * p, U.d, rd));
+    ax = fabs(u) + cs;
+    ay = fabs(v) + cs;
+}
+
 // 1-d flattening coefficient, pyro/mesh/reconstruction.py:123-164
 //   pm2..pp2 : pressure at -2..+2,  um1/up1 : normal velocity at -1/+1
 __device__ __forceinline__ double flatten_1d(double pm2, double pm1, double pp1, double pp2,
@@ -351,24 +366,45 @@ __device__ __forceinline__ ConsN cons_flux_n(const ConsN &U, double gamma, bool 
 // HLLC flux for one face, riemann.py:681-860, in the (normal, transverse)
 // frame.  normal_is_x only fixes the order of the two squares in the kinetic
 // energy of consFlux.
-__device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, const GasK &K,
-                                           bool normal_is_x)
+// (normal velocity, transverse velocity, pressure) of a face state whose
+// conserved form is also at hand
+struct FaceQ { double un, ut, p; };
+
+// HAVEQ (fast build only): the primitive face states ql / qr are given (the
+// characteristic tracing produced them; prim_to_cons turned them into Ul / Ur),
+// so velocities and pressure are not recovered from the conserved states again.
+// Differs from the reference's round trip by rounding only.
+template <bool HAVEQ>
+__device__ __forceinline__ ConsN hllc_flux_impl(const ConsN &Ul, const ConsN &Ur, const FaceQ &ql,
+                                                const FaceQ &qr, const GasK &K, bool normal_is_x)
 {
     const double gamma = K.gamma;
     const double smallc = 1.e-10, smallp = 1.e-10;
     double rho_l = Ul.d;
     const double ril = PYRO_FAST ? prcp(rho_l) : 0.0;
-    double un_l = pdivr(Ul.mn, rho_l, ril);
-    double ut_l = pdivr(Ul.mt, rho_l, ril);
-    double rhoe_l = Ul.E - 0.5 * rho_l * (un_l * un_l + ut_l * ut_l);
-    double p_l = rhoe_l * (gamma - 1.0);
+    double un_l, ut_l, p_l;
+    if (HAVEQ) {
+        un_l = ql.un; ut_l = ql.ut; p_l = ql.p;
+    } else {
+        un_l = pdivr(Ul.mn, rho_l, ril);
+        ut_l = pdivr(Ul.mt, rho_l, ril);
+        double rhoe_l = Ul.E - 0.5 * rho_l * (un_l * un_l + ut_l * ut_l);
+        p_l = rhoe_l * (gamma - 1.0);
+    }
+    const double pf_l = p_l;            // pressure of the physical flux (HAVEQ)
     p_l = fmax(p_l, smallp);
     double rho_r = Ur.d;
     const double rir = PYRO_FAST ? prcp(rho_r) : 0.0;
-    double un_r = pdivr(Ur.mn, rho_r, rir);
-    double ut_r = pdivr(Ur.mt, rho_r, rir);
-    double rhoe_r = Ur.E - 0.5 * rho_r * (un_r * un_r + ut_r * ut_r);
-    double p_r = rhoe_r * (gamma - 1.0);
+    double un_r, ut_r, p_r;
+    if (HAVEQ) {
+        un_r = qr.un; ut_r = qr.ut; p_r = qr.p;
+    } else {
+        un_r = pdivr(Ur.mn, rho_r, rir);
+        ut_r = pdivr(Ur.mt, rho_r, rir);
+        double rhoe_r = Ur.E - 0.5 * rho_r * (un_r * un_r + ut_r * ut_r);
+        p_r = rhoe_r * (gamma - 1.0);
+    }
+    const double pf_r = p_r;
     p_r = fmax(p_r, smallp);
     double c_l = fmax(smallc, psqrt_nc(pdivr(gamma * p_l, rho_l, ril)));
     double c_r = fmax(smallc, psqrt_nc(pdivr(gamma * p_r, rho_r, rir)));
@@ -376,9 +412,20 @@ __device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, con
     estimate_wave_speed(rho_l, un_l, p_l, c_l, rho_r, un_r, p_r, c_r, K, S_l, S_r);
     double S_c = pdiv(p_r - p_l + rho_l * un_l * (S_l - un_l) - rho_r * un_r * (S_r - un_r),
                       rho_l * (S_l - un_l) - rho_r * (S_r - un_r));
+    // physical flux of one side: consFlux of the conserved state, or directly
+    // from the given primitives
+    auto side_flux = [&](const ConsN &U, double un, double pf) {
+        if (!HAVEQ) return cons_flux_n(U, gamma, normal_is_x);
+        ConsN F;
+        F.d = U.d * un;
+        F.mn = U.mn * un + pf;
+        F.mt = U.mt * un;
+        F.E = (U.E + pf) * un;
+        return F;
+    };
     ConsN F;
     if (S_r <= 0.0) {
-        F = cons_flux_n(Ur, gamma, normal_is_x);
+        F = side_flux(Ur, un_r, pf_r);
     } else if (S_c <= 0.0 && 0.0 < S_r) {
 #if PYRO_FAST && !defined(PYRO_EMU)
         const double a = rho_r * (S_r - un_r), b = S_r - S_c;
@@ -393,7 +440,7 @@ __device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, con
         Us.mn = f * S_c;
         Us.mt = f * ut_r;
         Us.E = f * (pdivr(Ur.E, rho_r, rir) + (S_c - un_r) * (S_c + pa));
-        F = cons_flux_n(Ur, gamma, normal_is_x);
+        F = side_flux(Ur, un_r, pf_r);
         F.d = F.d + S_r * (Us.d - Ur.d);
         F.mn = F.mn + S_r * (Us.mn - Ur.mn);
         F.mt = F.mt + S_r * (Us.mt - Ur.mt);
@@ -412,15 +459,21 @@ __device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, con
         Us.mn = f * S_c;
         Us.mt = f * ut_l;
         Us.E = f * (pdivr(Ul.E, rho_l, ril) + (S_c - un_l) * (S_c + pa));
-        F = cons_flux_n(Ul, gamma, normal_is_x);
+        F = side_flux(Ul, un_l, pf_l);
         F.d = F.d + S_l * (Us.d - Ul.d);
         F.mn = F.mn + S_l * (Us.mn - Ul.mn);
         F.mt = F.mt + S_l * (Us.mt - Ul.mt);
         F.E = F.E + S_l * (Us.E - Ul.E);
     } else {
-        F = cons_flux_n(Ul, gamma, normal_is_x);
+        F = side_flux(Ul, un_l, pf_l);
     }
     return F;
+}
+__device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, const GasK &K,
+                                           bool normal_is_x)
+{
+    const FaceQ none{0.0, 0.0, 0.0};
+    return hllc_flux_impl<false>(Ul, Ur, none, none, K, normal_is_x);
 }
 
 
