@@ -14,10 +14,20 @@ exchange), CFL time step (device reduction + driver dt policy), evolve.
 State is resident in HBM before the timed region starts.
 
 Rank 0 prints ONE JSON line.  At N=1 it also carries
-  roofline      HBM roofline of the update kernels (HIP events, per launch)
+  roofline      HBM roofline of the update kernels (HIP events, per launch),
+                with the FP64-VALU figures that actually bind this kernel
   cpu_baseline  the oracle (CPU port of the reference) on a bounded sample
-  also          advection 2048^2 (configs[1]) and multigrid 4096^2 V-cycles/s
-                (configs[3]), measured the same way
+  also          sedov_developed: the SAME kernel on developed flow (a 1024^2
+                Sedov blast run to t = 0.1 on the GPU and tiled over the grid:
+                the shocked region covers ~30 % of the cells; the headline state
+                is 99.9 % ambient gas), >= 200 timed steps, both builds;
+                sedov_exact: the headline workload in the bit-faithful build;
+                advection 2048^2 (configs[1]), multigrid 4096^2 V-cycles/s
+                (configs[3]) and the incompressible solver, measured the same way
+
+`python bench.py --gpus N` without a launcher spawns its own N ranks
+(127.0.0.1 rendezvous); under `python -m torch.distributed.run` it uses the
+RANK / WORLD_SIZE it is given.
 """
 import argparse
 import json
@@ -35,6 +45,11 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 SEDOV_BYTES_PER_CELL = 64   # read 4 + write 4 conserved doubles
 ADV_BYTES_PER_CELL = 16     # read a + write a
 MG_BYTES_PER_CELL_VCYCLE = 720
+FP64_PEAK_FLOPS = 78.6e12           # MI355X FP64 vector peak (FMA = 2 flop), MI355X_MICROARCH.md
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4  # wave-instructions/s: 1024 SIMDs, 4 cycles per FP64 wave-instruction
+# arithmetic minimum of one CTU + HLLC cell update (operation count of the
+# reference's formulas with every shared quantity computed once; FMA counted as 2)
+SEDOV_MIN_FLOPS_PER_CELL = 820
 
 
 def parse():
@@ -49,7 +64,31 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--cpu-sample-nx", type=int, default=1024)
+    ap.add_argument("--developed-steps", type=int, default=250)
+    ap.add_argument("--no-developed", action="store_true")
     return ap.parse_args()
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N ranks of this
+    script with a 127.0.0.1 rendezvous, relay rank 0's JSON line"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYRO_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        sys.exit(f"bench.py: rank exit codes {rcs}")
 
 
 class Dist:
@@ -63,7 +102,17 @@ class Dist:
         self.td = None
         if world > 1:
             import torch.distributed as td
-            td.init_process_group("gloo", rank=self.rank, world_size=world)
+            # gloo announces its connections on the C stdout; rank 0's stdout
+            # carries exactly ONE JSON line, so park fd 1 on stderr meanwhile
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                td.init_process_group("gloo", rank=self.rank, world_size=world)
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
             self.td = td
 
     def barrier(self):
@@ -93,11 +142,37 @@ def kernel_table(prof, nlaunch_unit):
     return {k: {"launches": n, "avg_ms": ms / max(n, 1)} for k, (n, ms) in prof.items()}
 
 
-def bench_sedov(args, dist, ctx, device, defaults):
+def developed_tile(ctx, device, n=1024, tmax=0.1):
+    """Sedov (inputs.sedov physics) at n x n run on this GPU to t = tmax with the
+    bit-faithful build: the blast has grown to r ~ 0.3 and is far from the outflow
+    boundary, so copies of the tile can sit side by side without seams.
+    Returns the interior (n, n, 4) and the fraction of cells the blast has reached."""
+    from pyro2_amd.compressible.problems.sedov import sedov_state
+    from pyro2_amd.decomp import DtPolicy
+    ng = 4
+    st = device.DeviceState(ctx, n, n, ng, [["outflow"] * 4] * 4)
+    st.upload(np.nan_to_num(sedov_state(n, n, ng, 0.0, 1.0, 0.0, 1.0, 1.4, 0.01, 4)))
+    P = device.make_comp_params(1.0 / n, 1.0 / n, fast_math=0, kernel_set=-1)
+    pol = DtPolicy(tmax)
+    while pol.t < tmax and pol.n < 100000:
+        st.fill_bc()
+        dt = pol(st.comp_dt(P, 0.8))
+        st.comp_step(P, dt)
+        pol.advance(dt)
+    U = st.download()[ng:-ng, ng:-ng].copy()
+    frac = float((np.abs(U[..., 0] - 1.0) > 1e-8).mean())
+    return U, frac, pol.n
+
+
+def bench_sedov(args, dist, ctx, device, defaults, steps=None, warmup=None, tile=None):
+    """tile = None: the Sedov initial condition at t = 0 (BASELINE config);
+    tile = (n, n, 4) array: that state repeated over the whole grid"""
     from pyro2_amd.compressible.problems.sedov import sedov_state
     from pyro2_amd.decomp import DtPolicy, NoComm, RcclComm, SlabCompressible, SlabDecomp
     nx = ny = args.nx
     ng = 4
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     dec = SlabDecomp(nx, dist.world, dist.rank, periodic=False)
     if dist.world == 1:
         comm = NoComm()
@@ -110,22 +185,30 @@ def bench_sedov(args, dist, ctx, device, defaults):
               kernel_set=defaults["kernel_set"])
     slab = SlabCompressible(ctx, dec, ny, ["outflow"] * 4, kw, comm, ng=ng)
     st = slab.state
-    # initial condition (inputs.sedov): generated slab by slab on the host (never
-    # more than 512 rows in memory), resident in HBM before the timed region
-    chunk = 512
+    # initial condition: generated slab by slab on the host (never more than a few
+    # hundred rows in memory), resident in HBM before the timed region
+    chunk = 512 if tile is None else 256
+    if tile is not None:
+        n = tile.shape[0]
+        cols = (np.arange(ny + 2 * ng) - ng) % n
+        tile_cols = np.ascontiguousarray(tile[:, cols, :])      # (n, qy, 4)
     for r0 in range(0, dec.nx_local + 2 * ng, chunk):
         nr = min(chunk, dec.nx_local + 2 * ng - r0)
-        st.upload_rows(r0, sedov_state(nx, ny, ng, 0.0, 1.0, 0.0, 1.0, 1.4, 0.01, 4,
-                                       i0=dec.i0 + r0, ni=nr))
-    pol = DtPolicy(tmax=0.1)
-    for _ in range(args.warmup):
+        if tile is None:
+            st.upload_rows(r0, sedov_state(nx, ny, ng, 0.0, 1.0, 0.0, 1.0, 1.4, 0.01, 4,
+                                           i0=dec.i0 + r0, ni=nr))
+        else:
+            rows = (np.arange(dec.i0 + r0, dec.i0 + r0 + nr) - ng) % n
+            st.upload_rows(r0, tile_cols[rows])
+    pol = DtPolicy(tmax=0.1 if tile is None else 1.0e9)
+    for _ in range(warmup):
         slab.step(pol, 0.8)
     ctx.sync()
     dist.barrier()
     ctx.prof_enable(True)
     ctx.timer_start()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         slab.step(pol, 0.8)
     ctx.sync()
     t1 = time.perf_counter()
@@ -135,9 +218,26 @@ def bench_sedov(args, dist, ctx, device, defaults):
     dist.barrier()
     elapsed = dist.max(t1 - t0)
     res = {"elapsed": elapsed, "cells": float(nx) * ny, "prof": prof, "event_ms": ev_ms,
-           "t": pol.t, "dt": pol.dt_old, "local_cells": float(dec.nx_local) * ny}
+           "t": pol.t, "dt": pol.dt_old, "local_cells": float(dec.nx_local) * ny, "steps": steps}
     del slab, st
     return res
+
+
+def sedov_leg(r, defaults, nx, extra=None):
+    """summary of a secondary Sedov measurement for the `also` block"""
+    upd = r["prof"]
+    tot_ms = sum(ms for (_, ms) in upd.values()) / r["steps"]
+    gbs = SEDOV_BYTES_PER_CELL * r["local_cells"] / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0
+    out = {"value": r["cells"] * r["steps"] / r["elapsed"], "unit": "cell-updates/s",
+           "ms_per_step": r["elapsed"] / r["steps"] * 1e3, "steps": r["steps"],
+           "timed_seconds": r["elapsed"], "fast_math": defaults["fast_math"],
+           "kernel_set": defaults["kernel_set"],
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": gbs / HBM_PEAK_GBS,
+                        "kernels": {k: {"launches": n, "avg_ms": ms / n} for k, (n, ms) in upd.items()}}}
+    if extra:
+        out.update(extra)
+    return out
 
 
 def bench_advection(ctx, device, nx=2048, steps=100, warmup=10):
@@ -258,6 +358,15 @@ def cpu_baseline_sedov(sample_nx, max_seconds=25.0):
     el = time.perf_counter() - t0
     return {"value": sample_nx * sample_nx * n / el, "unit": "cell-updates/s",
             "cores": 1, "kind": "port",
+            # the reference's own time next to the port.  numba is not
+            # installable here, so what can be timed of the reference itself is its
+            # NumPy stages with the njit kernels stubbed out: a LOWER bound on its step
+            # time, measured once in the survey container (1 core, 2.1 GHz Xeon), carried
+            # here as a labelled constant -- not re-measured on this host
+            "reference_numpy_stages_only": {
+                "value_upper_bound": [0.55e6, 0.36e6, 0.26e6], "at_nx": [512, 1024, 2048],
+                "unit": "cell-updates/s", "source": "SURVEY.md 6 (compressible step, NumPy-only "
+                "stages, njit kernels stubbed): real reference <= these rates"},
             "sample": f"oracle/pyro_oracle.c (gcc -O2, 1 thread), compressible sedov "
                       f"{sample_nx}x{sample_nx}, {n} steps from t=0, {el:.1f} s; host has "
                       f"{os.cpu_count()} cores; the reference itself is single-threaded "
@@ -271,18 +380,21 @@ def main():
     # all ranks of this bench live on ONE node: let RCCL's bootstrap use the
     # loopback interface unless the caller chose one
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return self_spawn(args)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if "RANK" not in os.environ and args.gpus > 1:
-            sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run "
-                     "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
-                     "--master-port P bench.py --gpus N ...")
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dist = Dist(world)
     from pyro2_amd import device
     ndev = device.device_count()
-    dist.oversubscribed = world > 1 and dist.local_rank >= ndev
+    dist.oversubscribed = world > 1 and world > ndev
+    if dist.oversubscribed and dist.rank == 0:
+        print(f"[bench] WARNING: --gpus {world} on a box with {ndev} GPU(s): ranks share GPUs; "
+              "this run checks the multi-rank path, its number is NOT a scaling result "
+              "(flagged as config.oversubscribed)", file=sys.stderr)
     # one rank per GPU; several ranks on one GPU only happens when debugging
     # the launcher on a smaller box and is flagged in the output
     ctx = device.Context(dist.local_rank % ndev)
@@ -309,9 +421,10 @@ def main():
             print(f"[bench rank {dist.rank}] WARNING: RCCL unavailable ({dist.comm_note}); "
                   "halo exchange staged through the host over gloo", file=sys.stderr)
     # default: the contracted / reciprocal-division build, parity-tested to the
-    # north_star tolerance (1e-10); --fast-math 0 times the bit-faithful build
+    # north_star tolerance (1e-10); --fast-math 0 times the bit-faithful build.
+    # kernel_set -1: the library picks (row-marching wavefront kernel from 2048^2 on)
     defaults = {"fast_math": 1 if args.fast_math is None else args.fast_math,
-                "kernel_set": 1 if args.kernel_set is None else args.kernel_set}
+                "kernel_set": -1 if args.kernel_set is None else args.kernel_set}
     try:
         import torch
         if torch.cuda.is_available():
@@ -334,11 +447,13 @@ def main():
                                   else "HOST-STAGED halo exchange (RCCL init failed)"),
                    "parallelism": f"slab{world}",
                    "halo": dist.comm_kind if world > 1 else "none", "fast_math": defaults["fast_math"],
-                   "kernel_set": defaults["kernel_set"], "sim_time": r["t"]},
+                   "kernel_set": defaults["kernel_set"], "sim_time": r["t"],
+                   "state": "steps %d-%d from t = 0 (blast radius << grid: > 99 %% of the cells are "
+                            "ambient gas; see also.sedov_developed)" % (args.warmup, args.warmup + args.steps)},
     }
     if dist.comm_note:
         out["config"]["halo_note"] = dist.comm_note
-    if dist.max(1.0 if dist.oversubscribed else 0.0) > 0.0:
+    if dist.oversubscribed:
         out["config"]["oversubscribed"] = "several ranks share one GPU (debug run, not a result)"
     if dist.rank == 0:
         # roofline of the update kernels: algorithmic bytes of ONE rank's slab
@@ -348,6 +463,7 @@ def main():
         tot_ms = sum(ms for (_, ms) in upd.values()) / args.steps
         dom = max(upd, key=lambda k: upd[k][1]) if upd else None
         gbs = SEDOV_BYTES_PER_CELL * r["local_cells"] / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0
+        cells_per_s_kernel = r["local_cells"] / (tot_ms * 1e-3) if tot_ms else 0.0
         out["roofline"] = {
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": gbs / HBM_PEAK_GBS, "traffic": None,
@@ -357,31 +473,66 @@ def main():
             "kernels": {k: {"launches": n, "avg_ms": ms / n} for k, (n, ms) in upd.items()},
             "stream_event_ms_per_step": r["event_ms"] / args.steps,
         }
-        # traffic: fabric bytes per launch from the committed rocprofv3 PMC
+        # the roof that binds this kernel is the FP64 vector unit, not HBM
+        # (DESIGN.md 3): arithmetic minimum x cell rate against the FMA peak
+        out["roofline_fp64"] = {
+            "bound": "fp64_valu", "peak": FP64_PEAK_FLOPS / 1e12, "unit": "TFLOP/s",
+            "achieved": SEDOV_MIN_FLOPS_PER_CELL * cells_per_s_kernel / 1e12,
+            "frac": SEDOV_MIN_FLOPS_PER_CELL * cells_per_s_kernel / FP64_PEAK_FLOPS,
+            "flops_per_cell_update": SEDOV_MIN_FLOPS_PER_CELL,
+            "basis": "arithmetic minimum of one CTU + 4 x HLLC cell update (DESIGN.md 3, FMA = 2 "
+                     "flop) x cell rate of the update kernel; the kernel is mostly non-FMA, so "
+                     "the instruction-issue figures below are the tighter statement"}
+        # traffic + VALU instruction counts: from the committed rocprofv3 PMC
         # passes of this same default command (profiles/traffic.json, written by
-        # tools/gpu_round.sh + tools/make_traffic.py), scaled to this rank's
-        # cells; null for other kernel sets
+        # tools/gpu_round.sh + tools/make_traffic.py), scaled to this rank's cells
         tr = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tr) and defaults["kernel_set"] == 1:
+        if os.path.exists(tr):
             try:
                 t = json.load(open(tr))[f"fast_math_{defaults['fast_math']}"]
-                out["roofline"]["traffic"] = t["bytes_per_cell_update"] * r["local_cells"]
-                out["roofline"]["traffic_source"] = "profiles/traffic.json: " + t["measured_at"]
-                # the binding roof of this kernel is FP64 VALU issue, not HBM
-                # (DESIGN.md 3): report it next to the HBM roofline
-                out["roofline"]["valu"] = {
-                    "valu_insts_per_wave": t["valu_insts_per_wave"],
-                    "valu_busy_frac_of_kernel_time": t["valu_busy_ms"] / t["kernel_ms"],
-                    "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU, same profile"}
+                if t.get("kernel") == dom:
+                    out["roofline"]["traffic"] = t["bytes_per_cell_update"] * r["local_cells"]
+                    out["roofline"]["traffic_source"] = "profiles/traffic.json: " + t["measured_at"]
+                    ipc = t["valu_insts_per_cell_update"]        # lane-instructions per cell update
+                    out["roofline_fp64"]["valu_issue"] = {
+                        "valu_lane_insts_per_cell_update": ipc,
+                        "executed_flops_per_cell_update": t.get("flops_per_cell_update"),
+                        "achieved_wave_insts_per_s": ipc / 64.0 * cells_per_s_kernel,
+                        "peak_wave_insts_per_s": VALU_ISSUE_PEAK,
+                        "frac": ipc / 64.0 * cells_per_s_kernel / VALU_ISSUE_PEAK,
+                        "valu_busy_frac_of_kernel_time": t["valu_busy_ms"] / t["kernel_ms"],
+                        "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU of the same kernel, " + t["measured_at"]}
             except Exception:
                 pass
         if world == 1:
+            also = {}
+            if not args.no_also:
+                # the headline workload in the other build
+                d2 = dict(defaults, fast_math=1 - defaults["fast_math"])
+                r2 = bench_sedov(args, dist, ctx, device, d2, steps=max(5, args.steps // 2), warmup=2)
+                also["sedov_exact" if d2["fast_math"] == 0 else "sedov_fast"] = sedov_leg(r2, d2, args.nx)
+            if not args.no_developed and not args.no_also:
+                tile, frac, nst = developed_tile(ctx, device)
+                info = {"workload": f"compressible sedov {args.nx}x{args.nx}, DEVELOPED flow: a 1024x1024 "
+                                    f"Sedov blast at t = 0.1 ({nst} steps on this GPU) tiled over the grid",
+                        "shocked_cell_fraction": frac}
+                rd = bench_sedov(args, dist, ctx, device, defaults, steps=args.developed_steps,
+                                 warmup=5, tile=tile)
+                also["sedov_developed"] = sedov_leg(rd, defaults, args.nx, info)
+                also["sedov_developed"]["ratio_to_headline"] = also["sedov_developed"]["value"] / value
+                d2 = dict(defaults, fast_math=1 - defaults["fast_math"])
+                rd2 = bench_sedov(args, dist, ctx, device, d2, steps=max(20, args.developed_steps // 5),
+                                  warmup=3, tile=tile)
+                also["sedov_developed_exact" if d2["fast_math"] == 0 else "sedov_developed_fast"] = \
+                    sedov_leg(rd2, d2, args.nx, info)
+                del tile
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_sedov(args.cpu_sample_nx)
             if not args.no_also:
-                out["also"] = {"advection": bench_advection(ctx, device),
-                               "multigrid": bench_mg(ctx, device),
-                               "incompressible": bench_incompressible(ctx, device)}
+                also.update({"advection": bench_advection(ctx, device),
+                             "multigrid": bench_mg(ctx, device),
+                             "incompressible": bench_incompressible(ctx, device)})
+                out["also"] = also
         print(json.dumps(out), flush=True)
     dist.barrier()
 

@@ -175,7 +175,8 @@ typedef struct {
     /* 0 = bit-faithful arithmetic (no FMA contraction, true divisions);
        1 = contracted / reciprocal arithmetic, parity-tested to 1e-10      */
     int fast_math;
-    /* kernel set: 0 = staged kernels with global intermediates (debuggable,
+    /* kernel set: -1 = chosen by the library from the grid size (2 from
+       2048^2 cells on, 1 below); 0 = staged kernels with global intermediates (debuggable,
        supports pyrohip_comp_stage_dump); 1 = one fused kernel on 2-d LDS
        tiles (best below ~1024^2); 2 = one fused kernel of autonomous
        wavefronts marching along the rows (x windows in registers, y exchange

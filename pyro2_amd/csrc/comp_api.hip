@@ -29,6 +29,14 @@ int comp_dt_sph(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 
 using namespace pyro;
 
+// kernel_set -1: the row-marching wavefront kernel needs >= ~2 wavefronts per SIMD
+// of 56 columns x >= 32 rows to fill the chip; measured crossover with the tile
+// kernel at 2048^2 (profiles/r02_kernel_sets_by_size.txt)
+static bool wave_kernel_pays(const Geom &g)
+{
+    return (double)g.nx * (double)g.ny >= 2048.0 * 2048.0;
+}
+
 static int check_comp(pyrohip_state *s, const pyrohip_comp_params *p)
 {
     PYRO_REQUIRE(s && p, "NULL argument");
@@ -63,7 +71,7 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
 {
     PYRO_TRY(check_comp(s, p));
     PYRO_REQUIRE(dt > 0.0, "dt must be positive");
-    PYRO_REQUIRE(p->kernel_set >= 0 && p->kernel_set <= 2, "kernel_set must be 0, 1 or 2");
+    PYRO_REQUIRE(p->kernel_set >= -1 && p->kernel_set <= 2, "kernel_set must be -1 (automatic), 0, 1 or 2");
     PYRO_REQUIRE(p->riemann >= 0 && p->riemann <= 2, "riemann must be 0 (HLLC), 1 (CGF) or 2 (HLLC_lm)");
     int rc;
     if (s->sph) {
@@ -72,9 +80,9 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
         PYRO_REQUIRE(!s->user_bc && !s->ramp_bc && !s->heat,
                      "hse / ambient / ramp boundaries and heating are Cartesian-only");
         rc = p->fast_math ? fastm::comp_step_sph(s, p, dt) : exact::comp_step_sph(s, p, dt);
-    } else if (p->kernel_set == 2)
+    } else if (p->kernel_set == 2 || (p->kernel_set == -1 && wave_kernel_pays(s->g)))
         rc = p->fast_math ? fastm::comp_step_wave(s, p, dt) : exact::comp_step_wave(s, p, dt);
-    else if (p->kernel_set == 1)
+    else if (p->kernel_set == 1 || p->kernel_set == -1)
         rc = p->fast_math ? fastm::comp_step_fused(s, p, dt) : exact::comp_step_fused(s, p, dt);
     else
         rc = p->fast_math ? fastm::comp_step_staged(s, p, dt) : exact::comp_step_staged(s, p, dt);

@@ -1,43 +1,42 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from the per-kernel PMC summaries written by
-tools/summarize_rocprof.py.  usage: make_traffic.py <nx> <pmc_fm1.json> <pmc_fm0.json> <stats_fm1.csv> <stats_fm0.csv>"""
-import csv
+"""profiles/traffic.json from two tools/pmc_step.sh summaries (TRAFFIC=1) of the default
+compressible step: usage: make_traffic.py <pmc_fm1_summary.json> <pmc_fm0_summary.json>"""
 import json
 import sys
 
 
-def kernel_ms(stats_csv, name):
-    for r in csv.DictReader(open(stats_csv)):
-        if name in r["Name"]:
-            return float(r["AverageNs"]) * 1e-6
-    return None
+def entry(d):
+    nx = d["config"]["nx"]
+    cells = float(nx) * nx
+    rd = d.get("FETCH_SIZE", 0) * 1024 * 2       # gfx950: FETCH_SIZE reports half of coalesced reads
+    wr = d.get("WRITE_SIZE", 0) * 1024
+    # one FP64 wave instruction occupies a SIMD for 4 cycles (16 lanes);
+    # SQ_ACTIVE_INST_VALU counts those quad-cycles summed over the SIMDs
+    valu_ms = d["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * 2.4e9) * 1e3
+    kernel_ms = d["GRBM_GUI_ACTIVE"] / 8 / 2.4e9 * 1e3   # 8 XCDs count, 2.4 GHz
+    flops = (d.get("SQ_INSTS_VALU_ADD_F64", 0) + d.get("SQ_INSTS_VALU_MUL_F64", 0) +
+             2 * d.get("SQ_INSTS_VALU_FMA_F64", 0) + d.get("SQ_INSTS_VALU_TRANS_F64", 0)) * 64
+    return {
+        "kernel": d["config"]["kernel"],
+        "measured_at": f"sedov {nx}x{nx} (bench.py default state), 1 MI355X, rocprofv3 --pmc, "
+                       "separate passes per counter group (tools/pmc_step.sh)",
+        "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+        "bytes_per_cell_update": (rd + wr) / cells,
+        "note": "FETCH_SIZE doubled (gfx950 reports half of coalesced read bytes; calibrated in "
+                "round 1 on k_prim: 4 planes read, 2 reported), WRITE_SIZE as reported; "
+                "Infinity-Cache hits are counted, so this is fabric traffic >= HBM traffic",
+        "waves": d["SQ_WAVES"],
+        "valu_insts_per_wave": d["SQ_INSTS_VALU"] / d["SQ_WAVES"],
+        "valu_insts_per_cell_update": d["SQ_INSTS_VALU"] * 64 / cells,
+        "flops_per_cell_update": flops / cells,
+        "trans_f64_per_cell_update": d.get("SQ_INSTS_VALU_TRANS_F64", 0) * 64 / cells,
+        "valu_busy_ms": valu_ms, "kernel_ms": kernel_ms,
+    }
 
 
 def main():
-    nx = int(sys.argv[1])
-    out = {}
-    for key, pmc, stats in (("fast_math_1", sys.argv[2], sys.argv[4]),
-                            ("fast_math_0", sys.argv[3], sys.argv[5])):
-        d = json.load(open(pmc))
-        k = next(n for n in d if "k_ctu_fused" in n)
-        e = d[k]
-        rd, wr = e["hbm_read_bytes_per_launch"], e["hbm_write_bytes_per_launch"]
-        ms = kernel_ms(stats, "k_ctu_fused")
-        # fp64 VALU: one wave instruction occupies a SIMD for 4 cycles (16 lanes);
-        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs
-        valu_ms = e["SQ_ACTIVE_INST_VALU_per_launch"] * 4 / (1024 * 2.4e9) * 1e3
-        out[key] = {
-            "kernel": "k_ctu_fused",
-            "measured_at": f"sedov {nx}x{nx}, 1 MI355X, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                           "(separate passes)",
-            "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
-            "bytes_per_cell_update": (rd + wr) / (nx * nx),
-            "note": "FETCH_SIZE doubled (gfx950 reports half of coalesced read bytes; calibrated "
-                    "on k_prim: 4 planes read, 2 reported), WRITE_SIZE as reported; "
-                    "Infinity-Cache hits are counted, so this is fabric traffic >= HBM traffic",
-            "valu_insts_per_wave": e["SQ_INSTS_VALU_per_launch"] / e["SQ_WAVES_per_launch"],
-            "valu_busy_ms": valu_ms, "kernel_ms": ms,
-        }
+    out = {"fast_math_1": entry(json.load(open(sys.argv[1]))),
+           "fast_math_0": entry(json.load(open(sys.argv[2])))}
     json.dump(out, open("profiles/traffic.json", "w"), indent=1)
     print(json.dumps(out, indent=1))
 

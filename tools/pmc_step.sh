@@ -3,7 +3,7 @@
 #   NX=8192 FM=1 KS=2 TAG=pmc bash tools/pmc_step.sh
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
 NX=${NX:-8192}; FM=${FM:-1}; KS=${KS:-2}; TAG=${TAG:-pmc}
-KN=$(case "$KS" in 2) echo k_ctu_wave;; *) echo k_ctu_fused;; esac)
+KN=$(case "$KS" in 1) echo k_ctu_fused;; *) echo k_ctu_wave;; esac)
 B="python $R/bench.py --nx $NX --steps 5 --warmup 2 --no-also --no-cpu-baseline --fast-math $FM --kernel-set $KS"
 n=0
 for grp in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE" \
