@@ -6,6 +6,17 @@ sums per variable and the dt sequence are kept (tests/golden/
 comp_sedov_4096_samples.npz).  TEST INFRASTRUCTURE ONLY.
 
     python oracle/gen_fullsize.py        # ~10 min on one core
+
+The bench's own size, Sedov 16384^2 (BASELINE config 5 on one GPU), is pinned
+through a WINDOW: after 25 steps the blast (r_init = 0.01 = 164 cells) plus the
+4-cells-per-step domain of dependence stays inside the central 1024 x 1024
+cells, every cell outside is still the untouched ambient state, and the oracle
+on that window -- same dx, same cell-centre coordinates (all dyadic, so the
+window's xmin + (i + 1/2) dx is the full grid's value bit for bit), outflow
+boundaries in ambient gas -- computes exactly what it would compute on the full
+grid (which needs 40 min and 60 GB).  tests/golden/comp_sedov_16384_window.npz:
+
+    python oracle/gen_fullsize.py --window16384      # ~15 s
 """
 import os
 import sys
@@ -37,5 +48,37 @@ def main():
     print("wrote", out, os.path.getsize(out) // 1024, "KiB")
 
 
+def window16384():
+    NXF, W, NST = 16384, 1024, 25
+    lo = (NXF - W) // 2                      # first full-grid interior index of the window
+    x0, x1 = lo / NXF, (lo + W) / NXF
+    ic, meta, bcs = sedov_ic(W, xmin=x0, xmax=x1, ymin=x0, ymax=x1)
+    assert meta[3] == 1.0 / NXF and meta[4] == 1.0 / NXF
+    # the window's state IS the full grid's: compare a band of rows with the slab generator
+    from pyro2_amd.compressible.problems.sedov import sedov_state
+    full = sedov_state(NXF, NXF, 4, 0.0, 1.0, 0.0, 1.0, 1.4, 0.01, 4, i0=lo + 500, ni=32)
+    assert np.array_equal(full[:, lo:lo + W + 8], ic[500:532]), "window IC differs from the full grid's"
+    t0 = time.time()
+    U, dts, t = oracle_comp_run(ic, meta, bcs, 0.1, NST)
+    print("oracle window", W, NST, "steps:", time.time() - t0, "s")
+    I = U[4:-4, 4:-4]
+    amb = ic[4, 4].copy()                    # the ambient state of the initial condition
+    touched = np.argwhere(np.any(I != amb, axis=2))
+    r = np.abs(touched - (W - 1) / 2.0).max()
+    print("disturbed half-width: %.1f cells of %d" % (r, W // 2))
+    assert r < W // 2 - 32, "the disturbance reaches the window boundary"
+    step = W // 64
+    out = os.path.join(ROOT, "tests", "golden", "comp_sedov_16384_window.npz")
+    np.savez_compressed(out, samples=I[::step, ::step].copy(), row_sums=I.sum(axis=1),
+                        col_sums=I.sum(axis=0), dts=dts, t=np.array(t), nsteps=np.array(NST),
+                        umax=np.abs(I).max(axis=(0, 1)), lo=np.array(lo), width=np.array(W),
+                        # a dense patch across the shock for the element-wise comparison
+                        patch=I[W // 2 - 8:W // 2 + 8, W // 2:W // 2 + 256].copy())
+    print("wrote", out, os.path.getsize(out) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    main()
+    if "--window16384" in sys.argv:
+        window16384()
+    else:
+        main()

@@ -64,6 +64,29 @@ def max_rel_err(a, b):
     return float(np.abs(a - b).max() / scale)
 
 
+def elementwise_err(a, b, floor):
+    """max over the ELEMENTS of |a - b| / (|b| + floor): an element-wise rtol
+    with atol = rtol * floor, floor = the local scale of that variable (e.g. its
+    ambient value), so that cells eight decades below the array maximum are
+    held to the same relative tolerance as the peak (the array-wide
+    max_rel_err above lets an O(1e-2) relative error in an ambient cell pass)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float((np.abs(a - b) / (np.abs(b) + floor)).max())
+
+
+def comp_floors(ref, gamma=1.4):
+    """per-variable local scales of a compressible state (density, energy,
+    x-momentum, y-momentum): the smallest density / energy magnitudes of the
+    reference (the ambient gas) and, for the momenta, rho * c of that gas"""
+    r = np.asarray(ref)
+    rho = float(np.abs(r[..., 0]).min())
+    ener = float(np.abs(r[..., 1]).min())
+    # ambient sound speed from the smallest internal energy: p = (gamma - 1) rho e
+    c = float(np.sqrt(gamma * (gamma - 1.0) * ener / max(rho, 1e-300)))
+    return np.array([rho, ener, rho * c, rho * c])
+
+
 # ---------------------------------------------------------------------------
 # device backends.  "hip" = the product library on a real MI355X (marked gpu);
 # "emu" = the same kernel sources compiled for the host by tests/emu (so the

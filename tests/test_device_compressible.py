@@ -5,12 +5,33 @@ Tolerance: north_star asks 1e-10 rtol.  exact build (fast_math=0, no FMA
 contraction, reference operation order): bit-identical on the emulated
 backend, <= 1e-13 per step on the GPU (TOL_EXACT; the only expected source of
 difference is libm pow in the rare two-rarefaction branch).  fast build
-(fast_math=1): <= 1e-10 (TOL_FAST).
+(fast_math=1): <= 1e-10 (TOL_FAST), ELEMENT-WISE: |a - b| <= 1e-10 (|b| + floor_n)
+with floor_n the ambient scale of variable n (conftest.elementwise_err) -- the
+array-wide max_rel_err is only used for the bit-faithful build, whose errors
+are at round-off.
+
+The fast build's reciprocal / rsqrt intrinsics and FMA contraction exist on the
+GPU only (hydro.h `#if PYRO_FAST && !defined(PYRO_EMU)`): the CPU suite runs the
+fast build's CODE PATHS with true divisions (test_comp_fast_path_logic), every
+test of its ARITHMETIC is marked gpu.
 """
+
+
+def assert_state_close(U, ref, tol, fast, what=""):
+    """bit-faithful build: array-wide relative error; fast build: element-wise"""
+    if fast:
+        fl = comp_floors(ref)
+        for n in range(4):
+            e = elementwise_err(U[..., n], ref[..., n], fl[n])
+            assert e <= tol, (what, "element-wise", n, e)
+    else:
+        for n in range(4):
+            assert max_rel_err(U[..., n], ref[..., n]) <= tol, (what, n)
+
 import numpy as np
 import pytest
 
-from conftest import max_rel_err
+from conftest import comp_floors, elementwise_err, max_rel_err
 from helpers import DtPolicy, meta_to_params
 from oracle import orc
 from pyro2_amd import _lib, device
@@ -206,6 +227,10 @@ def test_comp_reference_regression_quad(hip, golden, fast, kset):
     for n in range(4):
         e = max_rel_err(U[4:-4, 4:-4, n], g["gold"][..., n])
         assert e < (1e-11 if not fast else TOL_FAST), (n, e)
+        if fast:    # element-wise, floor = the variable's median magnitude (measured: 5e-13)
+            ref = g["gold"][..., n]
+            fl = float(np.median(np.abs(ref))) or float(np.abs(ref).max())
+            assert elementwise_err(U[4:-4, 4:-4, n], ref, fl) <= TOL_FAST, n
 
 
 @pytest.mark.gpu
@@ -222,6 +247,11 @@ def test_comp_reference_regression_rt(hip, golden, fast, kset):
     scale = np.abs(g["gold"]).max(axis=(0, 1))
     err = np.abs(U[4:-4, 4:-4] - g["gold"]).max(axis=(0, 1)) / scale
     assert err.max() < (1e-11 if not fast else TOL_FAST), err
+    if fast:    # element-wise after 945 steps of an unstable flow (measured: 2.3e-11)
+        for n in range(4):
+            ref = g["gold"][..., n]
+            fl = float(np.median(np.abs(ref))) or float(np.abs(ref).max())
+            assert elementwise_err(U[4:-4, 4:-4, n], ref, fl) <= TOL_FAST, n
 
 
 def test_comp_fast_path_logic(dev, golden, kset=2):
@@ -289,10 +319,56 @@ def test_comp_sedov_512_vs_oracle(hip, fast, kset):
     U, dts, _ = device_comp_run(hip, ic, meta, bcs, 0.1, 30, fast_math=fast, **kset_kw(kset))
     tol = TOL_FAST if fast else 1e-12
     assert max_rel_err(dts, dto) <= tol
-    for n in range(4):
-        assert max_rel_err(U[4:-4, 4:-4, n], Uo[4:-4, 4:-4, n]) <= tol
+    assert_state_close(U[4:-4, 4:-4], Uo[4:-4, 4:-4], tol, fast, "sedov 512")
     # conservation of mass and energy away from the (outflow) boundary
     assert abs(U[4:-4, 4:-4, 0].sum() - ic[4:-4, 4:-4, 0].sum()) < 1e-9 * nx * nx
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fast", [0, 1])
+def test_comp_sedov_16384_vs_oracle_window(hip, golden, fast):
+    """the bench's own workload and size (Sedov 16384^2, 25 steps from t = 0,
+    default kernel set) against the C oracle.  The oracle ran the central
+    1024^2 window with the full grid's cell coordinates (oracle/gen_fullsize.py
+    --window16384): the disturbance (half-width 177 cells after 25 steps) never
+    reaches the window's edge, so window == full grid there, and every cell
+    outside must still hold the ambient state bit for bit.  dt sequence, a 64x64
+    lattice, row / column sums of the window and a dense 16x256 patch across the
+    shock; fast build element-wise (1e-10), bit-faithful build 1e-12."""
+    from pyro2_amd.compressible.problems.sedov import sedov_state
+    g = golden("comp_sedov_16384_window")
+    nx, ng, nsteps = 16384, 4, int(g["nsteps"])
+    lo, W = int(g["lo"]), int(g["width"])
+    s = comp_state(hip, nx, nx, ["outflow"] * 4)
+    for r0 in range(0, nx + 2 * ng, 512):
+        nr = min(512, nx + 2 * ng - r0)
+        s.upload_rows(r0, sedov_state(nx, nx, ng, 0.0, 1.0, 0.0, 1.0, 1.4, 0.01, 4, i0=r0, ni=nr))
+    P = device.make_comp_params(1.0 / nx, 1.0 / nx, fast_math=fast, kernel_set=-1)
+    pol = DtPolicy(0.1)
+    dts = []
+    for _ in range(nsteps):
+        s.fill_bc()
+        dt = pol(s.comp_dt(P, 0.8))
+        s.comp_step(P, dt)
+        pol.advance(dt)
+        dts.append(dt)
+    tol = TOL_FAST if fast else 1e-12
+    assert max_rel_err(np.array(dts), g["dts"]) <= tol
+    I = s.download_rows(ng + lo, W)[:, ng + lo:ng + lo + W]
+    step = W // 64
+    assert_state_close(I[::step, ::step], g["samples"], tol, fast, "lattice")
+    assert_state_close(I[W // 2 - 8:W // 2 + 8, W // 2:W // 2 + 256], g["patch"], tol, fast, "patch")
+    umax = g["umax"]
+    for n in range(4):
+        for ax, key in ((1, "row_sums"), (0, "col_sums")):
+            ref = g[key][:, n]
+            assert np.abs(I[..., n].sum(axis=ax) - ref).max() <= tol * max(np.abs(ref).max(), W * umax[n] * 1e-3)
+    # outside the window: untouched ambient gas (rows next to the window and far away)
+    amb = sedov_state(nx, nx, ng, 0.0, 1.0, 0.0, 1.0, 1.4, 0.01, 4, i0=0, ni=1)[0, 0]
+    for r in (ng, ng + lo - 1, ng + lo + W, ng + nx - 1):
+        row = s.download_rows(r, 1)[0, ng:-ng]
+        assert np.array_equal(row, np.broadcast_to(amb, row.shape)), r
+    assert np.array_equal(I[:, 0], np.broadcast_to(amb, I[:, 0].shape))
 
 
 @pytest.mark.gpu
@@ -339,14 +415,14 @@ def test_comp_sedov_4096_vs_oracle_samples(hip, golden, fast):
     g = golden("comp_sedov_4096_samples")
     nx, nsteps = 4096, int(g["nsteps"])
     ic, meta, bcs = sedov_ic(nx)
-    U, dts, t = device_comp_run(hip, ic, meta, bcs, 0.1, nsteps, fast_math=fast, kernel_set=1)
+    U, dts, t = device_comp_run(hip, ic, meta, bcs, 0.1, nsteps, fast_math=fast, kernel_set=-1)
     tol = TOL_FAST if fast else 1e-12
     assert max_rel_err(dts, g["dts"]) <= tol
     I = U[4:-4, 4:-4]
     step = nx // 64
     umax = g["umax"]
+    assert_state_close(I[::step, ::step], g["samples"], tol, fast, "lattice")
     for n in range(4):
-        assert np.abs(I[::step, ::step, n] - g["samples"][..., n]).max() <= tol * umax[n]
         for ax, key in ((1, "row_sums"), (0, "col_sums")):
             ref = g[key][:, n]
             assert np.abs(I[..., n].sum(axis=ax) - ref).max() <= tol * max(np.abs(ref).max(), nx * umax[n] * 1e-3)
