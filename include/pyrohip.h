@@ -154,6 +154,14 @@ int pyrohip_state_minmax(pyrohip_state *s, int n, int buf, double *vmin,
         (:4-43) and reconstruction.limit (reconstruction.py:9-120) fused ---- */
 int pyrohip_adv_step(pyrohip_state *s, int n, double dx, double dy, double u,
                      double v, double dt, int limiter);
+/* the same with the ghost fill of variable n (ArrayIndexer.fill_ghost,
+   array_indexer.py:150-274; outflow / reflect-even / reflect-odd / periodic
+   sides only) folded into the step when fill != 0: ONE launch does what
+   pyrohip_fill_bc(s, n) + pyrohip_adv_step do, the ghost cells of the result
+   hold the filled values of the old time level like after the in-place update
+   of the reference.  fill = 0: ghost cells are used as they are. */
+int pyrohip_adv_step_fill(pyrohip_state *s, int n, double dx, double dy, double u,
+                          double v, double dt, int limiter, int fill);
 
 /* ---- compressible ---------------------------------------------------- */
 /* conserved order: density(0) energy(1) x-momentum(2) y-momentum(3)

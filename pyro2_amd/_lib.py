@@ -114,6 +114,8 @@ _PROTOS = {
     "pyrohip_state_minmax": [_VP, C.c_int, C.c_int, _DP, _DP],
     "pyrohip_adv_step": [_VP, C.c_int, C.c_double, C.c_double, C.c_double,
                          C.c_double, C.c_double, C.c_int],
+    "pyrohip_adv_step_fill": [_VP, C.c_int, C.c_double, C.c_double, C.c_double,
+                              C.c_double, C.c_double, C.c_int, C.c_int],
     "pyrohip_comp_dt": [_VP, C.POINTER(CompParams), C.c_double, _DP],
     "pyrohip_comp_step": [_VP, C.POINTER(CompParams), C.c_double],
     "pyrohip_comp_stage_dump": [_VP, C.c_int, _DP],

@@ -14,6 +14,9 @@ class Simulation(NullSimulation):
         bc = bc_setup(self.rp)[0]
         my_data.register_var("density", bc)
         my_data.create()
+        # the step kernel does the ghost fill itself (index remap at load):
+        # fill_BC_all() of the driver is deferred into it, one launch per step
+        my_data.lazy_fill = True
         self.cc_data = my_data
         self.setup_particles(bc)         # advection/simulation.py:30-33
         self.problem_func(self.cc_data, self.rp)
@@ -34,11 +37,12 @@ class Simulation(NullSimulation):
         tm = self.tc.timer("evolve")
         tm.begin()
         g = self.cc_data.grid
-        st = self.cc_data.device_state()
+        st = self.cc_data.device_state(fuse_fill=True)
         st.adv_step(self.cc_data.names.index("density"), g.dx, g.dy,
                     float(self.rp.get_param("advection.u")),
                     float(self.rp.get_param("advection.v")), float(self.dt),
-                    int(self.rp.get_param("advection.limiter")))
+                    int(self.rp.get_param("advection.limiter")),
+                    fill=self.cc_data.take_pending_fill())
         self.cc_data.device_modified()
         if self.particles is not None:   # constant velocity field, advection/simulation.py:82-90
             self.advance_particles(g.scratch_array() + self.rp.get_param("advection.u"),

@@ -1,40 +1,39 @@
-// Linear advection, 2nd-order unsplit CTU update, one fused LDS-tiled kernel.
+// Linear advection, 2nd-order unsplit CTU update: ONE launch per time step.
 //
 // Replaces (reference file:line)
 //   pyro/advection/simulation.py:56-94        Simulation.evolve
 //   pyro/advection/advective_fluxes.py:1-92   unsplit_fluxes
 //   pyro/advection/interface.py:4-43          linear_interface
 //   pyro/mesh/reconstruction.py:9-120         limit / limit2 / limit4
+//   pyro/mesh/array_indexer.py:150-274        fill_ghost (when `fill` is set)
 //
-// Roofline: HBM bound, 16 B per cell update (read a, write a).  The tile
-// (TI x TJ interior + 3-cell apron) is staged once in LDS; interface states
-// a_x / a_y are built in LDS; the conservative update reads them from LDS, so
-// every input cell is fetched from HBM once (aprons are L2 hits: tiles are
-// dealt to XCDs in contiguous bands).
+// Roofline: HBM bound, 16 B per cell update (read a, write a).
 //
-// The result is written to the state's second buffer (neighbouring tiles read
-// the old apron while we write), then the buffers are swapped.
+// Same design as the compressible row-marching kernel (comp_wave.hip): one
+// wavefront = 64 columns (lane = column j, 512-B row loads), the inner 56 are
+// updated; it walks down a strip of rows.  x direction (rows): a 5-row window of
+// a, limit2_x and the x interface states in registers, each computed once; y
+// direction: DPP lane rotation.  No LDS, no barrier.  Per cell: one limit2 and
+// one limit4 per direction (the tile kernel of round 1 evaluated limit2 three
+// times per face: ~165 VALU per cell, now ~75).
+//
+// Ghost cells.  With `fill` the boundary fill of the variable (outflow,
+// reflect-even / -odd, periodic) is folded into the loads: a ghost cell's value
+// is fetched from its interior source cell (index remap + sign), exactly the
+// value fill_ghost would have stored.  The kernel also writes the ghost frame of
+// the NEW buffer (the reference updates in place, so after a step the ghost
+// cells hold the values the fill at the start of the step gave them), which
+// removes the separate fill_x / fill_y / copy_frame launches: 4 launches -> 1.
 #include "common.h"
 #include "stencil.h"
 
 namespace pyro {
 
-#ifndef PYRO_ADV_TI
-#define PYRO_ADV_TI 16
+constexpr int AW_OUT = 56;        // columns a wavefront updates
+#ifndef PYRO_ADV_PF
+#define PYRO_ADV_PF 4
 #endif
-constexpr int ADV_TI = PYRO_ADV_TI;   // tile rows   (i, slow axis)
-constexpr int ADV_TJ = 64;   // tile columns (j, fast axis) = one wave
-constexpr int ADV_H = 3;     // apron
-constexpr int ADV_AW = ADV_TJ + 2 * ADV_H;       // 70
-constexpr int ADV_AH = ADV_TI + 2 * ADV_H;       // 22
-constexpr int ADV_XW = ADV_TJ + 2;               // a_x: j in [j0-1, j0+TJ]
-constexpr int ADV_XH = ADV_TI + 1;               //      i in [i0, i0+TI]
-constexpr int ADV_YW = ADV_TJ + 1;               // a_y: j in [j0, j0+TJ]
-constexpr int ADV_YH = ADV_TI + 2;               //      i in [i0-1, i0+TI]
-#ifndef PYRO_ADV_THREADS
-#define PYRO_ADV_THREADS 256
-#endif
-constexpr int ADV_THREADS = PYRO_ADV_THREADS;
+constexpr int ADV_PF = PYRO_ADV_PF;   // rows loaded ahead of their use
 
 struct AdvParams {
     double u, v, dt, dx, dy;
@@ -45,167 +44,198 @@ struct AdvParams {
     double cx, cy;          // u*dt/dx, v*dt/dy          interface.py:10-11
     double dtdx2, dtdy2;    // 0.5*dt/dx, 0.5*dt/dy      advective_fluxes.py:60-61
     double dtdx, dtdy;      // dt/dx, dt/dy              simulation.py:63-64
+    int ncb, L;             // column strips, rows per strip
+    int fill;               // fold the ghost fill into the loads
+    int bxl, bxr, byl, byr; // boundary types of the variable (fill)
 };
 
-// LIM: limiter (0 none, 1 MC2, 2 MC4); UNEG / VNEG: u < 0 / v < 0 (upwind side)
-//
-// Thread layout: 4 waves; wave w, lane l.  Every phase walks rows w, w+4, ...
-// with the lane as the column (no integer division, one LDS address add per
-// row); the few columns beyond 64 (apron of A, the two extra face columns of
-// a_x, the extra one of a_y) are a short second pass of a partial wave.
-template <int LIM, bool UNEG, bool VNEG>
-__global__ __launch_bounds__(ADV_THREADS) void k_adv_step(const double *__restrict__ ain,
-                                                          double *__restrict__ aout, Geom g,
-                                                          AdvParams P, int ntj, int ntiles)
+// lane l-1 / l+1 (rotation: the end lanes are apron, see comp_wave.hip)
+#if !defined(PYRO_EMU)
+template <int CTRL> __device__ __forceinline__ double adv_dpp(double v)
 {
-    static_assert(ADV_THREADS == 256 && ADV_TJ == 64, "4 waves, lane = column");
-    // rows padded to 4 * NR so that every wave stores all the rows it loaded
-    // (no predicate the compiler could sink a load under)
-    __shared__ double A[((ADV_AH + 3) / 4) * 4][ADV_AW];
-    __shared__ double AX[ADV_XH][ADV_XW];
-    __shared__ double AY[ADV_YH][ADV_YW];
-    const int tile = xcd_tile(blockIdx.x, ntiles);
-    const int i0 = g.ilo + (tile / ntj) * ADV_TI;
-    const int j0 = g.jlo + (tile % ntj) * ADV_TJ;
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double adv_m1(double v) { return adv_dpp<0x13C>(v); }   // wave_ror:1
+__device__ __forceinline__ double adv_p1(double v) { return adv_dpp<0x134>(v); }   // wave_rol:1
+#else
+__device__ __forceinline__ double adv_m1(double v) { return __shfl_up(v, 1, 64); }
+__device__ __forceinline__ double adv_p1(double v) { return __shfl_down(v, 1, 64); }
+#endif
+
+// Ghost fill as an index map (array_indexer.py:163-274 / k_fill_x, k_fill_y of
+// ctx.hip): the source of array index i is a * i + b with (a, b) per side --
+// outflow (0, edge), reflect (-1, mirror), periodic (1, shift); interior and
+// other boundary types map to themselves.  Branch-free, so that the row map in
+// the marching loop stays on the scalar unit.
+struct BcMap { int alo, blo, ahi, bhi; bool odd_lo, odd_hi; };
+__host__ __device__ inline BcMap bc_map(int lo, int hi, int ng, int bl, int br, bool fill)
+{
+    BcMap m{1, 0, 1, 0, false, false};
+    if (!fill) return m;
+    if (bl == PYROHIP_BC_OUTFLOW) { m.alo = 0; m.blo = lo; }
+    else if (bl == PYROHIP_BC_REFLECT_EVEN || bl == PYROHIP_BC_REFLECT_ODD) { m.alo = -1; m.blo = 2 * ng - 1; }
+    else if (bl == PYROHIP_BC_PERIODIC) { m.alo = 1; m.blo = hi - ng + 1; }
+    if (br == PYROHIP_BC_OUTFLOW) { m.ahi = 0; m.bhi = hi; }
+    else if (br == PYROHIP_BC_REFLECT_EVEN || br == PYROHIP_BC_REFLECT_ODD) { m.ahi = -1; m.bhi = 2 * hi + 1; }
+    else if (br == PYROHIP_BC_PERIODIC) { m.ahi = 1; m.bhi = ng - hi - 1; }
+    m.odd_lo = (bl == PYROHIP_BC_REFLECT_ODD);
+    m.odd_hi = (br == PYROHIP_BC_REFLECT_ODD);
+    return m;
+}
+__device__ __forceinline__ int bc_src(const BcMap &m, int i, int lo, int hi)
+{
+    return i < lo ? m.alo * i + m.blo : (i > hi ? m.ahi * i + m.bhi : i);
+}
+
+// limited slope from shared limit2 values (reconstruction.py:9-120)
+template <int LIM>
+__device__ __forceinline__ double adv_slope(double l2m, double l20, double l2p, double am1, double a0,
+                                            double ap1)
+{
+    if (LIM == 0) return 0.5 * (ap1 - am1);
+    if (LIM == 1) return l20;
+    const double dc = (2. / 3.) * (ap1 - am1 - 0.25 * (l2p + l2m));
+    const double dl = ap1 - a0;
+    const double dr = a0 - am1;
+    return mc_select(dc, dl, dr);
+}
+
+// LIM: limiter (0 none, 1 MC2, 2 MC4); UNEG / VNEG: u < 0 / v < 0 (upwind side)
+template <int LIM, bool UNEG, bool VNEG>
+__global__ __launch_bounds__(64) void k_adv_step(const double *__restrict__ ain,
+                                                 double *__restrict__ aout, Geom g, AdvParams P)
+{
+    const int l = threadIdx.x;
+    const int cb = blockIdx.x % P.ncb, sb = blockIdx.x / P.ncb;
+    const int i0 = g.ilo + sb * P.L;                       // strip rows [i0, i1)
+    const int i1 = (i0 + P.L < g.ihi + 1) ? i0 + P.L : g.ihi + 1;
+    const int j = g.jlo + cb * AW_OUT - 4 + l;             // this lane's column
+    const bool jvalid = (j < g.qy);
+    const bool jghost = jvalid && (j < g.jlo || j > g.jhi);
+    const bool jout = (j >= g.jlo && j <= g.jhi && l >= 4 && l <= 59);
+    const bool jown = jvalid && ((l >= 4 && l <= 59) || jghost);   // columns whose ghost cells we carry
     const int p = g.pitch;
-
-    // ---- phase 0: stage a (tile + apron) in LDS -------------------------
-    // Every load of the thread (up to 6 tile rows + 1 apron cell) is issued
-    // before the first LDS store: written as load/store loops, each iteration
-    // waited for its own load -- seven dependent HBM round trips per workgroup.
-    constexpr int NR = (ADV_AH + 3) / 4;          // rows per wave
-    double av[NR];
-#pragma unroll
-    for (int n = 0; n < NR; n++) {
-        // columns H .. H+63 (the tile's own, 512-byte aligned rows) by all lanes
-        int i = i0 - ADV_H + w + 4 * n, j = j0 + l;
-        i = (i < g.qx) ? i : g.qx - 1;   // partial tiles / rows beyond the apron: clamp (unused)
-        j = (j < g.qy) ? j : g.qy - 1;
-        av[n] = ain[(size_t)i * p + j];
-    }
-    // the 2 x H apron columns: ADV_AH rows x 6 columns, one cell per thread
-    static_assert(ADV_AH * 2 * ADV_H <= ADV_THREADS, "one apron cell per thread");
-    static_assert(ADV_THREADS <= 2 * ADV_AH * 2 * ADV_H, "apron cell index wraps once");
-    // threads beyond the apron cells repeat one of them (same value to the same
-    // LDS word): no predicate the compiler could sink the load under
-    const int at = (tid < ADV_AH * 2 * ADV_H) ? tid : tid - ADV_AH * 2 * ADV_H;
-    const int apr = at / (2 * ADV_H), apk = at - apr * (2 * ADV_H);
-    const int apc = (apk < ADV_H) ? apk : ADV_TJ + apk;          // 0..2, 67..69
-    double apv;
-    {
-        int i = i0 - ADV_H + apr, j = j0 - ADV_H + apc;
-        i = (i < g.qx) ? i : g.qx - 1;
-        j = (j < g.qy) ? j : g.qy - 1;
-        apv = ain[(size_t)i * p + j];
-    }
-#pragma unroll
-    for (int n = 0; n < NR; n++) {
-        A[w + 4 * n][ADV_H + l] = av[n];
-    }
-    A[apr][apc] = apv;
-    __syncthreads();
-
+    // row / column maps of the ghost fill
+    const BcMap mr = bc_map(g.ilo, g.ihi, g.ng, P.bxl, P.bxr, P.fill != 0);
+    const BcMap mc = bc_map(g.jlo, g.jhi, g.ng, P.byl, P.byr, P.fill != 0);
+    const int jcl = jvalid ? j : g.qy - 1;
+    const int js = bc_src(mc, jcl, g.jlo, g.jhi);
+    const bool neg_c = (jcl < g.jlo && mc.odd_lo) || (jcl > g.jhi && mc.odd_hi);
+    // the first / last strip also carries the ghost rows
+    const int ka = (i0 == g.ilo) ? 0 : i0 - 3;
+    const int kb = (i1 == g.ihi + 1) ? g.qx - 1 : i1 + 2;
     const double u = P.u, v = P.v;
     const double cx = P.cx, cy = P.cy;
-
-    // ---- phase 1: upwind interface states (interface.py:25-41) ----------
-    // a_x at faces i in [i0, i0+TI], j in [j0-1, j0+TJ]: AX[r][c], c = 0..65
-    auto ax_state = [&](int r, int c) {
-        // A-tile coordinates of the upwind cell of face (i0 + r, j0 - 1 + c)
-        const int br = r + ADV_H - (UNEG ? 0 : 1), ac = c - 1 + ADV_H;
-        const double a0 = A[br][ac];
-        const double ld = limited_slope(A[br - 2][ac], A[br - 1][ac], a0, A[br + 1][ac],
-                                        A[br + 2][ac], LIM);
-        AX[r][c] = UNEG ? a0 - 0.5 * (1.0 + cx) * ld : a0 + 0.5 * (1.0 - cx) * ld;
-    };
-    for (int r = w; r < ADV_XH; r += 4) ax_state(r, l + 1);          // columns 1..64
-    if (tid < 2 * ADV_XH) ax_state(tid >> 1, (tid & 1) ? ADV_XW - 1 : 0);   // columns 0, 65
-    // a_y at faces i in [i0-1, i0+TI], j in [j0, j0+TJ]: AY[r][c], c = 0..64
-    auto ay_state = [&](int r, int c) {
-        const int ar = r - 1 + ADV_H, bc = c + ADV_H - (VNEG ? 0 : 1);
-        const double a0 = A[ar][bc];
-        const double ld = limited_slope(A[ar][bc - 2], A[ar][bc - 1], a0, A[ar][bc + 1],
-                                        A[ar][bc + 2], LIM);
-        AY[r][c] = VNEG ? a0 - 0.5 * (1.0 + cy) * ld : a0 + 0.5 * (1.0 - cy) * ld;
-    };
-    for (int r = w; r < ADV_YH; r += 4) ay_state(r, l);              // columns 0..63
-    if (tid >= 64 && tid < 64 + ADV_YH) ay_state(tid - 64, ADV_YW - 1);   // column 64
-    __syncthreads();
-
-    // ---- phase 2: transverse-corrected fluxes + conservative update -----
     const int mx = (u <= 0) ? 0 : -1;   // advective_fluxes.py:71-79
     const int my = (v <= 0) ? 0 : -1;
-    const double dtdx2 = P.dtdx2, dtdy2 = P.dtdy2;
-    const double dtdx = P.dtdx, dtdy = P.dtdy;      // simulation.py:63-64
 
-    const int c = l;
-    for (int r = w; r < ADV_TI; r += 4) {
-        const int i = i0 + r, j = j0 + c;
-        if (i > g.ihi || j > g.jhi) continue;
-        // AX[r][c+1] is a_x at (i, j);  AY[r+1][c] is a_y at (i, j)
-        // F_x[i,j] = u*(a_x[i,j] - dtdy2*(F_yt[i+mx,j+1] - F_yt[i+mx,j]))
-        double Fx0 = u * (AX[r][c + 1] -
-                          dtdy2 * (v * AY[r + 1 + mx][c + 1] - v * AY[r + 1 + mx][c]));
-        double Fx1 = u * (AX[r + 1][c + 1] -
-                          dtdy2 * (v * AY[r + 2 + mx][c + 1] - v * AY[r + 2 + mx][c]));
-        // F_y[i,j] = v*(a_y[i,j] - dtdx2*(F_xt[i+1,j+my] - F_xt[i,j+my]))
-        double Fy0 = v * (AY[r + 1][c] -
-                          dtdx2 * (u * AX[r + 1][c + 1 + my] - u * AX[r][c + 1 + my]));
-        double Fy1 = v * (AY[r + 1][c + 1] -
-                          dtdx2 * (u * AX[r + 1][c + 2 + my] - u * AX[r][c + 2 + my]));
-        double a = A[r + ADV_H][c + ADV_H];
-        aout[(size_t)i * p + j] = a + dtdx * (Fx0 - Fx1) + dtdy * (Fy0 - Fy1);
+    // source row of array row k under the ghost fill; its sign goes with the value
+    auto row_src = [&](int k) { return bc_src(mr, k > kb ? kb : k, g.ilo, g.ihi); };
+    const bool odd_lo = mr.odd_lo, odd_hi = mr.odd_hi;
+
+    double w[5] = {0, 0, 0, 0, 0};      // a of rows k-4..k
+    double l2b = 0.0, l2c = 0.0;        // limit2_x of rows k-3, k-2
+    double Xm1 = 0.0, Xm2 = 0.0;        // x states of rows c-1, c-2  (c = k-2)
+    double Ym1 = 0.0;                   // y state of row c-1
+    double Fxm1 = 0.0;                  // F_x of row c-1
+    // rows k .. k+ADV_PF-1 in flight: the kernel is HBM bound and a wavefront
+    // consumes a row right after it arrives, so the loads run ahead of the use
+    double pf[ADV_PF];
+#pragma unroll
+    for (int n = 0; n < ADV_PF; n++) pf[n] = ain[(size_t)row_src(ka + n) * p + js];
+    for (int k = ka; k <= kb; k++) {
+#pragma unroll
+        for (int n = 0; n < 4; n++) w[n] = w[n + 1];
+        {   // row k arrives (through the ghost fill's index map), row k+ADV_PF leaves
+            const double raw = pf[0];
+#pragma unroll
+            for (int n = 0; n < ADV_PF - 1; n++) pf[n] = pf[n + 1];
+            pf[ADV_PF - 1] = ain[(size_t)row_src(k + ADV_PF) * p + js];
+            const bool neg = neg_c != ((k < g.ilo && odd_lo) || (k > g.ihi && odd_hi));
+            w[4] = neg ? -raw : raw;
+            // ghost frame of the new buffer
+            const bool rghost = (k < g.ilo || k > g.ihi);
+            if (jown && (rghost || (jghost && k >= i0 && k < i1))) aout[(size_t)k * p + j] = w[4];
+        }
+        const double l2n = (LIM != 0) ? limit2(w[2], w[3], w[4]) : 0.0;       // limit2_x of row k-1
+        if (k < i0 + 1 || k > i1 + 2) {
+            l2b = l2c; l2c = l2n;
+            continue;
+        }
+        // ---- row c = k-2 (window index 2): limited slopes, interface states
+        const double sx = adv_slope<LIM>(l2b, l2c, l2n, w[1], w[2], w[3]);
+        const double am = adv_m1(w[2]), ap = adv_p1(w[2]);
+        const double l2y = (LIM != 0) ? limit2(am, w[2], ap) : 0.0;
+        const double l2ym = (LIM == 2) ? adv_m1(l2y) : 0.0, l2yp = (LIM == 2) ? adv_p1(l2y) : 0.0;
+        const double sy = adv_slope<LIM>(l2ym, l2y, l2yp, am, w[2], ap);
+        // upwind states of cell c (interface.py:25-41): its lower face if the
+        // velocity is negative, its upper face otherwise
+        const double X = UNEG ? w[2] - 0.5 * (1.0 + cx) * sx : w[2] + 0.5 * (1.0 - cx) * sx;
+        const double Y = VNEG ? w[2] - 0.5 * (1.0 + cy) * sy : w[2] + 0.5 * (1.0 - cy) * sy;
+        // a_x on the lower x faces of rows c, c-1; a_y on the lower y faces of rows c, c-1
+        const double ax_c = UNEG ? X : Xm1, ax_m = UNEG ? Xm1 : Xm2;
+        const double ay_c = VNEG ? Y : adv_m1(Y), ay_m = VNEG ? Ym1 : adv_m1(Ym1);
+        // F_x[c,j] = u*(a_x[c,j] - dtdy2*(F_yt[c+mx,j+1] - F_yt[c+mx,j]))
+        const double ayt = (mx == 0) ? ay_c : ay_m;
+        const double Fx = u * (ax_c - P.dtdy2 * (v * adv_p1(ayt) - v * ayt));
+        // ---- row g = c-1: F_y and the conservative update
+        if (k >= i0 + 3) {
+            // F_y[g,j] = v*(a_y[g,j] - dtdx2*(F_xt[g+1,j+my] - F_xt[g,j+my]))
+            const double axc_s = (my == 0) ? ax_c : adv_m1(ax_c);
+            const double axm_s = (my == 0) ? ax_m : adv_m1(ax_m);
+            const double Fy = v * (ay_m - P.dtdx2 * (u * axc_s - u * axm_s));
+            const double Fyh = adv_p1(Fy);
+            if (jout)
+                aout[(size_t)(k - 3) * p + j] = w[1] + P.dtdx * (Fxm1 - Fx) + P.dtdy * (Fy - Fyh);
+        }
+        l2b = l2c; l2c = l2n;
+        Xm2 = Xm1; Xm1 = X;
+        Ym1 = Y;
+        Fxm1 = Fx;
     }
+}
+
+// rows per strip.  Measured (tools/adv_time.py): 16-20 rows at 2048^2 (enough
+// wavefronts for 4 per SIMD matter more than the 6 apron rows a strip re-reads),
+// 48-64 rows from 8192^2 on
+static int adv_rows(int nx, int ncb, int cus)
+{
+    const long slots = 16L * cus;       // 4 wavefronts per SIMD
+    int L = (int)(((long)nx * ncb + slots - 1) / slots);
+    L = L < 16 ? 16 : (L > 64 ? 64 : L);
+    return L < nx ? L : nx;
 }
 
 template <int LIM>
-static void adv_launch(pyrohip_ctx *c, bool uneg, bool vneg, int ntiles, const double *cur,
-                       double *nxt, const Geom &g, const AdvParams &P, int ntj)
+static void adv_launch(pyrohip_ctx *c, bool uneg, bool vneg, int nwg, const double *cur,
+                       double *nxt, const Geom &g, const AdvParams &P)
 {
-    const dim3 grid(ntiles), block(ADV_THREADS);
+    const dim3 grid(nwg), block(64);
     if (uneg && vneg)
-        PYRO_LAUNCH(c, "k_adv_step", (k_adv_step<LIM, true, true>), grid, block, 0, cur, nxt, g, P, ntj, ntiles);
+        PYRO_LAUNCH(c, "k_adv_step", (k_adv_step<LIM, true, true>), grid, block, 0, cur, nxt, g, P);
     else if (uneg)
-        PYRO_LAUNCH(c, "k_adv_step", (k_adv_step<LIM, true, false>), grid, block, 0, cur, nxt, g, P, ntj, ntiles);
+        PYRO_LAUNCH(c, "k_adv_step", (k_adv_step<LIM, true, false>), grid, block, 0, cur, nxt, g, P);
     else if (vneg)
-        PYRO_LAUNCH(c, "k_adv_step", (k_adv_step<LIM, false, true>), grid, block, 0, cur, nxt, g, P, ntj, ntiles);
+        PYRO_LAUNCH(c, "k_adv_step", (k_adv_step<LIM, false, true>), grid, block, 0, cur, nxt, g, P);
     else
-        PYRO_LAUNCH(c, "k_adv_step", (k_adv_step<LIM, false, false>), grid, block, 0, cur, nxt, g, P, ntj, ntiles);
-}
-
-// copy the ghost frame of one plane from src to dst (keeps the "stale ghost"
-// semantics of the reference's in-place update).  O(perimeter): blockIdx.y
-// enumerates the 2*ng ghost rows (all j), then groups of interior rows (only
-// their 2*ng ghost columns).
-__global__ void k_copy_frame(const double *__restrict__ src, double *__restrict__ dst, Geom g)
-{
-    const int ng = g.ng;
-    const int b = blockIdx.y;
-    int i, j;
-    if (b < 2 * ng) {
-        i = (b < ng) ? b : g.ihi + 1 + (b - ng);
-        j = blockIdx.x * blockDim.x + threadIdx.x;
-        if (j >= g.qy) return;
-    } else {
-        if (blockIdx.x != 0) return;
-        const int t = threadIdx.x;
-        const int rows_per_block = 256 / (2 * ng);
-        const int r = (b - 2 * ng) * rows_per_block + t / (2 * ng);
-        const int kx = t % (2 * ng);
-        if (r >= g.nx || t >= rows_per_block * 2 * ng) return;
-        i = g.ilo + r;
-        j = (kx < ng) ? kx : g.jhi + 1 + (kx - ng);
-    }
-    dst[(size_t)i * g.pitch + j] = src[(size_t)i * g.pitch + j];
+        PYRO_LAUNCH(c, "k_adv_step", (k_adv_step<LIM, false, false>), grid, block, 0, cur, nxt, g, P);
 }
 
 }  // namespace pyro
 
 using namespace pyro;
 
-extern "C" int pyrohip_adv_step(pyrohip_state *s, int n, double dx, double dy, double u, double v,
-                                double dt, int limiter)
+static bool simple_bc(int b)
+{
+    return b == PYROHIP_BC_OUTFLOW || b == PYROHIP_BC_REFLECT_EVEN || b == PYROHIP_BC_REFLECT_ODD ||
+           b == PYROHIP_BC_PERIODIC;
+}
+
+extern "C" int pyrohip_adv_step_fill(pyrohip_state *s, int n, double dx, double dy, double u,
+                                     double v, double dt, int limiter, int fill)
 {
     PYRO_REQUIRE(s, "NULL state");
     PYRO_REQUIRE(n >= 0 && n < s->nvar, "variable index out of range");
@@ -213,6 +243,10 @@ extern "C" int pyrohip_adv_step(pyrohip_state *s, int n, double dx, double dy, d
     PYRO_REQUIRE(limiter >= 0 && limiter <= 2, "limiter must be 0, 1 or 2");
     pyrohip_ctx *c = s->ctx;
     const Geom &g = s->g;
+    if (fill)
+        for (int k = 0; k < 4; k++)
+            PYRO_REQUIRE(simple_bc(s->bc[n * 4 + k]),
+                         "fused ghost fill: outflow / reflect / periodic boundaries only");
     // scratch plane for the new time level
     if (s->work_planes < 1) {
         if (s->work) PYRO_CHECK_HIP(hipFree(s->work));
@@ -227,21 +261,20 @@ extern "C" int pyrohip_adv_step(pyrohip_state *s, int n, double dx, double dy, d
     P.cx = u * dt / dx; P.cy = v * dt / dy;
     P.dtdx2 = 0.5 * dt / dx; P.dtdy2 = 0.5 * dt / dy;
     P.dtdx = dt / dx; P.dtdy = dt / dy;
-    const int nti = (g.nx + ADV_TI - 1) / ADV_TI, ntj = (g.ny + ADV_TJ - 1) / ADV_TJ;
-    const int ntiles = nti * ntj;
-    const bool uneg = (u < 0), vneg = (v < 0);   // interface.py:28,38
-    if (limiter == 0) adv_launch<0>(c, uneg, vneg, ntiles, cur, nxt, g, P, ntj);
-    else if (limiter == 1) adv_launch<1>(c, uneg, vneg, ntiles, cur, nxt, g, P, ntj);
-    else adv_launch<2>(c, uneg, vneg, ntiles, cur, nxt, g, P, ntj);
-    // interior back into the state plane: swap roles by copying the interior
-    // is avoided -- instead copy the (tiny) ghost frame into the new buffer
-    // and exchange the two planes' contents by pointer where possible.
-    {
-        const int rows_per_block = 256 / (2 * g.ng);
-        const int nby = 2 * g.ng + (g.nx + rows_per_block - 1) / rows_per_block;
-        hipLaunchKernelGGL(k_copy_frame, dim3((g.qy + 255) / 256, nby), dim3(256), 0, c->stream,
-                           (const double *)cur, nxt, g);
+    P.ncb = (g.ny + AW_OUT - 1) / AW_OUT;
+    P.L = adv_rows(g.nx, P.ncb, c->num_cus > 0 ? c->num_cus : 256);
+    if (const char *e = getenv("PYRO_ADV_ROWS")) {   // tuning / test knob
+        const int r = atoi(e);
+        if (r > 0) P.L = r < g.nx ? (r < 4 ? 4 : r) : g.nx;
     }
+    P.fill = fill ? 1 : 0;
+    P.bxl = s->bc[n * 4 + 0]; P.bxr = s->bc[n * 4 + 1];
+    P.byl = s->bc[n * 4 + 2]; P.byr = s->bc[n * 4 + 3];
+    const int nwg = P.ncb * ((g.nx + P.L - 1) / P.L);
+    const bool uneg = (u < 0), vneg = (v < 0);   // interface.py:28,38
+    if (limiter == 0) adv_launch<0>(c, uneg, vneg, nwg, cur, nxt, g, P);
+    else if (limiter == 1) adv_launch<1>(c, uneg, vneg, nwg, cur, nxt, g, P);
+    else adv_launch<2>(c, uneg, vneg, nwg, cur, nxt, g, P);
     PYRO_CHECK_HIP(hipGetLastError());
     if (s->nvar == 1) {
         // single-variable state: swap the two allocations
@@ -254,4 +287,10 @@ extern "C" int pyrohip_adv_step(pyrohip_state *s, int n, double dx, double dy, d
                                       hipMemcpyDeviceToDevice, c->stream));
     }
     return 0;
+}
+
+extern "C" int pyrohip_adv_step(pyrohip_state *s, int n, double dx, double dy, double u, double v,
+                                double dt, int limiter)
+{
+    return pyrohip_adv_step_fill(s, n, dx, dy, u, v, dt, limiter, 0);
 }

@@ -372,9 +372,11 @@ class DeviceState:
         return mn.value, mx.value
 
     # ---- solvers ------------------------------------------------------
-    def adv_step(self, n, dx, dy, u, v, dt, limiter):
+    def adv_step(self, n, dx, dy, u, v, dt, limiter, fill=False):
+        """fill: fold the ghost fill of variable n into the step (one launch)"""
         with self.ctx.lock:
-            check(self._l.pyrohip_adv_step(self.h, int(n), dx, dy, u, v, dt, int(limiter)))
+            check(self._l.pyrohip_adv_step_fill(self.h, int(n), dx, dy, u, v, dt, int(limiter),
+                                                int(bool(fill))))
 
     def comp_dt(self, params, cfl):
         dt = C.c_double()

@@ -12,6 +12,8 @@ Differences in mechanism (not in behaviour):
     operation uploads first.  In Pyro.run_sim's steady loop nothing touches
     the host copy, so the state never leaves HBM.
 """
+import sys
+
 import numpy as np
 
 from .. import device
@@ -222,6 +224,15 @@ class CellCenterData2d:
         self._dev = None
         self._host_valid = True
         self._dev_valid = False
+        # deferred ghost fill (fill_BC_all with lazy_fill, see there)
+        self.lazy_fill = False
+        self._fill_pending = False
+        # NumPy views handed out by get_var() / .data keep the host copy's
+        # ArrayIndexer alive through their .base chain, so its reference count
+        # tells whether user code still holds one (see device_modified)
+        self._root = None
+        self._root_refs = 0
+        self._warned_views = False
 
     # ---- construction ---------------------------------------------------
     def register_var(self, name, bc):
@@ -247,9 +258,20 @@ class CellCenterData2d:
         if self.initialized == 1:
             msg.fail("ERROR: grid already initialized")
         g = self.grid
-        self._host = ArrayIndexer(np.zeros((g.qx, g.qy, self.nvar)), grid=g)
+        self._set_host(np.zeros((g.qx, g.qy, self.nvar)))
         self._host_valid, self._dev_valid = True, False
         self.initialized = 1
+
+    def _set_host(self, arr):
+        self._root = np.ascontiguousarray(arr, dtype=np.float64)
+        self._host = ArrayIndexer(self._root, grid=self.grid)
+        self._root_refs = sys.getrefcount(self._host)
+
+    def _views_alive(self):
+        """does user code hold a NumPy view of the host copy (a get_var() result
+        kept across steps, like `dens = sim.cc_data.get_var("density")` in the
+        reference's scripts)?"""
+        return self._host is not None and sys.getrefcount(self._host) > self._root_refs
 
     # ---- host / device coherence ---------------------------------------
     @property
@@ -258,9 +280,14 @@ class CellCenterData2d:
             self._ctx = device.Context.default()
         return self._ctx
 
-    def device_state(self):
+    def device_state(self, fuse_fill=False):
         """the DeviceState with a current copy of the data (uploads if the host
-        copy was touched since the last device operation)"""
+        copy was touched since the last device operation).  A ghost fill that
+        fill_BC_all() deferred (see there) is carried out now unless the caller
+        takes it over (fuse_fill=True, then take_pending_fill())"""
+        if self._fill_pending and not fuse_fill:
+            self._fill_pending = False
+            self._fill_now()
         if self._dev is None:
             g = self.grid
             dub = self._device_user_bc()
@@ -272,11 +299,36 @@ class CellCenterData2d:
         return self._dev
 
     def device_modified(self):
-        """to be called after a kernel changed the device copy"""
+        """to be called after a kernel changed the device copy.  In the
+        reference the arrays are updated in place, so a view taken before a
+        step shows the new state after it and can be written through at any
+        time.  While user code holds such a view the host copy is therefore
+        refreshed right away (same memory, the view sees it) and uploaded again
+        before the next kernel (the view may have been written): correct, at
+        the price of two PCIe transfers per step -- scripts that re-fetch
+        get_var() after each step (or never look) run without them."""
         self._dev_valid = True
         self._host_valid = False
+        if self._views_alive():
+            if not self._warned_views:
+                self._warned_views = True
+                msg.warning("a view of the simulation data (get_var / .data) is held across "
+                            "device steps: keeping the host copy coherent costs a download and "
+                            "an upload per step")
+            self._dev.download(np.asarray(self._host))
+            self._host_valid = True
+            self._dev_valid = False
+
+    def take_pending_fill(self):
+        """True if fill_BC_all() deferred a ghost fill that the caller now does
+        as part of its own kernel"""
+        p, self._fill_pending = self._fill_pending, False
+        return p
 
     def _host_rw(self):
+        if self._fill_pending:           # the host copy must see filled ghost cells
+            self._fill_pending = False
+            self._fill_now()
         if not self._host_valid:
             self._dev.download(np.asarray(self._host))
             self._host_valid = True
@@ -290,8 +342,9 @@ class CellCenterData2d:
 
     @data.setter
     def data(self, value):
-        self._host = ArrayIndexer(np.ascontiguousarray(value, dtype=np.float64), grid=self.grid)
+        self._set_host(np.array(value, dtype=np.float64))
         self._host_valid, self._dev_valid = True, False
+        self._fill_pending = False
 
     # ---- variable access ------------------------------------------------
     def get_var(self, name):
@@ -329,13 +382,13 @@ class CellCenterData2d:
     def min(self, name, *, ng=0):
         n = self.names.index(name)
         if self._dev_valid and self._dev is not None:
-            return self._dev.minmax(n, buf=ng)[0]
+            return self.device_state().minmax(n, buf=ng)[0]
         return np.min(self._host.v(buf=ng, n=n))
 
     def max(self, name, *, ng=0):
         n = self.names.index(name)
         if self._dev_valid and self._dev is not None:
-            return self._dev.minmax(n, buf=ng)[1]
+            return self.device_state().minmax(n, buf=ng)[1]
         return np.max(self._host.v(buf=ng, n=n))
 
     # ---- boundary conditions -------------------------------------------
@@ -384,6 +437,23 @@ class CellCenterData2d:
             st.set_ramp_bc(**comp_bc.ramp_params(self.grid, self.get_aux("gamma"), self.t))
 
     def fill_BC_all(self):
+        """ghost fill of every variable.  A solver whose step kernel can do the
+        fill itself (advection: index remap at load, one launch instead of four)
+        sets `lazy_fill`: the fill is then only NOTED here and carried out by the
+        next thing that touches the data -- the solver's kernel (fused), or any
+        other device / host access (a real fill, device_state / _host_rw)."""
+        if self.lazy_fill and self._lazy_fill_ok():
+            self._fill_pending = True
+            return
+        self._fill_now()
+
+    def _lazy_fill_ok(self):
+        simple = ("outflow", "reflect-even", "reflect-odd", "periodic")
+        return self._dev_valid and self._dev is not None and \
+            not any(self._has_host_bc(n) for n in self.names) and \
+            all(b in simple for n in self.names for b in self.BCs[n].sides())
+
+    def _fill_now(self):
         if not any(self._has_host_bc(n) for n in self.names):
             st = self.device_state()
             self._push_user_bc(st)

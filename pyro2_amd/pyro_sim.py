@@ -152,6 +152,11 @@ class Pyro:
         else:       # a file written by pyro itself: no dt history
             self.sim.n = max(self.sim.n, 1)
             self.sim.dt_old = 1.e33
+        # the output counter of do_output() (simulation_null.py:270-290): without it
+        # every step after a restart is "due" until the counter has caught up
+        dt_out = self.rp.get_param("io.dt_out")
+        if dt_out > 0.0:
+            self.sim.n_num_out = int(dst.t / dt_out)
 
     def run_sim(self):
         if not self.is_initialized:
@@ -278,9 +283,9 @@ class PyroBenchmark(Pyro):
 def parse_args():
     p = argparse.ArgumentParser(description="pyro hot path on MI355X")
     p.add_argument("--make_benchmark", action="store_true",
-                   help="(accepted for command-line compatibility)")
+                   help="create a new benchmark file for regression testing")
     p.add_argument("--compare_benchmark", action="store_true",
-                   help="(accepted for command-line compatibility)")
+                   help="compare the end result to the stored benchmark")
     p.add_argument("solver", metavar="solver-name", choices=valid_solvers)
     p.add_argument("problem", metavar="problem-name")
     p.add_argument("param", metavar="inputs-file")
@@ -295,9 +300,15 @@ def main():
     for param_string in args.other:
         k, v = param_string.split("=")
         other[k] = _get_val(v)
-    pyro = Pyro(args.solver, from_commandline=True)
+    if args.compare_benchmark or args.make_benchmark:     # pyro_sim.py:453-461
+        pyro = PyroBenchmark(args.solver, comp_bench=args.compare_benchmark,
+                             make_bench=args.make_benchmark)
+    else:
+        pyro = Pyro(args.solver, from_commandline=True)
     pyro.initialize_problem(args.problem, inputs_file=args.param, inputs_dict=other)
-    pyro.run_sim()
+    result = pyro.run_sim()
+    if args.compare_benchmark and result != 0:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -41,6 +41,45 @@ def _run(dev, ic, dts, nx, limiter=2, u=1.0, v=1.0):
     return s.download()[:, :, 0]
 
 
+@pytest.mark.parametrize("rows", ["0", "9"])
+@pytest.mark.parametrize("bcs,uv,lim", [
+    (("periodic", "periodic", "periodic", "periodic"), (1.0, 1.0), 2),
+    (("outflow", "outflow", "outflow", "outflow"), (-0.7, 0.4), 2),
+    (("reflect-even", "outflow", "reflect-odd", "reflect-even"), (0.8, -1.1), 2),
+    (("reflect-odd", "reflect-even", "outflow", "reflect-odd"), (-0.5, -0.9), 1),
+    (("periodic", "periodic", "outflow", "reflect-even"), (0.0, 0.6), 0),
+])
+def test_adv_fused_fill(dev, bcs, uv, lim, rows, monkeypatch):
+    """the ghost fill folded into the step (index remap at load, one launch)
+    against fill_bc() followed by the plain step: interior AND ghost frame, 120 x
+    150 cells = 3 column strips (the last ragged), one strip and 9-row strips,
+    both signs of the velocities, every boundary type.  The plain step itself is
+    pinned on the reference's dumps (test_adv_single_step_cases) and must leave the
+    ghost frame as it found it."""
+    monkeypatch.setenv("PYRO_ADV_ROWS", rows)
+    nx, ny, ng = 120, 150, 4
+    rng = np.random.default_rng(7)
+    a0 = rng.random((nx + 2 * ng, ny + 2 * ng)) + 0.3        # ghost cells: junk on purpose
+    dx, dy = 1.0 / nx, 1.0 / ny
+    dt = 0.8 * min(dx / max(abs(uv[0]), 1e-3), dy / max(abs(uv[1]), 1e-3))
+    out = {}
+    for fused in (False, True):
+        s = device.DeviceState(dev, nx, ny, ng, [list(bcs)])
+        s.upload(a0)
+        for _ in range(3):
+            if not fused:
+                s.fill_bc()
+            s.adv_step(0, dx, dy, uv[0], uv[1], dt, lim, fill=fused)
+        out[fused] = s.download()[:, :, 0]
+    assert np.array_equal(out[True], out[False])
+    # and against the oracle on the interior
+    a = a0.copy()
+    for _ in range(3):
+        orc.fill_ghost(a, nx, ny, ng, list(bcs))
+        orc.adv_step(a, nx, ny, ng, dx, dy, uv[0], uv[1], dt, lim)
+    assert max_rel_err(out[True][ng:-ng, ng:-ng], a[ng:-ng, ng:-ng]) <= (0.0 if dev.kind == "emu" else TOL)
+
+
 def test_adv_reference_regression_smooth_0040(dev, golden):
     """pyro/test.py:93 -- advection smooth 32^2, 40 steps vs smooth_0040.h5"""
     g = golden("adv_smooth_0040")

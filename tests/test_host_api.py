@@ -60,6 +60,38 @@ def test_pyro_advection_smooth_regression(api, golden):
     assert os.path.exists("inputs.auto")
 
 
+def test_views_held_across_steps_stay_live(api):
+    """reference scripts keep `dens = sim.cc_data.get_var("density")` across
+    steps: the arrays are updated in place there, so the view shows every new
+    state and writes through it count.  Here the state lives on the
+    device; while such a view is alive the host copy is refreshed after every
+    kernel and uploaded before the next one."""
+    from pyro2_amd.pyro_sim import Pyro
+    p = Pyro("advection")
+    p.initialize_problem("smooth", inputs_dict={"mesh.nx": 16, "mesh.ny": 16})
+    q = Pyro("advection")                       # twin without any view held
+    q.initialize_problem("smooth", inputs_dict={"mesh.nx": 16, "mesh.ny": 16})
+    dens = p.sim.cc_data.get_var("density")     # held across the steps below
+    start = dens.v().copy()
+    for _ in range(2):
+        p.single_step()
+        q.single_step()
+    assert not np.array_equal(dens.v(), start)                       # the old view sees the new state
+    assert np.array_equal(dens.v(), q.get_var("density").v())        # ... exactly
+    dens.v()[:, :] = 7.0                                             # a write through the old view
+    p.single_step()
+    assert abs(float(np.mean(p.get_var("density").v())) - 7.0) < 1e-12
+    # without a held view nothing is transferred: the deferred ghost fill stays deferred
+    del dens
+    p.single_step()
+    p.sim.cc_data.fill_BC_all()
+    assert p.sim.cc_data._fill_pending and not p.sim.cc_data._views_alive()
+    a = p.get_var("density")                                         # any access carries the fill out
+    assert not p.sim.cc_data._fill_pending
+    g = p.sim.cc_data.grid
+    assert np.array_equal(a[g.ilo - 1, g.jlo:g.jhi + 1], a[g.ihi, g.jlo:g.jhi + 1])   # periodic ghosts
+
+
 def test_pyro_compressible_sedov(api, golden):
     from pyro2_amd.pyro_sim import Pyro
     g = golden("comp_sedov_64_020")

@@ -1,34 +1,30 @@
-#!/usr/bin/env python3
-"""time of one advection step at 2048^2 (developer tool)"""
-import os
-import sys
-import time
-
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np  # noqa: E402
-
-from pyro2_amd import device  # noqa: E402
-
+"""developer tool: advection step timing by size and strip length (GPU box)"""
+import os, sys, time
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+from pyro2_amd import device
 ctx = device.Context(0)
-nx = int(os.environ.get("ADV_NX", "2048"))
-s = device.DeviceState(ctx, nx, nx, 4, [[3, 3, 3, 3]])
-x = (np.arange(nx + 8) - 3.5) / nx
-X, Y = np.meshgrid(x, x, indexing="ij")
-s.upload(np.ascontiguousarray((1.0 + np.exp(-60.0 * ((X - 0.5)**2 + (Y - 0.5)**2)))[:, :, None]))
-dx = 1.0 / nx
-dt = 0.8 * dx
-for _ in range(20):
-    s.fill_bc(); s.adv_step(0, dx, dx, 1.0, 1.0, dt, 2)
-ctx.sync()
-n = 300
-t0 = time.perf_counter()
-for _ in range(n):
-    s.fill_bc(); s.adv_step(0, dx, dx, 1.0, 1.0, dt, 2)
-ctx.sync()
-t1 = time.perf_counter()
-ctx.prof_enable(True)
-for _ in range(20):
-    s.fill_bc(); s.adv_step(0, dx, dx, 1.0, 1.0, dt, 2)
-prof = ctx.prof_report(); ctx.prof_enable(False)
-print(f"nx={nx}: {(t1 - t0) / n * 1e6:.1f} us/step = {nx * nx / ((t1 - t0) / n) / 1e9:.1f} Gcell/s",
-      {k: round(ms / cnt * 1e3, 1) for k, (cnt, ms) in prof.items()}, "sum", float(s.download().sum()))
+for nx in (2048, 8192):
+    x = (np.arange(nx + 8) - 3.5) / nx
+    X, Y = np.meshgrid(x, x, indexing="ij")
+    ic = 1.0 + np.exp(-60.0 * ((X - 0.5) ** 2 + (Y - 0.5) ** 2))
+    for rows in os.environ.get("ROWS", "0").split(","):
+        os.environ["PYRO_ADV_ROWS"] = rows
+        st = device.DeviceState(ctx, nx, nx, 4, [["periodic"] * 4])
+        st.upload(ic)
+        dt = 0.8 / nx
+        for fused in (1, 0):
+            def step():
+                if not fused:
+                    st.fill_bc()
+                st.adv_step(0, 1 / nx, 1 / nx, 1.0, 1.0, dt, 2, fill=bool(fused))
+            for _ in range(10): step()
+            ctx.sync(); ctx.prof_enable(True)
+            n = 200 if nx <= 2048 else 50
+            t0 = time.perf_counter()
+            for _ in range(n): step()
+            ctx.sync(); t1 = time.perf_counter()
+            prof = ctx.prof_report(); ctx.prof_enable(False)
+            k, ms = prof["k_adv_step"]
+            print(f"nx={nx} rows={rows} fused={fused} step {1e6*(t1-t0)/n:8.1f} us  kernel {1e3*ms/k:8.1f} us  "
+                  f"{16*nx*nx/(ms/k*1e-3)/1e12:.2f} TB/s kernel, {16*nx*nx*n/(t1-t0)/1e12:.2f} TB/s step")
