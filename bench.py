@@ -138,6 +138,19 @@ class Dist:
         return bytes(t.numpy().tobytes())
 
 
+def also_traffic(section, key):
+    """measured fabric bytes of the advection step / the multigrid V-cycle from the committed
+    PMC passes (tools/pmc_also.sh -> profiles/r*_also_traffic.json); None when absent"""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_also_traffic.json")))
+    if not fs:
+        return None
+    try:
+        return json.load(open(fs[-1]))[section][key]
+    except Exception:
+        return None
+
+
 def kernel_table(prof, nlaunch_unit):
     return {k: {"launches": n, "avg_ms": ms / max(n, 1)} for k, (n, ms) in prof.items()}
 
@@ -248,9 +261,8 @@ def bench_advection(ctx, device, nx=2048, steps=100, warmup=10):
     st.upload(ic)
     dt = 0.8 * min((1 / nx) / 1.0, (1 / nx) / 1.0)     # advection/simulation.py:38-54, u = v = 1, cfl 0.8
 
-    def step():
-        st.fill_bc()
-        st.adv_step(0, 1 / nx, 1 / nx, 1.0, 1.0, dt, 2)
+    def step():      # the ghost fill is folded into the step kernel (one launch per step)
+        st.adv_step(0, 1 / nx, 1 / nx, 1.0, 1.0, dt, 2, fill=True)
     for _ in range(warmup):
         step()
     ctx.sync()
@@ -264,6 +276,7 @@ def bench_advection(ctx, device, nx=2048, steps=100, warmup=10):
     ctx.prof_enable(False)
     n, ms = prof["k_adv_step"]
     kern_s = ms / n * 1e-3
+    traffic = also_traffic("adv_summary", "bytes_per_step") if nx == 2048 else None
     return {"workload": f"advection smooth {nx}x{nx} periodic, limiter 2",
             "value": nx * nx * steps / (t1 - t0), "unit": "cell-updates/s",
             "ms_per_step": (t1 - t0) / steps * 1e3, "steps": steps,
@@ -271,7 +284,9 @@ def bench_advection(ctx, device, nx=2048, steps=100, warmup=10):
                          "achieved": ADV_BYTES_PER_CELL * nx * nx / kern_s / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ADV_BYTES_PER_CELL * nx * nx / kern_s / 1e9 / HBM_PEAK_GBS,
-                         "kernel_avg_ms": ms / n, "traffic": None}}
+                         "kernel_avg_ms": ms / n, "traffic": traffic,
+                         "step_frac": ADV_BYTES_PER_CELL * nx * nx * steps / (t1 - t0) / 1e9 / HBM_PEAK_GBS,
+                         "launches_per_step": 1}}
 
 
 def bench_mg(ctx, device, nx=4096, cycles=10):
@@ -293,12 +308,17 @@ def bench_mg(ctx, device, nx=4096, cycles=10):
     t1 = time.perf_counter()
     vps = cycles / (t1 - t0)
     gbs = MG_BYTES_PER_CELL_VCYCLE * nx * nx * vps / 1e9
+    traffic = also_traffic("mg_summary", "bytes_per_vcycle") if nx == 4096 else None
     return {"workload": f"multigrid constant-coeff Poisson {nx}x{nx} dirichlet, "
                         f"{cycles} V-cycles (nsmooth 10, bottom 50)",
             "value": vps, "unit": "V-cycles/s", "ms_per_vcycle": (t1 - t0) / cycles * 1e3,
             "residual_error_after": res,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "basis": "720 B per finest cell per V-cycle (SURVEY 8(d) model of the per-level "
+                                  "passes) x V-cycles/s: an algorithmic-equivalent rate, the 5-sweep LDS "
+                                  "smoother moves fewer bytes than the model (traffic = measured fabric "
+                                  "bytes per V-cycle, profiles/*_also_traffic.json)"}}
 
 
 def bench_incompressible(ctx, device, nx=2048, steps=5):

@@ -396,6 +396,17 @@ int pyrohip_comp_dt_is_global(pyrohip_state *s, int *flag);
    for PYROHIP_BC_HALO sides; y ghost fill must follow (fill order of
    array_indexer.py:150-274). */
 int pyrohip_halo_exchange(pyrohip_state *s, int rank_lo, int rank_hi);
+/* tell a slab's state who its x neighbours are (-1 = none).  pyrohip_comp_step
+   (kernel_set 2) then updates the first and the last strip of rows first and
+   posts the exchange of the NEW boundary rows on a second stream / communicator,
+   so that it overlaps the update of the interior strips; the next
+   pyrohip_halo_exchange(s, same neighbours) only waits for it.  Any write to
+   the state in between (upload, fill of another kind) makes that call exchange
+   again.  Without this call every exchange is synchronous. */
+int pyrohip_state_set_neighbours(pyrohip_state *s, int rank_lo, int rank_hi);
+/* 1 if the last step posted the halo exchange of the state it produced and
+   nothing has touched the state since (diagnostics / tests) */
+int pyrohip_state_halo_pending(pyrohip_state *s, int *flag);
 int pyrohip_allreduce_min(pyrohip_ctx *ctx, double *value);
 int pyrohip_allreduce_max(pyrohip_ctx *ctx, double *value);
 

@@ -145,6 +145,8 @@ _PROTOS = {
     "pyrohip_comm_init": [_VP, C.c_int, C.c_int, C.c_char_p],
     "pyrohip_comm_destroy": [_VP],
     "pyrohip_halo_exchange": [_VP, C.c_int, C.c_int],
+    "pyrohip_state_set_neighbours": [_VP, C.c_int, C.c_int],
+    "pyrohip_state_halo_pending": [_VP, _IP],
     "pyrohip_allreduce_min": [_VP, _DP],
     "pyrohip_allreduce_max": [_VP, _DP],
 }

@@ -52,6 +52,18 @@ int pyrohip_comm_init(pyrohip_ctx *c, int nranks, int rank, const char *unique_i
     c->comm = (void *)comm;
     c->nranks = nranks;
     c->rank = rank;
+    // second communicator + stream for the overlapped halo exchange; without
+    // them (old RCCL, split refused) the exchange stays on the main stream
+    ncclComm_t comm2 = nullptr;
+    if (ncclCommSplit(comm, 0, rank, &comm2, nullptr) == ncclSuccess && comm2 != nullptr &&
+        hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&c->ev_boundary, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming) == hipSuccess) {
+        c->comm_halo = (void *)comm2;
+    } else {
+        if (comm2) ncclCommDestroy(comm2);
+        c->comm_halo = nullptr;
+    }
     return 0;
 }
 
@@ -60,8 +72,43 @@ int pyrohip_comm_destroy(pyrohip_ctx *c)
     if (!c || !c->comm) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+    if (c->comm_halo) ncclCommDestroy((ncclComm_t)c->comm_halo);
+    c->comm_halo = nullptr;
+    if (c->comm_stream) { (void)hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
+    if (c->ev_boundary) { (void)hipEventDestroy(c->ev_boundary); c->ev_boundary = nullptr; }
+    if (c->ev_halo) { (void)hipEventDestroy(c->ev_halo); c->ev_halo = nullptr; }
     ncclCommDestroy((ncclComm_t)c->comm);
     c->comm = nullptr;
+    return 0;
+}
+
+// one grouped send / recv pair per neighbour and variable for the planes at d
+static int post_halo(pyrohip_state *s, double *d, int rank_lo, int rank_hi, ncclComm_t comm,
+                     hipStream_t stream)
+{
+    const Geom &g = s->g;
+    const size_t cnt = (size_t)g.ng * g.pitch;   // ng whole rows, contiguous
+    PYRO_CHECK_NCCL(ncclGroupStart());
+    // order (per variable): send low rows -> lo, recv hi ghosts <- hi,
+    // send high rows -> hi, recv lo ghosts <- lo.  With lo == hi (two ranks,
+    // periodic) the per-peer FIFO matching pairs my hi ghosts with the peer's
+    // low rows and my lo ghosts with its high rows, as required.
+    for (int n = 0; n < s->nvar; n++) {
+        double *a = d + (size_t)n * g.plane;
+        if (rank_lo >= 0)
+            PYRO_CHECK_NCCL(ncclSend(a + (size_t)g.ilo * g.pitch, cnt, ncclDouble, rank_lo, comm,
+                                     stream));
+        if (rank_hi >= 0)
+            PYRO_CHECK_NCCL(ncclRecv(a + (size_t)(g.ihi + 1) * g.pitch, cnt, ncclDouble, rank_hi,
+                                     comm, stream));
+        if (rank_hi >= 0)
+            PYRO_CHECK_NCCL(ncclSend(a + (size_t)(g.ihi - g.ng + 1) * g.pitch, cnt, ncclDouble,
+                                     rank_hi, comm, stream));
+        if (rank_lo >= 0)
+            PYRO_CHECK_NCCL(ncclRecv(a, cnt, ncclDouble, rank_lo, comm, stream));
+    }
+    PYRO_CHECK_NCCL(ncclGroupEnd());
     return 0;
 }
 
@@ -73,30 +120,34 @@ int pyrohip_halo_exchange(pyrohip_state *s, int rank_lo, int rank_hi)
     PYRO_REQUIRE(rank_lo >= -1 && rank_lo < c->nranks && rank_hi >= -1 && rank_hi < c->nranks,
                  "neighbour rank out of range");
     if (rank_lo < 0 && rank_hi < 0) return 0;
-    const Geom &g = s->g;
-    PYRO_REQUIRE(g.nx >= g.ng, "slab thinner than the ghost width");
-    ncclComm_t comm = (ncclComm_t)c->comm;
-    const size_t cnt = (size_t)g.ng * g.pitch;   // ng whole rows, contiguous
-    PYRO_CHECK_NCCL(ncclGroupStart());
-    // order (per variable): send low rows -> lo, recv hi ghosts <- hi,
-    // send high rows -> hi, recv lo ghosts <- lo.  With lo == hi (two ranks,
-    // periodic) the per-peer FIFO matching pairs my hi ghosts with the peer's
-    // low rows and my lo ghosts with its high rows, as required.
-    for (int n = 0; n < s->nvar; n++) {
-        double *a = s->d + (size_t)n * g.plane;
-        if (rank_lo >= 0)
-            PYRO_CHECK_NCCL(ncclSend(a + (size_t)g.ilo * g.pitch, cnt, ncclDouble, rank_lo, comm,
-                                     c->stream));
-        if (rank_hi >= 0)
-            PYRO_CHECK_NCCL(ncclRecv(a + (size_t)(g.ihi + 1) * g.pitch, cnt, ncclDouble, rank_hi,
-                                     comm, c->stream));
-        if (rank_hi >= 0)
-            PYRO_CHECK_NCCL(ncclSend(a + (size_t)(g.ihi - g.ng + 1) * g.pitch, cnt, ncclDouble,
-                                     rank_hi, comm, c->stream));
-        if (rank_lo >= 0)
-            PYRO_CHECK_NCCL(ncclRecv(a, cnt, ncclDouble, rank_lo, comm, c->stream));
+    PYRO_REQUIRE(s->g.nx >= s->g.ng, "slab thinner than the ghost width");
+    if (s->halo_pending) {
+        // the step that produced this state posted the exchange already (beside
+        // its interior strips): the main stream only has to wait for it.  Any
+        // write to the state since then dropped the cached CFL minimum -- then
+        // the rows on the wire are stale and the exchange is done again.
+        s->halo_pending = false;
+        PYRO_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+        if (s->next_cfl_min > 0.0 && rank_lo == s->nb_lo && rank_hi == s->nb_hi) return 0;
     }
-    PYRO_CHECK_NCCL(ncclGroupEnd());
+    return post_halo(s, s->d, rank_lo, rank_hi, (ncclComm_t)c->comm, c->stream);
+}
+
+int pyrohip_state_halo_pending(pyrohip_state *s, int *flag)
+{
+    PYRO_REQUIRE(s && flag, "NULL argument");
+    *flag = (s->halo_pending && s->next_cfl_min > 0.0) ? 1 : 0;
+    return 0;
+}
+
+int pyrohip_state_set_neighbours(pyrohip_state *s, int rank_lo, int rank_hi)
+{
+    PYRO_REQUIRE(s, "NULL state");
+    pyrohip_ctx *c = s->ctx;
+    PYRO_REQUIRE(rank_lo >= -1 && rank_lo < c->nranks && rank_hi >= -1 && rank_hi < c->nranks,
+                 "neighbour rank out of range");
+    s->nb_lo = rank_lo; s->nb_hi = rank_hi;
+    s->nb_set = (rank_lo >= 0 || rank_hi >= 0);
     return 0;
 }
 
@@ -138,6 +189,22 @@ int pyrohip_allreduce_max(pyrohip_ctx *c, double *value)
 }  // extern "C"
 
 namespace pyro {
+bool comm_can_overlap(const pyrohip_state *s)
+{
+    const pyrohip_ctx *c = s->ctx;
+    return c->comm_halo != nullptr && c->comm_stream != nullptr;
+}
+
+int comm_post_halo(pyrohip_state *s, double *d)
+{
+    pyrohip_ctx *c = s->ctx;
+    PYRO_CHECK_HIP(hipEventRecord(c->ev_boundary, c->stream));
+    PYRO_CHECK_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
+    PYRO_TRY(post_halo(s, d, s->nb_lo, s->nb_hi, (ncclComm_t)c->comm_halo, c->comm_stream));
+    PYRO_CHECK_HIP(hipEventRecord(c->ev_halo, c->comm_stream));
+    return 0;
+}
+
 int comm_allreduce_min_device(pyrohip_ctx *c, double *d)
 {
     if (c->comm == nullptr) return 0;

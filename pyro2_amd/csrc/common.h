@@ -88,7 +88,14 @@ struct pyrohip_ctx {
     pyro::DevBuf staging;     // AoS <-> planar staging
     pyro::DevBuf reduce;      // reduction scratch (device)
     void *reduce_host = nullptr;  // pinned host words for scalar results
-    void *comm = nullptr;     // ncclComm_t
+    void *comm = nullptr;     // ncclComm_t (scalar all-reduces, synchronous halo exchange)
+    // overlapped halo exchange (comm.hip): its own communicator (split off `comm`)
+    // on its own stream, so that the point-to-point traffic of step n+1's halos
+    // runs beside the interior strips of step n and never interleaves with the
+    // dt all-reduce on `stream`
+    void *comm_halo = nullptr;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_boundary = nullptr, ev_halo = nullptr;
     int nranks = 1, rank = 0;
     bool global_cfl = false;  // all-reduce the step kernels' CFL minimum on the device
     int num_cus = 0;
@@ -114,6 +121,12 @@ namespace pyro {
 // in-place min all-reduce of one device double over the context's communicator
 // on its stream; no-op without a communicator (comm.hip / tests/emu/comm_emu.cpp)
 int comm_allreduce_min_device(pyrohip_ctx *c, double *d);
+// can the halo exchange of a state be posted beside a running kernel?
+bool comm_can_overlap(const pyrohip_state *s);
+// post the exchange of the ng boundary rows of the planes at `d` (laid out like
+// the state's) with the state's neighbours on the halo stream: it starts when
+// everything queued on the context's stream so far is done and signals ev_halo
+int comm_post_halo(pyrohip_state *s, double *d);
 // plain ghost fill (x sides, then y sides) of cnt planes laid out like the
 // state's planes n0.. with the boundary types of those variables (ctx.hip)
 int fill_bc_planes(pyrohip_state *s, double *planes, int n0, int cnt);
@@ -163,6 +176,12 @@ struct pyrohip_state {
     int *d_flag = nullptr;    // positivity flag
     double *d_cval = nullptr; // per-variable ghost value of PYROHIP_BC_CONST sides
     pyro::SphGeom *sph = nullptr;   // SphericalPolar geometry (compressible solver)
+    // x neighbours of a slab (pyrohip_state_set_neighbours, -1 = none) and
+    // "the halo rows of this state are already on their way" (posted by the step
+    // that produced it; only meaningful while next_cfl_min is still cached, i.e.
+    // nothing touched the state since)
+    int nb_lo = -1, nb_hi = -1;
+    bool nb_set = false, halo_pending = false;
     double next_cfl_min = -1.0;  // min over interior of dx/(|u|+c) etc. of the
                                  // state after the last step (-1: unknown)
     bool cfl_is_global = false;  // ... already reduced over all ranks

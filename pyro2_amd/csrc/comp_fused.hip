@@ -387,6 +387,7 @@ int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP 
     P.solid_xl = p->solid_xl; P.solid_yl = p->solid_yl;
     P.ntj = P.ntiles = 0;
     P.L = P.ncb = 0;
+    P.sb_first = 0; P.sb_step = 1;
     PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
     return 0;
 }
@@ -394,18 +395,21 @@ int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP 
 // after the step kernel: ghost frame old -> new, minimum of the per-workgroup
 // CFL partials (all-reduced over the slabs when decomposed), positivity flag,
 // swap of the two state buffers
-int fused_finish(pyrohip_state *s, double *part, int nparts)
+void fused_copy_frame(pyrohip_state *s)
 {
     pyrohip_ctx *c = s->ctx;
     const Geom &g = s->g;
-    double *Uin = s->d;
-    double *Uout = s->alt_base + geom_lead(g);
-    {
-        const int rows_per_block = 256 / (2 * g.ng);
-        const int nby = 2 * g.ng + (g.nx + rows_per_block - 1) / rows_per_block;
-        hipLaunchKernelGGL(k_copy_frame4, dim3((g.qy + 255) / 256, nby), dim3(256), 0, c->stream,
-                           (const double *)Uin, Uout, g);
-    }
+    const int rows_per_block = 256 / (2 * g.ng);
+    const int nby = 2 * g.ng + (g.nx + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(k_copy_frame4, dim3((g.qy + 255) / 256, nby), dim3(256), 0, c->stream,
+                       (const double *)s->d, s->alt_base + geom_lead(g), g);
+}
+
+int fused_finish(pyrohip_state *s, double *part, int nparts, bool frame_copied)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    if (!frame_copied) fused_copy_frame(s);
     const double *dmin = launch_min_reduce(c->stream, part, nparts);
     s->cfl_is_global = false;
     if (c->global_cfl) {   // multi-GPU: the next dt needs the minimum over all slabs

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     HIP_DYNAMIC_SHARED(double, lds)
     const int l = threadIdx.x;
     double *st = lds + l;
-    const int cb = blockIdx.x % P.ncb, sb = blockIdx.x / P.ncb;
+    const int cb = blockIdx.x % P.ncb, sb = P.sb_first + (blockIdx.x / P.ncb) * P.sb_step;
     const int i0 = g.ilo + sb * P.L;                       // strip rows [i0, i1)
     const int i1 = (i0 + P.L < g.ihi + 1) ? i0 + P.L : g.ihi + 1;
     const int j = g.jlo + cb * WOUT - 4 + l;               // this lane's column
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     const double ax = st[ST_AX * 64], ay = st[ST_AY * 64];
     double cfl = fmin(ax > 0.0 ? pdiv(P.dx, ax) : INFINITY, ay > 0.0 ? pdiv(P.dy, ay) : INFINITY);
     cfl = wave_reduce_min(cfl);
-    if (l == 0) partial[blockIdx.x] = cfl;
+    if (l == 0) partial[sb * P.ncb + cb] = cfl;
 }
 
 // rows per strip: the strip count that minimises (rounds of resident
@@ -487,6 +487,22 @@ int comp_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
         {k_ctu_wave<2, false>, k_ctu_wave<2, true>}};
     const int solver = (p->riemann == 1 || p->riemann == 2) ? p->riemann : 0;
     const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
+    if (s->nb_set && nsb >= 3 && comm_can_overlap(s)) {
+        // slab of a decomposed run: the first and the last strip of
+        // rows -- the rows the neighbours need as their next halo -- go first; their
+        // exchange is posted on the halo stream and runs beside the interior strips
+        P.sb_first = 0; P.sb_step = nsb - 1;
+        PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(2 * P.ncb), dim3(64), WLDS_BYTES,
+                    (const double *)Uin, Uout, g, P, s->d_flag, part);
+        fused_copy_frame(s);           // old ghost frame -> new buffer, BEFORE the halos land in it
+        PYRO_TRY(comm_post_halo(s, Uout));
+        P.sb_first = 1; P.sb_step = 1;
+        PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3((nsb - 2) * P.ncb), dim3(64),
+                    WLDS_BYTES, (const double *)Uin, Uout, g, P, s->d_flag, part);
+        const int rc = fused_finish(s, part, nwg, true);
+        s->halo_pending = (rc == 0);
+        return rc;
+    }
     PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(nwg), dim3(64), WLDS_BYTES,
                 (const double *)Uin, Uout, g, P, s->d_flag, part);
     return fused_finish(s, part, nwg);

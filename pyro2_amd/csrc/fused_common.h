@@ -22,13 +22,15 @@ struct FP {   // kernel parameters
     const double *heat;
     int solid_xl, solid_yl;   // CGF wall rule (riemann.py:274-286)
     int L, ncb;               // row-marching kernel: rows per strip, column blocks
+    int sb_first, sb_step;    // ... strip of workgroup b: sb_first + (b / ncb) * sb_step
 };
 
 // host side, defined in comp_fused.hip
 __global__ void k_copy_frame4(const double *__restrict__ src, double *__restrict__ dst, Geom g);
 int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP &P, double *&Uin,
                   double *&Uout);
-int fused_finish(pyrohip_state *s, double *part, int nparts);
+int fused_finish(pyrohip_state *s, double *part, int nparts, bool frame_copied = false);
+void fused_copy_frame(pyrohip_state *s);
 
 __device__ __forceinline__ ConsN to_nf(const Cons &U, bool x)
 {

@@ -404,6 +404,16 @@ class DeviceState:
             check(self._l.pyrohip_comp_stage_dump(self.h, sid, dptr(out)))
         return out[:, :, 0] if ncomp == 1 else out
 
+    def set_neighbours(self, rank_lo, rank_hi):
+        """x neighbours of this slab: enables the overlapped halo exchange"""
+        with self.ctx.lock:
+            check(self._l.pyrohip_state_set_neighbours(self.h, int(rank_lo), int(rank_hi)))
+
+    def halo_pending(self):
+        f = C.c_int()
+        check(self._l.pyrohip_state_halo_pending(self.h, C.byref(f)))
+        return bool(f.value)
+
     def halo_exchange(self, rank_lo, rank_hi):
         with self.ctx.lock:
             check(self._l.pyrohip_halo_exchange(self.h, int(rank_lo), int(rank_hi)))

@@ -14,7 +14,18 @@ int pyrohip_comm_set_global_dt(pyrohip_ctx *, int on)
     if (on) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
     return 0;
 }
+int pyrohip_state_halo_pending(pyrohip_state *s, int *flag) { *flag = 0; (void)s; return 0; }
+int pyrohip_state_set_neighbours(pyrohip_state *s, int lo, int hi)
+{
+    // the emulated backend has no communicator: the neighbours only select the
+    // boundary-strips-first launch order of the row-marching kernel (the halos
+    // still travel through the host, tests/test_decomp_gloo.py)
+    s->nb_lo = lo; s->nb_hi = hi; s->nb_set = (lo >= 0 || hi >= 0);
+    return 0;
+}
 }
 namespace pyro {
 int comm_allreduce_min_device(pyrohip_ctx *, double *) { return 0; }
+bool comm_can_overlap(const pyrohip_state *) { return true; }
+int comm_post_halo(pyrohip_state *, double *) { return 0; }     // nothing to post: see above
 }

@@ -34,7 +34,9 @@ def _worker(rank, world, port, case, out_dir):
         nx, ny, nsteps = 40, 24, 6
         ic, meta, bcs = sedov_ic(nx, ny, r_init=0.12)
         dec = SlabDecomp(nx, world, rank)
-        kw = dict(dx=meta[3], dy=meta[4], kernel_set=rank % 2)   # mix staged / fused
+        # mix the kernel sets; rank 1: row-marching kernel with 5-row strips, i.e. the
+        # boundary-strips-first launch order of a slab with neighbours (4 strips)
+        kw = dict(dx=meta[3], dy=meta[4], kernel_set=2 * (rank % 2), march_rows=5)
         sl = SlabCompressible(ctx, dec, ny, bcs, kw, comm)
         a, b = dec.local_rows(4)
         sl.state.upload(np.ascontiguousarray(ic[a:b]))

@@ -58,3 +58,127 @@ def test_rccl_step_with_device_side_dt_allreduce(hip):
     hip.comm_set_global_dt(False)
     assert runs[0][1] == runs[1][1]
     assert np.array_equal(runs[0][0], runs[1][0])
+
+
+@pytest.mark.gpu
+def test_rccl_overlapped_halo_self_neighbour(hip):
+    """the overlapped exchange (boundary strips first, halos of the NEW state on the
+    halo stream / second communicator beside the interior strips, next step only
+    waits) on ONE GPU: a slab whose both x neighbours are the rank itself is the
+    periodic single-domain problem.  Sedov blast crossing the periodic x boundary,
+    kernel_set 2 with 16-row strips (8 strips), 12 steps: bit-identical to the run
+    with periodic boundaries and no communicator -- and to the synchronous
+    exchange."""
+    from pyro2_amd.decomp import DtPolicy
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from sedov_ic import sedov_ic
+    try:
+        hip.comm_init(1, 0, device.Context.comm_unique_id())
+    except Exception:
+        pass
+    hip.comm_set_global_dt(False)
+    nx, ng = 128, 4
+    ic, meta, _ = sedov_ic(nx, r_init=0.05)
+    ic = np.roll(np.nan_to_num(ic)[ng:-ng, ng:-ng], nx // 2 - 6, axis=0)     # blast next to the x boundary
+    full = np.zeros((nx + 2 * ng, nx + 2 * ng, 4))
+    full[ng:-ng, ng:-ng] = ic
+    P = device.make_comp_params(1.0 / nx, 1.0 / nx, fast_math=0, kernel_set=2, march_rows=16)
+
+    def run(mode):
+        bx = "periodic" if mode == "periodic" else "halo"
+        s = device.DeviceState(hip, nx, nx, ng, [[bx, bx, "outflow", "outflow"]] * 4)
+        s.upload(full)
+        if mode == "overlap":
+            s.set_neighbours(0, 0)
+        pol, dts = DtPolicy(0.1), []
+        for _ in range(12):
+            if mode != "periodic":
+                s.halo_exchange(0, 0)
+            s.fill_bc()
+            dt = pol(s.comp_dt(P, 0.8))
+            s.comp_step(P, dt)
+            assert s.halo_pending() == (mode == "overlap")     # the step posted the next exchange
+            pol.advance(dt)
+            dts.append(dt)
+        return s.download()[ng:-ng, ng:-ng], dts
+
+    ref, dref = run("periodic")
+    for mode in ("sync", "overlap"):
+        U, d = run(mode)
+        assert d == dref, mode
+        assert np.array_equal(U, ref), mode
+    assert np.abs(ref[:4, :, 2]).max() > 0.0          # the blast did reach the x boundary
+
+
+def _rccl_rank(rank, world, port, out_dir):
+    """one rank of the 2-GPU test below"""
+    import os
+    import sys
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from pyro2_amd import device as dv
+    from pyro2_amd.decomp import DtPolicy, RcclComm, SlabCompressible, SlabDecomp
+    from sedov_ic import sedov_ic
+    ctx = dv.Context(rank)
+    t = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        t = torch.frombuffer(bytearray(dv.Context.comm_unique_id()), dtype=torch.uint8).clone()
+    td.broadcast(t, 0)
+    ctx.comm_init(world, rank, bytes(t.numpy().tobytes()))
+    nx = 256
+    ic, meta, bcs = sedov_ic(nx, r_init=0.05)
+    dec = SlabDecomp(nx, world, rank)
+    kw = dict(dx=1.0 / nx, dy=1.0 / nx, fast_math=0, kernel_set=2, march_rows=16)
+    sl = SlabCompressible(ctx, dec, nx, bcs, kw, RcclComm(ctx))
+    a, b = dec.local_rows(4)
+    sl.state.upload(np.nan_to_num(ic)[a:b])
+    pol = DtPolicy(0.1)
+    dts = [sl.step(pol, 0.8) for _ in range(20)]
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), U=sl.state.download(), dts=np.array(dts),
+             rows=np.array([a, b]))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_two_ranks_bit_identical(hip, tmp_path):
+    """2 GPUs, one process each, x slabs exchanged over RCCL (overlapped with the
+    interior update) and the dt all-reduced on the device: bit-identical to the
+    single-GPU run.  Skipped on boxes with one GPU."""
+    if device.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import socket
+    import sys, os
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.dirname(__file__))
+    from sedov_ic import sedov_ic
+    from pyro2_amd.decomp import DtPolicy
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    mp.spawn(_rccl_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    nx, ng = 256, 4
+    ic, meta, bcs = sedov_ic(nx, r_init=0.05)
+    s = device.DeviceState(hip, nx, nx, ng, [["outflow"] * 4] * 4)
+    s.upload(np.nan_to_num(ic))
+    P = device.make_comp_params(1.0 / nx, 1.0 / nx, fast_math=0, kernel_set=2, march_rows=16)
+    pol, dts = DtPolicy(0.1), []
+    for _ in range(20):
+        s.fill_bc()
+        dt = pol(s.comp_dt(P, 0.8))
+        s.comp_step(P, dt)
+        pol.advance(dt)
+        dts.append(dt)
+    ref = s.download()
+    for r in range(2):
+        d = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        assert list(d["dts"]) == dts, r
+        a, b = d["rows"]
+        assert np.array_equal(d["U"][ng:-ng, ng:-ng], ref[a + ng:b - ng, ng:-ng]), r
