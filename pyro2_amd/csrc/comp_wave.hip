@@ -427,8 +427,15 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 const size_t ko = (size_t)(i - 1) * p + j;
                 if (P.have_src)   // simulation.py:406-423
                     grav_update(Un, Uc, UC(GRAV), UC(DT), UC(HEATR), P.heat ? P.heat[ko] : 0.0);
+#if defined(PYRO_WAVE_NT_STORE) && !defined(PYRO_EMU)
+                __builtin_nontemporal_store(Un.d, &Uout[ko]);
+                __builtin_nontemporal_store(Un.E, &Uout[pl + ko]);
+                __builtin_nontemporal_store(Un.mx, &Uout[2 * pl + ko]);
+                __builtin_nontemporal_store(Un.my, &Uout[3 * pl + ko]);
+#else
                 Uout[ko] = Un.d; Uout[pl + ko] = Un.E; Uout[2 * pl + ko] = Un.mx;
                 Uout[3 * pl + ko] = Un.my;
+#endif
                 double ax, ay;   // CFL: running maxima of the divisors, one division at the end
                 cfl_speeds(Un, UC(GAMMA), ax, ay);
                 st[ST_AX * 64] = fmax(st[ST_AX * 64], ax);
@@ -448,21 +455,15 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     if (l == 0) partial[sb * P.ncb + cb] = cfl;
 }
 
-// rows per strip: the strip count that minimises (rounds of resident
-// wavefronts) x (iterations per strip)
+// rows per strip: about four rounds of resident wavefronts, so that the dynamic
+// dispatch evens out the tail, within 32..128 rows (a strip costs L + 8
+// iterations).  Measured at 16384^2: 128 rows 11.91 ms, 400 rows 12.17 ms,
+// 600 rows 12.36 ms (profiles/r02_kernel_sets_by_size.txt)
 static int wave_rows(int nx, int ncb, int slots)
 {
-    int bestL = nx;
-    long best = 1L << 60;
-    for (int nsb = 1; nsb <= nx; nsb++) {
-        const int L = (nx + nsb - 1) / nsb;
-        if (L < 32 && nsb > 1) break;
-        const long wgs = (long)ncb * ((nx + L - 1) / L);
-        const long rounds = (wgs + slots - 1) / slots;
-        const long cost = rounds * (L + 8);
-        if (cost < best) { best = cost; bestL = L; }
-    }
-    return bestL;
+    long L = ((long)nx * ncb) / (4L * slots);
+    L = L < 32 ? 32 : (L > 128 ? 128 : L);
+    return L < nx ? (int)L : nx;
 }
 
 int comp_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
@@ -476,6 +477,10 @@ int comp_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     const int cus = c->num_cus > 0 ? c->num_cus : 256;
     P.L = wave_rows(g.nx, P.ncb, 4 * PYRO_WAVE_MINW * cus);
     if (p->march_rows > 0) P.L = p->march_rows < g.nx ? p->march_rows : g.nx;
+    else if (const char *e = getenv("PYRO_MARCH_ROWS")) {   // tuning knob (tools/march_ab.sh)
+        const int r = atoi(e);
+        if (r > 0) P.L = r < g.nx ? r : g.nx;
+    }
     const int nsb = (g.nx + P.L - 1) / P.L;
     const int nwg = P.ncb * nsb;
     PYRO_TRY(c->reduce.ensure((nwg + kMinStageBlocks + 2) * sizeof(double)));
