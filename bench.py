@@ -49,7 +49,7 @@ FP64_PEAK_FLOPS = 78.6e12           # MI355X FP64 vector peak (FMA = 2 flop), MI
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4  # wave-instructions/s: 1024 SIMDs, 4 cycles per FP64 wave-instruction
 # arithmetic minimum of one CTU + HLLC cell update (operation count of the
 # reference's formulas with every shared quantity computed once; FMA counted as 2)
-SEDOV_MIN_FLOPS_PER_CELL = 820
+SEDOV_MIN_FLOPS_PER_CELL = 880
 
 
 def parse():
