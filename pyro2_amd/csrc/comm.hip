@@ -143,9 +143,9 @@ int pyrohip_state_halo_pending(pyrohip_state *s, int *flag)
 int pyrohip_state_set_neighbours(pyrohip_state *s, int rank_lo, int rank_hi)
 {
     PYRO_REQUIRE(s, "NULL state");
-    pyrohip_ctx *c = s->ctx;
-    PYRO_REQUIRE(rank_lo >= -1 && rank_lo < c->nranks && rank_hi >= -1 && rank_hi < c->nranks,
-                 "neighbour rank out of range");
+    // (no upper bound: without a communicator -- halos staged through the host --
+    // the neighbours only select the launch order, see comp_step_wave)
+    PYRO_REQUIRE(rank_lo >= -1 && rank_hi >= -1, "neighbour rank out of range");
     s->nb_lo = rank_lo; s->nb_hi = rank_hi;
     s->nb_set = (rank_lo >= 0 || rank_hi >= 0);
     return 0;

@@ -57,7 +57,7 @@ if out["mg"]:
                          "note": "fabric bytes (FETCH_SIZE doubled, WRITE_SIZE as reported) of every multigrid kernel "
                                  "of the bench leg (setup + solve: 2 warm-up + 10 timed V-cycles); LDS / VALU: "
                                  "SQ_ACTIVE_INST_* quad-cycles summed over the SIMDs / (1024 SIMDs x busy cycles)"}
-json.dump(out, open("profiles/${TAG}_also_traffic.json", "w"), indent=1)
+json.dump(out, open("$O/${TAG}_also_traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k.endswith("summary")}, indent=1))
 PY
 find $O -name "*.db" -delete 2>/dev/null; find $O -name "*.csv" -size +3M -delete 2>/dev/null
