@@ -102,17 +102,7 @@ class Dist:
         self.td = None
         if world > 1:
             import torch.distributed as td
-            # gloo announces its connections on the C stdout; rank 0's stdout
-            # carries exactly ONE JSON line, so park fd 1 on stderr meanwhile
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                td.init_process_group("gloo", rank=self.rank, world_size=world)
-            finally:
-                sys.stdout.flush()
-                os.dup2(saved, 1)
-                os.close(saved)
+            td.init_process_group("gloo", rank=self.rank, world_size=world)
             self.td = td
 
     def barrier(self):
@@ -402,6 +392,12 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "RANK" not in os.environ:
         return self_spawn(args)
+    # stdout carries exactly ONE JSON line: libraries that announce themselves on the
+    # C stdout (RCCL's version banner at communicator creation, gloo) are sent to
+    # stderr for the whole run, the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -553,7 +549,7 @@ def main():
                              "multigrid": bench_mg(ctx, device),
                              "incompressible": bench_incompressible(ctx, device)})
                 out["also"] = also
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     dist.barrier()
 
 
