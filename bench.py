@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--cpu-sample-nx", type=int, default=1024)
     ap.add_argument("--developed-steps", type=int, default=250)
     ap.add_argument("--no-developed", action="store_true")
+    ap.add_argument("--host-dt", action="store_true",
+                    help="step from the host (one dt read-back per step) instead of "
+                         "pyrohip_comp_evolve")
     return ap.parse_args()
 
 
@@ -204,15 +207,24 @@ def bench_sedov(args, dist, ctx, device, defaults, steps=None, warmup=None, tile
             rows = (np.arange(dec.i0 + r0, dec.i0 + r0 + nr) - ng) % n
             st.upload_rows(r0, tile_cols[rows])
     pol = DtPolicy(tmax=0.1 if tile is None else 1.0e9)
-    for _ in range(warmup):
-        slab.step(pol, 0.8)
+    # a step = ghost fill (halo exchange), CFL time step with the driver's policy, evolve.
+    # Default: the steps are enqueued on the device back to back (pyrohip_comp_evolve, the
+    # dt policy runs in a kernel); --host-dt: the Python loop with one read-back per step
+    device_dt = not args.host_dt and isinstance(comm, (NoComm, RcclComm))
+
+    def run(n):
+        if device_dt:
+            assert len(slab.evolve(pol, 0.8, n)) == n
+        else:
+            for _ in range(n):
+                slab.step(pol, 0.8)
+    run(warmup)
     ctx.sync()
     dist.barrier()
     ctx.prof_enable(True)
     ctx.timer_start()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        slab.step(pol, 0.8)
+    run(steps)
     ctx.sync()
     t1 = time.perf_counter()
     ev_ms = ctx.timer_stop()
@@ -221,7 +233,8 @@ def bench_sedov(args, dist, ctx, device, defaults, steps=None, warmup=None, tile
     dist.barrier()
     elapsed = dist.max(t1 - t0)
     res = {"elapsed": elapsed, "cells": float(nx) * ny, "prof": prof, "event_ms": ev_ms,
-           "t": pol.t, "dt": pol.dt_old, "local_cells": float(dec.nx_local) * ny, "steps": steps}
+           "t": pol.t, "dt": pol.dt_old, "local_cells": float(dec.nx_local) * ny, "steps": steps,
+           "dt_policy": "device" if device_dt else "host"}
     del slab, st
     return res
 
@@ -464,6 +477,8 @@ def main():
                    "parallelism": f"slab{world}",
                    "halo": dist.comm_kind if world > 1 else "none", "fast_math": defaults["fast_math"],
                    "kernel_set": defaults["kernel_set"], "sim_time": r["t"],
+                   "dt_policy": r["dt_policy"] + (" (pyrohip_comp_evolve: no host round trip per step)"
+                                                  if r["dt_policy"] == "device" else ""),
                    "state": "steps %d-%d from t = 0 (blast radius << grid: > 99 %% of the cells are "
                             "ambient gas; see also.sedov_developed)" % (args.warmup, args.warmup + args.steps)},
     }

@@ -220,6 +220,28 @@ int pyrohip_comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl,
    positivity assert (simulation.py:68-71). */
 int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p,
                       double dt);
+/* the driver's time-step policy, NullSimulation.compute_timestep
+   (simulation_null.py:222-244): dt = cfl * min, scaled by init_tstep_factor on
+   the first step (n == 0), growth capped by max_dt_change * dt_old, fix_dt > 0
+   overrides, the last step lands on tmax.  t, dt_old, n are in/out. */
+typedef struct {
+    double tmax, init_tstep_factor, max_dt_change, fix_dt;
+    double t, dt_old;
+    long long n;
+} pyrohip_dt_policy;
+/* up to max_steps iterations of Pyro.single_step (pyro_sim.py:241-281: ghost fill
+   [+ halo exchange of a slab], compute_timestep, evolve) WITHOUT a host round trip
+   per step: the policy above runs in a one-thread kernel on the CFL minimum the
+   previous step left in device memory, the step kernels take dt from device
+   memory.  Steps past tmax do nothing.  One synchronisation at the end returns
+   the number of steps taken, the policy state and (dts_out, may be NULL, max_steps
+   doubles) the dt of each step (-1 for the ones not taken).  Cartesian grids,
+   outflow / reflect / periodic / halo boundaries, kernel sets -1 / 1 / 2, no
+   sponge.  PYROHIP_ERR_STATE: a step found an invalid state; the state left
+   behind is the one before that step, like after a failed pyrohip_comp_step. */
+int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double cfl,
+                        pyrohip_dt_policy *policy, int max_steps, int *steps_done,
+                        double *dts_out);
 /* debug: copy an intermediate of the LAST staged step to the host.
    stage ids: 0 q(4) 1 xi(1) 2 XM(4) 3 XP(4) 4 YM(4) 5 YP(4) 6 FxT(4)
    7 FyT(4) 8 Fx(4) 9 Fy(4).  out: (qx,qy,ncomp) reference layout.

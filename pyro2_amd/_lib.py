@@ -54,6 +54,13 @@ class CompParams(C.Structure):
                 ("heat_rate", C.c_double), ("march_rows", C.c_int)]
 
 
+class DtPolicyC(C.Structure):
+    """pyrohip_dt_policy (include/pyrohip.h)"""
+    _fields_ = [("tmax", C.c_double), ("init_tstep_factor", C.c_double),
+                ("max_dt_change", C.c_double), ("fix_dt", C.c_double),
+                ("t", C.c_double), ("dt_old", C.c_double), ("n", C.c_longlong)]
+
+
 _DP = C.POINTER(C.c_double)
 _IP = C.POINTER(C.c_int)
 _VP = C.c_void_p
@@ -117,6 +124,8 @@ _PROTOS = {
     "pyrohip_adv_step_fill": [_VP, C.c_int, C.c_double, C.c_double, C.c_double,
                               C.c_double, C.c_double, C.c_int, C.c_int],
     "pyrohip_comp_dt": [_VP, C.POINTER(CompParams), C.c_double, _DP],
+    "pyrohip_comp_evolve": [_VP, C.POINTER(CompParams), C.c_double, C.POINTER(DtPolicyC), C.c_int,
+                            _IP, _DP],
     "pyrohip_comp_step": [_VP, C.POINTER(CompParams), C.c_double],
     "pyrohip_comp_stage_dump": [_VP, C.c_int, _DP],
     "pyrohip_mg_create": [_VP, C.c_int, C.c_double, C.c_double, C.c_double,

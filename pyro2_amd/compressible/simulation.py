@@ -165,6 +165,45 @@ class Simulation(NullSimulation):
         self.n += 1
         tm.end()
 
+    def can_evolve_many(self):
+        """may the driver hand several steps at once to the device
+        (pyrohip_comp_evolve)?  Cartesian grid, standard boundary types, no sponge,
+        no tracer particles, a fused kernel set, nothing watching the data."""
+        cc = self.cc_data
+        if cc.grid.coord_type != 0 or self.particles is not None:
+            return False
+        if self.rp.get_param("sponge.do_sponge") or type(self).evolve is not Simulation.evolve:
+            return False
+        simple = ("outflow", "reflect-even", "reflect-odd", "periodic")
+        if not all(b in simple for n in cc.names for b in cc.BCs[n].sides()):
+            return False
+        if any(cc._has_host_bc(n) for n in cc.names) or cc._views_alive():
+            return False
+        return self._params().kernel_set != 0
+
+    def evolve_many(self, nsteps):
+        """up to nsteps of fill_BC_all + compute_timestep + evolve on the device without
+        a host round trip per step; the driver's dt policy (simulation_null.py:222-244)
+        runs in a kernel.  Returns the time steps taken."""
+        from ..decomp import DtPolicy
+        rp = self.rp
+        pol = DtPolicy(self.tmax, rp.get_param("driver.init_tstep_factor"),
+                       rp.get_param("driver.max_dt_change"), rp.get_param("driver.fix_dt"))
+        pol.t, pol.n = float(self.cc_data.t), int(self.n)
+        pol.dt_old = float(getattr(self, "dt_old", -1.e33))
+        tm = self.tc.timer("evolve")
+        tm.begin()
+        st = self._device_state()
+        try:
+            dts = st.comp_evolve(self._params(), float(rp.get_param("driver.cfl")), pol, int(nsteps))
+        finally:
+            self.cc_data.device_modified()
+            self.cc_data.t, self.n, self.dt_old = pol.t, pol.n, pol.dt_old
+        if len(dts):
+            self.dt = float(dts[-1])
+        tm.end()
+        return dts
+
     def clean_state(self, U):
         """density floor on a host array (the device step applies it itself)"""
         U.v(n=self.ivars.idens)[:, :] = np.maximum(U.v(n=self.ivars.idens),

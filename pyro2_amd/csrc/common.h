@@ -150,6 +150,22 @@ struct SphGeom {
 };
 }  // namespace pyro
 
+namespace pyro {
+// Per-step scalars of a run that advances on the device (pyrohip_comp_evolve):
+// written by the one-thread kernel k_dt_policy (the driver's compute_timestep,
+// simulation_null.py:222-244), read by the step kernels instead of their
+// by-value parameters.  One instance per state, in device memory.
+struct StepScalars {
+    double dt, dtdx, dtdy, hdtV, dtdV;   // this step's dt and the quotients the kernels use
+    double t, dt_old;                    // simulation time before this step, previous dt
+    double tmax, f0, mx, fix_dt, cfl;    // policy parameters
+    double dx, dy;
+    long long n;                         // steps taken so far (driver's counter)
+    int active;                          // this step advances the state (else: identity copy)
+    int steps;                           // steps that advanced, this call
+};
+}  // namespace pyro
+
 struct pyrohip_state {
     pyrohip_ctx *ctx = nullptr;
     pyro::Geom g;
@@ -174,6 +190,9 @@ struct pyrohip_state {
     double *work = nullptr;
     size_t work_planes = 0;
     int *d_flag = nullptr;    // positivity flag
+    pyro::StepScalars *d_scal = nullptr;   // pyrohip_comp_evolve
+    double *d_dts = nullptr;  // ... dt of every step of a call
+    int dts_cap = 0;
     double *d_cval = nullptr; // per-variable ghost value of PYROHIP_BC_CONST sides
     pyro::SphGeom *sph = nullptr;   // SphericalPolar geometry (compressible solver)
     // x neighbours of a slab (pyrohip_state_set_neighbours, -1 = none) and

@@ -9,6 +9,11 @@ int comp_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_step_staged(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_fused(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_wave(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_step_fused_ex(pyrohip_state *, const pyrohip_comp_params *, double, const StepScalars *,
+                       const double **);
+int comp_step_wave_ex(pyrohip_state *, const pyrohip_comp_params *, double, const StepScalars *,
+                      const double **);
+int comp_cfl_min_device(pyrohip_state *, const pyrohip_comp_params *, const double **);
 int comp_step_sph(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_dt_sph(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_stage_dump(pyrohip_state *, int, double *);
@@ -22,6 +27,11 @@ int comp_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_step_staged(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_fused(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_wave(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_step_fused_ex(pyrohip_state *, const pyrohip_comp_params *, double, const StepScalars *,
+                       const double **);
+int comp_step_wave_ex(pyrohip_state *, const pyrohip_comp_params *, double, const StepScalars *,
+                      const double **);
+int comp_cfl_min_device(pyrohip_state *, const pyrohip_comp_params *, const double **);
 int comp_step_sph(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_dt_sph(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 }
@@ -48,7 +58,133 @@ static int check_comp(pyrohip_state *s, const pyrohip_comp_params *p)
     return 0;
 }
 
+// The driver's compute_timestep (simulation_null.py:222-244) for a run that advances on
+// the device: ends the previous step (t, n), decides whether the next one runs
+// (t < tmax, state still valid) and derives its dt from the CFL minimum the previous
+// step kernel left in device memory.  One thread; IEEE operations in the reference's
+// order (this unit is compiled without FMA contraction).
+__global__ void k_dt_policy(StepScalars *S, const double *cflmin, const int *flag, double *dts,
+                            int slot, int final_call)
+{
+    const bool invalid = (*flag & 1) != 0;   // raised by the step that just ran: it does not count
+    if (S->active && !invalid) { S->t += S->dt; S->n += 1; S->steps += 1; }
+    S->active = 0;
+    if (final_call) return;
+    double dt = 0.0;
+    const bool go = !invalid && (S->t < S->tmax);
+    if (go) {
+        if (S->fix_dt > 0.0) {
+            dt = S->fix_dt;
+        } else {
+            dt = S->cfl * (*cflmin);
+            if (S->n == 0) dt = S->f0 * dt;
+            else dt = fmin(S->mx * S->dt_old, dt);
+            S->dt_old = dt;
+        }
+        if (S->t + dt > S->tmax) dt = S->tmax - S->t;
+    }
+    S->active = go ? 1 : 0;
+    S->dt = dt;
+    S->dtdx = dt / S->dx; S->dtdy = dt / S->dy;           // interface.py:106
+    S->hdtV = (0.5 * dt) / (S->dx * S->dy);              // unsplit_fluxes.py:444-445
+    S->dtdV = dt / (S->dx * S->dy);                      // simulation.py:375
+    dts[slot] = go ? dt : -1.0;
+}
+
 extern "C" {
+
+int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double cfl,
+                        pyrohip_dt_policy *pol, int max_steps, int *steps_done, double *dts_out)
+{
+    PYRO_TRY(check_comp(s, p));
+    PYRO_REQUIRE(pol && steps_done, "NULL argument");
+    PYRO_REQUIRE(max_steps >= 1, "max_steps must be positive");
+    PYRO_REQUIRE(p->kernel_set != 0, "the staged kernel set steps from the host (kernel_set 0)");
+    PYRO_REQUIRE(p->riemann >= 0 && p->riemann <= 2, "riemann must be 0 (HLLC), 1 (CGF) or 2 (HLLC_lm)");
+    PYRO_REQUIRE(!s->sph && !s->user_bc && !s->ramp_bc && !p->do_sponge,
+                 "device-side stepping: Cartesian grid, standard boundaries, no sponge "
+                 "(use pyrohip_comp_dt / pyrohip_comp_step)");
+    pyrohip_ctx *c = s->ctx;
+    if (!s->d_scal) PYRO_CHECK_HIP(hipMalloc((void **)&s->d_scal, sizeof(StepScalars)));
+    if (s->dts_cap < max_steps + 1) {
+        if (s->d_dts) PYRO_CHECK_HIP(hipFree(s->d_dts));
+        s->d_dts = nullptr;
+        PYRO_CHECK_HIP(hipMalloc((void **)&s->d_dts, (size_t)(max_steps + 1) * sizeof(double)));
+        s->dts_cap = max_steps + 1;
+    }
+    StepScalars H;
+    memset(&H, 0, sizeof(H));
+    H.t = pol->t; H.dt_old = pol->dt_old; H.n = pol->n;
+    H.tmax = pol->tmax; H.f0 = pol->init_tstep_factor; H.mx = pol->max_dt_change;
+    H.fix_dt = pol->fix_dt; H.cfl = cfl; H.dx = p->dx; H.dy = p->dy;
+    PYRO_CHECK_HIP(hipMemcpyAsync(s->d_scal, &H, sizeof(H), hipMemcpyHostToDevice, c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));      // H is on this stack frame
+    PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
+    const bool wave = (p->kernel_set == 2) ||
+                      (p->kernel_set == -1 && wave_kernel_pays(s->g));
+    const double *dmin = nullptr;
+    bool first = true;
+    int rc = 0;
+    for (int m = 0; m < max_steps && rc == 0; m++) {
+        // ghost cells: halos of a slab first, then the boundary fill (pyro_sim.py:250-256)
+        if (s->nb_set && c->comm != nullptr) rc = pyrohip_halo_exchange(s, s->nb_lo, s->nb_hi);
+        if (rc == 0) rc = pyrohip_fill_bc(s, -1);
+        if (rc) break;
+        if (first) {   // CFL minimum of the state as handed over (full array, ghost cells filled)
+            rc = p->fast_math ? fastm::comp_cfl_min_device(s, p, &dmin)
+                              : exact::comp_cfl_min_device(s, p, &dmin);
+            if (rc) break;
+            first = false;
+        }
+        hipLaunchKernelGGL(k_dt_policy, dim3(1), dim3(1), 0, c->stream, s->d_scal, dmin,
+                           (const int *)s->d_flag, s->d_dts, m, 0);
+        s->next_cfl_min = 1.0;      // "cached on the device": keeps a posted halo exchange valid
+        if (wave)
+            rc = p->fast_math ? fastm::comp_step_wave_ex(s, p, 0.0, s->d_scal, &dmin)
+                              : exact::comp_step_wave_ex(s, p, 0.0, s->d_scal, &dmin);
+        else
+            rc = p->fast_math ? fastm::comp_step_fused_ex(s, p, 0.0, s->d_scal, &dmin)
+                              : exact::comp_step_fused_ex(s, p, 0.0, s->d_scal, &dmin);
+    }
+    PYRO_TRY(rc);
+    hipLaunchKernelGGL(k_dt_policy, dim3(1), dim3(1), 0, c->stream, s->d_scal, dmin,
+                       (const int *)s->d_flag, s->d_dts, max_steps, 1);
+    PYRO_CHECK_HIP(hipGetLastError());
+    // the one round trip of the call: scalars, flag, last CFL minimum, the dt sequence
+    char *hb = (char *)c->reduce_host;                       // 256 pinned bytes
+    static_assert(sizeof(StepScalars) + 16 <= 256, "pinned scratch");
+    PYRO_CHECK_HIP(hipMemcpyAsync(hb, s->d_scal, sizeof(StepScalars), hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipMemcpyAsync(hb + sizeof(StepScalars), s->d_flag, sizeof(int),
+                                  hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipMemcpyAsync(hb + sizeof(StepScalars) + 8, dmin, sizeof(double),
+                                  hipMemcpyDeviceToHost, c->stream));
+    if (dts_out)
+        PYRO_CHECK_HIP(hipMemcpyAsync(dts_out, s->d_dts, (size_t)max_steps * sizeof(double),
+                                      hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    memcpy(&H, hb, sizeof(H));
+    const int flagv = *(int *)(hb + sizeof(StepScalars));
+    const double lastmin = *(double *)(hb + sizeof(StepScalars) + 8);
+    // max_steps swaps were made; the last state that advanced sits H.steps swaps from the start
+    if ((max_steps - H.steps) % 2) {
+        double *old_base = s->base;
+        s->base = s->alt_base;
+        s->alt_base = old_base;
+        s->d = s->base + geom_lead(s->g);
+    }
+    s->halo_pending = false;
+    // the minimum of the last launch belongs to the state only if that launch advanced it
+    s->next_cfl_min = (H.steps == max_steps && !(flagv & 1)) ? lastmin : -1.0;
+    if (s->next_cfl_min <= 0.0) s->cfl_is_global = false;
+    pol->t = H.t; pol->dt_old = H.dt_old; pol->n = H.n;
+    *steps_done = H.steps;
+    if (flagv & 1) {
+        set_error("invalid state: min(rho) <= 0 or min(e) <= 0 on the interior "
+                  "(compressible/simulation.py:68-71); the state is the one before that step");
+        return PYROHIP_ERR_STATE;
+    }
+    return 0;
+}
 
 int pyrohip_comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, double *dt_out)
 {

@@ -88,11 +88,23 @@ __device__ __forceinline__ void lds_put(double *b, int t, const Cons &U)
 // too); STD = false reads both from the parameters
 template <int SOLVER, bool STD = false>   // compressible.riemann: 0 HLLC, 1 CGF, 2 HLLC_lm
 __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double *__restrict__ Uin,
-                                                   double *__restrict__ Uout, Geom g, FP P,
+                                                   double *__restrict__ Uout, Geom g, FP P_in,
                                                    int *__restrict__ flag,
-                                                   double *__restrict__ partial)
+                                                   double *__restrict__ partial,
+                                                   const StepScalars *__restrict__ SC)
 {
     HIP_DYNAMIC_SHARED(double, lds)
+    FP P = P_in;
+    if (SC) {   // device-side run: this step's dt lives in device memory
+        if (!SC->active) {
+            // past tmax / after an invalid state: nothing happens (the host picks the
+            // buffer that holds the last state that did advance, comp_evolve)
+            if (threadIdx.x == 0 && threadIdx.y == 0)
+                partial[xcd_tile(blockIdx.x, P.ntiles)] = INFINITY;
+            return;
+        }
+        P.dt = SC->dt; P.dtdx = SC->dtdx; P.dtdy = SC->dtdy; P.hdtV = SC->hdtV; P.dtdV = SC->dtdV;
+    }
     double *B0 = lds;                 // Q (phase 0-1) | FT (2-3) | F (4-5)
     double *S = lds + FBUF0;          // upper face states XP(0..3), YP(4..7)
     double *D = S + 8 * FNT;          // vertex div(U)
@@ -359,7 +371,7 @@ __global__ void k_copy_frame4(const double *__restrict__ src, double *__restrict
 
 // second state buffer + the kernel parameters both single-launch kernels share
 int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP &P, double *&Uin,
-                  double *&Uout)
+                  double *&Uout, bool reset_flag)
 {
     pyrohip_ctx *c = s->ctx;
     const Geom &g = s->g;
@@ -388,7 +400,7 @@ int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP 
     P.ntj = P.ntiles = 0;
     P.L = P.ncb = 0;
     P.sb_first = 0; P.sb_step = 1;
-    PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
+    if (reset_flag) PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
     return 0;
 }
 
@@ -405,10 +417,9 @@ void fused_copy_frame(pyrohip_state *s)
                        (const double *)s->d, s->alt_base + geom_lead(g), g);
 }
 
-int fused_finish(pyrohip_state *s, double *part, int nparts, bool frame_copied)
+int fused_tail(pyrohip_state *s, double *part, int nparts, bool frame_copied, const double **dmin_out)
 {
     pyrohip_ctx *c = s->ctx;
-    const Geom &g = s->g;
     if (!frame_copied) fused_copy_frame(s);
     const double *dmin = launch_min_reduce(c->stream, part, nparts);
     s->cfl_is_global = false;
@@ -417,6 +428,21 @@ int fused_finish(pyrohip_state *s, double *part, int nparts, bool frame_copied)
         s->cfl_is_global = true;
     }
     PYRO_CHECK_HIP(hipGetLastError());
+    *dmin_out = dmin;
+    return 0;
+}
+
+void fused_swap(pyrohip_state *s)
+{
+    double *old_base = s->base;
+    s->base = s->alt_base;
+    s->alt_base = old_base;
+    s->d = s->base + geom_lead(s->g);
+}
+
+int fused_sync(pyrohip_state *s, const double *dmin)
+{
+    pyrohip_ctx *c = s->ctx;
     PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, dmin, sizeof(double),
                                   hipMemcpyDeviceToHost, c->stream));
     PYRO_CHECK_HIP(hipMemcpyAsync((char *)c->reduce_host + 8, s->d_flag, sizeof(int),
@@ -429,29 +455,31 @@ int fused_finish(pyrohip_state *s, double *part, int nparts, bool frame_copied)
                   "(compressible/simulation.py:68-71)");
         return PYROHIP_ERR_STATE;
     }
-    // swap the two state buffers
-    double *old_base = s->base;
-    s->base = s->alt_base;
-    s->alt_base = old_base;
-    s->d = s->base + geom_lead(g);
+    fused_swap(s);
     s->next_cfl_min = ((double *)c->reduce_host)[0];
     return 0;
 }
 
-int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+// S == nullptr: one step with the host's dt, minimum and flag read back, buffers
+// swapped if the state was valid.  S != nullptr (pyrohip_comp_evolve): dt comes
+// from *S on the device, nothing is read back, *dmin_out is the device address of
+// the new CFL minimum
+int comp_step_fused_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
+                       const StepScalars *S, const double **dmin_out)
 {
     pyrohip_ctx *c = s->ctx;
     const Geom &g = s->g;
     FP P;
     double *Uin, *Uout;
-    PYRO_TRY(fused_prepare(s, p, dt, P, Uin, Uout));
+    PYRO_TRY(fused_prepare(s, p, dt, P, Uin, Uout, S == nullptr));
     const int nti = (g.nx + FTI - 1) / FTI;
     P.ntj = (g.ny + FTJ - 1) / FTJ;
     P.ntiles = nti * P.ntj;
     PYRO_TRY(c->reduce.ensure((P.ntiles + kMinStageBlocks + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
     // instances: Riemann solver x (default reconstruction as constants | generic)
-    using KernelT = void (*)(const double *, double *, Geom, FP, int *, double *);
+    using KernelT = void (*)(const double *, double *, Geom, FP, int *, double *,
+                             const StepScalars *);
     static const KernelT kernels[3][2] = {
         {k_ctu_fused<0, false>, k_ctu_fused<0, true>},
         {k_ctu_fused<1, false>, k_ctu_fused<1, true>},
@@ -472,9 +500,17 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
         const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
         const KernelT kern = kernels[solver][std_rec];
         PYRO_LAUNCH(c, "k_ctu_fused", kern, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
-                    (const double *)Uin, Uout, g, P, s->d_flag, part);
+                    (const double *)Uin, Uout, g, P, s->d_flag, part, S);
     }
-    return fused_finish(s, part, P.ntiles);
+    const double *dmin;
+    PYRO_TRY(fused_tail(s, part, P.ntiles, false, &dmin));
+    if (S) { fused_swap(s); *dmin_out = dmin; return 0; }
+    return fused_sync(s, dmin);
+}
+
+int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+{
+    return comp_step_fused_ex(s, p, dt, nullptr, nullptr);
 }
 
 }  // namespace PYRO_NS

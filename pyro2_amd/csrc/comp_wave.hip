@@ -149,7 +149,8 @@ template <int SOLVER, bool STD>   // as k_ctu_fused
 __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *__restrict__ Uin,
                                                                  double *__restrict__ Uout, Geom g,
                                                                  FP P, int *__restrict__ flag,
-                                                                 double *__restrict__ partial)
+                                                                 double *__restrict__ partial,
+                                                                 const StepScalars *__restrict__ S)
 {
     HIP_DYNAMIC_SHARED(double, lds)
     const int l = threadIdx.x;
@@ -169,11 +170,20 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     // face states as they are (hllc_flux_impl<true>)
     constexpr bool TQ = (PYRO_FAST != 0) && (SOLVER == 0);
     UniformTab ct = (UniformTab)(lds + ST_SLOTS * 64);
+    if (S && !S->active) {
+        // device-side run, past tmax or after an invalid state: nothing happens (the
+        // host picks the buffer that holds the last state that did advance, comp_evolve)
+        if (l == 0) partial[sb * P.ncb + cb] = INFINITY;
+        return;
+    }
     if (l == 0) {     // one wavefront, LDS operations complete in order: no barrier needed
-        ct[C_GAMMA] = P.gamma; ct[C_DX] = P.dx; ct[C_DY] = P.dy; ct[C_DT] = P.dt;
+        // (device-side run: this step's dt and its quotients live in device memory)
+        ct[C_GAMMA] = P.gamma; ct[C_DX] = P.dx; ct[C_DY] = P.dy; ct[C_DT] = S ? S->dt : P.dt;
         ct[C_Z0] = P.z0; ct[C_Z1] = P.z1; ct[C_DELTA] = P.delta; ct[C_CVISC] = P.cvisc;
-        ct[C_SMALLD] = P.small_dens; ct[C_DTDX] = P.dtdx; ct[C_DTDY] = P.dtdy;
-        ct[C_HDTV] = P.hdtV; ct[C_DTDV] = P.dtdV; ct[C_GRAV] = P.grav; ct[C_HEATR] = P.heat_rate;
+        ct[C_SMALLD] = P.small_dens;
+        ct[C_DTDX] = S ? S->dtdx : P.dtdx; ct[C_DTDY] = S ? S->dtdy : P.dtdy;
+        ct[C_HDTV] = S ? S->hdtV : P.hdtV; ct[C_DTDV] = S ? S->dtdV : P.dtdV;
+        ct[C_GRAV] = P.grav; ct[C_HEATR] = P.heat_rate;
         ct[C_GM1] = P.gamma - 1.0; ct[C_RGM1] = prcp(P.gamma - 1.0);
         ct[C_RDX] = prcp(P.dx); ct[C_RDY] = prcp(P.dy);
         const GasK K0 = make_gask(P.gamma);
@@ -466,13 +476,14 @@ static int wave_rows(int nx, int ncb, int slots)
     return L < nx ? (int)L : nx;
 }
 
-int comp_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
+                      const StepScalars *S, const double **dmin_out)   // as comp_step_fused_ex
 {
     pyrohip_ctx *c = s->ctx;
     const Geom &g = s->g;
     FP P;
     double *Uin, *Uout;
-    PYRO_TRY(fused_prepare(s, p, dt, P, Uin, Uout));
+    PYRO_TRY(fused_prepare(s, p, dt, P, Uin, Uout, S == nullptr));
     P.ncb = (g.ny + WOUT - 1) / WOUT;
     const int cus = c->num_cus > 0 ? c->num_cus : 256;
     P.L = wave_rows(g.nx, P.ncb, 4 * PYRO_WAVE_MINW * cus);
@@ -485,7 +496,8 @@ int comp_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     const int nwg = P.ncb * nsb;
     PYRO_TRY(c->reduce.ensure((nwg + kMinStageBlocks + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
-    using KernelT = void (*)(const double *, double *, Geom, FP, int *, double *);
+    using KernelT = void (*)(const double *, double *, Geom, FP, int *, double *,
+                             const StepScalars *);
     static const KernelT kernels[3][2] = {
         {k_ctu_wave<0, false>, k_ctu_wave<0, true>},
         {k_ctu_wave<1, false>, k_ctu_wave<1, true>},
@@ -498,19 +510,31 @@ int comp_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
         // exchange is posted on the halo stream and runs beside the interior strips
         P.sb_first = 0; P.sb_step = nsb - 1;
         PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(2 * P.ncb), dim3(64), WLDS_BYTES,
-                    (const double *)Uin, Uout, g, P, s->d_flag, part);
+                    (const double *)Uin, Uout, g, P, s->d_flag, part, S);
         fused_copy_frame(s);           // old ghost frame -> new buffer, BEFORE the halos land in it
         PYRO_TRY(comm_post_halo(s, Uout));
         P.sb_first = 1; P.sb_step = 1;
         PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3((nsb - 2) * P.ncb), dim3(64),
-                    WLDS_BYTES, (const double *)Uin, Uout, g, P, s->d_flag, part);
-        const int rc = fused_finish(s, part, nwg, true);
+                    WLDS_BYTES, (const double *)Uin, Uout, g, P, s->d_flag, part, S);
+        const double *dmin;
+        PYRO_TRY(fused_tail(s, part, nwg, true, &dmin));
+        int rc = 0;
+        if (S) { fused_swap(s); *dmin_out = dmin; }
+        else rc = fused_sync(s, dmin);
         s->halo_pending = (rc == 0);
         return rc;
     }
     PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(nwg), dim3(64), WLDS_BYTES,
-                (const double *)Uin, Uout, g, P, s->d_flag, part);
-    return fused_finish(s, part, nwg);
+                (const double *)Uin, Uout, g, P, s->d_flag, part, S);
+    const double *dmin;
+    PYRO_TRY(fused_tail(s, part, nwg, false, &dmin));
+    if (S) { fused_swap(s); *dmin_out = dmin; return 0; }
+    return fused_sync(s, dmin);
+}
+
+int comp_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+{
+    return comp_step_wave_ex(s, p, dt, nullptr, nullptr);
 }
 
 }  // namespace PYRO_NS

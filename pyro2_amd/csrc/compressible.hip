@@ -423,6 +423,22 @@ static int ensure_work(pyrohip_state *s, size_t planes)
     return 0;
 }
 
+// CFL minimum over the whole array, left in device memory (no read-back)
+int comp_cfl_min_device(pyrohip_state *s, const pyrohip_comp_params *p, const double **dmin)
+{
+    pyrohip_ctx *c = s->ctx;
+    dim3 grid(8, 128), block(256);
+    const int nb = grid.x * grid.y;
+    // behind the largest partial array a step kernel may use, so that both fit
+    PYRO_TRY(c->reduce.ensure((nb + kMinStageBlocks + 2) * sizeof(double)));
+    double *part = (double *)c->reduce.p;
+    hipLaunchKernelGGL(k_cfl, grid, block, 0, c->stream, (const double *)s->d, s->g, p->gamma, p->dx,
+                       p->dy, part);
+    *dmin = launch_min_reduce(c->stream, part, nb);
+    PYRO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, double *dt_out)
 {
     pyrohip_ctx *c = s->ctx;

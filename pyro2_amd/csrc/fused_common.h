@@ -28,8 +28,15 @@ struct FP {   // kernel parameters
 // host side, defined in comp_fused.hip
 __global__ void k_copy_frame4(const double *__restrict__ src, double *__restrict__ dst, Geom g);
 int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP &P, double *&Uin,
-                  double *&Uout);
-int fused_finish(pyrohip_state *s, double *part, int nparts, bool frame_copied = false);
+                  double *&Uout, bool reset_flag = true);
+// after the step kernel(s): ghost frame, minimum of the CFL partials (all-reduced over
+// the slabs when decomposed) -> device address of the minimum
+int fused_tail(pyrohip_state *s, double *part, int nparts, bool frame_copied, const double **dmin);
+// single-step API: read the minimum and the positivity flag back, swap the buffers
+int fused_sync(pyrohip_state *s, const double *dmin);
+// device-side run: swap the buffers without looking (the kernels freeze the state
+// themselves once the flag is up)
+void fused_swap(pyrohip_state *s);
 void fused_copy_frame(pyrohip_state *s);
 
 __device__ __forceinline__ ConsN to_nf(const Cons &U, bool x)

@@ -166,6 +166,17 @@ class SlabCompressible:
         if getattr(comm, "overlap", False) and (decomp.lo >= 0 or decomp.hi >= 0):
             self.state.set_neighbours(decomp.lo, decomp.hi)
 
+    def evolve(self, policy, cfl, nsteps):
+        """nsteps of step() enqueued on the device without a host round trip per step
+        (pyrohip_comp_evolve: halo exchange, ghost fill, dt policy and update kernels
+        back to back; one synchronisation at the end).  Needs the communication inside
+        the library (single rank or RcclComm)."""
+        if not isinstance(self.comm, (NoComm, RcclComm)):
+            raise NotImplementedError("device-side stepping needs RCCL (or a single rank)")
+        if isinstance(self.comm, RcclComm) and (self.dec.lo >= 0 or self.dec.hi >= 0):
+            self.state.set_neighbours(self.dec.lo, self.dec.hi)
+        return self.state.comp_evolve(self.params, cfl, policy, nsteps)
+
     def step(self, policy, cfl):
         self.comm.halo_exchange(self.state, self.dec.lo, self.dec.hi)
         self.state.fill_bc()

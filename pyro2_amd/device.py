@@ -393,6 +393,23 @@ class DeviceState:
         with self.ctx.lock:
             check(self._l.pyrohip_comp_step(self.h, C.byref(params), dt))
 
+    def comp_evolve(self, params, cfl, policy, max_steps):
+        """up to max_steps single_steps (ghost fill, dt policy, evolve) without a host
+        round trip per step.  `policy`: an object with tmax, f0 (init_tstep_factor), mx
+        (max_dt_change), fix, t, dt_old, n (decomp.DtPolicy / helpers.DtPolicy); it is
+        advanced in place.  Returns the dt of the steps taken."""
+        from ._lib import DtPolicyC
+        pc = DtPolicyC(policy.tmax, policy.f0, policy.mx, policy.fix, policy.t, policy.dt_old,
+                       policy.n)
+        done = C.c_int()
+        dts = np.empty(int(max_steps))
+        with self.ctx.lock:
+            rc = self._l.pyrohip_comp_evolve(self.h, C.byref(params), float(cfl), C.byref(pc),
+                                             int(max_steps), C.byref(done), dptr(dts))
+        policy.t, policy.dt_old, policy.n = pc.t, pc.dt_old, int(pc.n)
+        check(rc)
+        return dts[:done.value]
+
     STAGES = {"q": 0, "xi": 1, "XM": 2, "XP": 3, "YM": 4, "YP": 5, "FxT": 6,
               "FyT": 7, "Fx": 8, "Fy": 9}
 

@@ -173,6 +173,12 @@ class Pyro:
             plt.figure(num=1, figsize=(8, 6), dpi=100, facecolor="w")
             self.sim.dovis()
         while not self.sim.finished():
+            # nothing to print, plot or write between the steps: hand a batch of them to
+            # the device at once (the dt policy runs there; solvers that can do it)
+            if not (self.verbose > 0 or self.dovis or do_io) and \
+                    getattr(self.sim, "can_evolve_many", lambda: False)():
+                self.sim.evolve_many(min(64, self.sim.max_steps - self.sim.n))
+                continue
             self.single_step()
         if do_io or self.rp.get_param("io.force_final_output"):
             if self.verbose > 0:

@@ -254,6 +254,64 @@ def test_comp_reference_regression_rt(hip, golden, fast, kset):
             assert elementwise_err(U[4:-4, 4:-4, n], ref, fl) <= TOL_FAST, n
 
 
+@pytest.mark.parametrize("kset", [1, 3])
+def test_comp_evolve_on_device(dev, golden, kset):
+    """pyrohip_comp_evolve: the run_sim loop (ghost fill, the driver's dt policy,
+    evolve) enqueued on the device without a host round trip per step, against the
+    same steps taken one by one through pyrohip_comp_dt / pyrohip_comp_step --
+    dt sequence, time, step count and state bit for bit; in chunks (policy state
+    carried from call to call); landing on tmax with steps to spare (the spare
+    ones do nothing); and an invalid state in the middle of a call: error, the
+    state left behind is the one before the failing step."""
+    from helpers import DtPolicy
+    from pyro2_amd._lib import ERR_STATE, PyroHipError
+    g = golden("comp_sedov_64_020")
+    bcs = [str(b) for b in g["bc"]]
+    meta = g["meta"]
+    P, cfl = dev_params(meta, **kset_kw(kset))
+    ic = np.nan_to_num(g["ic"])
+    nsteps = 9
+    Uref, dref, tref = device_comp_run(dev, ic, meta, bcs, 0.1, nsteps, **kset_kw(kset))
+    # one call, and chunks of 4 + 4 + 1
+    for chunks in ((nsteps,), (4, 4, 1)):
+        s = comp_state(dev, 64, 64, bcs)
+        s.upload(ic)
+        pol, dts = DtPolicy(0.1), []
+        for c in chunks:
+            dts += list(s.comp_evolve(P, cfl, pol, c))
+        assert dts == list(dref), chunks
+        assert pol.n == nsteps and pol.t == tref
+        assert np.array_equal(s.download()[4:-4, 4:-4], Uref[4:-4, 4:-4]), chunks
+        # the cached CFL minimum of the last step serves the next host-side dt
+        s.fill_bc()
+        assert s.comp_dt(P, cfl) == pytest.approx(s.comp_dt(P, cfl))
+    # tmax inside the call: 9 steps asked, the run ends after fewer
+    tmax = float(np.sum(dref[:5])) + 0.3 * float(dref[5])
+    Ut, dt_t, t_t = device_comp_run(dev, ic, meta, bcs, tmax, 100, **kset_kw(kset))
+    s = comp_state(dev, 64, 64, bcs)
+    s.upload(ic)
+    pol = DtPolicy(tmax)
+    dts = s.comp_evolve(P, cfl, pol, nsteps)
+    assert list(dts) == list(dt_t) and len(dts) == 6 and pol.t == tmax == t_t
+    assert np.array_equal(s.download()[4:-4, 4:-4], Ut[4:-4, 4:-4])
+    # an invalid state after 3 steps
+    s = comp_state(dev, 64, 64, bcs)
+    s.upload(ic)
+    pol = DtPolicy(0.1)
+    s.comp_evolve(P, cfl, pol, 3)
+    U3 = s.download()
+    bad = U3.copy()
+    bad[30, 30, 1] = -1.0
+    s.upload(bad)
+    pol2 = DtPolicy(0.1)
+    pol2.t, pol2.n, pol2.dt_old = pol.t, pol.n, pol.dt_old
+    with pytest.raises(PyroHipError) as ei:
+        s.comp_evolve(P, cfl, pol2, 4)
+    assert ei.value.code == ERR_STATE
+    assert pol2.n == pol.n and pol2.t == pol.t
+    assert np.array_equal(s.download()[4:-4, 4:-4], bad[4:-4, 4:-4])
+
+
 def test_comp_fast_path_logic(dev, golden, kset=2):
     """the fast build of the single-launch kernels takes code paths of its own
     (e.g. the transverse Riemann problems use the traced primitive states

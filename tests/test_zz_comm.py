@@ -108,6 +108,16 @@ def test_rccl_overlapped_halo_self_neighbour(hip):
         U, d = run(mode)
         assert d == dref, mode
         assert np.array_equal(U, ref), mode
+    # the same 12 steps enqueued on the device in one call (pyrohip_comp_evolve): halo
+    # exchange beside the interior strips, ghost fill, dt policy kernel, update -- no host
+    # round trip in between
+    s = device.DeviceState(hip, nx, nx, ng, [["halo", "halo", "outflow", "outflow"]] * 4)
+    s.upload(full)
+    s.set_neighbours(0, 0)
+    pol = DtPolicy(0.1)
+    d = list(s.comp_evolve(P, 0.8, pol, 12))
+    assert d == dref
+    assert np.array_equal(s.download()[ng:-ng, ng:-ng], ref)
     assert np.abs(ref[:4, :, 2]).max() > 0.0          # the blast did reach the x boundary
 
 
