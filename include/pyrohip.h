@@ -278,6 +278,38 @@ int pyrohip_mg_set_bcval(pyrohip_mg *m, int side, const double *vals);
 int pyrohip_mg_zero(pyrohip_mg *m, int level, int var);        /* patch.py:562 */
 int pyrohip_mg_fill_bc(pyrohip_mg *m, int level, int var);
 int pyrohip_mg_smooth(pyrohip_mg *m, int level, int nsmooth);  /* MG.py:544-621 */
+/* Row windows: the building blocks of a V-cycle whose levels are split into x
+   slabs across GPUs (pyro2_amd/multigrid/slab.py; constant coefficients, levels
+   above 64^2).  Rows are 1-based interior rows of the (n+2, n+2) level arrays.
+   smooth_rows: ONE launch of the LDS tile smoother, nsweeps <= 5 red-black
+   iterations on rows [row0, row1]; the 2*nsweeps rows beyond them must hold the
+   neighbours' current values (physical boundaries are refreshed by the kernel);
+   prolong != 0: add the prolongation of the coarser level's solution while
+   staging (needs nsweeps + 1 coarse halo rows).  Identical, bit for bit, to what
+   the whole-level launch computes on those rows.
+   residual_restrict_rows: residual of the fine rows 2*crow0-1 .. 2*crow1 and its
+   restriction into the coarse right-hand side rows [crow0, crow1].
+   get_rows / set_rows: rows [i0, i0+ni) of a level array incl. ghost columns
+   (host staging of the halos; var 0 = v, 1 = f, 2 = r).
+   mark_zero: the level's solution is zero from here on (MG.py:658-659). */
+int pyrohip_mg_smooth_rows(pyrohip_mg *m, int level, int nsweeps, int row0, int row1,
+                           int prolong);
+int pyrohip_mg_residual_restrict_rows(pyrohip_mg *m, int fine, int crow0, int crow1);
+int pyrohip_mg_get_rows(pyrohip_mg *m, int level, int var, int i0, int ni, double *host);
+int pyrohip_mg_set_rows(pyrohip_mg *m, int level, int var, int i0, int ni, const double *host);
+int pyrohip_mg_mark_zero(pyrohip_mg *m, int level);
+/* the same row moves over RCCL, device to device (pyrohip_comm_init first):
+   exchange_rows: h halo rows on either side of the slab [row0, row1] with the x
+   neighbours (-1 = none), one grouped send / recv pair per neighbour;
+   send_rows / recv_rows: a block of rows to / from one peer (gather of the
+   right-hand side to, scatter of the solution from the rank that owns the
+   collapsed levels); several of them form one step between
+   pyrohip_comm_group(1) and pyrohip_comm_group(0). */
+int pyrohip_mg_exchange_rows(pyrohip_mg *m, int level, int var, int row0, int row1, int h,
+                             int rank_lo, int rank_hi);
+int pyrohip_mg_send_rows(pyrohip_mg *m, int level, int var, int i0, int ni, int peer);
+int pyrohip_mg_recv_rows(pyrohip_mg *m, int level, int var, int i0, int ni, int peer);
+int pyrohip_comm_group(int begin);
 int pyrohip_mg_residual(pyrohip_mg *m, int level);             /* MG.py:529-542 */
 int pyrohip_mg_restrict(pyrohip_mg *m, int fine_level);        /* patch.py:640-676 */
 int pyrohip_mg_prolong_add(pyrohip_mg *m, int fine_level);     /* patch.py:678-736 */

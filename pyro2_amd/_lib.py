@@ -140,6 +140,15 @@ _PROTOS = {
     "pyrohip_mg_zero": [_VP, C.c_int, C.c_int],
     "pyrohip_mg_fill_bc": [_VP, C.c_int, C.c_int],
     "pyrohip_mg_smooth": [_VP, C.c_int, C.c_int],
+    "pyrohip_mg_smooth_rows": [_VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
+    "pyrohip_mg_residual_restrict_rows": [_VP, C.c_int, C.c_int, C.c_int],
+    "pyrohip_mg_get_rows": [_VP, C.c_int, C.c_int, C.c_int, C.c_int, _DP],
+    "pyrohip_mg_set_rows": [_VP, C.c_int, C.c_int, C.c_int, C.c_int, _DP],
+    "pyrohip_mg_mark_zero": [_VP, C.c_int],
+    "pyrohip_mg_exchange_rows": [_VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
+    "pyrohip_mg_send_rows": [_VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
+    "pyrohip_mg_recv_rows": [_VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
+    "pyrohip_comm_group": [C.c_int],
     "pyrohip_mg_residual": [_VP, C.c_int],
     "pyrohip_mg_restrict": [_VP, C.c_int],
     "pyrohip_mg_prolong_add": [_VP, C.c_int],

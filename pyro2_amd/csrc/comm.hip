@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>
 
 #include "common.h"
+#include "mg_internal.h"
 
 namespace pyro {
 
@@ -148,6 +149,69 @@ int pyrohip_state_set_neighbours(pyrohip_state *s, int rank_lo, int rank_hi)
     PYRO_REQUIRE(rank_lo >= -1 && rank_hi >= -1, "neighbour rank out of range");
     s->nb_lo = rank_lo; s->nb_hi = rank_hi;
     s->nb_set = (rank_lo >= 0 || rank_hi >= 0);
+    return 0;
+}
+
+// ---- row moves of a slab-decomposed multigrid V-cycle (multigrid/slab.py) ----
+// Whole rows of a level array are contiguous (pitch doubles each), so a block of
+// rows is one message.
+int pyrohip_mg_exchange_rows(pyrohip_mg *m, int level, int var, int row0, int row1, int h,
+                             int rank_lo, int rank_hi)
+{
+    double *p = nullptr;
+    int pitch = 0;
+    pyrohip_ctx *c = nullptr;
+    PYRO_REQUIRE(h >= 1 && row1 - row0 + 1 >= h, "halo deeper than the slab");
+    PYRO_TRY(mg_rows_ptr(m, level, var, row0 - (rank_lo >= 0 ? h : 0),
+                         (row1 - row0 + 1) + (rank_lo >= 0 ? h : 0) + (rank_hi >= 0 ? h : 0), &p,
+                         &pitch, &c));
+    PYRO_REQUIRE(c->comm != nullptr, "communicator not initialised");
+    double *slab = p + (size_t)(rank_lo >= 0 ? h : 0) * pitch;      // row0
+    const size_t cnt = (size_t)h * pitch;
+    const size_t nrows = (size_t)(row1 - row0 + 1);
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    PYRO_CHECK_NCCL(ncclGroupStart());
+    if (rank_lo >= 0) {
+        PYRO_CHECK_NCCL(ncclSend(slab, cnt, ncclDouble, rank_lo, comm, c->stream));
+        PYRO_CHECK_NCCL(ncclRecv(slab - cnt, cnt, ncclDouble, rank_lo, comm, c->stream));
+    }
+    if (rank_hi >= 0) {
+        PYRO_CHECK_NCCL(ncclSend(slab + (nrows - h) * pitch, cnt, ncclDouble, rank_hi, comm, c->stream));
+        PYRO_CHECK_NCCL(ncclRecv(slab + nrows * pitch, cnt, ncclDouble, rank_hi, comm, c->stream));
+    }
+    PYRO_CHECK_NCCL(ncclGroupEnd());
+    return 0;
+}
+
+// rows [i0, i0 + ni) of a level array to / from one peer (gather to and scatter from
+// the rank that owns the collapsed levels); calls of one collective step are grouped
+// by the caller with pyrohip_comm_group(1) ... pyrohip_comm_group(0)
+int pyrohip_mg_send_rows(pyrohip_mg *m, int level, int var, int i0, int ni, int peer)
+{
+    double *p = nullptr;
+    int pitch = 0;
+    pyrohip_ctx *c = nullptr;
+    PYRO_TRY(mg_rows_ptr(m, level, var, i0, ni, &p, &pitch, &c));
+    PYRO_REQUIRE(c->comm != nullptr && peer >= 0 && peer < c->nranks, "bad peer / no communicator");
+    PYRO_CHECK_NCCL(ncclSend(p, (size_t)ni * pitch, ncclDouble, peer, (ncclComm_t)c->comm, c->stream));
+    return 0;
+}
+
+int pyrohip_mg_recv_rows(pyrohip_mg *m, int level, int var, int i0, int ni, int peer)
+{
+    double *p = nullptr;
+    int pitch = 0;
+    pyrohip_ctx *c = nullptr;
+    PYRO_TRY(mg_rows_ptr(m, level, var, i0, ni, &p, &pitch, &c));
+    PYRO_REQUIRE(c->comm != nullptr && peer >= 0 && peer < c->nranks, "bad peer / no communicator");
+    PYRO_CHECK_NCCL(ncclRecv(p, (size_t)ni * pitch, ncclDouble, peer, (ncclComm_t)c->comm, c->stream));
+    return 0;
+}
+
+int pyrohip_comm_group(int begin)
+{
+    if (begin) PYRO_CHECK_NCCL(ncclGroupStart());
+    else PYRO_CHECK_NCCL(ncclGroupEnd());
     return 0;
 }
 

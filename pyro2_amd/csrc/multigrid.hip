@@ -219,6 +219,8 @@ struct MGTile {
     const double *cv;
     int cpitch;
     int vin_zero;   // 1: take vin as 0 (down leg: MG.py:658-659 zeroes the coarse solutions)
+    int row0, row1; // interior rows the launch updates (whole level: 1, n; a slab of a
+                    // decomposed level: its rows -- the 2K apron rows beyond them are read)
 };
 
 // a / b for a divisor that is the same in every cell, with rb = RN(1 / b)
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
         gi0 = 0; gi1 = n + 1; gj0 = 0; gj1 = n + 1;
     } else {
         const int tile = xcd_tile(blockIdx.x, A.ntiles);
-        ti0 = 1 + (tile / A.ntj) * A.TI; ti1 = min(ti0 + A.TI - 1, n);
+        ti0 = A.row0 + (tile / A.ntj) * A.TI; ti1 = min(ti0 + A.TI - 1, A.row1);
         tj0 = 1 + (tile % A.ntj) * A.TJ; tj1 = min(tj0 + A.TJ - 1, n);
         gi0 = ti0 - H; gi1 = ti1 + H; gj0 = tj0 - H; gj1 = tj1 + H;
         if (!per_i) { gi0 = max(gi0, 0); gi1 = min(gi1, n + 1); }
@@ -974,10 +976,11 @@ __global__ __launch_bounds__(256) void k_mg_restrict(const double *__restrict__ 
 // re-reading r and one launch per level.
 __global__ __launch_bounds__(256) void k_mg_residual_restrict(
     const double *__restrict__ v, const double *__restrict__ f, double *__restrict__ r, int fpitch,
-    double *__restrict__ cf, int cpitch, int nc, double alpha, double beta, double dx2)
+    double *__restrict__ cf, int cpitch, int nc, double alpha, double beta, double dx2,
+    int ci0 = 0)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
+    const int i = ci0 + blockIdx.y;   // 0-based coarse row (ci0: first row of a slab)
     if (j >= nc) return;
     const size_t k00 = (size_t)(1 + 2 * i) * fpitch + (1 + 2 * j);
     auto res = [&](size_t k) {
@@ -1173,9 +1176,12 @@ static bool mg_prolong_fusable(pyrohip_mg *m, int level, int nsmooth)
            (L.n + 2) * (L.n + 2) > MGS_CELLS;
 }
 
-static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong = false)
+static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong = false,
+                           int row0 = 1, int row1 = -1)
 {
     MGLevel &L = m->lev[level];
+    if (row1 < 0) row1 = L.n;
+    const int nrows = row1 - row0 + 1;
 #ifndef PYRO_EMU
     static bool attr_set = false;
     if (!attr_set) {
@@ -1199,6 +1205,7 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
     A.cv = nullptr; A.cpitch = 0;
     if (prolong) { A.cv = m->lev[level - 1].v; A.cpitch = m->lev[level - 1].pitch; }
     A.vin_zero = 0;
+    A.row0 = row0; A.row1 = row1;
     if (m->v_is_zero[level]) {
         if (A.single) PYRO_TRY(mg_zero(m, level, 0));   // generic variant: materialise
         else A.vin_zero = 1;
@@ -1230,11 +1237,11 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
             }();
             if (target > 0) {
                 const int want = (target + A.ntj - 1) / A.ntj;
-                int ti = (L.n + want - 1) / want;
+                int ti = (nrows + want - 1) / want;
                 if (ti < 4) ti = 4;
                 if (ti < A.TI) A.TI = ti;
             }
-            const int nti = (L.n + A.TI - 1) / A.TI;
+            const int nti = (nrows + A.TI - 1) / A.TI;
             A.ntiles = nti * A.ntj;
             PYRO_LAUNCH(m->ctx, "k_mg_smooth_tile", (k_mg_smooth_tile<MGW_NT, MGW_LP>),
                         dim3(A.ntiles), dim3(MGW_NT), MGW_LDS, A);
@@ -1402,7 +1409,7 @@ static int mg_vcycle(pyrohip_mg *m, int level)
             PYRO_LAUNCH(m->ctx, "k_mg_residual_restrict", k_mg_residual_restrict,
                         dim3((Cc.n + bx - 1) / bx, Cc.n), dim3(bx), 0, (const double *)F.v,
                         (const double *)F.f, F.r, F.pitch, Cc.f, Cc.pitch, Cc.n, m->alpha, m->beta,
-                        F.dx * F.dx);
+                        F.dx * F.dx, 0);
         } else {
             PYRO_TRY(mg_residual(m, level));              // :724
             PYRO_TRY(mg_restrict(m, level));              // :731-732
@@ -1623,6 +1630,89 @@ int pyrohip_mg_prolong_add(pyrohip_mg *m, int fine)
     PYRO_REQUIRE(fine >= 1, "no coarser level");
     PYRO_TRY(mg_prolong_add(m, fine));
     PYRO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- row windows: building blocks of a V-cycle on x slabs (multigrid/slab.py) ----
+int pyrohip_mg_smooth_rows(pyrohip_mg *m, int level, int nsweeps, int row0, int row1, int prolong)
+{
+    MG_CHECK_LEVEL(m, level);
+    MGLevel &L = m->lev[level];
+    PYRO_REQUIRE(!m->vc && m->smoother != 0, "row windows: constant coefficients, tile smoother");
+    PYRO_REQUIRE((L.n + 2) * (L.n + 2) > MGS_CELLS, "row windows: levels above 64^2 only");
+    PYRO_REQUIRE(nsweeps >= 1 && nsweeps <= MGW_KMAX, "one launch: 1..5 iterations");
+    PYRO_REQUIRE(row0 >= 1 && row1 <= L.n && row0 <= row1, "rows outside the level");
+    PYRO_REQUIRE(!prolong || level > 0, "no coarser level to prolong from");
+    const int ks = m->kmax_small;
+    m->kmax_small = 0;                       // exactly `nsweeps` iterations in ONE launch
+    const int rc = mg_smooth_tiles(m, level, nsweeps, prolong != 0, row0, row1);
+    m->kmax_small = ks;
+    m->corners_stale[level] = true;
+    PYRO_CHECK_HIP(hipGetLastError());
+    return rc;
+}
+
+int pyrohip_mg_residual_restrict_rows(pyrohip_mg *m, int fine, int crow0, int crow1)
+{
+    MG_CHECK_LEVEL(m, fine);
+    PYRO_REQUIRE(fine >= 1 && !m->vc, "needs a coarser level, constant coefficients");
+    MGLevel &F = m->lev[fine], &Cc = m->lev[fine - 1];
+    PYRO_REQUIRE(crow0 >= 1 && crow1 <= Cc.n && crow0 <= crow1, "coarse rows outside the level");
+    const int bx = (Cc.n >= 256) ? 256 : 64;
+    PYRO_LAUNCH(m->ctx, "k_mg_residual_restrict", k_mg_residual_restrict,
+                dim3((Cc.n + bx - 1) / bx, crow1 - crow0 + 1), dim3(bx), 0, (const double *)F.v,
+                (const double *)F.f, F.r, F.pitch, Cc.f, Cc.pitch, Cc.n, m->alpha, m->beta,
+                F.dx * F.dx, crow0 - 1);
+    PYRO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// rows [i0, i0 + ni) of an (n+2, n+2) level array (ghost rows / columns included)
+int pyrohip_mg_get_rows(pyrohip_mg *m, int level, int var, int i0, int ni, double *host)
+{
+    MG_CHECK_LEVEL(m, level);
+    MGLevel &L = m->lev[level];
+    PYRO_REQUIRE(var >= 0 && var <= 2 && host, "bad var / NULL host");
+    PYRO_REQUIRE(i0 >= 0 && ni >= 1 && i0 + ni <= L.n + 2, "rows outside the array");
+    const int q = L.n + 2;
+    PYRO_CHECK_HIP(hipMemcpy2DAsync(host, q * sizeof(double),
+                                    plane(m, level, var) + (size_t)i0 * L.pitch,
+                                    L.pitch * sizeof(double), q * sizeof(double), ni,
+                                    hipMemcpyDeviceToHost, m->ctx->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+    return 0;
+}
+
+int pyrohip_mg_set_rows(pyrohip_mg *m, int level, int var, int i0, int ni, const double *host)
+{
+    MG_CHECK_LEVEL(m, level);
+    MGLevel &L = m->lev[level];
+    PYRO_REQUIRE(var >= 0 && var <= 2 && host, "bad var / NULL host");
+    PYRO_REQUIRE(i0 >= 0 && ni >= 1 && i0 + ni <= L.n + 2, "rows outside the array");
+    const int q = L.n + 2;
+    if (var == 0 && m->v_is_zero[level]) {   // rows are about to be written: materialise the zeros
+        PYRO_TRY(mg_zero(m, level, 0));
+        m->v_is_zero[level] = false;
+    }
+    PYRO_CHECK_HIP(hipMemcpy2DAsync(plane(m, level, var) + (size_t)i0 * L.pitch,
+                                    L.pitch * sizeof(double), host, q * sizeof(double),
+                                    q * sizeof(double), ni, hipMemcpyHostToDevice,
+                                    m->ctx->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+    return 0;
+}
+
+// the solution of `level` counts as zero from here on (the lazily zeroed coarse
+// solutions of MG.py:658-659: the first smoothing launch takes v = 0 while staging)
+int pyrohip_mg_mark_zero(pyrohip_mg *m, int level)
+{
+    MG_CHECK_LEVEL(m, level);
+    MGLevel &L = m->lev[level];
+    if (!m->vc && m->smoother != 0 && m->nsmooth > 0 &&
+        ((L.n + 2) * (L.n + 2) > MGS_CELLS || (m->coarse_kernel && level <= MGC_TOP)))
+        m->v_is_zero[level] = true;
+    else
+        PYRO_TRY(mg_zero(m, level, 0));
     return 0;
 }
 
@@ -1885,6 +1975,23 @@ int mg_finest(pyrohip_mg *m, MgFinest *out)
     const int Lf = m->nlevels - 1;
     const MGLevel &F = m->lev[Lf];
     *out = MgFinest{m->ctx, Lf, F.n, F.pitch, F.dx, F.v, F.f, F.r};
+    return 0;
+}
+
+int mg_rows_ptr(pyrohip_mg *m, int level, int var, int i0, int ni, double **ptr, int *pitch,
+                pyrohip_ctx **ctx)
+{
+    MG_CHECK_LEVEL(m, level);
+    MGLevel &L = m->lev[level];
+    PYRO_REQUIRE(var >= 0 && var <= 2, "bad var");
+    PYRO_REQUIRE(i0 >= 0 && ni >= 1 && i0 + ni <= L.n + 2, "rows outside the array");
+    if (var == 0 && m->v_is_zero[level]) {
+        PYRO_TRY(mg_zero(m, level, 0));
+        m->v_is_zero[level] = false;
+    }
+    *ptr = plane(m, level, var) + (size_t)i0 * L.pitch;
+    *pitch = L.pitch;
+    *ctx = m->ctx;
     return 0;
 }
 

@@ -517,6 +517,27 @@ class DeviceMG:
     def set_smoother(self, kind):
         self._call("pyrohip_mg_set_smoother", int(kind))
 
+    # ---- row windows (slab-decomposed V-cycle, multigrid/slab.py) ----------
+    def smooth_rows(self, level, nsweeps, row0, row1, prolong=False):
+        self._call("pyrohip_mg_smooth_rows", int(level), int(nsweeps), int(row0), int(row1),
+                   int(bool(prolong)))
+
+    def residual_restrict_rows(self, fine, crow0, crow1):
+        self._call("pyrohip_mg_residual_restrict_rows", int(fine), int(crow0), int(crow1))
+
+    def get_rows(self, level, var, i0, ni):
+        out = np.empty((int(ni), self._n(level)))
+        self._call("pyrohip_mg_get_rows", int(level), int(var), int(i0), int(ni), dptr(out))
+        return out
+
+    def set_rows(self, level, var, i0, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.ndim == 2 and a.shape[1] == self._n(level)
+        self._call("pyrohip_mg_set_rows", int(level), int(var), int(i0), a.shape[0], dptr(a))
+
+    def mark_zero(self, level):
+        self._call("pyrohip_mg_mark_zero", int(level))
+
     def set_helmholtz(self, alpha, beta):
         """new constant coefficients of (alpha - beta L) phi = f"""
         self._call("pyrohip_mg_set_helmholtz", float(alpha), float(beta))

@@ -1,0 +1,217 @@
+"""V-cycle of MG.CellCenterMG2d with the fine levels split into x slabs across the
+GPUs of one node and the coarse levels collapsed onto one GPU (north_star: "the
+multigrid coarse levels collapse to one GPU").
+
+The reference's multigrid is single-block (pyro/multigrid/MG.py:623-778 walks
+whole levels).  Here every rank holds the full level hierarchy of a
+`device.DeviceMG` but owns, on the levels above `collapse_n`, only its slab of
+rows; what it reads beyond the slab arrives as halo rows from its two x
+neighbours:
+
+* smoothing (MG.py:544-621): the LDS tile smoother advances K <= 5 red-black
+  iterations per launch by temporal blocking, which needs the 2K rows beyond the
+  slab as they were BEFORE the launch -- one exchange of 2K rows per launch (two
+  per smoothing with nsmooth = 10), after which the slab holds, bit for bit, what
+  the whole-level launch computes there;
+* residual + restriction (MG.py:529-542, patch.py:640-676): one halo row of v;
+  the restriction is local because slabs start on odd rows and hold an even
+  number of them; the new coarse right-hand side then needs its own 2K halo rows
+  (the smoother's apron cells are relaxed with THEIR right-hand side);
+* prolongation (patch.py:678-736, MG.py:745-748) rides on the first smoothing
+  launch of the up leg: K + 1 halo rows of the coarse solution;
+* levels of `collapse_n`^2 and below (0.5 MB at 256^2): the right-hand side is
+  gathered to rank 0, which runs the ordinary single-GPU V-cycle from there down
+  (`pyrohip_mg_vcycle`), and the rows of the solution each rank prolongs from are
+  scattered back.
+
+The communicator only has to move rows (`exchange`, `gather_rows`,
+`scatter_rows`): `HostRowComm` stages them through the host over a
+torch.distributed group (tests, gloo); on GPUs the same three moves are RCCL
+send / recv pairs on the level arrays (`RcclRowComm`; it needs two GPUs and has
+not run yet, tests/test_zz_comm.py::test_rccl_multigrid_slabs_two_ranks skips on
+one: DESIGN.md 6).
+"""
+import numpy as np
+
+KMAX = 5          # iterations per launch of the tile smoother (multigrid.hip MGW_KMAX)
+
+
+class HostRowComm:
+    """rows of level arrays between ranks, staged through the host (torch.distributed)"""
+
+    def __init__(self, td, rank, nranks):
+        self.td, self.rank, self.nranks = td, rank, nranks
+
+    def _send(self, a, dst, tag):
+        import torch
+        return self.td.isend(torch.from_numpy(np.ascontiguousarray(a)), dst, tag=tag)
+
+    def _recv(self, shape, src, tag):
+        import torch
+        buf = torch.empty(shape, dtype=torch.float64)
+        return buf, self.td.irecv(buf, src, tag=tag)
+
+    def exchange(self, mg, level, var, r0, r1, h):
+        """h halo rows on either side of the slab [r0, r1] of `var` on `level`"""
+        lo = self.rank - 1 if self.rank > 0 else -1
+        hi = self.rank + 1 if self.rank < self.nranks - 1 else -1
+        q = mg._n(level)
+        reqs, recvs = [], []
+        if lo >= 0:
+            reqs.append(self._send(mg.get_rows(level, var, r0, h), lo, 1))
+            buf, rq = self._recv((h, q), lo, 2)
+            reqs.append(rq)
+            recvs.append((r0 - h, buf))
+        if hi >= 0:
+            reqs.append(self._send(mg.get_rows(level, var, r1 - h + 1, h), hi, 2))
+            buf, rq = self._recv((h, q), hi, 1)
+            reqs.append(rq)
+            recvs.append((r1 + 1, buf))
+        for r in reqs:
+            r.wait()
+        for i0, buf in recvs:
+            mg.set_rows(level, var, i0, buf.numpy())
+
+    def gather_rows(self, mg, level, var, rows_of):
+        """every rank's slab rows_of(rank) of `var` on `level` -> rank 0's array"""
+        q = mg._n(level)
+        if self.rank == 0:
+            pend = []
+            for r in range(1, self.nranks):
+                a, b = rows_of(r)
+                buf, rq = self._recv((b - a + 1, q), r, 3)
+                pend.append((a, buf, rq))
+            for a, buf, rq in pend:
+                rq.wait()
+                mg.set_rows(level, var, a, buf.numpy())
+        else:
+            a, b = rows_of(self.rank)
+            self._send(mg.get_rows(level, var, a, b - a + 1), 0, 3).wait()
+
+    def scatter_rows(self, mg, level, var, rows_of):
+        """rows rows_of(rank) (array rows, ghost rows allowed) of rank 0's `var` -> each rank"""
+        q = mg._n(level)
+        if self.rank == 0:
+            reqs = []
+            for r in range(1, self.nranks):
+                a, b = rows_of(r)
+                reqs.append(self._send(mg.get_rows(level, var, a, b - a + 1), r, 4))
+            for rq in reqs:
+                rq.wait()
+        else:
+            a, b = rows_of(self.rank)
+            buf, rq = self._recv((b - a + 1, q), 0, 4)
+            rq.wait()
+            mg.set_rows(level, var, a, buf.numpy())
+
+
+class RcclRowComm:
+    """the same three moves device to device over RCCL (csrc/comm.hip); the context of
+    the DeviceMG must carry a communicator (Context.comm_init)"""
+
+    def __init__(self, rank, nranks):
+        self.rank, self.nranks = rank, nranks
+
+    def exchange(self, mg, level, var, r0, r1, h):
+        lo = self.rank - 1 if self.rank > 0 else -1
+        hi = self.rank + 1 if self.rank < self.nranks - 1 else -1
+        mg._call("pyrohip_mg_exchange_rows", int(level), int(var), int(r0), int(r1), int(h), lo, hi)
+
+    def _grouped(self, mg, calls):
+        from .._lib import check, lib
+        check(lib().pyrohip_comm_group(1))
+        try:
+            for fn, args in calls:
+                mg._call(fn, *args)
+        finally:
+            check(lib().pyrohip_comm_group(0))
+
+    def gather_rows(self, mg, level, var, rows_of):
+        if self.rank == 0:
+            calls = [("pyrohip_mg_recv_rows", (level, var, rows_of(r)[0],
+                                               rows_of(r)[1] - rows_of(r)[0] + 1, r))
+                     for r in range(1, self.nranks)]
+        else:
+            a, b = rows_of(self.rank)
+            calls = [("pyrohip_mg_send_rows", (level, var, a, b - a + 1, 0))]
+        self._grouped(mg, calls)
+
+    def scatter_rows(self, mg, level, var, rows_of):
+        if self.rank == 0:
+            calls = [("pyrohip_mg_send_rows", (level, var, rows_of(r)[0],
+                                               rows_of(r)[1] - rows_of(r)[0] + 1, r))
+                     for r in range(1, self.nranks)]
+        else:
+            a, b = rows_of(self.rank)
+            calls = [("pyrohip_mg_recv_rows", (level, var, a, b - a + 1, 0))]
+        self._grouped(mg, calls)
+
+
+class SlabMG:
+    """one rank's part of the decomposed V-cycle on a `device.DeviceMG`"""
+
+    def __init__(self, mg, comm, rank, nranks, collapse_n=256, nsmooth=10):
+        self.mg, self.comm, self.rank, self.R = mg, comm, rank, nranks
+        self.nsmooth = nsmooth
+        self.Lf = mg.nlevels - 1
+        if collapse_n < 64:
+            raise ValueError("levels of 64^2 and below live in single-workgroup kernels")
+        self.Lc = max(l for l in range(mg.nlevels) if 2 ** (l + 1) <= collapse_n)
+        if self.Lc >= self.Lf:
+            raise ValueError("nothing to decompose: the finest level is below the collapse size")
+        per = 2 ** (self.Lc + 2) // nranks
+        if per * nranks != 2 ** (self.Lc + 2) or per % 2 or per < 2 * KMAX:
+            raise ValueError("the coarsest decomposed level needs an even number of at least "
+                             f"{2 * KMAX} rows per rank")
+
+    def rows(self, level, rank=None):
+        """interior rows (1-based, inclusive) of a rank's slab on a level"""
+        rank = self.rank if rank is None else rank
+        per = 2 ** (level + 1) // self.R
+        return 1 + rank * per, (rank + 1) * per
+
+    def _smooth(self, level, v_is_zero=False, prolong=False):
+        r0, r1 = self.rows(level)
+        left, first = self.nsmooth, True
+        while left > 0:
+            k = min(left, KMAX)
+            if not (first and v_is_zero):       # a zero solution needs no halo
+                self.comm.exchange(self.mg, level, 0, r0, r1, 2 * k)
+            self.mg.smooth_rows(level, k, r0, r1, prolong=prolong and first)
+            left -= k
+            first = False
+
+    def _cycle(self, level):
+        mg = self.mg
+        r0, r1 = self.rows(level)
+        self._smooth(level, v_is_zero=level < self.Lf)                      # MG.py:722
+        self.comm.exchange(mg, level, 0, r0, r1, 1)
+        mg.residual_restrict_rows(level, *self.rows(level - 1))             # :724-732
+        if level - 1 > self.Lc:
+            # the smoother recomputes its 2K apron rows, right-hand side included: the
+            # neighbours' rows of the new coarse right-hand side, once per visit
+            self.comm.exchange(mg, level - 1, 1, *self.rows(level - 1), 2 * KMAX)
+            self._cycle(level - 1)                                          # :735
+            c0, c1 = self.rows(level - 1)
+            self.comm.exchange(mg, level - 1, 0, c0, c1, KMAX + 1)
+        else:                                                               # collapse
+            lc = level - 1
+            self.comm.gather_rows(mg, lc, 1, lambda r: self.rows(lc, r))
+            if self.rank == 0:
+                mg.vcycle(lc)
+            n = 2 ** (lc + 1)
+            self.comm.scatter_rows(mg, lc, 0, lambda r: (max(self.rows(lc, r)[0] - KMAX - 1, 0),
+                                                         min(self.rows(lc, r)[1] + KMAX + 1, n + 1)))
+        self._smooth(level, prolong=True)                                   # :745-758
+
+    def vcycle(self):
+        """one V-cycle from the finest level (MG.py:699-778), coarse solutions zeroed
+        first like MG.solve does (MG.py:658-659)"""
+        for l in range(self.Lf):
+            self.mg.mark_zero(l)
+        self._cycle(self.Lf)
+
+    def solution_rows(self):
+        """this rank's rows of the finest solution, ghost columns included"""
+        r0, r1 = self.rows(self.Lf)
+        return self.mg.get_rows(self.Lf, 0, r0, r1 - r0 + 1)

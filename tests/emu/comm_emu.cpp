@@ -14,6 +14,10 @@ int pyrohip_comm_set_global_dt(pyrohip_ctx *, int on)
     if (on) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
     return 0;
 }
+int pyrohip_mg_exchange_rows(pyrohip_mg *, int, int, int, int, int, int, int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
+int pyrohip_mg_send_rows(pyrohip_mg *, int, int, int, int, int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
+int pyrohip_mg_recv_rows(pyrohip_mg *, int, int, int, int, int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
+int pyrohip_comm_group(int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
 int pyrohip_state_halo_pending(pyrohip_state *s, int *flag) { *flag = 0; (void)s; return 0; }
 int pyrohip_state_set_neighbours(pyrohip_state *s, int lo, int hi)
 {

@@ -45,6 +45,27 @@ def _worker(rank, world, port, case, out_dir):
         res = sl.state.download()
         np.savez(os.path.join(out_dir, f"sedov_{rank}.npz"), U=res, dts=np.array(dts),
                  rows=np.array([a, b]))
+    elif case == "mg":
+        # multigrid V-cycles with the levels above 64^2 split into x slabs and the rest
+        # collapsed onto rank 0 (pyro2_amd/multigrid/slab.py)
+        from pyro2_amd.multigrid.slab import HostRowComm, SlabMG
+        nx, ncyc = 256, 2
+        x = (np.arange(nx + 2) - 0.5) / nx
+        X, Y = np.meshgrid(x, x, indexing="ij")
+        rhs = -2.0 * ((1 - 6 * X**2) * Y**2 * (1 - Y**2) + (1 - 6 * Y**2) * X**2 * (1 - X**2))
+        rng = np.random.default_rng(3)
+        v0 = np.zeros((nx + 2, nx + 2))
+        v0[1:-1, 1:-1] = 0.01 * rng.standard_normal((nx, nx))     # a start that is not symmetric
+        m = device.DeviceMG(ctx, nx)
+        L = m.nlevels - 1
+        m.set(L, 0, v0)
+        m.set(L, 1, rhs)
+        sm = SlabMG(m, HostRowComm(td, rank, world), rank, world, collapse_n=64)
+        for _ in range(ncyc):
+            sm.vcycle()
+        r0, r1 = sm.rows(L)
+        np.savez(os.path.join(out_dir, f"mg_{rank}.npz"), v=sm.solution_rows(), rows=np.array([r0, r1]),
+                 v0=v0, rhs=rhs)
     else:   # periodic advection, lo == hi for two ranks
         nx, ny, nsteps = 32, 16, 10
         dec = SlabDecomp(nx, world, rank, periodic=True)
@@ -119,3 +140,32 @@ def test_two_rank_periodic_advection_bit_identical(tmp_path):
         z = np.load(tmp_path / f"adv_{r}.npz")
         lo, hi = z["rows"]
         assert np.array_equal(z["U"][4:-4, 4:-4, 0], a[lo + 4:hi - 4, 4:-4]), r
+
+
+def test_multigrid_slabs_with_collapse(tmp_path):
+    """2 ranks, Poisson 256^2, levels 256^2 and 128^2 in x slabs (halo rows over gloo),
+    64^2 and below collapsed onto rank 0: two V-cycles, bit-identical to the
+    single-domain V-cycles of the same library (which the reference's own runs pin,
+    tests/test_device_multigrid.py)"""
+    _spawn("mg", tmp_path)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    from pyro2_amd import _lib, device
+    _lib.use_library(build_emu.LIB, allow_backends=("host-emu",))
+    ctx = device.Context(0)
+    d0 = np.load(os.path.join(str(tmp_path), "mg_0.npz"))
+    nx = d0["rhs"].shape[0] - 2
+    m = device.DeviceMG(ctx, nx)
+    L = m.nlevels - 1
+    m.set(L, 0, d0["v0"])
+    m.set(L, 1, d0["rhs"])
+    for _ in range(2):
+        for l in range(L):
+            m.mark_zero(l)
+        m.vcycle(L)
+    ref = m.get(L, 0)
+    for r in range(2):
+        d = np.load(os.path.join(str(tmp_path), f"mg_{r}.npz"))
+        a, b = d["rows"]
+        assert np.array_equal(d["v"][:, 1:-1], ref[a:b + 1, 1:-1]), r
+    assert np.abs(ref[1:-1, 1:-1]).max() > 0

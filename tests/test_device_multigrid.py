@@ -334,3 +334,111 @@ def test_mg_general(dev, golden, tmp_path, monkeypatch):
     assert max_rel_err(np.asarray(a.beta_edge[L].x)[1:nx + 2, 1:nx + 1],
                        g[pre + f"ex_l{L}"][1:nx + 2, 1:nx + 1]) <= tol
     assert max_rel_err(np.asarray(a.grids[L].get_var("alpha")), g[pre + f"alpha_l{L}"]) <= tol
+
+
+class _LockstepRows:
+    """the three row moves of multigrid/slab.py between `nranks` SlabMG instances that
+    run as threads of ONE process on one device: a mailbox and a barrier; library calls
+    never overlap (every thread holds `lock` except while it waits)"""
+
+    class Shared:
+        def __init__(self, nranks):
+            import threading
+            self.lock, self.barrier, self.box = threading.Lock(), threading.Barrier(nranks), {}
+
+    def __init__(self, shared, rank, nranks):
+        self.s, self.rank, self.nranks = shared, rank, nranks
+
+    def _sync(self):
+        self.s.lock.release()
+        try:
+            self.s.barrier.wait(timeout=120)
+        finally:
+            self.s.lock.acquire()
+
+    def exchange(self, mg, level, var, r0, r1, h):
+        lo = self.rank - 1 if self.rank > 0 else -1
+        hi = self.rank + 1 if self.rank < self.nranks - 1 else -1
+        self.s.box[(self.rank, "lo")] = mg.get_rows(level, var, r0, h)
+        self.s.box[(self.rank, "hi")] = mg.get_rows(level, var, r1 - h + 1, h)
+        self._sync()
+        if lo >= 0:
+            mg.set_rows(level, var, r0 - h, self.s.box[(lo, "hi")])
+        if hi >= 0:
+            mg.set_rows(level, var, r1 + 1, self.s.box[(hi, "lo")])
+        self._sync()
+
+    def gather_rows(self, mg, level, var, rows_of):
+        if self.rank:
+            a, b = rows_of(self.rank)
+            self.s.box[(self.rank, "g")] = mg.get_rows(level, var, a, b - a + 1)
+        self._sync()
+        if self.rank == 0:
+            for r in range(1, self.nranks):
+                mg.set_rows(level, var, rows_of(r)[0], self.s.box[(r, "g")])
+        self._sync()
+
+    def scatter_rows(self, mg, level, var, rows_of):
+        if self.rank == 0:
+            for r in range(1, self.nranks):
+                a, b = rows_of(r)
+                self.s.box[(r, "s")] = mg.get_rows(level, var, a, b - a + 1)
+        self._sync()
+        if self.rank:
+            mg.set_rows(level, var, rows_of(self.rank)[0], self.s.box[(self.rank, "s")])
+        self._sync()
+
+
+@pytest.mark.parametrize("nranks,nx,collapse", [(2, 256, 64), (4, 512, 128), (2, 1024, 256)])
+def test_mg_slab_vcycle_bit_identical(dev, nranks, nx, collapse):
+    """the V-cycle with its fine levels in x slabs and the coarse ones collapsed onto
+    slab 0 (multigrid/slab.py: row-window launches of the tile smoother and of the
+    residual+restriction, halo rows of v, of the coarse right-hand side and of the
+    coarse solution) is, bit for bit, the single-domain V-cycle.  The slabs are separate
+    DeviceMG hierarchies on one device, the rows move through the host; between
+    processes: tests/test_decomp_gloo.py (gloo) and tests/test_zz_comm.py (RCCL)."""
+    import threading
+    from pyro2_amd.multigrid.slab import SlabMG
+    if dev.kind == "emu" and nx > 512:
+        pytest.skip("size for the GPU")
+    x = (np.arange(nx + 2) - 0.5) / nx
+    X, Y = np.meshgrid(x, x, indexing="ij")
+    rhs = -2.0 * ((1 - 6 * X**2) * Y**2 * (1 - Y**2) + (1 - 6 * Y**2) * X**2 * (1 - X**2))
+    v0 = np.zeros((nx + 2, nx + 2))
+    v0[1:-1, 1:-1] = 0.01 * np.random.default_rng(3).standard_normal((nx, nx))
+    ref = device.DeviceMG(dev, nx)
+    L = ref.nlevels - 1
+    ref.set(L, 0, v0)
+    ref.set(L, 1, rhs)
+    for _ in range(2):
+        for l in range(L):
+            ref.mark_zero(l)
+        ref.vcycle(L)
+    want = ref.get(L, 0)
+
+    shared = _LockstepRows.Shared(nranks)
+    out, errs = {}, []
+
+    def rank_main(rank):
+        with shared.lock:
+            try:
+                m = device.DeviceMG(dev, nx)
+                m.set(L, 0, v0)
+                m.set(L, 1, rhs)
+                sm = SlabMG(m, _LockstepRows(shared, rank, nranks), rank, nranks, collapse_n=collapse)
+                for _ in range(2):
+                    sm.vcycle()
+                out[rank] = (sm.rows(L), sm.solution_rows())
+            except BaseException as e:          # noqa: BLE001 - reported below
+                errs.append((rank, e))
+                shared.barrier.abort()
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for r in range(nranks):
+        (a, b), v = out[r]
+        assert np.array_equal(v[:, 1:-1], want[a:b + 1, 1:-1]), r
+    assert np.abs(want[1:-1, 1:-1]).max() > 0

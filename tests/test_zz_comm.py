@@ -2,6 +2,8 @@
 the rank itself must reproduce the periodic x ghost fill (send/recv to self
 inside one group), and the scalar all-reduce must return its input.  The
 N > 1 logic is covered on CPU by tests/test_decomp_gloo.py (gloo)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -192,3 +194,109 @@ def test_rccl_two_ranks_bit_identical(hip, tmp_path):
         assert list(d["dts"]) == dts, r
         a, b = d["rows"]
         assert np.array_equal(d["U"][ng:-ng, ng:-ng], ref[a + ng:b - ng, ng:-ng]), r
+
+
+def _rccl_mg_rank(rank, world, port, out_dir):
+    """one rank of the 2-GPU multigrid test below"""
+    import os
+    import sys
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from pyro2_amd import device as dv
+    from pyro2_amd.multigrid.slab import RcclRowComm, SlabMG
+    ctx = dv.Context(rank)
+    t = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        t = torch.frombuffer(bytearray(dv.Context.comm_unique_id()), dtype=torch.uint8).clone()
+    td.broadcast(t, 0)
+    ctx.comm_init(world, rank, bytes(t.numpy().tobytes()))
+    d = np.load(os.path.join(out_dir, "in.npz"))
+    nx = d["rhs"].shape[0] - 2
+    m = dv.DeviceMG(ctx, nx)
+    L = m.nlevels - 1
+    m.set(L, 0, d["v0"])
+    m.set(L, 1, d["rhs"])
+    sm = SlabMG(m, RcclRowComm(rank, world), rank, world, collapse_n=256)
+    for _ in range(2):
+        sm.vcycle()
+    np.savez(os.path.join(out_dir, f"mg{rank}.npz"), v=sm.solution_rows(), rows=np.array(sm.rows(L)))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_multigrid_slabs_two_ranks(hip, tmp_path):
+    """2 GPUs: Poisson 2048^2 V-cycles, levels 2048^2..512^2 in x slabs with their halo
+    rows over RCCL, 256^2 and below collapsed onto rank 0 -- bit-identical to the
+    single-GPU V-cycles.  Skipped on boxes with one GPU (the same SlabMG runs on one GPU
+    with host-staged rows in tests/test_device_multigrid.py and over gloo in
+    tests/test_decomp_gloo.py)."""
+    if device.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import socket
+    import torch.multiprocessing as mp
+    nx = 2048
+    x = (np.arange(nx + 2) - 0.5) / nx
+    X, Y = np.meshgrid(x, x, indexing="ij")
+    rhs = -2.0 * ((1 - 6 * X**2) * Y**2 * (1 - Y**2) + (1 - 6 * Y**2) * X**2 * (1 - X**2))
+    v0 = np.zeros((nx + 2, nx + 2))
+    v0[1:-1, 1:-1] = 0.01 * np.random.default_rng(3).standard_normal((nx, nx))
+    np.savez(os.path.join(str(tmp_path), "in.npz"), v0=v0, rhs=rhs)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    mp.spawn(_rccl_mg_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    m = device.DeviceMG(hip, nx)
+    L = m.nlevels - 1
+    m.set(L, 0, v0)
+    m.set(L, 1, rhs)
+    for _ in range(2):
+        for l in range(L):
+            m.mark_zero(l)
+        m.vcycle(L)
+    ref = m.get(L, 0)
+    for r in range(2):
+        d = np.load(os.path.join(str(tmp_path), f"mg{r}.npz"))
+        a, b = d["rows"]
+        assert np.array_equal(d["v"][:, 1:-1], ref[a:b + 1, 1:-1]), r
+
+
+@pytest.mark.gpu
+def test_rccl_multigrid_row_moves_to_self(hip):
+    """the RCCL row moves of the slab V-cycle on ONE GPU: with the rank as its own low
+    (high) neighbour the halo rows below (above) the slab become copies of the slab's
+    first (last) rows, and a grouped send + recv to self copies a block of rows"""
+    from pyro2_amd._lib import check, lib
+    try:      # the context may already carry the 1-rank communicator of the tests above
+        hip.comm_init(1, 0, device.Context.comm_unique_id())
+    except Exception:
+        pass
+    nx = 256
+    m = device.DeviceMG(hip, nx)
+    L = m.nlevels - 1
+    a = np.random.default_rng(5).standard_normal((nx + 2, nx + 2))
+    for var in (0, 1):
+        m.set(L, var, a)
+        m._call("pyrohip_mg_exchange_rows", L, var, 65, 128, 10, 0, -1)
+        got = m.get(L, var)
+        want = a.copy()
+        want[55:65] = a[65:75]
+        assert np.array_equal(got, want)
+        m.set(L, var, a)
+        m._call("pyrohip_mg_exchange_rows", L, var, 65, 128, 6, -1, 0)
+        want = a.copy()
+        want[129:135] = a[123:129]
+        assert np.array_equal(m.get(L, var), want)
+    m.set(L, 0, a)
+    check(lib().pyrohip_comm_group(1))
+    m._call("pyrohip_mg_send_rows", L, 0, 3, 20, 0)
+    m._call("pyrohip_mg_recv_rows", L, 0, 100, 20, 0)
+    check(lib().pyrohip_comm_group(0))
+    want = a.copy()
+    want[100:120] = a[3:23]
+    assert np.array_equal(m.get(L, 0), want)
