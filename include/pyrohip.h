@@ -351,6 +351,24 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles,
 int pyrohip_comp_rk_rhs(pyrohip_state *y, const pyrohip_comp_params *p,
                         pyrohip_state *k, int slot);
 /* its CFL step (compressible_rk/simulation.py:46-56)                        */
+/* Arbitrary problem source terms (the `source_terms(myg, U, ivars, rp)` callback of
+   a problem module, compressible/simulation.py:157-159) are evaluated by the HOST;
+   the device applies them where the reference does.  Per step:
+     1. src_old := S_h(U^n) uploaded into a 4-variable state with the boundary types
+        of the reference's aux data (simulation.py:248-253; hse / ambient as outflow,
+        BC.py:56-63,146-151), ghost-filled (pyrohip_state_fill_bc);
+        pyrohip_state_set_source(s, 0, src_old);
+     2. pyrohip_comp_step: interface states with dt/2 (S_grav + S_h) (unsplit_fluxes.py:
+        295-328), fluxes, conservative update and the predictor U* = U + dt S(U^n)
+        (simulation.py:406-412) -- staged kernels, any kernel_set;
+     3. download U*, src_new := S_h(U*); pyrohip_state_set_source(s, 1, src_new);
+     4. pyrohip_comp_source_correct: U = U* + dt/2 (S(U*) - S(U^n)) with the
+        time-centred gravity of simulation.py:126-155, then the sponge.
+   The states passed in are borrowed (keep them alive); NULL removes the source.
+   Cartesian grids; excludes the heating profile and the ramp boundary. */
+int pyrohip_state_set_source(pyrohip_state *s, int which, pyrohip_state *src);
+int pyrohip_comp_source_correct(pyrohip_state *s, const pyrohip_comp_params *p, double dt);
+
 int pyrohip_comp_rk_dt(pyrohip_state *s, const pyrohip_comp_params *p,
                        double cfl, double *dt_out);
 /* RKIntegrator.get_stage_start / compute_final_update (pyro/mesh/

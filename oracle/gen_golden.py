@@ -794,6 +794,39 @@ def gen_compressible_heating():
     save("comp_heating", **out)
 
 
+def gen_compressible_general_source():
+    """an arbitrary problem source (tests/general_source.py: all four
+    components, state dependent) through the reference's predictor / corrector and
+    interface-state source terms -- outflow, hse (+ gravity), ambient + sponge, and
+    reflecting walls + gravity"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from general_source import source_terms
+    cases = [
+        ("sedov", {"mesh.nx": 24, "mesh.ny": 20, "driver.tmax": 100.0}, 10),
+        ("plume", {"mesh.nx": 16, "mesh.ny": 32, "plume.r_pert": 0.6}, 10),
+        ("convection", {"mesh.nx": 16, "mesh.ny": 48, "convection.thickness": 0.5}, 10),
+        ("rt", {"mesh.nx": 16, "mesh.ny": 48, "mesh.ylboundary": "reflect",
+                "mesh.yrboundary": "reflect", "mesh.xlboundary": "reflect",
+                "mesh.xrboundary": "outflow"}, 10),
+    ]
+    out = {"ncases": np.array(len(cases))}
+    for k, (prob, d, nsteps) in enumerate(cases):
+        p = Pyro("compressible")
+        p.initialize_problem(prob, inputs_dict=d)
+        sim = p.sim
+        sim.problem_source = source_terms
+        pre = f"c{k}_"
+        out[pre + "ic"] = np.array(sim.cc_data.data)
+        dts = []
+        for _ in range(nsteps):
+            p.single_step()
+            dts.append(sim.dt)
+        out[pre + "final"] = np.array(sim.cc_data.data)
+        out[pre + "dts"] = np.array(dts)
+        print("general source case", k, prob, "t", sim.cc_data.t)
+    save("comp_general_source", **out)
+
+
 def gen_problem_ics():
     """initial conditions of the remaining compressible problem set-ups"""
     cases = {"acoustic_pulse": {"mesh.nx": 24, "mesh.ny": 24},
@@ -1329,6 +1362,8 @@ if __name__ == "__main__":
         gen_compressible_ramp()
     if "comp_heating" in sys.argv[1:]:
         gen_compressible_heating()
+    if "comp_general_source" in sys.argv[1:]:
+        gen_compressible_general_source()
     if "problem_ics" in sys.argv[1:]:
         gen_problem_ics()
     if "incomp_viscous" in sys.argv[1:]:

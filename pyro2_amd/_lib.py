@@ -117,6 +117,8 @@ _PROTOS = {
     "pyrohip_fill_bc": [_VP, C.c_int],
     "pyrohip_state_set_user_bc": [_VP, C.c_double, C.c_double, C.c_double, _DP],
     "pyrohip_state_set_heating": [_VP, _DP],
+    "pyrohip_state_set_source": [_VP, C.c_int, _VP],
+    "pyrohip_comp_source_correct": [_VP, C.POINTER(CompParams), C.c_double],
     "pyrohip_state_set_ramp_bc": [_VP, _DP, C.c_double, _DP, _DP, _DP, _DP],
     "pyrohip_state_minmax": [_VP, C.c_int, C.c_int, _DP, _DP],
     "pyrohip_adv_step": [_VP, C.c_int, C.c_double, C.c_double, C.c_double,

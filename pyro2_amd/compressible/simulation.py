@@ -100,14 +100,15 @@ class Simulation(NullSimulation):
         if self.verbose > 0:
             print(my_data)
 
+    def _rp_opt(self, key, default):
+        try:
+            return self.rp.get_param(key)
+        except KeyError:
+            return default
+
     def _params(self):
         rp, g = self.rp, self.cc_data.grid
-
-        def opt(key, default):
-            try:
-                return rp.get_param(key)
-            except KeyError:
-                return default
+        opt = self._rp_opt
         return device.make_comp_params(
             g.dx, g.dy, gamma=rp.get_param("eos.gamma"),
             limiter=rp.get_param("compressible.limiter"),
@@ -128,7 +129,7 @@ class Simulation(NullSimulation):
         """(e_rate, profile) of the problem source rho * e_rate * profile(x, y)
         (problems heating / plume / convection), evaluated once; None without"""
         fn = getattr(self, "problem_heating", None)
-        if fn is None:
+        if fn is None or self._rp_opt("gpu.host_source", 0):
             return None
         if getattr(self, "_heat_cache", None) is None:
             rate, prof = fn(self.cc_data.grid, self.rp)
@@ -154,11 +155,60 @@ class Simulation(NullSimulation):
         cfl = self.rp.get_param("driver.cfl")
         self.dt = self._device_state().comp_dt(self._params(), float(cfl))
 
+    def _host_source(self):
+        """is the problem source an arbitrary callback the host has to evaluate
+        (no heating_profile companion, or gpu.host_source = 1)?"""
+        return self.problem_source is not None and self._heating() is None
+
+    def _source_states(self):
+        """two device states for S_h(U^n) and S_h(U*), with the boundary types of the
+        reference's aux data (dens_src, E_src: bc; xmom_src: bc_xodd; ymom_src: bc_yodd
+        -- simulation.py:248-253 -- i.e. those of the state itself; hse and ambient
+        fill the source ghost cells with copies of the last interior row,
+        BC.py:56-63,104-110,146-151)"""
+        if getattr(self, "_src_states", None) is None:
+            cc, g = self.cc_data, self.cc_data.grid
+            rows = []
+            for name in cc.names:
+                sides = list(cc.BCs[name].sides())
+                if "ramp" in sides:
+                    msg.fail("ERROR: the ramp boundary zeroes the source arrays (BC.py:198-200)")
+                rows.append(["outflow" if b in ("hse", "ambient") else b for b in sides])
+            self._src_states = tuple(device.DeviceState(cc.ctx, g.nx, g.ny, g.ng, rows)
+                                     for _ in range(2))
+        return self._src_states
+
+    def _evolve_host_source(self):
+        """one step with the problem's source_terms() evaluated on the host, twice, where
+        compressible/simulation.py evaluates it (:317-320 through unsplit_fluxes.py:295,
+        :406-408 share S(U^n); :416-418 is S(U*)); everything else stays on the device"""
+        cc, g, dt, P = self.cc_data, self.cc_data.grid, float(self.dt), self._params()
+        if g.coord_type != 0:
+            msg.fail("ERROR: host-evaluated source terms need a Cartesian grid")
+        src_old, src_new = self._source_states()
+        S = self.problem_source(g, cc.data, self.ivars, self.rp)
+        src_old.upload(np.ascontiguousarray(S, dtype=np.float64))
+        src_old.fill_bc()
+        del S
+        st = self._device_state()
+        st.set_source(0, src_old)
+        st.comp_step(P, dt)                              # ... up to U* = U + dt S(U^n)
+        cc.device_modified()
+        S = self.problem_source(g, cc.data, self.ivars, self.rp)
+        src_new.upload(np.ascontiguousarray(S, dtype=np.float64))
+        del S
+        st = self._device_state()
+        st.set_source(1, src_new)
+        st.comp_source_correct(P, dt)
+
     def evolve(self):
         tm = self.tc.timer("evolve")
         tm.begin()
         st = self._device_state()
-        st.comp_step(self._params(), float(self.dt))
+        if self._host_source():
+            self._evolve_host_source()
+        else:
+            st.comp_step(self._params(), float(self.dt))
         self.cc_data.device_modified()
         self.advance_particles()         # compressible/simulation.py:443-444
         self.cc_data.t += self.dt
@@ -170,7 +220,7 @@ class Simulation(NullSimulation):
         (pyrohip_comp_evolve)?  Cartesian grid, standard boundary types, no sponge,
         no tracer particles, a fused kernel set, nothing watching the data."""
         cc = self.cc_data
-        if cc.grid.coord_type != 0 or self.particles is not None:
+        if cc.grid.coord_type != 0 or self.particles is not None or self._host_source():
             return False
         if self.rp.get_param("sponge.do_sponge") or type(self).evolve is not Simulation.evolve:
             return False

@@ -181,6 +181,11 @@ struct pyrohip_state {
     bool user_bc_set = false;
     double ubc_gamma = 0.0, ubc_grav = 0.0, ubc_dy = 0.0, ubc_amb[4] = {0, 0, 0, 0};
     double *heat_base = nullptr, *heat = nullptr;   // heating profile plane (set_heating)
+    // host-evaluated problem source (pyrohip_state_set_source): planes of two other
+    // states (not owned), S_h(U^n) ghost-filled and S_h(U*); ext_pending: the
+    // predictor ran, pyrohip_comp_source_correct has not yet
+    const double *ext_old = nullptr, *ext_new = nullptr;
+    int ext_pending = 0;
     // "ramp" boundary (pyrohip_state_set_ramp_bc)
     bool ramp_bc = false, ramp_set = false;
     double *d_x = nullptr;    // cell-centre x coordinates (qx)

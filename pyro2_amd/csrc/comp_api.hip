@@ -18,6 +18,7 @@ int comp_step_sph(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_dt_sph(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_stage_dump(pyrohip_state *, int, double *);
 int comp_sponge(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_source_correct(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_rk_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_rk_rhs(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, int);
 }
@@ -101,9 +102,9 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
     PYRO_REQUIRE(max_steps >= 1, "max_steps must be positive");
     PYRO_REQUIRE(p->kernel_set != 0, "the staged kernel set steps from the host (kernel_set 0)");
     PYRO_REQUIRE(p->riemann >= 0 && p->riemann <= 2, "riemann must be 0 (HLLC), 1 (CGF) or 2 (HLLC_lm)");
-    PYRO_REQUIRE(!s->sph && !s->user_bc && !s->ramp_bc && !p->do_sponge,
-                 "device-side stepping: Cartesian grid, standard boundaries, no sponge "
-                 "(use pyrohip_comp_dt / pyrohip_comp_step)");
+    PYRO_REQUIRE(!s->sph && !s->user_bc && !s->ramp_bc && !p->do_sponge && !s->ext_old,
+                 "device-side stepping: Cartesian grid, standard boundaries, no sponge, no "
+                 "host-evaluated source (use pyrohip_comp_dt / pyrohip_comp_step)");
     pyrohip_ctx *c = s->ctx;
     if (!s->d_scal) PYRO_CHECK_HIP(hipMalloc((void **)&s->d_scal, sizeof(StepScalars)));
     if (s->dts_cap < max_steps + 1) {
@@ -210,18 +211,57 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     PYRO_REQUIRE(p->kernel_set >= -1 && p->kernel_set <= 2, "kernel_set must be -1 (automatic), 0, 1 or 2");
     PYRO_REQUIRE(p->riemann >= 0 && p->riemann <= 2, "riemann must be 0 (HLLC), 1 (CGF) or 2 (HLLC_lm)");
     int rc;
+    PYRO_REQUIRE(!s->ext_pending, "the corrector of the host-evaluated source has not run "
+                                  "(pyrohip_comp_source_correct)");
     if (s->sph) {
         // compressible/simulation.py:206-208: no HLLC on a SphericalPolar grid
         PYRO_REQUIRE(p->riemann == 1, "a SphericalPolar grid needs the CGF Riemann solver");
-        PYRO_REQUIRE(!s->user_bc && !s->ramp_bc && !s->heat,
+        PYRO_REQUIRE(!s->user_bc && !s->ramp_bc && !s->heat && !s->ext_old,
                      "hse / ambient / ramp boundaries and heating are Cartesian-only");
         rc = p->fast_math ? fastm::comp_step_sph(s, p, dt) : exact::comp_step_sph(s, p, dt);
+    } else if (s->ext_old) {
+        // host-evaluated source: staged kernels up to the predictor U* = U + dt S(U^n);
+        // the caller evaluates S_h(U*) and finishes with pyrohip_comp_source_correct
+        PYRO_REQUIRE(!s->heat && !s->ramp_bc, "a host-evaluated source excludes the heating "
+                     "profile and the ramp boundary (which zeroes the source arrays, BC.py:198-200)");
+        return p->fast_math ? fastm::comp_step_staged(s, p, dt) : exact::comp_step_staged(s, p, dt);
     } else if (p->kernel_set == 2 || (p->kernel_set == -1 && wave_kernel_pays(s->g)))
         rc = p->fast_math ? fastm::comp_step_wave(s, p, dt) : exact::comp_step_wave(s, p, dt);
     else if (p->kernel_set == 1 || p->kernel_set == -1)
         rc = p->fast_math ? fastm::comp_step_fused(s, p, dt) : exact::comp_step_fused(s, p, dt);
     else
         rc = p->fast_math ? fastm::comp_step_staged(s, p, dt) : exact::comp_step_staged(s, p, dt);
+    if (rc == 0 && p->do_sponge) {
+        PYRO_REQUIRE(p->sponge_rho_begin > p->sponge_rho_full,
+                     "sponge_rho_begin must exceed sponge_rho_full (simulation.py:172)");
+        rc = exact::comp_sponge(s, p, dt);
+    }
+    return rc;
+}
+
+int pyrohip_state_set_source(pyrohip_state *s, int which, pyrohip_state *src)
+{
+    PYRO_REQUIRE(s && (which == 0 || which == 1), "NULL state / which must be 0 (old) or 1 (new)");
+    if (src) {
+        PYRO_REQUIRE(src->nvar == 4 && s->nvar == 4 && src->g.nx == s->g.nx &&
+                     src->g.ny == s->g.ny && src->g.ng == s->g.ng && src->ctx == s->ctx,
+                     "the source state must match the 4-variable state it acts on");
+    }
+    if (which == 0) {
+        PYRO_REQUIRE(!s->ext_pending, "the corrector of the previous step has not run");
+        s->ext_old = src ? src->d : nullptr;
+    } else {
+        s->ext_new = src ? src->d : nullptr;
+    }
+    return 0;
+}
+
+int pyrohip_comp_source_correct(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+{
+    PYRO_TRY(check_comp(s, p));
+    PYRO_REQUIRE(s->ext_pending && s->ext_old && s->ext_new,
+                 "needs a predictor step (pyrohip_comp_step with a source set) and S_h(U*)");
+    int rc = exact::comp_source_correct(s, p, dt);
     if (rc == 0 && p->do_sponge) {
         PYRO_REQUIRE(p->sponge_rho_begin > p->sponge_rho_full,
                      "sponge_rho_begin must exceed sponge_rho_full (simulation.py:172)");

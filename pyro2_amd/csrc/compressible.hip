@@ -58,6 +58,8 @@ struct CP {   // kernel-side parameters
     int have_src;             // gravity and / or a heating source
     double heat_rate;         // S[E] += rho * heat_rate * heat[i,j] (ghost-filled plane)
     const double *heat;
+    const double *ext;        // host-evaluated source S_h(U^n), 4 ghost-filled planes (or NULL):
+                              // the step then ends with the predictor U* = U + dt S(U^n)
     int riemann, solid_xl, solid_yl;   // 0 HLLC / 1 CGF / 2 HLLC_lm; CGF wall rule
 };
 
@@ -187,6 +189,21 @@ __global__ __launch_bounds__(256) void k_states(const double *__restrict__ U,
         add_grav_to_state(XP, Uc, P.grav, P.dt, sgn, P.heat_rate, hp);
         add_grav_to_state(YM, Uc, P.grav, P.dt, sgn, P.heat_rate, hp);
         add_grav_to_state(YP, Uc, P.grav, P.dt, sgn, P.heat_rate, hp);
+    }
+    if (P.ext) {   // S = gravity + S_heating (simulation.py:157-159), ghost-filled as
+                   // aux data (unsplit_fluxes.py:298-306); gravity alone when have_src
+        const Cons X = load_cons(P.ext, pl, k);
+        Cons *F[4] = {&XM, &XP, &YM, &YP};
+        const Cons Uc = load_cons(U, pl, (P.amb_yhi && j > g.jhi) ? k - (j - g.jhi) : k);
+        const double sgn = ((j < g.jlo && P.refl_ylo) || (j > g.jhi && P.refl_yhi)) ? -1.0 : 1.0;
+        const double Sy = sgn * (Uc.d * P.grav) + X.my;
+        const double SE = sgn * (Uc.my * P.grav) + X.E;
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            F[f]->mx += 0.5 * P.dt * X.mx;
+            F[f]->my += 0.5 * P.dt * Sy;
+            F[f]->E += 0.5 * P.dt * SE;
+        }
     }
     store_cons(Wout + (size_t)W_XM * pl, pl, k, XM);
     store_cons(Wout + (size_t)W_XP * pl, pl, k, XP);
@@ -324,7 +341,8 @@ __global__ __launch_bounds__(256) void k_final(const double *__restrict__ U,
 // == full-array min for outflow / reflect / periodic ghost fills).
 __global__ __launch_bounds__(256) void k_update(double *__restrict__ U,
                                                 const double *__restrict__ W_, Geom g, CP P,
-                                                double *__restrict__ partial, int gx, int gy)
+                                                double *__restrict__ partial, int gx, int gy,
+                                                double *__restrict__ keep)
 {
     int bx, by;
     if (!xcd_block_2d(gx, gy, bx, by)) return;   // whole block leaves together
@@ -346,7 +364,17 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ U,
             Un[n] = Uo[n] + dtdV * (fx[k] * Ax - fx[k + p] * Ax + fy[k] * Ay - fy[k + 1] * Ay);
         }
         Cons Uc{Un[0], Un[1], Un[2], Un[3]};
-        if (P.have_src)
+        if (P.ext) {
+            // predictor only (simulation.py:406-412): U* = U + dt (S_grav(U^n) + S_h(U^n));
+            // U^n's density and y momentum stay behind for the corrector
+            const Cons X = load_cons(P.ext, pl, k);
+            Uc.d = Uc.d + P.dt * X.d;
+            Uc.mx = Uc.mx + P.dt * X.mx;
+            Uc.my = Uc.my + P.dt * (Uo[0] * P.grav + X.my);
+            Uc.E = Uc.E + P.dt * (Uo[3] * P.grav + X.E);
+            keep[k] = Uo[0];
+            keep[pl + k] = Uo[3];
+        } else if (P.have_src)
             grav_update(Uc, Cons{Uo[0], Uo[1], Uo[2], Uo[3]}, P.grav, P.dt, P.heat_rate,
                         P.heat ? P.heat[k] : 0.0);
         store_cons(U, pl, k, Uc);
@@ -354,6 +382,36 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ U,
     }
     cfl = block_reduce_min(cfl);
     if (threadIdx.x == 0) partial[by * gx + bx] = cfl;
+}
+
+// ---- corrector of a host-evaluated source (simulation.py:414-423) ---------
+// U = U* + dt/2 (S(U*) - S(U^n)), S = gravity (with the time-centred y momentum,
+// :148-155) + S_h; U^n's density and y momentum come from k_update (keep)
+__global__ __launch_bounds__(256) void k_source_correct(double *__restrict__ U,
+                                                        const double *__restrict__ keep,
+                                                        const double *__restrict__ Xo_,
+                                                        const double *__restrict__ Xn_, Geom g,
+                                                        double grav, double dt)
+{
+    const int j = g.jlo + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = g.ilo + blockIdx.y;
+    if (j > g.jhi) return;
+    const size_t pl = g.plane, k = (size_t)i * g.pitch + j;
+    Cons Us = load_cons(U, pl, k);
+    const Cons Xo = load_cons(Xo_, pl, k), Xn = load_cons(Xn_, pl, k);
+    const double d_old = keep[k], my_old = keep[pl + k];
+    const double Sy_old_g = d_old * grav;
+    const double Sy_old = Sy_old_g + Xo.my;
+    const double SE_old = my_old * grav + Xo.E;
+    const double Sy_new_g = Us.d * grav;
+    const double ymom_new = Us.my + 0.5 * dt * (Sy_new_g - Sy_old_g);
+    const double SE_new = ymom_new * grav + Xn.E;
+    const double Sy_new = Sy_new_g + Xn.my;
+    Us.d = Us.d + 0.5 * dt * (Xn.d - Xo.d);
+    Us.mx = Us.mx + 0.5 * dt * (Xn.mx - Xo.mx);
+    Us.my = Us.my + 0.5 * dt * (Sy_new - Sy_old);
+    Us.E = Us.E + 0.5 * dt * (SE_new - SE_old);
+    store_cons(U, pl, k, Us);
 }
 
 // ---- sponge over the whole array (simulation.py:427-441) -----------------
@@ -406,6 +464,8 @@ static CP make_cp(const pyrohip_comp_params *p, double dt, const pyrohip_state *
     c.amb_yhi = (s->bc[3 * 4 + 3] == PYROHIP_BC_AMBIENT);
     c.heat = s->heat; c.heat_rate = s->heat ? p->heat_rate : 0.0;
     c.have_src = (p->grav != 0.0 || s->heat != nullptr);
+    c.ext = s->ext_old;
+    if (c.ext) c.have_src = 0;     // the ext branch adds gravity itself
     c.riemann = p->riemann; c.solid_xl = p->solid_xl; c.solid_yl = p->solid_yl;
     return c;
 }
@@ -494,8 +554,11 @@ int comp_step_staged(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     const int nb = gx * gy;
     PYRO_TRY(c->reduce.ensure((nb + kMinStageBlocks + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
+    // the primitive planes are dead by now: U^n's density and y momentum go there
+    // when the step stops at the predictor of a host-evaluated source
     PYRO_LAUNCH(c, "k_update", k_update, dim3(xcd_grid_1d(gx, gy)), block, 0, U,
-                (const double *)W, g, P, part, gx, gy);
+                (const double *)W, g, P, part, gx, gy, W + (size_t)W_Q * g.plane);
+    if (P.ext) s->ext_pending = 1;
     const double *dmin = launch_min_reduce(c->stream, part, nb);
     s->cfl_is_global = false;
     if (c->global_cfl) {   // multi-GPU: the next dt needs the minimum over all slabs
@@ -509,7 +572,7 @@ int comp_step_staged(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     PYRO_CHECK_HIP(hipMemcpyAsync((char *)c->reduce_host + 8, s->d_flag, sizeof(int),
                                   hipMemcpyDeviceToHost, c->stream));
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
-    s->next_cfl_min = ((double *)c->reduce_host)[0];
+    s->next_cfl_min = P.ext ? -1.0 : ((double *)c->reduce_host)[0];   // U* is not the new state
     int flag = *(int *)((char *)c->reduce_host + 8);
     if (flag & 1) {
         s->next_cfl_min = -1.0;
@@ -517,6 +580,19 @@ int comp_step_staged(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
                   "(compressible/simulation.py:68-71)");
         return PYROHIP_ERR_STATE;
     }
+    return 0;
+}
+
+int comp_source_correct(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    const double *keep = s->work + geom_lead(g) + (size_t)W_Q * g.plane;
+    hipLaunchKernelGGL(k_source_correct, dim3((g.ny + 255) / 256, g.nx), dim3(256), 0, c->stream,
+                       s->d, keep, s->ext_old, s->ext_new, g, p->grav, dt);
+    PYRO_CHECK_HIP(hipGetLastError());
+    s->ext_pending = 0;
+    s->next_cfl_min = -1.0;
     return 0;
 }
 

@@ -393,6 +393,18 @@ class DeviceState:
         with self.ctx.lock:
             check(self._l.pyrohip_comp_step(self.h, C.byref(params), dt))
 
+    def set_source(self, which, src):
+        """host-evaluated problem source: `src` is a 4-variable DeviceState holding
+        S_h(U^n), ghost-filled (which = 0) or S_h(U*) (which = 1); None removes it"""
+        with self.ctx.lock:
+            check(self._l.pyrohip_state_set_source(self.h, int(which), src.h if src is not None else None))
+        self._src = getattr(self, "_src", {})
+        self._src[which] = src          # borrowed by the library: keep it alive
+
+    def comp_source_correct(self, params, dt):
+        with self.ctx.lock:
+            check(self._l.pyrohip_comp_source_correct(self.h, C.byref(params), dt))
+
     def comp_evolve(self, params, cfl, policy, max_steps):
         """up to max_steps single_steps (ghost fill, dt policy, evolve) without a host
         round trip per step.  `policy`: an object with tmax, f0 (init_tstep_factor), mx

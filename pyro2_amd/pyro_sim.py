@@ -70,13 +70,14 @@ class Pyro:
         # Problem sources run on the device when they have the form of the
         # reference's three heating problems, S[energy] = rho * e_rate *
         # profile(x, y): the problem module then also provides
-        # heating_profile(grid, rp) -> (e_rate, profile).  Arbitrary Python
-        # source callbacks would need the state on the host twice per step.
+        # heating_profile(grid, rp) -> (e_rate, profile).  Any other source_terms()
+        # is evaluated on the host, twice per step, by the compressible solver
+        # (Simulation._evolve_host_source: two PCIe round trips of the state per step).
         self.problem_heating = None
         if self.problem_source is not None:
             self.problem_heating = getattr(
                 sys.modules.get(self.problem_source.__module__), "heating_profile", None)
-            if self.problem_heating is None:
+            if self.problem_heating is None and self.solver_name != "compressible":
                 msg.fail("ERROR: this problem's source_terms() has no heating_profile() "
                          "companion; only sources of the form rho * e_rate * profile(x, y) "
                          "are carried by the device path")

@@ -350,6 +350,71 @@ def test_pyro_problem_sources(api, golden, k, prob, d):
         assert (np.abs(np.asarray(p.sim.cc_data.data)[4:-4, 4:-4] - fin) / scale).max() < 1e-11
 
 
+GENERAL_SOURCE_CASES = [
+    ("sedov", {"mesh.nx": 24, "mesh.ny": 20, "driver.tmax": 100.0}),
+    ("plume", {"mesh.nx": 16, "mesh.ny": 32, "plume.r_pert": 0.6}),
+    ("convection", {"mesh.nx": 16, "mesh.ny": 48, "convection.thickness": 0.5}),
+    ("rt", {"mesh.nx": 16, "mesh.ny": 48, "mesh.ylboundary": "reflect", "mesh.yrboundary": "reflect",
+            "mesh.xlboundary": "reflect", "mesh.xrboundary": "outflow"}),
+]
+
+
+@pytest.mark.parametrize("k", range(4))
+@pytest.mark.parametrize("fast", [0, 1])
+def test_arbitrary_problem_source_vs_reference(api, golden, k, fast):
+    """an arbitrary source_terms() callback (tests/general_source.py: four components,
+    state dependent) evaluated on the host twice per step, applied on the device where
+    compressible/simulation.py applies it (interface states, predictor, corrector):
+    10 steps of the REFERENCE run with the same callback (oracle/gen_golden.py
+    comp_general_source) -- outflow; hse + gravity; ambient + sponge + gravity;
+    reflecting walls + gravity"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from general_source import source_terms
+    from pyro2_amd.pyro_sim import Pyro
+    g = golden("comp_general_source")
+    prob, d = GENERAL_SOURCE_CASES[k]
+    pre = f"c{k}_"
+    p = Pyro("compressible")
+    p.initialize_problem(prob, inputs_dict=dict(d, **{"gpu.fast_math": fast}))
+    p.sim.problem_source, p.sim.problem_heating = source_terms, None
+    p.sim._heat_cache = None
+    assert p.sim._host_source() and not p.sim.can_evolve_many()
+    ic = np.asarray(p.sim.cc_data.data)
+    assert np.allclose(ic, g[pre + "ic"], rtol=2e-15, atol=1e-30, equal_nan=True)
+    dts = []
+    for _ in range(len(g[pre + "dts"])):
+        p.single_step()
+        dts.append(p.sim.dt)
+    tol = 1e-9 if fast else 1e-12
+    assert max_rel_err(np.array(dts), g[pre + "dts"]) < tol
+    fin = g[pre + "final"][4:-4, 4:-4]
+    scale = np.maximum(np.abs(fin).max(axis=(0, 1)), 1e-3)
+    err = (np.abs(np.asarray(p.sim.cc_data.data)[4:-4, 4:-4] - fin) / scale).max()
+    assert err < (1e-8 if fast else 1e-11), err
+
+
+@pytest.mark.parametrize("prob,d", [("heating", {"mesh.nx": 24, "mesh.ny": 24, "heating.r_src": 0.15, "heating.e_rate": 5.0}),
+          ("plume", {"mesh.nx": 16, "mesh.ny": 32, "plume.r_pert": 0.6}),
+          ("convection", {"mesh.nx": 16, "mesh.ny": 48, "convection.thickness": 0.5})])
+def test_host_source_equals_device_heating(api, prob, d):
+    """the three heating problems through the host-evaluated source path
+    (gpu.host_source = 1, their own source_terms()) give bit for bit what the device
+    heating profile gives with the staged kernels: same arithmetic, other plumbing"""
+    from pyro2_amd.pyro_sim import Pyro
+    res = []
+    for host in (0, 1):
+        p = Pyro("compressible")
+        p.initialize_problem(prob, inputs_dict=dict(d, **{"gpu.host_source": host,
+                                                          "gpu.kernel_set": 0}))
+        assert p.sim._host_source() == bool(host)
+        for _ in range(6):
+            p.single_step()
+        res.append((p.sim.dt, np.array(p.sim.cc_data.data)[4:-4, 4:-4]))
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("prob,d", [
     ("acoustic_pulse", {"mesh.nx": 24, "mesh.ny": 24}),
     ("advect", {"mesh.nx": 16, "mesh.ny": 20}),
