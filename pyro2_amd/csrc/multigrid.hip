@@ -27,6 +27,7 @@
 #include "mg_internal.h"
 #include "reduce.h"
 #include "stencil.h"
+#include <cmath>
 
 namespace pyro {
 
@@ -212,6 +213,7 @@ struct MGTile {
     double *vout;
     int n, pitch;
     double dx, xc, yc, denom, rdenom;   // rdenom = RN(1 / denom), see div_by
+    double kx, ky;                      // xc * rdenom, yc * rdenom (POW2 variants, see mg_pow2)
     int K, TI, TJ, ntj, ntiles, single;
     MGBC bc;
     // up leg: v += prolong(coarse v) while staging (patch.py:678-736 + MG.py:
@@ -222,6 +224,29 @@ struct MGTile {
     int row0, row1; // interior rows the launch updates (whole level: 1, n; a slab of a
                     // decomposed level: its rows -- the 2K apron rows beyond them are read)
 };
+
+// Power-of-two coefficients (the Poisson problems: alpha = 0, beta = +-1 on a unit
+// square give xc = yc = +-4^k and denom = 4 xc): scaling by a power of two
+// commutes with rounding, so the reference's
+//     v = ((f + xc (a + b)) + yc (c + d)) / denom                  [9 operations]
+// is, bit for bit,
+//     v = fma(ky, c + d, fma(kx, a + b, f rd)),  kx = xc rd, ky = yc rd, rd = 1 / denom
+// -- every product is exact, each fma rounds once where the reference's addition
+// rounds, and the final division only scales (barring overflow / underflow of the
+// scaled values: |f rd| < 2^-1022 with f != 0 does not occur on these grids).
+// Four operations instead of nine, with f rd prepared once per launch; the
+// smoother is VALU bound.  mg_pow2: are xc, yc, 1 / denom all powers of two?
+static bool mg_is_pow2(double x)
+{
+    int e;
+    return x != 0.0 && std::isfinite(x) && std::fabs(std::frexp(x, &e)) == 0.5;
+}
+static bool mg_pow2(double xc, double yc, double denom)
+{
+    static const bool off = getenv("PYRO_MG_NOPOW2") != nullptr;
+    return !off && mg_is_pow2(xc) && mg_is_pow2(yc) && mg_is_pow2(denom) &&
+           (1.0 / denom) * denom == 1.0;
+}
 
 // a / b for a divisor that is the same in every cell, with rb = RN(1 / b)
 // evaluated once on the host: Markstein's sequence q = a rb; e = a - b q
@@ -244,7 +269,7 @@ __device__ __forceinline__ int mg_wrap(int g, int n)   // periodic image in [1, 
     return w + 1;
 }
 
-template <int NT, int LPC>
+template <int NT, int LPC, bool POW2 = false>
 __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
 {
     HIP_DYNAMIC_SHARED(double, lds)
@@ -372,6 +397,7 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
             sa = min(si, sjA); sb = min(si, sjB);
             b = r * HP + ln;
             ga = qA ? fb : fa; gb = qA ? fa : fb;
+            if (POW2) { ga *= A.rdenom; gb *= A.rdenom; }     // exact: f rd
         };
         plan(0, f00, f01, sA0, sB0, b0, fA0, fB0);
         plan(1, f10, f11, sA1, sB1, b1, fA1, fB1);
@@ -397,9 +423,13 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
             const double *Vn = V + (odd ? P1 ^ 1 : P1) * HALF;
             const double *Vq = Vn + (odd ? qA : qB);
             auto relax = [&](int b, int last, double fc) {
-                if (s <= last)
-                    Vo[b] = div_by(fc + A.xc * (Vn[b + HP] + Vn[b - HP]) +
-                                   A.yc * (Vq[b] + Vq[b - 1]), A.denom, A.rdenom);
+                if (s <= last) {
+                    if (POW2)
+                        Vo[b] = fma(A.ky, Vq[b] + Vq[b - 1], fma(A.kx, Vn[b + HP] + Vn[b - HP], fc));
+                    else
+                        Vo[b] = div_by(fc + A.xc * (Vn[b + HP] + Vn[b - HP]) +
+                                       A.yc * (Vq[b] + Vq[b - 1]), A.denom, A.rdenom);
+                }
             };
             if (odd) { relax(b0, sA0, fA0); relax(b1, sA1, fA1); relax(b2, sA2, fA2); relax(b3, sA3, fA3); }
             else     { relax(b0, sB0, fB0); relax(b1, sB1, fB1); relax(b2, sB2, fB2); relax(b3, sB3, fB3); }
@@ -520,7 +550,14 @@ struct MGCoarse {
     MGBC bc;                                     // val[] only meaningful when finest
     int wave_top;                                // levels 0 .. wave_top: wave 0 only (-1: none)
     unsigned zero_mask;                          // bit l: take v of level l as 0 (no memset before)
+    int allow_pow2;                              // 0: PYRO_MG_NOPOW2 (see mg_pow2)
+    long long *trace;                            // developer aid: clock64() at the phase marks
 };
+#ifdef PYRO_EMU
+#define MGC_MARK(k) ((void)0)
+#else
+#define MGC_MARK(k) do { if (A.trace && tid == 0) A.trace[k] = clock64(); } while (0)
+#endif
 __host__ __device__ inline int mgc_off(int l)    // LDS offset (doubles) of level l's v
 {
     int o = 0;
@@ -632,6 +669,65 @@ __device__ __forceinline__ void mgc_sweeps(double *V, const double *F, int n, in
     }
 }
 
+// The same sweeps with everything that does not change from sweep to sweep taken out
+// of the loop: a thread keeps the (at most two) cells it relaxes per colour for the
+// whole smoothing -- LDS index, and for cells next to a boundary the index and the
+// rule of the ghost cell(s) that mirror them (-1: none) -- so that a sweep is five
+// LDS reads, the update, one write and, for boundary cells only, the ghost writes.
+// (mgc_sweeps re-derives cell and ghost indices in every sweep and issues four
+// predicated-by-select ghost stores per cell: ~60 instructions around a 9-operation
+// update.)  Homogeneous boundaries; n * n / 2 <= 2 NT.
+template <int NT, bool POW2>
+__device__ __forceinline__ void mgc_sweeps_lean(double *V, const double *F, int n, int lg,
+                                                double xc, double yc, double denom,
+                                                double rdenom, int iters, int c0, int c1, int c2,
+                                                int c3, int tid)
+{
+    const int q = n + 2, half = n >> 1, ncell = n * half;
+    const bool p0 = (c0 == PYROHIP_BC_PERIODIC), p1 = (c1 == PYROHIP_BC_PERIODIC);
+    const bool p2 = (c2 == PYROHIP_BC_PERIODIC), p3 = (c3 == PYROHIP_BC_PERIODIC);
+    const double kx = xc * rdenom, ky = yc * rdenom;
+    int cell[2][2], gi_t[2][2], gj_t[2][2], gi_c[2][2], gj_c[2][2];
+#pragma unroll
+    for (int colour = 0; colour < 2; colour++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int idx = tid + k * NT;
+            int c = -1, ti = -1, tj = -1, ci = 0, cj = 0;
+            if (idx < ncell) {
+                const int ri = (lg > 1) ? (idx >> (lg - 1)) : idx, h = idx - ri * half;
+                const int i = 1 + ri, j = 1 + 2 * h + ((ri + colour) & 1);
+                c = i * q + j;
+                // ghost cell mirrored across an x side / a y side (n >= 2: at most one each)
+                if (i == 1) { ti = p0 ? (n + 1) * q + j : j; ci = p0 ? -1 : c0; }
+                if (i == n) { ti = p1 ? j : (n + 1) * q + j; ci = p1 ? -1 : c1; }
+                if (j == 1) { tj = p2 ? i * q + n + 1 : i * q; cj = p2 ? -1 : c2; }
+                if (j == n) { tj = p3 ? i * q : i * q + n + 1; cj = p3 ? -1 : c3; }
+            }
+            cell[colour][k] = c; gi_t[colour][k] = ti; gj_t[colour][k] = tj;
+            gi_c[colour][k] = ci; gj_c[colour][k] = cj;
+        }
+    auto relax = [&](int c, int ti, int tj, int ci, int cj) __attribute__((always_inline)) {
+        if (c < 0) return;
+        double vn;
+        if (POW2)
+            vn = fma(ky, V[c + 1] + V[c - 1], fma(kx, V[c + q] + V[c - q], F[c] * rdenom));
+        else
+            vn = div_by(F[c] + xc * (V[c + q] + V[c - q]) + yc * (V[c + 1] + V[c - 1]), denom, rdenom);
+        V[c] = vn;
+        if (ti >= 0) V[ti] = (ci < 0) ? vn : ghost_h(ci, vn);
+        if (tj >= 0) V[tj] = (cj < 0) ? vn : ghost_h(cj, vn);
+    };
+    for (int it = 0; it < iters; it++) {
+        relax(cell[0][0], gi_t[0][0], gj_t[0][0], gi_c[0][0], gj_c[0][0]);
+        relax(cell[0][1], gi_t[0][1], gj_t[0][1], gi_c[0][1], gj_c[0][1]);
+        mgc_sync<NT>();
+        relax(cell[1][0], gi_t[1][0], gj_t[1][0], gi_c[1][0], gj_c[1][0]);
+        relax(cell[1][1], gi_t[1][1], gj_t[1][1], gi_c[1][1], gj_c[1][1]);
+        mgc_sync<NT>();
+    }
+}
+
 // Red-black sweeps of one LDS-resident level.  The thread that updates a cell
 // next to a boundary also refreshes the ghost cell(s) that mirror it (like
 // k_mg_smooth): during a colour sweep a ghost cell is only read by the cell it
@@ -646,10 +742,17 @@ __device__ __forceinline__ void mgc_sweeps(double *V, const double *F, int n, in
 // sweeps at nsmooth 10 / bottom 50) is bound by the dependent chain LDS read
 // -> 8 fp64 operations -> LDS write -> barrier of each sweep, not by the
 // number of barriers.
+__device__ __forceinline__ bool mgc_is_pow2(double x)     // device twin of mg_is_pow2
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const unsigned e = (unsigned)(b >> 52) & 0x7ffu;
+    return (b & 0x000fffffffffffffull) == 0 && e != 0 && e != 0x7ffu;
+}
+
 template <int NT>
 __device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, double dx,
                                   double alpha, double beta, int iters, const MGBC &bc,
-                                  bool use_val, int tid)
+                                  bool use_val, int tid, bool allow_pow2 = true)
 {
     const int q = n + 2;
     const double xc = beta / (dx * dx), yc = beta / (dx * dx);
@@ -660,7 +763,12 @@ __device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, dou
     const int c0 = bc.code[0], c1 = bc.code[1], c2 = bc.code[2], c3 = bc.code[3];
     const double *v0 = use_val ? bc.val[0] : nullptr, *v1 = use_val ? bc.val[1] : nullptr;
     const double *v2 = use_val ? bc.val[2] : nullptr, *v3 = use_val ? bc.val[3] : nullptr;
-    if (!(v0 || v1 || v2 || v3))   // boundary values only on a finest level <= 64^2
+    if (!(v0 || v1 || v2 || v3) && n * (n >> 1) <= 2 * NT) {
+        const bool pow2 = allow_pow2 && mgc_is_pow2(xc) && mgc_is_pow2(yc) && mgc_is_pow2(denom) &&
+                          rdenom * denom == 1.0;                // see mg_pow2
+        if (pow2) mgc_sweeps_lean<NT, true>(V, F, n, lg, xc, yc, denom, rdenom, iters, c0, c1, c2, c3, tid);
+        else mgc_sweeps_lean<NT, false>(V, F, n, lg, xc, yc, denom, rdenom, iters, c0, c1, c2, c3, tid);
+    } else if (!(v0 || v1 || v2 || v3))   // boundary values only on a finest level <= 64^2
         mgc_sweeps<NT, true>(V, F, n, lg, dx, xc, yc, denom, rdenom, iters, c0, c1, c2, c3, v0, v1,
                              v2, v3, tid);
     else
@@ -736,7 +844,9 @@ __device__ inline void mgc_down(const MGCoarse &A, int l, double *lds, int tid)
     double *V = lds + mgc_off(l), *F = V + q * q;
     double *Fc = lds + mgc_off(l - 1) + qc * qc;
     const bool uv = A.finest && l == A.top;
-    mgc_smooth<NT>(V, F, n, l + 1, A.dx[l], A.alpha, A.beta, A.nsmooth, A.bc, uv, tid);
+    if (l == 2) MGC_MARK(14);
+    mgc_smooth<NT>(V, F, n, l + 1, A.dx[l], A.alpha, A.beta, A.nsmooth, A.bc, uv, tid, A.allow_pow2);
+    if (l == 2) MGC_MARK(15);
     const double dx2 = A.dx[l] * A.dx[l];
     for (int idx = tid; idx < nc * nc; idx += NT) {
         const int ci = idx / nc, cj = idx - ci * nc;
@@ -776,13 +886,14 @@ __device__ inline void mgc_up(const MGCoarse &A, int l, double *lds, int tid)
     }
     mgc_sync<NT>();
     mgc_smooth<NT>(V, F, n, l + 1, A.dx[l], A.alpha, A.beta, A.nsmooth, A.bc,
-                   A.finest && l == A.top, tid);
+                   A.finest && l == A.top, tid, A.allow_pow2);
 }
 
 __global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
 {
     HIP_DYNAMIC_SHARED(double, lds)
     const int tid = threadIdx.x;
+    MGC_MARK(0);
     // stage v and f of every level
     for (int l = 0; l <= A.top; l++) {
         const int n = 2 << l, q = n + 2;
@@ -795,9 +906,10 @@ __global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
         }
     }
     __syncthreads();
+    MGC_MARK(1);
     const int wtop = (A.top < A.wave_top) ? A.top : A.wave_top;
     // down leg of the larger levels: the whole workgroup
-    for (int l = A.top; l > wtop && l >= 1; l--) mgc_down<MGC_NT>(A, l, lds, tid);
+    for (int l = A.top; l > wtop && l >= 1; l--) { mgc_down<MGC_NT>(A, l, lds, tid); MGC_MARK(2 + (A.top - l)); }
     if (wtop >= 0) {
         // the smallest levels: wave 0, no workgroup barriers
         if (tid < 64) {
@@ -805,7 +917,7 @@ __global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
             {   // bottom solve (MG.py:776-778)
                 double *V = lds + mgc_off(0), *F = V + 16;
                 mgc_smooth<64>(V, F, 2, 1, A.dx[0], A.alpha, A.beta, A.nsmooth_bottom, A.bc,
-                               A.finest && A.top == 0, tid);
+                               A.finest && A.top == 0, tid, A.allow_pow2);
             }
             for (int l = 1; l <= wtop; l++) mgc_up<64>(A, l, lds, tid);
         }
@@ -820,7 +932,8 @@ __global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
         __syncthreads();
         if (A.nsmooth_bottom > 0) mgc_fill<MGC_NT>(V, 2, A.dx[0], A.bc, uv, tid);
     }
-    for (int l = (wtop > 0 ? wtop : 0) + 1; l <= A.top; l++) mgc_up<MGC_NT>(A, l, lds, tid);
+    MGC_MARK(8);
+    for (int l = (wtop > 0 ? wtop : 0) + 1; l <= A.top; l++) { mgc_up<MGC_NT>(A, l, lds, tid); MGC_MARK(8 + l); }
     // write back: v of every level, f of the levels below the top
     for (int l = 0; l <= A.top; l++) {
         const int n = 2 << l, q = n + 2;
@@ -1191,6 +1304,9 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
         PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_mg_smooth_tile<MGW_NT, MGW_LP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)MGW_LDS));
+        PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_mg_smooth_tile<MGW_NT, MGW_LP, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)MGW_LDS));
         attr_set = true;
     }
 #endif
@@ -1200,6 +1316,8 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
     A.yc = m->beta / (L.dx * L.dx);
     A.denom = m->alpha + 2.0 * A.xc + 2.0 * A.yc;
     A.rdenom = 1.0 / A.denom;
+    A.kx = A.xc * A.rdenom; A.ky = A.yc * A.rdenom;
+    const bool pow2 = mg_pow2(A.xc, A.yc, A.denom);
     A.bc = make_bc(m, level, true);
     A.single = ((L.n + 2) * (L.n + 2) <= MGS_CELLS) ? 1 : 0;   // whole level in one tile
     A.cv = nullptr; A.cpitch = 0;
@@ -1243,8 +1361,12 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
             }
             const int nti = (nrows + A.TI - 1) / A.TI;
             A.ntiles = nti * A.ntj;
-            PYRO_LAUNCH(m->ctx, "k_mg_smooth_tile", (k_mg_smooth_tile<MGW_NT, MGW_LP>),
-                        dim3(A.ntiles), dim3(MGW_NT), MGW_LDS, A);
+            if (pow2)
+                PYRO_LAUNCH(m->ctx, "k_mg_smooth_tile", (k_mg_smooth_tile<MGW_NT, MGW_LP, true>),
+                            dim3(A.ntiles), dim3(MGW_NT), MGW_LDS, A);
+            else
+                PYRO_LAUNCH(m->ctx, "k_mg_smooth_tile", (k_mg_smooth_tile<MGW_NT, MGW_LP>),
+                            dim3(A.ntiles), dim3(MGW_NT), MGW_LDS, A);
         }
         double *t = L.v; L.v = L.v2; L.v2 = t;
         left -= K;
@@ -1387,12 +1509,33 @@ static int mg_coarse_vcycle(pyrohip_mg *m, int top)
         return e ? atoi(e) : MGC_WAVE_TOP;
     }();
     A.wave_top = wave_top;
+    A.allow_pow2 = getenv("PYRO_MG_NOPOW2") ? 0 : 1;
     A.zero_mask = 0;
     for (int l = 0; l <= top; l++)
         if (m->v_is_zero[l]) { A.zero_mask |= 1u << l; m->v_is_zero[l] = false; }
     A.bc = make_bc(m, top, true);
+    A.trace = nullptr;
+#ifndef PYRO_EMU
+    static const bool tracing = getenv("PYRO_MGC_TRACE") != nullptr;
+    static long long *d_trace = nullptr;
+    if (tracing) {
+        if (!d_trace) PYRO_CHECK_HIP(hipMalloc((void **)&d_trace, 16 * sizeof(long long)));
+        A.trace = d_trace;
+    }
+#endif
     PYRO_LAUNCH(m->ctx, "k_mg_coarse_vcycle", k_mg_coarse_vcycle, dim3(1), dim3(MGC_NT), MGC_LDS,
                 A);
+#ifndef PYRO_EMU
+    if (tracing) {
+        long long h[16];
+        PYRO_CHECK_HIP(hipMemcpy(h, d_trace, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "mgc trace (cycles): stage %lld | down", h[1] - h[0]);
+        for (int k = 2; k < 2 + top; k++) fprintf(stderr, " %lld", h[k] - h[k - 1]);
+        fprintf(stderr, " | bottom %lld | up", h[8] - h[1 + top]);
+        for (int l = 1; l <= top; l++) fprintf(stderr, " %lld", h[8 + l] - h[8 + l - 1]);
+        fprintf(stderr, " | level 8^2 down: smooth %lld\n", h[15] - h[14]);
+    }
+#endif
     for (int l = 0; l <= top; l++) m->corners_stale[l] = false;   // full fills inside
     return 0;
 }
