@@ -202,6 +202,11 @@ def _load():
                 f"{path} is missing: the HIP extension has not been built "
                 "(run `python -m pyro2_amd.build` or __graft_entry__.build()). "
                 "pyro2_amd has no CPU fallback.")
+        # kernel arguments in device memory instead of host-coherent memory: the first
+        # scalar load of every workgroup otherwise crosses to the host (~1 us per launch,
+        # 15-30 us per multigrid V-cycle, tools/mg_ab.sh).  Read by the HIP runtime when it
+        # initialises; a value set by the user wins.
+        os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
         lib = C.CDLL(path)
         lib.pyrohip_last_error.restype = C.c_char_p
         lib.pyrohip_backend.restype = C.c_char_p

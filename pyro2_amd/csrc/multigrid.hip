@@ -28,6 +28,7 @@
 #include "reduce.h"
 #include "stencil.h"
 #include <cmath>
+#include <type_traits>
 
 namespace pyro {
 
@@ -63,7 +64,13 @@ struct pyrohip_mg {
     double source_norm = 0.0;
     int smoother = 1;             // 0: one launch per colour, 1: LDS tile smoother
     int kmax = 5;                 // red-black iterations fused per tile launch
-    int kmax_small = 5;           // ... on levels <= 1024^2 (latency bound)
+    // ... on levels <= nsmall^2: one launch lasts as long as its slowest workgroup and
+    // costs ~5 us before it starts; 10 iterations in one launch instead of 2 x 5 (the
+    // apron doubles, which is free while most CUs idle).  Measured per V-cycle at
+    // 512^2 / 2048^2 / 4096^2 (tools/mg_ab.sh): 5 everywhere 309 / 700 / 1590 us,
+    // 10 up to 512^2 284 / 668 / 1529, 10 up to 1024^2 286 / 714 / 1578.
+    int kmax_small = getenv("PYRO_MG_KSMALL") ? atoi(getenv("PYRO_MG_KSMALL")) : 10;
+    int nsmall = getenv("PYRO_MG_NSMALL") ? atoi(getenv("PYRO_MG_NSMALL")) : 512;
     int coarse_kernel = 1;        // levels <= 64^2 in one LDS-resident workgroup
     int fuse_res_restrict = getenv("PYRO_MG_NOFUSE_RR") ? 0 : 1;   // down leg: residual + restriction in one pass
     int vc = 0;                   // 1: div(eta grad phi) = f; 2: general (alpha, beta, gamma)
@@ -221,6 +228,7 @@ struct MGTile {
     const double *cv;
     int cpitch;
     int vin_zero;   // 1: take vin as 0 (down leg: MG.py:658-659 zeroes the coarse solutions)
+    long long *trace;   // developer aid (PYRO_MG_TRACE): clock64() of workgroup 0 at phase marks
     int row0, row1; // interior rows the launch updates (whole level: 1, n; a slab of a
                     // decomposed level: its rows -- the 2K apron rows beyond them are read)
 };
@@ -530,6 +538,239 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
 
 
 // ---------------------------------------------------------------------------
+// Band variant of the wide tile smoother (same region, same staging rules, same
+// expression on the same operands: bit-identical).  Measured on the kernel above:
+// 56 cycles per 64 cell updates and SIMD whatever the arithmetic costs (9 or 4
+// operations) -- it is bound by its LDS traffic, five 512-B reads and one write per
+// wavefront update against 128-256 B per clock and CU.  Here wave w keeps the four
+// CONSECUTIVE region rows 4w ... 4w+3 (lane h: columns 2h, 2h+1) in registers for
+// the whole launch: of the four neighbours of a cell two rows are the thread's own
+// registers, one column neighbour is the thread's other cell and the other one
+// comes from the neighbouring lane by a whole-wave DPP rotation.  LDS only carries
+// the two band-edge rows to the neighbouring waves (and, on tiles at a physical
+// boundary, the ghost refresh): 2 reads + 2 writes per pass and thread instead of
+// 20 + 4.
+// ---------------------------------------------------------------------------
+#if !defined(PYRO_EMU)
+template <int CTRL> __device__ __forceinline__ double mgb_dpp(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double mgb_from_lower(double v) { return mgb_dpp<0x13C>(v); }   // wave_ror:1
+__device__ __forceinline__ double mgb_from_upper(double v) { return mgb_dpp<0x134>(v); }   // wave_rol:1
+#else
+__device__ __forceinline__ double mgb_from_lower(double v) { return __shfl_up(v, 1, 64); }
+__device__ __forceinline__ double mgb_from_upper(double v) { return __shfl_down(v, 1, 64); }
+#endif
+
+// Ghost cells are not kept at all: a cell next to a physical boundary takes
+// ghost_h(its own value) where the stencil asks for the ghost cell -- what the
+// reference's fill_BC after every colour sweep stores there (MG.py:598-599) -- and
+// the ghost cells next to the tile are written from their mirror cells at the end.
+// No cell is excluded from a pass either: a cell beyond the still-valid part of the
+// apron (or at a ghost position) computes something that no cell of the tile ever
+// reads.  Homogeneous boundaries (a finest level with boundary VALUES: k_mg_smooth_tile).
+template <bool POW2, bool EDGE>
+__global__ __launch_bounds__(MGW_NT, 4) void k_mg_smooth_band(MGTile A)
+{
+    HIP_DYNAMIC_SHARED(double, lds)
+    static_assert(MGW_RI == 64 && MGW_LP == 128 && MGW_NT == 1024, "16 waves x 4 rows x 128 columns");
+    constexpr int HP = MGW_LP / 2, HALF = MGW_RI * HP;
+    const int n = A.n;
+    const bool per_i = (A.bc.code[0] == PYROHIP_BC_PERIODIC);
+    const bool per_j = (A.bc.code[2] == PYROHIP_BC_PERIODIC);
+    const int H = 2 * A.K;
+    const int tile = xcd_tile(blockIdx.x, A.ntiles);
+    const int ti0 = A.row0 + (tile / A.ntj) * A.TI, ti1 = min(ti0 + A.TI - 1, A.row1);
+    const int tj0 = 1 + (tile % A.ntj) * A.TJ, tj1 = min(tj0 + A.TJ - 1, n);
+    int gi0 = ti0 - H, gi1 = ti1 + H, gj0 = tj0 - H, gj1 = tj1 + H;
+    if (!per_i) { gi0 = max(gi0, 0); gi1 = min(gi1, n + 1); }
+    if (!per_j) { gj0 = max(gj0, 0); gj1 = min(gj1, n + 1); }
+    const int RI = gi1 - gi0 + 1;
+    double *V = lds;
+    // LDS index of region cell (r, c): the two checkerboard classes apart, so that the
+    // lanes of a wave (one class of one row) touch consecutive doubles
+    auto at = [&](int r, int c) -> int { return ((r + c) & 1) * HALF + r * HP + (c >> 1); };
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    // sides on which the staged region ends at the level's ghost ring
+    const bool plo_i = (gi0 == 0) && !per_i, phi_i = (gi1 == n + 1) && !per_i;
+    const bool plo_j = (gj0 == 0) && !per_j, phi_j = (gj1 == n + 1) && !per_j;
+    const int c0 = A.bc.code[0], c1 = A.bc.code[1], c2 = A.bc.code[2], c3 = A.bc.code[3];
+#ifndef PYRO_EMU
+#define MGB_MARK(k) do { if (A.trace && blockIdx.x == (unsigned)A.ntiles / 2 && tid == 0) A.trace[k] = clock64(); } while (0)
+#else
+#define MGB_MARK(k) ((void)0)
+#endif
+    MGB_MARK(0);
+
+    // ---- stage (prolongation of the up leg on the way).  Rows / columns beyond the
+    // region load its last row / column again: inside the array, never read by the tile ----
+    double v[4][2], f[4][2];
+    int gi_[4], gj_[2];             // array row / column of the thread's cells (wrapped, clamped)
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int g = gi0 + 4 * wv + m;
+        const int w = g + (g < 1 ? n : 0) - (g > n ? n : 0);      // |apron| <= n: one correction wraps
+        gi_[m] = per_i ? w : min(g, n + 1);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int g = gj0 + 2 * ln + q;
+        int w = g + (g < 1 ? n : 0);
+        w -= (w > n ? n : 0);
+        w -= (w > n ? n : 0);                                     // lanes far beyond a narrow region
+        gj_[q] = per_j ? w : min(g, n + 1);
+    }
+    {
+        const double *src = A.vin_zero ? A.f : A.vin;             // zero solution: cache hits, dropped
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const size_t k = (size_t)gi_[m] * A.pitch + gj_[q];
+                const double x = src[k], y = A.f[k];
+                v[m][q] = A.vin_zero ? 0.0 : x;
+                f[m][q] = POW2 ? y * A.rdenom : y;                // exact: see mg_pow2
+            }
+    }
+    if (A.cv) {
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                // k_mg_prolong_add's expression for fine cell (gi-1, gj-1); cells outside the
+                // level read coarse cell (1, 1) and drop the result
+                const bool in = gi_[m] >= 1 && gi_[m] <= n && gj_[q] >= 1 && gj_[q] <= n;
+                const int fi = in ? gi_[m] - 1 : 0, fj = in ? gj_[q] - 1 : 0;
+                const size_t ck = (size_t)(1 + (fi >> 1)) * A.cpitch + 1 + (fj >> 1);
+                const double q0 = A.cv[ck];
+                const double m_x = 0.5 * (A.cv[ck + A.cpitch] - A.cv[ck - A.cpitch]);
+                const double m_y = 0.5 * (A.cv[ck + 1] - A.cv[ck - 1]);
+                const double tx = 0.25 * m_x, ty = 0.25 * m_y;    // x - y == x + (-y)
+                const double e = (q0 + ((fi & 1) ? tx : -tx)) + ((fj & 1) ? ty : -ty);
+                v[m][q] += in ? e : 0.0;
+            }
+    }
+    // LDS slots of the band-edge rows (this band's rows 0 and 3, both columns) and of
+    // the rows next to the band (clamped: an edge band's outer rows are never read by
+    // a cell that matters)
+    const int r0 = 4 * wv;
+    const int w00 = at(r0, 2 * ln), w01 = at(r0, 2 * ln + 1);
+    const int w30 = at(r0 + 3, 2 * ln), w31 = at(r0 + 3, 2 * ln + 1);
+    const int rb = max(r0 - 1, 0), rt = min(r0 + 4, MGW_RI - 1);
+    const int b0 = at(rb, 2 * ln), b1 = at(rb, 2 * ln + 1), t0 = at(rt, 2 * ln), t1 = at(rt, 2 * ln + 1);
+    V[w00] = v[0][0]; V[w01] = v[0][1]; V[w30] = v[3][0]; V[w31] = v[3][1];
+    // cells whose neighbour is a ghost cell (EDGE tiles)
+    bool isTop[4], isBot[4], isE[2], isW[2];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        isTop[m] = EDGE && phi_i && gi0 + r0 + m == n;
+        isBot[m] = EDGE && plo_i && gi0 + r0 + m == 1;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        isE[q] = EDGE && phi_j && gj0 + 2 * ln + q == n;
+        isW[q] = EDGE && plo_j && gj0 + 2 * ln + q == 1;
+    }
+    // the band is part of the region; beyond pass wave_last none of its rows is valid
+    // any more (rows only: one scalar for the wave, the whole wave skips the pass)
+    int wave_last = -1;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int r = r0 + m;
+        if (r < RI) wave_last = max(wave_last, min(plo_i ? (1 << 20) : r, phi_i ? (1 << 20) : RI - 1 - r));
+    }
+#ifndef PYRO_EMU
+    wave_last = __builtin_amdgcn_readfirstlane(wave_last);
+#endif
+    __syncthreads();
+    MGB_MARK(1);
+    MGB_MARK(2);
+
+    // ---- 2K colour passes ----
+    // class relaxed in pass s: (gi + gj + colour) even <=> (r + c + par) even; the
+    // thread's cell of that class in row 4w + m is its column (par + m) & 1
+    auto pass = [&](auto par_c) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value;
+        // band-edge rows of the other class from the neighbouring waves
+        const double below = V[(PAR & 1) ? b1 : b0];             // (4w-1, column of row 0's cell)
+        const double above = V[((PAR + 3) & 1) ? t1 : t0];       // (4w+4, column of row 3's cell)
+        double vn[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int q = (PAR + m) & 1;
+            const double me = v[m][q];
+            double up = (m < 3) ? v[m < 3 ? m + 1 : 3][q] : above;     // row r + 1
+            double dn = (m > 0) ? v[m > 0 ? m - 1 : 0][q] : below;     // row r - 1
+            // the thread's other cell and the neighbouring lane's
+            const double own = v[m][q ^ 1];
+            const double oth = q ? mgb_from_upper(v[m][0]) : mgb_from_lower(v[m][1]);
+            double e = q ? oth : own, w = q ? own : oth;               // columns c + 1, c - 1
+            if (EDGE) {
+                up = isTop[m] ? ghost_h(c1, me) : up;
+                dn = isBot[m] ? ghost_h(c0, me) : dn;
+                e = isE[q] ? ghost_h(c3, me) : e;
+                w = isW[q] ? ghost_h(c2, me) : w;
+            }
+            if (POW2)
+                vn[m] = fma(A.ky, e + w, fma(A.kx, up + dn, f[m][q]));
+            else
+                vn[m] = div_by(f[m][q] + A.xc * (up + dn) + A.yc * (e + w), A.denom, A.rdenom);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) v[m][(PAR + m) & 1] = vn[m];
+        V[(PAR & 1) ? w01 : w00] = v[0][PAR & 1];
+        V[((PAR + 3) & 1) ? w31 : w30] = v[3][(PAR + 3) & 1];
+    };
+    const int npass = 2 * A.K;
+    for (int s = 1; s <= npass; s++) {
+        const int par = (gi0 + gj0 + ((s - 1) & 1)) & 1;
+        if (s <= wave_last) {
+            if (par) pass(std::integral_constant<int, 1>{});
+            else pass(std::integral_constant<int, 0>{});
+        }
+        __syncthreads();
+        MGB_MARK(2 + s);
+    }
+
+    // ---- tile -> vout; on physical sides the ghost cells next to it from their mirror
+    // cells; on periodic sides the tile that owns row / column n (1) also writes ghost
+    // row / column 0 (n + 1), so that the other kernels find current edge ghosts ----
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int gi = gi0 + r0 + m;                      // unwrapped
+        if (gi < ti0 || gi > ti1) continue;
+        const size_t row = (size_t)gi * A.pitch;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int gj = gj0 + 2 * ln + q;
+            if (gj < tj0 || gj > tj1) continue;
+            const double x = v[m][q];
+            A.vout[row + gj] = x;
+            if (per_i) {
+                if (gi == n) A.vout[gj] = x;
+                if (gi == 1) A.vout[(size_t)(n + 1) * A.pitch + gj] = x;
+            } else {
+                if (gi == 1) A.vout[gj] = ghost_h(c0, x);
+                if (gi == n) A.vout[(size_t)(n + 1) * A.pitch + gj] = ghost_h(c1, x);
+            }
+            if (per_j) {
+                if (gj == n) A.vout[row] = x;
+                if (gj == 1) A.vout[row + n + 1] = x;
+            } else {
+                if (gj == 1) A.vout[row] = ghost_h(c2, x);
+                if (gj == n) A.vout[row + n + 1] = ghost_h(c3, x);
+            }
+        }
+    }
+    MGB_MARK(23);
+}
+
+
+// ---------------------------------------------------------------------------
 // Coarse sub-V-cycle: every level with n <= 64 (v and f of 2^2 ... 64^2, 96 KB)
 // lives in the LDS of ONE workgroup, which runs the whole recursion below the
 // 64^2 level -- smoothing, residual, restriction, bottom solve, prolongation --
@@ -835,6 +1076,38 @@ __device__ inline void mgc_bottom_regs(double *V, const double *F, double dx, do
         for (int j = 0; j < 4; j++) V[i * 4 + j] = v[i][j];
 }
 
+// The same bottom solve for homogeneous, non-periodic boundaries without the ghost
+// cells: every cell of the 2 x 2 level has a ghost neighbour on two sides, and that
+// ghost cell mirrors the cell itself -- ghost_h(own value) where the stencil asks
+// for it (what the refresh after every colour stores there).  One wave issues a VALU
+// instruction every ~5 cycles whatever the dependencies, so the ~220 instructions per
+// iteration of the general form above cost ~0.4 us; here an iteration is 4 x (update +
+// two ghost values).  The closing fill restores the stored ghost cells.
+template <bool POW2>
+__device__ inline void mgc_bottom_fast(double *V, const double *F, double dx, double alpha,
+                                       double beta, int iters, const MGBC &bc)
+{
+    const double xc = beta / (dx * dx), yc = beta / (dx * dx);
+    const double denom = alpha + 2.0 * xc + 2.0 * yc;
+    const double rdenom = 1.0 / denom;
+    const double kx = xc * rdenom, ky = yc * rdenom;
+    const int c0 = bc.code[0], c1 = bc.code[1], c2 = bc.code[2], c3 = bc.code[3];
+    double a = V[5], b = V[6], c = V[9], d = V[10];            // (1,1) (1,2) (2,1) (2,2)
+    const double fa = POW2 ? F[5] * rdenom : F[5], fb = POW2 ? F[6] * rdenom : F[6];
+    const double fc = POW2 ? F[9] * rdenom : F[9], fd = POW2 ? F[10] * rdenom : F[10];
+    auto relax = [&](double f, double up, double dn, double e, double w) __attribute__((always_inline)) {
+        return POW2 ? fma(ky, e + w, fma(kx, up + dn, f))
+                    : div_by(f + xc * (up + dn) + yc * (e + w), denom, rdenom);
+    };
+    for (int it = 0; it < iters; it++) {
+        a = relax(fa, c, ghost_h(c0, a), b, ghost_h(c2, a));   // colour 0: (1,1), (2,2)
+        d = relax(fd, ghost_h(c1, d), b, ghost_h(c3, d), c);
+        b = relax(fb, d, ghost_h(c0, b), ghost_h(c3, b), a);   // colour 1: (1,2), (2,1)
+        c = relax(fc, ghost_h(c1, c), a, d, ghost_h(c2, c));
+    }
+    V[5] = a; V[6] = b; V[9] = c; V[10] = d;
+}
+
 // one level of the down leg (MG.py:722-735): smooth, residual -> global r,
 // its restriction -> f of the next coarser level
 template <int NT>
@@ -927,8 +1200,18 @@ __global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
         double *V = lds + mgc_off(0), *F = V + 16;
         const bool uv = A.finest && A.top == 0;
         mgc_fill<MGC_NT>(V, 2, A.dx[0], A.bc, uv, tid);
-        if (tid == 0 && A.nsmooth_bottom > 0)
-            mgc_bottom_regs(V, F, A.dx[0], A.alpha, A.beta, A.nsmooth_bottom, A.bc, uv);
+        const bool plain = !uv && A.bc.code[0] != PYROHIP_BC_PERIODIC && A.bc.code[2] != PYROHIP_BC_PERIODIC;
+        if (tid == 0 && A.nsmooth_bottom > 0) {
+            const double xc0 = A.beta / (A.dx[0] * A.dx[0]), den0 = A.alpha + 2.0 * xc0 + 2.0 * xc0;
+            const bool pow2 = A.allow_pow2 && mgc_is_pow2(xc0) && mgc_is_pow2(den0) &&
+                              (1.0 / den0) * den0 == 1.0;
+            if (plain && pow2)
+                mgc_bottom_fast<true>(V, F, A.dx[0], A.alpha, A.beta, A.nsmooth_bottom, A.bc);
+            else if (plain)
+                mgc_bottom_fast<false>(V, F, A.dx[0], A.alpha, A.beta, A.nsmooth_bottom, A.bc);
+            else
+                mgc_bottom_regs(V, F, A.dx[0], A.alpha, A.beta, A.nsmooth_bottom, A.bc, uv);
+        }
         __syncthreads();
         if (A.nsmooth_bottom > 0) mgc_fill<MGC_NT>(V, 2, A.dx[0], A.bc, uv, tid);
     }
@@ -1307,6 +1590,13 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
         PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_mg_smooth_tile<MGW_NT, MGW_LP, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)MGW_LDS));
+        const void *bands[4] = {(const void *)k_mg_smooth_band<false, false>,
+                                (const void *)k_mg_smooth_band<false, true>,
+                                (const void *)k_mg_smooth_band<true, false>,
+                                (const void *)k_mg_smooth_band<true, true>};
+        for (const void *fn : bands)
+            PYRO_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)MGW_LDS));
         attr_set = true;
     }
 #endif
@@ -1324,6 +1614,15 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
     if (prolong) { A.cv = m->lev[level - 1].v; A.cpitch = m->lev[level - 1].pitch; }
     A.vin_zero = 0;
     A.row0 = row0; A.row1 = row1;
+    A.trace = nullptr;
+#ifndef PYRO_EMU
+    static const bool tracing = getenv("PYRO_MG_TRACE") != nullptr;
+    static long long *d_trace = nullptr;
+    if (tracing) {
+        if (!d_trace) PYRO_CHECK_HIP(hipMalloc((void **)&d_trace, 32 * sizeof(long long)));
+        A.trace = d_trace;
+    }
+#endif
     if (m->v_is_zero[level]) {
         if (A.single) PYRO_TRY(mg_zero(m, level, 0));   // generic variant: materialise
         else A.vin_zero = 1;
@@ -1332,7 +1631,7 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
     int kmax = (m->kmax >= 1 && m->kmax <= MGW_KMAX) ? m->kmax : MGW_KMAX;
     // levels up to 1024^2 live in L2 / Infinity Cache and are launch-latency
     // bound: fuse as many iterations per launch as the 32-row region allows
-    if (L.n <= 1024 && m->kmax_small > kmax) kmax = m->kmax_small;
+    if (L.n <= m->nsmall && m->kmax_small > kmax) kmax = m->kmax_small;
     int left = nsmooth;
     while (left > 0) {
         const int K = A.single ? left : (left < kmax ? left : kmax);
@@ -1361,13 +1660,41 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
             }
             const int nti = (nrows + A.TI - 1) / A.TI;
             A.ntiles = nti * A.ntj;
-            if (pow2)
+            static const int band_maxn = getenv("PYRO_MG_BAND") ? atoi(getenv("PYRO_MG_BAND")) : 1024;
+            const bool band = L.n <= band_maxn;
+            // the band kernel: homogeneous boundaries; its EDGE instance (ghost values
+            // synthesised at the physical sides) wherever a tile can touch one
+            const bool hom = !(A.bc.val[0] || A.bc.val[1] || A.bc.val[2] || A.bc.val[3]);
+            const bool edge = A.bc.code[0] != PYROHIP_BC_PERIODIC || A.bc.code[2] != PYROHIP_BC_PERIODIC;
+            if (band && hom && pow2 && edge)
+                PYRO_LAUNCH(m->ctx, "k_mg_smooth_band", (k_mg_smooth_band<true, true>), dim3(A.ntiles),
+                            dim3(MGW_NT), MGW_LDS, A);
+            else if (band && hom && pow2)
+                PYRO_LAUNCH(m->ctx, "k_mg_smooth_band", (k_mg_smooth_band<true, false>), dim3(A.ntiles),
+                            dim3(MGW_NT), MGW_LDS, A);
+            else if (band && hom && edge)
+                PYRO_LAUNCH(m->ctx, "k_mg_smooth_band", (k_mg_smooth_band<false, true>), dim3(A.ntiles),
+                            dim3(MGW_NT), MGW_LDS, A);
+            else if (band && hom)
+                PYRO_LAUNCH(m->ctx, "k_mg_smooth_band", (k_mg_smooth_band<false, false>), dim3(A.ntiles),
+                            dim3(MGW_NT), MGW_LDS, A);
+            else if (pow2)
                 PYRO_LAUNCH(m->ctx, "k_mg_smooth_tile", (k_mg_smooth_tile<MGW_NT, MGW_LP, true>),
                             dim3(A.ntiles), dim3(MGW_NT), MGW_LDS, A);
             else
                 PYRO_LAUNCH(m->ctx, "k_mg_smooth_tile", (k_mg_smooth_tile<MGW_NT, MGW_LP>),
                             dim3(A.ntiles), dim3(MGW_NT), MGW_LDS, A);
         }
+#ifndef PYRO_EMU
+        if (tracing && !A.single) {
+            long long h[32];
+            PYRO_CHECK_HIP(hipMemcpy(h, d_trace, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "band trace n=%d K=%d tiles=%d prolong=%d: stage %lld ghosts0 %lld passes", L.n, K,
+                    A.ntiles, A.cv != nullptr, h[1] - h[0], h[2] - h[1]);
+            for (int s = 1; s <= 2 * K; s++) fprintf(stderr, " %lld", h[2 + s] - h[1 + s]);
+            fprintf(stderr, " store %lld total %lld\n", h[23] - h[2 + 2 * K], h[23] - h[0]);
+        }
+#endif
         double *t = L.v; L.v = L.v2; L.v2 = t;
         left -= K;
         A.cv = nullptr;   // only the first launch carries the prolongation
@@ -1666,7 +1993,7 @@ int pyrohip_mg_set_smoother(pyrohip_mg *m, int kind)
     // 10 + k selects the tile smoother with k fused iterations (tuning knob)
     // 20 + k: the same without the single-workgroup coarse V-cycle kernel
     m->coarse_kernel = 1;
-    m->kmax_small = 5;
+    m->kmax_small = getenv("PYRO_MG_KSMALL") ? atoi(getenv("PYRO_MG_KSMALL")) : 10;
     if (kind >= 20) { m->smoother = 1; m->kmax = kind - 20; m->coarse_kernel = 0; m->kmax_small = 0; }
     else if (kind >= 10) { m->smoother = 1; m->kmax = kind - 10; }
     else m->smoother = kind;
