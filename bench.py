@@ -310,18 +310,25 @@ def bench_mg(ctx, device, nx=4096, cycles=10):
     ctx.sync()
     t1 = time.perf_counter()
     vps = cycles / (t1 - t0)
-    gbs = MG_BYTES_PER_CELL_VCYCLE * nx * nx * vps / 1e9
+    model_gbs = MG_BYTES_PER_CELL_VCYCLE * nx * nx * vps / 1e9
     traffic = also_traffic("mg_summary", "bytes_per_vcycle") if nx == 4096 else None
+    # the roofline entry is priced with the bytes the V-cycle really moves (PMC, committed
+    # under profiles/): the 720 B model of SURVEY 8(d) counts one pass per smoothing
+    # iteration, the temporally blocked smoothers move a level once per 5 iterations
+    gbs = traffic * vps / 1e9 if traffic else model_gbs
     return {"workload": f"multigrid constant-coeff Poisson {nx}x{nx} dirichlet, "
                         f"{cycles} V-cycles (nsmooth 10, bottom 50)",
             "value": vps, "unit": "V-cycles/s", "ms_per_vcycle": (t1 - t0) / cycles * 1e3,
             "residual_error_after": res,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "basis": "720 B per finest cell per V-cycle (SURVEY 8(d) model of the per-level "
-                                  "passes) x V-cycles/s: an algorithmic-equivalent rate, the 5-sweep LDS "
-                                  "smoother moves fewer bytes than the model (traffic = measured fabric "
-                                  "bytes per V-cycle, profiles/*_also_traffic.json)"}}
+                         "model_equivalent_gbs": model_gbs,
+                         "basis": ("measured fabric bytes per V-cycle (traffic; profiles/*_also_traffic.json, "
+                                   "rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE over every multigrid kernel) x "
+                                   "V-cycles/s" if traffic else
+                                   "720 B per finest cell per V-cycle (SURVEY 8(d) model) x V-cycles/s: an "
+                                   "algorithmic-equivalent rate, no measured traffic for this size") +
+                                  "; model_equivalent_gbs = the 720 B model x V-cycles/s"}}
 
 
 def bench_incompressible(ctx, device, nx=2048, steps=5):

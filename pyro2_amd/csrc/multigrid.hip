@@ -808,14 +808,17 @@ __host__ __device__ inline int mgc_off(int l)    // LDS offset (doubles) of leve
 constexpr int MGC_LDS_DOUBLES = 2 * (16 + 36 + 100 + 324 + 1156 + 4356);
 constexpr size_t MGC_LDS = (size_t)MGC_LDS_DOUBLES * sizeof(double);
 
-// Synchronisation inside the coarse kernel.  The levels up to wave_top can be
-// run by wave 0 alone with wave-level barriers instead of workgroup barriers
-// (within one wave LDS operations complete in program order).  Measured on
-// MI355X (gpurun_out/mgc_wave.log, V-cycle of a 64^2 grid = this kernel):
-// 325 / 333 / 329 / 320 / 333 / 353 us for wave_top = -1 / 0 / 1 / 2 / 3 / 4 --
-// no gain: the kernel is bound by the dependent LDS round trips of the ~300
-// colour sweeps (update, x fill, y fill), not by the barriers, whose other 15
-// waves arrive at once.  Default: off (-1); env PYRO_MGC_WAVE_TOP.
+// Synchronisation inside the coarse kernel.  The levels up to wave_top can be run by
+// wave 0 alone with wave-level barriers instead of workgroup barriers (within one
+// wave LDS operations complete in program order).  No gain, measured twice: round 1
+// with the LDS sweeps (325 / 333 / 329 / 320 / 333 / 353 us for wave_top = -1 / 0 /
+// 1 / 2 / 3 / 4 on a 64^2 V-cycle), round 2 with sweeps of one wavefront in
+// registers (a B x B block of cells per lane, neighbours by ds_bpermute, ghost
+// values synthesised: 295 instead of 390 cycles per colour sweep on the 8^2 level,
+// eaten up by the single-wave residual / restriction / prolongation phases: 129 us
+// against 125 us; removed again).  A colour sweep of a tiny level is an LDS-latency
+// round trip (~150 cycles) plus ~60 dependent-issue-bound instructions either way.
+// Default: off (-1); env PYRO_MGC_WAVE_TOP.
 #ifdef PYRO_EMU
 __device__ inline void mgc_wave_sync() { hipemu::wave_barrier(); }
 #else
@@ -1004,9 +1007,9 @@ __device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, dou
     const int c0 = bc.code[0], c1 = bc.code[1], c2 = bc.code[2], c3 = bc.code[3];
     const double *v0 = use_val ? bc.val[0] : nullptr, *v1 = use_val ? bc.val[1] : nullptr;
     const double *v2 = use_val ? bc.val[2] : nullptr, *v3 = use_val ? bc.val[3] : nullptr;
+    const bool pow2 = allow_pow2 && mgc_is_pow2(xc) && mgc_is_pow2(yc) && mgc_is_pow2(denom) &&
+                      rdenom * denom == 1.0;                    // see mg_pow2
     if (!(v0 || v1 || v2 || v3) && n * (n >> 1) <= 2 * NT) {
-        const bool pow2 = allow_pow2 && mgc_is_pow2(xc) && mgc_is_pow2(yc) && mgc_is_pow2(denom) &&
-                          rdenom * denom == 1.0;                // see mg_pow2
         if (pow2) mgc_sweeps_lean<NT, true>(V, F, n, lg, xc, yc, denom, rdenom, iters, c0, c1, c2, c3, tid);
         else mgc_sweeps_lean<NT, false>(V, F, n, lg, xc, yc, denom, rdenom, iters, c0, c1, c2, c3, tid);
     } else if (!(v0 || v1 || v2 || v3))   // boundary values only on a finest level <= 64^2

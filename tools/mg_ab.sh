@@ -7,7 +7,10 @@ python -m pytest tests/test_device_multigrid.py tests/test_incompressible.py tes
 echo "=== defaults"
 python tools/mg_prof.py $SIZES
 python tools/mgc_trace.py 2>&1 | tail -1
-echo "=== round-1 smoother (LDS tile kernel, 5 iterations per launch, 9-operation update)"
-PYRO_MG_BAND=0 PYRO_MG_KSMALL=5 PYRO_MG_NOPOW2=1 HIP_FORCE_DEV_KERNARG=0 python tools/mg_prof.py $SIZES | grep -E "nx="
+for WT in -1 2 3; do
+echo "=== coarse kernel wave_top=$WT"
+PYRO_MGC_WAVE_TOP=$WT python tools/mg_prof.py 512 | grep -E "nx=|coarse"
+PYRO_MGC_WAVE_TOP=$WT python tools/mgc_trace.py 2>&1 | tail -1
+done
 } > gpurun_out/mg_ab.log 2>&1
 tail -80 gpurun_out/mg_ab.log
