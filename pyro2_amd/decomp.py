@@ -28,6 +28,10 @@ class SlabDecomp:
         self.i0 = sum(counts[:rank])
         self.lo = rank - 1 if rank > 0 else (nranks - 1 if periodic and nranks > 1 else -1)
         self.hi = rank + 1 if rank < nranks - 1 else (0 if periodic and nranks > 1 else -1)
+        # halo sides that are the periodic wrap-around of the global grid (the x ghost
+        # rows of the single-domain run), not interior cuts
+        self.wrap_lo = bool(periodic and nranks > 1 and rank == 0)
+        self.wrap_hi = bool(periodic and nranks > 1 and rank == nranks - 1)
 
     def var_bcs(self, per_var):
         """per-variable [xl,xr,yl,yr] names/codes -> int table with HALO on the
@@ -150,17 +154,28 @@ class SlabCompressible:
     The driver's dt policy (simulation_null.py:222-244) is applied to the
     GLOBAL minimum, so every rank takes the same step."""
 
-    def __init__(self, ctx, decomp, ny, bcs, params_kw, comm, ng=4):
+    def __init__(self, ctx, decomp, ny, bcs, params_kw, comm, ng=4, user_bc=None):
+        """user_bc: (gamma, grav, dy, (ambient rho, u, v, p)) for the hse / ambient
+        boundaries on the y sides (compressible/BC.py).  They decompose as they are:
+        the halo rows travel whole, WITH the neighbour's y ghost cells, and the y fill
+        treats halo rows like interior rows.  One quirk of the reference needs care on
+        a grid that is PERIODIC in x: fill_BC_all fills variable after variable, so the
+        hse energy of the x ghost rows is built from momenta ghost rows of the previous
+        step (`_exchange_fill_wrapped_hse`)."""
         from . import device
-        if any(b in ("hse", "ambient") for b in bcs):
-            # the hse energy fill reads the momenta's x ghosts of the PREVIOUS
-            # fill (fill_BC_all order); a halo exchange refreshes all variables
-            # at once, so the corner ghosts would differ from the single-domain run
-            raise NotImplementedError("hse / ambient boundaries are single-GPU only")
+        if any(b in ("hse", "ambient") for b in bcs) and user_bc is None:
+            raise ValueError("hse / ambient boundaries need user_bc = (gamma, grav, dy, ambient)")
         self.dec, self.comm = decomp, comm
         self.state = device.DeviceState(ctx, decomp.nx_local, ny, ng, decomp.comp_var_bcs(bcs))
+        if user_bc is not None:
+            self.state.set_user_bc(*user_bc)
+        self._hse_wrap = user_bc is not None and "hse" in bcs[2:] and \
+            (decomp.wrap_lo or decomp.wrap_hi)
         kw = dict(params_kw)
-        kw["avisc_xhi_interior"] = int(decomp.hi >= 0)
+        # the artificial viscosity lives on the faces ilo ... ihi of the GLOBAL grid
+        # (interface.py:312-364): a slab computes it on its upper face when that face is an
+        # interior cut, not when it is the periodic wrap-around (= global face ihi + 1)
+        kw["avisc_xhi_interior"] = int(decomp.hi >= 0 and not decomp.wrap_hi)
         self.params = device.make_comp_params(**kw)
         # boundary strips first + halo exchange beside the interior strips (kernel_set 2)
         if getattr(comm, "overlap", False) and (decomp.lo >= 0 or decomp.hi >= 0):
@@ -173,13 +188,50 @@ class SlabCompressible:
         the library (single rank or RcclComm)."""
         if not isinstance(self.comm, (NoComm, RcclComm)):
             raise NotImplementedError("device-side stepping needs RCCL (or a single rank)")
+        if self._hse_wrap:
+            raise NotImplementedError("hse boundaries on a grid periodic in x step from the host "
+                                      "(momenta halo rows of the previous step: step())")
         if isinstance(self.comm, RcclComm) and (self.dec.lo >= 0 or self.dec.hi >= 0):
             self.state.set_neighbours(self.dec.lo, self.dec.hi)
         return self.state.comp_evolve(self.params, cfl, policy, nsteps)
 
+    def _exchange_fill_wrapped_hse(self):
+        """halo exchange + ghost fill where a wrap-around side meets an hse boundary.
+        The reference fills density, energy, x-momentum, y-momentum one after the other
+        (patch.py fill_BC_all), so when the hse energy of an x GHOST row is integrated
+        (BC.py:64-84, :95-115: it keeps the kinetic energy of the last interior cell of
+        that row) the momenta of that row are still the periodic images of the PREVIOUS
+        step.  The rows of the wrap-around halo therefore take their new momenta only
+        after density and energy are filled.  (Analytically the kinetic energy cancels
+        out of the ghost energy -- e_ghost = E_base + k g rho dy / (gamma - 1) -- so what is
+        at stake is the last bit, measured: 1 ulp in the corner cells; bit-identity with
+        the single-domain run is the contract here.)  Staged through the host (two extra
+        row transfers per step on the two end ranks): an edge case kept exact, not fast."""
+        st, ng, nxl = self.state, self.state.ng, self.state.nx
+        rows = [r for r, on in ((0, self.dec.wrap_lo), (nxl + ng, self.dec.wrap_hi)) if on]
+        old = {r: st.download_rows(r, ng).copy() for r in rows}
+        self.comm.halo_exchange(st, self.dec.lo, self.dec.hi)
+        new = {}
+        for r in rows:
+            new[r] = st.download_rows(r, ng).copy()
+            mixed = new[r].copy()
+            mixed[:, :, 2:4] = old[r][:, :, 2:4]
+            st.upload_rows(r, mixed)
+        st.fill_bc(0)
+        st.fill_bc(1)
+        for r in rows:
+            cur = st.download_rows(r, ng).copy()
+            cur[:, :, 2:4] = new[r][:, :, 2:4]
+            st.upload_rows(r, cur)
+        st.fill_bc(2)
+        st.fill_bc(3)
+
     def step(self, policy, cfl):
-        self.comm.halo_exchange(self.state, self.dec.lo, self.dec.hi)
-        self.state.fill_bc()
+        if self._hse_wrap:
+            self._exchange_fill_wrapped_hse()
+        else:
+            self.comm.halo_exchange(self.state, self.dec.lo, self.dec.hi)
+            self.state.fill_bc()
         if hasattr(self.comm, "dt_min"):
             dt = policy(self.comm.dt_min(self.state, self.params, cfl))
         else:
