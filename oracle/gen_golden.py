@@ -827,6 +827,30 @@ def gen_compressible_general_source():
     save("comp_general_source", **out)
 
 
+def gen_mesh_utils():
+    """the general mesh utilities next to the hot path: CellCenterData2d.restrict (by 2 and
+    by 4) / prolong on a rectangular grid with ng = 2, EdgeCoeffs and its restriction"""
+    import pyro.multigrid.edge_coeffs as ec
+    rng = np.random.default_rng(11)
+    g = patch.Grid2d(12, 8, ng=2, xmax=1.5, ymax=1.0)
+    d = patch.CellCenterData2d(g)
+    bc = bnd.BC(xlb="outflow", xrb="outflow", ylb="periodic", yrb="periodic")
+    d.register_var("a", bc)
+    d.create()
+    a = d.get_var("a")
+    a[:, :] = rng.standard_normal(a.shape)
+    out = {"a": np.array(a), "r2": np.array(d.restrict("a")), "r4": np.array(d.restrict("a", N=4)),
+           "p": np.array(d.prolong("a"))}
+    ge = patch.Grid2d(8, 12, ng=1, xmax=2.0, ymax=3.0)
+    eta = ge.scratch_array()
+    eta[:, :] = 1.0 + rng.random(eta.shape)
+    e = ec.EdgeCoeffs(ge, eta)
+    c = e.restrict()
+    out.update(eta=np.array(eta), ex=np.array(e.x), ey=np.array(e.y), cx=np.array(c.x),
+               cy=np.array(c.y))
+    save("mesh_utils", **out)
+
+
 def gen_problem_ics():
     """initial conditions of the remaining compressible problem set-ups"""
     cases = {"acoustic_pulse": {"mesh.nx": 24, "mesh.ny": 24},
@@ -1362,6 +1386,8 @@ if __name__ == "__main__":
         gen_compressible_ramp()
     if "comp_heating" in sys.argv[1:]:
         gen_compressible_heating()
+    if "mesh_utils" in sys.argv[1:]:
+        gen_mesh_utils()
     if "comp_general_source" in sys.argv[1:]:
         gen_compressible_general_source()
     if "problem_ics" in sys.argv[1:]:

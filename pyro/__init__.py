@@ -37,3 +37,7 @@ class _AliasFinder(importlib.abc.MetaPathFinder):
 sys.meta_path.insert(0, _AliasFinder())
 # the top-level names of the package (Pyro, ...) are reachable as pyro.<name>
 globals().update({k: v for k, v in vars(pyro2_amd).items() if not k.startswith("__")})
+
+
+def __getattr__(name):       # lazily resolved exports of the package (Pyro, CellCenterData2d, ...)
+    return getattr(pyro2_amd, name)

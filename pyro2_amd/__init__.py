@@ -11,8 +11,19 @@ needs pyro2_amd/lib/libpyrohip.so (python -m pyro2_amd.build) and a GPU.
 __version__ = "0.1.0"
 
 
+# the names pyro/__init__.py exports, resolved on first use (importing the package
+# stays cheap and needs no GPU)
+_LAZY = {"Pyro": ("pyro_sim", "Pyro"),
+         "BC": ("mesh.boundary", "BC"), "ArrayIndexer": ("mesh.array_indexer", "ArrayIndexer"),
+         "CellCenterData2d": ("mesh.patch", "CellCenterData2d"), "Grid2d": ("mesh.patch", "Grid2d"),
+         "RKIntegrator": ("mesh.integration", "RKIntegrator"),
+         "RuntimeParameters": ("util.runparams", "RuntimeParameters"),
+         "TimerCollection": ("util.profile_pyro", "TimerCollection")}
+
+
 def __getattr__(name):
-    if name == "Pyro":
-        from .pyro_sim import Pyro
-        return Pyro
+    if name in _LAZY:
+        import importlib
+        mod, attr = _LAZY[name]
+        return getattr(importlib.import_module(f"{__name__}.{mod}"), attr)
     raise AttributeError(name)

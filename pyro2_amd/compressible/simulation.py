@@ -67,10 +67,12 @@ class Simulation(NullSimulation):
     def initialize(self, *, extra_vars=None, ng=4):
         my_grid = grid_setup(self.rp, ng=ng, spherical_ok=type(self).spherical_ok)
         my_data = self.data_class(my_grid)
-        riemann_method = self.rp.get_param("compressible.riemann")
-        if riemann_method not in ("HLLC", "CGF", "HLLC_lm"):
+        # a bare RuntimeParameters (the reference's unit tests build one by hand) may
+        # not carry the solver's parameters yet: they are only needed from the first step on
+        riemann_method = self._rp_opt("compressible.riemann", None)
+        if riemann_method is not None and riemann_method not in ("HLLC", "CGF", "HLLC_lm"):
             msg.fail("ERROR: Riemann solver undefined")
-        if my_grid.coord_type == 1 and riemann_method != "CGF":   # simulation.py:206-208
+        if my_grid.coord_type == 1 and riemann_method not in (None, "CGF"):   # simulation.py:206-208
             msg.fail("ERROR: only the CGF Riemann solver is supported "
                      "with SphericalPolar geometry")
         # compressible/simulation.py:212-214; both have device kernels
@@ -99,12 +101,6 @@ class Simulation(NullSimulation):
         self.problem_func(self.cc_data, self.rp)
         if self.verbose > 0:
             print(my_data)
-
-    def _rp_opt(self, key, default):
-        try:
-            return self.rp.get_param(key)
-        except KeyError:
-            return default
 
     def _params(self):
         rp, g = self.rp, self.cc_data.grid

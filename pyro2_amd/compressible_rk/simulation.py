@@ -14,7 +14,7 @@ class Simulation(CompressibleSimulation):
     spherical_ok = False   # compressible_rk/fluxes.py has no geometry terms
 
     def initialize(self, *, extra_vars=None, ng=4):
-        if self.rp.get_param("compressible.well_balanced"):
+        if self._rp_opt("compressible.well_balanced", 0):
             msg.fail("ERROR: compressible.well_balanced is not carried by the device path")
         super().initialize(extra_vars=extra_vars, ng=ng)
         self._rk_scratch = None

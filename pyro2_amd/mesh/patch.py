@@ -206,10 +206,11 @@ class CellCenterData2d:
     (patch.py:315-794).  Storage order of `data` is (qx, qy, nvar)."""
 
     def __init__(self, grid, *, dtype=np.float64, ctx=None):
-        if dtype != np.float64:
-            raise ValueError("the device path is float64 only (like the reference's defaults)")
+        # the kernels compute in float64 (the reference's default); any other dtype
+        # (patch.py:315 takes one; its own unit tests use int) is kept on the host in
+        # that type and converted on the way to / from the device
         self.grid = grid
-        self.dtype = dtype
+        self.dtype = np.dtype(dtype)
         self.names = []
         self.vars = self.names   # same alias as the reference
         self.nvar = 0
@@ -258,12 +259,12 @@ class CellCenterData2d:
         if self.initialized == 1:
             msg.fail("ERROR: grid already initialized")
         g = self.grid
-        self._set_host(np.zeros((g.qx, g.qy, self.nvar)))
+        self._set_host(np.zeros((g.qx, g.qy, self.nvar), dtype=self.dtype))
         self._host_valid, self._dev_valid = True, False
         self.initialized = 1
 
     def _set_host(self, arr):
-        self._root = np.ascontiguousarray(arr, dtype=np.float64)
+        self._root = np.ascontiguousarray(arr, dtype=self.dtype)
         self._host = ArrayIndexer(self._root, grid=self.grid)
         self._root_refs = sys.getrefcount(self._host)
 
@@ -294,9 +295,17 @@ class CellCenterData2d:
             rows = [_bc_row(self.BCs[n], dub) for n in self.names]
             self._dev = device.DeviceState(self.ctx, g.nx, g.ny, g.ng, rows)
         if not self._dev_valid:
-            self._dev.upload(np.asarray(self._host))
+            self._dev.upload(np.asarray(self._host, dtype=np.float64))
             self._dev_valid = True
         return self._dev
+
+    def _download_to_host(self):
+        """device copy -> the host array (same memory: views stay valid)"""
+        host = np.asarray(self._host)
+        if host.dtype == np.float64:
+            self._dev.download(host)
+        else:
+            host[...] = self._dev.download()
 
     def device_modified(self):
         """to be called after a kernel changed the device copy.  In the
@@ -315,7 +324,7 @@ class CellCenterData2d:
                 msg.warning("a view of the simulation data (get_var / .data) is held across "
                             "device steps: keeping the host copy coherent costs a download and "
                             "an upload per step")
-            self._dev.download(np.asarray(self._host))
+            self._download_to_host()
             self._host_valid = True
             self._dev_valid = False
 
@@ -330,7 +339,7 @@ class CellCenterData2d:
             self._fill_pending = False
             self._fill_now()
         if not self._host_valid:
-            self._dev.download(np.asarray(self._host))
+            self._download_to_host()
             self._host_valid = True
         # views handed out may be written through: the device copy is stale
         self._dev_valid = False
@@ -342,7 +351,7 @@ class CellCenterData2d:
 
     @data.setter
     def data(self, value):
-        self._set_host(np.array(value, dtype=np.float64))
+        self._set_host(np.array(value, dtype=self.dtype))
         self._host_valid, self._dev_valid = True, False
         self._fill_pending = False
 
@@ -485,12 +494,9 @@ class CellCenterData2d:
 
     # ---- grid transfer (patch.py:640-736) ------------------------------
     def restrict(self, varname, N=2):
-        """4-cell average onto a grid coarser by N = 2 (device kernel shared
-        with the multigrid solver)"""
-        if N != 2:
-            raise ValueError("restriction on the device is implemented for N = 2")
+        """average onto a grid coarser by N = 2 or 4 (multigrid/_transfer.py)"""
         from ..multigrid import _transfer
-        return _transfer.restrict(self, varname)
+        return _transfer.restrict(self, varname, N)
 
     def prolong(self, varname):
         from ..multigrid import _transfer

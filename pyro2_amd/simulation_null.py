@@ -79,6 +79,12 @@ class NullSimulation:
         except (AttributeError, KeyError):
             return None
 
+    def _rp_opt(self, key, default):
+        """a runtime parameter that a hand-built RuntimeParameters (the reference's
+        unit tests) may not carry"""
+        v = self._opt(key)
+        return default if v is None else v
+
     def __str__(self):
         return f"pyro Simulation:\n  solver: {self.solver_name}\n  problem: {self.problem_name}\n"
 

@@ -61,10 +61,10 @@ class Simulation(NullSimulation):
         my_data.register_var("fuel", bc)
         if extra_vars:
             msg.fail("ERROR: additional advected scalars are not carried by the device path")
-        if self.rp.get_param("swe.use_flattening"):
+        if self._rp_opt("swe.use_flattening", 0):
             msg.fail("ERROR: swe.use_flattening needs a pressure variable the swe state "
                      "does not have (it fails in the reference too)")
-        if self.rp.get_param("swe.riemann") not in ("Roe", "HLLC"):
+        if self._rp_opt("swe.riemann", "Roe") not in ("Roe", "HLLC"):
             msg.fail("ERROR: Riemann solver undefined")
         my_data.set_aux("g", self.rp.get_param("swe.grav"))
         my_data.create()
