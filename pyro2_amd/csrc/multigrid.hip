@@ -542,14 +542,13 @@ __global__ __launch_bounds__(NT, LPC ? 8 : 1) void k_mg_smooth_tile(MGTile A)
 // expression on the same operands: bit-identical).  Measured on the kernel above:
 // 56 cycles per 64 cell updates and SIMD whatever the arithmetic costs (9 or 4
 // operations) -- it is bound by its LDS traffic, five 512-B reads and one write per
-// wavefront update against 128-256 B per clock and CU.  Here wave w keeps the four
-// CONSECUTIVE region rows 4w ... 4w+3 (lane h: columns 2h, 2h+1) in registers for
-// the whole launch: of the four neighbours of a cell two rows are the thread's own
-// registers, one column neighbour is the thread's other cell and the other one
-// comes from the neighbouring lane by a whole-wave DPP rotation.  LDS only carries
-// the two band-edge rows to the neighbouring waves (and, on tiles at a physical
-// boundary, the ghost refresh): 2 reads + 2 writes per pass and thread instead of
-// 20 + 4.
+// wavefront update against 128-256 B per clock and CU.  Here wave w keeps R = 4
+// CONSECUTIVE region rows R w ... R w + R - 1 (lane h: columns 2h, 2h+1) in
+// registers for the whole launch: of the four neighbours of a cell the rows are the
+// thread's own registers, one column neighbour is the thread's other cell and the
+// other one comes from the neighbouring lane by a whole-wave DPP rotation.  LDS
+// only carries the two band-edge rows to the neighbouring waves: 2 reads + 2 writes
+// per pass and thread instead of 20 + 4.
 // ---------------------------------------------------------------------------
 #if !defined(PYRO_EMU)
 template <int CTRL> __device__ __forceinline__ double mgb_dpp(double v)
@@ -561,7 +560,9 @@ template <int CTRL> __device__ __forceinline__ double mgb_dpp(double v)
 }
 __device__ __forceinline__ double mgb_from_lower(double v) { return mgb_dpp<0x13C>(v); }   // wave_ror:1
 __device__ __forceinline__ double mgb_from_upper(double v) { return mgb_dpp<0x134>(v); }   // wave_rol:1
+#define MGB_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
+#define MGB_SCHED_FENCE() ((void)0)
 __device__ __forceinline__ double mgb_from_lower(double v) { return __shfl_up(v, 1, 64); }
 __device__ __forceinline__ double mgb_from_upper(double v) { return __shfl_down(v, 1, 64); }
 #endif
@@ -573,11 +574,19 @@ __device__ __forceinline__ double mgb_from_upper(double v) { return __shfl_down(
 // No cell is excluded from a pass either: a cell beyond the still-valid part of the
 // apron (or at a ghost position) computes something that no cell of the tile ever
 // reads.  Homogeneous boundaries (a finest level with boundary VALUES: k_mg_smooth_tile).
+// R region rows per wavefront, 64 / R wavefronts per workgroup.  R = 4: 1024 threads at
+// 128 VGPRs, one workgroup per CU.  Two per CU (like the tile kernel, which is what the
+// levels >= 2048^2 need) would take R = 4 at 64 VGPRs (68 spills) or R = 8 with 512
+// threads at 128 VGPRs (139 spills, all in the staging of 16 cells + prolongation per
+// thread; the pass loop itself fits): measured slower than one workgroup per CU.
+constexpr int MGB_R = 4, MGB_NT = 64 * (MGW_RI / MGB_R);
+
 template <bool POW2, bool EDGE>
-__global__ __launch_bounds__(MGW_NT, 4) void k_mg_smooth_band(MGTile A)
+__global__ __launch_bounds__(MGB_NT, 4) void k_mg_smooth_band(MGTile A)
 {
     HIP_DYNAMIC_SHARED(double, lds)
-    static_assert(MGW_RI == 64 && MGW_LP == 128 && MGW_NT == 1024, "16 waves x 4 rows x 128 columns");
+    static_assert(MGW_RI == 64 && MGW_LP == 128 && MGB_R >= 2, "64 / R waves x R rows x 128 columns");
+    constexpr int R = MGB_R;
     constexpr int HP = MGW_LP / 2, HALF = MGW_RI * HP;
     const int n = A.n;
     const bool per_i = (A.bc.code[0] == PYROHIP_BC_PERIODIC);
@@ -608,11 +617,11 @@ __global__ __launch_bounds__(MGW_NT, 4) void k_mg_smooth_band(MGTile A)
 
     // ---- stage (prolongation of the up leg on the way).  Rows / columns beyond the
     // region load its last row / column again: inside the array, never read by the tile ----
-    double v[4][2], f[4][2];
-    int gi_[4], gj_[2];             // array row / column of the thread's cells (wrapped, clamped)
+    double v[R][2], f[R][2];
+    int gi_[R], gj_[2];             // array row / column of the thread's cells (wrapped, clamped)
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
-        const int g = gi0 + 4 * wv + m;
+    for (int m = 0; m < R; m++) {
+        const int g = gi0 + R * wv + m;
         const int w = g + (g < 1 ? n : 0) - (g > n ? n : 0);      // |apron| <= n: one correction wraps
         gi_[m] = per_i ? w : min(g, n + 1);
     }
@@ -627,46 +636,49 @@ __global__ __launch_bounds__(MGW_NT, 4) void k_mg_smooth_band(MGTile A)
     {
         const double *src = A.vin_zero ? A.f : A.vin;             // zero solution: cache hits, dropped
 #pragma unroll
-        for (int m = 0; m < 4; m++)
+        for (int m = 0; m < R; m++)
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-                const size_t k = (size_t)gi_[m] * A.pitch + gj_[q];
+                // 32-bit element offsets (a level is < 2^25 elements): scalar base + one VGPR
+                const unsigned k = (unsigned)(gi_[m] * A.pitch + gj_[q]);
                 const double x = src[k], y = A.f[k];
                 v[m][q] = A.vin_zero ? 0.0 : x;
                 f[m][q] = POW2 ? y * A.rdenom : y;                // exact: see mg_pow2
             }
+        MGB_SCHED_FENCE();
     }
     if (A.cv) {
 #pragma unroll
-        for (int m = 0; m < 4; m++)
+        for (int m = 0; m < R; m++)
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 // k_mg_prolong_add's expression for fine cell (gi-1, gj-1); cells outside the
                 // level read coarse cell (1, 1) and drop the result
                 const bool in = gi_[m] >= 1 && gi_[m] <= n && gj_[q] >= 1 && gj_[q] <= n;
                 const int fi = in ? gi_[m] - 1 : 0, fj = in ? gj_[q] - 1 : 0;
-                const size_t ck = (size_t)(1 + (fi >> 1)) * A.cpitch + 1 + (fj >> 1);
+                const unsigned ck = (unsigned)((1 + (fi >> 1)) * A.cpitch + 1 + (fj >> 1));
                 const double q0 = A.cv[ck];
                 const double m_x = 0.5 * (A.cv[ck + A.cpitch] - A.cv[ck - A.cpitch]);
                 const double m_y = 0.5 * (A.cv[ck + 1] - A.cv[ck - 1]);
                 const double tx = 0.25 * m_x, ty = 0.25 * m_y;    // x - y == x + (-y)
                 const double e = (q0 + ((fi & 1) ? tx : -tx)) + ((fj & 1) ? ty : -ty);
                 v[m][q] += in ? e : 0.0;
+                if (q == 1 && (m & 1)) MGB_SCHED_FENCE();      // 4 cells' coarse reads in flight, not 16
             }
     }
     // LDS slots of the band-edge rows (this band's rows 0 and 3, both columns) and of
     // the rows next to the band (clamped: an edge band's outer rows are never read by
     // a cell that matters)
-    const int r0 = 4 * wv;
+    const int r0 = R * wv;
     const int w00 = at(r0, 2 * ln), w01 = at(r0, 2 * ln + 1);
-    const int w30 = at(r0 + 3, 2 * ln), w31 = at(r0 + 3, 2 * ln + 1);
-    const int rb = max(r0 - 1, 0), rt = min(r0 + 4, MGW_RI - 1);
+    const int w30 = at(r0 + R - 1, 2 * ln), w31 = at(r0 + R - 1, 2 * ln + 1);
+    const int rb = max(r0 - 1, 0), rt = min(r0 + R, MGW_RI - 1);
     const int b0 = at(rb, 2 * ln), b1 = at(rb, 2 * ln + 1), t0 = at(rt, 2 * ln), t1 = at(rt, 2 * ln + 1);
-    V[w00] = v[0][0]; V[w01] = v[0][1]; V[w30] = v[3][0]; V[w31] = v[3][1];
+    V[w00] = v[0][0]; V[w01] = v[0][1]; V[w30] = v[R - 1][0]; V[w31] = v[R - 1][1];
     // cells whose neighbour is a ghost cell (EDGE tiles)
-    bool isTop[4], isBot[4], isE[2], isW[2];
+    bool isTop[R], isBot[R], isE[2], isW[2];
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
+    for (int m = 0; m < R; m++) {
         isTop[m] = EDGE && phi_i && gi0 + r0 + m == n;
         isBot[m] = EDGE && plo_i && gi0 + r0 + m == 1;
     }
@@ -679,7 +691,7 @@ __global__ __launch_bounds__(MGW_NT, 4) void k_mg_smooth_band(MGTile A)
     // any more (rows only: one scalar for the wave, the whole wave skips the pass)
     int wave_last = -1;
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
+    for (int m = 0; m < R; m++) {
         const int r = r0 + m;
         if (r < RI) wave_last = max(wave_last, min(plo_i ? (1 << 20) : r, phi_i ? (1 << 20) : RI - 1 - r));
     }
@@ -696,14 +708,14 @@ __global__ __launch_bounds__(MGW_NT, 4) void k_mg_smooth_band(MGTile A)
     auto pass = [&](auto par_c) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
         // band-edge rows of the other class from the neighbouring waves
-        const double below = V[(PAR & 1) ? b1 : b0];             // (4w-1, column of row 0's cell)
-        const double above = V[((PAR + 3) & 1) ? t1 : t0];       // (4w+4, column of row 3's cell)
-        double vn[4];
+        const double below = V[(PAR & 1) ? b1 : b0];             // (row below the band, column of row 0's cell)
+        const double above = V[((PAR + R - 1) & 1) ? t1 : t0];   // (row above the band, column of the last row's cell)
+        // a pass only reads cells of the other class: every result goes straight back
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
+        for (int m = 0; m < R; m++) {
             const int q = (PAR + m) & 1;
             const double me = v[m][q];
-            double up = (m < 3) ? v[m < 3 ? m + 1 : 3][q] : above;     // row r + 1
+            double up = (m < R - 1) ? v[m < R - 1 ? m + 1 : R - 1][q] : above;     // row r + 1
             double dn = (m > 0) ? v[m > 0 ? m - 1 : 0][q] : below;     // row r - 1
             // the thread's other cell and the neighbouring lane's
             const double own = v[m][q ^ 1];
@@ -716,14 +728,13 @@ __global__ __launch_bounds__(MGW_NT, 4) void k_mg_smooth_band(MGTile A)
                 w = isW[q] ? ghost_h(c2, me) : w;
             }
             if (POW2)
-                vn[m] = fma(A.ky, e + w, fma(A.kx, up + dn, f[m][q]));
+                v[m][q] = fma(A.ky, e + w, fma(A.kx, up + dn, f[m][q]));
             else
-                vn[m] = div_by(f[m][q] + A.xc * (up + dn) + A.yc * (e + w), A.denom, A.rdenom);
+                v[m][q] = div_by(f[m][q] + A.xc * (up + dn) + A.yc * (e + w), A.denom, A.rdenom);
+            if (m % 4 == 3) MGB_SCHED_FENCE();             // four rows interleaved, not R (VGPR budget)
         }
-#pragma unroll
-        for (int m = 0; m < 4; m++) v[m][(PAR + m) & 1] = vn[m];
         V[(PAR & 1) ? w01 : w00] = v[0][PAR & 1];
-        V[((PAR + 3) & 1) ? w31 : w30] = v[3][(PAR + 3) & 1];
+        V[((PAR + R - 1) & 1) ? w31 : w30] = v[R - 1][(PAR + R - 1) & 1];
     };
     const int npass = 2 * A.K;
     for (int s = 1; s <= npass; s++) {
@@ -740,10 +751,10 @@ __global__ __launch_bounds__(MGW_NT, 4) void k_mg_smooth_band(MGTile A)
     // cells; on periodic sides the tile that owns row / column n (1) also writes ghost
     // row / column 0 (n + 1), so that the other kernels find current edge ghosts ----
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
+    for (int m = 0; m < R; m++) {
         const int gi = gi0 + r0 + m;                      // unwrapped
         if (gi < ti0 || gi > ti1) continue;
-        const size_t row = (size_t)gi * A.pitch;
+        const unsigned row = (unsigned)(gi * A.pitch);
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int gj = gj0 + 2 * ln + q;
@@ -752,10 +763,10 @@ __global__ __launch_bounds__(MGW_NT, 4) void k_mg_smooth_band(MGTile A)
             A.vout[row + gj] = x;
             if (per_i) {
                 if (gi == n) A.vout[gj] = x;
-                if (gi == 1) A.vout[(size_t)(n + 1) * A.pitch + gj] = x;
+                if (gi == 1) A.vout[(unsigned)((n + 1) * A.pitch + gj)] = x;
             } else {
                 if (gi == 1) A.vout[gj] = ghost_h(c0, x);
-                if (gi == n) A.vout[(size_t)(n + 1) * A.pitch + gj] = ghost_h(c1, x);
+                if (gi == n) A.vout[(unsigned)((n + 1) * A.pitch + gj)] = ghost_h(c1, x);
             }
             if (per_j) {
                 if (gj == n) A.vout[row] = x;
@@ -1671,16 +1682,16 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
             const bool edge = A.bc.code[0] != PYROHIP_BC_PERIODIC || A.bc.code[2] != PYROHIP_BC_PERIODIC;
             if (band && hom && pow2 && edge)
                 PYRO_LAUNCH(m->ctx, "k_mg_smooth_band", (k_mg_smooth_band<true, true>), dim3(A.ntiles),
-                            dim3(MGW_NT), MGW_LDS, A);
+                            dim3(MGB_NT), MGW_LDS, A);
             else if (band && hom && pow2)
                 PYRO_LAUNCH(m->ctx, "k_mg_smooth_band", (k_mg_smooth_band<true, false>), dim3(A.ntiles),
-                            dim3(MGW_NT), MGW_LDS, A);
+                            dim3(MGB_NT), MGW_LDS, A);
             else if (band && hom && edge)
                 PYRO_LAUNCH(m->ctx, "k_mg_smooth_band", (k_mg_smooth_band<false, true>), dim3(A.ntiles),
-                            dim3(MGW_NT), MGW_LDS, A);
+                            dim3(MGB_NT), MGW_LDS, A);
             else if (band && hom)
                 PYRO_LAUNCH(m->ctx, "k_mg_smooth_band", (k_mg_smooth_band<false, false>), dim3(A.ntiles),
-                            dim3(MGW_NT), MGW_LDS, A);
+                            dim3(MGB_NT), MGW_LDS, A);
             else if (pow2)
                 PYRO_LAUNCH(m->ctx, "k_mg_smooth_tile", (k_mg_smooth_tile<MGW_NT, MGW_LP, true>),
                             dim3(A.ntiles), dim3(MGW_NT), MGW_LDS, A);
