@@ -206,6 +206,16 @@ typedef struct {
     /* kernel_set 2: rows per strip of the row-marching kernel; 0 = chosen by
        the library from the grid size and the CU count (tuning / test knob)  */
     int march_rows;
+    /* 1: pyrohip_comp_step / pyrohip_comp_evolve take the state with UNFILLED ghost cells
+       and apply the boundary rules themselves (CellCenterData2d.fill_BC_all, patch.py:
+       582-624, folded into the step).  The 2-d tile kernel (kernel_set 1, grids below
+       2048^2) then reads every ghost cell from the cell the rule copies from -- two
+       launches less per step, which is what a step on a 64^2 ... 512^2 grid consists
+       of -- wherever the boundaries are outflow / reflect / periodic / halo and there
+       are no source terms; in every other case the step runs the ordinary fill first.
+       Either way the ghost cells of the new state hold the filled ghost cells of the old
+       one, like the reference's array after evolve(). */
+    int fuse_fill;
 } pyrohip_comp_params;
 
 /* method_compute_timestep (compressible/simulation.py:267-288 +
@@ -462,6 +472,9 @@ int pyrohip_comm_destroy(pyrohip_ctx *ctx);
    pyrohip_comp_dt comes from that reduced value (no pyrohip_allreduce_min
    needed) or from a local reduction (first step, after an upload).          */
 int pyrohip_comm_set_global_dt(pyrohip_ctx *ctx, int on);
+/* flag = 1: pyrohip_comp_dt will answer from the CFL minimum the last step kernel left
+   behind, without reading the state (so its ghost cells need not be filled: fuse_fill) */
+int pyrohip_comp_dt_is_cached(pyrohip_state *s, int *flag);
 int pyrohip_comp_dt_is_global(pyrohip_state *s, int *flag);
 /* exchange ng ghost rows of every variable with the x neighbours
    (rank_lo / rank_hi, -1 = none).  Replaces the single-domain x ghost fill

@@ -827,6 +827,33 @@ def gen_compressible_general_source():
     save("comp_general_source", **out)
 
 
+def _regression(solver, problem, inputs, h5name, names, save_as, ng):
+    """run the reference (pyro/test.py entry), check it against its stored regression file
+    and keep IC, dt sequence, the run's end state and the stored one"""
+    p = Pyro(solver)
+    p.initialize_problem(problem, inputs_file=inputs)
+    ic = np.array(p.sim.cc_data.data)
+    dts = []
+    while not p.sim.finished():
+        p.single_step()
+        dts.append(p.sim.dt)
+    with h5py.File(REF + "/" + h5name, "r") as f:
+        assert int(f.attrs["nsteps"]) == p.sim.n, (f.attrs["nsteps"], p.sim.n)
+        gold = np.stack([f["state/" + nm + "/data"][...] for nm in names], axis=-1)
+    run = np.stack([np.array(p.sim.cc_data.get_var(nm).v()) for nm in names], axis=-1)
+    print(save_as, ": reference run vs stored golden, max abs err", np.abs(run - gold).max(),
+          "steps", p.sim.n)
+    save(save_as, ic=ic, gold=gold, run=run, dts=np.array(dts), nsteps=np.array(p.sim.n))
+
+
+def gen_regressions2():
+    """pyro/test.py:99 burgers test (test_0051.h5) and :103 compressible_rk rt (rt_1835.h5)"""
+    _regression("burgers", "test", "inputs.test", "burgers/tests/test_0051.h5",
+                ["x-velocity", "y-velocity"], "burgers_test_0051", 4)
+    _regression("compressible_rk", "rt", "inputs.rt", "compressible_rk/tests/rt_1835.h5",
+                ["density", "energy", "x-momentum", "y-momentum"], "comp_rk_rt_1835", 4)
+
+
 def gen_mesh_utils():
     """the general mesh utilities next to the hot path: CellCenterData2d.restrict (by 2 and
     by 4) / prolong on a rectangular grid with ng = 2, EdgeCoeffs and its restriction"""
@@ -1386,6 +1413,8 @@ if __name__ == "__main__":
         gen_compressible_ramp()
     if "comp_heating" in sys.argv[1:]:
         gen_compressible_heating()
+    if "regressions2" in sys.argv[1:]:
+        gen_regressions2()
     if "mesh_utils" in sys.argv[1:]:
         gen_mesh_utils()
     if "comp_general_source" in sys.argv[1:]:

@@ -51,7 +51,7 @@ class CompParams(C.Structure):
                 ("riemann", C.c_int), ("solid_xl", C.c_int), ("solid_yl", C.c_int),
                 ("do_sponge", C.c_int), ("sponge_rho_begin", C.c_double),
                 ("sponge_rho_full", C.c_double), ("sponge_timescale", C.c_double),
-                ("heat_rate", C.c_double), ("march_rows", C.c_int)]
+                ("heat_rate", C.c_double), ("march_rows", C.c_int), ("fuse_fill", C.c_int)]
 
 
 class DtPolicyC(C.Structure):
@@ -87,6 +87,7 @@ _PROTOS = {
     "pyrohip_device_count": [C.POINTER(C.c_int)],
     "pyrohip_comm_set_global_dt": [_VP, C.c_int],
     "pyrohip_comp_dt_is_global": [_VP, C.POINTER(C.c_int)],
+    "pyrohip_comp_dt_is_cached": [_VP, C.POINTER(C.c_int)],
     "pyrohip_mg_set_general_coeffs": [_VP, _DP, _DP, _DP, _DP, C.POINTER(C.c_int)],
     "pyrohip_comp_rk_rhs": [_VP, C.POINTER(CompParams), _VP, C.c_int],
     "pyrohip_comp_rk_dt": [_VP, C.POINTER(CompParams), C.c_double, _DP],

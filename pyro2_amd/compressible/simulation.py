@@ -91,6 +91,10 @@ class Simulation(NullSimulation):
         my_data.set_aux("gamma", self.rp.get_param("eos.gamma"))
         my_data.set_aux("grav", self.rp.get_param("compressible.grav"))
         my_data.create()
+        # fill_BC_all may be folded into the step kernel (pyrohip_comp_params.fuse_fill:
+        # on grids below 2048^2 a step is mostly launches); any other look at the data
+        # carries the fill out first (mesh/patch.py fill_BC_all)
+        my_data.lazy_fill = True
         self.cc_data = my_data
         self.ivars = Variables(my_data)
         self.cc_data.add_derived(derives.derive_primitives)
@@ -132,9 +136,11 @@ class Simulation(NullSimulation):
             self._heat_cache = (float(rate), np.ascontiguousarray(prof, dtype=np.float64))
         return self._heat_cache
 
-    def _device_state(self):
-        """the state on the device, carrying the heating profile if there is one"""
-        st = self.cc_data.device_state()
+    def _device_state(self, fuse_fill=False):
+        """the state on the device, carrying the heating profile if there is one;
+        fuse_fill: a ghost fill that fill_BC_all deferred stays pending (the caller's
+        kernel does it, or does not need ghost cells)"""
+        st = self.cc_data.device_state(fuse_fill=fuse_fill)
         g = self.cc_data.grid
         if g.coord_type == 1 and getattr(st, "_geometry_set", False) is False:
             st.set_geometry(g.device_geometry(), g.xmin, g.ymin)
@@ -149,7 +155,10 @@ class Simulation(NullSimulation):
         """cfl * min(dx/(|u|+c), dy/(|v|+c)) over the whole array
         (compressible/simulation.py:267-288), reduced on the device"""
         cfl = self.rp.get_param("driver.cfl")
-        self.dt = self._device_state().comp_dt(self._params(), float(cfl))
+        st = self._device_state(fuse_fill=True)
+        if not st.comp_dt_is_cached():       # the reduction reads the ghost cells too
+            st = self._device_state()
+        self.dt = st.comp_dt(self._params(), float(cfl))
 
     def _host_source(self):
         """is the problem source an arbitrary callback the host has to evaluate
@@ -200,11 +209,14 @@ class Simulation(NullSimulation):
     def evolve(self):
         tm = self.tc.timer("evolve")
         tm.begin()
-        st = self._device_state()
         if self._host_source():
+            self._device_state()
             self._evolve_host_source()
         else:
-            st.comp_step(self._params(), float(self.dt))
+            st = self._device_state(fuse_fill=True)
+            P = self._params()
+            P.fuse_fill = int(self.cc_data.take_pending_fill())
+            st.comp_step(P, float(self.dt))
         self.cc_data.device_modified()
         self.advance_particles()         # compressible/simulation.py:443-444
         self.cc_data.t += self.dt

@@ -65,31 +65,6 @@ __device__ __forceinline__ double adv_m1(double v) { return __shfl_up(v, 1, 64);
 __device__ __forceinline__ double adv_p1(double v) { return __shfl_down(v, 1, 64); }
 #endif
 
-// Ghost fill as an index map (array_indexer.py:163-274 / k_fill_x, k_fill_y of
-// ctx.hip): the source of array index i is a * i + b with (a, b) per side --
-// outflow (0, edge), reflect (-1, mirror), periodic (1, shift); interior and
-// other boundary types map to themselves.  Branch-free, so that the row map in
-// the marching loop stays on the scalar unit.
-struct BcMap { int alo, blo, ahi, bhi; bool odd_lo, odd_hi; };
-__host__ __device__ inline BcMap bc_map(int lo, int hi, int ng, int bl, int br, bool fill)
-{
-    BcMap m{1, 0, 1, 0, false, false};
-    if (!fill) return m;
-    if (bl == PYROHIP_BC_OUTFLOW) { m.alo = 0; m.blo = lo; }
-    else if (bl == PYROHIP_BC_REFLECT_EVEN || bl == PYROHIP_BC_REFLECT_ODD) { m.alo = -1; m.blo = 2 * ng - 1; }
-    else if (bl == PYROHIP_BC_PERIODIC) { m.alo = 1; m.blo = hi - ng + 1; }
-    if (br == PYROHIP_BC_OUTFLOW) { m.ahi = 0; m.bhi = hi; }
-    else if (br == PYROHIP_BC_REFLECT_EVEN || br == PYROHIP_BC_REFLECT_ODD) { m.ahi = -1; m.bhi = 2 * hi + 1; }
-    else if (br == PYROHIP_BC_PERIODIC) { m.ahi = 1; m.bhi = ng - hi - 1; }
-    m.odd_lo = (bl == PYROHIP_BC_REFLECT_ODD);
-    m.odd_hi = (br == PYROHIP_BC_REFLECT_ODD);
-    return m;
-}
-__device__ __forceinline__ int bc_src(const BcMap &m, int i, int lo, int hi)
-{
-    return i < lo ? m.alo * i + m.blo : (i > hi ? m.ahi * i + m.bhi : i);
-}
-
 // limited slope from shared limit2 values (reconstruction.py:9-120)
 template <int LIM>
 __device__ __forceinline__ double adv_slope(double l2m, double l20, double l2p, double am1, double a0,

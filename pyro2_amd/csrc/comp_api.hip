@@ -48,6 +48,33 @@ static bool wave_kernel_pays(const Geom &g)
     return (double)g.nx * (double)g.ny >= 2048.0 * 2048.0;
 }
 
+// May the tile kernel read the ghost cells through the boundary rules instead of from
+// memory (pyrohip_comp_params.fuse_fill)?  Index maps exist for outflow / reflect /
+// periodic sides (halo rows are data); all four variables must follow the same kind of
+// rule on a side (they do for bc / bc_xodd / bc_yodd, simulation_null.py:72-112); the
+// source terms read ghost cells of their own.
+static bool comp_can_fuse_fill(const pyrohip_state *s, const pyrohip_comp_params *p, bool wave)
+{
+    if (wave || p->kernel_set == 0 || s->sph || s->user_bc || s->ramp_bc || s->ext_old ||
+        p->grav != 0.0 || s->heat != nullptr)
+        return false;
+    for (int sd = 0; sd < 4; sd++) {
+        int kind0 = -1;
+        for (int n = 0; n < 4; n++) {
+            const int b = s->bc[n * 4 + sd];
+            int kind;
+            if (b == PYROHIP_BC_OUTFLOW) kind = 0;
+            else if (b == PYROHIP_BC_REFLECT_EVEN || b == PYROHIP_BC_REFLECT_ODD) kind = 1;
+            else if (b == PYROHIP_BC_PERIODIC) kind = 2;
+            else if (b == PYROHIP_BC_HALO) kind = 3;
+            else return false;
+            if (n == 0) kind0 = kind;
+            else if (kind != kind0) return false;
+        }
+    }
+    return true;
+}
+
 static int check_comp(pyrohip_state *s, const pyrohip_comp_params *p)
 {
     PYRO_REQUIRE(s && p, "NULL argument");
@@ -126,10 +153,15 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
     const double *dmin = nullptr;
     bool first = true;
     int rc = 0;
+    // steps after the first: the tile kernel applies the boundary rules itself where it can
+    // (the first one needs filled ghost cells for the CFL minimum over the whole array)
+    const bool fuse = comp_can_fuse_fill(s, p, wave);
+    pyrohip_comp_params pf = *p;
     for (int m = 0; m < max_steps && rc == 0; m++) {
         // ghost cells: halos of a slab first, then the boundary fill (pyro_sim.py:250-256)
         if (s->nb_set && c->comm != nullptr) rc = pyrohip_halo_exchange(s, s->nb_lo, s->nb_hi);
-        if (rc == 0) rc = pyrohip_fill_bc(s, -1);
+        pf.fuse_fill = (fuse && !first) ? 1 : 0;
+        if (rc == 0 && !pf.fuse_fill) rc = pyrohip_fill_bc(s, -1);
         if (rc) break;
         if (first) {   // CFL minimum of the state as handed over (full array, ghost cells filled)
             rc = p->fast_math ? fastm::comp_cfl_min_device(s, p, &dmin)
@@ -144,8 +176,8 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
             rc = p->fast_math ? fastm::comp_step_wave_ex(s, p, 0.0, s->d_scal, &dmin)
                               : exact::comp_step_wave_ex(s, p, 0.0, s->d_scal, &dmin);
         else
-            rc = p->fast_math ? fastm::comp_step_fused_ex(s, p, 0.0, s->d_scal, &dmin)
-                              : exact::comp_step_fused_ex(s, p, 0.0, s->d_scal, &dmin);
+            rc = p->fast_math ? fastm::comp_step_fused_ex(s, &pf, 0.0, s->d_scal, &dmin)
+                              : exact::comp_step_fused_ex(s, &pf, 0.0, s->d_scal, &dmin);
     }
     PYRO_TRY(rc);
     hipLaunchKernelGGL(k_dt_policy, dim3(1), dim3(1), 0, c->stream, s->d_scal, dmin,
@@ -197,6 +229,13 @@ int pyrohip_comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, 
     return p->fast_math ? fastm::comp_dt(s, p, cfl, dt_out) : exact::comp_dt(s, p, cfl, dt_out);
 }
 
+int pyrohip_comp_dt_is_cached(pyrohip_state *s, int *flag)
+{
+    PYRO_REQUIRE(s && flag, "NULL argument");
+    *flag = (s->next_cfl_min > 0.0 && !s->sph && !s->user_bc && !s->ramp_bc) ? 1 : 0;
+    return 0;
+}
+
 int pyrohip_comp_dt_is_global(pyrohip_state *s, int *flag)
 {
     PYRO_REQUIRE(s && flag, "NULL argument");
@@ -213,6 +252,17 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     int rc;
     PYRO_REQUIRE(!s->ext_pending, "the corrector of the host-evaluated source has not run "
                                   "(pyrohip_comp_source_correct)");
+    pyrohip_comp_params pf = *p;
+    if (p->fuse_fill) {
+        // ghost cells not filled by the caller: folded into the tile kernel where that
+        // works, the ordinary fill first everywhere else
+        const bool wave = !s->sph && (p->kernel_set == 2 || (p->kernel_set == -1 && wave_kernel_pays(s->g)));
+        if (!comp_can_fuse_fill(s, p, wave)) {
+            PYRO_TRY(pyrohip_fill_bc(s, -1));
+            pf.fuse_fill = 0;
+        }
+        p = &pf;
+    }
     if (s->sph) {
         // compressible/simulation.py:206-208: no HLLC on a SphericalPolar grid
         PYRO_REQUIRE(p->riemann == 1, "a SphericalPolar grid needs the CGF Riemann solver");

@@ -54,6 +54,34 @@ constexpr size_t FLDS_BYTES = (size_t)FLDS_DOUBLES * sizeof(double);
 
 #include "fused_common.h"
 
+// parity of a 4-bit set of sides
+__device__ __forceinline__ bool odd_sides(unsigned m)
+{
+    m &= 15u;
+    m ^= m >> 2;
+    m ^= m >> 1;
+    return (m & 1u) != 0;
+}
+
+// Cell (gi, gj) of the old state as fill_BC_all leaves it: a ghost cell is read from the
+// cell its boundary rule copies from (x fill, then y fill: both maps; itself without
+// fuse_fill), with the sign of the variables that reflect oddly on the sides crossed.
+// sd: the sides the cell lies beyond (0: interior).
+__device__ __forceinline__ Cons load_cons_bc(const double *__restrict__ Uin, const Geom &g,
+                                             const FP &P, int gi, int gj, unsigned &sd)
+{
+    const int si = bc_src(P.mr, gi, g.ilo, g.ihi), sj = bc_src(P.mc, gj, g.jlo, g.jhi);
+    const size_t k = (size_t)si * g.pitch + sj, pl = g.plane;
+    sd = (gi < g.ilo ? 1u : 0u) | (gi > g.ihi ? 2u : 0u) | (gj < g.jlo ? 4u : 0u) |
+         (gj > g.jhi ? 8u : 0u);
+    Cons U{Uin[k], Uin[pl + k], Uin[2 * pl + k], Uin[3 * pl + k]};
+    U.d = odd_sides(P.odd & sd) ? -U.d : U.d;
+    U.E = odd_sides((P.odd >> 4) & sd) ? -U.E : U.E;
+    U.mx = odd_sides((P.odd >> 8) & sd) ? -U.mx : U.mx;
+    U.my = odd_sides((P.odd >> 12) & sd) ? -U.my : U.my;
+    return U;
+}
+
 __device__ __forceinline__ Cons lds_get(const double *b, int t)
 {
     return Cons{b[t], b[FNT + t], b[2 * FNT + t], b[3 * FNT + t]};
@@ -142,11 +170,24 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
             const int ii = act[n] ? idx : t;       // idle lanes re-read their first cell
             const int r = ii / FQW, c = ii - r * FQW;
             int gi = i0 - 4 + r, gj = j0 - 4 + c;
+            const bool inarr = act[n] && gi < g.qx && gj < g.qy;
             gi = (gi < g.qx) ? gi : g.qx - 1;   // ragged last tiles: clamp, unused
             gj = (gj < g.qy) ? gj : g.qy - 1;
-            const size_t k = (size_t)gi * p + gj;
-            Ul[n] = Cons{Uin[k], Uin[pl + k], Uin[2 * pl + k], Uin[3 * pl + k]};
-            interior[n] = (gi >= g.ilo && gi <= g.ihi && gj >= g.jlo && gj <= g.jhi);
+            // ghost cells: the cell the boundary rule copies from (itself without
+            // fuse_fill), with the sign of reflect-odd variables -- the value
+            // fill_BC_all would have stored (x fill, then y fill: both maps)
+            unsigned sd;
+            const Cons U = load_cons_bc(Uin, g, P, gi, gj, sd);
+            Ul[n] = U;
+            interior[n] = (sd == 0);
+            // the ghost frame of the new state: what the old state's ghost cells hold
+            // (after the fill, when it is folded in) -- as in the reference, where the
+            // update leaves the ghost cells of the array alone.  Tiles whose aprons
+            // overlap write the same values.
+            if (inarr && sd != 0) {
+                const size_t ko = (size_t)gi * p + gj;
+                Uout[ko] = U.d; Uout[pl + ko] = U.E; Uout[2 * pl + ko] = U.mx; Uout[3 * pl + ko] = U.my;
+            }
         }
 #pragma unroll
         for (int n = 0; n < NIT; n++) {
@@ -272,8 +313,10 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
 
     // ---- phase 4: final Riemann problems + artificial viscosity ---------
     const bool in_arr = (i < g.qx && j < g.qy);
-    const size_t k = (size_t)(in_arr ? i : g.qx - 1) * p + (in_arr ? j : g.qy - 1);
-    Cons Uc{Uin[k], Uin[pl + k], Uin[2 * pl + k], Uin[3 * pl + k]};
+    const int ic = in_arr ? i : g.qx - 1, jc = in_arr ? j : g.qy - 1;
+    const size_t k = (size_t)ic * p + jc;
+    unsigned sdc;
+    Cons Uc = load_cons_bc(Uin, g, P, ic, jc, sdc);
     const bool cell_interior = (i >= g.ilo && i <= g.ihi && j >= g.jlo && j <= g.jhi);
     if (cell_interior) Uc.d = fmax(Uc.d, P.small_dens);
     Cons Fx{0, 0, 0, 0}, Fy{0, 0, 0, 0};
@@ -281,8 +324,8 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
     // the lower neighbours' old states for the artificial-viscosity terms:
     // loaded (L2 hits) before the Riemann problems so that the latency is
     // covered by them.  k - p / k - 1 are inside the array for every thread.
-    Cons Umx{Uin[k - p], Uin[pl + k - p], Uin[2 * pl + k - p], Uin[3 * pl + k - p]};
-    Cons Umy{Uin[k - 1], Uin[pl + k - 1], Uin[2 * pl + k - 1], Uin[3 * pl + k - 1]};
+    Cons Umx = load_cons_bc(Uin, g, P, ic - 1, jc, sdc);
+    Cons Umy = load_cons_bc(Uin, g, P, ic, jc - 1, sdc);
     double avx = 0.0, avy = 0.0;
     // interface.py:366-376: only faces i in [ilo, ihi], j in [jlo, jhi]
     if (ti >= 1 && tj >= 1 && tj <= FBJ - 2 && i >= g.ilo &&
@@ -400,6 +443,9 @@ int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP 
     P.ntj = P.ntiles = 0;
     P.L = P.ncb = 0;
     P.sb_first = 0; P.sb_step = 1;
+    P.mr = bc_map(g.ilo, g.ihi, g.ng, 0, 0, false);      // identity (tile kernel: fused_fill_maps)
+    P.mc = P.mr;
+    P.odd = 0;
     if (reset_flag) PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
     return 0;
 }
@@ -472,6 +518,15 @@ int comp_step_fused_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt
     FP P;
     double *Uin, *Uout;
     PYRO_TRY(fused_prepare(s, p, dt, P, Uin, Uout, S == nullptr));
+    if (p->fuse_fill) {
+        // the caller checked comp_can_fuse_fill(): outflow / reflect / periodic / halo sides
+        // (the same kinds for all four variables; halo rows are data), no source terms
+        P.mr = bc_map(g.ilo, g.ihi, g.ng, s->bc[0], s->bc[1], true);
+        P.mc = bc_map(g.jlo, g.jhi, g.ng, s->bc[2], s->bc[3], true);
+        for (int n = 0; n < 4; n++)
+            for (int sd = 0; sd < 4; sd++)
+                if (s->bc[n * 4 + sd] == PYROHIP_BC_REFLECT_ODD) P.odd |= 1u << (4 * n + sd);
+    }
     const int nti = (g.nx + FTI - 1) / FTI;
     P.ntj = (g.ny + FTJ - 1) / FTJ;
     P.ntiles = nti * P.ntj;
@@ -503,7 +558,7 @@ int comp_step_fused_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt
                     (const double *)Uin, Uout, g, P, s->d_flag, part, S);
     }
     const double *dmin;
-    PYRO_TRY(fused_tail(s, part, P.ntiles, false, &dmin));
+    PYRO_TRY(fused_tail(s, part, P.ntiles, true, &dmin));   // the kernel wrote the ghost frame
     if (S) { fused_swap(s); *dmin_out = dmin; return 0; }
     return fused_sync(s, dmin);
 }

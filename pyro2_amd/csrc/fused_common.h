@@ -23,6 +23,11 @@ struct FP {   // kernel parameters
     int solid_xl, solid_yl;   // CGF wall rule (riemann.py:274-286)
     int L, ncb;               // row-marching kernel: rows per strip, column blocks
     int sb_first, sb_step;    // ... strip of workgroup b: sb_first + (b / ncb) * sb_step
+    // tile kernel: the ghost fill folded into the loads (pyrohip_comp_params.fuse_fill):
+    // row / column maps of the boundary rules (identity without) and, per variable and
+    // side, whether the ghost value changes sign (bit 4 n + side)
+    BcMap mr, mc;
+    unsigned odd;
 };
 
 // host side, defined in comp_fused.hip

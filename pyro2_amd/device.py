@@ -384,6 +384,12 @@ class DeviceState:
             check(self._l.pyrohip_comp_dt(self.h, C.byref(params), cfl, C.byref(dt)))
         return dt.value
 
+    def comp_dt_is_cached(self):
+        """will comp_dt answer from the CFL minimum of the last step (no look at the state)?"""
+        f = C.c_int()
+        check(self._l.pyrohip_comp_dt_is_cached(self.h, C.byref(f)))
+        return bool(f.value)
+
     def comp_dt_is_global(self):
         f = C.c_int()
         check(self._l.pyrohip_comp_dt_is_global(self.h, C.byref(f)))
@@ -452,7 +458,8 @@ def make_comp_params(dx, dy, gamma=1.4, limiter=2, use_flattening=1, z0=0.75,
                      z1=0.85, delta=0.33, cvisc=0.1, grav=0.0,
                      small_dens=-1.e200, avisc_xhi_interior=0,
                      avisc_yhi_interior=0, fast_math=0, kernel_set=0, riemann="HLLC",
-                     solid_xl=0, solid_yl=0, sponge=None, heat_rate=0.0, march_rows=0):
+                     solid_xl=0, solid_yl=0, sponge=None, heat_rate=0.0, march_rows=0,
+                     fuse_fill=0):
     p = CompParams()
     p.dx, p.dy, p.gamma = dx, dy, gamma
     p.limiter, p.use_flattening = int(limiter), int(use_flattening)
@@ -468,6 +475,7 @@ def make_comp_params(dx, dy, gamma=1.4, limiter=2, use_flattening=1, z0=0.75,
         p.sponge_rho_begin, p.sponge_rho_full, p.sponge_timescale = sponge
     p.heat_rate = float(heat_rate)     # used when the state carries a heating profile
     p.march_rows = int(march_rows)     # kernel_set 2 only; 0 = automatic
+    p.fuse_fill = int(fuse_fill)       # 1: the step applies the boundary rules itself
     return p
 
 

@@ -149,6 +149,42 @@ def test_comp_fused_vs_reference(dev, golden, k, kset):
     assert abs(s.comp_dt(P, cfl) - dto) <= tol * dto
 
 
+@pytest.mark.parametrize("fast", [0, 1])
+@pytest.mark.parametrize("k", range(8))
+def test_comp_fused_ghost_fill(dev, golden, k, fast):
+    """pyrohip_comp_params.fuse_fill: the step takes a state whose ghost cells are NOT
+    filled (here: overwritten with NaN) and applies the boundary rules itself -- inside
+    the tile kernel where it can (outflow / reflect / periodic sides, no sources), by the
+    ordinary fill first elsewhere.  Five steps: bit-identical, ghost frame included, to
+    fill_bc() + comp_step() on the eight reference states of comp_stages.npz (all
+    boundary combinations, gravity in some)"""
+    g = golden("comp_stages")
+    bcs = [str(b) for b in g[f"c{k}_bc"]]
+    meta = g[f"c{k}_meta"]
+    nx, ny, ng = int(meta[0]), int(meta[1]), int(meta[2])
+    P, cfl = dev_params(meta, fast_math=fast, kernel_set=1)
+    Pf, _ = dev_params(meta, fast_math=fast, kernel_set=1, fuse_fill=1)
+    a, b = comp_state(dev, nx, ny, bcs), comp_state(dev, nx, ny, bcs)
+    U0 = g[f"c{k}_U0"]
+    a.upload(U0)
+    a.fill_bc()
+    junk = U0.copy()
+    m = np.ones(U0.shape[:2], bool)
+    m[ng:-ng, ng:-ng] = False
+    junk[m] = np.nan
+    b.upload(junk)
+    dt = float(g[f"c{k}_dt"])
+    for step in range(5):
+        a.fill_bc()
+        a.comp_step(P, dt)
+        assert b.comp_dt_is_cached() == (step > 0)
+        b.comp_step(Pf, dt)
+        A, B = a.download(), b.download()
+        assert np.array_equal(A, B), (k, step, np.argwhere(A != B)[:5])
+        dt = 0.5 * cfl * min(a.comp_dt(P, 1.0), 1e30)
+        assert b.comp_dt(Pf, 1.0) == a.comp_dt(P, 1.0)
+
+
 def device_comp_run(dev, ic, meta, bcs, tmax, max_steps, ambient=None, **kw):
     """Pyro.run_sim loop (pyro_sim.py:219-256) with the device kernels"""
     P, cfl = dev_params(meta, **kw)
