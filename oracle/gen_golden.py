@@ -850,8 +850,14 @@ def gen_regressions2():
     """pyro/test.py:99 burgers test (test_0051.h5) and :103 compressible_rk rt (rt_1835.h5)"""
     _regression("burgers", "test", "inputs.test", "burgers/tests/test_0051.h5",
                 ["x-velocity", "y-velocity"], "burgers_test_0051", 4)
-    _regression("compressible_rk", "rt", "inputs.rt", "compressible_rk/tests/rt_1835.h5",
-                ["density", "energy", "x-momentum", "y-momentum"], "comp_rk_rt_1835", 4)
+    # compressible_rk rt: 1835 RK steps take hours with the njit kernels stubbed; the
+    # stored regression file alone is the target (the initial condition is that of the
+    # compressible rt problem, pinned by comp_rt_0945)
+    names = ["density", "energy", "x-momentum", "y-momentum"]
+    with h5py.File(REF + "/compressible_rk/tests/rt_1835.h5", "r") as f:
+        gold = np.stack([f["state/" + nm + "/data"][...] for nm in names], axis=-1)
+        save("comp_rk_rt_1835", gold=gold, nsteps=np.array(int(f.attrs["nsteps"])),
+             time=np.array(float(f.attrs["time"])))
 
 
 def gen_mesh_utils():

@@ -198,6 +198,10 @@ struct pyrohip_state {
     pyro::StepScalars *d_scal = nullptr;   // pyrohip_comp_evolve
     double *d_dts = nullptr;  // ... dt of every step of a call
     int dts_cap = 0;
+    // CFL partials of the last tile-kernel launch whose minimum the next policy kernel
+    // takes itself (device-side stepping of small grids: one launch less per step)
+    double *pend_part = nullptr;
+    int pend_n = 0;
     double *d_cval = nullptr; // per-variable ghost value of PYROHIP_BC_CONST sides
     pyro::SphGeom *sph = nullptr;   // SphericalPolar geometry (compressible solver)
     // x neighbours of a slab (pyrohip_state_set_neighbours, -1 = none) and

@@ -55,7 +55,8 @@ static bool wave_kernel_pays(const Geom &g)
 // source terms read ghost cells of their own.
 static bool comp_can_fuse_fill(const pyrohip_state *s, const pyrohip_comp_params *p, bool wave)
 {
-    if (wave || p->kernel_set == 0 || s->sph || s->user_bc || s->ramp_bc || s->ext_old ||
+    static const bool off = getenv("PYRO_COMP_NOFUSE") != nullptr;     // A/B knob (tools/small_step.py)
+    if (off || wave || p->kernel_set == 0 || s->sph || s->user_bc || s->ramp_bc || s->ext_old ||
         p->grav != 0.0 || s->heat != nullptr)
         return false;
     for (int sd = 0; sd < 4; sd++) {
@@ -91,9 +92,31 @@ static int check_comp(pyrohip_state *s, const pyrohip_comp_params *p)
 // (t < tmax, state still valid) and derives its dt from the CFL minimum the previous
 // step kernel left in device memory.  One thread; IEEE operations in the reference's
 // order (this unit is compiled without FMA contraction).
-__global__ void k_dt_policy(StepScalars *S, const double *cflmin, const int *flag, double *dts,
-                            int slot, int final_call)
+__global__ __launch_bounds__(256) void k_dt_policy(StepScalars *S, const double *cflmin,
+                                                   const int *flag, double *dts, int slot,
+                                                   int final_call, const double *part, int nparts,
+                                                   double *minout)
 {
+    // the CFL minimum of the previous step: already reduced (cflmin), or still the
+    // per-workgroup partials of the tile kernel (part: reduced here, kept in minout)
+    __shared__ double red[256];
+    __shared__ double cmin_s;
+    if (part != nullptr) {
+        double m = INFINITY;
+        for (int i = threadIdx.x; i < nparts; i += blockDim.x) m = fmin(m, part[i]);
+        red[threadIdx.x] = m;
+        __syncthreads();
+        for (int w = blockDim.x / 2; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) red[threadIdx.x] = fmin(red[threadIdx.x], red[threadIdx.x + w]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { cmin_s = red[0]; *minout = red[0]; }
+    } else if (threadIdx.x == 0) {
+        cmin_s = *cflmin;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double cmin = cmin_s;
     const bool invalid = (*flag & 1) != 0;   // raised by the step that just ran: it does not count
     if (S->active && !invalid) { S->t += S->dt; S->n += 1; S->steps += 1; }
     S->active = 0;
@@ -104,7 +127,7 @@ __global__ void k_dt_policy(StepScalars *S, const double *cflmin, const int *fla
         if (S->fix_dt > 0.0) {
             dt = S->fix_dt;
         } else {
-            dt = S->cfl * (*cflmin);
+            dt = S->cfl * cmin;
             if (S->n == 0) dt = S->f0 * dt;
             else dt = fmin(S->mx * S->dt_old, dt);
             S->dt_old = dt;
@@ -153,6 +176,7 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
     const double *dmin = nullptr;
     bool first = true;
     int rc = 0;
+    s->pend_part = nullptr;
     // steps after the first: the tile kernel applies the boundary rules itself where it can
     // (the first one needs filled ghost cells for the CFL minimum over the whole array)
     const bool fuse = comp_can_fuse_fill(s, p, wave);
@@ -169,8 +193,11 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
             if (rc) break;
             first = false;
         }
-        hipLaunchKernelGGL(k_dt_policy, dim3(1), dim3(1), 0, c->stream, s->d_scal, dmin,
-                           (const int *)s->d_flag, s->d_dts, m, 0);
+        // (the minimum of the previous tile-kernel launch is taken here: pend_part)
+        hipLaunchKernelGGL(k_dt_policy, dim3(1), dim3(256), 0, c->stream, s->d_scal, dmin,
+                           (const int *)s->d_flag, s->d_dts, m, 0, (const double *)s->pend_part,
+                           s->pend_n, const_cast<double *>(dmin));
+        s->pend_part = nullptr;
         s->next_cfl_min = 1.0;      // "cached on the device": keeps a posted halo exchange valid
         if (wave)
             rc = p->fast_math ? fastm::comp_step_wave_ex(s, p, 0.0, s->d_scal, &dmin)
@@ -180,8 +207,10 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
                               : exact::comp_step_fused_ex(s, &pf, 0.0, s->d_scal, &dmin);
     }
     PYRO_TRY(rc);
-    hipLaunchKernelGGL(k_dt_policy, dim3(1), dim3(1), 0, c->stream, s->d_scal, dmin,
-                       (const int *)s->d_flag, s->d_dts, max_steps, 1);
+    hipLaunchKernelGGL(k_dt_policy, dim3(1), dim3(256), 0, c->stream, s->d_scal, dmin,
+                       (const int *)s->d_flag, s->d_dts, max_steps, 1, (const double *)s->pend_part,
+                       s->pend_n, const_cast<double *>(dmin));
+    s->pend_part = nullptr;
     PYRO_CHECK_HIP(hipGetLastError());
     // the one round trip of the call: scalars, flag, last CFL minimum, the dt sequence
     char *hb = (char *)c->reduce_host;                       // 256 pinned bytes

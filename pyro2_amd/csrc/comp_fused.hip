@@ -463,10 +463,19 @@ void fused_copy_frame(pyrohip_state *s)
                        (const double *)s->d, s->alt_base + geom_lead(g), g);
 }
 
-int fused_tail(pyrohip_state *s, double *part, int nparts, bool frame_copied, const double **dmin_out)
+int fused_tail(pyrohip_state *s, double *part, int nparts, bool frame_copied, const double **dmin_out,
+               bool defer)
 {
     pyrohip_ctx *c = s->ctx;
     if (!frame_copied) fused_copy_frame(s);
+    if (defer && !c->global_cfl && nparts <= 4 * kMinStageBlocks) {
+        // device-side stepping: the next policy kernel (one workgroup anyway) takes the
+        // minimum of the partials itself and leaves it where this function would have
+        s->pend_part = part;
+        s->pend_n = nparts;
+        *dmin_out = part + nparts + kMinStageBlocks;
+        return 0;
+    }
     const double *dmin = launch_min_reduce(c->stream, part, nparts);
     s->cfl_is_global = false;
     if (c->global_cfl) {   // multi-GPU: the next dt needs the minimum over all slabs
@@ -558,7 +567,7 @@ int comp_step_fused_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt
                     (const double *)Uin, Uout, g, P, s->d_flag, part, S);
     }
     const double *dmin;
-    PYRO_TRY(fused_tail(s, part, P.ntiles, true, &dmin));   // the kernel wrote the ghost frame
+    PYRO_TRY(fused_tail(s, part, P.ntiles, true, &dmin, S != nullptr));   // the kernel wrote the ghost frame
     if (S) { fused_swap(s); *dmin_out = dmin; return 0; }
     return fused_sync(s, dmin);
 }

@@ -36,7 +36,8 @@ int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP 
                   double *&Uout, bool reset_flag = true);
 // after the step kernel(s): ghost frame, minimum of the CFL partials (all-reduced over
 // the slabs when decomposed) -> device address of the minimum
-int fused_tail(pyrohip_state *s, double *part, int nparts, bool frame_copied, const double **dmin);
+int fused_tail(pyrohip_state *s, double *part, int nparts, bool frame_copied, const double **dmin,
+               bool defer = false);
 // single-step API: read the minimum and the positivity flag back, swap the buffers
 int fused_sync(pyrohip_state *s, const double *dmin);
 // device-side run: swap the buffers without looking (the kernels freeze the state
