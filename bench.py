@@ -365,6 +365,30 @@ def bench_incompressible(ctx, device, nx=2048, steps=5):
             "vcycles_per_step": sum(cyc) / steps}
 
 
+def bench_small_grids(ctx, device, sizes=(64, 256, 512), steps=400):
+    """the grid sizes the reference's own problems use: time per step with the steps
+    enqueued on the device (pyrohip_comp_evolve: the tile kernel applies the boundary
+    rules and writes the ghost frame itself, the dt policy takes the CFL minimum: two
+    launches per step)"""
+    from pyro2_amd.compressible.problems.sedov import sedov_state
+    from pyro2_amd.decomp import DtPolicy
+    out = {}
+    for nx in sizes:
+        st = device.DeviceState(ctx, nx, nx, 4, [["outflow"] * 4] * 4)
+        st.upload(sedov_state(nx, nx, 4, 0.0, 1.0, 0.0, 1.0, 1.4, 0.01, 4))
+        P = device.make_comp_params(1.0 / nx, 1.0 / nx, fast_math=1, kernel_set=-1)
+        pol = DtPolicy(1.0e9)
+        st.comp_evolve(P, 0.8, pol, 50)
+        ctx.sync()
+        t0 = time.perf_counter()
+        st.comp_evolve(P, 0.8, pol, steps)
+        ctx.sync()
+        us = (time.perf_counter() - t0) / steps * 1e6
+        out[f"{nx}x{nx}"] = {"us_per_step": us, "value": nx * nx / (us * 1e-6), "unit": "cell-updates/s"}
+    return {"workload": f"compressible sedov on small grids, {steps} steps enqueued on the device, "
+                        "fast build", "sizes": out}
+
+
 def cpu_baseline_sedov(sample_nx, max_seconds=25.0):
     """the oracle (single-threaded C port of the reference) on a bounded sample
     of the same workload: Sedov, same physics, sample_nx^2, from t = 0"""
@@ -567,7 +591,8 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_sedov(args.cpu_sample_nx)
             if not args.no_also:
-                also.update({"advection": bench_advection(ctx, device),
+                also.update({"sedov_small_grids": bench_small_grids(ctx, device),
+                             "advection": bench_advection(ctx, device),
                              "multigrid": bench_mg(ctx, device),
                              "incompressible": bench_incompressible(ctx, device)})
                 out["also"] = also
