@@ -581,8 +581,11 @@ __device__ __forceinline__ double mgb_from_upper(double v) { return __shfl_down(
 // thread; the pass loop itself fits): measured slower than one workgroup per CU.
 constexpr int MGB_R = 4, MGB_NT = 64 * (MGW_RI / MGB_R);
 
-template <bool POW2, bool EDGE>
-__global__ __launch_bounds__(MGB_NT, 4) void k_mg_smooth_band(MGTile A)
+// PROL: the launch that opens the up leg adds the prolonged coarse correction while
+// staging.  That code (five coarse reads per cell, eight cells) is what needs 128 VGPRs;
+// the other launches fit 64 and share a CU two workgroups at a time.
+template <bool POW2, bool EDGE, bool PROL>
+__global__ __launch_bounds__(MGB_NT, PROL ? 4 : 8) void k_mg_smooth_band(MGTile A)
 {
     HIP_DYNAMIC_SHARED(double, lds)
     static_assert(MGW_RI == 64 && MGW_LP == 128 && MGB_R >= 2, "64 / R waves x R rows x 128 columns");
@@ -647,7 +650,7 @@ __global__ __launch_bounds__(MGB_NT, 4) void k_mg_smooth_band(MGTile A)
             }
         MGB_SCHED_FENCE();
     }
-    if (A.cv) {
+    if (PROL) {
 #pragma unroll
         for (int m = 0; m < R; m++)
 #pragma unroll
@@ -1604,10 +1607,14 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
         PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_mg_smooth_tile<MGW_NT, MGW_LP, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)MGW_LDS));
-        const void *bands[4] = {(const void *)k_mg_smooth_band<false, false>,
-                                (const void *)k_mg_smooth_band<false, true>,
-                                (const void *)k_mg_smooth_band<true, false>,
-                                (const void *)k_mg_smooth_band<true, true>};
+        const void *bands[8] = {(const void *)k_mg_smooth_band<false, false, false>,
+                                (const void *)k_mg_smooth_band<false, true, false>,
+                                (const void *)k_mg_smooth_band<true, false, false>,
+                                (const void *)k_mg_smooth_band<true, true, false>,
+                                (const void *)k_mg_smooth_band<false, false, true>,
+                                (const void *)k_mg_smooth_band<false, true, true>,
+                                (const void *)k_mg_smooth_band<true, false, true>,
+                                (const void *)k_mg_smooth_band<true, true, true>};
         for (const void *fn : bands)
             PYRO_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)MGW_LDS));
@@ -1674,24 +1681,24 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
             }
             const int nti = (nrows + A.TI - 1) / A.TI;
             A.ntiles = nti * A.ntj;
-            static const int band_maxn = getenv("PYRO_MG_BAND") ? atoi(getenv("PYRO_MG_BAND")) : 1024;
+            // measured per V-cycle at 2048^2 / 4096^2 (tools/mg_ab.sh): band kernel up to
+            // 1024^2: 625 / 1497 us, up to 2048^2: 611 / 1485, everywhere: 615 / 1501
+            static const int band_maxn = getenv("PYRO_MG_BAND") ? atoi(getenv("PYRO_MG_BAND")) : 2048;
             const bool band = L.n <= band_maxn;
             // the band kernel: homogeneous boundaries; its EDGE instance (ghost values
             // synthesised at the physical sides) wherever a tile can touch one
             const bool hom = !(A.bc.val[0] || A.bc.val[1] || A.bc.val[2] || A.bc.val[3]);
             const bool edge = A.bc.code[0] != PYROHIP_BC_PERIODIC || A.bc.code[2] != PYROHIP_BC_PERIODIC;
-            if (band && hom && pow2 && edge)
-                PYRO_LAUNCH(m->ctx, "k_mg_smooth_band", (k_mg_smooth_band<true, true>), dim3(A.ntiles),
-                            dim3(MGB_NT), MGW_LDS, A);
-            else if (band && hom && pow2)
-                PYRO_LAUNCH(m->ctx, "k_mg_smooth_band", (k_mg_smooth_band<true, false>), dim3(A.ntiles),
-                            dim3(MGB_NT), MGW_LDS, A);
-            else if (band && hom && edge)
-                PYRO_LAUNCH(m->ctx, "k_mg_smooth_band", (k_mg_smooth_band<false, true>), dim3(A.ntiles),
-                            dim3(MGB_NT), MGW_LDS, A);
-            else if (band && hom)
-                PYRO_LAUNCH(m->ctx, "k_mg_smooth_band", (k_mg_smooth_band<false, false>), dim3(A.ntiles),
-                            dim3(MGB_NT), MGW_LDS, A);
+            if (band && hom) {
+                using BandT = void (*)(MGTile);
+                static const BandT inst[2][2][2] = {
+                    {{k_mg_smooth_band<false, false, false>, k_mg_smooth_band<false, false, true>},
+                     {k_mg_smooth_band<false, true, false>, k_mg_smooth_band<false, true, true>}},
+                    {{k_mg_smooth_band<true, false, false>, k_mg_smooth_band<true, false, true>},
+                     {k_mg_smooth_band<true, true, false>, k_mg_smooth_band<true, true, true>}}};
+                PYRO_LAUNCH(m->ctx, "k_mg_smooth_band", inst[pow2 ? 1 : 0][edge ? 1 : 0][A.cv ? 1 : 0],
+                            dim3(A.ntiles), dim3(MGB_NT), MGW_LDS, A);
+            }
             else if (pow2)
                 PYRO_LAUNCH(m->ctx, "k_mg_smooth_tile", (k_mg_smooth_tile<MGW_NT, MGW_LP, true>),
                             dim3(A.ntiles), dim3(MGW_NT), MGW_LDS, A);
