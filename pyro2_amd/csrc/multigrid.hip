@@ -574,22 +574,17 @@ __device__ __forceinline__ double mgb_from_upper(double v) { return __shfl_down(
 // No cell is excluded from a pass either: a cell beyond the still-valid part of the
 // apron (or at a ghost position) computes something that no cell of the tile ever
 // reads.  Homogeneous boundaries (a finest level with boundary VALUES: k_mg_smooth_tile).
-// R region rows per wavefront, 64 / R wavefronts per workgroup.  R = 4: 1024 threads at
-// 128 VGPRs, one workgroup per CU.  Two per CU (like the tile kernel, which is what the
-// levels >= 2048^2 need) would take R = 4 at 64 VGPRs (68 spills) or R = 8 with 512
-// threads at 128 VGPRs (139 spills, all in the staging of 16 cells + prolongation per
-// thread; the pass loop itself fits): measured slower than one workgroup per CU.
-constexpr int MGB_R = 4, MGB_NT = 64 * (MGW_RI / MGB_R);
-
+// R region rows per wavefront, 64 / R wavefronts per workgroup.  R = 4 (1024 threads) is
+// what runs; R = 8 (512 threads, 102 VGPRs without the prolongation) measured 22.1 ->
+// 23.5 us per launch on the small levels, 29.9 -> 31.1 us at 2048^2.
 // PROL: the launch that opens the up leg adds the prolonged coarse correction while
 // staging.  That code (five coarse reads per cell, eight cells) is what needs 128 VGPRs;
 // the other launches fit 64 and share a CU two workgroups at a time.
-template <bool POW2, bool EDGE, bool PROL>
-__global__ __launch_bounds__(MGB_NT, PROL ? 4 : 8) void k_mg_smooth_band(MGTile A)
+template <bool POW2, bool EDGE, bool PROL, int R>
+__global__ __launch_bounds__(64 * (MGW_RI / R), (PROL || R == 8) ? 4 : 8) void k_mg_smooth_band(MGTile A)
 {
     HIP_DYNAMIC_SHARED(double, lds)
-    static_assert(MGW_RI == 64 && MGW_LP == 128 && MGB_R >= 2, "64 / R waves x R rows x 128 columns");
-    constexpr int R = MGB_R;
+    static_assert(MGW_RI == 64 && MGW_LP == 128 && (R == 4 || R == 8), "64 / R waves x R rows x 128 columns");
     constexpr int HP = MGW_LP / 2, HALF = MGW_RI * HP;
     const int n = A.n;
     const bool per_i = (A.bc.code[0] == PYROHIP_BC_PERIODIC);
@@ -1607,14 +1602,11 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
         PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)k_mg_smooth_tile<MGW_NT, MGW_LP, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)MGW_LDS));
-        const void *bands[8] = {(const void *)k_mg_smooth_band<false, false, false>,
-                                (const void *)k_mg_smooth_band<false, true, false>,
-                                (const void *)k_mg_smooth_band<true, false, false>,
-                                (const void *)k_mg_smooth_band<true, true, false>,
-                                (const void *)k_mg_smooth_band<false, false, true>,
-                                (const void *)k_mg_smooth_band<false, true, true>,
-                                (const void *)k_mg_smooth_band<true, false, true>,
-                                (const void *)k_mg_smooth_band<true, true, true>};
+        const void *bands[] = {
+#define MGB_INST(P2, E) (const void *)k_mg_smooth_band<P2, E, false, 4>, (const void *)k_mg_smooth_band<P2, E, true, 4>
+            MGB_INST(false, false), MGB_INST(false, true), MGB_INST(true, false), MGB_INST(true, true)
+#undef MGB_INST
+        };
         for (const void *fn : bands)
             PYRO_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)MGW_LDS));
@@ -1691,13 +1683,12 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
             const bool edge = A.bc.code[0] != PYROHIP_BC_PERIODIC || A.bc.code[2] != PYROHIP_BC_PERIODIC;
             if (band && hom) {
                 using BandT = void (*)(MGTile);
-                static const BandT inst[2][2][2] = {
-                    {{k_mg_smooth_band<false, false, false>, k_mg_smooth_band<false, false, true>},
-                     {k_mg_smooth_band<false, true, false>, k_mg_smooth_band<false, true, true>}},
-                    {{k_mg_smooth_band<true, false, false>, k_mg_smooth_band<true, false, true>},
-                     {k_mg_smooth_band<true, true, false>, k_mg_smooth_band<true, true, true>}}};
+#define MGB_ROW(P2, E) {k_mg_smooth_band<P2, E, false, 4>, k_mg_smooth_band<P2, E, true, 4>}
+                static const BandT inst[2][2][2] = {{MGB_ROW(false, false), MGB_ROW(false, true)},
+                                                    {MGB_ROW(true, false), MGB_ROW(true, true)}};
+#undef MGB_ROW
                 PYRO_LAUNCH(m->ctx, "k_mg_smooth_band", inst[pow2 ? 1 : 0][edge ? 1 : 0][A.cv ? 1 : 0],
-                            dim3(A.ntiles), dim3(MGB_NT), MGW_LDS, A);
+                            dim3(A.ntiles), dim3(1024), MGW_LDS, A);
             }
             else if (pow2)
                 PYRO_LAUNCH(m->ctx, "k_mg_smooth_tile", (k_mg_smooth_tile<MGW_NT, MGW_LP, true>),
