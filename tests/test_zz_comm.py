@@ -121,6 +121,16 @@ def test_rccl_overlapped_halo_self_neighbour(hip):
     assert d == dref
     assert np.array_equal(s.download()[ng:-ng, ng:-ng], ref)
     assert np.abs(ref[:4, :, 2]).max() > 0.0          # the blast did reach the x boundary
+    # ... and with the tile kernel, which from the second step on reads its ghost cells
+    # through the boundary rules (fuse_fill): halo rows are data, the y sides outflow
+    P1 = device.make_comp_params(1.0 / nx, 1.0 / nx, fast_math=0, kernel_set=1)
+    s = device.DeviceState(hip, nx, nx, ng, [["halo", "halo", "outflow", "outflow"]] * 4)
+    s.upload(full)
+    s.set_neighbours(0, 0)
+    pol = DtPolicy(0.1)
+    d = list(s.comp_evolve(P1, 0.8, pol, 12))
+    assert d == dref
+    assert np.array_equal(s.download()[ng:-ng, ng:-ng], ref)
 
 
 def _rccl_rank(rank, world, port, out_dir):
