@@ -37,6 +37,7 @@ UNITS = [
                                     "-amdgpu-sched-strategy=max-ilp"]),
     ("comp_api.hip", "comp_api", ["-ffp-contract=off"]),
     ("multigrid.hip", "multigrid", ["-ffp-contract=off"]),
+    ("mg_march.hip", "mg_march", ["-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=200000"]),
     ("incompressible.hip", "incompressible", ["-ffp-contract=off"]),
     ("swe.hip", "swe", ["-ffp-contract=off"]),
     ("comm.hip", "comm", ["-ffp-contract=off"]),

@@ -25,6 +25,7 @@
 // outside the colour loop.
 #include "common.h"
 #include "mg_internal.h"
+#include "mg_march.h"
 #include "reduce.h"
 #include "stencil.h"
 #include <cmath>
@@ -71,6 +72,17 @@ struct pyrohip_mg {
     // 10 up to 512^2 284 / 668 / 1529, 10 up to 1024^2 286 / 714 / 1578.
     int kmax_small = getenv("PYRO_MG_KSMALL") ? atoi(getenv("PYRO_MG_KSMALL")) : 10;
     int nsmall = getenv("PYRO_MG_NSMALL") ? atoi(getenv("PYRO_MG_NSMALL")) : 512;
+    // levels >= march_min^2 (0: none): the row-marching smoother (mg_march.hip), cut into
+    // at most march_waves wavefronts.  Read when the solver object is made (the tests
+    // exercise the kernel on small levels that way)
+    int march_min = getenv("PYRO_MG_MARCH") ? atoi(getenv("PYRO_MG_MARCH")) : 2048;
+    int march_waves = getenv("PYRO_MG_MARCH_WAVES") ? atoi(getenv("PYRO_MG_MARCH_WAVES")) : 0;   // 0: what the device holds
+    // the first / last column strip (a select more per update) in shorter chunks: their
+    // wavefronts are given 1 / march_side of the steps of the others (<= 1: cut like the others).
+    // Measured per V-cycle at 2048^2 / 4096^2: 1.0 562 / 1041 us, 1.17 547 / 1031, 1.3 532 / 1020,
+    // 1.5 535 / 1018, 1.8 527 / 1032
+    double march_side = getenv("PYRO_MG_MARCH_SIDE") ? atof(getenv("PYRO_MG_MARCH_SIDE")) : 1.5;
+    int march_minrows = getenv("PYRO_MG_MARCH_ROWS") ? atoi(getenv("PYRO_MG_MARCH_ROWS")) : 32;   // rows a part stores, at least
     int coarse_kernel = 1;        // levels <= 64^2 in one LDS-resident workgroup
     int fuse_res_restrict = getenv("PYRO_MG_NOFUSE_RR") ? 0 : 1;   // down leg: residual + restriction in one pass
     int vc = 0;                   // 1: div(eta grad phi) = f; 2: general (alpha, beta, gamma)
@@ -1646,6 +1658,45 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
     // bound: fuse as many iterations per launch as the 32-row region allows
     if (L.n <= m->nsmall && m->kmax_small > kmax) kmax = m->kmax_small;
     int left = nsmooth;
+    // the large levels: the row-marching smoother (mg_march.hip), the ten iterations of a
+    // V-cycle leg in one launch
+    const int march_min = m->march_min, march_waves = m->march_waves;
+    const bool hom_bc = !(A.bc.val[0] || A.bc.val[1] || A.bc.val[2] || A.bc.val[3]);
+    while (!A.single && hom_bc && march_min > 0 && L.n >= march_min && row0 == 1 && row1 == L.n) {
+        const int MK = 10;
+        if (left < MK) break;
+        MGMarch M;
+        M.vin = L.v; M.f = L.f; M.vout = L.v2; M.n = L.n; M.pitch = L.pitch;
+        M.xc = A.xc; M.yc = A.yc; M.denom = A.denom; M.rdenom = A.rdenom; M.kx = A.kx; M.ky = A.ky;
+        for (int s = 0; s < 4; s++) M.code[s] = A.bc.code[s];
+        M.cv = A.cv; M.cpitch = A.cpitch; M.vin_zero = A.vin_zero;
+        M.TJ = mgm_tj(MK); M.ncs = (L.n + M.TJ - 1) / M.TJ;
+        // row chunks: as many wavefronts as the device holds at once, not one more (two per
+        // SIMD at 256 registers: a wavefront too many would run alone after all the others); the
+        // parts that end at the top boundary start up to mgm_align rows lower (mg_march.hip:
+        // mgm_part), so the last chunk is made that much shorter
+        const int slots = march_waves > 0 ? march_waves : 8 * (m->ctx->num_cus > 0 ? m->ctx->num_cus : 256);
+        const int pad = (M.code[0] != PYROHIP_BC_PERIODIC) ? mgm_align(MK) : 0;
+        const bool sides = M.code[2] != PYROHIP_BC_PERIODIC && M.ncs >= 3 && m->march_side > 1.0;
+        auto chunks = [&](int rows, int least, int &cr) {   // chunks of about `rows` rows -> count
+            cr = rows < least ? least : rows;
+            return (L.n + cr - 1) / cr;
+        };
+        M.nchunks_side = 0; M.CR_side = 0;
+        for (int nch = slots / M.ncs > 2 ? slots / M.ncs : 2; nch >= 2; nch--) {
+            M.nchunks = chunks((L.n + pad + nch - 1) / nch, m->march_minrows, M.CR);
+            if (!sides) break;
+            // a wavefront of a side strip needs march_side times as long per row: fewer rows
+            const int steps = M.CR + 6 * MK;              // apron below and above, 2K steps to drain
+            M.nchunks_side = chunks((int)(steps / m->march_side) - 6 * MK, 8, M.CR_side);
+            if ((M.ncs - 2) * M.nchunks + 2 * M.nchunks_side <= slots || nch == 2) break;
+        }
+        if (!mg_march_usable(M, MK)) break;
+        PYRO_TRY(mg_march_launch(m->ctx, M, pow2, MK));
+        double *t = L.v; L.v = L.v2; L.v2 = t;
+        left -= MK;
+        A.cv = nullptr; A.vin_zero = 0;
+    }
     while (left > 0) {
         const int K = A.single ? left : (left < kmax ? left : kmax);
         A.K = K;

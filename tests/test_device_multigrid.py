@@ -442,3 +442,43 @@ def test_mg_slab_vcycle_bit_identical(dev, nranks, nx, collapse):
         (a, b), v = out[r]
         assert np.array_equal(v[:, 1:-1], want[a:b + 1, 1:-1]), r
     assert np.abs(want[1:-1, 1:-1]).max() > 0
+
+
+@pytest.mark.parametrize("bcs", [("dirichlet",) * 4, ("periodic",) * 4,
+                                 ("neumann", "dirichlet", "periodic", "periodic"),
+                                 ("periodic", "periodic", "dirichlet", "neumann")])
+@pytest.mark.parametrize("coef", [(0.3, -1.1), (0.0, -1.0)])
+def test_mg_march_smoother(dev, bcs, coef, monkeypatch):
+    """the row-marching smoother of the large levels (csrc/mg_march.hip), switched on
+    for a 256^2 level (column strips, row chunks with aprons, wrapped loads on the
+    periodic sides; general and power-of-two coefficients): ten and twenty iterations
+    (one and two launches) and a whole V-cycle (prolongation fused into the
+    load, zero start on the way down) must equal the one-launch-per-colour kernels bit
+    for bit"""
+    nx = 256
+    alpha, beta = coef
+    rng = np.random.default_rng(12)
+    v0 = rng.standard_normal((nx + 2, nx + 2))
+    f0 = rng.standard_normal((nx + 2, nx + 2))
+    res = {}
+    for march in (0, 1):
+        monkeypatch.setenv("PYRO_MG_MARCH", "256" if march else "0")
+        monkeypatch.setenv("PYRO_MG_MARCH_WAVES", "24")     # 8 row chunks of 32
+        m = device.DeviceMG(dev, nx, bcs=bcs, alpha=alpha, beta=beta)
+        L = m.nlevels - 1
+        m.set_smoother(0 if not march else 1)
+        out = []
+        for nsm in (10, 20):
+            m.set(L, 0, v0)
+            m.set(L, 1, f0)
+            m.smooth(L, nsm)
+            m.fill_bc(L, 0)
+            out.append(m.get(L, 0))
+        m.set(L, 0, v0)
+        m.set(L, 1, f0)
+        m.vcycle()
+        m.fill_bc(L, 0)
+        out.append(m.get(L, 0))
+        res[march] = out
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)

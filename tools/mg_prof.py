@@ -8,7 +8,8 @@ for nx in [int(a) for a in sys.argv[1:]] or [2048]:
     x = (np.arange(nx + 2) - 0.5) / nx
     X, Y = np.meshgrid(x, x, indexing="ij")
     rhs = -2.0 * ((1 - 6 * X**2) * Y**2 * (1 - Y**2) + (1 - 6 * Y**2) * X**2 * (1 - X**2))
-    m = device.DeviceMG(ctx, nx)
+    bc = os.environ.get("PYRO_MG_PROF_BC")
+    m = device.DeviceMG(ctx, nx, bcs=tuple(bc.split(',')) if ',' in bc else (bc,) * 4) if bc else device.DeviceMG(ctx, nx)
     L = m.nlevels - 1
     m.zero(L, 0); m.set(L, 1, rhs); m.init_rhs_norm()
     m.solve(rtol=0.0, max_cycles=2); m.zero(L, 0); ctx.sync()
