@@ -92,6 +92,20 @@ struct pyrohip_mg {
     // v of the level is to be taken as 0 by its next smoothing launch (set by
     // the solve loop instead of a memset, consumed inside the same V-cycle)
     bool v_is_zero[pyro::MG_MAXLEV] = {};
+    // Inside pyrohip_mg_solve the residual arrays are scratch: the passes that only need the
+    // residual on the way to something else (its restriction on the way down, its norm after
+    // the cycle) do not store it -- a level's worth of writes each -- and mark r of the level
+    // stale; whoever asks for the array (plane(), mg_finest) gets it computed from the level's
+    // current v and f first.  For the finest level that is what MG.py:668-671 leaves there;
+    // the coarser levels' r (the reference keeps the down leg's there) is nobody's input.
+    // PYRO_MG_EAGER_R: always store.
+    bool lazy_r = getenv("PYRO_MG_EAGER_R") == nullptr;
+    bool in_solve = false;
+    bool r_stale[pyro::MG_MAXLEV] = {};
+    // the solve loop's copy of the solution before the cycle (relative_error): the first
+    // smoothing launch of the cycle on the finest level reads v from one buffer and writes
+    // another -- the buffer it read IS that copy, the previous copy becomes the scratch buffer
+    bool capture_old = false, old_captured = false;
 };
 
 namespace pyro {
@@ -1394,6 +1408,7 @@ __global__ __launch_bounds__(256) void k_mg_restrict(const double *__restrict__ 
 // residual of its 2 x 2 fine cells with k_mg_residual's expression, stores
 // them (r stays observable) and averages them in k_mg_restrict's order.  Saves
 // re-reading r and one launch per level.
+template <bool STORE_R>
 __global__ __launch_bounds__(256) void k_mg_residual_restrict(
     const double *__restrict__ v, const double *__restrict__ f, double *__restrict__ r, int fpitch,
     double *__restrict__ cf, int cpitch, int nc, double alpha, double beta, double dx2,
@@ -1410,7 +1425,7 @@ __global__ __launch_bounds__(256) void k_mg_residual_restrict(
     };
     const double r00 = res(k00), r10 = res(k00 + fpitch), r01 = res(k00 + 1),
                  r11 = res(k00 + fpitch + 1);
-    r[k00] = r00; r[k00 + fpitch] = r10; r[k00 + 1] = r01; r[k00 + fpitch + 1] = r11;
+    if (STORE_R) { r[k00] = r00; r[k00 + fpitch] = r10; r[k00 + 1] = r01; r[k00 + fpitch + 1] = r11; }
     cf[(size_t)(1 + i) * cpitch + (1 + j)] = 0.25 * (r00 + r10 + r01 + r11);
 }
 
@@ -1481,6 +1496,7 @@ __global__ __launch_bounds__(256) void k_mg_sumsq(const double *__restrict__ a,
 // finest level: relative change of the solution (sum of ((v-old)/(v+small))^2,
 // then old <- v) and the residual r = f - (alpha - beta L) v with the sum of
 // r^2.  Replaces four kernels / two host syncs per V-cycle by two / one.
+template <bool STORE_R, bool COPY_OLD>
 __global__ __launch_bounds__(256) void k_mg_solve_diag(const double *__restrict__ v,
                                                        const double *__restrict__ f,
                                                        double *__restrict__ r,
@@ -1496,11 +1512,11 @@ __global__ __launch_bounds__(256) void k_mg_solve_diag(const double *__restrict_
             const double vk = v[k];
             const double d = (vk - old[k]) / (vk + small);
             srel += d * d;
-            old[k] = vk;
+            if (COPY_OLD) old[k] = vk;
             const double rr = f[k] - alpha * vk +
                               beta * ((v[k - pitch] + v[k + pitch] - 2 * vk) / dx2 +
                                       (v[k - 1] + v[k + 1] - 2 * vk) / dx2);
-            r[k] = rr;
+            if (STORE_R) r[k] = rr;
             sres += rr * rr;
         }
     srel = block_reduce_sum(srel);
@@ -1539,9 +1555,12 @@ static MGBC make_bc(const pyrohip_mg *m, int level, bool for_v)
     return b;
 }
 
+static int mg_residual(pyrohip_mg *m, int level);
+
 static double *plane(pyrohip_mg *m, int level, int var)
 {
     MGLevel &L = m->lev[level];
+    if (var == 2 && m->r_stale[level]) mg_residual(m, level);   // see pyrohip_mg::lazy_r
     switch (var) {
     case 0: return L.v;
     case 1: return L.f;
@@ -1594,6 +1613,24 @@ static bool mg_prolong_fusable(pyrohip_mg *m, int level, int nsmooth)
     const MGLevel &L = m->lev[level];
     return !m->vc && m->smoother != 0 && nsmooth > 0 && level > 0 &&
            (L.n + 2) * (L.n + 2) > MGS_CELLS;
+}
+
+// a smoothing launch read L.v and wrote L.v2: L.v2 is the solution now.  The first such
+// launch of a solve cycle on the finest level leaves the solution before the cycle in the
+// buffer it read: that buffer becomes old_phi (pyrohip_mg::capture_old), the previous
+// old_phi the scratch buffer.  (Whole-level launches only: a slab's launches share buffers.)
+static void mg_swap_solution(pyrohip_mg *m, int level)
+{
+    MGLevel &L = m->lev[level];
+    double *read = L.v;
+    L.v = L.v2;
+    if (m->capture_old && level == m->nlevels - 1) {
+        L.v2 = m->old_phi;
+        m->old_phi = read;
+        m->capture_old = false;
+        m->old_captured = true;
+    } else
+        L.v2 = read;
 }
 
 static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong = false,
@@ -1693,7 +1730,7 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
         }
         if (!mg_march_usable(M, MK)) break;
         PYRO_TRY(mg_march_launch(m->ctx, M, pow2, MK));
-        double *t = L.v; L.v = L.v2; L.v2 = t;
+        mg_swap_solution(m, level);
         left -= MK;
         A.cv = nullptr; A.vin_zero = 0;
     }
@@ -1758,7 +1795,8 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
             fprintf(stderr, " store %lld total %lld\n", h[23] - h[2 + 2 * K], h[23] - h[0]);
         }
 #endif
-        double *t = L.v; L.v = L.v2; L.v2 = t;
+        if (A.single) { double *t = L.v; L.v = L.v2; L.v2 = t; }
+        else mg_swap_solution(m, level);
         left -= K;
         A.cv = nullptr;   // only the first launch carries the prolongation
         A.vin_zero = 0;
@@ -1807,6 +1845,7 @@ static int mg_residual(pyrohip_mg *m, int level)
 {
     MGLevel &L = m->lev[level];
     const int bx = (L.n >= 256) ? 256 : 64;
+    m->r_stale[level] = false;
     if (m->vc) {
         const MGGen G{L.a, L.gx, L.gy};
         if (m->vc == 2)
@@ -1939,10 +1978,14 @@ static int mg_vcycle(pyrohip_mg *m, int level)
         if (!m->vc && m->fuse_res_restrict) {             // :724 + :731-732 in one pass
             MGLevel &F = m->lev[level], &Cc = m->lev[level - 1];
             const int bx = (Cc.n >= 256) ? 256 : 64;
-            PYRO_LAUNCH(m->ctx, "k_mg_residual_restrict", k_mg_residual_restrict,
-                        dim3((Cc.n + bx - 1) / bx, Cc.n), dim3(bx), 0, (const double *)F.v,
+            const bool store = !(m->lazy_r && m->in_solve);
+            using RRT = void (*)(const double *, const double *, double *, int, double *, int, int,
+                                 double, double, double, int);
+            const RRT rr = store ? (RRT)k_mg_residual_restrict<true> : (RRT)k_mg_residual_restrict<false>;
+            PYRO_LAUNCH(m->ctx, "k_mg_residual_restrict", rr, dim3((Cc.n + bx - 1) / bx, Cc.n), dim3(bx), 0, (const double *)F.v,
                         (const double *)F.f, F.r, F.pitch, Cc.f, Cc.pitch, Cc.n, m->alpha, m->beta,
                         F.dx * F.dx, 0);
+            m->r_stale[level] = !store;
         } else {
             PYRO_TRY(mg_residual(m, level));              // :724
             PYRO_TRY(mg_restrict(m, level));              // :731-732
@@ -2192,7 +2235,7 @@ int pyrohip_mg_residual_restrict_rows(pyrohip_mg *m, int fine, int crow0, int cr
     MGLevel &F = m->lev[fine], &Cc = m->lev[fine - 1];
     PYRO_REQUIRE(crow0 >= 1 && crow1 <= Cc.n && crow0 <= crow1, "coarse rows outside the level");
     const int bx = (Cc.n >= 256) ? 256 : 64;
-    PYRO_LAUNCH(m->ctx, "k_mg_residual_restrict", k_mg_residual_restrict,
+    PYRO_LAUNCH(m->ctx, "k_mg_residual_restrict", k_mg_residual_restrict<true>,
                 dim3((Cc.n + bx - 1) / bx, crow1 - crow0 + 1), dim3(bx), 0, (const double *)F.v,
                 (const double *)F.f, F.r, F.pitch, Cc.f, Cc.pitch, Cc.n, m->alpha, m->beta,
                 F.dx * F.dx, crow0 - 1);
@@ -2457,7 +2500,13 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
             if (lazy) m->v_is_zero[l] = true;
             else PYRO_TRY(mg_zero(m, l, 0));
         }
-        PYRO_TRY(mg_vcycle(m, Lf));
+        m->in_solve = true;
+        m->capture_old = !m->vc;
+        m->old_captured = false;
+        const int vrc = mg_vcycle(m, Lf);
+        m->in_solve = false;
+        m->capture_old = false;
+        PYRO_TRY(vrc);
         double s = 0.0, s2 = 0.0;                         // :673-678
         if (m->vc) {
             PYRO_TRY(mg_sumsq(m, F.v, m->old_phi, Lf, 1, &s));
@@ -2470,9 +2519,15 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
             const int nb = grid.x * grid.y;
             PYRO_TRY(c->reduce.ensure((2 * nb + 2) * sizeof(double)));
             double *part = (double *)c->reduce.p;
-            PYRO_LAUNCH(c, "k_mg_solve_diag", k_mg_solve_diag, grid, block, 0, (const double *)F.v,
-                        (const double *)F.f, F.r, m->old_phi, F.n, F.pitch, m->alpha, m->beta,
-                        F.dx * F.dx, 1.e-16, part);
+            using DiagT = void (*)(const double *, const double *, double *, double *, int, int, double,
+                                   double, double, double, double *);
+            static const DiagT diag[2][2] = {{k_mg_solve_diag<false, false>, k_mg_solve_diag<false, true>},
+                                            {k_mg_solve_diag<true, false>, k_mg_solve_diag<true, true>}};
+            const bool store = !m->lazy_r;
+            PYRO_LAUNCH(c, "k_mg_solve_diag", diag[store ? 1 : 0][m->old_captured ? 0 : 1], grid, block, 0,
+                        (const double *)F.v, (const double *)F.f, F.r, m->old_phi, F.n, F.pitch, m->alpha,
+                        m->beta, F.dx * F.dx, 1.e-16, part);
+            m->r_stale[Lf] = !store;
             hipLaunchKernelGGL(k_sum_final2, dim3(1), dim3(256), 0, c->stream,
                                (const double *)part, nb, part + 2 * nb);
             PYRO_CHECK_HIP(hipGetLastError());
@@ -2507,7 +2562,7 @@ int mg_finest(pyrohip_mg *m, MgFinest *out)
     PYRO_REQUIRE(m && out, "NULL argument");
     const int Lf = m->nlevels - 1;
     const MGLevel &F = m->lev[Lf];
-    *out = MgFinest{m->ctx, Lf, F.n, F.pitch, F.dx, F.v, F.f, F.r};
+    *out = MgFinest{m->ctx, Lf, F.n, F.pitch, F.dx, F.v, F.f, plane(m, Lf, 2)};
     return 0;
 }
 

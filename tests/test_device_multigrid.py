@@ -482,3 +482,32 @@ def test_mg_march_smoother(dev, bcs, coef, monkeypatch):
         res[march] = out
     for a, b in zip(res[0], res[1]):
         assert np.array_equal(a, b)
+
+
+def test_mg_solve_lazy_residual_and_old_copy(dev, monkeypatch):
+    """inside solve() the residual arrays are not stored by the fused residual passes and
+    the copy of the previous solution is a buffer rotation (csrc/multigrid.hip:
+    pyrohip_mg::lazy_r, capture_old): cycles, both error norms, the solution and the
+    finest level's residual array read afterwards equal those of the storing variant"""
+    nx = 128
+    x = (np.arange(nx + 2) - 0.5) / nx
+    X, Y = np.meshgrid(x, x, indexing="ij")
+    rhs = -2.0 * ((1.0 - 6.0 * X ** 2) * Y ** 2 * (1.0 - Y ** 2) +
+                  (1.0 - 6.0 * Y ** 2) * X ** 2 * (1.0 - X ** 2))
+    out = []
+    for eager in (True, False):
+        if eager:
+            monkeypatch.setenv("PYRO_MG_EAGER_R", "1")
+        else:
+            monkeypatch.delenv("PYRO_MG_EAGER_R", raising=False)
+        m = device.DeviceMG(dev, nx)
+        L = m.nlevels - 1
+        m.zero(L, 0)
+        m.set(L, 1, rhs)
+        m.init_rhs_norm()
+        r1 = m.solve(rtol=1e-11, max_cycles=4)
+        r2 = m.solve(rtol=0.0, max_cycles=2)           # a second solve starts from the first one's state
+        out.append((r1, r2, m.get(L, 0), m.get(L, 2)))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert np.array_equal(out[0][2], out[1][2])
+    assert np.array_equal(out[0][3][1:-1, 1:-1], out[1][3][1:-1, 1:-1])
