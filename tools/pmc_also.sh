@@ -19,7 +19,7 @@ for what, unit_launches in (("adv", None), ("mg", None)):
     cnt = collections.defaultdict(collections.Counter)
     for g in sorted(glob.glob(f"$O/also_{what}_g*/**/*counter_collection.csv", recursive=True)):
         for r in csv.DictReader(open(g)):
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             per[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
     ks = {}
     for k, d in per.items():
