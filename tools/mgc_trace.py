@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pyro2_amd import device
 ctx = device.Context(0)
-nx = 64
+nx = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 x = (np.arange(nx + 2) - 0.5) / nx
 X, Y = np.meshgrid(x, x, indexing="ij")
 m = device.DeviceMG(ctx, nx)
