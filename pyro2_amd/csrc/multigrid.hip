@@ -606,7 +606,16 @@ __device__ __forceinline__ double mgb_from_upper(double v) { return __shfl_down(
 // PROL: the launch that opens the up leg adds the prolonged coarse correction while
 // staging.  That code (five coarse reads per cell, eight cells) is what needs 128 VGPRs;
 // the other launches fit 64 and share a CU two workgroups at a time.
-template <bool POW2, bool EDGE, bool PROL, int R>
+// EDGE: 0 no physical side on the level; 2 physical sides, a select of ghost_h(own value) per
+// side and update (28 instructions around the 6 of the update: 4.5 us per launch, measured by
+// running the EDGE = 0 code on a Dirichlet problem); 1 the same for sides whose ghost cell is
+// +-(its mirror cell) (everything but the value-0 ghosts of PYROHIP_BC_CONST): the tiles at the
+// top / right side are staged from a region that ENDS at the ghost row / column, so that the
+// rows / columns next to a physical side sit at fixed places of the register layout (row 1:
+// wavefront 0, register row 1; row n: wavefront 15, register row 2; column 1: lane 0, cell 1;
+// column n: lane 63, cell 0), and x + s me in one fma stands for x + ghost -- one select per
+// update and direction instead of two selects of a three-way rule.
+template <bool POW2, int EDGE, bool PROL, int R>
 __global__ __launch_bounds__(64 * (MGW_RI / R), (PROL || R == 8) ? 4 : 8) void k_mg_smooth_band(MGTile A)
 {
     HIP_DYNAMIC_SHARED(double, lds)
@@ -622,6 +631,11 @@ __global__ __launch_bounds__(64 * (MGW_RI / R), (PROL || R == 8) ? 4 : 8) void k
     int gi0 = ti0 - H, gi1 = ti1 + H, gj0 = tj0 - H, gj1 = tj1 + H;
     if (!per_i) { gi0 = max(gi0, 0); gi1 = min(gi1, n + 1); }
     if (!per_j) { gj0 = max(gj0, 0); gj1 = min(gj1, n + 1); }
+    if (EDGE == 1) {
+        static_assert(EDGE != 1 || R == 4, "register row of the top row");
+        if (!per_i && gi1 == n + 1 && gi0 > 0) gi0 = n + 1 - (MGW_RI - 1);
+        if (!per_j && gj1 == n + 1 && gj0 > 0) gj0 = n + 1 - (MGW_LP - 1);
+    }
     const int RI = gi1 - gi0 + 1;
     double *V = lds;
     // LDS index of region cell (r, c): the two checkerboard classes apart, so that the
@@ -703,14 +717,21 @@ __global__ __launch_bounds__(64 * (MGW_RI / R), (PROL || R == 8) ? 4 : 8) void k
     bool isTop[R], isBot[R], isE[2], isW[2];
 #pragma unroll
     for (int m = 0; m < R; m++) {
-        isTop[m] = EDGE && phi_i && gi0 + r0 + m == n;
-        isBot[m] = EDGE && plo_i && gi0 + r0 + m == 1;
+        isTop[m] = EDGE == 2 && phi_i && gi0 + r0 + m == n;
+        isBot[m] = EDGE == 2 && plo_i && gi0 + r0 + m == 1;
     }
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-        isE[q] = EDGE && phi_j && gj0 + 2 * ln + q == n;
-        isW[q] = EDGE && plo_j && gj0 + 2 * ln + q == 1;
+        isE[q] = EDGE == 2 && phi_j && gj0 + 2 * ln + q == n;
+        isW[q] = EDGE == 2 && plo_j && gj0 + 2 * ln + q == 1;
     }
+    // EDGE == 1: the fixed places (see above) and the ghost cells' signs (1 where there is none)
+    const bool botW = EDGE == 1 && plo_i && wv == 0, topW = EDGE == 1 && phi_i && wv == MGW_RI / R - 1;
+    const bool isWl = EDGE == 1 && plo_j && ln == 0, isEl = EDGE == 1 && phi_j && ln == 63;
+    const double sBw = botW ? (c0 == PYROHIP_BC_REFLECT_ODD ? -1.0 : 1.0) : 1.0;
+    const double sTw = topW ? (c1 == PYROHIP_BC_REFLECT_ODD ? -1.0 : 1.0) : 1.0;
+    const double sWl = isWl ? (c2 == PYROHIP_BC_REFLECT_ODD ? -1.0 : 1.0) : 1.0;
+    const double sEl = isEl ? (c3 == PYROHIP_BC_REFLECT_ODD ? -1.0 : 1.0) : 1.0;
     // the band is part of the region; beyond pass wave_last none of its rows is valid
     // any more (rows only: one scalar for the wave, the whole wave skips the pass)
     int wave_last = -1;
@@ -745,16 +766,23 @@ __global__ __launch_bounds__(64 * (MGW_RI / R), (PROL || R == 8) ? 4 : 8) void k
             const double own = v[m][q ^ 1];
             const double oth = q ? mgb_from_upper(v[m][0]) : mgb_from_lower(v[m][1]);
             double e = q ? oth : own, w = q ? own : oth;               // columns c + 1, c - 1
-            if (EDGE) {
+            if (EDGE == 2) {
                 up = isTop[m] ? ghost_h(c1, me) : up;
                 dn = isBot[m] ? ghost_h(c0, me) : dn;
                 e = isE[q] ? ghost_h(c3, me) : e;
                 w = isW[q] ? ghost_h(c2, me) : w;
             }
+            double si, sj;                                             // up + dn, e + w
+            if (EDGE == 1 && m == 1) si = fma(botW ? me : dn, sBw, up);        // row 1: ghost below
+            else if (EDGE == 1 && m == 2) si = fma(topW ? me : up, sTw, dn);   // row n: ghost above
+            else si = up + dn;
+            if (EDGE == 1 && q == 1) sj = fma(isWl ? me : w, sWl, e);          // column 1: ghost left
+            else if (EDGE == 1) sj = fma(isEl ? me : e, sEl, w);               // column n: ghost right
+            else sj = e + w;
             if (POW2)
-                v[m][q] = fma(A.ky, e + w, fma(A.kx, up + dn, f[m][q]));
+                v[m][q] = fma(A.ky, sj, fma(A.kx, si, f[m][q]));
             else
-                v[m][q] = div_by(f[m][q] + A.xc * (up + dn) + A.yc * (e + w), A.denom, A.rdenom);
+                v[m][q] = div_by(f[m][q] + A.xc * si + A.yc * sj, A.denom, A.rdenom);
             if (m % 4 == 3) MGB_SCHED_FENCE();             // four rows interleaved, not R (VGPR budget)
         }
         V[(PAR & 1) ? w01 : w00] = v[0][PAR & 1];
@@ -1653,7 +1681,7 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
                                            (int)MGW_LDS));
         const void *bands[] = {
 #define MGB_INST(P2, E) (const void *)k_mg_smooth_band<P2, E, false, 4>, (const void *)k_mg_smooth_band<P2, E, true, 4>
-            MGB_INST(false, false), MGB_INST(false, true), MGB_INST(true, false), MGB_INST(true, true)
+            MGB_INST(false, 0), MGB_INST(false, 1), MGB_INST(false, 2), MGB_INST(true, 0), MGB_INST(true, 1), MGB_INST(true, 2)
 #undef MGB_INST
         };
         for (const void *fn : bands)
@@ -1768,14 +1796,18 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
             // the band kernel: homogeneous boundaries; its EDGE instance (ghost values
             // synthesised at the physical sides) wherever a tile can touch one
             const bool hom = !(A.bc.val[0] || A.bc.val[1] || A.bc.val[2] || A.bc.val[3]);
-            const bool edge = A.bc.code[0] != PYROHIP_BC_PERIODIC || A.bc.code[2] != PYROHIP_BC_PERIODIC;
+            // 0: no physical side; 1: mirror ghosts (+-own value); 2: value-0 ghosts among them
+            static const bool gen_edge = getenv("PYRO_MG_BAND_GENEDGE") != nullptr;
+            int edge = (A.bc.code[0] != PYROHIP_BC_PERIODIC || A.bc.code[2] != PYROHIP_BC_PERIODIC) ? 1 : 0;
+            for (int sd = 0; sd < 4; sd++)
+                if (A.bc.code[sd] == PYROHIP_BC_CONST || (edge && gen_edge)) edge = 2;
             if (band && hom) {
                 using BandT = void (*)(MGTile);
 #define MGB_ROW(P2, E) {k_mg_smooth_band<P2, E, false, 4>, k_mg_smooth_band<P2, E, true, 4>}
-                static const BandT inst[2][2][2] = {{MGB_ROW(false, false), MGB_ROW(false, true)},
-                                                    {MGB_ROW(true, false), MGB_ROW(true, true)}};
+                static const BandT inst[2][3][2] = {{MGB_ROW(false, 0), MGB_ROW(false, 1), MGB_ROW(false, 2)},
+                                                    {MGB_ROW(true, 0), MGB_ROW(true, 1), MGB_ROW(true, 2)}};
 #undef MGB_ROW
-                PYRO_LAUNCH(m->ctx, "k_mg_smooth_band", inst[pow2 ? 1 : 0][edge ? 1 : 0][A.cv ? 1 : 0],
+                PYRO_LAUNCH(m->ctx, "k_mg_smooth_band", inst[pow2 ? 1 : 0][edge][A.cv ? 1 : 0],
                             dim3(A.ntiles), dim3(1024), MGW_LDS, A);
             }
             else if (pow2)
