@@ -106,6 +106,7 @@ struct pyrohip_mg {
     // smoothing launch of the cycle on the finest level reads v from one buffer and writes
     // another -- the buffer it read IS that copy, the previous copy becomes the scratch buffer
     bool capture_old = false, old_captured = false;
+    hipEvent_t ev[2] = {nullptr, nullptr};   // solve loop: a cycle's norms have reached the host
 };
 
 namespace pyro {
@@ -2112,6 +2113,8 @@ int pyrohip_mg_destroy(pyrohip_mg *m)
     if (m->gen_pool) (void)hipFree(m->gen_pool);
     for (int s = 0; s < 4; s++)
         if (m->bcval[s]) (void)hipFree(m->bcval[s]);
+    for (int k = 0; k < 2; k++)
+        if (m->ev[k]) (void)hipEventDestroy(m->ev[k]);
     delete m;
     return 0;
 }
@@ -2521,7 +2524,10 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
     PYRO_CHECK_HIP(hipMemcpyAsync(m->old_phi, F.v, fbytes, hipMemcpyDeviceToDevice, c->stream));
     double res = 1.e33, rel = 1.e33;
     int cycle = 1;
-    while (res > rtol && cycle <= max_cycles) {           // MG.py:652
+    // one cycle on the stream: zeroed coarse solutions, V-cycle, both norms.  Constant
+    // coefficients: the norms land in host slot `slot` when event ev[slot] has passed;
+    // variable coefficients (sync = true): the old blocking sequence, norms returned at once
+    auto enqueue = [&](int slot, bool sync, double *s_out, double *s2_out) -> int {
         for (int l = 0; l < Lf; l++) {                    // :658-659 (zero the coarse solutions)
             // levels the wide tile smoother visits first: no memset (hipMemset runs
             // at ~270 GB/s: 123 us for the 2048^2 level), the staging takes v = 0
@@ -2539,39 +2545,91 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
         m->in_solve = false;
         m->capture_old = false;
         PYRO_TRY(vrc);
-        double s = 0.0, s2 = 0.0;                         // :673-678
-        if (m->vc) {
-            PYRO_TRY(mg_sumsq(m, F.v, m->old_phi, Lf, 1, &s));
+        if (sync) {                                       // :673-678
+            PYRO_TRY(mg_sumsq(m, F.v, m->old_phi, Lf, 1, s_out));
             PYRO_CHECK_HIP(hipMemcpyAsync(m->old_phi, F.v, fbytes, hipMemcpyDeviceToDevice,
                                           c->stream));
             PYRO_TRY(mg_residual(m, Lf));
-            PYRO_TRY(mg_sumsq(m, F.r, nullptr, Lf, 0, &s2));
-        } else {   // fused: relative change, old <- v, residual and its norm in one pass
-            const dim3 grid(F.n >= 2048 ? 16 : 1, F.n >= 64 ? 128 : 1), block(256);
-            const int nb = grid.x * grid.y;
-            PYRO_TRY(c->reduce.ensure((2 * nb + 2) * sizeof(double)));
-            double *part = (double *)c->reduce.p;
-            using DiagT = void (*)(const double *, const double *, double *, double *, int, int, double,
-                                   double, double, double, double *);
-            static const DiagT diag[2][2] = {{k_mg_solve_diag<false, false>, k_mg_solve_diag<false, true>},
-                                            {k_mg_solve_diag<true, false>, k_mg_solve_diag<true, true>}};
-            const bool store = !m->lazy_r;
-            PYRO_LAUNCH(c, "k_mg_solve_diag", diag[store ? 1 : 0][m->old_captured ? 0 : 1], grid, block, 0,
-                        (const double *)F.v, (const double *)F.f, F.r, m->old_phi, F.n, F.pitch, m->alpha,
-                        m->beta, F.dx * F.dx, 1.e-16, part);
-            m->r_stale[Lf] = !store;
-            hipLaunchKernelGGL(k_sum_final2, dim3(1), dim3(256), 0, c->stream,
-                               (const double *)part, nb, part + 2 * nb);
-            PYRO_CHECK_HIP(hipGetLastError());
-            PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, part + 2 * nb, 2 * sizeof(double),
-                                          hipMemcpyDeviceToHost, c->stream));
-            PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
-            s = ((double *)c->reduce_host)[0];
-            s2 = ((double *)c->reduce_host)[1];
+            PYRO_TRY(mg_sumsq(m, F.r, nullptr, Lf, 0, s2_out));
+            return 0;
+        }
+        // fused: relative change, old <- v (unless captured), residual and its norm in one pass
+        const dim3 grid(F.n >= 2048 ? 16 : 1, F.n >= 64 ? 128 : 1), block(256);
+        const int nb = grid.x * grid.y;
+        PYRO_TRY(c->reduce.ensure((2 * nb + 4) * sizeof(double)));
+        double *part = (double *)c->reduce.p;
+        using DiagT = void (*)(const double *, const double *, double *, double *, int, int, double,
+                               double, double, double, double *);
+        static const DiagT diag[2][2] = {{k_mg_solve_diag<false, false>, k_mg_solve_diag<false, true>},
+                                        {k_mg_solve_diag<true, false>, k_mg_solve_diag<true, true>}};
+        const bool store = !m->lazy_r;
+        PYRO_LAUNCH(c, "k_mg_solve_diag", diag[store ? 1 : 0][m->old_captured ? 0 : 1], grid, block, 0,
+                    (const double *)F.v, (const double *)F.f, F.r, m->old_phi, F.n, F.pitch, m->alpha,
+                    m->beta, F.dx * F.dx, 1.e-16, part);
+        m->r_stale[Lf] = !store;
+        hipLaunchKernelGGL(k_sum_final2, dim3(1), dim3(256), 0, c->stream,
+                           (const double *)part, nb, part + 2 * nb + 2 * slot);
+        PYRO_CHECK_HIP(hipGetLastError());
+        PYRO_CHECK_HIP(hipMemcpyAsync((double *)c->reduce_host + 2 * slot, part + 2 * nb + 2 * slot,
+                                      2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (!m->ev[slot]) PYRO_CHECK_HIP(hipEventCreateWithFlags(&m->ev[slot], hipEventDisableTiming));
+        PYRO_CHECK_HIP(hipEventRecord(m->ev[slot], c->stream));
+        return 0;
+    };
+    // Between a cycle's norms and the decision they feed (MG.py:652) the device would idle for
+    // the read-back and the next launch (~13 us per cycle, measured).  While that answer is on
+    // its way the NEXT cycle is already put on the stream when it is likely to be needed; the
+    // first smoothing launch of a cycle leaves the solution before the cycle untouched in
+    // old_phi (capture_old), so a cycle that turns out to be one too many is undone by taking
+    // that buffer back -- cycles, norms and solution are those of the loop that waits.  (The
+    // coarser levels' arrays, scratch between solves, then hold the undone cycle's values.)
+    // PYRO_MG_SPECULATE: 0 never, 2 whenever a further cycle is allowed (tests).
+    static const int spec_mode = getenv("PYRO_MG_SPECULATE") ? atoi(getenv("PYRO_MG_SPECULATE")) : 1;
+    const bool can_undo = !m->vc && m->smoother != 0 && m->nsmooth > 0 && Lf > MGC_TOP &&
+                          (F.n + 2) * (F.n + 2) > MGS_CELLS;      // the finest level's launches ping-pong
+    double res_prev = -1.0, res_pprev = -1.0;
+    bool pending = false;                                  // cycle `cycle` is already on the stream
+    while (res > rtol && cycle <= max_cycles) {           // MG.py:652
+        double s = 0.0, s2 = 0.0;
+        if (m->vc) {
+            PYRO_TRY(enqueue(0, true, &s, &s2));
+        } else {
+            const int slot = cycle & 1;
+            if (!pending) PYRO_TRY(enqueue(slot, false, nullptr, nullptr));
+            pending = false;
+            // would the loop run another cycle if this one's residual were what the trend says?
+            bool spec = false;
+            if (can_undo && spec_mode != 0 && cycle + 1 <= max_cycles) {
+                const double ratio = (res_pprev > 0.0 && res_prev > 0.0) ? fmin(1.0, fmax(0.02, res_prev / res_pprev)) : 0.05;
+                const double guess = (res_prev > 0.0) ? res_prev * ratio : 1.e33;
+                spec = spec_mode == 2 || rtol <= 0.0 || guess > 3.0 * rtol;
+            }
+            double *undo_v = nullptr;
+            if (spec) {
+                PYRO_TRY(enqueue(slot ^ 1, false, nullptr, nullptr));
+                PYRO_REQUIRE(m->old_captured, "internal: a speculative cycle must leave the solution before it");
+                undo_v = m->old_phi;                       // the solution after cycle `cycle`
+            }
+            PYRO_CHECK_HIP(hipEventSynchronize(m->ev[slot]));
+            s = ((double *)c->reduce_host)[2 * slot];
+            s2 = ((double *)c->reduce_host)[2 * slot + 1];
+            if (spec) {
+                const double rn_ = sqrt(F.dx * F.dx * s2);
+                const double res_ = (m->source_norm != 0.0) ? rn_ / m->source_norm : rn_;
+                if (res_ > rtol) pending = true;           // it was needed
+                else {                                     // undo: the buffers trade places again
+                    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+                    m->old_phi = F.v;
+                    F.v = undo_v;
+                    m->r_stale[Lf] = true;
+                    m->corners_stale[Lf] = true;
+                }
+            }
         }
         rel = sqrt(F.dx * F.dx * s);
         double rn = sqrt(F.dx * F.dx * s2);
         res = (m->source_norm != 0.0) ? rn / m->source_norm : rn;   // :682-685
+        res_pprev = res_prev; res_prev = res;
         cycle++;
     }
     PYRO_TRY(mg_fill(m, Lf, 0));                          // :697

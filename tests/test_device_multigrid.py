@@ -511,3 +511,50 @@ def test_mg_solve_lazy_residual_and_old_copy(dev, monkeypatch):
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     assert np.array_equal(out[0][2], out[1][2])
     assert np.array_equal(out[0][3][1:-1, 1:-1], out[1][3][1:-1, 1:-1])
+
+
+@pytest.mark.parametrize("nx", [128, 256])
+def test_mg_solve_speculative_cycle(dev, nx, monkeypatch):
+    """solve() puts the next V-cycle on the stream before the norms of the current one have
+    reached the host and undoes it when it was one too many (csrc/multigrid.hip,
+    pyrohip_mg_solve): with the speculation forced on for every cycle, the cycle count, both
+    norms, the solution and the residual array equal those of the loop that waits -- for a
+    solve that converges (the last cycle is undone), one that runs into max_cycles, and a
+    second solve on the same object"""
+    if dev.kind == "emu" and nx > 128:
+        pytest.skip("the larger grid on the GPU only (asynchronous there)")
+    import subprocess, sys, pickle
+    code = r"""
+import sys, pickle, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import _get_ctx
+from pyro2_amd import device
+dev = _get_ctx(%r)
+nx = %d
+x = (np.arange(nx + 2) - 0.5) / nx
+X, Y = np.meshgrid(x, x, indexing="ij")
+rhs = -2.0 * ((1.0 - 6.0 * X ** 2) * Y ** 2 * (1.0 - Y ** 2) + (1.0 - 6.0 * Y ** 2) * X ** 2 * (1.0 - X ** 2))
+m = device.DeviceMG(dev, nx)
+L = m.nlevels - 1
+m.zero(L, 0); m.set(L, 1, rhs); m.init_rhs_norm()
+out = [m.solve(rtol=1e-7, max_cycles=30), m.get(L, 0)]
+out += [m.solve(rtol=0.0, max_cycles=3), m.get(L, 0), m.get(L, 2)[1:-1, 1:-1]]
+out += [m.solve(rtol=1e-11, max_cycles=30), m.get(L, 0)]
+pickle.dump(out, sys.stdout.buffer)
+"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("0", "2", "1"):
+        env = dict(os.environ, PYRO_MG_SPECULATE=mode)
+        p = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests"), dev.kind, nx)],
+                           env=env, capture_output=True, timeout=900)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        res[mode] = pickle.loads(p.stdout)
+    assert 1 < res["0"][0][0] < 30            # converged: the forced speculation had a cycle to undo
+    for mode in ("2", "1"):
+        for a, b in zip(res["0"], res[mode]):
+            if isinstance(a, tuple):
+                assert a == b, mode
+            else:
+                assert np.array_equal(a, b), mode
