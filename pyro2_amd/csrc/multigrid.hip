@@ -2589,6 +2589,8 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
                           (F.n + 2) * (F.n + 2) > MGS_CELLS;      // the finest level's launches ping-pong
     double res_prev = -1.0, res_pprev = -1.0;
     bool pending = false;                                  // cycle `cycle` is already on the stream
+    static const bool spec_debug = getenv("PYRO_MG_SPEC_DEBUG") != nullptr;   // developer aid
+    int n_spec = 0, n_undo = 0;
     while (res > rtol && cycle <= max_cycles) {           // MG.py:652
         double s = 0.0, s2 = 0.0;
         if (m->vc) {
@@ -2606,6 +2608,7 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
             }
             double *undo_v = nullptr;
             if (spec) {
+                n_spec++;
                 PYRO_TRY(enqueue(slot ^ 1, false, nullptr, nullptr));
                 PYRO_REQUIRE(m->old_captured, "internal: a speculative cycle must leave the solution before it");
                 undo_v = m->old_phi;                       // the solution after cycle `cycle`
@@ -2618,6 +2621,7 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
                 const double res_ = (m->source_norm != 0.0) ? rn_ / m->source_norm : rn_;
                 if (res_ > rtol) pending = true;           // it was needed
                 else {                                     // undo: the buffers trade places again
+                    n_undo++;
                     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
                     m->old_phi = F.v;
                     F.v = undo_v;
@@ -2636,6 +2640,9 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
     m->corners_stale[Lf] = false;
     PYRO_CHECK_HIP(hipGetLastError());
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (spec_debug)
+        fprintf(stderr, "mg solve n=%d rtol=%g: %d cycles, %d launched ahead, %d undone, residual %g (before: %g)\n",
+                F.n, rtol, cycle - 1, n_spec, n_undo, res, res_pprev);
     if (num_cycles) *num_cycles = cycle - 1;
     if (residual_error) *residual_error = res;
     if (relative_error) *relative_error = rel;
