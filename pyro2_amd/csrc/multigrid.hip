@@ -687,23 +687,63 @@ __global__ __launch_bounds__(64 * (MGW_RI / R), (PROL || R == 8) ? 4 : 8) void k
         MGB_SCHED_FENCE();
     }
     if (PROL) {
+        // k_mg_prolong_add's expression for the thread's R x 2 fine cells.  They lie over 2-3
+        // coarse rows and 1-2 coarse columns, which of them depends only on the parity of the
+        // tile's first row / column: the coarse values are loaded once into a small array that
+        // is indexed at compile time (16 loads instead of 5 per cell = 40; the launch that opens
+        // the up leg was 6 us slower than the others), cells outside the level drop the result
+        const int gu0 = gi0 + R * wv, gv0 = gj0 + 2 * ln;     // the thread's first cell, unwrapped
+        const int nc = n >> 1;
+        auto prol = [&](auto pic, auto pjc) __attribute__((always_inline)) {
+            constexpr int PI = decltype(pic)::value, PJ = decltype(pjc)::value;   // parities of gu0, gv0
+            constexpr int NR = ((R - PI) >> 1) + 3, NC = ((2 - PJ) >> 1) + 3;
+            const int C0 = ((gu0 + 1) >> 1) - 1, D0 = ((gv0 + 1) >> 1) - 1;      // first coarse row / column read
+            double cc[NR][NC];
+            unsigned ccol[NC];
 #pragma unroll
-        for (int m = 0; m < R; m++)
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                // k_mg_prolong_add's expression for fine cell (gi-1, gj-1); cells outside the
-                // level read coarse cell (1, 1) and drop the result
-                const bool in = gi_[m] >= 1 && gi_[m] <= n && gj_[q] >= 1 && gj_[q] <= n;
-                const int fi = in ? gi_[m] - 1 : 0, fj = in ? gj_[q] - 1 : 0;
-                const unsigned ck = (unsigned)((1 + (fi >> 1)) * A.cpitch + 1 + (fj >> 1));
-                const double q0 = A.cv[ck];
-                const double m_x = 0.5 * (A.cv[ck + A.cpitch] - A.cv[ck - A.cpitch]);
-                const double m_y = 0.5 * (A.cv[ck + 1] - A.cv[ck - 1]);
-                const double tx = 0.25 * m_x, ty = 0.25 * m_y;    // x - y == x + (-y)
-                const double e = (q0 + ((fi & 1) ? tx : -tx)) + ((fj & 1) ? ty : -ty);
-                v[m][q] += in ? e : 0.0;
-                if (q == 1 && (m & 1)) MGB_SCHED_FENCE();      // 4 cells' coarse reads in flight, not 16
+            for (int b = 0; b < NC; b++) {
+                const int d = D0 + b;
+                int w = d + (d < 1 ? nc : 0);
+                w -= (w > nc ? nc : 0);
+                w -= (w > nc ? nc : 0);
+                ccol[b] = (unsigned)(per_j ? w : min(max(d, 0), nc + 1));
             }
+#pragma unroll
+            for (int a = 0; a < NR; a++) {
+                const int cr = C0 + a;
+                const int w = cr + (cr < 1 ? nc : 0) - (cr > nc ? nc : 0);
+                const unsigned base = (unsigned)((per_i ? w : min(max(cr, 0), nc + 1)) * A.cpitch);
+#pragma unroll
+                for (int b = 0; b < NC; b++) cc[a][b] = A.cv[base + ccol[b]];      // unused corners: dropped
+            }
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                const int g = gu0 + m;
+                const bool rin = per_i || (g >= 1 && g <= n);
+                const int ro = (m + 1 - PI) >> 1;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int h = gv0 + q;
+                    const bool in = rin && (per_j || (h >= 1 && h <= n));
+                    const int co = (q + 1 - PJ) >> 1;
+                    const double q0 = cc[ro + 1][co + 1];
+                    const double m_x = 0.5 * (cc[ro + 2][co + 1] - cc[ro][co + 1]);
+                    const double m_y = 0.5 * (cc[ro + 1][co + 2] - cc[ro + 1][co]);
+                    const double tx = 0.25 * m_x, ty = 0.25 * m_y;    // x - y == x + (-y)
+                    // fine cell (fi, fj) = (g - 1, h - 1): + for odd fi / fj
+                    const bool fio = ((PI + m + 1) & 1) != 0, fjo = ((PJ + q + 1) & 1) != 0;
+                    const double e = (q0 + (fio ? tx : -tx)) + (fjo ? ty : -ty);
+                    v[m][q] += in ? e : 0.0;
+                }
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        const int par = (gi0 & 1) * 2 + (gj0 & 1);            // the same for the whole tile
+        if (par == 0) prol(I0{}, I0{});
+        else if (par == 1) prol(I0{}, I1{});
+        else if (par == 2) prol(I1{}, I0{});
+        else prol(I1{}, I1{});
     }
     // LDS slots of the band-edge rows (this band's rows 0 and 3, both columns) and of
     // the rows next to the band (clamped: an edge band's outer rows are never read by
