@@ -893,9 +893,9 @@ struct MGCoarse {
     double alpha, beta;
     int nsmooth, nsmooth_bottom;
     MGBC bc;                                     // val[] only meaningful when finest
-    int wave_top;                                // levels 0 .. wave_top: wave 0 only (-1: none)
     unsigned zero_mask;                          // bit l: take v of level l as 0 (no memset before)
     int allow_pow2;                              // 0: PYRO_MG_NOPOW2 (see mg_pow2)
+    int band64;                                  // 1: the 64^2 level's sweeps in registers (mgc_sweeps_band64)
     long long *trace;                            // developer aid: clock64() at the phase marks
 };
 #ifdef PYRO_EMU
@@ -910,36 +910,26 @@ __host__ __device__ inline int mgc_off(int l)    // LDS offset (doubles) of leve
     return o;
 }
 constexpr int MGC_LDS_DOUBLES = 2 * (16 + 36 + 100 + 324 + 1156 + 4356);
-constexpr size_t MGC_LDS = (size_t)MGC_LDS_DOUBLES * sizeof(double);
+constexpr int MGC_EDGE_DOUBLES = 16 * 2 * 64;     // mgc_sweeps_band64: first / last row of every wavefront
+constexpr size_t MGC_LDS = (size_t)(MGC_LDS_DOUBLES + MGC_EDGE_DOUBLES) * sizeof(double);
 
-// Synchronisation inside the coarse kernel.  The levels up to wave_top can be run by
-// wave 0 alone with wave-level barriers instead of workgroup barriers (within one
-// wave LDS operations complete in program order).  No gain, measured twice: round 1
-// with the LDS sweeps (325 / 333 / 329 / 320 / 333 / 353 us for wave_top = -1 / 0 /
-// 1 / 2 / 3 / 4 on a 64^2 V-cycle), round 2 with sweeps of one wavefront in
-// registers (a B x B block of cells per lane, neighbours by ds_bpermute, ghost
-// values synthesised: 295 instead of 390 cycles per colour sweep on the 8^2 level,
-// eaten up by the single-wave residual / restriction / prolongation phases: 129 us
-// against 125 us; removed again).  A colour sweep of a tiny level is an LDS-latency
-// round trip (~150 cycles) plus ~60 dependent-issue-bound instructions either way.
-// Default: off (-1); env PYRO_MGC_WAVE_TOP.
-#ifdef PYRO_EMU
-__device__ inline void mgc_wave_sync() { hipemu::wave_barrier(); }
-#else
-__device__ __forceinline__ void mgc_wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-#endif
+// Synchronisation inside the coarse kernel: workgroup barriers.  Running the smallest levels
+// on wavefront 0 alone with wave-level barriers (within one wave LDS operations complete in
+// program order) was measured twice and never paid: round 1 with the LDS sweeps (325 / 333 /
+// 329 / 320 / 333 / 353 us on a 64^2 V-cycle for the levels up to none / 2^2 / 4^2 / 8^2 / 16^2 /
+// 32^2), round 2 with sweeps of one wavefront in registers (a B x B block of cells per lane,
+// neighbours by ds_bpermute, ghost values synthesised: 295 instead of 390 cycles per colour
+// sweep on the 8^2 level, eaten up by the single-wave residual / restriction / prolongation
+// phases: 129 us against 125 us).  A colour sweep of a tiny level is an LDS-latency round trip
+// (~150 cycles) plus ~60 dependent-issue-bound instructions either way.  The code is gone: its
+// second instantiation of every level function made the kernel 78 KB, more than the 64 KB
+// instruction cache holds.
 template <int NT>
 __device__ __forceinline__ void mgc_sync()
 {
-    if (NT == 64) mgc_wave_sync();
-    else __syncthreads();
+    static_assert(NT == MGC_NT, "the coarse kernel runs every level with the whole workgroup");
+    __syncthreads();
 }
-constexpr int MGC_WAVE_TOP = -1;   // default: every level by the whole workgroup
 
 template <int NT>
 __device__ inline void mgc_fill(double *V, int n, double dx, const MGBC &bc, bool use_val, int tid)
@@ -1076,6 +1066,96 @@ __device__ __forceinline__ void mgc_sweeps_lean(double *V, const double *F, int 
     }
 }
 
+// The sweeps of the 64^2 level in the layout of k_mg_smooth_band: wavefront w keeps rows
+// 4w+1 .. 4w+4 in registers for the whole smoothing, lane h the columns 2h+1, 2h+2 (64 columns
+// are 32 lanes: lanes 32 .. 63 compute what lanes 0 .. 31 compute, so that the whole-wave
+// rotations wrap at the level's width), column neighbours by DPP, the wavefronts' edge rows
+// through LDS (E), ghost values as +-(own value) in one fma (mirror sides; a side with
+// value-0 ghosts takes mgc_sweeps_lean).  A colour sweep is 4 updates per wavefront instead of
+// 2 x (5 LDS reads + update + write + ghost writes) per thread: 2000 -> ~600 cycles.
+#if !defined(PYRO_EMU)
+__device__ __forceinline__ double mgc_rot_from_lower(double v) { return mgb_from_lower(v); }   // lane 0 <- 63
+__device__ __forceinline__ double mgc_rot_from_upper(double v) { return mgb_from_upper(v); }
+#else
+__device__ __forceinline__ double mgc_rot_from_lower(double v) { return __shfl(v, (int)((threadIdx.x + 63) & 63), 64); }
+__device__ __forceinline__ double mgc_rot_from_upper(double v) { return __shfl(v, (int)((threadIdx.x + 1) & 63), 64); }
+#endif
+template <bool POW2>
+__device__ __forceinline__ void mgc_sweeps_band64(double *V, const double *F, double *E, double xc,
+                                                  double yc, double denom, double rdenom, int iters,
+                                                  int c0, int c1, int c2, int c3, int tid)
+{
+    constexpr int N = 64, Q = N + 2, R = 4;
+    const int wv = tid >> 6, ln = tid & 63, hl = ln & 31;
+    const bool per_i = (c0 == PYROHIP_BC_PERIODIC), per_j = (c2 == PYROHIP_BC_PERIODIC);
+    const bool botW = (wv == 0) && !per_i, topW = (wv == 15) && !per_i;       // rows 1 / 64
+    const bool isWl = (hl == 0) && !per_j, isEl = (hl == 31) && !per_j;       // columns 1 / 64
+    const double sBw = (botW && c0 == PYROHIP_BC_REFLECT_ODD) ? -1.0 : 1.0;
+    const double sTw = (topW && c1 == PYROHIP_BC_REFLECT_ODD) ? -1.0 : 1.0;
+    const double sWl = (isWl && c2 == PYROHIP_BC_REFLECT_ODD) ? -1.0 : 1.0;
+    const double sEl = (isEl && c3 == PYROHIP_BC_REFLECT_ODD) ? -1.0 : 1.0;
+    const double kx = xc * rdenom, ky = yc * rdenom;
+    const int wb = (wv + 15) & 15, wa = (wv + 1) & 15;
+    auto ei = [](int w, int which, int col) -> int { return (w * 2 + which) * N + col; };
+    double v[R][2], fs[R][2];
+#pragma unroll
+    for (int m = 0; m < R; m++)
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int c = (R * wv + m + 1) * Q + 2 * hl + 1 + q;
+            v[m][q] = V[c];
+            fs[m][q] = POW2 ? F[c] * rdenom : F[c];
+        }
+    if (ln < 32) {
+        E[ei(wv, 0, 2 * hl)] = v[0][0]; E[ei(wv, 0, 2 * hl + 1)] = v[0][1];
+        E[ei(wv, 1, 2 * hl)] = v[R - 1][0]; E[ei(wv, 1, 2 * hl + 1)] = v[R - 1][1];
+    }
+    __syncthreads();
+    // cell (i, j) = (4w+m+1, 2h+1+q) is relaxed in sweep s iff i + j + s - 1 is even:
+    // the thread's column q = (PAR + m) & 1 with PAR = (s + 1) & 1
+    auto pass = [&](auto par_c) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value;
+        const double below = E[ei(wb, 1, 2 * hl + (PAR & 1))];
+        const double above = E[ei(wa, 0, 2 * hl + ((PAR + R - 1) & 1))];
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            const int q = (PAR + m) & 1;
+            const double me = v[m][q];
+            const double up = (m < R - 1) ? v[m < R - 1 ? m + 1 : R - 1][q] : above;
+            const double dn = (m > 0) ? v[m > 0 ? m - 1 : 0][q] : below;
+            const double own = v[m][q ^ 1];
+            const double oth = q ? mgc_rot_from_upper(v[m][0]) : mgc_rot_from_lower(v[m][1]);
+            const double e = q ? oth : own, w = q ? own : oth;
+            double si, sj;
+            if (m == 0) si = fma(botW ? me : dn, sBw, up);
+            else if (m == R - 1) si = fma(topW ? me : up, sTw, dn);
+            else si = up + dn;
+            if (q == 0) sj = fma(isWl ? me : w, sWl, e);
+            else sj = fma(isEl ? me : e, sEl, w);
+            if (POW2)
+                v[m][q] = fma(ky, sj, fma(kx, si, fs[m][q]));
+            else
+                v[m][q] = div_by(fs[m][q] + xc * si + yc * sj, denom, rdenom);
+        }
+        if (ln < 32) {
+            E[ei(wv, 0, 2 * hl + (PAR & 1))] = v[0][PAR & 1];
+            E[ei(wv, 1, 2 * hl + ((PAR + R - 1) & 1))] = v[R - 1][(PAR + R - 1) & 1];
+        }
+    };
+    for (int s = 0; s < 2 * iters; s++) {
+        if (s & 1) pass(std::integral_constant<int, 1>{});
+        else pass(std::integral_constant<int, 0>{});
+        __syncthreads();
+    }
+    if (ln < 32) {
+#pragma unroll
+        for (int m = 0; m < R; m++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) V[(R * wv + m + 1) * Q + 2 * hl + 1 + q] = v[m][q];
+    }
+    __syncthreads();
+}
+
 // Red-black sweeps of one LDS-resident level.  The thread that updates a cell
 // next to a boundary also refreshes the ghost cell(s) that mirror it (like
 // k_mg_smooth): during a colour sweep a ghost cell is only read by the cell it
@@ -1100,7 +1180,7 @@ __device__ __forceinline__ bool mgc_is_pow2(double x)     // device twin of mg_i
 template <int NT>
 __device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, double dx,
                                   double alpha, double beta, int iters, const MGBC &bc,
-                                  bool use_val, int tid, bool allow_pow2 = true)
+                                  bool use_val, int tid, bool allow_pow2 = true, double *E = nullptr)
 {
     const int q = n + 2;
     const double xc = beta / (dx * dx), yc = beta / (dx * dx);
@@ -1113,7 +1193,12 @@ __device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, dou
     const double *v2 = use_val ? bc.val[2] : nullptr, *v3 = use_val ? bc.val[3] : nullptr;
     const bool pow2 = allow_pow2 && mgc_is_pow2(xc) && mgc_is_pow2(yc) && mgc_is_pow2(denom) &&
                       rdenom * denom == 1.0;                    // see mg_pow2
-    if (!(v0 || v1 || v2 || v3) && n * (n >> 1) <= 2 * NT) {
+    const bool mirror = c0 != PYROHIP_BC_CONST && c1 != PYROHIP_BC_CONST && c2 != PYROHIP_BC_CONST &&
+                        c3 != PYROHIP_BC_CONST;
+    if (NT == MGC_NT && n == 64 && E && mirror && !(v0 || v1 || v2 || v3)) {
+        if (pow2) mgc_sweeps_band64<true>(V, F, E, xc, yc, denom, rdenom, iters, c0, c1, c2, c3, tid);
+        else mgc_sweeps_band64<false>(V, F, E, xc, yc, denom, rdenom, iters, c0, c1, c2, c3, tid);
+    } else if (!(v0 || v1 || v2 || v3) && n * (n >> 1) <= 2 * NT) {
         if (pow2) mgc_sweeps_lean<NT, true>(V, F, n, lg, xc, yc, denom, rdenom, iters, c0, c1, c2, c3, tid);
         else mgc_sweeps_lean<NT, false>(V, F, n, lg, xc, yc, denom, rdenom, iters, c0, c1, c2, c3, tid);
     } else if (!(v0 || v1 || v2 || v3))   // boundary values only on a finest level <= 64^2
@@ -1225,7 +1310,8 @@ __device__ inline void mgc_down(const MGCoarse &A, int l, double *lds, int tid)
     double *Fc = lds + mgc_off(l - 1) + qc * qc;
     const bool uv = A.finest && l == A.top;
     if (l == 2) MGC_MARK(14);
-    mgc_smooth<NT>(V, F, n, l + 1, A.dx[l], A.alpha, A.beta, A.nsmooth, A.bc, uv, tid, A.allow_pow2);
+    mgc_smooth<NT>(V, F, n, l + 1, A.dx[l], A.alpha, A.beta, A.nsmooth, A.bc, uv, tid, A.allow_pow2,
+                   A.band64 ? lds + MGC_LDS_DOUBLES : nullptr);
     if (l == 2) MGC_MARK(15);
     const double dx2 = A.dx[l] * A.dx[l];
     for (int idx = tid; idx < nc * nc; idx += NT) {
@@ -1266,7 +1352,7 @@ __device__ inline void mgc_up(const MGCoarse &A, int l, double *lds, int tid)
     }
     mgc_sync<NT>();
     mgc_smooth<NT>(V, F, n, l + 1, A.dx[l], A.alpha, A.beta, A.nsmooth, A.bc,
-                   A.finest && l == A.top, tid, A.allow_pow2);
+                   A.finest && l == A.top, tid, A.allow_pow2, A.band64 ? lds + MGC_LDS_DOUBLES : nullptr);
 }
 
 __global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
@@ -1287,22 +1373,9 @@ __global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
     }
     __syncthreads();
     MGC_MARK(1);
-    const int wtop = (A.top < A.wave_top) ? A.top : A.wave_top;
-    // down leg of the larger levels: the whole workgroup
-    for (int l = A.top; l > wtop && l >= 1; l--) { mgc_down<MGC_NT>(A, l, lds, tid); MGC_MARK(2 + (A.top - l)); }
-    if (wtop >= 0) {
-        // the smallest levels: wave 0, no workgroup barriers
-        if (tid < 64) {
-            for (int l = wtop; l >= 1; l--) mgc_down<64>(A, l, lds, tid);
-            {   // bottom solve (MG.py:776-778)
-                double *V = lds + mgc_off(0), *F = V + 16;
-                mgc_smooth<64>(V, F, 2, 1, A.dx[0], A.alpha, A.beta, A.nsmooth_bottom, A.bc,
-                               A.finest && A.top == 0, tid, A.allow_pow2);
-            }
-            for (int l = 1; l <= wtop; l++) mgc_up<64>(A, l, lds, tid);
-        }
-        __syncthreads();
-    } else {
+    // down leg
+    for (int l = A.top; l >= 1; l--) { mgc_down<MGC_NT>(A, l, lds, tid); MGC_MARK(2 + (A.top - l)); }
+    {
         // MG.py:565 fill, the sweeps in registers of thread 0, closing fill (corners)
         double *V = lds + mgc_off(0), *F = V + 16;
         const bool uv = A.finest && A.top == 0;
@@ -1323,7 +1396,7 @@ __global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
         if (A.nsmooth_bottom > 0) mgc_fill<MGC_NT>(V, 2, A.dx[0], A.bc, uv, tid);
     }
     MGC_MARK(8);
-    for (int l = (wtop > 0 ? wtop : 0) + 1; l <= A.top; l++) { mgc_up<MGC_NT>(A, l, lds, tid); MGC_MARK(8 + l); }
+    for (int l = 1; l <= A.top; l++) { mgc_up<MGC_NT>(A, l, lds, tid); MGC_MARK(8 + l); }
     // write back: v of every level, f of the levels below the top
     for (int l = 0; l <= A.top; l++) {
         const int n = 2 << l, q = n + 2;
@@ -2006,12 +2079,8 @@ static int mg_coarse_vcycle(pyrohip_mg *m, int top)
     A.finest = (top == m->nlevels - 1) ? 1 : 0;
     A.alpha = m->alpha; A.beta = m->beta;
     A.nsmooth = m->nsmooth; A.nsmooth_bottom = m->nsmooth_bottom;
-    static const int wave_top = [] {
-        const char *e = getenv("PYRO_MGC_WAVE_TOP");
-        return e ? atoi(e) : MGC_WAVE_TOP;
-    }();
-    A.wave_top = wave_top;
     A.allow_pow2 = getenv("PYRO_MG_NOPOW2") ? 0 : 1;
+    A.band64 = getenv("PYRO_MGC_NOBAND64") ? 0 : 1;
     A.zero_mask = 0;
     for (int l = 0; l <= top; l++)
         if (m->v_is_zero[l]) { A.zero_mask |= 1u << l; m->v_is_zero[l] = false; }
