@@ -231,9 +231,11 @@ __global__ __launch_bounds__(256) void k_mg_smooth(double *__restrict__ v,
 //               Measured at 4096^2, smooth(10): 651 us with v and f in LDS
 //               (32 x 128 region, K = 3) -> 491 us with f in registers
 //               -> ~350 us with the 64-row region and K = 5 (two launches).
-constexpr int MG_SMALL_TILES_DEFAULT = 128;         // workgroups aimed at on small levels (0: off;
-                                                   // env PYRO_MG_SMALL_TILES; measured 0 / 128 / 256 / 512:
-                                                   // 655 / 591 / 600 / 640 us per V-cycle at 512^2)
+constexpr int MG_SMALL_TILES_DEFAULT = 192;         // workgroups aimed at on small levels (0: off;
+                                                   // env PYRO_MG_SMALL_TILES; measured per V-cycle at
+                                                   // 512^2 / 2048^2: 64 232 / 450 us, 128 233 / 452,
+                                                   // 192 229 / 448, 256 245 / 491 (the up-leg launch holds
+                                                   // one workgroup per CU: more than 256 is two rounds))
 constexpr int MGS_CELLS = 66 * 66;                 // single-tile levels: n <= 64
 constexpr size_t MGS_LDS = (size_t)2 * MGS_CELLS * sizeof(double);
 #ifndef PYRO_MGW_RI
