@@ -297,7 +297,9 @@ def bench_advection(ctx, device, nx=2048, steps=100, warmup=10):
                          "launches_per_step": 1}}
 
 
-def bench_mg(ctx, device, nx=4096, cycles=10):
+def _mg_vcycles(ctx, device, nx, cycles):
+    """seconds for `cycles` V-cycles of the Poisson test problem of MG.py's tests at nx^2 (the
+    solve loop with its norms and convergence test, rtol 0), and the residual it ends with"""
     x = (np.arange(nx + 2) - 0.5) / nx
     X, Y = np.meshgrid(x, x, indexing="ij")
     rhs = -2.0 * ((1.0 - 6.0 * X ** 2) * Y ** 2 * (1.0 - Y ** 2) +
@@ -313,8 +315,19 @@ def bench_mg(ctx, device, nx=4096, cycles=10):
     t0 = time.perf_counter()
     nc, res, rel = m.solve(rtol=0.0, max_cycles=cycles)
     ctx.sync()
-    t1 = time.perf_counter()
+    return time.perf_counter() - t0, res
+
+
+def bench_mg(ctx, device, nx=4096, cycles=10, small_sizes=True):
+    dt_, res = _mg_vcycles(ctx, device, nx, cycles)
+    t0, t1 = 0.0, dt_
     vps = cycles / (t1 - t0)
+    # the sizes the multigrid callers (incompressible, diffusion) solve on: launch-latency bound
+    small = {}
+    if nx == 4096 and small_sizes:
+        for n2 in (512, 1024, 2048):
+            d2, _ = _mg_vcycles(ctx, device, n2, 20)
+            small[str(n2)] = d2 / 20 * 1e6
     model_gbs = MG_BYTES_PER_CELL_VCYCLE * nx * nx * vps / 1e9
     traffic = also_traffic("mg_summary", "bytes_per_vcycle") if nx == 4096 else None
     # the roofline entry is priced with the bytes the V-cycle really moves (PMC, committed
@@ -324,7 +337,7 @@ def bench_mg(ctx, device, nx=4096, cycles=10):
     return {"workload": f"multigrid constant-coeff Poisson {nx}x{nx} dirichlet, "
                         f"{cycles} V-cycles (nsmooth 10, bottom 50)",
             "value": vps, "unit": "V-cycles/s", "ms_per_vcycle": (t1 - t0) / cycles * 1e3,
-            "residual_error_after": res,
+            "residual_error_after": res, "us_per_vcycle_by_size": small,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "model_equivalent_gbs": model_gbs,

@@ -10,5 +10,5 @@ if what == "adv":
     r = bench.bench_advection(ctx, device, nx=int(os.environ.get("NX", "2048")), steps=20, warmup=2)
     print(r["ms_per_step"], r["roofline"]["kernel_avg_ms"])
 else:
-    r = bench.bench_mg(ctx, device, nx=int(os.environ.get("NX", "4096")), cycles=10)
+    r = bench.bench_mg(ctx, device, nx=int(os.environ.get("NX", "4096")), cycles=10, small_sizes=False)
     print(r["ms_per_vcycle"])
