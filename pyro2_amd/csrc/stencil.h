@@ -85,6 +85,13 @@ inline int xcd_grid_1d(int gx, int gy) { return 8 * ((gx * gy + 7) / 8); }
 // outflow (0, edge), reflect (-1, mirror), periodic (1, shift); interior and
 // other boundary types map to themselves.  Branch-free, so that the row map in
 // the marching loop stays on the scalar unit.
+// a value that is the same in every lane of the wavefront, moved to a scalar register
+#if !defined(PYRO_EMU)
+__device__ __forceinline__ int pyro_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#else
+__device__ __forceinline__ int pyro_uniform(int v) { return v; }
+#endif
+
 struct BcMap { int alo, blo, ahi, bhi; bool odd_lo, odd_hi; };
 __host__ __device__ inline BcMap bc_map(int lo, int hi, int ng, int bl, int br, bool fill)
 {
