@@ -26,6 +26,7 @@
 // removes the separate fill_x / fill_y / copy_frame launches: 4 launches -> 1.
 #include "common.h"
 #include "stencil.h"
+#include <type_traits>
 
 namespace pyro {
 
@@ -34,6 +35,14 @@ constexpr int AW_OUT = 56;        // columns a wavefront updates
 #define PYRO_ADV_PF 4
 #endif
 constexpr int ADV_PF = PYRO_ADV_PF;   // rows loaded ahead of their use
+
+template <int N, int U = 0, class F> __device__ __forceinline__ void adv_static_for(F &&fn)
+{
+    if constexpr (U < N) {
+        fn(std::integral_constant<int, U>{});
+        adv_static_for<N, U + 1>(fn);
+    }
+}
 
 struct AdvParams {
     double u, v, dt, dx, dy;
@@ -114,45 +123,50 @@ __global__ __launch_bounds__(64) void k_adv_step(const double *__restrict__ ain,
     auto row_src = [&](int k) { return bc_src(mr, k > kb ? kb : k, g.ilo, g.ihi); };
     const bool odd_lo = mr.odd_lo, odd_hi = mr.odd_hi;
 
-    double w[5] = {0, 0, 0, 0, 0};      // a of rows k-4..k
-    double l2b = 0.0, l2c = 0.0;        // limit2_x of rows k-3, k-2
-    double Xm1 = 0.0, Xm2 = 0.0;        // x states of rows c-1, c-2  (c = k-2)
-    double Ym1 = 0.0;                   // y state of row c-1
-    double Fxm1 = 0.0;                  // F_x of row c-1
-    // rows k .. k+ADV_PF-1 in flight: the kernel is HBM bound and a wavefront
-    // consumes a row right after it arrives, so the loads run ahead of the use
-    double pf[ADV_PF];
+    // The rows the march carries from one iteration to the next live in rings that are indexed
+    // at compile time: the loop is unrolled over the least common period of the rings (18), so
+    // a value stays in the register it was computed into until it is dead -- a fifth of the
+    // loop's vector instructions were the moves of the sliding windows.
+    //   rows   a of rows k-4 .. k (the stencil window) and k+1 .. k+ADV_PF (loads in flight)
+    //   l2x    limit2_x of rows k-3, k-2, k-1
+    //   X      x states of rows c-2, c-1, c  (c = k-2);  Y, Fx  y state / F_x of rows c-1, c
+    constexpr int NR = 5 + ADV_PF, UNR = 18;
+    static_assert(NR == 9 && UNR % NR == 0 && UNR % 3 == 0 && UNR % 2 == 0, "ring periods");
+    double rows[NR], l2x[3] = {0, 0, 0}, Xr[3] = {0, 0, 0}, Yr[2] = {0, 0}, Fxr[2] = {0, 0};
 #pragma unroll
-    for (int n = 0; n < ADV_PF; n++) pf[n] = ain[(size_t)row_src(ka + n) * p + js];
-    for (int k = ka; k <= kb; k++) {
+    for (int n = 0; n < NR; n++) rows[n] = 0.0;
+    // rows k .. k+ADV_PF-1 in flight: a wavefront consumes a row right after it arrives, so
+    // the loads run ahead of the use
 #pragma unroll
-        for (int n = 0; n < 4; n++) w[n] = w[n + 1];
+    for (int n = 0; n < ADV_PF; n++) rows[4 + n] = ain[(size_t)row_src(ka + n) * p + js];
+    auto step = [&](auto uc, int k) __attribute__((always_inline)) {
+        constexpr int U = decltype(uc)::value;
+        // window row n (row k-4+n) and in-flight row n (row k+1+n)
+#define ADV_W(n) rows[(U + (n)) % NR]
         {   // row k arrives (through the ghost fill's index map), row k+ADV_PF leaves
-            const double raw = pf[0];
-#pragma unroll
-            for (int n = 0; n < ADV_PF - 1; n++) pf[n] = pf[n + 1];
-            pf[ADV_PF - 1] = ain[(size_t)row_src(k + ADV_PF) * p + js];
+            const double raw = ADV_W(4);
+            rows[(U + 4 + ADV_PF) % NR] = ain[(size_t)row_src(k + ADV_PF) * p + js];
             const bool neg = neg_c != ((k < g.ilo && odd_lo) || (k > g.ihi && odd_hi));
-            w[4] = neg ? -raw : raw;
+            ADV_W(4) = neg ? -raw : raw;
             // ghost frame of the new buffer
             const bool rghost = (k < g.ilo || k > g.ihi);
-            if (jown && (rghost || (jghost && k >= i0 && k < i1))) aout[(size_t)k * p + j] = w[4];
+            if (jown && (rghost || (jghost && k >= i0 && k < i1))) aout[(size_t)k * p + j] = ADV_W(4);
         }
-        const double l2n = (LIM != 0) ? limit2(w[2], w[3], w[4]) : 0.0;       // limit2_x of row k-1
-        if (k < i0 + 1 || k > i1 + 2) {
-            l2b = l2c; l2c = l2n;
-            continue;
-        }
+        const double l2b = l2x[U % 3], l2c = l2x[(U + 1) % 3];
+        const double l2n = (LIM != 0) ? limit2(ADV_W(2), ADV_W(3), ADV_W(4)) : 0.0;   // limit2_x of row k-1
+        l2x[(U + 2) % 3] = l2n;
+        if (k < i0 + 1 || k > i1 + 2) return;
+        const double Xm2 = Xr[U % 3], Xm1 = Xr[(U + 1) % 3], Ym1 = Yr[U % 2], Fxm1 = Fxr[U % 2];
         // ---- row c = k-2 (window index 2): limited slopes, interface states
-        const double sx = adv_slope<LIM>(l2b, l2c, l2n, w[1], w[2], w[3]);
-        const double am = adv_m1(w[2]), ap = adv_p1(w[2]);
-        const double l2y = (LIM != 0) ? limit2(am, w[2], ap) : 0.0;
+        const double sx = adv_slope<LIM>(l2b, l2c, l2n, ADV_W(1), ADV_W(2), ADV_W(3));
+        const double am = adv_m1(ADV_W(2)), ap = adv_p1(ADV_W(2));
+        const double l2y = (LIM != 0) ? limit2(am, ADV_W(2), ap) : 0.0;
         const double l2ym = (LIM == 2) ? adv_m1(l2y) : 0.0, l2yp = (LIM == 2) ? adv_p1(l2y) : 0.0;
-        const double sy = adv_slope<LIM>(l2ym, l2y, l2yp, am, w[2], ap);
+        const double sy = adv_slope<LIM>(l2ym, l2y, l2yp, am, ADV_W(2), ap);
         // upwind states of cell c (interface.py:25-41): its lower face if the
         // velocity is negative, its upper face otherwise
-        const double X = UNEG ? w[2] - 0.5 * (1.0 + cx) * sx : w[2] + 0.5 * (1.0 - cx) * sx;
-        const double Y = VNEG ? w[2] - 0.5 * (1.0 + cy) * sy : w[2] + 0.5 * (1.0 - cy) * sy;
+        const double X = UNEG ? ADV_W(2) - 0.5 * (1.0 + cx) * sx : ADV_W(2) + 0.5 * (1.0 - cx) * sx;
+        const double Y = VNEG ? ADV_W(2) - 0.5 * (1.0 + cy) * sy : ADV_W(2) + 0.5 * (1.0 - cy) * sy;
         // a_x on the lower x faces of rows c, c-1; a_y on the lower y faces of rows c, c-1
         const double ax_c = UNEG ? X : Xm1, ax_m = UNEG ? Xm1 : Xm2;
         const double ay_c = VNEG ? Y : adv_m1(Y), ay_m = VNEG ? Ym1 : adv_m1(Ym1);
@@ -167,13 +181,18 @@ __global__ __launch_bounds__(64) void k_adv_step(const double *__restrict__ ain,
             const double Fy = v * (ay_m - P.dtdx2 * (u * axc_s - u * axm_s));
             const double Fyh = adv_p1(Fy);
             if (jout)
-                aout[(size_t)(k - 3) * p + j] = w[1] + P.dtdx * (Fxm1 - Fx) + P.dtdy * (Fy - Fyh);
+                aout[(size_t)(k - 3) * p + j] = ADV_W(1) + P.dtdx * (Fxm1 - Fx) + P.dtdy * (Fy - Fyh);
         }
-        l2b = l2c; l2c = l2n;
-        Xm2 = Xm1; Xm1 = X;
-        Ym1 = Y;
-        Fxm1 = Fx;
-    }
+        Xr[(U + 2) % 3] = X;
+        Yr[(U + 1) % 2] = Y;
+        Fxr[(U + 1) % 2] = Fx;
+#undef ADV_W
+    };
+    for (int k0 = ka; k0 <= kb; k0 += UNR)
+        adv_static_for<UNR>([&](auto uc) __attribute__((always_inline)) {
+            const int k = k0 + decltype(uc)::value;
+            if (k <= kb) step(uc, k);
+        });
 }
 
 // rows per strip.  Measured (tools/adv_time.py): 16-20 rows at 2048^2 (enough
