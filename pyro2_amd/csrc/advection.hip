@@ -129,10 +129,11 @@ __global__ __launch_bounds__(64) void k_adv_step(const double *__restrict__ ain,
     // loop's vector instructions were the moves of the sliding windows.
     //   rows   a of rows k-4 .. k (the stencil window) and k+1 .. k+ADV_PF (loads in flight)
     //   l2x    limit2_x of rows k-3, k-2, k-1
-    //   X      x states of rows c-2, c-1, c  (c = k-2);  Y, Fx  y state / F_x of rows c-1, c
+    //   X      x states of rows c-2, c-1, c  (c = k-2);  Y, Ax, Fx  a_y / a_x (as used: at column
+    //          j-1 / j+my) and F_x of rows c-1, c
     constexpr int NR = 5 + ADV_PF, UNR = 18;
     static_assert(NR == 9 && UNR % NR == 0 && UNR % 3 == 0 && UNR % 2 == 0, "ring periods");
-    double rows[NR], l2x[3] = {0, 0, 0}, Xr[3] = {0, 0, 0}, Yr[2] = {0, 0}, Fxr[2] = {0, 0};
+    double rows[NR], l2x[3] = {0, 0, 0}, Xr[3] = {0, 0, 0}, Yr[2] = {0, 0}, Axr[2] = {0, 0}, Fxr[2] = {0, 0};
 #pragma unroll
     for (int n = 0; n < NR; n++) rows[n] = 0.0;
     // rows k .. k+ADV_PF-1 in flight: a wavefront consumes a row right after it arrives, so
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(64) void k_adv_step(const double *__restrict__ ain,
         const double l2n = (LIM != 0) ? limit2(ADV_W(2), ADV_W(3), ADV_W(4)) : 0.0;   // limit2_x of row k-1
         l2x[(U + 2) % 3] = l2n;
         if (k < i0 + 1 || k > i1 + 2) return;
-        const double Xm2 = Xr[U % 3], Xm1 = Xr[(U + 1) % 3], Ym1 = Yr[U % 2], Fxm1 = Fxr[U % 2];
+        const double Xm1 = Xr[(U + 1) % 3], Fxm1 = Fxr[U % 2];
         // ---- row c = k-2 (window index 2): limited slopes, interface states
         const double sx = adv_slope<LIM>(l2b, l2c, l2n, ADV_W(1), ADV_W(2), ADV_W(3));
         const double am = adv_m1(ADV_W(2)), ap = adv_p1(ADV_W(2));
@@ -167,24 +168,27 @@ __global__ __launch_bounds__(64) void k_adv_step(const double *__restrict__ ain,
         // velocity is negative, its upper face otherwise
         const double X = UNEG ? ADV_W(2) - 0.5 * (1.0 + cx) * sx : ADV_W(2) + 0.5 * (1.0 - cx) * sx;
         const double Y = VNEG ? ADV_W(2) - 0.5 * (1.0 + cy) * sy : ADV_W(2) + 0.5 * (1.0 - cy) * sy;
-        // a_x on the lower x faces of rows c, c-1; a_y on the lower y faces of rows c, c-1
-        const double ax_c = UNEG ? X : Xm1, ax_m = UNEG ? Xm1 : Xm2;
-        const double ay_c = VNEG ? Y : adv_m1(Y), ay_m = VNEG ? Ym1 : adv_m1(Ym1);
+        // a_x on the lower x face of row c; a_y on the lower y faces of rows c, c-1
+        const double ax_c = UNEG ? X : Xm1;
+        // (the lower row's values are the previous iteration's: kept as they were used there,
+        // i.e. already shifted by a lane where the velocity is positive -- two DPP moves less each)
+        const double ay_c = VNEG ? Y : adv_m1(Y), ay_m = Yr[U % 2];
         // F_x[c,j] = u*(a_x[c,j] - dtdy2*(F_yt[c+mx,j+1] - F_yt[c+mx,j]))
         const double ayt = (mx == 0) ? ay_c : ay_m;
         const double Fx = u * (ax_c - P.dtdy2 * (v * adv_p1(ayt) - v * ayt));
         // ---- row g = c-1: F_y and the conservative update
+        const double axc_s = (my == 0) ? ax_c : adv_m1(ax_c);
+        const double axm_s = Axr[U % 2];                  // a_x of row c-1 at column j + my
         if (k >= i0 + 3) {
             // F_y[g,j] = v*(a_y[g,j] - dtdx2*(F_xt[g+1,j+my] - F_xt[g,j+my]))
-            const double axc_s = (my == 0) ? ax_c : adv_m1(ax_c);
-            const double axm_s = (my == 0) ? ax_m : adv_m1(ax_m);
             const double Fy = v * (ay_m - P.dtdx2 * (u * axc_s - u * axm_s));
             const double Fyh = adv_p1(Fy);
             if (jout)
                 aout[(size_t)(k - 3) * p + j] = ADV_W(1) + P.dtdx * (Fxm1 - Fx) + P.dtdy * (Fy - Fyh);
         }
         Xr[(U + 2) % 3] = X;
-        Yr[(U + 1) % 2] = Y;
+        Yr[(U + 1) % 2] = ay_c;
+        Axr[(U + 1) % 2] = axc_s;
         Fxr[(U + 1) % 2] = Fx;
 #undef ADV_W
     };
