@@ -44,7 +44,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 SEDOV_BYTES_PER_CELL = 64   # read 4 + write 4 conserved doubles
 ADV_BYTES_PER_CELL = 16     # read a + write a
-MG_BYTES_PER_CELL_VCYCLE = 720
+MG_BYTES_PER_CELL_VCYCLE = 720      # SURVEY 8(d)'s one-pass-per-iteration model (kept as a labelled extra)
+# The floor under temporal blocking: a V-cycle visits every level twice, and a
+# visit cannot move less than  down-leg: read v, f + write v (24 B) + the restricted residual
+# (8 B / 4) ; up-leg: read v, f + the coarse correction (8 B / 4) + write v  = 52 B per level cell,
+# x 4/3 for the level pyramid = 69.3 B per finest cell per V-cycle.
+MG_FLOOR_BYTES_PER_LEVEL_CELL = 52
+MG_FLOOR_BYTES_PER_CELL_VCYCLE = MG_FLOOR_BYTES_PER_LEVEL_CELL * 4.0 / 3.0
 FP64_PEAK_FLOPS = 78.6e12           # MI355X FP64 vector peak (FMA = 2 flop), MI355X_MICROARCH.md
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4  # wave-instructions/s: 1024 SIMDs, 4 cycles per FP64 wave-instruction
 # arithmetic minimum of one CTU + HLLC cell update (operation count of the
@@ -66,6 +72,10 @@ def parse():
     ap.add_argument("--cpu-sample-nx", type=int, default=1024)
     ap.add_argument("--developed-steps", type=int, default=250)
     ap.add_argument("--no-developed", action="store_true")
+    ap.add_argument("--scale-check", action="store_true",
+                    help="before timing: compressible Sedov 2048^2, 12 steps, on 1 rank vs the N ranks "
+                         "of this run, must agree bit for bit (SURVEY 8(d).5); the result goes "
+                         "into config.scale_check, a mismatch is fatal")
     ap.add_argument("--host-dt", action="store_true",
                     help="step from the host (one dt read-back per step) instead of "
                          "pyrohip_comp_evolve")
@@ -170,12 +180,14 @@ def developed_tile(ctx, device, n=1024, tmax=0.1):
     return U, frac, pol.n
 
 
-def bench_sedov(args, dist, ctx, device, defaults, steps=None, warmup=None, tile=None):
+def bench_sedov(args, dist, ctx, device, defaults, steps=None, warmup=None, tile=None, nx=None,
+                collect=False):
     """tile = None: the Sedov initial condition at t = 0 (BASELINE config);
-    tile = (n, n, 4) array: that state repeated over the whole grid"""
+    tile = (n, n, 4) array: that state repeated over the whole grid;
+    collect: also return this rank's final slab interior (scale check)"""
     from pyro2_amd.compressible.problems.sedov import sedov_state
     from pyro2_amd.decomp import DtPolicy, NoComm, RcclComm, SlabCompressible, SlabDecomp
-    nx = ny = args.nx
+    nx = ny = args.nx if nx is None else nx
     ng = 4
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
@@ -235,8 +247,47 @@ def bench_sedov(args, dist, ctx, device, defaults, steps=None, warmup=None, tile
     res = {"elapsed": elapsed, "cells": float(nx) * ny, "prof": prof, "event_ms": ev_ms,
            "t": pol.t, "dt": pol.dt_old, "local_cells": float(dec.nx_local) * ny, "steps": steps,
            "dt_policy": "device" if device_dt else "host"}
+    if collect:
+        res["interior"] = st.download()[ng:-ng, ng:-ng].copy()
+        res["rows"] = (dec.i0, dec.nx_local)
     del slab, st
     return res
+
+
+def pmc_counts(fast_math):
+    """VALU instruction / traffic counts of the dominant update kernel from the committed
+    rocprofv3 PMC passes (profiles/traffic.json, tools/gpu_round.sh + tools/make_traffic.py)"""
+    tr = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(tr))[f"fast_math_{fast_math}"]
+    except Exception:
+        return None
+
+
+def fp64_roofline(cells_per_s_kernel, fast_math, dom):
+    """the roof that binds the CTU kernel is the FP64 vector unit, not HBM:
+    arithmetic minimum x cell rate against the FMA peak, and the instruction-issue figure"""
+    out = {
+        "bound": "fp64_valu", "peak": FP64_PEAK_FLOPS / 1e12, "unit": "TFLOP/s",
+        "achieved": SEDOV_MIN_FLOPS_PER_CELL * cells_per_s_kernel / 1e12,
+        "frac": SEDOV_MIN_FLOPS_PER_CELL * cells_per_s_kernel / FP64_PEAK_FLOPS,
+        "flops_per_cell_update": SEDOV_MIN_FLOPS_PER_CELL,
+        "basis": "arithmetic minimum of one CTU + 4 x HLLC cell update (DESIGN.md 3, FMA = 2 "
+                 "flop) x cell rate of the update kernel; the kernel is mostly non-FMA, so "
+                 "the instruction-issue figures below are the tighter statement"}
+    t = pmc_counts(fast_math)
+    if t and t.get("kernel") == dom:
+        ipc = t["valu_insts_per_cell_update"]        # lane-instructions per cell update
+        out["valu_issue"] = {
+            "valu_lane_insts_per_cell_update": ipc,
+            "executed_flops_per_cell_update": t.get("flops_per_cell_update"),
+            "achieved_wave_insts_per_s": ipc / 64.0 * cells_per_s_kernel,
+            "peak_wave_insts_per_s": VALU_ISSUE_PEAK,
+            "frac": ipc / 64.0 * cells_per_s_kernel / VALU_ISSUE_PEAK,
+            "valu_busy_frac_of_kernel_time": t["valu_busy_ms"] / t["kernel_ms"],
+            "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU of the same kernel (counted at 16384^2; "
+                      "per cell update, the strip geometry differs slightly by size), " + t["measured_at"]}
+    return out
 
 
 def sedov_leg(r, defaults, nx, extra=None):
@@ -244,16 +295,80 @@ def sedov_leg(r, defaults, nx, extra=None):
     upd = r["prof"]
     tot_ms = sum(ms for (_, ms) in upd.values()) / r["steps"]
     gbs = SEDOV_BYTES_PER_CELL * r["local_cells"] / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0
+    dom = max(upd, key=lambda k: upd[k][1]) if upd else None
     out = {"value": r["cells"] * r["steps"] / r["elapsed"], "unit": "cell-updates/s",
            "ms_per_step": r["elapsed"] / r["steps"] * 1e3, "steps": r["steps"],
            "timed_seconds": r["elapsed"], "fast_math": defaults["fast_math"],
            "kernel_set": defaults["kernel_set"],
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": gbs / HBM_PEAK_GBS,
-                        "kernels": {k: {"launches": n, "avg_ms": ms / n} for k, (n, ms) in upd.items()}}}
+                        "dominant_kernel": dom,
+                        "kernels": {k: {"launches": n, "avg_ms": ms / n} for k, (n, ms) in upd.items()}},
+           "roofline_fp64": fp64_roofline(r["local_cells"] / (tot_ms * 1e-3) if tot_ms else 0.0,
+                                          defaults["fast_math"], dom)}
     if extra:
         out.update(extra)
     return out
+
+
+class _Solo:
+    """a one-rank stand-in for Dist (scale check: the single-domain run on this rank's GPU)"""
+    world, rank, local_rank, td, comm_kind = 1, 0, 0, None, "rccl"
+
+    def barrier(self):
+        pass
+
+    def max(self, x):
+        return x
+
+
+def scale_check(args, dist, ctx, device, defaults, nx=2048, steps=12):
+    """Sedov nx^2 on the N ranks of this run against the single-domain run
+    (every rank repeats it on its own GPU and compares its slab's rows): bit-identical or
+    fatal.  Both runs use the row-marching kernel (kernel_set 2) and this run's arithmetic."""
+    d = dict(defaults, kernel_set=2)
+    rn = bench_sedov(args, dist, ctx, device, d, steps=steps, warmup=0, nx=nx, collect=True)
+    r1 = bench_sedov(args, _Solo(), ctx, device, d, steps=steps, warmup=0, nx=nx, collect=True)
+    i0, n = rn["rows"]
+    same = bool(np.array_equal(rn["interior"], r1["interior"][i0:i0 + n])) and rn["t"] == r1["t"]
+    bad = dist.max(0.0 if same else 1.0)
+    if bad > 0.0:
+        sys.exit(f"bench.py rank {dist.rank}: FATAL: scale check failed: sedov {nx}^2 x {steps} steps on "
+                 f"{dist.world} ranks differs from the single-domain run (this rank: "
+                 f"{'identical' if same else 'DIFFERENT'})")
+    return {"workload": f"sedov {nx}x{nx}, {steps} steps, {dist.world} ranks vs 1 rank, kernel_set 2, "
+                        f"fast_math {d['fast_math']}", "bit_identical": True, "sim_time": rn["t"]}
+
+
+def sedov_size_leg(args, dist, ctx, device, defaults, nx, steps, warmup=5):
+    """the same workload at another BASELINE size (configs[2] = 4096^2, north_star's target
+    8192^2), both builds, each with the HBM roofline and the FP64 issue figures"""
+    r = bench_sedov(args, dist, ctx, device, defaults, steps=steps, warmup=warmup, nx=nx)
+    leg = sedov_leg(r, defaults, nx, {
+        "workload": f"compressible sedov {nx}x{nx} (inputs.sedov physics), 1 GPU, steps "
+                    f"{warmup}-{warmup + steps} from t = 0"})
+    d2 = dict(defaults, fast_math=1 - defaults["fast_math"])
+    r2 = bench_sedov(args, dist, ctx, device, d2, steps=max(5, steps // 2), warmup=2, nx=nx)
+    leg["other_build"] = sedov_leg(r2, d2, nx)
+    return leg
+
+
+def reference_baseline(section, key):
+    """the REFERENCE ITSELF timed on host cores (oracle/time_reference.py ->
+    profiles/cpu_reference.json; measured in the build container: the GPU box has no copy of
+    the reference) as the cpu_baseline of a leg"""
+    try:
+        ref = json.load(open(os.path.join(ROOT, "profiles", "cpu_reference.json")))
+        r = ref[section][key]
+    except Exception:
+        return None
+    return {"value": r["value"], "unit": r["unit"], "cores": r["cores"], "kind": "reference",
+            "sample": f"{r['workload']}; " +
+                      (f"{r['steps']} steps, {r['seconds_per_step']:.3f} s/step" if "steps" in r else
+                       f"{r['cycles']} V-cycles, {r['seconds_per_vcycle']:.2f} s/V-cycle") +
+                      f"; host {ref['cpu']} ({ref['host_cores']} cores, 1 used: the reference is "
+                      f"single-threaded), {ref['date']}, oracle/time_reference.py -- measured in the "
+                      "build container, not on the GPU box"}
 
 
 def bench_advection(ctx, device, nx=2048, steps=100, warmup=10):
@@ -283,9 +398,7 @@ def bench_advection(ctx, device, nx=2048, steps=100, warmup=10):
     prof = ctx.prof_report()
     ctx.prof_enable(False)
     n, ms = prof["k_adv_step"]
-    # (event-to-event time of the instrumented pass; a launch cannot last longer than a step
-    # of the uninstrumented pass, which bounds it when the events' own cost shows)
-    kern_s = min(ms / n * 1e-3, (t1 - t0) / steps)
+    kern_s = ms / n * 1e-3     # HIP-event duration of the launch (instrumented pass)
     traffic = also_traffic("adv_summary", "bytes_per_step") if nx == 2048 else None
     return {"workload": f"advection smooth {nx}x{nx} periodic, limiter 2",
             "value": nx * nx * steps / (t1 - t0), "unit": "cell-updates/s",
@@ -296,7 +409,8 @@ def bench_advection(ctx, device, nx=2048, steps=100, warmup=10):
                          "frac": ADV_BYTES_PER_CELL * nx * nx / kern_s / 1e9 / HBM_PEAK_GBS,
                          "kernel_avg_ms": ms / n, "traffic": traffic,
                          "step_frac": ADV_BYTES_PER_CELL * nx * nx * steps / (t1 - t0) / 1e9 / HBM_PEAK_GBS,
-                         "launches_per_step": 1}}
+                         "launches_per_step": 1},
+            "cpu_baseline": reference_baseline("advection", str(nx))}
 
 
 def _mg_vcycles(ctx, device, nx, cycles):
@@ -332,10 +446,11 @@ def bench_mg(ctx, device, nx=4096, cycles=10, small_sizes=True):
             small[str(n2)] = d2 / 20 * 1e6
     model_gbs = MG_BYTES_PER_CELL_VCYCLE * nx * nx * vps / 1e9
     traffic = also_traffic("mg_summary", "bytes_per_vcycle") if nx == 4096 else None
-    # the roofline entry is priced with the bytes the V-cycle really moves (PMC, committed
-    # under profiles/): the 720 B model of SURVEY 8(d) counts one pass per smoothing
-    # iteration, the temporally blocked smoothers move a level once per 5 iterations
-    gbs = traffic * vps / 1e9 if traffic else model_gbs
+    # the roofline entry is priced with the ALGORITHMIC floor of a temporally blocked V-cycle
+    # (two visits per level, 52 B per level cell, x 4/3: MG_FLOOR_BYTES_PER_CELL_VCYCLE); the
+    # measured fabric bytes (PMC, committed under profiles/) ride along as `traffic`, the
+    # 720 B one-pass-per-iteration model of SURVEY 8(d) as `model_equivalent_gbs`
+    gbs = MG_FLOOR_BYTES_PER_CELL_VCYCLE * nx * nx * vps / 1e9
     return {"workload": f"multigrid constant-coeff Poisson {nx}x{nx} dirichlet, "
                         f"{cycles} V-cycles (nsmooth 10, bottom 50)",
             "value": vps, "unit": "V-cycles/s", "ms_per_vcycle": (t1 - t0) / cycles * 1e3,
@@ -343,12 +458,16 @@ def bench_mg(ctx, device, nx=4096, cycles=10, small_sizes=True):
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "model_equivalent_gbs": model_gbs,
-                         "basis": ("measured fabric bytes per V-cycle (traffic; profiles/*_also_traffic.json, "
-                                   "rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE over every multigrid kernel) x "
-                                   "V-cycles/s" if traffic else
-                                   "720 B per finest cell per V-cycle (SURVEY 8(d) model) x V-cycles/s: an "
-                                   "algorithmic-equivalent rate, no measured traffic for this size") +
-                                  "; model_equivalent_gbs = the 720 B model x V-cycles/s"}}
+                         "traffic_gbs": traffic * vps / 1e9 if traffic else None,
+                         "algorithmic_bytes_per_vcycle": MG_FLOOR_BYTES_PER_CELL_VCYCLE * nx * nx,
+                         "basis": "floor of a temporally blocked V-cycle: every level is visited twice, "
+                                  "down-leg read v, f + write v + restricted residual, up-leg read v, f + "
+                                  "coarse correction + write v = 52 B per level cell, x 4/3 for the pyramid = "
+                                  "69.3 B per finest cell per V-cycle, x V-cycles/s; traffic = measured fabric "
+                                  "bytes per V-cycle (profiles/*_also_traffic.json, rocprofv3 --pmc FETCH_SIZE "
+                                  "x 2 + WRITE_SIZE over every multigrid kernel); model_equivalent_gbs = the "
+                                  "720 B one-pass-per-iteration model of SURVEY 8(d) x V-cycles/s"},
+            "cpu_baseline": reference_baseline("multigrid", str(nx))}
 
 
 def bench_incompressible(ctx, device, nx=2048, steps=5):
@@ -479,13 +598,14 @@ def main():
     # the launcher on a smaller box and is flagged in the output
     ctx = device.Context(dist.local_rank % ndev)
     dist.comm_kind, dist.comm_note = "rccl", None
+    want_comm = os.environ.get("PYRO_BENCH_COMM", "rccl")
     if world > 1:
-        # data path: RCCL inside libpyrohip.  If the communicator cannot be
-        # created on every rank the run continues with host-staged halos over
-        # gloo and says so in the JSON line ("halo") -- a diagnosable number
-        # instead of a crash; it is not the product path.
+        # data path: RCCL inside libpyrohip.  A communicator that cannot be created on
+        # every rank is FATAL: a host-staged (PCIe-bound) number must never pass for a
+        # scaling result.  PYRO_BENCH_COMM=host asks for the host-staged path on purpose
+        # (debugging the launcher; flagged in config.halo).
         err = None
-        if os.environ.get("PYRO_BENCH_COMM", "rccl") == "rccl":
+        if want_comm == "rccl":
             try:
                 uid = device.Context.comm_unique_id() if dist.rank == 0 else b""
                 uid = dist.bcast_bytes(uid, 128)
@@ -493,13 +613,20 @@ def main():
                 assert ctx.allreduce_min(float(dist.rank + 1)) == 1.0
             except Exception as e:    # noqa: BLE001
                 err = f"{type(e).__name__}: {e}"
+            else:
+                dist.rccl_ranks = ctx.comm_size()
         else:
-            err = "PYRO_BENCH_COMM != rccl"
+            err = "PYRO_BENCH_COMM=%s: host-staged halos requested" % want_comm
         if dist.max(1.0 if err else 0.0) > 0.0:
+            note = err or "RCCL initialisation failed on another rank"
+            if want_comm == "rccl":
+                sys.exit(f"bench.py rank {dist.rank}: FATAL: RCCL communicator over {world} ranks could "
+                         f"not be created ({note}).  No number is printed: a host-staged run is not a "
+                         "scaling result (PYRO_BENCH_COMM=host runs that path on purpose).")
             dist.comm_kind = "host-staged"
-            dist.comm_note = err or "RCCL initialisation failed on another rank"
-            print(f"[bench rank {dist.rank}] WARNING: RCCL unavailable ({dist.comm_note}); "
-                  "halo exchange staged through the host over gloo", file=sys.stderr)
+            dist.comm_note = note
+            print(f"[bench rank {dist.rank}] WARNING: {note}; halo exchange staged through the "
+                  "host over gloo (NOT a scaling result)", file=sys.stderr)
     # default: the contracted / reciprocal-division build, parity-tested to the
     # north_star tolerance (1e-10); --fast-math 0 times the bit-faithful build.
     # kernel_set -1: the library picks (row-marching wavefront kernel from 2048^2 on)
@@ -512,6 +639,7 @@ def main():
     except Exception:
         pass
 
+    check = scale_check(args, dist, ctx, device, defaults) if (args.scale_check and world > 1) else None
     r = bench_sedov(args, dist, ctx, device, defaults)
     value = r["cells"] * args.steps / r["elapsed"]
     out = {
@@ -526,7 +654,9 @@ def main():
                                + ("RCCL halo exchange" if dist.comm_kind == "rccl"
                                   else "HOST-STAGED halo exchange (RCCL init failed)"),
                    "parallelism": f"slab{world}",
-                   "halo": dist.comm_kind if world > 1 else "none", "fast_math": defaults["fast_math"],
+                   "halo": dist.comm_kind if world > 1 else "none",
+                   "rccl_ranks": getattr(dist, "rccl_ranks", None) if world > 1 else None,
+                   "fast_math": defaults["fast_math"],
                    "kernel_set": defaults["kernel_set"], "sim_time": r["t"],
                    "dt_policy": r["dt_policy"] + (" (pyrohip_comp_evolve: no host round trip per step)"
                                                   if r["dt_policy"] == "device" else ""),
@@ -535,6 +665,8 @@ def main():
     }
     if dist.comm_note:
         out["config"]["halo_note"] = dist.comm_note
+    if check:
+        out["config"]["scale_check"] = check
     if dist.oversubscribed:
         out["config"]["oversubscribed"] = "several ranks share one GPU (debug run, not a result)"
     if dist.rank == 0:
@@ -555,37 +687,13 @@ def main():
             "kernels": {k: {"launches": n, "avg_ms": ms / n} for k, (n, ms) in upd.items()},
             "stream_event_ms_per_step": r["event_ms"] / args.steps,
         }
-        # the roof that binds this kernel is the FP64 vector unit, not HBM
-        # (DESIGN.md 3): arithmetic minimum x cell rate against the FMA peak
-        out["roofline_fp64"] = {
-            "bound": "fp64_valu", "peak": FP64_PEAK_FLOPS / 1e12, "unit": "TFLOP/s",
-            "achieved": SEDOV_MIN_FLOPS_PER_CELL * cells_per_s_kernel / 1e12,
-            "frac": SEDOV_MIN_FLOPS_PER_CELL * cells_per_s_kernel / FP64_PEAK_FLOPS,
-            "flops_per_cell_update": SEDOV_MIN_FLOPS_PER_CELL,
-            "basis": "arithmetic minimum of one CTU + 4 x HLLC cell update (DESIGN.md 3, FMA = 2 "
-                     "flop) x cell rate of the update kernel; the kernel is mostly non-FMA, so "
-                     "the instruction-issue figures below are the tighter statement"}
-        # traffic + VALU instruction counts: from the committed rocprofv3 PMC
-        # passes of this same default command (profiles/traffic.json, written by
-        # tools/gpu_round.sh + tools/make_traffic.py), scaled to this rank's cells
-        tr = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tr):
-            try:
-                t = json.load(open(tr))[f"fast_math_{defaults['fast_math']}"]
-                if t.get("kernel") == dom:
-                    out["roofline"]["traffic"] = t["bytes_per_cell_update"] * r["local_cells"]
-                    out["roofline"]["traffic_source"] = "profiles/traffic.json: " + t["measured_at"]
-                    ipc = t["valu_insts_per_cell_update"]        # lane-instructions per cell update
-                    out["roofline_fp64"]["valu_issue"] = {
-                        "valu_lane_insts_per_cell_update": ipc,
-                        "executed_flops_per_cell_update": t.get("flops_per_cell_update"),
-                        "achieved_wave_insts_per_s": ipc / 64.0 * cells_per_s_kernel,
-                        "peak_wave_insts_per_s": VALU_ISSUE_PEAK,
-                        "frac": ipc / 64.0 * cells_per_s_kernel / VALU_ISSUE_PEAK,
-                        "valu_busy_frac_of_kernel_time": t["valu_busy_ms"] / t["kernel_ms"],
-                        "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU of the same kernel, " + t["measured_at"]}
-            except Exception:
-                pass
+        out["roofline_fp64"] = fp64_roofline(cells_per_s_kernel, defaults["fast_math"], dom)
+        # traffic: from the committed rocprofv3 PMC passes of this same default command
+        # (profiles/traffic.json), scaled to this rank's cells
+        t = pmc_counts(defaults["fast_math"])
+        if t and t.get("kernel") == dom:
+            out["roofline"]["traffic"] = t["bytes_per_cell_update"] * r["local_cells"]
+            out["roofline"]["traffic_source"] = "profiles/traffic.json: " + t["measured_at"]
         if world == 1:
             also = {}
             if not args.no_also:
@@ -608,6 +716,10 @@ def main():
                 also["sedov_developed_exact" if d2["fast_math"] == 0 else "sedov_developed_fast"] = \
                     sedov_leg(rd2, d2, args.nx, info)
                 del tile
+            if not args.no_also and args.nx == 16384:
+                # BASELINE configs[2] and north_star's target size, both builds
+                also["sedov_4096"] = sedov_size_leg(args, dist, ctx, device, defaults, 4096, 100)
+                also["sedov_8192"] = sedov_size_leg(args, dist, ctx, device, defaults, 8192, 40)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_sedov(args.cpu_sample_nx)
             if not args.no_also:

@@ -466,6 +466,9 @@ int pyrohip_comm_unique_id(char *out_id /* PYROHIP_UNIQUE_ID_BYTES */);
 int pyrohip_comm_init(pyrohip_ctx *ctx, int nranks, int rank,
                       const char *unique_id);
 int pyrohip_comm_destroy(pyrohip_ctx *ctx);
+/* number of ranks RCCL itself reports for the context's communicator
+   (ncclCommCount; 0 without a communicator) -- bench.py prints it */
+int pyrohip_comm_size(pyrohip_ctx *ctx, int *nranks);
 /* on: pyrohip_comp_step all-reduces (min) the CFL minimum of the new state
    over the communicator on the device, inside the step -- every rank must then
    call comp_step in lock step.  pyrohip_comp_dt_is_global tells whether the next

@@ -17,6 +17,8 @@ boundaries in ambient gas -- computes exactly what it would compute on the full
 grid (which needs 40 min and 60 GB).  tests/golden/comp_sedov_16384_window.npz:
 
     python oracle/gen_fullsize.py --window16384      # ~15 s
+    python oracle/gen_fullsize.py --window8192       # the north_star target size, same way
+    python oracle/gen_fullsize.py --developed1024    # developed flow (t = 0.1), ~15 min
 """
 import os
 import sys
@@ -48,8 +50,8 @@ def main():
     print("wrote", out, os.path.getsize(out) // 1024, "KiB")
 
 
-def window16384():
-    NXF, W, NST = 16384, 1024, 25
+def window(NXF=16384):
+    W, NST = 1024, 25
     lo = (NXF - W) // 2                      # first full-grid interior index of the window
     x0, x1 = lo / NXF, (lo + W) / NXF
     ic, meta, bcs = sedov_ic(W, xmin=x0, xmax=x1, ymin=x0, ymax=x1)
@@ -68,7 +70,7 @@ def window16384():
     print("disturbed half-width: %.1f cells of %d" % (r, W // 2))
     assert r < W // 2 - 32, "the disturbance reaches the window boundary"
     step = W // 64
-    out = os.path.join(ROOT, "tests", "golden", "comp_sedov_16384_window.npz")
+    out = os.path.join(ROOT, "tests", "golden", "comp_sedov_%d_window.npz" % NXF)
     np.savez_compressed(out, samples=I[::step, ::step].copy(), row_sums=I.sum(axis=1),
                         col_sums=I.sum(axis=0), dts=dts, t=np.array(t), nsteps=np.array(NST),
                         umax=np.abs(I).max(axis=(0, 1)), lo=np.array(lo), width=np.array(W),
@@ -77,8 +79,34 @@ def window16384():
     print("wrote", out, os.path.getsize(out) // 1024, "KiB")
 
 
+def developed1024():
+    """the DEVELOPED-flow state the bench's `also.sedov_developed` leg tiles over its grid:
+    Sedov (inputs.sedov physics) 1024^2 run to t = 0.1 (the blast has grown to r ~ 0.3).
+    ~2300 oracle steps, ~15 min on one core.  Kept: the dt sequence, a 64 x 64 lattice,
+    row / column sums, a dense 16 x 512 patch from the centre across the shock
+    (tests/golden/comp_sedov_1024_developed.npz)."""
+    NX = 1024
+    ic, meta, bcs = sedov_ic(NX)
+    t0 = time.time()
+    U, dts, t = oracle_comp_run(ic, meta, bcs, 0.1, 100000)
+    print("oracle developed", NX, len(dts), "steps to t =", t, ":", time.time() - t0, "s")
+    I = U[4:-4, 4:-4]
+    step = NX // 64
+    out = os.path.join(ROOT, "tests", "golden", "comp_sedov_1024_developed.npz")
+    np.savez_compressed(out, samples=I[::step, ::step].copy(), row_sums=I.sum(axis=1),
+                        col_sums=I.sum(axis=0), dts=dts, t=np.array(t), nsteps=np.array(len(dts)),
+                        umax=np.abs(I).max(axis=(0, 1)),
+                        shocked=np.array(float((np.abs(I[..., 0] - 1.0) > 1e-8).mean())),
+                        patch=I[NX // 2 - 8:NX // 2 + 8, NX // 2:].copy())
+    print("wrote", out, os.path.getsize(out) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     if "--window16384" in sys.argv:
-        window16384()
+        window(16384)
+    elif "--window8192" in sys.argv:
+        window(8192)
+    elif "--developed1024" in sys.argv:
+        developed1024()
     else:
         main()

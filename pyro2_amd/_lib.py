@@ -165,6 +165,7 @@ _PROTOS = {
     "pyrohip_comm_unique_id": [C.c_char_p],
     "pyrohip_comm_init": [_VP, C.c_int, C.c_int, C.c_char_p],
     "pyrohip_comm_destroy": [_VP],
+    "pyrohip_comm_size": [_VP, C.POINTER(C.c_int)],
     "pyrohip_halo_exchange": [_VP, C.c_int, C.c_int],
     "pyrohip_state_set_neighbours": [_VP, C.c_int, C.c_int],
     "pyrohip_state_halo_pending": [_VP, _IP],

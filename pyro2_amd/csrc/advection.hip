@@ -90,7 +90,7 @@ __device__ __forceinline__ double adv_slope(double l2m, double l20, double l2p, 
     const double dc = (2. / 3.) * (ap1 - am1 - 0.25 * (l2p + l2m));
     const double dl = ap1 - a0;
     const double dr = a0 - am1;
-    return mc_select(dc, dl, dr);
+    return mc_select_l4(dc, dl, dr);
 }
 
 // LIM: limiter (0 none, 1 MC2, 2 MC4); UNEG / VNEG: u < 0 / v < 0 (upwind side)

@@ -65,6 +65,22 @@ int pyrohip_comm_init(pyrohip_ctx *c, int nranks, int rank, const char *unique_i
         if (comm2) ncclCommDestroy(comm2);
         c->comm_halo = nullptr;
     }
+    // every rank must take the same path through the exchange protocol: the halo
+    // communicator is used only if ALL ranks have it
+    double have = c->comm_halo ? 1.0 : 0.0;
+    PYRO_TRY(pyrohip_allreduce_min(c, &have));
+    if (have < 1.0 && c->comm_halo) {
+        ncclCommDestroy((ncclComm_t)c->comm_halo);
+        c->comm_halo = nullptr;
+    }
+    return 0;
+}
+
+int pyrohip_comm_size(pyrohip_ctx *c, int *nranks)
+{
+    PYRO_REQUIRE(c && nranks, "NULL argument");
+    *nranks = 0;
+    if (c->comm) PYRO_CHECK_NCCL(ncclCommCount((ncclComm_t)c->comm, nranks));
     return 0;
 }
 
@@ -124,12 +140,17 @@ int pyrohip_halo_exchange(pyrohip_state *s, int rank_lo, int rank_hi)
     PYRO_REQUIRE(s->g.nx >= s->g.ng, "slab thinner than the ghost width");
     if (s->halo_pending) {
         // the step that produced this state posted the exchange already (beside
-        // its interior strips): the main stream only has to wait for it.  Any
-        // write to the state since then dropped the cached CFL minimum -- then
-        // the rows on the wire are stale and the exchange is done again.
+        // its interior strips): the main stream only has to wait for it.
         s->halo_pending = false;
         PYRO_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
-        if (s->next_cfl_min > 0.0 && rank_lo == s->nb_lo && rank_hi == s->nb_hi) return 0;
+        // Any write to the state since then dropped the cached CFL minimum: the rows the
+        // neighbours hold are stale.  Exchanging again would need the neighbours to take
+        // part, and they cannot know (this is per-rank state): refuse instead of hanging.
+        PYRO_REQUIRE(s->next_cfl_min > 0.0 && rank_lo == s->nb_lo && rank_hi == s->nb_hi,
+                     "the state was written (or other neighbours named) while the halo exchange "
+                     "its last step posted was pending: call pyrohip_state_set_neighbours(s, -1, -1) "
+                     "before modifying a slab between steps");
+        return 0;
     }
     return post_halo(s, s->d, rank_lo, rank_hi, (ncclComm_t)c->comm, c->stream);
 }
@@ -147,6 +168,11 @@ int pyrohip_state_set_neighbours(pyrohip_state *s, int rank_lo, int rank_hi)
     // (no upper bound: without a communicator -- halos staged through the host --
     // the neighbours only select the launch order, see comp_step_wave)
     PYRO_REQUIRE(rank_lo >= -1 && rank_hi >= -1, "neighbour rank out of range");
+    if (s->halo_pending && (rank_lo != s->nb_lo || rank_hi != s->nb_hi)) {
+        // a posted exchange still belongs to the old neighbours: let it land, then forget it
+        PYRO_TRY(comm_wait_halo(s));
+        s->halo_pending = false;
+    }
     s->nb_lo = rank_lo; s->nb_hi = rank_hi;
     s->nb_set = (rank_lo >= 0 || rank_hi >= 0);
     return 0;
@@ -266,6 +292,14 @@ int comm_post_halo(pyrohip_state *s, double *d)
     PYRO_CHECK_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
     PYRO_TRY(post_halo(s, d, s->nb_lo, s->nb_hi, (ncclComm_t)c->comm_halo, c->comm_stream));
     PYRO_CHECK_HIP(hipEventRecord(c->ev_halo, c->comm_stream));
+    return 0;
+}
+
+int comm_wait_halo(pyrohip_state *s)
+{
+    pyrohip_ctx *c = s->ctx;
+    if (s->halo_pending && c->ev_halo)
+        PYRO_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
     return 0;
 }
 

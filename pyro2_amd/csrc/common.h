@@ -127,6 +127,10 @@ bool comm_can_overlap(const pyrohip_state *s);
 // the state's) with the state's neighbours on the halo stream: it starts when
 // everything queued on the context's stream so far is done and signals ev_halo
 int comm_post_halo(pyrohip_state *s, double *d);
+// a posted halo exchange writes the state's ghost rows from the halo stream: whoever
+// reads or writes the state's memory on the context's stream (accessors, ghost fill,
+// destroy) orders that stream behind it first.  No-op when nothing is pending.
+int comm_wait_halo(pyrohip_state *s);
 // plain ghost fill (x sides, then y sides) of cnt planes laid out like the
 // state's planes n0.. with the boundary types of those variables (ctx.hip)
 int fill_bc_planes(pyrohip_state *s, double *planes, int n0, int cnt);

@@ -212,6 +212,9 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
                        s->pend_n, const_cast<double *>(dmin));
     s->pend_part = nullptr;
     PYRO_CHECK_HIP(hipGetLastError());
+    // the last step's halo exchange (posted on the halo stream) must have landed before
+    // the call returns: the buffers may be read, written or freed by the caller next
+    PYRO_TRY(comm_wait_halo(s));
     // the one round trip of the call: scalars, flag, last CFL minimum, the dt sequence
     char *hb = (char *)c->reduce_host;                       // 256 pinned bytes
     static_assert(sizeof(StepScalars) + 16 <= 256, "pinned scratch");

@@ -441,7 +441,7 @@ int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP 
     P.have_src = (p->grav != 0.0 || s->heat != nullptr);
     P.solid_xl = p->solid_xl; P.solid_yl = p->solid_yl;
     P.ntj = P.ntiles = 0;
-    P.L = P.ncb = 0;
+    P.L = P.ncb = P.nsb = 0;
     P.sb_first = 0; P.sb_step = 1;
     P.mr = bc_map(g.ilo, g.ihi, g.ng, 0, 0, false);      // identity (tile kernel: fused_fill_maps)
     P.mc = P.mr;
@@ -566,10 +566,17 @@ int comp_step_fused_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt
         PYRO_LAUNCH(c, "k_ctu_fused", kern, dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES,
                     (const double *)Uin, Uout, g, P, s->d_flag, part, S);
     }
+    // slab of a decomposed run with the halo communicator: the new boundary rows go out
+    // on the halo stream right after the kernel (which wrote the ghost frame itself) --
+    // the same protocol as the row-marching kernel's, whatever kernel a rank picked
+    const bool post = s->nb_set && comm_can_overlap(s);
+    if (post) PYRO_TRY(comm_post_halo(s, Uout));
     const double *dmin;
     PYRO_TRY(fused_tail(s, part, P.ntiles, true, &dmin, S != nullptr));   // the kernel wrote the ghost frame
-    if (S) { fused_swap(s); *dmin_out = dmin; return 0; }
-    return fused_sync(s, dmin);
+    if (S) { fused_swap(s); *dmin_out = dmin; s->halo_pending = post; return 0; }
+    const int rc = fused_sync(s, dmin);
+    s->halo_pending = post && rc == 0;
+    return rc;
 }
 
 int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)

@@ -157,7 +157,9 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     double *st = lds + l;
     const int cb = blockIdx.x % P.ncb, sb = P.sb_first + (blockIdx.x / P.ncb) * P.sb_step;
     const int i0 = g.ilo + sb * P.L;                       // strip rows [i0, i1)
-    const int i1 = (i0 + P.L < g.ihi + 1) ? i0 + P.L : g.ihi + 1;
+    // (the last strip runs to the end of the grid: it may be up to ng - 1 rows longer
+    // than L, so that no strip is shorter than the ghost width -- comp_step_wave_ex)
+    const int i1 = (sb == P.nsb - 1) ? g.ihi + 1 : i0 + P.L;
     const int j = g.jlo + cb * WOUT - 4 + l;               // this lane's column
     const int jc = (j < g.qy) ? j : g.qy - 1;              // ragged last strip: clamp, unused
     const bool jin = (j >= g.jlo && j <= g.jhi);
@@ -492,8 +494,16 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         const int r = atoi(e);
         if (r > 0) P.L = r < g.nx ? r : g.nx;
     }
-    const int nsb = (g.nx + P.L - 1) / P.L;
+    int nsb = (g.nx + P.L - 1) / P.L;
+    // a last strip shorter than the ghost width joins its predecessor: the boundary
+    // strips of a slab must hold the ng rows the neighbour receives as its halo
+    if (nsb > 1 && g.nx - (nsb - 1) * P.L < g.ng) nsb--;
+    P.nsb = nsb;
     const int nwg = P.ncb * nsb;
+    // slab of a decomposed run with the halo communicator: EVERY step posts the
+    // exchange of its new boundary rows (overlapped when the strips allow it), so the
+    // protocol does not depend on this rank's geometry
+    const bool post = s->nb_set && comm_can_overlap(s);
     PYRO_TRY(c->reduce.ensure((nwg + kMinStageBlocks + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
     using KernelT = void (*)(const double *, double *, Geom, FP, int *, double *,
@@ -504,7 +514,7 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         {k_ctu_wave<2, false>, k_ctu_wave<2, true>}};
     const int solver = (p->riemann == 1 || p->riemann == 2) ? p->riemann : 0;
     const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
-    if (s->nb_set && nsb >= 3 && comm_can_overlap(s)) {
+    if (post && nsb >= 3 && P.L >= g.ng) {
         // slab of a decomposed run: the first and the last strip of
         // rows -- the rows the neighbours need as their next halo -- go first; their
         // exchange is posted on the halo stream and runs beside the interior strips
@@ -526,10 +536,16 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
     }
     PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(nwg), dim3(64), WLDS_BYTES,
                 (const double *)Uin, Uout, g, P, s->d_flag, part, S);
+    if (post) {        // too few strips to overlap: the exchange follows the whole update
+        fused_copy_frame(s);
+        PYRO_TRY(comm_post_halo(s, Uout));
+    }
     const double *dmin;
-    PYRO_TRY(fused_tail(s, part, nwg, false, &dmin));
-    if (S) { fused_swap(s); *dmin_out = dmin; return 0; }
-    return fused_sync(s, dmin);
+    PYRO_TRY(fused_tail(s, part, nwg, post, &dmin));
+    if (S) { fused_swap(s); *dmin_out = dmin; s->halo_pending = post; return 0; }
+    const int rc = fused_sync(s, dmin);
+    s->halo_pending = post && rc == 0;
+    return rc;
 }
 
 int comp_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, double dt)

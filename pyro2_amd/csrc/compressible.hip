@@ -576,6 +576,7 @@ int comp_step_staged(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     int flag = *(int *)((char *)c->reduce_host + 8);
     if (flag & 1) {
         s->next_cfl_min = -1.0;
+        s->ext_pending = 0;       // no predictor state to correct: the step did not happen
         set_error("invalid state: min(rho) <= 0 or min(e) <= 0 on the interior "
                   "(compressible/simulation.py:68-71)");
         return PYROHIP_ERR_STATE;

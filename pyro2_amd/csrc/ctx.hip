@@ -471,7 +471,10 @@ int pyrohip_state_destroy(pyrohip_state *s)
 {
     if (!s) return 0;
     (void)hipSetDevice(s->ctx->device);
+    (void)comm_wait_halo(s);          // a receive may still be writing the ghost rows
     (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->d_scal) (void)hipFree(s->d_scal);
+    if (s->d_dts) (void)hipFree(s->d_dts);
     if (s->base) (void)hipFree(s->base);
     if (s->alt_base) (void)hipFree(s->alt_base);
     if (s->d_bc) (void)hipFree(s->d_bc);
@@ -501,6 +504,7 @@ int pyrohip_state_upload_rows(pyrohip_state *s, int i0, int ni, const double *ho
     PYRO_REQUIRE(i0 >= 0 && ni >= 0 && i0 + ni <= s->g.qx, "row range out of bounds");
     pyrohip_ctx *c = s->ctx;
     PYRO_CHECK_HIP(hipSetDevice(c->device));
+    PYRO_TRY(comm_wait_halo(s));
     const Geom &g = s->g;
     const int chunk = rows_per_chunk(s);
     const size_t row = (size_t)g.qy * s->nvar;
@@ -527,6 +531,7 @@ int pyrohip_state_download_rows(pyrohip_state *s, int i0, int ni, double *host)
     PYRO_REQUIRE(i0 >= 0 && ni >= 0 && i0 + ni <= s->g.qx, "row range out of bounds");
     pyrohip_ctx *c = s->ctx;
     PYRO_CHECK_HIP(hipSetDevice(c->device));
+    PYRO_TRY(comm_wait_halo(s));
     const Geom &g = s->g;
     const int chunk = rows_per_chunk(s);
     const size_t row = (size_t)g.qy * s->nvar;
@@ -564,6 +569,7 @@ int pyrohip_state_upload_var(pyrohip_state *s, int n, const double *host)
     PYRO_REQUIRE(n >= 0 && n < s->nvar, "variable index out of range");
     pyrohip_ctx *c = s->ctx;
     PYRO_CHECK_HIP(hipSetDevice(c->device));
+    PYRO_TRY(comm_wait_halo(s));
     const Geom &g = s->g;
     PYRO_CHECK_HIP(hipMemcpy2DAsync(s->d + (size_t)n * g.plane, g.pitch * sizeof(double), host,
                                     g.qy * sizeof(double), g.qy * sizeof(double), g.qx,
@@ -579,6 +585,7 @@ int pyrohip_state_download_var(pyrohip_state *s, int n, double *host)
     PYRO_REQUIRE(n >= 0 && n < s->nvar, "variable index out of range");
     pyrohip_ctx *c = s->ctx;
     PYRO_CHECK_HIP(hipSetDevice(c->device));
+    PYRO_TRY(comm_wait_halo(s));
     const Geom &g = s->g;
     PYRO_CHECK_HIP(hipMemcpy2DAsync(host, g.qy * sizeof(double), s->d + (size_t)n * g.plane,
                                     g.pitch * sizeof(double), g.qy * sizeof(double), g.qx,
@@ -709,6 +716,7 @@ int pyrohip_fill_bc(pyrohip_state *s, int n)
 {
     PYRO_REQUIRE(s, "NULL state");
     PYRO_REQUIRE(n >= -1 && n < s->nvar, "variable index out of range");
+    PYRO_TRY(comm_wait_halo(s));
     if (s->ramp_bc) {
         PYRO_REQUIRE(s->ramp_set, "ramp boundary: call pyrohip_state_set_ramp_bc first");
         if (!s->user_bc) return fill_bc_range(s, n < 0 ? 0 : n, n < 0 ? s->nvar : 1);

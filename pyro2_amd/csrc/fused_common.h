@@ -21,7 +21,7 @@ struct FP {   // kernel parameters
     double heat_rate;         // S[E] += rho * heat_rate * heat[i,j] (ghost-filled plane)
     const double *heat;
     int solid_xl, solid_yl;   // CGF wall rule (riemann.py:274-286)
-    int L, ncb;               // row-marching kernel: rows per strip, column blocks
+    int L, ncb, nsb;          // row-marching kernel: rows per strip, column blocks, strips
     int sb_first, sb_step;    // ... strip of workgroup b: sb_first + (b / ncb) * sb_step
     // tile kernel: the ghost fill folded into the loads (pyrohip_comp_params.fuse_fill):
     // row / column maps of the boundary rules (identity without) and, per variable and
@@ -75,7 +75,7 @@ __device__ __forceinline__ double slope_shared(double l2m, double l20, double l2
     const double dc = (2. / 3.) * (ap1 - am1 - 0.25 * (l2p + l2m));
     const double dl = ap1 - a0;
     const double dr = a0 - am1;
-    return mc_select(dc, dl, dr);
+    return mc_select_l4(dc, dl, dr);
 }
 
 // cons_to_prim (hydro.h) without the branch on rho != 0: same operations on

@@ -12,6 +12,16 @@
 #endif
 
 namespace pyro {
+// The functions below differ between the bit-faithful and the fast build of a unit.  They
+// are inline functions of namespace pyro in BOTH, so in a host build (the emulator of
+// tests/emu links comp_exact.o and comp_fast.o into one library) the linker would keep ONE
+// copy of every function that was not inlined and both builds would run it.  The inline
+// namespace gives the two families distinct symbol names; callers do not see it.
+#if PYRO_FAST
+inline namespace hydro_fast {
+#else
+inline namespace hydro_exact {
+#endif
 
 // Division policy.  Bit-faithful build: IEEE division, exactly as written in
 // the reference.  fast_math build: v_rcp_f64 (~2^-23 relative) + ONE Newton
@@ -86,6 +96,12 @@ __device__ __forceinline__ double psqrt0(double x) { return psqrt(x); }
 __device__ __forceinline__ double psqrt0(double x) { return sqrt(x); }
 __device__ __forceinline__ double psqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ double psqrt_nc(double x) { return sqrt(x); }
+__device__ __forceinline__ double psqrt_r(double x, double &rinv)
+{
+    const double g = sqrt(x);
+    rinv = 1.0 / g;
+    return g;
+}
 __device__ __forceinline__ double prcp(double b) { return 1.0 / b; }
 __device__ __forceinline__ double pdiv(double a, double b) { return a / b; }
 __device__ __forceinline__ double pdivr(double a, double b, double rb) { (void)rb; return a / b; }
@@ -198,6 +214,52 @@ __device__ __forceinline__ double flatten_1d(double pm2, double pm1, double pp1,
 // face (q_l[face+]) with the same (rho, un, ut, p) convention.
 struct Trace { double r, un, ut, p; };
 
+#if PYRO_FAST
+// fast build: the same tracing with the characteristic projections written out.  With
+// e0 = un - cs, e1 = e2 = un, e3 = un + cs the factors (e3 - e_m) (sign(e_m) + 1) and
+// (e0 - e_m) (1 - sign(e_m)) of interface.py:193-201 are 0 or a multiple of cs:
+//   beta_l[0] = [e0 >= 0] dtdx cs (l_0 . dq)      beta_r[3] = -[e3 < 0] dtdx cs (l_3 . dq)
+//   beta_l[1,2] = [un >= 0] (dtdx/2) cs (l_1,2 . dq)   beta_r[1,2] = -[un < 0] (dtdx/2) cs (l_1,2 . dq)
+// ([.] by the SIGN BIT, as np.copysign does: -0.0 counts as negative).  beta_l[0] and
+// beta_r[3] vanish wherever the flow is subsonic in this direction and are evaluated
+// lazily; l_1 . dq = dr - dp / cs^2, l_2 . dq = dut.  Differs from the reference's
+// evaluation order by rounding only (tolerance-tested, north_star 1e-10).
+__device__ __forceinline__ void trace_states(double r, double un, double ut, double p,
+                                             double dr, double dun, double dut, double dp,
+                                             double gamma, double dtdx, Trace &lo, Trace &hi)
+{
+    const double rr = prcp(r);
+    double rcs;
+    const double cs = psqrt_r(gamma * p * rr, rcs);      // interface.py:122
+    const double hh = 0.5 * dtdx;
+    const double e0 = un - cs, e3 = un + cs;
+    // reference states, :174-191
+    const double fl = fma(-hh, fmax(e3, 0.0), 0.5);
+    const double fr = fma(hh, fmin(e0, 0.0), 0.5);
+    hi.r = fma(fl, dr, r);    hi.un = fma(fl, dun, un);
+    hi.ut = fma(fl, dut, ut); hi.p = fma(fl, dp, p);
+    lo.r = fma(-fr, dr, r);   lo.un = fma(-fr, dun, un);
+    lo.ut = fma(-fr, dut, ut); lo.p = fma(-fr, dp, p);
+    // the two waves that move with the fluid
+    const double w = hh * cs;
+    const double a1 = fma(-(rcs * rcs), dp, dr);
+    const bool pos = !__builtin_signbit(un);
+    const double gp = pos ? w : 0.0, gm = w - gp;
+    hi.r = fma(gp, a1, hi.r);   hi.ut = fma(gp, dut, hi.ut);
+    lo.r = fma(-gm, a1, lo.r);  lo.ut = fma(-gm, dut, lo.ut);
+    // the acoustic waves that run AGAINST their usual direction: supersonic flow only
+    if (!__builtin_signbit(e0) || e3 < 0.0) {
+        const double t = r * dun, hrcs = 0.5 * rcs, w2 = w + w;
+        const double a0 = hrcs * fma(rcs, dp, -t);
+        const double a3 = hrcs * fma(rcs, dp, t);
+        const double bl0 = !__builtin_signbit(e0) ? w2 * a0 : 0.0;
+        const double br3 = (e3 < 0.0) ? -(w2 * a3) : 0.0;
+        const double cr = cs * rr, c2 = cs * cs;
+        hi.r += bl0;  hi.un = fma(-bl0, cr, hi.un);  hi.p = fma(bl0, c2, hi.p);
+        lo.r += br3;  lo.un = fma(br3, cr, lo.un);   lo.p = fma(br3, c2, lo.p);
+    }
+}
+#else
 __device__ __forceinline__ void trace_states(double r, double un, double ut, double p,
                                              double dr, double dun, double dut, double dp,
                                              double gamma, double dtdx, Trace &lo, Trace &hi)
@@ -262,6 +324,7 @@ __device__ __forceinline__ void trace_states(double r, double un, double ut, dou
     lo.ut = lo.ut + br2;
     lo.p = lo.p + br3 * c2;
 }
+#endif
 
 // Wave-speed estimate, compressible/riemann.py:596-678 (quirk: S_r uses
 // (gamma+1)/(2/gamma), :675)
@@ -374,6 +437,105 @@ struct FaceQ { double un, ut, p; };
 // characteristic tracing produced them; prim_to_cons turned them into Ul / Ur),
 // so velocities and pressure are not recovered from the conserved states again.
 // Differs from the reference's round trip by rounding only.
+#if PYRO_FAST
+// fast build.  Same solver, written for the instruction count (differs from the
+// reference's evaluation order by rounding only; tolerance-tested, north_star 1e-10):
+//  * a_k = rho_k (S_k - u_k) is formed once and serves the contact speed
+//    S_c = (p_r - p_l + a_l u_l - a_r u_r) / (a_l - a_r) and the star state;
+//  * the star-region flux F_k + S_k (U*_k - U_k) of riemann.py:784-856 collapses, with
+//    f = a_k / (S_k - S_c) (= rho*_k) and p* = p_k + a_k (S_c - u_k), to
+//        F = (f S_c,  S_c (E* + p*),  f S_c^2 + p*,  f S_c ut_k),
+//        E* = ((S_k - u_k) E_k + (S_c - u_k) (a_k S_c + p_k)) / (S_k - S_c)
+//    (insert U*_k: the mass flux is rho u + S (f - rho) = f S - a = f S_c, and so on):
+//    one reciprocal, no physical flux of the outer state, 17 instead of 35 instructions;
+//  * PVRS pressure as one fma over (u_l - u_r) (rho_l + rho_r) (c_l + c_r) / 8.
+__device__ __forceinline__ void estimate_wave_speed_fast(double rho_l, double u_l, double p_l,
+                                                         double c_l, double rho_r, double u_r,
+                                                         double p_r, double c_r, const GasK &K,
+                                                         double &S_l, double &S_r)
+{
+    const double gamma = K.gamma;
+    const double p_max = fmax(p_l, p_r), p_min = fmin(p_l, p_r);
+    double pstar = fma(0.125 * (u_l - u_r), (rho_l + rho_r) * (c_l + c_r), 0.5 * (p_l + p_r));
+    if (p_max > 2.0 * p_min && (pstar < p_min || pstar > p_max)) {      // riemann.py:621-658
+        if (pstar < p_min) {   // two-rarefaction, :626-638
+            double z = pdiv(gamma - 1.0, 2.0 * gamma);
+            double p_lr = pow(pdiv(p_l, p_r), z);
+            double ustar = pdiv(pdiv(p_lr * u_l, c_l) + pdiv(u_r, c_r) +
+                                    pdiv(2.0 * (p_lr - 1.0), gamma - 1.0),
+                                pdiv(p_lr, c_l) + pdiv(1.0, c_r));
+            pstar = 0.5 * (p_l * pow(1.0 + pdiv((gamma - 1.0) * (u_l - ustar), 2.0 * c_l),
+                                     pdiv(1.0, z)) +
+                           p_r * pow(1.0 + pdiv((gamma - 1.0) * (ustar - u_r), 2.0 * c_r),
+                                     pdiv(1.0, z)));
+        } else {               // two-shock, :640-658
+            double A_r = pdiv(2.0, (gamma + 1.0) * rho_r);
+            double B_r = p_r * (gamma - 1.0) * K.rgp1;
+            double A_l = pdiv(2.0, (gamma + 1.0) * rho_l);
+            double B_l = p_l * (gamma - 1.0) * K.rgp1;
+            double p_guess = fmax(0.0, pstar);
+            double g_l = psqrt_nc(pdiv(A_l, p_guess + B_l));
+            double g_r = psqrt_nc(pdiv(A_r, p_guess + B_r));
+            pstar = pdiv(g_l * p_l + g_r * p_r - (u_r - u_l), g_l + g_r);
+        }
+    }
+    S_l = u_l - c_l;
+    if (pstar > p_l) S_l = fma(-c_l, psqrt_nc(fma(K.ksl, pstar * prcp(p_l) - 1.0, 1.0)), u_l);
+    S_r = u_r + c_r;
+    if (pstar > p_r) S_r = fma(c_r, psqrt_nc(fma(K.ksr, pstar * prcp(p_r) - 1.0, 1.0)), u_r);
+}
+
+template <bool HAVEQ>
+__device__ __forceinline__ ConsN hllc_flux_impl(const ConsN &Ul, const ConsN &Ur, const FaceQ &ql,
+                                                const FaceQ &qr, const GasK &K, bool normal_is_x)
+{
+    (void)normal_is_x;
+    const double gamma = K.gamma;
+    const double smallc = 1.e-10, smallp = 1.e-10;
+    const double rho_l = Ul.d, rho_r = Ur.d;
+    const double ril = prcp(rho_l), rir = prcp(rho_r);
+    double un_l, ut_l, pf_l, un_r, ut_r, pf_r;     // pf: pressure of the physical flux
+    if (HAVEQ) {
+        un_l = ql.un; ut_l = ql.ut; pf_l = ql.p;
+        un_r = qr.un; ut_r = qr.ut; pf_r = qr.p;
+    } else {
+        un_l = Ul.mn * ril; ut_l = Ul.mt * ril;
+        pf_l = fma(-0.5, fma(Ul.mt, ut_l, Ul.mn * un_l), Ul.E) * (gamma - 1.0);
+        un_r = Ur.mn * rir; ut_r = Ur.mt * rir;
+        pf_r = fma(-0.5, fma(Ur.mt, ut_r, Ur.mn * un_r), Ur.E) * (gamma - 1.0);
+    }
+    const double p_l = fmax(pf_l, smallp), p_r = fmax(pf_r, smallp);
+    const double c_l = fmax(smallc, psqrt_nc(gamma * p_l * ril));
+    const double c_r = fmax(smallc, psqrt_nc(gamma * p_r * rir));
+    double S_l, S_r;
+    estimate_wave_speed_fast(rho_l, un_l, p_l, c_l, rho_r, un_r, p_r, c_r, K, S_l, S_r);
+    const double d_l = S_l - un_l, d_r = S_r - un_r;
+    const double a_l = rho_l * d_l, a_r = rho_r * d_r;
+    const double S_c = fma(-a_r, un_r, fma(a_l, un_l, p_r - p_l)) * prcp(a_l - a_r);
+    // physical flux of an outer state (supersonic faces)
+    auto outer = [&](const ConsN &U, double un, double pf) {
+        return ConsN{U.d * un, (U.E + pf) * un, fma(U.mn, un, pf), U.mt * un};
+    };
+    auto star = [&](double un, double ut, double p, double E, double S, double d, double a) {
+        const double dS = S_c - un;
+        const double ps = fma(a, dS, p);
+        const double rb = prcp(S - S_c);
+        const double f = a * rb;
+        ConsN F;
+        F.d = f * S_c;
+        F.mn = fma(F.d, S_c, ps);
+        F.mt = F.d * ut;
+        const double Es = fma(dS, fma(a, S_c, p), d * E) * rb;
+        F.E = S_c * (Es + ps);
+        return F;
+    };
+    // riemann.py:784-856: S_r <= 0 | S_c <= 0 < S_r | S_l < 0 < S_c | else
+    if (S_r <= 0.0) return outer(Ur, un_r, pf_r);
+    if (S_c <= 0.0) return star(un_r, ut_r, p_r, Ur.E, S_r, d_r, a_r);
+    if (S_l < 0.0) return star(un_l, ut_l, p_l, Ul.E, S_l, d_l, a_l);
+    return outer(Ul, un_l, pf_l);
+}
+#else
 template <bool HAVEQ>
 __device__ __forceinline__ ConsN hllc_flux_impl(const ConsN &Ul, const ConsN &Ur, const FaceQ &ql,
                                                 const FaceQ &qr, const GasK &K, bool normal_is_x)
@@ -469,6 +631,7 @@ __device__ __forceinline__ ConsN hllc_flux_impl(const ConsN &Ul, const ConsN &Ur
     }
     return F;
 }
+#endif
 __device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, const GasK &K,
                                            bool normal_is_x)
 {
@@ -726,4 +889,5 @@ __device__ __forceinline__ double div_u_vertex_r(double u_ij, double u_ijm, doub
     return ux + vy;
 }
 
+}  // inline namespace hydro_fast / hydro_exact
 }  // namespace pyro

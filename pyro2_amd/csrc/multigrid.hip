@@ -2365,10 +2365,14 @@ int pyrohip_mg_smooth_rows(pyrohip_mg *m, int level, int nsweeps, int row0, int 
     PYRO_REQUIRE(nsweeps >= 1 && nsweeps <= MGW_KMAX, "one launch: 1..5 iterations");
     PYRO_REQUIRE(row0 >= 1 && row1 <= L.n && row0 <= row1, "rows outside the level");
     PYRO_REQUIRE(!prolong || level > 0, "no coarser level to prolong from");
-    const int ks = m->kmax_small;
-    m->kmax_small = 0;                       // exactly `nsweeps` iterations in ONE launch
+    // exactly `nsweeps` iterations in ONE launch (no halo exchange could happen between
+    // two launches of a split call): the tuning values do not apply to row windows
+    const int ks = m->kmax_small, km = m->kmax;
+    m->kmax_small = 0;
+    m->kmax = MGW_KMAX;
     const int rc = mg_smooth_tiles(m, level, nsweeps, prolong != 0, row0, row1);
     m->kmax_small = ks;
+    m->kmax = km;
     m->corners_stale[level] = true;
     PYRO_CHECK_HIP(hipGetLastError());
     return rc;

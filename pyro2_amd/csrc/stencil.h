@@ -35,6 +35,21 @@ __device__ __forceinline__ double limit2(double am, double a0, double ap)
     return (dl * dr > 0.0) ? r : 0.0;
 }
 
+// mc_select(dc, dl, dr) for the FOURTH-ORDER centred slope of limit4,
+// dc = (2/3) (ap1 - am1 - 0.25 (l2p + l2m)) with l2p / l2m the limit2 slopes of the two
+// neighbours, as two minima of magnitudes and a sign copy (like limit2 above).  Where
+// dl * dr > 0 this dc shares the sign of dl and dr: |l2p| <= 2 |dl| and |l2m| <= 2 |dr|
+// (as computed: m + m of the rounded differences), so 0.25 (l2p + l2m) stays below
+// 0.5 (1 + eps) (|dl| + |dr|) and can neither turn the sign of ap1 - am1 nor cancel it.
+// The SAME candidate comes out, bit for bit, at 8 instead of 11 vector instructions
+// (3 compares + 6 v_cndmask_b32 in mc_select).
+__device__ __forceinline__ double mc_select_l4(double dc, double dl, double dr)
+{
+    const double m = fmin(fabs(dl), fabs(dr));
+    const double r = copysign(fmin(fabs(dc), m + m), dl);
+    return (dl * dr > 0.0) ? r : 0.0;
+}
+
 // limited slope at the centre of the 5-point stencil (reconstruction.py:9-120)
 //   limiter 0: nolimit, 1: limit2, otherwise limit4
 __device__ __forceinline__ double limited_slope(double am2, double am1, double a0, double ap1,
@@ -47,7 +62,7 @@ __device__ __forceinline__ double limited_slope(double am2, double am1, double a
     double dc = (2. / 3.) * (ap1 - am1 - 0.25 * (l2p + l2m));
     double dl = ap1 - a0;
     double dr = a0 - am1;
-    return mc_select(dc, dl, dr);
+    return mc_select_l4(dc, dl, dr);
 }
 
 // blockIdx -> logical tile id such that each XCD (blocks are dealt round-robin

@@ -178,7 +178,10 @@ class SlabCompressible:
         kw["avisc_xhi_interior"] = int(decomp.hi >= 0 and not decomp.wrap_hi)
         self.params = device.make_comp_params(**kw)
         # boundary strips first + halo exchange beside the interior strips (kernel_set 2)
-        if getattr(comm, "overlap", False) and (decomp.lo >= 0 or decomp.hi >= 0):
+        # (not where a wrap-around side meets an hse boundary: that path rewrites halo rows
+        # from the host between the steps, _exchange_fill_wrapped_hse)
+        if getattr(comm, "overlap", False) and (decomp.lo >= 0 or decomp.hi >= 0) and \
+                not self._hse_wrap:
             self.state.set_neighbours(decomp.lo, decomp.hi)
 
     def evolve(self, policy, cfl, nsteps):

@@ -100,6 +100,13 @@ class Context:
         with self.lock:
             check(self._l.pyrohip_comm_init(self.h, nranks, rank, unique_id))
 
+    def comm_size(self):
+        """rank count of the communicator as RCCL reports it (0: none)"""
+        n = C.c_int()
+        with self.lock:
+            check(self._l.pyrohip_comm_size(self.h, C.byref(n)))
+        return n.value
+
     def comm_set_global_dt(self, on=True):
         """let comp_step all-reduce the next CFL minimum on the device"""
         with self.lock:

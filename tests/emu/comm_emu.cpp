@@ -6,6 +6,7 @@ extern "C" {
 int pyrohip_comm_unique_id(char *) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
 int pyrohip_comm_init(pyrohip_ctx *, int, int, const char *) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
 int pyrohip_comm_destroy(pyrohip_ctx *) { return 0; }
+int pyrohip_comm_size(pyrohip_ctx *, int *n) { if (n) *n = 0; return 0; }
 int pyrohip_halo_exchange(pyrohip_state *, int, int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
 int pyrohip_allreduce_min(pyrohip_ctx *, double *) { return 0; }
 int pyrohip_allreduce_max(pyrohip_ctx *, double *) { return 0; }
@@ -32,4 +33,5 @@ namespace pyro {
 int comm_allreduce_min_device(pyrohip_ctx *, double *) { return 0; }
 bool comm_can_overlap(const pyrohip_state *) { return true; }
 int comm_post_halo(pyrohip_state *, double *) { return 0; }     // nothing to post: see above
+int comm_wait_halo(pyrohip_state *) { return 0; }
 }

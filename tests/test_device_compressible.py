@@ -32,7 +32,7 @@ import numpy as np
 import pytest
 
 from conftest import comp_floors, elementwise_err, max_rel_err
-from helpers import DtPolicy, meta_to_params
+from helpers import DtPolicy, meta_to_params, oracle_comp_run
 from oracle import orc
 from pyro2_amd import _lib, device
 
@@ -290,6 +290,34 @@ def test_comp_reference_regression_rt(hip, golden, fast, kset):
             assert elementwise_err(U[4:-4, 4:-4, n], ref, fl) <= TOL_FAST, n
 
 
+@pytest.mark.parametrize("nb", [False, True])
+@pytest.mark.parametrize("nx", [34, 35, 36, 47])
+def test_comp_wave_short_last_strip(dev, nx, nb):
+    """row-marching kernel, 11-row strips on grids with nx % 11 in {1, 2, 3} (and 3 again at
+    4 strips): a last strip shorter than the ghost width joins its predecessor, so that the
+    boundary strips of a slab always hold the ng rows the neighbour receives (the overlapped
+    exchange posts them before the interior strips run).  nb: with neighbours named, i.e.
+    the boundary-strips-first launch order.  Sedov-like blast off-centre, 5 steps, against
+    the oracle."""
+    from sedov_ic import sedov_ic
+    ic, meta, bcs = sedov_ic(nx, 40, r_init=0.12)
+    Uo, dto, _ = oracle_comp_run(ic, meta, bcs, 0.1, 5)
+    P, cfl = dev_params(meta, kernel_set=2, march_rows=11)
+    s = comp_state(dev, nx, 40, bcs)
+    if nb:
+        s.set_neighbours(0, 0)          # launch order only: no communicator in this test
+    s.upload(ic)
+    pol = DtPolicy(0.1)
+    for _ in range(5):
+        s.fill_bc()
+        dt = pol(s.comp_dt(P, cfl))
+        s.comp_step(P, dt)
+        pol.advance(dt)
+    U = s.download()
+    tol = 0.0 if dev.kind == "emu" else 1e-13
+    assert max_rel_err(U[4:-4, 4:-4], Uo[4:-4, 4:-4]) <= tol
+
+
 @pytest.mark.parametrize("kset", [1, 3])
 def test_comp_evolve_on_device(dev, golden, kset):
     """pyrohip_comp_evolve: the run_sim loop (ghost fill, the driver's dt policy,
@@ -346,6 +374,45 @@ def test_comp_evolve_on_device(dev, golden, kset):
     assert ei.value.code == ERR_STATE
     assert pol2.n == pol.n and pol2.t == pol.t
     assert np.array_equal(s.download()[4:-4, 4:-4], bad[4:-4, 4:-4])
+
+
+@pytest.mark.parametrize("kset", [0, 1, 2])
+def test_comp_fast_algebra_supersonic(dev, kset):
+    """the fast build's OWN ALGEBRA (hydro.h: characteristic tracing with the projections
+    written out and the acoustic terms evaluated lazily; HLLC with a_k = rho_k (S_k - u_k),
+    the collapsed star-region flux and the outer-state fluxes) against the bit-faithful build
+    on a flow that takes every branch: a Mach-3 stream in +x / -y over half of the domain
+    (supersonic faces of both signs in both directions), a counter-stream, a blast and a
+    smooth density field; reflecting walls in y put -0.0 momenta into the ghost cells (the
+    sign BIT picks the upwind side, like np.copysign).  On the emulator both builds divide
+    exactly, so the difference is the re-association alone: element-wise 1e-12 after 6
+    steps; on the GPU the fast-build tolerance."""
+    from sedov_ic import sedov_ic
+    nx, ny = 48, 40
+    ic, meta, _ = sedov_ic(nx, ny, r_init=0.1)
+    bcs = ["outflow", "outflow", "reflect", "reflect"]
+    ic = np.nan_to_num(ic)
+    x = (np.arange(nx + 8) - 3.5)[:, None] / nx
+    y = (np.arange(ny + 8) - 3.5)[None, :] / ny
+    rho = 1.0 + 0.4 * np.sin(5 * x + 1) * np.cos(7 * y)
+    p = 1.0e-2 * (1.0 + 0.5 * np.cos(3 * x) * np.sin(4 * y))
+    p += 2.0 * np.exp(-((x - 0.5) ** 2 + (y - 0.45) ** 2) * 400.0)
+    c = np.sqrt(1.4 * p / rho)
+    u = np.where(y < 0.5, 3.0, -2.5) * c.mean() * np.ones_like(x)
+    v = np.where(x < 0.5, -3.0, 2.0) * c.mean() * np.ones_like(y)
+    v[:, :6] = 0.0          # at rest next to the lower wall: exact zeros, -0.0 in its ghosts
+    ic[..., 0] = rho
+    ic[..., 2] = rho * u
+    ic[..., 3] = rho * v
+    ic[..., 1] = p / 0.4 + 0.5 * rho * (u * u + v * v)
+    nsteps = 6
+    Ue, dte, _ = device_comp_run(dev, ic, meta, bcs, 1.0, nsteps, fast_math=0, **kset_kw(kset))
+    Uf, dtf, _ = device_comp_run(dev, ic, meta, bcs, 1.0, nsteps, fast_math=1, **kset_kw(kset))
+    tol = 1e-12 if dev.kind == "emu" else TOL_FAST
+    assert max_rel_err(dtf, dte) <= tol
+    fl = comp_floors(Ue[4:-4, 4:-4])
+    for n in range(4):
+        assert elementwise_err(Uf[4:-4, 4:-4, n], Ue[4:-4, 4:-4, n], fl[n]) <= tol, n
 
 
 def test_comp_fast_path_logic(dev, golden, kset=2):
@@ -420,7 +487,19 @@ def test_comp_sedov_512_vs_oracle(hip, fast, kset):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fast", [0, 1])
+def test_comp_sedov_8192_vs_oracle_window(hip, golden, fast):
+    """north_star's target size (Sedov 8192^2), checked like the 16384^2 case below
+    (oracle/gen_fullsize.py --window8192)"""
+    _sedov_window_check(hip, golden("comp_sedov_8192_window"), 8192, fast)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fast", [0, 1])
 def test_comp_sedov_16384_vs_oracle_window(hip, golden, fast):
+    _sedov_window_check(hip, golden("comp_sedov_16384_window"), 16384, fast)
+
+
+def _sedov_window_check(hip, g, nx, fast):
     """the bench's own workload and size (Sedov 16384^2, 25 steps from t = 0,
     default kernel set) against the C oracle.  The oracle ran the central
     1024^2 window with the full grid's cell coordinates (oracle/gen_fullsize.py
@@ -430,8 +509,7 @@ def test_comp_sedov_16384_vs_oracle_window(hip, golden, fast):
     lattice, row / column sums of the window and a dense 16x256 patch across the
     shock; fast build element-wise (1e-10), bit-faithful build 1e-12."""
     from pyro2_amd.compressible.problems.sedov import sedov_state
-    g = golden("comp_sedov_16384_window")
-    nx, ng, nsteps = 16384, 4, int(g["nsteps"])
+    ng, nsteps = 4, int(g["nsteps"])
     lo, W = int(g["lo"]), int(g["width"])
     s = comp_state(hip, nx, nx, ["outflow"] * 4)
     for r0 in range(0, nx + 2 * ng, 512):
@@ -463,6 +541,43 @@ def test_comp_sedov_16384_vs_oracle_window(hip, golden, fast):
         row = s.download_rows(r, 1)[0, ng:-ng]
         assert np.array_equal(row, np.broadcast_to(amb, row.shape)), r
     assert np.array_equal(I[:, 0], np.broadcast_to(amb, I[:, 0].shape))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fast", [0, 1])
+def test_comp_sedov_developed_vs_oracle(hip, golden, fast):
+    """the DEVELOPED-flow state the bench's `also.sedov_developed` leg times (a 1024^2
+    Sedov blast at t = 0.1, ~2300 steps: 30 % of the cells shocked) against the C oracle
+    (oracle/gen_fullsize.py --developed1024): dt sequence, a 64 x 64 lattice, row / column
+    sums and a dense patch from the centre across the shock.  Device-side stepping
+    (pyrohip_comp_evolve), default kernel set; fast build element-wise 1e-10,
+    bit-faithful build 1e-12."""
+    from sedov_ic import sedov_ic
+    g = golden("comp_sedov_1024_developed")
+    nx, ng, nsteps = 1024, 4, int(g["nsteps"])
+    ic, meta, bcs = sedov_ic(nx)
+    s = comp_state(hip, nx, nx, bcs)
+    s.upload(ic)
+    P = device.make_comp_params(1.0 / nx, 1.0 / nx, fast_math=fast, kernel_set=-1)
+    pol = DtPolicy(0.1)
+    dts = []
+    while pol.t < 0.1 and pol.n < nsteps + 10:
+        dts.extend(s.comp_evolve(P, 0.8, pol, min(256, nsteps + 10 - pol.n)))
+    dts = np.array(dts)
+    tol = TOL_FAST if fast else 1e-12
+    assert len(dts) == nsteps
+    assert max_rel_err(dts[:-1], g["dts"][:-1]) <= tol          # the last one is the clip to tmax
+    assert abs(dts[-1] - g["dts"][-1]) <= tol * g["dts"][-2]
+    I = s.download()[ng:-ng, ng:-ng]
+    step = nx // 64
+    assert_state_close(I[::step, ::step], g["samples"], tol, fast, "lattice")
+    assert_state_close(I[nx // 2 - 8:nx // 2 + 8, nx // 2:], g["patch"], tol, fast, "patch")
+    umax = g["umax"]
+    for n in range(4):
+        for ax, key in ((1, "row_sums"), (0, "col_sums")):
+            ref = g[key][:, n]
+            assert np.abs(I[..., n].sum(axis=ax) - ref).max() <= tol * max(np.abs(ref).max(), nx * umax[n] * 1e-3)
+    assert abs(float((np.abs(I[..., 0] - 1.0) > 1e-8).mean()) - float(g["shocked"])) < 1e-3
 
 
 @pytest.mark.gpu

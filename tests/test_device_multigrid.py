@@ -265,9 +265,13 @@ def test_mg_4096_vs_reference_samples(hip, golden):
     assert abs(src / float(g["source_norm"]) - 1) < 1e-13
     assert nc == int(g["num_cycles"]) == 10
     assert abs(res / float(g["residual_error"]) - 1) < 1e-10
-    scale = np.abs(g["samples"]).max()
     step = nx // 64
-    assert np.abs(v[::step, ::step] - g["samples"]).max() <= 1e-10 * scale
+    # ELEMENT-WISE: the solution vanishes toward the Dirichlet boundary (the lattice's first
+    # row / column are the cells next to it, |v| ~ 1e-11 there), every sample is held to the
+    # relative tolerance of its own magnitude
+    ref = g["samples"]
+    assert (np.abs(ref) > 0).all()
+    assert (np.abs(v[::step, ::step] - ref) / np.abs(ref)).max() <= 1e-10
     assert np.abs(v.sum(axis=1) - g["row_sums"]).max() <= 1e-10 * np.abs(g["row_sums"]).max()
     assert np.abs(v.sum(axis=0) - g["col_sums"]).max() <= 1e-10 * np.abs(g["col_sums"]).max()
 
