@@ -162,6 +162,21 @@ int pyrohip_adv_step(pyrohip_state *s, int n, double dx, double dy, double u,
    of the reference.  fill = 0: ghost cells are used as they are. */
 int pyrohip_adv_step_fill(pyrohip_state *s, int n, double dx, double dy, double u,
                           double v, double dt, int limiter, int fill);
+/* the same with the parameters in a struct.
+   fast_math   0: bit-faithful arithmetic (the reference's operation order, no
+               contraction: results identical to NumPy, what the two functions above
+               run); 1: the contracted build (fused multiply-adds; north_star's
+               tolerance for advection, 1e-12 relative, parity-tested)
+   march_rows  rows per strip of the row-marching kernel (0: chosen by the library
+               from the grid size and the number of compute units)            */
+typedef struct {
+    double dx, dy, u, v;
+    int limiter;       /* 0 none, 1 MC 2nd order, 2 MC 4th order (advection.limiter) */
+    int fill;          /* fold the ghost fill into the step (see above) */
+    int fast_math;
+    int march_rows;
+} pyrohip_adv_params;
+int pyrohip_adv_step_p(pyrohip_state *s, int n, const pyrohip_adv_params *p, double dt);
 
 /* ---- compressible ---------------------------------------------------- */
 /* conserved order: density(0) energy(1) x-momentum(2) y-momentum(3)

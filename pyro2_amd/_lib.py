@@ -39,6 +39,12 @@ class PyroHipError(RuntimeError):
         self.code = code
 
 
+class AdvParams(C.Structure):
+    _fields_ = [("dx", C.c_double), ("dy", C.c_double), ("u", C.c_double), ("v", C.c_double),
+                ("limiter", C.c_int), ("fill", C.c_int), ("fast_math", C.c_int),
+                ("march_rows", C.c_int)]
+
+
 class CompParams(C.Structure):
     _fields_ = [("dx", C.c_double), ("dy", C.c_double), ("gamma", C.c_double),
                 ("limiter", C.c_int), ("use_flattening", C.c_int),
@@ -126,6 +132,7 @@ _PROTOS = {
                          C.c_double, C.c_double, C.c_int],
     "pyrohip_adv_step_fill": [_VP, C.c_int, C.c_double, C.c_double, C.c_double,
                               C.c_double, C.c_double, C.c_int, C.c_int],
+    "pyrohip_adv_step_p": [_VP, C.c_int, C.POINTER(AdvParams), C.c_double],
     "pyrohip_comp_dt": [_VP, C.POINTER(CompParams), C.c_double, _DP],
     "pyrohip_comp_evolve": [_VP, C.POINTER(CompParams), C.c_double, C.POINTER(DtPolicyC), C.c_int,
                             _IP, _DP],

@@ -32,6 +32,13 @@ class Simulation(NullSimulation):
         ytmp = g.dy / max(abs(v), self.SMALL)
         self.dt = cfl * min(xtmp, ytmp)
 
+    def _fast_math(self):
+        """gpu.fast_math (default 1: the contracted build; 0: the bit-faithful audit build)"""
+        try:
+            return int(self.rp.get_param("gpu.fast_math"))
+        except (KeyError, ValueError):
+            return 1
+
     def evolve(self):
         """one time step of "density" on the device"""
         tm = self.tc.timer("evolve")
@@ -42,7 +49,7 @@ class Simulation(NullSimulation):
                     float(self.rp.get_param("advection.u")),
                     float(self.rp.get_param("advection.v")), float(self.dt),
                     int(self.rp.get_param("advection.limiter")),
-                    fill=self.cc_data.take_pending_fill())
+                    fill=self.cc_data.take_pending_fill(), fast_math=self._fast_math())
         self.cc_data.device_modified()
         if self.particles is not None:   # constant velocity field, advection/simulation.py:82-90
             self.advance_particles(g.scratch_array() + self.rp.get_param("advection.u"),

@@ -24,7 +24,8 @@ COMMON = ["-std=c++17", "-fPIC", "-O3"]
 # twice: bit-faithful (no FMA contraction) and contracted.
 UNITS = [
     ("ctx.hip", "ctx", ["-ffp-contract=off"]),
-    ("advection.hip", "advection", ["-ffp-contract=off"]),
+    ("advection.hip", "advection", ["-ffp-contract=off", "-DPYRO_FAST=0"]),
+    ("advection.hip", "adv_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1"]),
     ("compressible.hip", "comp_exact", ["-ffp-contract=off", "-DPYRO_FAST=0"]),
     ("compressible.hip", "comp_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1"]),
     ("comp_fused.hip", "fused_exact", ["-ffp-contract=off", "-DPYRO_FAST=0"]),

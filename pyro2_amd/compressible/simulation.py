@@ -117,7 +117,7 @@ class Simulation(NullSimulation):
             delta=rp.get_param("compressible.delta"), cvisc=rp.get_param("compressible.cvisc"),
             grav=rp.get_param("compressible.grav"),
             small_dens=rp.get_param("compressible.small_dens"),
-            fast_math=opt("gpu.fast_math", 0), kernel_set=opt("gpu.kernel_set", -1),
+            fast_math=opt("gpu.fast_math", 1), kernel_set=opt("gpu.kernel_set", -1),
             riemann=rp.get_param("compressible.riemann"),
             solid_xl=self.solid.xl, solid_yl=self.solid.yl,
             sponge=(rp.get_param("sponge.sponge_rho_begin"), rp.get_param("sponge.sponge_rho_full"),

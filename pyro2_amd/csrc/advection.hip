@@ -9,13 +9,19 @@
 //
 // Roofline: HBM bound, 16 B per cell update (read a, write a).
 //
-// Same design as the compressible row-marching kernel (comp_wave.hip): one
-// wavefront = 64 columns (lane = column j, 512-B row loads), the inner 56 are
-// updated; it walks down a strip of rows.  x direction (rows): a 5-row window of
-// a, limit2_x and the x interface states in registers, each computed once; y
-// direction: DPP lane rotation.  No LDS, no barrier.  Per cell: one limit2 and
-// one limit4 per direction (the tile kernel of round 1 evaluated limit2 three
-// times per face: ~165 VALU per cell, now ~75).
+// Same design as the compressible row-marching kernel (comp_wave.hip): a wavefront
+// walks down a strip of rows and keeps everything it needs of the rows above in
+// registers (a 5-row window of a, limit2_x and the x interface states, each computed
+// once); no LDS, no barrier.  Here every lane owns TWO adjacent columns (2 l, 2 l + 1 of
+// the wavefront's 128, of which the inner 120 are updated):
+//   * the y neighbour of the left column's right side / the right column's left side is
+//     in the lane's own registers, so a row needs 6-8 DPP double moves for two cells
+//     where the one-column layout needed 10 for one;
+//   * 8 apron columns in 128 instead of 8 in 64;
+//   * two independent cells per lane: instruction-level parallelism inside the wavefront
+//     where the one-column kernel depended on four wavefronts per SIMD to hide latency
+//     (VALU busy was 0.50, profiles/r02m_also_traffic.json).
+// Per cell: one limit2 and one limit4 per direction.
 //
 // Ghost cells.  With `fill` the boundary fill of the variable (outflow,
 // reflect-even / -odd, periodic) is folded into the loads: a ghost cell's value
@@ -24,20 +30,31 @@
 // the NEW buffer (the reference updates in place, so after a step the ghost
 // cells hold the values the fill at the start of the step gave them), which
 // removes the separate fill_x / fill_y / copy_frame launches: 4 launches -> 1.
+//
+// Compiled twice (build.py): bit-faithful (-ffp-contract=off, the reference's operation
+// order: results identical to NumPy) and contracted (-ffp-contract=fast: north_star's
+// tolerance for advection is 1e-12, the multiply-add pairs of the slope / state / flux
+// expressions fuse); pyrohip_adv_params.fast_math selects.
 #include "common.h"
 #include "stencil.h"
 #include <type_traits>
 
-namespace pyro {
-
-constexpr int AW_OUT = 56;        // columns a wavefront updates
-// rows loaded ahead of their use.  Measured per 2048^2 step with the unrolled loop: 1 row
-// 26.2 us (6 iterations unrolled), 3 rows 27.5 (24), 4 rows 27.2 (18), 7 rows 27.6 (12); 8192^2:
-// no difference (four wavefronts per SIMD hide the load of the next row)
-#ifndef PYRO_ADV_PF
-#define PYRO_ADV_PF 1
+#ifndef PYRO_FAST
+#define PYRO_FAST 0
 #endif
-constexpr int ADV_PF = PYRO_ADV_PF;
+#if PYRO_FAST
+#define PYRO_NS fastm
+#else
+#define PYRO_NS exact
+#endif
+
+namespace pyro {
+namespace PYRO_NS {
+
+constexpr int AW_OUT = 120;       // columns a wavefront updates (64 lanes x 2 - 8 apron)
+// rows loaded ahead of their use (one: the next row's loads are issued while this row is
+// worked on; more bought nothing in the one-column kernel either)
+constexpr int ADV_PF = 1;
 
 constexpr int adv_gcd(int a, int b) { return b == 0 ? a : adv_gcd(b, a % b); }
 constexpr int adv_lcm(int a, int b) { return a / adv_gcd(a, b) * b; }
@@ -80,6 +97,13 @@ __device__ __forceinline__ double adv_m1(double v) { return __shfl_up(v, 1, 64);
 __device__ __forceinline__ double adv_p1(double v) { return __shfl_down(v, 1, 64); }
 #endif
 
+// the lane's two cells of a row: a at column j0 = 2 l (+ strip offset), b at j0 + 1
+struct D2 { double a, b; };
+// the same quantity one column to the left / right of each of the two cells: one DPP
+// double move each, the other neighbour is the lane's own second cell
+__device__ __forceinline__ D2 adv_left(const D2 &q) { return D2{adv_m1(q.b), q.a}; }
+__device__ __forceinline__ D2 adv_right(const D2 &q) { return D2{q.b, adv_p1(q.a)}; }
+
 // limited slope from shared limit2 values (reconstruction.py:9-120)
 template <int LIM>
 __device__ __forceinline__ double adv_slope(double l2m, double l20, double l2p, double am1, double a0,
@@ -100,23 +124,30 @@ __global__ __launch_bounds__(64) void k_adv_step(const double *__restrict__ ain,
 {
     const int l = threadIdx.x;
     // (the quotient is computed by vector instructions; without the hint the strip's row
-    // range, the loop counter and every row offset derived from them stay in vector registers:
-    // 12 quarter-rate v_mul_lo_u32 per row)
+    // range, the loop counter and every row offset derived from them stay in vector registers)
     const int cb = pyro_uniform(blockIdx.x % P.ncb), sb = pyro_uniform(blockIdx.x / P.ncb);
     const int i0 = g.ilo + sb * P.L;                       // strip rows [i0, i1)
     const int i1 = (i0 + P.L < g.ihi + 1) ? i0 + P.L : g.ihi + 1;
-    const int j = g.jlo + cb * AW_OUT - 4 + l;             // this lane's column
-    const bool jvalid = (j < g.qy);
-    const bool jghost = jvalid && (j < g.jlo || j > g.jhi);
-    const bool jout = (j >= g.jlo && j <= g.jhi && l >= 4 && l <= 59);
-    const bool jown = jvalid && ((l >= 4 && l <= 59) || jghost);   // columns whose ghost cells we carry
+    const int ja = g.jlo + cb * AW_OUT - 4 + 2 * l;        // this lane's columns ja, ja + 1
+    const bool inner = (l >= 2 && l <= 61);                // not an apron lane
     const int p = g.pitch;
     // row / column maps of the ghost fill
     const BcMap mr = bc_map(g.ilo, g.ihi, g.ng, P.bxl, P.bxr, P.fill != 0);
     const BcMap mc = bc_map(g.jlo, g.jhi, g.ng, P.byl, P.byr, P.fill != 0);
-    const int jcl = jvalid ? j : g.qy - 1;
-    const int js = bc_src(mc, jcl, g.jlo, g.jhi);
-    const bool neg_c = (jcl < g.jlo && mc.odd_lo) || (jcl > g.jhi && mc.odd_hi);
+    // per column: in the array, ghost, updated by this wavefront, carried (ghost frame)
+    bool jout[2], jown[2], jghost[2], neg_c[2];
+    int js[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int j = ja + q;
+        const bool jvalid = (j < g.qy);
+        jghost[q] = jvalid && (j < g.jlo || j > g.jhi);
+        jout[q] = (j >= g.jlo && j <= g.jhi && inner);
+        jown[q] = jvalid && (inner || jghost[q]);          // columns whose ghost cells we carry
+        const int jcl = jvalid ? j : g.qy - 1;
+        js[q] = bc_src(mc, jcl, g.jlo, g.jhi);
+        neg_c[q] = (jcl < g.jlo && mc.odd_lo) || (jcl > g.jhi && mc.odd_hi);
+    }
     // the first / last strip also carries the ghost rows
     const int ka = pyro_uniform((i0 == g.ilo) ? 0 : i0 - 3);
     const int kb = pyro_uniform((i1 == g.ihi + 1) ? g.qx - 1 : i1 + 2);
@@ -128,69 +159,89 @@ __global__ __launch_bounds__(64) void k_adv_step(const double *__restrict__ ain,
     // source row of array row k under the ghost fill; its sign goes with the value
     auto row_src = [&](int k) { return bc_src(mr, k > kb ? kb : k, g.ilo, g.ihi); };
     const bool odd_lo = mr.odd_lo, odd_hi = mr.odd_hi;
+    auto load_row = [&](int k) {
+        const size_t r = (size_t)row_src(k) * p;
+        return D2{ain[r + js[0]], ain[r + js[1]]};
+    };
 
     // The rows the march carries from one iteration to the next live in rings that are indexed
-    // at compile time: the loop is unrolled over the least common period of the rings (18), so
-    // a value stays in the register it was computed into until it is dead -- a fifth of the
-    // loop's vector instructions were the moves of the sliding windows.
+    // at compile time: the loop is unrolled over the least common period of the rings, so
+    // a value stays in the register it was computed into until it is dead.
     //   rows   a of rows k-4 .. k (the stencil window) and k+1 .. k+ADV_PF (loads in flight)
     //   l2x    limit2_x of rows k-3, k-2, k-1
     //   X      x states of rows c-2, c-1, c  (c = k-2);  Y, Ax, Fx  a_y / a_x (as used: at column
     //          j-1 / j+my) and F_x of rows c-1, c
     constexpr int NR = 5 + ADV_PF, UNR = adv_lcm(NR, 6);
     static_assert(UNR % NR == 0 && UNR % 3 == 0 && UNR % 2 == 0 && UNR <= 36, "ring periods");
-    double rows[NR], l2x[3] = {0, 0, 0}, Xr[3] = {0, 0, 0}, Yr[2] = {0, 0}, Axr[2] = {0, 0}, Fxr[2] = {0, 0};
+    const D2 zero{0.0, 0.0};
+    D2 rows[NR], l2x[3] = {zero, zero, zero}, Xr[3] = {zero, zero, zero}, Yr[2] = {zero, zero},
+       Axr[2] = {zero, zero}, Fxr[2] = {zero, zero};
 #pragma unroll
-    for (int n = 0; n < NR; n++) rows[n] = 0.0;
-    // rows k .. k+ADV_PF-1 in flight: a wavefront consumes a row right after it arrives, so
-    // the loads run ahead of the use
+    for (int n = 0; n < NR; n++) rows[n] = zero;
 #pragma unroll
-    for (int n = 0; n < ADV_PF; n++) rows[4 + n] = ain[(size_t)row_src(ka + n) * p + js];
+    for (int n = 0; n < ADV_PF; n++) rows[4 + n] = load_row(ka + n);
+    // per cell functions of the two-cell rows
+    auto lim2 = [&](const D2 &m, const D2 &c, const D2 &q) {
+        return (LIM != 0) ? D2{limit2(m.a, c.a, q.a), limit2(m.b, c.b, q.b)} : zero;
+    };
+    auto slope = [&](const D2 &lm, const D2 &l0, const D2 &lp, const D2 &m, const D2 &c, const D2 &q) {
+        return D2{adv_slope<LIM>(lm.a, l0.a, lp.a, m.a, c.a, q.a),
+                  adv_slope<LIM>(lm.b, l0.b, lp.b, m.b, c.b, q.b)};
+    };
     auto step = [&](auto uc, int k) __attribute__((always_inline)) {
         constexpr int U = decltype(uc)::value;
         // window row n (row k-4+n) and in-flight row n (row k+1+n)
 #define ADV_W(n) rows[(U + (n)) % NR]
         {   // row k arrives (through the ghost fill's index map), row k+ADV_PF leaves
-            const double raw = ADV_W(4);
-            rows[(U + 4 + ADV_PF) % NR] = ain[(size_t)row_src(k + ADV_PF) * p + js];
-            const bool neg = neg_c != ((k < g.ilo && odd_lo) || (k > g.ihi && odd_hi));
-            ADV_W(4) = neg ? -raw : raw;
+            const D2 raw = ADV_W(4);
+            rows[(U + 4 + ADV_PF) % NR] = load_row(k + ADV_PF);
+            const bool neg_r = (k < g.ilo && odd_lo) || (k > g.ihi && odd_hi);
+            ADV_W(4) = D2{(neg_c[0] != neg_r) ? -raw.a : raw.a, (neg_c[1] != neg_r) ? -raw.b : raw.b};
             // ghost frame of the new buffer
-            const bool rghost = (k < g.ilo || k > g.ihi);
-            if (jown && (rghost || (jghost && k >= i0 && k < i1))) aout[(size_t)k * p + j] = ADV_W(4);
+            const bool rghost = (k < g.ilo || k > g.ihi), kin = (k >= i0 && k < i1);
+            if (jown[0] && (rghost || (jghost[0] && kin))) aout[(size_t)k * p + ja] = ADV_W(4).a;
+            if (jown[1] && (rghost || (jghost[1] && kin))) aout[(size_t)k * p + ja + 1] = ADV_W(4).b;
         }
-        const double l2b = l2x[U % 3], l2c = l2x[(U + 1) % 3];
-        const double l2n = (LIM != 0) ? limit2(ADV_W(2), ADV_W(3), ADV_W(4)) : 0.0;   // limit2_x of row k-1
+        const D2 l2b = l2x[U % 3], l2c = l2x[(U + 1) % 3];
+        const D2 l2n = lim2(ADV_W(2), ADV_W(3), ADV_W(4));                     // limit2_x of row k-1
         l2x[(U + 2) % 3] = l2n;
         if (k < i0 + 1 || k > i1 + 2) return;
-        const double Xm1 = Xr[(U + 1) % 3], Fxm1 = Fxr[U % 2];
+        const D2 Xm1 = Xr[(U + 1) % 3], Fxm1 = Fxr[U % 2];
         // ---- row c = k-2 (window index 2): limited slopes, interface states
-        const double sx = adv_slope<LIM>(l2b, l2c, l2n, ADV_W(1), ADV_W(2), ADV_W(3));
-        const double am = adv_m1(ADV_W(2)), ap = adv_p1(ADV_W(2));
-        const double l2y = (LIM != 0) ? limit2(am, ADV_W(2), ap) : 0.0;
-        const double l2ym = (LIM == 2) ? adv_m1(l2y) : 0.0, l2yp = (LIM == 2) ? adv_p1(l2y) : 0.0;
-        const double sy = adv_slope<LIM>(l2ym, l2y, l2yp, am, ADV_W(2), ap);
+        const D2 ac = ADV_W(2);
+        const D2 sx = slope(l2b, l2c, l2n, ADV_W(1), ac, ADV_W(3));
+        const D2 am = adv_left(ac), ap = adv_right(ac);
+        const D2 l2y = lim2(am, ac, ap);
+        const D2 l2ym = (LIM == 2) ? adv_left(l2y) : zero, l2yp = (LIM == 2) ? adv_right(l2y) : zero;
+        const D2 sy = slope(l2ym, l2y, l2yp, am, ac, ap);
         // upwind states of cell c (interface.py:25-41): its lower face if the
         // velocity is negative, its upper face otherwise
-        const double X = UNEG ? ADV_W(2) - 0.5 * (1.0 + cx) * sx : ADV_W(2) + 0.5 * (1.0 - cx) * sx;
-        const double Y = VNEG ? ADV_W(2) - 0.5 * (1.0 + cy) * sy : ADV_W(2) + 0.5 * (1.0 - cy) * sy;
+        const D2 X = UNEG ? D2{ac.a - 0.5 * (1.0 + cx) * sx.a, ac.b - 0.5 * (1.0 + cx) * sx.b}
+                          : D2{ac.a + 0.5 * (1.0 - cx) * sx.a, ac.b + 0.5 * (1.0 - cx) * sx.b};
+        const D2 Y = VNEG ? D2{ac.a - 0.5 * (1.0 + cy) * sy.a, ac.b - 0.5 * (1.0 + cy) * sy.b}
+                          : D2{ac.a + 0.5 * (1.0 - cy) * sy.a, ac.b + 0.5 * (1.0 - cy) * sy.b};
         // a_x on the lower x face of row c; a_y on the lower y faces of rows c, c-1
-        const double ax_c = UNEG ? X : Xm1;
+        const D2 ax_c = UNEG ? X : Xm1;
         // (the lower row's values are the previous iteration's: kept as they were used there,
-        // i.e. already shifted by a lane where the velocity is positive -- two DPP moves less each)
-        const double ay_c = VNEG ? Y : adv_m1(Y), ay_m = Yr[U % 2];
+        // i.e. already shifted by a column where the velocity is positive)
+        const D2 ay_c = VNEG ? Y : adv_left(Y), ay_m = Yr[U % 2];
         // F_x[c,j] = u*(a_x[c,j] - dtdy2*(F_yt[c+mx,j+1] - F_yt[c+mx,j]))
-        const double ayt = (mx == 0) ? ay_c : ay_m;
-        const double Fx = u * (ax_c - P.dtdy2 * (v * adv_p1(ayt) - v * ayt));
+        const D2 ayt = (mx == 0) ? ay_c : ay_m;
+        const D2 aytp = adv_right(ayt);
+        const D2 Fx{u * (ax_c.a - P.dtdy2 * (v * aytp.a - v * ayt.a)),
+                    u * (ax_c.b - P.dtdy2 * (v * aytp.b - v * ayt.b))};
         // ---- row g = c-1: F_y and the conservative update
-        const double axc_s = (my == 0) ? ax_c : adv_m1(ax_c);
-        const double axm_s = Axr[U % 2];                  // a_x of row c-1 at column j + my
+        const D2 axc_s = (my == 0) ? ax_c : adv_left(ax_c);
+        const D2 axm_s = Axr[U % 2];                  // a_x of row c-1 at column j + my
         if (k >= i0 + 3) {
             // F_y[g,j] = v*(a_y[g,j] - dtdx2*(F_xt[g+1,j+my] - F_xt[g,j+my]))
-            const double Fy = v * (ay_m - P.dtdx2 * (u * axc_s - u * axm_s));
-            const double Fyh = adv_p1(Fy);
-            if (jout)
-                aout[(size_t)(k - 3) * p + j] = ADV_W(1) + P.dtdx * (Fxm1 - Fx) + P.dtdy * (Fy - Fyh);
+            const D2 Fy{v * (ay_m.a - P.dtdx2 * (u * axc_s.a - u * axm_s.a)),
+                        v * (ay_m.b - P.dtdx2 * (u * axc_s.b - u * axm_s.b))};
+            const D2 Fyh = adv_right(Fy);
+            const D2 a1 = ADV_W(1);
+            const size_t ko = (size_t)(k - 3) * p + ja;
+            if (jout[0]) aout[ko] = a1.a + P.dtdx * (Fxm1.a - Fx.a) + P.dtdy * (Fy.a - Fyh.a);
+            if (jout[1]) aout[ko + 1] = a1.b + P.dtdx * (Fxm1.b - Fx.b) + P.dtdy * (Fy.b - Fyh.b);
         }
         Xr[(U + 2) % 3] = X;
         Yr[(U + 1) % 2] = ay_c;
@@ -205,12 +256,12 @@ __global__ __launch_bounds__(64) void k_adv_step(const double *__restrict__ ain,
         });
 }
 
-// rows per strip.  Measured (tools/adv_time.py): 16-20 rows at 2048^2 (enough
-// wavefronts for 4 per SIMD matter more than the 6 apron rows a strip re-reads),
-// 48-64 rows from 8192^2 on
+// rows per strip: two rounds of wavefronts at two per SIMD, within 16..64 rows (a strip
+// costs L + 6 iterations for L rows; with two cells per lane a wavefront carries the
+// instruction-level parallelism two wavefronts of the one-column kernel had)
 static int adv_rows(int nx, int ncb, int cus)
 {
-    const long slots = 16L * cus;       // 4 wavefronts per SIMD
+    const long slots = 16L * cus;
     int L = (int)(((long)nx * ncb + slots - 1) / slots);
     L = L < 16 ? 16 : (L > 64 ? 64 : L);
     return L < nx ? L : nx;
@@ -231,6 +282,43 @@ static void adv_launch(pyrohip_ctx *c, bool uneg, bool vneg, int nwg, const doub
         PYRO_LAUNCH(c, "k_adv_step", (k_adv_step<LIM, false, false>), grid, block, 0, cur, nxt, g, P);
 }
 
+// one step of variable n from `cur` into `nxt` (both laid out like a plane of the state)
+int adv_step_launch(pyrohip_state *s, int n, const pyrohip_adv_params *ap, double dt, const double *cur,
+                    double *nxt)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    const double u = ap->u, v = ap->v, dx = ap->dx, dy = ap->dy;
+    AdvParams P;
+    P.u = u; P.v = v; P.dt = dt; P.dx = dx; P.dy = dy; P.limiter = ap->limiter;
+    P.cx = u * dt / dx; P.cy = v * dt / dy;
+    P.dtdx2 = 0.5 * dt / dx; P.dtdy2 = 0.5 * dt / dy;
+    P.dtdx = dt / dx; P.dtdy = dt / dy;
+    P.ncb = (g.ny + AW_OUT - 1) / AW_OUT;
+    P.L = adv_rows(g.nx, P.ncb, c->num_cus > 0 ? c->num_cus : 256);
+    if (ap->march_rows > 0) P.L = ap->march_rows < g.nx ? (ap->march_rows < 4 ? 4 : ap->march_rows) : g.nx;
+    P.fill = ap->fill ? 1 : 0;
+    P.bxl = s->bc[n * 4 + 0]; P.bxr = s->bc[n * 4 + 1];
+    P.byl = s->bc[n * 4 + 2]; P.byr = s->bc[n * 4 + 3];
+    const int nwg = P.ncb * ((g.nx + P.L - 1) / P.L);
+    const bool uneg = (u < 0), vneg = (v < 0);   // interface.py:28,38
+    if (ap->limiter == 0) adv_launch<0>(c, uneg, vneg, nwg, cur, nxt, g, P);
+    else if (ap->limiter == 1) adv_launch<1>(c, uneg, vneg, nwg, cur, nxt, g, P);
+    else adv_launch<2>(c, uneg, vneg, nwg, cur, nxt, g, P);
+    PYRO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace PYRO_NS
+}  // namespace pyro
+
+#if !PYRO_FAST
+// ---- extern "C" entry points (in the bit-faithful unit; the contracted unit only adds
+// its kernel instances) ------------------------------------------------------------------
+namespace pyro {
+namespace fastm {
+int adv_step_launch(pyrohip_state *, int, const pyrohip_adv_params *, double, const double *, double *);
+}
 }  // namespace pyro
 
 using namespace pyro;
@@ -241,19 +329,20 @@ static bool simple_bc(int b)
            b == PYROHIP_BC_PERIODIC;
 }
 
-extern "C" int pyrohip_adv_step_fill(pyrohip_state *s, int n, double dx, double dy, double u,
-                                     double v, double dt, int limiter, int fill)
+extern "C" int pyrohip_adv_step_p(pyrohip_state *s, int n, const pyrohip_adv_params *ap, double dt)
 {
-    PYRO_REQUIRE(s, "NULL state");
+    PYRO_REQUIRE(s && ap, "NULL argument");
     PYRO_REQUIRE(n >= 0 && n < s->nvar, "variable index out of range");
     PYRO_REQUIRE(s->g.ng >= 4, "advection needs ng >= 4 (advection/simulation.py:20)");
-    PYRO_REQUIRE(limiter >= 0 && limiter <= 2, "limiter must be 0, 1 or 2");
+    PYRO_REQUIRE(ap->limiter >= 0 && ap->limiter <= 2, "limiter must be 0, 1 or 2");
+    PYRO_REQUIRE(ap->dx > 0.0 && ap->dy > 0.0, "bad dx / dy");
     pyrohip_ctx *c = s->ctx;
     const Geom &g = s->g;
-    if (fill)
+    if (ap->fill)
         for (int k = 0; k < 4; k++)
             PYRO_REQUIRE(simple_bc(s->bc[n * 4 + k]),
                          "fused ghost fill: outflow / reflect / periodic boundaries only");
+    PYRO_TRY(comm_wait_halo(s));
     // scratch plane for the new time level
     if (s->work_planes < 1) {
         if (s->work) PYRO_CHECK_HIP(hipFree(s->work));
@@ -263,26 +352,8 @@ extern "C" int pyrohip_adv_step_fill(pyrohip_state *s, int n, double dx, double 
     }
     double *cur = s->d + (size_t)n * g.plane;
     double *nxt = s->work + geom_lead(g);
-    AdvParams P;
-    P.u = u; P.v = v; P.dt = dt; P.dx = dx; P.dy = dy; P.limiter = limiter;
-    P.cx = u * dt / dx; P.cy = v * dt / dy;
-    P.dtdx2 = 0.5 * dt / dx; P.dtdy2 = 0.5 * dt / dy;
-    P.dtdx = dt / dx; P.dtdy = dt / dy;
-    P.ncb = (g.ny + AW_OUT - 1) / AW_OUT;
-    P.L = adv_rows(g.nx, P.ncb, c->num_cus > 0 ? c->num_cus : 256);
-    if (const char *e = getenv("PYRO_ADV_ROWS")) {   // tuning / test knob
-        const int r = atoi(e);
-        if (r > 0) P.L = r < g.nx ? (r < 4 ? 4 : r) : g.nx;
-    }
-    P.fill = fill ? 1 : 0;
-    P.bxl = s->bc[n * 4 + 0]; P.bxr = s->bc[n * 4 + 1];
-    P.byl = s->bc[n * 4 + 2]; P.byr = s->bc[n * 4 + 3];
-    const int nwg = P.ncb * ((g.nx + P.L - 1) / P.L);
-    const bool uneg = (u < 0), vneg = (v < 0);   // interface.py:28,38
-    if (limiter == 0) adv_launch<0>(c, uneg, vneg, nwg, cur, nxt, g, P);
-    else if (limiter == 1) adv_launch<1>(c, uneg, vneg, nwg, cur, nxt, g, P);
-    else adv_launch<2>(c, uneg, vneg, nwg, cur, nxt, g, P);
-    PYRO_CHECK_HIP(hipGetLastError());
+    PYRO_TRY(ap->fast_math ? fastm::adv_step_launch(s, n, ap, dt, cur, nxt)
+                           : exact::adv_step_launch(s, n, ap, dt, cur, nxt));
     if (s->nvar == 1) {
         // single-variable state: swap the two allocations
         double *old_base = s->base;
@@ -293,7 +364,17 @@ extern "C" int pyrohip_adv_step_fill(pyrohip_state *s, int n, double dx, double 
         PYRO_CHECK_HIP(hipMemcpyAsync(cur, nxt, g.plane * sizeof(double),
                                       hipMemcpyDeviceToDevice, c->stream));
     }
+    s->next_cfl_min = -1.0;
     return 0;
+}
+
+extern "C" int pyrohip_adv_step_fill(pyrohip_state *s, int n, double dx, double dy, double u,
+                                     double v, double dt, int limiter, int fill)
+{
+    pyrohip_adv_params ap;
+    memset(&ap, 0, sizeof(ap));
+    ap.dx = dx; ap.dy = dy; ap.u = u; ap.v = v; ap.limiter = limiter; ap.fill = fill;
+    return pyrohip_adv_step_p(s, n, &ap, dt);
 }
 
 extern "C" int pyrohip_adv_step(pyrohip_state *s, int n, double dx, double dy, double u, double v,
@@ -301,3 +382,4 @@ extern "C" int pyrohip_adv_step(pyrohip_state *s, int n, double dx, double dy, d
 {
     return pyrohip_adv_step_fill(s, n, dx, dy, u, v, dt, limiter, 0);
 }
+#endif

@@ -432,10 +432,18 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 const Cons Fxp = st_get(st, ST_FX);
                 const Cons &Uc = Uem;
                 Cons Un;   // simulation.py:377-384
+#if PYRO_FAST
+                const double cx = dtdV * Ax, cy = dtdV * Ay;
+                Un.d = fma(cx, Fxp.d - Fxn.d, fma(cy, Fy.d - Fyh.d, Uc.d));
+                Un.E = fma(cx, Fxp.E - Fxn.E, fma(cy, Fy.E - Fyh.E, Uc.E));
+                Un.mx = fma(cx, Fxp.mx - Fxn.mx, fma(cy, Fy.mx - Fyh.mx, Uc.mx));
+                Un.my = fma(cx, Fxp.my - Fxn.my, fma(cy, Fy.my - Fyh.my, Uc.my));
+#else
                 Un.d = Uc.d + dtdV * (Fxp.d * Ax - Fxn.d * Ax + Fy.d * Ay - Fyh.d * Ay);
                 Un.E = Uc.E + dtdV * (Fxp.E * Ax - Fxn.E * Ax + Fy.E * Ay - Fyh.E * Ay);
                 Un.mx = Uc.mx + dtdV * (Fxp.mx * Ax - Fxn.mx * Ax + Fy.mx * Ay - Fyh.mx * Ay);
                 Un.my = Uc.my + dtdV * (Fxp.my * Ax - Fxn.my * Ax + Fy.my * Ay - Fyh.my * Ay);
+#endif
                 const size_t ko = (size_t)(i - 1) * p + j;
                 if (P.have_src)   // simulation.py:406-423
                     grav_update(Un, Uc, UC(GRAV), UC(DT), UC(HEATR), P.heat ? P.heat[ko] : 0.0);
@@ -490,10 +498,6 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
     const int cus = c->num_cus > 0 ? c->num_cus : 256;
     P.L = wave_rows(g.nx, P.ncb, 4 * PYRO_WAVE_MINW * cus);
     if (p->march_rows > 0) P.L = p->march_rows < g.nx ? p->march_rows : g.nx;
-    else if (const char *e = getenv("PYRO_MARCH_ROWS")) {   // tuning knob (tools/march_ab.sh)
-        const int r = atoi(e);
-        if (r > 0) P.L = r < g.nx ? r : g.nx;
-    }
     int nsb = (g.nx + P.L - 1) / P.L;
     // a last strip shorter than the ghost width joins its predecessor: the boundary
     // strips of a slab must hold the ng rows the neighbour receives as its halo

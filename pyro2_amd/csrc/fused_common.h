@@ -57,10 +57,18 @@ __device__ __forceinline__ Cons corr(const Cons &U, const Cons &Fhi, const Cons 
                                      double A)
 {
     Cons r;   // U += -hdtV*(F_hi*A - F_lo*A), unsplit_fluxes.py:447-471
+#if PYRO_FAST
+    const double k = -hdtV * A;     // fast build: one product, one fma per component
+    r.d = fma(k, Fhi.d - Flo.d, U.d);
+    r.E = fma(k, Fhi.E - Flo.E, U.E);
+    r.mx = fma(k, Fhi.mx - Flo.mx, U.mx);
+    r.my = fma(k, Fhi.my - Flo.my, U.my);
+#else
     r.d = U.d + (-hdtV * (Fhi.d * A - Flo.d * A));
     r.E = U.E + (-hdtV * (Fhi.E * A - Flo.E * A));
     r.mx = U.mx + (-hdtV * (Fhi.mx * A - Flo.mx * A));
     r.my = U.my + (-hdtV * (Fhi.my * A - Flo.my * A));
+#endif
     return r;
 }
 
@@ -82,6 +90,21 @@ __device__ __forceinline__ double slope_shared(double l2m, double l20, double l2
 // the same operands when rho != 0 (bit-identical), zeros otherwise
 __device__ __forceinline__ Prim cons_to_prim_nb(const Cons &U, double gamma, bool &ok)
 {
+#if PYRO_FAST
+    // fast build: no guard for rho == 0 (a state the reference's assert rejects anyway:
+    // the quotients become NaN and `ok` comes out false), pressure without the detour
+    // through the specific internal energy
+    {
+        const double rd = prcp(U.d);
+        Prim q;
+        q.r = U.d;
+        q.u = U.mx * rd;
+        q.v = U.my * rd;
+        q.p = fma(-0.5, fma(U.my, q.v, U.mx * q.u), U.E) * (gamma - 1.0);
+        ok = (q.p > 0.0) && (U.d > 0.0);
+        return q;
+    }
+#else
     const bool nz = (U.d != 0.0);
     const double ds = nz ? U.d : 1.0;
     const double rd = PYRO_FAST ? prcp(ds) : 0.0;
@@ -96,5 +119,6 @@ __device__ __forceinline__ Prim cons_to_prim_nb(const Cons &U, double gamma, boo
     q.p = U.d * es * (gamma - 1.0);
     ok = (es > 0.0) && (U.d > 0.0);
     return q;
+#endif
 }
 

@@ -379,11 +379,13 @@ class DeviceState:
         return mn.value, mx.value
 
     # ---- solvers ------------------------------------------------------
-    def adv_step(self, n, dx, dy, u, v, dt, limiter, fill=False):
-        """fill: fold the ghost fill of variable n into the step (one launch)"""
+    def adv_step(self, n, dx, dy, u, v, dt, limiter, fill=False, fast_math=0, march_rows=0):
+        """fill: fold the ghost fill of variable n into the step (one launch);
+        fast_math: the contracted build (1e-12) instead of the bit-faithful one"""
+        from ._lib import AdvParams
+        ap = AdvParams(dx, dy, u, v, int(limiter), int(bool(fill)), int(fast_math), int(march_rows))
         with self.ctx.lock:
-            check(self._l.pyrohip_adv_step_fill(self.h, int(n), dx, dy, u, v, dt, int(limiter),
-                                                int(bool(fill))))
+            check(self._l.pyrohip_adv_step_p(self.h, int(n), C.byref(ap), dt))
 
     def comp_dt(self, params, cfl):
         dt = C.c_double()

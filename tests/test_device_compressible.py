@@ -383,7 +383,9 @@ def test_comp_fast_algebra_supersonic(dev, kset):
     the collapsed star-region flux and the outer-state fluxes) against the bit-faithful build
     on a flow that takes every branch: a Mach-3 stream in +x / -y over half of the domain
     (supersonic faces of both signs in both directions), a counter-stream, a blast and a
-    smooth density field; reflecting walls in y put -0.0 momenta into the ghost cells (the
+    smooth density field (velocities vary smoothly inside each stream: with an exactly uniform
+    velocity the flattening switch u(-1) - u(+1) > 0 would hang on the rounding noise of
+    momentum / density); reflecting walls in y put -0.0 momenta into the ghost cells (the
     sign BIT picks the upwind side, like np.copysign).  On the emulator both builds divide
     exactly, so the difference is the re-association alone: element-wise 1e-12 after 6
     steps; on the GPU the fast-build tolerance."""
@@ -398,8 +400,8 @@ def test_comp_fast_algebra_supersonic(dev, kset):
     p = 1.0e-2 * (1.0 + 0.5 * np.cos(3 * x) * np.sin(4 * y))
     p += 2.0 * np.exp(-((x - 0.5) ** 2 + (y - 0.45) ** 2) * 400.0)
     c = np.sqrt(1.4 * p / rho)
-    u = np.where(y < 0.5, 3.0, -2.5) * c.mean() * np.ones_like(x)
-    v = np.where(x < 0.5, -3.0, 2.0) * c.mean() * np.ones_like(y)
+    u = np.where(y < 0.5, 3.0, -2.5) * c.mean() * (1.0 + 0.2 * np.sin(9 * x + 2 * y))
+    v = np.where(x < 0.5, -3.0, 2.0) * c.mean() * (1.0 + 0.2 * np.cos(4 * x - 7 * y))
     v[:, :6] = 0.0          # at rest next to the lower wall: exact zeros, -0.0 in its ghosts
     ic[..., 0] = rho
     ic[..., 2] = rho * u

@@ -9,15 +9,16 @@ for nx in (2048, 8192):
     X, Y = np.meshgrid(x, x, indexing="ij")
     ic = 1.0 + np.exp(-60.0 * ((X - 0.5) ** 2 + (Y - 0.5) ** 2))
     for rows in os.environ.get("ROWS", "0").split(","):
-        os.environ["PYRO_ADV_ROWS"] = rows
+      for fast in (1, 0):
         st = device.DeviceState(ctx, nx, nx, 4, [["periodic"] * 4])
         st.upload(ic)
         dt = 0.8 / nx
-        for fused in (1, 0):
+        for fused in (1,):
             def step():
                 if not fused:
                     st.fill_bc()
-                st.adv_step(0, 1 / nx, 1 / nx, 1.0, 1.0, dt, 2, fill=bool(fused))
+                st.adv_step(0, 1 / nx, 1 / nx, 1.0, 1.0, dt, 2, fill=bool(fused), fast_math=fast,
+                            march_rows=int(rows))
             for _ in range(10): step()
             ctx.sync(); ctx.prof_enable(True)
             n = 200 if nx <= 2048 else 50
@@ -26,5 +27,5 @@ for nx in (2048, 8192):
             ctx.sync(); t1 = time.perf_counter()
             prof = ctx.prof_report(); ctx.prof_enable(False)
             k, ms = prof["k_adv_step"]
-            print(f"nx={nx} rows={rows} fused={fused} step {1e6*(t1-t0)/n:8.1f} us  kernel {1e3*ms/k:8.1f} us  "
+            print(f"nx={nx} rows={rows} fast={fast} fused={fused} step {1e6*(t1-t0)/n:8.1f} us  kernel {1e3*ms/k:8.1f} us  "
                   f"{16*nx*nx/(ms/k*1e-3)/1e12:.2f} TB/s kernel, {16*nx*nx*n/(t1-t0)/1e12:.2f} TB/s step")
