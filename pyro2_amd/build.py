@@ -17,6 +17,11 @@ LIB = os.path.join(LIBDIR, os.environ.get("PYRO_LIB_NAME", "libpyrohip.so"))
 EXTRA = os.environ.get("PYRO_EXTRA_FLAGS", "").split()   # developer experiments only
 FAST_EXTRA = os.environ.get("PYRO_FAST_EXTRA_FLAGS", "").split()   # ... fast_math units only
 
+# scheduling strategy of the row-marching compressible kernel (developer experiments:
+# PYRO_WAVE_SCHED=default builds it with the compiler's own choice)
+_WS = os.environ.get("PYRO_WAVE_SCHED", "max-ilp")
+WAVE_SCHED = [] if _WS == "default" else ["-mllvm", f"-amdgpu-sched-strategy={_WS}"]
+
 ARCH = "gfx950"
 COMMON = ["-std=c++17", "-fPIC", "-O3"]
 
@@ -32,10 +37,8 @@ UNITS = [
     ("comp_fused.hip", "fused_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1"]),
     # max-ilp scheduling: the row-marching kernel runs two wavefronts per SIMD, what
     # hides latency there is independent work inside a wavefront (12.30 -> 12.15 ms)
-    ("comp_wave.hip", "wave_exact", ["-ffp-contract=off", "-DPYRO_FAST=0", "-mllvm",
-                                     "-amdgpu-sched-strategy=max-ilp"]),
-    ("comp_wave.hip", "wave_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1", "-mllvm",
-                                    "-amdgpu-sched-strategy=max-ilp"]),
+    ("comp_wave.hip", "wave_exact", ["-ffp-contract=off", "-DPYRO_FAST=0"] + WAVE_SCHED),
+    ("comp_wave.hip", "wave_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1"] + WAVE_SCHED),
     ("comp_api.hip", "comp_api", ["-ffp-contract=off"]),
     ("multigrid.hip", "multigrid", ["-ffp-contract=off"]),
     ("mg_march.hip", "mg_march", ["-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=200000"]),

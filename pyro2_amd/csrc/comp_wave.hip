@@ -127,6 +127,18 @@ enum { C_GAMMA, C_DX, C_DY, C_DT, C_Z0, C_Z1, C_DELTA, C_CVISC, C_SMALLD, C_DTDX
        C_DTDV, C_GRAV, C_HEATR, C_GM1, C_RGM1, C_RDX, C_RDY, C_KSL, C_KSR, C_RGP1, C_N };
 constexpr size_t WLDS_BYTES = (size_t)(ST_SLOTS * 64 + C_N) * sizeof(double);
 #define UC(name) (ct[C_##name])
+// an entry only one of the two builds uses (the table reads are volatile: an unused one
+// would still be issued)
+#if defined(PYRO_EMU)     // (the emulated fast build divides by the operand, not by its reciprocal)
+#define UC_FAST(name) UC(name)
+#define UC_EXACT(name) UC(name)
+#elif PYRO_FAST
+#define UC_FAST(name) UC(name)
+#define UC_EXACT(name) 0.0
+#else
+#define UC_FAST(name) 0.0
+#define UC_EXACT(name) UC(name)
+#endif
 #define UC_GASK() GasK{UC(GAMMA), UC(KSL), UC(KSR), UC(RGP1)}
 // (an explicit LDS pointer type: a plain `volatile double *` is a generic pointer
 // that the address-space inference leaves alone, i.e. flat loads through vmcnt)
@@ -234,6 +246,9 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         Uem = Ue;
         Ue = Urep;
         if (row_in(k - 3) && jin) Ue.d = fmax(Ue.d, UC(SMALLD));      // clean_state
+        // (issuing this second read of row k-2 in the middle of the iteration instead -- eight
+        // registers less while the slopes and the first Riemann problems are worked on -- was
+        // measured: the allocator spills elsewhere, 10.35 vs 10.46 ms fast, 16.37 vs 15.96 exact)
         Urep = loadU(k - 2);
         // ---- S0: row k -> primitives
         {
@@ -325,8 +340,8 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             // vertex divergence at (i-1/2, j-1/2), interface.py:312-330, and the
             // artificial viscosity coefficients of the faces (i, j) in x and (i-1, j)
             // in y (interface.py:366-376: only faces i in [ilo, ihi], j in [jlo, jhi])
-            Dn = div_u_vertex_r(q0[1], um, qm[1], up, q0[2], qm[2], vm, vp, UC(DX), UC(DY), UC(RDX),
-                                UC(RDY));
+            Dn = div_u_vertex_r(q0[1], um, qm[1], up, q0[2], qm[2], vm, vp, UC_EXACT(DX), UC_EXACT(DY),
+                                UC_FAST(RDX), UC_FAST(RDY));
             const double Dn_p = lane_p1(Dn);
             double avx = 0.0, avy = 0.0;
             if (i >= g.ilo && (i <= g.ihi || (P.avx_hi && i == g.ihi + 1)) && jin) {
@@ -343,7 +358,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             double gamma = UC(GAMMA);
             trace_states(q0[0], q0[1], q0[2], q0[3], dqx[0], dqx[1], dqx[2], dqx[3], gamma,
                          UC(DTDX), lo, hi);
-            double gm1 = UC(GM1), rgm1 = UC(RGM1);
+            double gm1 = UC_EXACT(GM1), rgm1 = UC_FAST(RGM1);
             Cons XMn = prim_to_cons_g(Prim{lo.r, lo.un, lo.ut, lo.p}, gm1, rgm1);
             Cons XPn = prim_to_cons_g(Prim{hi.r, hi.un, hi.ut, hi.p}, gm1, rgm1);
             FaceQ qxm{lo.un, lo.ut, lo.p}, qxp{hi.un, hi.ut, hi.p};
@@ -352,7 +367,10 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 add_grav_to_state(XPn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
                 if (TQ) { qxm = faceq(to_nf(XMn, true), gamma); qxp = faceq(to_nf(XPn, true), gamma); }
             }
-            Cons FxTn{0.0, 0.0, 0.0, 0.0};
+            // (not initialised: FxTn / Fy / Fyh / Fxn are read only under the wave-uniform
+            // conditions they are computed under -- xface / frow -- and an initial value
+            // costs four register moves each in every iteration)
+            Cons FxTn;
             if (xface) {
                 if (TQ) {
                     const FaceQ ql{st[ST_XPQ * 64], st[(ST_XPQ + 1) * 64], st[(ST_XPQ + 2) * 64]};
@@ -368,7 +386,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             }
             STAGE_FENCE();
             // -- row f: y states corrected with FxT of rows f, f+1; final y flux
-            Cons Fy{0.0, 0.0, 0.0, 0.0}, Fyh = Fy;
+            Cons Fy, Fyh;
             if (frow) {
                 const Cons FxTp = st_get(st, ST_FXT);
                 const double hdtV = UC(HDTV), Ax = UC(DY);
@@ -383,13 +401,13 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 Fy.my += avy * (Umy.my - Uem.my);
                 Fyh = lane_p1(Fy);
             }
-            st_put(st, ST_FXT, FxTn);
+            if (xface) st_put(st, ST_FXT, FxTn);
             STAGE_FENCE();
             // -- y states of row c, transverse y flux on its lower face
             gamma = UC(GAMMA);
             trace_states(q0[0], q0[2], q0[1], q0[3], dqy[0], dqy[2], dqy[1], dqy[3], gamma,
                          UC(DTDY), lo, hi);
-            gm1 = UC(GM1); rgm1 = UC(RGM1);
+            gm1 = UC_EXACT(GM1); rgm1 = UC_FAST(RGM1);
             Cons YMn = prim_to_cons_g(Prim{lo.r, lo.ut, lo.un, lo.p}, gm1, rgm1);
             Cons YPn = prim_to_cons_g(Prim{hi.r, hi.ut, hi.un, hi.p}, gm1, rgm1);
             FaceQ qym{lo.un, lo.ut, lo.p}, qyp{hi.un, hi.ut, hi.p};
@@ -414,8 +432,11 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             const double hdtV = UC(HDTV), Ay = UC(DX);
             const Cons XMc = corr(XMn, FyTh, FyT, hdtV, Ay);
             const Cons XPc = corr(XPn, FyTh, FyT, hdtV, Ay);
-            st_put(st, ST_XP, XPn);
-            Cons Fxn{0.0, 0.0, 0.0, 0.0};
+            if (TQ) {   // the next row's transverse problem reads (rho, E) + ST_XPQ only
+                st[ST_XP * 64] = XPn.d; st[(ST_XP + 1) * 64] = XPn.E;
+            } else
+                st_put(st, ST_XP, XPn);
+            Cons Fxn;
             if (xface) {
                 Fxn = from_nf(riemann_face<SOLVER>(to_nf(st_get(st, ST_XPC), true), to_nf(XMc, true),
                                                    UC_GASK(), true, P.solid_xl && i == g.ilo), true);
@@ -461,7 +482,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 st[ST_AX * 64] = fmax(st[ST_AX * 64], ax);
                 st[ST_AY * 64] = fmax(st[ST_AY * 64], ay);
             }
-            st_put(st, ST_FX, Fxn);
+            if (xface) st_put(st, ST_FX, Fxn);
         }
         // hand the rows on
         fxa = fxb; fxb = fxn;
@@ -479,11 +500,28 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
 // dispatch evens out the tail, within 32..128 rows (a strip costs L + 8
 // iterations).  Measured at 16384^2: 128 rows 11.91 ms, 400 rows 12.17 ms,
 // 600 rows 12.36 ms (profiles/r02_kernel_sets_by_size.txt)
+// Below ~10 rounds the LAST round matters: 8214 wavefronts on 2048 slots (4096^2 with
+// 37-row strips) run a fifth round for 22 of them.  So the strip length is the one that
+// minimises  (rounds + 1/2) x (L + 8)  (rounds = wavefronts / resident slots, half a strip
+// for the tail of the dynamic dispatch, L + 8 iterations per strip; exactly one strip time
+// when everything is resident at once) over 32 .. 160 rows, the shorter strip winning a tie
+// within 1 % (row re-reads hit the L2 of the neighbouring column strips while those are
+// close in time).
 static int wave_rows(int nx, int ncb, int slots)
 {
-    long L = ((long)nx * ncb) / (4L * slots);
-    L = L < 32 ? 32 : (L > 128 ? 128 : L);
-    return L < nx ? (int)L : nx;
+    if (nx <= 32) return nx;
+    long best_cost = -1;
+    int best = 32;
+    for (int L = 32; L <= 160 && L <= nx; L++) {
+        int nsb = (nx + L - 1) / L;
+        if (nsb > 1 && nx - (nsb - 1) * L < 4) nsb--;        // short last strip joins its predecessor
+        const int Leff = (nx + nsb - 1) / nsb;                // longest strip
+        const long waves = (long)ncb * nsb;
+        // in units of 1 / (2 slots) strip iterations
+        const long cost = (waves <= slots ? 2L * slots : 2 * waves + slots) * (Leff + 8);
+        if (best_cost < 0 || cost * 100 < best_cost * 99) { best_cost = cost; best = L; }
+    }
+    return best;
 }
 
 int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
@@ -496,7 +534,7 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
     PYRO_TRY(fused_prepare(s, p, dt, P, Uin, Uout, S == nullptr));
     P.ncb = (g.ny + WOUT - 1) / WOUT;
     const int cus = c->num_cus > 0 ? c->num_cus : 256;
-    P.L = wave_rows(g.nx, P.ncb, 4 * PYRO_WAVE_MINW * cus);
+    P.L = wave_rows(g.nx, P.ncb, 4 * PYRO_WAVE_MINW * cus);      // slots: wavefronts resident at once
     if (p->march_rows > 0) P.L = p->march_rows < g.nx ? p->march_rows : g.nx;
     int nsb = (g.nx + P.L - 1) / P.L;
     // a last strip shorter than the ghost width joins its predecessor: the boundary

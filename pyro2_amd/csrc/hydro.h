@@ -317,7 +317,7 @@ __device__ __forceinline__ void trace_states(double r, double un, double ut, dou
     hi.r = fma(gp, a1, hi.r);   hi.ut = fma(gp, dut, hi.ut);
     lo.r = fma(-gm, a1, lo.r);  lo.ut = fma(-gm, dut, lo.ut);
     // the acoustic waves that run AGAINST their usual direction: supersonic flow only
-    if (!__builtin_signbit(e0) || e3 < 0.0) {
+    if (__builtin_expect(!__builtin_signbit(e0) || e3 < 0.0, 0)) {
         const double t = r * dun, hrcs = 0.5 * rcs, w2 = w + w;
         const double a0 = hrcs * fma(rcs, dp, -t);
         const double a3 = hrcs * fma(rcs, dp, t);
@@ -526,7 +526,7 @@ __device__ __forceinline__ void estimate_wave_speed_fast(double rho_l, double u_
     const double gamma = K.gamma;
     const double p_max = fmax(p_l, p_r), p_min = fmin(p_l, p_r);
     double pstar = fma(0.125 * (u_l - u_r), (rho_l + rho_r) * (c_l + c_r), 0.5 * (p_l + p_r));
-    if (p_max > 2.0 * p_min && (pstar < p_min || pstar > p_max)) {      // riemann.py:621-658
+    if (__builtin_expect(p_max > 2.0 * p_min && (pstar < p_min || pstar > p_max), 0)) {      // riemann.py:621-658
         if (pstar < p_min) {   // two-rarefaction, :626-638
             double z = pdiv(gamma - 1.0, 2.0 * gamma);
             double p_lr = pow(pdiv(p_l, p_r), z);
@@ -588,9 +588,12 @@ __device__ __forceinline__ ConsN hllc_flux_impl(const ConsN &Ul, const ConsN &Ur
     const double d_l = S_l - un_l, d_r = S_r - un_r;
     const double a_l = rho_l * d_l, a_r = rho_r * d_r;
     const double S_c = fma(-a_r, un_r, fma(a_l, un_l, p_r - p_l)) * prcp(a_l - a_r);
-    // physical flux of an outer state (supersonic faces)
-    auto outer = [&](const ConsN &U, double un, double pf) {
-        return ConsN{U.d * un, (U.E + pf) * un, fma(U.mn, un, pf), U.mt * un};
+    // physical flux of an outer state (supersonic faces).  With the primitives given the
+    // momenta of the conserved state are never touched (rho u, rho v are formed here, on the
+    // rare path), so a caller that moves the state between lanes moves density and energy only
+    auto outer = [&](const ConsN &U, double un, double ut, double pf) {
+        const double mn = HAVEQ ? U.d * un : U.mn, mt = HAVEQ ? U.d * ut : U.mt;
+        return ConsN{U.d * un, (U.E + pf) * un, fma(mn, un, pf), mt * un};
     };
     auto star = [&](double un, double ut, double p, double E, double S, double d, double a) {
         const double dS = S_c - un;
@@ -606,10 +609,10 @@ __device__ __forceinline__ ConsN hllc_flux_impl(const ConsN &Ul, const ConsN &Ur
         return F;
     };
     // riemann.py:784-856: S_r <= 0 | S_c <= 0 < S_r | S_l < 0 < S_c | else
-    if (S_r <= 0.0) return outer(Ur, un_r, pf_r);
+    if (__builtin_expect(S_r <= 0.0, 0)) return outer(Ur, un_r, ut_r, pf_r);
     if (S_c <= 0.0) return star(un_r, ut_r, p_r, Ur.E, S_r, d_r, a_r);
-    if (S_l < 0.0) return star(un_l, ut_l, p_l, Ul.E, S_l, d_l, a_l);
-    return outer(Ul, un_l, pf_l);
+    if (__builtin_expect(S_l < 0.0, 1)) return star(un_l, ut_l, p_l, Ul.E, S_l, d_l, a_l);
+    return outer(Ul, un_l, ut_l, pf_l);
 }
 #else
 template <bool HAVEQ>

@@ -4,12 +4,14 @@ sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
 from pyro2_amd import device
 ctx = device.Context(0)
-for nx in (2048, 8192):
+# SIZES="2048:0,12,13;8192:32,64" (rows 0 = the library's choice)
+SPEC = os.environ.get("SIZES", "2048:0;8192:0")
+for nx, rows_list in [(int(a.split(":")[0]), a.split(":")[1]) for a in SPEC.split(";")]:
     x = (np.arange(nx + 8) - 3.5) / nx
     X, Y = np.meshgrid(x, x, indexing="ij")
     ic = 1.0 + np.exp(-60.0 * ((X - 0.5) ** 2 + (Y - 0.5) ** 2))
-    for rows in os.environ.get("ROWS", "0").split(","):
-      for fast in (1, 0):
+    for rows in rows_list.split(","):
+      for fast in (1, 0) if os.environ.get("BOTH", "0") == "1" else (1,):
         st = device.DeviceState(ctx, nx, nx, 4, [["periodic"] * 4])
         st.upload(ic)
         dt = 0.8 / nx

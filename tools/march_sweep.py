@@ -1,0 +1,29 @@
+"""developer tool (GPU box): compressible step time by grid size and strip length of the
+row-marching kernel.  SIZES="4096:0,37,76,152;8192:0,128,149" (0 = the library's choice)"""
+import os, sys, time
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+from pyro2_amd import device
+from pyro2_amd.compressible.problems.sedov import sedov_state
+from pyro2_amd.decomp import DtPolicy
+ctx = device.Context(0)
+SPEC = os.environ.get("SIZES", "4096:0;8192:0")
+FM = int(os.environ.get("FM", "1"))
+for nx, rows_list in [(int(a.split(":")[0]), a.split(":")[1]) for a in SPEC.split(";")]:
+    ic = None
+    for rows in rows_list.split(","):
+        st = device.DeviceState(ctx, nx, nx, 4, [["outflow"] * 4] * 4)
+        for r0 in range(0, nx + 8, 512):
+            nr = min(512, nx + 8 - r0)
+            st.upload_rows(r0, sedov_state(nx, nx, 4, 0.0, 1.0, 0.0, 1.0, 1.4, 0.01, 4, i0=r0, ni=nr))
+        P = device.make_comp_params(1.0 / nx, 1.0 / nx, fast_math=FM, kernel_set=2, march_rows=int(rows))
+        pol = DtPolicy(1.0e9)
+        st.comp_evolve(P, 0.8, pol, 5)
+        ctx.sync()
+        n = max(10, int(2.0e9 / (nx * nx)))
+        t0 = time.perf_counter()
+        st.comp_evolve(P, 0.8, pol, n)
+        ctx.sync()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        print(f"nx={nx} march_rows={rows} fm={FM}: {ms:8.3f} ms/step  {nx * nx / ms / 1e6:6.2f} Gcell/s", flush=True)
+        del st
