@@ -52,9 +52,15 @@ namespace pyro {
 namespace PYRO_NS {
 
 constexpr int AW_OUT = 120;       // columns a wavefront updates (64 lanes x 2 - 8 apron)
-// rows loaded ahead of their use (one: the next row's loads are issued while this row is
-// worked on; more bought nothing in the one-column kernel either)
-constexpr int ADV_PF = 1;
+// rows loaded ahead of their use.  PMC (profiles/r03_adv_pmc.json): with ONE row ahead a
+// wavefront sat in s_waitcnt for 33 % (2048^2) / 53 % (8192^2) of its cycles -- an
+// iteration is ~1800 cycles, a load under traffic takes longer.  The rows in flight have a
+// small ring of their own (its length divides the period of the others, so the loop is still
+// unrolled 6 times; a row costs one register move when it enters the stencil window).
+#ifndef PYRO_ADV_PF
+#define PYRO_ADV_PF 3
+#endif
+constexpr int ADV_PF = PYRO_ADV_PF;
 
 constexpr int adv_gcd(int a, int b) { return b == 0 ? a : adv_gcd(b, a % b); }
 constexpr int adv_lcm(int a, int b) { return a / adv_gcd(a, b) * b; }
@@ -76,7 +82,7 @@ struct AdvParams {
     double cx, cy;          // u*dt/dx, v*dt/dy          interface.py:10-11
     double dtdx2, dtdy2;    // 0.5*dt/dx, 0.5*dt/dy      advective_fluxes.py:60-61
     double dtdx, dtdy;      // dt/dx, dt/dy              simulation.py:63-64
-    int ncb, L;             // column strips, rows per strip
+    int ncb, L, nunits;     // column strips, rows per strip, strips in all
     int fill;               // fold the ghost fill into the loads
     int bxl, bxr, byl, byr; // boundary types of the variable (fill)
 };
@@ -118,14 +124,29 @@ __device__ __forceinline__ double adv_slope(double l2m, double l20, double l2p, 
 }
 
 // LIM: limiter (0 none, 1 MC2, 2 MC4); UNEG / VNEG: u < 0 / v < 0 (upwind side)
+// wavefronts per workgroup (they do not cooperate: no LDS, no barrier).  Four per workgroup,
+// so that the dispatcher hands out four strips at a time, was measured: 24.3 vs 23.2 us at
+// 2048^2, 267 vs 261 us at 8192^2 -- one it is.
+#ifndef PYRO_ADV_WPB
+#define PYRO_ADV_WPB 1
+#endif
+constexpr int ADV_WPB = PYRO_ADV_WPB;
+
 template <int LIM, bool UNEG, bool VNEG>
-__global__ __launch_bounds__(64) void k_adv_step(const double *__restrict__ ain,
-                                                 double *__restrict__ aout, Geom g, AdvParams P)
+__global__ __launch_bounds__(64 * ADV_WPB) void k_adv_step(const double *__restrict__ ain,
+                                                           double *__restrict__ aout, Geom g, AdvParams P)
 {
-    const int l = threadIdx.x;
+    const int l = threadIdx.x & 63;
     // (the quotient is computed by vector instructions; without the hint the strip's row
     // range, the loop counter and every row offset derived from them stay in vector registers)
-    const int cb = pyro_uniform(blockIdx.x % P.ncb), sb = pyro_uniform(blockIdx.x / P.ncb);
+    // workgroup -> strip: workgroups are dealt round-robin to the 8 XCDs (each with its own
+    // L2); XCD x takes the strips [x per, (x + 1) per) in order, so the strips that share
+    // apron rows and the cache lines at a column cut meet in ONE L2 at about the same time
+    const int wg = (int)blockIdx.x * ADV_WPB + (int)(threadIdx.x >> 6);
+    const int per = (P.nunits + 7) / 8;
+    const int unit = pyro_uniform((wg % 8) * per + wg / 8);
+    if (unit >= P.nunits) return;
+    const int cb = pyro_uniform(unit % P.ncb), sb = pyro_uniform(unit / P.ncb);
     const int i0 = g.ilo + sb * P.L;                       // strip rows [i0, i1)
     const int i1 = (i0 + P.L < g.ihi + 1) ? i0 + P.L : g.ihi + 1;
     const int ja = g.jlo + cb * AW_OUT - 4 + 2 * l;        // this lane's columns ja, ja + 1
@@ -159,27 +180,43 @@ __global__ __launch_bounds__(64) void k_adv_step(const double *__restrict__ ain,
     // source row of array row k under the ghost fill; its sign goes with the value
     auto row_src = [&](int k) { return bc_src(mr, k > kb ? kb : k, g.ilo, g.ihi); };
     const bool odd_lo = mr.odd_lo, odd_hi = mr.odd_hi;
+    // (two 8-byte accesses per lane and row.  One 16-byte access where the two cells are
+    // neighbours in memory -- whole cache lines per instruction -- was measured: the second
+    // code path for remapped / ragged lanes costs more than it saves, 277-281 vs 262-269 us
+    // at 8192^2)
     auto load_row = [&](int k) {
         const size_t r = (size_t)row_src(k) * p;
         return D2{ain[r + js[0]], ain[r + js[1]]};
+    };
+    auto store2 = [&](size_t k0, bool s0, bool s1, const D2 &val) {
+        if (s0) aout[k0] = val.a;
+        if (s1) aout[k0 + 1] = val.b;
     };
 
     // The rows the march carries from one iteration to the next live in rings that are indexed
     // at compile time: the loop is unrolled over the least common period of the rings, so
     // a value stays in the register it was computed into until it is dead.
-    //   rows   a of rows k-4 .. k (the stencil window) and k+1 .. k+ADV_PF (loads in flight)
+    //   rows   a of rows k-4 .. k (the stencil window);  pre  rows k .. k+ADV_PF-1 (loads in flight)
     //   l2x    limit2_x of rows k-3, k-2, k-1
     //   X      x states of rows c-2, c-1, c  (c = k-2);  Y, Ax, Fx  a_y / a_x (as used: at column
     //          j-1 / j+my) and F_x of rows c-1, c
-    constexpr int NR = 5 + ADV_PF, UNR = adv_lcm(NR, 6);
-    static_assert(UNR % NR == 0 && UNR % 3 == 0 && UNR % 2 == 0 && UNR <= 36, "ring periods");
+    // (where the loop closes the compiler's s_waitcnt bookkeeping falls back to draining
+    // nearly all loads in flight -- vmcnt(2) instead of vmcnt(6) -- once per trip; unrolling
+    // over two or three periods was measured and changes nothing)
+#ifndef PYRO_ADV_UNR
+#define PYRO_ADV_UNR 1
+#endif
+    constexpr int NR = 6, UNR = PYRO_ADV_UNR * adv_lcm(NR, 6);
+    static_assert(UNR % NR == 0 && UNR % 3 == 0 && UNR % 2 == 0 && UNR % ADV_PF == 0 && UNR <= 36,
+                  "ring periods");
     const D2 zero{0.0, 0.0};
     D2 rows[NR], l2x[3] = {zero, zero, zero}, Xr[3] = {zero, zero, zero}, Yr[2] = {zero, zero},
        Axr[2] = {zero, zero}, Fxr[2] = {zero, zero};
 #pragma unroll
     for (int n = 0; n < NR; n++) rows[n] = zero;
+    D2 pre[ADV_PF];
 #pragma unroll
-    for (int n = 0; n < ADV_PF; n++) rows[4 + n] = load_row(ka + n);
+    for (int n = 0; n < ADV_PF; n++) pre[n] = load_row(ka + n);
     // per cell functions of the two-cell rows
     auto lim2 = [&](const D2 &m, const D2 &c, const D2 &q) {
         return (LIM != 0) ? D2{limit2(m.a, c.a, q.a), limit2(m.b, c.b, q.b)} : zero;
@@ -193,14 +230,14 @@ __global__ __launch_bounds__(64) void k_adv_step(const double *__restrict__ ain,
         // window row n (row k-4+n) and in-flight row n (row k+1+n)
 #define ADV_W(n) rows[(U + (n)) % NR]
         {   // row k arrives (through the ghost fill's index map), row k+ADV_PF leaves
-            const D2 raw = ADV_W(4);
-            rows[(U + 4 + ADV_PF) % NR] = load_row(k + ADV_PF);
+            const D2 raw = pre[U % ADV_PF];
+            pre[U % ADV_PF] = load_row(k + ADV_PF);
             const bool neg_r = (k < g.ilo && odd_lo) || (k > g.ihi && odd_hi);
             ADV_W(4) = D2{(neg_c[0] != neg_r) ? -raw.a : raw.a, (neg_c[1] != neg_r) ? -raw.b : raw.b};
             // ghost frame of the new buffer
             const bool rghost = (k < g.ilo || k > g.ihi), kin = (k >= i0 && k < i1);
-            if (jown[0] && (rghost || (jghost[0] && kin))) aout[(size_t)k * p + ja] = ADV_W(4).a;
-            if (jown[1] && (rghost || (jghost[1] && kin))) aout[(size_t)k * p + ja + 1] = ADV_W(4).b;
+            store2((size_t)k * p + ja, jown[0] && (rghost || (jghost[0] && kin)),
+                   jown[1] && (rghost || (jghost[1] && kin)), ADV_W(4));
         }
         const D2 l2b = l2x[U % 3], l2c = l2x[(U + 1) % 3];
         const D2 l2n = lim2(ADV_W(2), ADV_W(3), ADV_W(4));                     // limit2_x of row k-1
@@ -240,8 +277,9 @@ __global__ __launch_bounds__(64) void k_adv_step(const double *__restrict__ ain,
             const D2 Fyh = adv_right(Fy);
             const D2 a1 = ADV_W(1);
             const size_t ko = (size_t)(k - 3) * p + ja;
-            if (jout[0]) aout[ko] = a1.a + P.dtdx * (Fxm1.a - Fx.a) + P.dtdy * (Fy.a - Fyh.a);
-            if (jout[1]) aout[ko + 1] = a1.b + P.dtdx * (Fxm1.b - Fx.b) + P.dtdy * (Fy.b - Fyh.b);
+            store2(ko, jout[0], jout[1],
+                   D2{a1.a + P.dtdx * (Fxm1.a - Fx.a) + P.dtdy * (Fy.a - Fyh.a),
+                      a1.b + P.dtdx * (Fxm1.b - Fx.b) + P.dtdy * (Fy.b - Fyh.b)});
         }
         Xr[(U + 2) % 3] = X;
         Yr[(U + 1) % 2] = ay_c;
@@ -256,14 +294,15 @@ __global__ __launch_bounds__(64) void k_adv_step(const double *__restrict__ ain,
         });
 }
 
-// rows per strip: two rounds of wavefronts at two per SIMD, within 16..64 rows (a strip
-// costs L + 6 iterations for L rows; with two cells per lane a wavefront carries the
-// instruction-level parallelism two wavefronts of the one-column kernel had)
+// rows per strip: about three wavefronts per SIMD in ONE round (the kernel is short: a
+// second round of a few stragglers shows), within 12..48 rows (a strip costs L + 6
+// iterations for L rows, four of them cheap).  Measured (tools/adv_time.py, profiles/
+// r03_adv_time.txt): 2048^2 best at 12-13 rows, 8192^2 at 32-48.
 static int adv_rows(int nx, int ncb, int cus)
 {
-    const long slots = 16L * cus;
+    const long slots = 12L * cus;
     int L = (int)(((long)nx * ncb + slots - 1) / slots);
-    L = L < 16 ? 16 : (L > 64 ? 64 : L);
+    L = L < 12 ? 12 : (L > 48 ? 48 : L);
     return L < nx ? L : nx;
 }
 
@@ -271,7 +310,7 @@ template <int LIM>
 static void adv_launch(pyrohip_ctx *c, bool uneg, bool vneg, int nwg, const double *cur,
                        double *nxt, const Geom &g, const AdvParams &P)
 {
-    const dim3 grid(nwg), block(64);
+    const dim3 grid((8 * ((nwg + 7) / 8) + ADV_WPB - 1) / ADV_WPB), block(64 * ADV_WPB);
     if (uneg && vneg)
         PYRO_LAUNCH(c, "k_adv_step", (k_adv_step<LIM, true, true>), grid, block, 0, cur, nxt, g, P);
     else if (uneg)
@@ -301,6 +340,7 @@ int adv_step_launch(pyrohip_state *s, int n, const pyrohip_adv_params *ap, doubl
     P.bxl = s->bc[n * 4 + 0]; P.bxr = s->bc[n * 4 + 1];
     P.byl = s->bc[n * 4 + 2]; P.byr = s->bc[n * 4 + 3];
     const int nwg = P.ncb * ((g.nx + P.L - 1) / P.L);
+    P.nunits = nwg;
     const bool uneg = (u < 0), vneg = (v < 0);   // interface.py:28,38
     if (ap->limiter == 0) adv_launch<0>(c, uneg, vneg, nwg, cur, nxt, g, P);
     else if (ap->limiter == 1) adv_launch<1>(c, uneg, vneg, nwg, cur, nxt, g, P);

@@ -167,7 +167,14 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     HIP_DYNAMIC_SHARED(double, lds)
     const int l = threadIdx.x;
     double *st = lds + l;
-    const int cb = blockIdx.x % P.ncb, sb = P.sb_first + (blockIdx.x / P.ncb) * P.sb_step;
+    // workgroup -> (column strip, row strip): workgroups are dealt round-robin to the 8 XCDs
+    // (each with its own L2); XCD x takes the units [x per, (x + 1) per) in order, so the strips
+    // that share apron rows and the cache lines at a column cut meet in ONE L2 at about the
+    // same time (the launch pads the grid to a multiple of 8)
+    const int per = (P.nunits + 7) / 8;
+    const int unit = ((int)blockIdx.x % 8) * per + (int)blockIdx.x / 8;
+    if (unit >= P.nunits) return;
+    const int cb = unit % P.ncb, sb = P.sb_first + (unit / P.ncb) * P.sb_step;
     const int i0 = g.ilo + sb * P.L;                       // strip rows [i0, i1)
     // (the last strip runs to the end of the grid: it may be up to ng - 1 rows longer
     // than L, so that no strip is shorter than the ghost width -- comp_step_wave_ex)
@@ -561,12 +568,14 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         // rows -- the rows the neighbours need as their next halo -- go first; their
         // exchange is posted on the halo stream and runs beside the interior strips
         P.sb_first = 0; P.sb_step = nsb - 1;
-        PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(2 * P.ncb), dim3(64), WLDS_BYTES,
+        P.nunits = 2 * P.ncb;
+        PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((P.nunits + 7) / 8)), dim3(64), WLDS_BYTES,
                     (const double *)Uin, Uout, g, P, s->d_flag, part, S);
         fused_copy_frame(s);           // old ghost frame -> new buffer, BEFORE the halos land in it
         PYRO_TRY(comm_post_halo(s, Uout));
         P.sb_first = 1; P.sb_step = 1;
-        PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3((nsb - 2) * P.ncb), dim3(64),
+        P.nunits = (nsb - 2) * P.ncb;
+        PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((P.nunits + 7) / 8)), dim3(64),
                     WLDS_BYTES, (const double *)Uin, Uout, g, P, s->d_flag, part, S);
         const double *dmin;
         PYRO_TRY(fused_tail(s, part, nwg, true, &dmin));
@@ -576,7 +585,8 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         s->halo_pending = (rc == 0);
         return rc;
     }
-    PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(nwg), dim3(64), WLDS_BYTES,
+    P.nunits = nwg;
+    PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((nwg + 7) / 8)), dim3(64), WLDS_BYTES,
                 (const double *)Uin, Uout, g, P, s->d_flag, part, S);
     if (post) {        // too few strips to overlap: the exchange follows the whole update
         fused_copy_frame(s);

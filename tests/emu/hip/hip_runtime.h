@@ -37,6 +37,8 @@ struct dim3 {
     constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct uint3_ { unsigned x, y, z; };
+struct alignas(16) double2 { double x, y; };
+inline double2 make_double2(double x, double y) { return double2{x, y}; }
 
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };

@@ -1,6 +1,7 @@
 """developer tool: advection step timing by size and strip length (GPU box)"""
 import os, sys, time
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "tests"))
 import numpy as np
 from pyro2_amd import device
 ctx = device.Context(0)

@@ -1,7 +1,8 @@
 """developer tool (GPU box): compressible step time by grid size and strip length of the
 row-marching kernel.  SIZES="4096:0,37,76,152;8192:0,128,149" (0 = the library's choice)"""
 import os, sys, time
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "tests"))
 import numpy as np
 from pyro2_amd import device
 from pyro2_amd.compressible.problems.sedov import sedov_state
