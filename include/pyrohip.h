@@ -294,6 +294,40 @@ int pyrohip_mg_nlevels(pyrohip_mg *m, int *nlevels);
    red-black iterations per launch; 0 = one launch per colour.  Results are
    bit-identical. */
 int pyrohip_mg_set_smoother(pyrohip_mg *m, int kind);
+/* Tuning of the multigrid kernels.  Every setting gives bit-identical results; the
+   defaults (what pyrohip_mg_create leaves, read them with pyrohip_mg_get_tuning) are the
+   measured winners on MI355X.  Tests use this to run the large-level
+   kernels on small levels; it replaces the PYRO_MG_* environment knobs of round 2.
+     kmax             red-black iterations per launch of the tile / band smoother (1..5)
+     kmax_small       ... on levels up to nsmall^2 (0..10; 10: a whole leg in one launch)
+     nsmall           see kmax_small (512)
+     march_min        row-marching smoother (mg_march.hip) on levels >= march_min^2
+                      (2048; 0: never)
+     march_waves      wavefronts a marching launch is cut into (0: what the device holds)
+     march_side       the first / last column strip gets 1 / march_side of the rows (1.5)
+     march_minrows    rows a wavefront stores, at least (32)
+     fuse_res_restrict  residual + restriction in one pass on the way down (1)
+     lazy_residual    inside solve() residual arrays are computed on demand (1)
+     allow_pow2       scaled right-hand side where the coefficients are powers of two (1)
+     small_tiles      workgroups aimed at on the small levels (-1: built-in default)
+     band_maxn        band smoother up to this level size (2048)
+     band_genedge     band smoother: the general edge instance everywhere (0)
+     coarse_band64    coarse V-cycle kernel: the 64^2 level's sweeps in registers (1)
+     speculate        solve(): launch the next V-cycle while the norms travel to the host:
+                      0 never, 1 when a further cycle is likely (default), 2 always
+     trace, spec_debug  developer aids (phase clocks of the band / coarse kernels; solve()
+                      prints cycles / launched ahead / undone)                              */
+typedef struct {
+    int kmax, kmax_small, nsmall;
+    int march_min, march_waves;
+    double march_side;
+    int march_minrows;
+    int fuse_res_restrict, lazy_residual, allow_pow2;
+    int small_tiles, band_maxn, band_genedge, coarse_band64;
+    int speculate, trace, spec_debug;
+} pyrohip_mg_tuning;
+int pyrohip_mg_get_tuning(pyrohip_mg *m, pyrohip_mg_tuning *t);
+int pyrohip_mg_set_tuning(pyrohip_mg *m, const pyrohip_mg_tuning *t);
 /* var: 0 = v, 1 = f, 2 = r; arrays are (n+2, n+2) with ng = 1 */
 int pyrohip_mg_set(pyrohip_mg *m, int level, int var, const double *host);
 int pyrohip_mg_get(pyrohip_mg *m, int level, int var, double *host);

@@ -45,6 +45,15 @@ class AdvParams(C.Structure):
                 ("march_rows", C.c_int)]
 
 
+class MGTuning(C.Structure):
+    _fields_ = [("kmax", C.c_int), ("kmax_small", C.c_int), ("nsmall", C.c_int),
+                ("march_min", C.c_int), ("march_waves", C.c_int), ("march_side", C.c_double),
+                ("march_minrows", C.c_int), ("fuse_res_restrict", C.c_int),
+                ("lazy_residual", C.c_int), ("allow_pow2", C.c_int), ("small_tiles", C.c_int),
+                ("band_maxn", C.c_int), ("band_genedge", C.c_int), ("coarse_band64", C.c_int),
+                ("speculate", C.c_int), ("trace", C.c_int), ("spec_debug", C.c_int)]
+
+
 class CompParams(C.Structure):
     _fields_ = [("dx", C.c_double), ("dy", C.c_double), ("gamma", C.c_double),
                 ("limiter", C.c_int), ("use_flattening", C.c_int),
@@ -169,6 +178,8 @@ _PROTOS = {
     "pyrohip_mg_set_coeffs": [_VP, _DP, _IP],
     "pyrohip_mg_set_rhs_cn": [_VP, _VP, C.c_int, C.c_double, _DP],
     "pyrohip_mg_copy_solution": [_VP, _VP, C.c_int],
+    "pyrohip_mg_get_tuning": [_VP, C.POINTER(MGTuning)],
+    "pyrohip_mg_set_tuning": [_VP, C.POINTER(MGTuning)],
     "pyrohip_comm_unique_id": [C.c_char_p],
     "pyrohip_comm_init": [_VP, C.c_int, C.c_int, C.c_char_p],
     "pyrohip_comm_destroy": [_VP],

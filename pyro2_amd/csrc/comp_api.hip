@@ -55,8 +55,7 @@ static bool wave_kernel_pays(const Geom &g)
 // source terms read ghost cells of their own.
 static bool comp_can_fuse_fill(const pyrohip_state *s, const pyrohip_comp_params *p, bool wave)
 {
-    static const bool off = getenv("PYRO_COMP_NOFUSE") != nullptr;     // A/B knob (tools/small_step.py)
-    if (off || wave || p->kernel_set == 0 || s->sph || s->user_bc || s->ramp_bc || s->ext_old ||
+    if (wave || p->kernel_set == 0 || s->sph || s->user_bc || s->ramp_bc || s->ext_old ||
         p->grav != 0.0 || s->heat != nullptr)
         return false;
     for (int sd = 0; sd < 4; sd++) {

@@ -70,21 +70,21 @@ struct pyrohip_mg {
     // apron doubles, which is free while most CUs idle).  Measured per V-cycle at
     // 512^2 / 2048^2 / 4096^2 (tools/mg_ab.sh): 5 everywhere 309 / 700 / 1590 us,
     // 10 up to 512^2 284 / 668 / 1529, 10 up to 1024^2 286 / 714 / 1578.
-    int kmax_small = getenv("PYRO_MG_KSMALL") ? atoi(getenv("PYRO_MG_KSMALL")) : 10;
-    int nsmall = getenv("PYRO_MG_NSMALL") ? atoi(getenv("PYRO_MG_NSMALL")) : 512;
+    int kmax_small = 10, kmax_small_tuned = 10;
+    int nsmall = 512;
     // levels >= march_min^2 (0: none): the row-marching smoother (mg_march.hip), cut into
-    // at most march_waves wavefronts.  Read when the solver object is made (the tests
-    // exercise the kernel on small levels that way)
-    int march_min = getenv("PYRO_MG_MARCH") ? atoi(getenv("PYRO_MG_MARCH")) : 2048;
-    int march_waves = getenv("PYRO_MG_MARCH_WAVES") ? atoi(getenv("PYRO_MG_MARCH_WAVES")) : 0;   // 0: what the device holds
+    // at most march_waves wavefronts (pyrohip_mg_set_tuning: the tests exercise the kernel
+    // on small levels that way)
+    int march_min = 2048;
+    int march_waves = 0;   // 0: what the device holds
     // the first / last column strip (a select more per update) in shorter chunks: their
     // wavefronts are given 1 / march_side of the steps of the others (<= 1: cut like the others).
     // Measured per V-cycle at 2048^2 / 4096^2: 1.0 562 / 1041 us, 1.17 547 / 1031, 1.3 532 / 1020,
     // 1.5 535 / 1018, 1.8 527 / 1032
-    double march_side = getenv("PYRO_MG_MARCH_SIDE") ? atof(getenv("PYRO_MG_MARCH_SIDE")) : 1.5;
-    int march_minrows = getenv("PYRO_MG_MARCH_ROWS") ? atoi(getenv("PYRO_MG_MARCH_ROWS")) : 32;   // rows a part stores, at least
+    double march_side = 1.5;
+    int march_minrows = 32;   // rows a part stores, at least
     int coarse_kernel = 1;        // levels <= 64^2 in one LDS-resident workgroup
-    int fuse_res_restrict = getenv("PYRO_MG_NOFUSE_RR") ? 0 : 1;   // down leg: residual + restriction in one pass
+    int fuse_res_restrict = 1;   // down leg: residual + restriction in one pass
     int vc = 0;                   // 1: div(eta grad phi) = f; 2: general (alpha, beta, gamma)
     double *vc_pool = nullptr;
     double *gen_pool = nullptr;
@@ -98,8 +98,17 @@ struct pyrohip_mg {
     // stale; whoever asks for the array (plane(), mg_finest) gets it computed from the level's
     // current v and f first.  For the finest level that is what MG.py:668-671 leaves there;
     // the coarser levels' r (the reference keeps the down leg's there) is nobody's input.
-    // PYRO_MG_EAGER_R: always store.
-    bool lazy_r = getenv("PYRO_MG_EAGER_R") == nullptr;
+    // (pyrohip_mg_tuning.lazy_residual = 0: always store.)
+    bool lazy_r = true;
+    // frozen choices that used to be environment knobs (pyrohip_mg_set_tuning)
+    bool allow_pow2 = true;       // scaled right-hand side where the coefficients are powers of two
+    int small_tiles = -1;         // workgroups aimed at on the small levels (-1: MG_SMALL_TILES_DEFAULT)
+    int band_maxn = 2048;         // band smoother up to this level size
+    bool band_genedge = false;    // band smoother: the general edge instance everywhere (tests)
+    bool coarse_band64 = true;    // coarse kernel: the 64^2 level's sweeps in registers
+    int speculate = 1;            // solve loop: 0 never launch ahead, 1 when likely needed, 2 always
+    bool trace = false;           // developer aid: phase clocks of the band / coarse kernels
+    bool spec_debug = false;      // developer aid: print cycles / launched ahead / undone per solve
     bool in_solve = false;
     bool r_stale[pyro::MG_MAXLEV] = {};
     // the solve loop's copy of the solution before the cycle (relative_error): the first
@@ -278,10 +287,9 @@ static bool mg_is_pow2(double x)
     int e;
     return x != 0.0 && std::isfinite(x) && std::fabs(std::frexp(x, &e)) == 0.5;
 }
-static bool mg_pow2(double xc, double yc, double denom)
+static bool mg_pow2(double xc, double yc, double denom, bool allow = true)
 {
-    static const bool off = getenv("PYRO_MG_NOPOW2") != nullptr;
-    return !off && mg_is_pow2(xc) && mg_is_pow2(yc) && mg_is_pow2(denom) &&
+    return allow && mg_is_pow2(xc) && mg_is_pow2(yc) && mg_is_pow2(denom) &&
            (1.0 / denom) * denom == 1.0;
 }
 
@@ -1813,7 +1821,7 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
     A.denom = m->alpha + 2.0 * A.xc + 2.0 * A.yc;
     A.rdenom = 1.0 / A.denom;
     A.kx = A.xc * A.rdenom; A.ky = A.yc * A.rdenom;
-    const bool pow2 = mg_pow2(A.xc, A.yc, A.denom);
+    const bool pow2 = mg_pow2(A.xc, A.yc, A.denom, m->allow_pow2);
     A.bc = make_bc(m, level, true);
     A.single = ((L.n + 2) * (L.n + 2) <= MGS_CELLS) ? 1 : 0;   // whole level in one tile
     A.cv = nullptr; A.cpitch = 0;
@@ -1822,7 +1830,7 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
     A.row0 = row0; A.row1 = row1;
     A.trace = nullptr;
 #ifndef PYRO_EMU
-    static const bool tracing = getenv("PYRO_MG_TRACE") != nullptr;
+    const bool tracing = m->trace;
     static long long *d_trace = nullptr;
     if (tracing) {
         if (!d_trace) PYRO_CHECK_HIP(hipMalloc((void **)&d_trace, 32 * sizeof(long long)));
@@ -1893,10 +1901,7 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
             // region (2K sweeps over up to 64 x 128 cells on one CU), while most of
             // the 256 CUs idle.  Shorter tiles (fewer region rows per workgroup,
             // more workgroups) cut that latency; the extra apron rows are free here.
-            static const int target = [] {
-                const char *e = getenv("PYRO_MG_SMALL_TILES");
-                return e ? atoi(e) : MG_SMALL_TILES_DEFAULT;
-            }();
+            const int target = m->small_tiles >= 0 ? m->small_tiles : MG_SMALL_TILES_DEFAULT;
             if (target > 0) {
                 const int want = (target + A.ntj - 1) / A.ntj;
                 int ti = (nrows + want - 1) / want;
@@ -1907,13 +1912,12 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
             A.ntiles = nti * A.ntj;
             // measured per V-cycle at 2048^2 / 4096^2 (tools/mg_ab.sh): band kernel up to
             // 1024^2: 625 / 1497 us, up to 2048^2: 611 / 1485, everywhere: 615 / 1501
-            static const int band_maxn = getenv("PYRO_MG_BAND") ? atoi(getenv("PYRO_MG_BAND")) : 2048;
-            const bool band = L.n <= band_maxn;
+            const bool band = L.n <= m->band_maxn;
             // the band kernel: homogeneous boundaries; its EDGE instance (ghost values
             // synthesised at the physical sides) wherever a tile can touch one
             const bool hom = !(A.bc.val[0] || A.bc.val[1] || A.bc.val[2] || A.bc.val[3]);
             // 0: no physical side; 1: mirror ghosts (+-own value); 2: value-0 ghosts among them
-            static const bool gen_edge = getenv("PYRO_MG_BAND_GENEDGE") != nullptr;
+            const bool gen_edge = m->band_genedge;
             int edge = (A.bc.code[0] != PYROHIP_BC_PERIODIC || A.bc.code[2] != PYROHIP_BC_PERIODIC) ? 1 : 0;
             for (int sd = 0; sd < 4; sd++)
                 if (A.bc.code[sd] == PYROHIP_BC_CONST || (edge && gen_edge)) edge = 2;
@@ -2081,15 +2085,15 @@ static int mg_coarse_vcycle(pyrohip_mg *m, int top)
     A.finest = (top == m->nlevels - 1) ? 1 : 0;
     A.alpha = m->alpha; A.beta = m->beta;
     A.nsmooth = m->nsmooth; A.nsmooth_bottom = m->nsmooth_bottom;
-    A.allow_pow2 = getenv("PYRO_MG_NOPOW2") ? 0 : 1;
-    A.band64 = getenv("PYRO_MGC_NOBAND64") ? 0 : 1;
+    A.allow_pow2 = m->allow_pow2 ? 1 : 0;
+    A.band64 = m->coarse_band64 ? 1 : 0;
     A.zero_mask = 0;
     for (int l = 0; l <= top; l++)
         if (m->v_is_zero[l]) { A.zero_mask |= 1u << l; m->v_is_zero[l] = false; }
     A.bc = make_bc(m, top, true);
     A.trace = nullptr;
 #ifndef PYRO_EMU
-    static const bool tracing = getenv("PYRO_MGC_TRACE") != nullptr;
+    const bool tracing = m->trace;
     static long long *d_trace = nullptr;
     if (tracing) {
         if (!d_trace) PYRO_CHECK_HIP(hipMalloc((void **)&d_trace, 16 * sizeof(long long)));
@@ -2238,6 +2242,36 @@ int pyrohip_mg_set_helmholtz(pyrohip_mg *m, double alpha, double beta)
     return 0;
 }
 
+int pyrohip_mg_get_tuning(pyrohip_mg *m, pyrohip_mg_tuning *t)
+{
+    PYRO_REQUIRE(m && t, "NULL argument");
+    t->kmax = m->kmax; t->kmax_small = m->kmax_small_tuned; t->nsmall = m->nsmall;
+    t->march_min = m->march_min; t->march_waves = m->march_waves; t->march_side = m->march_side;
+    t->march_minrows = m->march_minrows; t->fuse_res_restrict = m->fuse_res_restrict;
+    t->lazy_residual = m->lazy_r ? 1 : 0; t->allow_pow2 = m->allow_pow2 ? 1 : 0;
+    t->small_tiles = m->small_tiles; t->band_maxn = m->band_maxn;
+    t->band_genedge = m->band_genedge ? 1 : 0; t->coarse_band64 = m->coarse_band64 ? 1 : 0;
+    t->speculate = m->speculate; t->trace = m->trace ? 1 : 0; t->spec_debug = m->spec_debug ? 1 : 0;
+    return 0;
+}
+
+int pyrohip_mg_set_tuning(pyrohip_mg *m, const pyrohip_mg_tuning *t)
+{
+    PYRO_REQUIRE(m && t, "NULL argument");
+    PYRO_REQUIRE(t->kmax >= 1 && t->kmax <= MGW_KMAX, "kmax: 1..5 iterations per tile launch");
+    PYRO_REQUIRE(t->kmax_small >= 0 && t->kmax_small <= 10, "kmax_small: 0..10");
+    PYRO_REQUIRE(t->speculate >= 0 && t->speculate <= 2, "speculate: 0, 1 or 2");
+    m->kmax = t->kmax; m->kmax_small_tuned = t->kmax_small; m->nsmall = t->nsmall;
+    if (m->kmax_small != 0) m->kmax_small = t->kmax_small;      // (0: switched off by set_smoother)
+    m->march_min = t->march_min; m->march_waves = t->march_waves; m->march_side = t->march_side;
+    m->march_minrows = t->march_minrows; m->fuse_res_restrict = t->fuse_res_restrict;
+    m->lazy_r = t->lazy_residual != 0; m->allow_pow2 = t->allow_pow2 != 0;
+    m->small_tiles = t->small_tiles; m->band_maxn = t->band_maxn;
+    m->band_genedge = t->band_genedge != 0; m->coarse_band64 = t->coarse_band64 != 0;
+    m->speculate = t->speculate; m->trace = t->trace != 0; m->spec_debug = t->spec_debug != 0;
+    return 0;
+}
+
 int pyrohip_mg_set_smoother(pyrohip_mg *m, int kind)
 {
     PYRO_REQUIRE(m, "NULL mg");
@@ -2245,7 +2279,7 @@ int pyrohip_mg_set_smoother(pyrohip_mg *m, int kind)
     // 10 + k selects the tile smoother with k fused iterations (tuning knob)
     // 20 + k: the same without the single-workgroup coarse V-cycle kernel
     m->coarse_kernel = 1;
-    m->kmax_small = getenv("PYRO_MG_KSMALL") ? atoi(getenv("PYRO_MG_KSMALL")) : 10;
+    m->kmax_small = m->kmax_small_tuned;
     if (kind >= 20) { m->smoother = 1; m->kmax = kind - 20; m->coarse_kernel = 0; m->kmax_small = 0; }
     else if (kind >= 10) { m->smoother = 1; m->kmax = kind - 10; }
     else m->smoother = kind;
@@ -2702,13 +2736,13 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
     // old_phi (capture_old), so a cycle that turns out to be one too many is undone by taking
     // that buffer back -- cycles, norms and solution are those of the loop that waits.  (The
     // coarser levels' arrays, scratch between solves, then hold the undone cycle's values.)
-    // PYRO_MG_SPECULATE: 0 never, 2 whenever a further cycle is allowed (tests).
-    static const int spec_mode = getenv("PYRO_MG_SPECULATE") ? atoi(getenv("PYRO_MG_SPECULATE")) : 1;
+    // pyrohip_mg_tuning.speculate: 0 never, 2 whenever a further cycle is allowed (tests).
+    const int spec_mode = m->speculate;
     const bool can_undo = !m->vc && m->smoother != 0 && m->nsmooth > 0 && Lf > MGC_TOP &&
                           (F.n + 2) * (F.n + 2) > MGS_CELLS;      // the finest level's launches ping-pong
     double res_prev = -1.0, res_pprev = -1.0;
     bool pending = false;                                  // cycle `cycle` is already on the stream
-    static const bool spec_debug = getenv("PYRO_MG_SPEC_DEBUG") != nullptr;   // developer aid
+    const bool spec_debug = m->spec_debug;   // developer aid
     int n_spec = 0, n_undo = 0;
     while (res > rtol && cycle <= max_cycles) {           // MG.py:652
         double s = 0.0, s2 = 0.0;

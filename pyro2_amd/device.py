@@ -493,7 +493,7 @@ class DeviceMG:
 
     def __init__(self, ctx, nx, xmin=0.0, xmax=1.0, ymin=0.0, ymax=1.0,
                  bcs=("dirichlet",) * 4, alpha=0.0, beta=-1.0, nsmooth=10,
-                 nsmooth_bottom=50):
+                 nsmooth_bottom=50, tuning=None):
         self.ctx = ctx
         self._l = ctx._l
         bc = np.array([BC_CODE[b] if isinstance(b, str) else int(b) for b in bcs],
@@ -507,6 +507,29 @@ class DeviceMG:
             check(self._l.pyrohip_mg_nlevels(self.h, C.byref(nl)))
         self.nx = int(nx)
         self.nlevels = nl.value
+        if tuning:
+            self.set_tuning(**tuning)
+
+    def get_tuning(self):
+        """the kernels' tuning values (pyrohip_mg_tuning) as a dict"""
+        from ._lib import MGTuning
+        t = MGTuning()
+        with self.ctx.lock:
+            check(self._l.pyrohip_mg_get_tuning(self.h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in MGTuning._fields_}
+
+    def set_tuning(self, **kw):
+        """change some of the tuning values (tests / developer tools; results do not depend
+        on them)"""
+        from ._lib import MGTuning
+        t = MGTuning()
+        with self.ctx.lock:
+            check(self._l.pyrohip_mg_get_tuning(self.h, C.byref(t)))
+            for k, v in kw.items():
+                if not hasattr(t, k):
+                    raise KeyError(k)
+                setattr(t, k, v)
+            check(self._l.pyrohip_mg_set_tuning(self.h, C.byref(t)))
 
     def __del__(self):
         try:

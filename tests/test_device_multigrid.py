@@ -466,9 +466,9 @@ def test_mg_march_smoother(dev, bcs, coef, monkeypatch):
     f0 = rng.standard_normal((nx + 2, nx + 2))
     res = {}
     for march in (0, 1):
-        monkeypatch.setenv("PYRO_MG_MARCH", "256" if march else "0")
-        monkeypatch.setenv("PYRO_MG_MARCH_WAVES", "24")     # 8 row chunks of 32
-        m = device.DeviceMG(dev, nx, bcs=bcs, alpha=alpha, beta=beta)
+        m = device.DeviceMG(dev, nx, bcs=bcs, alpha=alpha, beta=beta,
+                            tuning=dict(march_min=256 if march else 0,
+                                        march_waves=24))            # 8 row chunks of 32
         L = m.nlevels - 1
         m.set_smoother(0 if not march else 1)
         out = []
@@ -500,11 +500,7 @@ def test_mg_solve_lazy_residual_and_old_copy(dev, monkeypatch):
                   (1.0 - 6.0 * Y ** 2) * X ** 2 * (1.0 - X ** 2))
     out = []
     for eager in (True, False):
-        if eager:
-            monkeypatch.setenv("PYRO_MG_EAGER_R", "1")
-        else:
-            monkeypatch.delenv("PYRO_MG_EAGER_R", raising=False)
-        m = device.DeviceMG(dev, nx)
+        m = device.DeviceMG(dev, nx, tuning=dict(lazy_residual=0 if eager else 1))
         L = m.nlevels - 1
         m.zero(L, 0)
         m.set(L, 1, rhs)
@@ -538,7 +534,7 @@ nx = %d
 x = (np.arange(nx + 2) - 0.5) / nx
 X, Y = np.meshgrid(x, x, indexing="ij")
 rhs = -2.0 * ((1.0 - 6.0 * X ** 2) * Y ** 2 * (1.0 - Y ** 2) + (1.0 - 6.0 * Y ** 2) * X ** 2 * (1.0 - X ** 2))
-m = device.DeviceMG(dev, nx)
+m = device.DeviceMG(dev, nx, tuning=dict(speculate=%d))
 L = m.nlevels - 1
 m.zero(L, 0); m.set(L, 1, rhs); m.init_rhs_norm()
 out = [m.solve(rtol=1e-7, max_cycles=30), m.get(L, 0)]
@@ -550,9 +546,9 @@ pickle.dump(out, sys.stdout.buffer)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for mode in ("0", "2", "1"):
-        env = dict(os.environ, PYRO_MG_SPECULATE=mode)
-        p = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests"), dev.kind, nx)],
-                           env=env, capture_output=True, timeout=900)
+        p = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests"), dev.kind, nx,
+                                                          int(mode))],
+                           env=dict(os.environ), capture_output=True, timeout=900)
         assert p.returncode == 0, p.stderr.decode()[-2000:]
         res[mode] = pickle.loads(p.stdout)
     assert 1 < res["0"][0][0] < 30            # converged: the forced speculation had a cycle to undo
