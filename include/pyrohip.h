@@ -340,9 +340,12 @@ int pyrohip_mg_smooth(pyrohip_mg *m, int level, int nsmooth);  /* MG.py:544-621 
 /* Row windows: the building blocks of a V-cycle whose levels are split into x
    slabs across GPUs (pyro2_amd/multigrid/slab.py; constant coefficients, levels
    above 64^2).  Rows are 1-based interior rows of the (n+2, n+2) level arrays.
-   smooth_rows: ONE launch of the LDS tile smoother, nsweeps <= 5 red-black
+   rows_kmax: how many red-black iterations ONE launch does on that level: 10 (a whole
+   V-cycle leg) where the row-marching kernel (levels >= 2048^2) or the deep-apron band
+   kernel (levels <= 512^2) runs, 5 in between; 0: no row windows (variable coefficients).
+   smooth_rows: ONE launch, nsweeps <= rows_kmax red-black
    iterations on rows [row0, row1]; the 2*nsweeps rows beyond them must hold the
-   neighbours' current values (physical boundaries are refreshed by the kernel);
+   neighbours' current values, v and f (physical boundaries are refreshed by the kernel);
    prolong != 0: add the prolongation of the coarser level's solution while
    staging (needs nsweeps + 1 coarse halo rows).  Identical, bit for bit, to what
    the whole-level launch computes on those rows.
@@ -351,8 +354,15 @@ int pyrohip_mg_smooth(pyrohip_mg *m, int level, int nsmooth);  /* MG.py:544-621 
    get_rows / set_rows: rows [i0, i0+ni) of a level array incl. ghost columns
    (host staging of the halos; var 0 = v, 1 = f, 2 = r).
    mark_zero: the level's solution is zero from here on (MG.py:658-659). */
+int pyrohip_mg_rows_kmax(pyrohip_mg *m, int level, int *k);
 int pyrohip_mg_smooth_rows(pyrohip_mg *m, int level, int nsweeps, int row0, int row1,
                            int prolong);
+/* the diagnostics of one cycle of solve() (MG.py:670-686) over rows [row0, row1] of the
+   finest level: sums[0] = sum ((v - old) / (v + 1e-16))^2, sums[1] = sum r^2 (one current
+   halo row of v on either side); old <- v on those rows.  save_old: old <- v everywhere
+   (MG.py:647).  The slabs' sums are added over the ranks (pyrohip_allreduce_sum). */
+int pyrohip_mg_diag_rows(pyrohip_mg *m, int row0, int row1, double *sums);
+int pyrohip_mg_save_old(pyrohip_mg *m);
 int pyrohip_mg_residual_restrict_rows(pyrohip_mg *m, int fine, int crow0, int crow1);
 int pyrohip_mg_get_rows(pyrohip_mg *m, int level, int var, int i0, int ni, double *host);
 int pyrohip_mg_set_rows(pyrohip_mg *m, int level, int var, int i0, int ni, const double *host);
@@ -546,6 +556,8 @@ int pyrohip_state_set_neighbours(pyrohip_state *s, int rank_lo, int rank_hi);
 int pyrohip_state_halo_pending(pyrohip_state *s, int *flag);
 int pyrohip_allreduce_min(pyrohip_ctx *ctx, double *value);
 int pyrohip_allreduce_max(pyrohip_ctx *ctx, double *value);
+/* sum of n doubles over the ranks, in place (n <= 16) */
+int pyrohip_allreduce_sum(pyrohip_ctx *ctx, double *values, int n);
 
 #ifdef __cplusplus
 }

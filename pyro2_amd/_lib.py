@@ -189,6 +189,10 @@ _PROTOS = {
     "pyrohip_state_halo_pending": [_VP, _IP],
     "pyrohip_allreduce_min": [_VP, _DP],
     "pyrohip_allreduce_max": [_VP, _DP],
+    "pyrohip_allreduce_sum": [_VP, _DP, C.c_int],
+    "pyrohip_mg_rows_kmax": [_VP, C.c_int, _IP],
+    "pyrohip_mg_diag_rows": [_VP, C.c_int, C.c_int, _DP],
+    "pyrohip_mg_save_old": [_VP],
 }
 
 EXPORTS = sorted(list(_PROTOS) + ["pyrohip_last_error", "pyrohip_backend"])

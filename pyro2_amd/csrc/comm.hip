@@ -276,6 +276,22 @@ int pyrohip_allreduce_max(pyrohip_ctx *c, double *value)
     return allreduce_scalar(c, value, ncclMax);
 }
 
+int pyrohip_allreduce_sum(pyrohip_ctx *c, double *values, int n)
+{
+    PYRO_REQUIRE(c && values && n >= 1 && n <= 16, "NULL argument / 1..16 values");
+    if (c->comm == nullptr) return 0;   // single process, no communicator
+    PYRO_TRY(c->reduce.ensure(512));
+    double *d = (double *)c->reduce.p;
+    memcpy(c->reduce_host, values, n * sizeof(double));
+    PYRO_CHECK_HIP(hipMemcpyAsync(d, c->reduce_host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    PYRO_CHECK_NCCL(ncclAllReduce(d, d + 16, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
+    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, d + 16, n * sizeof(double), hipMemcpyDeviceToHost,
+                                  c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    memcpy(values, c->reduce_host, n * sizeof(double));
+    return 0;
+}
+
 }  // extern "C"
 
 namespace pyro {

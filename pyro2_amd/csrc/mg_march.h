@@ -17,6 +17,8 @@ struct MGMarch {
     const double *cv;               // up leg: coarse solution to prolong and add while loading
     int cpitch;
     int vin_zero;
+    int row0, row1;                 // rows to update (1 .. n: the whole level; a slab of it
+                                    // when decomposed: the rows beyond are halo rows)
     int TJ, ncs;                    // columns a strip updates, strips
     int CR, nchunks;                // rows a chunk updates, chunks
     // the first and the last strip (physical sides left / right: a select more per update)

@@ -84,7 +84,7 @@ __device__ __forceinline__ Part mgm_part(const MGMarch &A, int NP, int W)
         cs = (e & 1) ? A.ncs - 1 : 0; ch = e >> 1; CR = A.CR_side;
     }
     P.tj0 = 1 + cs * A.TJ; P.tj1 = min(P.tj0 + A.TJ - 1, n);
-    P.ra = 1 + ch * CR; P.rb = min(P.ra + CR - 1, n);
+    P.ra = A.row0 + ch * CR; P.rb = min(P.ra + CR - 1, A.row1);
     int gj0 = P.tj0 - NP, g0 = P.ra - NP, gend = P.rb + NP;
     if (!per_j) gj0 = max(gj0, 0);
     if (!per_i) { g0 = max(g0, 0); gend = min(gend, n); }
@@ -333,6 +333,14 @@ bool mg_march_usable(const MGMarch &A, int K)
     for (int s = 0; s < 4; s++)
         if (A.code[s] == PYROHIP_BC_CONST) return false;
     if (A.nchunks_side > 0 && (A.ncs < 3 || A.nchunks_side < 2 || A.CR_side + 4 * K + mgm_align(K) >= A.n))
+        return false;
+    // a window of rows (slab of a decomposed level): whole rows, and a part that ends at the
+    // top boundary must not be the window's first (it starts up to mgm_align rows lower:
+    // inside the window, not in halo rows the caller did not provide)
+    // (nchunks >= 2 below; the shorter chunks of the side strips are not used with windows)
+    const bool window = (A.row0 != 1 || A.row1 != A.n);
+    if (A.row0 < 1 || A.row1 > A.n || A.row1 - A.row0 + 1 <= A.CR) return false;
+    if (window && (A.code[0] == PYROHIP_BC_PERIODIC || A.nchunks_side > 0 || A.CR < mgm_align(K) + 4))
         return false;
     return mgm_has_k(K) && A.n % 2 == 0 && A.n >= 2 * MGM_COLS && A.nchunks >= 2 &&
            A.CR + 4 * K + mgm_align(K) < A.n;

@@ -1654,10 +1654,11 @@ __global__ __launch_bounds__(256) void k_mg_solve_diag(const double *__restrict_
                                                        double *__restrict__ r,
                                                        double *__restrict__ old, int n, int pitch,
                                                        double alpha, double beta, double dx2,
-                                                       double small, double *__restrict__ partial)
+                                                       double small, double *__restrict__ partial,
+                                                       int row0, int row1)
 {
     double srel = 0.0, sres = 0.0;
-    for (int i = 1 + blockIdx.y; i <= n; i += gridDim.y)
+    for (int i = row0 + blockIdx.y; i <= row1; i += gridDim.y)
         for (int j = 1 + blockIdx.x * blockDim.x + threadIdx.x; j <= n;
              j += gridDim.x * blockDim.x) {
             const size_t k = (size_t)i * pitch + j;
@@ -1786,11 +1787,12 @@ static void mg_swap_solution(pyrohip_mg *m, int level)
 }
 
 static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong = false,
-                           int row0 = 1, int row1 = -1)
+                           int row0 = 1, int row1 = -1, int *nlaunch = nullptr)
 {
     MGLevel &L = m->lev[level];
     if (row1 < 0) row1 = L.n;
     const int nrows = row1 - row0 + 1;
+    int launches = 0;
 #ifndef PYRO_EMU
     static bool attr_set = false;
     if (!attr_set) {
@@ -1851,7 +1853,7 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
     // V-cycle leg in one launch
     const int march_min = m->march_min, march_waves = m->march_waves;
     const bool hom_bc = !(A.bc.val[0] || A.bc.val[1] || A.bc.val[2] || A.bc.val[3]);
-    while (!A.single && hom_bc && march_min > 0 && L.n >= march_min && row0 == 1 && row1 == L.n) {
+    while (!A.single && hom_bc && march_min > 0 && L.n >= march_min) {
         const int MK = 10;
         if (left < MK) break;
         MGMarch M;
@@ -1859,21 +1861,23 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
         M.xc = A.xc; M.yc = A.yc; M.denom = A.denom; M.rdenom = A.rdenom; M.kx = A.kx; M.ky = A.ky;
         for (int s = 0; s < 4; s++) M.code[s] = A.bc.code[s];
         M.cv = A.cv; M.cpitch = A.cpitch; M.vin_zero = A.vin_zero;
+        M.row0 = row0; M.row1 = row1;
         M.TJ = mgm_tj(MK); M.ncs = (L.n + M.TJ - 1) / M.TJ;
         // row chunks: as many wavefronts as the device holds at once, not one more (two per
         // SIMD at 256 registers: a wavefront too many would run alone after all the others); the
         // parts that end at the top boundary start up to mgm_align rows lower (mg_march.hip:
         // mgm_part), so the last chunk is made that much shorter
         const int slots = march_waves > 0 ? march_waves : 8 * (m->ctx->num_cus > 0 ? m->ctx->num_cus : 256);
-        const int pad = (M.code[0] != PYROHIP_BC_PERIODIC) ? mgm_align(MK) : 0;
-        const bool sides = M.code[2] != PYROHIP_BC_PERIODIC && M.ncs >= 3 && m->march_side > 1.0;
+        const int pad = (M.code[0] != PYROHIP_BC_PERIODIC && row1 == L.n) ? mgm_align(MK) : 0;
+        const bool sides = M.code[2] != PYROHIP_BC_PERIODIC && M.ncs >= 3 && m->march_side > 1.0 &&
+                           row0 == 1 && row1 == L.n;
         auto chunks = [&](int rows, int least, int &cr) {   // chunks of about `rows` rows -> count
             cr = rows < least ? least : rows;
-            return (L.n + cr - 1) / cr;
+            return (nrows + cr - 1) / cr;
         };
         M.nchunks_side = 0; M.CR_side = 0;
         for (int nch = slots / M.ncs > 2 ? slots / M.ncs : 2; nch >= 2; nch--) {
-            M.nchunks = chunks((L.n + pad + nch - 1) / nch, m->march_minrows, M.CR);
+            M.nchunks = chunks((nrows + pad + nch - 1) / nch, m->march_minrows, M.CR);
             if (!sides) break;
             // a wavefront of a side strip needs march_side times as long per row: fewer rows
             const int steps = M.CR + 6 * MK;              // apron below and above, 2K steps to drain
@@ -1882,6 +1886,7 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
         }
         if (!mg_march_usable(M, MK)) break;
         PYRO_TRY(mg_march_launch(m->ctx, M, pow2, MK));
+        launches++;
         mg_swap_solution(m, level);
         left -= MK;
         A.cv = nullptr; A.vin_zero = 0;
@@ -1949,10 +1954,12 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
 #endif
         if (A.single) { double *t = L.v; L.v = L.v2; L.v2 = t; }
         else mg_swap_solution(m, level);
+        launches++;
         left -= K;
         A.cv = nullptr;   // only the first launch carries the prolongation
         A.vin_zero = 0;
     }
+    if (nlaunch) *nlaunch = launches;
     return 0;
 }
 
@@ -2390,26 +2397,94 @@ int pyrohip_mg_prolong_add(pyrohip_mg *m, int fine)
 }
 
 // ---- row windows: building blocks of a V-cycle on x slabs (multigrid/slab.py) ----
+int pyrohip_mg_rows_kmax(pyrohip_mg *m, int level, int *k)
+{
+    MG_CHECK_LEVEL(m, level);
+    PYRO_REQUIRE(k, "NULL argument");
+    const MGLevel &L = m->lev[level];
+    // ten iterations (a whole V-cycle leg) in one launch: the row-marching kernel on the
+    // large levels, the band kernel with its deep apron on the small ones; five in between
+    const bool hom = !(level == m->nlevels - 1 && (m->bcval[0] || m->bcval[1] || m->bcval[2] || m->bcval[3]));
+    bool cst = false;
+    for (int s = 0; s < 4; s++) cst = cst || m->bc[s] == PYROHIP_BC_CONST;
+    const bool march = hom && !cst && m->march_min > 0 && L.n >= m->march_min && L.n >= 2 * MGM_COLS &&
+                       m->bc[0] != PYROHIP_BC_PERIODIC;
+    const bool small10 = L.n <= m->nsmall && m->kmax_small_tuned >= 10;
+    *k = (m->vc || m->smoother == 0) ? 0 : ((march || small10) ? 10 : MGW_KMAX);
+    return 0;
+}
+
 int pyrohip_mg_smooth_rows(pyrohip_mg *m, int level, int nsweeps, int row0, int row1, int prolong)
 {
     MG_CHECK_LEVEL(m, level);
     MGLevel &L = m->lev[level];
     PYRO_REQUIRE(!m->vc && m->smoother != 0, "row windows: constant coefficients, tile smoother");
     PYRO_REQUIRE((L.n + 2) * (L.n + 2) > MGS_CELLS, "row windows: levels above 64^2 only");
-    PYRO_REQUIRE(nsweeps >= 1 && nsweeps <= MGW_KMAX, "one launch: 1..5 iterations");
+    PYRO_REQUIRE(nsweeps >= 1 && nsweeps <= 10, "one launch: 1..10 iterations");
+    int kcap = 0;
+    PYRO_TRY(pyrohip_mg_rows_kmax(m, level, &kcap));
+    PYRO_REQUIRE(nsweeps <= kcap, "more iterations than one launch does on this level "
+                                  "(pyrohip_mg_rows_kmax)");
     PYRO_REQUIRE(row0 >= 1 && row1 <= L.n && row0 <= row1, "rows outside the level");
     PYRO_REQUIRE(!prolong || level > 0, "no coarser level to prolong from");
     // exactly `nsweeps` iterations in ONE launch (no halo exchange could happen between
     // two launches of a split call): the tuning values do not apply to row windows
     const int ks = m->kmax_small, km = m->kmax;
-    m->kmax_small = 0;
-    m->kmax = MGW_KMAX;
-    const int rc = mg_smooth_tiles(m, level, nsweeps, prolong != 0, row0, row1);
+    m->kmax_small = nsweeps > MGW_KMAX ? nsweeps : 0;
+    m->kmax = nsweeps > MGW_KMAX ? MGW_KMAX : nsweeps;
+    int nl = 0;
+    const int rc = mg_smooth_tiles(m, level, nsweeps, prolong != 0, row0, row1, &nl);
     m->kmax_small = ks;
     m->kmax = km;
+    PYRO_REQUIRE(rc != 0 || nl == 1, "the window is too short for one launch of that many iterations");
     m->corners_stale[level] = true;
     PYRO_CHECK_HIP(hipGetLastError());
     return rc;
+}
+
+// the per-cycle diagnostics of solve() (MG.py:670-686) over rows [row0, row1] of the finest
+// level: sums[0] = sum of ((v - old) / (v + small))^2, sums[1] = sum of r^2 with
+// r = f - (alpha - beta L) v (one halo row of v on either side must be current); old <- v on
+// those rows.  The caller adds the slabs' sums (all-reduce) and takes the norms.
+int pyrohip_mg_diag_rows(pyrohip_mg *m, int row0, int row1, double *sums)
+{
+    PYRO_REQUIRE(m && sums, "NULL argument");
+    PYRO_REQUIRE(!m->vc, "row windows: constant coefficients");
+    pyrohip_ctx *c = m->ctx;
+    const int Lf = m->nlevels - 1;
+    MGLevel &F = m->lev[Lf];
+    PYRO_REQUIRE(row0 >= 1 && row1 <= F.n && row0 <= row1, "rows outside the level");
+    const int nrows = row1 - row0 + 1;
+    const int gx = F.n >= 4096 ? 16 : (F.n >= 256 ? F.n / 256 : 1);
+    const int gy = nrows >= 64 ? (2048 / gx < nrows ? 2048 / gx : nrows) : 1;
+    const dim3 grid(gx, gy), block(256);
+    const int nb = grid.x * grid.y;
+    PYRO_TRY(c->reduce.ensure((2 * nb + 4) * sizeof(double)));
+    double *part = (double *)c->reduce.p;
+    PYRO_LAUNCH(c, "k_mg_solve_diag", (k_mg_solve_diag<true, true>), grid, block, 0,
+                (const double *)F.v, (const double *)F.f, F.r, m->old_phi, F.n, F.pitch, m->alpha,
+                m->beta, F.dx * F.dx, 1.e-16, part, row0, row1);
+    m->r_stale[Lf] = false;
+    hipLaunchKernelGGL(k_sum_final2, dim3(1), dim3(256), 0, c->stream, (const double *)part, nb,
+                       part + 2 * nb);
+    PYRO_CHECK_HIP(hipGetLastError());
+    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, part + 2 * nb, 2 * sizeof(double),
+                                  hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    sums[0] = ((double *)c->reduce_host)[0];
+    sums[1] = ((double *)c->reduce_host)[1];
+    return 0;
+}
+
+// old <- v on the finest level (MG.py:647: the copy solve() keeps for relative_error)
+int pyrohip_mg_save_old(pyrohip_mg *m)
+{
+    PYRO_REQUIRE(m, "NULL mg");
+    pyrohip_ctx *c = m->ctx;
+    MGLevel &F = m->lev[m->nlevels - 1];
+    PYRO_CHECK_HIP(hipMemcpyAsync(m->old_phi, F.v, (size_t)(F.n + 2) * F.pitch * sizeof(double),
+                                  hipMemcpyDeviceToDevice, c->stream));
+    return 0;
 }
 
 int pyrohip_mg_residual_restrict_rows(pyrohip_mg *m, int fine, int crow0, int crow1)
@@ -2712,13 +2787,13 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
         PYRO_TRY(c->reduce.ensure((2 * nb + 4) * sizeof(double)));
         double *part = (double *)c->reduce.p;
         using DiagT = void (*)(const double *, const double *, double *, double *, int, int, double,
-                               double, double, double, double *);
+                               double, double, double, double *, int, int);
         static const DiagT diag[2][2] = {{k_mg_solve_diag<false, false>, k_mg_solve_diag<false, true>},
                                         {k_mg_solve_diag<true, false>, k_mg_solve_diag<true, true>}};
         const bool store = !m->lazy_r;
         PYRO_LAUNCH(c, "k_mg_solve_diag", diag[store ? 1 : 0][m->old_captured ? 0 : 1], grid, block, 0,
                     (const double *)F.v, (const double *)F.f, F.r, m->old_phi, F.n, F.pitch, m->alpha,
-                    m->beta, F.dx * F.dx, 1.e-16, part);
+                    m->beta, F.dx * F.dx, 1.e-16, part, 1, F.n);
         m->r_stale[Lf] = !store;
         hipLaunchKernelGGL(k_sum_final2, dim3(1), dim3(256), 0, c->stream,
                            (const double *)part, nb, part + 2 * nb + 2 * slot);

@@ -118,6 +118,12 @@ class Context:
             check(self._l.pyrohip_allreduce_min(self.h, C.byref(v)))
         return v.value
 
+    def allreduce_sum(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        with self.lock:
+            check(self._l.pyrohip_allreduce_sum(self.h, dptr(v), int(v.size)))
+        return v
+
     def allreduce_max(self, x):
         v = C.c_double(x)
         with self.lock:
@@ -507,6 +513,8 @@ class DeviceMG:
             check(self._l.pyrohip_mg_nlevels(self.h, C.byref(nl)))
         self.nx = int(nx)
         self.nlevels = nl.value
+        self.dx = (xmax - xmin) / nx
+        self.source_norm = 0.0
         if tuning:
             self.set_tuning(**tuning)
 
@@ -574,6 +582,22 @@ class DeviceMG:
         self._call("pyrohip_mg_smooth_rows", int(level), int(nsweeps), int(row0), int(row1),
                    int(bool(prolong)))
 
+    def rows_kmax(self, level):
+        """red-black iterations ONE row-window launch does on that level (10, 5 or 0)"""
+        k = C.c_int()
+        self._call("pyrohip_mg_rows_kmax", int(level), C.byref(k))
+        return k.value
+
+    def diag_rows(self, row0, row1):
+        """(sum ((v - old) / (v + small))^2, sum r^2) over rows [row0, row1] of the finest
+        level; old <- v there"""
+        out = np.zeros(2)
+        self._call("pyrohip_mg_diag_rows", int(row0), int(row1), dptr(out))
+        return float(out[0]), float(out[1])
+
+    def save_old(self):
+        self._call("pyrohip_mg_save_old")
+
     def residual_restrict_rows(self, fine, crow0, crow1):
         self._call("pyrohip_mg_residual_restrict_rows", int(fine), int(crow0), int(crow1))
 
@@ -624,6 +648,7 @@ class DeviceMG:
     def init_rhs_norm(self):
         out = C.c_double()
         self._call("pyrohip_mg_init_rhs_norm", C.byref(out))
+        self.source_norm = out.value
         return out.value
 
     def set_coeffs(self, coeffs, coeffs_bcs):

@@ -49,7 +49,7 @@ class CellCenterMG2d:
                  xl_BC=None, xr_BC=None, yl_BC=None, yr_BC=None,
                  alpha=0.0, beta=-1.0, nsmooth=10, nsmooth_bottom=50, verbose=0,
                  aux_field=None, aux_bc=None, true_function=None, vis=0, vis_title="",
-                 ctx=None):
+                 ctx=None, slab=None):
         if nx != ny:
             raise ValueError("ERROR: multigrid currently requires nx = ny")
         if (xmax - xmin) != (ymax - ymin):
@@ -77,6 +77,18 @@ class CellCenterMG2d:
                                     bcs=types, alpha=alpha, beta=beta, nsmooth=nsmooth,
                                     nsmooth_bottom=nsmooth_bottom)
         self.nlevels = self._dev.nlevels
+        # x-slab decomposition over the GPUs of a node (one process per GPU):
+        # slab = (comm, rank, nranks[, collapse_n]) or what SlabMG.set_decomposition()
+        # installed; every rank constructs the same solver and calls the same methods
+        from .slab import SlabMG
+        self._slab = None
+        slab = slab if slab is not None else SlabMG._default
+        if slab is not None and type(self) is CellCenterMG2d:
+            comm, rank, nranks = slab[:3]
+            collapse = slab[3] if len(slab) > 3 else 256
+            if nranks > 1 and nx > collapse:
+                self._slab = SlabMG(self._dev, comm, rank, nranks, collapse_n=collapse,
+                                    nsmooth=nsmooth)
         bc = bnd.BC(xlb=types[0], xrb=types[1], ylb=types[2], yrb=types[3])
         self.grids = []
         n = 2
@@ -162,6 +174,10 @@ class CellCenterMG2d:
         self._dev.fill_bc(level, 0)
 
     def v_cycle(self, level):
+        if self._slab is not None and level == self.nlevels - 1:
+            self._slab.vcycle()
+            self._slab.gather_solution()
+            return
         self._dev.vcycle(level)
 
     def solve(self, rtol=1.e-11):
@@ -169,7 +185,10 @@ class CellCenterMG2d:
             msg.fail("ERROR: RHS not initialized")
         if self.verbose:
             print("source norm = ", self.source_norm)
-        nc, res, rel = self._dev.solve(rtol=rtol, max_cycles=self.max_cycles)
+        if self._slab is not None:
+            nc, res, rel = self._slab.solve(rtol=rtol, max_cycles=self.max_cycles)
+        else:
+            nc, res, rel = self._dev.solve(rtol=rtol, max_cycles=self.max_cycles)
         self.num_cycles = nc
         self.residual_error = res
         self.relative_error = rel

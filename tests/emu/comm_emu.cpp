@@ -10,6 +10,7 @@ int pyrohip_comm_size(pyrohip_ctx *, int *n) { if (n) *n = 0; return 0; }
 int pyrohip_halo_exchange(pyrohip_state *, int, int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
 int pyrohip_allreduce_min(pyrohip_ctx *, double *) { return 0; }
 int pyrohip_allreduce_max(pyrohip_ctx *, double *) { return 0; }
+int pyrohip_allreduce_sum(pyrohip_ctx *, double *, int) { return 0; }
 int pyrohip_comm_set_global_dt(pyrohip_ctx *, int on)
 {
     if (on) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }

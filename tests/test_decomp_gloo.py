@@ -79,6 +79,22 @@ def _worker(rank, world, port, case, out_dir):
         r0, r1 = sm.rows(L)
         np.savez(os.path.join(out_dir, f"mg_{rank}.npz"), v=sm.solution_rows(), rows=np.array([r0, r1]),
                  v0=v0, rhs=rhs)
+    elif case == "mgsolve":
+        # MG.CellCenterMG2d.solve() with the decomposition installed for every solver object
+        # made from here on (what a caller like the diffusion solver would get)
+        from pyro2_amd.multigrid import MG
+        from pyro2_amd.multigrid.slab import HostRowComm, SlabMG
+        SlabMG.set_decomposition(HostRowComm(td, rank, world), rank, world, collapse_n=64)
+        nx = 256
+        a = MG.CellCenterMG2d(nx, nx, verbose=0, ctx=ctx)
+        assert a._slab is not None
+        a.init_zeros()
+        a.init_RHS(-2.0 * ((1 - 6 * a.x2d**2) * a.y2d**2 * (1 - a.y2d**2) +
+                           (1 - 6 * a.y2d**2) * a.x2d**2 * (1 - a.x2d**2)))
+        a.solve(rtol=1.e-6)
+        np.savez(os.path.join(out_dir, f"mgsolve_{rank}.npz"), v=np.asarray(a.get_solution()),
+                 info=np.array([a.num_cycles, a.residual_error, a.relative_error]))
+        SlabMG.set_decomposition(None, 0, 1)
     else:   # periodic advection, lo == hi for two ranks
         nx, ny, nsteps = 32, 16, 10
         dec = SlabDecomp(nx, world, rank, periodic=True)
@@ -217,6 +233,34 @@ def test_two_rank_periodic_advection_bit_identical(tmp_path):
         z = np.load(tmp_path / f"adv_{r}.npz")
         lo, hi = z["rows"]
         assert np.array_equal(z["U"][4:-4, 4:-4, 0], a[lo + 4:hi - 4, 4:-4]), r
+
+
+def test_multigrid_solve_through_class_two_ranks(tmp_path):
+    """2 processes (gloo): MG.CellCenterMG2d.solve() with SlabMG.set_decomposition() -- the
+    levels above 64^2 in x slabs, halo rows / the two sums of every cycle over gloo -- against
+    the single-domain solve() of the same library: same cycles, same solution bit for bit on
+    both ranks, norms to the order of the additions"""
+    _spawn("mgsolve", tmp_path)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    from pyro2_amd import _lib, device
+    from pyro2_amd.multigrid import MG
+    _lib.use_library(build_emu.LIB, allow_backends=("host-emu",))
+    ctx = device.Context(0)
+    nx = 256
+    a = MG.CellCenterMG2d(nx, nx, verbose=0, ctx=ctx)
+    assert a._slab is None
+    a.init_zeros()
+    a.init_RHS(-2.0 * ((1 - 6 * a.x2d**2) * a.y2d**2 * (1 - a.y2d**2) +
+                       (1 - 6 * a.y2d**2) * a.x2d**2 * (1 - a.x2d**2)))
+    a.solve(rtol=1.e-6)
+    want = np.asarray(a.get_solution())
+    for r in range(2):
+        d = np.load(os.path.join(str(tmp_path), f"mgsolve_{r}.npz"))
+        assert int(d["info"][0]) == a.num_cycles, r
+        assert abs(d["info"][1] / a.residual_error - 1) < 1e-10, r
+        assert abs(d["info"][2] / a.relative_error - 1) < 1e-10, r
+        assert np.array_equal(d["v"][1:-1, 1:-1], want[1:-1, 1:-1]), r
 
 
 def test_multigrid_slabs_with_collapse(tmp_path):

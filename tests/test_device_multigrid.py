@@ -393,6 +393,84 @@ class _LockstepRows:
         self._sync()
 
 
+    def allreduce_sum(self, mg, values):
+        self.s.box[(self.rank, "sum")] = list(values)
+        self._sync()
+        # the same order of additions on every rank
+        tot = [sum(self.s.box[(r, "sum")][k] for r in range(self.nranks)) for k in range(len(values))]
+        self._sync()
+        return tot
+
+    def allgather_rows(self, mg, level, var, rows_of):
+        a, b = rows_of(self.rank)
+        self.s.box[(self.rank, "ag")] = mg.get_rows(level, var, a, b - a + 1)
+        self._sync()
+        for r in range(self.nranks):
+            if r != self.rank:
+                mg.set_rows(level, var, rows_of(r)[0], self.s.box[(r, "ag")])
+        self._sync()
+
+
+@pytest.mark.parametrize("nranks,nx,collapse,march", [(2, 256, 64, 0), (2, 256, 64, 256), (4, 512, 128, 0),
+                                                      (2, 512, 64, 256), (2, 4096, 256, 2048)])
+def test_mg_slab_solve_through_class(dev, nranks, nx, collapse, march):
+    """MG.CellCenterMG2d.solve() on x slabs (SlabMG.solve behind the class: the slab option
+    of the constructor): V-cycles with the fine levels decomposed -- ten iterations per
+    launch on the levels of the row-marching kernel (switched on from `march`^2 here, 2048^2
+    in production) and of the deep-apron band kernel, five in between -- the residual and
+    relative-change sums all-reduced, against the single-domain solve(): same number of
+    cycles, the same solution bit for bit on every rank, norms to the order of the additions."""
+    import threading
+    from pyro2_amd.multigrid import MG
+    if dev.kind == "emu" and nx > 256:
+        pytest.skip("size for the GPU")
+    rtol = 1.e-6 if dev.kind == "emu" else 1.e-9
+    tun = dict(march_min=march, march_waves=16) if march and nx <= 512 else None
+
+    def make(slab=None):
+        a = MG.CellCenterMG2d(nx, nx, verbose=0, ctx=dev, slab=slab)
+        if tun:
+            a._dev.set_tuning(**tun)
+            if a._slab is not None:
+                a._slab.kcap = {l: max(1, min(a._dev.rows_kmax(l), 10)) if l > a._slab.Lc else 10
+                                for l in a._slab.kcap}
+        a.init_zeros()
+        a.init_RHS(-2.0 * ((1 - 6 * a.x2d**2) * a.y2d**2 * (1 - a.y2d**2) +
+                           (1 - 6 * a.y2d**2) * a.x2d**2 * (1 - a.x2d**2)))
+        return a
+    ref = make()
+    ref.solve(rtol=rtol)
+    want = np.asarray(ref.get_solution())
+    assert 1 < ref.num_cycles < 20
+
+    shared = _LockstepRows.Shared(nranks)
+    out, errs = {}, []
+
+    def rank_main(rank):
+        with shared.lock:
+            try:
+                a = make(slab=(_LockstepRows(shared, rank, nranks), rank, nranks, collapse))
+                assert a._slab is not None
+                if march:
+                    assert a._slab.kcap[a.nlevels - 1] == 10
+                a.solve(rtol=rtol)
+                out[rank] = (a.num_cycles, a.residual_error, a.relative_error, np.asarray(a.get_solution()))
+            except BaseException as e:          # noqa: BLE001 - reported below
+                errs.append((rank, e))
+                shared.barrier.abort()
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for r in range(nranks):
+        nc, res, rel, v = out[r]
+        assert nc == ref.num_cycles, r
+        assert abs(res / ref.residual_error - 1) < 1e-10 and abs(rel / ref.relative_error - 1) < 1e-10, r
+        assert np.array_equal(v[1:-1, 1:-1], want[1:-1, 1:-1]), r
+
+
 @pytest.mark.parametrize("nranks,nx,collapse", [(2, 256, 64), (4, 512, 128), (2, 1024, 256)])
 def test_mg_slab_vcycle_bit_identical(dev, nranks, nx, collapse):
     """the V-cycle with its fine levels in x slabs and the coarse ones collapsed onto
