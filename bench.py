@@ -371,7 +371,7 @@ def reference_baseline(section, key):
                       "build container, not on the GPU box"}
 
 
-def bench_advection(ctx, device, nx=2048, steps=100, warmup=10):
+def bench_advection(ctx, device, nx=2048, steps=100, warmup=10, fast_math=1, other=True):
     x = (np.arange(nx + 8) - 3.5) / nx
     X, Y = np.meshgrid(x, x, indexing="ij")
     ic = 1.0 + np.exp(-60.0 * ((X - 0.5) ** 2 + (Y - 0.5) ** 2))
@@ -380,7 +380,7 @@ def bench_advection(ctx, device, nx=2048, steps=100, warmup=10):
     dt = 0.8 * min((1 / nx) / 1.0, (1 / nx) / 1.0)     # advection/simulation.py:38-54, u = v = 1, cfl 0.8
 
     def step():      # the ghost fill is folded into the step kernel (one launch per step)
-        st.adv_step(0, 1 / nx, 1 / nx, 1.0, 1.0, dt, 2, fill=True)
+        st.adv_step(0, 1 / nx, 1 / nx, 1.0, 1.0, dt, 2, fill=True, fast_math=fast_math)
     for _ in range(warmup):
         step()
     ctx.sync()
@@ -400,7 +400,11 @@ def bench_advection(ctx, device, nx=2048, steps=100, warmup=10):
     n, ms = prof["k_adv_step"]
     kern_s = ms / n * 1e-3     # HIP-event duration of the launch (instrumented pass)
     traffic = also_traffic("adv_summary", "bytes_per_step") if nx == 2048 else None
+    out_other = None
+    if other:      # the other arithmetic (fast_math = 0: bit-faithful, the audit build)
+        out_other = bench_advection(ctx, device, nx, steps, warmup, 1 - fast_math, other=False)
     return {"workload": f"advection smooth {nx}x{nx} periodic, limiter 2",
+            "fast_math": fast_math, "other_build": out_other,
             "value": nx * nx * steps / (t1 - t0), "unit": "cell-updates/s",
             "ms_per_step": (t1 - t0) / steps * 1e3, "steps": steps,
             "roofline": {"bound": "hbm", "kernel": "k_adv_step",
@@ -410,7 +414,7 @@ def bench_advection(ctx, device, nx=2048, steps=100, warmup=10):
                          "kernel_avg_ms": ms / n, "traffic": traffic,
                          "step_frac": ADV_BYTES_PER_CELL * nx * nx * steps / (t1 - t0) / 1e9 / HBM_PEAK_GBS,
                          "launches_per_step": 1},
-            "cpu_baseline": reference_baseline("advection", str(nx))}
+            "cpu_baseline": reference_baseline("advection", str(nx)) if other else None}
 
 
 def _mg_vcycles(ctx, device, nx, cycles):
@@ -724,7 +728,9 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_sedov(args.cpu_sample_nx)
             if not args.no_also:
                 also.update({"sedov_small_grids": bench_small_grids(ctx, device),
-                             "advection": bench_advection(ctx, device),
+                             "advection": bench_advection(ctx, device, fast_math=defaults["fast_math"]),
+                             "advection_8192": bench_advection(ctx, device, nx=8192, steps=30, warmup=5,
+                                                               fast_math=defaults["fast_math"]),
                              "multigrid": bench_mg(ctx, device),
                              "incompressible": bench_incompressible(ctx, device)})
                 out["also"] = also
