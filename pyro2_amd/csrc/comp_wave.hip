@@ -124,7 +124,12 @@ constexpr int ST_SLOTS = 37;
 // i.e. behind the HBM prefetch of the next row.  `volatile` keeps the compiler
 // from hoisting the reads (and what is derived from them) out of the row loop.
 enum { C_GAMMA, C_DX, C_DY, C_DT, C_Z0, C_Z1, C_DELTA, C_CVISC, C_SMALLD, C_DTDX, C_DTDY, C_HDTV,
-       C_DTDV, C_GRAV, C_HEATR, C_GM1, C_RGM1, C_RDX, C_RDY, C_KSL, C_KSR, C_RGP1, C_N };
+       C_DTDV, C_GRAV, C_HEATR, C_GM1, C_RGM1, C_RDX, C_RDY, C_KSL, C_KSR, C_RGP1,
+       // fast build: products of the above that the stages use as one factor
+       C_KX, C_KY,          // -hdtV dy, -hdtV dx   (transverse corrections)
+       C_CX, C_CY,          // dtdV dy, dtdV dx     (conservative update)
+       C_CVDX, C_CVDY,      // cvisc dx, cvisc dy   (artificial viscosity)
+       C_N };
 constexpr size_t WLDS_BYTES = (size_t)(ST_SLOTS * 64 + C_N) * sizeof(double);
 #define UC(name) (ct[C_##name])
 // an entry only one of the two builds uses (the table reads are volatile: an unused one
@@ -139,7 +144,7 @@ constexpr size_t WLDS_BYTES = (size_t)(ST_SLOTS * 64 + C_N) * sizeof(double);
 #define UC_FAST(name) 0.0
 #define UC_EXACT(name) UC(name)
 #endif
-#define UC_GASK() GasK{UC(GAMMA), UC(KSL), UC(KSR), UC(RGP1)}
+#define UC_GASK() GasKTab{ct}
 // (an explicit LDS pointer type: a plain `volatile double *` is a generic pointer
 // that the address-space inference leaves alone, i.e. flat loads through vmcnt)
 #if defined(PYRO_EMU)
@@ -147,6 +152,24 @@ typedef volatile double *UniformTab;
 #else
 typedef volatile __attribute__((address_space(3))) double *UniformTab;
 #endif
+
+// gamma and the uniform quotients of it the HLLC solver uses (hydro.h GasK), read from the
+// table where a branch needs them: ksl / ksr only on compressed faces, rgp1 only in the
+// two-shock estimate (as a GasK value all four were read for every Riemann problem)
+struct GasKTab {
+    UniformTab ct;
+    __device__ __forceinline__ double g() const { return ct[C_GAMMA]; }
+    __device__ __forceinline__ double sl() const { return ct[C_KSL]; }
+    __device__ __forceinline__ double sr() const { return ct[C_KSR]; }
+    __device__ __forceinline__ double gp1() const { return ct[C_RGP1]; }
+};
+
+struct FlatKTab {     // flattening parameters, read past the early exits only
+    UniformTab ct;
+    __device__ __forceinline__ double z0() const { return ct[C_Z0]; }
+    __device__ __forceinline__ double z1() const { return ct[C_Z1]; }
+    __device__ __forceinline__ double delta() const { return ct[C_DELTA]; }
+};
 
 __device__ __forceinline__ Cons st_get(const double *st, int s)
 {
@@ -209,6 +232,12 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         ct[C_RDX] = prcp(P.dx); ct[C_RDY] = prcp(P.dy);
         const GasK K0 = make_gask(P.gamma);
         ct[C_KSL] = K0.ksl; ct[C_KSR] = K0.ksr; ct[C_RGP1] = K0.rgp1;
+#if PYRO_FAST
+        const double hdtV = S ? S->hdtV : P.hdtV, dtdV = S ? S->dtdV : P.dtdV;
+        ct[C_KX] = -hdtV * P.dy; ct[C_KY] = -hdtV * P.dx;
+        ct[C_CX] = dtdV * P.dy; ct[C_CY] = dtdV * P.dx;
+        ct[C_CVDX] = P.cvisc * P.dx; ct[C_CVDY] = P.cvisc * P.dy;
+#endif
     }
 
     auto loadU = [&](int row) {
@@ -272,7 +301,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         double fxn = 1.0, l2n[4] = {0, 0, 0, 0};
         if (k >= i0) {
             if (flat)
-                fxn = flatten_1d(wp[0], wp[1], wp[3], wp[4], wu[1], wu[3], UC(Z0), UC(Z1), UC(DELTA));
+                fxn = flatten_1d_k(wp[0], wp[1], wp[3], wp[4], wu[1], wu[3], FlatKTab{ct});
             if (limiter != 0) {
                 l2n[0] = limit2(wr[1], wr[2], wr[3]);
                 l2n[1] = limit2(wu[1], wu[2], wu[3]);
@@ -313,8 +342,8 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             if (flat) {
                 // flatten_multid (reconstruction.py:167-183): own coefficient and the
                 // one of the UPWIND neighbour (w.r.t. the pressure gradient)
-                const double fy = flatten_1d(lane_m2(q0[3]), ym[3], yp[3], lane_p2(q0[3]), ym[2],
-                                             yp[2], UC(Z0), UC(Z1), UC(DELTA));
+                const double fy = flatten_1d_k(lane_m2(q0[3]), ym[3], yp[3], lane_p2(q0[3]), ym[2],
+                                               yp[2], FlatKTab{ct});
                 const double fym = lane_m1(fy), fyp = lane_p1(fy);
                 const double px = (qp[3] - qm[3] > 0) ? fxa : fxn;
                 const double py = (yp[3] - ym[3] > 0) ? fym : fyp;
@@ -353,11 +382,19 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             double avx = 0.0, avy = 0.0;
             if (i >= g.ilo && (i <= g.ihi || (P.avx_hi && i == g.ihi + 1)) && jin) {
                 const double divU_x = 0.5 * (Dn + Dn_p);
+#if PYRO_FAST
+                avx = UC(CVDX) * fmax(-divU_x, 0.0);
+#else
                 avx = UC(CVISC) * fmax(-divU_x * UC(DX), 0.0);
+#endif
             }
             if (j >= g.jlo && (j <= g.jhi || (P.avy_hi && j == g.jhi + 1)) && row_in(i - 1)) {
                 const double divU_y = 0.5 * (Dp + Dn);
+#if PYRO_FAST
+                avy = UC(CVDY) * fmax(-divU_y, 0.0);
+#else
                 avy = UC(CVISC) * fmax(-divU_y * UC(DY), 0.0);
+#endif
             }
             STAGE_FENCE();
             // -- x states of row c, transverse x flux on its lower face
@@ -396,9 +433,15 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             Cons Fy, Fyh;
             if (frow) {
                 const Cons FxTp = st_get(st, ST_FXT);
+#if PYRO_FAST
+                const double kx = UC(KX);
+                const Cons YMc = corr_k(st_get(st, ST_YM), FxTn, FxTp, kx);
+                const Cons YPc = corr_k(st_get(st, ST_YP), FxTn, FxTp, kx);
+#else
                 const double hdtV = UC(HDTV), Ax = UC(DY);
                 const Cons YMc = corr(st_get(st, ST_YM), FxTn, FxTp, hdtV, Ax);
                 const Cons YPc = corr(st_get(st, ST_YP), FxTn, FxTp, hdtV, Ax);
+#endif
                 Fy = from_nf(riemann_face<SOLVER>(to_nf(lane_m1(YPc), false), to_nf(YMc, false),
                                                   UC_GASK(), false, P.solid_yl && j == g.jlo), false);
                 const Cons Umy = lane_m1(Uem);
@@ -436,9 +479,15 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             STAGE_FENCE();
             // -- transverse correction of the x states of row c, final x flux
             const Cons FyTh = lane_p1(FyT);            // FyT at (i, j+1)
+#if PYRO_FAST
+            const double ky = UC(KY);
+            const Cons XMc = corr_k(XMn, FyTh, FyT, ky);
+            const Cons XPc = corr_k(XPn, FyTh, FyT, ky);
+#else
             const double hdtV = UC(HDTV), Ay = UC(DX);
             const Cons XMc = corr(XMn, FyTh, FyT, hdtV, Ay);
             const Cons XPc = corr(XPn, FyTh, FyT, hdtV, Ay);
+#endif
             if (TQ) {   // the next row's transverse problem reads (rho, E) + ST_XPQ only
                 st[ST_XP * 64] = XPn.d; st[(ST_XP + 1) * 64] = XPn.E;
             } else
@@ -456,17 +505,17 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             STAGE_FENCE();
             // -- conservative update of row f + CFL of the new state
             if (frow && jout) {
-                const double dtdV = UC(DTDV), Ax = UC(DY);
                 const Cons Fxp = st_get(st, ST_FX);
                 const Cons &Uc = Uem;
                 Cons Un;   // simulation.py:377-384
 #if PYRO_FAST
-                const double cx = dtdV * Ax, cy = dtdV * Ay;
+                const double cx = UC(CX), cy = UC(CY);
                 Un.d = fma(cx, Fxp.d - Fxn.d, fma(cy, Fy.d - Fyh.d, Uc.d));
                 Un.E = fma(cx, Fxp.E - Fxn.E, fma(cy, Fy.E - Fyh.E, Uc.E));
                 Un.mx = fma(cx, Fxp.mx - Fxn.mx, fma(cy, Fy.mx - Fyh.mx, Uc.mx));
                 Un.my = fma(cx, Fxp.my - Fxn.my, fma(cy, Fy.my - Fyh.my, Uc.my));
 #else
+                const double dtdV = UC(DTDV), Ax = UC(DY);
                 Un.d = Uc.d + dtdV * (Fxp.d * Ax - Fxn.d * Ax + Fy.d * Ay - Fyh.d * Ay);
                 Un.E = Uc.E + dtdV * (Fxp.E * Ax - Fxn.E * Ax + Fy.E * Ay - Fyh.E * Ay);
                 Un.mx = Uc.mx + dtdV * (Fxp.mx * Ax - Fxn.mx * Ax + Fy.mx * Ay - Fyh.mx * Ay);

@@ -73,6 +73,13 @@ __device__ __forceinline__ Cons corr(const Cons &U, const Cons &Fhi, const Cons 
     return r;
 }
 
+// the same with k = -hdtV * A given (fast build of the row-marching kernel)
+__device__ __forceinline__ Cons corr_k(const Cons &U, const Cons &Fhi, const Cons &Flo, double k)
+{
+    return Cons{fma(k, Fhi.d - Flo.d, U.d), fma(k, Fhi.E - Flo.E, U.E),
+                fma(k, Fhi.mx - Flo.mx, U.mx), fma(k, Fhi.my - Flo.my, U.my)};
+}
+
 // limited slope from the limit2 values of the two neighbours (limiter 2), the
 // cell's own limit2 (limiter 1) or none: the expressions of limited_slope()
 // (stencil.h, reconstruction.py:9-120) with the shared limit2 passed in

@@ -256,9 +256,16 @@ __device__ __forceinline__ void cfl_speeds(const Cons &U, double gamma, double &
 
 // 1-d flattening coefficient, pyro/mesh/reconstruction.py:123-164
 //   pm2..pp2 : pressure at -2..+2,  um1/up1 : normal velocity at -1/+1
-__device__ __forceinline__ double flatten_1d(double pm2, double pm1, double pp1, double pp2,
-                                             double um1, double up1, double z0, double z1,
-                                             double delta)
+// (FT: any type with z0(), z1(), delta() -- read where the evaluation gets that far)
+struct FlatK {
+    double z0_, z1_, delta_;
+    __device__ __forceinline__ double z0() const { return z0_; }
+    __device__ __forceinline__ double z1() const { return z1_; }
+    __device__ __forceinline__ double delta() const { return delta_; }
+};
+template <class FT>
+__device__ __forceinline__ double flatten_1d_k(double pm2, double pm1, double pp1, double pp2,
+                                               double um1, double up1, const FT &K)
 {
     // The reference evaluates z and xi everywhere and then selects with
     // np.where(t1 > 0 and t2 > delta, xi, 1).  The selected value only depends
@@ -270,10 +277,17 @@ __device__ __forceinline__ double flatten_1d(double pm2, double pm1, double pp1,
     const double smallp = 1.e-10;
     const double t1 = fabs(pp1 - pm1);
     const double t2b = pdiv(t1, fmin(pp1, pm1));
-    if (!(t2b > delta)) return 1.0;
+    if (!(t2b > K.delta())) return 1.0;
     const double t2 = fabs(pp2 - pm2);
     const double z = pdiv(t1, fmax(t2, smallp));
+    const double z0 = K.z0(), z1 = K.z1();
     return fmin(1.0, fmax(0.0, 1.0 - pdiv(z - z0, z1 - z0)));
+}
+__device__ __forceinline__ double flatten_1d(double pm2, double pm1, double pp1, double pp2,
+                                             double um1, double up1, double z0, double z1,
+                                             double delta)
+{
+    return flatten_1d_k(pm2, pm1, pp1, pp2, um1, up1, FlatK{z0, z1, delta});
 }
 
 // Characteristic tracing of one cell in one direction,
@@ -405,6 +419,13 @@ struct GasK {
     double ksl;    // (gamma + 1) / (2 gamma)        riemann.py:665
     double ksr;    // (gamma + 1) / (2 / gamma)      riemann.py:675 (the quirk)
     double rgp1;   // fast build: 1 / (gamma + 1)
+    // (the solvers below take any type with these four accessors: a kernel that keeps its
+    // uniforms in a table passes one that reads an entry when -- and only when -- a branch
+    // needs it: ksl / ksr on compressed faces, rgp1 in the two-shock estimate)
+    __device__ __forceinline__ double g() const { return gamma; }
+    __device__ __forceinline__ double sl() const { return ksl; }
+    __device__ __forceinline__ double sr() const { return ksr; }
+    __device__ __forceinline__ double gp1() const { return rgp1; }
 };
 __device__ __forceinline__ GasK make_gask(double gamma)
 {
@@ -416,12 +437,13 @@ __device__ __forceinline__ GasK make_gask(double gamma)
     return k;
 }
 
+template <class KT>
 __device__ __forceinline__ void estimate_wave_speed(double rho_l, double u_l, double p_l,
                                                     double c_l, double rho_r, double u_r,
-                                                    double p_r, double c_r, const GasK &K,
+                                                    double p_r, double c_r, const KT &K,
                                                     double &S_l, double &S_r)
 {
-    const double gamma = K.gamma;
+    const double gamma = K.g();
     double p_max = fmax(p_l, p_r);
     double p_min = fmin(p_l, p_r);
 #if PYRO_FAST && !defined(PYRO_EMU)
@@ -448,9 +470,9 @@ __device__ __forceinline__ void estimate_wave_speed(double rho_l, double u_l, do
                                      pdiv(1.0, z)));
         } else {               // two-shock, :640-658
             double A_r = pdiv(2.0, (gamma + 1.0) * rho_r);
-            double B_r = pdivr(p_r * (gamma - 1.0), gamma + 1.0, K.rgp1);
+            double B_r = pdivr(p_r * (gamma - 1.0), gamma + 1.0, K.gp1());
             double A_l = pdiv(2.0, (gamma + 1.0) * rho_l);
-            double B_l = pdivr(p_l * (gamma - 1.0), gamma + 1.0, K.rgp1);
+            double B_l = pdivr(p_l * (gamma - 1.0), gamma + 1.0, K.gp1());
             double p_guess = fmax(0.0, pstar);
             double g_l = psqrt_nc(pdiv(A_l, p_guess + B_l));
             double g_r = psqrt_nc(pdiv(A_r, p_guess + B_r));
@@ -460,11 +482,11 @@ __device__ __forceinline__ void estimate_wave_speed(double rho_l, double u_l, do
     if (pstar <= p_l)
         S_l = u_l - c_l;
     else
-        S_l = u_l - c_l * psqrt_nc(1.0 + K.ksl * (pdiv(pstar, p_l) - 1.0));
+        S_l = u_l - c_l * psqrt_nc(1.0 + K.sl() * (pdiv(pstar, p_l) - 1.0));
     if (pstar <= p_r)
         S_r = u_r + c_r;
     else
-        S_r = u_r + c_r * psqrt_nc(1.0 + K.ksr * (pdiv(pstar, p_r) - 1.0));
+        S_r = u_r + c_r * psqrt_nc(1.0 + K.sr() * (pdiv(pstar, p_r) - 1.0));
 }
 
 // consFlux in the (normal, transverse) frame, riemann.py:1104-1179.
@@ -518,12 +540,13 @@ struct FaceQ { double un, ut, p; };
 //    (insert U*_k: the mass flux is rho u + S (f - rho) = f S - a = f S_c, and so on):
 //    one reciprocal, no physical flux of the outer state, 17 instead of 35 instructions;
 //  * PVRS pressure as one fma over (u_l - u_r) (rho_l + rho_r) (c_l + c_r) / 8.
+template <class KT>
 __device__ __forceinline__ void estimate_wave_speed_fast(double rho_l, double u_l, double p_l,
                                                          double c_l, double rho_r, double u_r,
-                                                         double p_r, double c_r, const GasK &K,
+                                                         double p_r, double c_r, const KT &K,
                                                          double &S_l, double &S_r)
 {
-    const double gamma = K.gamma;
+    const double gamma = K.g();
     const double p_max = fmax(p_l, p_r), p_min = fmin(p_l, p_r);
     double pstar = fma(0.125 * (u_l - u_r), (rho_l + rho_r) * (c_l + c_r), 0.5 * (p_l + p_r));
     if (__builtin_expect(p_max > 2.0 * p_min && (pstar < p_min || pstar > p_max), 0)) {      // riemann.py:621-658
@@ -539,9 +562,9 @@ __device__ __forceinline__ void estimate_wave_speed_fast(double rho_l, double u_
                                      pdiv(1.0, z)));
         } else {               // two-shock, :640-658
             double A_r = pdiv(2.0, (gamma + 1.0) * rho_r);
-            double B_r = p_r * (gamma - 1.0) * K.rgp1;
+            double B_r = p_r * (gamma - 1.0) * K.gp1();
             double A_l = pdiv(2.0, (gamma + 1.0) * rho_l);
-            double B_l = p_l * (gamma - 1.0) * K.rgp1;
+            double B_l = p_l * (gamma - 1.0) * K.gp1();
             double p_guess = fmax(0.0, pstar);
             double g_l = psqrt_nc(pdiv(A_l, p_guess + B_l));
             double g_r = psqrt_nc(pdiv(A_r, p_guess + B_r));
@@ -549,17 +572,17 @@ __device__ __forceinline__ void estimate_wave_speed_fast(double rho_l, double u_
         }
     }
     S_l = u_l - c_l;
-    if (pstar > p_l) S_l = fma(-c_l, psqrt_nc(fma(K.ksl, pstar * prcp(p_l) - 1.0, 1.0)), u_l);
+    if (pstar > p_l) S_l = fma(-c_l, psqrt_nc(fma(K.sl(), pstar * prcp(p_l) - 1.0, 1.0)), u_l);
     S_r = u_r + c_r;
-    if (pstar > p_r) S_r = fma(c_r, psqrt_nc(fma(K.ksr, pstar * prcp(p_r) - 1.0, 1.0)), u_r);
+    if (pstar > p_r) S_r = fma(c_r, psqrt_nc(fma(K.sr(), pstar * prcp(p_r) - 1.0, 1.0)), u_r);
 }
 
-template <bool HAVEQ>
+template <bool HAVEQ, class KT>
 __device__ __forceinline__ ConsN hllc_flux_impl(const ConsN &Ul, const ConsN &Ur, const FaceQ &ql,
-                                                const FaceQ &qr, const GasK &K, bool normal_is_x)
+                                                const FaceQ &qr, const KT &K, bool normal_is_x)
 {
     (void)normal_is_x;
-    const double gamma = K.gamma;
+    const double gamma = K.g();
     const double smallc = 1.e-10, smallp = 1.e-10;
     const double rho_l = Ul.d, rho_r = Ur.d;
     double un_l, ut_l, pf_l, un_r, ut_r, pf_r;     // pf: pressure of the physical flux
@@ -615,11 +638,11 @@ __device__ __forceinline__ ConsN hllc_flux_impl(const ConsN &Ul, const ConsN &Ur
     return outer(Ul, un_l, ut_l, pf_l);
 }
 #else
-template <bool HAVEQ>
+template <bool HAVEQ, class KT>
 __device__ __forceinline__ ConsN hllc_flux_impl(const ConsN &Ul, const ConsN &Ur, const FaceQ &ql,
-                                                const FaceQ &qr, const GasK &K, bool normal_is_x)
+                                                const FaceQ &qr, const KT &K, bool normal_is_x)
 {
-    const double gamma = K.gamma;
+    const double gamma = K.g();
     const double smallc = 1.e-10, smallp = 1.e-10;
     double rho_l = Ul.d;
     const double ril = PYRO_FAST ? prcp(rho_l) : 0.0;
@@ -711,11 +734,12 @@ __device__ __forceinline__ ConsN hllc_flux_impl(const ConsN &Ul, const ConsN &Ur
     return F;
 }
 #endif
-__device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, const GasK &K,
+template <class KT>
+__device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, const KT &K,
                                            bool normal_is_x)
 {
     const FaceQ none{0.0, 0.0, 0.0};
-    return hllc_flux_impl<false>(Ul, Ur, none, none, K, normal_is_x);
+    return hllc_flux_impl<false, KT>(Ul, Ur, none, none, K, normal_is_x);
 }
 
 
@@ -724,10 +748,11 @@ __device__ __forceinline__ ConsN hllc_flux(const ConsN &Ul, const ConsN &Ur, con
 // chi = min(1, max|v| / max c), and the star fluxes are written in the
 // (S_c (S U - F) + S p* D) / (S - S_c) form with D = (0, S_c, 1, 0) in
 // (density, energy, normal momentum, transverse momentum).
-__device__ __forceinline__ ConsN hllc_lm_flux(const ConsN &Ul, const ConsN &Ur, const GasK &K,
+template <class KT>
+__device__ __forceinline__ ConsN hllc_lm_flux(const ConsN &Ul, const ConsN &Ur, const KT &K,
                                               bool normal_is_x)
 {
-    const double gamma = K.gamma;
+    const double gamma = K.g();
     const double smallc = 1.e-10, smallp = 1.e-10;
     const double rho_l = Ul.d;
     const double ril = PYRO_FAST ? prcp(rho_l) : 0.0;
@@ -863,11 +888,11 @@ __device__ __forceinline__ ConsN cgf_flux(const ConsN &Ul, const ConsN &Ur, doub
 }
 
 // compressible.riemann dispatch: SOLVER 0 = HLLC, 1 = CGF, 2 = HLLC_lm
-template <int SOLVER>
-__device__ __forceinline__ ConsN riemann_face(const ConsN &Ul, const ConsN &Ur, const GasK &K,
+template <int SOLVER, class KT>
+__device__ __forceinline__ ConsN riemann_face(const ConsN &Ul, const ConsN &Ur, const KT &K,
                                               bool normal_is_x, bool wall_zero)
 {
-    if (SOLVER == 1) return cgf_flux(Ul, Ur, K.gamma, normal_is_x, wall_zero);
+    if (SOLVER == 1) return cgf_flux(Ul, Ur, K.g(), normal_is_x, wall_zero);
     if (SOLVER == 2) return hllc_lm_flux(Ul, Ur, K, normal_is_x);
     return hllc_flux(Ul, Ur, K, normal_is_x);
 }
