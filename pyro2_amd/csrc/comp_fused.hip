@@ -433,6 +433,8 @@ int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP 
     P.dtdx = dt / p->dx; P.dtdy = dt / p->dy;
     P.hdtV = (0.5 * dt) / (p->dx * p->dy);
     P.dtdV = dt / (p->dx * p->dy);
+    P.gm1 = p->gamma - 1.0; P.rgm1 = 1.0 / (p->gamma - 1.0);
+    P.rdx = 1.0 / p->dx; P.rdy = 1.0 / p->dy;
     P.grav = p->grav;
     P.refl_ylo = (s->bc[3 * 4 + 2] == PYROHIP_BC_REFLECT_ODD);
     P.refl_yhi = (s->bc[3 * 4 + 3] == PYROHIP_BC_REFLECT_ODD);

@@ -132,6 +132,18 @@ enum { C_GAMMA, C_DX, C_DY, C_DT, C_Z0, C_Z1, C_DELTA, C_CVISC, C_SMALLD, C_DTDX
        C_N };
 constexpr size_t WLDS_BYTES = (size_t)(ST_SLOTS * 64 + C_N) * sizeof(double);
 #define UC(name) (ct[C_##name])
+// Where a uniform comes from.  Bit-faithful build: the table (its stages keep more values
+// alive; scalar registers spilled into vector lanes cost it registers it does not have:
+// 16.4 vs 15.7 ms).  Fast build: scalar registers -- kernel arguments, this step's dt
+// quotients (scalar loads from the device-side scalars) and the products the stages use,
+// computed once per wavefront and moved to scalar registers -- measured 9.4 vs 9.9 ms at
+// 16384^2: a scalar operand needs no LDS round trip, and what the allocator spills goes to
+// vector LANES (v_readlane, no memory).
+#if PYRO_FAST && !defined(PYRO_EMU)
+#define US(name, expr) (expr)
+#else
+#define US(name, expr) UC(name)
+#endif
 // an entry only one of the two builds uses (the table reads are volatile: an unused one
 // would still be issued)
 #if defined(PYRO_EMU)     // (the emulated fast build divides by the operand, not by its reciprocal)
@@ -144,7 +156,7 @@ constexpr size_t WLDS_BYTES = (size_t)(ST_SLOTS * 64 + C_N) * sizeof(double);
 #define UC_FAST(name) 0.0
 #define UC_EXACT(name) UC(name)
 #endif
-#define UC_GASK() GasKTab{ct}
+#define UC_GASK() GasKTab{ct, US(GAMMA, P.gamma)}
 // (an explicit LDS pointer type: a plain `volatile double *` is a generic pointer
 // that the address-space inference leaves alone, i.e. flat loads through vmcnt)
 #if defined(PYRO_EMU)
@@ -158,7 +170,8 @@ typedef volatile __attribute__((address_space(3))) double *UniformTab;
 // two-shock estimate (as a GasK value all four were read for every Riemann problem)
 struct GasKTab {
     UniformTab ct;
-    __device__ __forceinline__ double g() const { return ct[C_GAMMA]; }
+    double gam;
+    __device__ __forceinline__ double g() const { return gam; }
     __device__ __forceinline__ double sl() const { return ct[C_KSL]; }
     __device__ __forceinline__ double sr() const { return ct[C_KSR]; }
     __device__ __forceinline__ double gp1() const { return ct[C_RGP1]; }
@@ -220,6 +233,19 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         if (l == 0) partial[sb * P.ncb + cb] = INFINITY;
         return;
     }
+#if PYRO_FAST && !defined(PYRO_EMU)
+    // this step's dt quotients (device-side run: scalar loads from the step scalars) and the
+    // products the stages use as one factor: computed once, kept in scalar registers
+    auto sgpr = [](double v) {
+        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                                __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    };
+    const double s_dtdx = S ? S->dtdx : P.dtdx, s_dtdy = S ? S->dtdy : P.dtdy;
+    const double s_hdtV = S ? S->hdtV : P.hdtV, s_dtdV = S ? S->dtdV : P.dtdV;
+    const double s_kx = sgpr(-s_hdtV * P.dy), s_ky = sgpr(-s_hdtV * P.dx);
+    const double s_cx = sgpr(s_dtdV * P.dy), s_cy = sgpr(s_dtdV * P.dx);
+    const double s_cvdx = sgpr(P.cvisc * P.dx), s_cvdy = sgpr(P.cvisc * P.dy);
+#endif
     if (l == 0) {     // one wavefront, LDS operations complete in order: no barrier needed
         // (device-side run: this step's dt and its quotients live in device memory)
         ct[C_GAMMA] = P.gamma; ct[C_DX] = P.dx; ct[C_DY] = P.dy; ct[C_DT] = S ? S->dt : P.dt;
@@ -281,7 +307,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         }
         Uem = Ue;
         Ue = Urep;
-        if (row_in(k - 3) && jin) Ue.d = fmax(Ue.d, UC(SMALLD));      // clean_state
+        if (row_in(k - 3) && jin) Ue.d = fmax(Ue.d, US(SMALLD, P.small_dens));      // clean_state
         // (issuing this second read of row k-2 in the middle of the iteration instead -- eight
         // registers less while the slopes and the first Riemann problems are worked on -- was
         // measured: the allocator spills elsewhere, 10.35 vs 10.46 ms fast, 16.37 vs 15.96 exact)
@@ -291,9 +317,9 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             Cons U = Upre;
             Upre = loadU(k + 1);
             const bool interior = row_in(k) && jin;
-            if (interior) U.d = fmax(U.d, UC(SMALLD));
+            if (interior) U.d = fmax(U.d, US(SMALLD, P.small_dens));
             bool ok;
-            const Prim q = cons_to_prim_nb(U, UC(GAMMA), ok);
+            const Prim q = cons_to_prim_nb(U, US(GAMMA, P.gamma), ok);
             if (interior && !ok) bad = true;
             wr[4] = q.r; wu[4] = q.u; wv[4] = q.v; wp[4] = q.p;
         }
@@ -369,7 +395,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 const size_t kc = (size_t)(ina ? i : g.qx - 1) * p + (ina ? js : g.qy - 1);
                 Ug.d = Uin[kc]; Ug.my = Uin[3 * pl + kc];
                 if (i >= g.ilo && i <= g.ihi && js >= g.jlo && js <= g.jhi)
-                    Ug.d = fmax(Ug.d, UC(SMALLD));
+                    Ug.d = fmax(Ug.d, US(SMALLD, P.small_dens));
                 sgn = ((j < g.jlo && P.refl_ylo) || (j > g.jhi && P.refl_yhi)) ? -1.0 : 1.0;
                 hp = P.heat ? P.heat[(size_t)(ina ? i : g.qx - 1) * p + (ina ? j : g.qy - 1)] : 0.0;
             }
@@ -377,13 +403,13 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             // artificial viscosity coefficients of the faces (i, j) in x and (i-1, j)
             // in y (interface.py:366-376: only faces i in [ilo, ihi], j in [jlo, jhi])
             Dn = div_u_vertex_r(q0[1], um, qm[1], up, q0[2], qm[2], vm, vp, UC_EXACT(DX), UC_EXACT(DY),
-                                UC_FAST(RDX), UC_FAST(RDY));
+                                US(RDX, P.rdx), US(RDY, P.rdy));
             const double Dn_p = lane_p1(Dn);
             double avx = 0.0, avy = 0.0;
             if (i >= g.ilo && (i <= g.ihi || (P.avx_hi && i == g.ihi + 1)) && jin) {
                 const double divU_x = 0.5 * (Dn + Dn_p);
 #if PYRO_FAST
-                avx = UC(CVDX) * fmax(-divU_x, 0.0);
+                avx = US(CVDX, s_cvdx) * fmax(-divU_x, 0.0);
 #else
                 avx = UC(CVISC) * fmax(-divU_x * UC(DX), 0.0);
 #endif
@@ -391,7 +417,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             if (j >= g.jlo && (j <= g.jhi || (P.avy_hi && j == g.jhi + 1)) && row_in(i - 1)) {
                 const double divU_y = 0.5 * (Dp + Dn);
 #if PYRO_FAST
-                avy = UC(CVDY) * fmax(-divU_y, 0.0);
+                avy = US(CVDY, s_cvdy) * fmax(-divU_y, 0.0);
 #else
                 avy = UC(CVISC) * fmax(-divU_y * UC(DY), 0.0);
 #endif
@@ -399,10 +425,10 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             STAGE_FENCE();
             // -- x states of row c, transverse x flux on its lower face
             Trace lo, hi;
-            double gamma = UC(GAMMA);
+            double gamma = US(GAMMA, P.gamma);
             trace_states(q0[0], q0[1], q0[2], q0[3], dqx[0], dqx[1], dqx[2], dqx[3], gamma,
-                         UC(DTDX), lo, hi);
-            double gm1 = UC_EXACT(GM1), rgm1 = UC_FAST(RGM1);
+                         US(DTDX, s_dtdx), lo, hi);
+            double gm1 = UC_EXACT(GM1), rgm1 = US(RGM1, P.rgm1);
             Cons XMn = prim_to_cons_g(Prim{lo.r, lo.un, lo.ut, lo.p}, gm1, rgm1);
             Cons XPn = prim_to_cons_g(Prim{hi.r, hi.un, hi.ut, hi.p}, gm1, rgm1);
             FaceQ qxm{lo.un, lo.ut, lo.p}, qxp{hi.un, hi.ut, hi.p};
@@ -434,7 +460,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             if (frow) {
                 const Cons FxTp = st_get(st, ST_FXT);
 #if PYRO_FAST
-                const double kx = UC(KX);
+                const double kx = US(KX, s_kx);
                 const Cons YMc = corr_k(st_get(st, ST_YM), FxTn, FxTp, kx);
                 const Cons YPc = corr_k(st_get(st, ST_YP), FxTn, FxTp, kx);
 #else
@@ -454,10 +480,10 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             if (xface) st_put(st, ST_FXT, FxTn);
             STAGE_FENCE();
             // -- y states of row c, transverse y flux on its lower face
-            gamma = UC(GAMMA);
+            gamma = US(GAMMA, P.gamma);
             trace_states(q0[0], q0[2], q0[1], q0[3], dqy[0], dqy[2], dqy[1], dqy[3], gamma,
-                         UC(DTDY), lo, hi);
-            gm1 = UC_EXACT(GM1); rgm1 = UC_FAST(RGM1);
+                         US(DTDY, s_dtdy), lo, hi);
+            gm1 = UC_EXACT(GM1); rgm1 = US(RGM1, P.rgm1);
             Cons YMn = prim_to_cons_g(Prim{lo.r, lo.ut, lo.un, lo.p}, gm1, rgm1);
             Cons YPn = prim_to_cons_g(Prim{hi.r, hi.ut, hi.un, hi.p}, gm1, rgm1);
             FaceQ qym{lo.un, lo.ut, lo.p}, qyp{hi.un, hi.ut, hi.p};
@@ -480,7 +506,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             // -- transverse correction of the x states of row c, final x flux
             const Cons FyTh = lane_p1(FyT);            // FyT at (i, j+1)
 #if PYRO_FAST
-            const double ky = UC(KY);
+            const double ky = US(KY, s_ky);
             const Cons XMc = corr_k(XMn, FyTh, FyT, ky);
             const Cons XPc = corr_k(XPn, FyTh, FyT, ky);
 #else
@@ -509,7 +535,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 const Cons &Uc = Uem;
                 Cons Un;   // simulation.py:377-384
 #if PYRO_FAST
-                const double cx = UC(CX), cy = UC(CY);
+                const double cx = US(CX, s_cx), cy = US(CY, s_cy);
                 Un.d = fma(cx, Fxp.d - Fxn.d, fma(cy, Fy.d - Fyh.d, Uc.d));
                 Un.E = fma(cx, Fxp.E - Fxn.E, fma(cy, Fy.E - Fyh.E, Uc.E));
                 Un.mx = fma(cx, Fxp.mx - Fxn.mx, fma(cy, Fy.mx - Fyh.mx, Uc.mx));
@@ -534,7 +560,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 Uout[3 * pl + ko] = Un.my;
 #endif
                 double ax, ay;   // CFL: running maxima of the divisors, one division at the end
-                cfl_speeds(Un, UC(GAMMA), ax, ay);
+                cfl_speeds(Un, US(GAMMA, P.gamma), ax, ay);
                 st[ST_AX * 64] = fmax(st[ST_AX * 64], ax);
                 st[ST_AY * 64] = fmax(st[ST_AY * 64], ay);
             }

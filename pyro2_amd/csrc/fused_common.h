@@ -14,6 +14,8 @@ struct FP {   // kernel parameters
     double dtdx, dtdy;    // dt/dx, dt/dy          interface.py:106
     double hdtV;          // (0.5*dt)/(dx*dy)      unsplit_fluxes.py:444-445
     double dtdV;          // dt/(dx*dy)            simulation.py:375
+    double gm1, rgm1;     // gamma - 1 and its reciprocal (the fast build multiplies by it)
+    double rdx, rdy;      // 1 / dx, 1 / dy (fast build)
     double grav;          // compressible.grav (0: no source terms)
     int refl_ylo, refl_yhi;   // y-momentum reflects oddly at the lower / upper y wall
     int amb_yhi;              // "ambient" boundary on the upper y side
