@@ -202,7 +202,9 @@ __global__ __launch_bounds__(64 * ADV_WPB) void k_adv_step(const double *__restr
     //          j-1 / j+my) and F_x of rows c-1, c
     // (where the loop closes the compiler's s_waitcnt bookkeeping falls back to draining
     // nearly all loads in flight -- vmcnt(2) instead of vmcnt(6) -- once per trip; unrolling
-    // over two or three periods was measured and changes nothing)
+    // over two or three periods was measured and changes nothing, and so does issuing the
+    // row loads by inline assembly with a hand-placed s_waitcnt vmcnt(2 ADV_PF): 271-274 vs
+    // 262-269 us at 8192^2 -- the waits are not the compiler's)
 #ifndef PYRO_ADV_UNR
 #define PYRO_ADV_UNR 1
 #endif

@@ -21,7 +21,7 @@ for nx, rows_list in [(int(a.split(":")[0]), a.split(":")[1]) for a in SPEC.spli
         pol = DtPolicy(1.0e9)
         st.comp_evolve(P, 0.8, pol, 5)
         ctx.sync()
-        n = max(10, int(2.0e9 / (nx * nx)))
+        n = int(os.environ.get("STEPS", "0")) or max(10, int(2.0e9 / (nx * nx)))
         t0 = time.perf_counter()
         st.comp_evolve(P, 0.8, pol, n)
         ctx.sync()
