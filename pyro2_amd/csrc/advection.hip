@@ -127,6 +127,9 @@ __device__ __forceinline__ double adv_slope(double l2m, double l20, double l2p, 
 // wavefronts per workgroup (they do not cooperate: no LDS, no barrier).  Four per workgroup,
 // so that the dispatcher hands out four strips at a time, was measured: 24.3 vs 23.2 us at
 // 2048^2, 267 vs 261 us at 8192^2 -- one it is.
+#ifndef PYRO_ADV_PRIO
+#define PYRO_ADV_PRIO 1
+#endif
 #ifndef PYRO_ADV_WPB
 #define PYRO_ADV_WPB 1
 #endif
@@ -289,11 +292,29 @@ __global__ __launch_bounds__(64 * ADV_WPB) void k_adv_step(const double *__restr
         Fxr[(U + 1) % 2] = Fx;
 #undef ADV_W
     };
-    for (int k0 = ka; k0 <= kb; k0 += UNR)
+#if !defined(PYRO_EMU) && PYRO_ADV_PRIO
+    // the wavefronts of a SIMD are served oldest first (comp_wave.hip: the younger ones get
+    // what is left and finish alone); they take turns at the priorities instead, by their
+    // slot number on the SIMD, one block of the unrolled loop each
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    int turn = (int)(hw_id & 3u);
+#endif
+    for (int k0 = ka; k0 <= kb; k0 += UNR) {
+#if !defined(PYRO_EMU) && PYRO_ADV_PRIO
+        switch (turn & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
+        turn++;
+#endif
         adv_static_for<UNR>([&](auto uc) __attribute__((always_inline)) {
             const int k = k0 + decltype(uc)::value;
             if (k <= kb) step(uc, k);
         });
+    }
 }
 
 // rows per strip: about three wavefronts per SIMD in ONE round (the kernel is short: a

@@ -444,6 +444,7 @@ int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP 
     P.solid_xl = p->solid_xl; P.solid_yl = p->solid_yl;
     P.ntj = P.ntiles = 0;
     P.L = P.ncb = P.nsb = P.nunits = 0;
+    P.prio_duty = 0;
     P.sb_first = 0; P.sb_step = 1;
     P.mr = bc_map(g.ilo, g.ihi, g.ng, 0, 0, false);      // identity (tile kernel: fused_fill_maps)
     P.mc = P.mr;

@@ -62,6 +62,9 @@ constexpr int WOUT = 56;          // columns a wavefront updates
 #else
 #define STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+#ifndef PYRO_WAVE_PRIO_SHIFT
+#define PYRO_WAVE_PRIO_SHIFT 1    // the priority changes hands in units of 2 rows
+#endif
 #ifndef PYRO_WAVE_MINW
 #define PYRO_WAVE_MINW 2          // waves per SIMD the register allocation must allow
 #endif
@@ -193,6 +196,7 @@ __device__ __forceinline__ void st_put(double *st, int s, const Cons &U)
     st[s * 64] = U.d; st[(s + 1) * 64] = U.E; st[(s + 2) * 64] = U.mx; st[(s + 3) * 64] = U.my;
 }
 
+
 template <int SOLVER, bool STD>   // as k_ctu_fused
 __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *__restrict__ Uin,
                                                                  double *__restrict__ Uout, Geom g,
@@ -300,7 +304,27 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         st[ST_XPQ * 64] = 0.0; st[(ST_XPQ + 1) * 64] = 0.0; st[(ST_XPQ + 2) * 64] = 1.0;
     }
 
+#if !defined(PYRO_EMU)
+    // The two wavefronts of a SIMD are arbitrated by age: the older one runs almost as if it
+    // were alone, the younger one gets what is left, and when the older one is done the younger
+    // finishes alone at half the issue rate -- measured per wavefront at 4096^2 (one round of
+    // resident wavefronts; tools/timeline_report.py): 1.11 M cycles for one half of the
+    // wavefronts, 1.56 M for the other half, on every SIMD.  With many rounds a new wavefront
+    // takes the place of the finished one and nothing is lost; with one or two rounds the
+    // tail is a third of the launch.  So the two take turns at the higher priority, a few
+    // rows each (by the wavefront's slot number on its SIMD), and finish together.
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    const int wslot = (int)(hw_id & 1u);
+#endif
     for (int k = i0 - 4; k <= i1 + 3; k++) {
+#if !defined(PYRO_EMU)
+        if (P.prio_duty > 0) {
+            const int phase = ((k - i0) >> PYRO_WAVE_PRIO_SHIFT) & 7;
+            if (wslot ? (phase < P.prio_duty) : (phase >= P.prio_duty)) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
 #pragma unroll
         for (int n = 0; n < 4; n++) {
             wr[n] = wr[n + 1]; wu[n] = wu[n + 1]; wv[n] = wv[n + 1]; wp[n] = wp[n + 1];
@@ -606,6 +630,13 @@ static int wave_rows(int nx, int ncb, int slots)
     return best;
 }
 
+// Launches of up to two rounds of resident wavefronts: the second wavefront of a SIMD (by
+// its slot number) holds the higher priority six eighths of the time, so that the pair ends
+// together (see the kernel; measured at 4096^2, one round: 0.804 -> 0.736 ms, duty 4 / 5 / 6 /
+// 7 of 8: 0.777 / 0.764 / 0.736 / 0.744).  With many rounds the arbitration by age is the
+// better one (8192^2, 8.5 rounds: 2.66 ms against 2.70 with the priorities).
+static int wave_prio_duty(int nwaves, int slots) { return nwaves <= 2 * slots ? 6 : 0; }
+
 int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
                       const StepScalars *S, const double **dmin_out)   // as comp_step_fused_ex
 {
@@ -644,12 +675,14 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         // exchange is posted on the halo stream and runs beside the interior strips
         P.sb_first = 0; P.sb_step = nsb - 1;
         P.nunits = 2 * P.ncb;
+        P.prio_duty = wave_prio_duty(P.nunits, 4 * PYRO_WAVE_MINW * cus);
         PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((P.nunits + 7) / 8)), dim3(64), WLDS_BYTES,
                     (const double *)Uin, Uout, g, P, s->d_flag, part, S);
         fused_copy_frame(s);           // old ghost frame -> new buffer, BEFORE the halos land in it
         PYRO_TRY(comm_post_halo(s, Uout));
         P.sb_first = 1; P.sb_step = 1;
         P.nunits = (nsb - 2) * P.ncb;
+        P.prio_duty = wave_prio_duty(P.nunits, 4 * PYRO_WAVE_MINW * cus);
         PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((P.nunits + 7) / 8)), dim3(64),
                     WLDS_BYTES, (const double *)Uin, Uout, g, P, s->d_flag, part, S);
         const double *dmin;
@@ -661,6 +694,7 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         return rc;
     }
     P.nunits = nwg;
+    P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus);
     PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((nwg + 7) / 8)), dim3(64), WLDS_BYTES,
                 (const double *)Uin, Uout, g, P, s->d_flag, part, S);
     if (post) {        // too few strips to overlap: the exchange follows the whole update

@@ -25,6 +25,7 @@ struct FP {   // kernel parameters
     int solid_xl, solid_yl;   // CGF wall rule (riemann.py:274-286)
     int L, ncb, nsb;          // row-marching kernel: rows per strip, column blocks, strips
     int nunits;               // ... (column block, strip) pairs of this launch
+    int prio_duty;            // ... eighths of the time the second wavefront of a SIMD has priority (0: age decides)
     int sb_first, sb_step;    // ... strip of workgroup b: sb_first + (b / ncb) * sb_step
     // tile kernel: the ghost fill folded into the loads (pyrohip_comp_params.fuse_fill):
     // row / column maps of the boundary rules (identity without) and, per variable and

@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_device_advection.py tests/test_zz_comm.py tests/test_host_api.py -m gpu -x -q 2>&1 | tail -2
-BOTH=1 SIZES="2048:0,13,13;8192:0,48,32" timeout 300 python tools/adv_time.py 2>&1
+for lib in libv_np.so libpyrohip.so; do echo $lib; PYRO2_AMD_LIB=$PWD/pyro2_amd/lib/$lib SIZES="2048:13,13,12;8192:48,48" timeout 300 python tools/adv_time.py 2>&1; done
+STEPS=12 SIZES="2048:0;4096:0;8192:0;16384:0" timeout 600 python tools/march_sweep.py
+FM=0 STEPS=12 SIZES="4096:0;16384:0" timeout 600 python tools/march_sweep.py
