@@ -162,6 +162,10 @@ int pyrohip_adv_step(pyrohip_state *s, int n, double dx, double dy, double u,
    of the reference.  fill = 0: ghost cells are used as they are. */
 int pyrohip_adv_step_fill(pyrohip_state *s, int n, double dx, double dy, double u,
                           double v, double dt, int limiter, int fill);
+/* (after a step with the fill folded in -- here and in pyrohip_comp_step with
+   pyrohip_comp_params.fuse_fill -- the ghost cells IN MEMORY hold what the fill at the
+   START of that step gave them, like the reference's array after evolve(); they are not
+   the fill of the new state: call pyrohip_fill_bc before reading ghost cells on the host) */
 /* the same with the parameters in a struct.
    fast_math   0: bit-faithful arithmetic (the reference's operation order, no
                contraction: results identical to NumPy, what the two functions above
