@@ -225,6 +225,8 @@ def bench_sedov(args, dist, ctx, device, defaults, steps=None, warmup=None, tile
     device_dt = not args.host_dt and isinstance(comm, (NoComm, RcclComm))
 
     def run(n):
+        if n <= 0:
+            return
         if device_dt:
             assert len(slab.evolve(pol, 0.8, n)) == n
         else:

@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_device_multigrid.py -m gpu -x -q 2>&1 | tail -2
-for lib in libv_np.so libpyrohip.so libv_np.so libpyrohip.so; do echo $lib; PYRO2_AMD_LIB=$PWD/pyro2_amd/lib/$lib MG_SIZES=2048,4096 timeout 300 python tools/mg_sizes.py; done
+mkdir -p gpurun_out
+O=gpurun_out
+PYRO_BENCH_COMM=host timeout 600 python bench.py --gpus 2 --nx 4096 --steps 5 --warmup 2 --no-also --no-cpu-baseline --scale-check > $O/r03z_bench_2rank.json 2> $O/r03z_bench_2rank.err; tail -c 900 $O/r03z_bench_2rank.json; tail -3 $O/r03z_bench_2rank.err
