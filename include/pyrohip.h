@@ -317,6 +317,8 @@ int pyrohip_mg_set_smoother(pyrohip_mg *m, int kind);
      band_maxn        band smoother up to this level size (2048)
      band_genedge     band smoother: the general edge instance everywhere (0)
      coarse_band64    coarse V-cycle kernel: the 64^2 level's sweeps in registers (1)
+     march_tail       inside solve(): the down leg's residual + restriction and the cycle's
+                      two sums ride on the marching smoother's launches (1)
      speculate        solve(): launch the next V-cycle while the norms travel to the host:
                       0 never, 1 when a further cycle is likely (default), 2 always
      trace, spec_debug  developer aids (phase clocks of the band / coarse kernels; solve()
@@ -329,9 +331,13 @@ typedef struct {
     int fuse_res_restrict, lazy_residual, allow_pow2;
     int small_tiles, band_maxn, band_genedge, coarse_band64;
     int speculate, trace, spec_debug;
+    int march_tail;
 } pyrohip_mg_tuning;
 int pyrohip_mg_get_tuning(pyrohip_mg *m, pyrohip_mg_tuning *t);
 int pyrohip_mg_set_tuning(pyrohip_mg *m, const pyrohip_mg_tuning *t);
+/* marching launches so far that carried the down leg's residual + restriction / a solve
+   cycle's two sums (march_tail above; the tests make sure the path they test is the one taken) */
+int pyrohip_mg_tail_counts(pyrohip_mg *m, int *restrictions, int *diagnostics);
 /* var: 0 = v, 1 = f, 2 = r; arrays are (n+2, n+2) with ng = 1 */
 int pyrohip_mg_set(pyrohip_mg *m, int level, int var, const double *host);
 int pyrohip_mg_get(pyrohip_mg *m, int level, int var, double *host);

@@ -51,7 +51,8 @@ class MGTuning(C.Structure):
                 ("march_minrows", C.c_int), ("fuse_res_restrict", C.c_int),
                 ("lazy_residual", C.c_int), ("allow_pow2", C.c_int), ("small_tiles", C.c_int),
                 ("band_maxn", C.c_int), ("band_genedge", C.c_int), ("coarse_band64", C.c_int),
-                ("speculate", C.c_int), ("trace", C.c_int), ("spec_debug", C.c_int)]
+                ("speculate", C.c_int), ("trace", C.c_int), ("spec_debug", C.c_int),
+                ("march_tail", C.c_int)]
 
 
 class CompParams(C.Structure):
@@ -180,6 +181,7 @@ _PROTOS = {
     "pyrohip_mg_copy_solution": [_VP, _VP, C.c_int],
     "pyrohip_mg_get_tuning": [_VP, C.POINTER(MGTuning)],
     "pyrohip_mg_set_tuning": [_VP, C.POINTER(MGTuning)],
+    "pyrohip_mg_tail_counts": [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "pyrohip_comm_unique_id": [C.c_char_p],
     "pyrohip_comm_init": [_VP, C.c_int, C.c_int, C.c_char_p],
     "pyrohip_comm_destroy": [_VP],

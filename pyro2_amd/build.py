@@ -42,6 +42,9 @@ UNITS = [
     ("comp_api.hip", "comp_api", ["-ffp-contract=off"]),
     ("multigrid.hip", "multigrid", ["-ffp-contract=off"]),
     ("mg_march.hip", "mg_march", ["-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=200000"]),
+    # ... its instances with a tail (MGMarch::tail) in units of their own: minutes each
+    ("mg_march.hip", "mg_march_t1", ["-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=200000", "-DMGM_UNIT=1"]),
+    ("mg_march.hip", "mg_march_t2", ["-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=200000", "-DMGM_UNIT=2"]),
     ("incompressible.hip", "incompressible", ["-ffp-contract=off"]),
     ("swe.hip", "swe", ["-ffp-contract=off"]),
     ("comm.hip", "comm", ["-ffp-contract=off"]),
@@ -84,6 +87,10 @@ def build(force=False, verbose=False):
         src, name, extra = u
         obj = os.path.join(LIBDIR, "obj", name + os.environ.get("PYRO_OBJ_SUFFIX", "") + ".o")
         fx = FAST_EXTRA if "-DPYRO_FAST=1" in extra else []
+        # an object newer than every source is kept (not with experiment flags: those may differ)
+        if not force and not EXTRA and not fx and not os.environ.get("PYRO_WAVE_SCHED") and \
+                not _stale(obj, deps + [os.path.abspath(__file__)]):
+            return obj
         cmd = [hipcc, f"--offload-arch={ARCH}"] + COMMON + extra + EXTRA + fx + \
               ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:

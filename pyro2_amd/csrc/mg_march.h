@@ -25,6 +25,17 @@ struct MGMarch {
     // in shorter chunks of their own, so that their wavefronts take as long as the others;
     // nchunks_side == 0: no such strips, every strip in chunks of CR rows
     int CR_side, nchunks_side;
+    // what rides on the tail of the march (whole-level launches only): the rows a wavefront
+    // has finished are still in its registers when their neighbours above become final
+    //   1  down leg: residual of the smoothed level, restricted into the next coarser level's
+    //      right-hand side cf (k_mg_residual_restrict's arithmetic and order; r is not stored)
+    //   2  last launch of a solve cycle on the finest level: the sums of MG.py:670-686,
+    //      ((v - old) / (v + small))^2 and r^2, one pair of partials per wavefront
+    //      (partial[b], partial[nblocks + b]: k_sum_final2 finishes)
+    int tail;
+    double alpha, beta, dx2, rdx2, small;
+    double *cf; int cfpitch;
+    const double *old; double *partial;
 };
 
 // red-black iterations per launch: 10, a whole V-cycle leg in one pass over the level.  (A
@@ -34,12 +45,15 @@ struct MGMarch {
 constexpr int MGM_PF = 2;
 constexpr bool mgm_has_k(int K) { return K == 10; }
 // columns a strip stores (the rest: the apron of 2K sweeps, one more column for parity)
-constexpr int mgm_tj(int K) { return MGM_COLS - 4 * K - 2; }
+// (a launch with tail 2: four less, mg_march.hip: mgm_part)
+constexpr int mgm_tj(int K, int tail = 0) { return MGM_COLS - 4 * K - 2 - (tail == 2 ? 4 : 0); }
 // rows by which a part that ends at the top boundary may start lower (window rows - 2)
 constexpr int mgm_align(int K) { return 2 * K + MGM_PF; }
 
 int mg_march_blocks(const MGMarch &A);
 int mg_march_launch(pyrohip_ctx *c, MGMarch &A, bool pow2, int K);
+int mg_march_launch_tail1(pyrohip_ctx *c, MGMarch &A, bool pow2);   // MGMarch::tail (own compile units)
+int mg_march_launch_tail2(pyrohip_ctx *c, MGMarch &A, bool pow2);
 bool mg_march_usable(const MGMarch &A, int K);
 
 }  // namespace pyro

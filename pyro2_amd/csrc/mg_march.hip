@@ -54,6 +54,13 @@ __device__ __forceinline__ double quot(double a, double b, double rb)
     return fma(e, rb, q);
 }
 
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
 template <int N, int U = 0, class F> __device__ __forceinline__ void static_for(F &&fn)
 {
     if constexpr (U < N) {
@@ -70,7 +77,7 @@ struct Part {
     bool plo_i, phi_i, plo_j, phi_j;   // its window reaches the physical boundary there
 };
 
-__device__ __forceinline__ Part mgm_part(const MGMarch &A, int NP, int W)
+__device__ __forceinline__ Part mgm_part(const MGMarch &A, int NP, int W, int tail)
 {
     Part P;
     const int n = A.n;
@@ -85,7 +92,14 @@ __device__ __forceinline__ Part mgm_part(const MGMarch &A, int NP, int W)
     }
     P.tj0 = 1 + cs * A.TJ; P.tj1 = min(P.tj0 + A.TJ - 1, n);
     P.ra = A.row0 + ch * CR; P.rb = min(P.ra + CR - 1, A.row1);
-    int gj0 = P.tj0 - NP, g0 = P.ra - NP, gend = P.rb + NP;
+    // (a tail needs row rb + 1 final too; row ra - 1 and the columns beside the strip are:
+    // ra and tj0 are odd, the even starts below add a row / a column, and the strip's 128
+    // columns leave NP + 1 on the right as well)
+    // (tail 2 rides on a launch that prolongs: the correction added to the window's first and
+    // last column takes a coarse value from beyond the window -- those columns start wrong,
+    // one sweep earlier than the rotation alone makes them; two more columns of apron on
+    // either side, the strips of such a launch store four columns less: mgm_tj)
+    int gj0 = P.tj0 - NP - (tail == 2 ? 2 : 0), g0 = P.ra - NP, gend = P.rb + NP + (tail ? 1 : 0);
     if (!per_j) gj0 = max(gj0, 0);
     if (!per_i) { g0 = max(g0, 0); gend = min(gend, n); }
     // even starts: the class a sweep relaxes in a row / lane is then known at compile time
@@ -106,8 +120,8 @@ __device__ __forceinline__ double ghost_sign(int code) { return code == PYROHIP_
 
 // EDGEI: the level has physical boundaries below / above; EDGEJ: this wavefront's strip
 // reaches a physical boundary left / right
-template <int NP, int PF, bool POW2, bool PROL, bool EDGEI, bool EDGEJ>
-__device__ __forceinline__ void mgm_march(const MGMarch &A, const Part &P)
+template <int NP, int PF, bool POW2, bool PROL, bool EDGEI, bool EDGEJ, int TAIL>
+__device__ __forceinline__ void mgm_march(const MGMarch &A, const Part &P, double (*fst)[64])
 {
     constexpr int W = NP + 2 + PF;      // window: rows k + PF (in flight) ... k - NP - 1
     static_assert(W % 2 == 0 && PF >= 1, "the unrolled block must keep the row parity");
@@ -145,6 +159,17 @@ __device__ __forceinline__ void mgm_march(const MGMarch &A, const Part &P)
     double v[W][2], f[W][2];
 #pragma unroll
     for (int r = 0; r < W; r++) { v[r][0] = v[r][1] = 0.0; f[r][0] = f[r][1] = 0.0; }
+    // The diagnostics' tail on top of the prolongation does not fit 256 registers: there the
+    // older half of the right-hand side's window (rows k - FA and older: twelve rows) lives
+    // in LDS, a slot per thread, written once when a row reaches that age and read once per
+    // step and row by the sweep that needs it.
+    constexpr bool FST = (TAIL == 2);
+    constexpr int FA = NP / 2, FR = W / 2;
+    static_assert(!FST || (NP + 1 - FA < FR && W % FR == 0), "the stashed rows must fit the ring");
+    // (indices and ages are compile-time constants once the loops are unrolled)
+    auto f_at = [&](int S, int age, int q) __attribute__((always_inline)) -> double {
+        return (FST && age >= FA) ? fst[(S % FR) * 2 + q][ln] : f[S][q];
+    };
 
     auto row_of = [&](int g) -> unsigned {      // array row of window row g (unwrapped)
         const int w = g + (g < 1 ? n : 0) - (g > n ? n : 0);
@@ -195,6 +220,11 @@ __device__ __forceinline__ void mgm_march(const MGMarch &A, const Part &P)
         load_crow(cpre, ci + 2);
     }
 
+    // ---- tail state: the row below the one whose residual is taken (its window slot is
+    // loaded over by then), the odd row's residuals (restriction), the old solution's row
+    // one step ahead and the two sums (diagnostics) ----
+    double vA[2] = {0, 0}, rodd[2] = {0, 0}, oldr[2][2] = {{0, 0}, {0, 0}}, srel = 0.0, sres = 0.0;
+
     const bool col_ghosts = P.tj0 == 1 || P.tj1 == n;   // the strip stores column 1 or n
     // rows 0 .. PF - 1 on their way
     static_for<PF>([&](auto sc) __attribute__((always_inline)) { load_row(sc, decltype(sc)::value); });
@@ -205,6 +235,11 @@ __device__ __forceinline__ void mgm_march(const MGMarch &A, const Part &P)
         const bool botBlk = EDGEI && P.plo_i && k0 == 0, topBlk = EDGEI && P.phi_i && k0 == kTop;
         // (1) row k + PF on its way
         load_row(std::integral_constant<int, (U + PF) % W>{}, k + PF);
+        if constexpr (TAIL == 2) {     // the old solution's row for the next step's tail
+            const unsigned base = row_of(g0 + k - NP) * pitch;
+            oldr[(U + 1) & 1][0] = A.old[base + gjw[0]];
+            oldr[(U + 1) & 1][1] = A.old[base + gjw[1]];
+        }
         // (2) row k enters: scale f (exact, see mg_pow2), add the prolonged correction
         {
             constexpr int S = U % W;
@@ -229,12 +264,18 @@ __device__ __forceinline__ void mgm_march(const MGMarch &A, const Part &P)
                 }
             }
         }
+        if constexpr (FST) {
+            constexpr int SF = (U - FA + 2 * W) % W;
+            fst[(SF % FR) * 2][ln] = f[SF][0];
+            fst[(SF % FR) * 2 + 1][ln] = f[SF][1];
+        }
         // (3) sweep s on row k - s; its cells of the class being relaxed are the thread's
         // column (k + 1) & 1 in every one of these rows
         constexpr int Q = (U + 1) & 1;
 #pragma unroll
         for (int s = 1; s <= NP; s++) {
             const int SR = (U - s + 2 * W) % W, SU = (SR + 1) % W, SD = (SR + W - 1) % W;
+            const double fq = f_at(SR, s, Q);
             const double me = v[SR][Q];
             const double up = v[SU][Q], dn = v[SD][Q];
             const double own = v[SR][Q ^ 1];
@@ -248,9 +289,9 @@ __device__ __forceinline__ void mgm_march(const MGMarch &A, const Part &P)
             else if (EDGEI && U == s && topBlk) si = fma(me, sT, dn);
             else si = up + dn;
             if (POW2)
-                v[SR][Q] = fma(A.ky, sj, fma(A.kx, si, f[SR][Q]));
+                v[SR][Q] = fma(A.ky, sj, fma(A.kx, si, fq));
             else
-                v[SR][Q] = quot(f[SR][Q] + A.xc * si + A.yc * sj, A.denom, A.rdenom);
+                v[SR][Q] = quot(fq + A.xc * si + A.yc * sj, A.denom, A.rdenom);
         }
         // (4) row k - NP is final
         {
@@ -282,37 +323,123 @@ __device__ __forceinline__ void mgm_march(const MGMarch &A, const Part &P)
                 }
             }
         }
+        // (5) the tail: row k - NP - 1 has been final since the previous step, now the rows
+        // below (vA) and above it are too: its residual, k_mg_residual's expression (the
+        // ghost cells' values are the mirror values the stores above keep current)
+        if constexpr (TAIL != 0) {
+            constexpr int SC = (U - NP + 2 * W) % W, SB = (U - NP - 1 + 2 * W) % W;
+            const int gi = g0 + k - NP - 1;
+            if (gi >= P.ra && gi <= P.rb) {
+                const bool bot = EDGEI && !per_i && gi == 1, top = EDGEI && !per_i && gi == n;
+                const double fromW = from_lower(v[SB][1]), fromE = from_upper(v[SB][0]);
+                double rr[2];
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const double me = v[SB][q];
+                    const double dn = bot ? sB * me : vA[q], up = top ? sT * me : v[SC][q];
+                    double w = q ? v[SB][0] : fromW, e = q ? fromE : v[SB][1];
+                    if (EDGEJ && q == 1 && isW1) w = sW * me;
+                    if (EDGEJ && q == 0 && isE0) e = sE * me;
+                    const double fs = f_at(SB, NP + 1, q);
+                    const double fo = POW2 ? fs * A.denom : fs;
+                    rr[q] = fo - A.alpha * me +
+                            A.beta * (quot(dn + up - 2 * me, A.dx2, A.rdx2) +
+                                      quot(w + e - 2 * me, A.dx2, A.rdx2));
+                }
+                if constexpr (TAIL == 1) {
+                    // fine rows 2 ci - 1, 2 ci and columns 2 cj - 1, 2 cj make coarse cell (ci, cj):
+                    // the thread's odd column and the next thread's even one, summed in
+                    // k_mg_restrict's order (r00 + r10 + r01 + r11)
+                    if constexpr ((U + 1) & 1) { rodd[0] = rr[0]; rodd[1] = rr[1]; }   // gi is odd
+                    else {
+                        const double r01 = from_upper(rodd[0]), r11 = from_upper(rr[0]);
+                        const double c = 0.25 * (rodd[1] + rr[1] + r01 + r11);
+                        if (st[1])
+                            A.cf[(unsigned)(gi >> 1) * (unsigned)A.cfpitch + (unsigned)((gj0 >> 1) + ln + 1)] = c;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const double d = (v[SB][q] - oldr[U & 1][q]) / (v[SB][q] + A.small);
+                        if (st[q]) { srel += d * d; sres += rr[q] * rr[q]; }
+                    }
+                }
+            }
+            vA[0] = v[SB][0]; vA[1] = v[SB][1];
+        }
     };
 
     const int nsteps = P.nload + NP;
     for (int k0 = 0; k0 < nsteps; k0 += W)
         static_for<W>([&](auto uc) __attribute__((always_inline)) { step(uc, k0); });
+    if constexpr (TAIL == 2) {
+        srel = wave_sum(srel);
+        sres = wave_sum(sres);
+        if (ln == 0) { A.partial[blockIdx.x] = srel; A.partial[gridDim.x + blockIdx.x] = sres; }
+    }
 }
 
 // (The two wavefronts of a SIMD taking turns at s_setprio, which shortens the single-round
 // launches of the compressible kernel by 8 %, was measured here too: 851 -> 1070 us per
 // 4096^2 V-cycle.  This kernel waits for memory, not for issue slots: arbitration by age.)
-template <int NP, int PF, bool POW2, bool PROL, bool ANYEDGE>
+template <int NP, int PF, bool POW2, bool PROL, bool ANYEDGE, int TAIL = 0>
 __global__ __launch_bounds__(64, 2) void k_mg_smooth_march(MGMarch A)
 {
-    const Part P = mgm_part(A, NP, NP + 2 + PF);
+    const Part P = mgm_part(A, NP, NP + 2 + PF, TAIL);
+    __shared__ double fst[TAIL == 2 ? NP + 2 + PF : 1][64];   // mgm_march: FST
     if (ANYEDGE && (P.plo_j || P.phi_j))
-        mgm_march<NP, PF, POW2, PROL, ANYEDGE, true>(A, P);
+        mgm_march<NP, PF, POW2, PROL, ANYEDGE, true, TAIL>(A, P, fst);
     else
-        mgm_march<NP, PF, POW2, PROL, ANYEDGE, false>(A, P);
+        mgm_march<NP, PF, POW2, PROL, ANYEDGE, false, TAIL>(A, P, fst);
 }
 
 }  // namespace
 
+// The file is compiled three times (build.py: MGM_UNIT 0, 1, 2 -- the instances without a
+// tail and the host side, those with the restriction, those with the diagnostics): one unit
+// with all sixteen instances takes minutes.
+#ifndef MGM_UNIT
+#define MGM_UNIT 0
+#endif
+using KernT = void (*)(MGMarch);
+constexpr int MGM_NP = 20;
+static bool mgm_edge(const MGMarch &A)
+{
+    return A.code[0] != PYROHIP_BC_PERIODIC || A.code[2] != PYROHIP_BC_PERIODIC;
+}
+
+#if MGM_UNIT == 1
+// the restriction rides on a down-leg launch (no prolongation)
+int mg_march_launch_tail1(pyrohip_ctx *c, MGMarch &A, bool pow2)
+{
+    constexpr int NP = MGM_NP, PF = MGM_PF;
+    static const KernT tail1[2][2] = {{k_mg_smooth_march<NP, PF, false, false, false, 1>, k_mg_smooth_march<NP, PF, false, false, true, 1>},
+                                      {k_mg_smooth_march<NP, PF, true, false, false, 1>, k_mg_smooth_march<NP, PF, true, false, true, 1>}};
+    PYRO_LAUNCH(c, "k_mg_smooth_march", tail1[pow2 ? 1 : 0][mgm_edge(A) ? 1 : 0], dim3(mg_march_blocks(A)), dim3(64), 0, A);
+    return 0;
+}
+#elif MGM_UNIT == 2
+// the solve diagnostics on the last up-leg launch (with the prolongation)
+int mg_march_launch_tail2(pyrohip_ctx *c, MGMarch &A, bool pow2)
+{
+    constexpr int NP = MGM_NP, PF = MGM_PF;
+    static const KernT tail2[2][2] = {{k_mg_smooth_march<NP, PF, false, true, false, 2>, k_mg_smooth_march<NP, PF, false, true, true, 2>},
+                                      {k_mg_smooth_march<NP, PF, true, true, false, 2>, k_mg_smooth_march<NP, PF, true, true, true, 2>}};
+    PYRO_LAUNCH(c, "k_mg_smooth_march", tail2[pow2 ? 1 : 0][mgm_edge(A) ? 1 : 0], dim3(mg_march_blocks(A)), dim3(64), 0, A);
+    return 0;
+}
+#else
 template <int K> static int launch_k(pyrohip_ctx *c, MGMarch &A, bool pow2)
 {
     constexpr int NP = 2 * K, PF = MGM_PF;
-    const bool edge = A.code[0] != PYROHIP_BC_PERIODIC || A.code[2] != PYROHIP_BC_PERIODIC;
-    using KernT = void (*)(MGMarch);
+    static_assert(NP == MGM_NP, "the tails' units are built for ten iterations");
+    const bool edge = mgm_edge(A);
 #define MGM_ROW(P2, PR) {k_mg_smooth_march<NP, PF, P2, PR, false>, k_mg_smooth_march<NP, PF, P2, PR, true>}
     static const KernT inst[2][2][2] = {{MGM_ROW(false, false), MGM_ROW(false, true)},
                                         {MGM_ROW(true, false), MGM_ROW(true, true)}};
 #undef MGM_ROW
+    if (A.tail == 1) return mg_march_launch_tail1(c, A, pow2);
+    if (A.tail == 2) return mg_march_launch_tail2(c, A, pow2);
     PYRO_LAUNCH(c, "k_mg_smooth_march", inst[pow2 ? 1 : 0][A.cv ? 1 : 0][edge ? 1 : 0],
                 dim3(mg_march_blocks(A)), dim3(64), 0, A);
     return 0;
@@ -345,8 +472,13 @@ bool mg_march_usable(const MGMarch &A, int K)
     if (A.row0 < 1 || A.row1 > A.n || A.row1 - A.row0 + 1 <= A.CR) return false;
     if (window && (A.code[0] == PYROHIP_BC_PERIODIC || A.nchunks_side > 0 || A.CR < mgm_align(K) + 4))
         return false;
+    // a tail: whole level, parts of whole coarse rows, the launch it is compiled into
+    if (A.tail != 0 && (window || (A.CR & 1) || (A.nchunks_side > 0 && (A.CR_side & 1)) ||
+                        (A.tail == 1 ? A.cv != nullptr : A.cv == nullptr)))
+        return false;
     return mgm_has_k(K) && A.n % 2 == 0 && A.n >= 2 * MGM_COLS && A.nchunks >= 2 &&
            A.CR + 4 * K + mgm_align(K) < A.n;
 }
+#endif   // MGM_UNIT
 
 }  // namespace pyro

@@ -85,6 +85,14 @@ struct pyrohip_mg {
     int march_minrows = 32;   // rows a part stores, at least
     int coarse_kernel = 1;        // levels <= 64^2 in one LDS-resident workgroup
     int fuse_res_restrict = 1;   // down leg: residual + restriction in one pass
+    // ... and inside solve(), where nobody reads r: on the tail of the marching smoother's
+    // launch (MGMarch::tail: no pass of its own at all); likewise the two sums after a cycle
+    int march_tail = 1;
+    int tail_done = 0;            // the tail the last smoothing call carried
+    int n_tail[3] = {0, 0, 0};    // launches with tail 1 / 2 so far (pyrohip_mg_tail_counts)
+    bool diag_req = false, diag_done = false;   // solve(): the sums are wanted / were taken
+    int diag_nb = 0;              // ... partials per sum
+    double *diag_part = nullptr;
     int vc = 0;                   // 1: div(eta grad phi) = f; 2: general (alpha, beta, gamma)
     double *vc_pool = nullptr;
     double *gen_pool = nullptr;
@@ -1787,9 +1795,10 @@ static void mg_swap_solution(pyrohip_mg *m, int level)
 }
 
 static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong = false,
-                           int row0 = 1, int row1 = -1, int *nlaunch = nullptr)
+                           int row0 = 1, int row1 = -1, int *nlaunch = nullptr, int tail = 0)
 {
     MGLevel &L = m->lev[level];
+    m->tail_done = 0;
     if (row1 < 0) row1 = L.n;
     const int nrows = row1 - row0 + 1;
     int launches = 0;
@@ -1862,30 +1871,51 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
         for (int s = 0; s < 4; s++) M.code[s] = A.bc.code[s];
         M.cv = A.cv; M.cpitch = A.cpitch; M.vin_zero = A.vin_zero;
         M.row0 = row0; M.row1 = row1;
-        M.TJ = mgm_tj(MK); M.ncs = (L.n + M.TJ - 1) / M.TJ;
+        // what rides on the launch that finishes the call (mg_march.h: MGMarch::tail)
+        M.tail = (left == MK && row0 == 1 && row1 == L.n && m->march_tail) ? tail : 0;
+        if (M.tail == 1 && !(level > 0 && !M.cv)) M.tail = 0;
+        if (M.tail == 2 && !(m->old_captured && M.cv && level == m->nlevels - 1)) M.tail = 0;
+        M.alpha = m->alpha; M.beta = m->beta; M.dx2 = L.dx * L.dx; M.rdx2 = 1.0 / M.dx2; M.small = 1.e-16;
+        M.cf = nullptr; M.cfpitch = 0; M.old = nullptr; M.partial = nullptr;
         // row chunks: as many wavefronts as the device holds at once, not one more (two per
         // SIMD at 256 registers: a wavefront too many would run alone after all the others); the
         // parts that end at the top boundary start up to mgm_align rows lower (mg_march.hip:
         // mgm_part), so the last chunk is made that much shorter
         const int slots = march_waves > 0 ? march_waves : 8 * (m->ctx->num_cus > 0 ? m->ctx->num_cus : 256);
         const int pad = (M.code[0] != PYROHIP_BC_PERIODIC && row1 == L.n) ? mgm_align(MK) : 0;
-        const bool sides = M.code[2] != PYROHIP_BC_PERIODIC && M.ncs >= 3 && m->march_side > 1.0 &&
-                           row0 == 1 && row1 == L.n;
-        auto chunks = [&](int rows, int least, int &cr) {   // chunks of about `rows` rows -> count
-            cr = rows < least ? least : rows;
-            return (nrows + cr - 1) / cr;
+        auto cut = [&]() {
+            M.TJ = mgm_tj(MK, M.tail); M.ncs = (L.n + M.TJ - 1) / M.TJ;
+            const bool sides = M.code[2] != PYROHIP_BC_PERIODIC && M.ncs >= 3 && m->march_side > 1.0 &&
+                               row0 == 1 && row1 == L.n;
+            auto chunks = [&](int rows, int least, int &cr) {   // chunks of about `rows` rows -> count
+                cr = rows < least ? least : rows;
+                if (M.tail) cr += cr & 1;                     // whole coarse rows
+                return (nrows + cr - 1) / cr;
+            };
+            M.nchunks_side = 0; M.CR_side = 0;
+            for (int nch = slots / M.ncs > 2 ? slots / M.ncs : 2; nch >= 2; nch--) {
+                M.nchunks = chunks((nrows + pad + nch - 1) / nch, m->march_minrows, M.CR);
+                if (!sides) break;
+                // a wavefront of a side strip needs march_side times as long per row: fewer rows
+                const int steps = M.CR + 6 * MK;              // apron below and above, 2K steps to drain
+                M.nchunks_side = chunks((int)(steps / m->march_side) - 6 * MK, 8, M.CR_side);
+                if ((M.ncs - 2) * M.nchunks + 2 * M.nchunks_side <= slots || nch == 2) break;
+            }
+            return mg_march_usable(M, MK);
         };
-        M.nchunks_side = 0; M.CR_side = 0;
-        for (int nch = slots / M.ncs > 2 ? slots / M.ncs : 2; nch >= 2; nch--) {
-            M.nchunks = chunks((nrows + pad + nch - 1) / nch, m->march_minrows, M.CR);
-            if (!sides) break;
-            // a wavefront of a side strip needs march_side times as long per row: fewer rows
-            const int steps = M.CR + 6 * MK;              // apron below and above, 2K steps to drain
-            M.nchunks_side = chunks((int)(steps / m->march_side) - 6 * MK, 8, M.CR_side);
-            if ((M.ncs - 2) * M.nchunks + 2 * M.nchunks_side <= slots || nch == 2) break;
+        bool ok = cut();
+        if (!ok && M.tail) { M.tail = 0; ok = cut(); }       // without the tail, then
+        if (!ok) break;
+        if (M.tail == 1) { M.cf = m->lev[level - 1].f; M.cfpitch = m->lev[level - 1].pitch; }
+        if (M.tail == 2) {
+            const int nb = mg_march_blocks(M);
+            PYRO_TRY(m->ctx->reduce.ensure((2 * (size_t)nb + 4) * sizeof(double)));
+            M.old = m->old_phi; M.partial = (double *)m->ctx->reduce.p;
+            m->diag_nb = nb; m->diag_part = M.partial;
         }
-        if (!mg_march_usable(M, MK)) break;
         PYRO_TRY(mg_march_launch(m->ctx, M, pow2, MK));
+        m->tail_done = M.tail;
+        m->n_tail[M.tail]++;
         launches++;
         mg_swap_solution(m, level);
         left -= MK;
@@ -1966,8 +1996,9 @@ static int mg_smooth_tiles(pyrohip_mg *m, int level, int nsmooth, bool prolong =
 // `corners`: also make the corner ghosts exact (needed only when the array is
 // handed to the host; no kernel reads corners)
 static int mg_smooth(pyrohip_mg *m, int level, int nsmooth, bool corners = true,
-                     bool prolong = false)
+                     bool prolong = false, int tail = 0)
 {
+    m->tail_done = 0;
     if (m->vc) {   // variable coefficients: one launch per colour
         PYRO_TRY(mg_fill(m, level, 0));
         MGLevel &L = m->lev[level];
@@ -1995,7 +2026,7 @@ static int mg_smooth(pyrohip_mg *m, int level, int nsmooth, bool corners = true,
     }
     // the tile kernel refreshes the edge ghosts itself on load (= the fill_BC
     // of MG.py:565) and leaves them current on exit
-    PYRO_TRY(mg_smooth_tiles(m, level, nsmooth, prolong));
+    PYRO_TRY(mg_smooth_tiles(m, level, nsmooth, prolong, 1, -1, nullptr, tail));
     m->corners_stale[level] = !corners;
     return corners ? mg_fill(m, level, 0) : 0;
 }
@@ -2129,8 +2160,12 @@ static int mg_vcycle(pyrohip_mg *m, int level)
     if (!m->vc && m->smoother != 0 && m->coarse_kernel && level <= MGC_TOP)
         return mg_coarse_vcycle(m, level);
     if (level > 0) {
-        PYRO_TRY(mg_smooth(m, level, m->nsmooth, false)); // MG.py:722
-        if (!m->vc && m->fuse_res_restrict) {             // :724 + :731-732 in one pass
+        // inside solve() nobody reads r: residual and restriction ride on the smoothing launch
+        const bool no_r = m->lazy_r && m->in_solve;
+        PYRO_TRY(mg_smooth(m, level, m->nsmooth, false, false,
+                           (!m->vc && m->fuse_res_restrict && no_r) ? 1 : 0)); // MG.py:722
+        if (m->tail_done == 1) m->r_stale[level] = true;  // :724 + :731-732 done there
+        else if (!m->vc && m->fuse_res_restrict) {        // :724 + :731-732 in one pass
             MGLevel &F = m->lev[level], &Cc = m->lev[level - 1];
             const int bx = (Cc.n >= 256) ? 256 : 64;
             const bool store = !(m->lazy_r && m->in_solve);
@@ -2149,7 +2184,9 @@ static int mg_vcycle(pyrohip_mg *m, int level)
         const bool fuse = mg_prolong_fusable(m, level, m->nsmooth);
         if (!fuse) PYRO_TRY(mg_prolong_add(m, level));    // :745-748 (else: while staging below)
         if (m->smoother == 0 || m->vc) PYRO_TRY(mg_fill(m, level, 0));   // :751 (tile smoother: on load)
-        PYRO_TRY(mg_smooth(m, level, m->nsmooth, false, fuse)); // :758
+        const bool diag = m->diag_req && level == m->nlevels - 1;
+        PYRO_TRY(mg_smooth(m, level, m->nsmooth, false, fuse, diag ? 2 : 0)); // :758
+        if (diag && m->tail_done == 2) m->diag_done = true;
     } else {
         PYRO_TRY(mg_smooth(m, level, m->nsmooth_bottom, false)); // :776
         if (m->smoother == 0 || m->vc) PYRO_TRY(mg_fill(m, level, 0));     // :778
@@ -2259,6 +2296,7 @@ int pyrohip_mg_get_tuning(pyrohip_mg *m, pyrohip_mg_tuning *t)
     t->small_tiles = m->small_tiles; t->band_maxn = m->band_maxn;
     t->band_genedge = m->band_genedge ? 1 : 0; t->coarse_band64 = m->coarse_band64 ? 1 : 0;
     t->speculate = m->speculate; t->trace = m->trace ? 1 : 0; t->spec_debug = m->spec_debug ? 1 : 0;
+    t->march_tail = m->march_tail;
     return 0;
 }
 
@@ -2276,6 +2314,15 @@ int pyrohip_mg_set_tuning(pyrohip_mg *m, const pyrohip_mg_tuning *t)
     m->small_tiles = t->small_tiles; m->band_maxn = t->band_maxn;
     m->band_genedge = t->band_genedge != 0; m->coarse_band64 = t->coarse_band64 != 0;
     m->speculate = t->speculate; m->trace = t->trace != 0; m->spec_debug = t->spec_debug != 0;
+    m->march_tail = t->march_tail;
+    return 0;
+}
+
+int pyrohip_mg_tail_counts(pyrohip_mg *m, int *restrictions, int *diagnostics)
+{
+    PYRO_REQUIRE(m && restrictions && diagnostics, "NULL argument");
+    *restrictions = m->n_tail[1];
+    *diagnostics = m->n_tail[2];
     return 0;
 }
 
@@ -2765,9 +2812,12 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
         m->in_solve = true;
         m->capture_old = !m->vc;
         m->old_captured = false;
+        m->diag_req = !sync && m->lazy_r;   // the sums below on the tail of the last launch
+        m->diag_done = false;
         const int vrc = mg_vcycle(m, Lf);
         m->in_solve = false;
         m->capture_old = false;
+        m->diag_req = false;
         PYRO_TRY(vrc);
         if (sync) {                                       // :673-678
             PYRO_TRY(mg_sumsq(m, F.v, m->old_phi, Lf, 1, s_out));
@@ -2783,17 +2833,19 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
         const int gx = F.n >= 4096 ? 16 : (F.n >= 256 ? F.n / 256 : 1);
         const int gy = F.n >= 64 ? (2048 / gx < F.n ? 2048 / gx : F.n) : 1;
         const dim3 grid(gx, gy), block(256);
-        const int nb = grid.x * grid.y;
+        const int nb = m->diag_done ? m->diag_nb : grid.x * grid.y;
         PYRO_TRY(c->reduce.ensure((2 * nb + 4) * sizeof(double)));
         double *part = (double *)c->reduce.p;
+        PYRO_REQUIRE(!m->diag_done || part == m->diag_part, "internal: the partial sums moved");
         using DiagT = void (*)(const double *, const double *, double *, double *, int, int, double,
                                double, double, double, double *, int, int);
         static const DiagT diag[2][2] = {{k_mg_solve_diag<false, false>, k_mg_solve_diag<false, true>},
                                         {k_mg_solve_diag<true, false>, k_mg_solve_diag<true, true>}};
         const bool store = !m->lazy_r;
-        PYRO_LAUNCH(c, "k_mg_solve_diag", diag[store ? 1 : 0][m->old_captured ? 0 : 1], grid, block, 0,
-                    (const double *)F.v, (const double *)F.f, F.r, m->old_phi, F.n, F.pitch, m->alpha,
-                    m->beta, F.dx * F.dx, 1.e-16, part, 1, F.n);
+        if (!m->diag_done)
+            PYRO_LAUNCH(c, "k_mg_solve_diag", diag[store ? 1 : 0][m->old_captured ? 0 : 1], grid, block, 0,
+                        (const double *)F.v, (const double *)F.f, F.r, m->old_phi, F.n, F.pitch, m->alpha,
+                        m->beta, F.dx * F.dx, 1.e-16, part, 1, F.n);
         m->r_stale[Lf] = !store;
         hipLaunchKernelGGL(k_sum_final2, dim3(1), dim3(256), 0, c->stream,
                            (const double *)part, nb, part + 2 * nb + 2 * slot);

@@ -526,6 +526,13 @@ class DeviceMG:
             check(self._l.pyrohip_mg_get_tuning(self.h, C.byref(t)))
         return {n: getattr(t, n) for n, _ in MGTuning._fields_}
 
+    def tail_counts(self):
+        """marching launches so far that carried (residual + restriction, the solve sums)"""
+        a, b = C.c_int(0), C.c_int(0)
+        with self.ctx.lock:
+            check(self._l.pyrohip_mg_tail_counts(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_tuning(self, **kw):
         """change some of the tuning values (tests / developer tools; results do not depend
         on them)"""

@@ -636,3 +636,46 @@ pickle.dump(out, sys.stdout.buffer)
                 assert a == b, mode
             else:
                 assert np.array_equal(a, b), mode
+
+
+@pytest.mark.parametrize("nx,bcs,coef", [
+    (256, ("dirichlet",) * 4, (0.0, -1.0)),
+    (256, ("periodic",) * 4, (0.3, -1.1)),
+    (256, ("neumann", "dirichlet", "periodic", "periodic"), (0.0, -1.0)),
+    (256, ("periodic", "periodic", "dirichlet", "neumann"), (0.3, -1.1)),
+    (512, ("dirichlet", "neumann", "neumann", "dirichlet"), (0.0, -1.0)),
+])
+def test_mg_march_tails(dev, nx, bcs, coef):
+    """inside solve() the marching smoother's launches carry what follows them (csrc/mg_march.hip,
+    MGMarch::tail): the down leg's residual + restriction (every marching level; 512^2: two of
+    them, the coarser one from a zero start) and, on the finest level's last launch, the two
+    sums of MG.py:670-686.  Cycle count, solution and the residual array read afterwards equal
+    those of the separate passes bit for bit; the two norms to rounding (other summation order)"""
+    alpha, beta = coef
+    rng = np.random.default_rng(5)
+    f0 = rng.standard_normal((nx + 2, nx + 2))
+    if alpha == 0.0 and "dirichlet" not in bcs:
+        f0[1:-1, 1:-1] -= f0[1:-1, 1:-1].mean()
+    out = {}
+    for tail in (0, 1):
+        m = device.DeviceMG(dev, nx, bcs=bcs, alpha=alpha, beta=beta,
+                            tuning=dict(march_min=256, march_waves=24 if nx == 256 else 48,
+                                        march_tail=tail, speculate=0))
+        L = m.nlevels - 1
+        m.zero(L, 0)
+        m.set(L, 1, f0)
+        m.init_rhs_norm()
+        r1 = m.solve(rtol=1e-30, max_cycles=2)
+        v1 = m.get(L, 0)
+        r2 = m.solve(rtol=1e-5, max_cycles=6)
+        ncyc = r1[0] + r2[0]
+        assert m.tail_counts() == ((ncyc * (2 if nx == 512 else 1), ncyc) if tail else (0, 0))
+        out[tail] = (r1, v1, r2, m.get(L, 0), m.get(L, 2)[1:-1, 1:-1])
+    a, b = out[0], out[1]
+    for k in (0, 2):
+        assert a[k][0] == b[k][0]
+        assert a[k][1] == pytest.approx(b[k][1], rel=1e-14)
+        assert a[k][2] == pytest.approx(b[k][2], rel=1e-14)
+    assert a[0][1] > 0 and a[0][2] > 0
+    for k in (1, 3, 4):
+        assert np.array_equal(a[k], b[k])
