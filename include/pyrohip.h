@@ -319,6 +319,8 @@ int pyrohip_mg_set_smoother(pyrohip_mg *m, int kind);
      coarse_band64    coarse V-cycle kernel: the 64^2 level's sweeps in registers (1)
      march_tail       inside solve(): the down leg's residual + restriction and the cycle's
                       two sums ride on the marching smoother's launches (1)
+     coarse_wave      coarse V-cycle kernel: the levels up to 32^2 on one wavefront, in
+                      registers (1)
      speculate        solve(): launch the next V-cycle while the norms travel to the host:
                       0 never, 1 when a further cycle is likely (default), 2 always
      trace, spec_debug  developer aids (phase clocks of the band / coarse kernels; solve()
@@ -331,7 +333,7 @@ typedef struct {
     int fuse_res_restrict, lazy_residual, allow_pow2;
     int small_tiles, band_maxn, band_genedge, coarse_band64;
     int speculate, trace, spec_debug;
-    int march_tail;
+    int march_tail, coarse_wave;
 } pyrohip_mg_tuning;
 int pyrohip_mg_get_tuning(pyrohip_mg *m, pyrohip_mg_tuning *t);
 int pyrohip_mg_set_tuning(pyrohip_mg *m, const pyrohip_mg_tuning *t);

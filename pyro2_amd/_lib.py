@@ -52,7 +52,7 @@ class MGTuning(C.Structure):
                 ("lazy_residual", C.c_int), ("allow_pow2", C.c_int), ("small_tiles", C.c_int),
                 ("band_maxn", C.c_int), ("band_genedge", C.c_int), ("coarse_band64", C.c_int),
                 ("speculate", C.c_int), ("trace", C.c_int), ("spec_debug", C.c_int),
-                ("march_tail", C.c_int)]
+                ("march_tail", C.c_int), ("coarse_wave", C.c_int)]
 
 
 class CompParams(C.Structure):

@@ -114,6 +114,7 @@ struct pyrohip_mg {
     int band_maxn = 2048;         // band smoother up to this level size
     bool band_genedge = false;    // band smoother: the general edge instance everywhere (tests)
     bool coarse_band64 = true;    // coarse kernel: the 64^2 level's sweeps in registers
+    bool coarse_wave = true;      // coarse kernel: the levels up to 32^2 on one wavefront
     int speculate = 1;            // solve loop: 0 never launch ahead, 1 when likely needed, 2 always
     bool trace = false;           // developer aid: phase clocks of the band / coarse kernels
     bool spec_debug = false;      // developer aid: print cycles / launched ahead / undone per solve
@@ -914,6 +915,7 @@ struct MGCoarse {
     unsigned zero_mask;                          // bit l: take v of level l as 0 (no memset before)
     int allow_pow2;                              // 0: PYRO_MG_NOPOW2 (see mg_pow2)
     int band64;                                  // 1: the 64^2 level's sweeps in registers (mgc_sweeps_band64)
+    int wave_levels;                             // 1: the levels up to 32^2 on one wavefront (mgw_vcycle)
     long long *trace;                            // developer aid: clock64() at the phase marks
 };
 #ifdef PYRO_EMU
@@ -928,7 +930,7 @@ __host__ __device__ inline int mgc_off(int l)    // LDS offset (doubles) of leve
     return o;
 }
 constexpr int MGC_LDS_DOUBLES = 2 * (16 + 36 + 100 + 324 + 1156 + 4356);
-constexpr int MGC_EDGE_DOUBLES = 16 * 2 * 64;     // mgc_sweeps_band64: first / last row of every wavefront
+constexpr int MGC_EDGE_DOUBLES = 32 * 2 * 64;     // mgc_sweeps_band64: first / last row of every half wavefront
 constexpr size_t MGC_LDS = (size_t)(MGC_LDS_DOUBLES + MGC_EDGE_DOUBLES) * sizeof(double);
 
 // Synchronisation inside the coarse kernel: workgroup barriers.  Running the smallest levels
@@ -1084,13 +1086,10 @@ __device__ __forceinline__ void mgc_sweeps_lean(double *V, const double *F, int 
     }
 }
 
-// The sweeps of the 64^2 level in the layout of k_mg_smooth_band: wavefront w keeps rows
-// 4w+1 .. 4w+4 in registers for the whole smoothing, lane h the columns 2h+1, 2h+2 (64 columns
-// are 32 lanes: lanes 32 .. 63 compute what lanes 0 .. 31 compute, so that the whole-wave
-// rotations wrap at the level's width), column neighbours by DPP, the wavefronts' edge rows
-// through LDS (E), ghost values as +-(own value) in one fma (mirror sides; a side with
-// value-0 ghosts takes mgc_sweeps_lean).  A colour sweep is 4 updates per wavefront instead of
-// 2 x (5 LDS reads + update + write + ghost writes) per thread: 2000 -> ~600 cycles.
+// The sweeps of the 64^2 level in the layout of k_mg_smooth_band: rows in registers for the
+// whole smoothing, lane h of a half wavefront the columns 2h+1, 2h+2, column neighbours by a
+// whole-wave DPP rotation, the edge rows through LDS (E), ghost values as +-(own value) in one
+// fma (mirror sides; a side with value-0 ghosts takes mgc_sweeps_lean).
 #if !defined(PYRO_EMU)
 __device__ __forceinline__ double mgc_rot_from_lower(double v) { return mgb_from_lower(v); }   // lane 0 <- 63
 __device__ __forceinline__ double mgc_rot_from_upper(double v) { return mgb_from_upper(v); }
@@ -1103,51 +1102,61 @@ __device__ __forceinline__ void mgc_sweeps_band64(double *V, const double *F, do
                                                   double yc, double denom, double rdenom, int iters,
                                                   int c0, int c1, int c2, int c3, int tid)
 {
-    constexpr int N = 64, Q = N + 2, R = 4;
-    const int wv = tid >> 6, ln = tid & 63, hl = ln & 31;
+    // Round 3: a wavefront's two halves (lanes 0 .. 31, 32 .. 63) hold different rows -- no
+    // lane computes a copy: slab sl = 2 w + half keeps rows 2 sl + 1, 2 sl + 2, lane h of the
+    // half the columns 2h + 1, 2h + 2.  The level's 2048 updates per colour are 32 per SIMD
+    // lane instead of 64 (the kernel's one CU is VALU bound on this level: sixteen wavefronts
+    // on four SIMDs, 1600 cycles per colour sweep before).  The whole-wave rotation hands lane
+    // 0 / 32 the other half's last column and lane 31 / 63 its first one: never read next to
+    // a mirror side (the ghost value is taken instead), traded back by a lane-xor-32 shuffle
+    // on periodic ones.  Every row is a slab's first or last one: E holds the level, a row
+    // per (slab, first / last).
+    constexpr int N = 64, Q = N + 2, R = 2, NS = 32;
+    const int wv = tid >> 6, ln = tid & 63, hl = ln & 31, sl = 2 * wv + (ln >> 5);
     const bool per_i = (c0 == PYROHIP_BC_PERIODIC), per_j = (c2 == PYROHIP_BC_PERIODIC);
-    const bool botW = (wv == 0) && !per_i, topW = (wv == 15) && !per_i;       // rows 1 / 64
+    const bool botW = (sl == 0) && !per_i, topW = (sl == NS - 1) && !per_i;   // rows 1 / 64
     const bool isWl = (hl == 0) && !per_j, isEl = (hl == 31) && !per_j;       // columns 1 / 64
     const double sBw = (botW && c0 == PYROHIP_BC_REFLECT_ODD) ? -1.0 : 1.0;
     const double sTw = (topW && c1 == PYROHIP_BC_REFLECT_ODD) ? -1.0 : 1.0;
     const double sWl = (isWl && c2 == PYROHIP_BC_REFLECT_ODD) ? -1.0 : 1.0;
     const double sEl = (isEl && c3 == PYROHIP_BC_REFLECT_ODD) ? -1.0 : 1.0;
     const double kx = xc * rdenom, ky = yc * rdenom;
-    const int wb = (wv + 15) & 15, wa = (wv + 1) & 15;
-    auto ei = [](int w, int which, int col) -> int { return (w * 2 + which) * N + col; };
+    const int sb = (sl + NS - 1) & (NS - 1), sa = (sl + 1) & (NS - 1);
+    auto ei = [](int s_, int which, int col) -> int { return (s_ * 2 + which) * N + col; };
     double v[R][2], fs[R][2];
 #pragma unroll
     for (int m = 0; m < R; m++)
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            const int c = (R * wv + m + 1) * Q + 2 * hl + 1 + q;
+            const int c = (R * sl + m + 1) * Q + 2 * hl + 1 + q;
             v[m][q] = V[c];
             fs[m][q] = POW2 ? F[c] * rdenom : F[c];
         }
-    if (ln < 32) {
-        E[ei(wv, 0, 2 * hl)] = v[0][0]; E[ei(wv, 0, 2 * hl + 1)] = v[0][1];
-        E[ei(wv, 1, 2 * hl)] = v[R - 1][0]; E[ei(wv, 1, 2 * hl + 1)] = v[R - 1][1];
-    }
+    E[ei(sl, 0, 2 * hl)] = v[0][0]; E[ei(sl, 0, 2 * hl + 1)] = v[0][1];
+    E[ei(sl, 1, 2 * hl)] = v[1][0]; E[ei(sl, 1, 2 * hl + 1)] = v[1][1];
     __syncthreads();
-    // cell (i, j) = (4w+m+1, 2h+1+q) is relaxed in sweep s iff i + j + s - 1 is even:
-    // the thread's column q = (PAR + m) & 1 with PAR = (s + 1) & 1
+    // cell (i, j) = (2 sl + m + 1, 2h + 1 + q) is relaxed in sweep s iff i + j + s is even:
+    // the thread's column q = (PAR + m) & 1 with PAR = s & 1
     auto pass = [&](auto par_c) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
-        const double below = E[ei(wb, 1, 2 * hl + (PAR & 1))];
-        const double above = E[ei(wa, 0, 2 * hl + ((PAR + R - 1) & 1))];
+        const double below = E[ei(sb, 1, 2 * hl + (PAR & 1))];
+        const double above = E[ei(sa, 0, 2 * hl + ((PAR + 1) & 1))];
 #pragma unroll
         for (int m = 0; m < R; m++) {
             const int q = (PAR + m) & 1;
             const double me = v[m][q];
-            const double up = (m < R - 1) ? v[m < R - 1 ? m + 1 : R - 1][q] : above;
-            const double dn = (m > 0) ? v[m > 0 ? m - 1 : 0][q] : below;
+            const double up = (m == 0) ? v[1][q] : above;
+            const double dn = (m == 0) ? below : v[0][q];
             const double own = v[m][q ^ 1];
-            const double oth = q ? mgc_rot_from_upper(v[m][0]) : mgc_rot_from_lower(v[m][1]);
+            double oth = q ? mgc_rot_from_upper(v[m][0]) : mgc_rot_from_lower(v[m][1]);
+            if (per_j) {                      // the level's first / last column: the other half got it
+                const double sw = __shfl_xor(oth, 32);
+                oth = (hl == (q ? 31 : 0)) ? sw : oth;
+            }
             const double e = q ? oth : own, w = q ? own : oth;
             double si, sj;
             if (m == 0) si = fma(botW ? me : dn, sBw, up);
-            else if (m == R - 1) si = fma(topW ? me : up, sTw, dn);
-            else si = up + dn;
+            else si = fma(topW ? me : up, sTw, dn);
             if (q == 0) sj = fma(isWl ? me : w, sWl, e);
             else sj = fma(isEl ? me : e, sEl, w);
             if (POW2)
@@ -1155,22 +1164,18 @@ __device__ __forceinline__ void mgc_sweeps_band64(double *V, const double *F, do
             else
                 v[m][q] = div_by(fs[m][q] + xc * si + yc * sj, denom, rdenom);
         }
-        if (ln < 32) {
-            E[ei(wv, 0, 2 * hl + (PAR & 1))] = v[0][PAR & 1];
-            E[ei(wv, 1, 2 * hl + ((PAR + R - 1) & 1))] = v[R - 1][(PAR + R - 1) & 1];
-        }
+        E[ei(sl, 0, 2 * hl + (PAR & 1))] = v[0][PAR & 1];
+        E[ei(sl, 1, 2 * hl + ((PAR + 1) & 1))] = v[1][(PAR + 1) & 1];
     };
     for (int s = 0; s < 2 * iters; s++) {
         if (s & 1) pass(std::integral_constant<int, 1>{});
         else pass(std::integral_constant<int, 0>{});
         __syncthreads();
     }
-    if (ln < 32) {
 #pragma unroll
-        for (int m = 0; m < R; m++)
+    for (int m = 0; m < R; m++)
 #pragma unroll
-            for (int q = 0; q < 2; q++) V[(R * wv + m + 1) * Q + 2 * hl + 1 + q] = v[m][q];
-    }
+        for (int q = 0; q < 2; q++) V[(R * sl + m + 1) * Q + 2 * hl + 1 + q] = v[m][q];
     __syncthreads();
 }
 
@@ -1204,16 +1209,18 @@ __device__ inline void mgc_smooth(double *V, const double *F, int n, int lg, dou
     const double xc = beta / (dx * dx), yc = beta / (dx * dx);
     const double denom = alpha + 2.0 * xc + 2.0 * yc;
     const double rdenom = 1.0 / denom;                          // correctly rounded: div_by
-    mgc_fill<NT>(V, n, dx, bc, use_val, tid);                   // MG.py:565
-    if (iters <= 0) return;
     const int c0 = bc.code[0], c1 = bc.code[1], c2 = bc.code[2], c3 = bc.code[3];
     const double *v0 = use_val ? bc.val[0] : nullptr, *v1 = use_val ? bc.val[1] : nullptr;
     const double *v2 = use_val ? bc.val[2] : nullptr, *v3 = use_val ? bc.val[3] : nullptr;
-    const bool pow2 = allow_pow2 && mgc_is_pow2(xc) && mgc_is_pow2(yc) && mgc_is_pow2(denom) &&
-                      rdenom * denom == 1.0;                    // see mg_pow2
     const bool mirror = c0 != PYROHIP_BC_CONST && c1 != PYROHIP_BC_CONST && c2 != PYROHIP_BC_CONST &&
                         c3 != PYROHIP_BC_CONST;
-    if (NT == MGC_NT && n == 64 && E && mirror && !(v0 || v1 || v2 || v3)) {
+    // (the sweeps in registers read no ghost cell: no fill before them)
+    const bool band = NT == MGC_NT && n == 64 && E && mirror && !(v0 || v1 || v2 || v3) && iters > 0;
+    if (!band) mgc_fill<NT>(V, n, dx, bc, use_val, tid);        // MG.py:565
+    if (iters <= 0) return;
+    const bool pow2 = allow_pow2 && mgc_is_pow2(xc) && mgc_is_pow2(yc) && mgc_is_pow2(denom) &&
+                      rdenom * denom == 1.0;                    // see mg_pow2
+    if (band) {
         if (pow2) mgc_sweeps_band64<true>(V, F, E, xc, yc, denom, rdenom, iters, c0, c1, c2, c3, tid);
         else mgc_sweeps_band64<false>(V, F, E, xc, yc, denom, rdenom, iters, c0, c1, c2, c3, tid);
     } else if (!(v0 || v1 || v2 || v3) && n * (n >> 1) <= 2 * NT) {
@@ -1318,6 +1325,337 @@ __device__ inline void mgc_bottom_fast(double *V, const double *F, double dx, do
     V[5] = a; V[6] = b; V[9] = c; V[10] = d;
 }
 
+// ---------------------------------------------------------------------------
+// The levels up to 32^2 of the coarse V-cycle on ONE wavefront.
+//
+// A colour sweep of a tiny level by the whole workgroup is an LDS round trip and a
+// 16-wavefront barrier around a dozen operations: ~850 cycles whatever the level's
+// size (trace: 19-20 thousand cycles per level and leg, 136 of the kernel's 265
+// thousand for the levels 2^2 ... 16^2).  Here wavefront 0 takes a level's cells into
+// registers in the layout of the band / marching kernels -- a lane holds two
+// neighbouring columns of up to eight rows; the column pairs of an N^2 level sit 32 / N
+// lanes apart in a row of 16 lanes so that a DPP rotation of that row by 32 / N lanes
+// wraps at the level's width (the lanes in between, and the other rows of 16, hold
+// copies); the 16^2 level's upper eight rows are in the second row of lanes, the 32^2 level
+// takes all four, eight rows each, and the rows of lanes trade their edge rows by a
+// shuffle -- and smooths without LDS and
+// without a barrier: no ghost cells, a cell next to a mirror boundary takes +-(its own
+// value) (what the fill after every colour stores there), the rotation's wrap is the
+// periodic neighbour.  Between levels the data goes through the levels' LDS arrays
+// (lane-private reads and writes; the four fine cells under a coarse cell are one
+// lane's): down a level = load, smooth, store, residual -> global r, restriction -> the
+// coarser level's f; up = load, add the prolonged correction, smooth, store, fill the
+// ghost cells (corners too: the arrays are written back to global as they are).
+// Arithmetic and operation order are those of mgc_sweeps_lean / mgc_down / mgc_up.
+// Mirror / periodic sides, levels below the kernel's top level (no boundary values).
+// ---------------------------------------------------------------------------
+template <int N> struct MGWave {
+    static constexpr int R = N < 8 ? N : 8;   // rows a lane holds
+    static constexpr int G = N / R;           // rows of 16 lanes the level's rows are spread over (1, 2, 4)
+    static constexpr int S = 32 / N;          // lanes between neighbouring column pairs
+    static constexpr int Q = N + 2;
+};
+
+__device__ __forceinline__ void mgw_sync()    // LDS written by one lane, read by another of the wavefront
+{
+#if defined(PYRO_EMU)
+    hipemu::wave_barrier();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+// the value of the lane S lanes below / above in the row of 16 lanes, wrapping (S = 16: itself)
+template <int S> __device__ __forceinline__ double mgw_from_lower(double v, int ln)
+{
+    if constexpr (S >= 16) return v;
+#if defined(PYRO_EMU)
+    else return __shfl(v, (ln & ~15) | ((ln - S) & 15), 64);
+#else
+    else return mgb_dpp<0x120 + S>(v);          // row_ror:S
+#endif
+}
+template <int S> __device__ __forceinline__ double mgw_from_upper(double v, int ln)
+{
+    if constexpr (S >= 16) return v;
+#if defined(PYRO_EMU)
+    else return __shfl(v, (ln & ~15) | ((ln + S) & 15), 64);
+#else
+    else return mgb_dpp<0x120 + 16 - S>(v);     // row_ror:(16 - S)
+#endif
+}
+
+struct MGWSide {        // what a lane is next to, and the mirror signs
+    bool botW, topW, isW, isE;
+    double sB, sT, sW, sE;
+    int grp, h;         // row of lanes that holds the lane's part of the level, column pair
+};
+template <int N> __device__ __forceinline__ MGWSide mgw_side(const MGBC &bc, int ln)
+{
+    using W = MGWave<N>;
+    MGWSide s;
+    const bool per_i = (bc.code[0] == PYROHIP_BC_PERIODIC), per_j = (bc.code[2] == PYROHIP_BC_PERIODIC);
+    s.grp = (ln >> 4) & (W::G - 1);
+    s.h = (ln & 15) / W::S;
+    s.botW = !per_i && s.grp == 0;
+    s.topW = !per_i && s.grp == W::G - 1;
+    s.isW = !per_j && s.h == 0;
+    s.isE = !per_j && s.h == N / 2 - 1;
+    s.sB = (s.botW && bc.code[0] == PYROHIP_BC_REFLECT_ODD) ? -1.0 : 1.0;
+    s.sT = (s.topW && bc.code[1] == PYROHIP_BC_REFLECT_ODD) ? -1.0 : 1.0;
+    s.sW = (s.isW && bc.code[2] == PYROHIP_BC_REFLECT_ODD) ? -1.0 : 1.0;
+    s.sE = (s.isE && bc.code[3] == PYROHIP_BC_REFLECT_ODD) ? -1.0 : 1.0;
+    return s;
+}
+// the rows beyond the lane's first / last one (the other half's edge rows at 16^2; the
+// periodic image otherwise -- not read where the row is next to a mirror boundary)
+template <int N> __device__ __forceinline__ double mgw_below(const double (&v)[MGWave<N>::R][2], int q, int ln)
+{
+    constexpr int G = MGWave<N>::G, R = MGWave<N>::R;
+    if constexpr (G == 1) return v[R - 1][q];
+    else if constexpr (G == 2) return __shfl_xor(v[R - 1][q], 16);
+    else return __shfl(v[R - 1][q], (ln + 48) & 63, 64);      // the row of lanes below, wrapping
+}
+template <int N> __device__ __forceinline__ double mgw_above(const double (&v)[MGWave<N>::R][2], int q, int ln)
+{
+    constexpr int G = MGWave<N>::G;
+    if constexpr (G == 1) return v[0][q];
+    else if constexpr (G == 2) return __shfl_xor(v[0][q], 16);
+    else return __shfl(v[0][q], (ln + 16) & 63, 64);
+}
+
+template <int N>
+__device__ __forceinline__ void mgw_load(const double *V, double (&v)[MGWave<N>::R][2], const MGWSide &sd)
+{
+    using W = MGWave<N>;
+#pragma unroll
+    for (int r = 0; r < W::R; r++) {
+        const int c = (1 + W::R * sd.grp + r) * W::Q + 1 + 2 * sd.h;
+        v[r][0] = V[c]; v[r][1] = V[c + 1];
+    }
+}
+template <int N>
+__device__ __forceinline__ void mgw_store(double *V, const double (&v)[MGWave<N>::R][2], const MGWSide &sd, int ln)
+{
+    using W = MGWave<N>;
+    if ((ln & 15) % W::S == 0 && (ln >> 4) < W::G) {
+#pragma unroll
+        for (int r = 0; r < W::R; r++) {
+            const int c = (1 + W::R * sd.grp + r) * W::Q + 1 + 2 * sd.h;
+            V[c] = v[r][0]; V[c + 1] = v[r][1];
+        }
+    }
+    mgw_sync();
+}
+// mgc_fill by one wavefront (homogeneous): x sides over all j, then y sides over all i
+__device__ inline void mgw_fill(double *V, int n, const MGBC &bc, int ln)
+{
+    const int q = n + 2;
+    for (int j = ln; j < q; j += 64) {
+        V[j] = (bc.code[0] == PYROHIP_BC_PERIODIC) ? V[n * q + j] : ghost_lo(bc.code[0], V[q + j], nullptr, j, 0.0);
+        V[(n + 1) * q + j] = (bc.code[1] == PYROHIP_BC_PERIODIC) ? V[q + j] : ghost_hi(bc.code[1], V[n * q + j], nullptr, j, 0.0);
+    }
+    mgw_sync();
+    for (int i = ln; i < q; i += 64) {
+        double *row = V + i * q;
+        row[0] = (bc.code[2] == PYROHIP_BC_PERIODIC) ? row[n] : ghost_lo(bc.code[2], row[1], nullptr, i, 0.0);
+        row[n + 1] = (bc.code[3] == PYROHIP_BC_PERIODIC) ? row[1] : ghost_hi(bc.code[3], row[n], nullptr, i, 0.0);
+    }
+    mgw_sync();
+}
+
+// red-black sweeps on the registers; fs: f (POW2: f / denom)
+template <int N, bool POW2>
+__device__ __forceinline__ void mgw_sweeps(double (&v)[MGWave<N>::R][2], const double (&fs)[MGWave<N>::R][2],
+                                           double xc, double yc, double denom, double rdenom, int iters,
+                                           const MGWSide &sd, int ln)
+{
+    using W = MGWave<N>;
+    constexpr int R = W::R, S = W::S;
+    const double kx = xc * rdenom, ky = yc * rdenom;
+    // cell (i, j) is relaxed in colour c iff j - 1 = (i - 1 + c) mod 2 (mgc_sweeps): in the
+    // lane's row r (the rows before it are an even number) its column q = (r + c) & 1
+    auto pass = [&](auto cc) __attribute__((always_inline)) {
+        constexpr int C = decltype(cc)::value;
+        const double below = mgw_below<N>(v, C & 1, ln);             // for row 0, column (0 + C) & 1
+        const double above = mgw_above<N>(v, (R - 1 + C) & 1, ln);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int q = (r + C) & 1;
+            const double me = v[r][q], own = v[r][q ^ 1];
+            const double oth = q ? mgw_from_upper<S>(v[r][0], ln) : mgw_from_lower<S>(v[r][1], ln);
+            const double e = q ? oth : own, w = q ? own : oth;
+            const double up = (r < R - 1) ? v[r < R - 1 ? r + 1 : r][q] : above;
+            const double dn = (r > 0) ? v[r > 0 ? r - 1 : 0][q] : below;
+            double si, sj;
+            if (R == 1) si = up + dn;
+            else if (r == 0) si = fma(sd.botW ? me : dn, sd.sB, up);
+            else if (r == R - 1) si = fma(sd.topW ? me : up, sd.sT, dn);
+            else si = up + dn;
+            if (q == 0) sj = fma(sd.isW ? me : w, sd.sW, e);
+            else sj = fma(sd.isE ? me : e, sd.sE, w);
+            if (POW2) v[r][q] = fma(ky, sj, fma(kx, si, fs[r][q]));
+            else v[r][q] = div_by(fs[r][q] + xc * si + yc * sj, denom, rdenom);
+        }
+    };
+    for (int it = 0; it < iters; it++) {
+        pass(std::integral_constant<int, 0>{});
+        pass(std::integral_constant<int, 1>{});
+    }
+}
+
+struct MGWCoef { double xc, yc, denom, rdenom; bool pow2; };
+__device__ __forceinline__ MGWCoef mgw_coef(const MGCoarse &A, int l)
+{
+    MGWCoef c;
+    c.xc = A.beta / (A.dx[l] * A.dx[l]); c.yc = c.xc;
+    c.denom = A.alpha + 2.0 * c.xc + 2.0 * c.yc;
+    c.rdenom = 1.0 / c.denom;
+    c.pow2 = A.allow_pow2 && mgc_is_pow2(c.xc) && mgc_is_pow2(c.yc) && mgc_is_pow2(c.denom) &&
+             c.rdenom * c.denom == 1.0;                  // mgc_smooth
+    return c;
+}
+
+// level l = log2(N) - 1 on the way down (MG.py:722-735)
+template <int N, bool POW2>
+__device__ inline void mgw_down_t(const MGCoarse &A, double *lds, const MGWCoef &cf, int ln)
+{
+    using W = MGWave<N>;
+    constexpr int R = W::R, S = W::S, Q = W::Q, l = (N == 32) ? 4 : (N == 16) ? 3 : (N == 8) ? 2 : 1, QC = N / 2 + 2;
+    double *V = lds + mgc_off(l), *F = V + Q * Q, *Fc = lds + mgc_off(l - 1) + QC * QC;
+    const MGWSide sd = mgw_side<N>(A.bc, ln);
+    double v[R][2], fs[R][2];
+    mgw_load<N>(V, v, sd);
+    mgw_load<N>(F, fs, sd);
+    if (POW2) {
+#pragma unroll
+        for (int r = 0; r < R; r++) { fs[r][0] *= cf.rdenom; fs[r][1] *= cf.rdenom; }
+    }
+    mgw_sweeps<N, POW2>(v, fs, cf.xc, cf.yc, cf.denom, cf.rdenom, A.nsmooth, sd, ln);
+    mgw_store<N>(V, v, sd, ln);
+    // residual (mgc_down's expression; the divisions by dx^2 as div_by: the same bits), its
+    // restriction: the lane's rows 2m, 2m + 1 and its two columns are one coarse cell
+    const double dx2 = A.dx[l] * A.dx[l], rdx2 = 1.0 / dx2;
+    const bool primary = (ln & 15) % S == 0 && (ln >> 4) < W::G;
+    const double below0 = mgw_below<N>(v, 0, ln), below1 = mgw_below<N>(v, 1, ln);
+    const double above0 = mgw_above<N>(v, 0, ln), above1 = mgw_above<N>(v, 1, ln);
+#pragma unroll
+    for (int m = 0; m < R / 2; m++) {
+        double rr[2][2];
+#pragma unroll
+        for (int rl = 0; rl < 2; rl++) {
+            const int r = 2 * m + rl;
+            const double fromW = mgw_from_lower<S>(v[r][1], ln), fromE = mgw_from_upper<S>(v[r][0], ln);
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const double me = v[r][q];
+                double dn = (r > 0) ? v[r > 0 ? r - 1 : 0][q] : (q ? below1 : below0);
+                double up = (r < R - 1) ? v[r < R - 1 ? r + 1 : r][q] : (q ? above1 : above0);
+                if (r == 0 && sd.botW) dn = sd.sB * me;
+                if (r == R - 1 && sd.topW) up = sd.sT * me;
+                double w = q ? v[r][0] : fromW, e = q ? fromE : v[r][1];
+                if (q == 0 && sd.isW) w = sd.sW * me;
+                if (q == 1 && sd.isE) e = sd.sE * me;
+                const double f = POW2 ? fs[r][q] * cf.denom : fs[r][q];
+                rr[rl][q] = f - A.alpha * me +
+                            A.beta * (div_by(dn + up - 2 * me, dx2, rdx2) + div_by(w + e - 2 * me, dx2, rdx2));
+            }
+        }
+        if (primary) {
+#pragma unroll
+            for (int rl = 0; rl < 2; rl++) {
+                const size_t g = (size_t)(1 + R * sd.grp + 2 * m + rl) * A.pitch[l] + 1 + 2 * sd.h;
+                A.r[l][g] = rr[rl][0]; A.r[l][g + 1] = rr[rl][1];
+            }
+            // patch.py:660-662: (i,j) + (i+1,j) + (i,j+1) + (i+1,j+1)
+            Fc[(1 + (R / 2) * sd.grp + m) * QC + 1 + sd.h] = 0.25 * (rr[0][0] + rr[1][0] + rr[0][1] + rr[1][1]);
+        }
+    }
+    mgw_sync();
+}
+
+// ... on the way up (MG.py:745-758): the coarser level's array has its ghost cells
+template <int N, bool POW2>
+__device__ inline void mgw_up_t(const MGCoarse &A, double *lds, const MGWCoef &cf, int ln)
+{
+    using W = MGWave<N>;
+    constexpr int R = W::R, Q = W::Q, l = (N == 32) ? 4 : (N == 16) ? 3 : (N == 8) ? 2 : 1, QC = N / 2 + 2;
+    double *V = lds + mgc_off(l), *F = V + Q * Q;
+    const double *Vc = lds + mgc_off(l - 1);
+    const MGWSide sd = mgw_side<N>(A.bc, ln);
+    double v[R][2], fs[R][2];
+    mgw_load<N>(V, v, sd);
+    mgw_load<N>(F, fs, sd);
+#pragma unroll
+    for (int m = 0; m < R / 2; m++) {        // the coarse cell under the lane's rows 2m, 2m + 1
+        const int ck = (1 + (R / 2) * sd.grp + m) * QC + 1 + sd.h;
+        const double c0 = Vc[ck];
+        const double m_x = 0.5 * (Vc[ck + QC] - Vc[ck - QC]);
+        const double m_y = 0.5 * (Vc[ck + 1] - Vc[ck - 1]);
+        v[2 * m][0] += c0 - 0.25 * m_x - 0.25 * m_y;        // mgc_up: fi even / odd, fj even / odd
+        v[2 * m][1] += c0 - 0.25 * m_x + 0.25 * m_y;
+        v[2 * m + 1][0] += c0 + 0.25 * m_x - 0.25 * m_y;
+        v[2 * m + 1][1] += c0 + 0.25 * m_x + 0.25 * m_y;
+    }
+    if (POW2) {
+#pragma unroll
+        for (int r = 0; r < R; r++) { fs[r][0] *= cf.rdenom; fs[r][1] *= cf.rdenom; }
+    }
+    mgw_sweeps<N, POW2>(v, fs, cf.xc, cf.yc, cf.denom, cf.rdenom, A.nsmooth, sd, ln);
+    mgw_store<N>(V, v, sd, ln);
+    mgw_fill(V, N, A.bc, ln);
+}
+
+// the 2^2 level (MG.py:776-778)
+template <bool POW2>
+__device__ inline void mgw_bottom_t(const MGCoarse &A, double *lds, const MGWCoef &cf, int ln)
+{
+    constexpr int N = 2;
+    double *V = lds + mgc_off(0), *F = V + 16;
+    const MGWSide sd = mgw_side<N>(A.bc, ln);
+    double v[2][2], fs[2][2];
+    mgw_load<N>(V, v, sd);
+    mgw_load<N>(F, fs, sd);
+    if (POW2) { fs[0][0] *= cf.rdenom; fs[0][1] *= cf.rdenom; fs[1][0] *= cf.rdenom; fs[1][1] *= cf.rdenom; }
+    mgw_sweeps<N, POW2>(v, fs, cf.xc, cf.yc, cf.denom, cf.rdenom, A.nsmooth_bottom, sd, ln);
+    mgw_store<N>(V, v, sd, ln);
+    mgw_fill(V, N, A.bc, ln);
+}
+
+template <int N> __device__ __forceinline__ void mgw_down(const MGCoarse &A, double *lds, int ln)
+{
+    const MGWCoef cf = mgw_coef(A, (N == 32) ? 4 : (N == 16) ? 3 : (N == 8) ? 2 : 1);
+    if (cf.pow2) mgw_down_t<N, true>(A, lds, cf, ln);
+    else mgw_down_t<N, false>(A, lds, cf, ln);
+}
+template <int N> __device__ __forceinline__ void mgw_up(const MGCoarse &A, double *lds, int ln)
+{
+    const MGWCoef cf = mgw_coef(A, (N == 32) ? 4 : (N == 16) ? 3 : (N == 8) ? 2 : 1);
+    if (cf.pow2) mgw_up_t<N, true>(A, lds, cf, ln);
+    else mgw_up_t<N, false>(A, lds, cf, ln);
+}
+
+// the sub-V-cycle below level `from` + 1 (from <= 3): wavefront 0 of the workgroup
+__device__ inline void mgw_vcycle(const MGCoarse &A, double *lds, int from, int ln)
+{
+    const int tid = ln;
+    if (from >= 4) { mgw_down<32>(A, lds, ln); MGC_MARK(2 + (A.top - 4)); }
+    if (from >= 3) { mgw_down<16>(A, lds, ln); MGC_MARK(2 + (A.top - 3)); }
+    if (from >= 2) { mgw_down<8>(A, lds, ln); MGC_MARK(2 + (A.top - 2)); }
+    if (from >= 1) { mgw_down<4>(A, lds, ln); MGC_MARK(2 + (A.top - 1)); }
+    {
+        const MGWCoef cf = mgw_coef(A, 0);
+        if (cf.pow2) mgw_bottom_t<true>(A, lds, cf, ln);
+        else mgw_bottom_t<false>(A, lds, cf, ln);
+    }
+    MGC_MARK(8);
+    if (from >= 1) { mgw_up<4>(A, lds, ln); MGC_MARK(9); }
+    if (from >= 2) { mgw_up<8>(A, lds, ln); MGC_MARK(10); }
+    if (from >= 3) { mgw_up<16>(A, lds, ln); MGC_MARK(11); }
+    if (from >= 4) { mgw_up<32>(A, lds, ln); MGC_MARK(12); }
+}
+
 // one level of the down leg (MG.py:722-735): smooth, residual -> global r,
 // its restriction -> f of the next coarser level
 template <int NT>
@@ -1327,10 +1665,10 @@ __device__ inline void mgc_down(const MGCoarse &A, int l, double *lds, int tid)
     double *V = lds + mgc_off(l), *F = V + q * q;
     double *Fc = lds + mgc_off(l - 1) + qc * qc;
     const bool uv = A.finest && l == A.top;
-    if (l == 2) MGC_MARK(14);
+    if (l == A.top) MGC_MARK(14);
     mgc_smooth<NT>(V, F, n, l + 1, A.dx[l], A.alpha, A.beta, A.nsmooth, A.bc, uv, tid, A.allow_pow2,
                    A.band64 ? lds + MGC_LDS_DOUBLES : nullptr);
-    if (l == 2) MGC_MARK(15);
+    if (l == A.top) MGC_MARK(15);
     const double dx2 = A.dx[l] * A.dx[l];
     for (int idx = tid; idx < nc * nc; idx += NT) {
         const int ci = idx / nc, cj = idx - ci * nc;
@@ -1391,9 +1729,16 @@ __global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
     }
     __syncthreads();
     MGC_MARK(1);
+    // the levels up to 32^2 (below the top level) on wavefront 0: mgw_vcycle
+    const bool mirror_bc = A.bc.code[0] != PYROHIP_BC_CONST && A.bc.code[1] != PYROHIP_BC_CONST &&
+                           A.bc.code[2] != PYROHIP_BC_CONST && A.bc.code[3] != PYROHIP_BC_CONST;
+    const int wave_from = (A.wave_levels && mirror_bc) ? (A.top - 1 < 4 ? A.top - 1 : 4) : -1;
     // down leg
-    for (int l = A.top; l >= 1; l--) { mgc_down<MGC_NT>(A, l, lds, tid); MGC_MARK(2 + (A.top - l)); }
-    {
+    for (int l = A.top; l >= 1 && l > wave_from; l--) { mgc_down<MGC_NT>(A, l, lds, tid); MGC_MARK(2 + (A.top - l)); }
+    if (wave_from >= 0) {
+        if (tid < 64) mgw_vcycle(A, lds, wave_from, tid);
+        __syncthreads();
+    } else {
         // MG.py:565 fill, the sweeps in registers of thread 0, closing fill (corners)
         double *V = lds + mgc_off(0), *F = V + 16;
         const bool uv = A.finest && A.top == 0;
@@ -1413,8 +1758,8 @@ __global__ __launch_bounds__(MGC_NT) void k_mg_coarse_vcycle(MGCoarse A)
         __syncthreads();
         if (A.nsmooth_bottom > 0) mgc_fill<MGC_NT>(V, 2, A.dx[0], A.bc, uv, tid);
     }
-    MGC_MARK(8);
-    for (int l = 1; l <= A.top; l++) { mgc_up<MGC_NT>(A, l, lds, tid); MGC_MARK(8 + l); }
+    if (wave_from < 0) MGC_MARK(8);
+    for (int l = (wave_from >= 0 ? wave_from + 1 : 1); l <= A.top; l++) { mgc_up<MGC_NT>(A, l, lds, tid); MGC_MARK(8 + l); }
     // write back: v of every level, f of the levels below the top
     for (int l = 0; l <= A.top; l++) {
         const int n = 2 << l, q = n + 2;
@@ -2125,6 +2470,7 @@ static int mg_coarse_vcycle(pyrohip_mg *m, int top)
     A.nsmooth = m->nsmooth; A.nsmooth_bottom = m->nsmooth_bottom;
     A.allow_pow2 = m->allow_pow2 ? 1 : 0;
     A.band64 = m->coarse_band64 ? 1 : 0;
+    A.wave_levels = m->coarse_wave ? 1 : 0;
     A.zero_mask = 0;
     for (int l = 0; l <= top; l++)
         if (m->v_is_zero[l]) { A.zero_mask |= 1u << l; m->v_is_zero[l] = false; }
@@ -2148,7 +2494,7 @@ static int mg_coarse_vcycle(pyrohip_mg *m, int top)
         for (int k = 2; k < 2 + top; k++) fprintf(stderr, " %lld", h[k] - h[k - 1]);
         fprintf(stderr, " | bottom %lld | up", h[8] - h[1 + top]);
         for (int l = 1; l <= top; l++) fprintf(stderr, " %lld", h[8 + l] - h[8 + l - 1]);
-        fprintf(stderr, " | level 8^2 down: smooth %lld\n", h[15] - h[14]);
+        fprintf(stderr, " | top level down: smooth %lld\n", h[15] - h[14]);
     }
 #endif
     for (int l = 0; l <= top; l++) m->corners_stale[l] = false;   // full fills inside
@@ -2296,7 +2642,7 @@ int pyrohip_mg_get_tuning(pyrohip_mg *m, pyrohip_mg_tuning *t)
     t->small_tiles = m->small_tiles; t->band_maxn = m->band_maxn;
     t->band_genedge = m->band_genedge ? 1 : 0; t->coarse_band64 = m->coarse_band64 ? 1 : 0;
     t->speculate = m->speculate; t->trace = m->trace ? 1 : 0; t->spec_debug = m->spec_debug ? 1 : 0;
-    t->march_tail = m->march_tail;
+    t->march_tail = m->march_tail; t->coarse_wave = m->coarse_wave ? 1 : 0;
     return 0;
 }
 
@@ -2314,7 +2660,7 @@ int pyrohip_mg_set_tuning(pyrohip_mg *m, const pyrohip_mg_tuning *t)
     m->small_tiles = t->small_tiles; m->band_maxn = t->band_maxn;
     m->band_genedge = t->band_genedge != 0; m->coarse_band64 = t->coarse_band64 != 0;
     m->speculate = t->speculate; m->trace = t->trace != 0; m->spec_debug = t->spec_debug != 0;
-    m->march_tail = t->march_tail;
+    m->march_tail = t->march_tail; m->coarse_wave = t->coarse_wave != 0;
     return 0;
 }
 

@@ -679,3 +679,42 @@ def test_mg_march_tails(dev, nx, bcs, coef):
     assert a[0][1] > 0 and a[0][2] > 0
     for k in (1, 3, 4):
         assert np.array_equal(a[k], b[k])
+
+
+@pytest.mark.parametrize("bcs", [("dirichlet",) * 4, ("periodic",) * 4, ("neumann",) * 4,
+                                 ("neumann", "dirichlet", "periodic", "periodic"),
+                                 ("periodic", "periodic", "dirichlet", "neumann")])
+@pytest.mark.parametrize("coef", [(0.3, -1.1), (0.0, -1.0)])
+@pytest.mark.parametrize("nx", [4, 8, 16, 32, 64, 128])
+def test_mg_coarse_wave_levels(dev, nx, bcs, coef):
+    """the levels up to 32^2 of the coarse V-cycle kernel run on one wavefront with a level's
+    cells in registers (csrc/multigrid.hip: mgw_vcycle) -- mirror and periodic sides, general
+    and power-of-two coefficients, every depth of the recursion (a 4^2 finest level has only
+    the 2^2 level below it, 128^2 enters the kernel at 64^2): v, f and r of every level after
+    a V-cycle equal those of the workgroup's LDS sweeps bit for bit"""
+    alpha, beta = coef
+    rng = np.random.default_rng(nx)
+    v0 = rng.standard_normal((nx + 2, nx + 2))
+    f0 = rng.standard_normal((nx + 2, nx + 2))
+    if alpha == 0.0 and "dirichlet" not in bcs:
+        f0[1:-1, 1:-1] -= f0[1:-1, 1:-1].mean()
+    out = []
+    # (the workgroup's LDS sweeps on every level; + the 64^2 level's sweeps in registers, rows
+    # through LDS: mgc_sweeps_band64; + the wavefront-resident levels)
+    for wave, band in ((0, 0), (0, 1), (1, 1)):
+        m = device.DeviceMG(dev, nx, bcs=bcs, alpha=alpha, beta=beta,
+                            tuning=dict(coarse_wave=wave, coarse_band64=band))
+        L = m.nlevels - 1
+        m.set(L, 0, v0)
+        m.set(L, 1, f0)
+        m.vcycle()
+        m.vcycle()
+        out.append([m.get(l, var) for l in range(m.nlevels) for var in (0, 1, 2)])
+    for other in out[1:]:
+        for k, (a, b) in enumerate(zip(out[0], other)):
+            l, var = divmod(k, 3)
+            if var == 2:
+                a, b = a[1:-1, 1:-1], b[1:-1, 1:-1]
+            if var == 2 and l in (0, m.nlevels - 1):
+                continue                      # r of the bottom / finest level: nobody's output
+            assert np.array_equal(a, b), (l, var)
