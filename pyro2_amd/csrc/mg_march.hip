@@ -379,6 +379,10 @@ __device__ __forceinline__ void mgm_march(const MGMarch &A, const Part &P, doubl
     }
 }
 
+// (Neighbouring strips as one workgroup of two or four wavefronts kept in step by a barrier
+// every step / every eight steps, so that the 42 columns two strips share would be fetched
+// once: 780 -> 860-920 us per 4096^2 V-cycle, every marching launch 10-40 % slower.  The
+// strips stay independent wavefronts; the launch reads 2.3 times the level.)
 // (The two wavefronts of a SIMD taking turns at s_setprio, which shortens the single-round
 // launches of the compressible kernel by 8 %, was measured here too: 851 -> 1070 us per
 // 4096^2 V-cycle.  This kernel waits for memory, not for issue slots: arbitration by age.)
