@@ -57,6 +57,9 @@ constexpr int AW_OUT = 120;       // columns a wavefront updates (64 lanes x 2 -
 // iteration is ~1800 cycles, a load under traffic takes longer.  The rows in flight have a
 // small ring of their own (its length divides the period of the others, so the loop is still
 // unrolled 6 times; a row costs one register move when it enters the stencil window).
+// (2, 3 and 6 rows in flight measured at the end of round 3: 27.1 / 27.2 / 29.9 us per 2048^2
+// launch under the event timers, 281 / 282 / 287 us at 8192^2 -- the strips do not wait for
+// their rows; three wavefronts per SIMD take turns at ~160 instructions per row)
 #ifndef PYRO_ADV_PF
 #define PYRO_ADV_PF 3
 #endif
