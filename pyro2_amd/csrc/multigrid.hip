@@ -3138,7 +3138,13 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
     const int Lf = m->nlevels - 1;
     MGLevel &F = m->lev[Lf];
     const size_t fbytes = (size_t)(F.n + 2) * F.pitch * sizeof(double);
-    PYRO_CHECK_HIP(hipMemcpyAsync(m->old_phi, F.v, fbytes, hipMemcpyDeviceToDevice, c->stream));
+    // the solution before the first cycle, for its relative change -- unless the cycle's first
+    // smoothing launch leaves it behind anyway (capture_old: the finest level's launches read
+    // one buffer and write another; 87 us of copy per solve at 4096^2)
+    const bool first_launch_keeps_old = !m->vc && m->smoother != 0 && m->nsmooth > 0 && Lf > MGC_TOP &&
+                                        (F.n + 2) * (F.n + 2) > MGS_CELLS;
+    if (!first_launch_keeps_old)
+        PYRO_CHECK_HIP(hipMemcpyAsync(m->old_phi, F.v, fbytes, hipMemcpyDeviceToDevice, c->stream));
     double res = 1.e33, rel = 1.e33;
     int cycle = 1;
     // one cycle on the stream: zeroed coarse solutions, V-cycle, both norms.  Constant
@@ -3165,6 +3171,8 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
         m->capture_old = false;
         m->diag_req = false;
         PYRO_TRY(vrc);
+        PYRO_REQUIRE(!first_launch_keeps_old || m->old_captured,
+                     "internal: the cycle did not leave the solution before it behind");
         if (sync) {                                       // :673-678
             PYRO_TRY(mg_sumsq(m, F.v, m->old_phi, Lf, 1, s_out));
             PYRO_CHECK_HIP(hipMemcpyAsync(m->old_phi, F.v, fbytes, hipMemcpyDeviceToDevice,
@@ -3211,8 +3219,7 @@ int pyrohip_mg_solve(pyrohip_mg *m, double rtol, int max_cycles, int *num_cycles
     // coarser levels' arrays, scratch between solves, then hold the undone cycle's values.)
     // pyrohip_mg_tuning.speculate: 0 never, 2 whenever a further cycle is allowed (tests).
     const int spec_mode = m->speculate;
-    const bool can_undo = !m->vc && m->smoother != 0 && m->nsmooth > 0 && Lf > MGC_TOP &&
-                          (F.n + 2) * (F.n + 2) > MGS_CELLS;      // the finest level's launches ping-pong
+    const bool can_undo = first_launch_keeps_old;          // the finest level's launches ping-pong
     double res_prev = -1.0, res_pprev = -1.0;
     bool pending = false;                                  // cycle `cycle` is already on the stream
     const bool spec_debug = m->spec_debug;   // developer aid
