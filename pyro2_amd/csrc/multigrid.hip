@@ -1097,6 +1097,18 @@ __device__ __forceinline__ double mgc_rot_from_upper(double v) { return mgb_from
 __device__ __forceinline__ double mgc_rot_from_lower(double v) { return __shfl(v, (int)((threadIdx.x + 63) & 63), 64); }
 __device__ __forceinline__ double mgc_rot_from_upper(double v) { return __shfl(v, (int)((threadIdx.x + 1) & 63), 64); }
 #endif
+// the value lane L (a constant) holds, in every lane
+__device__ __forceinline__ double mgc_lane_value(double v, int L)
+{
+#if defined(PYRO_EMU)
+    return __shfl(v, L, 64);
+#else
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), L);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), L);
+    return __hiloint2double(hi, lo);
+#endif
+}
+
 template <bool POW2>
 __device__ __forceinline__ void mgc_sweeps_band64(double *V, const double *F, double *E, double xc,
                                                   double yc, double denom, double rdenom, int iters,
@@ -1108,7 +1120,7 @@ __device__ __forceinline__ void mgc_sweeps_band64(double *V, const double *F, do
     // lane instead of 64 (the kernel's one CU is VALU bound on this level: sixteen wavefronts
     // on four SIMDs, 1600 cycles per colour sweep before).  The whole-wave rotation hands lane
     // 0 / 32 the other half's last column and lane 31 / 63 its first one: never read next to
-    // a mirror side (the ghost value is taken instead), traded back by a lane-xor-32 shuffle
+    // a mirror side (the ghost value is taken instead), read back from the two lanes that got it
     // on periodic ones.  Every row is a slab's first or last one: E holds the level, a row
     // per (slab, first / last).
     constexpr int N = 64, Q = N + 2, R = 2, NS = 32;
@@ -1150,8 +1162,9 @@ __device__ __forceinline__ void mgc_sweeps_band64(double *V, const double *F, do
             const double own = v[m][q ^ 1];
             double oth = q ? mgc_rot_from_upper(v[m][0]) : mgc_rot_from_lower(v[m][1]);
             if (per_j) {                      // the level's first / last column: the other half got it
-                const double sw = __shfl_xor(oth, 32);
-                oth = (hl == (q ? 31 : 0)) ? sw : oth;
+                // (two lanes read, two selects: no trip through the LDS crossbar in the chain)
+                const double x0 = mgc_lane_value(oth, q ? 31 : 0), x1 = mgc_lane_value(oth, q ? 63 : 32);
+                oth = (ln == (q ? 31 : 0)) ? x1 : (ln == (q ? 63 : 32)) ? x0 : oth;
             }
             const double e = q ? oth : own, w = q ? own : oth;
             double si, sj;
