@@ -320,16 +320,22 @@ __global__ __launch_bounds__(64 * ADV_WPB) void k_adv_step(const double *__restr
     }
 }
 
-// rows per strip: about three wavefronts per SIMD in ONE round (the kernel is short: a
-// second round of a few stragglers shows), within 12..48 rows (a strip costs L + 6
-// iterations for L rows, four of them cheap).  Measured (tools/adv_time.py, profiles/
-// r03_adv_time.txt): 2048^2 best at 12-13 rows, 8192^2 at 32-48.
+// Rows per strip.  Three wavefronts per SIMD are resident (12 per CU: `slots`); a launch that
+// fits them at once must fit them EXACTLY at once -- a handful of wavefronts more than the
+// device holds run alone after all the others.  (Round 2's ceil(nx ncb / slots) rows did
+// not count the strips it cut: 2048^2 -> 12 rows = 171 x 18 = 3078 wavefronts for 3072 slots;
+// 13 rows, 2844 wavefronts: 26.1 -> 21.0 us per step; 3072^2: 47.1 -> 36.4 us, 4096^2:
+// 78.4 -> 64.5 us; tools/adv_time.py, profiles/r03_adv_time.txt.)  So: the shortest strip
+// of 12 .. 64 rows with which all wavefronts are resident at once (a strip costs L + 6
+// iterations for L rows, four of them cheap); grids beyond that run several rounds, where
+// 36 .. 52 rows are all within 1 % (8192^2: 265-271 us; 16-20 rows 288, 63-64 rows 280).
 static int adv_rows(int nx, int ncb, int cus)
 {
     const long slots = 12L * cus;
-    int L = (int)(((long)nx * ncb + slots - 1) / slots);
-    L = L < 12 ? 12 : (L > 48 ? 48 : L);
-    return L < nx ? L : nx;
+    if (nx <= 12) return nx;
+    for (int L = 12; L <= 64 && L < nx; L++)
+        if ((long)ncb * ((nx + L - 1) / L) <= slots) return L;
+    return nx < 48 ? nx : 48;
 }
 
 template <int LIM>
