@@ -20,7 +20,7 @@ for nx, rows_list in [(int(a.split(":")[0]), a.split(":")[1]) for a in SPEC.spli
             if os.environ.get("AMBIENT") == "1":       # no blast: every cell the ambient gas
                 blk = np.broadcast_to(np.nan_to_num(sedov_state(nx, nx, 4, 0.0, 1.0, 0.0, 1.0, 1.4, 0.01, 4, i0=8, ni=1))[0, 8], blk.shape).copy()
             st.upload_rows(r0, blk)
-        P = device.make_comp_params(1.0 / nx, 1.0 / nx, fast_math=FM, kernel_set=2, march_rows=int(rows))
+        P = device.make_comp_params(1.0 / nx, 1.0 / nx, fast_math=FM, kernel_set=int(os.environ.get("KS", "2")), march_rows=int(rows))
         pol = DtPolicy(1.0e9)
         st.comp_evolve(P, 0.8, pol, 5)
         ctx.sync()
