@@ -13,11 +13,11 @@
 // walks down a strip of rows and keeps everything it needs of the rows above in
 // registers (a 5-row window of a, limit2_x and the x interface states, each computed
 // once); no LDS, no barrier.  Here every lane owns TWO adjacent columns (2 l, 2 l + 1 of
-// the wavefront's 128, of which the inner 120 are updated):
+// the wavefront's 128, of which up to 123 are updated: adv_strip):
 //   * the y neighbour of the left column's right side / the right column's left side is
 //     in the lane's own registers, so a row needs 6-8 DPP double moves for two cells
 //     where the one-column layout needed 10 for one;
-//   * 8 apron columns in 128 instead of 8 in 64;
+//   * 5 apron columns in 128 (3 on the upwind side of v, 2 on the other) instead of 8 in 64;
 //   * two independent cells per lane: instruction-level parallelism inside the wavefront
 //     where the one-column kernel depended on four wavefronts per SIMD to hide latency
 //     (VALU busy was 0.50, profiles/r02m_also_traffic.json).
@@ -51,7 +51,42 @@
 namespace pyro {
 namespace PYRO_NS {
 
-constexpr int AW_OUT = 120;       // columns a wavefront updates (64 lanes x 2 - 8 apron)
+// Column strips.  A wavefront's window is 128 columns; a cell's update reads three columns
+// on the upwind side of v and two on the other (the y state of the upwind neighbour carries
+// a limited slope: two more columns), so a strip inside the grid updates 128 - 5 = 123 of
+// them.  The first strip's window starts at the ghost columns (it carries the ghost frame of
+// the new buffer: 4 columns), the last one's must reach the last ghost column.  (Round 2/3
+// until here: 4 + 120 + 4 whatever the sign -- 2048 columns were 17 x 120 + 8: eighteen
+// strips, the last one for eight columns.)
+constexpr int AW_WIN = 128, AW_GHOST = 4;
+struct AdvStrip { int A, U0, U1; };           // window start, first / last column updated
+__host__ __device__ inline AdvStrip adv_strip(int cb, int ncb, int jlo, int jhi, bool vneg)
+{
+    const int nl = vneg ? 2 : 3, nr = vneg ? 3 : 2;
+    const int first = AW_WIN - AW_GHOST - nr, mid = AW_WIN - nl - nr;
+    AdvStrip S;
+    if (cb == 0) { S.A = jlo - AW_GHOST; S.U0 = jlo; S.U1 = jlo + first - 1; }
+    else { S.U0 = jlo + first + (cb - 1) * mid; S.A = S.U0 - nl; S.U1 = S.U0 + mid - 1; }
+    if (cb == ncb - 1) {                      // reach the ghost columns on the right
+        const int amin = jhi + AW_GHOST - (AW_WIN - 1);
+        if (S.A < amin) S.A = amin;
+    }
+    if (S.U1 > jhi) S.U1 = jhi;
+    return S;
+}
+// strips of a grid of ny columns (ng = 4 ghost columns)
+__host__ __device__ inline int adv_nstrips(int ny, bool vneg)
+{
+    const int nl = vneg ? 2 : 3, nr = vneg ? 3 : 2;
+    const int first = AW_WIN - AW_GHOST - nr, mid = AW_WIN - nl - nr;
+    int ncb = ny <= first ? 1 : 1 + (ny - first + mid - 1) / mid;
+    // The last strip's window is moved right until it holds the ghost columns (adv_strip).
+    // If that costs it its apron on the left -- or, for a single strip, the ghost columns on
+    // the left -- one more strip carries the ghost columns alone (nothing to update).
+    const AdvStrip S = adv_strip(ncb - 1, ncb, 0, ny - 1, vneg);
+    if (ncb == 1 ? S.A != -AW_GHOST : S.U0 - S.A < nl) ncb++;
+    return ncb;
+}
 // rows loaded ahead of their use.  PMC (profiles/r03_adv_pmc.json): with ONE row ahead a
 // wavefront sat in s_waitcnt for 33 % (2048^2) / 53 % (8192^2) of its cycles -- an
 // iteration is ~1800 cycles, a load under traffic takes longer.  The rows in flight have a
@@ -155,8 +190,8 @@ __global__ __launch_bounds__(64 * ADV_WPB) void k_adv_step(const double *__restr
     const int cb = pyro_uniform(unit % P.ncb), sb = pyro_uniform(unit / P.ncb);
     const int i0 = g.ilo + sb * P.L;                       // strip rows [i0, i1)
     const int i1 = (i0 + P.L < g.ihi + 1) ? i0 + P.L : g.ihi + 1;
-    const int ja = g.jlo + cb * AW_OUT - 4 + 2 * l;        // this lane's columns ja, ja + 1
-    const bool inner = (l >= 2 && l <= 61);                // not an apron lane
+    const AdvStrip strip = adv_strip(cb, P.ncb, g.jlo, g.jhi, VNEG);
+    const int ja = strip.A + 2 * l;                        // this lane's columns ja, ja + 1
     const int p = g.pitch;
     // row / column maps of the ghost fill
     const BcMap mr = bc_map(g.ilo, g.ihi, g.ng, P.bxl, P.bxr, P.fill != 0);
@@ -169,8 +204,8 @@ __global__ __launch_bounds__(64 * ADV_WPB) void k_adv_step(const double *__restr
         const int j = ja + q;
         const bool jvalid = (j < g.qy);
         jghost[q] = jvalid && (j < g.jlo || j > g.jhi);
-        jout[q] = (j >= g.jlo && j <= g.jhi && inner);
-        jown[q] = jvalid && (inner || jghost[q]);          // columns whose ghost cells we carry
+        jout[q] = (j >= strip.U0 && j <= strip.U1);
+        jown[q] = jvalid && (jout[q] || jghost[q]);        // columns whose ghost cells we carry
         const int jcl = jvalid ? j : g.qy - 1;
         js[q] = bc_src(mc, jcl, g.jlo, g.jhi);
         neg_c[q] = (jcl < g.jlo && mc.odd_lo) || (jcl > g.jhi && mc.odd_hi);
@@ -365,7 +400,7 @@ int adv_step_launch(pyrohip_state *s, int n, const pyrohip_adv_params *ap, doubl
     P.cx = u * dt / dx; P.cy = v * dt / dy;
     P.dtdx2 = 0.5 * dt / dx; P.dtdy2 = 0.5 * dt / dy;
     P.dtdx = dt / dx; P.dtdy = dt / dy;
-    P.ncb = (g.ny + AW_OUT - 1) / AW_OUT;
+    P.ncb = adv_nstrips(g.ny, v < 0);
     P.L = adv_rows(g.nx, P.ncb, c->num_cus > 0 ? c->num_cus : 256);
     if (ap->march_rows > 0) P.L = ap->march_rows < g.nx ? (ap->march_rows < 4 ? 4 : ap->march_rows) : g.nx;
     P.fill = ap->fill ? 1 : 0;

@@ -84,6 +84,40 @@ def test_adv_fused_fill(dev, bcs, uv, lim, rows, fast):
     assert max_rel_err(out[True][ng:-ng, ng:-ng], a[ng:-ng, ng:-ng]) <= tol
 
 
+@pytest.mark.parametrize("v", [0.9, -0.9])
+@pytest.mark.parametrize("ny", [118, 120, 121, 122, 123, 243, 244, 245, 246, 247, 248])
+def test_adv_column_strip_edges(dev, ny, v):
+    """the column strips of the step kernel (csrc/advection.hip: adv_strip -- three apron
+    columns on the upwind side of v, two on the other; the first window starts at the ghost
+    columns, the last one is moved right until it holds them, one more strip carries them alone
+    when that would cost the last strip its apron): widths around one and two strips, both
+    signs of v, interior and ghost frame against fill + plain step and the oracle"""
+    nx, ng = 20, 4
+    bcs = ("outflow", "reflect-even", "periodic", "periodic") if ny % 2 else \
+          ("periodic", "periodic", "reflect-odd", "outflow")
+    rng = np.random.default_rng(ny)
+    a0 = rng.random((nx + 2 * ng, ny + 2 * ng)) + 0.3
+    dx, dy = 1.0 / nx, 1.0 / ny
+    u = 0.7
+    dt = 0.8 * min(dx / abs(u), dy / abs(v))
+    out = {}
+    for fused in (False, True):
+        s = device.DeviceState(dev, nx, ny, ng, [list(bcs)])
+        s.upload(a0)
+        for _ in range(2):
+            if not fused:
+                s.fill_bc()
+            s.adv_step(0, dx, dy, u, v, dt, 2, fill=fused, fast_math=0)
+        out[fused] = s.download()[:, :, 0]
+    assert np.array_equal(out[True], out[False])
+    a = a0.copy()
+    for _ in range(2):
+        orc.fill_ghost(a, nx, ny, ng, list(bcs))
+        orc.adv_step(a, nx, ny, ng, dx, dy, u, v, dt, 2)
+    tol = 0.0 if dev.kind == "emu" else TOL
+    assert max_rel_err(out[True][ng:-ng, ng:-ng], a[ng:-ng, ng:-ng]) <= tol
+
+
 def test_adv_reference_regression_smooth_0040(dev, golden):
     """pyro/test.py:93 -- advection smooth 32^2, 40 steps vs smooth_0040.h5"""
     g = golden("adv_smooth_0040")
