@@ -686,7 +686,7 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((P.nunits + 7) / 8)), dim3(64),
                     WLDS_BYTES, (const double *)Uin, Uout, g, P, s->d_flag, part, S);
         const double *dmin;
-        PYRO_TRY(fused_tail(s, part, nwg, true, &dmin));
+        PYRO_TRY(fused_tail(s, part, nwg, true, &dmin, S != nullptr));
         int rc = 0;
         if (S) { fused_swap(s); *dmin_out = dmin; }
         else rc = fused_sync(s, dmin);
@@ -702,7 +702,7 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         PYRO_TRY(comm_post_halo(s, Uout));
     }
     const double *dmin;
-    PYRO_TRY(fused_tail(s, part, nwg, post, &dmin));
+    PYRO_TRY(fused_tail(s, part, nwg, post, &dmin, S != nullptr));
     if (S) { fused_swap(s); *dmin_out = dmin; s->halo_pending = post; return 0; }
     const int rc = fused_sync(s, dmin);
     s->halo_pending = post && rc == 0;
