@@ -214,6 +214,9 @@ struct pyrohip_state {
     // nothing touched the state since)
     int nb_lo = -1, nb_hi = -1;
     bool nb_set = false, halo_pending = false;
+    // the ghost frame of the OTHER buffer already holds this step's boundary fill (written
+    // together with this buffer's by k_fill_frame2, comp_api.hip): the step need not copy it
+    bool frame_prefilled = false;
     double next_cfl_min = -1.0;  // min over interior of dx/(|u|+c) etc. of the
                                  // state after the last step (-1: unknown)
     bool cfl_is_global = false;  // ... already reduced over all ranks

@@ -702,7 +702,11 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         PYRO_TRY(comm_post_halo(s, Uout));
     }
     const double *dmin;
-    PYRO_TRY(fused_tail(s, part, nwg, post, &dmin, S != nullptr));
+    // (device-side stepping: the fill before this step may have written the new buffer's ghost
+    // frame already, comp_api.hip: k_fill_frame2)
+    const bool frame_done = post || s->frame_prefilled;
+    s->frame_prefilled = false;
+    PYRO_TRY(fused_tail(s, part, nwg, frame_done, &dmin, S != nullptr));
     if (S) { fused_swap(s); *dmin_out = dmin; s->halo_pending = post; return 0; }
     const int rc = fused_sync(s, dmin);
     s->halo_pending = post && rc == 0;

@@ -376,6 +376,38 @@ def test_comp_evolve_on_device(dev, golden, kset):
     assert np.array_equal(s.download()[4:-4, 4:-4], bad[4:-4, 4:-4])
 
 
+@pytest.mark.parametrize("bcs", [("outflow", "outflow", "outflow", "outflow"),
+                                 ("reflect", "outflow", "periodic", "periodic"),
+                                 ("periodic", "periodic", "reflect", "reflect"),
+                                 ("outflow", "reflect", "reflect", "outflow")])
+def test_comp_evolve_wave_fill_and_frame(dev, golden, bcs):
+    """device-side stepping with the row-marching kernel: one launch fills the ghost cells of
+    the state AND writes the other buffer's ghost frame (comp_api.hip: k_fill_frame2; corners
+    through the x rule and then the y rule), the policy kernel takes the minimum of the
+    wavefronts' CFL partials itself -- against the same steps taken one by one (two fill
+    launches, frame copy, reduction launches): dt sequence and the WHOLE array, ghost frame
+    and corners included, bit for bit"""
+    from helpers import DtPolicy
+    g = golden("comp_sedov_64_020")
+    meta = g["meta"]
+    ic = np.nan_to_num(g["ic"]).copy()
+    rng = np.random.default_rng(3)
+    ic[:, :, 2] += 1.e-3 * rng.standard_normal(ic.shape[:2])     # momenta: the odd reflections matter
+    ic[:, :, 3] += 1.e-3 * rng.standard_normal(ic.shape[:2])
+    nsteps = 7
+    kw = dict(kernel_set=2, march_rows=13)
+    Uref, dref, tref = device_comp_run(dev, ic, meta, list(bcs), 0.1, nsteps, **kw)
+    P, cfl = dev_params(meta, **kw)
+    for chunks in ((nsteps,), (3, 4)):
+        s = comp_state(dev, 64, 64, list(bcs))
+        s.upload(ic)
+        pol, dts = DtPolicy(0.1), []
+        for c in chunks:
+            dts += list(s.comp_evolve(P, cfl, pol, c))
+        assert dts == list(dref), chunks
+        assert np.array_equal(s.download(), Uref), chunks
+
+
 @pytest.mark.parametrize("kset", [0, 1, 2])
 def test_comp_fast_algebra_supersonic(dev, kset):
     """the fast build's OWN ALGEBRA (hydro.h: characteristic tracing with the projections
