@@ -471,10 +471,10 @@ int fused_tail(pyrohip_state *s, double *part, int nparts, bool frame_copied, co
 {
     pyrohip_ctx *c = s->ctx;
     if (!frame_copied) fused_copy_frame(s);
-    if (defer && !c->global_cfl && nparts <= 64 * kMinStageBlocks) {
+    if (defer && !c->global_cfl && nparts <= 128 * kMinStageBlocks) {
         // device-side stepping: the next policy kernel (one workgroup anyway) takes the
-        // minimum of the partials itself (up to 64 per thread: the row-marching kernel's
-        // wavefronts up to 8192^2; two launches less per step, 14 us of a 0.72 ms step at
+        // minimum of the partials itself (up to 128 per thread: the row-marching kernel's
+        // wavefronts up to 16384^2; two launches less per step, 14 us of a 0.72 ms step at
         // 4096^2) and leaves it where this function would have
         s->pend_part = part;
         s->pend_n = nparts;
