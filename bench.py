@@ -669,7 +669,8 @@ def main():
                                "HLLC, limiter 2, flattening, cvisc 0.1, cfl 0.8, outflow), "
                                f"x-slab decomposed over {world} GPU(s), "
                                + ("RCCL halo exchange" if dist.comm_kind == "rccl"
-                                  else "HOST-STAGED halo exchange (RCCL init failed)"),
+                                  else f"HOST-STAGED halo exchange ({dist.comm_note or 'debug path'}): "
+                                       "NOT a scaling result"),
                    "parallelism": f"slab{world}",
                    "halo": dist.comm_kind if world > 1 else "none",
                    "rccl_ranks": getattr(dist, "rccl_ranks", None) if world > 1 else None,
