@@ -138,10 +138,15 @@ def test_adv_64_to_tmax(hip, golden):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fast", [0, 1])
-@pytest.mark.parametrize("nx,uv", [(2048, (1.0, 1.0)), (1000, (-0.6, 0.9))])
+@pytest.mark.parametrize("nx,uv", [(2048, (1.0, 1.0)), (1000, (-0.6, 0.9)), (4096, (0.8, -1.0)),
+                                   (8192, (-1.0, 0.7))])
 def test_adv_large_vs_oracle(hip, nx, uv, fast):
-    """BASELINE config 2 size (2048^2 periodic) and a ragged size: 20 steps
-    against the oracle on identical inputs, rtol 1e-12"""
+    """BASELINE config 2 size (2048^2 periodic), a ragged size, and the sizes whose launches
+    run one full round (4096^2: 34 column strips x 86 chunks of 48 rows) and several rounds
+    (8192^2) of resident wavefronts: 20 steps (6 / 3 on the two large grids) against the oracle
+    on identical inputs, rtol 1e-12"""
+    if nx >= 8192 and fast == 0:
+        pytest.skip("the 8192^2 case once (the contracted build: the product default)")
     x = (np.arange(nx + 8) - 4 + 0.5) / nx
     X, Y = np.meshgrid(x, x, indexing="ij")
     ic = 1.0 + np.exp(-60.0 * ((X - 0.5) ** 2 + (Y - 0.5) ** 2))
@@ -149,10 +154,11 @@ def test_adv_large_vs_oracle(hip, nx, uv, fast):
     u, v = uv
     dt = orc.adv_dt(1 / nx, 1 / nx, u, v, 0.8)
     a = ic.copy()
-    for _ in range(20):
+    nsteps = 20 if nx <= 2048 else (6 if nx <= 4096 else 3)
+    for _ in range(nsteps):
         orc.fill_ghost(a, nx, nx, 4, ("periodic",) * 4)
         orc.adv_step(a, nx, nx, 4, 1 / nx, 1 / nx, u, v, dt, 2)
-    b = _run(hip, ic, [dt] * 20, nx, u=u, v=v, fast=fast)
+    b = _run(hip, ic, [dt] * nsteps, nx, u=u, v=v, fast=fast)
     assert max_rel_err(b[4:-4, 4:-4], a[4:-4, 4:-4]) <= 1e-12
     # element-wise (the field is >= 1 everywhere: every cell to its own magnitude)
     assert (np.abs(b[4:-4, 4:-4] - a[4:-4, 4:-4]) / np.abs(a[4:-4, 4:-4])).max() <= 1e-12
