@@ -718,3 +718,38 @@ def test_mg_coarse_wave_levels(dev, nx, bcs, coef):
             if var == 2 and l in (0, m.nlevels - 1):
                 continue                      # r of the bottom / finest level: nobody's output
             assert np.array_equal(a, b), (l, var)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,bcs,coef", [
+    (2048, ("periodic",) * 4, (0.0, -1.0)),
+    (2048, ("neumann", "dirichlet", "periodic", "periodic"), (0.3, -1.1)),
+    (8192, ("dirichlet",) * 4, (0.0, -1.0)),
+])
+def test_mg_march_tails_production_sizes(hip, nx, bcs, coef):
+    """test_mg_march_tails on the levels the marching smoother runs on in production (2048^2:
+    one marching level; 8192^2: three, 2048 wavefronts each): inside solve() with and without
+    the work that rides on the marching launches -- cycle count, solution and residual array
+    bit for bit, norms to rounding"""
+    alpha, beta = coef
+    rng = np.random.default_rng(nx)
+    f0 = rng.standard_normal((nx + 2, nx + 2))
+    if alpha == 0.0 and "dirichlet" not in bcs:
+        f0[1:-1, 1:-1] -= f0[1:-1, 1:-1].mean()
+    out = {}
+    for tail in (0, 1):
+        m = device.DeviceMG(hip, nx, bcs=bcs, alpha=alpha, beta=beta, tuning=dict(march_tail=tail, speculate=0))
+        L = m.nlevels - 1
+        m.zero(L, 0)
+        m.set(L, 1, f0)
+        m.init_rhs_norm()
+        r = m.solve(rtol=1e-30, max_cycles=2)
+        nmarch = {2048: 1, 8192: 3}[nx]
+        assert m.tail_counts() == ((2 * nmarch, 2) if tail else (0, 0))
+        out[tail] = (r, m.get(L, 0), m.get(L, 2)[1:-1, 1:-1])
+        del m
+    assert out[0][0][0] == out[1][0][0]
+    assert out[0][0][1] == pytest.approx(out[1][0][1], rel=1e-13)
+    assert out[0][0][2] == pytest.approx(out[1][0][2], rel=1e-13)
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2])
