@@ -2430,12 +2430,24 @@ static int mg_prolong_add(pyrohip_mg *m, int fine)
     return 0;
 }
 
+// (hipMemset runs at ~1.2 TB/s on this part: 110 us for the 4096^2 level)
+__global__ __launch_bounds__(256) void k_mg_zero_plane(double *__restrict__ a, size_t n)
+{
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
+        a[k] = 0.0;
+}
+
 static int mg_zero(pyrohip_mg *m, int level, int var)
 {
     MGLevel &L = m->lev[level];
     // patch.py:562-573 zeroes the whole array incl. ghosts
-    PYRO_CHECK_HIP(hipMemsetAsync(plane(m, level, var), 0,
-                                  (size_t)(L.n + 2) * L.pitch * sizeof(double), m->ctx->stream));
+    const size_t n = (size_t)(L.n + 2) * L.pitch;
+    double *a = plane(m, level, var);
+    if (n >= ((size_t)1 << 20)) {
+        hipLaunchKernelGGL(k_mg_zero_plane, dim3(4096), dim3(256), 0, m->ctx->stream, a, n);
+        PYRO_CHECK_HIP(hipGetLastError());
+    } else
+        PYRO_CHECK_HIP(hipMemsetAsync(a, 0, n * sizeof(double), m->ctx->stream));
     return 0;
 }
 
