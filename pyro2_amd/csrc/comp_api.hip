@@ -94,22 +94,25 @@ static int check_comp(pyrohip_state *s, const pyrohip_comp_params *p)
 // and then the y rule (array_indexer.py:163-274 fills x over all columns first, so a corner
 // takes its value from an x ghost cell): for outflow / reflect / periodic sides both are index
 // maps with a sign, and their composition is what the two passes leave.  One thread per
-// cell of the frame, the enumeration of k_copy_frame4.
+// cell of the frame.
 __global__ __launch_bounds__(256) void k_fill_frame2(double *__restrict__ cur, double *__restrict__ alt,
                                                      Geom g, const int *__restrict__ bc)
 {
+    // 1-d grid: first the 2 ng full ghost rows in pieces of 256 columns, then the ghost
+    // columns of the interior rows, 256 / (2 ng) rows per workgroup
     const int ng = g.ng;
-    const int b = blockIdx.y;
+    const int nxb = (g.qy + 255) / 256, nrowblk = 2 * ng * nxb;
+    const int b = blockIdx.x;
     int i, j;
-    if (b < 2 * ng) {                               // a full ghost row
-        i = (b < ng) ? b : g.ihi + 1 + (b - ng);
-        j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nrowblk) {                              // a piece of a full ghost row
+        const int rr = b / nxb;
+        i = (rr < ng) ? rr : g.ihi + 1 + (rr - ng);
+        j = (b - rr * nxb) * 256 + (int)threadIdx.x;
         if (j >= g.qy) return;
     } else {                                        // ghost columns of interior rows
-        if (blockIdx.x != 0) return;
         const int t = threadIdx.x;
         const int rows_per_block = 256 / (2 * ng);
-        const int r = (b - 2 * ng) * rows_per_block + t / (2 * ng);
+        const int r = (b - nrowblk) * rows_per_block + t / (2 * ng);
         const int kx = t % (2 * ng);
         if (r >= g.nx || t >= rows_per_block * 2 * ng) return;
         i = g.ilo + r;
@@ -245,8 +248,8 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
             if (wave && frame_fill_ok(s)) {      // fill + the other buffer's ghost frame: one launch
                 const Geom &g = s->g;
                 const int rows_per_block = 256 / (2 * g.ng);
-                const int nby = 2 * g.ng + (g.nx + rows_per_block - 1) / rows_per_block;
-                hipLaunchKernelGGL(k_fill_frame2, dim3((g.qy + 255) / 256, nby), dim3(256), 0, c->stream,
+                const int nblk = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + rows_per_block - 1) / rows_per_block;
+                hipLaunchKernelGGL(k_fill_frame2, dim3(nblk), dim3(256), 0, c->stream,
                                    s->d, s->alt_base + geom_lead(g), g, (const int *)s->d_bc);
                 s->frame_prefilled = true;
             } else
