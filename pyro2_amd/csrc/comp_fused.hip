@@ -390,18 +390,22 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
 // the nx interior rows (only their 2*ng ghost columns)
 __global__ void k_copy_frame4(const double *__restrict__ src, double *__restrict__ dst, Geom g)
 {
+    // 1-d grid: the 2 ng full ghost rows in pieces of 256 columns, then the ghost columns of
+    // the interior rows (a 2-d grid whose column part ran in block column 0 only launched
+    // 33 thousand workgroups at 16384^2 for 1024 that had work)
     const int ng = g.ng;
-    const int b = blockIdx.y;
+    const int nxb = (g.qy + 255) / 256, nrowblk = 2 * ng * nxb;
+    const int b = blockIdx.x;
     int i, j;
-    if (b < 2 * ng) {                               // a full ghost row
-        i = (b < ng) ? b : g.ihi + 1 + (b - ng);
-        j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nrowblk) {                              // a piece of a full ghost row
+        const int rr = b / nxb;
+        i = (rr < ng) ? rr : g.ihi + 1 + (rr - ng);
+        j = (b - rr * nxb) * 256 + (int)threadIdx.x;
         if (j >= g.qy) return;
     } else {                                        // ghost columns of interior rows
-        if (blockIdx.x != 0) return;
         const int t = threadIdx.x;                  // 256 threads: 2*ng columns x rows
         const int rows_per_block = 256 / (2 * ng);
-        const int r = (b - 2 * ng) * rows_per_block + t / (2 * ng);
+        const int r = (b - nrowblk) * rows_per_block + t / (2 * ng);
         const int kx = t % (2 * ng);
         if (r >= g.nx || t >= rows_per_block * 2 * ng) return;
         i = g.ilo + r;
@@ -461,8 +465,8 @@ void fused_copy_frame(pyrohip_state *s)
     pyrohip_ctx *c = s->ctx;
     const Geom &g = s->g;
     const int rows_per_block = 256 / (2 * g.ng);
-    const int nby = 2 * g.ng + (g.nx + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL(k_copy_frame4, dim3((g.qy + 255) / 256, nby), dim3(256), 0, c->stream,
+    const int nblk = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(k_copy_frame4, dim3(nblk), dim3(256), 0, c->stream,
                        (const double *)s->d, s->alt_base + geom_lead(g), g);
 }
 
