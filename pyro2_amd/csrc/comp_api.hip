@@ -275,6 +275,7 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
             rc = p->fast_math ? fastm::comp_step_fused_ex(s, &pf, 0.0, s->d_scal, &dmin)
                               : exact::comp_step_fused_ex(s, &pf, 0.0, s->d_scal, &dmin);
     }
+    s->frame_prefilled = false;      // (an iteration that stopped between the fill and its step)
     PYRO_TRY(rc);
     hipLaunchKernelGGL(k_dt_policy, dim3(1), dim3(256), 0, c->stream, s->d_scal, dmin,
                        (const int *)s->d_flag, s->d_dts, max_steps, 1, (const double *)s->pend_part,
