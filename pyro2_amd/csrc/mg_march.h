@@ -29,9 +29,9 @@ struct MGMarch {
     // has finished are still in its registers when their neighbours above become final
     //   1  down leg: residual of the smoothed level, restricted into the next coarser level's
     //      right-hand side cf (k_mg_residual_restrict's arithmetic and order; r is not stored)
-    //   2  last launch of a solve cycle on the finest level: the sums of MG.py:670-686,
-    //      ((v - old) / (v + small))^2 and r^2, one pair of partials per wavefront
-    //      (partial[b], partial[nblocks + b]: k_sum_final2 finishes)
+    //   2  last launch of a solve cycle on the finest level: the sum of r^2 (MG.py:668-671), a
+    //      partial per wavefront (partial[nblocks + b]; partial[b] = 0: the relative change of
+    //      the solution is taken once, after the solve's last cycle; k_sum_final2 finishes)
     int tail;
     double alpha, beta, dx2, rdx2, small;
     double *cf; int cfpitch;

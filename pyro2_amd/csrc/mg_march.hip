@@ -223,7 +223,8 @@ __device__ __forceinline__ void mgm_march(const MGMarch &A, const Part &P, doubl
     // ---- tail state: the row below the one whose residual is taken (its window slot is
     // loaded over by then), the odd row's residuals (restriction), the old solution's row
     // one step ahead and the two sums (diagnostics) ----
-    double vA[2] = {0, 0}, rodd[2] = {0, 0}, oldr[2][2] = {{0, 0}, {0, 0}}, srel = 0.0, sres = 0.0;
+    double vA[2] = {0, 0}, rodd[2] = {0, 0}, sres = 0.0;
+    const double srel = 0.0;     // (relative_error: once, after the solve's last cycle -- multigrid.hip)
 
     const bool col_ghosts = P.tj0 == 1 || P.tj1 == n;   // the strip stores column 1 or n
     // rows 0 .. PF - 1 on their way
@@ -235,11 +236,6 @@ __device__ __forceinline__ void mgm_march(const MGMarch &A, const Part &P, doubl
         const bool botBlk = EDGEI && P.plo_i && k0 == 0, topBlk = EDGEI && P.phi_i && k0 == kTop;
         // (1) row k + PF on its way
         load_row(std::integral_constant<int, (U + PF) % W>{}, k + PF);
-        if constexpr (TAIL == 2) {     // the old solution's row for the next step's tail
-            const unsigned base = row_of(g0 + k - NP) * pitch;
-            oldr[(U + 1) & 1][0] = A.old[base + gjw[0]];
-            oldr[(U + 1) & 1][1] = A.old[base + gjw[1]];
-        }
         // (2) row k enters: scale f (exact, see mg_pow2), add the prolonged correction
         {
             constexpr int S = U % W;
@@ -359,10 +355,8 @@ __device__ __forceinline__ void mgm_march(const MGMarch &A, const Part &P, doubl
                     }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const double d = (v[SB][q] - oldr[U & 1][q]) / (v[SB][q] + A.small);
-                        if (st[q]) { srel += d * d; sres += rr[q] * rr[q]; }
-                    }
+                    for (int q = 0; q < 2; q++)
+                        if (st[q]) sres += rr[q] * rr[q];
                 }
             }
             vA[0] = v[SB][0]; vA[1] = v[SB][1];
@@ -373,7 +367,6 @@ __device__ __forceinline__ void mgm_march(const MGMarch &A, const Part &P, doubl
     for (int k0 = 0; k0 < nsteps; k0 += W)
         static_for<W>([&](auto uc) __attribute__((always_inline)) { step(uc, k0); });
     if constexpr (TAIL == 2) {
-        srel = wave_sum(srel);
         sres = wave_sum(sres);
         if (ln == 0) { A.partial[blockIdx.x] = srel; A.partial[gridDim.x + blockIdx.x] = sres; }
     }

@@ -753,3 +753,40 @@ def test_mg_march_tails_production_sizes(hip, nx, bcs, coef):
     assert out[0][0][2] == pytest.approx(out[1][0][2], rel=1e-13)
     assert np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize("nx", [256, 2048])
+def test_mg_solve_speculation_with_tails(dev, nx):
+    """the cycle launched ahead and undone, with the sums riding on the marching launches:
+    relative_error is then taken once after the loop from the solution and the one before it,
+    which a fourth finest-level buffer keeps through the speculative cycle (csrc/multigrid.hip:
+    pyrohip_mg::older).  Speculation forced on every cycle against the loop that waits: cycle
+    count, both norms and the solution identical -- for a solve that converges (the last cycle is
+    undone), one that runs into max_cycles, and a second solve on the same object"""
+    if (dev.kind == "emu") != (nx == 256):
+        pytest.skip("256^2 on the emulator (marching kernel switched on there), 2048^2 on the GPU")
+    x = (np.arange(nx + 2) - 0.5) / nx
+    X, Y = np.meshgrid(x, x, indexing="ij")
+    rhs = -2.0 * ((1.0 - 6.0 * X ** 2) * Y ** 2 * (1.0 - Y ** 2) + (1.0 - 6.0 * Y ** 2) * X ** 2 * (1.0 - X ** 2))
+    res = {}
+    for spec in (0, 2, 1):
+        tun = dict(speculate=spec)
+        if nx == 256:
+            tun.update(march_min=256, march_waves=24)
+        m = device.DeviceMG(dev, nx, tuning=tun)
+        L = m.nlevels - 1
+        m.zero(L, 0)
+        m.set(L, 1, rhs)
+        m.init_rhs_norm()
+        out = [m.solve(rtol=1e-7, max_cycles=30), m.get(L, 0)]
+        out += [m.solve(rtol=0.0, max_cycles=3), m.get(L, 0)]
+        out += [m.solve(rtol=1e-10, max_cycles=30), m.get(L, 0), m.get(L, 2)[1:-1, 1:-1]]
+        assert m.tail_counts()[1] > 0
+        res[spec] = out
+    assert 1 < res[0][0][0] < 30
+    for spec in (2, 1):
+        for a, b in zip(res[0], res[spec]):
+            if isinstance(a, tuple):
+                assert a == b, spec
+            else:
+                assert np.array_equal(a, b), spec
