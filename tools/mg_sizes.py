@@ -16,7 +16,7 @@ for nx in [int(a) for a in os.environ.get("MG_SIZES", "64,128,256,512,1024,2048,
     x = (np.arange(nx + 2) - 0.5) / nx
     X, Y = np.meshgrid(x, x, indexing="ij")
     rhs = -2.0 * ((1 - 6 * X**2) * Y**2 * (1 - Y**2) + (1 - 6 * Y**2) * X**2 * (1 - X**2))
-    m = device.DeviceMG(ctx, nx, tuning=dict(march_tail=int(os.environ.get('MG_TAIL', '1')), coarse_wave=int(os.environ.get('MG_WAVE', '1')), march_waves=int(os.environ.get('MG_WAVES', '0')), march_side=float(os.environ.get('MG_SIDE', '1.5')), march_minrows=int(os.environ.get('MG_MINROWS', '32'))))
+    m = device.DeviceMG(ctx, nx, tuning=dict(march_tail=int(os.environ.get('MG_TAIL', '1')), coarse_wave=int(os.environ.get('MG_WAVE', '1')), march_waves=int(os.environ.get('MG_WAVES', '0')), march_side=float(os.environ.get('MG_SIDE', '1.5')), march_minrows=int(os.environ.get('MG_MINROWS', '32')), nsmall=int(os.environ.get('MG_NSMALL', '512'))))
     L = m.nlevels - 1
     m.zero(L, 0); m.set(L, 1, rhs); m.init_rhs_norm()
     m.solve(rtol=0.0, max_cycles=3)
