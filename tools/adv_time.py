@@ -20,7 +20,7 @@ for nx, rows_list in [(int(a.split(":")[0]), a.split(":")[1]) for a in SPEC.spli
             def step():
                 if not fused:
                     st.fill_bc()
-                st.adv_step(0, 1 / nx, 1 / nx, 1.0, 1.0, dt, 2, fill=bool(fused), fast_math=fast,
+                st.adv_step(0, 1 / nx, 1 / nx, 1.0, 1.0, dt, int(os.environ.get("LIM", "2")), fill=bool(fused), fast_math=fast,
                             march_rows=int(rows))
             for _ in range(10): step()
             noprof = os.environ.get("NOPROF", "0") == "1"
