@@ -179,8 +179,24 @@ typedef struct {
     int fill;          /* fold the ghost fill into the step (see above) */
     int fast_math;
     int march_rows;
+    int multi_k;       /* pyrohip_adv_evolve: time steps per launch on periodic grids
+                          (0: the library's choice; 1: one step per launch of the
+                          several-steps kernel; at most 3)                          */
+    int multi_prio;    /* ... its wavefronts take turns at the priority levels     */
 } pyrohip_adv_params;
 int pyrohip_adv_step_p(pyrohip_state *s, int n, const pyrohip_adv_params *p, double dt);
+/* nsteps iterations of the driver's loop body for the advection solver
+   (pyro_sim.py:250-256: fill_BC_all, then Simulation.evolve, advection/simulation.py:56-94)
+   with the time steps dts[0 .. nsteps) the driver's policy gave (simulation_null.py:222-244;
+   the advective CFL step is closed-form, advection/simulation.py:38-54, so the caller knows
+   them all beforehand).  Nothing reads the data between the steps, so on periodic grids
+   several steps are taken in ONE pass over the grid (time-skewed row march: intermediate
+   time levels stay in registers); the bit-faithful build gives, bit for bit, what nsteps
+   calls of pyrohip_adv_step_fill(fill = 1) give, ghost frame included.  Outflow / reflect
+   sides, u = 0 or v = 0 and slabs with neighbours take one launch per step.  p->fill is
+   ignored (every step fills).                                                          */
+int pyrohip_adv_evolve(pyrohip_state *s, int n, const pyrohip_adv_params *p,
+                       const double *dts, int nsteps);
 
 /* ---- compressible ---------------------------------------------------- */
 /* conserved order: density(0) energy(1) x-momentum(2) y-momentum(3)

@@ -42,7 +42,7 @@ class PyroHipError(RuntimeError):
 class AdvParams(C.Structure):
     _fields_ = [("dx", C.c_double), ("dy", C.c_double), ("u", C.c_double), ("v", C.c_double),
                 ("limiter", C.c_int), ("fill", C.c_int), ("fast_math", C.c_int),
-                ("march_rows", C.c_int)]
+                ("march_rows", C.c_int), ("multi_k", C.c_int), ("multi_prio", C.c_int)]
 
 
 class MGTuning(C.Structure):
@@ -143,6 +143,7 @@ _PROTOS = {
     "pyrohip_adv_step_fill": [_VP, C.c_int, C.c_double, C.c_double, C.c_double,
                               C.c_double, C.c_double, C.c_int, C.c_int],
     "pyrohip_adv_step_p": [_VP, C.c_int, C.POINTER(AdvParams), C.c_double],
+    "pyrohip_adv_evolve": [_VP, C.c_int, C.POINTER(AdvParams), C.POINTER(C.c_double), C.c_int],
     "pyrohip_comp_dt": [_VP, C.POINTER(CompParams), C.c_double, _DP],
     "pyrohip_comp_evolve": [_VP, C.POINTER(CompParams), C.c_double, C.POINTER(DtPolicyC), C.c_int,
                             _IP, _DP],

@@ -88,8 +88,9 @@ def build(force=False, verbose=False):
         obj = os.path.join(LIBDIR, "obj", name + os.environ.get("PYRO_OBJ_SUFFIX", "") + ".o")
         fx = FAST_EXTRA if "-DPYRO_FAST=1" in extra else []
         # an object newer than every source is kept (not with experiment flags: those may differ)
+        own = [d for d in deps if not d.endswith(".hip")] + [os.path.join(CSRC, src)]
         if not force and not EXTRA and not fx and not os.environ.get("PYRO_WAVE_SCHED") and \
-                not _stale(obj, deps + [os.path.abspath(__file__)]):
+                not _stale(obj, own + [os.path.abspath(__file__)]):
             return obj
         cmd = [hipcc, f"--offload-arch={ARCH}"] + COMMON + extra + EXTRA + fx + \
               ["-c", os.path.join(CSRC, src), "-o", obj]

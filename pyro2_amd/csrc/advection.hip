@@ -416,6 +416,317 @@ int adv_step_launch(pyrohip_state *s, int n, const pyrohip_adv_params *ap, doubl
     return 0;
 }
 
+// =========================================================================================
+// Several time steps per pass over the grid (periodic grids): k_adv_multi<.., K>.
+//
+// One step per launch reads and writes the whole grid once per step: at 8192^2 the launch
+// runs at the speed of a copy, at 2048^2 the launch's ramp and the write-back of its dirty
+// lines at the kernel boundary are a third of the step (profiles/r03_copy_probe.txt,
+// DESIGN 3.2).  Here the march is time-skewed like the multigrid marching smoother
+// (mg_march.hip): stage s (level s-1 -> level s, s = 1 .. K) consumes the row stage s-1
+// produced in the same iteration, three rows behind it -- stage 1 takes row k from memory,
+// stage s row k - 3 (s - 1), and the final level's row k - 3 K is stored.  Intermediate rows
+// never leave the registers; memory sees one read and one write of the grid per K steps.
+// Every stage is exactly the single step above (same expressions in the same order: the
+// bit-faithful build is bit-identical to K launches of k_adv_step with the ghost fill
+// folded in), with its own dt quotients (the driver's first steps grow, the last one lands
+// on tmax: simulation_null.py:222-244).
+//
+// Ghost cells.  Between two steps the reference refills the ghost cells
+// (pyro_sim.py:250-256).  On a periodic grid the filled array is the periodic image of the
+// interior, so a strip simply works in unwrapped ("virtual") row / column numbers and wraps
+// them where it loads level 0: a virtual ghost cell of an intermediate level is computed by
+// the same operations on the same inputs as the interior cell it is the image of.  The
+// aprons grow with K: 3 K rows above and below a chunk, (3 + 2) K columns per strip.
+// The ghost frame of the new buffer holds, as after K in-place steps of the reference, the
+// fill of level K - 1: every strip stores the cells of level K - 1 it owns that lie within ng
+// of a side to their ghost images as well (the input rows of the last stage).
+// Other boundary types need the intermediate levels' ghost values from cells a strip does not
+// compute at that moment (the mirror image is upstream of the march): pyrohip_adv_evolve
+// takes single steps there.
+constexpr int ADV_KMAX = 3;
+struct AdvCoef { double cx, cy, dtdx2, dtdy2, dtdx, dtdy; };   // of one step (AdvParams)
+struct AdvMultiParams {
+    double u, v;
+    AdvCoef st[ADV_KMAX];
+    int ncb, L, nunits, W;    // column strips, rows per chunk, chunks in all, columns a strip updates
+    int prio;                 // rotate wavefront priorities (k_adv_step)
+};
+
+// the rows one stage carries from one iteration to the next (k_adv_step's rings)
+struct AdvRings { D2 rows[6], l2x[3], Xr[3], Yr[2], Axr[2], Fxr[2]; };
+
+// One iteration of one stage: row k of its input level arrives, row k - 3 of its output level
+// leaves (returns true and sets `out`) once k >= o0 + 3; the stage's output is needed on the
+// rows [o0, o1).  U: position in the unrolled loop (ring indices).
+template <int LIM, bool UNEG, bool VNEG, int U>
+__device__ __forceinline__ bool adv_stage(AdvRings &R, const D2 &in, int k, int o0, int o1, double u,
+                                          double v, const AdvCoef &C, D2 &out)
+{
+    constexpr int NR = 6;
+    const D2 zero{0.0, 0.0};
+#define ADV_W(n) R.rows[(U + (n)) % NR]
+    ADV_W(4) = in;
+    const D2 l2b = R.l2x[U % 3], l2c = R.l2x[(U + 1) % 3];
+    const D2 l2n = (LIM != 0) ? D2{limit2(ADV_W(2).a, ADV_W(3).a, ADV_W(4).a),
+                                   limit2(ADV_W(2).b, ADV_W(3).b, ADV_W(4).b)}
+                              : zero;                                           // limit2_x of row k-1
+    R.l2x[(U + 2) % 3] = l2n;
+    if (k < o0 + 1 || k > o1 + 2) return false;
+    const D2 Xm1 = R.Xr[(U + 1) % 3], Fxm1 = R.Fxr[U % 2];
+    // ---- row c = k-2: limited slopes, interface states (interface.py:25-41)
+    const D2 ac = ADV_W(2), a_up = ADV_W(1), a_dn = ADV_W(3);
+    const D2 sx{adv_slope<LIM>(l2b.a, l2c.a, l2n.a, a_up.a, ac.a, a_dn.a),
+                adv_slope<LIM>(l2b.b, l2c.b, l2n.b, a_up.b, ac.b, a_dn.b)};
+    const D2 am = adv_left(ac), ap = adv_right(ac);
+    const D2 l2y = (LIM != 0) ? D2{limit2(am.a, ac.a, ap.a), limit2(am.b, ac.b, ap.b)} : zero;
+    const D2 l2ym = (LIM == 2) ? adv_left(l2y) : zero, l2yp = (LIM == 2) ? adv_right(l2y) : zero;
+    const D2 sy{adv_slope<LIM>(l2ym.a, l2y.a, l2yp.a, am.a, ac.a, ap.a),
+                adv_slope<LIM>(l2ym.b, l2y.b, l2yp.b, am.b, ac.b, ap.b)};
+    const double cx = C.cx, cy = C.cy;
+    const D2 X = UNEG ? D2{ac.a - 0.5 * (1.0 + cx) * sx.a, ac.b - 0.5 * (1.0 + cx) * sx.b}
+                      : D2{ac.a + 0.5 * (1.0 - cx) * sx.a, ac.b + 0.5 * (1.0 - cx) * sx.b};
+    const D2 Y = VNEG ? D2{ac.a - 0.5 * (1.0 + cy) * sy.a, ac.b - 0.5 * (1.0 + cy) * sy.b}
+                      : D2{ac.a + 0.5 * (1.0 - cy) * sy.a, ac.b + 0.5 * (1.0 - cy) * sy.b};
+    // a_x on the lower x face of row c; a_y on the lower y faces of rows c, c-1 (u, v != 0
+    // here: the upwind offsets of advective_fluxes.py:71-79 are the signs)
+    const D2 ax_c = UNEG ? X : Xm1;
+    const D2 ay_c = VNEG ? Y : adv_left(Y), ay_m = R.Yr[U % 2];
+    const D2 ayt = UNEG ? ay_c : ay_m;
+    const D2 aytp = adv_right(ayt);
+    const D2 Fx{u * (ax_c.a - C.dtdy2 * (v * aytp.a - v * ayt.a)),
+                u * (ax_c.b - C.dtdy2 * (v * aytp.b - v * ayt.b))};
+    const D2 axc_s = VNEG ? ax_c : adv_left(ax_c);
+    const D2 axm_s = R.Axr[U % 2];
+    bool made = false;
+    if (k >= o0 + 3) {   // ---- row g = c-1: F_y and the conservative update
+        const D2 Fy{v * (ay_m.a - C.dtdx2 * (u * axc_s.a - u * axm_s.a)),
+                    v * (ay_m.b - C.dtdx2 * (u * axc_s.b - u * axm_s.b))};
+        const D2 Fyh = adv_right(Fy);
+        out = D2{a_up.a + C.dtdx * (Fxm1.a - Fx.a) + C.dtdy * (Fy.a - Fyh.a),
+                 a_up.b + C.dtdx * (Fxm1.b - Fx.b) + C.dtdy * (Fy.b - Fyh.b)};
+        made = true;
+    }
+    R.Xr[(U + 2) % 3] = X;
+    R.Yr[(U + 1) % 2] = ay_c;
+    R.Axr[(U + 1) % 2] = axc_s;
+    R.Fxr[(U + 1) % 2] = Fx;
+#undef ADV_W
+    return made;
+}
+
+// wavefronts per SIMD the instances are built for (registers: 84 carried per stage + the
+// rows in flight + ~50 temporaries)
+#ifndef PYRO_ADVM_NT
+#define PYRO_ADVM_NT 0      // non-temporal stores of the final level (developer A/B)
+#endif
+#ifndef PYRO_ADVM_WPE2
+#define PYRO_ADVM_WPE2 2
+#endif
+#ifndef PYRO_ADVM_WPE3
+#define PYRO_ADVM_WPE3 2
+#endif
+constexpr int advm_wpe(int K) { return K <= 1 ? 3 : (K == 2 ? PYRO_ADVM_WPE2 : PYRO_ADVM_WPE3); }
+
+template <int LIM, bool UNEG, bool VNEG, int K>
+__global__ __launch_bounds__(64, advm_wpe(K)) void k_adv_multi(const double *__restrict__ ain,
+                                                               double *__restrict__ aout, Geom g,
+                                                               AdvMultiParams P)
+{
+    const int l = threadIdx.x & 63;
+    const int wg = (int)blockIdx.x;
+    const int per = (P.nunits + 7) / 8;                    // XCD x: the units [x per, (x + 1) per)
+    const int unit = pyro_uniform((wg % 8) * per + wg / 8);
+    if (unit >= P.nunits) return;
+    const int cb = pyro_uniform(unit % P.ncb), sb = pyro_uniform(unit / P.ncb);
+    const int i0 = g.ilo + sb * P.L;                       // final rows [i0, i1)
+    const int i1 = (i0 + P.L < g.ihi + 1) ? i0 + P.L : g.ihi + 1;
+    constexpr int nl = VNEG ? 2 : 3, nr = VNEG ? 3 : 2;
+    const int U0 = g.jlo + cb * P.W;                       // final columns [U0, U1]
+    const int U1 = (U0 + P.W - 1 < g.jhi) ? U0 + P.W - 1 : g.jhi;
+    const int ja = U0 - nl * K + 2 * l;                    // this lane's (virtual) columns ja, ja + 1
+    const int p = g.pitch, nx = g.nx, ny = g.ny, ng = g.ng;
+    bool jout[2], jgl[2], jgh[2];
+    int js[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int j = ja + q;
+        int m = (j - g.jlo) % ny;
+        if (m < 0) m += ny;
+        js[q] = g.jlo + m;                                 // the interior column j is the image of
+        jout[q] = (j >= U0 && j <= U1);
+        jgl[q] = jout[q] && (j - g.jlo < ng);              // ... with a ghost image at j + ny
+        jgh[q] = jout[q] && (g.jhi - j < ng);              // ... at j - ny
+    }
+    const bool colghost = pyro_uniform((U0 - g.jlo < ng || g.jhi - U1 < ng) ? 1 : 0) != 0;
+    const int ka = pyro_uniform(i0 - 3 * K), kb = pyro_uniform(i1 + 3 * K - 1);
+    const double u = P.u, v = P.v;
+    auto load_row = [&](int k) {
+        int ks = k > kb ? kb : k;
+        ks = ks < g.ilo ? ks + nx : (ks > g.ihi ? ks - nx : ks);
+        const size_t r = (size_t)ks * p;
+        return D2{ain[r + js[0]], ain[r + js[1]]};
+    };
+    // level K - 1 on row r (owned: i0 <= r < i1) to its images in the ghost frame
+    auto frame_row = [&](int t, bool own, const D2 &val) {
+        const size_t o = (size_t)t * p + ja;
+        if (own) {
+            if (jout[0]) aout[o] = val.a;
+            if (jout[1]) aout[o + 1] = val.b;
+        }
+        if (colghost) {
+            if (jgl[0]) aout[o + ny] = val.a;
+            if (jgl[1]) aout[o + 1 + ny] = val.b;
+            if (jgh[0]) aout[o - ny] = val.a;
+            if (jgh[1]) aout[o + 1 - ny] = val.b;
+        }
+    };
+    constexpr int UNR = 6;
+    const D2 zero{0.0, 0.0};
+    AdvRings R[K];
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+#pragma unroll
+        for (int n = 0; n < 6; n++) R[s].rows[n] = zero;
+#pragma unroll
+        for (int n = 0; n < 3; n++) { R[s].l2x[n] = zero; R[s].Xr[n] = zero; }
+#pragma unroll
+        for (int n = 0; n < 2; n++) { R[s].Yr[n] = zero; R[s].Axr[n] = zero; R[s].Fxr[n] = zero; }
+    }
+    D2 pre[ADV_PF];
+#pragma unroll
+    for (int n = 0; n < ADV_PF; n++) pre[n] = load_row(ka + n);
+    auto step = [&](auto uc, int k) __attribute__((always_inline)) {
+        constexpr int U = decltype(uc)::value;
+        D2 cur = pre[U % ADV_PF];
+        pre[U % ADV_PF] = load_row(k + ADV_PF);
+        adv_static_for<K>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc)::value;
+            const int ks = k - 3 * s;
+            if constexpr (s == K - 1) {
+                if (ks >= i0 && ks < i1) {                 // an owned row of level K - 1
+                    const bool rlo = (ks - g.ilo < ng), rhi = (g.ihi - ks < ng);
+                    if (colghost) frame_row(ks, false, cur);
+                    if (rlo) frame_row(ks + nx, true, cur);
+                    if (rhi) frame_row(ks - nx, true, cur);
+                }
+            }
+            D2 nxt = cur;
+            const bool made = adv_stage<LIM, UNEG, VNEG, U>(R[s], cur, ks, i0 - 3 * (K - 1 - s),
+                                                            i1 + 3 * (K - 1 - s), u, v, P.st[s], nxt);
+            if constexpr (s == K - 1) {
+                if (made) {
+                    const size_t ko = (size_t)(ks - 3) * p + ja;
+#if PYRO_ADVM_NT
+                    if (jout[0]) __builtin_nontemporal_store(nxt.a, &aout[ko]);
+                    if (jout[1]) __builtin_nontemporal_store(nxt.b, &aout[ko + 1]);
+#else
+                    if (jout[0]) aout[ko] = nxt.a;
+                    if (jout[1]) aout[ko + 1] = nxt.b;
+#endif
+                }
+            }
+            cur = nxt;
+        });
+    };
+#if !defined(PYRO_EMU) && PYRO_ADV_PRIO
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    int turn = (int)(hw_id & 3u);
+#endif
+    for (int k0 = ka; k0 <= kb; k0 += UNR) {
+#if !defined(PYRO_EMU) && PYRO_ADV_PRIO
+        if (P.prio) {
+            switch (turn & 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+            }
+            turn++;
+        }
+#endif
+        adv_static_for<UNR>([&](auto uc) __attribute__((always_inline)) {
+            const int k = k0 + decltype(uc)::value;
+            if (k <= kb) step(uc, k);
+        });
+    }
+}
+
+// chunk length of a K-step launch: the shortest chunk with which every wavefront is resident
+// at once (adv_rows), for the wavefronts per SIMD the instance is built for; beyond that
+// several rounds of chunks long enough to make the 6 K apron rows cheap
+static int advm_rows(int nx, int ncb, int cus, int K)
+{
+    const long slots = 4L * advm_wpe(K) * cus;
+    const int lmin = 6 * K;
+    if (nx <= lmin) return nx;
+    for (int L = lmin; L <= 40 * K && L < nx; L++)
+        if ((long)ncb * ((nx + L - 1) / L) <= slots) return L;
+    // whole rounds: the fewest rounds whose chunks stay below ~48 K rows
+    for (int rounds = 1; rounds < 64; rounds++) {
+        const long chunks = slots * rounds / ncb;
+        if (chunks < 1) continue;
+        const int L = (int)((nx + chunks - 1) / chunks);
+        if (L <= 48 * K) return L < lmin ? lmin : L;
+    }
+    return 48 * K;
+}
+
+template <int LIM, int K>
+static void advm_launch(pyrohip_ctx *c, bool uneg, bool vneg, int nwg, const double *cur, double *nxt,
+                        const Geom &g, const AdvMultiParams &P)
+{
+    const dim3 grid(8 * ((nwg + 7) / 8)), block(64);
+    if (uneg && vneg)
+        PYRO_LAUNCH(c, "k_adv_multi", (k_adv_multi<LIM, true, true, K>), grid, block, 0, cur, nxt, g, P);
+    else if (uneg)
+        PYRO_LAUNCH(c, "k_adv_multi", (k_adv_multi<LIM, true, false, K>), grid, block, 0, cur, nxt, g, P);
+    else if (vneg)
+        PYRO_LAUNCH(c, "k_adv_multi", (k_adv_multi<LIM, false, true, K>), grid, block, 0, cur, nxt, g, P);
+    else
+        PYRO_LAUNCH(c, "k_adv_multi", (k_adv_multi<LIM, false, false, K>), grid, block, 0, cur, nxt, g, P);
+}
+
+// K steps (dts[0 .. K)) of variable n from `cur` into `nxt`, periodic sides, u, v != 0
+int adv_multi_launch(pyrohip_state *s, const pyrohip_adv_params *ap, const double *dts, int K,
+                     const double *cur, double *nxt)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    const double u = ap->u, v = ap->v, dx = ap->dx, dy = ap->dy;
+    AdvMultiParams P;
+    memset(&P, 0, sizeof(P));
+    P.u = u; P.v = v;
+    for (int k = 0; k < K; k++) {
+        const double dt = dts[k];
+        AdvCoef &C = P.st[k];
+        C.cx = u * dt / dx; C.cy = v * dt / dy;
+        C.dtdx2 = 0.5 * dt / dx; C.dtdy2 = 0.5 * dt / dy;
+        C.dtdx = dt / dx; C.dtdy = dt / dy;
+    }
+    P.W = AW_WIN - 5 * K;
+    P.ncb = (g.ny + P.W - 1) / P.W;
+    P.L = advm_rows(g.nx, P.ncb, c->num_cus > 0 ? c->num_cus : 256, K);
+    if (ap->march_rows > 0) P.L = ap->march_rows < g.nx ? (ap->march_rows < 4 ? 4 : ap->march_rows) : g.nx;
+    P.prio = (ap->multi_prio != 0);
+    const int nwg = P.ncb * ((g.nx + P.L - 1) / P.L);
+    P.nunits = nwg;
+    const bool uneg = (u < 0), vneg = (v < 0);
+#define ADVM_K(KK)                                                                         \
+    do {                                                                                   \
+        if (ap->limiter == 0) advm_launch<0, KK>(c, uneg, vneg, nwg, cur, nxt, g, P);       \
+        else if (ap->limiter == 1) advm_launch<1, KK>(c, uneg, vneg, nwg, cur, nxt, g, P);  \
+        else advm_launch<2, KK>(c, uneg, vneg, nwg, cur, nxt, g, P);                        \
+    } while (0)
+    if (K == 1) ADVM_K(1);
+    else if (K == 2) ADVM_K(2);
+    else ADVM_K(3);
+#undef ADVM_K
+    PYRO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace PYRO_NS
 }  // namespace pyro
 
@@ -425,6 +736,8 @@ int adv_step_launch(pyrohip_state *s, int n, const pyrohip_adv_params *ap, doubl
 namespace pyro {
 namespace fastm {
 int adv_step_launch(pyrohip_state *, int, const pyrohip_adv_params *, double, const double *, double *);
+int adv_multi_launch(pyrohip_state *, const pyrohip_adv_params *, const double *, int, const double *,
+                     double *);
 }
 }  // namespace pyro
 
@@ -434,6 +747,36 @@ static bool simple_bc(int b)
 {
     return b == PYROHIP_BC_OUTFLOW || b == PYROHIP_BC_REFLECT_EVEN || b == PYROHIP_BC_REFLECT_ODD ||
            b == PYROHIP_BC_PERIODIC;
+}
+
+// after a step of variable n from s->d into s->work: the new level becomes the state's
+static int adv_commit(pyrohip_state *s, int n)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    if (s->nvar == 1) {
+        // single-variable state: swap the two allocations
+        double *old_base = s->base;
+        s->base = s->work;
+        s->work = old_base;
+        s->d = s->base + geom_lead(g);
+    } else {
+        PYRO_CHECK_HIP(hipMemcpyAsync(s->d + (size_t)n * g.plane, s->work + geom_lead(g),
+                                      g.plane * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    s->next_cfl_min = -1.0;
+    return 0;
+}
+
+static int adv_ensure_work(pyrohip_state *s)
+{
+    if (s->work_planes < 1) {
+        if (s->work) PYRO_CHECK_HIP(hipFree(s->work));
+        s->work = nullptr;
+        PYRO_CHECK_HIP(hipMalloc((void **)&s->work, (s->g.plane + 16) * sizeof(double)));
+        s->work_planes = 1;
+    }
+    return 0;
 }
 
 extern "C" int pyrohip_adv_step_p(pyrohip_state *s, int n, const pyrohip_adv_params *ap, double dt)
@@ -450,28 +793,57 @@ extern "C" int pyrohip_adv_step_p(pyrohip_state *s, int n, const pyrohip_adv_par
             PYRO_REQUIRE(simple_bc(s->bc[n * 4 + k]),
                          "fused ghost fill: outflow / reflect / periodic boundaries only");
     PYRO_TRY(comm_wait_halo(s));
-    // scratch plane for the new time level
-    if (s->work_planes < 1) {
-        if (s->work) PYRO_CHECK_HIP(hipFree(s->work));
-        s->work = nullptr;
-        PYRO_CHECK_HIP(hipMalloc((void **)&s->work, (g.plane + 16) * sizeof(double)));
-        s->work_planes = 1;
-    }
+    PYRO_TRY(adv_ensure_work(s));
     double *cur = s->d + (size_t)n * g.plane;
     double *nxt = s->work + geom_lead(g);
     PYRO_TRY(ap->fast_math ? fastm::adv_step_launch(s, n, ap, dt, cur, nxt)
                            : exact::adv_step_launch(s, n, ap, dt, cur, nxt));
-    if (s->nvar == 1) {
-        // single-variable state: swap the two allocations
-        double *old_base = s->base;
-        s->base = s->work;
-        s->work = old_base;
-        s->d = s->base + geom_lead(g);
-    } else {
-        PYRO_CHECK_HIP(hipMemcpyAsync(cur, nxt, g.plane * sizeof(double),
-                                      hipMemcpyDeviceToDevice, c->stream));
+    return adv_commit(s, n);
+}
+
+// nsteps x (ghost fill of variable n + step) with the time steps dts[0 .. nsteps): what the
+// driver's loop (pyro_sim.py:241-281) does to the data when nothing reads it in between.  On
+// periodic grids up to p->multi_k (0: the library's choice, at most 3) steps go into one launch
+// of k_adv_multi; everything else takes the single-step kernel with the fill folded in.
+extern "C" int pyrohip_adv_evolve(pyrohip_state *s, int n, const pyrohip_adv_params *ap,
+                                  const double *dts, int nsteps)
+{
+    PYRO_REQUIRE(s && ap && (dts || nsteps == 0), "NULL argument");
+    PYRO_REQUIRE(nsteps >= 0, "negative step count");
+    PYRO_REQUIRE(n >= 0 && n < s->nvar, "variable index out of range");
+    PYRO_REQUIRE(s->g.ng >= 4, "advection needs ng >= 4 (advection/simulation.py:20)");
+    PYRO_REQUIRE(ap->limiter >= 0 && ap->limiter <= 2, "limiter must be 0, 1 or 2");
+    PYRO_REQUIRE(ap->dx > 0.0 && ap->dy > 0.0, "bad dx / dy");
+    const Geom &g = s->g;
+    for (int k = 0; k < 4; k++)
+        PYRO_REQUIRE(simple_bc(s->bc[n * 4 + k]),
+                     "pyrohip_adv_evolve: outflow / reflect / periodic boundaries only");
+    bool periodic = true;
+    for (int k = 0; k < 4; k++) periodic = periodic && s->bc[n * 4 + k] == PYROHIP_BC_PERIODIC;
+    int kmax = ap->multi_k > 0 ? ap->multi_k : 2;
+    if (kmax > 3) kmax = 3;
+    // the unwrapped indices of a K-step launch wrap once: 3 K rows / the strip's apron columns
+    // must fit the grid; u = 0 or v = 0 keep the single step (its upwind offsets are not the signs)
+    if (!periodic || ap->u == 0.0 || ap->v == 0.0 || s->nb_set || g.nx < 16 || g.ny < 16) kmax = 1;
+    PYRO_TRY(comm_wait_halo(s));
+    PYRO_TRY(adv_ensure_work(s));
+    pyrohip_adv_params one = *ap;
+    one.fill = 1;
+    int done = 0;
+    while (done < nsteps) {
+        const int K = (nsteps - done < kmax) ? nsteps - done : kmax;
+        double *cur = s->d + (size_t)n * g.plane;
+        double *nxt = s->work + geom_lead(g);
+        if (K == 1 && !(ap->multi_k == 1 && periodic && ap->u != 0.0 && ap->v != 0.0 && !s->nb_set)) {
+            PYRO_TRY(ap->fast_math ? fastm::adv_step_launch(s, n, &one, dts[done], cur, nxt)
+                                   : exact::adv_step_launch(s, n, &one, dts[done], cur, nxt));
+        } else {
+            PYRO_TRY(ap->fast_math ? fastm::adv_multi_launch(s, &one, dts + done, K, cur, nxt)
+                                   : exact::adv_multi_launch(s, &one, dts + done, K, cur, nxt));
+        }
+        PYRO_TRY(adv_commit(s, n));
+        done += K;
     }
-    s->next_cfl_min = -1.0;
     return 0;
 }
 

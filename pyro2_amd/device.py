@@ -393,6 +393,17 @@ class DeviceState:
         with self.ctx.lock:
             check(self._l.pyrohip_adv_step_p(self.h, int(n), C.byref(ap), dt))
 
+    def adv_evolve(self, n, dx, dy, u, v, dts, limiter, fast_math=0, march_rows=0, multi_k=0,
+                   multi_prio=0):
+        """len(dts) x (ghost fill + step) of variable n without a host round trip; on
+        periodic grids several steps per pass over the grid (pyrohip_adv_evolve)"""
+        from ._lib import AdvParams
+        ap = AdvParams(dx, dy, u, v, int(limiter), 1, int(fast_math), int(march_rows), int(multi_k),
+                       int(multi_prio))
+        arr = (C.c_double * len(dts))(*[float(d) for d in dts])
+        with self.ctx.lock:
+            check(self._l.pyrohip_adv_evolve(self.h, int(n), C.byref(ap), arr, len(dts)))
+
     def comp_dt(self, params, cfl):
         dt = C.c_double()
         with self.ctx.lock:

@@ -30,10 +30,15 @@ def build(force=False):
              "-I" + HERE, "-DPYRO_EMU=1", '-DPYRO_BACKEND_NAME="host-emu"']
     units = [u for u in hb.units() if u[1] not in ("comm",)]
 
+    headers = [d for d in deps if not d.endswith(".hip")] + [os.path.abspath(__file__)]
+
     def cc(u):
         src, name, extra = u
         defs = [f for f in extra if f.startswith("-D")]
         obj = os.path.join(OUT, name + ".o")
+        # an object newer than its own source and every header is kept
+        if not force and not hb._stale(obj, headers + [os.path.join(hb.CSRC, src)]):
+            return obj
         subprocess.check_call(["g++"] + flags + defs + ["-x", "c++", "-c",
                               os.path.join(hb.CSRC, src), "-o", obj])
         return obj

@@ -164,3 +164,99 @@ def test_adv_large_vs_oracle(hip, nx, uv, fast):
     assert (np.abs(b[4:-4, 4:-4] - a[4:-4, 4:-4]) / np.abs(a[4:-4, 4:-4])).max() <= 1e-12
     # conservation (periodic): sum is preserved to round-off
     assert abs(b[4:-4, 4:-4].sum() - ic[4:-4, 4:-4].sum()) < 1e-9 * nx * nx
+
+
+def _evolve_pair(dev, nx, ny, bcs, uv, lim, dts, K, rows=0, fast=0, seed=11):
+    """(n single steps with the fill folded in, pyrohip_adv_evolve) on the same random data"""
+    ng = 4
+    rng = np.random.default_rng(seed)
+    a0 = rng.random((nx + 2 * ng, ny + 2 * ng)) + 0.3        # ghost cells: junk on purpose
+    dx, dy = 1.0 / nx, 1.0 / ny
+    s = device.DeviceState(dev, nx, ny, ng, [list(bcs)])
+    s.upload(a0)
+    for dt in dts:
+        s.adv_step(0, dx, dy, uv[0], uv[1], dt, lim, fill=True, fast_math=fast)
+    m = device.DeviceState(dev, nx, ny, ng, [list(bcs)])
+    m.upload(a0)
+    m.adv_evolve(0, dx, dy, uv[0], uv[1], dts, lim, fast_math=fast, march_rows=rows, multi_k=K)
+    return s.download()[:, :, 0], m.download()[:, :, 0], a0
+
+
+@pytest.mark.parametrize("K", [1, 2, 3])
+@pytest.mark.parametrize("nx,ny,uv,lim,rows", [
+    (40, 300, (1.0, 1.0), 2, 0),       # three column strips, one chunk
+    (33, 130, (-0.7, 0.4), 2, 7),      # ragged chunks, u < 0
+    (64, 64, (0.8, -1.1), 2, 9),       # the window wider than the grid: wraps onto itself
+    (20, 118, (-0.5, -0.9), 1, 0),     # one strip exactly (K = 2: 118 columns), limiter 1
+    (16, 16, (0.6, 0.9), 0, 5),        # the smallest grid that takes several steps per launch
+])
+def test_adv_evolve_several_steps_per_launch(dev, nx, ny, uv, lim, rows, K):
+    """pyrohip_adv_evolve on periodic grids: K steps per pass over the grid (time-skewed march,
+    csrc/advection.hip k_adv_multi) against K launches of the single-step kernel with the ghost
+    fill folded in -- interior AND ghost frame, bit for bit in the bit-faithful build; growing
+    time steps like the driver's first steps (simulation_null.py:222-244); 5 steps = K-step
+    launches plus a remainder; and against the oracle (fill_ghost + step per step)."""
+    dx, dy = 1.0 / nx, 1.0 / ny
+    dt0 = 0.8 * min(dx / abs(uv[0]), dy / abs(uv[1]))
+    dts = [dt0 * f for f in (0.1, 0.2, 0.4, 0.8, 1.0)]
+    single, multi, a0 = _evolve_pair(dev, nx, ny, ("periodic",) * 4, uv, lim, dts, K, rows)
+    assert np.array_equal(single, multi)
+    a = a0.copy()
+    for dt in dts:
+        orc.fill_ghost(a, nx, ny, 4, ["periodic"] * 4)
+        orc.adv_step(a, nx, ny, 4, dx, dy, uv[0], uv[1], dt, lim)
+    tol = 0.0 if dev.kind == "emu" else TOL
+    assert max_rel_err(multi[4:-4, 4:-4], a[4:-4, 4:-4]) <= tol
+
+
+@pytest.mark.parametrize("bcs,uv", [
+    (("outflow", "outflow", "outflow", "outflow"), (-0.7, 0.4)),
+    (("reflect-even", "outflow", "reflect-odd", "reflect-even"), (0.8, -1.1)),
+    (("periodic", "periodic", "outflow", "reflect-even"), (0.5, 0.6)),
+    (("periodic", "periodic", "periodic", "periodic"), (0.0, 0.6)),     # u = 0: single steps
+])
+def test_adv_evolve_other_boundaries_take_single_steps(dev, bcs, uv):
+    """anything but four periodic sides (and u = 0 / v = 0) runs one launch per step inside
+    pyrohip_adv_evolve: same result as stepping from the host, ghost frame included"""
+    nx, ny = 24, 140
+    dt = 0.8 * min(1.0 / nx / max(abs(uv[0]), 1e-3), 1.0 / ny / max(abs(uv[1]), 1e-3))
+    single, multi, _ = _evolve_pair(dev, nx, ny, bcs, uv, 2, [dt] * 4, 3)
+    assert np.array_equal(single, multi)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [2, 3])
+@pytest.mark.parametrize("nx,uv", [(2048, (1.0, 1.0)), (1000, (-0.6, 0.9)), (4096, (0.8, -1.0))])
+def test_adv_evolve_large_vs_single_steps_and_oracle(hip, nx, uv, K):
+    """BASELINE config 2 (2048^2 periodic), a ragged size and a grid of several rounds of
+    resident wavefronts: pyrohip_adv_evolve with K steps per launch -- the bit-faithful build
+    bit-identical to single steps (whole array), the contracted build within 1e-12 of the oracle
+    element-wise"""
+    x = (np.arange(nx + 8) - 4 + 0.5) / nx
+    X, Y = np.meshgrid(x, x, indexing="ij")
+    ic = 1.0 + np.exp(-60.0 * ((X - 0.5) ** 2 + (Y - 0.5) ** 2))
+    ic[X > 0.7] += 0.5
+    u, v = uv
+    dt = orc.adv_dt(1 / nx, 1 / nx, u, v, 0.8)
+    nsteps = 7 if nx <= 2048 else 5
+    out = {}
+    for fast in (0, 1):
+        s = device.DeviceState(hip, nx, nx, 4, [["periodic"] * 4])
+        s.upload(ic)
+        for _ in range(nsteps):
+            s.adv_step(0, 1 / nx, 1 / nx, u, v, dt, 2, fill=True, fast_math=fast)
+        m = device.DeviceState(hip, nx, nx, 4, [["periodic"] * 4])
+        m.upload(ic)
+        m.adv_evolve(0, 1 / nx, 1 / nx, u, v, [dt] * nsteps, 2, fast_math=fast, multi_k=K)
+        a, b = s.download()[:, :, 0], m.download()[:, :, 0]
+        if fast == 0:
+            assert np.array_equal(a, b)
+        else:
+            assert (np.abs(b - a) / np.abs(a)).max() <= 1e-12
+        out[fast] = b
+    a = ic.copy()
+    for _ in range(nsteps):
+        orc.fill_ghost(a, nx, nx, 4, ("periodic",) * 4)
+        orc.adv_step(a, nx, nx, 4, 1 / nx, 1 / nx, u, v, dt, 2)
+    for fast in (0, 1):
+        assert (np.abs(out[fast][4:-4, 4:-4] - a[4:-4, 4:-4]) / np.abs(a[4:-4, 4:-4])).max() <= 1e-12
