@@ -182,7 +182,8 @@ typedef struct {
     int multi_k;       /* pyrohip_adv_evolve: time steps per launch on periodic grids
                           (0: the library's choice; 1: one step per launch of the
                           several-steps kernel; at most 3)                          */
-    int multi_prio;    /* ... its wavefronts take turns at the priority levels     */
+    int multi_prio;    /* ... its wavefronts take turns at the priority levels (0: the
+                          library's choice = yes, -1: no)                           */
 } pyrohip_adv_params;
 int pyrohip_adv_step_p(pyrohip_state *s, int n, const pyrohip_adv_params *p, double dt);
 /* nsteps iterations of the driver's loop body for the advection solver

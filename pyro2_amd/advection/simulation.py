@@ -58,6 +58,69 @@ class Simulation(NullSimulation):
         self.n += 1
         tm.end()
 
+    def can_evolve_many(self):
+        """may the driver hand several steps at once to the device (pyrohip_adv_evolve)?
+        Standard boundary types, nothing watching the data, the plain evolve() of this class
+        (tracer particles ride along: the velocity field is constant, they never read the
+        data)."""
+        cc = self.cc_data
+        if type(self).evolve is not Simulation.evolve:
+            return False
+        simple = ("outflow", "reflect-even", "reflect-odd", "periodic")
+        if not all(b in simple for n in cc.names for b in cc.BCs[n].sides()):
+            return False
+        return not (any(cc._has_host_bc(n) for n in cc.names) or cc._views_alive())
+
+    def evolve_many(self, nsteps):
+        """up to nsteps iterations of fill_BC_all + compute_timestep + evolve
+        (pyro_sim.py:250-256) in one device call.  The advective CFL step is closed-form
+        (advection/simulation.py:38-54), so the driver's policy (simulation_null.py:222-244)
+        gives the whole dt sequence beforehand -- computed here by the very methods the
+        single step uses; on periodic grids the device then takes several steps per pass
+        over the grid (csrc/advection.hip: k_adv_multi).  Returns the time steps taken."""
+        tm = self.tc.timer("evolve")
+        tm.begin()
+        t0, n0 = self.cc_data.t, self.n
+        dts = []
+        while len(dts) < nsteps and not self.finished():
+            self.compute_timestep()
+            if not self.dt > 0.0:
+                break
+            dts.append(float(self.dt))
+            self.cc_data.t += self.dt       # as evolve() does
+            self.n += 1
+        if dts:
+            self.cc_data.t, self.n = t0, n0
+            g = self.cc_data.grid
+            st = self.cc_data.device_state(fuse_fill=True)
+            self.cc_data.take_pending_fill()     # every step of the call fills
+            try:
+                st.adv_evolve(self.cc_data.names.index("density"), g.dx, g.dy,
+                              float(self.rp.get_param("advection.u")),
+                              float(self.rp.get_param("advection.v")), dts,
+                              int(self.rp.get_param("advection.limiter")),
+                              fast_math=self._fast_math(), multi_k=self._multi_k())
+            finally:
+                self.cc_data.device_modified()
+            if self.particles is not None:   # advection/simulation.py:82-90, step by step
+                uu = g.scratch_array() + self.rp.get_param("advection.u")
+                vv = g.scratch_array() + self.rp.get_param("advection.v")
+            for dt in dts:                  # the same additions in the same order
+                if self.particles is not None:
+                    self.dt = dt
+                    self.advance_particles(uu, vv)
+                self.cc_data.t += dt
+            self.n = n0 + len(dts)
+        tm.end()
+        return dts
+
+    def _multi_k(self):
+        """gpu.adv_steps_per_launch (0: the library's choice)"""
+        try:
+            return int(self.rp.get_param("gpu.adv_steps_per_launch"))
+        except (KeyError, ValueError, RuntimeError):
+            return 0
+
     def dovis(self):
         """runtime plot of the density (same picture as the reference's dovis)"""
         import matplotlib.pyplot as plt

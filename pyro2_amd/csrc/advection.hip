@@ -709,7 +709,7 @@ int adv_multi_launch(pyrohip_state *s, const pyrohip_adv_params *ap, const doubl
     P.ncb = (g.ny + P.W - 1) / P.W;
     P.L = advm_rows(g.nx, P.ncb, c->num_cus > 0 ? c->num_cus : 256, K);
     if (ap->march_rows > 0) P.L = ap->march_rows < g.nx ? (ap->march_rows < 4 ? 4 : ap->march_rows) : g.nx;
-    P.prio = (ap->multi_prio != 0);
+    P.prio = (ap->multi_prio >= 0);   // measured: 2048^2 19.0 -> 18.1 us per step, 8192^2 212.5 -> 209.7
     const int nwg = P.ncb * ((g.nx + P.L - 1) / P.L);
     P.nunits = nwg;
     const bool uneg = (u < 0), vneg = (v < 0);

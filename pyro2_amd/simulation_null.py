@@ -177,6 +177,10 @@ class NullSimulation:
             # max_dt_change limiter of the next step exactly
             f.attrs["dt"] = self.dt
             f.attrs["dt_old"] = self.dt_old
+            try:      # which arithmetic wrote the file (0: bit-faithful, 1: contracted)
+                f.attrs["gpu_fast_math"] = int(self.rp.get_param("gpu.fast_math"))
+            except (KeyError, RuntimeError, ValueError):
+                pass
             self.cc_data.write_data(f)
             if self.particles is not None:
                 self.particles.write_particles(f)

@@ -243,6 +243,13 @@ def test_hdf5_roundtrip_and_benchmark_compare(api, tmp_path):
     q = PyroBenchmark("advection", comp_bench=True, bench_dir=str(tmp_path) + "/bench/")
     q.initialize_problem("smooth", inputs_dict={"driver.max_steps": 3})
     assert q.run_sim() == 0
+    # a benchmark run takes the bit-faithful build unless told otherwise (the comparison is at
+    # the reference's rtol = 1e-12, pyro_sim.py:353), and the file says which build wrote it
+    assert p.rp.get_param("gpu.fast_math") == 0 and q.rp.get_param("gpu.fast_math") == 0
+    assert int(s.restart_info["params"]["gpu.fast_math"]) == 0
+    r = PyroBenchmark("advection", comp_bench=True, bench_dir=str(tmp_path) + "/bench/")
+    r.initialize_problem("smooth", inputs_dict={"driver.max_steps": 3, "gpu.fast_math": 1})
+    assert r.rp.get_param("gpu.fast_math") == 1
 
 
 def test_restart_is_bit_identical(api, tmp_path):
@@ -524,3 +531,32 @@ def test_compressible_rk_reference_regression(hip, golden, tmp_path, monkeypatch
     # regression tool does (pyro/util/compare.py: relative to the field's magnitude)
     scale = np.abs(g["gold"]).max(axis=(0, 1))
     assert (np.abs(U - g["gold"]) / scale).max() < 1e-9
+
+
+@pytest.mark.parametrize("problem,extra", [
+    ("smooth", {}),                                                   # periodic: several steps per launch
+    ("tophat", {"mesh.xlboundary": "outflow", "mesh.xrboundary": "outflow"}),   # single steps inside the call
+])
+def test_advection_run_sim_batches_steps(api, problem, extra):
+    """Pyro.run_sim hands batches of steps to pyrohip_adv_evolve when nothing happens between
+    them (verbose = 0, no output, no plot): same data (ghost cells included), step count, time,
+    dt and dt_old as the step-by-step loop of pyro_sim.py:241-281 -- the first steps grow by
+    max_dt_change, the last one lands on tmax (simulation_null.py:222-244)"""
+    from pyro2_amd.pyro_sim import Pyro
+    got = {}
+    for batch in (False, True):
+        p = Pyro("advection")
+        p.initialize_problem(problem, inputs_dict=dict({"mesh.nx": 32, "mesh.ny": 48, "driver.tmax": 0.3,
+                                                        "gpu.fast_math": 0, "gpu.adv_steps_per_launch": 3},
+                                                       **extra))
+        assert p.sim.can_evolve_many()
+        if not batch:
+            p.sim.can_evolve_many = lambda: False
+        p.run_sim()
+        got[batch] = (np.array(p.sim.cc_data.data), p.sim.n, p.sim.cc_data.t, p.sim.dt, p.sim.dt_old)
+        parts = p.sim.particles       # inputs.smooth carries tracer particles (constant velocity)
+        got[batch] += (None if parts is None else np.array(parts.get_positions()),)
+    assert got[True][1:5] == got[False][1:5] and got[True][1] > 10
+    assert np.array_equal(got[True][0], got[False][0])
+    assert (got[True][5] is None) == (got[False][5] is None)
+    assert got[True][5] is None or np.array_equal(got[True][5], got[False][5])
