@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0 # ... 6.29 TB/s measured (float4 copy, 79 %)
 SEDOV_BYTES_PER_CELL = 64   # read 4 + write 4 conserved doubles
 ADV_BYTES_PER_CELL = 16     # read a + write a
 MG_BYTES_PER_CELL_VCYCLE = 720      # SURVEY 8(d)'s one-pass-per-iteration model (kept as a labelled extra)
@@ -58,6 +59,13 @@ VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4  # wave-instructions/s: 1024 SIMDs, 4 cycles 
 SEDOV_MIN_FLOPS_PER_CELL = 880
 
 
+# DESIGN.md 6 "Predicted ... step at 16384^2": the committed prediction a first hardware
+# SCALE line is read against (ms per step; slab kernel = single-GPU kernel / N x the tail of
+# its ~2 rounds of wavefronts, + ~0.1 ms of dt all-reduce and small launches on the critical
+# path; the halo exchange runs beside the interior strips)
+PREDICTED_MS_16384 = {1: 9.42, 2: 4.75, 4: 2.45, 8: 1.40}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,10 +80,12 @@ def parse():
     ap.add_argument("--cpu-sample-nx", type=int, default=1024)
     ap.add_argument("--developed-steps", type=int, default=250)
     ap.add_argument("--no-developed", action="store_true")
-    ap.add_argument("--scale-check", action="store_true",
+    ap.add_argument("--scale-check", action="store_true", default=None,
                     help="before timing: compressible Sedov 2048^2, 12 steps, on 1 rank vs the N ranks "
                          "of this run, must agree bit for bit (SURVEY 8(d).5); the result goes "
-                         "into config.scale_check, a mismatch is fatal")
+                         "into config.scale_check, a mismatch is fatal.  On by default at --gpus > 1")
+    ap.add_argument("--no-scale-check", dest="scale_check", action="store_false",
+                    help="skip the bit-identity check of the decomposed run (--gpus > 1)")
     ap.add_argument("--host-dt", action="store_true",
                     help="step from the host (one dt read-back per step) instead of "
                          "pyrohip_comp_evolve")
@@ -130,6 +140,16 @@ class Dist:
         self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
         return float(t[0])
 
+    def gather(self, values):
+        """list of floats of every rank -> list (over ranks) of lists, on every rank"""
+        if not self.td:
+            return [list(values)]
+        import torch
+        mine = torch.tensor(list(values), dtype=torch.float64)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.td.all_gather(out, mine)
+        return [[float(v) for v in t] for t in out]
+
     def bcast_bytes(self, b, n):
         if not self.td:
             return b
@@ -152,6 +172,21 @@ def also_traffic(section, key):
         return json.load(open(fs[-1]))[section][key]
     except Exception:
         return None
+
+
+def also_traffic_source():
+    """which committed PMC file the `traffic` entries of the advection / multigrid legs come
+    from, with the commit / box / date recorded in it"""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_also_traffic.json")))
+    if not fs:
+        return None
+    try:
+        prov = json.load(open(fs[-1])).get("provenance")
+    except Exception:
+        prov = None
+    return {"file": "profiles/" + os.path.basename(fs[-1]), "provenance": prov,
+            "note": "counters of a separate rocprofv3 --pmc run of the same leg, not of this run"}
 
 
 def kernel_table(prof, nlaunch_unit):
@@ -255,6 +290,7 @@ def bench_sedov(args, dist, ctx, device, defaults, steps=None, warmup=None, tile
     dist.barrier()
     res = {"elapsed": elapsed, "cells": float(nx) * ny, "prof": prof, "event_ms": ev_ms,
            "t": pol.t, "dt": pol.dt_old, "local_cells": float(dec.nx_local) * ny, "steps": steps,
+           "rows_local": dec.nx_local,
            "prof_steps": nprof, "dt_policy": "device" if device_dt else "host"}
     if collect:
         res["interior"] = st.download()[ng:-ng, ng:-ng].copy()
@@ -270,17 +306,26 @@ def r_short(elapsed, steps):
     return steps > 0 and elapsed / steps < 5.0e-3
 
 
-def pmc_counts(fast_math):
+def pmc_counts(fast_math, nx=16384):
     """VALU instruction / traffic counts of the dominant update kernel from the committed
-    rocprofv3 PMC passes (profiles/traffic.json, tools/gpu_round.sh + tools/make_traffic.py)"""
+    rocprofv3 PMC passes (profiles/traffic.json: tools/profile_round.sh + tools/make_traffic.py),
+    counted at this grid size when the file has it, else at 16384^2 (entry "counted_at_nx"
+    says which); every entry carries the commit, box and date of the session that counted it"""
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        return json.load(open(tr))[f"fast_math_{fast_math}"]
+        tab = json.load(open(tr))
     except Exception:
         return None
+    for key, at in ((f"nx{nx}_fast_math_{fast_math}", nx), (f"fast_math_{fast_math}", 16384)):
+        if key in tab and (at == nx or key.startswith("fast_math")):
+            e = dict(tab[key])
+            e["counted_at_nx"] = e.get("nx", 16384)
+            e.setdefault("provenance", tab.get("provenance"))
+            return e
+    return None
 
 
-def fp64_roofline(cells_per_s_kernel, fast_math, dom):
+def fp64_roofline(cells_per_s_kernel, fast_math, dom, nx=16384):
     """the roof that binds the CTU kernel is the FP64 vector unit, not HBM:
     arithmetic minimum x cell rate against the FMA peak, and the instruction-issue figure"""
     out = {
@@ -291,7 +336,7 @@ def fp64_roofline(cells_per_s_kernel, fast_math, dom):
         "basis": "arithmetic minimum of one CTU + 4 x HLLC cell update (DESIGN.md 3, FMA = 2 "
                  "flop) x cell rate of the update kernel; the kernel is mostly non-FMA, so "
                  "the instruction-issue figures below are the tighter statement"}
-    t = pmc_counts(fast_math)
+    t = pmc_counts(fast_math, nx)
     if t and t.get("kernel") == dom:
         ipc = t["valu_insts_per_cell_update"]        # lane-instructions per cell update
         out["valu_issue"] = {
@@ -301,14 +346,15 @@ def fp64_roofline(cells_per_s_kernel, fast_math, dom):
             "peak_wave_insts_per_s": VALU_ISSUE_PEAK,
             "frac": ipc / 64.0 * cells_per_s_kernel / VALU_ISSUE_PEAK,
             "valu_busy_frac_of_kernel_time": t["valu_busy_ms"] / t["kernel_ms"],
-            "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU of the same kernel (counted at 16384^2; "
-                      "per cell update, the strip geometry differs slightly by size), " + t["measured_at"]}
+            "counted_at_nx": t["counted_at_nx"], "provenance": t.get("provenance"),
+            "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU of the same kernel in a separate rocprofv3 "
+                      "--pmc session (profiles/traffic.json; NOT counters of this run), " + t["measured_at"]}
     return out
 
 
 def sedov_leg(r, defaults, nx, extra=None):
     """summary of a secondary Sedov measurement for the `also` block"""
-    upd = r["prof"]
+    upd = {k: v for k, v in r["prof"].items() if not k.startswith("comm:")}
     tot_ms = sum(ms for (_, ms) in upd.values()) / max(r["prof_steps"], 1)
     timer = "events per launch (instrumented pass after the timed one)"
     if r_short(r["elapsed"], r["steps"]):
@@ -328,7 +374,8 @@ def sedov_leg(r, defaults, nx, extra=None):
                         "dominant_kernel": dom,
                         "kernels": {k: {"launches": n, "avg_ms": ms / n} for k, (n, ms) in upd.items()}},
            "roofline_fp64": fp64_roofline(r["local_cells"] / (tot_ms * 1e-3) if tot_ms else 0.0,
-                                          defaults["fast_math"], dom)}
+                                          defaults["fast_math"], dom, nx)}
+    out["roofline"]["frac_of_achievable"] = gbs / HBM_ACHIEVABLE_GBS
     if extra:
         out.update(extra)
     return out
@@ -394,7 +441,29 @@ def reference_baseline(section, key):
                       "build container, not on the GPU box"}
 
 
-def bench_advection(ctx, device, nx=2048, steps=100, warmup=10, fast_math=1, other=True):
+def reference_numpy_stages():
+    """the reference's compressible step with its njit kernels stubbed (an upper bound of its
+    rate), as timed by oracle/time_reference.py in the build container"""
+    try:
+        ref = json.load(open(os.path.join(ROOT, "profiles", "cpu_reference.json")))
+        rows = ref["compressible_numpy_stages_only"]
+    except Exception:
+        return None
+    sizes = sorted(rows, key=int)
+    return {"value_upper_bound": [rows[k]["value_upper_bound"] for k in sizes],
+            "at_nx": [int(k) for k in sizes], "seconds_per_step": [rows[k]["seconds_per_step"] for k in sizes],
+            "unit": "cell-updates/s", "cores": 1,
+            "source": f"profiles/cpu_reference.json ({ref['date']}, {ref['cpu']}, build container): "
+                      "Pyro.single_step of the reference with interface.states / riemann_hllc / "
+                      "artificial_viscosity replaced by allocate-only stubs; real reference <= these rates"}
+
+
+def bench_advection(ctx, device, nx=2048, steps=120, warmup=12, fast_math=1, other=True, multi_k=0):
+    """advection smooth nx^2 periodic through pyrohip_adv_evolve: the driver's loop body
+    (fill_BC_all + evolve) `steps` times in one call, several time steps per pass over the
+    grid (k_adv_multi; multi_k = 0: the library's choice, 2).  A step moves 16 algorithmic
+    bytes per cell (read a, write a) whatever the launch fuses: step_frac = 16 B x cells x
+    steps / wall time; the kernel entry prices one launch = K steps."""
     x = (np.arange(nx + 8) - 3.5) / nx
     X, Y = np.meshgrid(x, x, indexing="ij")
     ic = 1.0 + np.exp(-60.0 * ((X - 0.5) ** 2 + (Y - 0.5) ** 2))
@@ -402,52 +471,70 @@ def bench_advection(ctx, device, nx=2048, steps=100, warmup=10, fast_math=1, oth
     st.upload(ic)
     dt = 0.8 * min((1 / nx) / 1.0, (1 / nx) / 1.0)     # advection/simulation.py:38-54, u = v = 1, cfl 0.8
 
-    def step():      # the ghost fill is folded into the step kernel (one launch per step)
-        st.adv_step(0, 1 / nx, 1 / nx, 1.0, 1.0, dt, 2, fill=True, fast_math=fast_math)
-    for _ in range(warmup):
-        step()
+    def run(n, k=multi_k):
+        if k < 0:        # one launch per step of the single-step kernel (round 3's leg)
+            for _ in range(n):
+                st.adv_step(0, 1 / nx, 1 / nx, 1.0, 1.0, dt, 2, fill=True, fast_math=fast_math)
+        else:
+            st.adv_evolve(0, 1 / nx, 1 / nx, 1.0, 1.0, [dt] * n, 2, fast_math=fast_math, multi_k=k)
+    run(warmup)
     ctx.sync()
-    # a HIP-event pair on the library's stream brackets the timed region: `steps` launches of
-    # the one kernel a step is, back to back -- elapsed / steps is the average launch duration
-    # including the gap to the next launch.  (Events around EVERY launch, the second pass
-    # below, stretch a 21 us kernel to 25 us: rocprofv3 says 21.35, profiles/r03_adv2048_*.)
+    # a HIP-event pair on the library's stream brackets the timed region: the launches of
+    # `steps` steps back to back -- elapsed / launches is the average launch duration including
+    # the gap to the next launch.  (Events around EVERY launch, the second pass below, stretch
+    # a short kernel by ~4 us.)
     ctx.timer_start()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    run(steps)
     ev_ms = ctx.timer_stop()
     ctx.sync()
     t1 = time.perf_counter()
     ctx.prof_enable(True)
-    for _ in range(steps):
-        step()
+    run(steps)
     ctx.sync()
     prof = ctx.prof_report()
     ctx.prof_enable(False)
-    n, ms = prof["k_adv_step"]
+    kname = "k_adv_multi" if "k_adv_multi" in prof else "k_adv_step"
+    n, ms = prof[kname]
+    spl = steps / n                                     # time steps per launch
     # launches of >= 100 us: the events around every launch (their ~4 us are < 4 % there, and
-    # they leave out the write-back between two launches, as rocprofv3 does: 8192^2 254-266 us
-    # against 280 us from launch to launch); shorter ones: the pair around the timed region
+    # they leave out the write-back between two launches, as rocprofv3 does); shorter ones:
+    # the pair around the timed region
     per_launch = ms / n >= 0.1
-    kern_s = (ms / n if per_launch else ev_ms / steps) * 1e-3
-    traffic = also_traffic("adv_summary", "bytes_per_step") if nx == 2048 else None
+    kern_s = (ms / n if per_launch else ev_ms / n) * 1e-3
+    traffic = also_traffic("adv_summary", f"bytes_per_launch_{nx}")
+    # the same steps one launch each (the single-step kernel: what round 3 timed)
+    ctx.sync()
+    s0 = time.perf_counter()
+    run(steps, -1)
+    ctx.sync()
+    single_ms = (time.perf_counter() - s0) / steps * 1e3
     out_other = None
     if other:      # the other arithmetic (fast_math = 0: bit-faithful, the audit build)
-        out_other = bench_advection(ctx, device, nx, steps, warmup, 1 - fast_math, other=False)
-    return {"workload": f"advection smooth {nx}x{nx} periodic, limiter 2",
+        out_other = bench_advection(ctx, device, nx, steps, warmup, 1 - fast_math, other=False, multi_k=multi_k)
+    abytes = ADV_BYTES_PER_CELL * nx * nx
+    return {"workload": f"advection smooth {nx}x{nx} periodic, limiter 2, {steps} steps in one "
+                        f"pyrohip_adv_evolve call ({spl:g} time steps per launch)",
             "fast_math": fast_math, "other_build": out_other,
             "value": nx * nx * steps / (t1 - t0), "unit": "cell-updates/s",
-            "ms_per_step": (t1 - t0) / steps * 1e3, "steps": steps,
-            "roofline": {"bound": "hbm", "kernel": "k_adv_step",
-                         "achieved": ADV_BYTES_PER_CELL * nx * nx / kern_s / 1e9,
+            "ms_per_step": (t1 - t0) / steps * 1e3, "steps": steps, "steps_per_launch": spl,
+            "ms_per_step_one_launch_per_step": single_ms,
+            "roofline": {"bound": "hbm", "kernel": kname,
+                         "achieved": abytes * spl / kern_s / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ADV_BYTES_PER_CELL * nx * nx / kern_s / 1e9 / HBM_PEAK_GBS,
+                         "frac": abytes * spl / kern_s / 1e9 / HBM_PEAK_GBS,
+                         "frac_of_achievable": abytes * spl / kern_s / 1e9 / HBM_ACHIEVABLE_GBS,
+                         "algorithmic_bytes_per_launch": abytes * spl,
                          "kernel_avg_ms": kern_s * 1e3, "kernel_avg_ms_events_per_launch": ms / n,
-                         "kernel_avg_ms_events_over_region": ev_ms / steps,
+                         "kernel_avg_ms_events_over_region": ev_ms / n,
                          "kernel_timer": "events per launch" if per_launch else "event pair over the timed region",
-                         "traffic": traffic,
-                         "step_frac": ADV_BYTES_PER_CELL * nx * nx * steps / (t1 - t0) / 1e9 / HBM_PEAK_GBS,
-                         "launches_per_step": 1},
+                         "traffic": traffic, "traffic_source": also_traffic_source(),
+                         "step_frac": abytes * steps / (t1 - t0) / 1e9 / HBM_PEAK_GBS,
+                         "launches_per_step": 1.0 / spl,
+                         "basis": "16 B per cell and time step (read a, write a) x the time steps one launch "
+                                  "takes / the launch's duration; traffic = measured fabric bytes per launch "
+                                  "(one read and one write of the grid per launch: below the algorithmic "
+                                  "bytes from two steps per launch on)"},
             "cpu_baseline": reference_baseline("advection", str(nx)) if other else None}
 
 
@@ -542,6 +629,96 @@ def bench_incompressible(ctx, device, nx=2048, steps=5):
             "vcycles_per_step": sum(cyc) / steps}
 
 
+def bench_pyro_run(ctx, device, solver, problem, inputs, steps, warm, model=None, inputs_file=None):
+    """`steps` time steps THROUGH THE CLASS SURFACE: Pyro(solver).initialize_problem(...) and
+    Pyro.run_sim() (pyro_sim.py:197-281: verbose 0, no output, no plot -- the loop the reference's
+    driver runs), after `warm` untimed steps of the same object.  model = (bytes per cell and
+    step, text): the algorithmic bytes the step is priced with for an HBM figure."""
+    import contextlib
+    import io
+    import tempfile
+    from pyro2_amd.pyro_sim import Pyro
+    cwd = os.getcwd()
+    os.chdir(tempfile.mkdtemp())          # Pyro writes inputs.auto
+    old = device.Context._default
+    try:
+        device.Context._default = ctx
+        with contextlib.redirect_stdout(io.StringIO()):
+            p = Pyro(solver)
+            p.initialize_problem(problem, inputs_file=inputs_file,
+                                 inputs_dict=dict(inputs, **{"driver.max_steps": warm, "driver.tmax": 1.0e9}))
+            p.run_sim()
+            ctx.sync()
+            n0, p.sim.max_steps = p.sim.n, warm + steps
+            t0 = time.perf_counter()
+            p.run_sim()
+            ctx.sync()
+            t1 = time.perf_counter()
+        done = p.sim.n - n0
+        g = p.sim.cc_data.grid
+        cells = float(g.nx) * g.ny
+        extra = {}
+        if hasattr(p.sim, "mg_cycles"):
+            c = p.sim.mg_cycles
+            extra["vcycles_last_step"] = int(sum(c)) if hasattr(c, "__len__") else int(c)
+        del p
+    finally:
+        device.Context._default = old
+        os.chdir(cwd)
+    ms = (t1 - t0) / max(done, 1) * 1e3
+    out = {"workload": f"Pyro('{solver}') {problem} {g.nx}x{g.ny} through run_sim(), {done} steps "
+                       f"after {warm} untimed ones", "value": cells * done / (t1 - t0),
+           "unit": "cell-updates/s", "ms_per_step": ms, "steps": done}
+    out.update(extra)
+    if model:
+        gbs = model[0] * cells / (ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": gbs / HBM_PEAK_GBS, "bytes_per_cell_step": model[0], "basis": model[1]}
+    return out
+
+
+def bench_pyro_driver(ctx, device, bare):
+    """the two hyperbolic solvers timed through Pyro.run_sim() -- the call
+    surface north_star keeps -- next to the bare C-ABI legs of this line (`bare`: ms per step
+    of also.sedov_4096 / also.advection), and one-line legs of the SURVEY 8(f) solvers with
+    the bytes model each is priced with."""
+    out = {}
+    r = bench_pyro_run(ctx, device, "compressible", "sedov", {"mesh.nx": 4096, "mesh.ny": 4096}, 100, 10,
+                       (SEDOV_BYTES_PER_CELL, "64 B per cell update (SURVEY 8(d))"))
+    if bare.get("sedov_4096"):
+        r["bare_c_abi_ms_per_step"] = bare["sedov_4096"]
+        r["ratio_to_bare"] = bare["sedov_4096"] / r["ms_per_step"]
+    out["compressible_sedov_4096"] = r
+    r = bench_pyro_run(ctx, device, "advection", "smooth",
+                       {"mesh.nx": 2048, "mesh.ny": 2048, "particles.do_particles": 0}, 240, 24,
+                       (ADV_BYTES_PER_CELL, "16 B per cell update"))
+    r["note"] = ("inputs.smooth carries 100 tracer particles (host-side NumPy, two grid-sized velocity "
+                 "arrays per call): switched off here, the leg times the grid update")
+    if bare.get("advection"):
+        r["bare_c_abi_ms_per_step"] = bare["advection"]
+        r["ratio_to_bare"] = bare["advection"] / r["ms_per_step"]
+    out["advection_smooth_2048"] = r
+    # SURVEY 8(f) rows: parity-tested solvers that had no timing at all
+    out["diffusion_gaussian_2048"] = bench_pyro_run(
+        ctx, device, "diffusion", "gaussian", {"mesh.nx": 2048, "mesh.ny": 2048}, 10, 2,
+        (16 + 24, "read + write phi (16 B) and the Crank-Nicolson right-hand side pass (24 B) per cell and "
+                  "step; the multigrid solve on top is priced in also.multigrid (V-cycles per step "
+                  "reported beside it)"))
+    out["swe_dam_4096"] = bench_pyro_run(
+        ctx, device, "swe", "dam", {"mesh.nx": 4096, "mesh.ny": 4096}, 20, 3,
+        (48, "read 3 + write 3 conserved doubles per cell update"), inputs_file="inputs.dam.x")
+    out["compressible_rk_sedov_2048"] = bench_pyro_run(
+        ctx, device, "compressible_rk", "sedov", {"mesh.nx": 2048, "mesh.ny": 2048}, 20, 3,
+        (4 * 64, "4 stages (RK4, the solver's default) x 64 B per cell: every stage reads the state and "
+                 "writes a right-hand side"))
+    out["compressible_sedov_spherical_2048"] = bench_pyro_run(
+        ctx, device, "compressible", "sedov", {"mesh.nx": 2048, "mesh.ny": 2048}, 10, 2,
+        (SEDOV_BYTES_PER_CELL, "64 B per cell update; the staged kernel set (kernel_set 0: the only one with "
+                               "the geometry terms) moves 37 work planes per step on top of that"),
+        inputs_file="inputs.sedov.spherical")
+    return out
+
+
 def bench_small_grids(ctx, device, sizes=(64, 256, 512), steps=400):
     """the grid sizes the reference's own problems use: time per step with the steps
     enqueued on the device (pyrohip_comp_evolve: the tile kernel applies the boundary
@@ -590,14 +767,11 @@ def cpu_baseline_sedov(sample_nx, max_seconds=25.0):
     return {"value": sample_nx * sample_nx * n / el, "unit": "cell-updates/s",
             "cores": 1, "kind": "port",
             # the reference's own time next to the port.  numba is not
-            # installable here, so what can be timed of the reference itself is its
-            # NumPy stages with the njit kernels stubbed out: a LOWER bound on its step
-            # time, measured once in the survey container (1 core, 2.1 GHz Xeon), carried
-            # here as a labelled constant -- not re-measured on this host
-            "reference_numpy_stages_only": {
-                "value_upper_bound": [0.55e6, 0.36e6, 0.26e6], "at_nx": [512, 1024, 2048],
-                "unit": "cell-updates/s", "source": "SURVEY.md 6 (compressible step, NumPy-only "
-                "stages, njit kernels stubbed): real reference <= these rates"},
+            # installable here, so what can be timed of the reference itself is its step with
+            # the three njit kernels stubbed out (oracle/time_reference.py
+            # time_compressible_numpy_stages -> profiles/cpu_reference.json): the real
+            # reference is slower than that
+            "reference_numpy_stages_only": reference_numpy_stages(),
             "sample": f"oracle/pyro_oracle.c (gcc -O2, 1 thread), compressible sedov "
                       f"{sample_nx}x{sample_nx}, {n} steps from t=0, {el:.1f} s; host has "
                       f"{os.cpu_count()} cores; the reference itself is single-threaded "
@@ -677,7 +851,10 @@ def main():
     except Exception:
         pass
 
-    check = scale_check(args, dist, ctx, device, defaults) if (args.scale_check and world > 1) else None
+    # a decomposed run is checked against the single-domain one BEFORE anything is timed,
+    # unless the caller says --no-scale-check
+    do_check = world > 1 and args.scale_check is not False
+    check = scale_check(args, dist, ctx, device, defaults) if do_check else None
     r = bench_sedov(args, dist, ctx, device, defaults)
     value = r["cells"] * args.steps / r["elapsed"]
     out = {
@@ -688,10 +865,11 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"compressible sedov {args.nx}x{args.nx} (inputs.sedov physics: "
                                "HLLC, limiter 2, flattening, cvisc 0.1, cfl 0.8, outflow), "
-                               f"x-slab decomposed over {world} GPU(s), "
-                               + ("RCCL halo exchange" if dist.comm_kind == "rccl"
-                                  else f"HOST-STAGED halo exchange ({dist.comm_note or 'debug path'}): "
-                                       "NOT a scaling result"),
+                               + ("one GPU, single domain (no decomposition, no halo exchange)" if world == 1
+                                  else f"x-slab decomposed over {world} GPUs, "
+                                  + ("RCCL halo exchange" if dist.comm_kind == "rccl"
+                                     else f"HOST-STAGED halo exchange ({dist.comm_note or 'debug path'}): "
+                                          "NOT a scaling result")),
                    "parallelism": f"slab{world}",
                    "halo": dist.comm_kind if world > 1 else "none",
                    "rccl_ranks": getattr(dist, "rccl_ranks", None) if world > 1 else None,
@@ -708,11 +886,36 @@ def main():
         out["config"]["scale_check"] = check
     if dist.oversubscribed:
         out["config"]["oversubscribed"] = "several ranks share one GPU (debug run, not a result)"
+    # every rank's own figures (kernel time, what the main stream waited for), gathered: a
+    # first hardware scaling line must say WHERE the time of a step went
+    geo = device.comp_wave_geometry(r["rows_local"], args.nx, 4, ctx.info().get("compute_units", 0))
+    pr, nst = r["prof"], max(r["prof_steps"], 1)
+    per_rank = dist.gather([
+        sum(ms for k, (_, ms) in pr.items() if not k.startswith("comm:")) / nst,
+        pr.get("comm:halo_wait", (0, 0.0))[1] / nst, pr.get("comm:halo_sync", (0, 0.0))[1] / nst,
+        pr.get("comm:allreduce_dt", (0, 0.0))[1] / nst, r["event_ms"] / max(args.steps, 1),
+        float(r["rows_local"]), float(geo["col_strips"]), float(geo["rows_per_strip"]),
+        float(geo["row_strips"]), float(geo["overlap"]), float(geo["wavefronts"])])
+    if world > 1:
+        cols = ("kernel_ms", "halo_wait_ms", "halo_sync_ms", "allreduce_ms", "stream_ms_per_step",
+                "rows", "col_strips", "rows_per_strip", "row_strips", "overlap", "wavefronts")
+        table = {c: [row[i] for row in per_rank] for i, c in enumerate(cols)}
+        out["ranks"] = {
+            "per_rank": table,
+            "min": {c: min(v) for c, v in table.items()}, "max": {c: max(v) for c, v in table.items()},
+            "note": "per step, from the library's HIP events in the instrumented pass after the timed "
+                    "one: kernel_ms = this rank's kernels; halo_wait_ms = the main stream standing "
+                    "still for the posted halo exchange (0 when it finished beside the interior "
+                    "strips); halo_sync_ms = exchanges on the main stream (no overlap possible); "
+                    "allreduce_ms = the dt all-reduce; stream_ms_per_step = event pair over the timed "
+                    "region / steps; the rest = pyrohip_comp_wave_geometry of the rank's slab",
+            "predicted_ms_per_step": PREDICTED_MS_16384.get(world) if args.nx == 16384 else None,
+            "predicted_source": "DESIGN.md 6 (kernel / N x tail + ~0.1 ms all-reduce and small launches)"}
     if dist.rank == 0:
         # roofline of the update kernels: algorithmic bytes of ONE rank's slab
         # per step / HIP-event time of that rank's kernels per step
         prof = r["prof"]
-        upd = {k: v for k, v in prof.items()}
+        upd = {k: v for k, v in prof.items() if not k.startswith("comm:")}
         tot_ms = sum(ms for (_, ms) in upd.values()) / max(r["prof_steps"], 1)
         dom = max(upd, key=lambda k: upd[k][1]) if upd else None
         gbs = SEDOV_BYTES_PER_CELL * r["local_cells"] / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0
@@ -727,13 +930,19 @@ def main():
             "kernels": {k: {"launches": n, "avg_ms": ms / n} for k, (n, ms) in upd.items()},
             "stream_event_ms_per_step": r["event_ms"] / args.steps,
         }
-        out["roofline_fp64"] = fp64_roofline(cells_per_s_kernel, defaults["fast_math"], dom)
-        # traffic: from the committed rocprofv3 PMC passes of this same default command
-        # (profiles/traffic.json), scaled to this rank's cells
-        t = pmc_counts(defaults["fast_math"])
+        out["roofline"]["frac_of_achievable"] = gbs / HBM_ACHIEVABLE_GBS
+        out["roofline_fp64"] = fp64_roofline(cells_per_s_kernel, defaults["fast_math"], dom, args.nx)
+        # traffic: from the committed rocprofv3 PMC passes of this same command
+        # (profiles/traffic.json), scaled to this rank's cells -- counters of a SEPARATE
+        # session, whose commit / box / date ride along
+        t = pmc_counts(defaults["fast_math"], args.nx)
         if t and t.get("kernel") == dom:
             out["roofline"]["traffic"] = t["bytes_per_cell_update"] * r["local_cells"]
-            out["roofline"]["traffic_source"] = "profiles/traffic.json: " + t["measured_at"]
+            out["roofline"]["traffic_source"] = {
+                "file": "profiles/traffic.json", "counted_at_nx": t["counted_at_nx"],
+                "measured_at": t["measured_at"], "provenance": t.get("provenance"),
+                "note": "fabric bytes per cell update of a separate rocprofv3 --pmc session x the "
+                        "cells of this run; not counters of this run"}
         if world == 1:
             also = {}
             if not args.no_also:
@@ -769,6 +978,12 @@ def main():
                                                                fast_math=defaults["fast_math"]),
                              "multigrid": bench_mg(ctx, device),
                              "incompressible": bench_incompressible(ctx, device)})
+                bare = {"sedov_4096": also.get("sedov_4096", {}).get("ms_per_step"),
+                        "advection": also["advection"]["ms_per_step"]}
+                try:
+                    also["pyro_driver"] = bench_pyro_driver(ctx, device, bare)
+                except Exception as e:      # noqa: BLE001 -- a secondary leg must not cost the headline
+                    also["pyro_driver"] = {"error": f"{type(e).__name__}: {e}"}
                 out["also"] = also
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     dist.barrier()

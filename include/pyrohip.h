@@ -266,6 +266,13 @@ int pyrohip_comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl,
    positivity assert (simulation.py:68-71). */
 int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p,
                       double dt);
+/* the launch geometry kernel_set 2 (the row-marching kernel) takes for an nx x ny grid or
+   slab on a device of num_cus compute units (<= 0: 256), without launching anything:
+   out6 = { column strips, rows per strip, row strips, 1 if a slab's first and last strip go
+   first with the halo exchange (pyrohip_state_set_neighbours) beside the interior strips,
+   wavefronts per launch, wavefronts resident at once }.  For callers that decompose a grid
+   (decomp.py; bench.py's scaling line records it per rank).                            */
+int pyrohip_comp_wave_geometry(int nx, int ny, int ng, int num_cus, int march_rows, int *out6);
 /* the driver's time-step policy, NullSimulation.compute_timestep
    (simulation_null.py:222-244): dt = cfl * min, scaled by init_tstep_factor on
    the first step (n == 0), growth capped by max_dt_change * dt_old, fix_dt > 0

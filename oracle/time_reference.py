@@ -104,6 +104,48 @@ def time_compressible(nx, steps):
             "value": nx * nx * steps / el, "unit": "cell-updates/s", "cores": 1}
 
 
+def time_compressible_numpy_stages(nx, steps):
+    """The reference's compressible step WITHOUT its njit kernels: interface.states,
+    riemann_hllc and artificial_viscosity (pyro/compressible/interface.py:5,239,
+    riemann.py:681 -- the code numba compiles) are replaced by stubs that only allocate their
+    results, so what is timed is every NumPy stage of unsplit_fluxes.py:134-549 and
+    simulation.py:290-450 (primitive variables, flattening, limiting, the conversions, the
+    transverse corrections, sources, the update) plus the driver's ghost fill and time step.
+    The real reference also runs the three kernels: its step is LONGER than this, its rate
+    BELOW the one returned here.  The stub flux is zero, so the state stays the physical
+    initial state for every timed step."""
+    import pyro.compressible.interface as ifc
+    import pyro.compressible.riemann as riemann
+    saved = (ifc.states, ifc.artificial_viscosity, riemann.riemann_hllc)
+
+    def states(idir, ng, dx, dloga, dt, irho, iu, iv, ip, ix, nspec, gamma, qv, dqv):
+        return np.zeros_like(qv), np.zeros_like(qv)
+
+    def avisc(ng, dx, dy, Lx, Ly, xmin, ymin, coord_type, cvisc, u, v):
+        return np.zeros_like(u), np.zeros_like(u)
+
+    def hllc(idir, ng, idens, ixmom, iymom, iener, irhoX, nspec, lower_solid, upper_solid,
+             gamma, U_l, U_r):
+        return np.zeros_like(U_l)
+    ifc.states, ifc.artificial_viscosity, riemann.riemann_hllc = states, avisc, hllc
+    try:
+        p = Pyro("compressible")
+        p.initialize_problem("sedov", inputs_dict={"mesh.nx": nx, "mesh.ny": nx,
+                                                   "driver.max_steps": 10 ** 6})
+        p.single_step()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            p.single_step()
+        el = time.perf_counter() - t0
+    finally:
+        ifc.states, ifc.artificial_viscosity, riemann.riemann_hllc = saved
+    return {"workload": f"compressible sedov {nx}x{nx}: Pyro.single_step of the reference with its three "
+                        "njit kernels (interface.states, riemann_hllc, artificial_viscosity) replaced by "
+                        "allocate-only stubs -- the NumPy stages alone; the real step takes longer",
+            "nx": nx, "steps": steps, "seconds_per_step": el / steps,
+            "value_upper_bound": nx * nx * steps / el, "unit": "cell-updates/s", "cores": 1}
+
+
 def main():
     quick = "--quick" in sys.argv
     out = {"host": platform.node(), "cpu": cpu_model(), "host_cores": os.cpu_count(),
@@ -114,7 +156,8 @@ def main():
                    "in the build container (the GPU box has no /root/reference), conda python3.9, "
                    "numba.njit = identity shim (irrelevant for advection / multigrid: no njit code "
                    "on those paths)",
-           "advection": {}, "multigrid": {}, "compressible_identity_njit": {}}
+           "advection": {}, "multigrid": {}, "compressible_identity_njit": {},
+           "compressible_numpy_stages_only": {}}
     for nx, steps in ((512, 4), (2048, 3)) if not quick else ((256, 2),):
         r = time_advection(nx, steps)
         out["advection"][str(nx)] = r
@@ -127,6 +170,11 @@ def main():
         r = time_compressible(nx, steps)
         out["compressible_identity_njit"][str(nx)] = r
         print("compressible", nx, r["seconds_per_step"], "s/step", flush=True)
+    for nx, steps in ((512, 4), (1024, 3), (2048, 2)) if not quick else ((128, 2),):
+        r = time_compressible_numpy_stages(nx, steps)
+        out["compressible_numpy_stages_only"][str(nx)] = r
+        print("compressible, NumPy stages only", nx, r["seconds_per_step"], "s/step",
+              r["value_upper_bound"], "cells/s at most", flush=True)
     if not quick:
         with open(OUT, "w") as f:
             json.dump(out, f, indent=1)

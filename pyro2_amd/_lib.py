@@ -143,6 +143,7 @@ _PROTOS = {
     "pyrohip_adv_step_fill": [_VP, C.c_int, C.c_double, C.c_double, C.c_double,
                               C.c_double, C.c_double, C.c_int, C.c_int],
     "pyrohip_adv_step_p": [_VP, C.c_int, C.POINTER(AdvParams), C.c_double],
+    "pyrohip_comp_wave_geometry": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)],
     "pyrohip_adv_evolve": [_VP, C.c_int, C.POINTER(AdvParams), C.POINTER(C.c_double), C.c_int],
     "pyrohip_comp_dt": [_VP, C.POINTER(CompParams), C.c_double, _DP],
     "pyrohip_comp_evolve": [_VP, C.POINTER(CompParams), C.c_double, C.POINTER(DtPolicyC), C.c_int,

@@ -424,8 +424,9 @@ int adv_step_launch(pyrohip_state *s, int n, const pyrohip_adv_params *ap, doubl
 // lines at the kernel boundary are a third of the step (profiles/r03_copy_probe.txt,
 // DESIGN 3.2).  Here the march is time-skewed like the multigrid marching smoother
 // (mg_march.hip): stage s (level s-1 -> level s, s = 1 .. K) consumes the row stage s-1
-// produced in the same iteration, three rows behind it -- stage 1 takes row k from memory,
-// stage s row k - 3 (s - 1), and the final level's row k - 3 K is stored.  Intermediate rows
+// produced in the same iteration, t rows behind it (t = 2 for u > 0, 3 for u < 0: the rows a
+// cell's update reaches downstream of the march, AdvReach) -- stage 1 takes row k from memory,
+// stage s row k - t (s - 1), and the final level's row k - t K is stored.  Intermediate rows
 // never leave the registers; memory sees one read and one write of the grid per K steps.
 // Every stage is exactly the single step above (same expressions in the same order: the
 // bit-faithful build is bit-identical to K launches of k_adv_step with the ghost fill
@@ -437,7 +438,7 @@ int adv_step_launch(pyrohip_state *s, int n, const pyrohip_adv_params *ap, doubl
 // interior, so a strip simply works in unwrapped ("virtual") row / column numbers and wraps
 // them where it loads level 0: a virtual ghost cell of an intermediate level is computed by
 // the same operations on the same inputs as the interior cell it is the image of.  The
-// aprons grow with K: 3 K rows above and below a chunk, (3 + 2) K columns per strip.
+// aprons grow with K: (3 + 2) K rows per chunk, (3 + 2) K columns per strip.
 // The ghost frame of the new buffer holds, as after K in-place steps of the reference, the
 // fill of level K - 1: every strip stores the cells of level K - 1 it owns that lie within ng
 // of a side to their ghost images as well (the input rows of the last stage).
@@ -456,9 +457,15 @@ struct AdvMultiParams {
 // the rows one stage carries from one iteration to the next (k_adv_step's rings)
 struct AdvRings { D2 rows[6], l2x[3], Xr[3], Yr[2], Axr[2], Fxr[2]; };
 
-// One iteration of one stage: row k of its input level arrives, row k - 3 of its output level
-// leaves (returns true and sets `out`) once k >= o0 + 3; the stage's output is needed on the
-// rows [o0, o1).  U: position in the unrolled loop (ring indices).
+// Rows a cell's update reaches: three on the upwind side of u, two on the other (the x state
+// of the upwind neighbour carries a fourth-order slope) -- so a stage needs ADV_LEAD rows of its
+// input level above the first row it produces and ADV_TRAIL below the last, and produces row
+// k - ADV_TRAIL when row k of its input arrives.
+template <bool UNEG> struct AdvReach { static constexpr int lead = UNEG ? 2 : 3, trail = UNEG ? 3 : 2; };
+
+// One iteration of one stage: row k of its input level arrives, row k - trail of its output
+// level leaves (returns true and sets `out`) once that row is >= o0; the stage's output is
+// needed on the rows [o0, o1).  U: position in the unrolled loop (ring indices).
 template <int LIM, bool UNEG, bool VNEG, int U>
 __device__ __forceinline__ bool adv_stage(AdvRings &R, const D2 &in, int k, int o0, int o1, double u,
                                           double v, const AdvCoef &C, D2 &out)
@@ -472,9 +479,11 @@ __device__ __forceinline__ bool adv_stage(AdvRings &R, const D2 &in, int k, int 
                                    limit2(ADV_W(2).b, ADV_W(3).b, ADV_W(4).b)}
                               : zero;                                           // limit2_x of row k-1
     R.l2x[(U + 2) % 3] = l2n;
-    if (k < o0 + 1 || k > o1 + 2) return false;
-    const D2 Xm1 = R.Xr[(U + 1) % 3], Fxm1 = R.Fxr[U % 2];
-    // ---- row c = k-2: limited slopes, interface states (interface.py:25-41)
+    // the states of row c = k-2 are needed for c in [o0 - 1, o1 - 1] (u > 0: the face below
+    // row c takes the state of row c - 1) or [o0, o1] (u < 0)
+    const int c = k - 2;
+    if (UNEG ? (c < o0 || c > o1) : (c < o0 - 1 || c > o1 - 1)) return false;
+    // ---- row c: limited slopes, interface states (interface.py:25-41)
     const D2 ac = ADV_W(2), a_up = ADV_W(1), a_dn = ADV_W(3);
     const D2 sx{adv_slope<LIM>(l2b.a, l2c.a, l2n.a, a_up.a, ac.a, a_dn.a),
                 adv_slope<LIM>(l2b.b, l2c.b, l2n.b, a_up.b, ac.b, a_dn.b)};
@@ -484,32 +493,38 @@ __device__ __forceinline__ bool adv_stage(AdvRings &R, const D2 &in, int k, int 
     const D2 sy{adv_slope<LIM>(l2ym.a, l2y.a, l2yp.a, am.a, ac.a, ap.a),
                 adv_slope<LIM>(l2ym.b, l2y.b, l2yp.b, am.b, ac.b, ap.b)};
     const double cx = C.cx, cy = C.cy;
+    // the x state row c gives to a face: its lower face (u < 0) or its upper one, which is the
+    // lower face of row c + 1 (u > 0); y likewise
     const D2 X = UNEG ? D2{ac.a - 0.5 * (1.0 + cx) * sx.a, ac.b - 0.5 * (1.0 + cx) * sx.b}
                       : D2{ac.a + 0.5 * (1.0 - cx) * sx.a, ac.b + 0.5 * (1.0 - cx) * sx.b};
     const D2 Y = VNEG ? D2{ac.a - 0.5 * (1.0 + cy) * sy.a, ac.b - 0.5 * (1.0 + cy) * sy.b}
                       : D2{ac.a + 0.5 * (1.0 - cy) * sy.a, ac.b + 0.5 * (1.0 - cy) * sy.b};
-    // a_x on the lower x face of row c; a_y on the lower y faces of rows c, c-1 (u, v != 0
-    // here: the upwind offsets of advective_fluxes.py:71-79 are the signs)
-    const D2 ax_c = UNEG ? X : Xm1;
-    const D2 ay_c = VNEG ? Y : adv_left(Y), ay_m = R.Yr[U % 2];
-    const D2 ayt = UNEG ? ay_c : ay_m;
-    const D2 aytp = adv_right(ayt);
-    const D2 Fx{u * (ax_c.a - C.dtdy2 * (v * aytp.a - v * ayt.a)),
-                u * (ax_c.b - C.dtdy2 * (v * aytp.b - v * ayt.b))};
-    const D2 axc_s = VNEG ? ax_c : adv_left(ax_c);
-    const D2 axm_s = R.Axr[U % 2];
+    // a_y on the lower y faces of row c (u, v != 0 here: the upwind offsets of
+    // advective_fluxes.py:71-79 are the signs)
+    const D2 ay_c = VNEG ? Y : adv_left(Y);
+    // F_x on the x face X belongs to -- face c (u < 0) or c + 1 (u > 0); its transverse term
+    // takes a_y of the row upwind of the face, which is row c either way:
+    // F_x[i,j] = u*(a_x[i,j] - dtdy2*(F_yt[i+mx,j+1] - F_yt[i+mx,j]))
+    const D2 aytp = adv_right(ay_c);
+    const D2 Fx{u * (X.a - C.dtdy2 * (v * aytp.a - v * ay_c.a)),
+                u * (X.b - C.dtdy2 * (v * aytp.b - v * ay_c.b))};
+    const D2 Xs = VNEG ? X : adv_left(X);           // a_x of that face at column j + my
+    const D2 Xs_m = R.Axr[U % 2], Fx_m = R.Fxr[U % 2];   // the same of the face above it
     bool made = false;
-    if (k >= o0 + 3) {   // ---- row g = c-1: F_y and the conservative update
-        const D2 Fy{v * (ay_m.a - C.dtdx2 * (u * axc_s.a - u * axm_s.a)),
-                    v * (ay_m.b - C.dtdx2 * (u * axc_s.b - u * axm_s.b))};
+    if (UNEG ? (c >= o0 + 1) : (c >= o0)) {
+        // ---- row g = c (u > 0: its faces are those of X's of rows c - 1 and c) or c - 1 (u < 0):
+        // F_y[g,j] = v*(a_y[g,j] - dtdx2*(F_xt[g+1,j+my] - F_xt[g,j+my])) and the update
+        const D2 ay_g = UNEG ? R.Yr[U % 2] : ay_c;
+        const D2 a_g = UNEG ? a_up : ac;
+        const D2 Fy{v * (ay_g.a - C.dtdx2 * (u * Xs.a - u * Xs_m.a)),
+                    v * (ay_g.b - C.dtdx2 * (u * Xs.b - u * Xs_m.b))};
         const D2 Fyh = adv_right(Fy);
-        out = D2{a_up.a + C.dtdx * (Fxm1.a - Fx.a) + C.dtdy * (Fy.a - Fyh.a),
-                 a_up.b + C.dtdx * (Fxm1.b - Fx.b) + C.dtdy * (Fy.b - Fyh.b)};
+        out = D2{a_g.a + C.dtdx * (Fx_m.a - Fx.a) + C.dtdy * (Fy.a - Fyh.a),
+                 a_g.b + C.dtdx * (Fx_m.b - Fx.b) + C.dtdy * (Fy.b - Fyh.b)};
         made = true;
     }
-    R.Xr[(U + 2) % 3] = X;
-    R.Yr[(U + 1) % 2] = ay_c;
-    R.Axr[(U + 1) % 2] = axc_s;
+    if (UNEG) R.Yr[(U + 1) % 2] = ay_c;
+    R.Axr[(U + 1) % 2] = Xs;
     R.Fxr[(U + 1) % 2] = Fx;
 #undef ADV_W
     return made;
@@ -559,7 +574,8 @@ __global__ __launch_bounds__(64, advm_wpe(K)) void k_adv_multi(const double *__r
         jgh[q] = jout[q] && (g.jhi - j < ng);              // ... at j - ny
     }
     const bool colghost = pyro_uniform((U0 - g.jlo < ng || g.jhi - U1 < ng) ? 1 : 0) != 0;
-    const int ka = pyro_uniform(i0 - 3 * K), kb = pyro_uniform(i1 + 3 * K - 1);
+    constexpr int LEAD = AdvReach<UNEG>::lead, TRAIL = AdvReach<UNEG>::trail;
+    const int ka = pyro_uniform(i0 - LEAD * K), kb = pyro_uniform(i1 + TRAIL * K - 1);
     const double u = P.u, v = P.v;
     auto load_row = [&](int k) {
         int ks = k > kb ? kb : k;
@@ -602,7 +618,7 @@ __global__ __launch_bounds__(64, advm_wpe(K)) void k_adv_multi(const double *__r
         pre[U % ADV_PF] = load_row(k + ADV_PF);
         adv_static_for<K>([&](auto sc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value;
-            const int ks = k - 3 * s;
+            const int ks = k - TRAIL * s;
             if constexpr (s == K - 1) {
                 if (ks >= i0 && ks < i1) {                 // an owned row of level K - 1
                     const bool rlo = (ks - g.ilo < ng), rhi = (g.ihi - ks < ng);
@@ -612,14 +628,17 @@ __global__ __launch_bounds__(64, advm_wpe(K)) void k_adv_multi(const double *__r
                 }
             }
             D2 nxt = cur;
-            const bool made = adv_stage<LIM, UNEG, VNEG, U>(R[s], cur, ks, i0 - 3 * (K - 1 - s),
-                                                            i1 + 3 * (K - 1 - s), u, v, P.st[s], nxt);
+            const bool made = adv_stage<LIM, UNEG, VNEG, U>(R[s], cur, ks, i0 - LEAD * (K - 1 - s),
+                                                            i1 + TRAIL * (K - 1 - s), u, v, P.st[s], nxt);
             if constexpr (s == K - 1) {
                 if (made) {
-                    const size_t ko = (size_t)(ks - 3) * p + ja;
-#if PYRO_ADVM_NT
+                    const size_t ko = (size_t)(ks - TRAIL) * p + ja;
+#if PYRO_ADVM_NT == 1
                     if (jout[0]) __builtin_nontemporal_store(nxt.a, &aout[ko]);
                     if (jout[1]) __builtin_nontemporal_store(nxt.b, &aout[ko + 1]);
+#elif PYRO_ADVM_NT == 2     // write-through (sc1): no dirty lines left for the kernel boundary
+                    if (jout[0]) __hip_atomic_store(&aout[ko], nxt.a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (jout[1]) __hip_atomic_store(&aout[ko + 1], nxt.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
                     if (jout[0]) aout[ko] = nxt.a;
                     if (jout[1]) aout[ko + 1] = nxt.b;

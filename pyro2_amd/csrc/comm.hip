@@ -142,7 +142,10 @@ int pyrohip_halo_exchange(pyrohip_state *s, int rank_lo, int rank_hi)
         // the step that produced this state posted the exchange already (beside
         // its interior strips): the main stream only has to wait for it.
         s->halo_pending = false;
-        PYRO_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+        {   // (profiling: how long the main stream stands still for the posted exchange)
+            ProfScope ps(c, "comm:halo_wait");
+            PYRO_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+        }
         // Any write to the state since then dropped the cached CFL minimum: the rows the
         // neighbours hold are stale.  Exchanging again would need the neighbours to take
         // part, and they cannot know (this is per-rank state): refuse instead of hanging.
@@ -152,6 +155,7 @@ int pyrohip_halo_exchange(pyrohip_state *s, int rank_lo, int rank_hi)
                      "before modifying a slab between steps");
         return 0;
     }
+    ProfScope ps(c, "comm:halo_sync");       // exchange on the main stream, nothing beside it
     return post_halo(s, s->d, rank_lo, rank_hi, (ncclComm_t)c->comm, c->stream);
 }
 
@@ -314,14 +318,17 @@ int comm_post_halo(pyrohip_state *s, double *d)
 int comm_wait_halo(pyrohip_state *s)
 {
     pyrohip_ctx *c = s->ctx;
-    if (s->halo_pending && c->ev_halo)
+    if (s->halo_pending && c->ev_halo) {
+        ProfScope ps(c, "comm:halo_wait");
         PYRO_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+    }
     return 0;
 }
 
 int comm_allreduce_min_device(pyrohip_ctx *c, double *d)
 {
     if (c->comm == nullptr) return 0;
+    ProfScope ps(c, "comm:allreduce_dt");
     PYRO_CHECK_NCCL(ncclAllReduce(d, d, 1, ncclDouble, ncclMin, (ncclComm_t)c->comm, c->stream));
     return 0;
 }

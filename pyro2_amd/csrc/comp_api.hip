@@ -22,6 +22,7 @@ int comp_sponge(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_source_correct(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_rk_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_rk_rhs(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, int);
+int comp_wave_geometry(int, int, int, int, int, int *);
 }
 namespace fastm {
 int comp_rk_rhs(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, int);
@@ -450,3 +451,9 @@ int pyrohip_comp_stage_dump(pyrohip_state *s, int stage_id, double *out)
 }
 
 }  // extern "C"
+
+extern "C" int pyrohip_comp_wave_geometry(int nx, int ny, int ng, int num_cus, int march_rows, int *out6)
+{
+    PYRO_REQUIRE(out6 && nx > 0 && ny > 0 && ng >= 0, "bad argument");
+    return pyro::exact::comp_wave_geometry(nx, ny, ng, num_cus, march_rows, out6);
+}

@@ -637,6 +637,34 @@ static int wave_rows(int nx, int ncb, int slots)
 // better one (8192^2, 8.5 rounds: 2.66 ms against 2.70 with the priorities).
 static int wave_prio_duty(int nwaves, int slots) { return nwaves <= 2 * slots ? 6 : 0; }
 
+// the launch geometry of a step on an nx x ny slab: column strips, rows per strip, row strips
+// (a last strip shorter than the ghost width joins its predecessor: the boundary strips of a
+// slab must hold the ng rows the neighbour receives as its halo), and whether the first and
+// the last strip can go first with the halo exchange beside the interior ones
+struct WaveGeom { int ncb, L, nsb, overlap; };
+static WaveGeom wave_geometry(int nx, int ny, int ng, int cus, int march_rows)
+{
+    WaveGeom w;
+    w.ncb = (ny + WOUT - 1) / WOUT;
+    w.L = wave_rows(nx, w.ncb, 4 * PYRO_WAVE_MINW * cus);      // slots: wavefronts resident at once
+    if (march_rows > 0) w.L = march_rows < nx ? march_rows : nx;
+    w.nsb = (nx + w.L - 1) / w.L;
+    if (w.nsb > 1 && nx - (w.nsb - 1) * w.L < ng) w.nsb--;
+    w.overlap = (w.nsb >= 3 && w.L >= ng) ? 1 : 0;
+    return w;
+}
+#if !PYRO_FAST
+// (for callers that want to know before they launch: bench.py's scaling line, the tests of
+// the decomposed runs)  out: ncb, L, nsb, overlap, wavefronts, resident slots
+int comp_wave_geometry(int nx, int ny, int ng, int cus, int march_rows, int *out)
+{
+    const WaveGeom w = wave_geometry(nx, ny, ng, cus > 0 ? cus : 256, march_rows);
+    out[0] = w.ncb; out[1] = w.L; out[2] = w.nsb; out[3] = w.overlap;
+    out[4] = w.ncb * w.nsb; out[5] = 4 * PYRO_WAVE_MINW * (cus > 0 ? cus : 256);
+    return 0;
+}
+#endif
+
 int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
                       const StepScalars *S, const double **dmin_out)   // as comp_step_fused_ex
 {
@@ -645,14 +673,11 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
     FP P;
     double *Uin, *Uout;
     PYRO_TRY(fused_prepare(s, p, dt, P, Uin, Uout, S == nullptr));
-    P.ncb = (g.ny + WOUT - 1) / WOUT;
     const int cus = c->num_cus > 0 ? c->num_cus : 256;
-    P.L = wave_rows(g.nx, P.ncb, 4 * PYRO_WAVE_MINW * cus);      // slots: wavefronts resident at once
-    if (p->march_rows > 0) P.L = p->march_rows < g.nx ? p->march_rows : g.nx;
-    int nsb = (g.nx + P.L - 1) / P.L;
-    // a last strip shorter than the ghost width joins its predecessor: the boundary
-    // strips of a slab must hold the ng rows the neighbour receives as its halo
-    if (nsb > 1 && g.nx - (nsb - 1) * P.L < g.ng) nsb--;
+    const WaveGeom wg = wave_geometry(g.nx, g.ny, g.ng, cus, p->march_rows);
+    P.ncb = wg.ncb;
+    P.L = wg.L;
+    const int nsb = wg.nsb;
     P.nsb = nsb;
     const int nwg = P.ncb * nsb;
     // slab of a decomposed run with the halo communicator: EVERY step posts the
@@ -669,7 +694,7 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         {k_ctu_wave<2, false>, k_ctu_wave<2, true>}};
     const int solver = (p->riemann == 1 || p->riemann == 2) ? p->riemann : 0;
     const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
-    if (post && nsb >= 3 && P.L >= g.ng) {
+    if (post && wg.overlap) {
         // slab of a decomposed run: the first and the last strip of
         // rows -- the rows the neighbours need as their next halo -- go first; their
         // exchange is posted on the halo stream and runs beside the interior strips

@@ -14,6 +14,17 @@ from . import _lib
 from ._lib import BC_CODE, CompParams, check, dptr, iptr
 
 
+def comp_wave_geometry(nx, ny, ng=4, num_cus=0, march_rows=0):
+    """launch geometry of the row-marching compressible kernel on an nx x ny grid / slab
+    (pyrohip_comp_wave_geometry): dict of column strips, rows per strip, row strips, overlap
+    eligibility, wavefronts per launch, resident wavefront slots"""
+    out = (C.c_int * 6)()
+    check(_lib.lib().pyrohip_comp_wave_geometry(int(nx), int(ny), int(ng), int(num_cus),
+                                                  int(march_rows), out))
+    return dict(zip(("col_strips", "rows_per_strip", "row_strips", "overlap", "wavefronts", "slots"),
+                    (int(v) for v in out)))
+
+
 def device_count():
     n = C.c_int()
     check(_lib.lib().pyrohip_device_count(C.byref(n)))

@@ -1118,3 +1118,40 @@ def test_comp_spherical_512_vs_oracle(hip):
     scale = np.maximum(np.abs(Uo[I]).max(axis=(0, 1)), 1e-3)
     assert (np.abs(U1 - Uo)[I] / scale).max() <= TOL_EXACT
     assert np.isfinite(U1[I]).all() and U1[I][:, :, 0].min() > 0
+
+
+def test_bench_rank_geometry_16384(dev):
+    """the slabs bench.py --gpus N cuts out of its 16384^2 grid (decomp.SlabDecomp) and the
+    launch geometry the row-marching kernel takes on each of them
+    (pyrohip_comp_wave_geometry, no kernel runs): on 2 / 4 / 8 ranks every rank has the same
+    column strips, strip length and strip count, the first and the last strip can go first
+    with the halo exchange beside the interior ones (>= 3 strips of >= ng rows), no strip is
+    shorter than the ghost width, and a slab's launch still runs several rounds of resident
+    wavefronts at N = 8 (36 strips of 57 rows x 293 column strips = 5 rounds: the tail and the
+    8 apron rows per strip are what DESIGN 6's prediction prices).  Uneven slabs: the last strip still holds the
+    ng rows a neighbour receives (a shorter one joins its predecessor), whatever the rank's
+    own strip count -- the exchange protocol does not depend on it (every step posts)."""
+    from pyro2_amd.decomp import SlabDecomp
+    ng, cus = 4, 256
+    for nranks in (1, 2, 4, 8):
+        geos = []
+        for rank in range(nranks):
+            dec = SlabDecomp(16384, nranks, rank)
+            assert dec.nx_local == 16384 // nranks and dec.i0 == rank * dec.nx_local
+            geos.append(device.comp_wave_geometry(dec.nx_local, 16384, ng, cus))
+        g0 = geos[0]
+        assert all(g == g0 for g in geos)
+        assert g0["col_strips"] == 293 and g0["slots"] == 2048
+        assert g0["overlap"] == 1 and g0["row_strips"] >= 3 and g0["rows_per_strip"] >= 32
+        last = 16384 // nranks - (g0["row_strips"] - 1) * g0["rows_per_strip"]
+        assert last >= ng
+        assert g0["wavefronts"] == g0["col_strips"] * g0["row_strips"]
+        if nranks == 8:
+            assert 4 * g0["slots"] <= g0["wavefronts"] <= 6 * g0["slots"]
+    for nx, nranks in ((10000, 8), (16385, 4), (1250 * 3 + 1, 3)):
+        for rank in range(nranks):
+            dec = SlabDecomp(nx, nranks, rank)
+            g = device.comp_wave_geometry(dec.nx_local, 4096, ng, cus)
+            last = dec.nx_local - (g["row_strips"] - 1) * g["rows_per_strip"]
+            assert ng <= last <= 2 * g["rows_per_strip"]
+            assert g["overlap"] == int(g["row_strips"] >= 3 and g["rows_per_strip"] >= ng)

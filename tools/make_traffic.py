@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from two tools/pmc_step.sh summaries (TRAFFIC=1) of the default
-compressible step: usage: make_traffic.py <pmc_fm1_summary.json> <pmc_fm0_summary.json>"""
+"""traffic.json (in the current directory) from tools/pmc_step.sh summaries (TRAFFIC=1) of the
+compressible step: usage: make_traffic.py <summary.json> ...   One entry per summary, keyed
+fast_math_<fm> for the 16384^2 headline and nx<N>_fast_math_<fm> for the other sizes, each with
+the provenance (commit, box, date) of the session that counted it (PYRO_PROVENANCE = path of
+the session's provenance file, tools/profile_round.sh)."""
+import os
 import json
 import sys
 
@@ -35,9 +39,16 @@ def entry(d):
 
 
 def main():
-    out = {"fast_math_1": entry(json.load(open(sys.argv[1]))),
-           "fast_math_0": entry(json.load(open(sys.argv[2])))}
-    json.dump(out, open("profiles/traffic.json", "w"), indent=1)
+    prov = None
+    if os.environ.get("PYRO_PROVENANCE"):
+        prov = json.load(open(os.environ["PYRO_PROVENANCE"]))
+    out = {"provenance": prov}
+    for path in sys.argv[1:]:
+        d = json.load(open(path))
+        nx, fm = d["config"]["nx"], d["config"]["fast_math"]
+        key = f"fast_math_{fm}" if nx == 16384 else f"nx{nx}_fast_math_{fm}"
+        out[key] = dict(entry(d), nx=nx, provenance=prov)
+    json.dump(out, open("traffic.json", "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 

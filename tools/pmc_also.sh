@@ -33,13 +33,21 @@ for what, unit_launches in (("adv", None), ("mg", None)):
         e["write_bytes_total"] = d.get("WRITE_SIZE", 0) * 1024
         ks[k] = e
     out[what] = ks
-# advection: bytes per step (22 launches profiled: 2 warm-up + 20 timed)
-if out["adv"]:
-    k = next(iter(out["adv"]))
+import os
+if os.environ.get("PYRO_PROVENANCE"):
+    out["provenance"] = json.load(open(os.environ["PYRO_PROVENANCE"]))
+# advection (also_run.py adv = the bench leg at 2048^2): the several-steps-per-launch kernel
+# k_adv_multi takes STEPS_PER_LAUNCH time steps per launch
+spl = int(os.environ.get("ADV_STEPS_PER_LAUNCH", "2"))
+multi = [k for k in out["adv"] if "k_adv_multi" in k]
+if multi:
+    k = multi[0]
     e = out["adv"][k]
-    out["adv_summary"] = {"kernel": k, "nx": 2048, "bytes_per_step": (e["read_bytes_total"] + e["write_bytes_total"]) / e["launches"],
+    per_launch = (e["read_bytes_total"] + e["write_bytes_total"]) / e["launches"]
+    out["adv_summary"] = {"kernel": k, "nx": 2048, "steps_per_launch": spl,
+                          "bytes_per_launch_2048": per_launch, "bytes_per_step": per_launch / spl,
                           "algorithmic_bytes_per_step": 16 * 2048 * 2048,
-                          "valu_insts_per_cell_update": e.get("SQ_INSTS_VALU_total", 0) * 64 / e["launches"] / (2048 * 2048),
+                          "valu_insts_per_cell_update": e.get("SQ_INSTS_VALU_total", 0) * 64 / e["launches"] / (2048 * 2048) / spl,
                           "valu_busy_frac": e.get("SQ_ACTIVE_INST_VALU_total", 0) * 4 / 1024 / max(e.get("GRBM_GUI_ACTIVE_total", 1) / 8, 1)}
 # multigrid: all kernels of the 12 V-cycles the leg runs (2 warm-up + 10 timed)
 if out["mg"]:
