@@ -13,7 +13,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-OUT = os.path.join(ROOT, "tests", "_emu_build")
+# PYRO_EMU_NAME / PYRO_EMU_DEFS: a second emulated library built with extra -D flags (e.g. the
+# marching smoother with several strips per workgroup: PYRO_EMU_NAME=g4 PYRO_EMU_DEFS=-DMGM_G=4)
+_NAME = os.environ.get("PYRO_EMU_NAME", "")
+OUT = os.path.join(ROOT, "tests", "_emu_build" + ("_" + _NAME if _NAME else ""))
 LIB = os.path.join(OUT, "libpyrohip_emu.so")
 
 sys.path.insert(0, ROOT)
@@ -27,7 +30,8 @@ def build(force=False):
     if not force and not hb._stale(LIB, deps):
         return LIB
     flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off",
-             "-I" + HERE, "-DPYRO_EMU=1", '-DPYRO_BACKEND_NAME="host-emu"']
+             "-I" + HERE, "-DPYRO_EMU=1", '-DPYRO_BACKEND_NAME="host-emu"'] + \
+        os.environ.get("PYRO_EMU_DEFS", "").split()
     units = [u for u in hb.units() if u[1] not in ("comm",)]
 
     headers = [d for d in deps if not d.endswith(".hip")] + [os.path.abspath(__file__)]
