@@ -80,23 +80,31 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     deps = _deps()
     us = units()
-    if not force and not _stale(LIB, deps):
+    flagline = " ".join(EXTRA + FAST_EXTRA + WAVE_SCHED)
+    libstamp = LIB + ".flags"
+    if not force and not _stale(LIB, deps) and os.path.exists(libstamp) and \
+            open(libstamp).read() == flagline:
         return LIB
 
     def compile_one(u):
         src, name, extra = u
         obj = os.path.join(LIBDIR, "obj", name + os.environ.get("PYRO_OBJ_SUFFIX", "") + ".o")
         fx = FAST_EXTRA if "-DPYRO_FAST=1" in extra else []
-        # an object newer than every source is kept (not with experiment flags: those may differ)
-        own = [d for d in deps if not d.endswith(".hip")] + [os.path.join(CSRC, src)]
-        if not force and not EXTRA and not fx and not os.environ.get("PYRO_WAVE_SCHED") and \
-                not _stale(obj, own + [os.path.abspath(__file__)]):
-            return obj
         cmd = [hipcc, f"--offload-arch={ARCH}"] + COMMON + extra + EXTRA + fx + \
               ["-c", os.path.join(CSRC, src), "-o", obj]
+        # an object newer than its source and every header is kept -- if it was compiled by
+        # exactly this command line (the flags are recorded beside it: an object left behind
+        # by a build with experiment flags is never linked into a flag-free library)
+        own = [d for d in deps if not d.endswith(".hip")] + [os.path.join(CSRC, src)]
+        stamp, line = obj + ".flags", " ".join(cmd)
+        same = os.path.exists(stamp) and open(stamp).read() == line
+        if not force and same and not _stale(obj, own + [os.path.abspath(__file__)]):
+            return obj
         if verbose:
-            print(" ".join(cmd))
+            print(line)
         subprocess.check_call(cmd)
+        with open(stamp, "w") as f:
+            f.write(line)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, len(us))) as ex:
@@ -107,6 +115,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(libstamp, "w") as f:
+        f.write(flagline)
     return LIB
 
 

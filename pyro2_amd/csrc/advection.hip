@@ -762,6 +762,8 @@ int adv_multi_launch(pyrohip_state *, const pyrohip_adv_params *, const double *
 
 using namespace pyro;
 
+constexpr int AW_GHOST_COLS = 4;   // = pyro::exact::AW_GHOST
+
 static bool simple_bc(int b)
 {
     return b == PYROHIP_BC_OUTFLOW || b == PYROHIP_BC_REFLECT_EVEN || b == PYROHIP_BC_REFLECT_ODD ||
@@ -803,6 +805,10 @@ extern "C" int pyrohip_adv_step_p(pyrohip_state *s, int n, const pyrohip_adv_par
     PYRO_REQUIRE(s && ap, "NULL argument");
     PYRO_REQUIRE(n >= 0 && n < s->nvar, "variable index out of range");
     PYRO_REQUIRE(s->g.ng >= 4, "advection needs ng >= 4 (advection/simulation.py:20)");
+    // the kernel carries the ghost frame of the new buffer in windows cut for four ghost
+    // columns (adv_strip): with a wider frame the outermost columns would stay unwritten
+    PYRO_REQUIRE(!ap->fill || s->g.ng == AW_GHOST_COLS,
+                 "the step with the ghost fill folded in is built for ng = 4 (advection/simulation.py:20)");
     PYRO_REQUIRE(ap->limiter >= 0 && ap->limiter <= 2, "limiter must be 0, 1 or 2");
     PYRO_REQUIRE(ap->dx > 0.0 && ap->dy > 0.0, "bad dx / dy");
     pyrohip_ctx *c = s->ctx;
@@ -830,7 +836,7 @@ extern "C" int pyrohip_adv_evolve(pyrohip_state *s, int n, const pyrohip_adv_par
     PYRO_REQUIRE(s && ap && (dts || nsteps == 0), "NULL argument");
     PYRO_REQUIRE(nsteps >= 0, "negative step count");
     PYRO_REQUIRE(n >= 0 && n < s->nvar, "variable index out of range");
-    PYRO_REQUIRE(s->g.ng >= 4, "advection needs ng >= 4 (advection/simulation.py:20)");
+    PYRO_REQUIRE(s->g.ng == AW_GHOST_COLS, "pyrohip_adv_evolve is built for ng = 4 (advection/simulation.py:20)");
     PYRO_REQUIRE(ap->limiter >= 0 && ap->limiter <= 2, "limiter must be 0, 1 or 2");
     PYRO_REQUIRE(ap->dx > 0.0 && ap->dy > 0.0, "bad dx / dy");
     const Geom &g = s->g;

@@ -252,7 +252,12 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
                 const int nblk = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + rows_per_block - 1) / rows_per_block;
                 hipLaunchKernelGGL(k_fill_frame2, dim3(nblk), dim3(256), 0, c->stream,
                                    s->d, s->alt_base + geom_lead(g), g, (const int *)s->d_bc);
-                s->frame_prefilled = true;
+                const hipError_t e = hipGetLastError();
+                if (e != hipSuccess) {
+                    set_error(std::string("k_fill_frame2: ") + hipGetErrorString(e));
+                    rc = (int)e;
+                }
+                s->frame_prefilled = (rc == 0);
             } else
                 rc = pyrohip_fill_bc(s, -1);
         }

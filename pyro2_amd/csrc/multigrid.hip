@@ -2895,7 +2895,9 @@ int pyrohip_mg_diag_rows(pyrohip_mg *m, int row0, int row1, double *sums)
     PYRO_LAUNCH(c, "k_mg_solve_diag", (k_mg_solve_diag<true, true>), grid, block, 0,
                 (const double *)F.v, (const double *)F.f, F.r, m->old_phi, F.n, F.pitch, m->alpha,
                 m->beta, F.dx * F.dx, 1.e-16, part, row0, row1);
-    m->r_stale[Lf] = false;
+    // r holds the residual on the rows of the window only: a whole-level consumer (get r, the
+    // residual norm, the restriction) must not take the rows outside it for current
+    if (row0 == 1 && row1 == F.n) m->r_stale[Lf] = false;
     hipLaunchKernelGGL(k_sum_final2, dim3(1), dim3(256), 0, c->stream, (const double *)part, nb,
                        part + 2 * nb);
     PYRO_CHECK_HIP(hipGetLastError());

@@ -180,9 +180,32 @@ class SlabCompressible:
         # boundary strips first + halo exchange beside the interior strips (kernel_set 2)
         # (not where a wrap-around side meets an hse boundary: that path rewrites halo rows
         # from the host between the steps, _exchange_fill_wrapped_hse)
-        if getattr(comm, "overlap", False) and (decomp.lo >= 0 or decomp.hi >= 0) and \
-                not self._hse_wrap:
+        self._overlap = bool(getattr(comm, "overlap", False) and (decomp.lo >= 0 or decomp.hi >= 0) and
+                             not self._hse_wrap)
+        self._rearm = False
+        if self._overlap:
             self.state.set_neighbours(decomp.lo, decomp.hi)
+
+    def modified(self):
+        """COLLECTIVE: the slab's data is about to be / has been written between two steps
+        (upload, upload_rows, a kernel of the caller's).  A step that ran with the overlap on has
+        already sent its boundary rows to the neighbours; those rows are stale now, and a rank
+        cannot redo the exchange alone (pyrohip_halo_exchange refuses).  Every rank therefore
+        drops the posted exchange -- it is let land, then forgotten -- and the next step
+        exchanges synchronously; the overlap is switched on again after it."""
+        if self._overlap:
+            self.state.set_neighbours(-1, -1)
+            self._rearm = True
+
+    def upload(self, data):
+        """COLLECTIVE (see modified()): replace the slab's data"""
+        self.modified()
+        self.state.upload(data)
+
+    def upload_rows(self, i0, data):
+        """COLLECTIVE (see modified()): replace rows of the slab"""
+        self.modified()
+        self.state.upload_rows(i0, data)
 
     def evolve(self, policy, cfl, nsteps):
         """nsteps of step() enqueued on the device without a host round trip per step
@@ -196,6 +219,7 @@ class SlabCompressible:
                                       "(momenta halo rows of the previous step: step())")
         if isinstance(self.comm, RcclComm) and (self.dec.lo >= 0 or self.dec.hi >= 0):
             self.state.set_neighbours(self.dec.lo, self.dec.hi)
+            self._rearm = False
         return self.state.comp_evolve(self.params, cfl, policy, nsteps)
 
     def _exchange_fill_wrapped_hse(self):
@@ -234,6 +258,9 @@ class SlabCompressible:
             self._exchange_fill_wrapped_hse()
         else:
             self.comm.halo_exchange(self.state, self.dec.lo, self.dec.hi)
+            if self._rearm:       # after modified(): that was the synchronous exchange
+                self.state.set_neighbours(self.dec.lo, self.dec.hi)
+                self._rearm = False
             self.state.fill_bc()
         if hasattr(self.comm, "dt_min"):
             dt = policy(self.comm.dt_min(self.state, self.params, cfl))

@@ -310,3 +310,74 @@ def test_rccl_multigrid_row_moves_to_self(hip):
     want = a.copy()
     want[100:120] = a[3:23]
     assert np.array_equal(m.get(L, 0), want)
+
+
+@pytest.mark.gpu
+def test_rccl_slab_modified_between_steps(hip):
+    """a slab that is written between two host-driven steps while the overlapped
+    exchange of its last step is posted.  SlabCompressible.modified() / upload_rows() (collective)
+    drop the posted exchange, the next step exchanges synchronously and switches the overlap on
+    again: one rank that is its own neighbour on both sides (a periodic single-domain problem),
+    Sedov next to the x boundary, 6 steps, the boundary rows scaled from the host, 6 more steps
+    -- bit-identical to the same sequence on a periodic state without a communicator; writing
+    the state behind the library's back is refused with a message, not a hang."""
+    from pyro2_amd.decomp import DtPolicy, RcclComm, SlabCompressible, SlabDecomp
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from sedov_ic import sedov_ic
+    try:
+        hip.comm_init(1, 0, device.Context.comm_unique_id())
+    except Exception:
+        pass
+    nx, ng = 128, 4
+    ic, meta, _ = sedov_ic(nx, r_init=0.05)
+    ic = np.roll(np.nan_to_num(ic)[ng:-ng, ng:-ng], nx // 2 - 6, axis=0)
+    full = np.zeros((nx + 2 * ng, nx + 2 * ng, 4))
+    full[ng:-ng, ng:-ng] = ic
+    kw = dict(dx=1.0 / nx, dy=1.0 / nx, fast_math=0, kernel_set=2, march_rows=16)
+
+    class SelfDecomp(SlabDecomp):          # one rank, periodic in x: both neighbours are rank 0
+        def __init__(self):
+            super().__init__(nx, 1, 0, periodic=False)
+            self.lo = self.hi = 0
+            self.wrap_lo = self.wrap_hi = True
+
+    def poke(rows):
+        rows = rows.copy()
+        rows[..., 0] *= 1.25
+        rows[..., 1] *= 1.25
+        return rows
+
+    # reference: periodic boundaries, no communicator
+    P = device.make_comp_params(**kw)
+    s = device.DeviceState(hip, nx, nx, ng, [["periodic", "periodic", "outflow", "outflow"]] * 4)
+    s.upload(full)
+    pol, dref = DtPolicy(0.1), []
+    for n in range(12):
+        if n == 6:
+            s.upload_rows(ng, poke(s.download_rows(ng, 8)))
+        s.fill_bc()
+        dt = pol(s.comp_dt(P, 0.8))
+        s.comp_step(P, dt)
+        pol.advance(dt)
+        dref.append(dt)
+    ref = s.download()[ng:-ng, ng:-ng]
+
+    hip.comm_set_global_dt(False)
+    sl = SlabCompressible(hip, SelfDecomp(), nx, ["periodic", "periodic", "outflow", "outflow"], kw,
+                          RcclComm(hip, global_dt=False))
+    sl.state.upload(full)
+    pol, dts = DtPolicy(0.1), []
+    for n in range(12):
+        if n == 6:
+            assert sl.state.halo_pending()
+            sl.upload_rows(ng, poke(sl.state.download_rows(ng, 8)))
+            assert not sl.state.halo_pending()
+        dts.append(sl.step(pol, 0.8))
+        assert sl.state.halo_pending()               # the overlap is on (again)
+    assert dts == dref
+    assert np.array_equal(sl.state.download()[ng:-ng, ng:-ng], ref)
+    # the write behind the library's back: refused, with the remedy in the message
+    sl.state.upload_rows(ng, sl.state.download_rows(ng, 4))
+    with pytest.raises(Exception, match="set_neighbours"):
+        sl.step(pol, 0.8)
