@@ -180,8 +180,8 @@ typedef struct {
     int fast_math;
     int march_rows;
     int multi_k;       /* pyrohip_adv_evolve: time steps per launch on periodic grids
-                          (0: the library's choice; 1: one step per launch of the
-                          several-steps kernel; at most 3)                          */
+                          (0: the library's choice = 3; 1: one step per launch of
+                          the several-steps kernel; at most 3)                          */
     int multi_prio;    /* ... its wavefronts take turns at the priority levels (0: the
                           library's choice = yes, -1: no)                           */
 } pyrohip_adv_params;
@@ -492,6 +492,12 @@ int pyrohip_swe_dt(pyrohip_state *s, double dx, double dy, double grav,
                    double cfl, double *dt_out);
 int pyrohip_swe_step(pyrohip_state *s, double dx, double dy, double grav,
                      int limiter, int riemann, double dt);
+/* the same with the kernel set named: 0 the staged kernels (every stage dumpable through
+   pyrohip_swe_stage_dump), 1 the whole step in one launch (row-marching wavefronts, state
+   read once and written once; bit-identical to the staged set), -1 the library's choice
+   (= 1; what pyrohip_swe_step runs) */
+int pyrohip_swe_step_ks(pyrohip_state *s, double dx, double dy, double grav, int limiter,
+                        int riemann, double dt, int kernel_set);
 /* test hook: 0-3 U_xl U_xr U_yl U_yr before the transverse terms, 4 FxT 5 FyT
    (transverse fluxes), 6 Fx 7 Fy -> host (qx, qy, 4)                        */
 int pyrohip_swe_stage_dump(pyrohip_state *s, int stage, double *out);

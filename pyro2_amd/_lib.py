@@ -110,6 +110,7 @@ _PROTOS = {
     "pyrohip_state_lincomb": [_VP, _VP, _VP, _DP, C.c_int],
     "pyrohip_swe_dt": [_VP, C.c_double, C.c_double, C.c_double, C.c_double, _DP],
     "pyrohip_swe_step": [_VP, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double],
+    "pyrohip_swe_step_ks": [_VP, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int],
     "pyrohip_swe_stage_dump": [_VP, C.c_int, _DP],
     "pyrohip_bg_step": [_VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int],
     "pyrohip_inc_mac_rhs": [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,

@@ -845,7 +845,9 @@ extern "C" int pyrohip_adv_evolve(pyrohip_state *s, int n, const pyrohip_adv_par
                      "pyrohip_adv_evolve: outflow / reflect / periodic boundaries only");
     bool periodic = true;
     for (int k = 0; k < 4; k++) periodic = periodic && s->bc[n * 4 + k] == PYROHIP_BC_PERIODIC;
-    int kmax = ap->multi_k > 0 ? ap->multi_k : 2;
+    // (measured, profiles/r04_adv_multi_sweep.txt: three steps per launch 193.7 / 16.4 us per step at
+    // 8192^2 / 2048^2 against 204.6 / 17.5 with two, once the stages' reach followed the sign of u)
+    int kmax = ap->multi_k > 0 ? ap->multi_k : 3;
     if (kmax > 3) kmax = 3;
     // the unwrapped indices of a K-step launch wrap once: 3 K rows / the strip's apron columns
     // must fit the grid; u = 0 or v = 0 keep the single step (its upwind offsets are not the signs)

@@ -11,6 +11,7 @@
 // h, u, v, X.  Compiled with -ffp-contract=off and the reference's operation
 // order (4-term in-order dot products included): bit-identical to the oracle.
 #include "common.h"
+#include "hydro.h"     // pdiv / psqrt: the IEEE quotient / root without the expansion's scaling (bit-identical)
 #include "reduce.h"
 #include "stencil.h"
 
@@ -53,7 +54,7 @@ __device__ __forceinline__ V4 sw_prim_to_cons(const double q[4])
 // interface.py:557-578; x: idir == 1
 __device__ __forceinline__ V4 sw_cons_flux(const V4 &U, double g, bool x)
 {
-    const double u = U.a[1] / U.a[0], v = U.a[2] / U.a[0];
+    const double u = pdiv(U.a[1], U.a[0]), v = pdiv(U.a[2], U.a[0]);
     const double w = x ? u : v;
     V4 F;
     F.a[0] = U.a[0] * w;
@@ -72,7 +73,7 @@ __device__ __forceinline__ void sw_trace(const double q[4], const double dq[4], 
                                          double dtdx, bool x, double lo[4], double hi[4])
 {
     const int in = x ? 1 : 2, it = x ? 2 : 1;
-    const double cs = sqrt(g * q[0]);
+    const double cs = psqrt(g * q[0]);
     const double dtdx3 = 0.33333 * dtdx;   // sic, interface.py:100
     double lvec[4][4] = {}, rvec[4][4] = {}, e_val[4], betal[4], betar[4];
     e_val[0] = q[in] - cs; e_val[1] = q[in]; e_val[2] = q[in] + cs; e_val[3] = q[in];
@@ -85,8 +86,8 @@ __device__ __forceinline__ void sw_trace(const double q[4], const double dq[4], 
     lvec[3][3] = 1.0; rvec[3][3] = 1.0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        lvec[0][k] = lvec[0][k] * 0.50 / (cs * q[0]);
-        lvec[2][k] = -lvec[2][k] * 0.50 / (cs * q[0]);
+        lvec[0][k] = pdiv(lvec[0][k] * 0.50, cs * q[0]);
+        lvec[2][k] = pdiv(-lvec[2][k] * 0.50, cs * q[0]);
     }
     double factor = 0.5 * (1.0 - dtdx * fmax(e_val[2], 0.0));
 #pragma unroll
@@ -120,23 +121,23 @@ __device__ __forceinline__ V4 sw_roe(const V4 &Ul, const V4 &Ur, double g, bool 
 {
     const double smallc = 1.e-10, tol = 0.1e-1;
     const int im = x ? 1 : 2, it = x ? 2 : 1;
-    const double h_l = Ul.a[0], un_l = Ul.a[im] / h_l;
-    const double h_r = Ur.a[0], un_r = Ur.a[im] / h_r;
-    const double c_l = fmax(smallc, sqrt(g * h_l)), c_r = fmax(smallc, sqrt(g * h_r));
+    const double h_l = Ul.a[0], un_l = pdiv(Ul.a[im], h_l);
+    const double h_r = Ur.a[0], un_r = pdiv(Ur.a[im], h_r);
+    const double c_l = fmax(smallc, psqrt(g * h_l)), c_r = fmax(smallc, psqrt(g * h_r));
     double U_roe[4], delta[4], lambda[4], alpha[4], K[4][4] = {};
 #pragma unroll
     for (int n = 0; n < 4; n++) {
-        U_roe[n] = (Ul.a[n] / sqrt(h_l) + Ur.a[n] / sqrt(h_r)) / (sqrt(h_l) + sqrt(h_r));
-        delta[n] = Ur.a[n] / h_r - Ul.a[n] / h_l;
+        U_roe[n] = pdiv(pdiv(Ul.a[n], psqrt(h_l)) + pdiv(Ur.a[n], psqrt(h_r)), psqrt(h_l) + psqrt(h_r));
+        delta[n] = pdiv(Ur.a[n], h_r) - pdiv(Ul.a[n], h_l);
     }
-    U_roe[0] = sqrt(h_l * h_r);
-    const double c_roe = sqrt(0.5 * (c_l * c_l + c_r * c_r));
+    U_roe[0] = psqrt(h_l * h_r);
+    const double c_roe = psqrt(0.5 * (c_l * c_l + c_r * c_r));
     delta[0] = h_r - h_l;
     const double un_roe = U_roe[im];
     lambda[0] = un_roe - c_roe; lambda[1] = un_roe; lambda[2] = un_roe + c_roe; lambda[3] = un_roe;
-    alpha[0] = 0.5 * (delta[0] - U_roe[0] / c_roe * delta[im]);
+    alpha[0] = 0.5 * (delta[0] - pdiv(U_roe[0], c_roe) * delta[im]);
     alpha[1] = U_roe[0] * delta[it];
-    alpha[2] = 0.5 * (delta[0] + U_roe[0] / c_roe * delta[im]);
+    alpha[2] = 0.5 * (delta[0] + pdiv(U_roe[0], c_roe) * delta[im]);
     alpha[3] = U_roe[0] * delta[3];
     K[0][0] = 1.0; K[0][im] = un_roe - c_roe; K[0][it] = U_roe[it];
     K[1][it] = 1.0;
@@ -147,13 +148,13 @@ __device__ __forceinline__ V4 sw_roe(const V4 &Ul, const V4 &Ur, double g, bool 
 #pragma unroll
     for (int n = 0; n < 4; n++) F.a[n] = 0.5 * (Fl.a[n] + Fr.a[n]);
     const double hs = 0.5 * (c_l + c_r) + 0.25 * (un_l - un_r);
-    const double h_star = 1.0 / g * (hs * hs);
+    const double h_star = pdiv(1.0, g) * (hs * hs);
     const double u_star = 0.5 * (un_l + un_r) + c_l - c_r;
-    const double c_star = sqrt(g * h_star);
+    const double c_star = psqrt(g * h_star);
     if (fabs(lambda[0]) < tol)
-        lambda[0] = lambda[0] * (u_star - c_star - lambda[0]) / (u_star - c_star - (un_l - c_l));
+        lambda[0] = pdiv(lambda[0] * (u_star - c_star - lambda[0]), u_star - c_star - (un_l - c_l));
     if (fabs(lambda[2]) < tol)
-        lambda[2] = lambda[2] * (u_star + c_star - lambda[2]) / (u_star + c_star - (un_r + c_r));
+        lambda[2] = pdiv(lambda[2] * (u_star + c_star - lambda[2]), u_star + c_star - (un_r + c_r));
 #pragma unroll
     for (int n = 0; n < 4; n++)
 #pragma unroll
@@ -166,32 +167,32 @@ __device__ __forceinline__ V4 sw_hllc(const V4 &Ul, const V4 &Ur, double g, bool
 {
     const double smallc = 1.e-10;
     const int im = x ? 1 : 2, it = x ? 2 : 1;
-    const double h_l = Ul.a[0], un_l = Ul.a[im] / h_l, ut_l = Ul.a[it] / h_l;
-    const double h_r = Ur.a[0], un_r = Ur.a[im] / h_r, ut_r = Ur.a[it] / h_r;
-    const double c_l = fmax(smallc, sqrt(g * h_l)), c_r = fmax(smallc, sqrt(g * h_r));
+    const double h_l = Ul.a[0], un_l = pdiv(Ul.a[im], h_l), ut_l = pdiv(Ul.a[it], h_l);
+    const double h_r = Ur.a[0], un_r = pdiv(Ur.a[im], h_r), ut_r = pdiv(Ur.a[it], h_r);
+    const double c_l = fmax(smallc, psqrt(g * h_l)), c_r = fmax(smallc, psqrt(g * h_r));
     const double h_avg = 0.5 * (h_l + h_r), c_avg = 0.5 * (c_l + c_r);
-    const double hstar = h_avg - 0.25 * (un_r - un_l) * h_avg / c_avg;
+    const double hstar = h_avg - pdiv(0.25 * (un_r - un_l) * h_avg, c_avg);
     const double S_l = (hstar <= h_l) ? un_l - c_l
-                                      : un_l - c_l * sqrt(0.5 * (hstar + h_l) * hstar) / h_l;
+                                      : un_l - pdiv(c_l * psqrt(0.5 * (hstar + h_l) * hstar), h_l);
     const double S_r = (hstar <= h_r) ? un_r + c_r
-                                      : un_r + c_r * sqrt(0.5 * (hstar + h_r) * hstar) / h_r;
-    const double S_c = (S_l * h_r * (un_r - S_r) - S_r * h_l * (un_l - S_l)) /
-                       (h_r * (un_r - S_r) - h_l * (un_l - S_l));
+                                      : un_r + pdiv(c_r * psqrt(0.5 * (hstar + h_r) * hstar), h_r);
+    const double S_c = pdiv(S_l * h_r * (un_r - S_r) - S_r * h_l * (un_l - S_l),
+                            h_r * (un_r - S_r) - h_l * (un_l - S_l));
     V4 Us, F;
     if (S_r <= 0.0) return sw_cons_flux(Ur, g, x);
     if (S_c <= 0.0 && 0.0 < S_r) {
-        const double fac = h_r * (S_r - un_r) / (S_r - S_c);
+        const double fac = pdiv(h_r * (S_r - un_r), S_r - S_c);
         Us.a[0] = fac; Us.a[im] = fac * S_c; Us.a[it] = fac * ut_r;
-        Us.a[3] = fac * Ur.a[3] / h_r;
+        Us.a[3] = pdiv(fac * Ur.a[3], h_r);
         F = sw_cons_flux(Ur, g, x);
 #pragma unroll
         for (int n = 0; n < 4; n++) F.a[n] = F.a[n] + S_r * (Us.a[n] - Ur.a[n]);
         return F;
     }
     if (S_l < 0.0 && 0.0 < S_c) {
-        const double fac = h_l * (S_l - un_l) / (S_l - S_c);
+        const double fac = pdiv(h_l * (S_l - un_l), S_l - S_c);
         Us.a[0] = fac; Us.a[im] = fac * S_c; Us.a[it] = fac * ut_l;
-        Us.a[3] = fac * Ul.a[3] / h_l;
+        Us.a[3] = pdiv(fac * Ul.a[3], h_l);
         F = sw_cons_flux(Ul, g, x);
 #pragma unroll
         for (int n = 0; n < 4; n++) F.a[n] = F.a[n] + S_l * (Us.a[n] - Ul.a[n]);
@@ -215,9 +216,9 @@ __global__ __launch_bounds__(256) void k_sw_prim(const double *__restrict__ U,
     const V4 Uc = ld4(U, pl, k);
     double *Q = W + (size_t)SW_Q * pl;
     Q[k] = Uc.a[0];
-    Q[pl + k] = Uc.a[1] / Uc.a[0];
-    Q[2 * pl + k] = Uc.a[2] / Uc.a[0];
-    Q[3 * pl + k] = Uc.a[3] / Uc.a[0];
+    Q[pl + k] = pdiv(Uc.a[1], Uc.a[0]);
+    Q[2 * pl + k] = pdiv(Uc.a[2], Uc.a[0]);
+    Q[3 * pl + k] = pdiv(Uc.a[3], Uc.a[0]);
 }
 
 // ---- stage 1: limited slopes + tracing for the cells of R(1) --------------
@@ -327,12 +328,208 @@ __global__ __launch_bounds__(256) void k_sw_cfl(const double *__restrict__ U, Ge
     for (int i = blockIdx.y; i < g.qx; i += gridDim.y)
         for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < g.qy; j += gridDim.x * blockDim.x) {
             const size_t k = (size_t)i * g.pitch + j;
-            const double h = U[k], u = U[g.plane + k] / h, v = U[2 * g.plane + k] / h;
-            const double cs = sqrt(grav * h);
-            m = fmin(m, fmin(dx / (fabs(u) + cs), dy / (fabs(v) + cs)));
+            const double h = U[k], u = pdiv(U[g.plane + k], h), v = pdiv(U[2 * g.plane + k], h);
+            const double cs = psqrt(grav * h);
+            m = fmin(m, fmin(pdiv(dx, fabs(u) + cs), pdiv(dy, fabs(v) + cs)));
         }
     m = block_reduce_min(m);
     if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = m;
+}
+
+// ---- the whole step in ONE launch: row-marching wavefronts (like comp_wave.hip) ------------
+// One wavefront = 64 columns (lane = column, 58 updated: a cell's update reaches three columns
+// either way), marching down a chunk of rows.  Row k arrives (load, primitives); the rows'
+// primitive window (k-4 .. k), the conserved rows still to be updated, and what row c - 1 hands
+// to row c = k - 2 (its x / y face states, F_xT, F_yT, F_x) live in registers; the y direction
+// comes from the neighbouring lanes by whole-wave DPP rotations.  Per iteration: slopes, tracing
+// and the two transverse Riemann problems of row c, the final x flux on its lower face, the
+// final y flux and the conservative update of row c - 1 -- the same device functions, on the
+// same operands, in the same order as the staged kernels above (which stay: every stage
+// dumpable for the parity tests): bit-identical.  No LDS, no barrier; HBM sees the state once
+// in (x 64/58 and the chunks' apron rows) and once out instead of the staged set's ~100
+// doubles per cell.  The new time level goes to the state's second buffer (neighbouring
+// chunks still read the old one); the ghost frame is carried over.
+constexpr int SWW_OUT = 58, SWW_REACH = 3;
+// stage boundary: the scheduler may not move instructions across it (left alone it
+// interleaves the four Riemann problems of an iteration for ILP and spills: comp_wave.hip)
+#if defined(PYRO_EMU)
+#define SWW_FENCE() do {} while (0)
+#else
+#define SWW_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+struct SWW {
+    double dx, dy, dt, g;
+    int limiter;
+    int ncb, L, nunits;
+};
+
+#if !defined(PYRO_EMU)
+template <int CTRL> __device__ __forceinline__ double sww_dpp(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sww_m1(double v) { return sww_dpp<0x13C>(v); }   // wave_ror:1
+__device__ __forceinline__ double sww_p1(double v) { return sww_dpp<0x134>(v); }   // wave_rol:1
+#else
+__device__ __forceinline__ double sww_m1(double v) { return __shfl_up(v, 1, 64); }
+__device__ __forceinline__ double sww_p1(double v) { return __shfl_down(v, 1, 64); }
+#endif
+__device__ __forceinline__ V4 sww_m1(const V4 &v) { return V4{{sww_m1(v.a[0]), sww_m1(v.a[1]), sww_m1(v.a[2]), sww_m1(v.a[3])}}; }
+__device__ __forceinline__ V4 sww_p1(const V4 &v) { return V4{{sww_p1(v.a[0]), sww_p1(v.a[1]), sww_p1(v.a[2]), sww_p1(v.a[3])}}; }
+
+template <int RS>
+__device__ __forceinline__ V4 sww_riemann(const V4 &Ul, const V4 &Ur, double g, bool x)
+{
+    return RS == 1 ? sw_hllc(Ul, Ur, g, x) : sw_roe(Ul, Ur, g, x);
+}
+
+template <int RS>   // swe.riemann: 0 Roe, 1 HLLC
+__global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Uin,
+                                                   double *__restrict__ Uout, Geom g, SWW P)
+{
+    const int l = threadIdx.x & 63;
+    const int per = (P.nunits + 7) / 8;                     // XCD x: the units [x per, (x + 1) per)
+    const int unit = pyro_uniform(((int)blockIdx.x % 8) * per + (int)blockIdx.x / 8);
+    if (unit >= P.nunits) return;
+    const int cb = pyro_uniform(unit % P.ncb), sb = pyro_uniform(unit / P.ncb);
+    const int i0 = g.ilo + sb * P.L;                        // rows [i0, i1)
+    const int i1 = (i0 + P.L < g.ihi + 1) ? i0 + P.L : g.ihi + 1;
+    const int j = g.jlo - SWW_REACH + cb * SWW_OUT + l;
+    const int jc = j < 0 ? 0 : (j < g.qy ? j : g.qy - 1);
+    const bool jout = l >= SWW_REACH && l < SWW_REACH + SWW_OUT && j >= g.jlo && j <= g.jhi;
+    const int p = g.pitch;
+    const size_t pl = g.plane;
+    const double dtdx = P.dt / P.dx, dtdy = P.dt / P.dy;                  // k_sw_update
+    const double hdtdx = 0.5 * (P.dt / P.dx), hdtdy = 0.5 * (P.dt / P.dy);   // k_sw_final
+    auto loadU = [&](int row) {
+        row = row < 0 ? 0 : (row > g.qx - 1 ? g.qx - 1 : row);
+        return ld4(Uin, pl, (size_t)row * p + jc);
+    };
+    const V4 zero{{1.0, 0.0, 0.0, 0.0}};      // (h = 1: the warm-up rows divide by it)
+    // rows k-4 .. k of the primitives in registers.  (The conserved row k-3, which is updated
+    // when row k arrives, is read a second time one iteration ahead -- an L1 / L2 hit.)  What
+    // row c-1 = k-3 left for row c -- its upper x state, its y states, F_xT, F_yT and F_x on
+    // its lower faces: six 4-vectors -- sits in a per-lane LDS stash (own-lane slots, no
+    // barrier: the LDS operations of a wavefront complete in order) and is read where it is
+    // used: with them in registers the Roe instance spilled 164 B per lane.
+    __shared__ double stash[6 * 4][64];
+    enum { S_XP = 0, S_YP = 4, S_YM = 8, S_FXT = 12, S_FYT = 16, S_FX = 20 };
+    auto put = [&](int slot, const V4 &v) {
+#pragma unroll
+        for (int n = 0; n < 4; n++) stash[slot + n][l] = v.a[n];
+    };
+    auto get = [&](int slot) { return V4{{stash[slot][l], stash[slot + 1][l], stash[slot + 2][l], stash[slot + 3][l]}}; };
+    put(S_XP, zero); put(S_YP, zero); put(S_YM, zero); put(S_FXT, zero); put(S_FYT, zero); put(S_FX, zero);
+    double q[5][4];
+#pragma unroll
+    for (int r = 0; r < 5; r++) { q[r][0] = 1.0; q[r][1] = q[r][2] = q[r][3] = 0.0; }
+    V4 Upre = loadU(i0 - 3), Urep = loadU(i0 - 6);
+    for (int k = i0 - 3; k <= i1 + 2; k++) {
+        // ---- row k arrives: primitives (k_sw_prim)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+#pragma unroll
+            for (int n = 0; n < 4; n++) q[r][n] = q[r + 1][n];
+        }
+        const V4 Uk = Upre, Uold = Urep;     // rows k and k-3
+        Upre = loadU(k + 1);
+        Urep = loadU(k - 2);
+        q[4][0] = Uk.a[0];
+        q[4][1] = pdiv(Uk.a[1], Uk.a[0]);
+        q[4][2] = pdiv(Uk.a[2], Uk.a[0]);
+        q[4][3] = pdiv(Uk.a[3], Uk.a[0]);
+        const int c = k - 2;                 // window row 2
+        if (c < i0 - 1) continue;
+        // ---- row c: limited slopes, tracing (k_sw_states)
+        double qc[4], dqx[4], dqy[4];
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            qc[n] = q[2][n];
+            const double m1 = sww_m1(qc[n]), p1 = sww_p1(qc[n]);
+            dqx[n] = 1.0 * limited_slope(q[0][n], q[1][n], q[2][n], q[3][n], q[4][n], P.limiter);
+            dqy[n] = 1.0 * limited_slope(sww_m1(m1), m1, qc[n], p1, sww_p1(p1), P.limiter);
+        }
+        double lo[4], hi[4];
+        sw_trace(qc, dqx, P.g, P.dt / P.dx, true, lo, hi);
+        const V4 XM = sw_prim_to_cons(lo), XP = sw_prim_to_cons(hi);
+        sw_trace(qc, dqy, P.g, P.dt / P.dy, false, lo, hi);
+        const V4 YM = sw_prim_to_cons(lo), YP = sw_prim_to_cons(hi);
+        SWW_FENCE();
+        // ---- transverse Riemann problems on the lower faces of row c (k_sw_riemann_t)
+        const V4 XPm = get(S_XP);
+        const V4 FXT = sww_riemann<RS>(XPm, XM, P.g, true);
+        SWW_FENCE();
+        const V4 FYT = sww_riemann<RS>(sww_m1(YP), YM, P.g, false);
+        const V4 FYT_p = sww_p1(FYT);
+        SWW_FENCE();
+        if (c >= i0) {
+            // ---- final x flux on the lower face of row c (k_sw_final)
+            const V4 FYTm = get(S_FYT);
+            const V4 Uxl = sw_corrected(XPm, sww_p1(FYTm), FYTm, hdtdy);
+            const V4 Uxr = sw_corrected(XM, FYT_p, FYT, hdtdy);
+            const V4 Fx = sww_riemann<RS>(Uxl, Uxr, P.g, true);
+            SWW_FENCE();
+            if (c >= i0 + 1) {
+                // ---- row r = c-1: final y flux, conservative update (k_sw_final, k_sw_update)
+                const V4 FXTm = get(S_FXT);
+                const V4 Uyl = sww_m1(sw_corrected(get(S_YP), FXT, FXTm, hdtdx));
+                const V4 Uyr = sw_corrected(get(S_YM), FXT, FXTm, hdtdx);
+                const V4 Fy = sww_riemann<RS>(Uyl, Uyr, P.g, false);
+                const V4 Fy_p = sww_p1(Fy);
+                const V4 Fxm = get(S_FX);
+                if (jout) {
+                    const size_t ko = (size_t)(c - 1) * p + j;
+#pragma unroll
+                    for (int n = 0; n < 4; n++)
+                        Uout[(size_t)n * pl + ko] =
+                            Uold.a[n] + (dtdx * (Fxm.a[n] - Fx.a[n]) + dtdy * (Fy.a[n] - Fy_p.a[n]));
+                }
+            }
+            put(S_FX, Fx);
+        }
+        put(S_XP, XP); put(S_YP, YP); put(S_YM, YM); put(S_FXT, FXT); put(S_FYT, FYT);
+    }
+}
+
+// rows per chunk of the fused step: the shortest with which all wavefronts are resident at once
+// (two per SIMD), several rounds of ~96 rows beyond that
+static int sww_rows(int nx, int ncb, int cus)
+{
+    const long slots = 8L * cus;
+    if (nx <= 16) return nx;
+    for (int L = 16; L <= 96 && L < nx; L++)
+        if ((long)ncb * ((nx + L - 1) / L) <= slots) return L;
+    return nx < 96 ? nx : 96;
+}
+
+// ghost frame of the four planes from one buffer to the other (1-d grid: 2 ng blocks of
+// columns for the ghost rows, then row blocks for the ghost columns)
+__global__ __launch_bounds__(256) void k_sw_copy_frame(const double *__restrict__ src,
+                                                        double *__restrict__ dst, Geom g)
+{
+    const int ng = g.ng, ncolb = (g.qy + 255) / 256, nrowb = 2 * ng * ncolb;
+    const int b = blockIdx.x;
+    int i, j;
+    if (b < nrowb) {
+        const int gr = b / ncolb;                       // ghost row index 0 .. 2 ng - 1
+        i = gr < ng ? gr : g.ihi + 1 + (gr - ng);
+        j = (b % ncolb) * 256 + (int)threadIdx.x;
+        if (j >= g.qy) return;
+    } else {
+        const int rpb = 256 / (2 * ng);                 // interior rows per block
+        const int t = (int)threadIdx.x;
+        if (t >= rpb * 2 * ng) return;
+        i = g.ilo + (b - nrowb) * rpb + t / (2 * ng);
+        if (i > g.ihi) return;
+        const int gc = t % (2 * ng);
+        j = gc < ng ? gc : g.jhi + 1 + (gc - ng);
+    }
+    const size_t k = (size_t)i * g.pitch + j;
+#pragma unroll
+    for (int n = 0; n < 4; n++) dst[(size_t)n * g.plane + k] = src[(size_t)n * g.plane + k];
 }
 
 static int sw_work(pyrohip_state *s)
@@ -384,14 +581,45 @@ int pyrohip_swe_dt(pyrohip_state *s, double dx, double dy, double grav, double c
     return 0;
 }
 
-int pyrohip_swe_step(pyrohip_state *s, double dx, double dy, double grav, int limiter, int riemann,
-                     double dt)
+// kernel_set: 0 the staged kernels (every stage dumpable: pyrohip_swe_stage_dump), 1 the whole
+// step in one launch (k_sw_wave), -1 the library's choice (1)
+int pyrohip_swe_step_ks(pyrohip_state *s, double dx, double dy, double grav, int limiter, int riemann,
+                        double dt, int kernel_set)
 {
     PYRO_TRY(sw_check(s, dx, dy, grav, limiter, riemann));
     PYRO_REQUIRE(dt > 0.0, "dt must be positive");
-    PYRO_TRY(sw_work(s));
+    PYRO_REQUIRE(kernel_set >= -1 && kernel_set <= 1, "kernel_set must be -1, 0 or 1");
     pyrohip_ctx *c = s->ctx;
     const Geom &g = s->g;
+    if (kernel_set != 0) {
+        if (!s->alt_base) {
+            const size_t n = (size_t)s->nvar * g.plane + 16;
+            PYRO_CHECK_HIP(hipMalloc((void **)&s->alt_base, n * sizeof(double)));
+            PYRO_CHECK_HIP(hipMemsetAsync(s->alt_base, 0, n * sizeof(double), c->stream));
+        }
+        SWW P{dx, dy, dt, grav, limiter, 0, 0, 0};
+        P.ncb = (g.ny + SWW_OUT - 1) / SWW_OUT;
+        P.L = sww_rows(g.nx, P.ncb, c->num_cus > 0 ? c->num_cus : 256);
+        P.nunits = P.ncb * ((g.nx + P.L - 1) / P.L);
+        double *Uout = s->alt_base + geom_lead(g);
+        const dim3 grid(8 * ((P.nunits + 7) / 8)), block(64);
+        if (riemann == 1)
+            PYRO_LAUNCH(c, "k_sw_wave", k_sw_wave<1>, grid, block, 0, (const double *)s->d, Uout, g, P);
+        else
+            PYRO_LAUNCH(c, "k_sw_wave", k_sw_wave<0>, grid, block, 0, (const double *)s->d, Uout, g, P);
+        // the ghost frame is carried over (the reference updates the interior in place), then
+        // the buffers change places
+        const int fb = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + 256 / (2 * g.ng) - 1) / (256 / (2 * g.ng));
+        hipLaunchKernelGGL(k_sw_copy_frame, dim3(fb), dim3(256), 0, c->stream, (const double *)s->d, Uout, g);
+        PYRO_CHECK_HIP(hipGetLastError());
+        double *old_base = s->base;
+        s->base = s->alt_base;
+        s->alt_base = old_base;
+        s->d = s->base + geom_lead(g);
+        s->next_cfl_min = -1.0;
+        return 0;
+    }
+    PYRO_TRY(sw_work(s));
     const SW P{dx, dy, dt, grav, limiter, riemann};
     double *W = s->work + geom_lead(g);
     const dim3 block(256);
@@ -405,6 +633,12 @@ int pyrohip_swe_step(pyrohip_state *s, double dx, double dy, double grav, int li
     PYRO_CHECK_HIP(hipGetLastError());
     s->next_cfl_min = -1.0;
     return 0;
+}
+
+int pyrohip_swe_step(pyrohip_state *s, double dx, double dy, double grav, int limiter, int riemann,
+                     double dt)
+{
+    return pyrohip_swe_step_ks(s, dx, dy, grav, limiter, riemann, dt, -1);
 }
 
 // stage: 0 Uxl0 1 Uxr0 2 Uyl0 3 Uyr0 (face states before the transverse

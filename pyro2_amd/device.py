@@ -250,11 +250,12 @@ class DeviceState:
                                          C.byref(out)))
         return out.value
 
-    def swe_step(self, dx, dy, grav, limiter, riemann, dt):
+    def swe_step(self, dx, dy, grav, limiter, riemann, dt, kernel_set=-1):
+        """kernel_set: 0 staged kernels (swe_stage() dumps), 1 one launch per step (default)"""
         r = self.SWE_RIEMANN[riemann] if isinstance(riemann, str) else int(riemann)
         with self.ctx.lock:
-            check(self._l.pyrohip_swe_step(self.h, float(dx), float(dy), float(grav), int(limiter),
-                                           r, float(dt)))
+            check(self._l.pyrohip_swe_step_ks(self.h, float(dx), float(dy), float(grav), int(limiter),
+                                              r, float(dt), int(kernel_set)))
 
     def swe_stage(self, name):
         names = ("Uxl0", "Uxr0", "Uyl0", "Uyr0", "FxT", "FyT", "Fx", "Fy")

@@ -37,7 +37,12 @@ def test_swe_vs_reference(dev, golden, k):
     dt = float(g[pre + "dt"])
     Uo = g[pre + "U0"].copy()
     so = orc.swe_step(Uo, P, dt, stages=True)
-    s.swe_step(P.dx, P.dy, P.g, P.limiter, riemann, dt)
+    s.swe_step(P.dx, P.dy, P.g, P.limiter, riemann, dt, kernel_set=0)     # staged: every stage dumpable
+    # the same step in one launch (k_sw_wave): bit-identical incl. the untouched ghost cells
+    f = swe_state(dev, P, bcs)
+    f.upload(g[pre + "U0"])
+    f.swe_step(P.dx, P.dy, P.g, P.limiter, riemann, dt, kernel_set=1)
+    assert np.array_equal(f.download(), s.download())
     xf = (slice(ng, ng + nx + 1), slice(ng, ng + ny))       # faces the update uses
     yf = (slice(ng, ng + nx), slice(ng, ng + ny + 1))
     xt = (slice(ng, ng + nx + 1), slice(ng - 1, ng + ny + 1))   # transverse faces
@@ -116,3 +121,34 @@ def test_swe_reference_regression_dam(hip, golden, tmp_path, monkeypatch):
     assert p.sim.n == 81
     U = np.asarray(p.sim.cc_data.data)[4:-4, 4:-4]
     assert np.abs(U - g["gold"]).max() < 1e-11
+
+
+@pytest.mark.parametrize("riemann", ["Roe", "HLLC"])
+@pytest.mark.parametrize("nx,ny,lim", [(40, 130, 2), (57, 59, 1), (16, 200, 2), (35, 58, 0)])
+def test_swe_one_launch_per_step_equals_staged(dev, nx, ny, lim, riemann):
+    """k_sw_wave (csrc/swe.hip: the whole step in one launch, row-marching wavefronts of 64
+    columns / 58 updated, chunks of >= 16 rows) against the staged kernels on random smooth
+    states: several column strips (ragged last one), several row chunks, both Riemann solvers,
+    three steps with the ghost fill in between -- the whole array, bit for bit"""
+    ng = 4
+    rng = np.random.default_rng(nx * ny)
+    x = np.arange(nx + 2 * ng)[:, None] / nx
+    y = np.arange(ny + 2 * ng)[None, :] / ny
+    U0 = np.zeros((nx + 2 * ng, ny + 2 * ng, 4))
+    U0[..., 0] = 1.0 + 0.3 * np.sin(6 * x) * np.cos(4 * y) + 0.05 * rng.random(U0.shape[:2])
+    U0[..., 1] = U0[..., 0] * (0.4 * np.cos(3 * x + y))
+    U0[..., 2] = U0[..., 0] * (-0.5 * np.sin(5 * y - x))
+    U0[..., 3] = U0[..., 0] * (0.5 + 0.5 * np.sin(9 * x * y))
+    bcs = [["periodic", "periodic", "outflow", "outflow"]] * 4
+    dx, dy, grav = 1.0 / nx, 1.0 / ny, 1.0
+    out = {}
+    for ks in (0, 1):
+        s = device.DeviceState(dev, nx, ny, ng, bcs)
+        s.upload(U0)
+        for _ in range(3):
+            s.fill_bc()
+            dt = s.swe_dt(dx, dy, grav, 0.8)
+            s.swe_step(dx, dy, grav, lim, riemann, dt, kernel_set=ks)
+        out[ks] = s.download()
+    assert np.array_equal(out[0], out[1])
+    assert np.abs(out[1][ng:-ng, ng:-ng] - U0[ng:-ng, ng:-ng]).max() > 1e-4     # it did move
