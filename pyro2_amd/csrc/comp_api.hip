@@ -22,10 +22,12 @@ int comp_sponge(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_source_correct(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_rk_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_rk_rhs(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, int);
+int comp_rk_rhs_wave(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, int);
 int comp_wave_geometry(int, int, int, int, int, int *);
 }
 namespace fastm {
 int comp_rk_rhs(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, int);
+int comp_rk_rhs_wave(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, int);
 int comp_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_step_staged(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_fused(pyrohip_state *, const pyrohip_comp_params *, double);
@@ -446,6 +448,12 @@ int pyrohip_comp_rk_rhs(pyrohip_state *y, const pyrohip_comp_params *p, pyrohip_
     if (p->do_sponge)
         PYRO_REQUIRE(p->sponge_rho_begin > p->sponge_rho_full,
                      "sponge_rho_begin must exceed sponge_rho_full (simulation.py:172)");
+    // kernel_set 2, or the library's choice from 2048^2 cells on: one launch of the row-marching
+    // kernel's method-of-lines instance; the staged kernels otherwise (small grids, the sponge)
+    const bool wave = !p->do_sponge && y->nvar == 4 &&
+                      (p->kernel_set == 2 || (p->kernel_set < 0 && wave_kernel_pays(y->g)));
+    if (wave)
+        return p->fast_math ? fastm::comp_rk_rhs_wave(y, p, k, slot) : exact::comp_rk_rhs_wave(y, p, k, slot);
     return p->fast_math ? fastm::comp_rk_rhs(y, p, k, slot) : exact::comp_rk_rhs(y, p, k, slot);
 }
 

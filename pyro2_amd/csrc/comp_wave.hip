@@ -197,7 +197,14 @@ __device__ __forceinline__ void st_put(double *st, int s, const Cons &U)
 }
 
 
-template <int SOLVER, bool STD>   // as k_ctu_fused
+// MOL: the method-of-lines right-hand side of compressible_rk (compressible_rk/fluxes.py:28-180,
+// simulation.py:10-44) instead of the CTU step: the same march -- density floor, primitives,
+// flattening, limited slopes, artificial viscosity, one Riemann problem per face -- with
+// piecewise linear face states (no tracing), no transverse problems / corrections, and
+// k = -div F + S stored in place of the new state (Uout = four planes of the k state; the
+// arithmetic of the staged k_rk_states / k_rk_flux / k_rk_rhs of compressible.hip, expression by
+// expression).  No sponge (the staged set carries it).
+template <int SOLVER, bool STD, bool MOL = false>   // SOLVER, STD as k_ctu_fused
 __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *__restrict__ Uin,
                                                                  double *__restrict__ Uout, Geom g,
                                                                  FP P, int *__restrict__ flag,
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     const bool flat = STD || P.use_flattening;
     // fast build, HLLC: the transverse Riemann problems take the traced primitive
     // face states as they are (hllc_flux_impl<true>)
-    constexpr bool TQ = (PYRO_FAST != 0) && (SOLVER == 0);
+    constexpr bool TQ = (PYRO_FAST != 0) && (SOLVER == 0) && !MOL;
     UniformTab ct = (UniformTab)(lds + ST_SLOTS * 64);
     if (S && !S->active) {
         // device-side run, past tmax or after an invalid state: nothing happens (the
@@ -341,6 +348,8 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             Cons U = Upre;
             Upre = loadU(k + 1);
             const bool interior = row_in(k) && jin;
+            if (MOL && interior && U.d < US(SMALLD, P.small_dens))     // clean_state works in place
+                const_cast<double *>(Uin)[(size_t)k * p + jc] = US(SMALLD, P.small_dens);
             if (interior) U.d = fmax(U.d, US(SMALLD, P.small_dens));
             bool ok;
             const Prim q = cons_to_prim_nb(U, US(GAMMA, P.gamma), ok);
@@ -411,7 +420,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             // source terms of the face states (apply_source_terms, unsplit_fluxes.py:247-330)
             Cons Ug{0.0, 0.0, 0.0, 0.0};
             double sgn = 1.0, hp = 0.0;
-            if (P.have_src) {
+            if (!MOL && P.have_src) {
                 const bool ina = (j < g.qy);
                 // "ambient" upper boundary: the source ghosts are copies of row jhi
                 // (BC.py:159-160), not the sources of the ambient ghost state
@@ -450,13 +459,19 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             // -- x states of row c, transverse x flux on its lower face
             Trace lo, hi;
             double gamma = US(GAMMA, P.gamma);
-            trace_states(q0[0], q0[1], q0[2], q0[3], dqx[0], dqx[1], dqx[2], dqx[3], gamma,
-                         US(DTDX, s_dtdx), lo, hi);
+            if (MOL) {     // fluxes.py:107-140: V_r[i] = q - ld/2, V_l[i+1] = q + ld/2
+                lo = Trace{q0[0] + -1.0 * 0.5 * dqx[0], q0[1] + -1.0 * 0.5 * dqx[1],
+                           q0[2] + -1.0 * 0.5 * dqx[2], q0[3] + -1.0 * 0.5 * dqx[3]};
+                hi = Trace{q0[0] + 1.0 * 0.5 * dqx[0], q0[1] + 1.0 * 0.5 * dqx[1],
+                           q0[2] + 1.0 * 0.5 * dqx[2], q0[3] + 1.0 * 0.5 * dqx[3]};
+            } else
+                trace_states(q0[0], q0[1], q0[2], q0[3], dqx[0], dqx[1], dqx[2], dqx[3], gamma,
+                             US(DTDX, s_dtdx), lo, hi);
             double gm1 = UC_EXACT(GM1), rgm1 = US(RGM1, P.rgm1);
             Cons XMn = prim_to_cons_g(Prim{lo.r, lo.un, lo.ut, lo.p}, gm1, rgm1);
             Cons XPn = prim_to_cons_g(Prim{hi.r, hi.un, hi.ut, hi.p}, gm1, rgm1);
             FaceQ qxm{lo.un, lo.ut, lo.p}, qxp{hi.un, hi.ut, hi.p};
-            if (P.have_src) {
+            if (!MOL && P.have_src) {
                 add_grav_to_state(XMn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
                 add_grav_to_state(XPn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
                 if (TQ) { qxm = faceq(to_nf(XMn, true), gamma); qxp = faceq(to_nf(XPn, true), gamma); }
@@ -465,7 +480,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             // conditions they are computed under -- xface / frow -- and an initial value
             // costs four register moves each in every iteration)
             Cons FxTn;
-            if (xface) {
+            if (!MOL && xface) {
                 if (TQ) {
                     const FaceQ ql{st[ST_XPQ * 64], st[(ST_XPQ + 1) * 64], st[(ST_XPQ + 2) * 64]};
                     FxTn = from_nf(hllc_flux_impl<true>(to_nf(st_get(st, ST_XP), true), to_nf(XMn, true),
@@ -482,16 +497,20 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             // -- row f: y states corrected with FxT of rows f, f+1; final y flux
             Cons Fy, Fyh;
             if (frow) {
+                Cons YMc, YPc;
+                if (MOL) { YMc = st_get(st, ST_YM); YPc = st_get(st, ST_YP); }
+                else {
                 const Cons FxTp = st_get(st, ST_FXT);
 #if PYRO_FAST
                 const double kx = US(KX, s_kx);
-                const Cons YMc = corr_k(st_get(st, ST_YM), FxTn, FxTp, kx);
-                const Cons YPc = corr_k(st_get(st, ST_YP), FxTn, FxTp, kx);
+                YMc = corr_k(st_get(st, ST_YM), FxTn, FxTp, kx);
+                YPc = corr_k(st_get(st, ST_YP), FxTn, FxTp, kx);
 #else
                 const double hdtV = UC(HDTV), Ax = UC(DY);
-                const Cons YMc = corr(st_get(st, ST_YM), FxTn, FxTp, hdtV, Ax);
-                const Cons YPc = corr(st_get(st, ST_YP), FxTn, FxTp, hdtV, Ax);
+                YMc = corr(st_get(st, ST_YM), FxTn, FxTp, hdtV, Ax);
+                YPc = corr(st_get(st, ST_YP), FxTn, FxTp, hdtV, Ax);
 #endif
+                }
                 Fy = from_nf(riemann_face<SOLVER>(to_nf(lane_m1(YPc), false), to_nf(YMc, false),
                                                   UC_GASK(), false, P.solid_yl && j == g.jlo), false);
                 const Cons Umy = lane_m1(Uem);
@@ -501,17 +520,23 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 Fy.my += avy * (Umy.my - Uem.my);
                 Fyh = lane_p1(Fy);
             }
-            if (xface) st_put(st, ST_FXT, FxTn);
+            if (!MOL && xface) st_put(st, ST_FXT, FxTn);
             STAGE_FENCE();
             // -- y states of row c, transverse y flux on its lower face
             gamma = US(GAMMA, P.gamma);
-            trace_states(q0[0], q0[2], q0[1], q0[3], dqy[0], dqy[2], dqy[1], dqy[3], gamma,
-                         US(DTDY, s_dtdy), lo, hi);
+            if (MOL) {     // (normal / transverse frame of the y direction: un = v, ut = u)
+                lo = Trace{q0[0] + -1.0 * 0.5 * dqy[0], q0[2] + -1.0 * 0.5 * dqy[2],
+                           q0[1] + -1.0 * 0.5 * dqy[1], q0[3] + -1.0 * 0.5 * dqy[3]};
+                hi = Trace{q0[0] + 1.0 * 0.5 * dqy[0], q0[2] + 1.0 * 0.5 * dqy[2],
+                           q0[1] + 1.0 * 0.5 * dqy[1], q0[3] + 1.0 * 0.5 * dqy[3]};
+            } else
+                trace_states(q0[0], q0[2], q0[1], q0[3], dqy[0], dqy[2], dqy[1], dqy[3], gamma,
+                             US(DTDY, s_dtdy), lo, hi);
             gm1 = UC_EXACT(GM1); rgm1 = US(RGM1, P.rgm1);
             Cons YMn = prim_to_cons_g(Prim{lo.r, lo.ut, lo.un, lo.p}, gm1, rgm1);
             Cons YPn = prim_to_cons_g(Prim{hi.r, hi.ut, hi.un, hi.p}, gm1, rgm1);
             FaceQ qym{lo.un, lo.ut, lo.p}, qyp{hi.un, hi.ut, hi.p};
-            if (P.have_src) {
+            if (!MOL && P.have_src) {
                 add_grav_to_state(YMn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
                 add_grav_to_state(YPn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
                 if (TQ) { qym = faceq(to_nf(YMn, false), gamma); qyp = faceq(to_nf(YPn, false), gamma); }
@@ -519,7 +544,8 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             st_put(st, ST_YM, YMn);
             st_put(st, ST_YP, YPn);
             Cons FyT;
-            if (TQ) {
+            if (MOL) {
+            } else if (TQ) {
                 const FaceQ ql{lane_m1(qyp.un), lane_m1(qyp.ut), lane_m1(qyp.p)};
                 FyT = from_nf(hllc_flux_impl<true>(to_nf(lane_m1(YPn), false), to_nf(YMn, false), ql,
                                                    qym, UC_GASK(), false), false);
@@ -528,16 +554,22 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                                                    UC_GASK(), false, P.solid_yl && j == g.jlo), false);
             STAGE_FENCE();
             // -- transverse correction of the x states of row c, final x flux
+            Cons XMc = XMn, XPc = XPn;
+#if !PYRO_FAST
+            const double Ay = UC(DX);
+#endif
+            if (!MOL) {
             const Cons FyTh = lane_p1(FyT);            // FyT at (i, j+1)
 #if PYRO_FAST
             const double ky = US(KY, s_ky);
-            const Cons XMc = corr_k(XMn, FyTh, FyT, ky);
-            const Cons XPc = corr_k(XPn, FyTh, FyT, ky);
+            XMc = corr_k(XMn, FyTh, FyT, ky);
+            XPc = corr_k(XPn, FyTh, FyT, ky);
 #else
-            const double hdtV = UC(HDTV), Ay = UC(DX);
-            const Cons XMc = corr(XMn, FyTh, FyT, hdtV, Ay);
-            const Cons XPc = corr(XPn, FyTh, FyT, hdtV, Ay);
+            const double hdtV = UC(HDTV);
+            XMc = corr(XMn, FyTh, FyT, hdtV, Ay);
+            XPc = corr(XPn, FyTh, FyT, hdtV, Ay);
 #endif
+            }
             if (TQ) {   // the next row's transverse problem reads (rho, E) + ST_XPQ only
                 st[ST_XP * 64] = XPn.d; st[(ST_XP + 1) * 64] = XPn.E;
             } else
@@ -558,6 +590,22 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 const Cons Fxp = st_get(st, ST_FX);
                 const Cons &Uc = Uem;
                 Cons Un;   // simulation.py:377-384
+                if (MOL) {
+                    // compressible_rk/simulation.py:16-42 (k_rk_rhs): k = (Fx[i] - Fx[i+1])/dx +
+                    // (Fy[j] - Fy[j+1])/dy + S,  S = (0, ymom g + rho e_rate heat, 0, rho g)
+                    const size_t kr = (size_t)(i - 1) * p + j;
+                    const double dxx = UC(DX), dyy = UC(DY);
+                    Un.d = pdiv(Fxp.d - Fxn.d, dxx) + pdiv(Fy.d - Fyh.d, dyy);
+                    Un.E = pdiv(Fxp.E - Fxn.E, dxx) + pdiv(Fy.E - Fyh.E, dyy);
+                    Un.mx = pdiv(Fxp.mx - Fxn.mx, dxx) + pdiv(Fy.mx - Fyh.mx, dyy);
+                    Un.my = pdiv(Fxp.my - Fxn.my, dxx) + pdiv(Fy.my - Fyh.my, dyy);
+                    Un.d = Un.d + 0.0;
+                    Un.E = Un.E + (Uc.my * UC(GRAV) + Uc.d * UC(HEATR) * (P.heat ? P.heat[kr] : 0.0));
+                    Un.mx = Un.mx + 0.0;
+                    Un.my = Un.my + Uc.d * UC(GRAV);
+                    Uout[kr] = Un.d; Uout[pl + kr] = Un.E; Uout[2 * pl + kr] = Un.mx;
+                    Uout[3 * pl + kr] = Un.my;
+                } else {
 #if PYRO_FAST
                 const double cx = US(CX, s_cx), cy = US(CY, s_cy);
                 Un.d = fma(cx, Fxp.d - Fxn.d, fma(cy, Fy.d - Fyh.d, Uc.d));
@@ -587,6 +635,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 cfl_speeds(Un, US(GAMMA, P.gamma), ax, ay);
                 st[ST_AX * 64] = fmax(st[ST_AX * 64], ax);
                 st[ST_AY * 64] = fmax(st[ST_AY * 64], ay);
+                }
             }
             if (xface) st_put(st, ST_FX, Fxn);
         }
@@ -741,6 +790,46 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
 int comp_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
 {
     return comp_step_wave_ex(s, p, dt, nullptr, nullptr);
+}
+
+// compressible_rk: k of the stage state y into slot `slot` of the k state, ONE launch of the
+// row-marching kernel's method-of-lines instance (no sponge: comp_rk_rhs of compressible.hip)
+int comp_rk_rhs_wave(pyrohip_state *s, const pyrohip_comp_params *p, pyrohip_state *kst, int slot)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    FP P;
+    double *Uin, *Uout;
+    PYRO_TRY(fused_prepare(s, p, 1.0, P, Uin, Uout, true));
+    Uout = kst->d + (size_t)(4 * slot) * g.plane;
+    const int cus = c->num_cus > 0 ? c->num_cus : 256;
+    const WaveGeom wg = wave_geometry(g.nx, g.ny, g.ng, cus, p->march_rows);
+    P.ncb = wg.ncb; P.L = wg.L; P.nsb = wg.nsb;
+    const int nwg = P.ncb * wg.nsb;
+    PYRO_TRY(c->reduce.ensure((nwg + kMinStageBlocks + 2) * sizeof(double)));
+    using KernelT = void (*)(const double *, double *, Geom, FP, int *, double *,
+                             const StepScalars *);
+    static const KernelT kernels[3][2] = {
+        {k_ctu_wave<0, false, true>, k_ctu_wave<0, true, true>},
+        {k_ctu_wave<1, false, true>, k_ctu_wave<1, true, true>},
+        {k_ctu_wave<2, false, true>, k_ctu_wave<2, true, true>}};
+    const int solver = (p->riemann == 1 || p->riemann == 2) ? p->riemann : 0;
+    const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
+    P.nunits = nwg;
+    P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus);
+    PYRO_LAUNCH(c, "k_ctu_wave_mol", kernels[solver][std_rec], dim3(8 * ((nwg + 7) / 8)), dim3(64), WLDS_BYTES,
+                (const double *)Uin, Uout, g, P, s->d_flag, (double *)c->reduce.p, nullptr);
+    PYRO_CHECK_HIP(hipGetLastError());
+    PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, s->d_flag, sizeof(int), hipMemcpyDeviceToHost,
+                                  c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    s->next_cfl_min = -1.0;
+    if (*(int *)c->reduce_host & 1) {
+        set_error("invalid state: min(rho) <= 0 or min(e) <= 0 on the interior "
+                  "(compressible/simulation.py:68-71)");
+        return PYROHIP_ERR_STATE;
+    }
+    return 0;
 }
 
 }  // namespace PYRO_NS

@@ -1155,3 +1155,40 @@ def test_bench_rank_geometry_16384(dev):
             last = dec.nx_local - (g["row_strips"] - 1) * g["rows_per_strip"]
             assert ng <= last <= 2 * g["rows_per_strip"]
             assert g["overlap"] == int(g["row_strips"] >= 3 and g["rows_per_strip"] >= ng)
+
+
+@pytest.mark.parametrize("riemann", ["HLLC", "CGF", "HLLC_lm"])
+@pytest.mark.parametrize("nx,ny,grav,lim,flat,rows", [
+    (40, 130, 0.0, 2, 1, 0), (33, 57, -1.5, 2, 1, 7), (64, 64, -1.5, 1, 0, 16)])
+def test_rk_rhs_one_launch_equals_staged(dev, riemann, nx, ny, grav, lim, flat, rows):
+    """compressible_rk's right-hand side by ONE launch of the row-marching kernel's
+    method-of-lines instance (k_ctu_wave<.., MOL>: piecewise linear face states, no transverse
+    problems, k = -div F + S stored) against the staged k_prim / k_xi / k_rk_states / k_rk_flux /
+    k_rk_rhs: every solver, gravity, both reconstructions, strips of 7 / 16 rows and the
+    library's choice, a density floor that bites (clean_state works in place: the stage state
+    is compared too) -- bit for bit in the bit-faithful build"""
+    rng = np.random.default_rng(5)
+    ic = np.zeros((nx + 8, ny + 8, 4))
+    x = np.arange(nx + 8)[:, None] / nx
+    y = np.arange(ny + 8)[None, :] / ny
+    ic[..., 0] = 1.0 + 0.5 * np.sin(7 * x) * np.cos(5 * y) + 0.1 * rng.random((nx + 8, ny + 8))
+    ic[..., 2] = 0.4 * np.cos(3 * x + y)
+    ic[..., 3] = -0.3 * np.sin(4 * y - x)
+    ic[..., 1] = 2.5 + 5.0 * np.exp(-40 * ((x - 0.5) ** 2 + (y - 0.5) ** 2)) + \
+        0.5 * (ic[..., 2] ** 2 + ic[..., 3] ** 2) / ic[..., 0]
+    bcs = [["outflow", "outflow", "reflect-even", "outflow"]] * 3 + [["outflow", "outflow", "reflect-odd", "outflow"]]
+    out = {}
+    for ks in (0, 2):
+        P = device.make_comp_params(1.0 / nx, 1.0 / ny, fast_math=0, kernel_set=ks, riemann=riemann,
+                                    grav=grav, limiter=lim, use_flattening=flat, march_rows=rows,
+                                    small_dens=1.05)
+        s = device.DeviceState(dev, nx, ny, 4, bcs)
+        s.upload(ic)
+        s.fill_bc()
+        k = device.DeviceState(dev, nx, ny, 4, [["outflow"] * 4] * 8)
+        k.upload(np.zeros((nx + 8, ny + 8, 8)))
+        s.comp_rk_rhs(P, k, 1)
+        out[ks] = (k.download()[4:-4, 4:-4, 4:8].copy(), s.download().copy())
+    assert np.array_equal(out[0][0], out[2][0])
+    assert np.array_equal(out[0][1], out[2][1])
+    assert (out[2][1][4:-4, 4:-4, 0] >= 1.05).all() and (ic[4:-4, 4:-4, 0] < 1.05).any()
