@@ -38,10 +38,11 @@ if os.environ.get("PYRO_PROVENANCE"):
     out["provenance"] = json.load(open(os.environ["PYRO_PROVENANCE"]))
 # advection (also_run.py adv = the bench leg at 2048^2): the several-steps-per-launch kernel
 # k_adv_multi takes STEPS_PER_LAUNCH time steps per launch
-spl = int(os.environ.get("ADV_STEPS_PER_LAUNCH", "2"))
-multi = [k for k in out["adv"] if "k_adv_multi" in k]
+import re
+multi = sorted((k for k in out["adv"] if "k_adv_multi" in k), key=lambda k: -out["adv"][k]["launches"])
 if multi:
-    k = multi[0]
+    k = multi[0]                                  # the instance the leg launches most
+    spl = int(re.findall(r"(\d+)>", k)[-1])       # its last template argument: steps per launch
     e = out["adv"][k]
     per_launch = (e["read_bytes_total"] + e["write_bytes_total"]) / e["launches"]
     out["adv_summary"] = {"kernel": k, "nx": 2048, "steps_per_launch": spl,

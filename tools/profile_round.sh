@@ -25,7 +25,7 @@ def sh(c):
     except Exception: return ""
 print(json.dumps({"commit": "${COMMIT:-unknown}", "tag": "$TAG", "date": time.strftime("%Y-%m-%d %H:%M:%S UTC", time.gmtime()),
                   "box": {"host": platform.node(), "gpu_unique_id": "${GPUID:-unknown}",
-                          "gpu": sh("rocm-smi --showproductname 2>/dev/null | grep -m1 'Card Series' | sed 's/.*: *//'")},
+                          "gpu": sh("rocminfo 2>/dev/null | grep -m1 'Marketing Name.*MI' | sed 's/.*: *//'")},
                   "rocm": sh("cat /opt/rocm/.info/version 2>/dev/null")}, indent=1))
 PY
 cat $P/${TAG}_provenance.json
@@ -61,7 +61,7 @@ python - > $P/${TAG}_adv_pmc.json <<PY
 import json, subprocess
 out = {"provenance": json.load(open("$P/${TAG}_provenance.json"))}
 for nx in (2048, 8192):
-    subprocess.run(f"NX={nx} MULTI=2 TAG=pmcadv_${TAG}_{nx} bash tools/pmc_adv.sh > $O/pmcadv_${TAG}_{nx}.txt 2>&1", shell=True)
+    subprocess.run(f"NX={nx} MULTI=3 TAG=pmcadv_${TAG}_{nx} bash tools/pmc_adv.sh > $O/pmcadv_${TAG}_{nx}.txt 2>&1", shell=True)
     out[str(nx)] = json.load(open(f"$O/pmcadv_${TAG}_{nx}_summary.json"))
 print(json.dumps(out, indent=1))
 PY
