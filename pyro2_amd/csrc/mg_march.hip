@@ -28,6 +28,10 @@
 #include "stencil.h"
 #include <type_traits>
 
+#ifndef MGM_SKIP
+#define MGM_SKIP 1     // no steps past the last one a stored row depends on (mgm_march)
+#endif
+
 namespace pyro {
 namespace {
 
@@ -230,6 +234,16 @@ __device__ __forceinline__ void mgm_march(const MGMarch &A, const Part &P, doubl
     // rows 0 .. PF - 1 on their way
     static_for<PF>([&](auto sc) __attribute__((always_inline)) { load_row(sc, decltype(sc)::value); });
 
+    // The last step that matters.  Step k sweeps the rows k - 1 ... k - NP; a stored row depends
+    // on sweep s of the rows within NP - s of it, so beyond k = (last row that is stored -- or,
+    // with a tail, must be final) + NP no sweep touches anything a stored row reads: the NP apron
+    // rows above a part are loaded for the sweeps of the rows below them and need no steps of
+    // their own (round 3 ran nload + NP steps: 20 of 159 for nothing on a 98-row chunk).
+    // (Skipping the apron rows' late sweeps one by one as well -- a second copy of the unrolled
+    // block with a scalar compare and branch per sweep for the first and last blocks -- was built
+    // and measured: 707 -> 1018 us per 4096^2 V-cycle; two 35 KB copies do not fit the
+    // instruction cache.)
+    const int sk_hi = P.rb + (TAIL ? 1 : 0) - g0 + NP;
     auto step = [&](auto uc, int k0) __attribute__((always_inline)) {
         constexpr int U = decltype(uc)::value;
         const int k = k0 + U;
@@ -363,7 +377,11 @@ __device__ __forceinline__ void mgm_march(const MGMarch &A, const Part &P, doubl
         }
     };
 
+#if MGM_SKIP
+    const int nsteps = (P.nload + NP < sk_hi + 1) ? P.nload + NP : sk_hi + 1;
+#else
     const int nsteps = P.nload + NP;
+#endif
     for (int k0 = 0; k0 < nsteps; k0 += W)
         static_for<W>([&](auto uc) __attribute__((always_inline)) { step(uc, k0); });
     if constexpr (TAIL == 2) {
