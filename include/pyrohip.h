@@ -180,7 +180,7 @@ typedef struct {
     int fast_math;
     int march_rows;
     int multi_k;       /* pyrohip_adv_evolve: time steps per launch on periodic grids
-                          (0: the library's choice = 3; 1: one step per launch of
+                          (0: the library's choice = 3 for u > 0, 2 for u < 0; 1: one step per launch of
                           the several-steps kernel; at most 3)                          */
     int multi_prio;    /* ... its wavefronts take turns at the priority levels (0: the
                           library's choice = yes, -1: no)                           */

@@ -845,9 +845,11 @@ extern "C" int pyrohip_adv_evolve(pyrohip_state *s, int n, const pyrohip_adv_par
                      "pyrohip_adv_evolve: outflow / reflect / periodic boundaries only");
     bool periodic = true;
     for (int k = 0; k < 4; k++) periodic = periodic && s->bc[n * 4 + k] == PYROHIP_BC_PERIODIC;
-    // (measured, profiles/r04_adv_multi_sweep.txt: three steps per launch 193.7 / 16.4 us per step at
-    // 8192^2 / 2048^2 against 204.6 / 17.5 with two, once the stages' reach followed the sign of u)
-    int kmax = ap->multi_k > 0 ? ap->multi_k : 3;
+    // (measured, profiles/r04_adv_multi_sweep.txt: for u > 0 -- a stage reaches two rows
+    // downstream, 248 registers -- three steps per launch 190.5 / 47 / 16.2 us per step at 8192^2 /
+    // 4096^2 / 2048^2 against 204.5 / 51 / 16.7 with two; for u < 0 -- three rows, 256 registers and
+    // 12 B of scratch -- 206.7 / 17.0 against 202.3 / 16.9: two)
+    int kmax = ap->multi_k > 0 ? ap->multi_k : (ap->u > 0.0 ? 3 : 2);
     if (kmax > 3) kmax = 3;
     // the unwrapped indices of a K-step launch wrap once: 3 K rows / the strip's apron columns
     // must fit the grid; u = 0 or v = 0 keep the single step (its upwind offsets are not the signs)

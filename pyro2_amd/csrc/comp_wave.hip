@@ -651,17 +651,18 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     if (l == 0) partial[sb * P.ncb + cb] = cfl;
 }
 
-// rows per strip: about four rounds of resident wavefronts, so that the dynamic
-// dispatch evens out the tail, within 32..128 rows (a strip costs L + 8
-// iterations).  Measured at 16384^2: 128 rows 11.91 ms, 400 rows 12.17 ms,
-// 600 rows 12.36 ms (profiles/r02_kernel_sets_by_size.txt)
-// Below ~10 rounds the LAST round matters: 8214 wavefronts on 2048 slots (4096^2 with
-// 37-row strips) run a fifth round for 22 of them.  So the strip length is the one that
-// minimises  (rounds + 1/2) x (L + 8)  (rounds = wavefronts / resident slots, half a strip
-// for the tail of the dynamic dispatch, L + 8 iterations per strip; exactly one strip time
-// when everything is resident at once) over 32 .. 160 rows, the shorter strip winning a tie
-// within 1 % (row re-reads hit the L2 of the neighbouring column strips while those are
-// close in time).
+// Rows per strip (a strip costs L + 8 iterations, of which the 8 warm-up ones are cheap: ~3 % of
+// the instructions at L = 69).  What matters is the LAST round of resident wavefronts: the
+// launch lasts ceil(wavefronts / slots) strip times, and a last round that fills a third to a
+// half of the slots is the worst case -- measured at 8192^2 (147 column strips, 2048 slots,
+// profiles/r04_march_sweep.txt): 59 rows = 9.98 rounds 2.525 ms, 74 rows = 7.97 rounds 2.525,
+// 75 rows = 7.9 rounds 2.549, 64 rows = 9.19 rounds 2.576, 82 rows = 7.18 rounds 2.588, 69 rows =
+// 8.54 rounds 2.624 (round 3's choice, by (rounds + 1/2)(L + 8) with fractional rounds), 112 rows
+// = 5.31 rounds 2.628, 128 rows 2.688.  So: the strip length in 32 .. 160 rows that minimises
+// (ceil(wavefronts / slots) + 1) x (L + 8) -- WHOLE rounds, plus a strip time for the stragglers of
+// the last one (few long rounds end worse than many short ones: the two wavefronts of a SIMD are
+// served oldest first) --, the shorter strip winning a tie.  One round when everything is resident at once
+// (4096^2: 74 x 27 strips of 152 rows).
 static int wave_rows(int nx, int ncb, int slots)
 {
     if (nx <= 32) return nx;
@@ -672,9 +673,11 @@ static int wave_rows(int nx, int ncb, int slots)
         if (nsb > 1 && nx - (nsb - 1) * L < 4) nsb--;        // short last strip joins its predecessor
         const int Leff = (nx + nsb - 1) / nsb;                // longest strip
         const long waves = (long)ncb * nsb;
-        // in units of 1 / (2 slots) strip iterations
-        const long cost = (waves <= slots ? 2L * slots : 2 * waves + slots) * (Leff + 8);
-        if (best_cost < 0 || cost * 100 < best_cost * 99) { best_cost = cost; best = L; }
+        const long rounds = (waves + slots - 1) / slots;
+        // strip times: one round when everything is resident at once, otherwise whole rounds
+        // + one more for the stragglers of the last one
+        const long cost = (waves <= slots ? 1 : rounds + 1) * (Leff + 8);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = L; }
     }
     return best;
 }

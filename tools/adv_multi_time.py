@@ -3,7 +3,7 @@ by grid size, steps per launch and chunk length (GPU box).
 
   SPEC="2048:1/0,2/0,2/19;8192:2/0,3/0"   size:K/rows,...   (K = 0: the single-step kernel,
                                           rows = 0: the library's choice)
-  PRIO=0/1, FAST=1/0, LIM=2, CHECK=1 (compare the end state with single steps, bit for bit
+  UV="-1,-1" (advection velocity), PRIO=0/1, FAST=1/0, LIM=2, CHECK=1 (compare the end state with single steps, bit for bit
   in the exact build)
 """
 import os, sys, time
@@ -18,6 +18,7 @@ PRIO = int(os.environ.get("PRIO", "0"))
 FAST = int(os.environ.get("FAST", "1"))
 LIM = int(os.environ.get("LIM", "2"))
 CHECK = int(os.environ.get("CHECK", "0"))
+UU, VV = (float(a) for a in os.environ.get("UV", "1,1").split(","))      # advection velocity
 for part in SPEC.split(";"):
     nx = int(part.split(":")[0])
     x = (np.arange(nx + 8) - 3.5) / nx
@@ -34,9 +35,9 @@ for part in SPEC.split(";"):
         def run(n):
             if K == 0:
                 for _ in range(n):
-                    st.adv_step(0, 1 / nx, 1 / nx, 1.0, 1.0, dt, LIM, fill=True, fast_math=FAST, march_rows=rows)
+                    st.adv_step(0, 1 / nx, 1 / nx, UU, VV, dt, LIM, fill=True, fast_math=FAST, march_rows=rows)
             else:
-                st.adv_evolve(0, 1 / nx, 1 / nx, 1.0, 1.0, [dt] * n, LIM, fast_math=FAST, march_rows=rows,
+                st.adv_evolve(0, 1 / nx, 1 / nx, UU, VV, [dt] * n, LIM, fast_math=FAST, march_rows=rows,
                               multi_k=K, multi_prio=PRIO)
         run(12)
         ctx.sync()
