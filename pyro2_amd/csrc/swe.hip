@@ -494,15 +494,24 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
     }
 }
 
-// rows per chunk of the fused step: the shortest with which all wavefronts are resident at once
-// (two per SIMD), several rounds of ~96 rows beyond that
+// rows per chunk of the fused step (a chunk costs L + 6 iterations): whole rounds of resident
+// wavefronts (two per SIMD) + one chunk time for the stragglers of the last round -- the rule of
+// the compressible kernel (comp_wave.hip: wave_rows) without its one-round case: this kernel's
+// wavefronts do not take turns at the priority, a single round ends with every SIMD's younger
+// wavefront alone (4096^2: one round of 147 rows 1.26 ms, 1.5 rounds of 96 rows 1.21)
 static int sww_rows(int nx, int ncb, int cus)
 {
     const long slots = 8L * cus;
     if (nx <= 16) return nx;
-    for (int L = 16; L <= 96 && L < nx; L++)
-        if ((long)ncb * ((nx + L - 1) / L) <= slots) return L;
-    return nx < 96 ? nx : 96;
+    long best_cost = -1;
+    int best = 16;
+    for (int L = 16; L <= 160 && L <= nx; L++) {
+        const long waves = (long)ncb * ((nx + L - 1) / L);
+        const long rounds = (waves + slots - 1) / slots;
+        const long cost = (rounds + 1) * (L + 6);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = L; }
+    }
+    return best;
 }
 
 // ghost frame of the four planes from one buffer to the other (1-d grid: 2 ng blocks of
