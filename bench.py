@@ -458,7 +458,7 @@ def reference_numpy_stages():
                       "artificial_viscosity replaced by allocate-only stubs; real reference <= these rates"}
 
 
-def bench_advection(ctx, device, nx=2048, steps=120, warmup=12, fast_math=1, other=True, multi_k=0):
+def bench_advection(ctx, device, nx=2048, steps=600, warmup=30, fast_math=1, other=True, multi_k=0):
     """advection smooth nx^2 periodic through pyrohip_adv_evolve: the driver's loop body
     (fill_BC_all + evolve) `steps` times in one call, several time steps per pass over the
     grid (k_adv_multi; multi_k = 0: the library's choice, 2).  A step moves 16 algorithmic
@@ -974,7 +974,7 @@ def main():
             if not args.no_also:
                 also.update({"sedov_small_grids": bench_small_grids(ctx, device),
                              "advection": bench_advection(ctx, device, fast_math=defaults["fast_math"]),
-                             "advection_8192": bench_advection(ctx, device, nx=8192, steps=30, warmup=5,
+                             "advection_8192": bench_advection(ctx, device, nx=8192, steps=60, warmup=6,
                                                                fast_math=defaults["fast_math"]),
                              "multigrid": bench_mg(ctx, device),
                              "incompressible": bench_incompressible(ctx, device)})

@@ -7,7 +7,7 @@ import bench
 ctx = device.Context(0)
 what = sys.argv[1]
 if what == "adv":
-    r = bench.bench_advection(ctx, device, nx=int(os.environ.get("NX", "2048")), steps=20, warmup=2,
+    r = bench.bench_advection(ctx, device, nx=int(os.environ.get("NX", "2048")), steps=60, warmup=6,
                               fast_math=int(os.environ.get("FM", "1")), other=False)
     print(r["ms_per_step"], r["roofline"]["kernel_avg_ms"])
 else:
