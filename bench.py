@@ -683,14 +683,14 @@ def bench_pyro_driver(ctx, device, bare):
     of also.sedov_4096 / also.advection), and one-line legs of the SURVEY 8(f) solvers with
     the bytes model each is priced with."""
     out = {}
-    r = bench_pyro_run(ctx, device, "compressible", "sedov", {"mesh.nx": 4096, "mesh.ny": 4096}, 100, 10,
+    r = bench_pyro_run(ctx, device, "compressible", "sedov", {"mesh.nx": 4096, "mesh.ny": 4096}, 256, 16,
                        (SEDOV_BYTES_PER_CELL, "64 B per cell update (SURVEY 8(d))"))
     if bare.get("sedov_4096"):
         r["bare_c_abi_ms_per_step"] = bare["sedov_4096"]
         r["ratio_to_bare"] = bare["sedov_4096"] / r["ms_per_step"]
     out["compressible_sedov_4096"] = r
     r = bench_pyro_run(ctx, device, "advection", "smooth",
-                       {"mesh.nx": 2048, "mesh.ny": 2048, "particles.do_particles": 0}, 240, 24,
+                       {"mesh.nx": 2048, "mesh.ny": 2048, "particles.do_particles": 0}, 768, 48,
                        (ADV_BYTES_PER_CELL, "16 B per cell update"))
     r["note"] = ("inputs.smooth carries 100 tracer particles (host-side NumPy, two grid-sized velocity "
                  "arrays per call): switched off here, the leg times the grid update")

@@ -6,6 +6,10 @@ from ..simulation_null import NullSimulation, bc_setup, grid_setup
 
 
 class Simulation(NullSimulation):
+    # steps the driver hands over at once when it batches (a multiple of the two / three steps
+    # a launch of the several-steps kernel takes)
+    batch_steps = 96
+
     def initialize(self):
         """grid (ng = 4, advection/simulation.py:20), the single variable
         "density", then the problem's initial condition"""

@@ -218,7 +218,8 @@ class Pyro:
             self.sim.dovis()
         while not self.sim.finished():
             if self._can_batch(writing):
-                self.sim.evolve_many(min(64, self.sim.max_steps - self.sim.n))
+                batch = getattr(self.sim, "batch_steps", 64)
+                self.sim.evolve_many(min(batch, self.sim.max_steps - self.sim.n))
             else:
                 self.single_step()
         if writing or self.rp.get_param("io.force_final_output"):
