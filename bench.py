@@ -189,6 +189,23 @@ def also_traffic_source():
             "note": "counters of a separate rocprofv3 --pmc run of the same leg, not of this run"}
 
 
+def adv_traffic(nx, steps_per_launch):
+    """fabric bytes per launch of the advection kernel at this size from the committed PMC passes
+    (tools/pmc_adv.sh -> profiles/r*_adv_pmc.json), if they were counted for the same number of
+    steps per launch; None otherwise"""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_adv_pmc.json")))
+    if not fs:
+        return None
+    try:
+        e = json.load(open(fs[-1]))[str(nx)]
+        if int(e["steps_per_launch"]) != int(round(steps_per_launch)):
+            return None
+        return e["read_bytes"] + e["write_bytes"]
+    except Exception:
+        return None
+
+
 def kernel_table(prof, nlaunch_unit):
     return {k: {"launches": n, "avg_ms": ms / max(n, 1)} for k, (n, ms) in prof.items()}
 
@@ -502,7 +519,7 @@ def bench_advection(ctx, device, nx=2048, steps=600, warmup=30, fast_math=1, oth
     # the pair around the timed region
     per_launch = ms / n >= 0.1
     kern_s = (ms / n if per_launch else ev_ms / n) * 1e-3
-    traffic = also_traffic("adv_summary", f"bytes_per_launch_{nx}")
+    traffic = adv_traffic(nx, spl)
     # the same steps one launch each (the single-step kernel: what round 3 timed)
     ctx.sync()
     s0 = time.perf_counter()
@@ -528,7 +545,10 @@ def bench_advection(ctx, device, nx=2048, steps=600, warmup=30, fast_math=1, oth
                          "kernel_avg_ms": kern_s * 1e3, "kernel_avg_ms_events_per_launch": ms / n,
                          "kernel_avg_ms_events_over_region": ev_ms / n,
                          "kernel_timer": "events per launch" if per_launch else "event pair over the timed region",
-                         "traffic": traffic, "traffic_source": also_traffic_source(),
+                         "traffic": traffic,
+                         "traffic_source": {"file": "profiles/r*_adv_pmc.json (the last one)",
+                                            "note": "counters of a separate rocprofv3 --pmc session "
+                                                    "(tools/pmc_adv.sh), with its provenance in the file"},
                          "step_frac": abytes * steps / (t1 - t0) / 1e9 / HBM_PEAK_GBS,
                          "launches_per_step": 1.0 / spl,
                          "basis": "16 B per cell and time step (read a, write a) x the time steps one launch "
