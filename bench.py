@@ -703,7 +703,9 @@ def bench_pyro_driver(ctx, device, bare):
     of also.sedov_4096 / also.advection), and one-line legs of the SURVEY 8(f) solvers with
     the bytes model each is priced with."""
     out = {}
-    r = bench_pyro_run(ctx, device, "compressible", "sedov", {"mesh.nx": 4096, "mesh.ny": 4096}, 256, 16,
+    # (the same steps of the same run as the bare leg also.sedov_4096: 100 after 5 untimed ones --
+    # later steps cost more, the blast grows)
+    r = bench_pyro_run(ctx, device, "compressible", "sedov", {"mesh.nx": 4096, "mesh.ny": 4096}, 100, 5,
                        (SEDOV_BYTES_PER_CELL, "64 B per cell update (SURVEY 8(d))"))
     if bare.get("sedov_4096"):
         r["bare_c_abi_ms_per_step"] = bare["sedov_4096"]
