@@ -858,8 +858,12 @@ def test_compressible_rk(dev, golden, k):
     assert (np.abs(U[I] - Uo[I]) / scale).max() <= tol * nsteps * 10
 
 
+@pytest.mark.parametrize("kset", [-1, 2])
 @pytest.mark.parametrize("k", [0, 1])
-def test_pyro_compressible_rk(dev, golden, k, tmp_path, monkeypatch):
+def test_pyro_compressible_rk(dev, golden, k, kset, tmp_path, monkeypatch):
+    """compressible_rk through Pyro against runs of the reference (dt sequence, end state); kset
+    2: every right-hand side by one launch of the row-marching kernel's method-of-lines instance
+    (what the library picks from 2048^2 cells on), -1: the staged kernels at these sizes"""
     monkeypatch.setattr(device.Context, "_default", dev)
     monkeypatch.chdir(tmp_path)
     from pyro2_amd.pyro_sim import Pyro
@@ -868,6 +872,7 @@ def test_pyro_compressible_rk(dev, golden, k, tmp_path, monkeypatch):
     prob, d = [("sedov", {"mesh.nx": 16, "mesh.ny": 16, "sedov.r_init": 0.2}),
                ("rt", {"mesh.nx": 12, "mesh.ny": 36, "rt.amp": 0.4,
                        "compressible.temporal_method": "TVD3"})][k]
+    d = dict(d, **{"gpu.kernel_set": kset, "gpu.fast_math": 0})
     nsteps = len(g[pre + "dts"]) if dev.kind == "hip" else 2
     p = Pyro("compressible_rk")
     p.initialize_problem(prob, inputs_dict=dict(d, **{"driver.max_steps": nsteps}))
