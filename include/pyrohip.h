@@ -252,6 +252,13 @@ typedef struct {
        Either way the ghost cells of the new state hold the filled ghost cells of the old
        one, like the reference's array after evolve(). */
     int fuse_fill;
+    /* pyrohip_comp_evolve with the row-marching kernel (kernel_set 2): 0 = the library's choice
+       (today 3); 3 = boundary fill, dt policy and step kernel as three launches per step; 1 =
+       ONE launch per step on a single domain with outflow / reflect / periodic sides: the
+       kernel reads ghost cells through the boundary rules and every wavefront derives the
+       step's dt from the CFL minima of the previous launch by the driver's policy
+       (simulation_null.py:222-244) -- bit-identical, measured no faster */
+    int step_launches;
 } pyrohip_comp_params;
 
 /* method_compute_timestep (compressible/simulation.py:267-288 +

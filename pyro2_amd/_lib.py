@@ -67,7 +67,8 @@ class CompParams(C.Structure):
                 ("riemann", C.c_int), ("solid_xl", C.c_int), ("solid_yl", C.c_int),
                 ("do_sponge", C.c_int), ("sponge_rho_begin", C.c_double),
                 ("sponge_rho_full", C.c_double), ("sponge_timescale", C.c_double),
-                ("heat_rate", C.c_double), ("march_rows", C.c_int), ("fuse_fill", C.c_int)]
+                ("heat_rate", C.c_double), ("march_rows", C.c_int), ("fuse_fill", C.c_int),
+                ("step_launches", C.c_int)]
 
 
 class DtPolicyC(C.Structure):

@@ -167,6 +167,67 @@ struct StepScalars {
     long long n;                         // steps taken so far (driver's counter)
     int active;                          // this step advances the state (else: identity copy)
     int steps;                           // steps that advanced, this call
+    int dead;                            // an invalid state was met: nothing runs any more
+};
+
+// The driver's compute_timestep (simulation_null.py:222-244) for a run that advances on the
+// device: ends the previous step (t, n), decides whether the next one runs (t < tmax, state
+// still valid) and derives its dt from the CFL minimum `cmin` of the state the previous step
+// left.  ONE thread calls it: k_dt_policy (comp_api.hip) between two steps, or the last
+// wavefront of the row-marching step kernel to finish (comp_wave.hip: one launch per step).
+// IEEE operations in the reference's order, never contracted.
+__device__ inline void dt_policy_apply(StepScalars *S, double cmin, bool invalid, double *dts,
+                                       int slot, int final_call)
+{
+#pragma clang fp contract(off)
+    invalid = invalid || S->dead != 0;       // (once invalid, always: the run has ended)
+    S->dead = invalid ? 1 : 0;
+    if (S->active && !invalid) { S->t += S->dt; S->n += 1; S->steps += 1; }
+    S->active = 0;
+    if (final_call) return;
+    double dt = 0.0;
+    const bool go = !invalid && (S->t < S->tmax);
+    if (go) {
+        if (S->fix_dt > 0.0) {
+            dt = S->fix_dt;
+        } else {
+            dt = S->cfl * cmin;
+            if (S->n == 0) dt = S->f0 * dt;
+            else dt = fmin(S->mx * S->dt_old, dt);
+            S->dt_old = dt;
+        }
+        if (S->t + dt > S->tmax) dt = S->tmax - S->t;
+    }
+    S->active = go ? 1 : 0;
+    S->dt = dt;
+    S->dtdx = dt / S->dx; S->dtdy = dt / S->dy;           // interface.py:106
+    S->hdtV = (0.5 * dt) / (S->dx * S->dy);              // unsplit_fluxes.py:444-445
+    S->dtdV = dt / (S->dx * S->dy);                      // simulation.py:375
+    dts[slot] = go ? dt : -1.0;
+}
+
+// The row-marching step kernel as the ONLY launch of a step (pyrohip_comp_evolve).  Nothing in
+// it waits for another wavefront or for the return of an atomic (a device-scope atomic with
+// return costs the wavefront tens of microseconds at its end, a release fence writes the whole
+// L2 back: both measured, profiles/r04_one_launch_step.txt):
+//  - every wavefront of launch m folds its CFL minimum into one of 64 slots of set m % 3 by a
+//    fire-and-forget unsigned 64-bit atomic minimum (positive doubles order like their bit
+//    patterns: exact, order-independent);
+//    (and raises bit 2 << (m & 1) of the positivity flag on an invalid state: its own bit, so
+//    that a wavefront of the same launch that starts later does not take it for the previous
+//    step's -- the policy remembers in StepScalars.dead);
+//  - every wavefront of launch m + 1 starts by taking the minimum of set m % 3 and running the
+//    driver's dt policy (dt_policy_apply) on a copy of S[m & 1] in its registers -- the same
+//    IEEE operations in every wavefront; the wavefront of unit 0 also stores the result as
+//    S[(m + 1) & 1] and dts[m + 1], and re-arms set (m + 2) % 3 for the launch after.
+// The first policy call of a run (the CFL minimum of the state as handed over) and the closing
+// one are launches of k_dt_policy.  One instance per state in device memory, set up per call.
+constexpr int kPolSlots = 64, kPolStride = 16;          // a 128-byte line per slot
+constexpr int kPolSetWords = kPolSlots * kPolStride;    // words of a set (the unused ones hold +inf)
+struct StepPolicy {
+    StepScalars S[2];
+    unsigned long long *slots;   // 3 sets of kPolSetWords bit patterns
+    double *dts;                 // dt sequence of the call
 };
 }  // namespace pyro
 
@@ -217,6 +278,11 @@ struct pyrohip_state {
     // the ghost frame of the OTHER buffer already holds this step's boundary fill (written
     // together with this buffer's by k_fill_frame2, comp_api.hip): the step need not copy it
     bool frame_prefilled = false;
+    // ... or the next launch of the row-marching kernel is the whole step (pyrohip_comp_evolve):
+    // it reads ghost cells through the boundary rules and ends with the dt policy (StepPolicy)
+    pyro::StepPolicy *pol_next = nullptr;
+    int pol_m = 0;            // ... step of the call the next launch is
+    unsigned long long *d_polmem = nullptr;   // 3 sets of slots, the reduced minimum, the StepPolicy
     double next_cfl_min = -1.0;  // min over interior of dx/(|u|+c) etc. of the
                                  // state after the last step (-1: unknown)
     bool cfl_is_global = false;  // ... already reduced over all ranks

@@ -98,9 +98,10 @@ static int check_comp(pyrohip_state *s, const pyrohip_comp_params *p)
 // takes its value from an x ghost cell): for outflow / reflect / periodic sides both are index
 // maps with a sign, and their composition is what the two passes leave.  One thread per
 // cell of the frame.
-__global__ __launch_bounds__(256) void k_fill_frame2(double *__restrict__ cur, double *__restrict__ alt,
+__global__ __launch_bounds__(256) void k_fill_frame2(const double *src, double *cur, double *alt,
                                                      Geom g, const int *__restrict__ bc)
-{
+{   // src: the buffer whose interior the images are taken from (cur itself, or -- at the end of a
+    // run of one-launch steps -- the buffer that holds the previous state); alt may be nullptr
     // 1-d grid: first the 2 ng full ghost rows in pieces of 256 columns, then the ghost
     // columns of the interior rows, 256 / (2 ng) rows per workgroup
     const int ng = g.ng;
@@ -129,10 +130,10 @@ __global__ __launch_bounds__(256) void k_fill_frame2(double *__restrict__ cur, d
         const int si = pyro::bc_src(mx, i, g.ilo, g.ihi), sj = pyro::bc_src(my, j, g.jlo, g.jhi);
         const bool neg = ((i < g.ilo && mx.odd_lo) || (i > g.ihi && mx.odd_hi)) !=
                          ((j < g.jlo && my.odd_lo) || (j > g.jhi && my.odd_hi));
-        const double v = cur[n * g.plane + (size_t)si * g.pitch + sj];
+        const double v = src[n * g.plane + (size_t)si * g.pitch + sj];
         const double w = neg ? -v : v;
         cur[n * g.plane + k] = w;
-        alt[n * g.plane + k] = w;
+        if (alt) alt[n * g.plane + k] = w;
     }
 }
 
@@ -148,15 +149,13 @@ static bool frame_fill_ok(const pyrohip_state *s)
     return true;
 }
 
-// The driver's compute_timestep (simulation_null.py:222-244) for a run that advances on
-// the device: ends the previous step (t, n), decides whether the next one runs
-// (t < tmax, state still valid) and derives its dt from the CFL minimum the previous
-// step kernel left in device memory.  One thread; IEEE operations in the reference's
-// order (this unit is compiled without FMA contraction).
+// The driver's compute_timestep (simulation_null.py:222-244) between two steps of a run that
+// advances on the device (dt_policy_apply, common.h), from the CFL minimum the previous step
+// kernel left in device memory.
 __global__ __launch_bounds__(256) void k_dt_policy(StepScalars *S, const double *cflmin,
                                                    const int *flag, double *dts, int slot,
                                                    int final_call, const double *part, int nparts,
-                                                   double *minout)
+                                                   double *minout, int flag_mask)
 {
     // the CFL minimum of the previous step: already reduced (cflmin), or still the
     // per-workgroup partials of the tile kernel (part: reduced here, kept in minout)
@@ -177,30 +176,8 @@ __global__ __launch_bounds__(256) void k_dt_policy(StepScalars *S, const double 
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    const double cmin = cmin_s;
-    const bool invalid = (*flag & 1) != 0;   // raised by the step that just ran: it does not count
-    if (S->active && !invalid) { S->t += S->dt; S->n += 1; S->steps += 1; }
-    S->active = 0;
-    if (final_call) return;
-    double dt = 0.0;
-    const bool go = !invalid && (S->t < S->tmax);
-    if (go) {
-        if (S->fix_dt > 0.0) {
-            dt = S->fix_dt;
-        } else {
-            dt = S->cfl * cmin;
-            if (S->n == 0) dt = S->f0 * dt;
-            else dt = fmin(S->mx * S->dt_old, dt);
-            S->dt_old = dt;
-        }
-        if (S->t + dt > S->tmax) dt = S->tmax - S->t;
-    }
-    S->active = go ? 1 : 0;
-    S->dt = dt;
-    S->dtdx = dt / S->dx; S->dtdy = dt / S->dy;           // interface.py:106
-    S->hdtV = (0.5 * dt) / (S->dx * S->dy);              // unsplit_fluxes.py:444-445
-    S->dtdV = dt / (S->dx * S->dy);                      // simulation.py:375
-    dts[slot] = go ? dt : -1.0;
+    // (raised by the step that just ran: it does not count)
+    pyro::dt_policy_apply(S, cmin_s, (*flag & flag_mask) != 0, dts, slot, final_call);
 }
 
 extern "C" {
@@ -242,7 +219,47 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
     // (the first one needs filled ghost cells for the CFL minimum over the whole array)
     const bool fuse = comp_can_fuse_fill(s, p, wave);
     pyrohip_comp_params pf = *p;
+    // step_launches 1: the row-marching kernel as the ONLY launch of a step (single domain;
+    // outflow / reflect / periodic sides, the same kind for the four variables): it reads ghost
+    // cells through the boundary rules instead of a filled frame, and every wavefront derives
+    // the step's dt from the CFL minima the previous launch left (k_ctu_wave<.., ONE>, common.h:
+    // StepPolicy).  The first step keeps its fill + CFL + policy launches (the CFL minimum of
+    // the state as handed over), the closing policy call is a launch, and the ghost cells of
+    // the final state are filled once at the end.  Bit-identical to the three launches, and
+    // measured no faster (profiles/r04_one_launch_step.txt: the step kernel pays in spilled
+    // registers what the two small launches cost; -1.5 % at 16384^2): not the default.
+    bool one_launch = wave && p->step_launches == 1 && !s->nb_set && !c->global_cfl &&
+                      comp_can_fuse_fill(s, p, false);
+    for (int k = 0; k < 16 && one_launch; k++) one_launch = (s->bc[k] != PYROHIP_BC_HALO);
+    pyro::StepPolicy *d_pol = nullptr;
+    if (one_launch) {
+        // three sets of slots (+inf), the reduced minimum, then the StepPolicy of this call
+        using namespace pyro;
+        const size_t nw = 3 * (size_t)kPolSetWords + 1;
+        const size_t bytes = nw * 8 + sizeof(StepPolicy);
+        if (!s->d_polmem) PYRO_CHECK_HIP(hipMalloc((void **)&s->d_polmem, bytes));
+        std::vector<unsigned long long> init(nw + (sizeof(StepPolicy) + 7) / 8, 0ull);
+        const double inf = INFINITY;
+        for (size_t k = 0; k < nw; k++) memcpy(&init[k], &inf, 8);
+        StepPolicy sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.S[0] = H;
+        sp.slots = s->d_polmem;
+        sp.dts = s->d_dts;
+        memcpy(&init[nw], &sp, sizeof(sp));
+        PYRO_CHECK_HIP(hipMemcpy(s->d_polmem, init.data(), bytes, hipMemcpyHostToDevice));
+        d_pol = (StepPolicy *)(s->d_polmem + nw);
+    }
+    // (the step scalars of a one-launch run live in the StepPolicy: two copies, by step parity)
+    StepScalars *const d_scal0 = one_launch ? &d_pol->S[0] : s->d_scal;
     for (int m = 0; m < max_steps && rc == 0; m++) {
+        if (one_launch && m > 0) {
+            s->pol_next = d_pol;
+            s->pol_m = m;
+            rc = p->fast_math ? fastm::comp_step_wave_ex(s, p, 0.0, d_scal0, &dmin)
+                              : exact::comp_step_wave_ex(s, p, 0.0, d_scal0, &dmin);
+            continue;
+        }
         // ghost cells: halos of a slab first, then the boundary fill (pyro_sim.py:250-256)
         if (s->nb_set && c->comm != nullptr) rc = pyrohip_halo_exchange(s, s->nb_lo, s->nb_hi);
         pf.fuse_fill = (fuse && !first) ? 1 : 0;
@@ -252,8 +269,8 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
                 const Geom &g = s->g;
                 const int rows_per_block = 256 / (2 * g.ng);
                 const int nblk = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + rows_per_block - 1) / rows_per_block;
-                hipLaunchKernelGGL(k_fill_frame2, dim3(nblk), dim3(256), 0, c->stream,
-                                   s->d, s->alt_base + geom_lead(g), g, (const int *)s->d_bc);
+                PYRO_LAUNCH(c, "k_fill_frame2", k_fill_frame2, dim3(nblk), dim3(256), 0, (const double *)s->d,
+                            s->d, s->alt_base + geom_lead(g), g, (const int *)s->d_bc);
                 const hipError_t e = hipGetLastError();
                 if (e != hipSuccess) {
                     set_error(std::string("k_fill_frame2: ") + hipGetErrorString(e));
@@ -271,23 +288,35 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
             first = false;
         }
         // (the minimum of the previous tile-kernel launch is taken here: pend_part)
-        hipLaunchKernelGGL(k_dt_policy, dim3(1), dim3(256), 0, c->stream, s->d_scal, dmin,
-                           (const int *)s->d_flag, s->d_dts, m, 0, (const double *)s->pend_part,
-                           s->pend_n, const_cast<double *>(dmin));
+        PYRO_LAUNCH(c, "k_dt_policy", k_dt_policy, dim3(1), dim3(256), 0, d_scal0, dmin,
+                    (const int *)s->d_flag, s->d_dts, m, 0, (const double *)s->pend_part,
+                    s->pend_n, const_cast<double *>(dmin), 1);
         s->pend_part = nullptr;
         s->next_cfl_min = 1.0;      // "cached on the device": keeps a posted halo exchange valid
+        s->pol_next = d_pol;    // (one launch per step: this is step 0, its dt is in S[0])
+        s->pol_m = 0;
         if (wave)
-            rc = p->fast_math ? fastm::comp_step_wave_ex(s, p, 0.0, s->d_scal, &dmin)
-                              : exact::comp_step_wave_ex(s, p, 0.0, s->d_scal, &dmin);
+            rc = p->fast_math ? fastm::comp_step_wave_ex(s, p, 0.0, d_scal0, &dmin)
+                              : exact::comp_step_wave_ex(s, p, 0.0, d_scal0, &dmin);
         else
             rc = p->fast_math ? fastm::comp_step_fused_ex(s, &pf, 0.0, s->d_scal, &dmin)
                               : exact::comp_step_fused_ex(s, &pf, 0.0, s->d_scal, &dmin);
     }
     s->frame_prefilled = false;      // (an iteration that stopped between the fill and its step)
+    s->pol_next = nullptr;
     PYRO_TRY(rc);
-    hipLaunchKernelGGL(k_dt_policy, dim3(1), dim3(256), 0, c->stream, s->d_scal, dmin,
+    // the closing policy call (one launch per step: on the scalars of the last step's parity,
+    // with the minimum of the slots the last launch filled -- unused words hold +inf)
+    StepScalars *const d_scalN = one_launch ? &d_pol->S[(max_steps - 1) & 1] : s->d_scal;
+    if (one_launch) {
+        s->pend_part = (double *)(s->d_polmem + (size_t)((max_steps - 1) % 3) * pyro::kPolSetWords);
+        s->pend_n = pyro::kPolSetWords;
+        dmin = (const double *)(s->d_polmem + 3 * (size_t)pyro::kPolSetWords);
+    }
+    hipLaunchKernelGGL(k_dt_policy, dim3(1), dim3(256), 0, c->stream, d_scalN, dmin,
                        (const int *)s->d_flag, s->d_dts, max_steps, 1, (const double *)s->pend_part,
-                       s->pend_n, const_cast<double *>(dmin));
+                       s->pend_n, const_cast<double *>(dmin),
+                       one_launch ? (2 << ((max_steps - 1) & 1)) : 1);
     s->pend_part = nullptr;
     PYRO_CHECK_HIP(hipGetLastError());
     // the last step's halo exchange (posted on the halo stream) must have landed before
@@ -296,7 +325,7 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
     // the one round trip of the call: scalars, flag, last CFL minimum, the dt sequence
     char *hb = (char *)c->reduce_host;                       // 256 pinned bytes
     static_assert(sizeof(StepScalars) + 16 <= 256, "pinned scratch");
-    PYRO_CHECK_HIP(hipMemcpyAsync(hb, s->d_scal, sizeof(StepScalars), hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipMemcpyAsync(hb, d_scalN, sizeof(StepScalars), hipMemcpyDeviceToHost, c->stream));
     PYRO_CHECK_HIP(hipMemcpyAsync(hb + sizeof(StepScalars), s->d_flag, sizeof(int),
                                   hipMemcpyDeviceToHost, c->stream));
     PYRO_CHECK_HIP(hipMemcpyAsync(hb + sizeof(StepScalars) + 8, dmin, sizeof(double),
@@ -306,7 +335,8 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
                                       hipMemcpyDeviceToHost, c->stream));
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
     memcpy(&H, hb, sizeof(H));
-    const int flagv = *(int *)(hb + sizeof(StepScalars));
+    // (a one-launch run raises per-launch bits of the flag; the policy keeps the verdict)
+    const int flagv = (*(int *)(hb + sizeof(StepScalars)) & 1) | (H.dead ? 1 : 0);
     const double lastmin = *(double *)(hb + sizeof(StepScalars) + 8);
     // max_steps swaps were made; the last state that advanced sits H.steps swaps from the start
     if ((max_steps - H.steps) % 2) {
@@ -316,6 +346,19 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
         s->d = s->base + geom_lead(s->g);
     }
     s->halo_pending = false;
+    if (one_launch && H.steps >= 1) {
+        // the steps read their ghost cells through the boundary rules and wrote none: the final
+        // state's ghost cells hold the filled ghost cells of the state before its last step, like
+        // the reference's array after evolve() -- that state sits untouched in the other buffer
+        // (after an invalid step the other buffer is that step's debris: the state's own images)
+        const Geom &g = s->g;
+        const int rows_per_block = 256 / (2 * g.ng);
+        const int nblk = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + rows_per_block - 1) / rows_per_block;
+        const double *src = (flagv & 1) ? s->d : s->alt_base + geom_lead(g);
+        PYRO_LAUNCH(c, "k_fill_frame2", k_fill_frame2, dim3(nblk), dim3(256), 0, src, s->d,
+                    (double *)nullptr, g, (const int *)s->d_bc);
+        PYRO_CHECK_HIP(hipGetLastError());
+    }
     // the minimum of the last launch belongs to the state only if that launch advanced it
     s->next_cfl_min = (H.steps == max_steps && !(flagv & 1)) ? lastmin : -1.0;
     if (s->next_cfl_min <= 0.0) s->cfl_is_global = false;

@@ -54,15 +54,6 @@ constexpr size_t FLDS_BYTES = (size_t)FLDS_DOUBLES * sizeof(double);
 
 #include "fused_common.h"
 
-// parity of a 4-bit set of sides
-__device__ __forceinline__ bool odd_sides(unsigned m)
-{
-    m &= 15u;
-    m ^= m >> 2;
-    m ^= m >> 1;
-    return (m & 1u) != 0;
-}
-
 // Cell (gi, gj) of the old state as fill_BC_all leaves it: a ghost cell is read from the
 // cell its boundary rule copies from (x fill, then y fill: both maps; itself without
 // fuse_fill), with the sign of the variables that reflect oddly on the sides crossed.
@@ -453,6 +444,7 @@ int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP 
     P.mr = bc_map(g.ilo, g.ihi, g.ng, 0, 0, false);      // identity (tile kernel: fused_fill_maps)
     P.mc = P.mr;
     P.odd = 0;
+    P.pol = nullptr; P.pol_m = 0; P.pol_pre = 0;
     if (reset_flag) PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
     return 0;
 }

@@ -52,6 +52,17 @@ namespace PYRO_NS {
 
 #include "fused_common.h"
 
+// a value another launch left in device memory by atomics (performed at memory, past the L2s)
+template <class T>
+__device__ __forceinline__ T dev_load(const T *p)
+{
+#if defined(PYRO_EMU)
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 constexpr int WOUT = 56;          // columns a wavefront updates
 // stage boundary: the scheduler may not move instructions across it.  The
 // stages are written in the order that keeps the live ranges short (a value is
@@ -204,7 +215,10 @@ __device__ __forceinline__ void st_put(double *st, int s, const Cons &U)
 // k = -div F + S stored in place of the new state (Uout = four planes of the k state; the
 // arithmetic of the staged k_rk_states / k_rk_flux / k_rk_rhs of compressible.hip, expression by
 // expression).  No sponge (the staged set carries it).
-template <int SOLVER, bool STD, bool MOL = false>   // SOLVER, STD as k_ctu_fused
+// ONE: this launch is the whole step of a device-side run (pyrohip_comp_evolve, comp_api.hip):
+// ghost cells are read through the boundary rules (no filled frame) and the last wavefront to
+// finish runs the driver's dt policy for the next step.
+template <int SOLVER, bool STD, bool MOL = false, bool ONE = false>   // SOLVER, STD as k_ctu_fused
 __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *__restrict__ Uin,
                                                                  double *__restrict__ Uout, Geom g,
                                                                  FP P, int *__restrict__ flag,
@@ -238,10 +252,51 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     // face states as they are (hllc_flux_impl<true>)
     constexpr bool TQ = (PYRO_FAST != 0) && (SOLVER == 0) && !MOL;
     UniformTab ct = (UniformTab)(lds + ST_SLOTS * 64);
-    if (S && !S->active) {
+    // this step's dt and its quotients: by value (single steps), from the step scalars in device
+    // memory (device-side run, k_dt_policy between the launches), or -- ONE -- derived here from
+    // the previous launch's CFL minima (common.h: StepPolicy)
+    double v_dt = P.dt, v_dtdx = P.dtdx, v_dtdy = P.dtdy, v_hdtV = P.hdtV, v_dtdV = P.dtdV;
+    bool active = true;
+    if (ONE) {
+        StepPolicy *const pol = P.pol;
+        const int m = P.pol_m;
+        if (P.pol_pre) {
+            const StepScalars *Sm = &pol->S[m & 1];
+            v_dt = Sm->dt; v_dtdx = Sm->dtdx; v_dtdy = Sm->dtdy; v_hdtV = Sm->hdtV; v_dtdV = Sm->dtdV;
+            active = Sm->active != 0;
+        } else {
+            StepScalars L = pol->S[(m - 1) & 1];
+            const unsigned long long *prev = pol->slots + (size_t)((m - 1) % 3) * kPolSetWords;
+            const double cmin = __shfl(wave_reduce_min(__longlong_as_double(
+                                           (long long)dev_load(&prev[(size_t)l * kPolStride]))), 0, 64);
+            double dtm;
+            dt_policy_apply(&L, cmin, (dev_load(flag) & (2 << ((m - 1) & 1))) != 0, &dtm, 0, 0);
+            if (unit == 0) {     // the books, and the slots of the launch after this one
+                atomicExch(&pol->slots[(size_t)((m + 1) % 3) * kPolSetWords + (size_t)l * kPolStride],
+                           (unsigned long long)__double_as_longlong((double)INFINITY));
+                if (l == 0) { pol->S[m & 1] = L; pol->dts[m] = dtm; }
+            }
+            v_dt = L.dt; v_dtdx = L.dtdx; v_dtdy = L.dtdy; v_hdtV = L.hdtV; v_dtdV = L.dtdV;
+            active = L.active != 0;
+        }
+    } else if (S) {
+        v_dt = S->dt; v_dtdx = S->dtdx; v_dtdy = S->dtdy; v_hdtV = S->hdtV; v_dtdV = S->dtdV;
+        active = S->active != 0;
+    }
+    // the wavefront's CFL minimum (in every lane) and its positivity flag at the end
+    auto finish = [&](double cfl, bool bad) {
+        if (bad) atomicOr(flag, ONE ? (2 << (P.pol_m & 1)) : 1);
+        if (l != 0) return;
+        if (ONE)
+            atomicMin(P.pol->slots + (size_t)(P.pol_m % 3) * kPolSetWords + (size_t)(unit % kPolSlots) * kPolStride,
+                      (unsigned long long)__double_as_longlong(cfl));
+        else
+            partial[sb * P.ncb + cb] = cfl;
+    };
+    if (!active) {
         // device-side run, past tmax or after an invalid state: nothing happens (the
         // host picks the buffer that holds the last state that did advance, comp_evolve)
-        if (l == 0) partial[sb * P.ncb + cb] = INFINITY;
+        if (!ONE) finish(INFINITY, false);
         return;
     }
 #if PYRO_FAST && !defined(PYRO_EMU)
@@ -251,36 +306,57 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
                                 __builtin_amdgcn_readfirstlane(__double2loint(v)));
     };
-    const double s_dtdx = S ? S->dtdx : P.dtdx, s_dtdy = S ? S->dtdy : P.dtdy;
-    const double s_hdtV = S ? S->hdtV : P.hdtV, s_dtdV = S ? S->dtdV : P.dtdV;
+    // (ONE: uniform values out of vector arithmetic)
+    const double s_dtdx = ONE ? sgpr(v_dtdx) : v_dtdx, s_dtdy = ONE ? sgpr(v_dtdy) : v_dtdy;
+    const double s_hdtV = ONE ? sgpr(v_hdtV) : v_hdtV, s_dtdV = ONE ? sgpr(v_dtdV) : v_dtdV;
     const double s_kx = sgpr(-s_hdtV * P.dy), s_ky = sgpr(-s_hdtV * P.dx);
     const double s_cx = sgpr(s_dtdV * P.dy), s_cy = sgpr(s_dtdV * P.dx);
     const double s_cvdx = sgpr(P.cvisc * P.dx), s_cvdy = sgpr(P.cvisc * P.dy);
 #endif
     if (l == 0) {     // one wavefront, LDS operations complete in order: no barrier needed
         // (device-side run: this step's dt and its quotients live in device memory)
-        ct[C_GAMMA] = P.gamma; ct[C_DX] = P.dx; ct[C_DY] = P.dy; ct[C_DT] = S ? S->dt : P.dt;
+        ct[C_GAMMA] = P.gamma; ct[C_DX] = P.dx; ct[C_DY] = P.dy; ct[C_DT] = v_dt;
         ct[C_Z0] = P.z0; ct[C_Z1] = P.z1; ct[C_DELTA] = P.delta; ct[C_CVISC] = P.cvisc;
         ct[C_SMALLD] = P.small_dens;
-        ct[C_DTDX] = S ? S->dtdx : P.dtdx; ct[C_DTDY] = S ? S->dtdy : P.dtdy;
-        ct[C_HDTV] = S ? S->hdtV : P.hdtV; ct[C_DTDV] = S ? S->dtdV : P.dtdV;
+        ct[C_DTDX] = v_dtdx; ct[C_DTDY] = v_dtdy;
+        ct[C_HDTV] = v_hdtV; ct[C_DTDV] = v_dtdV;
         ct[C_GRAV] = P.grav; ct[C_HEATR] = P.heat_rate;
         ct[C_GM1] = P.gamma - 1.0; ct[C_RGM1] = prcp(P.gamma - 1.0);
         ct[C_RDX] = prcp(P.dx); ct[C_RDY] = prcp(P.dy);
         const GasK K0 = make_gask(P.gamma);
         ct[C_KSL] = K0.ksl; ct[C_KSR] = K0.ksr; ct[C_RGP1] = K0.rgp1;
 #if PYRO_FAST
-        const double hdtV = S ? S->hdtV : P.hdtV, dtdV = S ? S->dtdV : P.dtdV;
+        const double hdtV = v_hdtV, dtdV = v_dtdV;
         ct[C_KX] = -hdtV * P.dy; ct[C_KY] = -hdtV * P.dx;
         ct[C_CX] = dtdV * P.dy; ct[C_CY] = dtdV * P.dx;
         ct[C_CVDX] = P.cvisc * P.dx; ct[C_CVDY] = P.cvisc * P.dy;
 #endif
     }
+#if defined(PYRO_EMU)
+    // (the emulator's lanes are fibers that run ahead of each other between two shuffles: after
+    // the shuffles of the dt policy above, lane 0 need not be the first to go on)
+    if (ONE) hipemu::wave_barrier();
+#endif
 
+    // ONE: a ghost cell is read from the cell its boundary rule copies from (x rule, then y rule:
+    // array_indexer.py:163-274), with the sign of the variables that reflect oddly -- what
+    // fill_BC_all would have left in it, so the frame of Uin need not be filled.  The sign is
+    // applied where the row is consumed, an iteration after its load (fix_sign).
+    const int jsrc = ONE ? bc_src(P.mc, jc, g.jlo, g.jhi) : jc;
     auto loadU = [&](int row) {
         row = row < 0 ? 0 : (row > g.qx - 1 ? g.qx - 1 : row);
-        const size_t kk = (size_t)row * p + jc;
+        const int srow = ONE ? bc_src(P.mr, row, g.ilo, g.ihi) : row;
+        const size_t kk = (size_t)srow * p + jsrc;
         return Cons{Uin[kk], Uin[pl + kk], Uin[2 * pl + kk], Uin[3 * pl + kk]};
+    };
+    auto fix_sign = [&](Cons &U, int row) {
+        if (!ONE || !P.odd) return;
+        const unsigned sd = (j < g.jlo ? 4u : 0u) | (j > g.jhi ? 8u : 0u) |
+                            (row < g.ilo ? 1u : 0u) | (row > g.ihi ? 2u : 0u);
+        U.d = odd_sides(P.odd & sd) ? -U.d : U.d;
+        U.E = odd_sides((P.odd >> 4) & sd) ? -U.E : U.E;
+        U.mx = odd_sides((P.odd >> 8) & sd) ? -U.mx : U.mx;
+        U.my = odd_sides((P.odd >> 12) & sd) ? -U.my : U.my;
     };
     auto row_in = [&](int r) { return r >= g.ilo && r <= g.ihi; };
     // (un, ut, p) of a conserved face state in the normal frame, as HLLC derives them
@@ -338,6 +414,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         }
         Uem = Ue;
         Ue = Urep;
+        fix_sign(Ue, k - 3);
         if (row_in(k - 3) && jin) Ue.d = fmax(Ue.d, US(SMALLD, P.small_dens));      // clean_state
         // (issuing this second read of row k-2 in the middle of the iteration instead -- eight
         // registers less while the slopes and the first Riemann problems are worked on -- was
@@ -346,6 +423,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         // ---- S0: row k -> primitives
         {
             Cons U = Upre;
+            fix_sign(U, k);
             Upre = loadU(k + 1);
             const bool interior = row_in(k) && jin;
             if (MOL && interior && U.d < US(SMALLD, P.small_dens))     // clean_state works in place
@@ -647,8 +725,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     // min over the lane's cells of min(dx / (|u| + c), dy / (|v| + c)), cfl_cell()
     const double ax = st[ST_AX * 64], ay = st[ST_AY * 64];
     double cfl = fmin(ax > 0.0 ? pdiv(P.dx, ax) : INFINITY, ay > 0.0 ? pdiv(P.dy, ay) : INFINITY);
-    cfl = wave_reduce_min(cfl);
-    if (l == 0) partial[sb * P.ncb + cb] = cfl;
+    finish(__shfl(wave_reduce_min(cfl), 0, 64), bad);
 }
 
 // Rows per strip (a strip costs L + 8 iterations, of which the 8 warm-up ones are cheap: ~3 % of
@@ -772,6 +849,30 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
     }
     P.nunits = nwg;
     P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus);
+    if (S && s->pol_next && !post) {
+        // this launch is the whole step (pyrohip_comp_evolve): ghost cells read through the
+        // boundary rules, the dt policy of the next step run by the last wavefront to finish
+        static const KernelT kernels_one[3][2] = {
+            {k_ctu_wave<0, false, false, true>, k_ctu_wave<0, true, false, true>},
+            {k_ctu_wave<1, false, false, true>, k_ctu_wave<1, true, false, true>},
+            {k_ctu_wave<2, false, false, true>, k_ctu_wave<2, true, false, true>}};
+        P.pol = s->pol_next;
+        P.pol_m = s->pol_m;
+        P.pol_pre = (s->pol_m == 0) ? 1 : 0;
+        P.mr = bc_map(g.ilo, g.ihi, g.ng, s->bc[0], s->bc[1], true);
+        P.mc = bc_map(g.jlo, g.jhi, g.ng, s->bc[2], s->bc[3], true);
+        for (int n = 0; n < 4; n++)
+            for (int sd = 0; sd < 4; sd++)
+                if (s->bc[n * 4 + sd] == PYROHIP_BC_REFLECT_ODD) P.odd |= 1u << (4 * n + sd);
+        PYRO_LAUNCH(c, "k_ctu_wave", kernels_one[solver][std_rec], dim3(8 * ((nwg + 7) / 8)), dim3(64),
+                    WLDS_BYTES, (const double *)Uin, Uout, g, P, s->d_flag, part, S);
+        PYRO_CHECK_HIP(hipGetLastError());
+        s->frame_prefilled = false;
+        fused_swap(s);
+        *dmin_out = (const double *)(s->d_polmem + 3 * kPolSetWords);
+        s->halo_pending = false;
+        return 0;
+    }
     PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((nwg + 7) / 8)), dim3(64), WLDS_BYTES,
                 (const double *)Uin, Uout, g, P, s->d_flag, part, S);
     if (post) {        // too few strips to overlap: the exchange follows the whole update

@@ -474,6 +474,7 @@ int pyrohip_state_destroy(pyrohip_state *s)
     (void)comm_wait_halo(s);          // a receive may still be writing the ghost rows
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->d_scal) (void)hipFree(s->d_scal);
+    if (s->d_polmem) (void)hipFree(s->d_polmem);
     if (s->d_dts) (void)hipFree(s->d_dts);
     if (s->base) (void)hipFree(s->base);
     if (s->alt_base) (void)hipFree(s->alt_base);

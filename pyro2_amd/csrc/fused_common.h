@@ -32,7 +32,22 @@ struct FP {   // kernel parameters
     // side, whether the ghost value changes sign (bit 4 n + side)
     BcMap mr, mc;
     unsigned odd;
+    // row-marching kernel as the only launch of a step (pyrohip_comp_evolve, k_ctu_wave<.., ONE>):
+    // ghost cells are READ through mr / mc / odd (no filled frame), and every wavefront derives
+    // this step's dt from the previous launch's CFL minima itself (common.h: StepPolicy)
+    StepPolicy *pol;          // (device memory)
+    int pol_m;                // step of the call this launch is
+    int pol_pre;              // S[pol_m & 1] is this step's already (k_dt_policy ran: step 0)
 };
+
+// parity of a 4-bit set of sides
+__device__ __forceinline__ bool odd_sides(unsigned m)
+{
+    m &= 15u;
+    m ^= m >> 2;
+    m ^= m >> 1;
+    return (m & 1u) != 0;
+}
 
 // host side, defined in comp_fused.hip
 __global__ void k_copy_frame4(const double *__restrict__ src, double *__restrict__ dst, Geom g);

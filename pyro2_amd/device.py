@@ -497,7 +497,7 @@ def make_comp_params(dx, dy, gamma=1.4, limiter=2, use_flattening=1, z0=0.75,
                      small_dens=-1.e200, avisc_xhi_interior=0,
                      avisc_yhi_interior=0, fast_math=0, kernel_set=0, riemann="HLLC",
                      solid_xl=0, solid_yl=0, sponge=None, heat_rate=0.0, march_rows=0,
-                     fuse_fill=0):
+                     fuse_fill=0, step_launches=0):
     p = CompParams()
     p.dx, p.dy, p.gamma = dx, dy, gamma
     p.limiter, p.use_flattening = int(limiter), int(use_flattening)
@@ -514,6 +514,7 @@ def make_comp_params(dx, dy, gamma=1.4, limiter=2, use_flattening=1, z0=0.75,
     p.heat_rate = float(heat_rate)     # used when the state carries a heating profile
     p.march_rows = int(march_rows)     # kernel_set 2 only; 0 = automatic
     p.fuse_fill = int(fuse_fill)       # 1: the step applies the boundary rules itself
+    p.step_launches = int(step_launches)   # comp_evolve, row-marching kernel: 1 = one launch per step, 3 (= 0) = fill / policy / step
     return p
 
 

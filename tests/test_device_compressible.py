@@ -47,7 +47,10 @@ FUSED_KSETS = [1, 2, 3]
 
 
 def kset_kw(kset):
-    """test id -> parameters: 3 = kernel_set 2 with short strips"""
+    """test id -> parameters: 3 = kernel_set 2 with short strips, 4 = the same with the step
+    kernel as the only launch of a step of pyrohip_comp_evolve"""
+    if kset == 4:
+        return dict(kernel_set=2, march_rows=11, step_launches=1)
     return dict(kernel_set=2, march_rows=11) if kset == 3 else dict(kernel_set=kset)
 
 
@@ -318,7 +321,7 @@ def test_comp_wave_short_last_strip(dev, nx, nb):
     assert max_rel_err(U[4:-4, 4:-4], Uo[4:-4, 4:-4]) <= tol
 
 
-@pytest.mark.parametrize("kset", [1, 3])
+@pytest.mark.parametrize("kset", [1, 3, 4])
 def test_comp_evolve_on_device(dev, golden, kset):
     """pyrohip_comp_evolve: the run_sim loop (ghost fill, the driver's dt policy,
     evolve) enqueued on the device without a host round trip per step, against the
@@ -376,15 +379,21 @@ def test_comp_evolve_on_device(dev, golden, kset):
     assert np.array_equal(s.download()[4:-4, 4:-4], bad[4:-4, 4:-4])
 
 
+@pytest.mark.parametrize("launches", [1, 3])
 @pytest.mark.parametrize("bcs", [("outflow", "outflow", "outflow", "outflow"),
                                  ("reflect", "outflow", "periodic", "periodic"),
                                  ("periodic", "periodic", "reflect", "reflect"),
                                  ("outflow", "reflect", "reflect", "outflow")])
-def test_comp_evolve_wave_fill_and_frame(dev, golden, bcs):
-    """device-side stepping with the row-marching kernel: one launch fills the ghost cells of
-    the state AND writes the other buffer's ghost frame (comp_api.hip: k_fill_frame2; corners
-    through the x rule and then the y rule), the policy kernel takes the minimum of the
-    wavefronts' CFL partials itself -- against the same steps taken one by one (two fill
+def test_comp_evolve_wave_fill_and_frame(dev, golden, bcs, launches):
+    """device-side stepping with the row-marching kernel.  launches = 3: one launch fills the
+    ghost cells of the state AND writes the other buffer's ghost frame (comp_api.hip:
+    k_fill_frame2; corners through the x rule and then the y rule), the policy kernel takes the
+    minimum of the wavefronts' CFL partials itself (the default).  launches = 1: the step kernel
+    is the ONLY launch of a step -- it reads ghost cells through the boundary rules (index maps,
+    odd reflections' signs) instead of a filled frame, its wavefronts fold their CFL minima
+    into 64 slots by atomic minimum and every wavefront of the next launch runs the driver's dt
+    policy on them (k_ctu_wave<.., ONE>); the final state's ghost cells are filled once at the
+    end from the state before its last step.  Both against the same steps taken one by one (two fill
     launches, frame copy, reduction launches): dt sequence and the WHOLE array, ghost frame
     and corners included, bit for bit"""
     from helpers import DtPolicy
@@ -397,8 +406,8 @@ def test_comp_evolve_wave_fill_and_frame(dev, golden, bcs):
     nsteps = 7
     kw = dict(kernel_set=2, march_rows=13)
     Uref, dref, tref = device_comp_run(dev, ic, meta, list(bcs), 0.1, nsteps, **kw)
-    P, cfl = dev_params(meta, **kw)
-    for chunks in ((nsteps,), (3, 4)):
+    P, cfl = dev_params(meta, step_launches=launches, **kw)
+    for chunks in ((nsteps,), (3, 4), (1, 1, 5)):
         s = comp_state(dev, 64, 64, list(bcs))
         s.upload(ic)
         pol, dts = DtPolicy(0.1), []
