@@ -295,6 +295,12 @@ def bench_sedov(args, dist, ctx, device, defaults, steps=None, warmup=None, tile
     ev_ms = ctx.timer_stop()
     dist.barrier()
     elapsed = dist.max(t1 - t0)
+    if collect:
+        # scale check: the state after exactly `steps` steps (the profiling steps below are as
+        # many as the elapsed time allows -- a count that differs between the N-rank run and the
+        # single-domain one; found by running two ranks on one GPU)
+        snap = {"interior": st.download()[ng:-ng, ng:-ng].copy(), "rows": (dec.i0, dec.nx_local),
+                "t": pol.t}
     # the kernels' own durations: more steps with the library's HIP events around every
     # launch, OUTSIDE the timed region (the events cost ~4 us per launch: nothing against the
     # 9.5 ms kernel of the headline, 2-7 % of a 4096^2 step)
@@ -310,8 +316,7 @@ def bench_sedov(args, dist, ctx, device, defaults, steps=None, warmup=None, tile
            "rows_local": dec.nx_local,
            "prof_steps": nprof, "dt_policy": "device" if device_dt else "host"}
     if collect:
-        res["interior"] = st.download()[ng:-ng, ng:-ng].copy()
-        res["rows"] = (dec.i0, dec.nx_local)
+        res.update(snap)
     del slab, st
     return res
 
@@ -420,9 +425,20 @@ def scale_check(args, dist, ctx, device, defaults, nx=2048, steps=12):
     same = bool(np.array_equal(rn["interior"], r1["interior"][i0:i0 + n])) and rn["t"] == r1["t"]
     bad = dist.max(0.0 if same else 1.0)
     if bad > 0.0:
+        what = "identical"
+        if not same:     # where, and by how much: the first thing anyone will ask
+            a, b = rn["interior"], r1["interior"][i0:i0 + n]
+            w = np.argwhere(a != b)
+            what = f"DIFFERENT: t {rn['t']!r} vs {r1['t']!r}; {len(w)} of {a.size} values differ"
+            if len(w):
+                r, c, v = (int(x) for x in w[0])
+                rl, cl, vl = (int(x) for x in w[-1])
+                what += (f", rows {int(w[:, 0].min())}..{int(w[:, 0].max())} of the slab's {n} (global row "
+                         f"{i0} + that), columns {int(w[:, 1].min())}..{int(w[:, 1].max())}; first at "
+                         f"[{r}, {c}, {v}]: {a[r, c, v]!r} vs {b[r, c, v]!r}; last at [{rl}, {cl}, {vl}]: "
+                         f"{a[rl, cl, vl]!r} vs {b[rl, cl, vl]!r}")
         sys.exit(f"bench.py rank {dist.rank}: FATAL: scale check failed: sedov {nx}^2 x {steps} steps on "
-                 f"{dist.world} ranks differs from the single-domain run (this rank: "
-                 f"{'identical' if same else 'DIFFERENT'})")
+                 f"{dist.world} ranks differs from the single-domain run (this rank: {what})")
     return {"workload": f"sedov {nx}x{nx}, {steps} steps, {dist.world} ranks vs 1 rank, kernel_set 2, "
                         f"fast_math {d['fast_math']}", "bit_identical": True, "sim_time": rn["t"]}
 
@@ -829,7 +845,14 @@ def main():
               "this run checks the multi-rank path, its number is NOT a scaling result "
               "(flagged as config.oversubscribed)", file=sys.stderr)
     # one rank per GPU; several ranks on one GPU only happens when debugging
-    # the launcher on a smaller box and is flagged in the output
+    # the launcher on a smaller box and is flagged in the output.  RCCL refuses two ranks on
+    # one device of one host ("Duplicate GPU detected"): each rank then names itself a host of
+    # its own (NCCL_HOSTID), and the communicator runs over the socket transport on lo -- the
+    # same RCCL calls, streams and events as on a node, none of its bandwidth
+    if dist.oversubscribed:
+        os.environ.setdefault("NCCL_HOSTID", f"pyro2amd-rank{dist.rank}")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
+        os.environ.setdefault("NCCL_P2P_DISABLE", "1")
     ctx = device.Context(dist.local_rank % ndev)
     dist.comm_kind, dist.comm_note = "rccl", None
     want_comm = os.environ.get("PYRO_BENCH_COMM", "rccl")

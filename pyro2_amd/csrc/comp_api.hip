@@ -296,6 +296,15 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
             rc = p->fast_math ? fastm::comp_cfl_min_device(s, p, &dmin)
                               : exact::comp_cfl_min_device(s, p, &dmin);
             if (rc) break;
+            // decomposed run: every rank steps with the minimum over ALL slabs -- also in the
+            // first step of a call (found by running four ranks on one GPU: the slabs far from
+            // the blast started every call with their own, larger dt; with two ranks the two
+            // local minima are equal by symmetry and nothing showed)
+            if (c->global_cfl) {
+                rc = comm_allreduce_min_device(c, const_cast<double *>(dmin));
+                if (rc) break;
+                s->cfl_is_global = true;
+            }
             first = false;
         }
         // (the minimum of the previous tile-kernel launch is taken here: pend_part)

@@ -133,6 +133,44 @@ def test_rccl_overlapped_halo_self_neighbour(hip):
     assert np.array_equal(s.download()[ng:-ng, ng:-ng], ref)
 
 
+def _rank_device(dv, rank, world):
+    """GPU of a rank.  On a box with fewer GPUs than ranks the ranks share them: RCCL refuses
+    two ranks on one device of one host ("Duplicate GPU detected"), so each rank names itself a
+    host of its own (NCCL_HOSTID) and the communicator runs over RCCL's socket transport on lo
+    -- the same RCCL calls, streams and events as between two GPUs, none of the bandwidth."""
+    import os
+    ndev = dv.device_count()
+    if ndev < world:
+        os.environ["NCCL_HOSTID"] = f"pyro2amd-test-rank{rank}"
+        os.environ["NCCL_IB_DISABLE"] = "1"
+        os.environ["NCCL_P2P_DISABLE"] = "1"
+    return rank % ndev
+
+
+def _run_two_ranks(fn, args, timeout=240.0, nprocs=2):
+    """two ranks of `fn`, bounded in time (a communicator that does not come up must not hang
+    the suite): None, or what went wrong.  With one GPU that is a skip, with two a failure."""
+    import time
+    import torch.multiprocessing as mp
+    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    t0 = time.time()
+    err = None
+    try:
+        while not ctx.join(timeout=5.0):
+            if time.time() - t0 > timeout:
+                err = f"no result after {timeout:.0f} s"
+                break
+    except Exception as e:      # noqa: BLE001  (a rank raised: torch re-raises it here)
+        err = f"{type(e).__name__}: {str(e)[-400:]}"
+    if err is not None:
+        for pr in ctx.processes:
+            if pr.is_alive():
+                pr.kill()
+        if device.device_count() < nprocs:
+            pytest.skip("RCCL ranks sharing a GPU (socket transport) did not run here: " + err)
+        pytest.fail(err)
+
+
 def _rccl_rank(rank, world, port, out_dir):
     """one rank of the 2-GPU test below"""
     import os
@@ -148,7 +186,7 @@ def _rccl_rank(rank, world, port, out_dir):
     from pyro2_amd import device as dv
     from pyro2_amd.decomp import DtPolicy, RcclComm, SlabCompressible, SlabDecomp
     from sedov_ic import sedov_ic
-    ctx = dv.Context(rank)
+    ctx = dv.Context(_rank_device(dv, rank, world))
     t = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
         t = torch.frombuffer(bytearray(dv.Context.comm_unique_id()), dtype=torch.uint8).clone()
@@ -173,9 +211,8 @@ def _rccl_rank(rank, world, port, out_dir):
 def test_rccl_two_ranks_bit_identical(hip, tmp_path):
     """2 GPUs, one process each, x slabs exchanged over RCCL (overlapped with the
     interior update) and the dt all-reduced on the device: bit-identical to the
-    single-GPU run.  Skipped on boxes with one GPU."""
-    if device.device_count() < 2:
-        pytest.skip("needs 2 GPUs")
+    single-GPU run.  On a box with one GPU the two ranks share it and RCCL runs
+    over its socket transport (_rank_device): the protocol is the same."""
     import socket
     import sys, os
     import torch.multiprocessing as mp
@@ -185,7 +222,7 @@ def test_rccl_two_ranks_bit_identical(hip, tmp_path):
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    mp.spawn(_rccl_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    _run_two_ranks(_rccl_rank, (2, port, str(tmp_path)))
     nx, ng = 256, 4
     ic, meta, bcs = sedov_ic(nx, r_init=0.05)
     s = device.DeviceState(hip, nx, nx, ng, [["outflow"] * 4] * 4)
@@ -206,6 +243,83 @@ def test_rccl_two_ranks_bit_identical(hip, tmp_path):
         assert np.array_equal(d["U"][ng:-ng, ng:-ng], ref[a + ng:b - ng, ng:-ng]), r
 
 
+def _rccl_evolve_rank(rank, world, port, out_dir):
+    """one rank of the four-rank test below"""
+    import os
+    import sys
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from pyro2_amd import device as dv
+    from pyro2_amd.decomp import DtPolicy, RcclComm, SlabCompressible, SlabDecomp
+    from sedov_ic import sedov_ic
+    ctx = dv.Context(_rank_device(dv, rank, world))
+    t = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        t = torch.frombuffer(bytearray(dv.Context.comm_unique_id()), dtype=torch.uint8).clone()
+    td.broadcast(t, 0)
+    ctx.comm_init(world, rank, bytes(t.numpy().tobytes()))
+    nx = 256
+    ic, meta, bcs = sedov_ic(nx, r_init=0.05)
+    dec = SlabDecomp(nx, world, rank)
+    out = {}
+    for fm in (0, 1):
+        kw = dict(dx=1.0 / nx, dy=1.0 / nx, fast_math=fm, kernel_set=2, march_rows=16)
+        sl = SlabCompressible(ctx, dec, nx, bcs, kw, RcclComm(ctx))
+        a, b = dec.local_rows(4)
+        sl.state.upload(np.nan_to_num(ic)[a:b])
+        pol = DtPolicy(0.1)
+        dts = list(sl.evolve(pol, 0.8, 7)) + [sl.step(pol, 0.8) for _ in range(2)] + \
+            list(sl.evolve(pol, 0.8, 5))
+        out[f"U{fm}"] = sl.state.download()
+        out[f"dts{fm}"] = np.array(dts)
+        out[f"t{fm}"] = np.array(pol.t)
+        del sl
+    np.savez(os.path.join(out_dir, f"e{rank}.npz"), rows=np.array([a, b]), **out)
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_four_ranks_device_side_stepping(hip, tmp_path):
+    """FOUR ranks (sharing the box's GPUs: _rank_device), device-side stepping
+    (pyrohip_comp_evolve) in two calls with host-side steps between them, both builds: every
+    rank takes the dt of the GLOBAL CFL minimum -- also in the first step of a call, where the
+    minimum comes from a kernel of its own (comp_cfl_min_device) -- and the slabs equal the
+    single-domain run bit for bit.  With two ranks the blast sits on the cut and both local
+    minima are equal: the outer slabs of four see ambient gas only, their own minimum is 40 x
+    larger (found on hardware in round 4, profiles/r04_rccl_ranks_one_gpu.txt)."""
+    import socket
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from sedov_ic import sedov_ic
+    from pyro2_amd.decomp import DtPolicy
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    _run_two_ranks(_rccl_evolve_rank, (4, port, str(tmp_path)), timeout=300.0, nprocs=4)
+    nx, ng = 256, 4
+    ic, meta, bcs = sedov_ic(nx, r_init=0.05)
+    for fm in (0, 1):
+        s = device.DeviceState(hip, nx, nx, ng, [["outflow"] * 4] * 4)
+        s.upload(np.nan_to_num(ic))
+        P = device.make_comp_params(1.0 / nx, 1.0 / nx, fast_math=fm, kernel_set=2, march_rows=16)
+        pol = DtPolicy(0.1)
+        dts = list(s.comp_evolve(P, 0.8, pol, 14))
+        ref = s.download()
+        for r in range(4):
+            d = np.load(os.path.join(str(tmp_path), f"e{r}.npz"))
+            assert list(d[f"dts{fm}"]) == dts, (fm, r)
+            assert float(d[f"t{fm}"]) == pol.t, (fm, r)
+            a, b = d["rows"]
+            assert np.array_equal(d[f"U{fm}"][ng:-ng, ng:-ng], ref[a + ng:b - ng, ng:-ng]), (fm, r)
+
+
 def _rccl_mg_rank(rank, world, port, out_dir):
     """one rank of the 2-GPU multigrid test below"""
     import os
@@ -219,7 +333,7 @@ def _rccl_mg_rank(rank, world, port, out_dir):
     td.init_process_group("gloo", rank=rank, world_size=world)
     from pyro2_amd import device as dv
     from pyro2_amd.multigrid.slab import RcclRowComm, SlabMG
-    ctx = dv.Context(rank)
+    ctx = dv.Context(_rank_device(dv, rank, world))
     t = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
         t = torch.frombuffer(bytearray(dv.Context.comm_unique_id()), dtype=torch.uint8).clone()
@@ -243,11 +357,9 @@ def _rccl_mg_rank(rank, world, port, out_dir):
 def test_rccl_multigrid_slabs_two_ranks(hip, tmp_path):
     """2 GPUs: Poisson 2048^2 V-cycles, levels 2048^2..512^2 in x slabs with their halo
     rows over RCCL, 256^2 and below collapsed onto rank 0 -- bit-identical to the
-    single-GPU V-cycles.  Skipped on boxes with one GPU (the same SlabMG runs on one GPU
-    with host-staged rows in tests/test_device_multigrid.py and over gloo in
+    single-GPU V-cycles.  On a box with one GPU the two ranks share it (_rank_device; the same
+    SlabMG also runs with host-staged rows in tests/test_device_multigrid.py and over gloo in
     tests/test_decomp_gloo.py)."""
-    if device.device_count() < 2:
-        pytest.skip("needs 2 GPUs")
     import socket
     import torch.multiprocessing as mp
     nx = 2048
@@ -260,7 +372,7 @@ def test_rccl_multigrid_slabs_two_ranks(hip, tmp_path):
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    mp.spawn(_rccl_mg_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    _run_two_ranks(_rccl_mg_rank, (2, port, str(tmp_path)))
     m = device.DeviceMG(hip, nx)
     L = m.nlevels - 1
     m.set(L, 0, v0)
