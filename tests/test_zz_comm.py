@@ -320,6 +320,85 @@ def test_rccl_four_ranks_device_side_stepping(hip, tmp_path):
             assert np.array_equal(d[f"U{fm}"][ng:-ng, ng:-ng], ref[a + ng:b - ng, ng:-ng]), (fm, r)
 
 
+def _periodic_ic(nx):
+    """Sedov blast moved off the centre onto the wrap-around cut of a grid periodic in x, plus
+    a smooth momentum field (no symmetry between the two slabs)"""
+    from sedov_ic import sedov_ic
+    ic, meta, _ = sedov_ic(nx, r_init=0.05)
+    U = np.nan_to_num(ic)[4:-4, 4:-4].copy()
+    U = np.roll(U, nx // 2 - 9, axis=0)
+    i = (np.arange(nx) + 0.5) / nx
+    U[:, :, 2] += 1.0e-2 * U[:, :, 0] * np.sin(2 * np.pi * i)[:, None]
+    U[:, :, 1] += 0.5 * 1.0e-4 * U[:, :, 0] * np.sin(2 * np.pi * i)[:, None] ** 2
+    full = np.zeros((nx + 8, nx + 8, 4))
+    full[4:-4, 4:-4] = U
+    return full
+
+
+def _rccl_periodic_rank(rank, world, port, out_dir):
+    """one rank of the periodic two-rank test below"""
+    import os
+    import sys
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from pyro2_amd import device as dv
+    from pyro2_amd.decomp import DtPolicy, RcclComm, SlabCompressible, SlabDecomp
+    ctx = dv.Context(_rank_device(dv, rank, world))
+    t = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        t = torch.frombuffer(bytearray(dv.Context.comm_unique_id()), dtype=torch.uint8).clone()
+    td.broadcast(t, 0)
+    ctx.comm_init(world, rank, bytes(t.numpy().tobytes()))
+    nx = 128
+    full = _periodic_ic(nx)
+    dec = SlabDecomp(nx, world, rank, periodic=True)
+    kw = dict(dx=1.0 / nx, dy=1.0 / nx, fast_math=0, kernel_set=2, march_rows=16)
+    sl = SlabCompressible(ctx, dec, nx, ["periodic", "periodic", "outflow", "outflow"], kw, RcclComm(ctx))
+    a, b = dec.local_rows(4)
+    sl.state.upload(full[a:b])
+    pol = DtPolicy(0.1)
+    dts = [sl.step(pol, 0.8) for _ in range(3)] + list(sl.evolve(pol, 0.8, 9))
+    np.savez(os.path.join(out_dir, f"p{rank}.npz"), U=sl.state.download(), dts=np.array(dts),
+             rows=np.array([a, b]))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_two_ranks_periodic_in_x(hip, tmp_path):
+    """two ranks on a grid periodic in x: BOTH neighbours of a rank are the other rank, and the
+    four transfers of an exchange between the pair are matched by their order alone (RCCL has no
+    tags; comm.hip: send low rows, receive high ghosts, send high rows, receive low ghosts).  A
+    blast on the wrap-around cut, host-side steps and device-side stepping: bit-identical to
+    the single-domain periodic run."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    _run_two_ranks(_rccl_periodic_rank, (2, port, str(tmp_path)))
+    nx, ng = 128, 4
+    full = _periodic_ic(nx)
+    from pyro2_amd.decomp import DtPolicy
+    s = device.DeviceState(hip, nx, nx, ng, [["periodic", "periodic", "outflow", "outflow"]] * 4)
+    s.upload(full)
+    P = device.make_comp_params(1.0 / nx, 1.0 / nx, fast_math=0, kernel_set=2, march_rows=16)
+    pol = DtPolicy(0.1)
+    dts = list(s.comp_evolve(P, 0.8, pol, 12))
+    ref = s.download()
+    assert np.abs(ref[ng:ng + 4, ng:-ng, 2]).max() > 1.0e-3      # the blast did cross the cut
+    for r in range(2):
+        d = np.load(os.path.join(str(tmp_path), f"p{r}.npz"))
+        assert list(d["dts"]) == dts, r
+        a, b = d["rows"]
+        assert np.array_equal(d["U"][ng:-ng, ng:-ng], ref[a + ng:b - ng, ng:-ng]), r
+
+
 def _rccl_mg_rank(rank, world, port, out_dir):
     """one rank of the 2-GPU multigrid test below"""
     import os
