@@ -433,8 +433,9 @@ def _rccl_mg_rank(rank, world, port, out_dir):
 
 
 @pytest.mark.gpu
-def test_rccl_multigrid_slabs_two_ranks(hip, tmp_path):
-    """2 GPUs: Poisson 2048^2 V-cycles, levels 2048^2..512^2 in x slabs with their halo
+@pytest.mark.parametrize("world", [2, 4])
+def test_rccl_multigrid_slabs_two_ranks(hip, tmp_path, world):
+    """2 (4: middle slabs with two neighbours) ranks: Poisson 2048^2 V-cycles, levels 2048^2..512^2 in x slabs with their halo
     rows over RCCL, 256^2 and below collapsed onto rank 0 -- bit-identical to the
     single-GPU V-cycles.  On a box with one GPU the two ranks share it (_rank_device; the same
     SlabMG also runs with host-staged rows in tests/test_device_multigrid.py and over gloo in
@@ -451,7 +452,7 @@ def test_rccl_multigrid_slabs_two_ranks(hip, tmp_path):
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    _run_two_ranks(_rccl_mg_rank, (2, port, str(tmp_path)))
+    _run_two_ranks(_rccl_mg_rank, (world, port, str(tmp_path)), nprocs=world)
     m = device.DeviceMG(hip, nx)
     L = m.nlevels - 1
     m.set(L, 0, v0)
@@ -461,7 +462,7 @@ def test_rccl_multigrid_slabs_two_ranks(hip, tmp_path):
             m.mark_zero(l)
         m.vcycle(L)
     ref = m.get(L, 0)
-    for r in range(2):
+    for r in range(world):
         d = np.load(os.path.join(str(tmp_path), f"mg{r}.npz"))
         a, b = d["rows"]
         assert np.array_equal(d["v"][:, 1:-1], ref[a:b + 1, 1:-1]), r
