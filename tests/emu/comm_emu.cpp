@@ -11,9 +11,17 @@ int pyrohip_halo_exchange(pyrohip_state *, int, int) { pyro::set_error("host-emu
 int pyrohip_allreduce_min(pyrohip_ctx *, double *) { return 0; }
 int pyrohip_allreduce_max(pyrohip_ctx *, double *) { return 0; }
 int pyrohip_allreduce_sum(pyrohip_ctx *, double *, int) { return 0; }
-int pyrohip_comm_set_global_dt(pyrohip_ctx *, int on)
+// Test hook: "the other ranks' CFL minimum".  With it set, the device-side all-reduce of the
+// step kernels' minimum (comm_allreduce_min_device) folds this value in, so a CPU test can see
+// whether EVERY dt of a device-side run -- the first one of a call included -- comes from the
+// global minimum (tests/test_device_compressible.py::test_comp_evolve_global_minimum_every_step;
+// the bug this pins was found on hardware in round 4).
+static double g_peer_min = -1.0;
+int pyrohip_emu_set_peer_min(double v) { g_peer_min = v; return 0; }
+int pyrohip_comm_set_global_dt(pyrohip_ctx *c, int on)
 {
-    if (on) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
+    if (on && !(g_peer_min > 0.0)) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
+    c->global_cfl = on != 0;
     return 0;
 }
 int pyrohip_mg_exchange_rows(pyrohip_mg *, int, int, int, int, int, int, int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
@@ -31,7 +39,11 @@ int pyrohip_state_set_neighbours(pyrohip_state *s, int lo, int hi)
 }
 }
 namespace pyro {
-int comm_allreduce_min_device(pyrohip_ctx *, double *) { return 0; }
+int comm_allreduce_min_device(pyrohip_ctx *, double *d)
+{
+    if (g_peer_min > 0.0 && g_peer_min < *d) *d = g_peer_min;    // (device memory is host memory here)
+    return 0;
+}
 bool comm_can_overlap(const pyrohip_state *) { return true; }
 int comm_post_halo(pyrohip_state *, double *) { return 0; }     // nothing to post: see above
 int comm_wait_halo(pyrohip_state *) { return 0; }

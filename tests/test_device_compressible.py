@@ -379,6 +379,48 @@ def test_comp_evolve_on_device(dev, golden, kset):
     assert np.array_equal(s.download()[4:-4, 4:-4], bad[4:-4, 4:-4])
 
 
+@pytest.mark.parametrize("kset", [1, 3])
+def test_comp_evolve_global_minimum_every_step(dev, golden, kset):
+    """decomposed run, device-side stepping: EVERY dt -- the first one of a call included, whose
+    CFL minimum comes from a kernel of its own -- is derived from the minimum over all ranks.
+    (Round 4, four RCCL ranks on hardware: the first minimum of a pyrohip_comp_evolve call was
+    rank-local, the slabs far from the blast ran ahead in time; two ranks hid it by symmetry.)
+    The emulated backend has no communicator; its all-reduce folds in a value the test sets as
+    \"the other ranks' minimum\" (tests/emu/comm_emu.cpp)."""
+    import ctypes
+    from helpers import DtPolicy
+    from pyro2_amd import _lib
+    if dev.kind != "emu":
+        pytest.skip("needs the emulated backend's test hook")
+    g = golden("comp_sedov_64_020")
+    bcs = [str(b) for b in g["bc"]]
+    meta = g["meta"]
+    P, cfl = dev_params(meta, **kset_kw(kset))
+    ic = np.nan_to_num(g["ic"])
+    hook = _lib.lib().pyrohip_emu_set_peer_min
+    hook.argtypes, hook.restype = [ctypes.c_double], ctypes.c_int
+    peer = 1.0e-5                      # far below this state's own minimum
+    try:
+        hook(peer)
+        dev.comm_set_global_dt(True)
+        s = comp_state(dev, 64, 64, bcs)
+        s.upload(ic)
+        pol, dts = DtPolicy(0.1), []
+        for n in (4, 3):               # two calls: two "first steps"
+            dts += list(s.comp_evolve(P, cfl, pol, n))
+    finally:
+        dev.comm_set_global_dt(False)
+        hook(-1.0)
+    ref = DtPolicy(0.1)
+    want = []
+    for _ in range(7):
+        dt = ref(cfl * peer)
+        ref.advance(dt)
+        want.append(dt)
+    assert dts == want
+    assert pol.t == ref.t and pol.n == 7
+
+
 @pytest.mark.parametrize("launches", [1, 3])
 @pytest.mark.parametrize("bcs", [("outflow", "outflow", "outflow", "outflow"),
                                  ("reflect", "outflow", "periodic", "periodic"),
