@@ -751,8 +751,8 @@ def bench_pyro_driver(ctx, device, bare):
                  "writes a right-hand side"))
     out["compressible_sedov_spherical_2048"] = bench_pyro_run(
         ctx, device, "compressible", "sedov", {"mesh.nx": 2048, "mesh.ny": 2048}, 10, 2,
-        (SEDOV_BYTES_PER_CELL, "64 B per cell update; the staged kernel set (kernel_set 0: the only one with "
-                               "the geometry terms) moves 37 work planes per step on top of that"),
+        (SEDOV_BYTES_PER_CELL, "64 B per cell update (one launch per step since round 4: the tile kernel "
+                               "with the geometry terms, k_ctu_fused_sph; + 8 geometry planes read)"),
         inputs_file="inputs.sedov.spherical")
     return out
 

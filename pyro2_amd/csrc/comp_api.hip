@@ -16,6 +16,7 @@ int comp_step_wave_ex(pyrohip_state *, const pyrohip_comp_params *, double, cons
                       const double **);
 int comp_cfl_min_device(pyrohip_state *, const pyrohip_comp_params *, const double **);
 int comp_step_sph(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_step_fused_sph(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_dt_sph(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_stage_dump(pyrohip_state *, int, double *);
 int comp_sponge(pyrohip_state *, const pyrohip_comp_params *, double);
@@ -38,6 +39,7 @@ int comp_step_wave_ex(pyrohip_state *, const pyrohip_comp_params *, double, cons
                       const double **);
 int comp_cfl_min_device(pyrohip_state *, const pyrohip_comp_params *, const double **);
 int comp_step_sph(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_step_fused_sph(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_dt_sph(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 }
 }  // namespace pyro
@@ -78,6 +80,10 @@ static bool comp_can_fuse_fill(const pyrohip_state *s, const pyrohip_comp_params
     }
     return true;
 }
+
+static bool c_nb_set(const pyrohip_state *s) { return s->nb_set; }
+// (the tile kernel's apron: 4 ghost cells must hold what a tile at the far side needs)
+static bool g_fits_tile(const pyrohip_state *s) { return s->g.ng >= 4 && s->g.nx >= 4 && s->g.ny >= 4; }
 
 static int check_comp(pyrohip_state *s, const pyrohip_comp_params *p)
 {
@@ -441,7 +447,24 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
         PYRO_REQUIRE(p->riemann == 1, "a SphericalPolar grid needs the CGF Riemann solver");
         PYRO_REQUIRE(!s->user_bc && !s->ramp_bc && !s->heat && !s->ext_old,
                      "hse / ambient / ramp boundaries and heating are Cartesian-only");
-        rc = p->fast_math ? fastm::comp_step_sph(s, p, dt) : exact::comp_step_sph(s, p, dt);
+        // one launch (the tile kernel with the geometry terms) where the boundaries are index
+        // maps; the staged set (kernel_set 0: stage dumps) everywhere else
+        bool fuse_sph = p->kernel_set != 0 && !c_nb_set(s) && g_fits_tile(s);
+        for (int sd = 0; sd < 4 && fuse_sph; sd++) {
+            int kind0 = -1;
+            for (int n = 0; n < 4 && fuse_sph; n++) {
+                const int b = s->bc[n * 4 + sd];
+                const int kind = (b == PYROHIP_BC_OUTFLOW) ? 0
+                                 : (b == PYROHIP_BC_REFLECT_EVEN || b == PYROHIP_BC_REFLECT_ODD) ? 1
+                                 : (b == PYROHIP_BC_PERIODIC) ? 2 : -1;
+                if (kind < 0 || (n > 0 && kind != kind0)) fuse_sph = false;
+                kind0 = kind;
+            }
+        }
+        if (fuse_sph)
+            rc = p->fast_math ? fastm::comp_step_fused_sph(s, p, dt) : exact::comp_step_fused_sph(s, p, dt);
+        else
+            rc = p->fast_math ? fastm::comp_step_sph(s, p, dt) : exact::comp_step_sph(s, p, dt);
     } else if (s->ext_old) {
         // host-evaluated source: staged kernels up to the predictor U* = U + dt S(U^n);
         // the caller evaluates S_h(U*) and finishes with pyrohip_comp_source_correct

@@ -375,6 +375,344 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
     if (t == 0) partial[tile] = cfl;
 }
 
+// ===========================================================================
+// SphericalPolar grids (x = r, y = theta; mesh/patch.py:242-312): the whole step of
+// compressible.hip's staged spherical set (k_prim, k_sph_src + ghost fill of the sources, k_xi,
+// k_sph_states, k_sph_riemann_t, k_sph_final, k_sph_update: nine launches through 45 work
+// planes) as ONE launch of the tile kernel above with the geometry terms -- the same phases,
+// the same expressions on the same operands (bit-identical in the bit-faithful build):
+//  - tracing with per-cell dt / Lx, dt / Ly and the geometric source (interface.py:106, 215-234);
+//  - external sources (radial gravity + the geometric terms, simulation.py:117-124): evaluated
+//    for the thread's own cell -- a ghost cell takes the value of the cell its boundary rule
+//    copies from, with the variable's sign, like the reference's ghost-filled source arrays;
+//  - CGF interface states whose pressure stays out of the area-weighted flux difference and
+//    enters as a gradient (riemann.py:1092-1096, 1156-1171; unsplit_fluxes.py:411-488): the
+//    face pressures travel in two more LDS planes;
+//  - transverse correction, conservative update and CFL with the area / volume / length
+//    arrays, the vertex divergence of interface.py:331-364, the source predictor-corrector
+//    (simulation.py:330-423).
+// Boundaries: outflow / reflect / periodic sides (index maps of the tile kernel); everything
+// else steps through the staged set.
+// ===========================================================================
+struct SphG {   // kernel-side geometry (pyrohip_state_set_geometry)
+    const double *Lx, *Ly, *Ax, *Ay, *V, *dlAx, *dlAy, *x2d, *sint, *sinb, *sinc;
+    double xmin;
+};
+constexpr int FLDS_DOUBLES_SPH = FLDS_DOUBLES + 2 * FNT;       // + the face pressures
+constexpr size_t FLDS_BYTES_SPH = (size_t)FLDS_DOUBLES_SPH * sizeof(double);
+
+// CGF interface state, its flux without the pressure and its pressure
+// (riemann_flux(return_cons=True) + cons_to_prim, unsplit_fluxes.py:411-423)
+__device__ __forceinline__ Cons sphf_face(const Cons &Ul, const Cons &Ur, double gamma, bool x,
+                                          bool wall, double &pface)
+{
+    const ConsN Uo = cgf_state(to_nf(Ul, x), to_nf(Ur, x), gamma, wall);
+    pface = cons_to_prim(from_nf(Uo, x), gamma).p;
+    return from_nf(cons_flux_n(Uo, gamma, x, false), x);
+}
+
+__device__ __forceinline__ Cons sphf_corrected(const Cons &U, const Cons &Fhi, double Ahi,
+                                               const Cons &Flo, double Alo, double hv)
+{
+    Cons r;   // U += -hdtV*(F_hi*A_hi - F_lo*A_lo), unsplit_fluxes.py:447-471
+    r.d = U.d + (-hv * (Fhi.d * Ahi - Flo.d * Alo));
+    r.E = U.E + (-hv * (Fhi.E * Ahi - Flo.E * Alo));
+    r.mx = U.mx + (-hv * (Fhi.mx * Ahi - Flo.mx * Alo));
+    r.my = U.my + (-hv * (Fhi.my * Ahi - Flo.my * Alo));
+    return r;
+}
+
+template <bool STD>
+__global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused_sph(const double *__restrict__ Uin,
+                                                       double *__restrict__ Uout, Geom g, FP P,
+                                                       SphG G, int *__restrict__ flag,
+                                                       double *__restrict__ partial)
+{
+    HIP_DYNAMIC_SHARED(double, lds)
+    double *B0 = lds;                 // Q (phase 0-1) | FT (2-3) | F (4-5)
+    double *S = lds + FBUF0;          // upper face states XP(0..3), YP(4..7)
+    double *D = S + 8 * FNT;          // vertex div(U)
+    double *PT = D + FNT;             // face pressures: x faces, y faces
+    const int tile = xcd_tile(blockIdx.x, P.ntiles);
+    const int i0 = g.ilo + (tile / P.ntj) * FTI;
+    const int j0 = g.jlo + (tile % P.ntj) * FTJ;
+    const int tj = threadIdx.x, ti = threadIdx.y;
+    const int t = ti * FBJ + tj;
+    const int i = i0 - 1 + ti, j = j0 - 1 + tj;
+    const int p = g.pitch;
+    const size_t pl = g.plane;
+    const double gamma = P.gamma;
+
+    // ---- phase 0: U -> Q for the tile + 4-cell apron (as k_ctu_fused) --------
+    bool bad = false;
+    {
+        constexpr int NIT = (FQN + FNT - 1) / FNT;
+        Cons Ul[NIT];
+        bool act[NIT], interior[NIT];
+#pragma unroll
+        for (int n = 0; n < NIT; n++) {
+            const int idx = t + n * FNT;
+            act[n] = idx < FQN;
+            const int ii = act[n] ? idx : t;
+            const int r = ii / FQW, c = ii - r * FQW;
+            int gi = i0 - 4 + r, gj = j0 - 4 + c;
+            const bool inarr = act[n] && gi < g.qx && gj < g.qy;
+            gi = (gi < g.qx) ? gi : g.qx - 1;
+            gj = (gj < g.qy) ? gj : g.qy - 1;
+            unsigned sd;
+            const Cons U = load_cons_bc(Uin, g, P, gi, gj, sd);
+            Ul[n] = U;
+            interior[n] = (sd == 0);
+            if (inarr && sd != 0) {       // the ghost frame of the new state: the old ghost cells
+                const size_t ko = (size_t)gi * p + gj;
+                Uout[ko] = U.d; Uout[pl + ko] = U.E; Uout[2 * pl + ko] = U.mx; Uout[3 * pl + ko] = U.my;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NIT; n++) {
+            const int idx = t + n * FNT;
+            Cons U = Ul[n];
+            if (interior[n]) U.d = fmax(U.d, P.small_dens);      // clean_state
+            bool ok;
+            const Prim q = cons_to_prim_nb(U, gamma, ok);
+            if (act[n] && interior[n] && !ok) bad = true;
+            if (act[n]) {
+                B0[idx] = q.r; B0[FQN + idx] = q.u; B0[2 * FQN + idx] = q.v; B0[3 * FQN + idx] = q.p;
+            }
+        }
+    }
+    if (bad) atomicOr(flag, 1);
+    __syncthreads();
+
+    // the thread's own cell in the arrays (ragged last tiles: clamped, unused)
+    const bool in_arr = (i < g.qx && j < g.qy);
+    const int ic = in_arr ? i : g.qx - 1, jc = in_arr ? j : g.qy - 1;
+    const size_t k = (size_t)ic * p + jc;
+    // (cells one row / column up: inside the array for every cell the tile uses)
+    const size_t kpi = (size_t)(ic + 1 < g.qx ? ic + 1 : ic) * p + jc;
+    const size_t kpj = (size_t)ic * p + (jc + 1 < g.qy ? jc + 1 : jc);
+    const double hdt = 0.5 * P.dt;
+
+    // ---- phase 1: xi, slopes, tracing, sources for the thread's own cell --------
+    Cons XM, XP, YM, YP;
+    {
+        const int qc = (ti + 3) * FQW + (tj + 3);
+        const double *Qr = B0, *Qu = B0 + FQN, *Qv = B0 + 2 * FQN, *Qp = B0 + 3 * FQN;
+        (void)Qr;
+        double xi = 1.0;
+        if (STD || P.use_flattening) {
+            const int sx = (Qp[qc + FQW] - Qp[qc - FQW] > 0) ? -FQW : FQW;
+            const int sy = (Qp[qc + 1] - Qp[qc - 1] > 0) ? -1 : 1;
+            const int cx = qc + sx, cy = qc + sy;
+            const double xix = flatten_1d(Qp[qc - 2 * FQW], Qp[qc - FQW], Qp[qc + FQW],
+                                          Qp[qc + 2 * FQW], Qu[qc - FQW], Qu[qc + FQW], P.z0, P.z1,
+                                          P.delta);
+            const double px = flatten_1d(Qp[cx - 2 * FQW], Qp[cx - FQW], Qp[cx + FQW],
+                                         Qp[cx + 2 * FQW], Qu[cx - FQW], Qu[cx + FQW], P.z0, P.z1,
+                                         P.delta);
+            const double xiy = flatten_1d(Qp[qc - 2], Qp[qc - 1], Qp[qc + 1], Qp[qc + 2],
+                                          Qv[qc - 1], Qv[qc + 1], P.z0, P.z1, P.delta);
+            const double py = flatten_1d(Qp[cy - 2], Qp[cy - 1], Qp[cy + 1], Qp[cy + 2],
+                                         Qv[cy - 1], Qv[cy + 1], P.z0, P.z1, P.delta);
+            xi = fmin(fmin(xix, px), fmin(xiy, py));
+        }
+        double q0[4], dqx[4], dqy[4];
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const double *a = B0 + n * FQN;
+            q0[n] = a[qc];
+            dqx[n] = xi * limited_slope(a[qc - 2 * FQW], a[qc - FQW], a[qc], a[qc + FQW],
+                                        a[qc + 2 * FQW], STD ? 2 : P.limiter);
+            dqy[n] = xi * limited_slope(a[qc - 2], a[qc - 1], a[qc], a[qc + 1], a[qc + 2],
+                                        STD ? 2 : P.limiter);
+        }
+        const double cs = psqrt(pdiv(gamma * q0[3], q0[0]));   // interface.py:122
+        Trace lo, hi;
+        trace_states(q0[0], q0[1], q0[2], q0[3], dqx[0], dqx[1], dqx[2], dqx[3], gamma,
+                     pdiv(P.dt, G.Lx[k]), lo, hi);
+        {   // :216-224
+            const double rs = -0.5 * P.dt * G.dlAx[k] * q0[0] * q0[1];
+            hi.r += rs; lo.r += rs;
+            hi.p += rs * cs * cs; lo.p += rs * cs * cs;
+        }
+        XM = prim_to_cons(Prim{lo.r, lo.un, lo.ut, lo.p}, gamma);
+        XP = prim_to_cons(Prim{hi.r, hi.un, hi.ut, hi.p}, gamma);
+        trace_states(q0[0], q0[2], q0[1], q0[3], dqy[0], dqy[2], dqy[1], dqy[3], gamma,
+                     pdiv(P.dt, G.Ly[k]), lo, hi);
+        {   // :226-234
+            const double rs = -0.5 * P.dt * G.dlAy[k] * q0[0] * q0[2];
+            hi.r += rs; lo.r += rs;
+            hi.p += rs * cs * cs; lo.p += rs * cs * cs;
+        }
+        YM = prim_to_cons(Prim{lo.r, lo.ut, lo.un, lo.p}, gamma);
+        YP = prim_to_cons(Prim{hi.r, hi.ut, hi.un, hi.p}, gamma);
+        // vertex divergence at (i-1/2, j-1/2), interface.py:331-364
+        {
+            const double rr = (i + 0.5 - g.ng) * P.dx + G.xmin;
+            const double rl = (i - 0.5 - g.ng) * P.dx + G.xmin;
+            const double rc = (i - g.ng) * P.dx + G.xmin;
+            const double ur = 0.5 * (Qu[qc] + Qu[qc - 1]);
+            const double ul = 0.5 * (Qu[qc - FQW] + Qu[qc - FQW - 1]);
+            const double ux = pdiv(ur * rr * rr - ul * rl * rl, rc * rc * P.dx);
+            const double sint = G.sint[jc], sinb = G.sinb[jc], sinc = G.sinc[jc];
+            double vy = 0.0;
+            if (sinc != 0.0) {
+                const double vt = 0.5 * (Qv[qc] + Qv[qc - FQW]);
+                const double vb = 0.5 * (Qv[qc - 1] + Qv[qc - FQW - 1]);
+                vy = pdiv(sint * vt - sinb * vb, rc * sinc * P.dy);
+            }
+            D[t] = ux + vy;
+        }
+        // get_external_sources on the interior (simulation.py:117-124), ghost cells by the
+        // boundary rules of the state's variables; apply_source_terms (unsplit_fluxes.py:308-326)
+        {
+            const int si = bc_src(P.mr, ic, g.ilo, g.ihi), sj = bc_src(P.mc, jc, g.jlo, g.jhi);
+            const size_t ks = (size_t)si * p + sj;
+            const unsigned sd = (ic < g.ilo ? 1u : 0u) | (ic > g.ihi ? 2u : 0u) | (jc < g.jlo ? 4u : 0u) |
+                                (jc > g.jhi ? 8u : 0u);
+            Cons Us{Uin[ks], Uin[pl + ks], Uin[2 * pl + ks], Uin[3 * pl + ks]};
+            Us.d = fmax(Us.d, P.small_dens);
+            double Sx = Us.d * P.grav;
+            double SE = Us.mx * P.grav;
+            Sx += pdiv(Us.my * Us.my, Us.d * G.x2d[ks]);
+            double Sy = pdiv(-Us.mx * Us.my, Us.d);
+            SE = odd_sides((P.odd >> 4) & sd) ? -SE : SE;
+            Sx = odd_sides((P.odd >> 8) & sd) ? -Sx : Sx;
+            Sy = odd_sides((P.odd >> 12) & sd) ? -Sy : Sy;
+            const double sE = hdt * SE, sx = hdt * Sx, sy = hdt * Sy;
+            XM.mx += sx; XM.my += sy; XM.E += sE;
+            XP.mx += sx; XP.my += sy; XP.E += sE;
+            YM.mx += sx; YM.my += sy; YM.E += sE;
+            YP.mx += sx; YP.my += sy; YP.E += sE;
+        }
+        lds_put(S, t, XP);
+        lds_put(S + 4 * FNT, t, YP);
+    }
+    __syncthreads();   // Q is dead from here on; B0 becomes the flux buffer
+
+    // ---- phase 2: transverse Riemann problems on the lower faces --------
+    Cons FxT{0, 0, 0, 0}, FyT{0, 0, 0, 0};
+    double pxt = 0.0, pyt = 0.0;
+    if (ti >= 1)
+        FxT = sphf_face(lds_get(S, t - FBJ), XM, gamma, true, P.solid_xl && i == g.ilo, pxt);
+    if (tj >= 1)
+        FyT = sphf_face(lds_get(S + 4 * FNT, t - 1), YM, gamma, false, P.solid_yl && j == g.jlo, pyt);
+    lds_put(B0, t, FxT);
+    lds_put(B0 + 4 * FNT, t, FyT);
+    PT[t] = pxt; PT[FNT + t] = pyt;
+    __syncthreads();
+
+    // ---- phase 3: transverse correction of the cell's own states.  A face's two states are
+    // corrected with the volume / length of the cell ABOVE the face (unsplit_fluxes.py:444-481:
+    // hdtV and Lx / Ly at (i, j) for the states of face (i, j)): the upper states of this cell
+    // take the next cell's
+    if (tj >= 1 && tj <= FBJ - 2) {
+        const Cons Fhi = lds_get(B0 + 4 * FNT, t + 1);   // F_yT at (i, j+1)
+        const double Ahi = G.Ay[kpj], Alo = G.Ay[k];
+        const double dpy = PT[FNT + t + 1] - pyt;
+        XM = sphf_corrected(XM, Fhi, Ahi, FyT, Alo, pdiv(hdt, G.V[k]));
+        XM.my += pdiv(-hdt * dpy, G.Ly[k]);
+        XP = sphf_corrected(XP, Fhi, Ahi, FyT, Alo, pdiv(hdt, G.V[kpi]));
+        XP.my += pdiv(-hdt * dpy, G.Ly[kpi]);
+    }
+    if (ti >= 1 && ti <= FBI - 2) {
+        const Cons Fhi = lds_get(B0, t + FBJ);           // F_xT at (i+1, j)
+        const double Ahi = G.Ax[kpi], Alo = G.Ax[k];
+        const double dpx = PT[t + FBJ] - pxt;
+        YM = sphf_corrected(YM, Fhi, Ahi, FxT, Alo, pdiv(hdt, G.V[k]));
+        YM.mx += pdiv(-hdt * dpx, G.Lx[k]);
+        YP = sphf_corrected(YP, Fhi, Ahi, FxT, Alo, pdiv(hdt, G.V[kpj]));
+        YP.mx += pdiv(-hdt * dpx, G.Lx[kpj]);
+    }
+    lds_put(S, t, XP);
+    lds_put(S + 4 * FNT, t, YP);
+    __syncthreads();
+
+    // ---- phase 4: final Riemann problems + artificial viscosity ---------
+    unsigned sdc;
+    Cons Uc = load_cons_bc(Uin, g, P, ic, jc, sdc);
+    const bool cell_interior = (i >= g.ilo && i <= g.ihi && j >= g.jlo && j <= g.jhi);
+    if (cell_interior) Uc.d = fmax(Uc.d, P.small_dens);
+    Cons Fx{0, 0, 0, 0}, Fy{0, 0, 0, 0};
+    double px = 0.0, py = 0.0;
+    const double d00 = D[t];
+    Cons Umx = load_cons_bc(Uin, g, P, ic - 1, jc, sdc);
+    Cons Umy = load_cons_bc(Uin, g, P, ic, jc - 1, sdc);
+    double avx = 0.0, avy = 0.0;
+    // interface.py:366-376: only faces i in [ilo, ihi], j in [jlo, jhi]
+    if (ti >= 1 && tj >= 1 && tj <= FBJ - 2 && i >= g.ilo && i <= g.ihi && j >= g.jlo && j <= g.jhi) {
+        const double divU_x = 0.5 * (d00 + D[t + 1]);
+        avx = P.cvisc * fmax(-divU_x * G.Lx[k], 0.0);
+    }
+    if (tj >= 1 && ti >= 1 && ti <= FBI - 2 && j >= g.jlo && j <= g.jhi && i >= g.ilo && i <= g.ihi) {
+        const double divU_y = 0.5 * (d00 + D[t + FBJ]);
+        avy = P.cvisc * fmax(-divU_y * G.Ly[k], 0.0);
+    }
+    if (i - 1 >= g.ilo && i - 1 <= g.ihi && j >= g.jlo && j <= g.jhi)
+        Umx.d = fmax(Umx.d, P.small_dens);
+    if (i >= g.ilo && i <= g.ihi && j - 1 >= g.jlo && j - 1 <= g.jhi)
+        Umy.d = fmax(Umy.d, P.small_dens);
+    if (ti >= 1 && tj >= 1 && tj <= FBJ - 2) {           // x face (i, j)
+        Fx = sphf_face(lds_get(S, t - FBJ), XM, gamma, true, P.solid_xl && i == g.ilo, px);
+        Fx.d += avx * (Umx.d - Uc.d);
+        Fx.E += avx * (Umx.E - Uc.E);
+        Fx.mx += avx * (Umx.mx - Uc.mx);
+        Fx.my += avx * (Umx.my - Uc.my);
+    }
+    if (tj >= 1 && ti >= 1 && ti <= FBI - 2) {           // y face (i, j)
+        Fy = sphf_face(lds_get(S + 4 * FNT, t - 1), YM, gamma, false, P.solid_yl && j == g.jlo, py);
+        Fy.d += avy * (Umy.d - Uc.d);
+        Fy.E += avy * (Umy.E - Uc.E);
+        Fy.mx += avy * (Umy.mx - Uc.mx);
+        Fy.my += avy * (Umy.my - Uc.my);
+    }
+    lds_put(B0, t, Fx);
+    lds_put(B0 + 4 * FNT, t, Fy);
+    PT[t] = px; PT[FNT + t] = py;      // (the transverse pressures were last read before the barrier above)
+    __syncthreads();
+
+    // ---- phase 5: conservative update with the area / volume arrays, the pressure
+    // gradients and the source predictor-corrector (simulation.py:375-423) + CFL -----------
+    double cfl = INFINITY;
+    if (ti >= 1 && ti <= FBI - 2 && tj >= 1 && tj <= FBJ - 2 && cell_interior) {
+        const double dtdV = pdiv(P.dt, G.V[k]);
+        const Cons Fxh = lds_get(B0, t + FBJ);
+        const Cons Fyh = lds_get(B0 + 4 * FNT, t + 1);
+        const double Ax0 = G.Ax[k], Ax1 = G.Ax[kpi], Ay0 = G.Ay[k], Ay1 = G.Ay[kpj];
+        double Un[4];
+        const double Uo[4] = {Uc.d, Uc.E, Uc.mx, Uc.my};
+        Un[0] = Uo[0] + dtdV * (Fx.d * Ax0 - Fxh.d * Ax1 + Fy.d * Ay0 - Fyh.d * Ay1);
+        Un[1] = Uo[1] + dtdV * (Fx.E * Ax0 - Fxh.E * Ax1 + Fy.E * Ay0 - Fyh.E * Ay1);
+        Un[2] = Uo[2] + dtdV * (Fx.mx * Ax0 - Fxh.mx * Ax1 + Fy.mx * Ay0 - Fyh.mx * Ay1);
+        Un[3] = Uo[3] + dtdV * (Fx.my * Ax0 - Fxh.my * Ax1 + Fy.my * Ay0 - Fyh.my * Ay1);
+        Un[2] -= pdiv(P.dt * (PT[t + FBJ] - px), G.Lx[k]);
+        Un[3] -= pdiv(P.dt * (PT[FNT + t + 1] - py), G.Ly[k]);
+        // S_old = S(U_old); U += dt S_old; S_new (time-centred x-momentum); U += dt/2 (S_new - S_old)
+        const double r = G.x2d[k], grav = P.grav, dt = P.dt;
+        const double Sx_g_old = Uo[0] * grav;
+        const double SE_old = Uo[2] * grav;
+        const double Sx_old = Sx_g_old + pdiv(Uo[3] * Uo[3], Uo[0] * r);
+        const double Sy_old = pdiv(-Uo[2] * Uo[3], Uo[0]);
+        Un[1] = Un[1] + dt * SE_old;
+        Un[2] = Un[2] + dt * Sx_old;
+        Un[3] = Un[3] + dt * Sy_old;
+        const double Sx_g_new = Un[0] * grav;
+        const double xmom_new = Un[2] + 0.5 * dt * (Sx_g_new - Sx_g_old);
+        const double SE_new = xmom_new * grav;
+        const double Sx_new = Sx_g_new + pdiv(Un[3] * Un[3], Un[0] * r);
+        const double Sy_new = pdiv(-Un[2] * Un[3], Un[0]);
+        Cons Uw;
+        Uw.d = Un[0];   // the density source is zero
+        Uw.E = Un[1] + 0.5 * dt * (SE_new - SE_old);
+        Uw.mx = Un[2] + 0.5 * dt * (Sx_new - Sx_old);
+        Uw.my = Un[3] + 0.5 * dt * (Sy_new - Sy_old);
+        Uout[k] = Uw.d; Uout[pl + k] = Uw.E; Uout[2 * pl + k] = Uw.mx; Uout[3 * pl + k] = Uw.my;
+        cfl = cfl_cell(Uw, gamma, G.Lx[k], G.Ly[k]);
+    }
+    cfl = block_reduce_min(cfl);
+    if (t == 0) partial[tile] = cfl;
+}
+
 // ghost frame of all 4 planes old -> new (the reference updates in place, so
 // ghost cells keep their pre-step values)
 // O(perimeter): blockIdx.y enumerates the 2*ng ghost rows (all j) followed by
@@ -583,6 +921,53 @@ int comp_step_fused_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt
 int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
 {
     return comp_step_fused_ex(s, p, dt, nullptr, nullptr);
+}
+
+// SphericalPolar grid, one step with the host's dt in ONE launch (k_ctu_fused_sph); the caller
+// (pyrohip_comp_step) checked comp_can_fuse_sph(): CGF, outflow / reflect / periodic sides
+int comp_step_fused_sph(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    FP P;
+    double *Uin, *Uout;
+    PYRO_TRY(fused_prepare(s, p, dt, P, Uin, Uout, true));
+    // ghost cells (of the state and of the source terms) through the boundary rules
+    P.mr = bc_map(g.ilo, g.ihi, g.ng, s->bc[0], s->bc[1], true);
+    P.mc = bc_map(g.jlo, g.jhi, g.ng, s->bc[2], s->bc[3], true);
+    for (int n = 0; n < 4; n++)
+        for (int sd = 0; sd < 4; sd++)
+            if (s->bc[n * 4 + sd] == PYROHIP_BC_REFLECT_ODD) P.odd |= 1u << (4 * n + sd);
+    const SphGeom &h = *s->sph;
+    const SphG G{h.Lx, h.Ly, h.Ax, h.Ay, h.V, h.dlAx, h.dlAy, h.x2d, h.sint, h.sinb, h.sinc, h.xmin};
+    const int nti = (g.nx + FTI - 1) / FTI;
+    P.ntj = (g.ny + FTJ - 1) / FTJ;
+    P.ntiles = nti * P.ntj;
+    PYRO_TRY(c->reduce.ensure((P.ntiles + kMinStageBlocks + 2) * sizeof(double)));
+    double *part = (double *)c->reduce.p;
+    using KernelT = void (*)(const double *, double *, Geom, FP, SphG, int *, double *);
+    static const KernelT kernels[2] = {k_ctu_fused_sph<false>, k_ctu_fused_sph<true>};
+#ifndef PYRO_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        for (int b = 0; b < 2; b++)
+            PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)kernels[b],
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)FLDS_BYTES_SPH));
+        attr_set = true;
+    }
+#endif
+    const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
+    PYRO_LAUNCH(c, "k_ctu_fused_sph", kernels[std_rec], dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES_SPH,
+                (const double *)Uin, Uout, g, P, G, s->d_flag, part);
+    const double *dmin;
+    PYRO_TRY(fused_tail(s, part, P.ntiles, true, &dmin, false));   // the kernel wrote the ghost frame
+    const int rc = fused_sync(s, dmin);
+    // (the minimum is the one of method_compute_timestep's interior; the reference takes it over
+    // the whole array with its ghost cells: pyrohip_comp_dt recomputes, as after the staged set)
+    s->next_cfl_min = -1.0;
+    s->cfl_is_global = false;
+    return rc;
 }
 
 }  // namespace PYRO_NS

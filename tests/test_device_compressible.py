@@ -1135,11 +1135,89 @@ def test_comp_spherical(dev, golden, k):
         s.comp_step(dev_params(meta, kernel_set=1)[0], dt)
 
 
+@pytest.mark.parametrize("k", range(3))
+def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
+    """SphericalPolar grid: the whole step in ONE launch (k_ctu_fused_sph: the tile kernel with
+    the geometry terms -- per-cell dt / Lx, dt / Ly and the geometric source in the tracing,
+    external sources with their ghost rule, CGF face pressures as gradients, area / volume
+    weighted corrections and update, spherical vertex divergence, source predictor-corrector)
+    against the staged spherical set (nine launches, pinned stage by stage to the oracle and
+    the reference's dumps above): the WHOLE array bit for bit in the bit-faithful build, 1e-10
+    in the contracted one; a run with the driver's dt policy"""
+    from helpers import DtPolicy
+    g = golden("comp_spherical")
+    pre = f"c{k}_"
+    bcs = [str(b) for b in g[pre + "bc"]]
+    meta = g[pre + "meta"]
+    solid = [int(b in ("reflect", "reflect-even", "reflect-odd", "dirichlet")) for b in bcs]
+    nx, ny, ng = int(meta[0]), int(meta[1]), int(meta[2])
+    dom = g[pre + "g_domain"]
+    f0, mx = g[pre + "drv"]
+    fix = 0.005 if str(g[pre + "problem"]) == "advect" else -1.0
+    nsteps = len(g[pre + "dts"])
+    for fm in (0, 1):
+        out = {}
+        for ks in (0, -1):
+            P, cfl = dev_params(meta, kernel_set=ks, riemann="CGF", solid_xl=solid[0], solid_yl=solid[2],
+                                fast_math=fm)
+            s = comp_state(dev, nx, ny, bcs)
+            s.set_geometry(sph_arrays(g, pre), dom[0], dom[2])
+            s.upload(g[pre + "ic"])
+            pol, dts = DtPolicy(1.e30, f0, mx, fix_dt=fix), []
+            for _ in range(nsteps):
+                s.fill_bc()
+                dtn = pol(s.comp_dt(P, cfl))
+                s.comp_step(P, dtn)
+                pol.advance(dtn)
+                dts.append(dtn)
+            out[ks] = (s.download(), dts)
+        (Ua, da), (Ub, db) = out[0], out[-1]
+        if fm == 0:
+            assert da == db, (k, "dts")
+            assert np.array_equal(Ua, Ub), (k, np.argwhere(Ua != Ub)[:5])
+        else:
+            assert np.abs(np.array(db) / np.array(da) - 1).max() < 1e-10
+            scale = np.maximum(np.abs(Ua).max(axis=(0, 1)), 1e-3)
+            assert (np.abs(Ub - Ua) / scale).max() < 1e-10, k
+    # other boundary kinds (the geometry arrays do not depend on them): a reflecting wall with
+    # its even / odd variables in both directions, periodic in theta -- momenta stirred so that
+    # the signs of the ghost sources matter
+    rng = np.random.default_rng(11 + k)
+    ic = g[pre + "ic"].copy()
+    ic[:, :, 2] += 1.e-2 * ic[:, :, 0] * rng.standard_normal(ic.shape[:2])
+    ic[:, :, 3] += 1.e-2 * ic[:, :, 0] * rng.standard_normal(ic.shape[:2])
+    ic[:, :, 1] += 1.e-3 * ic[:, :, 0]
+    for bcs2 in (("reflect", "outflow", "reflect", "reflect"), ("outflow", "reflect", "periodic", "periodic"),
+                 ("reflect", "reflect", "outflow", "reflect")):
+        solid2 = [int(b == "reflect") for b in bcs2]
+        out = {}
+        for ks in (0, -1):
+            P, cfl = dev_params(meta, kernel_set=ks, riemann="CGF", solid_xl=solid2[0], solid_yl=solid2[2])
+            s = comp_state(dev, nx, ny, list(bcs2))
+            s.set_geometry(sph_arrays(g, pre), dom[0], dom[2])
+            s.upload(ic)
+            pol = DtPolicy(1.e30, f0, mx, fix_dt=fix)
+            for _ in range(4):
+                s.fill_bc()
+                dtn = pol(s.comp_dt(P, cfl))
+                s.comp_step(P, dtn)
+                pol.advance(dtn)
+            out[ks] = s.download()
+        assert np.array_equal(out[0], out[-1]), (k, bcs2, np.argwhere(out[0] != out[-1])[:5])
+    # the launch count of the default really is one per step
+    dev.prof_enable(True)
+    s.comp_step(P, dts[-1])
+    rep = dev.prof_report()
+    dev.prof_enable(False)
+    assert rep.get("k_ctu_fused_sph", (0, 0))[0] == 1 and "k_sph_states" not in rep
+
+
 @pytest.mark.gpu
-def test_comp_spherical_512_vs_oracle(hip):
+@pytest.mark.parametrize("kset", [0, -1])
+def test_comp_spherical_512_vs_oracle(hip, kset):
     """SphericalPolar Sedov at 512 x 256 (the set-up of inputs.sedov.spherical),
-    12 steps with the driver's dt policy: device vs the C oracle, geometry from
-    pyro2_amd.mesh.patch.SphericalPolar"""
+    12 steps with the driver's dt policy: device (the staged set, and the one-launch tile
+    kernel the library picks) vs the C oracle, geometry from pyro2_amd.mesh.patch.SphericalPolar"""
     from helpers import DtPolicy
     from pyro2_amd.mesh import patch
     nx, ny, ng, gamma, cfl = 512, 256, 4, 1.4, 0.8
@@ -1151,7 +1229,7 @@ def test_comp_spherical_512_vs_oracle(hip):
     U0[:, :, 1] = 1.e-6 / (gamma - 1.0)
     U0[:, :, 1][np.asarray(grid.x2d) < 0.13] = 1.e6
     meta = [nx, ny, ng, grid.dx, grid.dy, gamma, 2, 1, 0.75, 0.85, 0.33, 0.1, 0.0, cfl]
-    P, _ = dev_params(meta, kernel_set=0, riemann="CGF", solid_xl=1, solid_yl=0)
+    P, _ = dev_params(meta, kernel_set=kset, riemann="CGF", solid_xl=1, solid_yl=0)
     Po, _ = meta_to_params(meta, bcs, riemann="CGF")
     og = orc.Geom(geo, grid.xmin, grid.ymin)
     s = comp_state(hip, nx, ny, bcs)
