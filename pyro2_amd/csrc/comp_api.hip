@@ -242,9 +242,9 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
     // StepPolicy).  The first step keeps its fill + CFL + policy launches (the CFL minimum of
     // the state as handed over), the closing policy call is a launch, and the ghost cells of
     // the final state are filled once at the end.  Bit-identical to the three launches, and
-    // measured no faster (profiles/r04_one_launch_step.txt: that instance of the step kernel is
-    // 2 % slower per row, the two small launches cost 1-2.5 % of a step; -1.5 % at 16384^2):
-    // not the default.
+    // measured no faster (profiles/r04_one_launch_step.txt: every wavefront of that instance starts
+    // with ~5 us of dependent latency, the two small launches cost 1-2.5 % of a step; -1.5 % at
+    // 16384^2): not the default.
     bool one_launch = wave && p->step_launches == 1 && !s->nb_set && !c->global_cfl &&
                       comp_can_fuse_fill(s, p, false);
     for (int k = 0; k < 16 && one_launch; k++) one_launch = (s->bc[k] != PYROHIP_BC_HALO);
