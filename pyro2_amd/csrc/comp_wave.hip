@@ -52,16 +52,6 @@ namespace PYRO_NS {
 
 #include "fused_common.h"
 
-// a value another launch left in device memory by atomics (performed at memory, past the L2s)
-template <class T>
-__device__ __forceinline__ T dev_load(const T *p)
-{
-#if defined(PYRO_EMU)
-    return *p;
-#else
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
 
 constexpr int WOUT = 56;          // columns a wavefront updates
 // stage boundary: the scheduler may not move instructions across it.  The
@@ -267,10 +257,13 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         } else {
             StepScalars L = pol->S[(m - 1) & 1];
             const unsigned long long *prev = pol->slots + (size_t)((m - 1) % 3) * kPolSetWords;
+            // (plain loads: what the previous launch left is visible across a kernel boundary like
+            // the state itself, and the 20 000 wavefronts of a launch then share 64 L2 lines -- loads
+            // past the L2 made this prologue ~5 us per wavefront)
             const double cmin = __shfl(wave_reduce_min(__longlong_as_double(
-                                           (long long)dev_load(&prev[(size_t)l * kPolStride]))), 0, 64);
+                                           (long long)prev[(size_t)l * kPolStride])), 0, 64);
             double dtm;
-            dt_policy_apply(&L, cmin, (dev_load(flag) & (2 << ((m - 1) & 1))) != 0, &dtm, 0, 0);
+            dt_policy_apply(&L, cmin, (*(volatile int *)flag & (2 << ((m - 1) & 1))) != 0, &dtm, 0, 0);
             if (unit == 0) {     // the books, and the slots of the launch after this one
                 atomicExch(&pol->slots[(size_t)((m + 1) % 3) * kPolSetWords + (size_t)l * kPolStride],
                            (unsigned long long)__double_as_longlong((double)INFINITY));
