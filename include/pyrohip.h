@@ -127,7 +127,10 @@ int pyrohip_state_set_const_bc(pyrohip_state *s, int n, double value);
    All arrays are copied.  With a geometry set, pyrohip_comp_dt / _step follow the
    coord_type == 1 branches of compressible/simulation.py:117-147, 284-288,
    330-398, unsplit_fluxes.py:411-488, interface.py:215-234, 331-376 and
-   riemann.py:1156-1171 (CGF solver only, like the reference); NULL removes it. */
+   riemann.py:1156-1171 (CGF solver only, like the reference); NULL removes it.
+   pyrohip_comp_step then is one launch (the 2-d tile kernel with the geometry terms) where
+   the sides are outflow / reflect / periodic, the staged kernel set with its stage dumps
+   for kernel_set 0 and any other boundary (same arithmetic: bit-identical).            */
 typedef struct pyrohip_geom {
     const double *Lx, *Ly, *Ax, *Ay, *V, *dlogAx, *dlogAy, *x2d;
     const double *sint, *sinb, *sinc;
