@@ -85,6 +85,28 @@ static bool c_nb_set(const pyrohip_state *s) { return s->nb_set; }
 // (the tile kernel's apron: 4 ghost cells must hold what a tile at the far side needs)
 static bool g_fits_tile(const pyrohip_state *s) { return s->g.ng >= 4 && s->g.nx >= 4 && s->g.ny >= 4; }
 
+// SphericalPolar grid: one launch (k_ctu_fused_sph) where the boundaries are index maps -- the
+// same kind (outflow / reflect / periodic) for the four variables on every side; the staged set
+// (kernel_set 0: stage dumps) everywhere else
+static bool comp_can_fuse_sph(const pyrohip_state *s, const pyrohip_comp_params *p)
+{
+    if (!s->sph || p->kernel_set == 0 || c_nb_set(s) || !g_fits_tile(s) || s->user_bc || s->ramp_bc ||
+        s->heat || s->ext_old || p->riemann != 1)
+        return false;
+    for (int sd = 0; sd < 4; sd++) {
+        int kind0 = -1;
+        for (int n = 0; n < 4; n++) {
+            const int b = s->bc[n * 4 + sd];
+            const int kind = (b == PYROHIP_BC_OUTFLOW) ? 0
+                             : (b == PYROHIP_BC_REFLECT_EVEN || b == PYROHIP_BC_REFLECT_ODD) ? 1
+                             : (b == PYROHIP_BC_PERIODIC) ? 2 : -1;
+            if (kind < 0 || (n > 0 && kind != kind0)) return false;
+            kind0 = kind;
+        }
+    }
+    return true;
+}
+
 static int check_comp(pyrohip_state *s, const pyrohip_comp_params *p)
 {
     PYRO_REQUIRE(s && p, "NULL argument");
@@ -402,16 +424,20 @@ int pyrohip_comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, 
 {
     PYRO_TRY(check_comp(s, p));
     PYRO_REQUIRE(dt_out, "dt_out is NULL");
-    if (s->sph)
+    if (s->sph) {
+        // (cached by the one-launch spherical step: whole-array minimum of the new state; every
+        // other path that touches the state, the staged spherical set included, resets it)
+        if (s->next_cfl_min > 0.0) { *dt_out = cfl * s->next_cfl_min; return 0; }
         return p->fast_math ? fastm::comp_dt_sph(s, p, cfl, dt_out)
                             : exact::comp_dt_sph(s, p, cfl, dt_out);
+    }
     return p->fast_math ? fastm::comp_dt(s, p, cfl, dt_out) : exact::comp_dt(s, p, cfl, dt_out);
 }
 
 int pyrohip_comp_dt_is_cached(pyrohip_state *s, int *flag)
 {
     PYRO_REQUIRE(s && flag, "NULL argument");
-    *flag = (s->next_cfl_min > 0.0 && !s->sph && !s->user_bc && !s->ramp_bc) ? 1 : 0;
+    *flag = (s->next_cfl_min > 0.0 && !s->user_bc && !s->ramp_bc) ? 1 : 0;
     return 0;
 }
 
@@ -435,8 +461,9 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
     if (p->fuse_fill) {
         // ghost cells not filled by the caller: folded into the tile kernel where that
         // works, the ordinary fill first everywhere else
+        // (the spherical one-launch kernel reads every ghost cell through the boundary rules)
         const bool wave = !s->sph && (p->kernel_set == 2 || (p->kernel_set == -1 && wave_kernel_pays(s->g)));
-        if (!comp_can_fuse_fill(s, p, wave)) {
+        if (!comp_can_fuse_fill(s, p, wave) && !comp_can_fuse_sph(s, p)) {
             PYRO_TRY(pyrohip_fill_bc(s, -1));
             pf.fuse_fill = 0;
         }
@@ -447,20 +474,7 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
         PYRO_REQUIRE(p->riemann == 1, "a SphericalPolar grid needs the CGF Riemann solver");
         PYRO_REQUIRE(!s->user_bc && !s->ramp_bc && !s->heat && !s->ext_old,
                      "hse / ambient / ramp boundaries and heating are Cartesian-only");
-        // one launch (the tile kernel with the geometry terms) where the boundaries are index
-        // maps; the staged set (kernel_set 0: stage dumps) everywhere else
-        bool fuse_sph = p->kernel_set != 0 && !c_nb_set(s) && g_fits_tile(s);
-        for (int sd = 0; sd < 4 && fuse_sph; sd++) {
-            int kind0 = -1;
-            for (int n = 0; n < 4 && fuse_sph; n++) {
-                const int b = s->bc[n * 4 + sd];
-                const int kind = (b == PYROHIP_BC_OUTFLOW) ? 0
-                                 : (b == PYROHIP_BC_REFLECT_EVEN || b == PYROHIP_BC_REFLECT_ODD) ? 1
-                                 : (b == PYROHIP_BC_PERIODIC) ? 2 : -1;
-                if (kind < 0 || (n > 0 && kind != kind0)) fuse_sph = false;
-                kind0 = kind;
-            }
-        }
+        const bool fuse_sph = comp_can_fuse_sph(s, p);
         if (fuse_sph)
             rc = p->fast_math ? fastm::comp_step_fused_sph(s, p, dt) : exact::comp_step_fused_sph(s, p, dt);
         else

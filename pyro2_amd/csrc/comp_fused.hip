@@ -422,6 +422,44 @@ __device__ __forceinline__ Cons sphf_corrected(const Cons &U, const Cons &Fhi, d
     return r;
 }
 
+// method_compute_timestep takes its minimum over the WHOLE array (simulation.py:284-288), and
+// on this grid a ghost cell's Lx, Ly are its own: the minimum over the ghost cells that take
+// their value from interior cell (i, j) -- the cell's new state with the signs of the boundary
+// rule, the lengths of the ghost cell -- folded into `cfl`, so that the next dt needs neither a
+// ghost fill nor a reduction launch
+__device__ __forceinline__ double sphf_ghost_cfl(const Cons &U, double gamma, const Geom &g,
+                                                 const FP &P, const SphG &G, int i, int j, double cfl)
+{
+    const int ng = g.ng;
+    const bool ei = (i < g.ilo + ng) || (i > g.ihi - ng), ej = (j < g.jlo + ng) || (j > g.jhi - ng);
+    if (!ei && !ej) return cfl;
+    for (int a = -1; a < 2 * ng; a++) {       // a = -1: the cell's own row
+        int r = i;
+        if (a >= 0) {
+            r = a < ng ? a : g.ihi + 1 + (a - ng);
+            if (!ei || bc_src(P.mr, r, g.ilo, g.ihi) != i) continue;
+        }
+        for (int b = -1; b < 2 * ng; b++) {
+            int c = j;
+            if (b >= 0) {
+                c = b < ng ? b : g.jhi + 1 + (b - ng);
+                if (!ej || bc_src(P.mc, c, g.jlo, g.jhi) != j) continue;
+            }
+            if (a < 0 && b < 0) continue;
+            const unsigned sd = (r < g.ilo ? 1u : 0u) | (r > g.ihi ? 2u : 0u) | (c < g.jlo ? 4u : 0u) |
+                                (c > g.jhi ? 8u : 0u);
+            Cons Ug = U;
+            Ug.d = odd_sides(P.odd & sd) ? -Ug.d : Ug.d;
+            Ug.E = odd_sides((P.odd >> 4) & sd) ? -Ug.E : Ug.E;
+            Ug.mx = odd_sides((P.odd >> 8) & sd) ? -Ug.mx : Ug.mx;
+            Ug.my = odd_sides((P.odd >> 12) & sd) ? -Ug.my : Ug.my;
+            const size_t kk = (size_t)r * g.pitch + c;
+            cfl = fmin(cfl, cfl_cell(Ug, gamma, G.Lx[kk], G.Ly[kk]));
+        }
+    }
+    return cfl;
+}
+
 template <bool STD>
 __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused_sph(const double *__restrict__ Uin,
                                                        double *__restrict__ Uout, Geom g, FP P,
@@ -708,6 +746,7 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused_sph(const do
         Uw.my = Un[3] + 0.5 * dt * (Sy_new - Sy_old);
         Uout[k] = Uw.d; Uout[pl + k] = Uw.E; Uout[2 * pl + k] = Uw.mx; Uout[3 * pl + k] = Uw.my;
         cfl = cfl_cell(Uw, gamma, G.Lx[k], G.Ly[k]);
+        cfl = sphf_ghost_cfl(Uw, gamma, g, P, G, i, j, cfl);
     }
     cfl = block_reduce_min(cfl);
     if (t == 0) partial[tile] = cfl;
@@ -962,10 +1001,9 @@ int comp_step_fused_sph(pyrohip_state *s, const pyrohip_comp_params *p, double d
                 (const double *)Uin, Uout, g, P, G, s->d_flag, part);
     const double *dmin;
     PYRO_TRY(fused_tail(s, part, P.ntiles, true, &dmin, false));   // the kernel wrote the ghost frame
+    // (the minimum is method_compute_timestep's: whole array, ghost cells of the NEW state as the
+    // boundary rules will fill them included -- sphf_ghost_cfl; pyrohip_comp_dt takes it from here)
     const int rc = fused_sync(s, dmin);
-    // (the minimum is the one of method_compute_timestep's interior; the reference takes it over
-    // the whole array with its ghost cells: pyrohip_comp_dt recomputes, as after the staged set)
-    s->next_cfl_min = -1.0;
     s->cfl_is_global = false;
     return rc;
 }

@@ -1155,6 +1155,7 @@ def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
     f0, mx = g[pre + "drv"]
     fix = 0.005 if str(g[pre + "problem"]) == "advect" else -1.0
     nsteps = len(g[pre + "dts"])
+    staged = {}
     for fm in (0, 1):
         out = {}
         for ks in (0, -1):
@@ -1172,6 +1173,7 @@ def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
                 dts.append(dtn)
             out[ks] = (s.download(), dts)
         (Ua, da), (Ub, db) = out[0], out[-1]
+        staged[fm] = out[0]
         if fm == 0:
             assert da == db, (k, "dts")
             assert np.array_equal(Ua, Ub), (k, np.argwhere(Ua != Ub)[:5])
@@ -1179,6 +1181,42 @@ def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
             assert np.abs(np.array(db) / np.array(da) - 1).max() < 1e-10
             scale = np.maximum(np.abs(Ua).max(axis=(0, 1)), 1e-3)
             assert (np.abs(Ub - Ua) / scale).max() < 1e-10, k
+    # the next dt without a ghost fill or a reduction launch: the kernel's CFL minimum covers the
+    # ghost cells of the new state (their own Lx, Ly: on this grid NOT some interior cell's
+    # value) -- equal to method_compute_timestep's whole-array minimum after a fill; and the
+    # caller may leave the fill to the step (fuse_fill)
+    for fm in (0, 1):
+        P, cfl = dev_params(meta, kernel_set=-1, riemann="CGF", solid_xl=solid[0], solid_yl=solid[2],
+                            fast_math=fm, fuse_fill=1)
+        P0, _ = dev_params(meta, kernel_set=0, riemann="CGF", solid_xl=solid[0], solid_yl=solid[2],
+                           fast_math=fm)
+        s = comp_state(dev, nx, ny, bcs)
+        s.set_geometry(sph_arrays(g, pre), dom[0], dom[2])
+        s.upload(g[pre + "ic"])
+        s.fill_bc()
+        pol, dts = DtPolicy(1.e30, f0, mx, fix_dt=fix), []
+        for n in range(nsteps):
+            assert s.comp_dt_is_cached() == (n > 0)
+            dtn = pol(s.comp_dt(P, cfl))
+            s.comp_step(P, dtn)              # (no fill_bc: fuse_fill)
+            pol.advance(dtn)
+            dts.append(dtn)
+        cached = s.comp_dt(P, cfl)
+        U = s.download()
+        s2 = comp_state(dev, nx, ny, bcs)
+        s2.set_geometry(sph_arrays(g, pre), dom[0], dom[2])
+        s2.upload(U)
+        s2.fill_bc()
+        assert not s2.comp_dt_is_cached()
+        fresh = s2.comp_dt(P0, cfl)          # k_sph_cfl over the whole filled array
+        I = (slice(ng, -ng), slice(ng, -ng))
+        Us, ds = staged[fm]
+        if fm == 0:
+            assert cached == fresh, (k, cached, fresh)
+            assert dts == ds and np.array_equal(U[I], Us[I]), k
+        else:
+            assert abs(cached / fresh - 1) < 1e-13
+            assert np.abs(np.array(dts) / np.array(ds) - 1).max() < 1e-10
     # other boundary kinds (the geometry arrays do not depend on them): a reflecting wall with
     # its even / odd variables in both directions, periodic in theta -- momenta stirred so that
     # the signs of the ghost sources matter
