@@ -7,7 +7,7 @@
 # gpurun_out/profiles_<tag>/traffic.json:
 #   <tag>_provenance.json                commit, box (host, GPU id), date, ROCm -- every JSON below carries it too
 #   <tag>_pytest_gpu.txt                 pytest -m gpu summary line (TESTS=0 skips)
-#   <tag>_bench_default.json             python bench.py (the driver's command)
+#   <tag>_bench_default.json             python bench.py (the driver's command; ONLY=bench: just this, with <tag>_bench_default_provenance.json)
 #   <tag>_default16384_fm{1,0}_kernel_stats.csv, _pmc.json      the headline launch, both builds
 #   <tag>_sedov{8192,4096}_kernel_stats.csv, _pmc.json         north_star's target size, config 3
 #   traffic.json                         per size and build: bytes / instructions per cell update (tools/make_traffic.py)
@@ -36,6 +36,13 @@ stats() {   # stats <name> <command...>: rocprofv3 kernel statistics of a comman
   find $O/prof_${TAG}_$name -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} $P/${TAG}_${name}_kernel_stats.csv
   head -4 $P/${TAG}_${name}_kernel_stats.csv 2>/dev/null | cut -c1-200
 }
+if [ "${ONLY:-}" = "bench" ]; then
+  # only the driver's command again, at a later commit than the rest of the set: its own stamp
+  mv $P/${TAG}_provenance.json $P/${TAG}_bench_default_provenance.json
+  ( time timeout 600 python bench.py < /dev/null > $P/${TAG}_bench_default.json ) 2> $O/bench_${TAG}.err
+  head -c 300 $P/${TAG}_bench_default.json; echo; tail -3 $O/bench_${TAG}.err
+  exit 0
+fi
 if [ "${TESTS:-1}" = "1" ]; then
   ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu_${TAG}.log 2>&1
   grep -E "passed|failed|error" $O/pytest_gpu_${TAG}.log | tail -2 > $P/${TAG}_pytest_gpu.txt; cat $P/${TAG}_pytest_gpu.txt
