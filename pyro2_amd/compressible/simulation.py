@@ -225,10 +225,13 @@ class Simulation(NullSimulation):
 
     def can_evolve_many(self):
         """may the driver hand several steps at once to the device
-        (pyrohip_comp_evolve)?  Cartesian grid, standard boundary types, no sponge,
-        no tracer particles, a fused kernel set, nothing watching the data."""
+        (pyrohip_comp_evolve)?  Standard boundary types, no sponge, no tracer particles,
+        a fused kernel set, nothing watching the data (a SphericalPolar grid: its one-launch
+        step, i.e. no heating profile either)."""
         cc = self.cc_data
-        if cc.grid.coord_type != 0 or self.particles is not None or self._host_source():
+        if self.particles is not None or self._host_source():
+            return False
+        if cc.grid.coord_type != 0 and self._heating() is not None:
             return False
         if self.rp.get_param("sponge.do_sponge") or type(self).evolve is not Simulation.evolve:
             return False

@@ -17,6 +17,9 @@ int comp_step_wave_ex(pyrohip_state *, const pyrohip_comp_params *, double, cons
 int comp_cfl_min_device(pyrohip_state *, const pyrohip_comp_params *, const double **);
 int comp_step_sph(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_fused_sph(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_step_fused_sph_ex(pyrohip_state *, const pyrohip_comp_params *, double, const StepScalars *,
+                           const double **);
+int comp_cfl_min_device_sph(pyrohip_state *, const pyrohip_comp_params *, const double **);
 int comp_dt_sph(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_stage_dump(pyrohip_state *, int, double *);
 int comp_sponge(pyrohip_state *, const pyrohip_comp_params *, double);
@@ -40,6 +43,9 @@ int comp_step_wave_ex(pyrohip_state *, const pyrohip_comp_params *, double, cons
 int comp_cfl_min_device(pyrohip_state *, const pyrohip_comp_params *, const double **);
 int comp_step_sph(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_fused_sph(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_step_fused_sph_ex(pyrohip_state *, const pyrohip_comp_params *, double, const StepScalars *,
+                           const double **);
+int comp_cfl_min_device_sph(pyrohip_state *, const pyrohip_comp_params *, const double **);
 int comp_dt_sph(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 }
 }  // namespace pyro
@@ -228,9 +234,12 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
     PYRO_REQUIRE(max_steps >= 1, "max_steps must be positive");
     PYRO_REQUIRE(p->kernel_set != 0, "the staged kernel set steps from the host (kernel_set 0)");
     PYRO_REQUIRE(p->riemann >= 0 && p->riemann <= 2, "riemann must be 0 (HLLC), 1 (CGF) or 2 (HLLC_lm)");
-    PYRO_REQUIRE(!s->sph && !s->user_bc && !s->ramp_bc && !p->do_sponge && !s->ext_old,
-                 "device-side stepping: Cartesian grid, standard boundaries, no sponge, no "
-                 "host-evaluated source (use pyrohip_comp_dt / pyrohip_comp_step)");
+    // (a SphericalPolar grid steps on the device where its step is one launch: comp_can_fuse_sph)
+    const bool sphf = s->sph != nullptr && comp_can_fuse_sph(s, p);
+    PYRO_REQUIRE((!s->sph || sphf) && !s->user_bc && !s->ramp_bc && !p->do_sponge && !s->ext_old,
+                 "device-side stepping: standard boundaries, no sponge, no host-evaluated source; "
+                 "a SphericalPolar grid needs CGF and outflow / reflect / periodic sides "
+                 "(use pyrohip_comp_dt / pyrohip_comp_step)");
     pyrohip_ctx *c = s->ctx;
     if (!s->d_scal) PYRO_CHECK_HIP(hipMalloc((void **)&s->d_scal, sizeof(StepScalars)));
     if (s->dts_cap < max_steps + 1) {
@@ -247,15 +256,16 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
     PYRO_CHECK_HIP(hipMemcpyAsync(s->d_scal, &H, sizeof(H), hipMemcpyHostToDevice, c->stream));
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));      // H is on this stack frame
     PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
-    const bool wave = (p->kernel_set == 2) ||
-                      (p->kernel_set == -1 && wave_kernel_pays(s->g));
+    const bool wave = !sphf && ((p->kernel_set == 2) ||
+                                (p->kernel_set == -1 && wave_kernel_pays(s->g)));
     const double *dmin = nullptr;
     bool first = true;
     int rc = 0;
     s->pend_part = nullptr;
     // steps after the first: the tile kernel applies the boundary rules itself where it can
     // (the first one needs filled ghost cells for the CFL minimum over the whole array)
-    const bool fuse = comp_can_fuse_fill(s, p, wave);
+    // (the spherical kernel reads every ghost cell through the boundary rules anyway)
+    const bool fuse = sphf || comp_can_fuse_fill(s, p, wave);
     pyrohip_comp_params pf = *p;
     // step_launches 1: the row-marching kernel as the ONLY launch of a step (single domain;
     // outflow / reflect / periodic sides, the same kind for the four variables): it reads ghost
@@ -321,8 +331,12 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
         }
         if (rc) break;
         if (first) {   // CFL minimum of the state as handed over (full array, ghost cells filled)
-            rc = p->fast_math ? fastm::comp_cfl_min_device(s, p, &dmin)
-                              : exact::comp_cfl_min_device(s, p, &dmin);
+            if (sphf)
+                rc = p->fast_math ? fastm::comp_cfl_min_device_sph(s, p, &dmin)
+                                  : exact::comp_cfl_min_device_sph(s, p, &dmin);
+            else
+                rc = p->fast_math ? fastm::comp_cfl_min_device(s, p, &dmin)
+                                  : exact::comp_cfl_min_device(s, p, &dmin);
             if (rc) break;
             // decomposed run: every rank steps with the minimum over ALL slabs -- also in the
             // first step of a call (found by running four ranks on one GPU: the slabs far from
@@ -343,7 +357,10 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
         s->next_cfl_min = 1.0;      // "cached on the device": keeps a posted halo exchange valid
         s->pol_next = d_pol;    // (one launch per step: this is step 0, its dt is in S[0])
         s->pol_m = 0;
-        if (wave)
+        if (sphf)
+            rc = p->fast_math ? fastm::comp_step_fused_sph_ex(s, &pf, 0.0, s->d_scal, &dmin)
+                              : exact::comp_step_fused_sph_ex(s, &pf, 0.0, s->d_scal, &dmin);
+        else if (wave)
             rc = p->fast_math ? fastm::comp_step_wave_ex(s, p, 0.0, d_scal0, &dmin)
                               : exact::comp_step_wave_ex(s, p, 0.0, d_scal0, &dmin);
         else

@@ -462,11 +462,21 @@ __device__ __forceinline__ double sphf_ghost_cfl(const Cons &U, double gamma, co
 
 template <bool STD>
 __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused_sph(const double *__restrict__ Uin,
-                                                       double *__restrict__ Uout, Geom g, FP P,
+                                                       double *__restrict__ Uout, Geom g, FP P_in,
                                                        SphG G, int *__restrict__ flag,
-                                                       double *__restrict__ partial)
+                                                       double *__restrict__ partial,
+                                                       const StepScalars *__restrict__ SC)
 {
     HIP_DYNAMIC_SHARED(double, lds)
+    FP P = P_in;
+    if (SC) {   // device-side run (pyrohip_comp_evolve): this step's dt lives in device memory
+        if (!SC->active) {
+            if (threadIdx.x == 0 && threadIdx.y == 0)
+                partial[xcd_tile(blockIdx.x, P.ntiles)] = INFINITY;
+            return;
+        }
+        P.dt = SC->dt;
+    }
     double *B0 = lds;                 // Q (phase 0-1) | FT (2-3) | F (4-5)
     double *S = lds + FBUF0;          // upper face states XP(0..3), YP(4..7)
     double *D = S + 8 * FNT;          // vertex div(U)
@@ -964,13 +974,16 @@ int comp_step_fused(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
 
 // SphericalPolar grid, one step with the host's dt in ONE launch (k_ctu_fused_sph); the caller
 // (pyrohip_comp_step) checked comp_can_fuse_sph(): CGF, outflow / reflect / periodic sides
-int comp_step_fused_sph(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+// S == nullptr: one step with the host's dt; S != nullptr (pyrohip_comp_evolve): dt from *S on the
+// device, nothing read back, *dmin_out = device address of the new CFL minimum (comp_step_fused_ex)
+int comp_step_fused_sph_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
+                           const StepScalars *S, const double **dmin_out)
 {
     pyrohip_ctx *c = s->ctx;
     const Geom &g = s->g;
     FP P;
     double *Uin, *Uout;
-    PYRO_TRY(fused_prepare(s, p, dt, P, Uin, Uout, true));
+    PYRO_TRY(fused_prepare(s, p, dt, P, Uin, Uout, S == nullptr));
     // ghost cells (of the state and of the source terms) through the boundary rules
     P.mr = bc_map(g.ilo, g.ihi, g.ng, s->bc[0], s->bc[1], true);
     P.mc = bc_map(g.jlo, g.jhi, g.ng, s->bc[2], s->bc[3], true);
@@ -984,7 +997,8 @@ int comp_step_fused_sph(pyrohip_state *s, const pyrohip_comp_params *p, double d
     P.ntiles = nti * P.ntj;
     PYRO_TRY(c->reduce.ensure((P.ntiles + kMinStageBlocks + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
-    using KernelT = void (*)(const double *, double *, Geom, FP, SphG, int *, double *);
+    using KernelT = void (*)(const double *, double *, Geom, FP, SphG, int *, double *,
+                             const StepScalars *);
     static const KernelT kernels[2] = {k_ctu_fused_sph<false>, k_ctu_fused_sph<true>};
 #ifndef PYRO_EMU
     static bool attr_set = false;
@@ -998,14 +1012,20 @@ int comp_step_fused_sph(pyrohip_state *s, const pyrohip_comp_params *p, double d
 #endif
     const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
     PYRO_LAUNCH(c, "k_ctu_fused_sph", kernels[std_rec], dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES_SPH,
-                (const double *)Uin, Uout, g, P, G, s->d_flag, part);
+                (const double *)Uin, Uout, g, P, G, s->d_flag, part, S);
     const double *dmin;
-    PYRO_TRY(fused_tail(s, part, P.ntiles, true, &dmin, false));   // the kernel wrote the ghost frame
+    PYRO_TRY(fused_tail(s, part, P.ntiles, true, &dmin, S != nullptr));   // the kernel wrote the ghost frame
+    if (S) { fused_swap(s); *dmin_out = dmin; s->halo_pending = false; return 0; }
     // (the minimum is method_compute_timestep's: whole array, ghost cells of the NEW state as the
     // boundary rules will fill them included -- sphf_ghost_cfl; pyrohip_comp_dt takes it from here)
     const int rc = fused_sync(s, dmin);
     s->cfl_is_global = false;
     return rc;
+}
+
+int comp_step_fused_sph(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+{
+    return comp_step_fused_sph_ex(s, p, dt, nullptr, nullptr);
 }
 
 }  // namespace PYRO_NS

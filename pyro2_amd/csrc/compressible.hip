@@ -910,6 +910,21 @@ static SG make_sg(const pyrohip_state *s)
               h.ymin};
 }
 
+// ... left in device memory (no read-back): the first step of a device-side run
+int comp_cfl_min_device_sph(pyrohip_state *s, const pyrohip_comp_params *p, const double **dmin)
+{
+    pyrohip_ctx *c = s->ctx;
+    dim3 grid(8, 128), block(256);
+    const int nb = grid.x * grid.y;
+    PYRO_TRY(c->reduce.ensure((nb + kMinStageBlocks + 2) * sizeof(double)));
+    double *part = (double *)c->reduce.p;
+    hipLaunchKernelGGL(k_sph_cfl, grid, block, 0, c->stream, (const double *)s->d, s->g, p->gamma,
+                       s->sph->Lx, s->sph->Ly, part);
+    *dmin = launch_min_reduce(c->stream, part, nb);
+    PYRO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int comp_dt_sph(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, double *dt_out)
 {
     pyrohip_ctx *c = s->ctx;

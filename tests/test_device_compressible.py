@@ -1217,6 +1217,30 @@ def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
         else:
             assert abs(cached / fresh - 1) < 1e-13
             assert np.abs(np.array(dts) / np.array(ds) - 1).max() < 1e-10
+    # device-side stepping (pyrohip_comp_evolve: the first CFL minimum by k_sph_cfl, then the
+    # kernel's own whole-array minima and the dt policy kernel, no host round trip per step), in
+    # two calls, against the steps taken one by one: dt sequence, time and the WHOLE array
+    for fm in (0, 1):
+        P, cfl = dev_params(meta, kernel_set=-1, riemann="CGF", solid_xl=solid[0], solid_yl=solid[2],
+                            fast_math=fm)
+        s = comp_state(dev, nx, ny, bcs)
+        s.set_geometry(sph_arrays(g, pre), dom[0], dom[2])
+        s.upload(g[pre + "ic"])
+        pol, dts = DtPolicy(1.e30, f0, mx, fix_dt=fix), []
+        for c in (3, nsteps - 3):
+            dts += list(s.comp_evolve(P, cfl, pol, c))
+        s1 = comp_state(dev, nx, ny, bcs)
+        s1.set_geometry(sph_arrays(g, pre), dom[0], dom[2])
+        s1.upload(g[pre + "ic"])
+        pol1, d1 = DtPolicy(1.e30, f0, mx, fix_dt=fix), []
+        for _ in range(nsteps):
+            s1.fill_bc()
+            dtn = pol1(s1.comp_dt(P, cfl))
+            s1.comp_step(P, dtn)
+            pol1.advance(dtn)
+            d1.append(dtn)
+        assert dts == d1 and pol.t == pol1.t and pol.n == nsteps, (k, fm)
+        assert np.array_equal(s.download(), s1.download()), (k, fm)
     # other boundary kinds (the geometry arrays do not depend on them): a reflecting wall with
     # its even / odd variables in both directions, periodic in theta -- momenta stirred so that
     # the signs of the ghost sources matter
