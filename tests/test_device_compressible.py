@@ -1241,6 +1241,26 @@ def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
             d1.append(dtn)
         assert dts == d1 and pol.t == pol1.t and pol.n == nsteps, (k, fm)
         assert np.array_equal(s.download(), s1.download()), (k, fm)
+        if fm == 0 and fix < 0:
+            # tmax inside the call: the spare launches do nothing, the state is the one at tmax
+            tmax = float(np.sum(d1[:3])) + 0.4 * float(d1[3])
+            s = comp_state(dev, nx, ny, bcs)
+            s.set_geometry(sph_arrays(g, pre), dom[0], dom[2])
+            s.upload(g[pre + "ic"])
+            pol = DtPolicy(tmax, f0, mx)
+            dts = list(s.comp_evolve(P, cfl, pol, nsteps))
+            s1 = comp_state(dev, nx, ny, bcs)
+            s1.set_geometry(sph_arrays(g, pre), dom[0], dom[2])
+            s1.upload(g[pre + "ic"])
+            pol1, d1t = DtPolicy(tmax, f0, mx), []
+            while pol1.t < tmax:
+                s1.fill_bc()
+                dtn = pol1(s1.comp_dt(P, cfl))
+                s1.comp_step(P, dtn)
+                pol1.advance(dtn)
+                d1t.append(dtn)
+            assert dts == d1t and len(dts) == 4 and pol.t == tmax == pol1.t, (k, dts, d1t)
+            assert np.array_equal(s.download(), s1.download()), k
     # other boundary kinds (the geometry arrays do not depend on them): a reflecting wall with
     # its even / odd variables in both directions, periodic in theta -- momenta stirred so that
     # the signs of the ghost sources matter
