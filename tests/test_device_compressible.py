@@ -1261,6 +1261,17 @@ def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
                 d1t.append(dtn)
             assert dts == d1t and len(dts) == 4 and pol.t == tmax == pol1.t, (k, dts, d1t)
             assert np.array_equal(s.download(), s1.download()), k
+            # an invalid state handed to a call: error, nothing advances, the state stays
+            from pyro2_amd._lib import ERR_STATE, PyroHipError
+            bad = s1.download().copy()
+            bad[ng + 5, ng + 3, 1] = -1.0
+            s1.upload(bad)
+            polb = DtPolicy(1.e30, f0, mx)
+            polb.t, polb.n, polb.dt_old = pol1.t, pol1.n, pol1.dt_old
+            with pytest.raises(PyroHipError) as ei:
+                s1.comp_evolve(P, cfl, polb, 3)
+            assert ei.value.code == ERR_STATE and polb.n == pol1.n and polb.t == pol1.t
+            assert np.array_equal(s1.download()[ng:-ng, ng:-ng], bad[ng:-ng, ng:-ng])
     # other boundary kinds (the geometry arrays do not depend on them): a reflecting wall with
     # its even / odd variables in both directions, periodic in theta -- momenta stirred so that
     # the signs of the ghost sources matter
