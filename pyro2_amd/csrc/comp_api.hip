@@ -87,17 +87,14 @@ static bool comp_can_fuse_fill(const pyrohip_state *s, const pyrohip_comp_params
     return true;
 }
 
-static bool c_nb_set(const pyrohip_state *s) { return s->nb_set; }
-// (the tile kernel's apron: 4 ghost cells must hold what a tile at the far side needs)
-static bool g_fits_tile(const pyrohip_state *s) { return s->g.ng >= 4 && s->g.nx >= 4 && s->g.ny >= 4; }
-
 // SphericalPolar grid: one launch (k_ctu_fused_sph) where the boundaries are index maps -- the
 // same kind (outflow / reflect / periodic) for the four variables on every side; the staged set
 // (kernel_set 0: stage dumps) everywhere else
 static bool comp_can_fuse_sph(const pyrohip_state *s, const pyrohip_comp_params *p)
 {
-    if (!s->sph || p->kernel_set == 0 || c_nb_set(s) || !g_fits_tile(s) || s->user_bc || s->ramp_bc ||
-        s->heat || s->ext_old || p->riemann != 1)
+    // (single domain; the tile kernel's 4-cell apron needs ng >= 4 and as many interior cells)
+    if (!s->sph || p->kernel_set == 0 || s->nb_set || s->g.ng < 4 || s->g.nx < 4 || s->g.ny < 4 ||
+        s->user_bc || s->ramp_bc || s->heat || s->ext_old || p->riemann != 1)
         return false;
     for (int sd = 0; sd < 4; sd++) {
         int kind0 = -1;
