@@ -470,7 +470,7 @@ def reference_baseline(section, key):
                       (f"{r['steps']} steps, {r['seconds_per_step']:.3f} s/step" if "steps" in r else
                        f"{r['cycles']} V-cycles, {r['seconds_per_vcycle']:.2f} s/V-cycle") +
                       f"; host {ref['cpu']} ({ref['host_cores']} cores, 1 used: the reference is "
-                      f"single-threaded), {ref['date']}, oracle/time_reference.py -- measured in the "
+                      f"single-threaded), {ref[section].get('date', ref['date'])}, oracle/time_reference.py -- measured in the "
                       "build container, not on the GPU box"}
 
 
@@ -742,6 +742,9 @@ def bench_pyro_driver(ctx, device, bare):
         (16 + 24, "read + write phi (16 B) and the Crank-Nicolson right-hand side pass (24 B) per cell and "
                   "step; the multigrid solve on top is priced in also.multigrid (V-cycles per step "
                   "reported beside it)"))
+    ref = reference_baseline("diffusion", "2048")      # the reference itself (pure NumPy + its multigrid)
+    if ref:
+        out["diffusion_gaussian_2048"]["cpu_baseline"] = ref
     out["swe_dam_4096"] = bench_pyro_run(
         ctx, device, "swe", "dam", {"mesh.nx": 4096, "mesh.ny": 4096}, 20, 3,
         (48, "read 3 + write 3 conserved doubles per cell update"), inputs_file="inputs.dam.x")

@@ -146,7 +146,40 @@ def time_compressible_numpy_stages(nx, steps):
             "value_upper_bound": nx * nx * steps / el, "unit": "cell-updates/s", "cores": 1}
 
 
+def time_diffusion(nx, steps):
+    """Pyro("diffusion") gaussian nx^2 (pure NumPy + the multigrid solver: the reference at its
+    true speed): seconds per Pyro.single_step, pyro/diffusion/simulation.py:70-122"""
+    p = Pyro("diffusion")
+    p.initialize_problem("gaussian", inputs_dict={"mesh.nx": nx, "mesh.ny": nx,
+                                                  "driver.max_steps": 10 ** 6, "driver.tmax": 1.0e9})
+    p.single_step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        p.single_step()
+    el = time.perf_counter() - t0
+    return {"workload": f"diffusion gaussian {nx}x{nx} (inputs.gaussian), Pyro.single_step",
+            "nx": nx, "steps": steps, "seconds_per_step": el / steps,
+            "value": nx * nx * steps / el, "unit": "cell-updates/s", "cores": 1}
+
+
+def only_diffusion():
+    """add / refresh the diffusion section of profiles/cpu_reference.json (the other legs keep
+    their numbers and date; this section carries its own)"""
+    out = json.load(open(OUT))
+    sec = {"date": time.strftime("%Y-%m-%d %H:%M:%S %Z")}
+    for nx, steps in ((512, 3), (2048, 2)):
+        r = time_diffusion(nx, steps)
+        sec[str(nx)] = r
+        print("diffusion", nx, r["seconds_per_step"], "s/step", r["value"], "cells/s", flush=True)
+    out["diffusion"] = sec
+    with open(OUT, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", os.path.abspath(OUT))
+
+
 def main():
+    if "--only-diffusion" in sys.argv:
+        return only_diffusion()
     quick = "--quick" in sys.argv
     out = {"host": platform.node(), "cpu": cpu_model(), "host_cores": os.cpu_count(),
            "cores_used": 1,
