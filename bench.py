@@ -78,6 +78,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--cpu-sample-nx", type=int, default=1024)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="bound of the cpu_baseline sample (seconds of one host core)")
+    ap.add_argument("--also-div", type=int, default=1,
+                    help="> 1: the secondary legs run on grids this many times smaller and a few steps "
+                         "(tests/test_bench_line.py runs the whole script on the host emulator)")
     ap.add_argument("--developed-steps", type=int, default=250)
     ap.add_argument("--no-developed", action="store_true")
     ap.add_argument("--scale-check", action="store_true", default=None,
@@ -159,6 +164,38 @@ class Dist:
             t = torch.frombuffer(bytearray(b), dtype=torch.uint8).clone()
         self.td.broadcast(t, 0)
         return bytes(t.numpy().tobytes())
+
+
+def device_identity(index):
+    """an integer naming the physical GPU behind HIP device `index` on this host (its PCI
+    domain:bus:device.function), or None.  bench.py --gpus N compares the ranks' identities:
+    a first SCALE line must not silently be N ranks on one device"""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) != 0:
+            return None
+        dom, bus, rest = buf.value.decode().split(":")
+        dev, fn = rest.split(".")
+        return (int(dom, 16) << 24) | (int(bus, 16) << 16) | (int(dev, 16) << 8) | int(fn, 16)
+    except Exception:      # noqa: BLE001 -- the host emulator has no HIP runtime
+        return None
+
+
+def check_rank_devices(dist, ident, rccl_ranks):
+    """every rank of a --gpus N run on a GPU of its own and all N in the communicator, else
+    the run is either flagged (oversubscribed debug run) or refused"""
+    ids = [int(row[0]) for row in dist.gather([float(ident if ident is not None else -1 - dist.rank)])]
+    distinct = len(set(ids)) == len(ids)
+    if dist.world > 1 and dist.comm_kind == "rccl" and rccl_ranks != dist.world:
+        sys.exit(f"bench.py rank {dist.rank}: FATAL: the RCCL communicator has {rccl_ranks} ranks, "
+                 f"--gpus says {dist.world}")
+    if dist.world > 1 and not distinct and not dist.oversubscribed:
+        sys.exit(f"bench.py rank {dist.rank}: FATAL: {dist.world} ranks but only {len(set(ids))} distinct "
+                 f"GPUs (PCI ids {ids}): not a scaling run.  (A box with fewer GPUs than ranks is "
+                 "detected and flagged as config.oversubscribed; this is a launcher / visibility problem.)")
+    return ids, distinct
 
 
 def also_traffic(section, key):
@@ -713,50 +750,58 @@ def bench_pyro_run(ctx, device, solver, problem, inputs, steps, warm, model=None
     return out
 
 
-def bench_pyro_driver(ctx, device, bare):
+def bench_pyro_driver(ctx, device, bare, n_=lambda n, lo=32: n, k_=lambda k, few=3: k):
     """the two hyperbolic solvers timed through Pyro.run_sim() -- the call
     surface north_star keeps -- next to the bare C-ABI legs of this line (`bare`: ms per step
     of also.sedov_4096 / also.advection), and one-line legs of the SURVEY 8(f) solvers with
-    the bytes model each is priced with."""
+    the bytes model each is priced with (and, where oracle/time_reference.py has timed it, the
+    reference itself on one host core as `cpu_baseline`)."""
     out = {}
+
+    def leg(name, *a, bare_ms=None, ref=None, note=None, **kw):
+        try:
+            r = bench_pyro_run(ctx, device, *a, **kw)
+        except Exception as e:      # noqa: BLE001 -- one solver's failure must not hide the others
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+            return
+        if bare_ms:
+            r["bare_c_abi_ms_per_step"] = bare_ms
+            r["ratio_to_bare"] = bare_ms / r["ms_per_step"]
+        if note:
+            r["note"] = note
+        cb = reference_baseline(*ref) if ref else None
+        if cb:
+            r["cpu_baseline"] = cb
+        out[name] = r
+
     # (the same steps of the same run as the bare leg also.sedov_4096: 100 after 5 untimed ones --
     # later steps cost more, the blast grows)
-    r = bench_pyro_run(ctx, device, "compressible", "sedov", {"mesh.nx": 4096, "mesh.ny": 4096}, 100, 5,
-                       (SEDOV_BYTES_PER_CELL, "64 B per cell update (SURVEY 8(d))"))
-    if bare.get("sedov_4096"):
-        r["bare_c_abi_ms_per_step"] = bare["sedov_4096"]
-        r["ratio_to_bare"] = bare["sedov_4096"] / r["ms_per_step"]
-    out["compressible_sedov_4096"] = r
-    r = bench_pyro_run(ctx, device, "advection", "smooth",
-                       {"mesh.nx": 2048, "mesh.ny": 2048, "particles.do_particles": 0}, 768, 48,
-                       (ADV_BYTES_PER_CELL, "16 B per cell update"))
-    r["note"] = ("inputs.smooth carries 100 tracer particles (host-side NumPy, two grid-sized velocity "
-                 "arrays per call): switched off here, the leg times the grid update")
-    if bare.get("advection"):
-        r["bare_c_abi_ms_per_step"] = bare["advection"]
-        r["ratio_to_bare"] = bare["advection"] / r["ms_per_step"]
-    out["advection_smooth_2048"] = r
-    # SURVEY 8(f) rows: parity-tested solvers that had no timing at all
-    out["diffusion_gaussian_2048"] = bench_pyro_run(
-        ctx, device, "diffusion", "gaussian", {"mesh.nx": 2048, "mesh.ny": 2048}, 10, 2,
+    leg("compressible_sedov_4096", "compressible", "sedov", {"mesh.nx": n_(4096), "mesh.ny": n_(4096)},
+        k_(100), k_(5), (SEDOV_BYTES_PER_CELL, "64 B per cell update (SURVEY 8(d))"),
+        bare_ms=bare.get("sedov_4096"))
+    leg("advection_smooth_2048", "advection", "smooth",
+        {"mesh.nx": n_(2048), "mesh.ny": n_(2048), "particles.do_particles": 0}, k_(768, 6), k_(48, 6),
+        (ADV_BYTES_PER_CELL, "16 B per cell update"), bare_ms=bare.get("advection"),
+        note="inputs.smooth carries 100 tracer particles (host-side NumPy, two grid-sized velocity "
+             "arrays per call): switched off here, the leg times the grid update")
+    # SURVEY 8(f) rows
+    leg("diffusion_gaussian_2048", "diffusion", "gaussian", {"mesh.nx": n_(2048), "mesh.ny": n_(2048)},
+        k_(10, 1), k_(2, 1),
         (16 + 24, "read + write phi (16 B) and the Crank-Nicolson right-hand side pass (24 B) per cell and "
                   "step; the multigrid solve on top is priced in also.multigrid (V-cycles per step "
-                  "reported beside it)"))
-    ref = reference_baseline("diffusion", "2048")      # the reference itself (pure NumPy + its multigrid)
-    if ref:
-        out["diffusion_gaussian_2048"]["cpu_baseline"] = ref
-    out["swe_dam_4096"] = bench_pyro_run(
-        ctx, device, "swe", "dam", {"mesh.nx": 4096, "mesh.ny": 4096}, 20, 3,
-        (48, "read 3 + write 3 conserved doubles per cell update"), inputs_file="inputs.dam.x")
-    out["compressible_rk_sedov_2048"] = bench_pyro_run(
-        ctx, device, "compressible_rk", "sedov", {"mesh.nx": 2048, "mesh.ny": 2048}, 20, 3,
+                  "reported beside it)"), ref=("diffusion", "2048"))
+    leg("swe_dam_4096", "swe", "dam", {"mesh.nx": n_(4096), "mesh.ny": n_(4096)}, k_(20), k_(3),
+        (48, "read 3 + write 3 conserved doubles per cell update"), inputs_file="inputs.dam.x",
+        ref=("swe", "2048"))
+    leg("compressible_rk_sedov_2048", "compressible_rk", "sedov", {"mesh.nx": n_(2048), "mesh.ny": n_(2048)},
+        k_(20), k_(3),
         (4 * 64, "4 stages (RK4, the solver's default) x 64 B per cell: every stage reads the state and "
-                 "writes a right-hand side"))
-    out["compressible_sedov_spherical_2048"] = bench_pyro_run(
-        ctx, device, "compressible", "sedov", {"mesh.nx": 2048, "mesh.ny": 2048}, 10, 2,
+                 "writes a right-hand side"), ref=("compressible_rk", "1024"))
+    leg("compressible_sedov_spherical_2048", "compressible", "sedov",
+        {"mesh.nx": n_(2048, 64), "mesh.ny": n_(2048, 64)}, k_(10), k_(2),
         (SEDOV_BYTES_PER_CELL, "64 B per cell update (one launch per step since round 4: the tile kernel "
                                "with the geometry terms, k_ctu_fused_sph; + 8 geometry planes read)"),
-        inputs_file="inputs.sedov.spherical")
+        inputs_file="inputs.sedov.spherical", ref=("compressible_spherical", "1024"))
     return out
 
 
@@ -784,7 +829,7 @@ def bench_small_grids(ctx, device, sizes=(64, 256, 512), steps=400):
                         "fast build", "sizes": out}
 
 
-def cpu_baseline_sedov(sample_nx, max_seconds=25.0):
+def cpu_baseline_sedov(sample_nx, max_seconds=12.0):
     """the oracle (single-threaded C port of the reference) on a bounded sample
     of the same workload: Sedov, same physics, sample_nx^2, from t = 0"""
     from oracle import orc
@@ -817,6 +862,165 @@ def cpu_baseline_sedov(sample_nx, max_seconds=25.0):
                       f"{sample_nx}x{sample_nx}, {n} steps from t=0, {el:.1f} s; host has "
                       f"{os.cpu_count()} cores; the reference itself is single-threaded "
                       f"NumPy/numba (SURVEY 8(d))"}
+
+
+LINE_LIMIT = 4096       # the driver keeps a bounded tail of stdout: the ONE line must fit it whole
+
+
+def _rnd(x, sig=6):
+    """floats to `sig` significant digits (the full-precision record goes to the side file)"""
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, dict):
+        return {k: _rnd(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_rnd(v, sig) for v in x]
+    return x
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(out, full_path=None):
+    """The ONE stdout line of the bench contract, <= LINE_LIMIT bytes: headline, roofline,
+    cpu_baseline, and `targets` = one figure per secondary leg (round 4's
+    30 KB line did not survive the driver's tail buffer).  Everything else -- every `also` leg
+    with its notes, per-kernel tables, provenance -- goes to the side file / stderr."""
+    line = _pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                 "higher_is_better", "scaling", "dtype", "data")
+    line["vs_baseline"] = out.get("vs_baseline")
+    cfg = out.get("config", {})
+    c = _pick(cfg, "workload", "parallelism", "halo", "rccl_ranks", "fast_math", "kernel_set",
+              "sim_time", "oversubscribed", "halo_note")
+    if len(c.get("workload", "")) > 200:
+        c["workload"] = c["workload"][:197] + "..."
+    c["dt_policy"] = str(cfg.get("dt_policy", "")).split(" (")[0]
+    c["state"] = str(cfg.get("state", "")).split(" (")[0]
+    sc = cfg.get("scale_check")
+    if isinstance(sc, dict):
+        c["scale_check"] = _pick(sc, "ok", "bit_identical", "nx", "steps", "max_abs_diff", "ranks")
+    elif sc is not None:
+        c["scale_check"] = sc
+    line["config"] = c
+    rf = out.get("roofline")
+    if rf:
+        dom = rf.get("dominant_kernel")
+        r = _pick(rf, "bound", "achieved", "peak", "unit", "frac", "frac_of_achievable", "traffic",
+                  "update_kernels_ms_per_step", "stream_event_ms_per_step")
+        r["kernel"] = dom
+        r["kernel_avg_ms"] = (rf.get("kernels", {}).get(dom) or {}).get("avg_ms")
+        r["kernel_timer"] = "HIP events per launch, instrumented pass after the timed steps"
+        ts = rf.get("traffic_source")
+        if ts:
+            r["traffic_source"] = {"file": ts.get("file"), "counted_at_nx": ts.get("counted_at_nx"),
+                                   "commit": (ts.get("provenance") or {}).get("commit"),
+                                   "note": "separate rocprofv3 --pmc session, not counters of this run"}
+        r.setdefault("traffic", None)
+        line["roofline"] = r
+    f64 = out.get("roofline_fp64")
+    if f64:
+        vi = f64.get("valu_issue") or {}
+        line["roofline_fp64"] = {"bound": "fp64_valu_issue", "frac": vi.get("frac"),
+                                 "valu_lane_insts_per_cell_update": vi.get("valu_lane_insts_per_cell_update"),
+                                 "valu_busy": vi.get("valu_busy_frac_of_kernel_time"),
+                                 "flop_frac": f64.get("frac"), "counted_at_nx": vi.get("counted_at_nx"),
+                                 "commit": (vi.get("provenance") or {}).get("commit")}
+    cb = out.get("cpu_baseline")
+    if cb:
+        b = _pick(cb, "value", "unit", "cores", "kind")
+        b["sample"] = str(cb.get("sample", ""))[:160]
+        ref = cb.get("reference_numpy_stages_only")
+        if ref:
+            b["reference_upper_bound"] = {"value": ref["value_upper_bound"][-1], "at_nx": ref["at_nx"][-1],
+                                          "cores": ref.get("cores"), "kind": "reference, njit kernels stubbed"}
+        line["cpu_baseline"] = b
+    rk = out.get("ranks")
+    if rk:
+        t = rk.get("per_rank", {})
+        line["ranks"] = {k: t[k] for k in ("kernel_ms", "halo_wait_ms", "halo_sync_ms", "allreduce_ms",
+                                           "stream_ms_per_step") if k in t}
+        line["ranks"]["wavefronts"] = rk.get("max", {}).get("wavefronts")
+        line["ranks"]["predicted_ms_per_step"] = rk.get("predicted_ms_per_step")
+        if "gpu_unique_ids_distinct" in rk:
+            line["ranks"]["gpu_unique_ids_distinct"] = rk["gpu_unique_ids_distinct"]
+    also = out.get("also")
+    if also:
+        line["targets"] = targets_of(also)
+    if full_path:
+        line["full_record"] = full_path
+    line = _rnd(line)
+    s = json.dumps(line, separators=(",", ":"))
+    # belt and braces: shed the optional parts until the line fits
+    for k in ("targets", "ranks", "roofline_fp64"):
+        if len(s) < LINE_LIMIT:
+            break
+        if k == "targets" and isinstance(line.get("targets"), dict):
+            line["targets"] = {a: _pick(b, "value", "frac", "step_frac", "ms_per_step")
+                               for a, b in line["targets"].items()}
+        else:
+            line.pop(k, None)
+        s = json.dumps(line, separators=(",", ":"))
+    assert len(s) < LINE_LIMIT, len(s)
+    return s
+
+
+def targets_of(also):
+    """one compact entry per secondary leg: the figure VERDICT / north_star quote it by"""
+    t = {}
+
+    def leg(name, d, *keys):
+        if isinstance(d, dict) and "error" not in d:
+            e = _pick(d, *keys)
+            rf = d.get("roofline") or {}
+            for k in ("frac", "step_frac", "kernel_avg_ms"):
+                if k in rf and rf[k] is not None:
+                    e[k] = rf[k]
+            if e:
+                t[name] = e
+        elif isinstance(d, dict):
+            t[name] = {"error": str(d["error"])[:80]}
+
+    for name in ("sedov_exact", "sedov_fast", "sedov_developed", "sedov_4096", "sedov_8192"):
+        leg(name, also.get(name), "value", "ms_per_step")
+    for name in ("sedov_developed", "sedov_4096", "sedov_8192"):
+        ob = (also.get(name) or {}).get("other_build")
+        if isinstance(ob, dict) and name in t and "error" not in t[name]:
+            t[name]["exact_value" if ob.get("fast_math") == 0 else "fast_value"] = ob.get("value")
+    leg("advection_2048", also.get("advection"), "value", "ms_per_step")
+    leg("advection_8192", also.get("advection_8192"), "value", "ms_per_step")
+    mg = also.get("multigrid")
+    if isinstance(mg, dict):
+        leg("mg_4096", mg, "value", "unit", "ms_per_vcycle", "ms_per_step")
+    leg("incompressible_2048", also.get("incompressible"), "value", "ms_per_step")
+    pd = also.get("pyro_driver")
+    if isinstance(pd, dict):
+        if "error" in pd:
+            t["pyro_driver"] = {"error": str(pd["error"])[:80]}
+        else:
+            t["pyro_driver"] = {k: _pick(v, "ms_per_step", "value", "ratio_to_bare", "frac", "step_frac")
+                                for k, v in pd.items() if isinstance(v, dict)}
+    return t
+
+
+def emit(out, json_fd):
+    """full record -> bench_full.json (under gpurun_out/ when that exists or can be made) and,
+    leg by leg, stderr; the compact line -> stdout, last"""
+    full_path = None
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT, "/tmp"):
+        try:
+            os.makedirs(d, exist_ok=True)
+            full_path = os.path.join(d, "bench_full.json")
+            with open(full_path, "w") as f:
+                json.dump(out, f, indent=1)
+            break
+        except OSError:
+            full_path = None
+    for k, v in (out.get("also") or {}).items():
+        print(f"[bench also] {k}: {json.dumps(_rnd(v, 5))}", file=sys.stderr)
+    sys.stderr.flush()
+    rel = os.path.relpath(full_path, ROOT) if full_path and full_path.startswith(ROOT) else full_path
+    os.write(json_fd, (compact_line(out, rel) + "\n").encode())
 
 
 def main():
@@ -857,6 +1061,7 @@ def main():
         os.environ.setdefault("NCCL_IB_DISABLE", "1")
         os.environ.setdefault("NCCL_P2P_DISABLE", "1")
     ctx = device.Context(dist.local_rank % ndev)
+    ident = device_identity(dist.local_rank % ndev)
     dist.comm_kind, dist.comm_note = "rccl", None
     want_comm = os.environ.get("PYRO_BENCH_COMM", "rccl")
     if world > 1:
@@ -887,6 +1092,8 @@ def main():
             dist.comm_note = note
             print(f"[bench rank {dist.rank}] WARNING: {note}; halo exchange staged through the "
                   "host over gloo (NOT a scaling result)", file=sys.stderr)
+    # N ranks = N distinct GPUs in one communicator, checked BEFORE anything is timed
+    dev_ids, dev_distinct = check_rank_devices(dist, ident, getattr(dist, "rccl_ranks", None))
     # default: the contracted / reciprocal-division build, parity-tested to the
     # north_star tolerance (1e-10); --fast-math 0 times the bit-faithful build.
     # kernel_set -1: the library picks (row-marching wavefront kernel from 2048^2 on)
@@ -957,6 +1164,8 @@ def main():
                     "strips); halo_sync_ms = exchanges on the main stream (no overlap possible); "
                     "allreduce_ms = the dt all-reduce; stream_ms_per_step = event pair over the timed "
                     "region / steps; the rest = pyrohip_comp_wave_geometry of the rank's slab",
+            "gpu_pci_ids": ["%x" % i if i >= 0 else None for i in dev_ids],
+            "gpu_unique_ids_distinct": dev_distinct,
             "predicted_ms_per_step": PREDICTED_MS_16384.get(world) if args.nx == 16384 else None,
             "predicted_source": "DESIGN.md 6 (kernel / N x tail + ~0.1 ms all-reduce and small launches)"}
     if dist.rank == 0:
@@ -992,48 +1201,68 @@ def main():
                 "note": "fabric bytes per cell update of a separate rocprofv3 --pmc session x the "
                         "cells of this run; not counters of this run"}
         if world == 1:
-            also = {}
-            if not args.no_also:
-                # the headline workload in the other build
-                d2 = dict(defaults, fast_math=1 - defaults["fast_math"])
-                r2 = bench_sedov(args, dist, ctx, device, d2, steps=max(5, args.steps // 2), warmup=2)
-                also["sedov_exact" if d2["fast_math"] == 0 else "sedov_fast"] = sedov_leg(r2, d2, args.nx)
-            if not args.no_developed and not args.no_also:
-                tile, frac, nst = developed_tile(ctx, device)
-                info = {"workload": f"compressible sedov {args.nx}x{args.nx}, DEVELOPED flow: a 1024x1024 "
-                                    f"Sedov blast at t = 0.1 ({nst} steps on this GPU) tiled over the grid",
-                        "shocked_cell_fraction": frac}
-                rd = bench_sedov(args, dist, ctx, device, defaults, steps=args.developed_steps,
-                                 warmup=5, tile=tile)
-                also["sedov_developed"] = sedov_leg(rd, defaults, args.nx, info)
-                also["sedov_developed"]["ratio_to_headline"] = also["sedov_developed"]["value"] / value
-                d2 = dict(defaults, fast_math=1 - defaults["fast_math"])
-                rd2 = bench_sedov(args, dist, ctx, device, d2, steps=max(20, args.developed_steps // 5),
-                                  warmup=3, tile=tile)
-                also["sedov_developed_exact" if d2["fast_math"] == 0 else "sedov_developed_fast"] = \
-                    sedov_leg(rd2, d2, args.nx, info)
-                del tile
-            if not args.no_also and args.nx == 16384:
-                # BASELINE configs[2] and north_star's target size, both builds
-                also["sedov_4096"] = sedov_size_leg(args, dist, ctx, device, defaults, 4096, 100)
-                also["sedov_8192"] = sedov_size_leg(args, dist, ctx, device, defaults, 8192, 40)
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline_sedov(args.cpu_sample_nx)
-            if not args.no_also:
-                also.update({"sedov_small_grids": bench_small_grids(ctx, device),
-                             "advection": bench_advection(ctx, device, fast_math=defaults["fast_math"]),
-                             "advection_8192": bench_advection(ctx, device, nx=8192, steps=60, warmup=6,
-                                                               fast_math=defaults["fast_math"]),
-                             "multigrid": bench_mg(ctx, device),
-                             "incompressible": bench_incompressible(ctx, device)})
-                bare = {"sedov_4096": also.get("sedov_4096", {}).get("ms_per_step"),
-                        "advection": also["advection"]["ms_per_step"]}
+            also, legs_s = {}, {}
+            D = max(1, args.also_div)      # > 1: every secondary leg on a grid D times smaller,
+                                           # a few steps (the CPU test of this script's output)
+
+            def n_(nx, lo=32):
+                return nx if D == 1 else max(lo, nx // D)
+
+            def k_(steps, few=3):
+                return steps if D == 1 else min(steps, few)
+
+            def leg(name, thunk):
+                """a secondary leg must not cost the headline: errors are recorded, not raised"""
+                t0 = time.perf_counter()
                 try:
-                    also["pyro_driver"] = bench_pyro_driver(ctx, device, bare)
-                except Exception as e:      # noqa: BLE001 -- a secondary leg must not cost the headline
-                    also["pyro_driver"] = {"error": f"{type(e).__name__}: {e}"}
+                    also[name] = thunk()
+                except Exception as e:      # noqa: BLE001
+                    also[name] = {"error": f"{type(e).__name__}: {e}"}
+                legs_s[name] = round(time.perf_counter() - t0, 2)
+
+            if not args.no_cpu_baseline:
+                t0 = time.perf_counter()
+                out["cpu_baseline"] = cpu_baseline_sedov(args.cpu_sample_nx, args.cpu_seconds)
+                legs_s["cpu_baseline"] = round(time.perf_counter() - t0, 2)
+            if not args.no_also:
+                d2 = dict(defaults, fast_math=1 - defaults["fast_math"])
+                other = "sedov_exact" if d2["fast_math"] == 0 else "sedov_fast"
+                # the headline workload in the other build
+                leg(other, lambda: sedov_leg(bench_sedov(args, dist, ctx, device, d2, steps=max(5, args.steps // 2),
+                                                         warmup=2), d2, args.nx))
+                if not args.no_developed:
+                    def developed():
+                        tile, frac, nst = developed_tile(ctx, device, n_(1024), 0.1 if D == 1 else 0.004)
+                        info = {"workload": f"compressible sedov {args.nx}x{args.nx}, DEVELOPED flow: a "
+                                            f"{tile.shape[0]}x{tile.shape[0]} Sedov blast ({nst} steps on this "
+                                            "GPU) tiled over the grid", "shocked_cell_fraction": frac}
+                        rd = bench_sedov(args, dist, ctx, device, defaults, steps=k_(args.developed_steps),
+                                         warmup=k_(5), tile=tile)
+                        a = sedov_leg(rd, defaults, args.nx, info)
+                        a["ratio_to_headline"] = a["value"] / value
+                        rd2 = bench_sedov(args, dist, ctx, device, d2, steps=k_(max(10, args.developed_steps // 5)),
+                                          warmup=k_(3), tile=tile)
+                        a["other_build"] = sedov_leg(rd2, d2, args.nx, info)
+                        return a
+                    leg("sedov_developed", developed)
+                if args.nx == 16384 or D > 1:
+                    # BASELINE configs[2] and north_star's target size, both builds
+                    leg("sedov_4096", lambda: sedov_size_leg(args, dist, ctx, device, defaults, n_(4096), k_(100)))
+                    leg("sedov_8192", lambda: sedov_size_leg(args, dist, ctx, device, defaults, n_(8192), k_(40)))
+                leg("sedov_small_grids", lambda: bench_small_grids(
+                    ctx, device, sizes=(64, 256, 512) if D == 1 else (32, 64), steps=k_(400)))
+                leg("advection", lambda: bench_advection(ctx, device, nx=n_(2048), steps=k_(600, 6), warmup=k_(30),
+                                                         fast_math=defaults["fast_math"]))
+                leg("advection_8192", lambda: bench_advection(ctx, device, nx=n_(8192), steps=k_(60, 6),
+                                                              warmup=k_(6), fast_math=defaults["fast_math"]))
+                leg("multigrid", lambda: bench_mg(ctx, device, nx=n_(4096), cycles=k_(10), small_sizes=D == 1))
+                leg("incompressible", lambda: bench_incompressible(ctx, device, nx=n_(2048), steps=k_(5, 1)))
+                bare = {"sedov_4096": (also.get("sedov_4096") or {}).get("ms_per_step"),
+                        "advection": (also.get("advection") or {}).get("ms_per_step")}
+                leg("pyro_driver", lambda: bench_pyro_driver(ctx, device, bare, n_, k_))
                 out["also"] = also
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+            out["seconds_by_leg"] = legs_s
+        emit(out, json_fd)
     dist.barrier()
 
 
