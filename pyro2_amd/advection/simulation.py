@@ -87,8 +87,12 @@ class Simulation(NullSimulation):
         t0, n0 = self.cc_data.t, self.n
         dts = []
         while len(dts) < nsteps and not self.finished():
+            keep = (getattr(self, "dt", None), getattr(self, "dt_old", None))
             self.compute_timestep()
             if not self.dt > 0.0:
+                # no positive step to hand to the device: undo this policy call (t, n were not
+                # advanced for it) and let the driver take the step singly, like the reference
+                self.dt, self.dt_old = keep
                 break
             dts.append(float(self.dt))
             self.cc_data.t += self.dt       # as evolve() does

@@ -12,7 +12,7 @@ hse / ambient user boundaries.
 import numpy as np
 
 from .. import device
-from .._lib import BC_CODE
+from .._lib import BC_CODE, PyroHipError
 from ..mesh import boundary as bnd
 from ..simulation_null import NullSimulation, bc_setup, grid_setup
 from ..util import msg
@@ -240,6 +240,8 @@ class Simulation(NullSimulation):
             return False
         if any(cc._has_host_bc(n) for n in cc.names) or cc._views_alive():
             return False
+        if getattr(self, "_device_stepping_refused", False):
+            return False
         return self._params().kernel_set != 0
 
     def evolve_many(self, nsteps):
@@ -257,6 +259,14 @@ class Simulation(NullSimulation):
         st = self._device_state()
         try:
             dts = st.comp_evolve(self._params(), float(rp.get_param("driver.cfl")), pol, int(nsteps))
+        except PyroHipError as e:
+            # the library's own fusability rules (e.g. a SphericalPolar grid too small for the
+            # tile kernel, mixed boundary kinds on a side) are stricter than can_evolve_many's:
+            # a refusal before the first step means "step singly", which the staged set can
+            if "device-side stepping:" not in str(e) or pol.n != int(self.n):
+                raise
+            self._device_stepping_refused = True
+            dts = []
         finally:
             self.cc_data.device_modified()
             self.cc_data.t, self.n, self.dt_old = pol.t, pol.n, pol.dt_old

@@ -286,4 +286,12 @@ struct pyrohip_state {
     double next_cfl_min = -1.0;  // min over interior of dx/(|u|+c) etc. of the
                                  // state after the last step (-1: unknown)
     bool cfl_is_global = false;  // ... already reduced over all ranks
+    // the ghost cells hold exactly what the boundary rules (outflow / reflect / periodic index
+    // maps) give for the current interior: set by a full pyrohip_fill_bc, dropped by anything
+    // that writes the state (uploads -- a host-side boundary callback comes back as one --,
+    // steps, linear combinations).  Kernels that read ghost cells THROUGH the rules instead of
+    // from memory (k_ctu_fused_sph) need this or fuse_fill (a SphericalPolar run with
+    // a host-side define_bc lost its ghost values)
+    bool ghost_by_rules = false;
+    bool stages_valid = false;   // swe: the work planes hold the stages of the LAST step (staged set)
 };

@@ -488,7 +488,11 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
         PYRO_REQUIRE(p->riemann == 1, "a SphericalPolar grid needs the CGF Riemann solver");
         PYRO_REQUIRE(!s->user_bc && !s->ramp_bc && !s->heat && !s->ext_old,
                      "hse / ambient / ramp boundaries and heating are Cartesian-only");
-        const bool fuse_sph = comp_can_fuse_sph(s, p);
+        // the one-launch kernel reads EVERY ghost cell through the boundary rules: only where the
+        // ghost cells are known to be those images -- the caller left the fill to the kernel, or the
+        // last thing that wrote the state was the library's own full fill.  Ghost cells a host-side
+        // boundary callback wrote (uploaded afterwards) are read from memory by the staged set.
+        const bool fuse_sph = comp_can_fuse_sph(s, p) && (p->fuse_fill || s->ghost_by_rules);
         if (fuse_sph)
             rc = p->fast_math ? fastm::comp_step_fused_sph(s, p, dt) : exact::comp_step_fused_sph(s, p, dt);
         else
@@ -505,6 +509,7 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
         rc = p->fast_math ? fastm::comp_step_fused(s, p, dt) : exact::comp_step_fused(s, p, dt);
     else
         rc = p->fast_math ? fastm::comp_step_staged(s, p, dt) : exact::comp_step_staged(s, p, dt);
+    s->ghost_by_rules = false;      // a new time level: its ghost cells are stale until the next fill
     if (rc == 0 && p->do_sponge) {
         PYRO_REQUIRE(p->sponge_rho_begin > p->sponge_rho_full,
                      "sponge_rho_begin must exceed sponge_rho_full (simulation.py:172)");

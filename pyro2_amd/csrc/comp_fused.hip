@@ -796,17 +796,19 @@ __global__ void k_copy_frame4(const double *__restrict__ src, double *__restrict
 
 // second state buffer + the kernel parameters both single-launch kernels share
 int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP &P, double *&Uin,
-                  double *&Uout, bool reset_flag)
+                  double *&Uout, bool reset_flag, bool second_buffer)
 {
     pyrohip_ctx *c = s->ctx;
     const Geom &g = s->g;
-    if (!s->alt_base) {
+    // (second_buffer = false: a launch that writes somewhere else -- the method-of-lines
+    // right-hand side into the k state: no 4 planes allocated and zeroed on every stage state)
+    if (!s->alt_base && second_buffer) {
         size_t n = g.plane * 4 + 16;
         PYRO_CHECK_HIP(hipMalloc((void **)&s->alt_base, n * sizeof(double)));
         PYRO_CHECK_HIP(hipMemsetAsync(s->alt_base, 0, n * sizeof(double), c->stream));
     }
     Uin = s->d;
-    Uout = s->alt_base + geom_lead(g);
+    Uout = s->alt_base ? s->alt_base + geom_lead(g) : nullptr;
     P.gamma = p->gamma; P.dx = p->dx; P.dy = p->dy; P.dt = dt;
     P.z0 = p->z0; P.z1 = p->z1; P.delta = p->delta; P.cvisc = p->cvisc;
     P.small_dens = p->small_dens;

@@ -897,7 +897,7 @@ int comp_rk_rhs_wave(pyrohip_state *s, const pyrohip_comp_params *p, pyrohip_sta
     const Geom &g = s->g;
     FP P;
     double *Uin, *Uout;
-    PYRO_TRY(fused_prepare(s, p, 1.0, P, Uin, Uout, true));
+    PYRO_TRY(fused_prepare(s, p, 1.0, P, Uin, Uout, true, false));
     Uout = kst->d + (size_t)(4 * slot) * g.plane;
     const int cus = c->num_cus > 0 ? c->num_cus : 256;
     const WaveGeom wg = wave_geometry(g.nx, g.ny, g.ng, cus, p->march_rows);

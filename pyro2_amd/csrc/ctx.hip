@@ -523,6 +523,7 @@ int pyrohip_state_upload_rows(pyrohip_state *s, int i0, int ni, const double *ho
         PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
     }
     s->next_cfl_min = -1.0;
+    s->ghost_by_rules = false;
     return 0;
 }
 
@@ -577,6 +578,7 @@ int pyrohip_state_upload_var(pyrohip_state *s, int n, const double *host)
                                     hipMemcpyHostToDevice, c->stream));
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
     s->next_cfl_min = -1.0;
+    s->ghost_by_rules = false;
     return 0;
 }
 
@@ -718,6 +720,7 @@ int pyrohip_fill_bc(pyrohip_state *s, int n)
     PYRO_REQUIRE(s, "NULL state");
     PYRO_REQUIRE(n >= -1 && n < s->nvar, "variable index out of range");
     PYRO_TRY(comm_wait_halo(s));
+    if (n >= 0) s->ghost_by_rules = false;     // (one variable: the others may be anything)
     if (s->ramp_bc) {
         PYRO_REQUIRE(s->ramp_set, "ramp boundary: call pyrohip_state_set_ramp_bc first");
         if (!s->user_bc) return fill_bc_range(s, n < 0 ? 0 : n, n < 0 ? s->nvar : 1);
@@ -745,6 +748,14 @@ int pyrohip_fill_bc(pyrohip_state *s, int n)
                            (const double *)s->d_cval);
     }
     PYRO_CHECK_HIP(hipGetLastError());
+    if (n < 0) {
+        // every ghost cell is now the image its side's rule gives (index maps only)
+        bool rules = !s->nb_set;
+        for (size_t k = 0; k < s->bc.size(); k++)
+            rules = rules && (s->bc[k] == PYROHIP_BC_OUTFLOW || s->bc[k] == PYROHIP_BC_REFLECT_EVEN ||
+                              s->bc[k] == PYROHIP_BC_REFLECT_ODD || s->bc[k] == PYROHIP_BC_PERIODIC);
+        s->ghost_by_rules = rules;
+    }
     return 0;
 }
 
@@ -820,6 +831,7 @@ int pyrohip_state_lincomb(pyrohip_state *dst, const pyrohip_state *src, const py
                        dst->nvar, lc);
     PYRO_CHECK_HIP(hipGetLastError());
     dst->next_cfl_min = -1.0;
+    dst->ghost_by_rules = false;
     return 0;
 }
 

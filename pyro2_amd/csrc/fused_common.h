@@ -52,7 +52,7 @@ __device__ __forceinline__ bool odd_sides(unsigned m)
 // host side, defined in comp_fused.hip
 __global__ void k_copy_frame4(const double *__restrict__ src, double *__restrict__ dst, Geom g);
 int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP &P, double *&Uin,
-                  double *&Uout, bool reset_flag = true);
+                  double *&Uout, bool reset_flag = true, bool second_buffer = true);
 // after the step kernel(s): ghost frame, minimum of the CFL partials (all-reduced over
 // the slabs when decomposed) -> device address of the minimum
 int fused_tail(pyrohip_state *s, double *part, int nparts, bool frame_copied, const double **dmin,

@@ -626,6 +626,8 @@ int pyrohip_swe_step_ks(pyrohip_state *s, double dx, double dy, double grav, int
         s->alt_base = old_base;
         s->d = s->base + geom_lead(g);
         s->next_cfl_min = -1.0;
+        s->ghost_by_rules = false;
+        s->stages_valid = false;       // the one-launch kernel keeps no stage planes
         return 0;
     }
     PYRO_TRY(sw_work(s));
@@ -641,6 +643,8 @@ int pyrohip_swe_step_ks(pyrohip_state *s, double dx, double dy, double grav, int
     PYRO_LAUNCH(c, "k_sw_update", k_sw_update, gridI, block, 0, s->d, (const double *)W, g, P);
     PYRO_CHECK_HIP(hipGetLastError());
     s->next_cfl_min = -1.0;
+    s->ghost_by_rules = false;
+    s->stages_valid = true;
     return 0;
 }
 
@@ -656,7 +660,9 @@ int pyrohip_swe_stage_dump(pyrohip_state *s, int stage, double *out)
 {
     PYRO_REQUIRE(s && out, "NULL argument");
     PYRO_REQUIRE(stage >= 0 && stage < 8, "stage out of range");
-    PYRO_REQUIRE(s->work_planes >= (size_t)SW_NPL, "no swe step has been run");
+    PYRO_REQUIRE(s->work_planes >= (size_t)SW_NPL && s->stages_valid,
+                 "no staged swe step has been run on this state (the last step was the one-launch "
+                 "kernel, which keeps no stage planes: pyrohip_swe_step_ks with kernel_set 0)");
     static const int first[8] = {SW_XP, SW_XM, SW_YP, SW_YM, SW_FXT, SW_FYT, SW_FX, SW_FY};
     const Geom &g = s->g;
     pyrohip_ctx *c = s->ctx;

@@ -219,7 +219,10 @@ class Pyro:
         while not self.sim.finished():
             if self._can_batch(writing):
                 batch = getattr(self.sim, "batch_steps", 64)
-                self.sim.evolve_many(min(batch, self.sim.max_steps - self.sim.n))
+                if not len(self.sim.evolve_many(min(batch, self.sim.max_steps - self.sim.n))):
+                    # nothing the device would take (a zero time step, a refusal of the
+                    # batched path): the plain step, which always advances n
+                    self.single_step()
             else:
                 self.single_step()
         if writing or self.rp.get_param("io.force_final_output"):
@@ -295,9 +298,9 @@ class PyroBenchmark(Pyro):
         parity-tested to 1e-10 / 1e-12 of the reference, not to the last bits of a stored
         file.  The build is recorded in the output file (attribute gpu_fast_math and the
         runtime parameters), so a mismatch can be traced to it."""
-        chosen = dict(inputs_dict or {})
-        chosen.setdefault("gpu.fast_math", 0)
-        super().initialize_problem(problem_name, inputs_file=inputs_file, inputs_dict=chosen)
+        # at the strength of a default: an inputs file or inputs_dict that names the build wins
+        self.rp.set_param("gpu.fast_math", 0)
+        super().initialize_problem(problem_name, inputs_file=inputs_file, inputs_dict=inputs_dict)
 
     def run_sim(self, rtol=1.e-12):
         super().run_sim()
