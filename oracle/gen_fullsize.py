@@ -19,6 +19,8 @@ grid (which needs 40 min and 60 GB).  tests/golden/comp_sedov_16384_window.npz:
     python oracle/gen_fullsize.py --window16384      # ~15 s
     python oracle/gen_fullsize.py --window8192       # the north_star target size, same way
     python oracle/gen_fullsize.py --developed1024    # developed flow (t = 0.1), ~15 min
+    python oracle/gen_fullsize.py --swe4096 | --rk2048 | --sph2048 | --adv8192
+                     # the sizes the secondary bench legs are timed at (tests/fullsize_ics.py)
 """
 import os
 import sys
@@ -101,6 +103,81 @@ def developed1024():
     print("wrote", out, os.path.getsize(out) // 1024, "KiB")
 
 
+def _save(name, I, **extra):
+    from fullsize_ics import lattice
+    out = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(out, **lattice(I), **extra)
+    print("wrote", out, os.path.getsize(out) // 1024, "KiB")
+
+
+def swe_fullsize(nx=4096, nsteps=10):
+    """the shallow-water step at the size its bench leg times (4096^2), both
+    Riemann solvers, 10 steps of a genuinely 2-D dam break (tests/fullsize_ics.py) on the oracle"""
+    from oracle import orc
+    from fullsize_ics import swe_dam2d_ic, swe_meta, SWE_BCS
+    from test_oracle_golden import oracle_swe_run
+    ic = swe_dam2d_ic(nx)
+    m = swe_meta(nx, nx)
+    for riemann in ("Roe", "HLLC"):
+        P = orc.swe_params(nx, nx, 4, m[3], m[4], m[5], int(m[6]), riemann)
+        t0 = time.time()
+        U, dts, pol = oracle_swe_run(ic, P, m[7], SWE_BCS, nsteps)
+        print("oracle swe", riemann, nx, nsteps, "steps:", time.time() - t0, "s")
+        _save(f"swe_dam2d_{nx}_{riemann.lower()}", U[4:-4, 4:-4], dts=dts, nsteps=np.array(nsteps))
+
+
+def rk_fullsize(nx=2048, nsteps=5):
+    """compressible_rk (RK4, the solver's default) Sedov at its bench size on the oracle"""
+    from helpers import oracle_rk_run
+    ic, meta, bcs = sedov_ic(nx)
+    t0 = time.time()
+    U, dts = oracle_rk_run(ic, meta, bcs, nsteps, "RK4")
+    print("oracle rk4", nx, nsteps, "steps:", time.time() - t0, "s")
+    _save(f"comp_rk_sedov_{nx}", U[4:-4, 4:-4], dts=dts, nsteps=np.array(nsteps))
+
+
+def sph_fullsize(nx=2048, nsteps=10):
+    """SphericalPolar Sedov at its bench size (2048^2) on the oracle"""
+    from oracle import orc
+    from fullsize_ics import sph_sedov
+    from helpers import DtPolicy, meta_to_params
+    grid, geo, U0, bcs = sph_sedov(nx, nx)
+    gamma, cfl = 1.4, 0.8
+    meta = [nx, nx, 4, grid.dx, grid.dy, gamma, 2, 1, 0.75, 0.85, 0.33, 0.1, 0.0, cfl]
+    Po, _ = meta_to_params(meta, bcs, riemann="CGF")
+    og = orc.Geom(geo, grid.xmin, grid.ymin)
+    U = U0.copy()
+    pol = DtPolicy(1.e30)
+    dts = []
+    t0 = time.time()
+    for _ in range(nsteps):
+        orc.comp_fill_bc(U, nx, nx, 4, bcs, gamma, 0.0, grid.dy, (0.0,) * 4)
+        dt = pol(orc.comp_dt_geom(U, nx, nx, 4, og, gamma, cfl))
+        assert orc.comp_step(U, Po, dt, geom=og)[0] == 0
+        pol.advance(dt)
+        dts.append(dt)
+    print("oracle spherical", nx, nsteps, "steps:", time.time() - t0, "s")
+    _save(f"comp_sph_sedov_{nx}", U[4:-4, 4:-4], dts=np.array(dts), nsteps=np.array(nsteps))
+
+
+def adv_fullsize(nx=8192, nsteps=6):
+    """advection smooth at 8192^2 (the bench size of the steps-per-launch kernel: several rounds
+    of wavefronts, K = 3) on the oracle: 6 steps = two launches of k_adv_multi<3>"""
+    from oracle import orc
+    x = (np.arange(nx + 8) - 3.5) / nx
+    X, Y = np.meshgrid(x, x, indexing="ij")
+    a = 1.0 + np.exp(-60.0 * ((X - 0.5) ** 2 + (Y - 0.5) ** 2))
+    del X, Y
+    dx = 1.0 / nx
+    dt = orc.adv_dt(dx, dx, 1.0, 1.0, 0.8)
+    t0 = time.time()
+    for _ in range(nsteps):
+        orc.fill_ghost(a, nx, nx, 4, ["periodic"] * 4)
+        orc.adv_step(a, nx, nx, 4, dx, dx, 1.0, 1.0, dt, 2)
+    print("oracle advection", nx, nsteps, "steps:", time.time() - t0, "s")
+    _save(f"adv_smooth_{nx}", a[4:-4, 4:-4, None], dt=np.array(dt), nsteps=np.array(nsteps))
+
+
 if __name__ == "__main__":
     if "--window16384" in sys.argv:
         window(16384)
@@ -108,5 +185,13 @@ if __name__ == "__main__":
         window(8192)
     elif "--developed1024" in sys.argv:
         developed1024()
+    elif "--swe4096" in sys.argv:
+        swe_fullsize()
+    elif "--rk2048" in sys.argv:
+        rk_fullsize()
+    elif "--sph2048" in sys.argv:
+        sph_fullsize()
+    elif "--adv8192" in sys.argv:
+        adv_fullsize()
     else:
         main()

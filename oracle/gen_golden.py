@@ -1181,6 +1181,22 @@ def gen_diffusion():
     save("diff_small", **out)
 
 
+def gen_diffusion_2048(nx=2048, nsteps=2):
+    """the diffusion solver at the size its bench leg is timed at: the
+    REFERENCE itself (pure NumPy + its multigrid, ~12 s per step), gaussian, 2 steps; a 64 x 64
+    lattice of phi, row / column sums, dt (tests/fullsize_ics.py: lattice)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from fullsize_ics import lattice
+    p = Pyro("diffusion")
+    p.initialize_problem("gaussian", inputs_dict={"mesh.nx": nx, "mesh.ny": nx, "driver.max_steps": nsteps})
+    dts = []
+    while not p.sim.finished():
+        p.single_step()
+        dts.append(p.sim.dt)
+    phi = np.array(p.sim.cc_data.get_var("phi").v())
+    save(f"diff_gaussian_{nx}", dts=np.array(dts), nsteps=np.array(p.sim.n), **lattice(phi[:, :, None]))
+
+
 # --------------------------------------------------------------------------
 # variable-coefficient multigrid (SURVEY 8 row f1).  The reference's stored
 # goldens mg_vc_poisson_*.h5 are missing from this checkout
@@ -1445,6 +1461,8 @@ if __name__ == "__main__":
         gen_swe()
     if "mg_4096" in sys.argv[1:]:
         gen_mg_4096()
+    if "diff_2048" in sys.argv[1:]:
+        gen_diffusion_2048()
     which = sys.argv[1:] or ["bc", "adv", "comp_stages", "comp_runs", "mg", "diffusion"]
     if "diffusion" in which:
         gen_diffusion()

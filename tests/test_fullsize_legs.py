@@ -1,0 +1,118 @@
+"""Parity at the sizes the secondary bench legs are TIMED at.
+
+The one-launch kernels of round 4 (k_sw_wave, k_ctu_wave<.., MOL>, k_ctu_fused_sph) pick their
+strip / chunk lengths by whole rounds of resident wavefronts -- rules that only engage on large
+grids -- while their oracle tests stopped at 128 x 10 ... 512 x 256.  Here the device runs the
+bench-size problem and is held, element-wise on a 64 x 64 lattice of cells plus row / column sums
+of every variable, to the C oracle (oracle/gen_fullsize.py --swe4096 / --rk2048 / --sph2048,
+~1 min of one core each) or, for diffusion, to the reference itself (oracle/gen_golden.py
+diff_2048).  GPU only: the emulator would need hours."""
+import numpy as np
+import pytest
+
+from fullsize_ics import NG, SWE_BCS, assert_lattice, sph_sedov, swe_dam2d_ic, swe_meta
+from helpers import DtPolicy
+from pyro2_amd import device
+
+I = (slice(NG, -NG), slice(NG, -NG))
+
+
+@pytest.fixture
+def api(hip, tmp_path, monkeypatch):
+    monkeypatch.setattr(device.Context, "_default", hip)
+    monkeypatch.chdir(tmp_path)
+    return hip
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("riemann", ["Roe", "HLLC"])
+def test_swe_4096_vs_oracle_lattice(hip, golden, riemann):
+    """shallow water, a 2-D dam break at 4096^2 (the bench leg's size), 10 steps with the driver's
+    dt policy through the one-launch kernel (the library's choice) and, bit for bit, the staged set"""
+    from oracle import orc
+    nx = 4096
+    g = golden(f"swe_dam2d_{nx}_{riemann.lower()}")
+    m = swe_meta(nx, nx)
+    vb = orc.comp_var_bcs(SWE_BCS)
+    rows = [list(vb[0]), list(vb[2]), list(vb[3]), list(vb[0])]
+    ic = swe_dam2d_ic(nx)
+    out = []
+    for kset in (-1, 0):
+        s = device.DeviceState(hip, nx, nx, NG, rows)
+        s.upload(ic)
+        pol = DtPolicy(1.e30)
+        for n in range(int(g["nsteps"])):
+            s.fill_bc()
+            dt = pol(s.swe_dt(m[3], m[4], m[5], m[7]))
+            assert abs(dt / g["dts"][n] - 1) <= 1e-12
+            s.swe_step(m[3], m[4], m[5], int(m[6]), riemann, dt, kernel_set=kset)
+            pol.advance(dt)
+        out.append(s.download()[I])
+        del s
+    assert np.array_equal(out[0], out[1])
+    assert_lattice(out[0], g, 1e-12, what=f"swe {riemann}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fast", [0, 1])
+def test_compressible_rk_2048_vs_oracle_lattice(api, golden, fast):
+    """compressible_rk Sedov 2048^2, 5 RK4 steps through Pyro (the one-launch right-hand side from
+    2048^2 cells on, device-side stage combinations), both builds"""
+    from pyro2_amd.pyro_sim import Pyro
+    nx = 2048
+    g = golden(f"comp_rk_sedov_{nx}")
+    p = Pyro("compressible_rk")
+    p.initialize_problem("sedov", inputs_dict={"mesh.nx": nx, "mesh.ny": nx, "gpu.fast_math": fast,
+                                                "driver.max_steps": int(g["nsteps"])})
+    dts = []
+    while not p.sim.finished():
+        p.single_step()
+        dts.append(p.sim.dt)
+    tol = 1e-10 if fast else 1e-12
+    assert np.abs(np.array(dts) / g["dts"] - 1).max() <= tol
+    U = np.asarray(p.sim.cc_data.data)[I]
+    # floors: the ambient gas (rho 1, E 2.5e-5) and rho c of it for the momenta
+    assert_lattice(U, g, tol, floor=[1.0, 2.5e-5, 4e-3, 4e-3], what=f"rk fast {fast}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kset", [-1, 0])
+def test_spherical_sedov_2048_vs_oracle_lattice(hip, golden, kset):
+    """SphericalPolar Sedov 2048^2 (inputs.sedov.spherical's set-up with a weak angular modulation),
+    10 steps: the one-launch tile kernel (the library's choice) and the staged set vs the oracle"""
+    from test_device_compressible import comp_state, dev_params
+    nx = 2048
+    g = golden(f"comp_sph_sedov_{nx}")
+    grid, geo, U0, bcs = sph_sedov(nx, nx)
+    meta = [nx, nx, NG, grid.dx, grid.dy, 1.4, 2, 1, 0.75, 0.85, 0.33, 0.1, 0.0, 0.8]
+    P, _ = dev_params(meta, kernel_set=kset, riemann="CGF", solid_xl=1, solid_yl=0)
+    s = comp_state(hip, nx, nx, bcs)
+    s.set_geometry(geo, grid.xmin, grid.ymin)
+    s.upload(U0)
+    pol = DtPolicy(1.e30)
+    for n in range(int(g["nsteps"])):
+        s.fill_bc()
+        dt = pol(s.comp_dt(P, 0.8))
+        assert abs(dt / g["dts"][n] - 1) <= 1e-12
+        s.comp_step(P, dt)
+        pol.advance(dt)
+    assert_lattice(s.download()[I], g, 1e-11, floor=[1.0, 2.5e-6, 1e-3, 1e-3], what=f"spherical kset {kset}")
+
+
+@pytest.mark.gpu
+def test_diffusion_2048_vs_reference_lattice(api, golden):
+    """diffusion gaussian 2048^2, 2 steps through Pyro against the REFERENCE ITSELF run at that
+    size (multigrid solves to the reference's tolerance: 1e-10 of phi's range)"""
+    from pyro2_amd.pyro_sim import Pyro
+    nx = 2048
+    g = golden(f"diff_gaussian_{nx}")
+    p = Pyro("diffusion")
+    p.initialize_problem("gaussian", inputs_dict={"mesh.nx": nx, "mesh.ny": nx,
+                                                   "driver.max_steps": int(g["nsteps"])})
+    dts = []
+    while not p.sim.finished():
+        p.single_step()
+        dts.append(p.sim.dt)
+    assert np.abs(np.array(dts) / g["dts"] - 1).max() <= 1e-12
+    phi = np.asarray(p.get_var("phi").v())
+    assert_lattice(phi[:, :, None], g, 1e-10, floor=[1.0], what="diffusion")
