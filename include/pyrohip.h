@@ -486,6 +486,28 @@ int pyrohip_comp_source_correct(pyrohip_state *s, const pyrohip_comp_params *p, 
 
 int pyrohip_comp_rk_dt(pyrohip_state *s, const pyrohip_comp_params *p,
                        double cfl, double *dt_out);
+/* The WHOLE step of compressible_rk.Simulation.evolve (pyro/compressible_rk/simulation.py:
+   58-104) with the RKIntegrator of pyro/mesh/integration.py:76-129 in nstages launches:
+   stage 0 = pyrohip_comp_rk_rhs of the ghost-filled state; every later stage builds its start
+   y_0 + dt sum_j a[s][j] k_j (interior; ghost cells = the images the boundary rules give) as
+   the rows enter the kernel, the last one stores y_0 + dt sum_s b[s] k_s as the new state and
+   leaves the CFL minimum pyrohip_comp_rk_dt then answers from.  a: nstages x nstages row-major
+   (strictly lower triangular), b: nstages, 2 <= nstages <= 4; k: a state with >= 4 nstages
+   planes (scratch).  Needs pyrohip_comp_rk_can_fuse (single Cartesian domain, outflow /
+   reflect / periodic sides, no sponge / heating / host source, kernel_set 2 or >= 2048^2
+   cells); everything else goes stage by stage (pyrohip_comp_rk_rhs + pyrohip_state_lincomb).
+   PYROHIP_ERR_STATE: an invalid stage state; y is left as it was (floored).                */
+int pyrohip_comp_rk_can_fuse(pyrohip_state *y, const pyrohip_comp_params *p,
+                             pyrohip_state *k, int nstages, int *flag);
+int pyrohip_comp_rk_step(pyrohip_state *y, const pyrohip_comp_params *p,
+                         pyrohip_state *k, double dt, int nstages,
+                         const double *a, const double *b);
+/* ... and up to max_steps of them with the driver's dt policy on the device, as
+   pyrohip_comp_evolve (no host round trip per step; one synchronisation at the end)      */
+int pyrohip_comp_rk_evolve(pyrohip_state *y, const pyrohip_comp_params *p,
+                           pyrohip_state *k, int nstages, const double *a,
+                           const double *b, double cfl, pyrohip_dt_policy *policy,
+                           int max_steps, int *steps_done, double *dts_out);
 /* RKIntegrator.get_stage_start / compute_final_update (pyro/mesh/
    integration.py:84-113): dst <- src everywhere (clone), then on the interior
    dst += coef[0] k_0; dst += coef[1] k_1; ... in this order.  dst may be src. */

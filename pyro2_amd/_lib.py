@@ -108,6 +108,10 @@ _PROTOS = {
     "pyrohip_mg_set_general_coeffs": [_VP, _DP, _DP, _DP, _DP, C.POINTER(C.c_int)],
     "pyrohip_comp_rk_rhs": [_VP, C.POINTER(CompParams), _VP, C.c_int],
     "pyrohip_comp_rk_dt": [_VP, C.POINTER(CompParams), C.c_double, _DP],
+    "pyrohip_comp_rk_can_fuse": [_VP, C.POINTER(CompParams), _VP, C.c_int, C.POINTER(C.c_int)],
+    "pyrohip_comp_rk_step": [_VP, C.POINTER(CompParams), _VP, C.c_double, C.c_int, _DP, _DP],
+    "pyrohip_comp_rk_evolve": [_VP, C.POINTER(CompParams), _VP, C.c_int, _DP, _DP, C.c_double,
+                               C.POINTER(DtPolicyC), C.c_int, C.POINTER(C.c_int), _DP],
     "pyrohip_state_lincomb": [_VP, _VP, _VP, _DP, C.c_int],
     "pyrohip_swe_dt": [_VP, C.c_double, C.c_double, C.c_double, C.c_double, _DP],
     "pyrohip_swe_step": [_VP, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double],

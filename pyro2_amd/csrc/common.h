@@ -286,6 +286,8 @@ struct pyrohip_state {
     double next_cfl_min = -1.0;  // min over interior of dx/(|u|+c) etc. of the
                                  // state after the last step (-1: unknown)
     bool cfl_is_global = false;  // ... already reduced over all ranks
+    int cfl_kind = 0;            // ... 0: the CTU solver's quantity; 1: compressible_rk's
+                                 // min 1 / ((|u|+c)/dx + (|v|+c)/dy) (comp_rk_step_wave)
     // the ghost cells hold exactly what the boundary rules (outflow / reflect / periodic index
     // maps) give for the current interior: set by a full pyrohip_fill_bc, dropped by anything
     // that writes the state (uploads -- a host-side boundary callback comes back as one --,

@@ -27,11 +27,16 @@ int comp_source_correct(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_rk_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_rk_rhs(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, int);
 int comp_rk_rhs_wave(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, int);
+int comp_rk_step_wave(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, int, const double *,
+                      const double *, double, const StepScalars *, const double **);
+int comp_rk_cfl_min_device(pyrohip_state *, const pyrohip_comp_params *, const double **);
 int comp_wave_geometry(int, int, int, int, int, int *);
 }
 namespace fastm {
 int comp_rk_rhs(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, int);
 int comp_rk_rhs_wave(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, int);
+int comp_rk_step_wave(pyrohip_state *, const pyrohip_comp_params *, pyrohip_state *, int, const double *,
+                      const double *, double, const StepScalars *, const double **);
 int comp_dt(pyrohip_state *, const pyrohip_comp_params *, double, double *);
 int comp_step_staged(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_fused(pyrohip_state *, const pyrohip_comp_params *, double);
@@ -352,6 +357,7 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
                     s->pend_n, const_cast<double *>(dmin), 1);
         s->pend_part = nullptr;
         s->next_cfl_min = 1.0;      // "cached on the device": keeps a posted halo exchange valid
+        s->cfl_kind = 0;
         s->pol_next = d_pol;    // (one launch per step: this is step 0, its dt is in S[0])
         s->pol_m = 0;
         if (sphf)
@@ -423,6 +429,7 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
     }
     // the minimum of the last launch belongs to the state only if that launch advanced it
     s->next_cfl_min = (H.steps == max_steps && !(flagv & 1)) ? lastmin : -1.0;
+    s->cfl_kind = 0;
     if (s->next_cfl_min <= 0.0) s->cfl_is_global = false;
     pol->t = H.t; pol->dt_old = H.dt_old; pol->n = H.n;
     *steps_done = H.steps;
@@ -441,7 +448,7 @@ int pyrohip_comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, 
     if (s->sph) {
         // (cached by the one-launch spherical step: whole-array minimum of the new state; every
         // other path that touches the state, the staged spherical set included, resets it)
-        if (s->next_cfl_min > 0.0) { *dt_out = cfl * s->next_cfl_min; return 0; }
+        if (s->next_cfl_min > 0.0 && s->cfl_kind == 0) { *dt_out = cfl * s->next_cfl_min; return 0; }
         return p->fast_math ? fastm::comp_dt_sph(s, p, cfl, dt_out)
                             : exact::comp_dt_sph(s, p, cfl, dt_out);
     }
@@ -451,14 +458,14 @@ int pyrohip_comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, 
 int pyrohip_comp_dt_is_cached(pyrohip_state *s, int *flag)
 {
     PYRO_REQUIRE(s && flag, "NULL argument");
-    *flag = (s->next_cfl_min > 0.0 && !s->user_bc && !s->ramp_bc) ? 1 : 0;
+    *flag = (s->next_cfl_min > 0.0 && s->cfl_kind == 0 && !s->user_bc && !s->ramp_bc) ? 1 : 0;
     return 0;
 }
 
 int pyrohip_comp_dt_is_global(pyrohip_state *s, int *flag)
 {
     PYRO_REQUIRE(s && flag, "NULL argument");
-    *flag = (s->next_cfl_min > 0.0 && s->cfl_is_global && !s->user_bc && !s->ramp_bc) ? 1 : 0;
+    *flag = (s->next_cfl_min > 0.0 && s->cfl_kind == 0 && s->cfl_is_global && !s->user_bc && !s->ramp_bc) ? 1 : 0;
     return 0;
 }
 
@@ -553,7 +560,159 @@ int pyrohip_comp_rk_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cf
 {
     PYRO_TRY(check_comp(s, p));
     PYRO_REQUIRE(dt_out, "dt_out is NULL");
+    // (left by the last stage of pyrohip_comp_rk_step: the minimum over the new interior, which
+    // is the whole-array minimum of simulation.py:46-56 once the ghost cells are images)
+    if (s->next_cfl_min > 0.0 && s->cfl_kind == 1) { *dt_out = cfl * s->next_cfl_min; return 0; }
     return exact::comp_rk_dt(s, p, cfl, dt_out);
+}
+
+// The whole Runge-Kutta step in nstages launches of the row-marching kernel (comp_wave.hip:
+// comp_rk_step_wave)?  Single Cartesian domain, outflow / reflect / periodic sides (the same kind
+// for the four variables: the stage states' ghost cells are read through index maps), no sponge,
+// no heating profile, no host-evaluated source; kernel_set 2 or the library's choice from
+// 2048^2 cells on.
+static bool comp_rk_can_fuse(const pyrohip_state *y, const pyrohip_comp_params *p, const pyrohip_state *k,
+                             int nstages)
+{
+    if (y->nvar != 4 || y->sph || y->nb_set || y->user_bc || y->ramp_bc || y->heat || y->ext_old ||
+        p->do_sponge || y->g.ng < 4 || nstages < 2 || nstages > 4 || !k || k->nvar < 4 * nstages)
+        return false;
+    if (!(p->kernel_set == 2 || (p->kernel_set < 0 && wave_kernel_pays(y->g)))) return false;
+    for (int sd = 0; sd < 4; sd++) {
+        int kind0 = -1;
+        for (int n = 0; n < 4; n++) {
+            const int b = y->bc[n * 4 + sd];
+            const int kind = (b == PYROHIP_BC_OUTFLOW) ? 0
+                             : (b == PYROHIP_BC_REFLECT_EVEN || b == PYROHIP_BC_REFLECT_ODD) ? 1
+                             : (b == PYROHIP_BC_PERIODIC) ? 2 : -1;
+            if (kind < 0 || (n > 0 && kind != kind0)) return false;
+            kind0 = kind;
+        }
+    }
+    return true;
+}
+
+static int check_rk(pyrohip_state *y, const pyrohip_comp_params *p, pyrohip_state *k, int nstages,
+                    const double *a, const double *b)
+{
+    PYRO_TRY(check_comp(y, p));
+    PYRO_REQUIRE(k && a && b && k->ctx == y->ctx, "NULL argument / k state on another context");
+    PYRO_REQUIRE(nstages >= 2 && nstages <= 4, "2 to 4 stages (RK2, TVD2, TVD3, RK4)");
+    PYRO_REQUIRE(k->g.nx == y->g.nx && k->g.ny == y->g.ny && k->g.ng == y->g.ng && k->nvar >= 4 * nstages,
+                 "the k state must have the geometry of the state and 4 planes per stage");
+    PYRO_REQUIRE(p->riemann >= 0 && p->riemann <= 2, "riemann must be 0 (HLLC), 1 (CGF) or 2 (HLLC_lm)");
+    for (int s = 0; s < nstages; s++)
+        for (int j = s; j < nstages; j++)
+            PYRO_REQUIRE(a[s * nstages + j] == 0.0, "explicit methods only (strictly lower triangular a)");
+    return 0;
+}
+
+int pyrohip_comp_rk_can_fuse(pyrohip_state *y, const pyrohip_comp_params *p, pyrohip_state *k, int nstages,
+                             int *flag)
+{
+    PYRO_REQUIRE(y && p && flag, "NULL argument");
+    *flag = comp_rk_can_fuse(y, p, k, nstages) ? 1 : 0;
+    return 0;
+}
+
+int pyrohip_comp_rk_step(pyrohip_state *y, const pyrohip_comp_params *p, pyrohip_state *k, double dt,
+                         int nstages, const double *a, const double *b)
+{
+    PYRO_TRY(check_rk(y, p, k, nstages, a, b));
+    PYRO_REQUIRE(dt > 0.0, "dt must be positive");
+    PYRO_REQUIRE(comp_rk_can_fuse(y, p, k, nstages),
+                 "pyrohip_comp_rk_step: single Cartesian domain, outflow / reflect / periodic sides, no sponge / "
+                 "heating / host source, kernel_set 2 or a grid of >= 2048^2 cells (pyrohip_comp_rk_can_fuse; "
+                 "otherwise stage by stage: pyrohip_comp_rk_rhs + pyrohip_state_lincomb)");
+    const int rc = p->fast_math ? fastm::comp_rk_step_wave(y, p, k, nstages, a, b, dt, nullptr, nullptr)
+                                : exact::comp_rk_step_wave(y, p, k, nstages, a, b, dt, nullptr, nullptr);
+    y->ghost_by_rules = false;
+    return rc;
+}
+
+// Up to max_steps steps of the compressible_rk driver loop (pyro_sim.py:241-281 with
+// compressible_rk/simulation.py:46-104) without a host round trip per step: as pyrohip_comp_evolve,
+// with the Runge-Kutta step above between the policy calls.
+int pyrohip_comp_rk_evolve(pyrohip_state *y, const pyrohip_comp_params *p, pyrohip_state *k, int nstages,
+                           const double *a, const double *b, double cfl, pyrohip_dt_policy *pol,
+                           int max_steps, int *steps_done, double *dts_out)
+{
+    PYRO_TRY(check_rk(y, p, k, nstages, a, b));
+    PYRO_REQUIRE(pol && steps_done && max_steps >= 1, "NULL argument / max_steps must be positive");
+    PYRO_REQUIRE(comp_rk_can_fuse(y, p, k, nstages),
+                 "device-side stepping: compressible_rk needs the conditions of pyrohip_comp_rk_step "
+                 "(pyrohip_comp_rk_can_fuse)");
+    pyrohip_state *s = y;
+    pyrohip_ctx *c = s->ctx;
+    PYRO_REQUIRE(!c->global_cfl, "device-side stepping: compressible_rk runs on a single domain");
+    if (!s->d_scal) PYRO_CHECK_HIP(hipMalloc((void **)&s->d_scal, sizeof(StepScalars)));
+    if (s->dts_cap < max_steps + 1) {
+        if (s->d_dts) PYRO_CHECK_HIP(hipFree(s->d_dts));
+        s->d_dts = nullptr;
+        PYRO_CHECK_HIP(hipMalloc((void **)&s->d_dts, (size_t)(max_steps + 1) * sizeof(double)));
+        s->dts_cap = max_steps + 1;
+    }
+    StepScalars H;
+    memset(&H, 0, sizeof(H));
+    H.t = pol->t; H.dt_old = pol->dt_old; H.n = pol->n;
+    H.tmax = pol->tmax; H.f0 = pol->init_tstep_factor; H.mx = pol->max_dt_change;
+    H.fix_dt = pol->fix_dt; H.cfl = cfl; H.dx = p->dx; H.dy = p->dy;
+    PYRO_CHECK_HIP(hipMemcpyAsync(s->d_scal, &H, sizeof(H), hipMemcpyHostToDevice, c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));      // H is on this stack frame
+    PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
+    s->pend_part = nullptr;
+    const double *dmin = nullptr;
+    int rc = 0;
+    for (int m = 0; m < max_steps && rc == 0; m++) {
+        if (m == 0) {
+            // the CFL minimum of the state as handed over: whole array, ghost cells filled
+            rc = pyrohip_fill_bc(s, -1);
+            if (rc == 0) rc = exact::comp_rk_cfl_min_device(s, p, &dmin);
+            if (rc) break;
+        }
+        PYRO_LAUNCH(c, "k_dt_policy", k_dt_policy, dim3(1), dim3(kPolicyThreads), 0, s->d_scal, dmin,
+                    (const int *)s->d_flag, s->d_dts, m, 0, (const double *)nullptr, 0,
+                    const_cast<double *>(dmin), 1);
+        rc = p->fast_math ? fastm::comp_rk_step_wave(s, p, k, nstages, a, b, 0.0, s->d_scal, &dmin)
+                          : exact::comp_rk_step_wave(s, p, k, nstages, a, b, 0.0, s->d_scal, &dmin);
+    }
+    PYRO_TRY(rc);
+    hipLaunchKernelGGL(k_dt_policy, dim3(1), dim3(kPolicyThreads), 0, c->stream, s->d_scal, dmin,
+                       (const int *)s->d_flag, s->d_dts, max_steps, 1, (const double *)nullptr, 0,
+                       const_cast<double *>(dmin), 1);
+    PYRO_CHECK_HIP(hipGetLastError());
+    char *hb = (char *)c->reduce_host;                       // 256 pinned bytes
+    PYRO_CHECK_HIP(hipMemcpyAsync(hb, s->d_scal, sizeof(StepScalars), hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipMemcpyAsync(hb + sizeof(StepScalars), s->d_flag, sizeof(int),
+                                  hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipMemcpyAsync(hb + sizeof(StepScalars) + 8, dmin, sizeof(double),
+                                  hipMemcpyDeviceToHost, c->stream));
+    if (dts_out)
+        PYRO_CHECK_HIP(hipMemcpyAsync(dts_out, s->d_dts, (size_t)max_steps * sizeof(double),
+                                      hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    memcpy(&H, hb, sizeof(H));
+    const int flagv = (*(int *)(hb + sizeof(StepScalars)) & 1) | (H.dead ? 1 : 0);
+    const double lastmin = *(double *)(hb + sizeof(StepScalars) + 8);
+    // max_steps swaps were made; the last state that advanced sits H.steps swaps from the start
+    if ((max_steps - H.steps) % 2) {
+        double *old_base = s->base;
+        s->base = s->alt_base;
+        s->alt_base = old_base;
+        s->d = s->base + geom_lead(s->g);
+    }
+    s->next_cfl_min = (H.steps == max_steps && !(flagv & 1)) ? lastmin : -1.0;
+    s->cfl_kind = 1;
+    s->cfl_is_global = false;
+    s->ghost_by_rules = false;
+    pol->t = H.t; pol->dt_old = H.dt_old; pol->n = H.n;
+    *steps_done = H.steps;
+    if (flagv & 1) {
+        set_error("invalid state: min(rho) <= 0 or min(e) <= 0 on the interior "
+                  "(compressible/simulation.py:68-71); the state is the one before that step");
+        return PYROHIP_ERR_STATE;
+    }
+    return 0;
 }
 
 int pyrohip_comp_rk_rhs(pyrohip_state *y, const pyrohip_comp_params *p, pyrohip_state *k, int slot)

@@ -834,6 +834,8 @@ int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP 
     P.mc = P.mr;
     P.odd = 0;
     P.pol = nullptr; P.pol_m = 0; P.pol_pre = 0;
+    P.rk_k = nullptr; P.rk_n = 0; P.rk_a[0] = P.rk_a[1] = P.rk_a[2] = 0.0;
+    P.rk_final = 0; P.rk_nb = 0; P.rk_b[0] = P.rk_b[1] = P.rk_b[2] = P.rk_b[3] = 0.0; P.rk_out = nullptr;
     if (reset_flag) PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
     return 0;
 }
@@ -902,6 +904,7 @@ int fused_sync(pyrohip_state *s, const double *dmin)
     }
     fused_swap(s);
     s->next_cfl_min = ((double *)c->reduce_host)[0];
+    s->cfl_kind = 0;
     return 0;
 }
 

@@ -208,7 +208,10 @@ __device__ __forceinline__ void st_put(double *st, int s, const Cons &U)
 // ONE: this launch is the whole step of a device-side run (pyrohip_comp_evolve, comp_api.hip):
 // ghost cells are read through the boundary rules (no filled frame) and the last wavefront to
 // finish runs the driver's dt policy for the next step.
-template <int SOLVER, bool STD, bool MOL = false, bool ONE = false>   // SOLVER, STD as k_ctu_fused
+// RKF (with MOL): the Runge-Kutta stage folded into the launch -- the stage state built at load from
+// y_0 and the earlier increments, ghost cells through the boundary rules, and in the last stage
+// the final update + the CFL minimum of compressible_rk instead of the k store (fused_common.h: FP::rk_*)
+template <int SOLVER, bool STD, bool MOL = false, bool ONE = false, bool RKF = false>   // SOLVER, STD as k_ctu_fused
 __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *__restrict__ Uin,
                                                                  double *__restrict__ Uout, Geom g,
                                                                  FP P, int *__restrict__ flag,
@@ -216,6 +219,8 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                                                                  const StepScalars *__restrict__ S)
 {
     HIP_DYNAMIC_SHARED(double, lds)
+    static_assert(!RKF || (MOL && !ONE), "the folded Runge-Kutta stage is a method-of-lines launch");
+    constexpr bool MAPS = ONE || RKF;      // ghost cells are read through the boundary rules
     const int l = threadIdx.x;
     double *st = lds + l;
     // workgroup -> (column strip, row strip): workgroups are dealt round-robin to the 8 XCDs
@@ -335,15 +340,35 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     // array_indexer.py:163-274), with the sign of the variables that reflect oddly -- what
     // fill_BC_all would have left in it, so the frame of Uin need not be filled.  The sign is
     // applied where the row is consumed, an iteration after its load (fix_sign).
-    const int jsrc = ONE ? bc_src(P.mc, jc, g.jlo, g.jhi) : jc;
+    const int jsrc = MAPS ? bc_src(P.mc, jc, g.jlo, g.jhi) : jc;
+    // RKF: this stage's weights dt a_sj (integration.py:116: self.dt*a[istage, s], then times k)
+    const double rkc0 = RKF ? v_dt * P.rk_a[0] : 0.0, rkc1 = RKF ? v_dt * P.rk_a[1] : 0.0,
+                 rkc2 = RKF ? v_dt * P.rk_a[2] : 0.0;
     auto loadU = [&](int row) {
         row = row < 0 ? 0 : (row > g.qx - 1 ? g.qx - 1 : row);
-        const int srow = ONE ? bc_src(P.mr, row, g.ilo, g.ihi) : row;
+        const int srow = MAPS ? bc_src(P.mr, row, g.ilo, g.ihi) : row;
         const size_t kk = (size_t)srow * p + jsrc;
-        return Cons{Uin[kk], Uin[pl + kk], Uin[2 * pl + kk], Uin[3 * pl + kk]};
+        Cons U{Uin[kk], Uin[pl + kk], Uin[2 * pl + kk], Uin[3 * pl + kk]};
+        if (RKF) {
+            // (the source cell of a mapped ghost cell is an interior cell: y_0 + the increments, in
+            // the reference's order of accumulation; a zero weight adds nothing and is not read)
+            const double *K = P.rk_k + kk;
+            if (P.rk_n > 0 && P.rk_a[0] != 0.0) {
+                U.d += rkc0 * K[0]; U.E += rkc0 * K[pl]; U.mx += rkc0 * K[2 * pl]; U.my += rkc0 * K[3 * pl];
+            }
+            if (P.rk_n > 1 && P.rk_a[1] != 0.0) {
+                const double *K1 = K + 4 * pl;
+                U.d += rkc1 * K1[0]; U.E += rkc1 * K1[pl]; U.mx += rkc1 * K1[2 * pl]; U.my += rkc1 * K1[3 * pl];
+            }
+            if (P.rk_n > 2 && P.rk_a[2] != 0.0) {
+                const double *K2 = K + 8 * pl;
+                U.d += rkc2 * K2[0]; U.E += rkc2 * K2[pl]; U.mx += rkc2 * K2[2 * pl]; U.my += rkc2 * K2[3 * pl];
+            }
+        }
+        return U;
     };
     auto fix_sign = [&](Cons &U, int row) {
-        if (!ONE || !P.odd) return;
+        if (!MAPS || !P.odd) return;
         const unsigned sd = (j < g.jlo ? 4u : 0u) | (j > g.jhi ? 8u : 0u) |
                             (row < g.ilo ? 1u : 0u) | (row > g.ihi ? 2u : 0u);
         U.d = odd_sides(P.odd & sd) ? -U.d : U.d;
@@ -419,7 +444,8 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             fix_sign(U, k);
             Upre = loadU(k + 1);
             const bool interior = row_in(k) && jin;
-            if (MOL && interior && U.d < US(SMALLD, P.small_dens))     // clean_state works in place
+            // (RKF: the stage state is a temporary of the step -- nothing to keep the floor in)
+            if (MOL && !RKF && interior && U.d < US(SMALLD, P.small_dens))     // clean_state works in place
                 const_cast<double *>(Uin)[(size_t)k * p + jc] = US(SMALLD, P.small_dens);
             if (interior) U.d = fmax(U.d, US(SMALLD, P.small_dens));
             bool ok;
@@ -674,8 +700,32 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                     Un.E = Un.E + (Uc.my * UC(GRAV) + Uc.d * UC(HEATR) * (P.heat ? P.heat[kr] : 0.0));
                     Un.mx = Un.mx + 0.0;
                     Un.my = Un.my + Uc.d * UC(GRAV);
+                    if (RKF && P.rk_final) {
+                        // integration.py:120-129: y_0 += dt b_s k_s, s = 0 ... -- the earlier
+                        // increments from memory, the last one is Un; then the CFL quantity of
+                        // compressible_rk/simulation.py:46-56 on the new state
+                        Cons Y{Uin[kr], Uin[pl + kr], Uin[2 * pl + kr], Uin[3 * pl + kr]};
+#pragma unroll
+                        for (int sgm = 0; sgm < 3; sgm++) {
+                            if (sgm < P.rk_nb - 1 && P.rk_b[sgm] != 0.0) {
+                                const double w = v_dt * P.rk_b[sgm];
+                                const double *Ks = P.rk_k + (size_t)(4 * sgm) * pl + kr;
+                                Y.d += w * Ks[0]; Y.E += w * Ks[pl]; Y.mx += w * Ks[2 * pl]; Y.my += w * Ks[3 * pl];
+                            }
+                        }
+                        if (P.rk_b[P.rk_nb - 1] != 0.0) {
+                            const double w = v_dt * P.rk_b[P.rk_nb - 1];
+                            Y.d += w * Un.d; Y.E += w * Un.E; Y.mx += w * Un.mx; Y.my += w * Un.my;
+                        }
+                        double *O = P.rk_out + kr;
+                        O[0] = Y.d; O[pl] = Y.E; O[2 * pl] = Y.mx; O[3 * pl] = Y.my;
+                        double ax, ay;
+                        cfl_speeds(Y, US(GAMMA, P.gamma), ax, ay);
+                        st[ST_AX * 64] = fmax(st[ST_AX * 64], pdiv(ax, dxx) + pdiv(ay, dyy));
+                    } else {
                     Uout[kr] = Un.d; Uout[pl + kr] = Un.E; Uout[2 * pl + kr] = Un.mx;
                     Uout[3 * pl + kr] = Un.my;
+                    }
                 } else {
 #if PYRO_FAST
                 const double cx = US(CX, s_cx), cy = US(CY, s_cy);
@@ -718,6 +768,9 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     // min over the lane's cells of min(dx / (|u| + c), dy / (|v| + c)), cfl_cell()
     const double ax = st[ST_AX * 64], ay = st[ST_AY * 64];
     double cfl = fmin(ax > 0.0 ? pdiv(P.dx, ax) : INFINITY, ay > 0.0 ? pdiv(P.dy, ay) : INFINITY);
+    // (RKF, last stage: min 1 / ((|u| + c)/dx + (|v| + c)/dy) = 1 / max of the divisor, the
+    // correctly rounded reciprocal being monotone)
+    if (RKF) cfl = ax > 0.0 ? pdiv(1.0, ax) : INFINITY;
     finish(__shfl(wave_reduce_min(cfl), 0, 64), bad);
 }
 
@@ -927,6 +980,77 @@ int comp_rk_rhs_wave(pyrohip_state *s, const pyrohip_comp_params *p, pyrohip_sta
         return PYROHIP_ERR_STATE;
     }
     return 0;
+}
+
+// compressible_rk: the WHOLE Runge-Kutta step of compressible_rk/simulation.py:58-104 on the row-
+// marching kernel -- stage 0 on the filled state (the driver's fill + the stage's own, one fill:
+// idempotent), every later stage with its start y_0 + dt sum_j a_sj k_j built at load and its
+// ghost cells read through the boundary rules (k_ctu_wave<.., MOL, false, RKF>), the last one
+// storing y_0 + dt sum_s b_s k_s into the second buffer (ghost frame carried over, buffers
+// swapped) and leaving the CFL minimum of the new state.  No pyrohip_state_lincomb launches, no
+// stage state, no ghost fills of it: an RK4 step at 4096^2 was 4 x 0.49 ms of right-hand sides
+// + 4 x 0.44 ms of linear combinations + 0.14 ms of CFL reduction (profiles/r05_rk4096_*).
+// a: nstages x nstages, row-major (Butcher tableau, strictly lower triangular); b: nstages.
+// S == nullptr: dt by value, flag and minimum read back (single step); S != nullptr: a step of a
+// device-side run (pyrohip_comp_rk_evolve), dt from *S, *dmin_out = device address of the minimum.
+int comp_rk_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, pyrohip_state *kst, int nstages,
+                      const double *a, const double *b, double dt, const StepScalars *S,
+                      const double **dmin_out)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    FP P;
+    double *Uin, *Unew;
+    PYRO_TRY(fused_prepare(s, p, dt, P, Uin, Unew, S == nullptr, true));
+    const int cus = c->num_cus > 0 ? c->num_cus : 256;
+    const WaveGeom wg = wave_geometry(g.nx, g.ny, g.ng, cus, p->march_rows);
+    P.ncb = wg.ncb; P.L = wg.L; P.nsb = wg.nsb;
+    const int nwg = P.ncb * wg.nsb;
+    PYRO_TRY(c->reduce.ensure((nwg + kMinStageBlocks + 2) * sizeof(double)));
+    double *part = (double *)c->reduce.p;
+    using KernelT = void (*)(const double *, double *, Geom, FP, int *, double *, const StepScalars *);
+    static const KernelT first[3][2] = {
+        {k_ctu_wave<0, false, true>, k_ctu_wave<0, true, true>},
+        {k_ctu_wave<1, false, true>, k_ctu_wave<1, true, true>},
+        {k_ctu_wave<2, false, true>, k_ctu_wave<2, true, true>}};
+    static const KernelT later[3][2] = {
+        {k_ctu_wave<0, false, true, false, true>, k_ctu_wave<0, true, true, false, true>},
+        {k_ctu_wave<1, false, true, false, true>, k_ctu_wave<1, true, true, false, true>},
+        {k_ctu_wave<2, false, true, false, true>, k_ctu_wave<2, true, true, false, true>}};
+    const int solver = (p->riemann == 1 || p->riemann == 2) ? p->riemann : 0;
+    const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
+    P.nunits = nwg;
+    P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus);
+    const dim3 grid(8 * ((nwg + 7) / 8)), block(64);
+    // stage 0: the state itself, ghost cells filled in memory (they stay the state's "stale"
+    // ghost cells after the step, like the reference's), density floor in place
+    PYRO_TRY(pyrohip_fill_bc(s, -1));
+    PYRO_LAUNCH(c, "k_ctu_wave_mol", first[solver][std_rec], grid, block, WLDS_BYTES, (const double *)Uin,
+                kst->d, g, P, s->d_flag, part, S);
+    P.mr = bc_map(g.ilo, g.ihi, g.ng, s->bc[0], s->bc[1], true);
+    P.mc = bc_map(g.jlo, g.jhi, g.ng, s->bc[2], s->bc[3], true);
+    for (int n = 0; n < 4; n++)
+        for (int sd = 0; sd < 4; sd++)
+            if (s->bc[n * 4 + sd] == PYROHIP_BC_REFLECT_ODD) P.odd |= 1u << (4 * n + sd);
+    P.rk_k = kst->d;
+    for (int st = 1; st < nstages; st++) {
+        P.rk_n = st;
+        for (int j = 0; j < 3; j++) P.rk_a[j] = (j < st) ? a[st * nstages + j] : 0.0;
+        P.rk_final = (st == nstages - 1) ? 1 : 0;
+        P.rk_nb = nstages;
+        for (int j = 0; j < 4; j++) P.rk_b[j] = (j < nstages) ? b[j] : 0.0;
+        P.rk_out = Unew;
+        PYRO_LAUNCH(c, "k_ctu_wave_rk", later[solver][std_rec], grid, block, WLDS_BYTES, (const double *)Uin,
+                    kst->d + (size_t)(4 * st) * g.plane, g, P, s->d_flag, part, S);
+    }
+    PYRO_CHECK_HIP(hipGetLastError());
+    fused_copy_frame(s);                  // ghost frame of the state -> the new buffer
+    const double *dmin = launch_min_reduce(c->stream, part, nwg);
+    s->cfl_is_global = false;
+    if (S) { fused_swap(s); *dmin_out = dmin; return 0; }
+    const int rc = fused_sync(s, dmin);   // flag + minimum read back; swap if the state was valid
+    if (rc == 0) s->cfl_kind = 1;         // (the minimum is compressible_rk's CFL quantity)
+    return rc;
 }
 
 }  // namespace PYRO_NS

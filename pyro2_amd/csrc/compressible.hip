@@ -505,7 +505,7 @@ int comp_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, double *
     const Geom &g = s->g;
     // the hse / ambient boundaries put states into the y ghost rows that no
     // interior cell holds (they do enter the reference's full-array minimum)
-    if (s->next_cfl_min > 0.0 && !s->user_bc && !s->ramp_bc) {   // cached by the last k_update
+    if (s->next_cfl_min > 0.0 && s->cfl_kind == 0 && !s->user_bc && !s->ramp_bc) {   // cached by the last k_update
         *dt_out = cfl * s->next_cfl_min;
         return 0;
     }
@@ -573,6 +573,7 @@ int comp_step_staged(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
                                   hipMemcpyDeviceToHost, c->stream));
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
     s->next_cfl_min = P.ext ? -1.0 : ((double *)c->reduce_host)[0];   // U* is not the new state
+    s->cfl_kind = 0;
     int flag = *(int *)((char *)c->reduce_host + 8);
     if (flag & 1) {
         s->next_cfl_min = -1.0;
@@ -1152,6 +1153,23 @@ __global__ __launch_bounds__(256) void k_rk_cfl(const double *__restrict__ U, Ge
         }
     m = block_reduce_min(m);
     if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = m;
+}
+
+// the same minimum left in device memory (first step of pyrohip_comp_rk_evolve)
+int comp_rk_cfl_min_device(pyrohip_state *s, const pyrohip_comp_params *p, const double **dmin)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    dim3 grid(8, 128), block(256);
+    const int nb = grid.x * grid.y;
+    // (behind the partials of the step kernels, which use the front of the same buffer)
+    PYRO_TRY(c->reduce.ensure((size_t)(2 * nb + kMinStageBlocks + 2 + 65536) * sizeof(double)));
+    double *part = (double *)c->reduce.p + 65536;
+    hipLaunchKernelGGL(k_rk_cfl, grid, block, 0, c->stream, (const double *)s->d, g, p->gamma, p->dx,
+                       p->dy, part);
+    *dmin = launch_min_reduce(c->stream, part, nb);
+    PYRO_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int comp_rk_dt(pyrohip_state *s, const pyrohip_comp_params *p, double cfl, double *dt_out)

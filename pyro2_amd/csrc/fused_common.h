@@ -38,6 +38,18 @@ struct FP {   // kernel parameters
     StepPolicy *pol;          // (device memory)
     int pol_m;                // step of the call this launch is
     int pol_pre;              // S[pol_m & 1] is this step's already (k_dt_policy ran: step 0)
+    // method-of-lines instance with the Runge-Kutta stage folded in (k_ctu_wave<.., MOL, .., RKF>):
+    // the stage state y_s = y_0 + dt sum_j a_sj k_j (mesh/integration.py:105-118) is built per row
+    // as it enters the window -- interior cells; ghost cells are the images the boundary rules
+    // give (mr / mc / odd), as the fill of the stage state would have left them -- and the last
+    // stage stores y_0 + dt sum_s b_s k_s (:120-129) into the other state buffer instead of its k
+    const double *rk_k;       // the k state's first plane (slot j: rk_k + 4 j plane)
+    int rk_n;                 // increments that enter this stage's start (columns j < rk_n of a_s)
+    double rk_a[3];           // a[s][j] (terms with a zero weight are skipped)
+    int rk_final;             // this launch is the last stage: the final update
+    int rk_nb;                // ... stages of the method
+    double rk_b[4];           // ... b[s]
+    double *rk_out;           // ... the buffer the new state goes to
 };
 
 // parity of a 4-bit set of sides

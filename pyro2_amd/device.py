@@ -449,6 +449,39 @@ class DeviceState:
         with self.ctx.lock:
             check(self._l.pyrohip_comp_source_correct(self.h, C.byref(params), dt))
 
+    def comp_rk_can_fuse(self, params, kstate, nstages):
+        """may the whole Runge-Kutta step run as nstages launches (pyrohip_comp_rk_step)?"""
+        f = C.c_int()
+        with self.ctx.lock:
+            check(self._l.pyrohip_comp_rk_can_fuse(self.h, C.byref(params), kstate.h, int(nstages), C.byref(f)))
+        return bool(f.value)
+
+    def comp_rk_step(self, params, kstate, dt, a, b):
+        """one compressible_rk step: Butcher tableau a (n x n), b (n); kstate: scratch with 4 n planes"""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        with self.ctx.lock:
+            check(self._l.pyrohip_comp_rk_step(self.h, C.byref(params), kstate.h, float(dt), len(b),
+                                               dptr(a), dptr(b)))
+
+    def comp_rk_evolve(self, params, kstate, a, b, cfl, policy, max_steps):
+        """up to max_steps compressible_rk steps with the driver's dt policy on the device
+        (as comp_evolve); returns the dt of the steps taken"""
+        from ._lib import DtPolicyC
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        pc = DtPolicyC(policy.tmax, policy.f0, policy.mx, policy.fix, policy.t, policy.dt_old,
+                       policy.n)
+        done = C.c_int()
+        dts = np.empty(int(max_steps))
+        with self.ctx.lock:
+            rc = self._l.pyrohip_comp_rk_evolve(self.h, C.byref(params), kstate.h, len(b), dptr(a), dptr(b),
+                                                float(cfl), C.byref(pc), int(max_steps), C.byref(done),
+                                                dptr(dts))
+        policy.t, policy.dt_old, policy.n = pc.t, pc.dt_old, int(pc.n)
+        check(rc)
+        return dts[:done.value]
+
     def comp_evolve(self, params, cfl, policy, max_steps):
         """up to max_steps single_steps (ghost fill, dt policy, evolve) without a host
         round trip per step.  `policy`: an object with tmax, f0 (init_tstep_factor), mx

@@ -1425,3 +1425,119 @@ def test_rk_rhs_one_launch_equals_staged(dev, riemann, nx, ny, grav, lim, flat, 
     assert np.array_equal(out[0][0], out[2][0])
     assert np.array_equal(out[0][1], out[2][1])
     assert (out[2][1][4:-4, 4:-4, 0] >= 1.05).all() and (ic[4:-4, 4:-4, 0] < 1.05).any()
+
+
+RK_BCS = [("outflow", "outflow", "outflow", "outflow"), ("reflect", "reflect", "periodic", "periodic"),
+          ("periodic", "periodic", "reflect", "outflow")]
+
+
+def _rk_random_state(nx, ny, seed):
+    rng = np.random.default_rng(seed)
+    ng = 4
+    x = np.arange(nx + 2 * ng)[:, None] / nx
+    y = np.arange(ny + 2 * ng)[None, :] / ny
+    U = np.zeros((nx + 2 * ng, ny + 2 * ng, 4))
+    U[..., 0] = 1.0 + 0.3 * np.sin(5 * x) * np.cos(3 * y) + 0.05 * rng.random(U.shape[:2])
+    U[..., 2] = U[..., 0] * 0.3 * np.cos(4 * x + y)
+    U[..., 3] = U[..., 0] * -0.2 * np.sin(3 * y - 2 * x)
+    U[..., 1] = (1.0 + 0.5 * np.cos(2 * x) * np.sin(2 * y)) / 0.4 + 0.5 * (U[..., 2] ** 2 + U[..., 3] ** 2) / U[..., 0]
+    return U
+
+
+@pytest.mark.parametrize("method", ["RK2", "TVD2", "TVD3", "RK4"])
+@pytest.mark.parametrize("bcs", RK_BCS)
+@pytest.mark.parametrize("nx,ny,grav,riemann", [(40, 130, 0.0, "HLLC"), (23, 61, -0.7, "CGF")])
+def test_rk_step_in_one_call_equals_stage_by_stage(dev, method, bcs, nx, ny, grav, riemann):
+    """pyrohip_comp_rk_step (the stage states built at load from y_0 and the earlier increments,
+    ghost cells through the boundary rules, the final update + CFL minimum in the last stage:
+    k_ctu_wave<.., MOL, false, RKF>) against the stage-by-stage path -- lincomb, ghost fill,
+    pyrohip_comp_rk_rhs, final lincomb, comp_rk_dt -- three steps: the bit-faithful build bit for
+    bit (interior AND ghost cells), every method, boundary kinds incl. odd reflections, several
+    column strips / row chunks"""
+    from helpers import RK_TABLEAU
+    ng = 4
+    meta = [nx, ny, ng, 1.0 / nx, 1.5 / ny, 1.4, 2, 1, 0.75, 0.85, 0.33, 0.1, grav, 0.8]
+    solid = [int(b == "reflect") for b in bcs]
+    P, cfl = dev_params(meta, kernel_set=2, riemann=riemann, solid_xl=solid[0], solid_yl=solid[2], march_rows=16)
+    a, b = RK_TABLEAU[method]
+    ns = len(b)
+    U0 = _rk_random_state(nx, ny, nx * ny + ns)
+    out = {}
+    for fused in (0, 1):
+        s = comp_state(dev, nx, ny, list(bcs))
+        y = comp_state(dev, nx, ny, list(bcs))
+        kst = device.DeviceState(dev, nx, ny, ng, [["outflow"] * 4] * (4 * ns))
+        s.upload(U0)
+        if fused:
+            assert s.comp_rk_can_fuse(P, kst, ns)
+        dts = []
+        for n in range(3):
+            s.fill_bc()
+            dt = 0.3 * s.comp_rk_dt(P, cfl)
+            dts.append(dt)
+            if fused:
+                s.comp_rk_step(P, kst, dt, a, b)
+                continue
+            for st in range(ns):
+                cur = s
+                if st:
+                    y.lincomb(s, kst, [dt * a[st][j] for j in range(st)])
+                    y.fill_bc()
+                    cur = y
+                cur.comp_rk_rhs(P, kst, st)
+            s.lincomb(s, kst, [dt * b[st] for st in range(ns)])
+        out[fused] = (s.download(), dts)
+    if dev.kind == "emu":
+        assert out[0][1] == out[1][1]
+        assert np.array_equal(out[0][0], out[1][0]), np.argwhere(out[0][0] != out[1][0])[:5]
+    else:
+        assert np.abs(np.array(out[1][1]) / np.array(out[0][1]) - 1).max() <= TOL_EXACT
+        assert elementwise_close(out[1][0], out[0][0], TOL_EXACT)
+
+
+def elementwise_close(a, b, tol):
+    scale = np.maximum(np.abs(b).max(axis=(0, 1)), 1e-3)
+    return bool((np.abs(a - b) / scale).max() <= tol)
+
+
+@pytest.mark.parametrize("method", ["RK4", "TVD3"])
+def test_rk_evolve_on_device_equals_single_steps(dev, method):
+    """pyrohip_comp_rk_evolve (dt policy on the device between the steps, tmax inside the call)
+    against the same steps taken one by one from the host: dt sequence, time, state -- exact"""
+    from helpers import RK_TABLEAU
+    nx, ny, ng = 36, 70, 4
+    meta = [nx, ny, ng, 1.0 / nx, 1.0 / ny, 1.4, 2, 1, 0.75, 0.85, 0.33, 0.1, 0.0, 0.8]
+    bcs = ["outflow", "outflow", "periodic", "periodic"]
+    P, cfl = dev_params(meta, kernel_set=2, march_rows=16)
+    a, b = RK_TABLEAU[method]
+    ns = len(b)
+    U0 = _rk_random_state(nx, ny, 5)
+    res = []
+    for tmax in (1.e30, None):
+        s1 = comp_state(dev, nx, ny, bcs)
+        k1 = device.DeviceState(dev, nx, ny, ng, [["outflow"] * 4] * (4 * ns))
+        s1.upload(U0)
+        if tmax is None:      # ends inside the fifth step of the first run
+            tmax = sum(res[0][0][:4]) + 0.4 * res[0][0][4]
+        pol1 = DtPolicy(tmax)
+        d1 = []
+        while pol1.t < tmax and pol1.n < 6:
+            s1.fill_bc()
+            dt = pol1(s1.comp_rk_dt(P, cfl))
+            s1.comp_rk_step(P, k1, dt, a, b)
+            pol1.advance(dt)
+            d1.append(dt)
+        s = comp_state(dev, nx, ny, bcs)
+        k = device.DeviceState(dev, nx, ny, ng, [["outflow"] * 4] * (4 * ns))
+        s.upload(U0)
+        pol = DtPolicy(tmax)
+        dts = list(s.comp_rk_evolve(P, k, a, b, cfl, pol, 2))
+        dts += list(s.comp_rk_evolve(P, k, a, b, cfl, pol, 4))
+        assert dts == d1 and pol.t == pol1.t and pol.n == pol1.n, (dts, d1)
+        assert np.array_equal(s.download()[ng:-ng, ng:-ng], s1.download()[ng:-ng, ng:-ng])
+        # the next dt comes from the cached minimum: equal to a fresh reduction over the filled state
+        cached = s.comp_rk_dt(P, cfl)
+        s1.fill_bc()
+        s1.upload(s1.download())          # (drops the cache)
+        assert cached == s1.comp_rk_dt(P, cfl)
+        res.append((d1,))
