@@ -286,7 +286,7 @@ def bench_sedov(args, dist, ctx, device, defaults, steps=None, warmup=None, tile
     elif dist.comm_kind == "rccl":
         comm = RcclComm(ctx)
     else:
-        from pyro2_amd.decomp import HostStagedComm
+        from host_comm import HostStagedComm      # tests/host_comm.py: the debug transport, asked for by name
         comm = HostStagedComm(dist.td)
     kw = dict(dx=1.0 / nx, dy=1.0 / ny, fast_math=defaults["fast_math"],
               kernel_set=defaults["kernel_set"])

@@ -177,9 +177,48 @@ def only_diffusion():
     print("wrote", os.path.abspath(OUT))
 
 
+def time_solver_identity_njit(solver, problem, nx, ny, steps, inputs_file=None, extra=None):
+    """a solver whose step is mostly njit code, at the speed of the identity-njit shim (the
+    INTERPRETER's speed: a lower bound of what numba delivers, labelled as such)"""
+    p = Pyro(solver)
+    d = {"mesh.nx": nx, "mesh.ny": ny, "driver.max_steps": 10 ** 6, "driver.tmax": 1.0e9}
+    d.update(extra or {})
+    p.initialize_problem(problem, inputs_file=inputs_file, inputs_dict=d)
+    p.single_step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        p.single_step()
+    el = time.perf_counter() - t0
+    return {"workload": f"{solver} {problem} {nx}x{ny}" + (f" ({inputs_file})" if inputs_file else "") +
+                        ": Pyro.single_step of the reference with numba.njit replaced by the identity -- "
+                        "interpreter speed of the njit kernels, NOT what numba delivers",
+            "nx": nx, "ny": ny, "steps": steps, "seconds_per_step": el / steps,
+            "value": nx * ny * steps / el, "unit": "cell-updates/s", "cores": 1}
+
+
+def only_f4():
+    """SURVEY 8(f4) solvers (swe, compressible_rk, SphericalPolar compressible): sections of
+    their own in profiles/cpu_reference.json.  Their steps are njit code, so
+    the reference itself can only be timed at interpreter speed here (small grids, labelled);
+    the C port's rate at the bench size is recorded beside it by oracle/gen_fullsize.py's log."""
+    out = json.load(open(OUT))
+    date = time.strftime("%Y-%m-%d %H:%M:%S %Z")
+    for key, args in (("swe", ("swe", "dam", 128, 10, 2, "inputs.dam.x")),
+                      ("compressible_rk", ("compressible_rk", "sedov", 64, 64, 1, None)),
+                      ("compressible_spherical", ("compressible", "sedov", 64, 64, 1, "inputs.sedov.spherical"))):
+        r = time_solver_identity_njit(*args)
+        out[key] = {"date": date, "interpreted": r}
+        print(key, r["seconds_per_step"], "s/step", r["value"], "cells/s", flush=True)
+    with open(OUT, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", os.path.abspath(OUT))
+
+
 def main():
     if "--only-diffusion" in sys.argv:
         return only_diffusion()
+    if "--only-f4" in sys.argv:
+        return only_f4()
     quick = "--quick" in sys.argv
     out = {"host": platform.node(), "cpu": cpu_model(), "host_cores": os.cpu_count(),
            "cores_used": 1,

@@ -91,52 +91,6 @@ class RcclComm:
         return self.allreduce_min(state.comp_dt(params, cfl))
 
 
-class HostStagedComm:
-    """same contract as RcclComm over a torch.distributed process group
-    (gloo) with the halo rows staged through host memory.  NOT the product
-    data path: used by the CPU test-suite (no RCCL without GPUs) and as the
-    loudly reported fallback of bench.py when the RCCL communicator cannot
-    be created."""
-
-    # with the emulated backend set_neighbours only selects the launch order of the
-    # row-marching kernel (boundary strips first): same results, exercised on CPU
-    overlap = True
-
-    def __init__(self, td):
-        self.td = td
-
-    def halo_exchange(self, state, lo, hi):
-        import torch
-        ng, nxl = state.ng, state.nx
-        reqs, recvs = [], []
-        # same pairing as csrc/comm.hip: low rows -> lo, hi ghosts <- hi,
-        # high rows -> hi, lo ghosts <- lo
-        if lo >= 0:
-            t = torch.from_numpy(state.download_rows(ng, ng).copy())
-            reqs.append(self.td.isend(t, lo, tag=1))
-        if hi >= 0:
-            buf = torch.empty((ng, state.qy, state.nvar), dtype=torch.float64)
-            reqs.append(self.td.irecv(buf, hi, tag=1))
-            recvs.append((nxl + ng, buf))
-        if hi >= 0:
-            t = torch.from_numpy(state.download_rows(nxl, ng).copy())
-            reqs.append(self.td.isend(t, hi, tag=2))
-        if lo >= 0:
-            buf = torch.empty((ng, state.qy, state.nvar), dtype=torch.float64)
-            reqs.append(self.td.irecv(buf, lo, tag=2))
-            recvs.append((0, buf))
-        for r in reqs:
-            r.wait()
-        for row, buf in recvs:
-            state.upload_rows(row, buf.numpy())
-
-    def allreduce_min(self, x):
-        import torch
-        t = torch.tensor([x], dtype=torch.float64)
-        self.td.all_reduce(t, op=self.td.ReduceOp.MIN)
-        return float(t[0])
-
-
 class NoComm:
     """single rank"""
 

@@ -30,8 +30,8 @@ neighbours:
   scattered back.
 
 The communicator only has to move rows (`exchange`, `gather_rows`,
-`scatter_rows`): `HostRowComm` stages them through the host over a
-torch.distributed group (tests, gloo); on GPUs the same three moves are RCCL
+`scatter_rows`): the CPU tests stage them through the host over a
+torch.distributed group (tests/host_comm.py: HostRowComm, gloo); on GPUs the same three moves are RCCL
 send / recv pairs on the level arrays (`RcclRowComm`; it needs two GPUs and has
 not run yet, tests/test_zz_comm.py::test_rccl_multigrid_slabs_two_ranks skips on
 one: DESIGN.md 6).
@@ -40,101 +40,6 @@ import numpy as np
 
 KMAX = 5          # iterations per launch of the tile smoother (multigrid.hip MGW_KMAX)
 KDEEP = 10        # ... of the row-marching / deep-apron band kernels
-
-
-class HostRowComm:
-    """rows of level arrays between ranks, staged through the host (torch.distributed)"""
-
-    def __init__(self, td, rank, nranks):
-        self.td, self.rank, self.nranks = td, rank, nranks
-
-    def _send(self, a, dst, tag):
-        import torch
-        return self.td.isend(torch.from_numpy(np.ascontiguousarray(a)), dst, tag=tag)
-
-    def _recv(self, shape, src, tag):
-        import torch
-        buf = torch.empty(shape, dtype=torch.float64)
-        return buf, self.td.irecv(buf, src, tag=tag)
-
-    def exchange(self, mg, level, var, r0, r1, h):
-        """h halo rows on either side of the slab [r0, r1] of `var` on `level`"""
-        lo = self.rank - 1 if self.rank > 0 else -1
-        hi = self.rank + 1 if self.rank < self.nranks - 1 else -1
-        q = mg._n(level)
-        reqs, recvs = [], []
-        if lo >= 0:
-            reqs.append(self._send(mg.get_rows(level, var, r0, h), lo, 1))
-            buf, rq = self._recv((h, q), lo, 2)
-            reqs.append(rq)
-            recvs.append((r0 - h, buf))
-        if hi >= 0:
-            reqs.append(self._send(mg.get_rows(level, var, r1 - h + 1, h), hi, 2))
-            buf, rq = self._recv((h, q), hi, 1)
-            reqs.append(rq)
-            recvs.append((r1 + 1, buf))
-        for r in reqs:
-            r.wait()
-        for i0, buf in recvs:
-            mg.set_rows(level, var, i0, buf.numpy())
-
-    def gather_rows(self, mg, level, var, rows_of):
-        """every rank's slab rows_of(rank) of `var` on `level` -> rank 0's array"""
-        q = mg._n(level)
-        if self.rank == 0:
-            pend = []
-            for r in range(1, self.nranks):
-                a, b = rows_of(r)
-                buf, rq = self._recv((b - a + 1, q), r, 3)
-                pend.append((a, buf, rq))
-            for a, buf, rq in pend:
-                rq.wait()
-                mg.set_rows(level, var, a, buf.numpy())
-        else:
-            a, b = rows_of(self.rank)
-            self._send(mg.get_rows(level, var, a, b - a + 1), 0, 3).wait()
-
-    def scatter_rows(self, mg, level, var, rows_of):
-        """rows rows_of(rank) (array rows, ghost rows allowed) of rank 0's `var` -> each rank"""
-        q = mg._n(level)
-        if self.rank == 0:
-            reqs = []
-            for r in range(1, self.nranks):
-                a, b = rows_of(r)
-                reqs.append(self._send(mg.get_rows(level, var, a, b - a + 1), r, 4))
-            for rq in reqs:
-                rq.wait()
-        else:
-            a, b = rows_of(self.rank)
-            buf, rq = self._recv((b - a + 1, q), 0, 4)
-            rq.wait()
-            mg.set_rows(level, var, a, buf.numpy())
-
-
-    def allreduce_sum(self, mg, values):
-        import torch
-        t = torch.tensor(list(values), dtype=torch.float64)
-        self.td.all_reduce(t, op=self.td.ReduceOp.SUM)
-        return [float(x) for x in t]
-
-    def allgather_rows(self, mg, level, var, rows_of):
-        """every rank's slab rows_of(rank) of `var` on `level` -> every rank's array"""
-        q = mg._n(level)
-        a, b = rows_of(self.rank)
-        mine = mg.get_rows(level, var, a, b - a + 1)
-        reqs, recvs = [], []
-        for r in range(self.nranks):
-            if r == self.rank:
-                continue
-            ra, rb = rows_of(r)
-            buf, rq = self._recv((rb - ra + 1, q), r, 5)
-            recvs.append((ra, buf, rq))
-            reqs.append(self._send(mine, r, 5))
-        for ra, buf, rq in recvs:
-            rq.wait()
-            mg.set_rows(level, var, ra, buf.numpy())
-        for rq in reqs:
-            rq.wait()
 
 
 class RcclRowComm:

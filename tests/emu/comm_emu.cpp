@@ -7,7 +7,22 @@ int pyrohip_comm_unique_id(char *) { pyro::set_error("host-emu: no RCCL"); retur
 int pyrohip_comm_init(pyrohip_ctx *, int, int, const char *) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
 int pyrohip_comm_destroy(pyrohip_ctx *) { return 0; }
 int pyrohip_comm_size(pyrohip_ctx *, int *n) { if (n) *n = 0; return 0; }
-int pyrohip_halo_exchange(pyrohip_state *, int, int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
+// Test hooks: a communicator made of CALLBACKS (tests/test_decomp_gloo.py: four gloo processes
+// drive pyrohip_comp_evolve on their slabs; the halo rows and the CFL minimum travel through
+// torch.distributed in the callbacks).  The emulator runs everything synchronously, so the
+// exchange a real step POSTS for the new state (comm_post_halo) is carried out when the next
+// step asks for it -- the same rows, the same order of events on every rank.
+typedef int (*emu_halo_fn)(pyrohip_state *, int, int);
+typedef double (*emu_min_fn)(double);
+static emu_halo_fn g_halo_fn = nullptr;
+static emu_min_fn g_min_fn = nullptr;
+int pyrohip_emu_set_comm(emu_halo_fn h, emu_min_fn m) { g_halo_fn = h; g_min_fn = m; return 0; }
+int pyrohip_halo_exchange(pyrohip_state *s, int lo, int hi)
+{
+    if (!g_halo_fn) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
+    s->halo_pending = false;
+    return g_halo_fn(s, lo, hi);
+}
 int pyrohip_allreduce_min(pyrohip_ctx *, double *) { return 0; }
 int pyrohip_allreduce_max(pyrohip_ctx *, double *) { return 0; }
 int pyrohip_allreduce_sum(pyrohip_ctx *, double *, int) { return 0; }
@@ -20,8 +35,9 @@ static double g_peer_min = -1.0;
 int pyrohip_emu_set_peer_min(double v) { g_peer_min = v; return 0; }
 int pyrohip_comm_set_global_dt(pyrohip_ctx *c, int on)
 {
-    if (on && !(g_peer_min > 0.0)) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
+    if (on && !(g_peer_min > 0.0) && !g_min_fn) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
     c->global_cfl = on != 0;
+    if (g_halo_fn) c->comm = on ? (void *)&g_halo_fn : nullptr;     // "there is a communicator"
     return 0;
 }
 int pyrohip_mg_exchange_rows(pyrohip_mg *, int, int, int, int, int, int, int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
@@ -42,6 +58,7 @@ namespace pyro {
 int comm_allreduce_min_device(pyrohip_ctx *, double *d)
 {
     if (g_peer_min > 0.0 && g_peer_min < *d) *d = g_peer_min;    // (device memory is host memory here)
+    if (g_min_fn) *d = g_min_fn(*d);
     return 0;
 }
 bool comm_can_overlap(const pyrohip_state *) { return true; }

@@ -13,7 +13,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-from pyro2_amd.decomp import HostStagedComm as GlooComm  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from host_comm import HostStagedComm as GlooComm  # noqa: E402
 
 
 def _worker(rank, world, port, case, out_dir):
@@ -45,6 +46,49 @@ def _worker(rank, world, port, case, out_dir):
         res = sl.state.download()
         np.savez(os.path.join(out_dir, f"sedov_{rank}.npz"), U=res, dts=np.array(dts),
                  rows=np.array([a, b]))
+    elif case == "evolve4":
+        # DEVICE-SIDE stepping of a decomposed run (pyrohip_comp_evolve: halo exchange, ghost
+        # fill, the all-reduced CFL minimum, dt policy and update back to back) with the
+        # library's communicator calls answered by callbacks over gloo (tests/emu/comm_emu.cpp).
+        # Off-centre blast: the ranks' own CFL minima differ from the first step on -- the bug of
+        # round 4 (first minimum of a call not all-reduced) was invisible with two symmetric ranks.
+        import ctypes as C
+        import torch
+        from pyro2_amd.decomp import RcclComm
+        from sedov_ic import sedov_ic
+        nx, ny = 64, 24
+        ic, meta, bcs = sedov_ic(nx, ny, r_init=0.08)
+        ic = np.roll(ic, -22, axis=0)       # (uniform ambient gas: the blast moved into rank 0's slab)
+        dec = SlabDecomp(nx, world, rank)
+        host = GlooComm(td)
+        holder = {}
+
+        @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+        def halo_cb(handle, lo, hi):
+            host.halo_exchange(holder["state"], lo, hi)
+            return 0
+
+        @C.CFUNCTYPE(C.c_double, C.c_double)
+        def min_cb(x):
+            return host.allreduce_min(x)
+
+        l = _lib.lib()
+        l.pyrohip_emu_set_comm.argtypes = [C.c_void_p, C.c_void_p]
+        l.pyrohip_emu_set_comm(C.cast(halo_cb, C.c_void_p), C.cast(min_cb, C.c_void_p))
+
+        class LibComm(RcclComm):      # "the communicator lives in the library"
+            pass
+        comm2 = LibComm(ctx, global_dt=True)
+        kw = dict(dx=meta[3], dy=meta[4], kernel_set=1 + (rank % 2), march_rows=5)
+        sl = SlabCompressible(ctx, dec, ny, bcs, kw, comm2)
+        holder["state"] = sl.state
+        a, b = dec.local_rows(4)
+        sl.state.upload(np.ascontiguousarray(ic[a:b]))
+        pol = DtPolicy(0.1)
+        dts = list(sl.evolve(pol, 0.8, 3)) + list(sl.evolve(pol, 0.8, 4))
+        np.savez(os.path.join(out_dir, f"evolve4_{rank}.npz"), U=sl.state.download(), dts=np.array(dts),
+                 rows=np.array([a, b]), t=np.array(pol.t))
+        l.pyrohip_emu_set_comm(None, None)
     elif case.startswith("hse"):
         # gravity with hse / ambient y boundaries (reference runs of comp_hse.npz)
         g = np.load(os.path.join(ROOT, "tests", "golden", "comp_hse.npz"), allow_pickle=False)
@@ -61,7 +105,8 @@ def _worker(rank, world, port, case, out_dir):
     elif case == "mg":
         # multigrid V-cycles with the levels above 64^2 split into x slabs and the rest
         # collapsed onto rank 0 (pyro2_amd/multigrid/slab.py)
-        from pyro2_amd.multigrid.slab import HostRowComm, SlabMG
+        from host_comm import HostRowComm
+        from pyro2_amd.multigrid.slab import SlabMG
         nx, ncyc = 256, 2
         x = (np.arange(nx + 2) - 0.5) / nx
         X, Y = np.meshgrid(x, x, indexing="ij")
@@ -83,7 +128,8 @@ def _worker(rank, world, port, case, out_dir):
         # MG.CellCenterMG2d.solve() with the decomposition installed for every solver object
         # made from here on (what a caller like the diffusion solver would get)
         from pyro2_amd.multigrid import MG
-        from pyro2_amd.multigrid.slab import HostRowComm, SlabMG
+        from host_comm import HostRowComm
+        from pyro2_amd.multigrid.slab import SlabMG
         SlabMG.set_decomposition(HostRowComm(td, rank, world), rank, world, collapse_n=64)
         nx = 256
         a = MG.CellCenterMG2d(nx, nx, verbose=0, ctx=ctx)
@@ -177,6 +223,28 @@ def test_two_rank_sedov_bit_identical(tmp_path):
         a, b = z["rows"]
         assert np.array_equal(z["dts"], dto)
         assert np.array_equal(z["U"][4:-4, 4:-4], Uo[a + 4:b - 4, 4:-4]), r
+
+
+def test_four_rank_device_side_stepping_off_centre_blast(tmp_path):
+    """FOUR gloo processes, each stepping its slab through
+    pyrohip_comp_evolve (the library's halo exchange / CFL all-reduce answered over gloo), an
+    off-centre blast, two calls (3 + 4 steps: the first minimum of EACH call must be the global
+    one): dt sequence and state bit-identical to the single-domain oracle on every rank"""
+    from helpers import oracle_comp_run
+    from sedov_ic import sedov_ic
+    _spawn("evolve4", tmp_path, world=4)
+    ic, meta, bcs = sedov_ic(64, 24, r_init=0.08)
+    ic = np.roll(ic, -22, axis=0)
+    Uo, dto, to = oracle_comp_run(ic, meta, bcs, 0.1, 7)
+    mins = []
+    for r in range(4):
+        z = np.load(tmp_path / f"evolve4_{r}.npz")
+        a, b = z["rows"]
+        assert np.array_equal(z["dts"], dto), (r, z["dts"], dto)
+        assert float(z["t"]) == to
+        assert np.array_equal(z["U"][4:-4, 4:-4], Uo[a + 4:b - 4, 4:-4]), r
+        mins.append(float(np.abs(z["U"][4:-4, 4:-4, 2]).max()))
+    assert mins[0] > 1e-3 and mins[3] == 0.0     # the blast sits in rank 0's slab: the far slab is still at rest
 
 
 @pytest.mark.parametrize("k", [1, 3])
