@@ -530,6 +530,18 @@ int pyrohip_swe_step(pyrohip_state *s, double dx, double dy, double grav,
    (= 1; what pyrohip_swe_step runs) */
 int pyrohip_swe_step_ks(pyrohip_state *s, double dx, double dy, double grav, int limiter,
                         int riemann, double dt, int kernel_set);
+/* ... and the arithmetic (one-launch kernel): fast_math 0 the reference's operation order
+   (bit-identical to the staged set), 1 contracted, reciprocal-based quotients, the
+   characteristic sums without their structural zeros: <= 1e-10 element-wise of the former     */
+int pyrohip_swe_step_ex(pyrohip_state *s, double dx, double dy, double grav, int limiter,
+                        int riemann, double dt, int kernel_set, int fast_math);
+/* up to max_steps iterations of the swe driver loop (pyro_sim.py:241-281 with swe/simulation.py:
+   143-193) without a host round trip per step, as pyrohip_comp_evolve: ghost fill, the driver's
+   dt policy in a kernel on the CFL minimum the previous step's kernel left, the one-launch step.
+   Single Cartesian domain, standard boundary types.                                          */
+int pyrohip_swe_evolve(pyrohip_state *s, double dx, double dy, double grav, int limiter,
+                       int riemann, int fast_math, double cfl, pyrohip_dt_policy *policy,
+                       int max_steps, int *steps_done, double *dts_out);
 /* test hook: 0-3 U_xl U_xr U_yl U_yr before the transverse terms, 4 FxT 5 FyT
    (transverse fluxes), 6 Fx 7 Fy -> host (qx, qy, 4)                        */
 int pyrohip_swe_stage_dump(pyrohip_state *s, int stage, double *out);

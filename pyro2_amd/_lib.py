@@ -116,6 +116,10 @@ _PROTOS = {
     "pyrohip_swe_dt": [_VP, C.c_double, C.c_double, C.c_double, C.c_double, _DP],
     "pyrohip_swe_step": [_VP, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double],
     "pyrohip_swe_step_ks": [_VP, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int],
+    "pyrohip_swe_step_ex": [_VP, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int,
+                            C.c_int],
+    "pyrohip_swe_evolve": [_VP, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double,
+                           C.POINTER(DtPolicyC), C.c_int, C.POINTER(C.c_int), _DP],
     "pyrohip_swe_stage_dump": [_VP, C.c_int, _DP],
     "pyrohip_bg_step": [_VP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int],
     "pyrohip_inc_mac_rhs": [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,

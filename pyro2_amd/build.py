@@ -46,7 +46,8 @@ UNITS = [
     ("mg_march.hip", "mg_march_t1", ["-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=200000", "-DMGM_UNIT=1"]),
     ("mg_march.hip", "mg_march_t2", ["-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=200000", "-DMGM_UNIT=2"]),
     ("incompressible.hip", "incompressible", ["-ffp-contract=off"]),
-    ("swe.hip", "swe", ["-ffp-contract=off"]),
+    ("swe.hip", "swe", ["-ffp-contract=off", "-DPYRO_FAST=0"]),
+    ("swe.hip", "swe_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1"]),
     ("comm.hip", "comm", ["-ffp-contract=off"]),
 ]
 

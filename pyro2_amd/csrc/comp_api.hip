@@ -226,6 +226,33 @@ __global__ __launch_bounds__(kPolicyThreads) void k_dt_policy(StepScalars *S, co
     pyro::dt_policy_apply(S, cmin_s, (*flag & flag_mask) != 0, dts, slot, final_call);
 }
 
+namespace pyro {
+// the small launches of a device-side run, for the other solvers' stepping loops (swe.hip)
+int launch_fill_frame2(pyrohip_state *s, bool *done)
+{
+    *done = false;
+    if (!frame_fill_ok(s)) return pyrohip_fill_bc(s, -1);
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    const int rows_per_block = 256 / (2 * g.ng);
+    const int nblk = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + rows_per_block - 1) / rows_per_block;
+    PYRO_LAUNCH(c, "k_fill_frame2", k_fill_frame2, dim3(nblk), dim3(256), 0, (const double *)s->d, s->d,
+                s->alt_base + geom_lead(g), g, (const int *)s->d_bc);
+    PYRO_CHECK_HIP(hipGetLastError());
+    *done = true;
+    return 0;
+}
+
+int launch_dt_policy(pyrohip_ctx *c, StepScalars *S, const double *cflmin, const int *flag, double *dts,
+                     int slot, int final_call, const double *part, int nparts, double *minout)
+{
+    PYRO_LAUNCH(c, "k_dt_policy", k_dt_policy, dim3(1), dim3(kPolicyThreads), 0, S, cflmin, flag, dts, slot,
+                final_call, part, nparts, minout, 1);
+    PYRO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+}  // namespace pyro
+
 extern "C" {
 
 int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double cfl,

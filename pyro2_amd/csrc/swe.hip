@@ -10,12 +10,27 @@
 // State: 4 planes height, x-momentum, y-momentum, fuel (= h X); primitive
 // h, u, v, X.  Compiled with -ffp-contract=off and the reference's operation
 // order (4-term in-order dot products included): bit-identical to the oracle.
+//
+// Compiled twice (build.py): PYRO_FAST=0 -- the above, with every entry point -- and PYRO_FAST=1
+// (-ffp-contract=fast, unit swe_fast): the one-launch kernel again with reciprocal / rsq based
+// quotients and roots and the characteristic sums written out without their structural zeros
+// (sw_trace, sw_roe: the reference's dense 4 x 4 loops multiply by 0 and 1 a hundred times per
+// cell), held to 1e-10 element-wise against the bit-faithful build (gpu.fast_math = 1).
+#ifndef PYRO_FAST
+#define PYRO_FAST 0
+#endif
+#if PYRO_FAST
+#define PYRO_SWNS swf
+#else
+#define PYRO_SWNS swx
+#endif
 #include "common.h"
 #include "hydro.h"     // pdiv / psqrt: the IEEE quotient / root without the expansion's scaling (bit-identical)
 #include "reduce.h"
 #include "stencil.h"
 
 namespace pyro {
+namespace PYRO_SWNS {
 
 struct SW {   // kernel parameters
     double dx, dy, dt, g;
@@ -69,6 +84,36 @@ __device__ __forceinline__ V4 sw_cons_flux(const V4 &U, double g, bool x)
 // characteristic tracing of one cell in one direction, interface.py:5-213:
 // primitive states on the cell's lower face (q_r[face]) and upper face
 // (q_l[face+1])
+#if PYRO_FAST
+// the same sums without the terms that are structurally zero: l_0 . dq = (dq_h / h - dq_n / c) / 2,
+// l_2 . dq = -(dq_h / h + dq_n / c) / 2 (sic: the reference's sign), l_1 . dq = dq_t, l_3 . dq = dq_X;
+// beta_l of wave 2 and beta_r of wave 0 vanish (e_2 - e_2, e_0 - e_0); r_0 = (h, -c), r_2 = (h, c)
+__device__ __forceinline__ void sw_trace(const double q[4], const double dq[4], double g,
+                                         double dtdx, bool x, double lo[4], double hi[4])
+{
+    const int in = x ? 1 : 2, it = x ? 2 : 1;
+    double rcs;
+    const double cs = psqrt_r(g * q[0], rcs);
+    const double dtdx3 = 0.33333 * dtdx;   // sic, interface.py:100
+    const double un = q[in];
+    const double e0 = un - cs, e2 = un + cs;
+    const double a = 0.5 * dq[0] * prcp(q[0]), b = 0.5 * dq[in] * rcs;
+    const double as0 = a - b, as2 = -(a + b);
+    const double fhi = 0.5 * (1.0 - dtdx * fmax(e2, 0.0)), flo = 0.5 * (1.0 + dtdx * fmin(e0, 0.0));
+#pragma unroll
+    for (int m = 0; m < 4; m++) { hi[m] = q[m] + fhi * dq[m]; lo[m] = q[m] - flo * dq[m]; }
+    // (sign(e) + 1) is 2 for e >= +0, 0 below; (1 - sign(e)) the other way round
+    const double pl0 = (e0 >= 0.0 && !(e0 == 0.0 && __builtin_signbit(e0))) ? 2.0 : 0.0;
+    const double pl1 = (un >= 0.0 && !(un == 0.0 && __builtin_signbit(un))) ? 2.0 : 0.0;
+    const double pl2 = (e2 >= 0.0 && !(e2 == 0.0 && __builtin_signbit(e2))) ? 2.0 : 0.0;
+    const double bl0 = dtdx3 * (e2 - e0) * pl0 * as0;            // wave 0 seen from the upper face
+    const double bl1 = dtdx3 * cs * pl1;                        // waves 1, 3: (e_2 - u) = c, times dq_t / dq_X
+    const double br2 = dtdx3 * (e0 - e2) * (2.0 - pl2) * as2;    // wave 2 seen from the lower face
+    const double br1 = -dtdx3 * cs * (2.0 - pl1);
+    hi[0] += bl0 * q[0]; hi[in] -= bl0 * cs; hi[it] += bl1 * dq[it]; hi[3] += bl1 * dq[3];
+    lo[0] += br2 * q[0]; lo[in] += br2 * cs; lo[it] += br1 * dq[it]; lo[3] += br1 * dq[3];
+}
+#else
 __device__ __forceinline__ void sw_trace(const double q[4], const double dq[4], double g,
                                          double dtdx, bool x, double lo[4], double hi[4])
 {
@@ -115,6 +160,7 @@ __device__ __forceinline__ void sw_trace(const double q[4], const double dq[4], 
         lo[m] = lo[m] + sum_r;
     }
 }
+#endif
 
 // interface.py:216-385
 __device__ __forceinline__ V4 sw_roe(const V4 &Ul, const V4 &Ur, double g, bool x)
@@ -155,10 +201,21 @@ __device__ __forceinline__ V4 sw_roe(const V4 &Ul, const V4 &Ur, double g, bool 
         lambda[0] = pdiv(lambda[0] * (u_star - c_star - lambda[0]), u_star - c_star - (un_l - c_l));
     if (fabs(lambda[2]) < tol)
         lambda[2] = pdiv(lambda[2] * (u_star + c_star - lambda[2]), u_star + c_star - (un_r + c_r));
+#if PYRO_FAST
+    {   // K_0 = (1, u - c, u_t), K_1 = e_t, K_2 = (1, u + c, u_t), K_3 = e_X: the non-zero terms only
+        const double w0 = 0.5 * alpha[0] * fabs(lambda[0]), w1 = 0.5 * alpha[1] * fabs(lambda[1]);
+        const double w2 = 0.5 * alpha[2] * fabs(lambda[2]), w3 = 0.5 * alpha[3] * fabs(lambda[3]);
+        F.a[0] -= w0 + w2;
+        F.a[im] -= w0 * (un_roe - c_roe) + w2 * (un_roe + c_roe);
+        F.a[it] -= (w0 + w2) * U_roe[it] + w1;
+        F.a[3] -= w3;
+    }
+#else
 #pragma unroll
     for (int n = 0; n < 4; n++)
 #pragma unroll
         for (int m = 0; m < 4; m++) F.a[n] -= 0.5 * alpha[m] * fabs(lambda[m]) * K[m][n];
+#endif
     return F;
 }
 
@@ -206,6 +263,7 @@ __device__ __forceinline__ V4 sw_riemann(const V4 &Ul, const V4 &Ur, const SW &P
     return P.riemann == 1 ? sw_hllc(Ul, Ur, P.g, x) : sw_roe(Ul, Ur, P.g, x);
 }
 
+#if !PYRO_FAST     // the staged kernels (every stage dumpable) exist in the bit-faithful unit only
 // ---- stage 0: primitives over the whole array (simulation.py:48-63) ------
 __global__ __launch_bounds__(256) void k_sw_prim(const double *__restrict__ U,
                                                  double *__restrict__ W, Geom g)
@@ -267,6 +325,7 @@ __global__ __launch_bounds__(256) void k_sw_riemann_t(double *__restrict__ W, Ge
                        P, false));
 }
 
+#endif   // !PYRO_FAST
 __device__ __forceinline__ V4 sw_corrected(const V4 &U, const V4 &Fhi, const V4 &Flo, double c)
 {
     // U += -0.5*dtdy*(F_hi - F_lo), unsplit_fluxes.py:336-352 (c = 0.5*dt/d)
@@ -275,6 +334,7 @@ __device__ __forceinline__ V4 sw_corrected(const V4 &U, const V4 &Fhi, const V4 
     for (int n = 0; n < 4; n++) r.a[n] = U.a[n] + (-c * (Fhi.a[n] - Flo.a[n]));
     return r;
 }
+#if !PYRO_FAST
 
 // ---- stage 3: transverse correction + final Riemann problems --------------
 // thread (i,j) in [ilo, ihi+1] x [jlo, jhi+1]
@@ -336,6 +396,8 @@ __global__ __launch_bounds__(256) void k_sw_cfl(const double *__restrict__ U, Ge
     if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = m;
 }
 
+#endif   // !PYRO_FAST
+
 // ---- the whole step in ONE launch: row-marching wavefronts (like comp_wave.hip) ------------
 // One wavefront = 64 columns (lane = column, 58 updated: a cell's update reaches three columns
 // either way), marching down a chunk of rows.  Row k arrives (load, primitives); the rows'
@@ -386,14 +448,28 @@ __device__ __forceinline__ V4 sww_riemann(const V4 &Ul, const V4 &Ur, double g, 
     return RS == 1 ? sw_hllc(Ul, Ur, g, x) : sw_roe(Ul, Ur, g, x);
 }
 
+// S (device-side stepping, pyrohip_swe_evolve): this step's dt from the step scalars the policy
+// kernel left; partial: the wavefront's minimum of dx / (|u| + c), dy / (|v| + c) over the cells it
+// updated (swe/simulation.py:143-153 on the new state: the next step's CFL minimum without a
+// pass of its own -- 98 us of a 1.2 ms step at 4096^2)
 template <int RS>   // swe.riemann: 0 Roe, 1 HLLC
 __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Uin,
-                                                   double *__restrict__ Uout, Geom g, SWW P)
+                                                   double *__restrict__ Uout, Geom g, SWW P,
+                                                   const StepScalars *__restrict__ S,
+                                                   double *__restrict__ partial)
 {
     const int l = threadIdx.x & 63;
     const int per = (P.nunits + 7) / 8;                     // XCD x: the units [x per, (x + 1) per)
     const int unit = pyro_uniform(((int)blockIdx.x % 8) * per + (int)blockIdx.x / 8);
     if (unit >= P.nunits) return;
+    if (S) {
+        if (!S->active) {      // past tmax: nothing happens
+            if (l == 0 && partial) partial[unit] = INFINITY;
+            return;
+        }
+        P.dt = S->dt;
+    }
+    double amax = 0.0, bmax = 0.0;      // running maxima of |u| + c, |v| + c over the cells updated
     const int cb = pyro_uniform(unit % P.ncb), sb = pyro_uniform(unit / P.ncb);
     const int i0 = g.ilo + sb * P.L;                        // rows [i0, i1)
     const int i1 = (i0 + P.L < g.ihi + 1) ? i0 + P.L : g.ihi + 1;
@@ -482,15 +558,29 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
                 const V4 Fxm = get(S_FX);
                 if (jout) {
                     const size_t ko = (size_t)(c - 1) * p + j;
+                    V4 Un;
 #pragma unroll
-                    for (int n = 0; n < 4; n++)
-                        Uout[(size_t)n * pl + ko] =
-                            Uold.a[n] + (dtdx * (Fxm.a[n] - Fx.a[n]) + dtdy * (Fy.a[n] - Fy_p.a[n]));
+                    for (int n = 0; n < 4; n++) {
+                        Un.a[n] = Uold.a[n] + (dtdx * (Fxm.a[n] - Fx.a[n]) + dtdy * (Fy.a[n] - Fy_p.a[n]));
+                        Uout[(size_t)n * pl + ko] = Un.a[n];
+                    }
+                    if (partial) {     // k_sw_cfl's quantities: one division per direction at the end
+                        const double u = pdiv(Un.a[1], Un.a[0]), v = pdiv(Un.a[2], Un.a[0]);
+                        const double cs = psqrt(P.g * Un.a[0]);
+                        amax = fmax(amax, fabs(u) + cs);
+                        bmax = fmax(bmax, fabs(v) + cs);
+                    }
                 }
             }
             put(S_FX, Fx);
         }
         put(S_XP, XP); put(S_YP, YP); put(S_YM, YM); put(S_FXT, FXT); put(S_FYT, FYT);
+    }
+    if (partial) {
+        // min over cells of dx / a = dx / max a (the correctly rounded quotient is monotone)
+        const double m = fmin(amax > 0.0 ? pdiv(P.dx, amax) : INFINITY, bmax > 0.0 ? pdiv(P.dy, bmax) : INFINITY);
+        const double wm = wave_reduce_min(m);
+        if (l == 0) partial[unit] = wm;
     }
 }
 
@@ -541,6 +631,63 @@ __global__ __launch_bounds__(256) void k_sw_copy_frame(const double *__restrict_
     for (int n = 0; n < 4; n++) dst[(size_t)n * g.plane + k] = src[(size_t)n * g.plane + k];
 }
 
+// one step by the one-launch kernel: new time level into the second buffer, ghost frame carried
+// over (unless the caller has filled both frames: frame_done), buffers swapped.  S / part: see
+// k_sw_wave; *nparts = wavefronts of the launch
+int swe_step_wave(pyrohip_state *s, double dx, double dy, double grav, int limiter, int riemann,
+                  double dt, const StepScalars *S, double *part, int *nparts, bool frame_done)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    if (!s->alt_base) {
+        const size_t n = (size_t)s->nvar * g.plane + 16;
+        PYRO_CHECK_HIP(hipMalloc((void **)&s->alt_base, n * sizeof(double)));
+        PYRO_CHECK_HIP(hipMemsetAsync(s->alt_base, 0, n * sizeof(double), c->stream));
+    }
+    SWW P{dx, dy, dt, grav, limiter, 0, 0, 0};
+    P.ncb = (g.ny + SWW_OUT - 1) / SWW_OUT;
+    P.L = sww_rows(g.nx, P.ncb, c->num_cus > 0 ? c->num_cus : 256);
+    P.nunits = P.ncb * ((g.nx + P.L - 1) / P.L);
+    if (nparts) *nparts = P.nunits;
+    double *Uout = s->alt_base + geom_lead(g);
+    const dim3 grid(8 * ((P.nunits + 7) / 8)), block(64);
+    if (riemann == 1)
+        PYRO_LAUNCH(c, "k_sw_wave", k_sw_wave<1>, grid, block, 0, (const double *)s->d, Uout, g, P, S, part);
+    else
+        PYRO_LAUNCH(c, "k_sw_wave", k_sw_wave<0>, grid, block, 0, (const double *)s->d, Uout, g, P, S, part);
+    if (!frame_done) {
+        // the ghost frame is carried over (the reference updates the interior in place)
+        const int fb = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + 256 / (2 * g.ng) - 1) / (256 / (2 * g.ng));
+        hipLaunchKernelGGL(k_sw_copy_frame, dim3(fb), dim3(256), 0, c->stream, (const double *)s->d, Uout, g);
+    }
+    PYRO_CHECK_HIP(hipGetLastError());
+    double *old_base = s->base;       // the buffers change places
+    s->base = s->alt_base;
+    s->alt_base = old_base;
+    s->d = s->base + geom_lead(g);
+    s->next_cfl_min = -1.0;
+    s->ghost_by_rules = false;
+    s->stages_valid = false;       // the one-launch kernel keeps no stage planes
+    return 0;
+}
+
+}  // namespace PYRO_SWNS
+#if !PYRO_FAST
+namespace swf {    // the contracted unit (swe_fast)
+int swe_step_wave(pyrohip_state *, double, double, double, int, int, double, const StepScalars *, double *,
+                  int *, bool);
+}
+// (comp_api.hip: the small launches of a device-side run)
+int launch_fill_frame2(pyrohip_state *s, bool *done);
+int launch_dt_policy(pyrohip_ctx *c, StepScalars *S, const double *cflmin, const int *flag, double *dts,
+                     int slot, int final_call, const double *part, int nparts, double *minout);
+#endif
+}  // namespace pyro
+
+#if !PYRO_FAST
+using namespace pyro;
+using namespace pyro::swx;
+
 static int sw_work(pyrohip_state *s)
 {
     if (s->work_planes >= (size_t)SW_NPL) return 0;
@@ -553,10 +700,6 @@ static int sw_work(pyrohip_state *s)
     return 0;
 }
 
-}  // namespace pyro
-
-using namespace pyro;
-
 static int sw_check(pyrohip_state *s, double dx, double dy, double grav, int limiter, int riemann)
 {
     PYRO_REQUIRE(s, "NULL state");
@@ -568,6 +711,22 @@ static int sw_check(pyrohip_state *s, double dx, double dy, double grav, int lim
     return 0;
 }
 
+// the CFL minimum of the state left in device memory (-> *dmin)
+static int sw_cfl_min_device(pyrohip_state *s, double dx, double dy, double grav, const double **dmin)
+{
+    pyrohip_ctx *c = s->ctx;
+    const dim3 grid(8, 128), block(256);
+    const int nb = grid.x * grid.y;
+    // (behind the partials of the step kernel, which use the front of the same buffer)
+    PYRO_TRY(c->reduce.ensure((size_t)(65536 + 2 * nb + kMinStageBlocks + 2) * sizeof(double)));
+    double *part = (double *)c->reduce.p + 65536;
+    hipLaunchKernelGGL(k_sw_cfl, grid, block, 0, c->stream, (const double *)s->d, s->g, grav, dx, dy,
+                       part);
+    *dmin = launch_min_reduce(c->stream, part, nb);
+    PYRO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" {
 
 int pyrohip_swe_dt(pyrohip_state *s, double dx, double dy, double grav, double cfl, double *dt_out)
@@ -575,14 +734,8 @@ int pyrohip_swe_dt(pyrohip_state *s, double dx, double dy, double grav, double c
     PYRO_TRY(sw_check(s, dx, dy, grav, 0, 0));
     PYRO_REQUIRE(dt_out, "dt_out is NULL");
     pyrohip_ctx *c = s->ctx;
-    const dim3 grid(8, 128), block(256);
-    const int nb = grid.x * grid.y;
-    PYRO_TRY(c->reduce.ensure((nb + kMinStageBlocks + 2) * sizeof(double)));
-    double *part = (double *)c->reduce.p;
-    hipLaunchKernelGGL(k_sw_cfl, grid, block, 0, c->stream, (const double *)s->d, s->g, grav, dx, dy,
-                       part);
-    const double *dmin = launch_min_reduce(c->stream, part, nb);
-    PYRO_CHECK_HIP(hipGetLastError());
+    const double *dmin;
+    PYRO_TRY(sw_cfl_min_device(s, dx, dy, grav, &dmin));
     PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, dmin, sizeof(double), hipMemcpyDeviceToHost,
                                   c->stream));
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
@@ -591,45 +744,19 @@ int pyrohip_swe_dt(pyrohip_state *s, double dx, double dy, double grav, double c
 }
 
 // kernel_set: 0 the staged kernels (every stage dumpable: pyrohip_swe_stage_dump), 1 the whole
-// step in one launch (k_sw_wave), -1 the library's choice (1)
-int pyrohip_swe_step_ks(pyrohip_state *s, double dx, double dy, double grav, int limiter, int riemann,
-                        double dt, int kernel_set)
+// step in one launch (k_sw_wave), -1 the library's choice (1).  fast_math (one-launch kernel
+// only): 1 the contracted build (1e-10 element-wise of the bit-faithful one), 0 bit-faithful
+int pyrohip_swe_step_ex(pyrohip_state *s, double dx, double dy, double grav, int limiter, int riemann,
+                        double dt, int kernel_set, int fast_math)
 {
     PYRO_TRY(sw_check(s, dx, dy, grav, limiter, riemann));
     PYRO_REQUIRE(dt > 0.0, "dt must be positive");
     PYRO_REQUIRE(kernel_set >= -1 && kernel_set <= 1, "kernel_set must be -1, 0 or 1");
     pyrohip_ctx *c = s->ctx;
     const Geom &g = s->g;
-    if (kernel_set != 0) {
-        if (!s->alt_base) {
-            const size_t n = (size_t)s->nvar * g.plane + 16;
-            PYRO_CHECK_HIP(hipMalloc((void **)&s->alt_base, n * sizeof(double)));
-            PYRO_CHECK_HIP(hipMemsetAsync(s->alt_base, 0, n * sizeof(double), c->stream));
-        }
-        SWW P{dx, dy, dt, grav, limiter, 0, 0, 0};
-        P.ncb = (g.ny + SWW_OUT - 1) / SWW_OUT;
-        P.L = sww_rows(g.nx, P.ncb, c->num_cus > 0 ? c->num_cus : 256);
-        P.nunits = P.ncb * ((g.nx + P.L - 1) / P.L);
-        double *Uout = s->alt_base + geom_lead(g);
-        const dim3 grid(8 * ((P.nunits + 7) / 8)), block(64);
-        if (riemann == 1)
-            PYRO_LAUNCH(c, "k_sw_wave", k_sw_wave<1>, grid, block, 0, (const double *)s->d, Uout, g, P);
-        else
-            PYRO_LAUNCH(c, "k_sw_wave", k_sw_wave<0>, grid, block, 0, (const double *)s->d, Uout, g, P);
-        // the ghost frame is carried over (the reference updates the interior in place), then
-        // the buffers change places
-        const int fb = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + 256 / (2 * g.ng) - 1) / (256 / (2 * g.ng));
-        hipLaunchKernelGGL(k_sw_copy_frame, dim3(fb), dim3(256), 0, c->stream, (const double *)s->d, Uout, g);
-        PYRO_CHECK_HIP(hipGetLastError());
-        double *old_base = s->base;
-        s->base = s->alt_base;
-        s->alt_base = old_base;
-        s->d = s->base + geom_lead(g);
-        s->next_cfl_min = -1.0;
-        s->ghost_by_rules = false;
-        s->stages_valid = false;       // the one-launch kernel keeps no stage planes
-        return 0;
-    }
+    if (kernel_set != 0)
+        return fast_math ? swf::swe_step_wave(s, dx, dy, grav, limiter, riemann, dt, nullptr, nullptr, nullptr, false)
+                         : swx::swe_step_wave(s, dx, dy, grav, limiter, riemann, dt, nullptr, nullptr, nullptr, false);
     PYRO_TRY(sw_work(s));
     const SW P{dx, dy, dt, grav, limiter, riemann};
     double *W = s->work + geom_lead(g);
@@ -648,10 +775,101 @@ int pyrohip_swe_step_ks(pyrohip_state *s, double dx, double dy, double grav, int
     return 0;
 }
 
+int pyrohip_swe_step_ks(pyrohip_state *s, double dx, double dy, double grav, int limiter, int riemann,
+                        double dt, int kernel_set)
+{
+    return pyrohip_swe_step_ex(s, dx, dy, grav, limiter, riemann, dt, kernel_set, 0);
+}
+
 int pyrohip_swe_step(pyrohip_state *s, double dx, double dy, double grav, int limiter, int riemann,
                      double dt)
 {
-    return pyrohip_swe_step_ks(s, dx, dy, grav, limiter, riemann, dt, -1);
+    return pyrohip_swe_step_ex(s, dx, dy, grav, limiter, riemann, dt, -1, 0);
+}
+
+// Up to max_steps iterations of the swe driver loop (pyro_sim.py:241-281 with swe/simulation.py:
+// 143-193: ghost fill, CFL time step, evolve) without a host round trip per step -- as
+// pyrohip_comp_evolve: the ghost fill (both buffers' frames in one launch where the boundaries
+// are outflow / reflect / periodic), the driver's dt policy in a kernel on the CFL minimum the
+// previous step's wavefronts left, the one-launch step kernel.  One synchronisation at the end.
+int pyrohip_swe_evolve(pyrohip_state *s, double dx, double dy, double grav, int limiter, int riemann,
+                       int fast_math, double cfl, pyrohip_dt_policy *pol, int max_steps,
+                       int *steps_done, double *dts_out)
+{
+    PYRO_TRY(sw_check(s, dx, dy, grav, limiter, riemann));
+    PYRO_REQUIRE(pol && steps_done && max_steps >= 1, "NULL argument / max_steps must be positive");
+    PYRO_REQUIRE(!s->nb_set && !s->user_bc && !s->ramp_bc && !s->sph,
+                 "device-side stepping: swe runs on a single Cartesian domain with the standard boundary types");
+    pyrohip_ctx *c = s->ctx;
+    if (!s->d_scal) PYRO_CHECK_HIP(hipMalloc((void **)&s->d_scal, sizeof(StepScalars)));
+    if (!s->d_flag) {
+        PYRO_CHECK_HIP(hipMalloc((void **)&s->d_flag, sizeof(int)));
+    }
+    if (s->dts_cap < max_steps + 1) {
+        if (s->d_dts) PYRO_CHECK_HIP(hipFree(s->d_dts));
+        s->d_dts = nullptr;
+        PYRO_CHECK_HIP(hipMalloc((void **)&s->d_dts, (size_t)(max_steps + 1) * sizeof(double)));
+        s->dts_cap = max_steps + 1;
+    }
+    if (!s->alt_base) {     // (k_fill_frame2 writes the second buffer's frame)
+        const size_t n = (size_t)s->nvar * s->g.plane + 16;
+        PYRO_CHECK_HIP(hipMalloc((void **)&s->alt_base, n * sizeof(double)));
+        PYRO_CHECK_HIP(hipMemsetAsync(s->alt_base, 0, n * sizeof(double), c->stream));
+    }
+    StepScalars H;
+    memset(&H, 0, sizeof(H));
+    H.t = pol->t; H.dt_old = pol->dt_old; H.n = pol->n;
+    H.tmax = pol->tmax; H.f0 = pol->init_tstep_factor; H.mx = pol->max_dt_change;
+    H.fix_dt = pol->fix_dt; H.cfl = cfl; H.dx = dx; H.dy = dy;
+    PYRO_CHECK_HIP(hipMemcpyAsync(s->d_scal, &H, sizeof(H), hipMemcpyHostToDevice, c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));      // H is on this stack frame
+    PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
+    PYRO_TRY(c->reduce.ensure((size_t)(65536 + 2 * 1024 + kMinStageBlocks + 2) * sizeof(double)));
+    double *part = (double *)c->reduce.p;
+    const double *dmin = nullptr;
+    const double *pend = nullptr;
+    int npend = 0, rc = 0;
+    for (int m = 0; m < max_steps && rc == 0; m++) {
+        bool frame_done = false;
+        rc = launch_fill_frame2(s, &frame_done);          // pyro_sim.py:250: fill_BC_all
+        if (rc) break;
+        if (m == 0) {      // the CFL minimum of the state as handed over (whole array, filled)
+            rc = sw_cfl_min_device(s, dx, dy, grav, &dmin);
+            if (rc) break;
+        }
+        // (later steps: the policy kernel takes the minimum of the step kernel's partials itself)
+        rc = launch_dt_policy(c, s->d_scal, dmin, s->d_flag, s->d_dts, m, 0, pend, npend,
+                              const_cast<double *>(dmin));
+        if (rc) break;
+        int np = 0;
+        rc = fast_math ? swf::swe_step_wave(s, dx, dy, grav, limiter, riemann, 0.0, s->d_scal, part, &np, frame_done)
+                       : swx::swe_step_wave(s, dx, dy, grav, limiter, riemann, 0.0, s->d_scal, part, &np, frame_done);
+        pend = part; npend = np;
+    }
+    PYRO_TRY(rc);
+    PYRO_TRY(launch_dt_policy(c, s->d_scal, dmin, s->d_flag, s->d_dts, max_steps, 1, pend, npend,
+                              const_cast<double *>(dmin)));
+    char *hb = (char *)c->reduce_host;                       // 256 pinned bytes
+    PYRO_CHECK_HIP(hipMemcpyAsync(hb, s->d_scal, sizeof(StepScalars), hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipMemcpyAsync(hb + sizeof(StepScalars) + 8, dmin, sizeof(double),
+                                  hipMemcpyDeviceToHost, c->stream));
+    if (dts_out)
+        PYRO_CHECK_HIP(hipMemcpyAsync(dts_out, s->d_dts, (size_t)max_steps * sizeof(double),
+                                      hipMemcpyDeviceToHost, c->stream));
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    memcpy(&H, hb, sizeof(H));
+    // max_steps swaps were made; the last state that advanced sits H.steps swaps from the start
+    if ((max_steps - H.steps) % 2) {
+        double *old_base = s->base;
+        s->base = s->alt_base;
+        s->alt_base = old_base;
+        s->d = s->base + geom_lead(s->g);
+    }
+    s->next_cfl_min = -1.0;
+    s->ghost_by_rules = false;
+    pol->t = H.t; pol->dt_old = H.dt_old; pol->n = H.n;
+    *steps_done = H.steps;
+    return 0;
 }
 
 // stage: 0 Uxl0 1 Uxr0 2 Uyl0 3 Uyr0 (face states before the transverse
@@ -687,3 +905,4 @@ int pyrohip_swe_stage_dump(pyrohip_state *s, int stage, double *out)
 }
 
 }  // extern "C"
+#endif   // !PYRO_FAST

@@ -250,12 +250,30 @@ class DeviceState:
                                          C.byref(out)))
         return out.value
 
-    def swe_step(self, dx, dy, grav, limiter, riemann, dt, kernel_set=-1):
-        """kernel_set: 0 staged kernels (swe_stage() dumps), 1 one launch per step (default)"""
+    def swe_step(self, dx, dy, grav, limiter, riemann, dt, kernel_set=-1, fast_math=0):
+        """kernel_set: 0 staged kernels (swe_stage() dumps), 1 one launch per step (default);
+        fast_math (one-launch kernel): 1 the contracted build, 0 bit-faithful"""
         r = self.SWE_RIEMANN[riemann] if isinstance(riemann, str) else int(riemann)
         with self.ctx.lock:
-            check(self._l.pyrohip_swe_step_ks(self.h, float(dx), float(dy), float(grav), int(limiter),
-                                              r, float(dt), int(kernel_set)))
+            check(self._l.pyrohip_swe_step_ex(self.h, float(dx), float(dy), float(grav), int(limiter),
+                                              r, float(dt), int(kernel_set), int(fast_math)))
+
+    def swe_evolve(self, dx, dy, grav, limiter, riemann, cfl, policy, max_steps, fast_math=0):
+        """up to max_steps swe steps with the driver's dt policy on the device (as comp_evolve);
+        returns the dt of the steps taken"""
+        from ._lib import DtPolicyC
+        r = self.SWE_RIEMANN[riemann] if isinstance(riemann, str) else int(riemann)
+        pc = DtPolicyC(policy.tmax, policy.f0, policy.mx, policy.fix, policy.t, policy.dt_old,
+                       policy.n)
+        done = C.c_int()
+        dts = np.empty(int(max_steps))
+        with self.ctx.lock:
+            rc = self._l.pyrohip_swe_evolve(self.h, float(dx), float(dy), float(grav), int(limiter), r,
+                                            int(fast_math), float(cfl), C.byref(pc), int(max_steps),
+                                            C.byref(done), dptr(dts))
+        policy.t, policy.dt_old, policy.n = pc.t, pc.dt_old, int(pc.n)
+        check(rc)
+        return dts[:done.value]
 
     def swe_stage(self, name):
         names = ("Uxl0", "Uxr0", "Uyl0", "Uyr0", "FxT", "FyT", "Fx", "Fy")

@@ -89,12 +89,57 @@ class Simulation(NullSimulation):
         cc, g = self.cc_data, self.cc_data.grid
         cc.device_state().swe_step(g.dx, g.dy, self.rp.get_param("swe.grav"),
                                    self.rp.get_param("swe.limiter"),
-                                   self.rp.get_param("swe.riemann"), self.dt)
+                                   self.rp.get_param("swe.riemann"), self.dt,
+                                   kernel_set=self._rp_opt("gpu.kernel_set", -1) if
+                                   self._rp_opt("gpu.kernel_set", -1) in (0, 1) else -1,
+                                   fast_math=self._fast_math())
         cc.device_modified()
         self.advance_particles()         # swe/simulation.py:198-199 (derived "velocity")
         cc.t += self.dt
         self.n += 1
         tm.end()
+
+    def _fast_math(self):
+        """gpu.fast_math (default 1: the contracted one-launch kernel, <= 1e-10 element-wise of the
+        bit-faithful one; 0: the reference's operation order)"""
+        return int(self._rp_opt("gpu.fast_math", 1))
+
+    def can_evolve_many(self):
+        """batches of steps on the device (pyrohip_swe_evolve): standard boundary types filled
+        by the device, nothing watching the data, no tracer particles, the plain evolve()"""
+        cc = self.cc_data
+        if self.particles is not None or cc._views_alive() or type(self).evolve is not Simulation.evolve:
+            return False
+        simple = ("outflow", "reflect-even", "reflect-odd", "periodic")
+        if not all(b in simple for n in cc.names for b in cc.BCs[n].sides()):
+            return False
+        if self._rp_opt("gpu.kernel_set", -1) == 0:
+            return False
+        return not any(cc._has_host_bc(n) for n in cc.names)
+
+    def evolve_many(self, nsteps):
+        from ..decomp import DtPolicy
+        rp = self.rp
+        pol = DtPolicy(self.tmax, rp.get_param("driver.init_tstep_factor"),
+                       rp.get_param("driver.max_dt_change"), rp.get_param("driver.fix_dt"))
+        pol.t, pol.n = float(self.cc_data.t), int(self.n)
+        pol.dt_old = float(getattr(self, "dt_old", -1.e33))
+        tm = self.tc.timer("evolve")
+        tm.begin()
+        cc, g = self.cc_data, self.cc_data.grid
+        st = cc.device_state()
+        cc.take_pending_fill()
+        try:
+            dts = st.swe_evolve(g.dx, g.dy, rp.get_param("swe.grav"), rp.get_param("swe.limiter"),
+                                rp.get_param("swe.riemann"), float(rp.get_param("driver.cfl")), pol,
+                                int(nsteps), fast_math=self._fast_math())
+        finally:
+            cc.device_modified()
+            cc.t, self.n, self.dt_old = pol.t, pol.n, pol.dt_old
+        if len(dts):
+            self.dt = float(dts[-1])
+        tm.end()
+        return dts
 
     def dovis(self):
         import matplotlib.pyplot as plt

@@ -51,6 +51,15 @@ def test_swe_4096_vs_oracle_lattice(hip, golden, riemann):
         del s
     assert np.array_equal(out[0], out[1])
     assert_lattice(out[0], g, 1e-12, what=f"swe {riemann}")
+    # the contracted build (gpu.fast_math = 1, what Pyro("swe") runs by default), stepped on the
+    # device in one call: <= 1e-10 element-wise
+    from helpers import DtPolicy as Pol
+    s = device.DeviceState(hip, nx, nx, NG, rows)
+    s.upload(ic)
+    pol = Pol(1.e30)
+    dts = s.swe_evolve(m[3], m[4], m[5], int(m[6]), riemann, m[7], pol, int(g["nsteps"]), fast_math=1)
+    assert np.abs(np.array(dts) / g["dts"] - 1).max() <= 1e-10
+    assert_lattice(s.download()[I], g, 1e-10, what=f"swe {riemann} fast")
 
 
 @pytest.mark.gpu

@@ -84,7 +84,8 @@ def test_pyro_swe_dam(api, golden):
     nsteps = 10 if api.kind == "hip" else 3
     p = Pyro("swe")
     p.initialize_problem("dam", inputs_file="inputs.dam.x",
-                         inputs_dict={"mesh.nx": 32, "mesh.ny": 8, "driver.max_steps": nsteps})
+                         inputs_dict={"mesh.nx": 32, "mesh.ny": 8, "driver.max_steps": nsteps,
+                                      "gpu.fast_math": 0})
     assert np.array_equal(np.asarray(p.sim.cc_data.data), g["c0_ic"])
     assert p.sim.cc_data.BCs["y-momentum"].ylb == "reflect-odd"
     dts = []
@@ -115,12 +116,14 @@ def test_swe_reference_regression_dam(hip, golden, tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     from pyro2_amd.pyro_sim import Pyro
     g = golden("swe_dam_x_0081")
-    p = Pyro("swe")
-    p.initialize_problem("dam", inputs_file="inputs.dam.x")
-    p.run_sim()
-    assert p.sim.n == 81
-    U = np.asarray(p.sim.cc_data.data)[4:-4, 4:-4]
-    assert np.abs(U - g["gold"]).max() < 1e-11
+    for fast, tol in ((0, 1e-11), (1, 1e-10)):
+        # (run_sim batches the steps on the device: pyrohip_swe_evolve; fast: the contracted build)
+        p = Pyro("swe")
+        p.initialize_problem("dam", inputs_file="inputs.dam.x", inputs_dict={"gpu.fast_math": fast})
+        p.run_sim()
+        assert p.sim.n == 81
+        U = np.asarray(p.sim.cc_data.data)[4:-4, 4:-4]
+        assert np.abs(U - g["gold"]).max() < tol, fast
 
 
 @pytest.mark.parametrize("riemann", ["Roe", "HLLC"])
@@ -152,3 +155,104 @@ def test_swe_one_launch_per_step_equals_staged(dev, nx, ny, lim, riemann):
         out[ks] = s.download()
     assert np.array_equal(out[0], out[1])
     assert np.abs(out[1][ng:-ng, ng:-ng] - U0[ng:-ng, ng:-ng]).max() > 1e-4     # it did move
+
+
+def _swe_random_state(nx, ny, seed):
+    ng = 4
+    rng = np.random.default_rng(seed)
+    x = np.arange(nx + 2 * ng)[:, None] / nx
+    y = np.arange(ny + 2 * ng)[None, :] / ny
+    U0 = np.zeros((nx + 2 * ng, ny + 2 * ng, 4))
+    U0[..., 0] = 1.0 + 0.3 * np.sin(6 * x) * np.cos(4 * y) + 0.05 * rng.random(U0.shape[:2])
+    U0[..., 1] = U0[..., 0] * (0.4 * np.cos(3 * x + y))
+    U0[..., 2] = U0[..., 0] * (-0.5 * np.sin(5 * y - x))
+    U0[..., 3] = U0[..., 0] * (0.5 + 0.5 * np.sin(9 * x * y))
+    return U0
+
+
+@pytest.mark.parametrize("riemann", ["Roe", "HLLC"])
+@pytest.mark.parametrize("lim", [0, 1, 2])
+def test_swe_contracted_build_within_1e10(dev, riemann, lim):
+    """gpu.fast_math = 1 for the shallow-water one-launch kernel (unit swe_fast: contracted,
+    reciprocal-based quotients, the characteristic sums of sw_trace / sw_roe written out without
+    their structural zeros): five steps from a state with both signs of every wave speed (and a
+    transcritical patch), element-wise <= 1e-10 of the bit-faithful build"""
+    nx, ny, ng = 45, 70, 4
+    U0 = _swe_random_state(nx, ny, 11)
+    U0[..., 1] *= 2.4          # |u| up to ~1 ~ c: transcritical cells in both directions
+    bcs = [["outflow", "outflow", "periodic", "periodic"]] * 4
+    dx, dy, grav = 1.0 / nx, 1.0 / ny, 1.0
+    out = {}
+    for fast in (0, 1):
+        s = device.DeviceState(dev, nx, ny, ng, bcs)
+        s.upload(U0)
+        dts = []
+        for _ in range(5):
+            s.fill_bc()
+            dt = 0.5 * s.swe_dt(dx, dy, grav, 0.8)
+            dts.append(dt)
+            s.swe_step(dx, dy, grav, lim, riemann, dt, kernel_set=1, fast_math=fast)
+        out[fast] = s.download()[ng:-ng, ng:-ng]
+    a, b = out[1], out[0]
+    floor = np.array([1.0, 0.1, 0.1, 0.1])
+    err = (np.abs(a - b) / (np.abs(b) + floor)).max()
+    assert err <= 1e-10, err
+    assert np.abs(b - U0[ng:-ng, ng:-ng]).max() > 1e-3
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+@pytest.mark.parametrize("bcs", [("outflow", "outflow", "reflect", "reflect"), ("periodic", "periodic", "outflow", "reflect")])
+def test_swe_evolve_on_device_equals_single_steps(dev, bcs, fast):
+    """pyrohip_swe_evolve (ghost fill of both buffers' frames, dt policy on the device on the
+    minimum the step kernel's wavefronts left, tmax inside the call) against the same steps
+    taken one by one from the host: dt sequence, time and the whole array incl. ghost cells -- exact"""
+    from oracle import orc
+    nx, ny, ng = 40, 66, 4
+    vb = orc.comp_var_bcs(list(bcs))
+    rows = [list(vb[0]), list(vb[2]), list(vb[3]), list(vb[0])]
+    U0 = _swe_random_state(nx, ny, 3)
+    dx, dy, grav, cfl = 1.0 / nx, 1.0 / ny, 1.0, 0.8
+    ref = None
+    for tmax in (1.e30, None):
+        if tmax is None:
+            tmax = sum(ref[:4]) + 0.3 * ref[4]
+        s1 = device.DeviceState(dev, nx, ny, ng, rows)
+        s1.upload(U0)
+        pol1, d1 = DtPolicy(tmax), []
+        while pol1.t < tmax and pol1.n < 6:
+            s1.fill_bc()
+            dt = pol1(s1.swe_dt(dx, dy, grav, cfl))
+            s1.swe_step(dx, dy, grav, 1, "Roe", dt, kernel_set=1, fast_math=fast)
+            pol1.advance(dt)
+            d1.append(dt)
+        s = device.DeviceState(dev, nx, ny, ng, rows)
+        s.upload(U0)
+        pol = DtPolicy(tmax)
+        dts = list(s.swe_evolve(dx, dy, grav, 1, "Roe", cfl, pol, 2, fast_math=fast))
+        dts += list(s.swe_evolve(dx, dy, grav, 1, "Roe", cfl, pol, 4, fast_math=fast))
+        assert dts == d1 and pol.t == pol1.t and pol.n == pol1.n, (dts, d1)
+        a, b = s.download(), s1.download()
+        assert np.array_equal(a[ng:-ng, ng:-ng], b[ng:-ng, ng:-ng])
+        if tmax > 1.e29:      # (iterations of a call past tmax still refill the ghost cells)
+            assert np.array_equal(a, b)
+        ref = d1
+
+
+def test_pyro_swe_run_sim_batches_steps(api, golden):
+    """Pyro("swe").run_sim() hands batches of steps to the device (evolve_many): same dt
+    sequence end and state as single steps"""
+    from pyro2_amd.pyro_sim import Pyro
+    res = []
+    for batch in (True, False):
+        p = Pyro("swe")
+        p.initialize_problem("dam", inputs_file="inputs.dam.x",
+                             inputs_dict={"mesh.nx": 32, "mesh.ny": 8, "driver.max_steps": 7, "gpu.fast_math": 0})
+        assert p.sim.can_evolve_many()
+        if batch:
+            p.run_sim()
+        else:
+            while not p.sim.finished():
+                p.single_step()
+        res.append((p.sim.n, p.sim.cc_data.t, p.sim.dt, np.asarray(p.sim.cc_data.data).copy()))
+    assert res[0][:3] == res[1][:3]
+    assert np.array_equal(res[0][3][4:-4, 4:-4], res[1][3][4:-4, 4:-4])
