@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line.  At N=1 it also carries
   also          sedov_developed: the SAME kernel on developed flow (a 1024^2
                 Sedov blast run to t = 0.1 on the GPU and tiled over the grid:
                 the shocked region covers ~30 % of the cells; the headline state
-                is 99.9 % ambient gas), >= 200 timed steps, both builds;
+                is 99.9 % ambient gas), 120 timed steps, both builds;
                 sedov_exact: the headline workload in the bit-faithful build;
                 advection 2048^2 (configs[1]), multigrid 4096^2 V-cycles/s
                 (configs[3]) and the incompressible solver, measured the same way
@@ -78,12 +78,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--cpu-sample-nx", type=int, default=1024)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+    ap.add_argument("--cpu-seconds", type=float, default=10.0,
                     help="bound of the cpu_baseline sample (seconds of one host core)")
     ap.add_argument("--also-div", type=int, default=1,
                     help="> 1: the secondary legs run on grids this many times smaller and a few steps "
                          "(tests/test_bench_line.py runs the whole script on the host emulator)")
-    ap.add_argument("--developed-steps", type=int, default=250)
+    ap.add_argument("--developed-steps", type=int, default=120)
     ap.add_argument("--no-developed", action="store_true")
     ap.add_argument("--scale-check", action="store_true", default=None,
                     help="before timing: compressible Sedov 2048^2, 12 steps, on 1 rank vs the N ranks "

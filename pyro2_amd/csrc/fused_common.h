@@ -146,8 +146,8 @@ __device__ __forceinline__ Prim cons_to_prim_nb(const Cons &U, double gamma, boo
     const bool nz = (U.d != 0.0);
     const double ds = nz ? U.d : 1.0;
     const double rd = PYRO_FAST ? prcp(ds) : 0.0;
-    const double u = pdivr(U.mx, ds, rd);
-    const double v = pdivr(U.my, ds, rd);
+    const double u = pvel(U.mx, ds, rd);
+    const double v = pvel(U.my, ds, rd);
     const double e = pdivr(U.E - 0.5 * U.d * (u * u + v * v), ds, rd);
     Prim q;
     q.r = U.d;

@@ -155,6 +155,32 @@ __device__ __forceinline__ double psqrt_r(double x, double &rinv)
     rinv = pdiv(1.0, g);
     return g;
 }
+#elif PYRO_FAST && defined(PYRO_EMU) && defined(PYRO_EMU_FASTSEED)
+// Host emulator, developer variant (PYRO_EMU_DEFS=-DPYRO_EMU_FASTSEED): the contracted build's
+// reciprocal / root with the PRECISION of the GPU forms above -- a 2^-23 seed and one Newton /
+// Goldschmidt step -- so that the sensitivity of a kernel to the ~3e-14 quotients can be looked
+// at without a GPU (found with it: the Roe solver's eigenvector sums of the shallow-water build)
+__device__ __forceinline__ double prcp(double b)
+{
+    double r = (double)(1.0f / (float)b);
+    return fma(fma(-b, r, 1.0), r, r);
+}
+__device__ __forceinline__ double pdiv(double a, double b) { return a * prcp(b); }
+__device__ __forceinline__ double pdivr(double a, double b, double rb) { (void)b; return a * rb; }
+__device__ __forceinline__ double psqrt_r(double x, double &rinv)
+{
+    const double y = (double)(1.0f / sqrtf((float)x));
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    rinv = h + h;
+    return g;
+}
+__device__ __forceinline__ double psqrt(double x) { double ri; return (x > 0.0) ? psqrt_r(x, ri) : 0.0; }
+__device__ __forceinline__ double psqrt0(double x) { return psqrt(x); }
+__device__ __forceinline__ double psqrt_nc(double x) { double ri; return psqrt_r(x, ri); }
+__device__ __forceinline__ double prsqrt(double x) { double ri; psqrt_r(x, ri); return ri; }
 #else
 __device__ __forceinline__ double prsqrt(double x) { return 1.0 / sqrt(x); }
 __device__ __forceinline__ double psqrt0(double x) { return sqrt(x); }
@@ -171,6 +197,21 @@ __device__ __forceinline__ double pdiv(double a, double b) { return a / b; }
 __device__ __forceinline__ double pdivr(double a, double b, double rb) { (void)rb; return a / b; }
 #endif
 
+// velocity = momentum / density (d > 0) for the primitive variables: the bit-faithful GPU
+// quotient above is the IEEE one except for the SIGN of a zero quotient (-0 / d gives +0: the
+// Markstein correction adds +0), and the characteristic tracing takes copysign(1, u)
+// (interface.py:198-201) -- a cell at rest whose momentum is -0.0 (an odd reflection of +0.0)
+// would trace the other way than the reference.  One compare + select, bit-faithful build only.
+__device__ __forceinline__ double pvel(double m, double d, double rd)
+{
+    const double q = pdivr(m, d, rd);
+#if !PYRO_FAST && !defined(PYRO_EMU) && !defined(PYRO_IEEE_LIBCALLS)
+    return (m == 0.0) ? m : q;
+#else
+    return q;
+#endif
+}
+
 struct Cons { double d, E, mx, my; };   // density, energy, x-mom, y-mom
 struct Prim { double r, u, v, p; };     // rho, u, v, p
 
@@ -183,8 +224,8 @@ __device__ __forceinline__ Prim cons_to_prim(const Cons &U, double gamma, bool *
     double u = 0.0, v = 0.0, e = 0.0;
     if (U.d != 0.0) {
         const double rd = PYRO_FAST ? prcp(U.d) : 0.0;
-        u = pdivr(U.mx, U.d, rd);
-        v = pdivr(U.my, U.d, rd);
+        u = pvel(U.mx, U.d, rd);
+        v = pvel(U.my, U.d, rd);
         e = pdivr(U.E - 0.5 * U.d * (u * u + v * v), U.d, rd);
     }
     q.u = u;

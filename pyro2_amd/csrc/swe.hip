@@ -55,6 +55,17 @@ __device__ __forceinline__ void st4(double *__restrict__ p, size_t pl, size_t k,
     p[k] = v.a[0]; p[pl + k] = v.a[1]; p[2 * pl + k] = v.a[2]; p[3 * pl + k] = v.a[3];
 }
 
+// u = m / h of the primitive variables (simulation.py:48-63).  The bit-faithful build's quotient
+// (hydro.h: reciprocal + Markstein correction) is the IEEE quotient except for the SIGN of a zero:
+// -0 / h comes out as +0 -- and the tracing takes copysign(1, u) (interface.py:191-193), so a cell
+// whose momentum is exactly -0.0 took the other branch than the reference (found on the GPU with
+// the contracted build, whose a * (1 / h) keeps the sign: 2.5e-6 in the cells around one such cell)
+__device__ __forceinline__ double sw_vel(double m, double h)
+{
+    const double q = pdiv(m, h);
+    return (!PYRO_FAST && m == 0.0) ? m : q;
+}
+
 // simulation.py:65-80
 __device__ __forceinline__ V4 sw_prim_to_cons(const double q[4])
 {
@@ -84,7 +95,7 @@ __device__ __forceinline__ V4 sw_cons_flux(const V4 &U, double g, bool x)
 // characteristic tracing of one cell in one direction, interface.py:5-213:
 // primitive states on the cell's lower face (q_r[face]) and upper face
 // (q_l[face+1])
-#if PYRO_FAST
+#if PYRO_FAST && !defined(SWE_DENSE_TRACE)
 // the same sums without the terms that are structurally zero: l_0 . dq = (dq_h / h - dq_n / c) / 2,
 // l_2 . dq = -(dq_h / h + dq_n / c) / 2 (sic: the reference's sign), l_1 . dq = dq_t, l_3 . dq = dq_X;
 // beta_l of wave 2 and beta_r of wave 0 vanish (e_2 - e_2, e_0 - e_0); r_0 = (h, -c), r_2 = (h, c)
@@ -201,7 +212,7 @@ __device__ __forceinline__ V4 sw_roe(const V4 &Ul, const V4 &Ur, double g, bool 
         lambda[0] = pdiv(lambda[0] * (u_star - c_star - lambda[0]), u_star - c_star - (un_l - c_l));
     if (fabs(lambda[2]) < tol)
         lambda[2] = pdiv(lambda[2] * (u_star + c_star - lambda[2]), u_star + c_star - (un_r + c_r));
-#if PYRO_FAST
+#if PYRO_FAST && !defined(SWE_DENSE_ROE)
     {   // K_0 = (1, u - c, u_t), K_1 = e_t, K_2 = (1, u + c, u_t), K_3 = e_X: the non-zero terms only
         const double w0 = 0.5 * alpha[0] * fabs(lambda[0]), w1 = 0.5 * alpha[1] * fabs(lambda[1]);
         const double w2 = 0.5 * alpha[2] * fabs(lambda[2]), w3 = 0.5 * alpha[3] * fabs(lambda[3]);
@@ -274,9 +285,9 @@ __global__ __launch_bounds__(256) void k_sw_prim(const double *__restrict__ U,
     const V4 Uc = ld4(U, pl, k);
     double *Q = W + (size_t)SW_Q * pl;
     Q[k] = Uc.a[0];
-    Q[pl + k] = pdiv(Uc.a[1], Uc.a[0]);
-    Q[2 * pl + k] = pdiv(Uc.a[2], Uc.a[0]);
-    Q[3 * pl + k] = pdiv(Uc.a[3], Uc.a[0]);
+    Q[pl + k] = sw_vel(Uc.a[1], Uc.a[0]);
+    Q[2 * pl + k] = sw_vel(Uc.a[2], Uc.a[0]);
+    Q[3 * pl + k] = sw_vel(Uc.a[3], Uc.a[0]);
 }
 
 // ---- stage 1: limited slopes + tracing for the cells of R(1) --------------
@@ -514,9 +525,9 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
         Upre = loadU(k + 1);
         Urep = loadU(k - 2);
         q[4][0] = Uk.a[0];
-        q[4][1] = pdiv(Uk.a[1], Uk.a[0]);
-        q[4][2] = pdiv(Uk.a[2], Uk.a[0]);
-        q[4][3] = pdiv(Uk.a[3], Uk.a[0]);
+        q[4][1] = sw_vel(Uk.a[1], Uk.a[0]);
+        q[4][2] = sw_vel(Uk.a[2], Uk.a[0]);
+        q[4][3] = sw_vel(Uk.a[3], Uk.a[0]);
         const int c = k - 2;                 // window row 2
         if (c < i0 - 1) continue;
         // ---- row c: limited slopes, tracing (k_sw_states)

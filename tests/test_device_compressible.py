@@ -1541,3 +1541,47 @@ def test_rk_evolve_on_device_equals_single_steps(dev, method):
         s1.upload(s1.download())          # (drops the cache)
         assert cached == s1.comp_rk_dt(P, cfl)
         res.append((d1,))
+
+
+@pytest.mark.parametrize("kset", KSETS)
+def test_comp_negative_zero_momentum_traces_like_the_reference(dev, kset):
+    """the tracing takes copysign(1, u) (interface.py:198-201): a cell whose x-momentum is exactly
+    -0.0 -- e.g. the odd reflection of a gas at rest -- sends its shear / entropy waves to the LOWER
+    face.  The bit-faithful GPU quotient (reciprocal + Markstein correction) returned +0 for -0 / rho
+    (found in round 5 through the shallow-water build); hydro.h: pvel keeps the sign.  One step of
+    a sheared state at rest in x with -0.0 / +0.0 bands, against the oracle"""
+    from helpers import oracle_comp_run
+    nx, ny, ng = 24, 20, 4
+    meta = [nx, ny, ng, 1.0 / nx, 1.0 / ny, 1.4, 2, 1, 0.75, 0.85, 0.33, 0.1, 0.0, 0.8]
+    bcs = ["periodic"] * 4
+    x = np.arange(nx + 2 * ng)[:, None] / nx
+    y = np.arange(ny + 2 * ng)[None, :] / ny
+    U = np.zeros((nx + 2 * ng, ny + 2 * ng, 4))
+    U[..., 0] = 1.0 + 0.2 * np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y)
+    v = 0.3 * np.sin(2 * np.pi * x)                   # shear: d v / d x != 0
+    U[..., 3] = U[..., 0] * v
+    U[..., 2] = np.where((np.arange(nx + 2 * ng) % 4 < 2)[:, None], -0.0, 0.0)
+    U[..., 1] = 2.5 + 0.5 * U[..., 0] * v * v
+    assert np.signbit(U[..., 2]).any() and not np.signbit(U[..., 2]).all()
+    Uo, dto, _ = oracle_comp_run(U, meta, bcs, 1.0, 1, init_tstep_factor=1.0)
+    Ud, dts, _ = _one_full_step(dev, U, meta, bcs, kset)
+    tol = 0.0 if dev.kind == "emu" else 1e-13
+    assert max_rel_err(dts, dto) <= tol
+    for n in range(4):
+        assert max_rel_err(Ud[4:-4, 4:-4, n], Uo[4:-4, 4:-4, n]) <= tol, n
+    # the sign of the zero matters: with +0.0 everywhere the step is a different one
+    U2 = U.copy()
+    U2[..., 2] = 0.0
+    Uo2, _, _ = oracle_comp_run(U2, meta, bcs, 1.0, 1, init_tstep_factor=1.0)
+    assert np.abs(Uo2 - Uo)[4:-4, 4:-4].max() > 1e-9
+
+
+def _one_full_step(dev, U, meta, bcs, kset):
+    """one step with the full CFL time step (no init_tstep_factor)"""
+    P, cfl = dev_params(meta, **kset_kw(kset))
+    s = comp_state(dev, int(meta[0]), int(meta[1]), bcs)
+    s.upload(U)
+    s.fill_bc()
+    dt = s.comp_dt(P, cfl)
+    s.comp_step(P, dt)
+    return s.download(), np.array([dt]), dt
