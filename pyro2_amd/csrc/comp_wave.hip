@@ -148,6 +148,23 @@ constexpr size_t WLDS_BYTES = (size_t)(ST_SLOTS * 64 + C_N) * sizeof(double);
 #else
 #define US(name, expr) UC(name)
 #endif
+// ... a uniform that a row uses once (artificial viscosity, the two correction factors, the update's
+// factors, 1 / dx): experiment PYRO_WAVE_FEW_SGPR reads those from the table in the fast build too
+#if defined(PYRO_WAVE_FEW_SGPR)
+#define US1(name, expr) UC(name)
+#else
+#define US1(name, expr) US(name, expr)
+#endif
+#if defined(PYRO_WAVE_FEW_SGPR) && PYRO_WAVE_FEW_SGPR >= 2
+#define US2(name, expr) UC(name)
+#else
+#define US2(name, expr) US(name, expr)
+#endif
+#if defined(PYRO_WAVE_FEW_SGPR) && PYRO_WAVE_FEW_SGPR >= 3
+#define US3(name, expr) UC(name)
+#else
+#define US3(name, expr) US(name, expr)
+#endif
 // an entry only one of the two builds uses (the table reads are volatile: an unused one
 // would still be issued)
 #if defined(PYRO_EMU)     // (the emulated fast build divides by the operand, not by its reciprocal)
@@ -160,7 +177,7 @@ constexpr size_t WLDS_BYTES = (size_t)(ST_SLOTS * 64 + C_N) * sizeof(double);
 #define UC_FAST(name) 0.0
 #define UC_EXACT(name) UC(name)
 #endif
-#define UC_GASK() GasKTab{ct, US(GAMMA, P.gamma)}
+#define UC_GASK() GasKTab{ct, US3(GAMMA, P.gamma)}
 // (an explicit LDS pointer type: a plain `volatile double *` is a generic pointer
 // that the address-space inference leaves alone, i.e. flat loads through vmcnt)
 #if defined(PYRO_EMU)
@@ -439,11 +456,11 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         Uem = Ue;
         if (NOREP) {
             // (window index 1 = row k-3 after the shift above; floor and signs are in the primitives)
-            Ue = prim_to_cons_g(Prim{wr[1], wu[1], wv[1], wp[1]}, US(GM1, P.gm1), US(RGM1, P.rgm1));
+            Ue = prim_to_cons_g(Prim{wr[1], wu[1], wv[1], wp[1]}, US2(GM1, P.gm1), US2(RGM1, P.rgm1));
         } else {
         Ue = Urep;
         fix_sign(Ue, k - 3);
-        if (row_in(k - 3) && jin) Ue.d = fmax(Ue.d, US(SMALLD, P.small_dens));      // clean_state
+        if (row_in(k - 3) && jin) Ue.d = fmax(Ue.d, US2(SMALLD, P.small_dens));      // clean_state
         }
         // (issuing this second read of row k-2 in the middle of the iteration instead -- eight
         // registers less while the slopes and the first Riemann problems are worked on -- was
@@ -456,11 +473,11 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             Upre = loadU(k + 1);
             const bool interior = row_in(k) && jin;
             // (RKF: the stage state is a temporary of the step -- nothing to keep the floor in)
-            if (MOL && !RKF && interior && U.d < US(SMALLD, P.small_dens))     // clean_state works in place
-                const_cast<double *>(Uin)[(size_t)k * p + jc] = US(SMALLD, P.small_dens);
-            if (interior) U.d = fmax(U.d, US(SMALLD, P.small_dens));
+            if (MOL && !RKF && interior && U.d < US2(SMALLD, P.small_dens))     // clean_state works in place
+                const_cast<double *>(Uin)[(size_t)k * p + jc] = US2(SMALLD, P.small_dens);
+            if (interior) U.d = fmax(U.d, US2(SMALLD, P.small_dens));
             bool ok;
-            const Prim q = cons_to_prim_nb(U, US(GAMMA, P.gamma), ok);
+            const Prim q = cons_to_prim_nb(U, US3(GAMMA, P.gamma), ok);
             if (interior && !ok) bad = true;
             wr[4] = q.r; wu[4] = q.u; wv[4] = q.v; wp[4] = q.p;
         }
@@ -536,7 +553,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 const size_t kc = (size_t)(ina ? i : g.qx - 1) * p + (ina ? js : g.qy - 1);
                 Ug.d = Uin[kc]; Ug.my = Uin[3 * pl + kc];
                 if (i >= g.ilo && i <= g.ihi && js >= g.jlo && js <= g.jhi)
-                    Ug.d = fmax(Ug.d, US(SMALLD, P.small_dens));
+                    Ug.d = fmax(Ug.d, US2(SMALLD, P.small_dens));
                 sgn = ((j < g.jlo && P.refl_ylo) || (j > g.jhi && P.refl_yhi)) ? -1.0 : 1.0;
                 hp = P.heat ? P.heat[(size_t)(ina ? i : g.qx - 1) * p + (ina ? j : g.qy - 1)] : 0.0;
             }
@@ -544,13 +561,13 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             // artificial viscosity coefficients of the faces (i, j) in x and (i-1, j)
             // in y (interface.py:366-376: only faces i in [ilo, ihi], j in [jlo, jhi])
             Dn = div_u_vertex_r(q0[1], um, qm[1], up, q0[2], qm[2], vm, vp, UC_EXACT(DX), UC_EXACT(DY),
-                                US(RDX, P.rdx), US(RDY, P.rdy));
+                                US1(RDX, P.rdx), US1(RDY, P.rdy));
             const double Dn_p = lane_p1(Dn);
             double avx = 0.0, avy = 0.0;
             if (i >= g.ilo && (i <= g.ihi || (P.avx_hi && i == g.ihi + 1)) && jin) {
                 const double divU_x = 0.5 * (Dn + Dn_p);
 #if PYRO_FAST
-                avx = US(CVDX, s_cvdx) * fmax(-divU_x, 0.0);
+                avx = US1(CVDX, s_cvdx) * fmax(-divU_x, 0.0);
 #else
                 avx = UC(CVISC) * fmax(-divU_x * UC(DX), 0.0);
 #endif
@@ -558,7 +575,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             if (j >= g.jlo && (j <= g.jhi || (P.avy_hi && j == g.jhi + 1)) && row_in(i - 1)) {
                 const double divU_y = 0.5 * (Dp + Dn);
 #if PYRO_FAST
-                avy = US(CVDY, s_cvdy) * fmax(-divU_y, 0.0);
+                avy = US1(CVDY, s_cvdy) * fmax(-divU_y, 0.0);
 #else
                 avy = UC(CVISC) * fmax(-divU_y * UC(DY), 0.0);
 #endif
@@ -566,7 +583,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             STAGE_FENCE();
             // -- x states of row c, transverse x flux on its lower face
             Trace lo, hi;
-            double gamma = US(GAMMA, P.gamma);
+            double gamma = US3(GAMMA, P.gamma);
             if (MOL) {     // fluxes.py:107-140: V_r[i] = q - ld/2, V_l[i+1] = q + ld/2
                 lo = Trace{q0[0] + -1.0 * 0.5 * dqx[0], q0[1] + -1.0 * 0.5 * dqx[1],
                            q0[2] + -1.0 * 0.5 * dqx[2], q0[3] + -1.0 * 0.5 * dqx[3]};
@@ -574,8 +591,8 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                            q0[2] + 1.0 * 0.5 * dqx[2], q0[3] + 1.0 * 0.5 * dqx[3]};
             } else
                 trace_states(q0[0], q0[1], q0[2], q0[3], dqx[0], dqx[1], dqx[2], dqx[3], gamma,
-                             US(DTDX, s_dtdx), lo, hi);
-            double gm1 = UC_EXACT(GM1), rgm1 = US(RGM1, P.rgm1);
+                             US2(DTDX, s_dtdx), lo, hi);
+            double gm1 = UC_EXACT(GM1), rgm1 = US2(RGM1, P.rgm1);
             Cons XMn = prim_to_cons_g(Prim{lo.r, lo.un, lo.ut, lo.p}, gm1, rgm1);
             Cons XPn = prim_to_cons_g(Prim{hi.r, hi.un, hi.ut, hi.p}, gm1, rgm1);
             FaceQ qxm{lo.un, lo.ut, lo.p}, qxp{hi.un, hi.ut, hi.p};
@@ -610,7 +627,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 else {
                 const Cons FxTp = st_get(st, ST_FXT);
 #if PYRO_FAST
-                const double kx = US(KX, s_kx);
+                const double kx = US1(KX, s_kx);
                 YMc = corr_k(st_get(st, ST_YM), FxTn, FxTp, kx);
                 YPc = corr_k(st_get(st, ST_YP), FxTn, FxTp, kx);
 #else
@@ -631,7 +648,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             if (!MOL && xface) st_put(st, ST_FXT, FxTn);
             STAGE_FENCE();
             // -- y states of row c, transverse y flux on its lower face
-            gamma = US(GAMMA, P.gamma);
+            gamma = US3(GAMMA, P.gamma);
             if (MOL) {     // (normal / transverse frame of the y direction: un = v, ut = u)
                 lo = Trace{q0[0] + -1.0 * 0.5 * dqy[0], q0[2] + -1.0 * 0.5 * dqy[2],
                            q0[1] + -1.0 * 0.5 * dqy[1], q0[3] + -1.0 * 0.5 * dqy[3]};
@@ -639,8 +656,8 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                            q0[1] + 1.0 * 0.5 * dqy[1], q0[3] + 1.0 * 0.5 * dqy[3]};
             } else
                 trace_states(q0[0], q0[2], q0[1], q0[3], dqy[0], dqy[2], dqy[1], dqy[3], gamma,
-                             US(DTDY, s_dtdy), lo, hi);
-            gm1 = UC_EXACT(GM1); rgm1 = US(RGM1, P.rgm1);
+                             US2(DTDY, s_dtdy), lo, hi);
+            gm1 = UC_EXACT(GM1); rgm1 = US2(RGM1, P.rgm1);
             Cons YMn = prim_to_cons_g(Prim{lo.r, lo.ut, lo.un, lo.p}, gm1, rgm1);
             Cons YPn = prim_to_cons_g(Prim{hi.r, hi.ut, hi.un, hi.p}, gm1, rgm1);
             FaceQ qym{lo.un, lo.ut, lo.p}, qyp{hi.un, hi.ut, hi.p};
@@ -669,7 +686,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             if (!MOL) {
             const Cons FyTh = lane_p1(FyT);            // FyT at (i, j+1)
 #if PYRO_FAST
-            const double ky = US(KY, s_ky);
+            const double ky = US1(KY, s_ky);
             XMc = corr_k(XMn, FyTh, FyT, ky);
             XPc = corr_k(XPn, FyTh, FyT, ky);
 #else
@@ -731,7 +748,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                         double *O = P.rk_out + kr;
                         O[0] = Y.d; O[pl] = Y.E; O[2 * pl] = Y.mx; O[3 * pl] = Y.my;
                         double ax, ay;
-                        cfl_speeds(Y, US(GAMMA, P.gamma), ax, ay);
+                        cfl_speeds(Y, US3(GAMMA, P.gamma), ax, ay);
                         st[ST_AX * 64] = fmax(st[ST_AX * 64], pdiv(ax, dxx) + pdiv(ay, dyy));
                     } else {
                     Uout[kr] = Un.d; Uout[pl + kr] = Un.E; Uout[2 * pl + kr] = Un.mx;
@@ -739,7 +756,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                     }
                 } else {
 #if PYRO_FAST
-                const double cx = US(CX, s_cx), cy = US(CY, s_cy);
+                const double cx = US1(CX, s_cx), cy = US1(CY, s_cy);
                 Un.d = fma(cx, Fxp.d - Fxn.d, fma(cy, Fy.d - Fyh.d, Uc.d));
                 Un.E = fma(cx, Fxp.E - Fxn.E, fma(cy, Fy.E - Fyh.E, Uc.E));
                 Un.mx = fma(cx, Fxp.mx - Fxn.mx, fma(cy, Fy.mx - Fyh.mx, Uc.mx));
@@ -764,7 +781,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 Uout[3 * pl + ko] = Un.my;
 #endif
                 double ax, ay;   // CFL: running maxima of the divisors, one division at the end
-                cfl_speeds(Un, US(GAMMA, P.gamma), ax, ay);
+                cfl_speeds(Un, US3(GAMMA, P.gamma), ax, ay);
                 st[ST_AX * 64] = fmax(st[ST_AX * 64], ax);
                 st[ST_AY * 64] = fmax(st[ST_AY * 64], ay);
                 }
