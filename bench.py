@@ -1051,7 +1051,16 @@ def main():
     dist = Dist(world)
     from pyro2_amd import device
     ndev = device.device_count()
-    dist.oversubscribed = world > 1 and world > ndev
+    # several ranks on one GPU?  Decided by the devices the ranks actually get (PCI ids gathered
+    # over the process group), not by the device count one rank sees: a launcher that gives every
+    # rank ONE visible device (ROCR / HIP_VISIBLE_DEVICES per rank) is a proper one-rank-per-GPU
+    # run.  Without PCI ids (no HIP runtime answer) the device count decides, as before.
+    my_ident = device_identity(dist.local_rank % max(ndev, 1))
+    all_ids = [int(r[0]) for r in dist.gather([float(my_ident if my_ident is not None else -1)])]
+    if world > 1 and all(i >= 0 for i in all_ids):
+        dist.oversubscribed = len(set(all_ids)) < world
+    else:
+        dist.oversubscribed = world > 1 and world > ndev
     if dist.oversubscribed and dist.rank == 0:
         print(f"[bench] WARNING: --gpus {world} on a box with {ndev} GPU(s): ranks share GPUs; "
               "this run checks the multi-rank path, its number is NOT a scaling result "
@@ -1066,7 +1075,7 @@ def main():
         os.environ.setdefault("NCCL_IB_DISABLE", "1")
         os.environ.setdefault("NCCL_P2P_DISABLE", "1")
     ctx = device.Context(dist.local_rank % ndev)
-    ident = device_identity(dist.local_rank % ndev)
+    ident = my_ident
     dist.comm_kind, dist.comm_note = "rccl", None
     want_comm = os.environ.get("PYRO_BENCH_COMM", "rccl")
     if world > 1:

@@ -7,7 +7,10 @@
 # gpurun_out/profiles_<tag>/traffic.json:
 #   <tag>_provenance.json                commit, box (host, GPU id), date, ROCm -- every JSON below carries it too
 #   <tag>_pytest_gpu.txt                 pytest -m gpu summary line (TESTS=0 skips)
-#   <tag>_bench_default.json             python bench.py (the driver's command; ONLY=bench: just this, with <tag>_bench_default_provenance.json)
+#   <tag>_bench_line.json, <tag>_bench_default.json   python bench.py --gpus 1 --steps 20 --warmup 5 (the driver's command): its ONE stdout
+#                                        line and the full record (ONLY=bench: just these, with <tag>_bench_default_provenance.json)
+#   <tag>_{swe4096,rk4096,sph2048}_{kernel_stats.csv,pmc.json}   the SURVEY 8(f4) one-launch kernels (tools/pmc_leg.sh)
+#   <tag>_xcdbar_probe.txt               barrier confined to one XCD vs chip-wide (tools/xcdbar_probe.hip, gridbar_probe.hip)
 #   <tag>_default16384_fm{1,0}_kernel_stats.csv, _pmc.json      the headline launch, both builds
 #   <tag>_sedov{8192,4096}_kernel_stats.csv, _pmc.json         north_star's target size, config 3
 #   traffic.json                         per size and build: bytes / instructions per cell update (tools/make_traffic.py)
@@ -39,16 +42,20 @@ stats() {   # stats <name> <command...>: rocprofv3 kernel statistics of a comman
 if [ "${ONLY:-}" = "bench" ]; then
   # only the driver's command again, at a later commit than the rest of the set: its own stamp
   mv $P/${TAG}_provenance.json $P/${TAG}_bench_default_provenance.json
-  ( time timeout 600 python bench.py < /dev/null > $P/${TAG}_bench_default.json ) 2> $O/bench_${TAG}.err
-  head -c 300 $P/${TAG}_bench_default.json; echo; tail -3 $O/bench_${TAG}.err
+  ( time timeout 600 python bench.py < /dev/null > $P/${TAG}_bench_line.json ) 2> $O/bench_${TAG}.err
+  cp $O/bench_full.json $P/${TAG}_bench_default.json
+  head -c 300 $P/${TAG}_bench_line.json; echo; tail -3 $O/bench_${TAG}.err
   exit 0
 fi
 if [ "${TESTS:-1}" = "1" ]; then
   ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu_${TAG}.log 2>&1
   grep -E "passed|failed|error" $O/pytest_gpu_${TAG}.log | tail -2 > $P/${TAG}_pytest_gpu.txt; cat $P/${TAG}_pytest_gpu.txt
 fi
-( time timeout 1500 python bench.py > $P/${TAG}_bench_default.json ) 2> $O/bench_${TAG}.err
-head -c 400 $P/${TAG}_bench_default.json; echo; tail -3 $O/bench_${TAG}.err
+# the driver's command: the ONE compact stdout line (<tag>_bench_line.json) and the full record it
+# points at (gpurun_out/bench_full.json -> <tag>_bench_default.json, the name of the earlier rounds)
+( time timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $P/${TAG}_bench_line.json ) 2> $O/bench_${TAG}.err
+cp $O/bench_full.json $P/${TAG}_bench_default.json
+wc -c $P/${TAG}_bench_line.json; head -c 400 $P/${TAG}_bench_line.json; echo; grep -E "^real" $O/bench_${TAG}.err
 B="python $R/bench.py --steps 10 --warmup 3 --no-also --no-cpu-baseline"
 for fm in 1 0; do
   stats default16384_fm$fm $B --fast-math $fm
@@ -74,6 +81,19 @@ print(json.dumps(out, indent=1))
 PY
 TAG=$TAG bash tools/pmc_also.sh > $O/pmc_also_${TAG}.log 2>&1; cp $O/${TAG}_also_traffic.json $P/ 2>/dev/null
 python tools/mg_sizes.py > $P/${TAG}_mg_vcycle_by_size.txt 2>&1; cat $P/${TAG}_mg_vcycle_by_size.txt
+# the SURVEY 8(f4) kernels: kernel statistics + counters per leg (tools/pmc_leg.sh)
+RT=$TAG
+for spec in "swe k_sw_wave 4096 swe4096" "sph k_ctu_fused_sph 2048 sph2048"; do
+  set -- $spec
+  LEG=$1 KN=$2 NX=$3 TAG=${RT}_$4 bash tools/pmc_leg.sh > $O/pmc_leg_${RT}_$4.log 2>&1
+  cp $O/${RT}_$4_kernel_stats.csv $O/${RT}_$4_pmc.json $P/ 2>/dev/null
+done
+# (compressible_rk: the stages with the Runge-Kutta combination folded in -- template arguments
+# <SOLVER, STD, MOL, ONE, RKF> = <0, true, true, false, true> -- averaged over stages 1-3 of RK4)
+LEG=rk KN="true, true, false, true>" NX=4096 TAG=${RT}_rk4096 bash tools/pmc_leg.sh > $O/pmc_leg_${RT}_rk4096.log 2>&1
+cp $O/${RT}_rk4096_kernel_stats.csv $O/${RT}_rk4096_pmc.json $P/ 2>/dev/null
+# what a phase boundary costs: chip-wide barrier vs one confined to an XCD
+( timeout 120 tools/bin/xcdbar_probe; timeout 60 tools/bin/gridbar_probe ) > $P/${TAG}_xcdbar_probe.txt 2>&1
 find $O -name "*.db" -delete 2>/dev/null
 find $O -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null
 ls -la $P
