@@ -1444,9 +1444,12 @@ def _rk_random_state(nx, ny, seed):
     return U
 
 
-@pytest.mark.parametrize("method", ["RK2", "TVD2", "TVD3", "RK4"])
-@pytest.mark.parametrize("bcs", RK_BCS)
-@pytest.mark.parametrize("nx,ny,grav,riemann", [(40, 130, 0.0, "HLLC"), (23, 61, -0.7, "CGF")])
+RK_CASES = [(m, b, 40, 130, 0.0, "HLLC") for m in ("RK2", "TVD2", "TVD3", "RK4") for b in RK_BCS] + \
+           [("RK4", RK_BCS[1], 23, 61, -0.7, "CGF"), ("TVD3", RK_BCS[2], 23, 61, -0.7, "CGF"),
+            ("RK2", RK_BCS[0], 23, 61, -0.7, "HLLC_lm")]
+
+
+@pytest.mark.parametrize("method,bcs,nx,ny,grav,riemann", RK_CASES)
 def test_rk_step_in_one_call_equals_stage_by_stage(dev, method, bcs, nx, ny, grav, riemann):
     """pyrohip_comp_rk_step (the stage states built at load from y_0 and the earlier increments,
     ghost cells through the boundary rules, the final update + CFL minimum in the last stage:
