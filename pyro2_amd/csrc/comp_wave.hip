@@ -361,28 +361,56 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     // RKF: this stage's weights dt a_sj (integration.py:116: self.dt*a[istage, s], then times k)
     const double rkc0 = RKF ? v_dt * P.rk_a[0] : 0.0, rkc1 = RKF ? v_dt * P.rk_a[1] : 0.0,
                  rkc2 = RKF ? v_dt * P.rk_a[2] : 0.0;
-    auto loadU = [&](int row) {
+    // RKF: the LAST increment with a non-zero weight is added where the row is consumed, an
+    // iteration after its load (loadK / addK below) -- added right behind the loads, inside
+    // loadU, the sum waits for the row that was just requested: the stages ran at a VALU busy of
+    // 0.45 (profiles/r05_rk4096_pmc.json: 0.57-0.60 ms per stage against 0.46 for the plain
+    // right-hand side).  Earlier increments (TVD3's second stage has two) are added eagerly;
+    // the order of accumulation is the reference's either way.
+    // (contracted build only: the bit-faithful one reads every row twice, and a second deferred
+    // increment in flight costs it more in spills than the wait -- 3.9 -> 4.8 ms per RK4 step at 4096^2)
+    int rk_last = -1;
+    if (RKF && PYRO_FAST) {
+        for (int jn = 0; jn < 3; jn++)
+            if (jn < P.rk_n && P.rk_a[jn] != 0.0) rk_last = jn;
+    }
+    const int rk_eager = (RKF && !PYRO_FAST) ? 3 : rk_last;      // increments j < rk_eager are added at the load
+    const double rkcl = rk_last == 0 ? rkc0 : (rk_last == 1 ? rkc1 : rkc2);
+    auto src_of = [&](int row) {
         row = row < 0 ? 0 : (row > g.qx - 1 ? g.qx - 1 : row);
         const int srow = MAPS ? bc_src(P.mr, row, g.ilo, g.ihi) : row;
-        const size_t kk = (size_t)srow * p + jsrc;
+        return (size_t)srow * p + jsrc;
+    };
+    auto loadU = [&](int row) {
+        const size_t kk = src_of(row);
         Cons U{Uin[kk], Uin[pl + kk], Uin[2 * pl + kk], Uin[3 * pl + kk]};
         if (RKF) {
             // (the source cell of a mapped ghost cell is an interior cell: y_0 + the increments, in
             // the reference's order of accumulation; a zero weight adds nothing and is not read)
             const double *K = P.rk_k + kk;
-            if (P.rk_n > 0 && P.rk_a[0] != 0.0) {
+            if (rk_eager > 0 && P.rk_n > 0 && P.rk_a[0] != 0.0) {
                 U.d += rkc0 * K[0]; U.E += rkc0 * K[pl]; U.mx += rkc0 * K[2 * pl]; U.my += rkc0 * K[3 * pl];
             }
-            if (P.rk_n > 1 && P.rk_a[1] != 0.0) {
+            if (rk_eager > 1 && P.rk_n > 1 && P.rk_a[1] != 0.0) {
                 const double *K1 = K + 4 * pl;
                 U.d += rkc1 * K1[0]; U.E += rkc1 * K1[pl]; U.mx += rkc1 * K1[2 * pl]; U.my += rkc1 * K1[3 * pl];
             }
-            if (P.rk_n > 2 && P.rk_a[2] != 0.0) {
+            if (rk_eager > 2 && P.rk_n > 2 && P.rk_a[2] != 0.0) {
                 const double *K2 = K + 8 * pl;
                 U.d += rkc2 * K2[0]; U.E += rkc2 * K2[pl]; U.mx += rkc2 * K2[2 * pl]; U.my += rkc2 * K2[3 * pl];
             }
         }
         return U;
+    };
+    auto loadK = [&](int row) {      // the deferred increment of that row (RKF; unused elsewhere)
+        if (!RKF || rk_last < 0) return Cons{0.0, 0.0, 0.0, 0.0};
+        const double *K = P.rk_k + (size_t)(4 * rk_last) * pl + src_of(row);
+        return Cons{K[0], K[pl], K[2 * pl], K[3 * pl]};
+    };
+    auto addK = [&](Cons &U, const Cons &K) {
+        if (RKF && rk_last >= 0) {
+            U.d += rkcl * K.d; U.E += rkcl * K.E; U.mx += rkcl * K.mx; U.my += rkcl * K.my;
+        }
     };
     auto fix_sign = [&](Cons &U, int row) {
         if (!MAPS || !P.odd) return;
@@ -410,6 +438,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     double Dp = 0.0;                                           // vertex div(U) of row k-4
     double up = 0.0, vp = 0.0;                                 // u, v at (k-4, j-1)
     Cons Upre = loadU(i0 - 4);                                 // row k, in flight
+    Cons Kpre = loadK(i0 - 4);                                 // (RKF: its deferred increment)
     // (method of lines, contracted build: the old state of rows k-3 / k-4 -- artificial viscosity,
     // source terms -- is rebuilt from the primitive window instead of read a second time: with the
     // Runge-Kutta stage folded into the load the second read costs the increments' planes too,
@@ -417,6 +446,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     // an RKF stage took 0.65-1.37 ms at 4096^2 against 0.49 for the plain right-hand side)
     constexpr bool NOREP = (PYRO_FAST != 0) && MOL;
     Cons Urep = NOREP ? Cons{1.0, 1.0, 0.0, 0.0} : loadU(i0 - 7);    // row k-3 again, in flight
+    Cons Krep = NOREP ? Cons{0.0, 0.0, 0.0, 0.0} : loadK(i0 - 7);
     bool bad = false;
     // ... and in the stash: uncorrected YM, YP, XP, FxT, corrected XP and Fx of row k-4
     {
@@ -459,18 +489,21 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             Ue = prim_to_cons_g(Prim{wr[1], wu[1], wv[1], wp[1]}, US2(GM1, P.gm1), US2(RGM1, P.rgm1));
         } else {
         Ue = Urep;
+        addK(Ue, Krep);
         fix_sign(Ue, k - 3);
         if (row_in(k - 3) && jin) Ue.d = fmax(Ue.d, US2(SMALLD, P.small_dens));      // clean_state
         }
         // (issuing this second read of row k-2 in the middle of the iteration instead -- eight
         // registers less while the slopes and the first Riemann problems are worked on -- was
         // measured: the allocator spills elsewhere, 10.35 vs 10.46 ms fast, 16.37 vs 15.96 exact)
-        if (!NOREP) Urep = loadU(k - 2);
+        if (!NOREP) { Urep = loadU(k - 2); Krep = loadK(k - 2); }
         // ---- S0: row k -> primitives
         {
             Cons U = Upre;
+            addK(U, Kpre);
             fix_sign(U, k);
             Upre = loadU(k + 1);
+            Kpre = loadK(k + 1);
             const bool interior = row_in(k) && jin;
             // (RKF: the stage state is a temporary of the step -- nothing to keep the floor in)
             if (MOL && !RKF && interior && U.d < US2(SMALLD, P.small_dens))     // clean_state works in place
@@ -511,6 +544,27 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             const int i = k - 3;
             const bool xface = (k >= i0 + 3);          // row c has a lower x face in the strip
             const bool frow = (k >= i0 + 4);           // row f is updated by this strip
+            // RKF, last stage (contracted build): the operands of row f's final update -- y_0 and the
+            // earlier increments of the cell -- are requested HERE and summed behind the slopes
+            // (below), the sum waits in the stash slots the method of lines leaves free (ST_FXT).
+            // Loaded where they are used, at the end of the iteration, the wavefront stood still
+            // for them: the last stage took 1.22 ms against 0.50 for the others.
+            const bool yfin = RKF && (PYRO_FAST != 0) && P.rk_final && frow && jout;
+            Cons Yf0{0.0, 0.0, 0.0, 0.0}, Yf1 = Yf0, Yf2 = Yf0, Yf3 = Yf0;
+            if (yfin) {
+                const size_t kr = (size_t)(i - 1) * p + j;
+                Yf0 = Cons{Uin[kr], Uin[pl + kr], Uin[2 * pl + kr], Uin[3 * pl + kr]};
+                const double *K0 = P.rk_k + kr;
+                if (P.rk_nb > 1 && P.rk_b[0] != 0.0) Yf1 = Cons{K0[0], K0[pl], K0[2 * pl], K0[3 * pl]};
+                if (P.rk_nb > 2 && P.rk_b[1] != 0.0) {
+                    const double *K1 = K0 + 4 * pl;
+                    Yf2 = Cons{K1[0], K1[pl], K1[2 * pl], K1[3 * pl]};
+                }
+                if (P.rk_nb > 3 && P.rk_b[2] != 0.0) {
+                    const double *K2 = K0 + 8 * pl;
+                    Yf3 = Cons{K2[0], K2[pl], K2[2 * pl], K2[3 * pl]};
+                }
+            }
             const double q0[4] = {wr[1], wu[1], wv[1], wp[1]};
             const double qm[4] = {wr[0], wu[0], wv[0], wp[0]};
             const double qp[4] = {wr[2], wu[2], wv[2], wp[2]};
@@ -540,6 +594,21 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 const double l2m = (limiter == 2) ? lane_m1(l2y[n]) : 0.0;
                 const double l2p = (limiter == 2) ? lane_p1(l2y[n]) : 0.0;
                 dqy[n] = xi * slope_shared(l2m, l2y[n], l2p, ym[n], q0[n], yp[n], limiter);
+            }
+            if (yfin) {      // integration.py:120-129, the terms before this stage's own increment
+                if (P.rk_nb > 1 && P.rk_b[0] != 0.0) {
+                    const double w = v_dt * P.rk_b[0];
+                    Yf0.d += w * Yf1.d; Yf0.E += w * Yf1.E; Yf0.mx += w * Yf1.mx; Yf0.my += w * Yf1.my;
+                }
+                if (P.rk_nb > 2 && P.rk_b[1] != 0.0) {
+                    const double w = v_dt * P.rk_b[1];
+                    Yf0.d += w * Yf2.d; Yf0.E += w * Yf2.E; Yf0.mx += w * Yf2.mx; Yf0.my += w * Yf2.my;
+                }
+                if (P.rk_nb > 3 && P.rk_b[2] != 0.0) {
+                    const double w = v_dt * P.rk_b[2];
+                    Yf0.d += w * Yf3.d; Yf0.E += w * Yf3.E; Yf0.mx += w * Yf3.mx; Yf0.my += w * Yf3.my;
+                }
+                st_put(st, ST_FXT, Yf0);
             }
             STAGE_FENCE();
             // source terms of the face states (apply_source_terms, unsplit_fluxes.py:247-330)
@@ -732,7 +801,10 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                         // integration.py:120-129: y_0 += dt b_s k_s, s = 0 ... -- the earlier
                         // increments from memory, the last one is Un; then the CFL quantity of
                         // compressible_rk/simulation.py:46-56 on the new state
-                        Cons Y{Uin[kr], Uin[pl + kr], Uin[2 * pl + kr], Uin[3 * pl + kr]};
+                        Cons Y;
+                        if (PYRO_FAST) Y = st_get(st, ST_FXT);      // (summed behind the slopes: yfin above)
+                        else {
+                        Y = Cons{Uin[kr], Uin[pl + kr], Uin[2 * pl + kr], Uin[3 * pl + kr]};
 #pragma unroll
                         for (int sgm = 0; sgm < 3; sgm++) {
                             if (sgm < P.rk_nb - 1 && P.rk_b[sgm] != 0.0) {
@@ -740,6 +812,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                                 const double *Ks = P.rk_k + (size_t)(4 * sgm) * pl + kr;
                                 Y.d += w * Ks[0]; Y.E += w * Ks[pl]; Y.mx += w * Ks[2 * pl]; Y.my += w * Ks[3 * pl];
                             }
+                        }
                         }
                         if (P.rk_b[P.rk_nb - 1] != 0.0) {
                             const double w = v_dt * P.rk_b[P.rk_nb - 1];

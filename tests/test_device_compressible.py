@@ -1461,10 +1461,18 @@ def test_rk_step_in_one_call_equals_stage_by_stage(dev, method, bcs, nx, ny, gra
     ng = 4
     meta = [nx, ny, ng, 1.0 / nx, 1.5 / ny, 1.4, 2, 1, 0.75, 0.85, 0.33, 0.1, grav, 0.8]
     solid = [int(b == "reflect") for b in bcs]
-    P, cfl = dev_params(meta, kernel_set=2, riemann=riemann, solid_xl=solid[0], solid_yl=solid[2], march_rows=16)
     a, b = RK_TABLEAU[method]
     ns = len(b)
     U0 = _rk_random_state(nx, ny, nx * ny + ns)
+    # (the contracted build defers the last increment of a stage start to the row's consumption:
+    # on the emulator its arithmetic is the bit-faithful one, so it is held to the same identity)
+    for fast in ((0, 1) if method in ("RK4", "TVD3") else (0,)):
+        _rk_one_call_vs_stages(dev, meta, riemann, solid, bcs, a, b, ns, U0, nx, ny, ng, fast)
+
+
+def _rk_one_call_vs_stages(dev, meta, riemann, solid, bcs, a, b, ns, U0, nx, ny, ng, fast):
+    P, cfl = dev_params(meta, kernel_set=2, riemann=riemann, solid_xl=solid[0], solid_yl=solid[2], march_rows=16,
+                        fast_math=fast)
     out = {}
     for fused in (0, 1):
         s = comp_state(dev, nx, ny, list(bcs))
@@ -1494,8 +1502,9 @@ def test_rk_step_in_one_call_equals_stage_by_stage(dev, method, bcs, nx, ny, gra
         assert out[0][1] == out[1][1]
         assert np.array_equal(out[0][0], out[1][0]), np.argwhere(out[0][0] != out[1][0])[:5]
     else:
-        assert np.abs(np.array(out[1][1]) / np.array(out[0][1]) - 1).max() <= TOL_EXACT
-        assert elementwise_close(out[1][0], out[0][0], TOL_EXACT)
+        tol = TOL_FAST if fast else TOL_EXACT
+        assert np.abs(np.array(out[1][1]) / np.array(out[0][1]) - 1).max() <= tol
+        assert elementwise_close(out[1][0], out[0][0], tol)
 
 
 def elementwise_close(a, b, tol):
