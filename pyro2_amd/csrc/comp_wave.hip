@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     // RKF: the LAST increment with a non-zero weight is added where the row is consumed, an
     // iteration after its load (loadK / addK below) -- added right behind the loads, inside
     // loadU, the sum waits for the row that was just requested: the stages ran at a VALU busy of
-    // 0.45 (profiles/r05_rk4096_pmc.json: 0.57-0.60 ms per stage against 0.46 for the plain
+    // 0.45 (first counter pass; 0.65 with this: profiles/r05_rk4096_pmc.json; 0.57-0.60 ms per stage against 0.46 for the plain
     // right-hand side).  Earlier increments (TVD3's second stage has two) are added eagerly;
     // the order of accumulation is the reference's either way.
     // (contracted build only: the bit-faithful one reads every row twice, and a second deferred
