@@ -25,7 +25,8 @@ def _parallel_cpu_suite(config):
         return
     if (config.getoption("markexpr", "") or "").replace(" ", "") != "notgpu":
         return
-    n = int(os.environ.get("PYRO_TEST_WORKERS", "4"))
+    # (default: the cores of the box less two, between 2 and 8 workers)
+    n = int(os.environ.get("PYRO_TEST_WORKERS", str(min(8, max(2, (os.cpu_count() or 4) - 2)))))
     if n <= 1 or not config.pluginmanager.hasplugin("xdist"):
         return
     if getattr(config.option, "numprocesses", None) or getattr(config.option, "dist", "no") != "no":
