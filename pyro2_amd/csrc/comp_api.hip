@@ -457,6 +457,7 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
     // the minimum of the last launch belongs to the state only if that launch advanced it
     s->next_cfl_min = (H.steps == max_steps && !(flagv & 1)) ? lastmin : -1.0;
     s->cfl_kind = 0;
+    s->ghost_by_rules = false;      // a new time level: its ghost cells are stale until the next fill
     if (s->next_cfl_min <= 0.0) s->cfl_is_global = false;
     pol->t = H.t; pol->dt_old = H.dt_old; pol->n = H.n;
     *steps_done = H.steps;
