@@ -23,6 +23,7 @@ _WS = os.environ.get("PYRO_WAVE_SCHED", "max-ilp")
 WAVE_SCHED = [] if _WS == "default" else ["-mllvm", f"-amdgpu-sched-strategy={_WS}"]
 
 ARCH = "gfx950"
+LAST_BUILD = None     # what the last build() call did: {"mode": "reused" | "compiled", ...} (__graft_entry__ prints it)
 COMMON = ["-std=c++17", "-fPIC", "-O3"]
 
 # (source, object name, extra flags).  The compressible kernels are built
@@ -83,9 +84,13 @@ def build(force=False, verbose=False):
     us = units()
     flagline = " ".join(EXTRA + FAST_EXTRA + WAVE_SCHED)
     libstamp = LIB + ".flags"
+    global LAST_BUILD
     if not force and not _stale(LIB, deps) and os.path.exists(libstamp) and \
             open(libstamp).read() == flagline:
+        LAST_BUILD = {"mode": "reused", "compiled_units": [], "library": LIB,
+                      "why": "the library in the tree is newer than every source and was built with these flags"}
         return LIB
+    compiled = []
 
     def compile_one(u):
         src, name, extra = u
@@ -104,6 +109,7 @@ def build(force=False, verbose=False):
         if verbose:
             print(line)
         subprocess.check_call(cmd)
+        compiled.append(name)
         with open(stamp, "w") as f:
             f.write(line)
         return obj
@@ -118,6 +124,7 @@ def build(force=False, verbose=False):
     subprocess.check_call(cmd)
     with open(libstamp, "w") as f:
         f.write(flagline)
+    LAST_BUILD = {"mode": "compiled", "compiled_units": sorted(compiled), "units": len(us), "library": LIB}
     return LIB
 
 
