@@ -37,6 +37,7 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # as pyro2_amd/__init__.py (before any HIP call)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -91,6 +92,17 @@ def parse():
                          "into config.scale_check, a mismatch is fatal.  On by default at --gpus > 1")
     ap.add_argument("--no-scale-check", dest="scale_check", action="store_false",
                     help="skip the bit-identity check of the decomposed run (--gpus > 1)")
+    ap.add_argument("--slab-of", type=int, default=0,
+                    help="ONE GPU: time one rank's slab of a --slab-of N rank run of the headline grid "
+                         "(nx / N rows x nx columns, both x neighbours = the rank itself over a 1-rank RCCL "
+                         "communicator: boundary strips first, halo exchange of the new rows on the second "
+                         "stream beside the interior strips, all-reduced CFL minimum, device-side stepping) "
+                         "-- the critical path of the N-GPU run, measurable on one GPU; prints its own line")
+    ap.add_argument("--slab-rank", type=int, default=None,
+                    help="--slab-of: which rank's rows of the Sedov initial condition (default: 0, ambient gas "
+                         "only, and N/2, with the blast)")
+    ap.add_argument("--march-rows", type=int, default=0,
+                    help="--slab-of: rows per strip of the row-marching kernel (0: the library's choice)")
     ap.add_argument("--host-dt", action="store_true",
                     help="step from the host (one dt read-back per step) instead of "
                          "pyrohip_comp_evolve")
@@ -449,6 +461,84 @@ class _Solo:
 
     def max(self, x):
         return x
+
+
+def bench_slab(args, ctx, device, defaults, nranks, ranks=None, nx=None, steps=20, warmup=5, single_ms=None,
+               march_rows=0):
+    """the critical path of the N-GPU headline run on ONE GPU.  One rank's slab
+    (nx / nranks rows x nx columns) steps exactly as it does in the decomposed run -- halo sides on
+    both cuts, boundary strips first, the exchange of the NEW boundary rows posted on the halo
+    stream / second communicator beside the interior strips, CFL minimum all-reduced on the device,
+    fill + dt policy + update enqueued by pyrohip_comp_evolve -- over a ONE-rank RCCL communicator
+    whose both neighbours are the rank itself (tests/test_zz_comm.py::
+    test_rccl_overlapped_halo_self_neighbour: that slab is a periodic problem).  What it cannot
+    show is the xGMI transfer time (2.1 MB per neighbour and direction) and the latency of an
+    8-rank all-reduce; everything a rank's own GPU does per step it does.
+    speedup_upper_bound = single-GPU ms per step of the whole grid / slab ms per step."""
+    from pyro2_amd.compressible.problems.sedov import sedov_state
+    from pyro2_amd.decomp import DtPolicy, RcclComm, SlabCompressible, SlabDecomp
+    nx = args.nx if nx is None else nx
+    ng = 4
+    had_comm = ctx.comm_size() > 0
+    if not had_comm:
+        ctx.comm_init(1, 0, device.Context.comm_unique_id())
+    out = {"workload": f"one rank's slab of compressible sedov {nx}x{nx} on {nranks} ranks: "
+                       f"{nx // nranks} rows x {nx} columns on ONE GPU, both x neighbours = the rank itself "
+                       "(1-rank RCCL communicator): boundary strips first, halo exchange on the second "
+                       "stream beside the interior strips, all-reduced CFL minimum, device-side stepping",
+           "ranks": {}}
+    try:
+        for r in (ranks if ranks is not None else (0, nranks // 2)):
+            dec = SlabDecomp(nx, nranks, r, periodic=False)
+            dec.lo = dec.hi = 0              # this GPU plays both neighbours
+            comm = RcclComm(ctx)
+            kw = dict(dx=1.0 / nx, dy=1.0 / nx, fast_math=defaults["fast_math"],
+                      kernel_set=defaults["kernel_set"], march_rows=march_rows)
+            slab = SlabCompressible(ctx, dec, nx, ["outflow"] * 4, kw, comm, ng=ng)
+            st = slab.state
+            for r0 in range(0, dec.nx_local + 2 * ng, 512):
+                nr = min(512, dec.nx_local + 2 * ng - r0)
+                st.upload_rows(r0, sedov_state(nx, nx, ng, 0.0, 1.0, 0.0, 1.0, 1.4, 0.01, 4,
+                                               i0=dec.i0 + r0, ni=nr))
+            pol = DtPolicy(tmax=1.0e9)      # (a slab of ambient gas alone takes large steps)
+            assert len(slab.evolve(pol, 0.8, warmup)) == warmup
+            ctx.sync()
+            t0 = time.perf_counter()
+            assert len(slab.evolve(pol, 0.8, steps)) == steps
+            ctx.sync()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            ctx.prof_enable(True)
+            slab.evolve(pol, 0.8, steps)
+            ctx.sync()
+            prof = ctx.prof_report()
+            ctx.prof_enable(False)
+            geo = device.comp_wave_geometry(dec.nx_local, nx, ng, ctx.info().get("compute_units", 0),
+                                            march_rows)
+            e = {"slab_ms_per_step": ms, "rows": dec.nx_local, "ic_rows_from": dec.i0,
+                 "kernel_ms": sum(v[1] for k, v in prof.items() if not k.startswith("comm:")) / steps,
+                 "halo_wait_ms": prof.get("comm:halo_wait", (0, 0.0))[1] / steps,
+                 "halo_sync_ms": prof.get("comm:halo_sync", (0, 0.0))[1] / steps,
+                 "allreduce_ms": prof.get("comm:allreduce_dt", (0, 0.0))[1] / steps,
+                 "kernels": {k: {"launches": n, "avg_ms": t / max(n, 1)} for k, (n, t) in prof.items()},
+                 "geometry": geo, "rounds": geo["wavefronts"] / max(geo["slots"], 1),
+                 "overlapped": bool(geo["overlap"]), "sim_time": pol.t}
+            if single_ms:
+                e["speedup_upper_bound"] = single_ms / ms
+            out["ranks"][str(r)] = e
+            del slab, st
+    finally:
+        ctx.comm_set_global_dt(False)
+        if not had_comm:
+            ctx.comm_destroy()
+    worst = max(v["slab_ms_per_step"] for v in out["ranks"].values())
+    out["slab_ms_per_step"] = worst
+    out["of_ranks"] = nranks
+    if single_ms:
+        out["single_gpu_ms_per_step"] = single_ms
+        out["speedup_upper_bound"] = single_ms / worst
+    out["note"] = ("slowest of the measured slabs; an upper bound of the strong-scaling factor: the xGMI "
+                   "transfers and the N-rank all-reduce latency are not in it")
+    return out
 
 
 def scale_check(args, dist, ctx, device, defaults, nx=2048, steps=12):
@@ -949,6 +1039,10 @@ def compact_line(out, full_path=None):
         line["ranks"]["predicted_ms_per_step"] = rk.get("predicted_ms_per_step")
         if "gpu_unique_ids_distinct" in rk:
             line["ranks"]["gpu_unique_ids_distinct"] = rk["gpu_unique_ids_distinct"]
+    pdn = out.get("pyro_driver")
+    if isinstance(pdn, dict):
+        line["pyro_driver"] = _pick(pdn, "ms_per_step", "value", "ratio_to_bare") if "error" not in pdn \
+            else {"error": str(pdn["error"])[:80]}
     also = out.get("also")
     if also:
         line["targets"] = targets_of(also)
@@ -998,6 +1092,14 @@ def targets_of(also):
     if isinstance(mg, dict):
         leg("mg_4096", mg, "value", "unit", "ms_per_vcycle", "ms_per_step")
     leg("incompressible_2048", also.get("incompressible"), "value", "ms_per_step")
+    sl = also.get("slab_of_8")
+    if isinstance(sl, dict):
+        if "error" in sl:
+            t["slab_of_8"] = {"error": str(sl["error"])[:80]}
+        else:
+            w = max(sl["ranks"].values(), key=lambda v: v["slab_ms_per_step"])
+            t["slab_of_8"] = dict(_pick(sl, "slab_ms_per_step", "speedup_upper_bound"),
+                                  **_pick(w, "halo_wait_ms", "kernel_ms", "rounds"))
     pd = also.get("pyro_driver")
     if isinstance(pd, dict):
         if "error" in pd:
@@ -1113,12 +1215,26 @@ def main():
     # kernel_set -1: the library picks (row-marching wavefront kernel from 2048^2 on)
     defaults = {"fast_math": 1 if args.fast_math is None else args.fast_math,
                 "kernel_set": -1 if args.kernel_set is None else args.kernel_set}
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-    except Exception:
-        pass
+    if world > 1 and dist.comm_kind == "rccl":
+        # pyro's class surface steps its slab of ONE problem over this communicator
+        # (pyro2_amd.decomp: grid_setup hands out slabs, fill_BC_all exchanges halo rows)
+        from pyro2_amd import decomp
+        device.Context._default = ctx
+        _rc = decomp.RcclComm(ctx)
+        ctx.comm_set_global_dt(False)
+        decomp.set_decomposition(_rc, dist.rank, world)
+    if args.slab_of > 1:
+        if world != 1:
+            sys.exit("bench.py: --slab-of measures one slab on ONE GPU (--gpus 1)")
+        rs = None if args.slab_rank is None else (args.slab_rank,)
+        r1 = None
+        if not args.no_also:       # the whole grid on this GPU: the numerator of the bound
+            r1 = bench_sedov(args, dist, ctx, device, defaults)
+        o = bench_slab(args, ctx, device, defaults, args.slab_of, rs, steps=args.steps, warmup=args.warmup,
+                       single_ms=(r1["elapsed"] / args.steps * 1e3) if r1 else None,
+                       march_rows=args.march_rows)
+        os.write(json_fd, (json.dumps(_rnd(o), separators=(",", ":")) + "\n").encode())
+        return
 
     # a decomposed run is checked against the single-domain one BEFORE anything is timed,
     # unless the caller says --no-scale-check
@@ -1182,6 +1298,24 @@ def main():
             "gpu_unique_ids_distinct": dev_distinct,
             "predicted_ms_per_step": PREDICTED_MS_16384.get(world) if args.nx == 16384 else None,
             "predicted_source": "DESIGN.md 6 (kernel / N x tail + ~0.1 ms all-reduce and small launches)"}
+    if world > 1 and dist.comm_kind == "rccl" and not args.no_also:
+        # the SAME workload through pyro's class surface -- every rank
+        # runs Pyro("compressible").initialize_problem("sedov") + run_sim() and steps ITS slab
+        # (COLLECTIVE: all ranks take part)
+        try:
+            pr_ = bench_pyro_run(ctx, device, "compressible", "sedov",
+                                 {"mesh.nx": args.nx, "mesh.ny": args.nx, "gpu.fast_math": defaults["fast_math"],
+                                  "gpu.kernel_set": defaults["kernel_set"]}, args.steps, args.warmup)
+            ms_ = dist.max(pr_["ms_per_step"])
+            out["pyro_driver"] = {
+                "workload": f"Pyro('compressible') sedov {args.nx}x{args.nx} through run_sim() on {world} "
+                            f"processes: ONE problem in x-slabs behind the class surface, {args.steps} steps "
+                            f"after {args.warmup} untimed ones", "ms_per_step": ms_,
+                "value": float(args.nx) * args.nx / (ms_ * 1e-3), "unit": "cell-updates/s",
+                "bare_c_abi_ms_per_step": out["ms_per_step"], "ratio_to_bare": out["ms_per_step"] / ms_}
+        except Exception as e:      # noqa: BLE001 -- recorded, never fatal for the headline
+            out["pyro_driver"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            dist.barrier()
     if dist.rank == 0:
         # roofline of the update kernels: algorithmic bytes of ONE rank's slab
         # per step / HIP-event time of that rank's kernels per step
@@ -1274,6 +1408,12 @@ def main():
                 bare = {"sedov_4096": (also.get("sedov_4096") or {}).get("ms_per_step"),
                         "advection": (also.get("advection") or {}).get("ms_per_step")}
                 leg("pyro_driver", lambda: bench_pyro_driver(ctx, device, bare, n_, k_))
+                if args.nx == 16384 or D > 1:
+                    # the 8-GPU run's critical path, measured on this one GPU (last: it brings up
+                    # a communicator and takes it down again)
+                    leg("slab_of_8", lambda: bench_slab(args, ctx, device, defaults, 8, nx=n_(args.nx, 256),
+                                                        steps=k_(20), warmup=k_(5),
+                                                        single_ms=out["ms_per_step"] if D == 1 else None))
                 out["also"] = also
             out["seconds_by_leg"] = legs_s
         emit(out, json_fd)

@@ -640,6 +640,14 @@ int pyrohip_state_set_neighbours(pyrohip_state *s, int rank_lo, int rank_hi);
 /* 1 if the last step posted the halo exchange of the state it produced and
    nothing has touched the state since (diagnostics / tests) */
 int pyrohip_state_halo_pending(pyrohip_state *s, int *flag);
+/* whole rows [i0, i0 + ni) of every variable of a state to / from one peer rank (ghost columns
+   included: a row is `pitch` contiguous doubles per variable) -- how the slabs of a decomposed
+   run are gathered for output (CellCenterData2d.write_data / Simulation.write of a decomposed
+   run, pyro/mesh/patch.py:750-788 writes ONE array per variable).  The calls of one collective
+   step are bracketed by pyrohip_comm_group(1) ... pyrohip_comm_group(0); sender and receiver
+   must name the same number of rows of states with the same ny and ng. */
+int pyrohip_state_send_rows(pyrohip_state *s, int i0, int ni, int peer);
+int pyrohip_state_recv_rows(pyrohip_state *s, int i0, int ni, int peer);
 int pyrohip_allreduce_min(pyrohip_ctx *ctx, double *value);
 int pyrohip_allreduce_max(pyrohip_ctx *ctx, double *value);
 /* sum of n doubles over the ranks, in place (n <= 16) */

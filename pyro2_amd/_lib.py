@@ -200,6 +200,8 @@ _PROTOS = {
     "pyrohip_comm_size": [_VP, C.POINTER(C.c_int)],
     "pyrohip_halo_exchange": [_VP, C.c_int, C.c_int],
     "pyrohip_state_set_neighbours": [_VP, C.c_int, C.c_int],
+    "pyrohip_state_send_rows": [_VP, C.c_int, C.c_int, C.c_int],
+    "pyrohip_state_recv_rows": [_VP, C.c_int, C.c_int, C.c_int],
     "pyrohip_state_halo_pending": [_VP, _IP],
     "pyrohip_allreduce_min": [_VP, _DP],
     "pyrohip_allreduce_max": [_VP, _DP],

@@ -13,7 +13,8 @@ class Simulation(NullSimulation):
     def initialize(self):
         """grid (ng = 4, advection/simulation.py:20), the single variable
         "density", then the problem's initial condition"""
-        my_grid = grid_setup(self.rp, ng=4)
+        # (x-slabs with one process per GPU: the halo rows travel in cc_data.fill_BC_all)
+        my_grid = grid_setup(self.rp, ng=4, decomposable=True)
         my_data = patch.CellCenterData2d(my_grid)
         bc = bc_setup(self.rp)[0]
         my_data.register_var("density", bc)
@@ -68,8 +69,8 @@ class Simulation(NullSimulation):
         (tracer particles ride along: the velocity field is constant, they never read the
         data)."""
         cc = self.cc_data
-        if type(self).evolve is not Simulation.evolve:
-            return False
+        if type(self).evolve is not Simulation.evolve or cc.slab is not None:
+            return False      # (a slab exchanges halo rows before every step: fill_BC_all)
         simple = ("outflow", "reflect-even", "reflect-odd", "periodic")
         if not all(b in simple for n in cc.names for b in cc.BCs[n].sides()):
             return False

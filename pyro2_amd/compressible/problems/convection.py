@@ -45,7 +45,8 @@ def init_data(my_data, rp):
     my_data.get_var("energy")[:, :] = p2d / (gamma - 1.0)
     # seed: random velocities of up to 5 % of the sound speed inside the atmosphere
     rng = np.random.default_rng(12345)
-    pert = 2.0 * rng.random(size=(g.qx, g.qy, 2)) - 1
+    # (an x-slab of a decomposed run takes its rows of the whole grid's random field)
+    pert = (2.0 * rng.random(size=(g.nx_global + 2 * g.ng, g.qy, 2)) - 1)[g.i0:g.i0 + g.qx]
     with np.errstate(invalid="ignore", divide="ignore"):
         cs = np.sqrt(gamma * p2d / np.asarray(dens))
     pert[:, :, 0] *= 0.05 * cs

@@ -67,10 +67,11 @@ def init_data(my_data, rp):
         ener[:, :] = 1.e-6 / (gamma - 1.0)
         ener[np.asarray(g.x2d) < rp.get_param("sedov.r_init")] = 1.e6
         return
-    U = sedov_state(g.nx, g.ny, g.ng, rp.get_param("mesh.xmin"), rp.get_param("mesh.xmax"),
+    # (an x-slab of a decomposed run holds rows [i0, i0 + qx) of the nx_global-row grid)
+    U = sedov_state(g.nx_global, g.ny, g.ng, rp.get_param("mesh.xmin"), rp.get_param("mesh.xmax"),
                     rp.get_param("mesh.ymin"), rp.get_param("mesh.ymax"),
                     rp.get_param("eos.gamma"), rp.get_param("sedov.r_init"),
-                    rp.get_param("sedov.nsub"))
+                    rp.get_param("sedov.nsub"), i0=g.i0, ni=g.qx)
     for n, name in enumerate(("density", "energy", "x-momentum", "y-momentum")):
         my_data.get_var(name)[:, :] = U[:, :, n]
 

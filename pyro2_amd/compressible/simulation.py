@@ -63,9 +63,11 @@ def prim_to_cons(q, gamma, ivars, myg):
 
 class Simulation(NullSimulation):
     spherical_ok = True   # derived solvers without the geometry terms clear this
+    decomposable = True   # x-slabs, one process per GPU (derived solvers with other steps clear this)
 
     def initialize(self, *, extra_vars=None, ng=4):
-        my_grid = grid_setup(self.rp, ng=ng, spherical_ok=type(self).spherical_ok)
+        my_grid = grid_setup(self.rp, ng=ng, spherical_ok=type(self).spherical_ok,
+                             decomposable=type(self).decomposable)
         my_data = self.data_class(my_grid)
         # a bare RuntimeParameters (the reference's unit tests build one by hand) may
         # not carry the solver's parameters yet: they are only needed from the first step on
@@ -120,6 +122,7 @@ class Simulation(NullSimulation):
             fast_math=opt("gpu.fast_math", 1), kernel_set=opt("gpu.kernel_set", -1),
             riemann=rp.get_param("compressible.riemann"),
             solid_xl=self.solid.xl, solid_yl=self.solid.yl,
+            avisc_xhi_interior=self._slab().avisc_xhi_interior if self.cc_data.slab is not None else 0,
             sponge=(rp.get_param("sponge.sponge_rho_begin"), rp.get_param("sponge.sponge_rho_full"),
                     rp.get_param("sponge.sponge_timescale"))
             if rp.get_param("sponge.do_sponge") else None,
@@ -135,6 +138,23 @@ class Simulation(NullSimulation):
             rate, prof = fn(self.cc_data.grid, self.rp)
             self._heat_cache = (float(rate), np.ascontiguousarray(prof, dtype=np.float64))
         return self._heat_cache
+
+    def _slab(self):
+        """decomposed run: the driver of this rank's x-slab (decomp.SlabCompressible around the
+        device state of cc_data: halo exchange before the ghost fill, global CFL minimum,
+        boundary strips first + overlapped exchange, device-side stepping); None otherwise"""
+        cc = self.cc_data
+        if cc.slab is None:
+            return None
+        if cc._slab_driver is None:
+            from ..decomp import SlabCompressible
+            sides = list(cc.BCs["density"].sides())
+            # (the device state is created, not touched: the boundary table does not depend on
+            # the data)
+            st = cc.device_state(fuse_fill=True)
+            cc._slab_driver = SlabCompressible(cc.ctx, cc.slab, cc.grid.ny, sides, None, cc.comm,
+                                               ng=cc.grid.ng, state=st)
+        return cc._slab_driver
 
     def _device_state(self, fuse_fill=False):
         """the state on the device, carrying the heating profile if there is one;
@@ -155,6 +175,10 @@ class Simulation(NullSimulation):
         """cfl * min(dx/(|u|+c), dy/(|v|+c)) over the whole array
         (compressible/simulation.py:267-288), reduced on the device"""
         cfl = self.rp.get_param("driver.cfl")
+        if self.cc_data.slab is not None:    # COLLECTIVE: the minimum over every rank's slab
+            self._device_state()
+            self.dt = self._slab().dt(float(cfl), self._params())
+            return
         st = self._device_state(fuse_fill=True)
         if not st.comp_dt_is_cached():       # the reduction reads the ghost cells too
             st = self._device_state()
@@ -210,9 +234,12 @@ class Simulation(NullSimulation):
         tm = self.tc.timer("evolve")
         tm.begin()
         if self._host_source():
+            if self.cc_data.slab is not None:
+                msg.fail("ERROR: host-evaluated source terms are not carried by a decomposed run")
             self._device_state()
             self._evolve_host_source()
         else:
+            self._slab()
             st = self._device_state(fuse_fill=True)
             P = self._params()
             P.fuse_fill = int(self.cc_data.take_pending_fill())
@@ -242,6 +269,11 @@ class Simulation(NullSimulation):
             return False
         if getattr(self, "_device_stepping_refused", False):
             return False
+        if cc.slab is not None:
+            # the exchange must live in the library (RCCL); hse meeting a periodic cut steps singly
+            from ..decomp import RcclComm
+            if not isinstance(cc.comm, RcclComm) or self._slab()._hse_wrap:
+                return False
         return self._params().kernel_set != 0
 
     def evolve_many(self, nsteps):
@@ -258,7 +290,11 @@ class Simulation(NullSimulation):
         tm.begin()
         st = self._device_state()
         try:
-            dts = st.comp_evolve(self._params(), float(rp.get_param("driver.cfl")), pol, int(nsteps))
+            if self.cc_data.slab is not None:     # COLLECTIVE
+                dts = self._slab().evolve(pol, float(rp.get_param("driver.cfl")), int(nsteps),
+                                          params=self._params())
+            else:
+                dts = st.comp_evolve(self._params(), float(rp.get_param("driver.cfl")), pol, int(nsteps))
         except PyroHipError as e:
             # the library's own fusability rules (e.g. a SphericalPolar grid too small for the
             # tile kernel, mixed boundary kinds on a side) are stricter than can_evolve_many's:

@@ -12,6 +12,7 @@ from ..util import msg
 
 class Simulation(CompressibleSimulation):
     spherical_ok = False   # compressible_rk/fluxes.py has no geometry terms
+    decomposable = False   # (the stages would each need a halo exchange: single domain)
 
     def initialize(self, *, extra_vars=None, ng=4):
         if self._rp_opt("compressible.well_balanced", 0):

@@ -55,10 +55,19 @@ int pyrohip_comm_init(pyrohip_ctx *c, int nranks, int rank, const char *unique_i
     c->rank = rank;
     // second communicator + stream for the overlapped halo exchange; without
     // them (old RCCL, split refused) the exchange stays on the main stream
+    // (the halo stream at the highest priority: the boundary strips of a step and the exchange
+    // behind them are dispatched ahead of the interior strips they run beside)
     ncclComm_t comm2 = nullptr;
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    int prio_mode = 2;   // 2: a stream of normal priority (hipStreamCreateWithFlags); 1 / 0: highest / lowest (developer experiments)
+    if (const char *e = getenv("PYRO_HALO_PRIO")) prio_mode = atoi(e);
+    if (prio_mode == 0) prio_greatest = prio_least;
     if (ncclCommSplit(comm, 0, rank, &comm2, nullptr) == ncclSuccess && comm2 != nullptr &&
-        hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) == hipSuccess &&
+        (prio_mode == 2 ? hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking)
+                        : hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, prio_greatest)) == hipSuccess &&
         hipEventCreateWithFlags(&c->ev_boundary, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&c->ev_bdone, hipEventDisableTiming) == hipSuccess &&
         hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming) == hipSuccess) {
         c->comm_halo = (void *)comm2;
     } else {
@@ -95,6 +104,7 @@ int pyrohip_comm_destroy(pyrohip_ctx *c)
     if (c->comm_stream) { (void)hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
     if (c->ev_boundary) { (void)hipEventDestroy(c->ev_boundary); c->ev_boundary = nullptr; }
     if (c->ev_halo) { (void)hipEventDestroy(c->ev_halo); c->ev_halo = nullptr; }
+    if (c->ev_bdone) { (void)hipEventDestroy(c->ev_bdone); c->ev_bdone = nullptr; }
     ncclCommDestroy((ncclComm_t)c->comm);
     c->comm = nullptr;
     return 0;
@@ -238,6 +248,39 @@ int pyrohip_mg_recv_rows(pyrohip_mg *m, int level, int var, int i0, int ni, int 
     return 0;
 }
 
+// whole rows of every variable of a state to / from one peer (gather of the slabs for output)
+static int state_rows(pyrohip_state *s, int i0, int ni, int peer, bool send)
+{
+    PYRO_REQUIRE(s, "NULL state");
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    PYRO_REQUIRE(c->comm != nullptr && peer >= 0 && peer < c->nranks, "bad peer / no communicator");
+    PYRO_REQUIRE(i0 >= 0 && ni >= 1 && i0 + ni <= g.qx, "rows out of range");
+    PYRO_TRY(comm_wait_halo(s));
+    const size_t cnt = (size_t)ni * g.pitch;
+    for (int n = 0; n < s->nvar; n++) {
+        double *a = s->d + (size_t)n * g.plane + (size_t)i0 * g.pitch;
+        if (send)
+            PYRO_CHECK_NCCL(ncclSend(a, cnt, ncclDouble, peer, (ncclComm_t)c->comm, c->stream));
+        else
+            PYRO_CHECK_NCCL(ncclRecv(a, cnt, ncclDouble, peer, (ncclComm_t)c->comm, c->stream));
+    }
+    return 0;
+}
+
+int pyrohip_state_send_rows(pyrohip_state *s, int i0, int ni, int peer)
+{
+    return state_rows(s, i0, ni, peer, true);
+}
+
+int pyrohip_state_recv_rows(pyrohip_state *s, int i0, int ni, int peer)
+{
+    PYRO_TRY(state_rows(s, i0, ni, peer, false));
+    s->next_cfl_min = -1.0;      // the data changed: no cached CFL minimum
+    s->ghost_by_rules = false;
+    return 0;
+}
+
 int pyrohip_comm_group(int begin)
 {
     if (begin) PYRO_CHECK_NCCL(ncclGroupStart());
@@ -312,6 +355,31 @@ int comm_post_halo(pyrohip_state *s, double *d)
     PYRO_CHECK_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
     PYRO_TRY(post_halo(s, d, s->nb_lo, s->nb_hi, (ncclComm_t)c->comm_halo, c->comm_stream));
     PYRO_CHECK_HIP(hipEventRecord(c->ev_halo, c->comm_stream));
+    return 0;
+}
+
+int comm_fork_boundary(pyrohip_state *s, hipStream_t *bs)
+{
+    pyrohip_ctx *c = s->ctx;
+    PYRO_CHECK_HIP(hipEventRecord(c->ev_boundary, c->stream));
+    PYRO_CHECK_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_boundary, 0));
+    *bs = c->comm_stream;
+    return 0;
+}
+
+int comm_post_halo_here(pyrohip_state *s, double *d)
+{
+    pyrohip_ctx *c = s->ctx;
+    PYRO_CHECK_HIP(hipEventRecord(c->ev_bdone, c->comm_stream));
+    PYRO_TRY(post_halo(s, d, s->nb_lo, s->nb_hi, (ncclComm_t)c->comm_halo, c->comm_stream));
+    PYRO_CHECK_HIP(hipEventRecord(c->ev_halo, c->comm_stream));
+    return 0;
+}
+
+int comm_join_boundary(pyrohip_state *s)
+{
+    pyrohip_ctx *c = s->ctx;
+    PYRO_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ev_bdone, 0));
     return 0;
 }
 

@@ -95,7 +95,7 @@ struct pyrohip_ctx {
     // dt all-reduce on `stream`
     void *comm_halo = nullptr;
     hipStream_t comm_stream = nullptr;
-    hipEvent_t ev_boundary = nullptr, ev_halo = nullptr;
+    hipEvent_t ev_boundary = nullptr, ev_halo = nullptr, ev_bdone = nullptr;
     int nranks = 1, rank = 0;
     bool global_cfl = false;  // all-reduce the step kernels' CFL minimum on the device
     int num_cus = 0;
@@ -105,15 +105,17 @@ namespace pyro {
 struct ProfScope {
     pyrohip_ctx *c;
     hipEvent_t b = nullptr;
-    ProfScope(pyrohip_ctx *c_, const char *name) : c(c_)
+    hipStream_t st;
+    // (on: another stream of the context -- the boundary strips of a slab run on the halo stream)
+    ProfScope(pyrohip_ctx *c_, const char *name, hipStream_t on = nullptr) : c(c_), st(on ? on : c_->stream)
     {
         if (!c->prof.on) return;
         hipEvent_t a;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { b = nullptr; return; }
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, st);
         c->prof.recs.push_back(ProfRec{name, a, b});
     }
-    ~ProfScope() { if (b) (void)hipEventRecord(b, c->stream); }
+    ~ProfScope() { if (b) (void)hipEventRecord(b, st); }
 };
 }  // namespace pyro
 
@@ -127,6 +129,19 @@ bool comm_can_overlap(const pyrohip_state *s);
 // the state's) with the state's neighbours on the halo stream: it starts when
 // everything queued on the context's stream so far is done and signals ev_halo
 int comm_post_halo(pyrohip_state *s, double *d);
+// The boundary strips of a slab's step run on the halo stream, BESIDE the interior strips on the
+// context's stream (two launches in a row on one stream cost the first one's under-occupancy: 586
+// wavefronts on 2048 slots for a whole strip time, 0.21 of 1.5 ms on a 2048 x 16384 slab,
+// profiles/r06_slab2048x16384_*):
+//   comm_fork_boundary: the halo stream waits for everything queued on the context's stream;
+//     *bs = the stream to launch the boundary strips on (the context's own when there is no halo
+//     stream: the emulator);
+//   comm_post_halo_here: after that launch -- marks the boundary strips done (ev_bdone), posts the
+//     exchange of the new boundary rows of the planes at d behind them, signals ev_halo;
+//   comm_join_boundary: the context's stream waits for the boundary strips (their CFL partials).
+int comm_fork_boundary(pyrohip_state *s, hipStream_t *bs);
+int comm_post_halo_here(pyrohip_state *s, double *d);
+int comm_join_boundary(pyrohip_state *s);
 // a posted halo exchange writes the state's ghost rows from the halo stream: whoever
 // reads or writes the state's memory on the context's stream (accessors, ghost fill,
 // destroy) orders that stream behind it first.  No-op when nothing is pending.
@@ -141,6 +156,12 @@ int fill_bc_planes(pyrohip_state *s, double *planes, int n0, int cnt);
     do {                                                                          \
         ::pyro::ProfScope _ps((c), (name));                                       \
         hipLaunchKernelGGL(kern, (grid), (block), (shmem), (c)->stream, __VA_ARGS__); \
+    } while (0)
+// ... on another stream of the context
+#define PYRO_LAUNCH_ON(c, strm, name, kern, grid, block, shmem, ...)              \
+    do {                                                                          \
+        ::pyro::ProfScope _ps((c), (name), (strm));                               \
+        hipLaunchKernelGGL(kern, (grid), (block), (shmem), (strm), __VA_ARGS__);  \
     } while (0)
 
 namespace pyro {

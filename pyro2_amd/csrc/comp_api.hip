@@ -173,13 +173,16 @@ __global__ __launch_bounds__(256) void k_fill_frame2(const double *src, double *
     }
 }
 
-static bool frame_fill_ok(const pyrohip_state *s)
+// (x sides of a slab that are cuts -- PYROHIP_BC_HALO -- are identity maps: the halo rows are data
+// that arrived with the exchange, the y rule runs along them like along an interior row and the
+// other buffer's frame takes a copy, which the exchange posted by the coming step overwrites)
+static bool frame_fill_ok(const pyrohip_state *s, bool halo_ok = false)
 {
-    if (s->nvar != 4 || s->nb_set || s->user_bc || s->ramp_bc || s->sph || !s->alt_base) return false;
+    if (s->nvar != 4 || (s->nb_set && !halo_ok) || s->user_bc || s->ramp_bc || s->sph || !s->alt_base) return false;
     for (int k = 0; k < 16; k++) {
         const int b = s->bc[k];
         if (b != PYROHIP_BC_OUTFLOW && b != PYROHIP_BC_REFLECT_EVEN && b != PYROHIP_BC_REFLECT_ODD &&
-            b != PYROHIP_BC_PERIODIC)
+            b != PYROHIP_BC_PERIODIC && !(halo_ok && (k % 4) < 2 && b == PYROHIP_BC_HALO))
             return false;
     }
     return true;
@@ -343,7 +346,7 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
         pf.fuse_fill = (fuse && !first) ? 1 : 0;
         s->frame_prefilled = false;
         if (rc == 0 && !pf.fuse_fill) {
-            if (wave && frame_fill_ok(s)) {      // fill + the other buffer's ghost frame: one launch
+            if (wave && frame_fill_ok(s, true)) {      // fill + the other buffer's ghost frame: one launch
                 const Geom &g = s->g;
                 const int rows_per_block = 256 / (2 * g.ng);
                 const int nblk = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + rows_per_block - 1) / rows_per_block;

@@ -970,22 +970,55 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         {k_ctu_wave<2, false>, k_ctu_wave<2, true>}};
     const int solver = (p->riemann == 1 || p->riemann == 2) ? p->riemann : 0;
     const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
-    if (post && wg.overlap) {
-        // slab of a decomposed run: the first and the last strip of
-        // rows -- the rows the neighbours need as their next halo -- go first; their
-        // exchange is posted on the halo stream and runs beside the interior strips
+    static const int slab_mode = getenv("PYRO_SLAB_MODE") ? atoi(getenv("PYRO_SLAB_MODE")) : 1;   // developer experiments
+    if (post && wg.overlap && slab_mode == 0) {
+        // round 5: the boundary strips first, the interior strips behind them on the same stream
         P.sb_first = 0; P.sb_step = nsb - 1;
         P.nunits = 2 * P.ncb;
         P.prio_duty = wave_prio_duty(P.nunits, 4 * PYRO_WAVE_MINW * cus);
         PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((P.nunits + 7) / 8)), dim3(64), WLDS_BYTES,
                     (const double *)Uin, Uout, g, P, s->d_flag, part, S);
-        fused_copy_frame(s);           // old ghost frame -> new buffer, BEFORE the halos land in it
+        if (!s->frame_prefilled) fused_copy_frame(s);   // old ghost frame -> new buffer, BEFORE the halos land in it
+        s->frame_prefilled = false;
         PYRO_TRY(comm_post_halo(s, Uout));
         P.sb_first = 1; P.sb_step = 1;
         P.nunits = (nsb - 2) * P.ncb;
         P.prio_duty = wave_prio_duty(P.nunits, 4 * PYRO_WAVE_MINW * cus);
         PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((P.nunits + 7) / 8)), dim3(64),
                     WLDS_BYTES, (const double *)Uin, Uout, g, P, s->d_flag, part, S);
+        const double *dmin;
+        PYRO_TRY(fused_tail(s, part, nwg, true, &dmin, S != nullptr));
+        int rc = 0;
+        if (S) { fused_swap(s); *dmin_out = dmin; }
+        else rc = fused_sync(s, dmin);
+        s->halo_pending = (rc == 0);
+        return rc;
+    }
+    if (post && wg.overlap) {
+        // slab of a decomposed run: the first and the last strip of rows -- the
+        // rows the neighbours need as their next halo -- are a launch of their own on the halo
+        // stream (highest priority: dispatched first), their exchange is posted behind them
+        // there, and the interior strips run BESIDE both on the context's stream.  (Round 5 ran
+        // the two launches one after the other: the boundary launch held 586 of 2048 wavefront
+        // slots for a whole strip time.)
+        // old ghost frame -> new buffer, BEFORE the halos land in it (device-side stepping: the
+        // fill before this step has written it already, comp_api.hip: k_fill_frame2)
+        if (!s->frame_prefilled) fused_copy_frame(s);
+        s->frame_prefilled = false;
+        hipStream_t bs = nullptr;
+        PYRO_TRY(comm_fork_boundary(s, &bs));
+        P.sb_first = 0; P.sb_step = nsb - 1;
+        P.nunits = 2 * P.ncb;
+        P.prio_duty = 0;               // (the pair of a SIMD may belong to the other launch)
+        PYRO_LAUNCH_ON(c, bs, "k_ctu_wave_boundary", kernels[solver][std_rec], dim3(8 * ((P.nunits + 7) / 8)),
+                       dim3(64), WLDS_BYTES, (const double *)Uin, Uout, g, P, s->d_flag, part, S);
+        PYRO_TRY(comm_post_halo_here(s, Uout));
+        P.sb_first = 1; P.sb_step = 1;
+        P.nunits = (nsb - 2) * P.ncb;
+        P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus);
+        PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((P.nunits + 7) / 8)), dim3(64),
+                    WLDS_BYTES, (const double *)Uin, Uout, g, P, s->d_flag, part, S);
+        PYRO_TRY(comm_join_boundary(s));       // the minimum below reads the boundary strips' partials
         const double *dmin;
         PYRO_TRY(fused_tail(s, part, nwg, true, &dmin, S != nullptr));
         int rc = 0;
@@ -1023,7 +1056,7 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
     PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((nwg + 7) / 8)), dim3(64), WLDS_BYTES,
                 (const double *)Uin, Uout, g, P, s->d_flag, part, S);
     if (post) {        // too few strips to overlap: the exchange follows the whole update
-        fused_copy_frame(s);
+        if (!s->frame_prefilled) fused_copy_frame(s);
         PYRO_TRY(comm_post_halo(s, Uout));
     }
     const double *dmin;

@@ -64,13 +64,32 @@ static __global__ void k_min_stage(const double *__restrict__ partial, int nb,
     if (threadIdx.x == 0) stage[blockIdx.x] = m;
 }
 
+// ... up to 32k partials (the row-marching kernels: one per wavefront) in ONE launch: a single
+// workgroup of 1024 threads, four loads in flight each -- a launch and its gap less per step
+// where the minimum cannot ride on the next policy kernel (slabs: it is all-reduced first)
+static __global__ __launch_bounds__(1024) void k_min_one(const double *__restrict__ partial, int nb,
+                                                         double *__restrict__ out)
+{
+    double m0 = INFINITY, m1 = INFINITY, m2 = INFINITY, m3 = INFINITY;
+    int b = threadIdx.x;
+    for (; b + 3 * 1024 < nb; b += 4 * 1024) {
+        m0 = fmin(m0, partial[b]); m1 = fmin(m1, partial[b + 1024]);
+        m2 = fmin(m2, partial[b + 2048]); m3 = fmin(m3, partial[b + 3072]);
+    }
+    for (; b < nb; b += 1024) m0 = fmin(m0, partial[b]);
+    const double m = block_reduce_min(fmin(fmin(m0, m1), fmin(m2, m3)));
+    if (threadIdx.x == 0) *out = m;
+}
+
 constexpr int kMinStageBlocks = 256;
 // scratch needed behind the nb partials: kMinStageBlocks + 1 doubles; the
 // result lands in part[nb + kMinStageBlocks]
 inline double *launch_min_reduce(hipStream_t stream, double *part, int nb)
 {
     double *stage = part + nb, *out = part + nb + kMinStageBlocks;
-    if (nb > 4 * kMinStageBlocks) {
+    if (nb > 4 * kMinStageBlocks && nb <= 32768) {
+        hipLaunchKernelGGL(k_min_one, dim3(1), dim3(1024), 0, stream, (const double *)part, nb, out);
+    } else if (nb > 4 * kMinStageBlocks) {
         hipLaunchKernelGGL(k_min_stage, dim3(kMinStageBlocks), dim3(256), 0, stream,
                            (const double *)part, nb, stage);
         hipLaunchKernelGGL(k_min_stage, dim3(1), dim3(256), 0, stream, (const double *)stage,

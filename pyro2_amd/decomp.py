@@ -8,9 +8,143 @@ min all-reduce of dt reproduce the single-domain result bit for bit, provided
 the artificial-viscosity coefficient is also computed on slab faces that are
 interior to the global grid.
 """
+import os
+import time
+
 import numpy as np
 
 from ._lib import BC_CODE, BC_HALO
+
+
+# ---- the decomposition the class surface uses -----------------------------------------------
+# pyro's driver (pyro/pyro_sim.py:182-189) builds ONE Simulation per process.  Under a launcher
+# that starts one process per GPU (RANK / WORLD_SIZE / LOCAL_RANK in the environment, e.g.
+# `python -m torch.distributed.run --nproc-per-node 8 -m pyro2_amd.pyro_sim compressible sedov
+# inputs.sedov`) every process then builds the Simulation of ITS x-slab of the one problem:
+# grid_setup() hands out the slab's Grid2d, CellCenterData2d exchanges halo rows in fill_BC_all,
+# compute_timestep takes the global CFL minimum, write() gathers -- see simulation_null.py,
+# mesh/patch.py.  What is in force is kept here.
+
+class Decomposition:
+    """rank / nranks of this process and how to get the object that moves halo rows
+    (`comm_for(ctx)`: RcclComm in the product, a gloo transport in the CPU tests)"""
+
+    def __init__(self, comm, rank, nranks):
+        self.rank, self.nranks = int(rank), int(nranks)
+        self._comm = comm            # a comm object, or a factory taking the device Context
+        self._made = {}
+
+    def comm_for(self, ctx):
+        if not callable(self._comm):
+            return self._comm
+        if id(ctx) not in self._made:
+            self._made[id(ctx)] = self._comm(ctx)
+        return self._made[id(ctx)]
+
+
+_current = None        # set_decomposition() / the launcher's environment
+_env_tried = False
+
+
+def set_decomposition(comm, rank=0, nranks=1):
+    """install (comm = None: remove) the x-slab decomposition every Simulation made from here
+    on uses.  `comm`: an object with halo_exchange(state, lo, hi) / allreduce_min(x) / gather
+    (RcclComm, tests: HostStagedComm) or a factory `comm(ctx)` returning one."""
+    global _current, _env_tried
+    _current = None if comm is None else Decomposition(comm, rank, nranks)
+    _env_tried = comm is not None
+
+
+def _uid_rendezvous(rank, make_uid, timeout=300.0):
+    """rank 0's RCCL unique id to every process of ONE node without torch / MPI: a file under
+    /tmp named after the launcher (parent process id, MASTER_PORT, restart count), written
+    atomically by rank 0.  PYRO_COMM_ID_FILE names the file for launchers whose workers do not
+    share a parent."""
+    path = os.environ.get("PYRO_COMM_ID_FILE")
+    if not path:
+        tag = "_".join(str(x) for x in (os.getppid(), os.environ.get("MASTER_PORT", "0"),
+                                        os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"),
+                                        os.environ.get("TORCHELASTIC_RUN_ID", "none")))
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pyrohip_uid_{tag}")
+    if rank == 0:
+        uid = make_uid()
+        tmp = f"{path}.{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        import atexit
+        atexit.register(lambda: os.path.exists(path) and os.remove(path))
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if uid:
+                return uid
+        except OSError:
+            pass
+        if time.time() - t0 > timeout:
+            raise RuntimeError(f"no RCCL unique id from rank 0 after {timeout:.0f} s ({path})")
+        time.sleep(0.01)
+
+
+def _from_environment():
+    """one process per GPU under a launcher: RCCL communicator over all WORLD_SIZE ranks on the
+    default context (device LOCAL_RANK); None in a single process"""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None
+    rank = int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL between processes)
+    from . import device
+    ndev = device.device_count()
+    if ndev < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        # fewer GPUs than ranks: a debugging set-up (the launcher tried on a one-GPU box).  RCCL
+        # refuses two ranks on one device of one host, so every rank names itself a host of its
+        # own and the communicator runs over the socket transport: same calls, none of the
+        # bandwidth.  Never silently.
+        if os.environ.get("PYRO_SHARE_GPUS") != "1":
+            raise RuntimeError(f"{world} processes but {ndev} GPU(s): one process per GPU is the "
+                               "contract (PYRO_SHARE_GPUS=1 lets the ranks share for debugging, "
+                               "gpu.decompose=0 runs undecomposed copies)")
+        os.environ.setdefault("NCCL_HOSTID", f"pyro2amd-rank{rank}")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
+        os.environ.setdefault("NCCL_P2P_DISABLE", "1")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    ctx = device.Context.default(device_id=local % max(ndev, 1))
+    if ctx.comm_size() == 0:
+        uid = _uid_rendezvous(rank, device.Context.comm_unique_id)
+        ctx.comm_init(world, rank, uid)
+    if ctx.comm_size() != world:
+        raise RuntimeError(f"RCCL reports {ctx.comm_size()} ranks, the launcher {world}")
+    comm = RcclComm(ctx)
+    return Decomposition(lambda c: comm if c is ctx else RcclComm(c), rank, world)
+
+
+def active_decomposition(rp=None):
+    """the Decomposition in force, or None.  gpu.decompose: -1 (default) = decompose when a
+    decomposition is installed or the launcher's environment names more than one rank, 0 = never
+    (every process runs the whole problem, as the reference would under such a launcher),
+    1 = required (an error without ranks)."""
+    global _current, _env_tried
+    want = -1
+    if rp is not None:
+        try:
+            want = int(rp.get_param("gpu.decompose"))
+        except (KeyError, RuntimeError, ValueError, AttributeError):
+            want = -1
+    if want == 0:
+        return None
+    if _current is None and not _env_tried:
+        _env_tried = True
+        _current = _from_environment()
+    if _current is None and want == 1:
+        raise RuntimeError("gpu.decompose = 1 but there is one process only: start one process "
+                           "per GPU (RANK / WORLD_SIZE / LOCAL_RANK, e.g. torch.distributed.run) "
+                           "or call pyro2_amd.decomp.set_decomposition()")
+    return _current if _current is not None and _current.nranks > 1 else None
 
 
 class SlabDecomp:
@@ -90,6 +224,35 @@ class RcclComm:
             return state.comp_dt(params, cfl)
         return self.allreduce_min(state.comp_dt(params, cfl))
 
+    def gather(self, state, dec):
+        """COLLECTIVE: the slabs of every rank -> rank 0's host array (qx_global, qy, nvar)
+        (x ghost rows of the two end slabs included); None on the other ranks.  Device to
+        device over RCCL into a scratch state of the sender's shape, then one download."""
+        from . import device
+        from ._lib import check, lib
+        ng = state.ng
+        if dec.rank != 0:
+            check(lib().pyrohip_comm_group(1))
+            try:
+                state.send_rows(0, state.qx, 0)
+            finally:
+                check(lib().pyrohip_comm_group(0))
+            return None
+        out = np.empty((dec.nx + 2 * ng, state.qy, state.nvar))
+        out[:state.qx] = state.download()
+        for r in range(1, dec.nranks):
+            tmp = device.DeviceState(self.ctx, dec.counts[r], state.ny, ng,
+                                     [["outflow"] * 4] * state.nvar)
+            check(lib().pyrohip_comm_group(1))
+            try:
+                tmp.recv_rows(0, tmp.qx, r)
+            finally:
+                check(lib().pyrohip_comm_group(0))
+            i0 = sum(dec.counts[:r])
+            out[i0 + ng:i0 + tmp.qx] = tmp.download()[ng:]
+            del tmp
+        return out
+
 
 class NoComm:
     """single rank"""
@@ -108,8 +271,12 @@ class SlabCompressible:
     The driver's dt policy (simulation_null.py:222-244) is applied to the
     GLOBAL minimum, so every rank takes the same step."""
 
-    def __init__(self, ctx, decomp, ny, bcs, params_kw, comm, ng=4, user_bc=None):
-        """user_bc: (gamma, grav, dy, (ambient rho, u, v, p)) for the hse / ambient
+    def __init__(self, ctx, decomp, ny, bcs, params_kw, comm, ng=4, user_bc=None, state=None):
+        """state: an existing DeviceState of the slab (boundary table from
+        `decomp.comp_var_bcs`, user boundary data set by its owner -- CellCenterData2d behind the
+        class surface); params_kw may then be None (the caller passes its own parameter block
+        to dt() / evolve()).
+        user_bc: (gamma, grav, dy, (ambient rho, u, v, p)) for the hse / ambient
         boundaries on the y sides (compressible/BC.py).  They decompose as they are:
         the halo rows travel whole, WITH the neighbour's y ghost cells, and the y fill
         treats halo rows like interior rows.  One quirk of the reference needs care on
@@ -117,20 +284,26 @@ class SlabCompressible:
         hse energy of the x ghost rows is built from momenta ghost rows of the previous
         step (`_exchange_fill_wrapped_hse`)."""
         from . import device
-        if any(b in ("hse", "ambient") for b in bcs) and user_bc is None:
+        if any(b in ("hse", "ambient") for b in bcs) and user_bc is None and state is None:
             raise ValueError("hse / ambient boundaries need user_bc = (gamma, grav, dy, ambient)")
         self.dec, self.comm = decomp, comm
-        self.state = device.DeviceState(ctx, decomp.nx_local, ny, ng, decomp.comp_var_bcs(bcs))
-        if user_bc is not None:
-            self.state.set_user_bc(*user_bc)
-        self._hse_wrap = user_bc is not None and "hse" in bcs[2:] and \
-            (decomp.wrap_lo or decomp.wrap_hi)
-        kw = dict(params_kw)
+        if state is None:
+            self.state = device.DeviceState(ctx, decomp.nx_local, ny, ng, decomp.comp_var_bcs(bcs))
+            if user_bc is not None:
+                self.state.set_user_bc(*user_bc)
+        else:
+            self.state = state
+        self._hse_wrap = "hse" in bcs[2:] and (decomp.wrap_lo or decomp.wrap_hi)
         # the artificial viscosity lives on the faces ilo ... ihi of the GLOBAL grid
         # (interface.py:312-364): a slab computes it on its upper face when that face is an
         # interior cut, not when it is the periodic wrap-around (= global face ihi + 1)
-        kw["avisc_xhi_interior"] = int(decomp.hi >= 0 and not decomp.wrap_hi)
-        self.params = device.make_comp_params(**kw)
+        self.avisc_xhi_interior = int(decomp.hi >= 0 and not decomp.wrap_hi)
+        if params_kw is not None:
+            kw = dict(params_kw)
+            kw["avisc_xhi_interior"] = self.avisc_xhi_interior
+            self.params = device.make_comp_params(**kw)
+        else:
+            self.params = None
         # boundary strips first + halo exchange beside the interior strips (kernel_set 2)
         # (not where a wrap-around side meets an hse boundary: that path rewrites halo rows
         # from the host between the steps, _exchange_fill_wrapped_hse)
@@ -161,7 +334,7 @@ class SlabCompressible:
         self.modified()
         self.state.upload_rows(i0, data)
 
-    def evolve(self, policy, cfl, nsteps):
+    def evolve(self, policy, cfl, nsteps, params=None):
         """nsteps of step() enqueued on the device without a host round trip per step
         (pyrohip_comp_evolve: halo exchange, ghost fill, dt policy and update kernels
         back to back; one synchronisation at the end).  Needs the communication inside
@@ -174,7 +347,7 @@ class SlabCompressible:
         if isinstance(self.comm, RcclComm) and (self.dec.lo >= 0 or self.dec.hi >= 0):
             self.state.set_neighbours(self.dec.lo, self.dec.hi)
             self._rearm = False
-        return self.state.comp_evolve(self.params, cfl, policy, nsteps)
+        return self.state.comp_evolve(self.params if params is None else params, cfl, policy, nsteps)
 
     def _exchange_fill_wrapped_hse(self):
         """halo exchange + ghost fill where a wrap-around side meets an hse boundary.
@@ -207,7 +380,9 @@ class SlabCompressible:
         st.fill_bc(2)
         st.fill_bc(3)
 
-    def step(self, policy, cfl):
+    def fill(self):
+        """COLLECTIVE: CellCenterData2d.fill_BC_all of a slab -- halo rows from the x
+        neighbours, then the y / physical ghost fill (the order of array_indexer.py:150-274)"""
         if self._hse_wrap:
             self._exchange_fill_wrapped_hse()
         else:
@@ -216,10 +391,17 @@ class SlabCompressible:
                 self.state.set_neighbours(self.dec.lo, self.dec.hi)
                 self._rearm = False
             self.state.fill_bc()
+
+    def dt(self, cfl, params=None):
+        """COLLECTIVE: the CFL time step of the GLOBAL state (method_compute_timestep)"""
+        params = self.params if params is None else params
         if hasattr(self.comm, "dt_min"):
-            dt = policy(self.comm.dt_min(self.state, self.params, cfl))
-        else:
-            dt = policy(self.comm.allreduce_min(self.state.comp_dt(self.params, cfl)))
+            return self.comm.dt_min(self.state, params, cfl)
+        return self.comm.allreduce_min(self.state.comp_dt(params, cfl))
+
+    def step(self, policy, cfl):
+        self.fill()
+        dt = policy(self.dt(cfl))
         self.state.comp_step(self.params, dt)
         policy.advance(dt)
         return dt

@@ -111,6 +111,11 @@ class Context:
         with self.lock:
             check(self._l.pyrohip_comm_init(self.h, nranks, rank, unique_id))
 
+    def comm_destroy(self):
+        """drop the RCCL communicator(s) of this context (a no-op without one)"""
+        with self.lock:
+            check(self._l.pyrohip_comm_destroy(self.h))
+
     def comm_size(self):
         """rank count of the communicator as RCCL reports it (0: none)"""
         n = C.c_int()
@@ -541,6 +546,16 @@ class DeviceState:
     def halo_exchange(self, rank_lo, rank_hi):
         with self.ctx.lock:
             check(self._l.pyrohip_halo_exchange(self.h, int(rank_lo), int(rank_hi)))
+
+    def send_rows(self, i0, ni, peer):
+        """whole rows [i0, i0 + ni) of every variable to a peer rank (RCCL; inside a
+        pyrohip_comm_group bracket)"""
+        with self.ctx.lock:
+            check(self._l.pyrohip_state_send_rows(self.h, int(i0), int(ni), int(peer)))
+
+    def recv_rows(self, i0, ni, peer):
+        with self.ctx.lock:
+            check(self._l.pyrohip_state_recv_rows(self.h, int(i0), int(ni), int(peer)))
 
 
 def make_comp_params(dx, dy, gamma=1.4, limiter=2, use_flattening=1, z0=0.75,

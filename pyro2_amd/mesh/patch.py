@@ -29,18 +29,34 @@ class Grid2d:
 
     coord_type = None
 
-    def __init__(self, nx, ny, *, ng=1, xmin=0.0, xmax=1.0, ymin=0.0, ymax=1.0):
-        self.nx, self.ny, self.ng = int(nx), int(ny), int(ng)
-        self.qx, self.qy = int(2 * ng + nx), int(2 * ng + ny)
+    def __init__(self, nx, ny, *, ng=1, xmin=0.0, xmax=1.0, ymin=0.0, ymax=1.0, slab=None):
+        """slab: a decomp.SlabDecomp -- this rank's x-slab of the nx x ny grid (one process per
+        GPU).  The object then describes rows [i0, i0 + nx_local) of the global
+        grid: `nx`, `qx`, `ilo`, `ihi` and every array are the SLAB's, `xmin` / `xmax` / `dx`
+        stay the global ones and the coordinates are those of the global rows, bit for bit (the
+        global row number goes through the reference's expression), so a problem's init_data
+        fills a slab exactly as it fills those rows of the whole grid.  `nx_global` / `i0` tell
+        the two apart (nx / 0 on an undecomposed grid)."""
+        self.slab = slab
+        self.nx_global = int(nx)
+        self.i0 = 0 if slab is None else int(slab.i0)
+        if slab is not None:
+            if slab.nx != int(nx):
+                raise ValueError("the slab decomposition belongs to another grid")
+            nx_here = slab.nx_local
+        else:
+            nx_here = int(nx)
+        self.nx, self.ny, self.ng = int(nx_here), int(ny), int(ng)
+        self.qx, self.qy = int(2 * ng + self.nx), int(2 * ng + ny)
         self.xmin, self.xmax, self.ymin, self.ymax = xmin, xmax, ymin, ymax
         self.ilo, self.ihi = self.ng, self.ng + self.nx - 1
         self.jlo, self.jhi = self.ng, self.ng + self.ny - 1
         self.ic = self.ilo + self.nx // 2 - 1
         self.jc = self.jlo + self.ny // 2 - 1
-        # 1-d coordinates, same expressions as patch.py:121-134
-        self.dx = (xmax - xmin) / nx
-        self.xl = (np.arange(self.qx) - ng) * self.dx + xmin
-        self.xr = (np.arange(self.qx) + 1.0 - ng) * self.dx + xmin
+        # 1-d coordinates, same expressions as patch.py:121-134 (on the global row numbers)
+        self.dx = (xmax - xmin) / self.nx_global
+        self.xl = (np.arange(self.i0, self.i0 + self.qx) - ng) * self.dx + xmin
+        self.xr = (np.arange(self.i0, self.i0 + self.qx) + 1.0 - ng) * self.dx + xmin
         self.x = 0.5 * (self.xl + self.xr)
         self.dy = (ymax - ymin) / ny
         self.yl = (np.arange(self.qy) - ng) * self.dy + ymin
@@ -79,7 +95,9 @@ class Grid2d:
 
     def __eq__(self, other):
         keys = ("nx", "ny", "ng", "xmin", "xmax", "ymin", "ymax")
-        return all(getattr(self, k) == getattr(other, k) for k in keys)
+        return all(getattr(self, k) == getattr(other, k) for k in keys) and \
+            (getattr(self, "i0", 0), getattr(self, "nx_global", self.nx)) == \
+            (getattr(other, "i0", 0), getattr(other, "nx_global", getattr(other, "nx", None)))
 
     __hash__ = None
 
@@ -88,8 +106,8 @@ class Cartesian2d(Grid2d):
     """Cartesian geometry: Lx = dx, Ly = dy, Ax = Ly, Ay = Lx, V = dx dy
     (patch.py:192-239); the constant 2-d arrays are built on demand"""
 
-    def __init__(self, nx, ny, *, ng=1, xmin=0.0, xmax=1.0, ymin=0.0, ymax=1.0):
-        super().__init__(nx, ny, ng=ng, xmin=xmin, xmax=xmax, ymin=ymin, ymax=ymax)
+    def __init__(self, nx, ny, *, ng=1, xmin=0.0, xmax=1.0, ymin=0.0, ymax=1.0, slab=None):
+        super().__init__(nx, ny, ng=ng, xmin=xmin, xmax=xmax, ymin=ymin, ymax=ymax, slab=slab)
         self.coord_type = 0
 
     def _const(self, key, value):
@@ -234,6 +252,13 @@ class CellCenterData2d:
         self._root = None
         self._root_refs = 0
         self._warned_views = False
+        # x-slab of a decomposed run (grid.slab: decomp.SlabDecomp): halo rows from the x
+        # neighbours replace the x ghost fill on the cut faces; every operation marked
+        # COLLECTIVE below must then be called by all ranks (pyro's driver does: every process
+        # runs the same script)
+        self.slab = getattr(grid, "slab", None)
+        self._comm = None
+        self._slab_driver = None      # compressible: decomp.SlabCompressible around the device state
 
     # ---- construction ---------------------------------------------------
     def register_var(self, name, bc):
@@ -293,11 +318,28 @@ class CellCenterData2d:
             g = self.grid
             dub = self._device_user_bc()
             rows = [_bc_row(self.BCs[n], dub) for n in self.names]
+            if self.slab is not None:       # cut faces: halo rows, not a boundary rule
+                rows = self.slab.var_bcs(rows)
             self._dev = device.DeviceState(self.ctx, g.nx, g.ny, g.ng, rows)
         if not self._dev_valid:
+            if self._slab_driver is not None:
+                # (COLLECTIVE) rows a step has already sent to the neighbours are stale now
+                self._slab_driver.modified()
             self._dev.upload(np.asarray(self._host, dtype=np.float64))
             self._dev_valid = True
         return self._dev
+
+    @property
+    def comm(self):
+        """what moves halo rows of a decomposed run (decomp.RcclComm; tests: a gloo transport)"""
+        if self._comm is None and self.slab is not None:
+            from .. import decomp
+            dec = decomp.active_decomposition()
+            if dec is None:
+                raise RuntimeError("a slab grid without a decomposition in force "
+                                   "(pyro2_amd.decomp.set_decomposition)")
+            self._comm = dec.comm_for(self.ctx)
+        return self._comm
 
     def _download_to_host(self):
         """device copy -> the host array (same memory: views stay valid)"""
@@ -389,16 +431,21 @@ class CellCenterData2d:
         self._host_rw()[:, :, self.names.index(name)] = 0.0
 
     def min(self, name, *, ng=0):
+        """(COLLECTIVE on a slab: the minimum over the whole grid)"""
         n = self.names.index(name)
         if self._dev_valid and self._dev is not None:
-            return self.device_state().minmax(n, buf=ng)[0]
-        return np.min(self._host.v(buf=ng, n=n))
+            m = self.device_state().minmax(n, buf=ng)[0]
+        else:
+            m = np.min(self._host.v(buf=ng, n=n))
+        return m if self.slab is None else self.comm.allreduce_min(float(m))
 
     def max(self, name, *, ng=0):
         n = self.names.index(name)
         if self._dev_valid and self._dev is not None:
-            return self.device_state().minmax(n, buf=ng)[1]
-        return np.max(self._host.v(buf=ng, n=n))
+            m = self.device_state().minmax(n, buf=ng)[1]
+        else:
+            m = np.max(self._host.v(buf=ng, n=n))
+        return m if self.slab is None else -self.comm.allreduce_min(-float(m))
 
     # ---- boundary conditions -------------------------------------------
     def _device_user_bc(self):
@@ -458,11 +505,29 @@ class CellCenterData2d:
 
     def _lazy_fill_ok(self):
         simple = ("outflow", "reflect-even", "reflect-odd", "periodic")
-        return self._dev_valid and self._dev is not None and \
+        # (a slab's fill starts with the halo exchange, a collective: never deferred)
+        return self.slab is None and self._dev_valid and self._dev is not None and \
             not any(self._has_host_bc(n) for n in self.names) and \
             all(b in simple for n in self.names for b in self.BCs[n].sides())
 
     def _fill_now(self):
+        if self.slab is not None:
+            # COLLECTIVE: halo rows from the x neighbours first, then the y / physical sides
+            # (the x ghost rows are filled before the y ghost columns, array_indexer.py:150-274:
+            # a halo row arrives with the neighbour's y ghost cells of the previous fill and
+            # the y fill that follows rewrites them like those of an interior row)
+            if any(self._has_host_bc(n) for n in self.names):
+                msg.fail("ERROR: host-side boundary callbacks / inhomogeneous boundary values "
+                         "are not carried by a decomposed run")
+            st = self.device_state()
+            self._push_user_bc(st)
+            if self._slab_driver is not None:
+                self._slab_driver.fill()
+            else:
+                self.comm.halo_exchange(st, self.slab.lo, self.slab.hi)
+                st.fill_bc(-1)
+            self.device_modified()
+            return
         if not any(self._has_host_bc(n) for n in self.names):
             st = self.device_state()
             self._push_user_bc(st)
@@ -477,6 +542,10 @@ class CellCenterData2d:
         user-defined boundary callbacks on the host copy (patch.py:582-624)"""
         n = self.names.index(name)
         bc = self.BCs[name]
+        if self.slab is not None:
+            # COLLECTIVE; the halo rows of a slab travel for all variables at once
+            self._fill_now()
+            return
         st = self.device_state()
         self._push_user_bc(st)
         st.fill_bc(n)
@@ -510,8 +579,38 @@ class CellCenterData2d:
         with h5lite.open_file(filename, "w") as f:
             self.write_data(f)
 
+    def gather(self):
+        """COLLECTIVE on a slab: the whole grid's CellCenterData2d on rank 0 (host copy; grid,
+        variables, boundary objects, aux data and time of this object), None on the other ranks;
+        the object itself on an undecomposed grid."""
+        if self.slab is None:
+            return self
+        if self._fill_pending:
+            self._fill_pending = False
+            self._fill_now()
+        full = self.comm.gather(self.device_state(), self.slab)
+        if full is None:
+            return None
+        g = self.grid
+        whole = type(g)(g.nx_global, g.ny, ng=g.ng, xmin=g.xmin, xmax=g.xmax, ymin=g.ymin,
+                        ymax=g.ymax)
+        out = CellCenterData2d(whole, dtype=self.dtype, ctx=self._ctx)
+        for name in self.names:
+            out.register_var(name, self.BCs[name])
+        out.aux = dict(self.aux)
+        out.derives = list(self.derives)
+        out.ivars = self.ivars
+        out.create()
+        out._set_host(full)
+        out._host_valid, out._dev_valid = True, False
+        out.t = self.t
+        return out
+
     def write_data(self, f):
         """HDF5 layout of patch.py:750-788: groups aux / grid / state/<var>"""
+        if self.slab is not None:
+            raise RuntimeError("a slab writes through gather(): rank 0 holds the whole grid "
+                               "(Simulation.write does this)")
         gaux = f.create_group("aux")
         for k, v in self.aux.items():
             gaux.attrs[k] = v
@@ -549,6 +648,7 @@ def cell_center_data_clone(old):
     """a new CellCenterData2d with the same grid, variables, BCs and aux data
     and a copy of the data (patch.py:951-980)"""
     new = CellCenterData2d(old.grid, dtype=old.dtype, ctx=old._ctx)
+    new._comm = old._comm
     for name in old.names:
         new.register_var(name, old.BCs[name])
     new.aux = dict(old.aux)

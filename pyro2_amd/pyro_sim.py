@@ -61,6 +61,7 @@ class Pyro:
         self._problem = None
         self.sim = None
         self.is_initialized = False
+        self._quiet = False
         self.tc = profile.TimerCollection()
         # defaults of the package, then of the solver
         self.rp = RuntimeParameters()
@@ -126,7 +127,14 @@ class Pyro:
                 self.rp.set_param(key, 0)
         for key, value in (inputs_dict or {}).items():
             self.rp.set_param(key, value)
-        self.rp.print_paramfile()
+        # one process per GPU (a launcher's RANK / WORLD_SIZE, gpu.decompose): every process
+        # builds the Simulation of ITS x-slab of the one problem (simulation_null.grid_setup);
+        # rank 0 speaks and writes for all of them
+        from . import decomp
+        dec = decomp.active_decomposition(self.rp)
+        self._quiet = dec is not None and dec.rank != 0
+        if not self._quiet:
+            self.rp.print_paramfile()
         self.verbose = self.rp.get_param("driver.verbose")
         self.dovis = self.rp.get_param("vis.dovis")
 
@@ -193,7 +201,7 @@ class Pyro:
         return "%s%04d" % (self.rp.get_param("io.basename"), self.sim.n)
 
     def _write_output(self, announce=True):
-        if announce and self.verbose > 0:
+        if announce and self.verbose > 0 and not self._quiet:
             msg.warning("outputting...")
         self.sim.write(self._output_name())
 
@@ -228,10 +236,11 @@ class Pyro:
         if writing or self.rp.get_param("io.force_final_output"):
             self._write_output()
         clock.end()
-        if self.verbose > 0:
+        if self.verbose > 0 and not self._quiet:
             self.rp.print_unused_params()
             self.tc.report()
-        self.sim.finalize()
+        if not self._quiet:
+            self.sim.finalize()
 
     @_needs_problem
     def single_step(self):
@@ -239,7 +248,7 @@ class Pyro:
         sim.cc_data.fill_BC_all()       # the step of pyro_sim.py:250-256, in its order
         sim.compute_timestep()
         sim.evolve()
-        if self.verbose > 0:
+        if self.verbose > 0 and not self._quiet:
             print("%5d %10.5f %10.5f" % (sim.n, sim.cc_data.t, sim.dt))
         if sim.do_output():
             self._write_output()

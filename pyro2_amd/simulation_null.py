@@ -18,10 +18,17 @@ def _param(rp, key, default, what):
         return default
 
 
-def grid_setup(rp, ng=1, spherical_ok=False):
+_warned_replicas = False
+
+
+def grid_setup(rp, ng=1, spherical_ok=False, decomposable=False):
     """build the Grid2d described by the [mesh] parameters
     (simulation_null.py:10-69).  spherical_ok: the calling solver has the
-    geometry terms (only the compressible solver does, as in the reference)"""
+    geometry terms (only the compressible solver does, as in the reference).
+    decomposable: the calling solver steps x-slabs (compressible, advection): with one process
+    per GPU (decomp.active_decomposition: a launcher's RANK / WORLD_SIZE, gpu.decompose) the
+    grid handed out is THIS rank's slab of the [mesh] grid -- global xmin / xmax / dx, local nx,
+    the coordinates of its rows of the whole grid (mesh/patch.py Grid2d(slab=...))"""
     nx = rp.get_param("mesh.nx")
     ny = rp.get_param("mesh.ny")
     xmin = _param(rp, "mesh.xmin", 0.0, "0.0")
@@ -36,7 +43,20 @@ def grid_setup(rp, ng=1, spherical_ok=False):
         return patch.SphericalPolar(nx, ny, xmin=xmin, xmax=xmax, ymin=ymin, ymax=ymax, ng=ng)
     if grid_type != "Cartesian2d":
         raise ValueError("Unsupported grid type!")
-    return patch.Cartesian2d(nx, ny, xmin=xmin, xmax=xmax, ymin=ymin, ymax=ymax, ng=ng)
+    from . import decomp
+    dec = decomp.active_decomposition(rp)
+    if dec is not None and not decomposable:
+        global _warned_replicas
+        if not _warned_replicas:
+            _warned_replicas = True
+            msg.warning(f"{dec.nranks} processes: this solver is not domain-decomposed, every "
+                        "process runs the whole problem")
+        dec = None
+    slab = None
+    if dec is not None:
+        xlb = _param(rp, "mesh.xlboundary", "periodic", "periodic")
+        slab = decomp.SlabDecomp(nx, dec.nranks, dec.rank, periodic=(xlb == "periodic"))
+    return patch.Cartesian2d(nx, ny, xmin=xmin, xmax=xmax, ymin=ymin, ymax=ymax, ng=ng, slab=slab)
 
 
 def bc_setup(rp):
@@ -93,6 +113,8 @@ class NullSimulation:
         """particles.do_particles = 1: seed the tracers the way every solver's
         initialize() does (e.g. advection/simulation.py:30-33)"""
         if self.rp.get_param("particles.do_particles") == 1:
+            if getattr(self.cc_data, "slab", None) is not None:
+                msg.fail("ERROR: tracer particles are not carried by a decomposed run")
             from .particles import particles
             self.particles = particles.Particles(
                 self.cc_data, bc, self.rp.get_param("particles.n_particles"),
@@ -167,6 +189,25 @@ class NullSimulation:
     def write(self, filename):
         """HDF5 dump in the reference layout (simulation_null.py:270-290);
         this is a device -> host synchronisation point"""
+        from .util import h5lite
+        cc = self.cc_data
+        if getattr(cc, "slab", None) is not None:
+            # COLLECTIVE: the slabs are gathered, rank 0 writes the ONE file of the reference's
+            # layout (state/<var>/data is the whole nx x ny array, patch.py:750-788)
+            if self.particles is not None:
+                msg.fail("ERROR: tracer particles are not carried by a decomposed run")
+            whole = cc.gather()
+            if whole is None:
+                return
+            keep, self.cc_data = self.cc_data, whole
+            try:
+                self._write_one(filename)
+            finally:
+                self.cc_data = keep
+            return
+        self._write_one(filename)
+
+    def _write_one(self, filename):
         from .util import h5lite
         with h5lite.open_file(filename, "w") as f:
             f.attrs["solver"] = self.solver_name

@@ -43,6 +43,8 @@ int pyrohip_comm_set_global_dt(pyrohip_ctx *c, int on)
 int pyrohip_mg_exchange_rows(pyrohip_mg *, int, int, int, int, int, int, int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
 int pyrohip_mg_send_rows(pyrohip_mg *, int, int, int, int, int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
 int pyrohip_mg_recv_rows(pyrohip_mg *, int, int, int, int, int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
+int pyrohip_state_send_rows(pyrohip_state *, int, int, int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
+int pyrohip_state_recv_rows(pyrohip_state *, int, int, int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
 int pyrohip_comm_group(int) { pyro::set_error("host-emu: no RCCL"); return PYROHIP_ERR_UNSUPPORTED; }
 int pyrohip_state_halo_pending(pyrohip_state *s, int *flag) { *flag = 0; (void)s; return 0; }
 int pyrohip_state_set_neighbours(pyrohip_state *s, int lo, int hi)
@@ -63,5 +65,8 @@ int comm_allreduce_min_device(pyrohip_ctx *, double *d)
 }
 bool comm_can_overlap(const pyrohip_state *) { return true; }
 int comm_post_halo(pyrohip_state *, double *) { return 0; }     // nothing to post: see above
+int comm_fork_boundary(pyrohip_state *s, hipStream_t *bs) { *bs = s->ctx->stream; return 0; }
+int comm_post_halo_here(pyrohip_state *, double *) { return 0; }
+int comm_join_boundary(pyrohip_state *) { return 0; }
 int comm_wait_halo(pyrohip_state *) { return 0; }
 }

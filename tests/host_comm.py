@@ -54,6 +54,23 @@ class HostStagedComm:
         self.td.all_reduce(t, op=self.td.ReduceOp.MIN)
         return float(t[0])
 
+    def gather(self, state, dec):
+        """same contract as RcclComm.gather: every rank's slab -> rank 0's (qx_global, qy, nvar)"""
+        import torch
+        ng = state.ng
+        mine = state.download()
+        if dec.rank != 0:
+            self.td.send(torch.from_numpy(np.ascontiguousarray(mine)), 0, tag=7)
+            return None
+        out = np.empty((dec.nx + 2 * ng, state.qy, state.nvar))
+        out[:state.qx] = mine
+        for r in range(1, dec.nranks):
+            buf = torch.empty((dec.counts[r] + 2 * ng, state.qy, state.nvar), dtype=torch.float64)
+            self.td.recv(buf, r, tag=7)
+            i0 = sum(dec.counts[:r])
+            out[i0 + ng:i0 + buf.shape[0]] = buf.numpy()[ng:]
+        return out
+
 
 class HostRowComm:
     """rows of level arrays between ranks, staged through the host (torch.distributed)"""

@@ -573,3 +573,71 @@ def test_rccl_slab_modified_between_steps(hip):
     sl.state.upload_rows(ng, sl.state.download_rows(ng, 4))
     with pytest.raises(Exception, match="set_neighbours"):
         sl.step(pol, 0.8)
+
+
+def _launch_pyro_sim(nproc, port, args, cwd, timeout=420.0):
+    """`python -m torch.distributed.run --nproc-per-node N -m pyro2_amd.pyro_sim ...`: the
+    launcher line of the driver's multi-GPU bench with pyro's own command line behind it.  The
+    workers never import torch: the RCCL unique id travels through pyro2_amd.decomp's own
+    rendezvous.  On a box with fewer GPUs than ranks they share (PYRO_SHARE_GPUS=1: RCCL over
+    sockets, flagged)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if nproc > 1:
+        if device.device_count() < nproc:
+            env["PYRO_SHARE_GPUS"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "pyro2_amd.pyro_sim"]
+    else:
+        cmd = [sys.executable, "-m", "pyro2_amd.pyro_sim"]
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+    try:
+        r = subprocess.run(cmd + args, cwd=cwd, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return f"no result after {timeout:.0f} s"
+    return None if r.returncode == 0 else (r.stdout[-1500:] + r.stderr[-2500:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,batched", [(2, 0), (4, 1)])
+def test_pyro_sim_command_line_decomposed_over_rccl(hip, tmp_path, nproc, batched):
+    """pyro's command line under the launcher runs ONE decomposed problem --
+    `torch.distributed.run --nproc-per-node N -m pyro2_amd.pyro_sim compressible sedov
+    inputs.sedov ...` (N processes, x slabs, RCCL halo exchange, global CFL minimum, the output
+    file gathered to rank 0) writes the same file, bit for bit, as the plain single-process
+    command.  batched = 0: output every step count => Pyro.single_step; 1: nothing between the
+    steps => Simulation.evolve_many (device-side stepping of the slabs)."""
+    import socket
+    from pyro2_amd.util import io_pyro
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    common = ["compressible", "sedov", "inputs.sedov", "mesh.nx=256", "mesh.ny=192", "driver.max_steps=14",
+              "gpu.fast_math=0", "vis.dovis=0", "driver.verbose=0"]
+    if batched:
+        common += ["io.do_io=0", "io.force_final_output=1"]
+    else:
+        common += ["io.do_io=1", "io.n_out=7", "io.dt_out=1000.0"]
+    err = _launch_pyro_sim(nproc, port, common + [f"io.basename={tmp_path}/dec_"], str(tmp_path))
+    if err is not None:
+        if device.device_count() < nproc:
+            pytest.skip("RCCL ranks sharing a GPU (socket transport) did not run here: " + err[-600:])
+        pytest.fail(err)
+    one = tmp_path / "one"
+    one.mkdir()
+    err = _launch_pyro_sim(1, port, common + [f"io.basename={tmp_path}/one_"], str(one))
+    assert err is None, err
+    names = sorted(f for f in os.listdir(tmp_path) if f.startswith("one_"))
+    assert names and names[-1].startswith("one_0014"), names
+    for f in names:
+        a = io_pyro.read(str(tmp_path / f))
+        b = io_pyro.read(str(tmp_path / f.replace("one_", "dec_")))
+        assert a.cc_data.t == b.cc_data.t and a.n == b.n, f
+        assert (b.cc_data.grid.nx, b.cc_data.grid.ny) == (256, 192)
+        for v in a.cc_data.names:
+            assert np.array_equal(a.cc_data.get_var(v).v(), b.cc_data.get_var(v).v()), (f, v)
+    assert np.abs(a.cc_data.get_var("x-momentum").v()).max() > 0.0
