@@ -624,6 +624,9 @@ int pyrohip_comm_set_global_dt(pyrohip_ctx *ctx, int on);
    behind, without reading the state (so its ghost cells need not be filled: fuse_fill) */
 int pyrohip_comp_dt_is_cached(pyrohip_state *s, int *flag);
 int pyrohip_comp_dt_is_global(pyrohip_state *s, int *flag);
+/* flag = 1: pyrohip_comp_rk_dt will answer from the minimum the last stage of pyrohip_comp_rk_step
+   left (compressible_rk's CFL quantity), without reading the state or its ghost cells */
+int pyrohip_comp_rk_dt_is_cached(pyrohip_state *s, int *flag);
 /* exchange ng ghost rows of every variable with the x neighbours
    (rank_lo / rank_hi, -1 = none).  Replaces the single-domain x ghost fill
    for PYROHIP_BC_HALO sides; y ghost fill must follow (fill order of

@@ -104,6 +104,7 @@ _PROTOS = {
     "pyrohip_device_count": [C.POINTER(C.c_int)],
     "pyrohip_comm_set_global_dt": [_VP, C.c_int],
     "pyrohip_comp_dt_is_global": [_VP, C.POINTER(C.c_int)],
+    "pyrohip_comp_rk_dt_is_cached": [_VP, C.POINTER(C.c_int)],
     "pyrohip_comp_dt_is_cached": [_VP, C.POINTER(C.c_int)],
     "pyrohip_mg_set_general_coeffs": [_VP, _DP, _DP, _DP, _DP, C.POINTER(C.c_int)],
     "pyrohip_comp_rk_rhs": [_VP, C.POINTER(CompParams), _VP, C.c_int],

@@ -28,7 +28,12 @@ class Simulation(CompressibleSimulation):
         """cfl * min 1 / ((|u|+c)/dx + (|v|+c)/dy) over the whole array
         (compressible_rk/simulation.py:46-56)"""
         cfl = self.rp.get_param("driver.cfl")
-        self.dt = self._device_state().comp_rk_dt(self._params(), float(cfl))
+        # the one-call step leaves the minimum of the new state: no ghost cells needed for it
+        # (the step then does the only ghost fill of the iteration)
+        st = self._device_state(fuse_fill=True)
+        if not st.comp_rk_dt_is_cached():
+            st = self._device_state()
+        self.dt = st.comp_rk_dt(self._params(), float(cfl))
 
     def _rk_fusable(self, start, method):
         """the whole Runge-Kutta step as nstages launches of the row-marching kernel
@@ -49,7 +54,9 @@ class Simulation(CompressibleSimulation):
         tm.begin()
         cc = self.cc_data
         method = self.rp.get_param("compressible.temporal_method")
-        start = self._device_state()
+        start = self._device_state(fuse_fill=True)
+        if not self._rk_fusable(start, method):
+            start = self._device_state()     # (stage by stage: the deferred fill is carried out)
         if self._rk_fusable(start, method):
             cc.take_pending_fill()           # (the step fills the state's ghost cells itself)
             start.comp_rk_step(self._params(), self._rk_scratch[1], float(self.dt),

@@ -246,6 +246,25 @@ int launch_fill_frame2(pyrohip_state *s, bool *done)
     return 0;
 }
 
+// A device-side run whose last iterations were inactive (past tmax, after an invalid state) has
+// kept filling / copying ghost frames between the two buffers on those iterations: the frame of
+// the buffer that holds the final state then depends on their parity.  What a single step leaves
+// there is the filled ghost frame of the state BEFORE the last step that advanced -- whose
+// interior sits untouched in the other buffer (inactive launches store nothing): rebuild it.
+int restore_frame_after_inactive(pyrohip_state *s, int steps, int max_steps)
+{
+    if (steps < 1 || steps >= max_steps || !s->alt_base || !frame_fill_ok(s)) return 0;
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    const int rows_per_block = 256 / (2 * g.ng);
+    const int nblk = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + rows_per_block - 1) / rows_per_block;
+    PYRO_LAUNCH(c, "k_fill_frame2", k_fill_frame2, dim3(nblk), dim3(256), 0,
+                (const double *)(s->alt_base + geom_lead(g)), s->d, (double *)nullptr, g, (const int *)s->d_bc);
+    PYRO_CHECK_HIP(hipGetLastError());
+    PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int launch_dt_policy(pyrohip_ctx *c, StepScalars *S, const double *cflmin, const int *flag, double *dts,
                      int slot, int final_call, const double *part, int nparts, double *minout)
 {
@@ -493,6 +512,13 @@ int pyrohip_comp_dt_is_cached(pyrohip_state *s, int *flag)
     return 0;
 }
 
+int pyrohip_comp_rk_dt_is_cached(pyrohip_state *s, int *flag)
+{
+    PYRO_REQUIRE(s && flag, "NULL argument");
+    *flag = (s->next_cfl_min > 0.0 && s->cfl_kind == 1) ? 1 : 0;
+    return 0;
+}
+
 int pyrohip_comp_dt_is_global(pyrohip_state *s, int *flag)
 {
     PYRO_REQUIRE(s && flag, "NULL argument");
@@ -732,6 +758,7 @@ int pyrohip_comp_rk_evolve(pyrohip_state *y, const pyrohip_comp_params *p, pyroh
         s->alt_base = old_base;
         s->d = s->base + geom_lead(s->g);
     }
+    if (!(flagv & 1)) PYRO_TRY(restore_frame_after_inactive(s, H.steps, max_steps));
     s->next_cfl_min = (H.steps == max_steps && !(flagv & 1)) ? lastmin : -1.0;
     s->cfl_kind = 1;
     s->cfl_is_global = false;

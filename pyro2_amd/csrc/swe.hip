@@ -682,6 +682,17 @@ int swe_step_wave(pyrohip_state *s, double dx, double dy, double grav, int limit
     return 0;
 }
 
+#if !PYRO_FAST
+// wavefronts of a launch of the one-launch step on this grid (= CFL partials it leaves): the
+// caller of a device-side run sizes the reduction buffer with it BEFORE the first launch
+int swe_wave_units(const Geom &g, int cus)
+{
+    const int ncb = (g.ny + SWW_OUT - 1) / SWW_OUT;
+    const int L = sww_rows(g.nx, ncb, cus > 0 ? cus : 256);
+    return ncb * ((g.nx + L - 1) / L);
+}
+#endif
+
 }  // namespace PYRO_SWNS
 #if !PYRO_FAST
 namespace swf {    // the contracted unit (swe_fast)
@@ -692,6 +703,7 @@ int swe_step_wave(pyrohip_state *, double, double, double, int, int, double, con
 int launch_fill_frame2(pyrohip_state *s, bool *done);
 int launch_dt_policy(pyrohip_ctx *c, StepScalars *S, const double *cflmin, const int *flag, double *dts,
                      int slot, int final_call, const double *part, int nparts, double *minout);
+int restore_frame_after_inactive(pyrohip_state *s, int steps, int max_steps);
 #endif
 }  // namespace pyro
 
@@ -723,14 +735,20 @@ static int sw_check(pyrohip_state *s, double dx, double dy, double grav, int lim
 }
 
 // the CFL minimum of the state left in device memory (-> *dmin)
-static int sw_cfl_min_device(pyrohip_state *s, double dx, double dy, double grav, const double **dmin)
+constexpr int kSwCflBlocks = 8 * 128;
+// doubles of reduction scratch a device-side run needs: the step kernel's partials (one per
+// wavefront, `front` of them) in front, the partials + stages of k_sw_cfl behind them
+static size_t sw_reduce_doubles(size_t front) { return front + 2 * kSwCflBlocks + kMinStageBlocks + 2; }
+
+static int sw_cfl_min_device(pyrohip_state *s, double dx, double dy, double grav, const double **dmin,
+                             size_t front = 65536)
 {
     pyrohip_ctx *c = s->ctx;
     const dim3 grid(8, 128), block(256);
     const int nb = grid.x * grid.y;
     // (behind the partials of the step kernel, which use the front of the same buffer)
-    PYRO_TRY(c->reduce.ensure((size_t)(65536 + 2 * nb + kMinStageBlocks + 2) * sizeof(double)));
-    double *part = (double *)c->reduce.p + 65536;
+    PYRO_TRY(c->reduce.ensure(sw_reduce_doubles(front) * sizeof(double)));
+    double *part = (double *)c->reduce.p + front;
     hipLaunchKernelGGL(k_sw_cfl, grid, block, 0, c->stream, (const double *)s->d, s->g, grav, dx, dy,
                        part);
     *dmin = launch_min_reduce(c->stream, part, nb);
@@ -811,6 +829,15 @@ int pyrohip_swe_evolve(pyrohip_state *s, double dx, double dy, double grav, int 
     PYRO_REQUIRE(pol && steps_done && max_steps >= 1, "NULL argument / max_steps must be positive");
     PYRO_REQUIRE(!s->nb_set && !s->user_bc && !s->ramp_bc && !s->sph,
                  "device-side stepping: swe runs on a single Cartesian domain with the standard boundary types");
+    // from the second step on the CFL minimum is the step kernel's (interior of the new state):
+    // equal to the reference's whole-array minimum only where every ghost cell is an image of an
+    // interior cell (a constant-value side is not: swe/simulation.py:127-141 after fill_BC_all)
+    for (int k = 0; k < 4 * s->nvar; k++) {
+        const int b = s->bc[k];
+        PYRO_REQUIRE(b == PYROHIP_BC_OUTFLOW || b == PYROHIP_BC_REFLECT_EVEN || b == PYROHIP_BC_REFLECT_ODD ||
+                         b == PYROHIP_BC_PERIODIC,
+                     "device-side stepping: outflow / reflect / periodic boundaries only");
+    }
     pyrohip_ctx *c = s->ctx;
     if (!s->d_scal) PYRO_CHECK_HIP(hipMalloc((void **)&s->d_scal, sizeof(StepScalars)));
     if (!s->d_flag) {
@@ -835,7 +862,10 @@ int pyrohip_swe_evolve(pyrohip_state *s, double dx, double dy, double grav, int 
     PYRO_CHECK_HIP(hipMemcpyAsync(s->d_scal, &H, sizeof(H), hipMemcpyHostToDevice, c->stream));
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));      // H is on this stack frame
     PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
-    PYRO_TRY(c->reduce.ensure((size_t)(65536 + 2 * 1024 + kMinStageBlocks + 2) * sizeof(double)));
+    // one partial per wavefront of the step kernel (46 978 at 16384^2, 128 820 at 32768^2 on 256
+    // CUs), sized BEFORE the first launch: growing the buffer later would move what dmin points at
+    const size_t nunits = (size_t)swx::swe_wave_units(s->g, c->num_cus);
+    PYRO_TRY(c->reduce.ensure(sw_reduce_doubles(nunits) * sizeof(double)));
     double *part = (double *)c->reduce.p;
     const double *dmin = nullptr;
     const double *pend = nullptr;
@@ -845,7 +875,7 @@ int pyrohip_swe_evolve(pyrohip_state *s, double dx, double dy, double grav, int 
         rc = launch_fill_frame2(s, &frame_done);          // pyro_sim.py:250: fill_BC_all
         if (rc) break;
         if (m == 0) {      // the CFL minimum of the state as handed over (whole array, filled)
-            rc = sw_cfl_min_device(s, dx, dy, grav, &dmin);
+            rc = sw_cfl_min_device(s, dx, dy, grav, &dmin, nunits);
             if (rc) break;
         }
         // (later steps: the policy kernel takes the minimum of the step kernel's partials itself)
@@ -855,6 +885,10 @@ int pyrohip_swe_evolve(pyrohip_state *s, double dx, double dy, double grav, int 
         int np = 0;
         rc = fast_math ? swf::swe_step_wave(s, dx, dy, grav, limiter, riemann, 0.0, s->d_scal, part, &np, frame_done)
                        : swx::swe_step_wave(s, dx, dy, grav, limiter, riemann, 0.0, s->d_scal, part, &np, frame_done);
+        if (rc == 0 && (size_t)np > nunits) {
+            set_error("pyrohip_swe_evolve: the step kernel left more CFL partials than were sized for");
+            rc = PYROHIP_ERR_ARG;
+        }
         pend = part; npend = np;
     }
     PYRO_TRY(rc);
@@ -876,6 +910,7 @@ int pyrohip_swe_evolve(pyrohip_state *s, double dx, double dy, double grav, int 
         s->alt_base = old_base;
         s->d = s->base + geom_lead(s->g);
     }
+    PYRO_TRY(restore_frame_after_inactive(s, H.steps, max_steps));
     s->next_cfl_min = -1.0;
     s->ghost_by_rules = false;
     pol->t = H.t; pol->dt_old = H.dt_old; pol->n = H.n;

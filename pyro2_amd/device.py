@@ -451,6 +451,14 @@ class DeviceState:
         check(self._l.pyrohip_comp_dt_is_cached(self.h, C.byref(f)))
         return bool(f.value)
 
+    def comp_rk_dt_is_cached(self):
+        """will comp_rk_dt answer from the minimum the last one-call Runge-Kutta step left
+        (no look at the state or its ghost cells)?"""
+        f = C.c_int()
+        with self.ctx.lock:
+            check(self._l.pyrohip_comp_rk_dt_is_cached(self.h, C.byref(f)))
+        return bool(f.value)
+
     def comp_dt_is_global(self):
         f = C.c_int()
         check(self._l.pyrohip_comp_dt_is_global(self.h, C.byref(f)))

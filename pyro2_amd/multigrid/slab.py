@@ -36,8 +36,6 @@ send / recv pairs on the level arrays (`RcclRowComm`; it needs two GPUs and has
 not run yet, tests/test_zz_comm.py::test_rccl_multigrid_slabs_two_ranks skips on
 one: DESIGN.md 6).
 """
-import numpy as np
-
 KMAX = 5          # iterations per launch of the tile smoother (multigrid.hip MGW_KMAX)
 KDEEP = 10        # ... of the row-marching / deep-apron band kernels
 

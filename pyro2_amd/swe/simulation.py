@@ -102,7 +102,15 @@ class Simulation(NullSimulation):
     def _fast_math(self):
         """gpu.fast_math (default 1: the contracted one-launch kernel, <= 1e-10 element-wise of the
         bit-faithful one; 0: the reference's operation order)"""
-        return int(self._rp_opt("gpu.fast_math", 1))
+        fm = int(self._rp_opt("gpu.fast_math", 1))
+        if fm and self._rp_opt("gpu.kernel_set", -1) == 0:
+            # the staged kernels (every stage dumpable) exist in the reference's operation order only
+            if not getattr(self, "_warned_staged", False):
+                self._warned_staged = True
+                msg.warning("gpu.kernel_set = 0 (staged kernels) runs the bit-faithful arithmetic: "
+                            "gpu.fast_math = 1 is ignored")
+            return 0
+        return fm
 
     def can_evolve_many(self):
         """batches of steps on the device (pyrohip_swe_evolve): standard boundary types filled

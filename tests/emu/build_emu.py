@@ -36,10 +36,20 @@ def build(force=False):
 
     headers = [d for d in deps if not d.endswith(".hip")] + [os.path.abspath(__file__)]
 
+    # a variant built with extra -D flags for the CONTRACTED units only (PYRO_EMU_FAST_ONLY=1, e.g.
+    # -DPYRO_EMU_FASTSEED, which only the PYRO_FAST code reads) links the other units' objects of
+    # the default build instead of compiling them again
+    fast_only = bool(_NAME) and os.environ.get("PYRO_EMU_FAST_ONLY") == "1"
+    base_out = os.path.join(ROOT, "tests", "_emu_build")
+
     def cc(u):
         src, name, extra = u
         defs = [f for f in extra if f.startswith("-D")]
         obj = os.path.join(OUT, name + ".o")
+        if fast_only and "-DPYRO_FAST=1" not in extra:
+            base = os.path.join(base_out, name + ".o")
+            if os.path.exists(base) and not hb._stale(base, headers + [os.path.join(hb.CSRC, src)]):
+                return base
         # an object newer than its own source and every header is kept
         if not force and not hb._stale(obj, headers + [os.path.join(hb.CSRC, src)]):
             return obj

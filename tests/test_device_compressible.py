@@ -1546,7 +1546,9 @@ def test_rk_evolve_on_device_equals_single_steps(dev, method):
         dts = list(s.comp_rk_evolve(P, k, a, b, cfl, pol, 2))
         dts += list(s.comp_rk_evolve(P, k, a, b, cfl, pol, 4))
         assert dts == d1 and pol.t == pol1.t and pol.n == pol1.n, (dts, d1)
-        assert np.array_equal(s.download()[ng:-ng, ng:-ng], s1.download()[ng:-ng, ng:-ng])
+        # the whole array, ghost cells included -- also where tmax ended the run inside a call (the
+        # iterations past it keep filling frames; the library rebuilds the final state's: ADVICE r5)
+        assert np.array_equal(s.download(), s1.download())
         # the next dt comes from the cached minimum: equal to a fresh reduction over the filled state
         cached = s.comp_rk_dt(P, cfl)
         s1.fill_bc()

@@ -213,9 +213,11 @@ def test_swe_evolve_on_device_equals_single_steps(dev, bcs, fast):
     U0 = _swe_random_state(nx, ny, 3)
     dx, dy, grav, cfl = 1.0 / nx, 1.0 / ny, 1.0, 0.8
     ref = None
-    for tmax in (1.e30, None):
+    for tmax in (1.e30, None, -1):
         if tmax is None:
             tmax = sum(ref[:4]) + 0.3 * ref[4]
+        elif tmax == -1:          # ... with an odd number of inactive iterations behind the last step
+            tmax = sum(ref[:2]) + 0.3 * ref[2]
         s1 = device.DeviceState(dev, nx, ny, ng, rows)
         s1.upload(U0)
         pol1, d1 = DtPolicy(tmax), []
@@ -233,8 +235,9 @@ def test_swe_evolve_on_device_equals_single_steps(dev, bcs, fast):
         assert dts == d1 and pol.t == pol1.t and pol.n == pol1.n, (dts, d1)
         a, b = s.download(), s1.download()
         assert np.array_equal(a[ng:-ng, ng:-ng], b[ng:-ng, ng:-ng])
-        if tmax > 1.e29:      # (iterations of a call past tmax still refill the ghost cells)
-            assert np.array_equal(a, b)
+        # ghost cells too -- also where tmax ends the run inside a call: the iterations past it
+        # keep filling frames, the library rebuilds the final state's afterwards
+        assert np.array_equal(a, b)
         ref = d1
 
 
@@ -256,3 +259,20 @@ def test_pyro_swe_run_sim_batches_steps(api, golden):
         res.append((p.sim.n, p.sim.cc_data.t, p.sim.dt, np.asarray(p.sim.cc_data.data).copy()))
     assert res[0][:3] == res[1][:3]
     assert np.array_equal(res[0][3][4:-4, 4:-4], res[1][3][4:-4, 4:-4])
+
+
+def test_swe_evolve_refuses_boundaries_the_step_kernel_minimum_does_not_cover(dev):
+    """from the second step on pyrohip_swe_evolve takes the CFL minimum of the step
+    kernel's wavefronts (interior of the new state) -- the reference's whole-array minimum only
+    where every ghost cell is an image of an interior cell.  A constant-value side is refused by
+    the library itself (not only by Simulation.can_evolve_many)."""
+    from pyro2_amd._lib import BC_CODE, PyroHipError
+    nx, ny, ng = 24, 24, 4
+    rows = [["outflow", "outflow", "reflect-even", BC_CODE["moving_lid"]]] * 4
+    try:
+        s = device.DeviceState(dev, nx, ny, ng, rows)
+    except (PyroHipError, KeyError):
+        pytest.skip("no constant-value boundary code in this library")
+    s.upload(_swe_random_state(nx, ny, 1))
+    with pytest.raises(PyroHipError, match="outflow / reflect / periodic"):
+        s.swe_evolve(1.0 / nx, 1.0 / ny, 1.0, 1, "Roe", 0.8, DtPolicy(1.0), 2)

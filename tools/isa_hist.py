@@ -2,7 +2,7 @@
 """Static instruction statistics of one kernel in a hipcc -S listing.
 
     hipcc --offload-arch=gfx950 ... -S --cuda-device-only -o k.s file.hip
-    python tools/isa_hist.py k.s <substring of the kernel symbol> [--blocks] [--loop]
+    python tools/isa_hist.py k.s <substring of the kernel symbol> [--blocks] [--hot] [--mnem]
 
 Prints the basic blocks (label, instruction count, VALU count, terminator), the
 outermost backward branch (= the row loop of the marching kernels) and a histogram
@@ -97,6 +97,27 @@ def main():
     if not back:
         lo, hi = 0, len(insts) - 1
         print("no loop found")
+    elif "--hot" in sys.argv:
+        # The row loop proper: the compiler moves the bodies of unlikely branches (the two-rarefaction
+        # `pow` blocks of the Riemann solver, the supersonic fluxes) BEHIND the loop and lets them
+        # jump back into it, so the widest backward branch spans the loop AND that cold code.  The
+        # loop's own back edge is the one to the EARLIEST head; what lies behind its source and
+        # branches back into the loop is listed apart as out-of-line code.
+        # (a loop's range holds no branch to before its head -- a few instructions of slack: a
+        # `continue` may re-enter through a short preamble of the head block)
+        def closed(lo_, hi_):
+            for n_, (mn_, t_, _) in enumerate(insts[lo_:hi_ + 1]):
+                if mn_.startswith(("s_cbranch", "s_branch")):
+                    tg = t_.split()[1]
+                    if tg in labels and labels[tg] < lo_ - 8:
+                        return False
+            return True
+        ok = [b for b in back if closed(b[0], b[1])]
+        lo, hi, tgt = max(ok, key=lambda b: b[1] - b[0]) if ok else back[0]
+        cold = [b for b in back if b[1] > hi and lo <= b[0] <= hi]
+        ncold = (max(b[1] for b in cold) - hi) if cold else 0
+        print(f"row loop: {tgt} .. instruction {hi}  ({hi - lo + 1} instructions in line); "
+              f"{ncold} instructions of out-of-line blocks behind it ({len(cold)} jump back into the loop)")
     else:
         lo, hi, tgt = back[0]
         print(f"outermost loop: {tgt} .. instruction {hi}  ({hi - lo + 1} instructions); "
