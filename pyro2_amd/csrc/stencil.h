@@ -65,6 +65,16 @@ __device__ __forceinline__ double limited_slope(double am2, double am1, double a
     return mc_select_l4(dc, dl, dr);
 }
 
+// limit4 at the centre of (am1, a0, ap1) from the limit2 slopes of the two neighbours -- the
+// expression above with l2m = limit2(am2, am1, a0), l2p = limit2(a0, ap1, ap2) handed in: a
+// marching kernel computes every cell's centred limit2 ONCE and takes the neighbours' from the
+// row window / the neighbouring lanes (same function, same operands: the same bits)
+__device__ __forceinline__ double limit4_from(double l2m, double l2p, double am1, double a0, double ap1)
+{
+    const double dc = (2. / 3.) * (ap1 - am1 - 0.25 * (l2p + l2m));
+    return mc_select_l4(dc, ap1 - a0, a0 - am1);
+}
+
 // blockIdx -> logical tile id such that each XCD (blocks are dealt round-robin
 // to the 8 XCDs, MI355X_MICROARCH.md "block b runs on XCD b % 8") works on a
 // contiguous band of tiles and halo re-reads hit its own L2.  Performance

@@ -108,7 +108,8 @@ __device__ __forceinline__ void sw_trace(const double q[4], const double dq[4], 
     const double dtdx3 = 0.33333 * dtdx;   // sic, interface.py:100
     const double un = q[in];
     const double e0 = un - cs, e2 = un + cs;
-    const double a = 0.5 * dq[0] * prcp(q[0]), b = 0.5 * dq[in] * rcs;
+    // (1 / h = g / (g h) from the reciprocal root: no second seed)
+    const double a = 0.5 * dq[0] * (g * (rcs * rcs)), b = 0.5 * dq[in] * rcs;
     const double as0 = a - b, as2 = -(a + b);
     const double fhi = 0.5 * (1.0 - dtdx * fmax(e2, 0.0)), flo = 0.5 * (1.0 + dtdx * fmin(e0, 0.0));
 #pragma unroll
@@ -174,6 +175,66 @@ __device__ __forceinline__ void sw_trace(const double q[4], const double dq[4], 
 #endif
 
 // interface.py:216-385
+#if PYRO_FAST && !defined(SWE_DENSE_ROE)
+// The contracted build's Roe solver: the reference's formulas with every quotient and root that
+// shares an operand taken ONCE (round 6; the straightforward form below has ~25 reciprocal /
+// root evaluations per face -- Ul_n / sqrt(h_l), Ur_n / sqrt(h_r), ... / (sqrt(h_l) + sqrt(h_r))
+// for every component, U_n / h twice over in delta and in the two consFlux calls, three roots of
+// g h -- each a seed + Newton steps: a third of the kernel's instructions, profiles/
+// r06_isa_hist_sw_wave.txt).  Here: 1 / sqrt(h_l), 1 / sqrt(h_r) (rsq: the roots and, squared,
+// 1 / h come with them), 1 / (sqrt(h_l) + sqrt(h_r)), and sqrt + reciprocal of the Roe sound speed
+// -- four seeds per face; c = sqrt(g) sqrt(h); c* = |h*-root| (sqrt(g (1 / g) x^2)); the
+// transcritical fix's quotients only where a wave speed is near zero.  Algebraically the
+// reference's expressions; held to 1e-10 element-wise against the bit-faithful build
+// (tests/test_swe.py, tests/test_fastseed_emu.py, tests/test_fullsize_legs.py).
+__device__ __forceinline__ V4 sw_roe(const V4 &Ul, const V4 &Ur, double g, bool x, double sg = -1.0)
+{   // sg: sqrt(g) if the caller has it (the marching kernel takes the root once per launch)
+    const double smallc = 1.e-10, tol = 0.1e-1;
+    const int im = x ? 1 : 2, it = x ? 2 : 1;
+    const double h_l = Ul.a[0], h_r = Ur.a[0];
+    double isl, isr;                                   // 1 / sqrt(h)
+    const double sl = psqrt_r(h_l, isl), sr = psqrt_r(h_r, isr);
+    const double r_l = isl * isl, r_r = isr * isr;     // 1 / h
+    if (sg < 0.0) sg = psqrt(g);
+    const double un_l = Ul.a[im] * r_l, un_r = Ur.a[im] * r_r;
+    const double c_l = fmax(smallc, sg * sl), c_r = fmax(smallc, sg * sr);
+    const double rs = prcp(sl + sr);
+    const double h_roe = sl * sr;                      // sqrt(h_l h_r)
+    const double un_roe = (Ul.a[im] * isl + Ur.a[im] * isr) * rs;
+    const double ut_roe = (Ul.a[it] * isl + Ur.a[it] * isr) * rs;
+    const double d0 = h_r - h_l;
+    const double dn = un_r - un_l, dt_ = Ur.a[it] * r_r - Ul.a[it] * r_l, dX = Ur.a[3] * r_r - Ul.a[3] * r_l;
+    double rc_roe;
+    const double c_roe = psqrt_r(0.5 * (c_l * c_l + c_r * c_r), rc_roe);
+    double lam0 = un_roe - c_roe, lam2 = un_roe + c_roe;
+    const double hc = h_roe * rc_roe * dn;
+    // 0.5 (F(Ul) + F(Ur)) (consFlux, interface.py:557-578)
+    V4 F;
+    F.a[0] = 0.5 * (h_l * un_l + h_r * un_r);
+    F.a[im] = 0.5 * ((Ul.a[im] * un_l + 0.5 * g * (h_l * h_l)) + (Ur.a[im] * un_r + 0.5 * g * (h_r * h_r)));
+    F.a[it] = 0.5 * (Ul.a[it] * un_l + Ur.a[it] * un_r);
+    F.a[3] = 0.5 * (Ul.a[3] * un_l + Ur.a[3] * un_r);
+    if (fabs(lam0) < tol || fabs(lam2) < tol) {        // Harten-Hyman fix of a transcritical wave
+        const double hs = 0.5 * (c_l + c_r) + 0.25 * (un_l - un_r);
+        const double u_star = 0.5 * (un_l + un_r) + c_l - c_r;
+        const double c_star = psqrt(g * (pdiv(1.0, g) * (hs * hs)));
+        if (fabs(lam0) < tol)
+            lam0 = pdiv(lam0 * (u_star - c_star - lam0), u_star - c_star - (un_l - c_l));
+        if (fabs(lam2) < tol)
+            lam2 = pdiv(lam2 * (u_star + c_star - lam2), u_star + c_star - (un_r + c_r));
+    }
+    // K_0 = (1, u - c, u_t), K_1 = e_t, K_2 = (1, u + c, u_t), K_3 = e_X: the non-zero terms only
+    // w_m = 0.5 alpha_m |lambda_m| with alpha_0,2 = 0.5 (dh -+ h c^-1 du_n), alpha_1 = h du_t, alpha_3 = h dX
+    const double hh = 0.5 * h_roe * fabs(un_roe);
+    const double w0 = (0.25 * fabs(lam0)) * (d0 - hc), w1 = hh * dt_;
+    const double w2 = (0.25 * fabs(lam2)) * (d0 + hc), w3 = hh * dX;
+    F.a[0] -= w0 + w2;
+    F.a[im] -= w0 * (un_roe - c_roe) + w2 * (un_roe + c_roe);
+    F.a[it] -= (w0 + w2) * ut_roe + w1;
+    F.a[3] -= w3;
+    return F;
+}
+#else
 __device__ __forceinline__ V4 sw_roe(const V4 &Ul, const V4 &Ur, double g, bool x)
 {
     const double smallc = 1.e-10, tol = 0.1e-1;
@@ -229,6 +290,7 @@ __device__ __forceinline__ V4 sw_roe(const V4 &Ul, const V4 &Ur, double g, bool 
 #endif
     return F;
 }
+#endif
 
 // interface.py:388-554
 __device__ __forceinline__ V4 sw_hllc(const V4 &Ul, const V4 &Ur, double g, bool x)
@@ -454,16 +516,25 @@ __device__ __forceinline__ V4 sww_m1(const V4 &v) { return V4{{sww_m1(v.a[0]), s
 __device__ __forceinline__ V4 sww_p1(const V4 &v) { return V4{{sww_p1(v.a[0]), sww_p1(v.a[1]), sww_p1(v.a[2]), sww_p1(v.a[3])}}; }
 
 template <int RS>
-__device__ __forceinline__ V4 sww_riemann(const V4 &Ul, const V4 &Ur, double g, bool x)
+__device__ __forceinline__ V4 sww_riemann(const V4 &Ul, const V4 &Ur, double g, bool x, double sg)
 {
+#if PYRO_FAST && !defined(SWE_DENSE_ROE)
+    return RS == 1 ? sw_hllc(Ul, Ur, g, x) : sw_roe(Ul, Ur, g, x, sg);
+#else
+    (void)sg;
     return RS == 1 ? sw_hllc(Ul, Ur, g, x) : sw_roe(Ul, Ur, g, x);
+#endif
 }
 
 // S (device-side stepping, pyrohip_swe_evolve): this step's dt from the step scalars the policy
 // kernel left; partial: the wavefront's minimum of dx / (|u| + c), dy / (|v| + c) over the cells it
 // updated (swe/simulation.py:143-153 on the new state: the next step's CFL minimum without a
 // pass of its own -- 98 us of a 1.2 ms step at 4096^2)
-template <int RS>   // swe.riemann: 0 Roe, 1 HLLC
+// L4: swe.limiter = 2 (the default).  limit4 needs the limit2 slopes of the two neighbouring cells:
+// every cell's centred limit2 is computed once -- along x carried in the row window, along y
+// fetched from the neighbouring lanes -- instead of twice per direction (round 6: 8 of the 16
+// limit2 evaluations per cell and row, and the two-cells-away DPP moves; bit-identical).
+template <int RS, bool L4>   // swe.riemann: 0 Roe, 1 HLLC
 __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Uin,
                                                    double *__restrict__ Uout, Geom g, SWW P,
                                                    const StepScalars *__restrict__ S,
@@ -491,6 +562,7 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
     const size_t pl = g.plane;
     const double dtdx = P.dt / P.dx, dtdy = P.dt / P.dy;                  // k_sw_update
     const double hdtdx = 0.5 * (P.dt / P.dx), hdtdy = 0.5 * (P.dt / P.dy);   // k_sw_final
+    const double sg = (PYRO_FAST && RS == 0) ? psqrt(P.g) : 0.0;             // (contracted Roe solver)
     auto loadU = [&](int row) {
         row = row < 0 ? 0 : (row > g.qx - 1 ? g.qx - 1 : row);
         return ld4(Uin, pl, (size_t)row * p + jc);
@@ -514,6 +586,7 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
 #pragma unroll
     for (int r = 0; r < 5; r++) { q[r][0] = 1.0; q[r][1] = q[r][2] = q[r][3] = 0.0; }
     V4 Upre = loadU(i0 - 3), Urep = loadU(i0 - 6);
+    double l2a[4] = {0.0, 0.0, 0.0, 0.0}, l2b[4] = {0.0, 0.0, 0.0, 0.0};   // L4: limit2 along x centred on rows k-3, k-2
     for (int k = i0 - 3; k <= i1 + 2; k++) {
         // ---- row k arrives: primitives (k_sw_prim)
 #pragma unroll
@@ -529,6 +602,14 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
         q[4][2] = sw_vel(Uk.a[2], Uk.a[0]);
         q[4][3] = sw_vel(Uk.a[3], Uk.a[0]);
         const int c = k - 2;                 // window row 2
+        double l2n[4], l2m_[4];              // L4: limit2 along x centred on row k-1 = c+1, on row c-1
+        if (L4) {
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                l2n[n] = limit2(q[2][n], q[3][n], q[4][n]);
+                l2m_[n] = l2a[n]; l2a[n] = l2b[n]; l2b[n] = l2n[n];
+            }
+        }
         if (c < i0 - 1) continue;
         // ---- row c: limited slopes, tracing (k_sw_states)
         double qc[4], dqx[4], dqy[4];
@@ -536,8 +617,14 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
         for (int n = 0; n < 4; n++) {
             qc[n] = q[2][n];
             const double m1 = sww_m1(qc[n]), p1 = sww_p1(qc[n]);
-            dqx[n] = 1.0 * limited_slope(q[0][n], q[1][n], q[2][n], q[3][n], q[4][n], P.limiter);
-            dqy[n] = 1.0 * limited_slope(sww_m1(m1), m1, qc[n], p1, sww_p1(p1), P.limiter);
+            if (L4) {
+                dqx[n] = 1.0 * limit4_from(l2m_[n], l2n[n], q[1][n], q[2][n], q[3][n]);
+                const double l2y = limit2(m1, qc[n], p1);
+                dqy[n] = 1.0 * limit4_from(sww_m1(l2y), sww_p1(l2y), m1, qc[n], p1);
+            } else {
+                dqx[n] = 1.0 * limited_slope(q[0][n], q[1][n], q[2][n], q[3][n], q[4][n], P.limiter);
+                dqy[n] = 1.0 * limited_slope(sww_m1(m1), m1, qc[n], p1, sww_p1(p1), P.limiter);
+            }
         }
         double lo[4], hi[4];
         sw_trace(qc, dqx, P.g, P.dt / P.dx, true, lo, hi);
@@ -547,9 +634,9 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
         SWW_FENCE();
         // ---- transverse Riemann problems on the lower faces of row c (k_sw_riemann_t)
         const V4 XPm = get(S_XP);
-        const V4 FXT = sww_riemann<RS>(XPm, XM, P.g, true);
+        const V4 FXT = sww_riemann<RS>(XPm, XM, P.g, true, sg);
         SWW_FENCE();
-        const V4 FYT = sww_riemann<RS>(sww_m1(YP), YM, P.g, false);
+        const V4 FYT = sww_riemann<RS>(sww_m1(YP), YM, P.g, false, sg);
         const V4 FYT_p = sww_p1(FYT);
         SWW_FENCE();
         if (c >= i0) {
@@ -557,14 +644,14 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
             const V4 FYTm = get(S_FYT);
             const V4 Uxl = sw_corrected(XPm, sww_p1(FYTm), FYTm, hdtdy);
             const V4 Uxr = sw_corrected(XM, FYT_p, FYT, hdtdy);
-            const V4 Fx = sww_riemann<RS>(Uxl, Uxr, P.g, true);
+            const V4 Fx = sww_riemann<RS>(Uxl, Uxr, P.g, true, sg);
             SWW_FENCE();
             if (c >= i0 + 1) {
                 // ---- row r = c-1: final y flux, conservative update (k_sw_final, k_sw_update)
                 const V4 FXTm = get(S_FXT);
                 const V4 Uyl = sww_m1(sw_corrected(get(S_YP), FXT, FXTm, hdtdx));
                 const V4 Uyr = sw_corrected(get(S_YM), FXT, FXTm, hdtdx);
-                const V4 Fy = sww_riemann<RS>(Uyl, Uyr, P.g, false);
+                const V4 Fy = sww_riemann<RS>(Uyl, Uyr, P.g, false, sg);
                 const V4 Fy_p = sww_p1(Fy);
                 const V4 Fxm = get(S_FX);
                 if (jout) {
@@ -662,10 +749,11 @@ int swe_step_wave(pyrohip_state *s, double dx, double dy, double grav, int limit
     if (nparts) *nparts = P.nunits;
     double *Uout = s->alt_base + geom_lead(g);
     const dim3 grid(8 * ((P.nunits + 7) / 8)), block(64);
-    if (riemann == 1)
-        PYRO_LAUNCH(c, "k_sw_wave", k_sw_wave<1>, grid, block, 0, (const double *)s->d, Uout, g, P, S, part);
-    else
-        PYRO_LAUNCH(c, "k_sw_wave", k_sw_wave<0>, grid, block, 0, (const double *)s->d, Uout, g, P, S, part);
+    using KernelT = void (*)(const double *, double *, Geom, SWW, const StepScalars *, double *);
+    static const KernelT kernels[2][2] = {{k_sw_wave<0, false>, k_sw_wave<0, true>},
+                                          {k_sw_wave<1, false>, k_sw_wave<1, true>}};
+    PYRO_LAUNCH(c, "k_sw_wave", kernels[riemann == 1 ? 1 : 0][limiter == 2 ? 1 : 0], grid, block, 0,
+                (const double *)s->d, Uout, g, P, S, part);
     if (!frame_done) {
         // the ghost frame is carried over (the reference updates the interior in place)
         const int fb = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + 256 / (2 * g.ng) - 1) / (256 / (2 * g.ng));
