@@ -135,6 +135,14 @@ typedef struct pyrohip_geom {
     const double *Lx, *Ly, *Ax, *Ay, *V, *dlogAx, *dlogAy, *x2d;
     const double *sint, *sinb, *sinc;
     double xmin, ymin;
+    /* optional (may be NULL): the 1-d factors the 2-d arrays above are products of, evaluated by
+       the caller with the reference's expressions (mesh/patch.py:262-312) so that the kernels can
+       rebuild every geometry value in registers, bit for bit, instead of reading eight planes:
+         rowf: 7 arrays of qx doubles  A = -2 pi xl^2, D = xr^2 - xl^2, F = xr - xl,
+               G = xr^2 + xl^2 + xr xl, Ly = x dy, dlogAx = 2 / x, x
+         colf: 4 arrays of qy doubles  B = cos(yr) - cos(yl), C = pi sin(yl), E = (-2 pi / 3) B, T = tan(y)
+       with Ax = |A B|, Ay = |C D|, V = |(E F) G|, dlogAy = 1 / (T x), Lx = dx.               */
+    const double *rowf, *colf;
 } pyrohip_geom;
 int pyrohip_state_set_geometry(pyrohip_state *s, const pyrohip_geom *g);
 /* Parameters of the "ramp" boundary of the double Mach reflection problem

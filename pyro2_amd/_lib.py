@@ -26,7 +26,8 @@ class GeomArrays(C.Structure):
     """pyrohip_geom: the arrays of a SphericalPolar grid (include/pyrohip.h)"""
     NAMES = ("Lx", "Ly", "Ax", "Ay", "V", "dlogAx", "dlogAy", "x2d", "sint", "sinb", "sinc")
     _fields_ = [(n, C.POINTER(C.c_double)) for n in NAMES] + \
-               [("xmin", C.c_double), ("ymin", C.c_double)]
+               [("xmin", C.c_double), ("ymin", C.c_double),
+                ("rowf", C.POINTER(C.c_double)), ("colf", C.POINTER(C.c_double))]
 
 
 ERR_STATE = 10002

@@ -40,6 +40,9 @@ UNITS = [
     # hides latency there is independent work inside a wavefront (12.30 -> 12.15 ms)
     ("comp_wave.hip", "wave_exact", ["-ffp-contract=off", "-DPYRO_FAST=0"] + WAVE_SCHED),
     ("comp_wave.hip", "wave_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1"] + WAVE_SCHED),
+    # the row-marching kernel of SphericalPolar grids (round 6)
+    ("comp_sph_wave.hip", "sphw_exact", ["-ffp-contract=off", "-DPYRO_FAST=0"]),
+    ("comp_sph_wave.hip", "sphw_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1"]),
     ("comp_api.hip", "comp_api", ["-ffp-contract=off"]),
     ("multigrid.hip", "multigrid", ["-ffp-contract=off"]),
     ("mg_march.hip", "mg_march", ["-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=200000"]),

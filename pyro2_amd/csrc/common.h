@@ -172,6 +172,10 @@ struct SphGeom {
     const double *Lx, *Ly, *Ax, *Ay, *V, *dlAx, *dlAy, *x2d;
     const double *sint, *sinb, *sinc;
     double xmin, ymin;
+    // the 1-d factors of the planes (pyrohip_geom::rowf / colf), nullptr when the caller gave none:
+    // 7 arrays of qxp doubles (A D F G Ly dlogAx x), 4 of qyp doubles (B C E T)
+    const double *rowf = nullptr, *colf = nullptr;
+    size_t qxp = 0, qyp = 0;
 };
 }  // namespace pyro
 

@@ -16,6 +16,9 @@ int comp_step_wave_ex(pyrohip_state *, const pyrohip_comp_params *, double, cons
                       const double **);
 int comp_cfl_min_device(pyrohip_state *, const pyrohip_comp_params *, const double **);
 int comp_step_sph(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_step_wave_sph(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_step_wave_sph_ex(pyrohip_state *, const pyrohip_comp_params *, double, const StepScalars *,
+                          const double **);
 int comp_step_fused_sph(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_fused_sph_ex(pyrohip_state *, const pyrohip_comp_params *, double, const StepScalars *,
                            const double **);
@@ -47,6 +50,9 @@ int comp_step_wave_ex(pyrohip_state *, const pyrohip_comp_params *, double, cons
                       const double **);
 int comp_cfl_min_device(pyrohip_state *, const pyrohip_comp_params *, const double **);
 int comp_step_sph(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_step_wave_sph(pyrohip_state *, const pyrohip_comp_params *, double);
+int comp_step_wave_sph_ex(pyrohip_state *, const pyrohip_comp_params *, double, const StepScalars *,
+                          const double **);
 int comp_step_fused_sph(pyrohip_state *, const pyrohip_comp_params *, double);
 int comp_step_fused_sph_ex(pyrohip_state *, const pyrohip_comp_params *, double, const StepScalars *,
                            const double **);
@@ -176,9 +182,10 @@ __global__ __launch_bounds__(256) void k_fill_frame2(const double *src, double *
 // (x sides of a slab that are cuts -- PYROHIP_BC_HALO -- are identity maps: the halo rows are data
 // that arrived with the exchange, the y rule runs along them like along an interior row and the
 // other buffer's frame takes a copy, which the exchange posted by the coming step overwrites)
-static bool frame_fill_ok(const pyrohip_state *s, bool halo_ok = false)
+static bool frame_fill_ok(const pyrohip_state *s, bool halo_ok = false, bool sph_ok = false)
 {
-    if (s->nvar != 4 || (s->nb_set && !halo_ok) || s->user_bc || s->ramp_bc || s->sph || !s->alt_base) return false;
+    if (s->nvar != 4 || (s->nb_set && !halo_ok) || s->user_bc || s->ramp_bc || (s->sph && !sph_ok) || !s->alt_base)
+        return false;
     for (int k = 0; k < 16; k++) {
         const int b = s->bc[k];
         if (b != PYROHIP_BC_OUTFLOW && b != PYROHIP_BC_REFLECT_EVEN && b != PYROHIP_BC_REFLECT_ODD &&
@@ -251,9 +258,9 @@ int launch_fill_frame2(pyrohip_state *s, bool *done)
 // the buffer that holds the final state then depends on their parity.  What a single step leaves
 // there is the filled ghost frame of the state BEFORE the last step that advanced -- whose
 // interior sits untouched in the other buffer (inactive launches store nothing): rebuild it.
-int restore_frame_after_inactive(pyrohip_state *s, int steps, int max_steps)
+int restore_frame_after_inactive(pyrohip_state *s, int steps, int max_steps, bool halo_ok, bool sph_ok)
 {
-    if (steps < 1 || steps >= max_steps || !s->alt_base || !frame_fill_ok(s)) return 0;
+    if (steps < 1 || steps >= max_steps || !s->alt_base || !frame_fill_ok(s, halo_ok, sph_ok)) return 0;
     pyrohip_ctx *c = s->ctx;
     const Geom &g = s->g;
     const int rows_per_block = 256 / (2 * g.ng);
@@ -309,6 +316,8 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
     PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
     const bool wave = !sphf && ((p->kernel_set == 2) ||
                                 (p->kernel_set == -1 && wave_kernel_pays(s->g)));
+    // SphericalPolar grid on the row-marching kernel (comp_sph_wave.hip: reads a filled frame)
+    const bool sphw = sphf && ((p->kernel_set == 2) || (p->kernel_set == -1 && wave_kernel_pays(s->g)));
     const double *dmin = nullptr;
     bool first = true;
     int rc = 0;
@@ -316,7 +325,7 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
     // steps after the first: the tile kernel applies the boundary rules itself where it can
     // (the first one needs filled ghost cells for the CFL minimum over the whole array)
     // (the spherical kernel reads every ghost cell through the boundary rules anyway)
-    const bool fuse = sphf || comp_can_fuse_fill(s, p, wave);
+    const bool fuse = (sphf && !sphw) || comp_can_fuse_fill(s, p, wave);
     pyrohip_comp_params pf = *p;
     // step_launches 1: the row-marching kernel as the ONLY launch of a step (single domain;
     // outflow / reflect / periodic sides, the same kind for the four variables): it reads ghost
@@ -365,7 +374,7 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
         pf.fuse_fill = (fuse && !first) ? 1 : 0;
         s->frame_prefilled = false;
         if (rc == 0 && !pf.fuse_fill) {
-            if (wave && frame_fill_ok(s, true)) {      // fill + the other buffer's ghost frame: one launch
+            if ((wave && frame_fill_ok(s, true)) || (sphw && frame_fill_ok(s, false, true))) {      // fill + the other buffer's ghost frame: one launch
                 const Geom &g = s->g;
                 const int rows_per_block = 256 / (2 * g.ng);
                 const int nblk = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + rows_per_block - 1) / rows_per_block;
@@ -409,7 +418,10 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
         s->cfl_kind = 0;
         s->pol_next = d_pol;    // (one launch per step: this is step 0, its dt is in S[0])
         s->pol_m = 0;
-        if (sphf)
+        if (sphw)
+            rc = p->fast_math ? fastm::comp_step_wave_sph_ex(s, &pf, 0.0, s->d_scal, &dmin)
+                              : exact::comp_step_wave_sph_ex(s, &pf, 0.0, s->d_scal, &dmin);
+        else if (sphf)
             rc = p->fast_math ? fastm::comp_step_fused_sph_ex(s, &pf, 0.0, s->d_scal, &dmin)
                               : exact::comp_step_fused_sph_ex(s, &pf, 0.0, s->d_scal, &dmin);
         else if (wave)
@@ -476,6 +488,10 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
                     (double *)nullptr, g, (const int *)s->d_bc);
         PYRO_CHECK_HIP(hipGetLastError());
     }
+    // (the row-marching kernels work on filled frames: the iterations past the last step that
+    // advanced kept filling them -- rebuild the final state's, restore_frame_after_inactive)
+    if (!one_launch && (wave || sphw) && !(flagv & 1))
+        PYRO_TRY(restore_frame_after_inactive(s, H.steps, max_steps, true, sphw));
     // the minimum of the last launch belongs to the state only if that launch advanced it
     s->next_cfl_min = (H.steps == max_steps && !(flagv & 1)) ? lastmin : -1.0;
     s->cfl_kind = 0;
@@ -557,7 +573,12 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
         // last thing that wrote the state was the library's own full fill.  Ghost cells a host-side
         // boundary callback wrote (uploaded afterwards) are read from memory by the staged set.
         const bool fuse_sph = comp_can_fuse_sph(s, p) && (p->fuse_fill || s->ghost_by_rules);
-        if (fuse_sph)
+        if (fuse_sph && (p->kernel_set == 2 || (p->kernel_set == -1 && wave_kernel_pays(s->g)))) {
+            // the row-marching kernel reads the state's ghost cells from memory: filled here if
+            // the caller left the fill to the step
+            if (p->fuse_fill) PYRO_TRY(pyrohip_fill_bc(s, -1));
+            rc = p->fast_math ? fastm::comp_step_wave_sph(s, p, dt) : exact::comp_step_wave_sph(s, p, dt);
+        } else if (fuse_sph)
             rc = p->fast_math ? fastm::comp_step_fused_sph(s, p, dt) : exact::comp_step_fused_sph(s, p, dt);
         else
             rc = p->fast_math ? fastm::comp_step_sph(s, p, dt) : exact::comp_step_sph(s, p, dt);
@@ -758,7 +779,7 @@ int pyrohip_comp_rk_evolve(pyrohip_state *y, const pyrohip_comp_params *p, pyroh
         s->alt_base = old_base;
         s->d = s->base + geom_lead(s->g);
     }
-    if (!(flagv & 1)) PYRO_TRY(restore_frame_after_inactive(s, H.steps, max_steps));
+    if (!(flagv & 1)) PYRO_TRY(restore_frame_after_inactive(s, H.steps, max_steps, false, false));
     s->next_cfl_min = (H.steps == max_steps && !(flagv & 1)) ? lastmin : -1.0;
     s->cfl_kind = 1;
     s->cfl_is_global = false;

@@ -394,73 +394,11 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused(const double
 // Boundaries: outflow / reflect / periodic sides (index maps of the tile kernel); everything
 // else steps through the staged set.
 // ===========================================================================
-struct SphG {   // kernel-side geometry (pyrohip_state_set_geometry)
-    const double *Lx, *Ly, *Ax, *Ay, *V, *dlAx, *dlAy, *x2d, *sint, *sinb, *sinc;
-    double xmin;
-};
+#include "sph_common.h"
 constexpr int FLDS_DOUBLES_SPH = FLDS_DOUBLES + 2 * FNT;       // + the face pressures
 constexpr size_t FLDS_BYTES_SPH = (size_t)FLDS_DOUBLES_SPH * sizeof(double);
 
-// CGF interface state, its flux without the pressure and its pressure
-// (riemann_flux(return_cons=True) + cons_to_prim, unsplit_fluxes.py:411-423)
-__device__ __forceinline__ Cons sphf_face(const Cons &Ul, const Cons &Ur, double gamma, bool x,
-                                          bool wall, double &pface)
-{
-    const ConsN Uo = cgf_state(to_nf(Ul, x), to_nf(Ur, x), gamma, wall);
-    pface = cons_to_prim(from_nf(Uo, x), gamma).p;
-    return from_nf(cons_flux_n(Uo, gamma, x, false), x);
-}
-
-__device__ __forceinline__ Cons sphf_corrected(const Cons &U, const Cons &Fhi, double Ahi,
-                                               const Cons &Flo, double Alo, double hv)
-{
-    Cons r;   // U += -hdtV*(F_hi*A_hi - F_lo*A_lo), unsplit_fluxes.py:447-471
-    r.d = U.d + (-hv * (Fhi.d * Ahi - Flo.d * Alo));
-    r.E = U.E + (-hv * (Fhi.E * Ahi - Flo.E * Alo));
-    r.mx = U.mx + (-hv * (Fhi.mx * Ahi - Flo.mx * Alo));
-    r.my = U.my + (-hv * (Fhi.my * Ahi - Flo.my * Alo));
-    return r;
-}
-
-// method_compute_timestep takes its minimum over the WHOLE array (simulation.py:284-288), and
-// on this grid a ghost cell's Lx, Ly are its own: the minimum over the ghost cells that take
-// their value from interior cell (i, j) -- the cell's new state with the signs of the boundary
-// rule, the lengths of the ghost cell -- folded into `cfl`, so that the next dt needs neither a
-// ghost fill nor a reduction launch
-__device__ __forceinline__ double sphf_ghost_cfl(const Cons &U, double gamma, const Geom &g,
-                                                 const FP &P, const SphG &G, int i, int j, double cfl)
-{
-    const int ng = g.ng;
-    const bool ei = (i < g.ilo + ng) || (i > g.ihi - ng), ej = (j < g.jlo + ng) || (j > g.jhi - ng);
-    if (!ei && !ej) return cfl;
-    for (int a = -1; a < 2 * ng; a++) {       // a = -1: the cell's own row
-        int r = i;
-        if (a >= 0) {
-            r = a < ng ? a : g.ihi + 1 + (a - ng);
-            if (!ei || bc_src(P.mr, r, g.ilo, g.ihi) != i) continue;
-        }
-        for (int b = -1; b < 2 * ng; b++) {
-            int c = j;
-            if (b >= 0) {
-                c = b < ng ? b : g.jhi + 1 + (b - ng);
-                if (!ej || bc_src(P.mc, c, g.jlo, g.jhi) != j) continue;
-            }
-            if (a < 0 && b < 0) continue;
-            const unsigned sd = (r < g.ilo ? 1u : 0u) | (r > g.ihi ? 2u : 0u) | (c < g.jlo ? 4u : 0u) |
-                                (c > g.jhi ? 8u : 0u);
-            Cons Ug = U;
-            Ug.d = odd_sides(P.odd & sd) ? -Ug.d : Ug.d;
-            Ug.E = odd_sides((P.odd >> 4) & sd) ? -Ug.E : Ug.E;
-            Ug.mx = odd_sides((P.odd >> 8) & sd) ? -Ug.mx : Ug.mx;
-            Ug.my = odd_sides((P.odd >> 12) & sd) ? -Ug.my : Ug.my;
-            const size_t kk = (size_t)r * g.pitch + c;
-            cfl = fmin(cfl, cfl_cell(Ug, gamma, G.Lx[kk], G.Ly[kk]));
-        }
-    }
-    return cfl;
-}
-
-template <bool STD>
+template <bool STD, bool FAC>
 __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused_sph(const double *__restrict__ Uin,
                                                        double *__restrict__ Uout, Geom g, FP P_in,
                                                        SphG G, int *__restrict__ flag,
@@ -537,8 +475,8 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused_sph(const do
     const int ic = in_arr ? i : g.qx - 1, jc = in_arr ? j : g.qy - 1;
     const size_t k = (size_t)ic * p + jc;
     // (cells one row / column up: inside the array for every cell the tile uses)
-    const size_t kpi = (size_t)(ic + 1 < g.qx ? ic + 1 : ic) * p + jc;
-    const size_t kpj = (size_t)ic * p + (jc + 1 < g.qy ? jc + 1 : jc);
+    const int ipc = (ic + 1 < g.qx) ? ic + 1 : ic, jpc = (jc + 1 < g.qy) ? jc + 1 : jc;
+    const SphAt<FAC> GA{G, p, P.dx};
     const double hdt = 0.5 * P.dt;
 
     // ---- phase 1: xi, slopes, tracing, sources for the thread's own cell --------
@@ -577,18 +515,18 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused_sph(const do
         const double cs = psqrt(pdiv(gamma * q0[3], q0[0]));   // interface.py:122
         Trace lo, hi;
         trace_states(q0[0], q0[1], q0[2], q0[3], dqx[0], dqx[1], dqx[2], dqx[3], gamma,
-                     pdiv(P.dt, G.Lx[k]), lo, hi);
+                     pdiv(P.dt, GA.Lx(ic, jc)), lo, hi);
         {   // :216-224
-            const double rs = -0.5 * P.dt * G.dlAx[k] * q0[0] * q0[1];
+            const double rs = -0.5 * P.dt * GA.dlAx(ic, jc) * q0[0] * q0[1];
             hi.r += rs; lo.r += rs;
             hi.p += rs * cs * cs; lo.p += rs * cs * cs;
         }
         XM = prim_to_cons(Prim{lo.r, lo.un, lo.ut, lo.p}, gamma);
         XP = prim_to_cons(Prim{hi.r, hi.un, hi.ut, hi.p}, gamma);
         trace_states(q0[0], q0[2], q0[1], q0[3], dqy[0], dqy[2], dqy[1], dqy[3], gamma,
-                     pdiv(P.dt, G.Ly[k]), lo, hi);
+                     pdiv(P.dt, GA.Ly(ic, jc)), lo, hi);
         {   // :226-234
-            const double rs = -0.5 * P.dt * G.dlAy[k] * q0[0] * q0[2];
+            const double rs = -0.5 * P.dt * GA.dlAy(ic, jc) * q0[0] * q0[2];
             hi.r += rs; lo.r += rs;
             hi.p += rs * cs * cs; lo.p += rs * cs * cs;
         }
@@ -622,7 +560,7 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused_sph(const do
             Us.d = fmax(Us.d, P.small_dens);
             double Sx = Us.d * P.grav;
             double SE = Us.mx * P.grav;
-            Sx += pdiv(Us.my * Us.my, Us.d * G.x2d[ks]);
+            Sx += pdiv(Us.my * Us.my, Us.d * GA.x(si, sj));
             double Sy = pdiv(-Us.mx * Us.my, Us.d);
             SE = odd_sides((P.odd >> 4) & sd) ? -SE : SE;
             Sx = odd_sides((P.odd >> 8) & sd) ? -Sx : Sx;
@@ -656,21 +594,21 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused_sph(const do
     // take the next cell's
     if (tj >= 1 && tj <= FBJ - 2) {
         const Cons Fhi = lds_get(B0 + 4 * FNT, t + 1);   // F_yT at (i, j+1)
-        const double Ahi = G.Ay[kpj], Alo = G.Ay[k];
+        const double Ahi = GA.Ay(ic, jpc), Alo = GA.Ay(ic, jc);
         const double dpy = PT[FNT + t + 1] - pyt;
-        XM = sphf_corrected(XM, Fhi, Ahi, FyT, Alo, pdiv(hdt, G.V[k]));
-        XM.my += pdiv(-hdt * dpy, G.Ly[k]);
-        XP = sphf_corrected(XP, Fhi, Ahi, FyT, Alo, pdiv(hdt, G.V[kpi]));
-        XP.my += pdiv(-hdt * dpy, G.Ly[kpi]);
+        XM = sphf_corrected(XM, Fhi, Ahi, FyT, Alo, pdiv(hdt, GA.V(ic, jc)));
+        XM.my += pdiv(-hdt * dpy, GA.Ly(ic, jc));
+        XP = sphf_corrected(XP, Fhi, Ahi, FyT, Alo, pdiv(hdt, GA.V(ipc, jc)));
+        XP.my += pdiv(-hdt * dpy, GA.Ly(ipc, jc));
     }
     if (ti >= 1 && ti <= FBI - 2) {
         const Cons Fhi = lds_get(B0, t + FBJ);           // F_xT at (i+1, j)
-        const double Ahi = G.Ax[kpi], Alo = G.Ax[k];
+        const double Ahi = GA.Ax(ipc, jc), Alo = GA.Ax(ic, jc);
         const double dpx = PT[t + FBJ] - pxt;
-        YM = sphf_corrected(YM, Fhi, Ahi, FxT, Alo, pdiv(hdt, G.V[k]));
-        YM.mx += pdiv(-hdt * dpx, G.Lx[k]);
-        YP = sphf_corrected(YP, Fhi, Ahi, FxT, Alo, pdiv(hdt, G.V[kpj]));
-        YP.mx += pdiv(-hdt * dpx, G.Lx[kpj]);
+        YM = sphf_corrected(YM, Fhi, Ahi, FxT, Alo, pdiv(hdt, GA.V(ic, jc)));
+        YM.mx += pdiv(-hdt * dpx, GA.Lx(ic, jc));
+        YP = sphf_corrected(YP, Fhi, Ahi, FxT, Alo, pdiv(hdt, GA.V(ic, jpc)));
+        YP.mx += pdiv(-hdt * dpx, GA.Lx(ic, jpc));
     }
     lds_put(S, t, XP);
     lds_put(S + 4 * FNT, t, YP);
@@ -690,11 +628,11 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused_sph(const do
     // interface.py:366-376: only faces i in [ilo, ihi], j in [jlo, jhi]
     if (ti >= 1 && tj >= 1 && tj <= FBJ - 2 && i >= g.ilo && i <= g.ihi && j >= g.jlo && j <= g.jhi) {
         const double divU_x = 0.5 * (d00 + D[t + 1]);
-        avx = P.cvisc * fmax(-divU_x * G.Lx[k], 0.0);
+        avx = P.cvisc * fmax(-divU_x * GA.Lx(ic, jc), 0.0);
     }
     if (tj >= 1 && ti >= 1 && ti <= FBI - 2 && j >= g.jlo && j <= g.jhi && i >= g.ilo && i <= g.ihi) {
         const double divU_y = 0.5 * (d00 + D[t + FBJ]);
-        avy = P.cvisc * fmax(-divU_y * G.Ly[k], 0.0);
+        avy = P.cvisc * fmax(-divU_y * GA.Ly(ic, jc), 0.0);
     }
     if (i - 1 >= g.ilo && i - 1 <= g.ihi && j >= g.jlo && j <= g.jhi)
         Umx.d = fmax(Umx.d, P.small_dens);
@@ -723,20 +661,20 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused_sph(const do
     // gradients and the source predictor-corrector (simulation.py:375-423) + CFL -----------
     double cfl = INFINITY;
     if (ti >= 1 && ti <= FBI - 2 && tj >= 1 && tj <= FBJ - 2 && cell_interior) {
-        const double dtdV = pdiv(P.dt, G.V[k]);
+        const double dtdV = pdiv(P.dt, GA.V(ic, jc));
         const Cons Fxh = lds_get(B0, t + FBJ);
         const Cons Fyh = lds_get(B0 + 4 * FNT, t + 1);
-        const double Ax0 = G.Ax[k], Ax1 = G.Ax[kpi], Ay0 = G.Ay[k], Ay1 = G.Ay[kpj];
+        const double Ax0 = GA.Ax(ic, jc), Ax1 = GA.Ax(ipc, jc), Ay0 = GA.Ay(ic, jc), Ay1 = GA.Ay(ic, jpc);
         double Un[4];
         const double Uo[4] = {Uc.d, Uc.E, Uc.mx, Uc.my};
         Un[0] = Uo[0] + dtdV * (Fx.d * Ax0 - Fxh.d * Ax1 + Fy.d * Ay0 - Fyh.d * Ay1);
         Un[1] = Uo[1] + dtdV * (Fx.E * Ax0 - Fxh.E * Ax1 + Fy.E * Ay0 - Fyh.E * Ay1);
         Un[2] = Uo[2] + dtdV * (Fx.mx * Ax0 - Fxh.mx * Ax1 + Fy.mx * Ay0 - Fyh.mx * Ay1);
         Un[3] = Uo[3] + dtdV * (Fx.my * Ax0 - Fxh.my * Ax1 + Fy.my * Ay0 - Fyh.my * Ay1);
-        Un[2] -= pdiv(P.dt * (PT[t + FBJ] - px), G.Lx[k]);
-        Un[3] -= pdiv(P.dt * (PT[FNT + t + 1] - py), G.Ly[k]);
+        Un[2] -= pdiv(P.dt * (PT[t + FBJ] - px), GA.Lx(ic, jc));
+        Un[3] -= pdiv(P.dt * (PT[FNT + t + 1] - py), GA.Ly(ic, jc));
         // S_old = S(U_old); U += dt S_old; S_new (time-centred x-momentum); U += dt/2 (S_new - S_old)
-        const double r = G.x2d[k], grav = P.grav, dt = P.dt;
+        const double r = GA.x(ic, jc), grav = P.grav, dt = P.dt;
         const double Sx_g_old = Uo[0] * grav;
         const double SE_old = Uo[2] * grav;
         const double Sx_old = Sx_g_old + pdiv(Uo[3] * Uo[3], Uo[0] * r);
@@ -755,8 +693,8 @@ __global__ __launch_bounds__(FNT, PYRO_FUSED_MINW) void k_ctu_fused_sph(const do
         Uw.mx = Un[2] + 0.5 * dt * (Sx_new - Sx_old);
         Uw.my = Un[3] + 0.5 * dt * (Sy_new - Sy_old);
         Uout[k] = Uw.d; Uout[pl + k] = Uw.E; Uout[2 * pl + k] = Uw.mx; Uout[3 * pl + k] = Uw.my;
-        cfl = cfl_cell(Uw, gamma, G.Lx[k], G.Ly[k]);
-        cfl = sphf_ghost_cfl(Uw, gamma, g, P, G, i, j, cfl);
+        cfl = cfl_cell(Uw, gamma, GA.Lx(ic, jc), GA.Ly(ic, jc));
+        cfl = sphf_ghost_cfl<FAC>(Uw, gamma, g, P, GA, i, j, cfl);
     }
     cfl = block_reduce_min(cfl);
     if (t == 0) partial[tile] = cfl;
@@ -996,7 +934,9 @@ int comp_step_fused_sph_ex(pyrohip_state *s, const pyrohip_comp_params *p, doubl
         for (int sd = 0; sd < 4; sd++)
             if (s->bc[n * 4 + sd] == PYROHIP_BC_REFLECT_ODD) P.odd |= 1u << (4 * n + sd);
     const SphGeom &h = *s->sph;
-    const SphG G{h.Lx, h.Ly, h.Ax, h.Ay, h.V, h.dlAx, h.dlAy, h.x2d, h.sint, h.sinb, h.sinc, h.xmin};
+    const SphG G{h.Lx, h.Ly, h.Ax, h.Ay, h.V, h.dlAx, h.dlAy, h.x2d, h.sint, h.sinb, h.sinc, h.xmin,
+                 h.rowf, h.colf, (int)h.qxp, (int)h.qyp};
+    const int fac = (h.rowf && h.colf && !getenv("PYRO_SPH_PLANES")) ? 1 : 0;   // (PYRO_SPH_PLANES: developer A/B)
     const int nti = (g.nx + FTI - 1) / FTI;
     P.ntj = (g.ny + FTJ - 1) / FTJ;
     P.ntiles = nti * P.ntj;
@@ -1004,19 +944,20 @@ int comp_step_fused_sph_ex(pyrohip_state *s, const pyrohip_comp_params *p, doubl
     double *part = (double *)c->reduce.p;
     using KernelT = void (*)(const double *, double *, Geom, FP, SphG, int *, double *,
                              const StepScalars *);
-    static const KernelT kernels[2] = {k_ctu_fused_sph<false>, k_ctu_fused_sph<true>};
+    static const KernelT kernels[2][2] = {{k_ctu_fused_sph<false, false>, k_ctu_fused_sph<true, false>},
+                                          {k_ctu_fused_sph<false, true>, k_ctu_fused_sph<true, true>}};
 #ifndef PYRO_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        for (int b = 0; b < 2; b++)
-            PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)kernels[b],
+        for (int b = 0; b < 4; b++)
+            PYRO_CHECK_HIP(hipFuncSetAttribute((const void *)kernels[b >> 1][b & 1],
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)FLDS_BYTES_SPH));
         attr_set = true;
     }
 #endif
     const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
-    PYRO_LAUNCH(c, "k_ctu_fused_sph", kernels[std_rec], dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES_SPH,
+    PYRO_LAUNCH(c, "k_ctu_fused_sph", kernels[fac][std_rec], dim3(P.ntiles), dim3(FBJ, FBI), FLDS_BYTES_SPH,
                 (const double *)Uin, Uout, g, P, G, s->d_flag, part, S);
     const double *dmin;
     PYRO_TRY(fused_tail(s, part, P.ntiles, true, &dmin, S != nullptr));   // the kernel wrote the ghost frame

@@ -1,0 +1,516 @@
+// The compressible CTU step on a SphericalPolar grid (x = r, y = theta; pyro/mesh/patch.py:242-312)
+// as ONE launch of autonomous row-marching wavefronts -- the design of comp_wave.hip (kernel_set 2)
+// with the geometry terms of pyro/compressible (unsplit_fluxes.py:411-440, 444-494; interface.py:
+// 106, 215-234, 331-376; simulation.py:117-124, 330-423; riemann.py:1092-1096, 1156-1171):
+//
+//   * one wavefront = 64 columns (lane = column j = theta index), the inner 56 updated; it walks
+//     down a strip of rows (row i = r index); the x direction lives in a 5-row register window,
+//     what a row hands to the next (face states, F_xT, F_x, the face pressures) in a per-lane LDS
+//     stash (own-lane slots, no barrier); the y direction comes from the neighbouring lanes by
+//     whole-wave DPP rotations;
+//   * the geometry is rebuilt in registers from its 1-d factors (sph_common.h: SphAt<true>; the
+//     row factors are wavefront-uniform: scalar loads) or read from the planes (SphAt<false>);
+//   * the arithmetic is the tile kernel's (comp_fused.hip: k_ctu_fused_sph), expression by
+//     expression -- tracing with dt / Lx, dt / Ly and the geometric source, radial gravity + the
+//     geometric source terms on the four face states (a ghost cell takes the value of the cell its
+//     boundary rule copies from, with the variable's sign), CGF interface states whose pressure
+//     stays out of the area-weighted flux difference and enters as a gradient, the spherical
+//     vertex divergence, transverse corrections / update / CFL with areas, volumes and lengths,
+//     the source predictor-corrector -- so the bit-faithful build is BIT-IDENTICAL to it and to
+//     the staged spherical set (tests/test_device_compressible.py, tests/test_fullsize_legs.py).
+//
+// The tile kernel recomputes a 4-cell apron around 14 x 30 interior cells (2369 lane-instructions
+// per cell update, 81 k wavefronts at 2048^2: profiles/r05_sph2048_pmc.json); here the apron is 8
+// of 64 columns and 8 warm-up rows per strip.  Ghost cells of the state are read from a FILLED
+// frame (the caller's fill / k_fill_frame2 of a device-side run); the source terms and the CFL
+// minimum of the new state's ghost cells go through the boundary rules' index maps like the tile
+// kernel's.  Boundaries: outflow / reflect / periodic sides.
+// Compiled twice like the other compressible units (PYRO_FAST = 0 / 1).
+#include "common.h"
+#include "hydro.h"
+#include "reduce.h"
+
+#ifndef PYRO_FAST
+#define PYRO_FAST 0
+#endif
+#if PYRO_FAST
+#define PYRO_NS fastm
+#else
+#define PYRO_NS exact
+#endif
+
+namespace pyro {
+namespace PYRO_NS {
+
+#include "fused_common.h"
+#include "sph_common.h"
+
+namespace {
+
+constexpr int SWOUT = 56;          // columns a wavefront updates (reach of a cell update: 4 columns)
+#if defined(PYRO_EMU)
+#define SPHW_FENCE() do {} while (0)
+#else
+#define SPHW_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+#if !defined(PYRO_EMU)
+template <int CTRL> __device__ __forceinline__ double sphw_dpp(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lm1(double v) { return sphw_dpp<0x13C>(v); }   // wave_ror:1: lane l-1
+__device__ __forceinline__ double lp1(double v) { return sphw_dpp<0x134>(v); }   // wave_rol:1: lane l+1
+#else
+__device__ __forceinline__ double lm1(double v) { return __shfl_up(v, 1, 64); }
+__device__ __forceinline__ double lp1(double v) { return __shfl_down(v, 1, 64); }
+#endif
+__device__ __forceinline__ Cons lm1(const Cons &U) { return Cons{lm1(U.d), lm1(U.E), lm1(U.mx), lm1(U.my)}; }
+__device__ __forceinline__ Cons lp1(const Cons &U) { return Cons{lp1(U.d), lp1(U.E), lp1(U.mx), lp1(U.my)}; }
+
+// per-lane LDS stash (slot s of lane l at doubles s * 64 + l)
+constexpr int SS_YM = 0, SS_YP = 4, SS_FXT = 8, SS_XP = 12, SS_XPC = 16, SS_FX = 20, SS_L2 = 24,
+              SS_PXT = 32, SS_PX = 33, SS_CFL = 34,
+              SS_CB = 35, SS_CC = 36, SS_CT = 37,     // FAC: the lane's column factors B, C, T (sph_common.h)
+              SS_SLOTS = 38;
+constexpr size_t SPHW_LDS_BYTES = (size_t)SS_SLOTS * 64 * sizeof(double);
+
+__device__ __forceinline__ Cons sget(const double *st, int s)
+{
+    return Cons{st[s * 64], st[(s + 1) * 64], st[(s + 2) * 64], st[(s + 3) * 64]};
+}
+__device__ __forceinline__ void sput(double *st, int s, const Cons &U)
+{
+    st[s * 64] = U.d; st[(s + 1) * 64] = U.E; st[(s + 2) * 64] = U.mx; st[(s + 3) * 64] = U.my;
+}
+
+template <bool STD, bool FAC>
+__global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ Uin, double *__restrict__ Uout,
+                                                    Geom g, FP P, SphG G, int *__restrict__ flag,
+                                                    double *__restrict__ partial,
+                                                    const StepScalars *__restrict__ S)
+{
+    HIP_DYNAMIC_SHARED(double, lds)
+    const int l = threadIdx.x;
+    double *st = lds + l;
+    // workgroup -> (column strip, row strip): XCD x takes the units [x per, (x + 1) per) (comp_wave.hip)
+    const int per = (P.nunits + 7) / 8;
+    const int unit = pyro_uniform(((int)blockIdx.x % 8) * per + (int)blockIdx.x / 8);
+    if (unit >= P.nunits) return;
+    const int cb = pyro_uniform(unit % P.ncb), sb = pyro_uniform(unit / P.ncb);
+    double dt = P.dt;
+    if (S) {
+        if (!S->active) {      // past tmax / after an invalid state: nothing happens
+            if (l == 0) partial[sb * P.ncb + cb] = INFINITY;
+            return;
+        }
+        dt = S->dt;
+    }
+    const int i0 = g.ilo + sb * P.L;
+    const int i1 = (sb == P.nsb - 1) ? g.ihi + 1 : i0 + P.L;
+    const int j = g.jlo + cb * SWOUT - 4 + l;
+    const int jc = (j < g.qy) ? j : g.qy - 1;              // ragged last strip: clamped, unused
+    const int jpc = (jc + 1 < g.qy) ? jc + 1 : jc;
+    const bool jin = (j >= g.jlo && j <= g.jhi);
+    const bool jout = jin && l >= 4 && l <= 59;
+    const int p = g.pitch;
+    const size_t pl = g.plane;
+    const int limiter = STD ? 2 : P.limiter;
+    const bool flat = STD || P.use_flattening;
+    const double gamma = P.gamma;
+    const SphAt<FAC> GA{G, p, P.dx};
+    // FAC: the lane's column factors sit in the stash (read where used: an LDS read instead of a
+    // load through the vector memory path in the middle of a row's work), those of column j + 1
+    // come from the neighbouring lane; the row factors of rows i-1, i, i+1 are wavefront-uniform:
+    // scalar loads where they are used
+    if (FAC) {
+        st[SS_CB * 64] = GA.cf(0, jc); st[SS_CC * 64] = GA.cf(1, jc); st[SS_CT * 64] = GA.cf(3, jc);
+    }
+    // row factor k (A D F G Ly dlogAx x) of row r: the row number is wavefront-uniform, and told so
+    // the compiler reads the table with a scalar load (no vector memory traffic, no vector register)
+    // (through the constant address space: the tables are never written by a kernel, but only a
+    // pointer that says so lets the compiler use the scalar cache)
+#if defined(PYRO_EMU)
+    const double *const rowf_c = G.rowf;
+#else
+    typedef const __attribute__((address_space(4))) double *ConstTab;
+    const ConstTab rowf_c = (ConstTab)(unsigned long long)G.rowf;
+#endif
+    auto RF = [&](int kf, int r) { return rowf_c[kf * G.qxp + pyro_uniform(r)]; };
+    const double cE = -2.0 * 3.14159265358979323846 / 3.0;     // E = (-2 pi / 3) B (mesh/patch.py: device_geometry)
+    const double hdt = 0.5 * dt;
+    const double dtdx = pdiv(dt, P.dx);                    // dt / Lx: Lx = dr everywhere (patch.py:262)
+    const int sj = bc_src(P.mc, jc, g.jlo, g.jhi);         // column the source terms of a ghost column come from
+    const unsigned sdj = (jc < g.jlo ? 4u : 0u) | (jc > g.jhi ? 8u : 0u);
+    const double sint = G.sint[jc], sinb = G.sinb[jc], sinc = G.sinc[jc];
+
+    auto loadU = [&](int row) {
+        row = row < 0 ? 0 : (row > g.qx - 1 ? g.qx - 1 : row);
+        const size_t kk = (size_t)row * p + jc;
+        return Cons{Uin[kk], Uin[pl + kk], Uin[2 * pl + kk], Uin[3 * pl + kk]};
+    };
+    auto row_in = [&](int r) { return r >= g.ilo && r <= g.ihi; };
+
+    double wr[5] = {1, 1, 1, 1, 1}, wu[5] = {0, 0, 0, 0, 0};   // primitive window, rows k-4 .. k
+    double wv[5] = {0, 0, 0, 0, 0}, wp[5] = {1, 1, 1, 1, 1};
+    double fxa = 1.0, fxb = 1.0;                               // flatten_x of rows k-4, k-3
+    Cons Ue{1.0, 1.0, 0.0, 0.0}, Uem = Ue;                     // old state, rows k-3 / k-4
+    double Dp = 0.0, up = 0.0, vp = 0.0;                       // vertex div(U) of row k-4; u, v at (k-4, j-1)
+    Cons Upre = loadU(i0 - 4), Urep = loadU(i0 - 7);
+    bool bad = false;
+    {
+        const Cons one{1.0, 1.0, 0.0, 0.0};
+        sput(st, SS_YM, one); sput(st, SS_YP, one); sput(st, SS_XP, one); sput(st, SS_XPC, one);
+        sput(st, SS_FXT, one); sput(st, SS_FX, one); sput(st, SS_L2, one); sput(st, SS_L2 + 4, one);
+        st[SS_PXT * 64] = 1.0; st[SS_PX * 64] = 1.0; st[SS_CFL * 64] = INFINITY;
+    }
+    for (int k = i0 - 4; k <= i1 + 3; k++) {
+#pragma unroll
+        for (int n = 0; n < 4; n++) { wr[n] = wr[n + 1]; wu[n] = wu[n + 1]; wv[n] = wv[n + 1]; wp[n] = wp[n + 1]; }
+        Uem = Ue;
+        Ue = Urep;
+        if (row_in(k - 3) && jin) Ue.d = fmax(Ue.d, P.small_dens);      // clean_state
+        Urep = loadU(k - 2);
+        // ---- row k arrives: primitives
+        {
+            Cons U = Upre;
+            Upre = loadU(k + 1);
+            const bool interior = row_in(k) && jin;
+            if (interior) U.d = fmax(U.d, P.small_dens);
+            bool ok;
+            const Prim q = cons_to_prim_nb(U, gamma, ok);
+            if (interior && !ok) bad = true;
+            wr[4] = q.r; wu[4] = q.u; wv[4] = q.v; wp[4] = q.p;
+        }
+        // ---- flatten_x and limit2_x of row k-2 (window index 2)
+        double fxn = 1.0, l2n[4] = {0, 0, 0, 0};
+        if (k >= i0) {
+            if (flat) fxn = flatten_1d(wp[0], wp[1], wp[3], wp[4], wu[1], wu[3], P.z0, P.z1, P.delta);
+            if (limiter != 0) {
+                l2n[0] = limit2(wr[1], wr[2], wr[3]);
+                l2n[1] = limit2(wu[1], wu[2], wu[3]);
+                l2n[2] = limit2(wv[1], wv[2], wv[3]);
+                l2n[3] = limit2(wp[1], wp[2], wp[3]);
+            }
+        }
+        double l2a[4], l2b[4];     // limit2_x of rows k-4 (slot k & 1) and k-3; row k-2 takes the older one's place
+        {
+            double *sa = st + (SS_L2 + 4 * (k & 1)) * 64, *sb2 = st + (SS_L2 + 4 * ((k + 1) & 1)) * 64;
+#pragma unroll
+            for (int n = 0; n < 4; n++) { l2a[n] = sa[n * 64]; l2b[n] = sb2[n * 64]; sa[n * 64] = l2n[n]; }
+        }
+        double Dn = 0.0, um = 0.0, vm = 0.0;
+        if (k >= i0 + 2) {
+            const int i = k - 3;                       // row c: slopes, states, x flux; row f = i - 1: y flux, update
+            const int ipc = (i + 1 < g.qx) ? i + 1 : i;
+            const bool xface = (k >= i0 + 3);          // row c has a lower x face in the strip
+            const bool frow = (k >= i0 + 4);           // row f is updated by this strip
+            // geometry of rows i-1 (w = -1), i (0), i+1 (+1) at column j (jp: j + 1)
+            const double cB = FAC ? st[SS_CB * 64] : 0.0, cC = FAC ? st[SS_CC * 64] : 0.0;
+            const double cBp = FAC ? lp1(cB) : 0.0, cCp = FAC ? lp1(cC) : 0.0;
+            auto rowi = [&](int w) { return w < 0 ? i - 1 : (w == 0 ? i : ipc); };
+            auto gAx = [&](int w) { return FAC ? fabs(RF(0, rowi(w)) * cB) : GA.Ax(rowi(w), jc); };
+            auto gAy = [&](int w, bool jp) {
+                return FAC ? fabs((jp ? cCp : cC) * RF(1, rowi(w))) : GA.Ay(rowi(w), jp ? jpc : jc);
+            };
+            auto gV = [&](int w, bool jp) {
+                return FAC ? fabs(((cE * (jp ? cBp : cB)) * RF(2, rowi(w))) * RF(3, rowi(w))) : GA.V(rowi(w), jp ? jpc : jc);
+            };
+            auto gLy = [&](int w) { return FAC ? RF(4, rowi(w)) : GA.Ly(rowi(w), jc); };
+            const double gLx = P.dx;                   // Lx = dr everywhere (patch.py:262; checked by the caller for FAC)
+            const double q0[4] = {wr[1], wu[1], wv[1], wp[1]};
+            const double qm[4] = {wr[0], wu[0], wv[0], wp[0]};
+            const double qp[4] = {wr[2], wu[2], wv[2], wp[2]};
+            double ym[4], yp[4], l2y[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                ym[n] = lm1(q0[n]);
+                yp[n] = lp1(q0[n]);
+                if (limiter != 0) l2y[n] = limit2(ym[n], q0[n], yp[n]);
+            }
+            um = ym[1]; vm = ym[2];
+            double xi = 1.0;
+            if (flat) {     // flatten_multid (reconstruction.py:167-183)
+                const double fy = flatten_1d(lm1(ym[3]), ym[3], yp[3], lp1(yp[3]), ym[2], yp[2], P.z0, P.z1, P.delta);
+                const double fym = lm1(fy), fyp = lp1(fy);
+                const double px_ = (qp[3] - qm[3] > 0) ? fxa : fxn;
+                const double py_ = (yp[3] - ym[3] > 0) ? fym : fyp;
+                xi = fmin(fmin(fxb, px_), fmin(fy, py_));
+            }
+            double dqx[4], dqy[4];
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                dqx[n] = xi * slope_shared(l2a[n], l2b[n], l2n[n], qm[n], q0[n], qp[n], limiter);
+                const double l2m = (limiter == 2) ? lm1(l2y[n]) : 0.0;
+                const double l2p = (limiter == 2) ? lp1(l2y[n]) : 0.0;
+                dqy[n] = xi * slope_shared(l2m, l2y[n], l2p, ym[n], q0[n], yp[n], limiter);
+            }
+            SPHW_FENCE();
+            // ---- external sources on the face states (simulation.py:117-124, unsplit_fluxes.py:
+            // 308-326): a ghost cell takes the value of the cell its boundary rule copies from,
+            // with the variable's sign
+            double sE, sx, sy;
+            {
+                const unsigned sd = sdj | (i < g.ilo ? 1u : 0u) | (i > g.ihi ? 2u : 0u);
+                // (an interior cell is its own source: the old state of row i is in registers)
+                double Ud = Ue.d, Umx = Ue.mx, Umy = Ue.my, xs = FAC ? RF(6, i) : GA.x(i, jc);
+                if (sd != 0) {
+                    const int si = bc_src(P.mr, i, g.ilo, g.ihi);
+                    const size_t ks = (size_t)si * p + sj;
+                    Ud = Uin[ks]; Umx = Uin[2 * pl + ks]; Umy = Uin[3 * pl + ks];
+                    xs = GA.x(si, sj);
+                }
+                Ud = fmax(Ud, P.small_dens);
+                double Sx = Ud * P.grav;
+                double SE = Umx * P.grav;
+                Sx += pdiv(Umy * Umy, Ud * xs);
+                double Sy = pdiv(-Umx * Umy, Ud);
+                SE = odd_sides((P.odd >> 4) & sd) ? -SE : SE;
+                Sx = odd_sides((P.odd >> 8) & sd) ? -Sx : Sx;
+                Sy = odd_sides((P.odd >> 12) & sd) ? -Sy : Sy;
+                sE = hdt * SE; sx = hdt * Sx; sy = hdt * Sy;
+            }
+            // ---- vertex divergence at (i-1/2, j-1/2), interface.py:331-364, and the artificial
+            // viscosity coefficients of the faces (i, j) in x and (i-1, j) in y (:366-376)
+            {
+                const double rr = (i + 0.5 - g.ng) * P.dx + G.xmin;
+                const double rl = (i - 0.5 - g.ng) * P.dx + G.xmin;
+                const double rc = (i - g.ng) * P.dx + G.xmin;
+                const double ur = 0.5 * (q0[1] + um);
+                const double ul = 0.5 * (qm[1] + up);
+                const double ux = pdiv(ur * rr * rr - ul * rl * rl, rc * rc * P.dx);
+                double vy = 0.0;
+                if (sinc != 0.0) {
+                    const double vt = 0.5 * (q0[2] + qm[2]);
+                    const double vb = 0.5 * (vm + vp);
+                    vy = pdiv(sint * vt - sinb * vb, rc * sinc * P.dy);
+                }
+                Dn = ux + vy;
+            }
+            const double Dn_p = lp1(Dn);
+            double avx = 0.0, avy = 0.0;
+            if (row_in(i) && jin) {
+                const double divU_x = 0.5 * (Dn + Dn_p);
+                avx = P.cvisc * fmax(-divU_x * gLx, 0.0);
+            }
+            if (jin && row_in(i - 1)) {
+                const double divU_y = 0.5 * (Dp + Dn);
+                avy = P.cvisc * fmax(-divU_y * gLy(-1), 0.0);
+            }
+            SPHW_FENCE();
+            // ---- x states of row c (interface.py:106, 216-224), transverse x flux on its lower face
+            const double cs = psqrt(pdiv(gamma * q0[3], q0[0]));   // interface.py:122
+            Trace lo, hi;
+            trace_states(q0[0], q0[1], q0[2], q0[3], dqx[0], dqx[1], dqx[2], dqx[3], gamma, dtdx, lo, hi);
+            {
+                const double rs = -0.5 * dt * (FAC ? RF(5, i) : GA.dlAx(i, jc)) * q0[0] * q0[1];
+                hi.r += rs; lo.r += rs;
+                hi.p += rs * cs * cs; lo.p += rs * cs * cs;
+            }
+            Cons XMn = prim_to_cons(Prim{lo.r, lo.un, lo.ut, lo.p}, gamma);
+            Cons XPn = prim_to_cons(Prim{hi.r, hi.un, hi.ut, hi.p}, gamma);
+            XMn.mx += sx; XMn.my += sy; XMn.E += sE;
+            XPn.mx += sx; XPn.my += sy; XPn.E += sE;
+            Cons FxTn{0, 0, 0, 0};
+            double pxtn = 0.0;
+            if (xface) FxTn = sphf_face(sget(st, SS_XP), XMn, gamma, true, P.solid_xl && i == g.ilo, pxtn);
+            SPHW_FENCE();
+            // ---- row f: y states corrected with F_xT of rows f, f+1 (unsplit_fluxes.py:444-481: the
+            // upper state takes the volume of the cell above its face), final y flux
+            Cons Fy{0, 0, 0, 0}, Fyh{0, 0, 0, 0};
+            double py = 0.0, pyh = 0.0;
+            if (frow) {
+                const Cons FxTp = sget(st, SS_FXT);
+                const double Ahi = gAx(0), Alo = gAx(-1);
+                const double dpx = pxtn - st[SS_PXT * 64];
+                Cons YMc = sphf_corrected(sget(st, SS_YM), FxTn, Ahi, FxTp, Alo, pdiv(hdt, gV(-1, false)));
+                YMc.mx += pdiv(-hdt * dpx, gLx);
+                Cons YPc = sphf_corrected(sget(st, SS_YP), FxTn, Ahi, FxTp, Alo, pdiv(hdt, gV(-1, true)));
+                YPc.mx += pdiv(-hdt * dpx, gLx);
+                Fy = sphf_face(lm1(YPc), YMc, gamma, false, P.solid_yl && j == g.jlo, py);
+                const Cons Umy = lm1(Uem);
+                Fy.d += avy * (Umy.d - Uem.d);
+                Fy.E += avy * (Umy.E - Uem.E);
+                Fy.mx += avy * (Umy.mx - Uem.mx);
+                Fy.my += avy * (Umy.my - Uem.my);
+                Fyh = lp1(Fy);
+                pyh = lp1(py);
+            }
+            if (xface) { sput(st, SS_FXT, FxTn); st[SS_PXT * 64] = pxtn; }
+            SPHW_FENCE();
+            // ---- y states of row c (interface.py:106, 226-234), transverse y flux on its lower face
+            trace_states(q0[0], q0[2], q0[1], q0[3], dqy[0], dqy[2], dqy[1], dqy[3], gamma,
+                         pdiv(dt, gLy(0)), lo, hi);
+            {
+                const double rs = -0.5 * dt * (FAC ? pdiv(1.0, st[SS_CT * 64] * RF(6, i)) : GA.dlAy(i, jc)) * q0[0] * q0[2];
+                hi.r += rs; lo.r += rs;
+                hi.p += rs * cs * cs; lo.p += rs * cs * cs;
+            }
+            Cons YMn = prim_to_cons(Prim{lo.r, lo.ut, lo.un, lo.p}, gamma);
+            Cons YPn = prim_to_cons(Prim{hi.r, hi.ut, hi.un, hi.p}, gamma);
+            YMn.mx += sx; YMn.my += sy; YMn.E += sE;
+            YPn.mx += sx; YPn.my += sy; YPn.E += sE;
+            sput(st, SS_YM, YMn);
+            sput(st, SS_YP, YPn);
+            double pyt = 0.0;
+            const Cons FyT = sphf_face(lm1(YPn), YMn, gamma, false, P.solid_yl && j == g.jlo, pyt);
+            SPHW_FENCE();
+            // ---- transverse correction of the x states of row c, final x flux
+            Cons XMc, XPc;
+            {
+                const Cons FyTh = lp1(FyT);            // F_yT at (i, j+1)
+                const double Ahi = gAy(0, true), Alo = gAy(0, false);
+                const double dpy = lp1(pyt) - pyt;
+                XMc = sphf_corrected(XMn, FyTh, Ahi, FyT, Alo, pdiv(hdt, gV(0, false)));
+                XMc.my += pdiv(-hdt * dpy, gLy(0));
+                XPc = sphf_corrected(XPn, FyTh, Ahi, FyT, Alo, pdiv(hdt, gV(1, false)));
+                XPc.my += pdiv(-hdt * dpy, gLy(1));
+            }
+            sput(st, SS_XP, XPn);
+            Cons Fxn{0, 0, 0, 0};
+            double pxn = 0.0;
+            if (xface) {
+                Fxn = sphf_face(sget(st, SS_XPC), XMc, gamma, true, P.solid_xl && i == g.ilo, pxn);
+                Fxn.d += avx * (Uem.d - Ue.d);
+                Fxn.E += avx * (Uem.E - Ue.E);
+                Fxn.mx += avx * (Uem.mx - Ue.mx);
+                Fxn.my += avx * (Uem.my - Ue.my);
+            }
+            sput(st, SS_XPC, XPc);
+            SPHW_FENCE();
+            // ---- conservative update of row f with the area / volume arrays, the pressure gradients
+            // and the source predictor-corrector (simulation.py:375-423) + CFL of the new state
+            if (frow && jout) {
+                const int f = i - 1;
+                const Cons Fxp = sget(st, SS_FX);
+                const double pxp = st[SS_PX * 64];
+                const double dtdV = pdiv(dt, gV(-1, false));
+                const double Ax0 = gAx(-1), Ax1 = gAx(0), Ay0 = gAy(-1, false), Ay1 = gAy(-1, true);
+                double Un[4];
+                const double Uo[4] = {Uem.d, Uem.E, Uem.mx, Uem.my};
+                Un[0] = Uo[0] + dtdV * (Fxp.d * Ax0 - Fxn.d * Ax1 + Fy.d * Ay0 - Fyh.d * Ay1);
+                Un[1] = Uo[1] + dtdV * (Fxp.E * Ax0 - Fxn.E * Ax1 + Fy.E * Ay0 - Fyh.E * Ay1);
+                Un[2] = Uo[2] + dtdV * (Fxp.mx * Ax0 - Fxn.mx * Ax1 + Fy.mx * Ay0 - Fyh.mx * Ay1);
+                Un[3] = Uo[3] + dtdV * (Fxp.my * Ax0 - Fxn.my * Ax1 + Fy.my * Ay0 - Fyh.my * Ay1);
+                Un[2] -= pdiv(dt * (pxn - pxp), gLx);
+                Un[3] -= pdiv(dt * (pyh - py), gLy(-1));
+                // S_old = S(U_old); U += dt S_old; S_new (time-centred x-momentum); U += dt/2 (S_new - S_old)
+                const double r = FAC ? RF(6, f) : GA.x(f, jc), grav = P.grav;
+                const double Sx_g_old = Uo[0] * grav;
+                const double SE_old = Uo[2] * grav;
+                const double Sx_old = Sx_g_old + pdiv(Uo[3] * Uo[3], Uo[0] * r);
+                const double Sy_old = pdiv(-Uo[2] * Uo[3], Uo[0]);
+                Un[1] = Un[1] + dt * SE_old;
+                Un[2] = Un[2] + dt * Sx_old;
+                Un[3] = Un[3] + dt * Sy_old;
+                const double Sx_g_new = Un[0] * grav;
+                const double xmom_new = Un[2] + 0.5 * dt * (Sx_g_new - Sx_g_old);
+                const double SE_new = xmom_new * grav;
+                const double Sx_new = Sx_g_new + pdiv(Un[3] * Un[3], Un[0] * r);
+                const double Sy_new = pdiv(-Un[2] * Un[3], Un[0]);
+                Cons Uw;
+                Uw.d = Un[0];   // the density source is zero
+                Uw.E = Un[1] + 0.5 * dt * (SE_new - SE_old);
+                Uw.mx = Un[2] + 0.5 * dt * (Sx_new - Sx_old);
+                Uw.my = Un[3] + 0.5 * dt * (Sy_new - Sy_old);
+                const size_t ko = (size_t)f * p + j;
+                Uout[ko] = Uw.d; Uout[pl + ko] = Uw.E; Uout[2 * pl + ko] = Uw.mx; Uout[3 * pl + ko] = Uw.my;
+                double cfl = cfl_cell(Uw, gamma, gLx, gLy(-1));
+                cfl = sphf_ghost_cfl<FAC>(Uw, gamma, g, P, GA, f, j, cfl);
+                st[SS_CFL * 64] = fmin(st[SS_CFL * 64], cfl);
+            }
+            if (xface) { sput(st, SS_FX, Fxn); st[SS_PX * 64] = pxn; }
+        }
+        // hand the rows on
+        fxa = fxb; fxb = fxn;
+        Dp = Dn; up = um; vp = vm;
+    }
+    if (bad) atomicOr(flag, 1);
+    const double wm = wave_reduce_min(st[SS_CFL * 64]);
+    if (l == 0) partial[sb * P.ncb + cb] = wm;
+}
+
+// rows per strip: whole rounds of the resident wavefronts (two per SIMD) + one strip time for the
+// stragglers of the last round (comp_wave.hip: wave_rows); a strip costs L + 8 iterations
+int sphw_rows(int nx, int ncb, int slots)
+{
+    if (nx <= 32) return nx;
+    long best_cost = -1;
+    int best = 32;
+    for (int L = 32; L <= 160 && L <= nx; L++) {
+        int nsb = (nx + L - 1) / L;
+        if (nsb > 1 && nx - (nsb - 1) * L < 4) nsb--;
+        const int Leff = (nx + nsb - 1) / nsb;
+        const long waves = (long)ncb * nsb;
+        const long rounds = (waves + slots - 1) / slots;
+        const long cost = (waves <= slots ? 1 : rounds + 1) * (Leff + 8);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = L; }
+    }
+    return best;
+}
+
+}  // namespace
+
+// SphericalPolar grid, one step in ONE launch of the row-marching kernel.  The caller checked what
+// the tile kernel needs too (comp_api.hip: comp_can_fuse_sph: CGF, outflow / reflect / periodic
+// sides) and has FILLED the state's ghost cells.  S == nullptr: one step with the host's dt;
+// S != nullptr (pyrohip_comp_evolve): dt from *S, *dmin_out = device address of the CFL minimum.
+int comp_step_wave_sph_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
+                          const StepScalars *S, const double **dmin_out)
+{
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    FP P;
+    double *Uin, *Uout;
+    PYRO_TRY(fused_prepare(s, p, dt, P, Uin, Uout, S == nullptr));
+    // (the source terms of ghost cells and the CFL minimum over the new state's ghost cells go
+    // through the boundary rules)
+    P.mr = bc_map(g.ilo, g.ihi, g.ng, s->bc[0], s->bc[1], true);
+    P.mc = bc_map(g.jlo, g.jhi, g.ng, s->bc[2], s->bc[3], true);
+    for (int n = 0; n < 4; n++)
+        for (int sd = 0; sd < 4; sd++)
+            if (s->bc[n * 4 + sd] == PYROHIP_BC_REFLECT_ODD) P.odd |= 1u << (4 * n + sd);
+    const SphGeom &h = *s->sph;
+    const SphG G{h.Lx, h.Ly, h.Ax, h.Ay, h.V, h.dlAx, h.dlAy, h.x2d, h.sint, h.sinb, h.sinc, h.xmin,
+                 h.rowf, h.colf, (int)h.qxp, (int)h.qyp};
+    const int fac = (h.rowf && h.colf && !getenv("PYRO_SPH_PLANES")) ? 1 : 0;
+    const int cus = c->num_cus > 0 ? c->num_cus : 256;
+    P.ncb = (g.ny + SWOUT - 1) / SWOUT;
+    P.L = sphw_rows(g.nx, P.ncb, 8 * cus);
+    if (p->march_rows > 0) P.L = p->march_rows < g.nx ? p->march_rows : g.nx;
+    P.nsb = (g.nx + P.L - 1) / P.L;
+    if (P.nsb > 1 && g.nx - (P.nsb - 1) * P.L < g.ng) P.nsb--;
+    P.nunits = P.ncb * P.nsb;
+    PYRO_TRY(c->reduce.ensure((P.nunits + kMinStageBlocks + 2) * sizeof(double)));
+    double *part = (double *)c->reduce.p;
+    using KernelT = void (*)(const double *, double *, Geom, FP, SphG, int *, double *, const StepScalars *);
+    static const KernelT kernels[2][2] = {{k_sph_wave<false, false>, k_sph_wave<true, false>},
+                                          {k_sph_wave<false, true>, k_sph_wave<true, true>}};
+    const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
+    PYRO_LAUNCH(c, "k_sph_wave", kernels[fac][std_rec], dim3(8 * ((P.nunits + 7) / 8)), dim3(64), SPHW_LDS_BYTES,
+                (const double *)Uin, Uout, g, P, G, s->d_flag, part, S);
+    PYRO_CHECK_HIP(hipGetLastError());
+    // the ghost frame of the new buffer: the old (filled) ghost cells, unless the fill before this
+    // step of a device-side run has written both frames (comp_api.hip: k_fill_frame2)
+    const bool frame_done = s->frame_prefilled;
+    s->frame_prefilled = false;
+    const double *dmin;
+    PYRO_TRY(fused_tail(s, part, P.nunits, frame_done, &dmin, S != nullptr));
+    if (S) { fused_swap(s); *dmin_out = dmin; s->halo_pending = false; return 0; }
+    // (the minimum is method_compute_timestep's: whole array, the new state's ghost cells as the
+    // boundary rules will fill them included -- sphf_ghost_cfl)
+    const int rc = fused_sync(s, dmin);
+    s->cfl_is_global = false;
+    return rc;
+}
+
+int comp_step_wave_sph(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
+{
+    return comp_step_wave_sph_ex(s, p, dt, nullptr, nullptr);
+}
+
+}  // namespace PYRO_NS
+}  // namespace pyro

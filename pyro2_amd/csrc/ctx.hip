@@ -776,9 +776,11 @@ int pyrohip_state_set_geometry(pyrohip_state *s, const pyrohip_geom *hg)
     for (int k = 0; k < 8; k++) PYRO_REQUIRE(src[k], "NULL geometry array");
     PYRO_REQUIRE(hg->sint && hg->sinb && hg->sinc, "NULL geometry array");
     const Geom &g = s->g;
-    const size_t qyp = ((size_t)g.qy + 7) & ~(size_t)7;
+    const size_t qyp = ((size_t)g.qy + 7) & ~(size_t)7, qxp = ((size_t)g.qx + 7) & ~(size_t)7;
     SphGeom *G = new SphGeom();
-    const size_t n = 8 * g.plane + 3 * qyp + 16;
+    const bool fac = hg->rowf && hg->colf;
+    // (+ reciprocals the contracted builds multiply by: rows 1 / Ly, 1 / (F G); columns 1 / |E|, 1 / T)
+    const size_t n = 8 * g.plane + 3 * qyp + 16 + (fac ? 9 * qxp + 6 * qyp : 0);
     PYRO_CHECK_HIP(hipMalloc((void **)&G->base, n * sizeof(double)));
     PYRO_CHECK_HIP(hipMemsetAsync(G->base, 0, n * sizeof(double), c->stream));
     double *planes = G->base + geom_lead(g);
@@ -791,6 +793,26 @@ int pyrohip_state_set_geometry(pyrohip_state *s, const pyrohip_geom *hg)
     for (int k = 0; k < 3; k++)
         PYRO_CHECK_HIP(hipMemcpyAsync(sines + k * qyp, ssrc[k], g.qy * sizeof(double),
                                       hipMemcpyHostToDevice, c->stream));
+    if (fac) {
+        double *rf = G->base + 8 * g.plane + 3 * qyp + 16, *cf = rf + 9 * qxp;
+        std::vector<double> hr(9 * qxp, 0.0), hc(6 * qyp, 0.0);
+        for (int k = 0; k < 7; k++)
+            for (int i = 0; i < g.qx; i++) hr[k * qxp + i] = hg->rowf[(size_t)k * g.qx + i];
+        for (int k = 0; k < 4; k++)
+            for (int j = 0; j < g.qy; j++) hc[k * qyp + j] = hg->colf[(size_t)k * g.qy + j];
+        for (int i = 0; i < g.qx; i++) {
+            hr[7 * qxp + i] = 1.0 / hr[4 * qxp + i];                            // 1 / Ly
+            hr[8 * qxp + i] = 1.0 / (hr[2 * qxp + i] * hr[3 * qxp + i]);        // 1 / (F G)
+        }
+        for (int j = 0; j < g.qy; j++) {
+            hc[4 * qyp + j] = 1.0 / fabs(hc[2 * qyp + j]);                      // 1 / |E|
+            hc[5 * qyp + j] = 1.0 / hc[3 * qyp + j];                            // 1 / T
+        }
+        PYRO_CHECK_HIP(hipMemcpyAsync(rf, hr.data(), hr.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        PYRO_CHECK_HIP(hipMemcpyAsync(cf, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));      // (hr / hc are locals)
+        G->rowf = rf; G->colf = cf; G->qxp = qxp; G->qyp = qyp;
+    }
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));   // the host arrays are borrowed
     G->Lx = planes; G->Ly = planes + g.plane; G->Ax = planes + 2 * g.plane;
     G->Ay = planes + 3 * g.plane; G->V = planes + 4 * g.plane; G->dlAx = planes + 5 * g.plane;

@@ -791,7 +791,7 @@ int swe_step_wave(pyrohip_state *, double, double, double, int, int, double, con
 int launch_fill_frame2(pyrohip_state *s, bool *done);
 int launch_dt_policy(pyrohip_ctx *c, StepScalars *S, const double *cflmin, const int *flag, double *dts,
                      int slot, int final_call, const double *part, int nparts, double *minout);
-int restore_frame_after_inactive(pyrohip_state *s, int steps, int max_steps);
+int restore_frame_after_inactive(pyrohip_state *s, int steps, int max_steps, bool halo_ok, bool sph_ok);
 #endif
 }  // namespace pyro
 
@@ -998,7 +998,7 @@ int pyrohip_swe_evolve(pyrohip_state *s, double dx, double dy, double grav, int 
         s->alt_base = old_base;
         s->d = s->base + geom_lead(s->g);
     }
-    PYRO_TRY(restore_frame_after_inactive(s, H.steps, max_steps));
+    PYRO_TRY(restore_frame_after_inactive(s, H.steps, max_steps, false, false));
     s->next_cfl_min = -1.0;
     s->ghost_by_rules = false;
     pol->t = H.t; pol->dt_old = H.dt_old; pol->n = H.n;

@@ -347,6 +347,14 @@ class DeviceState:
                 keep.append(a)
                 setattr(G, n, dptr(a))
             G.xmin, G.ymin = float(xmin), float(ymin)
+            # the 1-d factors of the arrays (SphericalPolar.device_geometry): the one-launch
+            # kernel rebuilds the geometry from them instead of reading the planes
+            if "rowf" in arrays and "colf" in arrays:
+                rowf = np.ascontiguousarray(arrays["rowf"], dtype=np.float64)
+                colf = np.ascontiguousarray(arrays["colf"], dtype=np.float64)
+                assert rowf.shape == (7, self.qx) and colf.shape == (4, self.qy), (rowf.shape, colf.shape)
+                keep += [rowf, colf]
+                G.rowf, G.colf = dptr(rowf), dptr(colf)
             check(self._l.pyrohip_state_set_geometry(self.h, C.byref(G)))
 
     def set_const_bc(self, n, value):

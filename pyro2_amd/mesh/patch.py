@@ -163,6 +163,32 @@ class SphericalPolar(Grid2d):
         out["sint"] = np.array([np.sin((jj + 0.5 - self.ng) * self.dy + self.ymin) for jj in j])
         out["sinb"] = np.array([np.sin((jj - 0.5 - self.ng) * self.dy + self.ymin) for jj in j])
         out["sinc"] = np.array([np.sin((jj - self.ng) * self.dy + self.ymin) for jj in j])
+        # The 2-d arrays are products of a row factor and a column factor, in this order of
+        # operations (the expressions of __init__ above, patch.py:262-312): handed over as 1-d
+        # tables, the kernels rebuild Ax = |A B|, Ay = |C D|, V = |(E F) G|, dlogAy = 1 / (T x)
+        # in registers with the SAME bits (checked below) instead of reading eight planes
+        xl, xr, x = self.xl, self.xr, self.x
+        A = (-2.0 * np.pi) * xl**2
+        D = xr**2 - xl**2
+        F = xr - xl
+        G = xr**2 + xl**2 + xr * xl
+        B = np.cos(self.yr) - np.cos(self.yl)
+        Cc = np.pi * np.sin(self.yl)
+        E = (-2.0 * np.pi / 3.0) * B
+        T = np.tan(self.y)
+        rowf = np.array([A, D, F, G, x * self.dy, 2.0 / x, x])
+        colf = np.array([B, Cc, E, T])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            same = np.array_equal(out["Ax"], np.abs(A[:, None] * B[None, :])) and \
+                np.array_equal(out["Ay"], np.abs(Cc[None, :] * D[:, None])) and \
+                np.array_equal(out["V"], np.abs((E[None, :] * F[:, None]) * G[:, None])) and \
+                np.array_equal(out["dlogAy"], 1.0 / (T[None, :] * x[:, None]), equal_nan=True) and \
+                np.array_equal(out["Ly"], np.broadcast_to(rowf[4][:, None], out["Ly"].shape)) and \
+                np.array_equal(out["dlogAx"], np.broadcast_to(rowf[5][:, None], out["Ly"].shape)) and \
+                np.all(out["Lx"] == self.dx) and np.all(np.isfinite(out["dlogAy"])) and \
+                np.array_equal(out["x2d"], np.broadcast_to(x[:, None], out["Ly"].shape))
+        if same:       # (else: the kernels keep reading the planes)
+            out["rowf"], out["colf"] = rowf, colf
         return out
 
     def coarse_like(self, N):

@@ -1135,9 +1135,30 @@ def test_comp_spherical(dev, golden, k):
         s.comp_step(dev_params(meta, kernel_set=1)[0], dt)
 
 
+def sph_arrays_fac(g, pre, meta):
+    """the same arrays from pyro2_amd.mesh.patch.SphericalPolar with the 1-d factors the one-launch
+    kernels rebuild them from (rowf / colf: device_geometry checks the factorisation bit for bit)"""
+    from pyro2_amd.mesh import patch
+    dom = g[pre + "g_domain"]
+    grid = patch.SphericalPolar(int(meta[0]), int(meta[1]), ng=int(meta[2]), xmin=dom[0], xmax=dom[1],
+                                ymin=dom[2], ymax=dom[3])
+    geo = grid.device_geometry()
+    # (the golden file's arrays come from the reference run's NumPy, whose tan / sin may differ from
+    # this interpreter's in the last bit: the staged and the one-launch kernels of this test both
+    # take THIS grid's arrays)
+    for n in SPH_NAMES:
+        assert np.allclose(geo[n], g[pre + "g_" + n], rtol=1e-14, atol=0), n
+    assert "rowf" in geo and "colf" in geo
+    return geo
+
+
+@pytest.mark.parametrize("onek,fac", [(-1, 0), (-1, 1), (2, 0), (2, 1)])
 @pytest.mark.parametrize("k", range(3))
-def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
-    """SphericalPolar grid: the whole step in ONE launch (k_ctu_fused_sph: the tile kernel with
+def test_comp_spherical_one_launch_equals_staged(dev, golden, k, onek, fac):
+    """(onek = -1: the tile kernel k_ctu_fused_sph, the library's choice on these small grids; 2:
+    the row-marching kernel k_sph_wave of round 6.  fac: the geometry rebuilt from its 1-d factors
+    instead of read from the planes.)
+    SphericalPolar grid: the whole step in ONE launch (k_ctu_fused_sph: the tile kernel with
     the geometry terms -- per-cell dt / Lx, dt / Ly and the geometric source in the tracing,
     external sources with their ghost rule, CGF face pressures as gradients, area / volume
     weighted corrections and update, spherical vertex divergence, source predictor-corrector)
@@ -1155,14 +1176,16 @@ def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
     f0, mx = g[pre + "drv"]
     fix = 0.005 if str(g[pre + "problem"]) == "advect" else -1.0
     nsteps = len(g[pre + "dts"])
+    geo = sph_arrays_fac(g, pre, meta) if fac else sph_arrays(g, pre)
+    kname = "k_sph_wave" if onek == 2 else "k_ctu_fused_sph"
     staged = {}
     for fm in (0, 1):
         out = {}
-        for ks in (0, -1):
+        for ks in (0, onek):
             P, cfl = dev_params(meta, kernel_set=ks, riemann="CGF", solid_xl=solid[0], solid_yl=solid[2],
                                 fast_math=fm)
             s = comp_state(dev, nx, ny, bcs)
-            s.set_geometry(sph_arrays(g, pre), dom[0], dom[2])
+            s.set_geometry(geo, dom[0], dom[2])
             s.upload(g[pre + "ic"])
             pol, dts = DtPolicy(1.e30, f0, mx, fix_dt=fix), []
             for _ in range(nsteps):
@@ -1172,7 +1195,7 @@ def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
                 pol.advance(dtn)
                 dts.append(dtn)
             out[ks] = (s.download(), dts)
-        (Ua, da), (Ub, db) = out[0], out[-1]
+        (Ua, da), (Ub, db) = out[0], out[onek]
         staged[fm] = out[0]
         if fm == 0:
             assert da == db, (k, "dts")
@@ -1186,12 +1209,12 @@ def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
     # value) -- equal to method_compute_timestep's whole-array minimum after a fill; and the
     # caller may leave the fill to the step (fuse_fill)
     for fm in (0, 1):
-        P, cfl = dev_params(meta, kernel_set=-1, riemann="CGF", solid_xl=solid[0], solid_yl=solid[2],
+        P, cfl = dev_params(meta, kernel_set=onek, riemann="CGF", solid_xl=solid[0], solid_yl=solid[2],
                             fast_math=fm, fuse_fill=1)
         P0, _ = dev_params(meta, kernel_set=0, riemann="CGF", solid_xl=solid[0], solid_yl=solid[2],
                            fast_math=fm)
         s = comp_state(dev, nx, ny, bcs)
-        s.set_geometry(sph_arrays(g, pre), dom[0], dom[2])
+        s.set_geometry(geo, dom[0], dom[2])
         s.upload(g[pre + "ic"])
         s.fill_bc()
         pol, dts = DtPolicy(1.e30, f0, mx, fix_dt=fix), []
@@ -1204,7 +1227,7 @@ def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
         cached = s.comp_dt(P, cfl)
         U = s.download()
         s2 = comp_state(dev, nx, ny, bcs)
-        s2.set_geometry(sph_arrays(g, pre), dom[0], dom[2])
+        s2.set_geometry(geo, dom[0], dom[2])
         s2.upload(U)
         s2.fill_bc()
         assert not s2.comp_dt_is_cached()
@@ -1221,16 +1244,16 @@ def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
     # kernel's own whole-array minima and the dt policy kernel, no host round trip per step), in
     # two calls, against the steps taken one by one: dt sequence, time and the WHOLE array
     for fm in (0, 1):
-        P, cfl = dev_params(meta, kernel_set=-1, riemann="CGF", solid_xl=solid[0], solid_yl=solid[2],
+        P, cfl = dev_params(meta, kernel_set=onek, riemann="CGF", solid_xl=solid[0], solid_yl=solid[2],
                             fast_math=fm)
         s = comp_state(dev, nx, ny, bcs)
-        s.set_geometry(sph_arrays(g, pre), dom[0], dom[2])
+        s.set_geometry(geo, dom[0], dom[2])
         s.upload(g[pre + "ic"])
         pol, dts = DtPolicy(1.e30, f0, mx, fix_dt=fix), []
         for c in (3, nsteps - 3):
             dts += list(s.comp_evolve(P, cfl, pol, c))
         s1 = comp_state(dev, nx, ny, bcs)
-        s1.set_geometry(sph_arrays(g, pre), dom[0], dom[2])
+        s1.set_geometry(geo, dom[0], dom[2])
         s1.upload(g[pre + "ic"])
         pol1, d1 = DtPolicy(1.e30, f0, mx, fix_dt=fix), []
         for _ in range(nsteps):
@@ -1245,12 +1268,12 @@ def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
             # tmax inside the call: the spare launches do nothing, the state is the one at tmax
             tmax = float(np.sum(d1[:3])) + 0.4 * float(d1[3])
             s = comp_state(dev, nx, ny, bcs)
-            s.set_geometry(sph_arrays(g, pre), dom[0], dom[2])
+            s.set_geometry(geo, dom[0], dom[2])
             s.upload(g[pre + "ic"])
             pol = DtPolicy(tmax, f0, mx)
             dts = list(s.comp_evolve(P, cfl, pol, nsteps))
             s1 = comp_state(dev, nx, ny, bcs)
-            s1.set_geometry(sph_arrays(g, pre), dom[0], dom[2])
+            s1.set_geometry(geo, dom[0], dom[2])
             s1.upload(g[pre + "ic"])
             pol1, d1t = DtPolicy(tmax, f0, mx), []
             while pol1.t < tmax:
@@ -1284,10 +1307,10 @@ def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
                  ("reflect", "reflect", "outflow", "reflect")):
         solid2 = [int(b == "reflect") for b in bcs2]
         out = {}
-        for ks in (0, -1):
+        for ks in (0, onek):
             P, cfl = dev_params(meta, kernel_set=ks, riemann="CGF", solid_xl=solid2[0], solid_yl=solid2[2])
             s = comp_state(dev, nx, ny, list(bcs2))
-            s.set_geometry(sph_arrays(g, pre), dom[0], dom[2])
+            s.set_geometry(geo, dom[0], dom[2])
             s.upload(ic)
             pol = DtPolicy(1.e30, f0, mx, fix_dt=fix)
             for _ in range(4):
@@ -1296,7 +1319,7 @@ def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
                 s.comp_step(P, dtn)
                 pol.advance(dtn)
             out[ks] = s.download()
-        assert np.array_equal(out[0], out[-1]), (k, bcs2, np.argwhere(out[0] != out[-1])[:5])
+        assert np.array_equal(out[0], out[onek]), (k, bcs2, np.argwhere(out[0] != out[onek])[:5])
     # the launch count of the default really is one per step -- after the library's own fill (the
     # kernel reads ghost cells through the boundary rules); a state whose ghost cells were not
     # filled by the rules (here: nothing filled them since the last step) takes the staged set
@@ -1304,11 +1327,11 @@ def test_comp_spherical_one_launch_equals_staged(dev, golden, k):
     dev.prof_enable(True)
     s.comp_step(P, dts[-1])
     rep = dev.prof_report()
-    assert rep.get("k_ctu_fused_sph", (0, 0))[0] == 1 and "k_sph_states" not in rep
+    assert rep.get(kname, (0, 0))[0] == 1 and "k_sph_states" not in rep
     s.comp_step(P, dts[-1])
     rep = dev.prof_report()
     dev.prof_enable(False)
-    assert "k_ctu_fused_sph" not in rep and "k_sph_states" in rep
+    assert kname not in rep and "k_sph_states" in rep
 
 
 @pytest.mark.gpu
