@@ -54,6 +54,14 @@ namespace PYRO_NS {
 
 
 constexpr int WOUT = 56;          // columns a wavefront updates
+// the limited slopes: stencil.h's (bit-faithful build) / the half slopes of fused_common.h
+#if PYRO_FAST
+#define LIMIT2 half_limit2
+#define SLOPE_SHARED half_slope_shared
+#else
+#define LIMIT2 limit2
+#define SLOPE_SHARED slope_shared
+#endif
 // stage boundary: the scheduler may not move instructions across it.  The
 // stages are written in the order that keeps the live ranges short (a value is
 // produced right before the Riemann problem that consumes it); left alone, the
@@ -381,7 +389,28 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         const int srow = MAPS ? bc_src(P.mr, row, g.ilo, g.ihi) : row;
         return (size_t)srow * p + jsrc;
     };
+    // Plain instances (a filled frame, no Runge-Kutta stage): the rows of a strip are addressed as
+    // [scalar base of the strip's first row, per plane] + [32-bit byte offset: row offset (scalar) +
+    // lane offset] -- the `saddr` form of global_load / global_store, ONE v_add_u32 per row instead of
+    // a 64-bit multiply-add + shift + four 64-bit adds per four-plane access (18 of the 870 vector
+    // instructions of a row).  A strip spans at most 160 + 15 rows: the offset stays far below 4 GB.
+#if !defined(PYRO_EMU)
+    constexpr bool SADDR = !MAPS && !RKF;
+#else
+    constexpr bool SADDR = false;
+#endif
+    const int rbase = (i0 - 7 > 0) ? i0 - 7 : 0;           // first row the strip touches
+    const char *const sbase_in = (const char *)(Uin + (size_t)rbase * p);
+    char *const sbase_out = (char *)(Uout + (size_t)rbase * p);
+    const unsigned pitch8 = (unsigned)p * 8u, lane8 = (unsigned)jc * 8u;
+    const size_t plb = pl * sizeof(double);
     auto loadU = [&](int row) {
+        if (SADDR) {
+            row = row < 0 ? 0 : (row > g.qx - 1 ? g.qx - 1 : row);
+            const unsigned off = (unsigned)(row - rbase) * pitch8 + lane8;
+            return Cons{*(const double *)(sbase_in + off), *(const double *)(sbase_in + plb + off),
+                        *(const double *)(sbase_in + 2 * plb + off), *(const double *)(sbase_in + 3 * plb + off)};
+        }
         const size_t kk = src_of(row);
         Cons U{Uin[kk], Uin[pl + kk], Uin[2 * pl + kk], Uin[3 * pl + kk]};
         if (RKF) {
@@ -520,10 +549,10 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             if (flat)
                 fxn = flatten_1d_k(wp[0], wp[1], wp[3], wp[4], wu[1], wu[3], FlatKTab{ct});
             if (limiter != 0) {
-                l2n[0] = limit2(wr[1], wr[2], wr[3]);
-                l2n[1] = limit2(wu[1], wu[2], wu[3]);
-                l2n[2] = limit2(wv[1], wv[2], wv[3]);
-                l2n[3] = limit2(wp[1], wp[2], wp[3]);
+                l2n[0] = LIMIT2(wr[1], wr[2], wr[3]);
+                l2n[1] = LIMIT2(wu[1], wu[2], wu[3]);
+                l2n[2] = LIMIT2(wv[1], wv[2], wv[3]);
+                l2n[3] = LIMIT2(wp[1], wp[2], wp[3]);
             }
         }
         // limit2_x of rows k-4 (slot k & 1) and k-3 from the stash; row k-2 takes the
@@ -573,7 +602,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             for (int n = 0; n < 4; n++) {
                 ym[n] = lane_m1(q0[n]);
                 yp[n] = lane_p1(q0[n]);
-                if (limiter != 0) l2y[n] = limit2(ym[n], q0[n], yp[n]);
+                if (limiter != 0) l2y[n] = LIMIT2(ym[n], q0[n], yp[n]);
             }
             um = ym[1]; vm = ym[2];
             double xi = 1.0;
@@ -587,13 +616,16 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 const double py = (yp[3] - ym[3] > 0) ? fym : fyp;
                 xi = fmin(fmin(fxb, px), fmin(fy, py));
             }
+#if PYRO_FAST
+            xi = xi + xi;      // (the contracted build's slopes are half slopes: fused_common.h)
+#endif
             double dqx[4], dqy[4];
 #pragma unroll
             for (int n = 0; n < 4; n++) {
-                dqx[n] = xi * slope_shared(l2a[n], l2b[n], l2n[n], qm[n], q0[n], qp[n], limiter);
+                dqx[n] = xi * SLOPE_SHARED(l2a[n], l2b[n], l2n[n], qm[n], q0[n], qp[n], limiter);
                 const double l2m = (limiter == 2) ? lane_m1(l2y[n]) : 0.0;
                 const double l2p = (limiter == 2) ? lane_p1(l2y[n]) : 0.0;
-                dqy[n] = xi * slope_shared(l2m, l2y[n], l2p, ym[n], q0[n], yp[n], limiter);
+                dqy[n] = xi * SLOPE_SHARED(l2m, l2y[n], l2p, ym[n], q0[n], yp[n], limiter);
             }
             if (yfin) {      // integration.py:120-129, the terms before this stage's own increment
                 if (P.rk_nb > 1 && P.rk_b[0] != 0.0) {
@@ -850,8 +882,14 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 __builtin_nontemporal_store(Un.mx, &Uout[2 * pl + ko]);
                 __builtin_nontemporal_store(Un.my, &Uout[3 * pl + ko]);
 #else
+                if (SADDR) {
+                    const unsigned off = (unsigned)(i - 1 - rbase) * pitch8 + (unsigned)j * 8u;
+                    *(double *)(sbase_out + off) = Un.d; *(double *)(sbase_out + plb + off) = Un.E;
+                    *(double *)(sbase_out + 2 * plb + off) = Un.mx; *(double *)(sbase_out + 3 * plb + off) = Un.my;
+                } else {
                 Uout[ko] = Un.d; Uout[pl + ko] = Un.E; Uout[2 * pl + ko] = Un.mx;
                 Uout[3 * pl + ko] = Un.my;
+                }
 #endif
                 double ax, ay;   // CFL: running maxima of the divisors, one division at the end
                 cfl_speeds(Un, US3(GAMMA, P.gamma), ax, ay);
