@@ -140,23 +140,23 @@ static int check_comp(pyrohip_state *s, const pyrohip_comp_params *p)
 // takes its value from an x ghost cell): for outflow / reflect / periodic sides both are index
 // maps with a sign, and their composition is what the two passes leave.  One thread per
 // cell of the frame.
-__global__ __launch_bounds__(256) void k_fill_frame2(const double *src, double *cur, double *alt,
-                                                     Geom g, const int *__restrict__ bc)
+// (b: piece of 256 threads, t: thread in the piece -- a workgroup of k_fill_frame2, or a quarter
+// of one of k_fill_frame2_policy)
+__device__ __forceinline__ void fill_frame2_piece(const double *src, double *cur, double *alt,
+                                                  const Geom &g, const int *__restrict__ bc, int b, int t)
 {   // src: the buffer whose interior the images are taken from (cur itself, or -- at the end of a
     // run of one-launch steps -- the buffer that holds the previous state); alt may be nullptr
     // 1-d grid: first the 2 ng full ghost rows in pieces of 256 columns, then the ghost
-    // columns of the interior rows, 256 / (2 ng) rows per workgroup
+    // columns of the interior rows, 256 / (2 ng) rows per piece
     const int ng = g.ng;
     const int nxb = (g.qy + 255) / 256, nrowblk = 2 * ng * nxb;
-    const int b = blockIdx.x;
     int i, j;
     if (b < nrowblk) {                              // a piece of a full ghost row
         const int rr = b / nxb;
         i = (rr < ng) ? rr : g.ihi + 1 + (rr - ng);
-        j = (b - rr * nxb) * 256 + (int)threadIdx.x;
+        j = (b - rr * nxb) * 256 + t;
         if (j >= g.qy) return;
     } else {                                        // ghost columns of interior rows
-        const int t = threadIdx.x;
         const int rows_per_block = 256 / (2 * ng);
         const int r = (b - nrowblk) * rows_per_block + t / (2 * ng);
         const int kx = t % (2 * ng);
@@ -177,6 +177,11 @@ __global__ __launch_bounds__(256) void k_fill_frame2(const double *src, double *
         cur[n * g.plane + k] = w;
         if (alt) alt[n * g.plane + k] = w;
     }
+}
+__global__ __launch_bounds__(256) void k_fill_frame2(const double *src, double *cur, double *alt,
+                                                     Geom g, const int *__restrict__ bc)
+{
+    fill_frame2_piece(src, cur, alt, g, bc, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // (x sides of a slab that are cuts -- PYROHIP_BC_HALO -- are identity maps: the halo rows are data
@@ -199,10 +204,10 @@ constexpr int kPolicyThreads = 1024;
 // The driver's compute_timestep (simulation_null.py:222-244) between two steps of a run that
 // advances on the device (dt_policy_apply, common.h), from the CFL minimum the previous step
 // kernel left in device memory.
-__global__ __launch_bounds__(kPolicyThreads) void k_dt_policy(StepScalars *S, const double *cflmin,
-                                                   const int *flag, double *dts, int slot,
-                                                   int final_call, const double *part, int nparts,
-                                                   double *minout, int flag_mask)
+__device__ __forceinline__ void dt_policy_block(StepScalars *S, const double *cflmin,
+                                                const int *flag, double *dts, int slot,
+                                                int final_call, const double *part, int nparts,
+                                                double *minout, int flag_mask)
 {
     // the CFL minimum of the previous step: already reduced (cflmin), or still the
     // per-workgroup partials of the tile kernel (part: reduced here, kept in minout)
@@ -234,6 +239,30 @@ __global__ __launch_bounds__(kPolicyThreads) void k_dt_policy(StepScalars *S, co
     if (threadIdx.x != 0) return;
     // (raised by the step that just ran: it does not count)
     pyro::dt_policy_apply(S, cmin_s, (*flag & flag_mask) != 0, dts, slot, final_call);
+}
+__global__ __launch_bounds__(kPolicyThreads) void k_dt_policy(StepScalars *S, const double *cflmin,
+                                                   const int *flag, double *dts, int slot,
+                                                   int final_call, const double *part, int nparts,
+                                                   double *minout, int flag_mask)
+{
+    dt_policy_block(S, cflmin, flag, dts, slot, final_call, part, nparts, minout, flag_mask);
+}
+// The two small launches between two steps of a device-side run in ONE (round 6): the ghost
+// frames of both buffers (k_fill_frame2: reads the state the last step left) and the driver's dt
+// policy (k_dt_policy: reads that step's CFL partials) do not depend on each other.  Workgroups
+// of 1024 threads: the first nfill hold four 256-thread pieces of the fill each, the last one
+// runs the policy.  One launch and its gap less per step (8 us of a 0.68 ms step at 4096^2).
+__global__ __launch_bounds__(kPolicyThreads) void k_fill_frame2_policy(
+    const double *src, double *cur, double *alt, Geom g, const int *__restrict__ bc, int npieces,
+    StepScalars *S, const double *cflmin, const int *flag, double *dts, int slot, const double *part,
+    int nparts, double *minout)
+{
+    if (blockIdx.x + 1 == gridDim.x) {
+        dt_policy_block(S, cflmin, flag, dts, slot, 0, part, nparts, minout, 1);
+        return;
+    }
+    const int piece = (int)blockIdx.x * 4 + (int)threadIdx.x / 256;
+    if (piece < npieces) fill_frame2_piece(src, cur, alt, g, bc, piece, (int)threadIdx.x % 256);
 }
 
 namespace pyro {
@@ -322,6 +351,7 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
     bool first = true;
     int rc = 0;
     s->pend_part = nullptr;
+    static const bool merge_small = !getenv("PYRO_NO_MERGE_SMALL");     // (developer A/B)
     // steps after the first: the tile kernel applies the boundary rules itself where it can
     // (the first one needs filled ghost cells for the CFL minimum over the whole array)
     // (the spherical kernel reads every ghost cell through the boundary rules anyway)
@@ -373,11 +403,20 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
         if (s->nb_set && c->comm != nullptr) rc = pyrohip_halo_exchange(s, s->nb_lo, s->nb_hi);
         pf.fuse_fill = (fuse && !first) ? 1 : 0;
         s->frame_prefilled = false;
+        bool policy_done = false;
         if (rc == 0 && !pf.fuse_fill) {
             if ((wave && frame_fill_ok(s, true)) || (sphw && frame_fill_ok(s, false, true))) {      // fill + the other buffer's ghost frame: one launch
                 const Geom &g = s->g;
                 const int rows_per_block = 256 / (2 * g.ng);
                 const int nblk = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + rows_per_block - 1) / rows_per_block;
+                if (!first && merge_small) {
+                    // ... and the dt policy of this step in the same launch (k_fill_frame2_policy)
+                    PYRO_LAUNCH(c, "k_fill_frame2_policy", k_fill_frame2_policy, dim3((nblk + 3) / 4 + 1),
+                                dim3(kPolicyThreads), 0, (const double *)s->d, s->d, s->alt_base + geom_lead(g), g,
+                                (const int *)s->d_bc, nblk, d_scal0, dmin, (const int *)s->d_flag, s->d_dts, m,
+                                (const double *)s->pend_part, s->pend_n, const_cast<double *>(dmin));
+                    policy_done = true;
+                } else
                 PYRO_LAUNCH(c, "k_fill_frame2", k_fill_frame2, dim3(nblk), dim3(256), 0, (const double *)s->d,
                             s->d, s->alt_base + geom_lead(g), g, (const int *)s->d_bc);
                 const hipError_t e = hipGetLastError();
@@ -410,6 +449,7 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
             first = false;
         }
         // (the minimum of the previous tile-kernel launch is taken here: pend_part)
+        if (!policy_done)
         PYRO_LAUNCH(c, "k_dt_policy", k_dt_policy, dim3(1), dim3(kPolicyThreads), 0, d_scal0, dmin,
                     (const int *)s->d_flag, s->d_dts, m, 0, (const double *)s->pend_part,
                     s->pend_n, const_cast<double *>(dmin), 1);

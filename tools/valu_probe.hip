@@ -38,6 +38,9 @@ PROBE(p_rsq64, "v_rsq_f64 %0, %4\n v_rsq_f64 %1, %5\n v_rsq_f64 %2, %6\n v_rsq_f
 PROBE(p_add32, "v_add_u32 %8, %8, %9\n v_add_u32 %9, %9, %8\n v_add_u32 %8, %8, %9\n v_add_u32 %9, %9, %8")
 PROBE(p_bfi32, "v_bfi_b32 %8, %8, %9, %9\n v_bfi_b32 %9, %9, %8, %8\n v_bfi_b32 %8, %8, %9, %9\n v_bfi_b32 %9, %9, %8, %8")
 PROBE(p_pkmov, "v_pk_mov_b32 %0, %4, %5\n v_pk_mov_b32 %1, %5, %6\n v_pk_mov_b32 %2, %6, %7\n v_pk_mov_b32 %3, %7, %4")
+PROBE(p_ldexp64, "v_ldexp_f64 %0, %4, -2\n v_ldexp_f64 %1, %5, -2\n v_ldexp_f64 %2, %6, -2\n v_ldexp_f64 %3, %7, -2")
+PROBE(p_max64, "v_max_f64 %0, %4, %0\n v_max_f64 %1, %4, %1\n v_max_f64 %2, %4, %2\n v_max_f64 %3, %4, %3")
+PROBE(p_fma64_8, "v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %1, %4, %5, %1\n v_fma_f64 %2, %4, %5, %2\n v_fma_f64 %3, %4, %5, %3\n v_fma_f64 %6, %4, %5, %6\n v_fma_f64 %7, %4, %5, %7\n v_mul_f64 %4, %4, %4\n v_mul_f64 %5, %5, %5")
 PROBE(p_mix, "v_fma_f64 %0, %4, %5, %0\n v_mov_b32 %8, %9\n v_fma_f64 %1, %4, %5, %1\n v_mov_b32 %9, %8")
 typedef void (*K)(long long *, double *);
 int main()
@@ -48,7 +51,7 @@ int main()
         {"v_add_f64", p_add64}, {"v_mul_f64", p_mul64}, {"v_min_f64", p_min64}, {"v_mov_b32", p_mov32},
         {"v_mov_b64", p_mov64}, {"v_cndmask_b32", p_cnd32}, {"cndmask sgpr-pair mask", p_cnd_sgpr}, {"cndmask same-dst indep", p_cnd_indep}, {"cmp,cnd,cnd,fma (vcc)", p_cmpcnd}, {"cmp,cnd,cnd,fma (sgpr)", p_cmpcnd_s}, {"cnd,fma,fma,fma", p_cnd_fma}, {"v_mov_b32_dpp wave_sh", p_dpp32},
         {"v_cmp_lt_f64", p_cmp64}, {"v_rcp_f64", p_rcp64}, {"v_rsq_f64", p_rsq64}, {"v_add_u32", p_add32},
-        {"v_bfi_b32", p_bfi32}, {"v_pk_mov_b32", p_pkmov}, {"fma64+mov32 alternating", p_mix}};
+        {"v_bfi_b32", p_bfi32}, {"v_ldexp_f64", p_ldexp64}, {"v_max_f64", p_max64}, {"v_pk_mov_b32", p_pkmov}, {"fma64+mov32 alternating", p_mix}};
     for (auto &e : ks) {
         long long c[3];
         const int nt[3] = {64, 512, 1024};      // 1 wave; 2 waves per SIMD; 4 waves per SIMD
