@@ -54,7 +54,7 @@ UNITS = [
     ("mg_march.hip", "mg_march_t2", ["-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=200000", "-DMGM_UNIT=2"]),
     ("incompressible.hip", "incompressible", ["-ffp-contract=off"]),
     ("swe.hip", "swe", ["-ffp-contract=off", "-DPYRO_FAST=0"]),
-    ("swe.hip", "swe_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1"]),
+    ("swe.hip", "swe_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1", "-fno-honor-nans"]),
     ("comm.hip", "comm", ["-ffp-contract=off"]),
 ]
 

@@ -125,6 +125,52 @@ __device__ __forceinline__ void sw_trace(const double q[4], const double dq[4], 
     hi[0] += bl0 * q[0]; hi[in] -= bl0 * cs; hi[it] += bl1 * dq[it]; hi[3] += bl1 * dq[3];
     lo[0] += br2 * q[0]; lo[in] += br2 * cs; lo[it] += br1 * dq[it]; lo[3] += br1 * dq[3];
 }
+// the same from HALF slopes hq = dq / 2 (round 6, the one-launch kernel: the limited slopes in the
+// signed min / max form of half_limit2 below): the factors 1/2 of the projections and of the
+// reference states disappear into hq, the 2 of (sign + 1) into the wave factors
+__device__ __forceinline__ void sw_trace_h(const double q[4], const double hq[4], double g,
+                                           double dtdx, bool x, double lo[4], double hi[4])
+{
+    const int in = x ? 1 : 2, it = x ? 2 : 1;
+    double rcs;
+    const double cs = psqrt_r(g * q[0], rcs);
+    const double dtdx3 = 0.33333 * dtdx;   // sic, interface.py:100
+    const double un = q[in];
+    const double e0 = un - cs, e2 = un + cs;
+    const double a = hq[0] * (g * (rcs * rcs)), b = hq[in] * rcs;
+    const double as0 = a - b, as2 = -(a + b);
+    const double fhi = 1.0 - dtdx * fmax(e2, 0.0), flo = 1.0 + dtdx * fmin(e0, 0.0);
+#pragma unroll
+    for (int m = 0; m < 4; m++) { hi[m] = q[m] + fhi * hq[m]; lo[m] = q[m] - flo * hq[m]; }
+    const double pl0 = (e0 >= 0.0 && !(e0 == 0.0 && __builtin_signbit(e0))) ? 2.0 : 0.0;
+    const double pl1 = (un >= 0.0 && !(un == 0.0 && __builtin_signbit(un))) ? 4.0 : 0.0;
+    const double pl2 = (e2 >= 0.0 && !(e2 == 0.0 && __builtin_signbit(e2))) ? 2.0 : 0.0;
+    const double bl0 = dtdx3 * (e2 - e0) * pl0 * as0;
+    const double bl1 = dtdx3 * cs * pl1;
+    const double br2 = dtdx3 * (e0 - e2) * (2.0 - pl2) * as2;
+    const double br1 = -dtdx3 * cs * (4.0 - pl1);
+    hi[0] += bl0 * q[0]; hi[in] -= bl0 * cs; hi[it] += bl1 * hq[it]; hi[3] += bl1 * hq[3];
+    lo[0] += br2 * q[0]; lo[in] += br2 * cs; lo[it] += br1 * hq[it]; lo[3] += br1 * hq[3];
+}
+// MC-limited slopes as half slopes (the compressible kernel's: fused_common.h half_limit2 /
+// half_slope_shared -- signed min / max, no sign copy, product, compare or select)
+__device__ __forceinline__ void sw_half_clip(double dl, double dr, double &a, double &b)
+{
+    a = fmax(fmin(dl, dr), 0.0);
+    b = fmin(fmax(dl, dr), 0.0);
+}
+__device__ __forceinline__ double sw_half_limit2(double am, double a0, double ap)
+{
+    double a, b;
+    sw_half_clip(ap - a0, a0 - am, a, b);
+    return fmax(fmin(0.25 * (ap - am), a), b);
+}
+__device__ __forceinline__ double sw_half_limit4_from(double h2m, double h2p, double am1, double a0, double ap1)
+{
+    double a, b;
+    sw_half_clip(ap1 - a0, a0 - am1, a, b);
+    return fmax(fmin((1. / 3.) * (ap1 - am1 - 0.5 * (h2p + h2m)), a), b);
+}
 #else
 __device__ __forceinline__ void sw_trace(const double q[4], const double dq[4], double g,
                                          double dtdx, bool x, double lo[4], double hi[4])
@@ -534,6 +580,13 @@ __device__ __forceinline__ V4 sww_riemann(const V4 &Ul, const V4 &Ur, double g, 
 // every cell's centred limit2 is computed once -- along x carried in the row window, along y
 // fetched from the neighbouring lanes -- instead of twice per direction (round 6: 8 of the 16
 // limit2 evaluations per cell and row, and the two-cells-away DPP moves; bit-identical).
+#if PYRO_FAST
+#define SW_LIMIT2 sw_half_limit2
+#define SW_LIMIT4_FROM sw_half_limit4_from
+#else
+#define SW_LIMIT2 limit2
+#define SW_LIMIT4_FROM limit4_from
+#endif
 template <int RS, bool L4>   // swe.riemann: 0 Roe, 1 HLLC
 __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Uin,
                                                    double *__restrict__ Uout, Geom g, SWW P,
@@ -563,9 +616,22 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
     const double dtdx = P.dt / P.dx, dtdy = P.dt / P.dy;                  // k_sw_update
     const double hdtdx = 0.5 * (P.dt / P.dx), hdtdy = 0.5 * (P.dt / P.dy);   // k_sw_final
     const double sg = (PYRO_FAST && RS == 0) ? psqrt(P.g) : 0.0;             // (contracted Roe solver)
+    // the rows of a strip as [scalar base of the strip's first row, per plane] + [32-bit byte offset]
+    // (saddr form of the loads / stores: comp_wave.hip)
+    const int rbase = (i0 - 6 > 0) ? i0 - 6 : 0;
+    const char *const sbase_in = (const char *)(Uin + (size_t)rbase * p);
+    char *const sbase_out = (char *)(Uout + (size_t)rbase * p);
+    const unsigned pitch8 = (unsigned)p * 8u, lane8 = (unsigned)jc * 8u;
+    const size_t plb = pl * sizeof(double);
     auto loadU = [&](int row) {
         row = row < 0 ? 0 : (row > g.qx - 1 ? g.qx - 1 : row);
+#if defined(PYRO_EMU)
         return ld4(Uin, pl, (size_t)row * p + jc);
+#else
+        const unsigned off = (unsigned)(row - rbase) * pitch8 + lane8;
+        return V4{{*(const double *)(sbase_in + off), *(const double *)(sbase_in + plb + off),
+                   *(const double *)(sbase_in + 2 * plb + off), *(const double *)(sbase_in + 3 * plb + off)}};
+#endif
     };
     const V4 zero{{1.0, 0.0, 0.0, 0.0}};      // (h = 1: the warm-up rows divide by it)
     // rows k-4 .. k of the primitives in registers.  (The conserved row k-3, which is updated
@@ -606,7 +672,7 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
         if (L4) {
 #pragma unroll
             for (int n = 0; n < 4; n++) {
-                l2n[n] = limit2(q[2][n], q[3][n], q[4][n]);
+                l2n[n] = SW_LIMIT2(q[2][n], q[3][n], q[4][n]);
                 l2m_[n] = l2a[n]; l2a[n] = l2b[n]; l2b[n] = l2n[n];
             }
         }
@@ -618,17 +684,24 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
             qc[n] = q[2][n];
             const double m1 = sww_m1(qc[n]), p1 = sww_p1(qc[n]);
             if (L4) {
-                dqx[n] = 1.0 * limit4_from(l2m_[n], l2n[n], q[1][n], q[2][n], q[3][n]);
-                const double l2y = limit2(m1, qc[n], p1);
-                dqy[n] = 1.0 * limit4_from(sww_m1(l2y), sww_p1(l2y), m1, qc[n], p1);
+                // (contracted build: half slopes, traced by sw_trace_h)
+                dqx[n] = 1.0 * SW_LIMIT4_FROM(l2m_[n], l2n[n], q[1][n], q[2][n], q[3][n]);
+                const double l2y = SW_LIMIT2(m1, qc[n], p1);
+                dqy[n] = 1.0 * SW_LIMIT4_FROM(sww_m1(l2y), sww_p1(l2y), m1, qc[n], p1);
             } else {
                 dqx[n] = 1.0 * limited_slope(q[0][n], q[1][n], q[2][n], q[3][n], q[4][n], P.limiter);
                 dqy[n] = 1.0 * limited_slope(sww_m1(m1), m1, qc[n], p1, sww_p1(p1), P.limiter);
             }
         }
         double lo[4], hi[4];
+#if PYRO_FAST
+        if (L4) sw_trace_h(qc, dqx, P.g, P.dt / P.dx, true, lo, hi); else
+#endif
         sw_trace(qc, dqx, P.g, P.dt / P.dx, true, lo, hi);
         const V4 XM = sw_prim_to_cons(lo), XP = sw_prim_to_cons(hi);
+#if PYRO_FAST
+        if (L4) sw_trace_h(qc, dqy, P.g, P.dt / P.dy, false, lo, hi); else
+#endif
         sw_trace(qc, dqy, P.g, P.dt / P.dy, false, lo, hi);
         const V4 YM = sw_prim_to_cons(lo), YP = sw_prim_to_cons(hi);
         SWW_FENCE();
@@ -656,12 +729,18 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
                 const V4 Fxm = get(S_FX);
                 if (jout) {
                     const size_t ko = (size_t)(c - 1) * p + j;
+                    const unsigned offo = (unsigned)(c - 1 - rbase) * pitch8 + (unsigned)j * 8u;
                     V4 Un;
 #pragma unroll
                     for (int n = 0; n < 4; n++) {
                         Un.a[n] = Uold.a[n] + (dtdx * (Fxm.a[n] - Fx.a[n]) + dtdy * (Fy.a[n] - Fy_p.a[n]));
+#if defined(PYRO_EMU)
                         Uout[(size_t)n * pl + ko] = Un.a[n];
+#else
+                        *(double *)(sbase_out + (size_t)n * plb + offo) = Un.a[n];
+#endif
                     }
+                    (void)ko; (void)offo;
                     if (partial) {     // k_sw_cfl's quantities: one division per direction at the end
                         const double u = pdiv(Un.a[1], Un.a[0]), v = pdiv(Un.a[2], Un.a[0]);
                         const double cs = psqrt(P.g * Un.a[0]);
