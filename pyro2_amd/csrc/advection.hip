@@ -149,6 +149,36 @@ __device__ __forceinline__ D2 adv_left(const D2 &q) { return D2{adv_m1(q.b), q.a
 __device__ __forceinline__ D2 adv_right(const D2 &q) { return D2{q.b, adv_p1(q.a)}; }
 
 // limited slope from shared limit2 values (reconstruction.py:9-120)
+#if PYRO_FAST && defined(PYRO_ADV_HALFSLOPE)
+// NOT the default (round 6, measured: tools/build_variant.sh halfslope "-DPYRO_ADV_HALFSLOPE" adv_fast):
+// the form that pays in the compressible and shallow-water kernels keeps two more values alive per
+// cell (a, b), and the three-steps-per-launch instance -- 248-256 registers already -- starts to
+// spill (scratch 0 / 12 -> 20 / 68 B per lane): 8192^2 0.195 -> 0.209 ms per step, 2048^2 18.4 -> 18.0 us.
+// Contracted build: HALF slopes in signed min / max form -- with lo = min(dl, dr),
+// hi = max(dl, dr), a = max(lo, 0), b = min(hi, 0):  limit2 / 2 = max(min((ap - am) / 4, a), b),
+// and the same with half the fourth-order centred slope for limit4 (where dl dr > 0 it shares
+// their sign: stencil.h mc_select_l4); no sign copy, product, compare or select: 10 + 5 instead
+// of 12 + 7 instructions per cell and direction.  The interface states take (1 -+ c) x half slope.
+constexpr double ADV_HALF = 1.0;       // factor of the slope in the interface states
+__device__ __forceinline__ double adv_limit2(double am, double a0, double ap)
+{
+    const double dl = ap - a0, dr = a0 - am;
+    const double a = fmax(fmin(dl, dr), 0.0), b = fmin(fmax(dl, dr), 0.0);
+    return fmax(fmin(0.25 * (ap - am), a), b);
+}
+template <int LIM>
+__device__ __forceinline__ double adv_slope(double l2m, double l20, double l2p, double am1, double a0,
+                                            double ap1)
+{
+    if (LIM == 0) return 0.25 * (ap1 - am1);
+    if (LIM == 1) return l20;
+    const double dl = ap1 - a0, dr = a0 - am1;
+    const double a = fmax(fmin(dl, dr), 0.0), b = fmin(fmax(dl, dr), 0.0);
+    return fmax(fmin((1. / 3.) * (ap1 - am1 - 0.5 * (l2p + l2m)), a), b);
+}
+#else
+constexpr double ADV_HALF = 0.5;
+__device__ __forceinline__ double adv_limit2(double am, double a0, double ap) { return limit2(am, a0, ap); }
 template <int LIM>
 __device__ __forceinline__ double adv_slope(double l2m, double l20, double l2p, double am1, double a0,
                                             double ap1)
@@ -160,6 +190,7 @@ __device__ __forceinline__ double adv_slope(double l2m, double l20, double l2p, 
     const double dr = a0 - am1;
     return mc_select_l4(dc, dl, dr);
 }
+#endif
 
 // LIM: limiter (0 none, 1 MC2, 2 MC4); UNEG / VNEG: u < 0 / v < 0 (upwind side)
 // wavefronts per workgroup (they do not cooperate: no LDS, no barrier).  Four per workgroup,
@@ -262,7 +293,7 @@ __global__ __launch_bounds__(64 * ADV_WPB) void k_adv_step(const double *__restr
     for (int n = 0; n < ADV_PF; n++) pre[n] = load_row(ka + n);
     // per cell functions of the two-cell rows
     auto lim2 = [&](const D2 &m, const D2 &c, const D2 &q) {
-        return (LIM != 0) ? D2{limit2(m.a, c.a, q.a), limit2(m.b, c.b, q.b)} : zero;
+        return (LIM != 0) ? D2{adv_limit2(m.a, c.a, q.a), adv_limit2(m.b, c.b, q.b)} : zero;
     };
     auto slope = [&](const D2 &lm, const D2 &l0, const D2 &lp, const D2 &m, const D2 &c, const D2 &q) {
         return D2{adv_slope<LIM>(lm.a, l0.a, lp.a, m.a, c.a, q.a),
@@ -296,10 +327,10 @@ __global__ __launch_bounds__(64 * ADV_WPB) void k_adv_step(const double *__restr
         const D2 sy = slope(l2ym, l2y, l2yp, am, ac, ap);
         // upwind states of cell c (interface.py:25-41): its lower face if the
         // velocity is negative, its upper face otherwise
-        const D2 X = UNEG ? D2{ac.a - 0.5 * (1.0 + cx) * sx.a, ac.b - 0.5 * (1.0 + cx) * sx.b}
-                          : D2{ac.a + 0.5 * (1.0 - cx) * sx.a, ac.b + 0.5 * (1.0 - cx) * sx.b};
-        const D2 Y = VNEG ? D2{ac.a - 0.5 * (1.0 + cy) * sy.a, ac.b - 0.5 * (1.0 + cy) * sy.b}
-                          : D2{ac.a + 0.5 * (1.0 - cy) * sy.a, ac.b + 0.5 * (1.0 - cy) * sy.b};
+        const D2 X = UNEG ? D2{ac.a - ADV_HALF * (1.0 + cx) * sx.a, ac.b - ADV_HALF * (1.0 + cx) * sx.b}
+                          : D2{ac.a + ADV_HALF * (1.0 - cx) * sx.a, ac.b + ADV_HALF * (1.0 - cx) * sx.b};
+        const D2 Y = VNEG ? D2{ac.a - ADV_HALF * (1.0 + cy) * sy.a, ac.b - ADV_HALF * (1.0 + cy) * sy.b}
+                          : D2{ac.a + ADV_HALF * (1.0 - cy) * sy.a, ac.b + ADV_HALF * (1.0 - cy) * sy.b};
         // a_x on the lower x face of row c; a_y on the lower y faces of rows c, c-1
         const D2 ax_c = UNEG ? X : Xm1;
         // (the lower row's values are the previous iteration's: kept as they were used there,
@@ -475,8 +506,8 @@ __device__ __forceinline__ bool adv_stage(AdvRings &R, const D2 &in, int k, int 
 #define ADV_W(n) R.rows[(U + (n)) % NR]
     ADV_W(4) = in;
     const D2 l2b = R.l2x[U % 3], l2c = R.l2x[(U + 1) % 3];
-    const D2 l2n = (LIM != 0) ? D2{limit2(ADV_W(2).a, ADV_W(3).a, ADV_W(4).a),
-                                   limit2(ADV_W(2).b, ADV_W(3).b, ADV_W(4).b)}
+    const D2 l2n = (LIM != 0) ? D2{adv_limit2(ADV_W(2).a, ADV_W(3).a, ADV_W(4).a),
+                                   adv_limit2(ADV_W(2).b, ADV_W(3).b, ADV_W(4).b)}
                               : zero;                                           // limit2_x of row k-1
     R.l2x[(U + 2) % 3] = l2n;
     // the states of row c = k-2 are needed for c in [o0 - 1, o1 - 1] (u > 0: the face below
@@ -488,17 +519,17 @@ __device__ __forceinline__ bool adv_stage(AdvRings &R, const D2 &in, int k, int 
     const D2 sx{adv_slope<LIM>(l2b.a, l2c.a, l2n.a, a_up.a, ac.a, a_dn.a),
                 adv_slope<LIM>(l2b.b, l2c.b, l2n.b, a_up.b, ac.b, a_dn.b)};
     const D2 am = adv_left(ac), ap = adv_right(ac);
-    const D2 l2y = (LIM != 0) ? D2{limit2(am.a, ac.a, ap.a), limit2(am.b, ac.b, ap.b)} : zero;
+    const D2 l2y = (LIM != 0) ? D2{adv_limit2(am.a, ac.a, ap.a), adv_limit2(am.b, ac.b, ap.b)} : zero;
     const D2 l2ym = (LIM == 2) ? adv_left(l2y) : zero, l2yp = (LIM == 2) ? adv_right(l2y) : zero;
     const D2 sy{adv_slope<LIM>(l2ym.a, l2y.a, l2yp.a, am.a, ac.a, ap.a),
                 adv_slope<LIM>(l2ym.b, l2y.b, l2yp.b, am.b, ac.b, ap.b)};
     const double cx = C.cx, cy = C.cy;
     // the x state row c gives to a face: its lower face (u < 0) or its upper one, which is the
     // lower face of row c + 1 (u > 0); y likewise
-    const D2 X = UNEG ? D2{ac.a - 0.5 * (1.0 + cx) * sx.a, ac.b - 0.5 * (1.0 + cx) * sx.b}
-                      : D2{ac.a + 0.5 * (1.0 - cx) * sx.a, ac.b + 0.5 * (1.0 - cx) * sx.b};
-    const D2 Y = VNEG ? D2{ac.a - 0.5 * (1.0 + cy) * sy.a, ac.b - 0.5 * (1.0 + cy) * sy.b}
-                      : D2{ac.a + 0.5 * (1.0 - cy) * sy.a, ac.b + 0.5 * (1.0 - cy) * sy.b};
+    const D2 X = UNEG ? D2{ac.a - ADV_HALF * (1.0 + cx) * sx.a, ac.b - ADV_HALF * (1.0 + cx) * sx.b}
+                      : D2{ac.a + ADV_HALF * (1.0 - cx) * sx.a, ac.b + ADV_HALF * (1.0 - cx) * sx.b};
+    const D2 Y = VNEG ? D2{ac.a - ADV_HALF * (1.0 + cy) * sy.a, ac.b - ADV_HALF * (1.0 + cy) * sy.b}
+                      : D2{ac.a + ADV_HALF * (1.0 - cy) * sy.a, ac.b + ADV_HALF * (1.0 - cy) * sy.b};
     // a_y on the lower y faces of row c (u, v != 0 here: the upwind offsets of
     // advective_fluxes.py:71-79 are the signs)
     const D2 ay_c = VNEG ? Y : adv_left(Y);
