@@ -45,6 +45,8 @@ UNITS = [
     ("comp_wave.hip", "wave_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1", "-fno-honor-nans"] + WAVE_SCHED),
     # the row-marching kernel of SphericalPolar grids (round 6)
     ("comp_sph_wave.hip", "sphw_exact", ["-ffp-contract=off", "-DPYRO_FAST=0"]),
+    # (no -fno-honor-nans here: ghost faces of an oddly reflected density hold NaN roots that the
+    # fmin / fmax floors of the CGF solver are there to absorb)
     ("comp_sph_wave.hip", "sphw_fast", ["-ffp-contract=fast", "-DPYRO_FAST=1"]),
     ("comp_api.hip", "comp_api", ["-ffp-contract=off"]),
     ("multigrid.hip", "multigrid", ["-ffp-contract=off"]),

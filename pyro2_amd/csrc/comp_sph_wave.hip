@@ -48,6 +48,14 @@ namespace PYRO_NS {
 namespace {
 
 constexpr int SWOUT = 56;          // columns a wavefront updates (reach of a cell update: 4 columns)
+// the limited slopes: stencil.h's (bit-faithful build) / the half slopes of fused_common.h
+#if PYRO_FAST
+#define SPHW_LIMIT2 half_limit2
+#define SPHW_SLOPE half_slope_shared
+#else
+#define SPHW_LIMIT2 limit2
+#define SPHW_SLOPE slope_shared
+#endif
 #if defined(PYRO_EMU)
 #define SPHW_FENCE() do {} while (0)
 #else
@@ -75,7 +83,10 @@ __device__ __forceinline__ Cons lp1(const Cons &U) { return Cons{lp1(U.d), lp1(U
 constexpr int SS_YM = 0, SS_YP = 4, SS_FXT = 8, SS_XP = 12, SS_XPC = 16, SS_FX = 20, SS_L2 = 24,
               SS_PXT = 32, SS_PX = 33, SS_CFL = 34,
               SS_CB = 35, SS_CC = 36, SS_CT = 37,     // FAC: the lane's column factors B, C, T (sph_common.h)
-              SS_SLOTS = 38;
+              // FAC, contracted build: |B|, |C|, 1 / T in SS_CB / SS_CC / SS_CT, 1 / |E| in SS_CRE; the
+              // running maximum of (|u| + c) / Lx, (|v| + c) / Ly over the lane's new cells in SS_AMAX
+              SS_CRE = 38, SS_AMAX = 39,
+              SS_SLOTS = 40;     // (40 x 512 B x 8 wavefronts = 160 KB: the LDS of a CU exactly)
 constexpr size_t SPHW_LDS_BYTES = (size_t)SS_SLOTS * 64 * sizeof(double);
 
 __device__ __forceinline__ Cons sget(const double *st, int s)
@@ -126,8 +137,18 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
     // load through the vector memory path in the middle of a row's work), those of column j + 1
     // come from the neighbouring lane; the row factors of rows i-1, i, i+1 are wavefront-uniform:
     // scalar loads where they are used
+    // FF: contracted build on the factors -- every quotient by a geometry value is a product with
+    // tabulated reciprocals (rows: 1 / Ly, 1 / (F G), 1 / x = dlogAx / 2; columns: 1 / |E|, 1 / T:
+    // pyrohip_state_set_geometry), 1 / V = (1 / |E|) (1 / (F G)); the bit-faithful build divides
+    constexpr bool FF = (PYRO_FAST != 0) && FAC;
     if (FAC) {
-        st[SS_CB * 64] = GA.cf(0, jc); st[SS_CC * 64] = GA.cf(1, jc); st[SS_CT * 64] = GA.cf(3, jc);
+        if (FF) {
+            st[SS_CB * 64] = fabs(GA.cf(0, jc)); st[SS_CC * 64] = fabs(GA.cf(1, jc));
+            st[SS_CT * 64] = GA.cf(5, jc); st[SS_CRE * 64] = GA.cf(4, jc);
+            st[SS_AMAX * 64] = 0.0;
+        } else {
+            st[SS_CB * 64] = GA.cf(0, jc); st[SS_CC * 64] = GA.cf(1, jc); st[SS_CT * 64] = GA.cf(3, jc);
+        }
     }
     // row factor k (A D F G Ly dlogAx x) of row r: the row number is wavefront-uniform, and told so
     // the compiler reads the table with a scalar load (no vector memory traffic, no vector register)
@@ -147,10 +168,24 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
     const unsigned sdj = (jc < g.jlo ? 4u : 0u) | (jc > g.jhi ? 8u : 0u);
     const double sint = G.sint[jc], sinb = G.sinb[jc], sinc = G.sinc[jc];
 
+    // the rows of a strip as [scalar base of the strip's first row, per plane] + [32-bit byte offset]
+    // (saddr form of the loads / stores: comp_wave.hip)
+    const int rbase = (i0 - 7 > 0) ? i0 - 7 : 0;
+    const char *const sbase_in = (const char *)(Uin + (size_t)rbase * p);
+    char *const sbase_out = (char *)(Uout + (size_t)rbase * p);
+    const unsigned pitch8 = (unsigned)p * 8u, lane8 = (unsigned)jc * 8u;
+    const size_t plb = pl * sizeof(double);
+    (void)sbase_in; (void)sbase_out; (void)plb; (void)pitch8; (void)lane8;
     auto loadU = [&](int row) {
         row = row < 0 ? 0 : (row > g.qx - 1 ? g.qx - 1 : row);
+#if defined(PYRO_EMU)
         const size_t kk = (size_t)row * p + jc;
         return Cons{Uin[kk], Uin[pl + kk], Uin[2 * pl + kk], Uin[3 * pl + kk]};
+#else
+        const unsigned off = (unsigned)(row - rbase) * pitch8 + lane8;
+        return Cons{*(const double *)(sbase_in + off), *(const double *)(sbase_in + plb + off),
+                    *(const double *)(sbase_in + 2 * plb + off), *(const double *)(sbase_in + 3 * plb + off)};
+#endif
     };
     auto row_in = [&](int r) { return r >= g.ilo && r <= g.ihi; };
 
@@ -190,10 +225,10 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
         if (k >= i0) {
             if (flat) fxn = flatten_1d(wp[0], wp[1], wp[3], wp[4], wu[1], wu[3], P.z0, P.z1, P.delta);
             if (limiter != 0) {
-                l2n[0] = limit2(wr[1], wr[2], wr[3]);
-                l2n[1] = limit2(wu[1], wu[2], wu[3]);
-                l2n[2] = limit2(wv[1], wv[2], wv[3]);
-                l2n[3] = limit2(wp[1], wp[2], wp[3]);
+                l2n[0] = SPHW_LIMIT2(wr[1], wr[2], wr[3]);
+                l2n[1] = SPHW_LIMIT2(wu[1], wu[2], wu[3]);
+                l2n[2] = SPHW_LIMIT2(wv[1], wv[2], wv[3]);
+                l2n[3] = SPHW_LIMIT2(wp[1], wp[2], wp[3]);
             }
         }
         double l2a[4], l2b[4];     // limit2_x of rows k-4 (slot k & 1) and k-3; row k-2 takes the older one's place
@@ -221,6 +256,13 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
             };
             auto gLy = [&](int w) { return FAC ? RF(4, rowi(w)) : GA.Ly(rowi(w), jc); };
             const double gLx = P.dx;                   // Lx = dr everywhere (patch.py:262; checked by the caller for FAC)
+            // FF: a / V, a / Ly, a / Lx as products (|A B| = |A| |B| exactly: the stash holds |B|, |C|)
+            const double cRE = FF ? st[SS_CRE * 64] : 0.0, cREp = FF ? lp1(cRE) : 0.0;
+            auto overV = [&](double a, int w, bool jp) {
+                return FF ? a * ((jp ? cREp : cRE) * RF(8, rowi(w))) : pdiv(a, gV(w, jp));
+            };
+            auto overLy = [&](double a, int w) { return FF ? a * RF(7, rowi(w)) : pdiv(a, gLy(w)); };
+            auto overLx = [&](double a) { return FF ? a * P.rdx : pdiv(a, gLx); };
             const double q0[4] = {wr[1], wu[1], wv[1], wp[1]};
             const double qm[4] = {wr[0], wu[0], wv[0], wp[0]};
             const double qp[4] = {wr[2], wu[2], wv[2], wp[2]};
@@ -229,7 +271,7 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
             for (int n = 0; n < 4; n++) {
                 ym[n] = lm1(q0[n]);
                 yp[n] = lp1(q0[n]);
-                if (limiter != 0) l2y[n] = limit2(ym[n], q0[n], yp[n]);
+                if (limiter != 0) l2y[n] = SPHW_LIMIT2(ym[n], q0[n], yp[n]);
             }
             um = ym[1]; vm = ym[2];
             double xi = 1.0;
@@ -240,13 +282,16 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
                 const double py_ = (yp[3] - ym[3] > 0) ? fym : fyp;
                 xi = fmin(fmin(fxb, px_), fmin(fy, py_));
             }
+#if PYRO_FAST
+            xi = xi + xi;      // (the contracted build's slopes are half slopes: fused_common.h)
+#endif
             double dqx[4], dqy[4];
 #pragma unroll
             for (int n = 0; n < 4; n++) {
-                dqx[n] = xi * slope_shared(l2a[n], l2b[n], l2n[n], qm[n], q0[n], qp[n], limiter);
+                dqx[n] = xi * SPHW_SLOPE(l2a[n], l2b[n], l2n[n], qm[n], q0[n], qp[n], limiter);
                 const double l2m = (limiter == 2) ? lm1(l2y[n]) : 0.0;
                 const double l2p = (limiter == 2) ? lp1(l2y[n]) : 0.0;
-                dqy[n] = xi * slope_shared(l2m, l2y[n], l2p, ym[n], q0[n], yp[n], limiter);
+                dqy[n] = xi * SPHW_SLOPE(l2m, l2y[n], l2p, ym[n], q0[n], yp[n], limiter);
             }
             SPHW_FENCE();
             // ---- external sources on the face states (simulation.py:117-124, unsplit_fluxes.py:
@@ -257,17 +302,26 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
                 const unsigned sd = sdj | (i < g.ilo ? 1u : 0u) | (i > g.ihi ? 2u : 0u);
                 // (an interior cell is its own source: the old state of row i is in registers)
                 double Ud = Ue.d, Umx = Ue.mx, Umy = Ue.my, xs = FAC ? RF(6, i) : GA.x(i, jc);
+                double rxs = FF ? 0.5 * RF(5, i) : 0.0;            // 1 / x = dlogAx / 2 (exact)
                 if (sd != 0) {
                     const int si = bc_src(P.mr, i, g.ilo, g.ihi);
                     const size_t ks = (size_t)si * p + sj;
                     Ud = Uin[ks]; Umx = Uin[2 * pl + ks]; Umy = Uin[3 * pl + ks];
                     xs = GA.x(si, sj);
+                    if (FF) rxs = 0.5 * RF(5, si);
                 }
                 Ud = fmax(Ud, P.small_dens);
                 double Sx = Ud * P.grav;
                 double SE = Umx * P.grav;
+                double Sy;
+                if (FF) {
+                    const double rUd = prcp(Ud);
+                    Sx = fma(Umy * Umy, rUd * rxs, Sx);
+                    Sy = -Umx * Umy * rUd;
+                } else {
                 Sx += pdiv(Umy * Umy, Ud * xs);
-                double Sy = pdiv(-Umx * Umy, Ud);
+                Sy = pdiv(-Umx * Umy, Ud);
+                }
                 SE = odd_sides((P.odd >> 4) & sd) ? -SE : SE;
                 Sx = odd_sides((P.odd >> 8) & sd) ? -Sx : Sx;
                 Sy = odd_sides((P.odd >> 12) & sd) ? -Sy : Sy;
@@ -302,13 +356,16 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
             }
             SPHW_FENCE();
             // ---- x states of row c (interface.py:106, 216-224), transverse x flux on its lower face
-            const double cs = psqrt(pdiv(gamma * q0[3], q0[0]));   // interface.py:122
+            // c^2 (interface.py:122; the contracted build: without the root)
+            const double cs2 = PYRO_FAST ? gamma * q0[3] * prcp(q0[0]) : 0.0;
+            const double cs = PYRO_FAST ? 0.0 : psqrt(pdiv(gamma * q0[3], q0[0]));
             Trace lo, hi;
             trace_states(q0[0], q0[1], q0[2], q0[3], dqx[0], dqx[1], dqx[2], dqx[3], gamma, dtdx, lo, hi);
             {
                 const double rs = -0.5 * dt * (FAC ? RF(5, i) : GA.dlAx(i, jc)) * q0[0] * q0[1];
                 hi.r += rs; lo.r += rs;
-                hi.p += rs * cs * cs; lo.p += rs * cs * cs;
+                if (PYRO_FAST) { hi.p = fma(rs, cs2, hi.p); lo.p = fma(rs, cs2, lo.p); }
+                else { hi.p += rs * cs * cs; lo.p += rs * cs * cs; }
             }
             Cons XMn = prim_to_cons(Prim{lo.r, lo.un, lo.ut, lo.p}, gamma);
             Cons XPn = prim_to_cons(Prim{hi.r, hi.un, hi.ut, hi.p}, gamma);
@@ -326,10 +383,10 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
                 const Cons FxTp = sget(st, SS_FXT);
                 const double Ahi = gAx(0), Alo = gAx(-1);
                 const double dpx = pxtn - st[SS_PXT * 64];
-                Cons YMc = sphf_corrected(sget(st, SS_YM), FxTn, Ahi, FxTp, Alo, pdiv(hdt, gV(-1, false)));
-                YMc.mx += pdiv(-hdt * dpx, gLx);
-                Cons YPc = sphf_corrected(sget(st, SS_YP), FxTn, Ahi, FxTp, Alo, pdiv(hdt, gV(-1, true)));
-                YPc.mx += pdiv(-hdt * dpx, gLx);
+                Cons YMc = sphf_corrected(sget(st, SS_YM), FxTn, Ahi, FxTp, Alo, overV(hdt, -1, false));
+                YMc.mx += overLx(-hdt * dpx);
+                Cons YPc = sphf_corrected(sget(st, SS_YP), FxTn, Ahi, FxTp, Alo, overV(hdt, -1, true));
+                YPc.mx += overLx(-hdt * dpx);
                 Fy = sphf_face(lm1(YPc), YMc, gamma, false, P.solid_yl && j == g.jlo, py);
                 const Cons Umy = lm1(Uem);
                 Fy.d += avy * (Umy.d - Uem.d);
@@ -343,11 +400,15 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
             SPHW_FENCE();
             // ---- y states of row c (interface.py:106, 226-234), transverse y flux on its lower face
             trace_states(q0[0], q0[2], q0[1], q0[3], dqy[0], dqy[2], dqy[1], dqy[3], gamma,
-                         pdiv(dt, gLy(0)), lo, hi);
+                         overLy(dt, 0), lo, hi);
             {
-                const double rs = -0.5 * dt * (FAC ? pdiv(1.0, st[SS_CT * 64] * RF(6, i)) : GA.dlAy(i, jc)) * q0[0] * q0[2];
+                // dlogAy = 1 / (tan(theta) r)   (FF: (1 / T) (1 / x))
+                const double dla = FF ? st[SS_CT * 64] * (0.5 * RF(5, i))
+                                      : (FAC ? pdiv(1.0, st[SS_CT * 64] * RF(6, i)) : GA.dlAy(i, jc));
+                const double rs = -0.5 * dt * dla * q0[0] * q0[2];
                 hi.r += rs; lo.r += rs;
-                hi.p += rs * cs * cs; lo.p += rs * cs * cs;
+                if (PYRO_FAST) { hi.p = fma(rs, cs2, hi.p); lo.p = fma(rs, cs2, lo.p); }
+                else { hi.p += rs * cs * cs; lo.p += rs * cs * cs; }
             }
             Cons YMn = prim_to_cons(Prim{lo.r, lo.ut, lo.un, lo.p}, gamma);
             Cons YPn = prim_to_cons(Prim{hi.r, hi.ut, hi.un, hi.p}, gamma);
@@ -364,10 +425,10 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
                 const Cons FyTh = lp1(FyT);            // F_yT at (i, j+1)
                 const double Ahi = gAy(0, true), Alo = gAy(0, false);
                 const double dpy = lp1(pyt) - pyt;
-                XMc = sphf_corrected(XMn, FyTh, Ahi, FyT, Alo, pdiv(hdt, gV(0, false)));
-                XMc.my += pdiv(-hdt * dpy, gLy(0));
-                XPc = sphf_corrected(XPn, FyTh, Ahi, FyT, Alo, pdiv(hdt, gV(1, false)));
-                XPc.my += pdiv(-hdt * dpy, gLy(1));
+                XMc = sphf_corrected(XMn, FyTh, Ahi, FyT, Alo, overV(hdt, 0, false));
+                XMc.my += overLy(-hdt * dpy, 0);
+                XPc = sphf_corrected(XPn, FyTh, Ahi, FyT, Alo, overV(hdt, 1, false));
+                XPc.my += overLy(-hdt * dpy, 1);
             }
             sput(st, SS_XP, XPn);
             Cons Fxn{0, 0, 0, 0};
@@ -387,7 +448,7 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
                 const int f = i - 1;
                 const Cons Fxp = sget(st, SS_FX);
                 const double pxp = st[SS_PX * 64];
-                const double dtdV = pdiv(dt, gV(-1, false));
+                const double dtdV = overV(dt, -1, false);
                 const double Ax0 = gAx(-1), Ax1 = gAx(0), Ay0 = gAy(-1, false), Ay1 = gAy(-1, true);
                 double Un[4];
                 const double Uo[4] = {Uem.d, Uem.E, Uem.mx, Uem.my};
@@ -395,32 +456,52 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
                 Un[1] = Uo[1] + dtdV * (Fxp.E * Ax0 - Fxn.E * Ax1 + Fy.E * Ay0 - Fyh.E * Ay1);
                 Un[2] = Uo[2] + dtdV * (Fxp.mx * Ax0 - Fxn.mx * Ax1 + Fy.mx * Ay0 - Fyh.mx * Ay1);
                 Un[3] = Uo[3] + dtdV * (Fxp.my * Ax0 - Fxn.my * Ax1 + Fy.my * Ay0 - Fyh.my * Ay1);
-                Un[2] -= pdiv(dt * (pxn - pxp), gLx);
-                Un[3] -= pdiv(dt * (pyh - py), gLy(-1));
+                Un[2] -= overLx(dt * (pxn - pxp));
+                Un[3] -= overLy(dt * (pyh - py), -1);
                 // S_old = S(U_old); U += dt S_old; S_new (time-centred x-momentum); U += dt/2 (S_new - S_old)
                 const double r = FAC ? RF(6, f) : GA.x(f, jc), grav = P.grav;
+                const double rr_ = FF ? 0.5 * RF(5, f) : 0.0;                // 1 / r
+                const double rUo = FF ? prcp(Uo[0]) : 0.0;
                 const double Sx_g_old = Uo[0] * grav;
                 const double SE_old = Uo[2] * grav;
-                const double Sx_old = Sx_g_old + pdiv(Uo[3] * Uo[3], Uo[0] * r);
-                const double Sy_old = pdiv(-Uo[2] * Uo[3], Uo[0]);
+                const double Sx_old = FF ? fma(Uo[3] * Uo[3], rUo * rr_, Sx_g_old)
+                                         : Sx_g_old + pdiv(Uo[3] * Uo[3], Uo[0] * r);
+                const double Sy_old = FF ? -Uo[2] * Uo[3] * rUo : pdiv(-Uo[2] * Uo[3], Uo[0]);
                 Un[1] = Un[1] + dt * SE_old;
                 Un[2] = Un[2] + dt * Sx_old;
                 Un[3] = Un[3] + dt * Sy_old;
                 const double Sx_g_new = Un[0] * grav;
                 const double xmom_new = Un[2] + 0.5 * dt * (Sx_g_new - Sx_g_old);
                 const double SE_new = xmom_new * grav;
-                const double Sx_new = Sx_g_new + pdiv(Un[3] * Un[3], Un[0] * r);
-                const double Sy_new = pdiv(-Un[2] * Un[3], Un[0]);
+                const double rUn = FF ? prcp(Un[0]) : 0.0;
+                const double Sx_new = FF ? fma(Un[3] * Un[3], rUn * rr_, Sx_g_new)
+                                         : Sx_g_new + pdiv(Un[3] * Un[3], Un[0] * r);
+                const double Sy_new = FF ? -Un[2] * Un[3] * rUn : pdiv(-Un[2] * Un[3], Un[0]);
                 Cons Uw;
                 Uw.d = Un[0];   // the density source is zero
                 Uw.E = Un[1] + 0.5 * dt * (SE_new - SE_old);
                 Uw.mx = Un[2] + 0.5 * dt * (Sx_new - Sx_old);
                 Uw.my = Un[3] + 0.5 * dt * (Sy_new - Sy_old);
+#if defined(PYRO_EMU)
                 const size_t ko = (size_t)f * p + j;
                 Uout[ko] = Uw.d; Uout[pl + ko] = Uw.E; Uout[2 * pl + ko] = Uw.mx; Uout[3 * pl + ko] = Uw.my;
+#else
+                const unsigned offo = (unsigned)(f - rbase) * pitch8 + (unsigned)j * 8u;
+                *(double *)(sbase_out + offo) = Uw.d; *(double *)(sbase_out + plb + offo) = Uw.E;
+                *(double *)(sbase_out + 2 * plb + offo) = Uw.mx; *(double *)(sbase_out + 3 * plb + offo) = Uw.my;
+#endif
+                if (FF) {
+                    // running maximum of (|u| + c) / Lx, (|v| + c) / Ly: one reciprocal at the end
+                    // (a ghost cell's lengths are its own: sphf_ghost_cfl keeps the quotient form)
+                    double ax, ay;
+                    cfl_speeds(Uw, gamma, ax, ay);
+                    st[SS_AMAX * 64] = fmax(st[SS_AMAX * 64], fmax(ax * P.rdx, ay * RF(7, f)));
+                    st[SS_CFL * 64] = sphf_ghost_cfl<FAC>(Uw, gamma, g, P, GA, f, j, st[SS_CFL * 64]);
+                } else {
                 double cfl = cfl_cell(Uw, gamma, gLx, gLy(-1));
                 cfl = sphf_ghost_cfl<FAC>(Uw, gamma, g, P, GA, f, j, cfl);
                 st[SS_CFL * 64] = fmin(st[SS_CFL * 64], cfl);
+                }
             }
             if (xface) { sput(st, SS_FX, Fxn); st[SS_PX * 64] = pxn; }
         }
@@ -429,7 +510,9 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
         Dp = Dn; up = um; vp = vm;
     }
     if (bad) atomicOr(flag, 1);
-    const double wm = wave_reduce_min(st[SS_CFL * 64]);
+    double cflw = st[SS_CFL * 64];
+    if (FF) { const double am = st[SS_AMAX * 64]; if (am > 0.0) cflw = fmin(cflw, prcp(am)); }
+    const double wm = wave_reduce_min(cflw);
     if (l == 0) partial[sb * P.ncb + cb] = wm;
 }
 
