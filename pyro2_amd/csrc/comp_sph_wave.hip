@@ -160,6 +160,9 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
     typedef const __attribute__((address_space(4))) double *ConstTab;
     const ConstTab rowf_c = (ConstTab)(unsigned long long)G.rowf;
 #endif
+    // (measured and dropped: a sliding window of the three rows' factors in scalar registers, the
+    // next row's requested an iteration ahead -- the kernel is out of scalar registers, the window
+    // went to vector lanes (v_writelane / v_readlane 116 -> 180 per row) and the step took the same time)
     auto RF = [&](int kf, int r) { return rowf_c[kf * G.qxp + pyro_uniform(r)]; };
     const double cE = -2.0 * 3.14159265358979323846 / 3.0;     // E = (-2 pi / 3) B (mesh/patch.py: device_geometry)
     const double hdt = 0.5 * dt;
@@ -202,7 +205,23 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
         sput(st, SS_FXT, one); sput(st, SS_FX, one); sput(st, SS_L2, one); sput(st, SS_L2 + 4, one);
         st[SS_PXT * 64] = 1.0; st[SS_PX * 64] = 1.0; st[SS_CFL * 64] = INFINITY;
     }
+#if !defined(PYRO_EMU)
+    // launches of up to two rounds of resident wavefronts: the two wavefronts of a SIMD take turns
+    // at the priority, two rows each, so that the pair ends together (comp_wave.hip; here the
+    // second one holds it five eighths of the time: 2048^2 0.325 / 0.314 / 0.307 / 0.315 / 0.326 ms
+    // per step with 0 / 4 / 5 / 6 / 7 eighths)
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    const int wslot = (int)(hw_id & 1u);
+#endif
     for (int k = i0 - 4; k <= i1 + 3; k++) {
+#if !defined(PYRO_EMU)
+        if (P.prio_duty > 0) {
+            const int phase = ((k - i0) >> 1) & 7;
+            if (wslot ? (phase < P.prio_duty) : (phase >= P.prio_duty)) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
 #pragma unroll
         for (int n = 0; n < 4; n++) { wr[n] = wr[n + 1]; wu[n] = wu[n + 1]; wv[n] = wv[n + 1]; wp[n] = wp[n + 1]; }
         Uem = Ue;
@@ -567,6 +586,7 @@ int comp_step_wave_sph_ex(pyrohip_state *s, const pyrohip_comp_params *p, double
     P.nsb = (g.nx + P.L - 1) / P.L;
     if (P.nsb > 1 && g.nx - (P.nsb - 1) * P.L < g.ng) P.nsb--;
     P.nunits = P.ncb * P.nsb;
+    P.prio_duty = (P.nunits <= 2 * 8 * cus) ? 5 : 0;
     PYRO_TRY(c->reduce.ensure((P.nunits + kMinStageBlocks + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
     using KernelT = void (*)(const double *, double *, Geom, FP, SphG, int *, double *, const StepScalars *);
