@@ -613,9 +613,22 @@ __device__ __forceinline__ void estimate_wave_speed_fast(double rho_l, double u_
         }
     }
     S_l = u_l - c_l;
-    if (pstar > p_l) S_l = fma(-c_l, psqrt_nc(fma(K.sl(), pstar * prcp(p_l) - 1.0, 1.0)), u_l);
     S_r = u_r + c_r;
-    if (pstar > p_r) S_r = fma(c_r, psqrt_nc(fma(K.sr(), pstar * prcp(p_r) - 1.0, 1.0)), u_r);
+    // the shock branch of a compressed side (riemann.py:660-678).  In smooth flow p* lies between p_l
+    // and p_r: every lane has exactly ONE compressed side, but which one differs from lane to lane,
+    // and a wavefront that evaluates the two branches one after the other pays two reciprocals and
+    // two roots (quarter rate) for one per lane.  So: one evaluation for the lane's (first)
+    // compressed side, and a second one only where both sides are compressed.  Same expressions on
+    // the same operands: the same bits as the two branches.
+    const bool hl = pstar > p_l, hr = pstar > p_r;
+    if (hl || hr) {
+        const double pk = hl ? p_l : p_r, ks = hl ? K.sl() : K.sr();
+        const double z = psqrt_nc(fma(ks, pstar * prcp(pk) - 1.0, 1.0));
+        if (hl) S_l = fma(-c_l, z, u_l);
+        else S_r = fma(c_r, z, u_r);
+        if (__builtin_expect(hl && hr, 0))
+            S_r = fma(c_r, psqrt_nc(fma(K.sr(), pstar * prcp(p_r) - 1.0, 1.0)), u_r);
+    }
 }
 
 template <bool HAVEQ, class KT>
