@@ -83,7 +83,7 @@ TAG=$TAG bash tools/pmc_also.sh > $O/pmc_also_${TAG}.log 2>&1; cp $O/${TAG}_also
 python tools/mg_sizes.py > $P/${TAG}_mg_vcycle_by_size.txt 2>&1; cat $P/${TAG}_mg_vcycle_by_size.txt
 # the SURVEY 8(f4) kernels: kernel statistics + counters per leg (tools/pmc_leg.sh)
 RT=$TAG
-for spec in "swe k_sw_wave 4096 swe4096" "sph k_ctu_fused_sph 2048 sph2048"; do
+for spec in "swe k_sw_wave 4096 swe4096" "sph k_sph_wave 2048 sph2048"; do
   set -- $spec
   LEG=$1 KN=$2 NX=$3 TAG=${RT}_$4 bash tools/pmc_leg.sh > $O/pmc_leg_${RT}_$4.log 2>&1
   cp $O/${RT}_$4_kernel_stats.csv $O/${RT}_$4_pmc.json $P/ 2>/dev/null
