@@ -542,6 +542,7 @@ struct SWW {
     double dx, dy, dt, g;
     int limiter;
     int ncb, L, nunits;
+    int prio_duty;      // eighths of the time the second wavefront of a SIMD holds the priority (0: age decides)
 };
 
 #if !defined(PYRO_EMU)
@@ -653,7 +654,19 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
     for (int r = 0; r < 5; r++) { q[r][0] = 1.0; q[r][1] = q[r][2] = q[r][3] = 0.0; }
     V4 Upre = loadU(i0 - 3), Urep = loadU(i0 - 6);
     double l2a[4] = {0.0, 0.0, 0.0, 0.0}, l2b[4] = {0.0, 0.0, 0.0, 0.0};   // L4: limit2 along x centred on rows k-3, k-2
+#if !defined(PYRO_EMU)
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    const int wslot = (int)(hw_id & 1u);
+#endif
     for (int k = i0 - 3; k <= i1 + 2; k++) {
+#if !defined(PYRO_EMU)
+        if (P.prio_duty > 0) {     // the two wavefronts of a SIMD take turns at the priority (comp_wave.hip)
+            const int phase = ((k - i0) >> 1) & 7;
+            if (wslot ? (phase < P.prio_duty) : (phase >= P.prio_duty)) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         // ---- row k arrives: primitives (k_sw_prim)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -762,20 +775,24 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
 }
 
 // rows per chunk of the fused step (a chunk costs L + 6 iterations): whole rounds of resident
-// wavefronts (two per SIMD) + one chunk time for the stragglers of the last round -- the rule of
-// the compressible kernel (comp_wave.hip: wave_rows) without its one-round case: this kernel's
-// wavefronts do not take turns at the priority, a single round ends with every SIMD's younger
-// wavefront alone (4096^2: one round of 147 rows 1.26 ms, 1.5 rounds of 96 rows 1.21)
+// wavefronts (two per SIMD) + one chunk time for the stragglers of the last round; ONE round when
+// everything is resident at once -- the rule of the compressible kernel (comp_wave.hip: wave_rows).
+// (Round 5 left the one-round case out: without turns at the priority a single round ends with
+// every SIMD's younger wavefront alone -- 4096^2: one round of 147 rows 1.26 ms, 1.5 rounds of 96
+// rows 1.21.  Round 6, with the turns (sww_prio_duty): 96 rows 0.614 ms, 147 rows 0.620 / 0.581 /
+// 0.573 ms with the second wavefront holding the priority 0 / 5 / 6 eighths of the time.)
 static int sww_rows(int nx, int ncb, int cus)
 {
     const long slots = 8L * cus;
     if (nx <= 16) return nx;
+    static const int forced = getenv("PYRO_SWW_ROWS") ? atoi(getenv("PYRO_SWW_ROWS")) : 0;    // (developer sweep)
+    if (forced > 0) return forced < nx ? forced : nx;
     long best_cost = -1;
     int best = 16;
     for (int L = 16; L <= 160 && L <= nx; L++) {
         const long waves = (long)ncb * ((nx + L - 1) / L);
         const long rounds = (waves + slots - 1) / slots;
-        const long cost = (rounds + 1) * (L + 6);
+        const long cost = (waves <= slots ? 1 : rounds + 1) * (L + 6);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = L; }
     }
     return best;
@@ -821,11 +838,16 @@ int swe_step_wave(pyrohip_state *s, double dx, double dy, double grav, int limit
         PYRO_CHECK_HIP(hipMalloc((void **)&s->alt_base, n * sizeof(double)));
         PYRO_CHECK_HIP(hipMemsetAsync(s->alt_base, 0, n * sizeof(double), c->stream));
     }
-    SWW P{dx, dy, dt, grav, limiter, 0, 0, 0};
+    SWW P{dx, dy, dt, grav, limiter, 0, 0, 0, 0};
     P.ncb = (g.ny + SWW_OUT - 1) / SWW_OUT;
     P.L = sww_rows(g.nx, P.ncb, c->num_cus > 0 ? c->num_cus : 256);
     P.nunits = P.ncb * ((g.nx + P.L - 1) / P.L);
     if (nparts) *nparts = P.nunits;
+    {
+        // one round of resident wavefronts: the pair of a SIMD takes turns at the priority and ends together
+        static const int duty = getenv("PYRO_SWW_DUTY") ? atoi(getenv("PYRO_SWW_DUTY")) : 6;   // (developer sweep)
+        P.prio_duty = (P.nunits <= 8 * (c->num_cus > 0 ? c->num_cus : 256)) ? duty : 0;
+    }
     double *Uout = s->alt_base + geom_lead(g);
     const dim3 grid(8 * ((P.nunits + 7) / 8)), block(64);
     using KernelT = void (*)(const double *, double *, Geom, SWW, const StepScalars *, double *);
