@@ -30,7 +30,7 @@ template <bool FAC> struct SphAt {
 };
 // CGF interface state, its flux without the pressure and its pressure
 // (riemann_flux(return_cons=True) + cons_to_prim, unsplit_fluxes.py:411-423)
-#if PYRO_FAST
+#if PYRO_FAST && !defined(PYRO_SPHF_RESTATED)      // (PYRO_SPHF_RESTATED: developer A/B)
 // Contracted build (round 6): the two-shock solver of riemann.py:8-310 written for the instruction
 // count -- the bit-faithful restatement (hydro.h: cgf_state, then cons_to_prim and cons_flux_n of
 // the conserved interface state) issues 13 quarter-rate reciprocals / roots per face, this one 5
