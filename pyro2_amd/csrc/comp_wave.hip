@@ -473,10 +473,26 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     // Runge-Kutta stage folded into the load the second read costs the increments' planes too,
     // and three rows of y_0 + k_j per wavefront no longer sit in the L2 between the two reads --
     // an RKF stage took 0.65-1.37 ms at 4096^2 against 0.49 for the plain right-hand side)
-    constexpr bool NOREP = (PYRO_FAST != 0) && MOL;
+    // DELAY (round 6; the plain contracted CTU instance): the four stores of a row's update are issued at
+    // the top of the NEXT iteration, between the consumption of the row that arrived and the request of
+    // the next one.  Stores and loads share the vmcnt counter and complete in order: with the stores at
+    // the end of the iteration, the wait for the prefetched row at the top of the next one also waited
+    // for the stores issued just before (they are conditional, the compiler must assume none is younger
+    // than the loads: s_waitcnt vmcnt(0)) -- a fifth of a wavefront's cycles (SQ_WAIT_INST_ANY 55 k of 255 k
+    // per wavefront, SQ_WAIT_INST_LDS 3 k: profiles/r06_default16384_fm1_pmc.json).  The new state waits in the
+    // registers the second read of the old state used to occupy: that one is rebuilt from the primitive
+    // window like in the method-of-lines instances.
+#if !defined(PYRO_WAVE_NO_DELAY)
+    constexpr bool REBUILD = (PYRO_FAST != 0) && !MOL && !MAPS;     // (the emulated contracted build too)
+    constexpr bool DELAY = REBUILD && SADDR;
+#else
+    constexpr bool REBUILD = false, DELAY = false;                   // (developer A/B)
+#endif
+    constexpr bool NOREP = (PYRO_FAST != 0) && (MOL || REBUILD);
     Cons Urep = NOREP ? Cons{1.0, 1.0, 0.0, 0.0} : loadU(i0 - 7);    // row k-3 again, in flight
     Cons Krep = NOREP ? Cons{0.0, 0.0, 0.0, 0.0} : loadK(i0 - 7);
     bool bad = false;
+    Cons Upend{0.0, 0.0, 0.0, 0.0};        // DELAY: the new state of row k-5, stored at the top of iteration k
     // ... and in the stash: uncorrected YM, YP, XP, FxT, corrected XP and Fx of row k-4
     {
         const Cons one{1.0, 1.0, 0.0, 0.0};
@@ -531,8 +547,10 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             Cons U = Upre;
             addK(U, Kpre);
             fix_sign(U, k);
+            if (!DELAY) {
             Upre = loadU(k + 1);
             Kpre = loadK(k + 1);
+            }
             const bool interior = row_in(k) && jin;
             // (RKF: the stage state is a temporary of the step -- nothing to keep the floor in)
             if (MOL && !RKF && interior && U.d < US2(SMALLD, P.small_dens))     // clean_state works in place
@@ -542,6 +560,22 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             const Prim q = cons_to_prim_nb(U, US3(GAMMA, P.gamma), ok);
             if (interior && !ok) bad = true;
             wr[4] = q.r; wu[4] = q.u; wv[4] = q.v; wp[4] = q.p;
+            if (DELAY) {
+                // (the row that arrived is consumed ABOVE this fence: its wait sees only its own loads
+                // outstanding; then the delayed stores, then the request of the next row.  The empty
+                // statement pins the primitives HERE: pure arithmetic sinks below a scheduling fence)
+#if !defined(PYRO_EMU)
+                asm volatile("" : "+v"(wr[4]), "+v"(wu[4]), "+v"(wv[4]), "+v"(wp[4]));
+#endif
+                STAGE_FENCE();
+                if (k - 1 >= i0 + 4 && jout) {      // the update of row k-5, made by iteration k-1
+                    const unsigned off = (unsigned)(k - 5 - rbase) * pitch8 + (unsigned)j * 8u;
+                    *(double *)(sbase_out + off) = Upend.d; *(double *)(sbase_out + plb + off) = Upend.E;
+                    *(double *)(sbase_out + 2 * plb + off) = Upend.mx; *(double *)(sbase_out + 3 * plb + off) = Upend.my;
+                }
+                Upre = loadU(k + 1);
+                STAGE_FENCE();
+            }
         }
         // ---- flatten_x and limit2_x of row k-2 (window index 2)
         double fxn = 1.0, l2n[4] = {0, 0, 0, 0};
@@ -882,7 +916,9 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 __builtin_nontemporal_store(Un.mx, &Uout[2 * pl + ko]);
                 __builtin_nontemporal_store(Un.my, &Uout[3 * pl + ko]);
 #else
-                if (SADDR) {
+                if (DELAY) {
+                    Upend = Un;
+                } else if (SADDR) {
                     const unsigned off = (unsigned)(i - 1 - rbase) * pitch8 + (unsigned)j * 8u;
                     *(double *)(sbase_out + off) = Un.d; *(double *)(sbase_out + plb + off) = Un.E;
                     *(double *)(sbase_out + 2 * plb + off) = Un.mx; *(double *)(sbase_out + 3 * plb + off) = Un.my;
@@ -902,6 +938,11 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         // hand the rows on
         fxa = fxb; fxb = fxn;
         Dp = Dn; up = um; vp = vm;
+    }
+    if (DELAY && i1 + 3 >= i0 + 4 && jout) {      // the update the last iteration made (row i1 - 1)
+        const unsigned off = (unsigned)(i1 - 1 - rbase) * pitch8 + (unsigned)j * 8u;
+        *(double *)(sbase_out + off) = Upend.d; *(double *)(sbase_out + plb + off) = Upend.E;
+        *(double *)(sbase_out + 2 * plb + off) = Upend.mx; *(double *)(sbase_out + 3 * plb + off) = Upend.my;
     }
     if (bad) atomicOr(flag, 1);
     // min over the lane's cells of min(dx / (|u| + c), dy / (|v| + c)), cfl_cell()
