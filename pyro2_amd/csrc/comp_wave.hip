@@ -236,7 +236,10 @@ __device__ __forceinline__ void st_put(double *st, int s, const Cons &U)
 // RKF (with MOL): the Runge-Kutta stage folded into the launch -- the stage state built at load from
 // y_0 and the earlier increments, ghost cells through the boundary rules, and in the last stage
 // the final update + the CFL minimum of compressible_rk instead of the k store (fused_common.h: FP::rk_*)
-template <int SOLVER, bool STD, bool MOL = false, bool ONE = false, bool RKF = false>   // SOLVER, STD as k_ctu_fused
+// SRC = false: an instance without the source-term blocks (gravity, heating) for runs that have none --
+// skipped at run time they still cost registers whose pending loads force a full vmcnt wait where their
+// paths join the row's work: 31.7 -> 32.3 Gcell/s at 16384^2 (round 6)
+template <int SOLVER, bool STD, bool MOL = false, bool ONE = false, bool RKF = false, bool SRC = true>   // SOLVER, STD as k_ctu_fused
 __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *__restrict__ Uin,
                                                                  double *__restrict__ Uout, Geom g,
                                                                  FP P, int *__restrict__ flag,
@@ -268,6 +271,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     const size_t pl = g.plane;
     const int limiter = STD ? 2 : P.limiter;
     const bool flat = STD || P.use_flattening;
+    const bool HAVE_SRC = SRC && P.have_src;
     // fast build, HLLC: the transverse Riemann problems take the traced primitive
     // face states as they are (hllc_flux_impl<true>)
     constexpr bool TQ = (PYRO_FAST != 0) && (SOLVER == 0) && !MOL;
@@ -680,7 +684,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             // source terms of the face states (apply_source_terms, unsplit_fluxes.py:247-330)
             Cons Ug{0.0, 0.0, 0.0, 0.0};
             double sgn = 1.0, hp = 0.0;
-            if (!MOL && P.have_src) {
+            if (!MOL && HAVE_SRC) {
                 const bool ina = (j < g.qy);
                 // "ambient" upper boundary: the source ghosts are copies of row jhi
                 // (BC.py:159-160), not the sources of the ambient ghost state
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             Cons XMn = prim_to_cons_g(Prim{lo.r, lo.un, lo.ut, lo.p}, gm1, rgm1);
             Cons XPn = prim_to_cons_g(Prim{hi.r, hi.un, hi.ut, hi.p}, gm1, rgm1);
             FaceQ qxm{lo.un, lo.ut, lo.p}, qxp{hi.un, hi.ut, hi.p};
-            if (!MOL && P.have_src) {
+            if (!MOL && HAVE_SRC) {
                 add_grav_to_state(XMn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
                 add_grav_to_state(XPn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
                 if (TQ) { qxm = faceq(to_nf(XMn, true), gamma); qxp = faceq(to_nf(XPn, true), gamma); }
@@ -796,7 +800,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             Cons YMn = prim_to_cons_g(Prim{lo.r, lo.ut, lo.un, lo.p}, gm1, rgm1);
             Cons YPn = prim_to_cons_g(Prim{hi.r, hi.ut, hi.un, hi.p}, gm1, rgm1);
             FaceQ qym{lo.un, lo.ut, lo.p}, qyp{hi.un, hi.ut, hi.p};
-            if (!MOL && P.have_src) {
+            if (!MOL && HAVE_SRC) {
                 add_grav_to_state(YMn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
                 add_grav_to_state(YPn, Ug, UC(GRAV), UC(DT), sgn, UC(HEATR), hp);
                 if (TQ) { qym = faceq(to_nf(YMn, false), gamma); qyp = faceq(to_nf(YPn, false), gamma); }
@@ -908,7 +912,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 Un.my = Uc.my + dtdV * (Fxp.my * Ax - Fxn.my * Ax + Fy.my * Ay - Fyh.my * Ay);
 #endif
                 const size_t ko = (size_t)(i - 1) * p + j;
-                if (P.have_src)   // simulation.py:406-423
+                if (HAVE_SRC)   // simulation.py:406-423
                     grav_update(Un, Uc, UC(GRAV), UC(DT), UC(HEATR), P.heat ? P.heat[ko] : 0.0);
 #if defined(PYRO_WAVE_NT_STORE) && !defined(PYRO_EMU)
                 __builtin_nontemporal_store(Un.d, &Uout[ko]);
@@ -1043,10 +1047,21 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
     double *part = (double *)c->reduce.p;
     using KernelT = void (*)(const double *, double *, Geom, FP, int *, double *,
                              const StepScalars *);
-    static const KernelT kernels[3][2] = {
+    static const KernelT kernels_src[3][2] = {
         {k_ctu_wave<0, false>, k_ctu_wave<0, true>},
         {k_ctu_wave<1, false>, k_ctu_wave<1, true>},
         {k_ctu_wave<2, false>, k_ctu_wave<2, true>}};
+#if PYRO_FAST
+    static const KernelT kernels_nosrc[3][2] = {
+        {k_ctu_wave<0, false, false, false, false, false>, k_ctu_wave<0, true, false, false, false, false>},
+        {k_ctu_wave<1, false, false, false, false, false>, k_ctu_wave<1, true, false, false, false, false>},
+        {k_ctu_wave<2, false, false, false, false, false>, k_ctu_wave<2, true, false, false, false, false>}};
+    const KernelT (*kernels)[2] = P.have_src ? kernels_src : kernels_nosrc;
+#else
+    // (the bit-faithful build keeps ONE instance: without the source blocks its register allocation
+    // comes out worse -- 15.8 -> 16.4 ms per step at 16384^2)
+    const KernelT (*kernels)[2] = kernels_src;
+#endif
     const int solver = (p->riemann == 1 || p->riemann == 2) ? p->riemann : 0;
     const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
     static const int slab_mode = getenv("PYRO_SLAB_MODE") ? atoi(getenv("PYRO_SLAB_MODE")) : 1;   // developer experiments
