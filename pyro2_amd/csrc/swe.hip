@@ -652,7 +652,29 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
     double q[5][4];
 #pragma unroll
     for (int r = 0; r < 5; r++) { q[r][0] = 1.0; q[r][1] = q[r][2] = q[r][3] = 0.0; }
-    V4 Upre = loadU(i0 - 3), Urep = loadU(i0 - 6);
+    // SWW_DELAY (contracted build on the GPU, round 6; comp_wave.hip has the measurement): the stores of a
+    // row's update are issued at the top of the NEXT iteration, behind the consumption of the row that
+    // arrived and in front of the next request -- loads and stores share vmcnt and complete in order, the
+    // wait for the prefetched row included the stores issued just before it.  The new state waits in the
+    // registers of the old state's second read, which is rebuilt from the primitive window (h, u, v, X).
+#if PYRO_FAST && !defined(PYRO_EMU) && !defined(PYRO_SWW_NO_DELAY)
+    constexpr bool SWW_DELAY = true;
+#else
+    constexpr bool SWW_DELAY = false;
+#endif
+    V4 Upre = loadU(i0 - 3), Urep = SWW_DELAY ? zero : loadU(i0 - 6);
+    V4 Upend = zero;
+    auto store_row = [&](const V4 &V, int row) {
+#if defined(PYRO_EMU)
+        const size_t ko = (size_t)row * p + j;
+#pragma unroll
+        for (int n = 0; n < 4; n++) Uout[(size_t)n * pl + ko] = V.a[n];
+#else
+        const unsigned offo = (unsigned)(row - rbase) * pitch8 + (unsigned)j * 8u;
+#pragma unroll
+        for (int n = 0; n < 4; n++) *(double *)(sbase_out + (size_t)n * plb + offo) = V.a[n];
+#endif
+    };
     double l2a[4] = {0.0, 0.0, 0.0, 0.0}, l2b[4] = {0.0, 0.0, 0.0, 0.0};   // L4: limit2 along x centred on rows k-3, k-2
 #if !defined(PYRO_EMU)
     unsigned hw_id;
@@ -673,13 +695,26 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
 #pragma unroll
             for (int n = 0; n < 4; n++) q[r][n] = q[r + 1][n];
         }
-        const V4 Uk = Upre, Uold = Urep;     // rows k and k-3
+        const V4 Uk = Upre;                  // row k
+        V4 Uold = Urep;                      // row k-3 (window row 1 after the shift above)
+        if (SWW_DELAY) Uold = sw_prim_to_cons(q[1]);
+        else {
         Upre = loadU(k + 1);
         Urep = loadU(k - 2);
+        }
         q[4][0] = Uk.a[0];
         q[4][1] = sw_vel(Uk.a[1], Uk.a[0]);
         q[4][2] = sw_vel(Uk.a[2], Uk.a[0]);
         q[4][3] = sw_vel(Uk.a[3], Uk.a[0]);
+        if (SWW_DELAY) {
+#if !defined(PYRO_EMU)
+            asm volatile("" : "+v"(q[4][0]), "+v"(q[4][1]), "+v"(q[4][2]), "+v"(q[4][3]));   // (the arrived row is consumed HERE)
+#endif
+            SWW_FENCE();
+            if (k - 1 - 2 >= i0 + 1 && jout) store_row(Upend, k - 4);      // the update iteration k-1 made (row c-1 = k-4)
+            Upre = loadU(k + 1);
+            SWW_FENCE();
+        }
         const int c = k - 2;                 // window row 2
         double l2n[4], l2m_[4];              // L4: limit2 along x centred on row k-1 = c+1, on row c-1
         if (L4) {
@@ -741,19 +776,12 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
                 const V4 Fy_p = sww_p1(Fy);
                 const V4 Fxm = get(S_FX);
                 if (jout) {
-                    const size_t ko = (size_t)(c - 1) * p + j;
-                    const unsigned offo = (unsigned)(c - 1 - rbase) * pitch8 + (unsigned)j * 8u;
                     V4 Un;
 #pragma unroll
-                    for (int n = 0; n < 4; n++) {
+                    for (int n = 0; n < 4; n++)
                         Un.a[n] = Uold.a[n] + (dtdx * (Fxm.a[n] - Fx.a[n]) + dtdy * (Fy.a[n] - Fy_p.a[n]));
-#if defined(PYRO_EMU)
-                        Uout[(size_t)n * pl + ko] = Un.a[n];
-#else
-                        *(double *)(sbase_out + (size_t)n * plb + offo) = Un.a[n];
-#endif
-                    }
-                    (void)ko; (void)offo;
+                    if (SWW_DELAY) Upend = Un;
+                    else store_row(Un, c - 1);
                     if (partial) {     // k_sw_cfl's quantities: one division per direction at the end
                         const double u = pdiv(Un.a[1], Un.a[0]), v = pdiv(Un.a[2], Un.a[0]);
                         const double cs = psqrt(P.g * Un.a[0]);
@@ -766,6 +794,7 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
         }
         put(S_XP, XP); put(S_YP, YP); put(S_YM, YM); put(S_FXT, FXT); put(S_FYT, FYT);
     }
+    if (SWW_DELAY && i1 >= i0 + 1 && jout) store_row(Upend, i1 - 1);      // the update the last iteration made
     if (partial) {
         // min over cells of dx / a = dx / max a (the correctly rounded quotient is monotone)
         const double m = fmin(amax > 0.0 ? pdiv(P.dx, amax) : INFINITY, bmax > 0.0 ? pdiv(P.dy, bmax) : INFINITY);
