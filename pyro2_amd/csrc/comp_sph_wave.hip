@@ -197,7 +197,26 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
     double fxa = 1.0, fxb = 1.0;                               // flatten_x of rows k-4, k-3
     Cons Ue{1.0, 1.0, 0.0, 0.0}, Uem = Ue;                     // old state, rows k-3 / k-4
     double Dp = 0.0, up = 0.0, vp = 0.0;                       // vertex div(U) of row k-4; u, v at (k-4, j-1)
-    Cons Upre = loadU(i0 - 4), Urep = loadU(i0 - 7);
+    // SPHW_DELAY (contracted build on the GPU; comp_wave.hip has the measurement): the stores of a row's
+    // update at the top of the next iteration -- behind the consumption of the arrived row, in front of
+    // the next request --, the old state rebuilt from the primitive window instead of read a second time
+#if PYRO_FAST && !defined(PYRO_EMU) && !defined(PYRO_SPHW_NO_DELAY)
+    constexpr bool SPHW_DELAY = true;
+#else
+    constexpr bool SPHW_DELAY = false;
+#endif
+    Cons Upre = loadU(i0 - 4), Urep = SPHW_DELAY ? Cons{1.0, 1.0, 0.0, 0.0} : loadU(i0 - 7);
+    Cons Upend{0.0, 0.0, 0.0, 0.0};
+    auto store_row = [&](const Cons &V, int row) {
+#if defined(PYRO_EMU)
+        const size_t ko = (size_t)row * p + j;
+        Uout[ko] = V.d; Uout[pl + ko] = V.E; Uout[2 * pl + ko] = V.mx; Uout[3 * pl + ko] = V.my;
+#else
+        const unsigned offo = (unsigned)(row - rbase) * pitch8 + (unsigned)j * 8u;
+        *(double *)(sbase_out + offo) = V.d; *(double *)(sbase_out + plb + offo) = V.E;
+        *(double *)(sbase_out + 2 * plb + offo) = V.mx; *(double *)(sbase_out + 3 * plb + offo) = V.my;
+#endif
+    };
     bool bad = false;
     {
         const Cons one{1.0, 1.0, 0.0, 0.0};
@@ -225,19 +244,33 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
 #pragma unroll
         for (int n = 0; n < 4; n++) { wr[n] = wr[n + 1]; wu[n] = wu[n + 1]; wv[n] = wv[n + 1]; wp[n] = wp[n + 1]; }
         Uem = Ue;
+        if (SPHW_DELAY) {
+            // (window index 1 = row k-3 after the shift above; the floor is in the primitives)
+            Ue = prim_to_cons(Prim{wr[1], wu[1], wv[1], wp[1]}, gamma);
+        } else {
         Ue = Urep;
         if (row_in(k - 3) && jin) Ue.d = fmax(Ue.d, P.small_dens);      // clean_state
         Urep = loadU(k - 2);
+        }
         // ---- row k arrives: primitives
         {
             Cons U = Upre;
-            Upre = loadU(k + 1);
+            if (!SPHW_DELAY) Upre = loadU(k + 1);
             const bool interior = row_in(k) && jin;
             if (interior) U.d = fmax(U.d, P.small_dens);
             bool ok;
             const Prim q = cons_to_prim_nb(U, gamma, ok);
             if (interior && !ok) bad = true;
             wr[4] = q.r; wu[4] = q.u; wv[4] = q.v; wp[4] = q.p;
+            if (SPHW_DELAY) {
+#if !defined(PYRO_EMU)
+                asm volatile("" : "+v"(wr[4]), "+v"(wu[4]), "+v"(wv[4]), "+v"(wp[4]));   // (the arrived row is consumed HERE)
+#endif
+                SPHW_FENCE();
+                if (k - 1 >= i0 + 4 && jout) store_row(Upend, k - 5);      // the update iteration k-1 made
+                Upre = loadU(k + 1);
+                SPHW_FENCE();
+            }
         }
         // ---- flatten_x and limit2_x of row k-2 (window index 2)
         double fxn = 1.0, l2n[4] = {0, 0, 0, 0};
@@ -501,14 +534,8 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
                 Uw.E = Un[1] + 0.5 * dt * (SE_new - SE_old);
                 Uw.mx = Un[2] + 0.5 * dt * (Sx_new - Sx_old);
                 Uw.my = Un[3] + 0.5 * dt * (Sy_new - Sy_old);
-#if defined(PYRO_EMU)
-                const size_t ko = (size_t)f * p + j;
-                Uout[ko] = Uw.d; Uout[pl + ko] = Uw.E; Uout[2 * pl + ko] = Uw.mx; Uout[3 * pl + ko] = Uw.my;
-#else
-                const unsigned offo = (unsigned)(f - rbase) * pitch8 + (unsigned)j * 8u;
-                *(double *)(sbase_out + offo) = Uw.d; *(double *)(sbase_out + plb + offo) = Uw.E;
-                *(double *)(sbase_out + 2 * plb + offo) = Uw.mx; *(double *)(sbase_out + 3 * plb + offo) = Uw.my;
-#endif
+                if (SPHW_DELAY) Upend = Uw;
+                else store_row(Uw, f);
                 if (FF) {
                     // running maximum of (|u| + c) / Lx, (|v| + c) / Ly: one reciprocal at the end
                     // (a ghost cell's lengths are its own: sphf_ghost_cfl keeps the quotient form)
@@ -528,6 +555,7 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
         fxa = fxb; fxb = fxn;
         Dp = Dn; up = um; vp = vm;
     }
+    if (SPHW_DELAY && i1 + 3 >= i0 + 4 && jout) store_row(Upend, i1 - 1);      // the update the last iteration made
     if (bad) atomicOr(flag, 1);
     double cflw = st[SS_CFL * 64];
     if (FF) { const double am = st[SS_AMAX * 64]; if (am > 0.0) cflw = fmin(cflw, prcp(am)); }
