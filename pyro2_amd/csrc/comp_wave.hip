@@ -488,6 +488,9 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     // window like in the method-of-lines instances.
 #if !defined(PYRO_WAVE_NO_DELAY)
     constexpr bool REBUILD = (PYRO_FAST != 0) && !MOL && !MAPS;     // (the emulated contracted build too)
+    // (the bit-faithful build must keep the second read -- rebuilding changes bits -- and has no eight
+    // registers for the waiting state: with the delayed stores it spills 76 instead of 28 B per lane,
+    // 15.7 -> 17.3 ms per step at 16384^2; the method-of-lines stages are fabric-bound: 2.13 -> 2.15 ms)
     constexpr bool DELAY = REBUILD && SADDR;
 #else
     constexpr bool REBUILD = false, DELAY = false;                   // (developer A/B)
