@@ -411,6 +411,9 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     auto loadU = [&](int row) {
         if (SADDR) {
             row = row < 0 ? 0 : (row > g.qx - 1 ? g.qx - 1 : row);
+#if defined(PYRO_WAVE_EXP_L2ROWS)      // (timing experiment, WRONG results: every strip re-reads its first 8 rows -- cache hits)
+            row = rbase + ((row - rbase) & 7);
+#endif
             const unsigned off = (unsigned)(row - rbase) * pitch8 + lane8;
             return Cons{*(const double *)(sbase_in + off), *(const double *)(sbase_in + plb + off),
                         *(const double *)(sbase_in + 2 * plb + off), *(const double *)(sbase_in + 3 * plb + off)};
