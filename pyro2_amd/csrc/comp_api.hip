@@ -351,7 +351,6 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
     bool first = true;
     int rc = 0;
     s->pend_part = nullptr;
-    static const bool merge_small = !getenv("PYRO_NO_MERGE_SMALL");     // (developer A/B)
     // steps after the first: the tile kernel applies the boundary rules itself where it can
     // (the first one needs filled ghost cells for the CFL minimum over the whole array)
     // (the spherical kernel reads every ghost cell through the boundary rules anyway)
@@ -409,7 +408,7 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
                 const Geom &g = s->g;
                 const int rows_per_block = 256 / (2 * g.ng);
                 const int nblk = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + rows_per_block - 1) / rows_per_block;
-                if (!first && merge_small) {
+                if (!first) {
                     // ... and the dt policy of this step in the same launch (k_fill_frame2_policy)
                     PYRO_LAUNCH(c, "k_fill_frame2_policy", k_fill_frame2_policy, dim3((nblk + 3) / 4 + 1),
                                 dim3(kPolicyThreads), 0, (const double *)s->d, s->d, s->alt_base + geom_lead(g), g,

@@ -936,7 +936,7 @@ int comp_step_fused_sph_ex(pyrohip_state *s, const pyrohip_comp_params *p, doubl
     const SphGeom &h = *s->sph;
     const SphG G{h.Lx, h.Ly, h.Ax, h.Ay, h.V, h.dlAx, h.dlAy, h.x2d, h.sint, h.sinb, h.sinc, h.xmin,
                  h.rowf, h.colf, (int)h.qxp, (int)h.qyp};
-    const int fac = (h.rowf && h.colf && !getenv("PYRO_SPH_PLANES")) ? 1 : 0;   // (PYRO_SPH_PLANES: developer A/B)
+    const int fac = (h.rowf && h.colf) ? 1 : 0;       // the caller handed the 1-d factors over
     const int nti = (g.nx + FTI - 1) / FTI;
     P.ntj = (g.ny + FTJ - 1) / FTJ;
     P.ntiles = nti * P.ntj;

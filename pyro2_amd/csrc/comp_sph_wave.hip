@@ -606,7 +606,7 @@ int comp_step_wave_sph_ex(pyrohip_state *s, const pyrohip_comp_params *p, double
     const SphGeom &h = *s->sph;
     const SphG G{h.Lx, h.Ly, h.Ax, h.Ay, h.V, h.dlAx, h.dlAy, h.x2d, h.sint, h.sinb, h.sinc, h.xmin,
                  h.rowf, h.colf, (int)h.qxp, (int)h.qyp};
-    const int fac = (h.rowf && h.colf && !getenv("PYRO_SPH_PLANES")) ? 1 : 0;
+    const int fac = (h.rowf && h.colf) ? 1 : 0;       // the caller handed the 1-d factors over
     const int cus = c->num_cus > 0 ? c->num_cus : 256;
     P.ncb = (g.ny + SWOUT - 1) / SWOUT;
     P.L = sphw_rows(g.nx, P.ncb, 8 * cus);

@@ -1070,30 +1070,6 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
 #endif
     const int solver = (p->riemann == 1 || p->riemann == 2) ? p->riemann : 0;
     const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
-    static const int slab_mode = getenv("PYRO_SLAB_MODE") ? atoi(getenv("PYRO_SLAB_MODE")) : 1;   // developer experiments
-    if (post && wg.overlap && slab_mode == 0) {
-        // round 5: the boundary strips first, the interior strips behind them on the same stream
-        P.sb_first = 0; P.sb_step = nsb - 1;
-        P.nunits = 2 * P.ncb;
-        P.prio_duty = wave_prio_duty(P.nunits, 4 * PYRO_WAVE_MINW * cus);
-        PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((P.nunits + 7) / 8)), dim3(64), WLDS_BYTES,
-                    (const double *)Uin, Uout, g, P, s->d_flag, part, S);
-        if (!s->frame_prefilled) fused_copy_frame(s);   // old ghost frame -> new buffer, BEFORE the halos land in it
-        s->frame_prefilled = false;
-        PYRO_TRY(comm_post_halo(s, Uout));
-        P.sb_first = 1; P.sb_step = 1;
-        P.nunits = (nsb - 2) * P.ncb;
-        P.prio_duty = wave_prio_duty(P.nunits, 4 * PYRO_WAVE_MINW * cus);
-        PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((P.nunits + 7) / 8)), dim3(64),
-                    WLDS_BYTES, (const double *)Uin, Uout, g, P, s->d_flag, part, S);
-        const double *dmin;
-        PYRO_TRY(fused_tail(s, part, nwg, true, &dmin, S != nullptr));
-        int rc = 0;
-        if (S) { fused_swap(s); *dmin_out = dmin; }
-        else rc = fused_sync(s, dmin);
-        s->halo_pending = (rc == 0);
-        return rc;
-    }
     if (post && wg.overlap) {
         // slab of a decomposed run: the first and the last strip of rows -- the
         // rows the neighbours need as their next halo -- are a launch of their own on the halo

@@ -814,8 +814,6 @@ static int sww_rows(int nx, int ncb, int cus)
 {
     const long slots = 8L * cus;
     if (nx <= 16) return nx;
-    static const int forced = getenv("PYRO_SWW_ROWS") ? atoi(getenv("PYRO_SWW_ROWS")) : 0;    // (developer sweep)
-    if (forced > 0) return forced < nx ? forced : nx;
     long best_cost = -1;
     int best = 16;
     for (int L = 16; L <= 160 && L <= nx; L++) {
@@ -874,8 +872,7 @@ int swe_step_wave(pyrohip_state *s, double dx, double dy, double grav, int limit
     if (nparts) *nparts = P.nunits;
     {
         // one round of resident wavefronts: the pair of a SIMD takes turns at the priority and ends together
-        static const int duty = getenv("PYRO_SWW_DUTY") ? atoi(getenv("PYRO_SWW_DUTY")) : 6;   // (developer sweep)
-        P.prio_duty = (P.nunits <= 8 * (c->num_cus > 0 ? c->num_cus : 256)) ? duty : 0;
+        P.prio_duty = (P.nunits <= 8 * (c->num_cus > 0 ? c->num_cus : 256)) ? 6 : 0;
     }
     double *Uout = s->alt_base + geom_lead(g);
     const dim3 grid(8 * ((P.nunits + 7) / 8)), block(64);
