@@ -787,16 +787,34 @@ int pyrohip_comp_rk_evolve(pyrohip_state *y, const pyrohip_comp_params *p, pyroh
             if (rc == 0) rc = exact::comp_rk_cfl_min_device(s, p, &dmin);
             if (rc) break;
         }
+        // steps after the first: the ghost frames of both buffers, the minimum of the last stage's
+        // CFL partials and the dt policy in ONE launch (k_fill_frame2_policy, round 6) -- they were
+        // k_fill_x + k_fill_y inside the step, k_copy_frame4, k_min_one and k_dt_policy: five
+        // launches, 30 us of a 0.64 ms step at 2048^2
+        s->frame_prefilled = false;
+        if (m > 0 && frame_fill_ok(s)) {
+            const Geom &g = s->g;
+            const int rows_per_block = 256 / (2 * g.ng);
+            const int nblk = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + rows_per_block - 1) / rows_per_block;
+            PYRO_LAUNCH(c, "k_fill_frame2_policy", k_fill_frame2_policy, dim3((nblk + 3) / 4 + 1),
+                        dim3(kPolicyThreads), 0, (const double *)s->d, s->d, s->alt_base + geom_lead(g), g,
+                        (const int *)s->d_bc, nblk, s->d_scal, dmin, (const int *)s->d_flag, s->d_dts, m,
+                        (const double *)s->pend_part, s->pend_n, const_cast<double *>(dmin));
+            s->frame_prefilled = true;
+        } else
         PYRO_LAUNCH(c, "k_dt_policy", k_dt_policy, dim3(1), dim3(kPolicyThreads), 0, s->d_scal, dmin,
-                    (const int *)s->d_flag, s->d_dts, m, 0, (const double *)nullptr, 0,
+                    (const int *)s->d_flag, s->d_dts, m, 0, (const double *)s->pend_part, s->pend_n,
                     const_cast<double *>(dmin), 1);
+        s->pend_part = nullptr;
         rc = p->fast_math ? fastm::comp_rk_step_wave(s, p, k, nstages, a, b, 0.0, s->d_scal, &dmin)
                           : exact::comp_rk_step_wave(s, p, k, nstages, a, b, 0.0, s->d_scal, &dmin);
     }
+    s->frame_prefilled = false;
     PYRO_TRY(rc);
     hipLaunchKernelGGL(k_dt_policy, dim3(1), dim3(kPolicyThreads), 0, c->stream, s->d_scal, dmin,
-                       (const int *)s->d_flag, s->d_dts, max_steps, 1, (const double *)nullptr, 0,
+                       (const int *)s->d_flag, s->d_dts, max_steps, 1, (const double *)s->pend_part, s->pend_n,
                        const_cast<double *>(dmin), 1);
+    s->pend_part = nullptr;
     PYRO_CHECK_HIP(hipGetLastError());
     char *hb = (char *)c->reduce_host;                       // 256 pinned bytes
     PYRO_CHECK_HIP(hipMemcpyAsync(hb, s->d_scal, sizeof(StepScalars), hipMemcpyDeviceToHost, c->stream));

@@ -1234,7 +1234,11 @@ int comp_rk_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, pyrohip_st
     const dim3 grid(8 * ((nwg + 7) / 8)), block(64);
     // stage 0: the state itself, ghost cells filled in memory (they stay the state's "stale"
     // ghost cells after the step, like the reference's), density floor in place
-    PYRO_TRY(pyrohip_fill_bc(s, -1));
+    // (a device-side run has filled the frames of both buffers with the launch of its dt policy:
+    // comp_api.hip: k_fill_frame2_policy)
+    const bool prefilled = s->frame_prefilled;
+    s->frame_prefilled = false;
+    if (!prefilled) PYRO_TRY(pyrohip_fill_bc(s, -1));
     PYRO_LAUNCH(c, "k_ctu_wave_mol", first[solver][std_rec], grid, block, WLDS_BYTES, (const double *)Uin,
                 kst->d, g, P, s->d_flag, part, S);
     P.mr = bc_map(g.ilo, g.ihi, g.ng, s->bc[0], s->bc[1], true);
@@ -1254,9 +1258,17 @@ int comp_rk_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, pyrohip_st
                     kst->d + (size_t)(4 * st) * g.plane, g, P, s->d_flag, part, S);
     }
     PYRO_CHECK_HIP(hipGetLastError());
-    fused_copy_frame(s);                  // ghost frame of the state -> the new buffer
-    const double *dmin = launch_min_reduce(c->stream, part, nwg);
+    if (!prefilled) fused_copy_frame(s);  // ghost frame of the state -> the new buffer
     s->cfl_is_global = false;
+    if (S && nwg <= 128 * kMinStageBlocks) {
+        // device-side run: the next policy launch takes the minimum of the partials itself (fused_tail)
+        s->pend_part = part;
+        s->pend_n = nwg;
+        fused_swap(s);
+        *dmin_out = part + nwg + kMinStageBlocks;
+        return 0;
+    }
+    const double *dmin = launch_min_reduce(c->stream, part, nwg);
     if (S) { fused_swap(s); *dmin_out = dmin; return 0; }
     const int rc = fused_sync(s, dmin);   // flag + minimum read back; swap if the state was valid
     if (rc == 0) s->cfl_kind = 1;         // (the minimum is compressible_rk's CFL quantity)
