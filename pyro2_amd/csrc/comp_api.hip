@@ -301,6 +301,25 @@ int restore_frame_after_inactive(pyrohip_state *s, int steps, int max_steps, boo
     return 0;
 }
 
+// both in ONE launch (k_fill_frame2_policy) where the frame fill is an index map; *merged = false and
+// nothing launched otherwise (the caller takes the two launches above)
+int launch_fill_frame2_policy(pyrohip_state *s, StepScalars *S, const double *cflmin, const int *flag, double *dts,
+                              int slot, const double *part, int nparts, double *minout, bool *merged)
+{
+    *merged = false;
+    if (!frame_fill_ok(s)) return 0;
+    pyrohip_ctx *c = s->ctx;
+    const Geom &g = s->g;
+    const int rows_per_block = 256 / (2 * g.ng);
+    const int nblk = 2 * g.ng * ((g.qy + 255) / 256) + (g.nx + rows_per_block - 1) / rows_per_block;
+    PYRO_LAUNCH(c, "k_fill_frame2_policy", k_fill_frame2_policy, dim3((nblk + 3) / 4 + 1), dim3(kPolicyThreads), 0,
+                (const double *)s->d, s->d, s->alt_base + geom_lead(g), g, (const int *)s->d_bc, nblk, S, cflmin,
+                flag, dts, slot, part, nparts, minout);
+    PYRO_CHECK_HIP(hipGetLastError());
+    *merged = true;
+    return 0;
+}
+
 int launch_dt_policy(pyrohip_ctx *c, StepScalars *S, const double *cflmin, const int *flag, double *dts,
                      int slot, int final_call, const double *part, int nparts, double *minout)
 {

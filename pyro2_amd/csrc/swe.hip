@@ -918,6 +918,8 @@ int swe_step_wave(pyrohip_state *, double, double, double, int, int, double, con
 int launch_fill_frame2(pyrohip_state *s, bool *done);
 int launch_dt_policy(pyrohip_ctx *c, StepScalars *S, const double *cflmin, const int *flag, double *dts,
                      int slot, int final_call, const double *part, int nparts, double *minout);
+int launch_fill_frame2_policy(pyrohip_state *s, StepScalars *S, const double *cflmin, const int *flag, double *dts,
+                              int slot, const double *part, int nparts, double *minout, bool *merged);
 int restore_frame_after_inactive(pyrohip_state *s, int steps, int max_steps, bool halo_ok, bool sph_ok);
 #endif
 }  // namespace pyro
@@ -1086,7 +1088,14 @@ int pyrohip_swe_evolve(pyrohip_state *s, double dx, double dy, double grav, int 
     const double *pend = nullptr;
     int npend = 0, rc = 0;
     for (int m = 0; m < max_steps && rc == 0; m++) {
-        bool frame_done = false;
+        bool frame_done = false, merged = false;
+        if (m > 0) {       // ghost frames of both buffers + the dt policy in one launch (comp_api.hip)
+            rc = launch_fill_frame2_policy(s, s->d_scal, dmin, s->d_flag, s->d_dts, m, pend, npend,
+                                           const_cast<double *>(dmin), &merged);
+            if (rc) break;
+            frame_done = merged;
+        }
+        if (!merged) {
         rc = launch_fill_frame2(s, &frame_done);          // pyro_sim.py:250: fill_BC_all
         if (rc) break;
         if (m == 0) {      // the CFL minimum of the state as handed over (whole array, filled)
@@ -1097,6 +1106,7 @@ int pyrohip_swe_evolve(pyrohip_state *s, double dx, double dy, double grav, int 
         rc = launch_dt_policy(c, s->d_scal, dmin, s->d_flag, s->d_dts, m, 0, pend, npend,
                               const_cast<double *>(dmin));
         if (rc) break;
+        }
         int np = 0;
         rc = fast_math ? swf::swe_step_wave(s, dx, dy, grav, limiter, riemann, 0.0, s->d_scal, part, &np, frame_done)
                        : swx::swe_step_wave(s, dx, dy, grav, limiter, riemann, 0.0, s->d_scal, part, &np, frame_done);
