@@ -1000,7 +1000,11 @@ static int wave_rows(int nx, int ncb, int slots)
 // together (see the kernel; measured at 4096^2, one round: 0.804 -> 0.736 ms, duty 4 / 5 / 6 /
 // 7 of 8: 0.777 / 0.764 / 0.736 / 0.744).  With many rounds the arbitration by age is the
 // better one (8192^2, 8.5 rounds: 2.66 ms against 2.70 with the priorities).
-static int wave_prio_duty(int nwaves, int slots) { return nwaves <= 2 * slots ? 6 : 0; }
+// (round 6, after the waits of a wavefront shrank: strips of 64 rows and more do better with seven
+// eighths -- 3072^2 0.389 -> 0.374 ms, 4096^2 0.639 -> 0.623 with 7, 0.651 with 8 --, the 38-row strips of
+// 2048^2 with six: 0.193 vs 0.195 / 0.201 with 5 / 7; the method-of-lines launches pass L = 0 and keep six:
+// an RK4 step at 4096^2 took 2.20 ms with seven against 2.13)
+static int wave_prio_duty(int nwaves, int slots, int L) { return nwaves <= 2 * slots ? (L >= 64 ? 7 : 6) : 0; }
 
 // the launch geometry of a step on an nx x ny slab: column strips, rows per strip, row strips
 // (a last strip shorter than the ghost width joins its predecessor: the boundary strips of a
@@ -1091,7 +1095,7 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         PYRO_TRY(comm_post_halo_here(s, Uout));
         P.sb_first = 1; P.sb_step = 1;
         P.nunits = (nsb - 2) * P.ncb;
-        P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus);
+        P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus, P.L);
         PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((P.nunits + 7) / 8)), dim3(64),
                     WLDS_BYTES, (const double *)Uin, Uout, g, P, s->d_flag, part, S);
         PYRO_TRY(comm_join_boundary(s));       // the minimum below reads the boundary strips' partials
@@ -1104,7 +1108,7 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         return rc;
     }
     P.nunits = nwg;
-    P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus);
+    P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus, P.L);
     if (S && s->pol_next && !post) {
         // this launch is the whole step (pyrohip_comp_evolve): ghost cells read through the
         // boundary rules, the dt policy of the next step run by the last wavefront to finish
@@ -1176,7 +1180,7 @@ int comp_rk_rhs_wave(pyrohip_state *s, const pyrohip_comp_params *p, pyrohip_sta
     const int solver = (p->riemann == 1 || p->riemann == 2) ? p->riemann : 0;
     const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
     P.nunits = nwg;
-    P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus);
+    P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus, 0);
     PYRO_LAUNCH(c, "k_ctu_wave_mol", kernels[solver][std_rec], dim3(8 * ((nwg + 7) / 8)), dim3(64), WLDS_BYTES,
                 (const double *)Uin, Uout, g, P, s->d_flag, (double *)c->reduce.p, nullptr);
     PYRO_CHECK_HIP(hipGetLastError());
@@ -1230,7 +1234,7 @@ int comp_rk_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, pyrohip_st
     const int solver = (p->riemann == 1 || p->riemann == 2) ? p->riemann : 0;
     const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
     P.nunits = nwg;
-    P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus);
+    P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus, 0);
     const dim3 grid(8 * ((nwg + 7) / 8)), block(64);
     // stage 0: the state itself, ghost cells filled in memory (they stay the state's "stale"
     // ghost cells after the step, like the reference's), density floor in place
