@@ -301,7 +301,7 @@ def bench_sedov(args, dist, ctx, device, defaults, steps=None, warmup=None, tile
         from host_comm import HostStagedComm      # tests/host_comm.py: the debug transport, asked for by name
         comm = HostStagedComm(dist.td)
     kw = dict(dx=1.0 / nx, dy=1.0 / ny, fast_math=defaults["fast_math"],
-              kernel_set=defaults["kernel_set"])
+              kernel_set=defaults["kernel_set"], march_rows=getattr(args, "march_rows", 0))
     slab = SlabCompressible(ctx, dec, ny, ["outflow"] * 4, kw, comm, ng=ng)
     st = slab.state
     # initial condition: generated slab by slab on the host (never more than a few

@@ -70,6 +70,16 @@ static bool wave_kernel_pays(const Geom &g)
 {
     return (double)g.nx * (double)g.ny >= 2048.0 * 2048.0;
 }
+// ... the Cartesian CTU step of the contracted build from 1024^2 cells on (round 6: with strips short
+// enough for ONE round of resident wavefronts -- wave_rows down to 8 rows -- the row-marching kernel
+// passes the tile kernel there: 1024^2 78.3 -> 71.0 us per step, 1152^2 90.9 -> 78.4, 1536^2 148.6 -> 136.6,
+// 1792^2 190.4 -> 155.7; 896^2 a tie, below it and in the bit-faithful build the tile kernel stays ahead
+// up to 2048^2: 1024^2 104.8 vs 114.6 us, 1536^2 203.5 vs 226.9)
+static bool wave_kernel_pays_ctu(const Geom &g, const pyrohip_comp_params *p)
+{
+    const double cells = (double)g.nx * (double)g.ny;
+    return cells >= (p->fast_math ? 1024.0 * 1024.0 : 2048.0 * 2048.0) && g.nx >= 512 && g.ny >= 512;
+}
 
 // May the tile kernel read the ghost cells through the boundary rules instead of from
 // memory (pyrohip_comp_params.fuse_fill)?  Index maps exist for outflow / reflect /
@@ -363,7 +373,7 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));      // H is on this stack frame
     PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
     const bool wave = !sphf && ((p->kernel_set == 2) ||
-                                (p->kernel_set == -1 && wave_kernel_pays(s->g)));
+                                (p->kernel_set == -1 && wave_kernel_pays_ctu(s->g, p)));
     // SphericalPolar grid on the row-marching kernel (comp_sph_wave.hip: reads a filled frame)
     const bool sphw = sphf && ((p->kernel_set == 2) || (p->kernel_set == -1 && wave_kernel_pays(s->g)));
     const double *dmin = nullptr;
@@ -614,7 +624,7 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
         // ghost cells not filled by the caller: folded into the tile kernel where that
         // works, the ordinary fill first everywhere else
         // (the spherical one-launch kernel reads every ghost cell through the boundary rules)
-        const bool wave = !s->sph && (p->kernel_set == 2 || (p->kernel_set == -1 && wave_kernel_pays(s->g)));
+        const bool wave = !s->sph && (p->kernel_set == 2 || (p->kernel_set == -1 && wave_kernel_pays_ctu(s->g, p)));
         if (!comp_can_fuse_fill(s, p, wave) && !comp_can_fuse_sph(s, p)) {
             PYRO_TRY(pyrohip_fill_bc(s, -1));
             pf.fuse_fill = 0;
@@ -646,7 +656,7 @@ int pyrohip_comp_step(pyrohip_state *s, const pyrohip_comp_params *p, double dt)
         PYRO_REQUIRE(!s->heat && !s->ramp_bc, "a host-evaluated source excludes the heating "
                      "profile and the ramp boundary (which zeroes the source arrays, BC.py:198-200)");
         return p->fast_math ? fastm::comp_step_staged(s, p, dt) : exact::comp_step_staged(s, p, dt);
-    } else if (p->kernel_set == 2 || (p->kernel_set == -1 && wave_kernel_pays(s->g)))
+    } else if (p->kernel_set == 2 || (p->kernel_set == -1 && wave_kernel_pays_ctu(s->g, p)))
         rc = p->fast_math ? fastm::comp_step_wave(s, p, dt) : exact::comp_step_wave(s, p, dt);
     else if (p->kernel_set == 1 || p->kernel_set == -1)
         rc = p->fast_math ? fastm::comp_step_fused(s, p, dt) : exact::comp_step_fused(s, p, dt);

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
 #else
     constexpr bool SADDR = false;
 #endif
-    const int rbase = (i0 - 7 > 0) ? i0 - 7 : 0;           // first row the strip touches
+    const int rbase = (i0 - 8 > 0) ? i0 - 8 : 0;           // first row the strip touches (k - 4 of its first iteration)
     const char *const sbase_in = (const char *)(Uin + (size_t)rbase * p);
     char *const sbase_out = (char *)(Uout + (size_t)rbase * p);
     const unsigned pitch8 = (unsigned)p * 8u, lane8 = (unsigned)jc * 8u;
@@ -486,11 +486,15 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     // the end of the iteration, the wait for the prefetched row at the top of the next one also waited
     // for the stores issued just before (they are conditional, the compiler must assume none is younger
     // than the loads: s_waitcnt vmcnt(0)) -- a fifth of a wavefront's cycles (SQ_WAIT_INST_ANY 55 k of 255 k
-    // per wavefront, SQ_WAIT_INST_LDS 3 k: profiles/r06_default16384_fm1_pmc.json).  The new state waits in the
-    // registers the second read of the old state used to occupy: that one is rebuilt from the primitive
-    // window like in the method-of-lines instances.
+    // per wavefront, SQ_WAIT_INST_LDS 3 k: profiles/r06_default16384_fm1_pmc.json).  The new state waits in
+    // registers.  To make room, the old states of rows k-3 / k-4 that feed the artificial-viscosity fluxes
+    // are rebuilt from the primitive window (conservative either way: a flux); the old state the UPDATE
+    // starts from is NOT -- the first version rebuilt that one too, and a conserved state that goes through
+    // u = m / rho, p = (gamma - 1)(E - ...) and back every step drifts: the developed 1024^2 blast (2333 steps)
+    // was 1.1e-9 from the oracle instead of 4e-11.  It is read a second time as before (a cache hit), requested
+    // behind the delayed stores at the top of the iteration whose end consumes it (Ucx).
 #if !defined(PYRO_WAVE_NO_DELAY)
-    constexpr bool REBUILD = (PYRO_FAST != 0) && !MOL && !MAPS;     // (the emulated contracted build too)
+    constexpr bool REBUILD = (PYRO_FAST != 0) && !MOL && !MAPS && SADDR;   // (viscosity operands only; GPU build)
     // (the bit-faithful build must keep the second read -- rebuilding changes bits -- and has no eight
     // registers for the waiting state: with the delayed stores it spills 76 instead of 28 B per lane,
     // 15.7 -> 17.3 ms per step at 16384^2; the method-of-lines stages are fabric-bound: 2.13 -> 2.15 ms)
@@ -503,6 +507,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     Cons Krep = NOREP ? Cons{0.0, 0.0, 0.0, 0.0} : loadK(i0 - 7);
     bool bad = false;
     Cons Upend{0.0, 0.0, 0.0, 0.0};        // DELAY: the new state of row k-5, stored at the top of iteration k
+    Cons Ucx{1.0, 1.0, 0.0, 0.0};          // DELAY: the old state of row k-4 (second read), for the update
     // ... and in the stash: uncorrected YM, YP, XP, FxT, corrected XP and Fx of row k-4
     {
         const Cons one{1.0, 1.0, 0.0, 0.0};
@@ -538,6 +543,9 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         for (int n = 0; n < 4; n++) {
             wr[n] = wr[n + 1]; wu[n] = wu[n + 1]; wv[n] = wv[n + 1]; wp[n] = wp[n + 1];
         }
+        if (DELAY)     // (row k-4 = window index 0 after the shift: rebuilt, not carried -- eight registers)
+            Uem = prim_to_cons_g(Prim{wr[0], wu[0], wv[0], wp[0]}, US2(GM1, P.gm1), US2(RGM1, P.rgm1));
+        else
         Uem = Ue;
         if (NOREP) {
             // (window index 1 = row k-3 after the shift above; floor and signs are in the primitives)
@@ -583,6 +591,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                     *(double *)(sbase_out + off) = Upend.d; *(double *)(sbase_out + plb + off) = Upend.E;
                     *(double *)(sbase_out + 2 * plb + off) = Upend.mx; *(double *)(sbase_out + 3 * plb + off) = Upend.my;
                 }
+                Ucx = loadU(k - 4);                 // (in front of the next row's request: its wait leaves that one out)
                 Upre = loadU(k + 1);
                 STAGE_FENCE();
             }
@@ -783,11 +792,14 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 }
                 Fy = from_nf(riemann_face<SOLVER>(to_nf(lane_m1(YPc), false), to_nf(YMc, false),
                                                   UC_GASK(), false, P.solid_yl && j == g.jlo), false);
-                const Cons Umy = lane_m1(Uem);
-                Fy.d += avy * (Umy.d - Uem.d);
-                Fy.E += avy * (Umy.E - Uem.E);
-                Fy.mx += avy * (Umy.mx - Uem.mx);
-                Fy.my += avy * (Umy.my - Uem.my);
+                // (DELAY: the exact old state of the row, read a second time -- not the rebuilt one)
+                Cons Uv = Uem;
+                if (DELAY) { Uv = Ucx; if (jin) Uv.d = fmax(Uv.d, US2(SMALLD, P.small_dens)); }
+                const Cons Umy = lane_m1(Uv);
+                Fy.d += avy * (Umy.d - Uv.d);
+                Fy.E += avy * (Umy.E - Uv.E);
+                Fy.mx += avy * (Umy.mx - Uv.mx);
+                Fy.my += avy * (Umy.my - Uv.my);
                 Fyh = lane_p1(Fy);
             }
             if (!MOL && xface) st_put(st, ST_FXT, FxTn);
@@ -848,17 +860,21 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             if (xface) {
                 Fxn = from_nf(riemann_face<SOLVER>(to_nf(st_get(st, ST_XPC), true), to_nf(XMc, true),
                                                    UC_GASK(), true, P.solid_xl && i == g.ilo), true);
-                Fxn.d += avx * (Uem.d - Ue.d);
-                Fxn.E += avx * (Uem.E - Ue.E);
-                Fxn.mx += avx * (Uem.mx - Ue.mx);
-                Fxn.my += avx * (Uem.my - Ue.my);
+                Cons Uxm = Uem;
+                if (DELAY) { Uxm = Ucx; if (jin && row_in(i - 1)) Uxm.d = fmax(Uxm.d, US2(SMALLD, P.small_dens)); }
+                Fxn.d += avx * (Uxm.d - Ue.d);
+                Fxn.E += avx * (Uxm.E - Ue.E);
+                Fxn.mx += avx * (Uxm.mx - Ue.mx);
+                Fxn.my += avx * (Uxm.my - Ue.my);
             }
             st_put(st, ST_XPC, XPc);
             STAGE_FENCE();
             // -- conservative update of row f + CFL of the new state
             if (frow && jout) {
                 const Cons Fxp = st_get(st, ST_FX);
-                const Cons &Uc = Uem;
+                Cons Ucd = Ucx;
+                Ucd.d = fmax(Ucd.d, US2(SMALLD, P.small_dens));      // clean_state (the rows updated are interior rows)
+                const Cons &Uc = DELAY ? Ucd : Uem;
                 Cons Un;   // simulation.py:377-384
                 if (MOL) {
                     // compressible_rk/simulation.py:16-42 (k_rk_rhs): k = (Fx[i] - Fx[i+1])/dx +
