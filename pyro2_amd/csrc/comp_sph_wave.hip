@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
 
     // the rows of a strip as [scalar base of the strip's first row, per plane] + [32-bit byte offset]
     // (saddr form of the loads / stores: comp_wave.hip)
-    const int rbase = (i0 - 7 > 0) ? i0 - 7 : 0;
+    const int rbase = (i0 - 8 > 0) ? i0 - 8 : 0;
     const char *const sbase_in = (const char *)(Uin + (size_t)rbase * p);
     char *const sbase_out = (char *)(Uout + (size_t)rbase * p);
     const unsigned pitch8 = (unsigned)p * 8u, lane8 = (unsigned)jc * 8u;
@@ -199,7 +199,10 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
     double Dp = 0.0, up = 0.0, vp = 0.0;                       // vertex div(U) of row k-4; u, v at (k-4, j-1)
     // SPHW_DELAY (contracted build on the GPU; comp_wave.hip has the measurement): the stores of a row's
     // update at the top of the next iteration -- behind the consumption of the arrived row, in front of
-    // the next request --, the old state rebuilt from the primitive window instead of read a second time
+    // the next request.  The old state of row k-4 (update, viscosity of its row) is still read a second
+    // time -- requested behind the delayed stores --: rebuilt from the primitives every step a conserved
+    // state drifts (comp_wave.hip); only row k-3's (source terms on the face states, the other operand of
+    // the x viscosity flux) is rebuilt
 #if PYRO_FAST && !defined(PYRO_EMU) && !defined(PYRO_SPHW_NO_DELAY)
     constexpr bool SPHW_DELAY = true;
 #else
@@ -207,6 +210,7 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
 #endif
     Cons Upre = loadU(i0 - 4), Urep = SPHW_DELAY ? Cons{1.0, 1.0, 0.0, 0.0} : loadU(i0 - 7);
     Cons Upend{0.0, 0.0, 0.0, 0.0};
+    Cons Ucx{1.0, 1.0, 0.0, 0.0};          // SPHW_DELAY: the old state of row k-4, read a second time
     auto store_row = [&](const Cons &V, int row) {
 #if defined(PYRO_EMU)
         const size_t ko = (size_t)row * p + j;
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
 #endif
 #pragma unroll
         for (int n = 0; n < 4; n++) { wr[n] = wr[n + 1]; wu[n] = wu[n + 1]; wv[n] = wv[n + 1]; wp[n] = wp[n + 1]; }
-        Uem = Ue;
+        if (!SPHW_DELAY) Uem = Ue;
         if (SPHW_DELAY) {
             // (window index 1 = row k-3 after the shift above; the floor is in the primitives)
             Ue = prim_to_cons(Prim{wr[1], wu[1], wv[1], wp[1]}, gamma);
@@ -268,6 +272,7 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
 #endif
                 SPHW_FENCE();
                 if (k - 1 >= i0 + 4 && jout) store_row(Upend, k - 5);      // the update iteration k-1 made
+                Ucx = loadU(k - 4);                 // (in front of the next row's request: its wait leaves that one out)
                 Upre = loadU(k + 1);
                 SPHW_FENCE();
             }
@@ -292,6 +297,12 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
         double Dn = 0.0, um = 0.0, vm = 0.0;
         if (k >= i0 + 2) {
             const int i = k - 3;                       // row c: slopes, states, x flux; row f = i - 1: y flux, update
+            // SPHW_DELAY: the old state of row f as read a second time, with the density floor of clean_state
+            auto old_f = [&]() {
+                Cons U = Ucx;
+                if (row_in(i - 1) && jin) U.d = fmax(U.d, P.small_dens);
+                return U;
+            };
             const int ipc = (i + 1 < g.qx) ? i + 1 : i;
             const bool xface = (k >= i0 + 3);          // row c has a lower x face in the strip
             const bool frow = (k >= i0 + 4);           // row f is updated by this strip
@@ -440,6 +451,7 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
                 Cons YPc = sphf_corrected(sget(st, SS_YP), FxTn, Ahi, FxTp, Alo, overV(hdt, -1, true));
                 YPc.mx += overLx(-hdt * dpx);
                 Fy = sphf_face(lm1(YPc), YMc, gamma, false, P.solid_yl && j == g.jlo, py);
+                if (SPHW_DELAY) Uem = old_f();
                 const Cons Umy = lm1(Uem);
                 Fy.d += avy * (Umy.d - Uem.d);
                 Fy.E += avy * (Umy.E - Uem.E);
@@ -487,6 +499,7 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
             double pxn = 0.0;
             if (xface) {
                 Fxn = sphf_face(sget(st, SS_XPC), XMc, gamma, true, P.solid_xl && i == g.ilo, pxn);
+                if (SPHW_DELAY) Uem = old_f();
                 Fxn.d += avx * (Uem.d - Ue.d);
                 Fxn.E += avx * (Uem.E - Ue.E);
                 Fxn.mx += avx * (Uem.mx - Ue.mx);
@@ -503,6 +516,7 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
                 const double dtdV = overV(dt, -1, false);
                 const double Ax0 = gAx(-1), Ax1 = gAx(0), Ay0 = gAy(-1, false), Ay1 = gAy(-1, true);
                 double Un[4];
+                if (SPHW_DELAY) Uem = old_f();
                 const double Uo[4] = {Uem.d, Uem.E, Uem.mx, Uem.my};
                 Un[0] = Uo[0] + dtdV * (Fxp.d * Ax0 - Fxn.d * Ax1 + Fy.d * Ay0 - Fyh.d * Ay1);
                 Un[1] = Uo[1] + dtdV * (Fxp.E * Ax0 - Fxn.E * Ax1 + Fy.E * Ay0 - Fyh.E * Ay1);

@@ -655,8 +655,9 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
     // SWW_DELAY (contracted build on the GPU, round 6; comp_wave.hip has the measurement): the stores of a
     // row's update are issued at the top of the NEXT iteration, behind the consumption of the row that
     // arrived and in front of the next request -- loads and stores share vmcnt and complete in order, the
-    // wait for the prefetched row included the stores issued just before it.  The new state waits in the
-    // registers of the old state's second read, which is rebuilt from the primitive window (h, u, v, X).
+    // wait for the prefetched row included the stores issued just before it.  The old state the update
+    // starts from is still read a second time (rebuilt from the primitives every step a conserved state
+    // drifts: comp_wave.hip), requested behind the delayed stores at the top of the iteration that consumes it.
 #if PYRO_FAST && !defined(PYRO_EMU) && !defined(PYRO_SWW_NO_DELAY)
     constexpr bool SWW_DELAY = true;
 #else
@@ -696,9 +697,8 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
             for (int n = 0; n < 4; n++) q[r][n] = q[r + 1][n];
         }
         const V4 Uk = Upre;                  // row k
-        V4 Uold = Urep;                      // row k-3 (window row 1 after the shift above)
-        if (SWW_DELAY) Uold = sw_prim_to_cons(q[1]);
-        else {
+        V4 Uold = Urep;                      // row k-3: requested an iteration ago (or, SWW_DELAY, below)
+        if (!SWW_DELAY) {
         Upre = loadU(k + 1);
         Urep = loadU(k - 2);
         }
@@ -712,6 +712,7 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
 #endif
             SWW_FENCE();
             if (k - 1 - 2 >= i0 + 1 && jout) store_row(Upend, k - 4);      // the update iteration k-1 made (row c-1 = k-4)
+            Uold = loadU(k - 3);                 // (in front of the next row's request: its wait leaves that one out)
             Upre = loadU(k + 1);
             SWW_FENCE();
         }
