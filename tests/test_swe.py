@@ -276,3 +276,38 @@ def test_swe_evolve_refuses_boundaries_the_step_kernel_minimum_does_not_cover(de
     s.upload(_swe_random_state(nx, ny, 1))
     with pytest.raises(PyroHipError, match="outflow / reflect / periodic"):
         s.swe_evolve(1.0 / nx, 1.0 / ny, 1.0, 1, "Roe", 0.8, DtPolicy(1.0), 2)
+
+
+@pytest.mark.gpu
+def test_swe_contracted_build_long_run(hip):
+    """1200 steps of a smooth periodic flow, contracted against bit-faithful build of the one-launch
+    kernel: what a per-step rounding difference may grow to.  (Round 6: a version of the contracted
+    kernels rebuilt the old state the update starts from out of the primitive variables instead of
+    reading it a second time -- a conserved state that goes through u = m / h and back every step
+    drifts; the compressible twin of this test, test_comp_sedov_developed_vs_oracle, caught that one
+    at 1.1e-9.)"""
+    nx = ny = 256
+    ng = 4
+    x = (np.arange(nx + 2 * ng) - ng + 0.5) / nx
+    X, Y = np.meshgrid(x, x, indexing="ij")
+    U0 = np.zeros((nx + 2 * ng, ny + 2 * ng, 4))
+    U0[..., 0] = 1.0 + 0.2 * np.sin(2 * np.pi * X) * np.cos(4 * np.pi * Y)
+    U0[..., 1] = U0[..., 0] * 0.3 * np.cos(2 * np.pi * Y)
+    U0[..., 2] = U0[..., 0] * 0.2 * np.sin(4 * np.pi * X)
+    U0[..., 3] = U0[..., 0] * (0.5 + 0.5 * np.sin(2 * np.pi * (X + Y)))
+    bcs = [["periodic"] * 4] * 4
+    dx, dy, grav = 1.0 / nx, 1.0 / ny, 1.0
+    out = {}
+    for fast in (0, 1):
+        s = device.DeviceState(hip, nx, ny, ng, bcs)
+        s.upload(U0)
+        for _ in range(1200):
+            s.fill_bc()
+            s.swe_step(dx, dy, grav, 2, "Roe", 0.2 * dx, kernel_set=1, fast_math=fast)
+        out[fast] = s.download()[ng:-ng, ng:-ng]
+    a, b = out[1], out[0]
+    assert np.isfinite(b).all() and np.abs(b - U0[ng:-ng, ng:-ng]).max() > 1e-2
+    floor = np.array([1.0, 0.1, 0.1, 0.1])
+    err = (np.abs(a - b) / (np.abs(b) + floor)).max()
+    print("swe long run: contracted vs bit-faithful", err)
+    assert err <= 1e-10, err
