@@ -994,10 +994,12 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
 // (4096^2: 74 x 27 strips of 152 rows).
 static int wave_rows(int nx, int ncb, int slots)
 {
+    // (round 6: strips down to 8 rows -- grids of 1024^2 ... 1792^2 cells fill the slots with ONE round of
+    // 10- to 28-row strips and pass the tile kernel that way: comp_api.hip: wave_kernel_pays_ctu)
     if (nx <= 32) return nx;
     long best_cost = -1;
     int best = 32;
-    for (int L = 32; L <= 160 && L <= nx; L++) {
+    for (int L = 8; L <= 160 && L <= nx; L++) {
         int nsb = (nx + L - 1) / L;
         if (nsb > 1 && nx - (nsb - 1) * L < 4) nsb--;        // short last strip joins its predecessor
         const int Leff = (nx + nsb - 1) / nsb;                // longest strip
