@@ -177,6 +177,10 @@ struct SphGeom {
     const double *rowf = nullptr, *colf = nullptr;
     size_t qxp = 0, qyp = 0;
 };
+// row factors on the device: kSphRowStride doubles per ROW (the nine factors of a row side by side, 128-byte
+// rows: a wavefront fetches a row's factors with one or two wide scalar loads instead of one load --
+// and one wait -- per factor); column factors stay one array per factor (stride qyp: per-lane reads)
+constexpr int kSphRowStride = 16;
 }  // namespace pyro
 
 namespace pyro {

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
     // (measured and dropped: a sliding window of the three rows' factors in scalar registers, the
     // next row's requested an iteration ahead -- the kernel is out of scalar registers, the window
     // went to vector lanes (v_writelane / v_readlane 116 -> 180 per row) and the step took the same time)
-    auto RF = [&](int kf, int r) { return rowf_c[kf * G.qxp + pyro_uniform(r)]; };
+    auto RF = [&](int kf, int r) { return rowf_c[pyro_uniform(r) * kSphRowStride + kf]; };
     const double cE = -2.0 * 3.14159265358979323846 / 3.0;     // E = (-2 pi / 3) B (mesh/patch.py: device_geometry)
     const double hdt = 0.5 * dt;
     const double dtdx = pdiv(dt, P.dx);                    // dt / Lx: Lx = dr everywhere (patch.py:262)

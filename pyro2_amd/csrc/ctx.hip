@@ -780,7 +780,7 @@ int pyrohip_state_set_geometry(pyrohip_state *s, const pyrohip_geom *hg)
     SphGeom *G = new SphGeom();
     const bool fac = hg->rowf && hg->colf;
     // (+ reciprocals the contracted builds multiply by: rows 1 / Ly, 1 / (F G); columns 1 / |E|, 1 / T)
-    const size_t n = 8 * g.plane + 3 * qyp + 16 + (fac ? 9 * qxp + 6 * qyp : 0);
+    const size_t n = 8 * g.plane + 3 * qyp + 16 + (fac ? (size_t)pyro::kSphRowStride * qxp + 6 * qyp : 0);
     PYRO_CHECK_HIP(hipMalloc((void **)&G->base, n * sizeof(double)));
     PYRO_CHECK_HIP(hipMemsetAsync(G->base, 0, n * sizeof(double), c->stream));
     double *planes = G->base + geom_lead(g);
@@ -794,15 +794,16 @@ int pyrohip_state_set_geometry(pyrohip_state *s, const pyrohip_geom *hg)
         PYRO_CHECK_HIP(hipMemcpyAsync(sines + k * qyp, ssrc[k], g.qy * sizeof(double),
                                       hipMemcpyHostToDevice, c->stream));
     if (fac) {
-        double *rf = G->base + 8 * g.plane + 3 * qyp + 16, *cf = rf + 9 * qxp;
-        std::vector<double> hr(9 * qxp, 0.0), hc(6 * qyp, 0.0);
+        constexpr size_t RS = pyro::kSphRowStride;
+        double *rf = G->base + 8 * g.plane + 3 * qyp + 16, *cf = rf + RS * qxp;
+        std::vector<double> hr(RS * qxp, 0.0), hc(6 * qyp, 0.0);
         for (int k = 0; k < 7; k++)
-            for (int i = 0; i < g.qx; i++) hr[k * qxp + i] = hg->rowf[(size_t)k * g.qx + i];
+            for (int i = 0; i < g.qx; i++) hr[(size_t)i * RS + k] = hg->rowf[(size_t)k * g.qx + i];
         for (int k = 0; k < 4; k++)
             for (int j = 0; j < g.qy; j++) hc[k * qyp + j] = hg->colf[(size_t)k * g.qy + j];
         for (int i = 0; i < g.qx; i++) {
-            hr[7 * qxp + i] = 1.0 / hr[4 * qxp + i];                            // 1 / Ly
-            hr[8 * qxp + i] = 1.0 / (hr[2 * qxp + i] * hr[3 * qxp + i]);        // 1 / (F G)
+            hr[(size_t)i * RS + 7] = 1.0 / hr[(size_t)i * RS + 4];                                   // 1 / Ly
+            hr[(size_t)i * RS + 8] = 1.0 / (hr[(size_t)i * RS + 2] * hr[(size_t)i * RS + 3]);       // 1 / (F G)
         }
         for (int j = 0; j < g.qy; j++) {
             hc[4 * qyp + j] = 1.0 / fabs(hc[2 * qyp + j]);                      // 1 / |E|

@@ -7,7 +7,7 @@ struct SphG {   // kernel-side geometry (pyrohip_state_set_geometry)
     const double *Lx, *Ly, *Ax, *Ay, *V, *dlAx, *dlAy, *x2d, *sint, *sinb, *sinc;
     double xmin;
     // FAC instance (round 6): the geometry rebuilt from its 1-d factors -- rowf: A D F G Ly dlogAx x
-    // (stride qxp), colf: B C E T (stride qyp) -- with the bits of the planes (include/pyrohip.h:
+    // (kSphRowStride doubles per row, common.h), colf: B C E T (stride qyp) -- with the bits of the planes (include/pyrohip.h:
     // pyrohip_geom; mesh/patch.py checks the factorisation when it hands the tables over).  The
     // plane-reading instance moved 312 B of fabric traffic per cell update for 64 algorithmic ones
     // (profiles/r05_sph2048_pmc.json): eight planes, most of them read for two or three cells.
@@ -17,7 +17,7 @@ struct SphG {   // kernel-side geometry (pyrohip_state_set_geometry)
 // value of a geometry array at (row r, column c) -- FAC: from the factors
 template <bool FAC> struct SphAt {
     const SphG &G; int p; double dx;
-    __device__ __forceinline__ double rf(int k, int r) const { return G.rowf[k * G.qxp + r]; }
+    __device__ __forceinline__ double rf(int k, int r) const { return G.rowf[r * kSphRowStride + k]; }
     __device__ __forceinline__ double cf(int k, int c) const { return G.colf[k * G.qyp + c]; }
     __device__ __forceinline__ double Lx(int r, int c) const { return FAC ? dx : G.Lx[(size_t)r * p + c]; }
     __device__ __forceinline__ double Ly(int r, int c) const { return FAC ? rf(4, r) : G.Ly[(size_t)r * p + c]; }
