@@ -239,7 +239,8 @@ __device__ __forceinline__ void st_put(double *st, int s, const Cons &U)
 // SRC = false: an instance without the source-term blocks (gravity, heating) for runs that have none --
 // skipped at run time they still cost registers whose pending loads force a full vmcnt wait where their
 // paths join the row's work: 31.7 -> 32.3 Gcell/s at 16384^2 (round 6)
-template <int SOLVER, bool STD, bool MOL = false, bool ONE = false, bool RKF = false, bool SRC = true>   // SOLVER, STD as k_ctu_fused
+template <int SOLVER, bool STD, bool MOL = false, bool ONE = false, bool RKF = false, bool SRC = true,
+          int FINT = -1>   // SOLVER, STD as k_ctu_fused
 __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *__restrict__ Uin,
                                                                  double *__restrict__ Uout, Geom g,
                                                                  FP P, int *__restrict__ flag,
@@ -249,6 +250,10 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     HIP_DYNAMIC_SHARED(double, lds)
     static_assert(!RKF || (MOL && !ONE), "the folded Runge-Kutta stage is a method-of-lines launch");
     constexpr bool MAPS = ONE || RKF;      // ghost cells are read through the boundary rules
+    // FINT: the last stage (final update instead of the k store) known to the compiler: 1 / 0; -1 = P.rk_final.
+    // One instance for both carried the last stage's operands through the others' rows (255 registers, 44 B of
+    // scratch per lane in the contracted build)
+    const bool rk_final = RKF && (FINT < 0 ? P.rk_final != 0 : FINT == 1);
     const int l = threadIdx.x;
     double *st = lds + l;
     // workgroup -> (column strip, row strip): workgroups are dealt round-robin to the 8 XCDs
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             // (below), the sum waits in the stash slots the method of lines leaves free (ST_FXT).
             // Loaded where they are used, at the end of the iteration, the wavefront stood still
             // for them: the last stage took 1.22 ms against 0.50 for the others.
-            const bool yfin = RKF && (PYRO_FAST != 0) && P.rk_final && frow && jout;
+            const bool yfin = RKF && (PYRO_FAST != 0) && rk_final && frow && jout;
             Cons Yf0{0.0, 0.0, 0.0, 0.0}, Yf1 = Yf0, Yf2 = Yf0, Yf3 = Yf0;
             if (yfin) {
                 const size_t kr = (size_t)(i - 1) * p + j;
@@ -889,7 +894,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                     Un.E = Un.E + (Uc.my * UC(GRAV) + Uc.d * UC(HEATR) * (P.heat ? P.heat[kr] : 0.0));
                     Un.mx = Un.mx + 0.0;
                     Un.my = Un.my + Uc.d * UC(GRAV);
-                    if (RKF && P.rk_final) {
+                    if (RKF && rk_final) {
                         // integration.py:120-129: y_0 += dt b_s k_s, s = 0 ... -- the earlier
                         // increments from memory, the last one is Un; then the CFL quantity of
                         // compressible_rk/simulation.py:46-56 on the new state
@@ -1245,10 +1250,22 @@ int comp_rk_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, pyrohip_st
         {k_ctu_wave<0, false, true>, k_ctu_wave<0, true, true>},
         {k_ctu_wave<1, false, true>, k_ctu_wave<1, true, true>},
         {k_ctu_wave<2, false, true>, k_ctu_wave<2, true, true>}};
-    static const KernelT later[3][2] = {
+#if PYRO_FAST && !defined(PYRO_EMU) && !defined(PYRO_RK_ONE_INSTANCE)
+    static const KernelT later_mid[3][2] = {
+        {k_ctu_wave<0, false, true, false, true, true, 0>, k_ctu_wave<0, true, true, false, true, true, 0>},
+        {k_ctu_wave<1, false, true, false, true, true, 0>, k_ctu_wave<1, true, true, false, true, true, 0>},
+        {k_ctu_wave<2, false, true, false, true, true, 0>, k_ctu_wave<2, true, true, false, true, true, 0>}};
+    static const KernelT later_fin[3][2] = {
+        {k_ctu_wave<0, false, true, false, true, true, 1>, k_ctu_wave<0, true, true, false, true, true, 1>},
+        {k_ctu_wave<1, false, true, false, true, true, 1>, k_ctu_wave<1, true, true, false, true, true, 1>},
+        {k_ctu_wave<2, false, true, false, true, true, 1>, k_ctu_wave<2, true, true, false, true, true, 1>}};
+#else
+    static const KernelT later_mid[3][2] = {
         {k_ctu_wave<0, false, true, false, true>, k_ctu_wave<0, true, true, false, true>},
         {k_ctu_wave<1, false, true, false, true>, k_ctu_wave<1, true, true, false, true>},
         {k_ctu_wave<2, false, true, false, true>, k_ctu_wave<2, true, true, false, true>}};
+    const KernelT (*later_fin)[2] = later_mid;
+#endif
     const int solver = (p->riemann == 1 || p->riemann == 2) ? p->riemann : 0;
     const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
     P.nunits = nwg;
@@ -1276,7 +1293,7 @@ int comp_rk_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, pyrohip_st
         P.rk_nb = nstages;
         for (int j = 0; j < 4; j++) P.rk_b[j] = (j < nstages) ? b[j] : 0.0;
         P.rk_out = Unew;
-        PYRO_LAUNCH(c, "k_ctu_wave_rk", later[solver][std_rec], grid, block, WLDS_BYTES, (const double *)Uin,
+        PYRO_LAUNCH(c, "k_ctu_wave_rk", (P.rk_final ? later_fin : later_mid)[solver][std_rec], grid, block, WLDS_BYTES, (const double *)Uin,
                     kst->d + (size_t)(4 * st) * g.plane, g, P, s->d_flag, part, S);
     }
     PYRO_CHECK_HIP(hipGetLastError());

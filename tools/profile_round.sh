@@ -89,8 +89,9 @@ for spec in "swe k_sw_wave 4096 swe4096" "sph k_sph_wave 2048 sph2048"; do
   cp $O/${RT}_$4_kernel_stats.csv $O/${RT}_$4_pmc.json $P/ 2>/dev/null
 done
 # (compressible_rk: the stages with the Runge-Kutta combination folded in -- template arguments
-# <SOLVER, STD, MOL, ONE, RKF, SRC> = <0, true, true, false, true, true> -- averaged over stages 1-3 of RK4)
-LEG=rk KN="true, true, false, true, true>" NX=4096 TAG=${RT}_rk4096 bash tools/pmc_leg.sh > $O/pmc_leg_${RT}_rk4096.log 2>&1
+# <SOLVER, STD, MOL, ONE, RKF, SRC, FINT> = <0, true, true, false, true, true, 0 | 1> -- averaged over stages 1-3 of RK4:
+# two middle-stage launches and the last one)
+LEG=rk KN="true, true, false, true, true, " NX=4096 TAG=${RT}_rk4096 bash tools/pmc_leg.sh > $O/pmc_leg_${RT}_rk4096.log 2>&1
 cp $O/${RT}_rk4096_kernel_stats.csv $O/${RT}_rk4096_pmc.json $P/ 2>/dev/null
 # what a phase boundary costs: chip-wide barrier vs one confined to an XCD
 ( timeout 120 tools/bin/xcdbar_probe; timeout 60 tools/bin/gridbar_probe ) > $P/${TAG}_xcdbar_probe.txt 2>&1
