@@ -880,7 +880,10 @@ def bench_pyro_driver(ctx, device, bare, n_=lambda n, lo=32: n, k_=lambda k, few
         (16 + 24, "read + write phi (16 B) and the Crank-Nicolson right-hand side pass (24 B) per cell and "
                   "step; the multigrid solve on top is priced in also.multigrid (V-cycles per step "
                   "reported beside it)"), ref=("diffusion", "2048"))
-    leg("swe_dam_4096", "swe", "dam", {"mesh.nx": n_(4096), "mesh.ny": n_(4096)}, k_(20), k_(3),
+    # (20 untimed steps in front of these legs, not 3: the problem set-up on the host leaves the GPU idle for
+    # hundreds of ms, the first ~10 ms of work after that run at a lower clock -- tools/runsim_overhead.py:
+    # swe 4096^2 20 steps 11.5 / 10.7 / 10.5 ms in three consecutive run_sim() calls)
+    leg("swe_dam_4096", "swe", "dam", {"mesh.nx": n_(4096), "mesh.ny": n_(4096)}, k_(20), k_(20),
         (48, "read 3 + write 3 conserved doubles per cell update"), inputs_file="inputs.dam.x",
         ref=("swe", "interpreted"))
     leg("compressible_rk_sedov_2048", "compressible_rk", "sedov", {"mesh.nx": n_(2048), "mesh.ny": n_(2048)},
@@ -888,14 +891,14 @@ def bench_pyro_driver(ctx, device, bare, n_=lambda n, lo=32: n, k_=lambda k, few
         (416, "RK4 in four launches (pyrohip_comp_rk_step): 64 + 96 + 96 + 160 B per cell and step, see the "
               "4096^2 leg"), ref=("compressible_rk", "interpreted"))
     leg("compressible_rk_sedov_4096", "compressible_rk", "sedov", {"mesh.nx": n_(4096), "mesh.ny": n_(4096)},
-        k_(20), k_(3),
+        k_(20), k_(10),
         (416, "RK4 with the stage folded into the right-hand side's load (pyrohip_comp_rk_step): stage 0 reads "
               "y_0 and writes k_0 (64 B), stages 1-2 read y_0 + one k and write a k (96 B each), the last reads "
               "y_0 + k_0..k_2 and writes the new state (160 B): 416 B per cell and step"))
     leg("compressible_sedov_spherical_2048", "compressible", "sedov",
-        {"mesh.nx": n_(2048, 64), "mesh.ny": n_(2048, 64)}, k_(10), k_(2),
-        (SEDOV_BYTES_PER_CELL, "64 B per cell update (one launch per step since round 4: the tile kernel "
-                               "with the geometry terms, k_ctu_fused_sph; + 8 geometry planes read)"),
+        {"mesh.nx": n_(2048, 64), "mesh.ny": n_(2048, 64)}, k_(20), k_(20),
+        (SEDOV_BYTES_PER_CELL, "64 B per cell update (round 6: the row-marching kernel with the geometry terms, "
+                               "k_sph_wave: row / column factor tables instead of 8 geometry planes)"),
         inputs_file="inputs.sedov.spherical", ref=("compressible_spherical", "interpreted"))
     return out
 

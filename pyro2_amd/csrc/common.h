@@ -197,6 +197,7 @@ struct StepScalars {
     int active;                          // this step advances the state (else: identity copy)
     int steps;                           // steps that advanced, this call
     int dead;                            // an invalid state was met: nothing runs any more
+    double min0;                         // the CFL minimum the call starts from where the last call left it (device-side runs)
 };
 
 // The driver's compute_timestep (simulation_null.py:222-244) for a run that advances on the
@@ -315,7 +316,8 @@ struct pyrohip_state {
     double next_cfl_min = -1.0;  // min over interior of dx/(|u|+c) etc. of the
                                  // state after the last step (-1: unknown)
     bool cfl_is_global = false;  // ... already reduced over all ranks
-    int cfl_kind = 0;            // ... 0: the CTU solver's quantity; 1: compressible_rk's
+    int cfl_kind = 0;            // ... 0: the CTU solver's quantity; 1: compressible_rk's; 2: swe's
+    double cfl_par[3] = {0.0, 0.0, 0.0};   // ... of a device-side run: the (gamma | g, dx, dy) it was taken with
                                  // min 1 / ((|u|+c)/dx + (|v|+c)/dy) (comp_rk_step_wave)
     // the ghost cells hold exactly what the boundary rules (outflow / reflect / periodic index
     // maps) give for the current interior: set by a full pyrohip_fill_bc, dropped by anything
@@ -326,3 +328,12 @@ struct pyrohip_state {
     bool ghost_by_rules = false;
     bool stages_valid = false;   // swe: the work planes hold the stages of the LAST step (staged set)
 };
+
+// the CFL minimum the last step of a device-side run left still describes the state: same kind of
+// quantity, same (gamma | g, dx, dy), nothing has written the state since (every writer resets it)
+inline bool cfl_min_cached(const pyrohip_state *s, int kind, double a, double dx, double dy)
+{
+    return s->next_cfl_min > 0.0 && s->cfl_kind == kind && s->cfl_par[0] == a && s->cfl_par[1] == dx &&
+           s->cfl_par[2] == dy;
+}
+

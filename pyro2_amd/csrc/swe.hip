@@ -1064,8 +1064,10 @@ int pyrohip_swe_evolve(pyrohip_state *s, double dx, double dy, double grav, int 
     if (s->dts_cap < max_steps + 1) {
         if (s->d_dts) PYRO_CHECK_HIP(hipFree(s->d_dts));
         s->d_dts = nullptr;
-        PYRO_CHECK_HIP(hipMalloc((void **)&s->d_dts, (size_t)(max_steps + 1) * sizeof(double)));
-        s->dts_cap = max_steps + 1;
+        // (not less than 1024: a run that asks for more steps call by call must not free + allocate every time)
+        const int cap = max_steps + 1 > 1024 ? max_steps + 1 : 1024;
+        PYRO_CHECK_HIP(hipMalloc((void **)&s->d_dts, (size_t)cap * sizeof(double)));
+        s->dts_cap = cap;
     }
     if (!s->alt_base) {     // (k_fill_frame2 writes the second buffer's frame)
         const size_t n = (size_t)s->nvar * s->g.plane + 16;
@@ -1077,6 +1079,10 @@ int pyrohip_swe_evolve(pyrohip_state *s, double dx, double dy, double grav, int 
     H.t = pol->t; H.dt_old = pol->dt_old; H.n = pol->n;
     H.tmax = pol->tmax; H.f0 = pol->init_tstep_factor; H.mx = pol->max_dt_change;
     H.fix_dt = pol->fix_dt; H.cfl = cfl; H.dx = dx; H.dy = dy;
+    // (the CFL minimum the previous call's last step left, where nothing touched the state since:
+    // pyrohip_comp_evolve)
+    const bool min_cached = cfl_min_cached(s, 2, grav, dx, dy);
+    H.min0 = min_cached ? s->next_cfl_min : 0.0;
     PYRO_CHECK_HIP(hipMemcpyAsync(s->d_scal, &H, sizeof(H), hipMemcpyHostToDevice, c->stream));
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));      // H is on this stack frame
     PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
@@ -1100,7 +1106,8 @@ int pyrohip_swe_evolve(pyrohip_state *s, double dx, double dy, double grav, int 
         rc = launch_fill_frame2(s, &frame_done);          // pyro_sim.py:250: fill_BC_all
         if (rc) break;
         if (m == 0) {      // the CFL minimum of the state as handed over (whole array, filled)
-            rc = sw_cfl_min_device(s, dx, dy, grav, &dmin, nunits);
+            if (min_cached) dmin = &s->d_scal->min0;
+            else rc = sw_cfl_min_device(s, dx, dy, grav, &dmin, nunits);
             if (rc) break;
         }
         // (later steps: the policy kernel takes the minimum of the step kernel's partials itself)
@@ -1129,6 +1136,7 @@ int pyrohip_swe_evolve(pyrohip_state *s, double dx, double dy, double grav, int 
                                       hipMemcpyDeviceToHost, c->stream));
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
     memcpy(&H, hb, sizeof(H));
+    const double lastmin = *(double *)(hb + sizeof(StepScalars) + 8);
     // max_steps swaps were made; the last state that advanced sits H.steps swaps from the start
     if ((max_steps - H.steps) % 2) {
         double *old_base = s->base;
@@ -1137,7 +1145,10 @@ int pyrohip_swe_evolve(pyrohip_state *s, double dx, double dy, double grav, int 
         s->d = s->base + geom_lead(s->g);
     }
     PYRO_TRY(restore_frame_after_inactive(s, H.steps, max_steps, false, false));
-    s->next_cfl_min = -1.0;
+    // the minimum of the last launch belongs to the state only if that launch advanced it
+    s->next_cfl_min = (H.steps == max_steps && !H.dead) ? lastmin : -1.0;
+    s->cfl_kind = 2;
+    s->cfl_par[0] = grav; s->cfl_par[1] = dx; s->cfl_par[2] = dy;
     s->ghost_by_rules = false;
     pol->t = H.t; pol->dt_old = H.dt_old; pol->n = H.n;
     *steps_done = H.steps;

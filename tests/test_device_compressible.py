@@ -1580,6 +1580,54 @@ def test_rk_evolve_on_device_equals_single_steps(dev, method):
         res.append((d1,))
 
 
+@pytest.mark.parametrize("solver", ["ctu_tile", "ctu_wave", "rk"])
+def test_evolve_starts_from_the_cached_minimum_only_for_an_untouched_state(dev, solver):
+    """a device-side run starts from the CFL minimum the previous call's last step left (no pass over the
+    whole array) -- only while that minimum still describes the state: after an upload, or with another
+    dx, the call reduces the array again.  Second call on a state written in between / with other
+    parameters against a fresh state object that has no history: dt sequence and state bit for bit"""
+    from helpers import RK_TABLEAU
+    nx, ny, ng = 36, 70, 4
+    meta = [nx, ny, ng, 1.0 / nx, 1.0 / ny, 1.4, 2, 1, 0.75, 0.85, 0.33, 0.1, 0.0, 0.8]
+    bcs = ["outflow", "outflow", "periodic", "periodic"]
+    kw = {"ctu_tile": dict(kernel_set=1), "ctu_wave": dict(kernel_set=2, march_rows=16),
+          "rk": dict(kernel_set=2, march_rows=16)}[solver]
+    P, cfl = dev_params(meta, **kw)
+    meta2 = list(meta)
+    meta2[3] = 0.5 / nx
+    P2, _ = dev_params(meta2, **kw)
+    a, b = RK_TABLEAU["RK4"]
+
+    def run(s, k, PP, pol, n):
+        if solver == "rk":
+            return list(s.comp_rk_evolve(PP, k, a, b, cfl, pol, n))
+        return list(s.comp_evolve(PP, cfl, pol, n))
+
+    def fresh(U):
+        s = comp_state(dev, nx, ny, bcs)
+        k = device.DeviceState(dev, nx, ny, ng, [["outflow"] * 4] * 16) if solver == "rk" else None
+        s.upload(U)
+        return s, k
+
+    U0, U1 = _rk_random_state(nx, ny, 5), _rk_random_state(nx, ny, 6)
+    for what in ("upload", "dx"):
+        s, k = fresh(U0)
+        pol = DtPolicy(1.e30)
+        run(s, k, P, pol, 3)
+        if what == "upload":
+            s.upload(U1)
+            Ustart, PP = U1, P
+        else:
+            Ustart, PP = s.download(), P2
+        polb = DtPolicy(1.e30)
+        polb.t, polb.n, polb.dt_old = pol.t, pol.n, pol.dt_old
+        d2 = run(s, k, PP, pol, 3)
+        sf, kf = fresh(Ustart)
+        df = run(sf, kf, PP, polb, 3)
+        assert d2 == df, (what, d2, df)
+        assert np.array_equal(s.download()[ng:-ng, ng:-ng], sf.download()[ng:-ng, ng:-ng]), what
+
+
 @pytest.mark.parametrize("kset", KSETS)
 def test_comp_negative_zero_momentum_traces_like_the_reference(dev, kset):
     """the tracing takes copysign(1, u) (interface.py:198-201): a cell whose x-momentum is exactly

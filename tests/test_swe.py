@@ -241,6 +241,35 @@ def test_swe_evolve_on_device_equals_single_steps(dev, bcs, fast):
         ref = d1
 
 
+def test_swe_evolve_cached_minimum_dropped_when_the_state_is_written(dev):
+    """pyrohip_swe_evolve starts from the minimum the previous call's last step left, unless the state
+    was written in between or the call comes with another dx: then as a state without history"""
+    nx, ny, ng = 40, 66, 4
+    vb = orc.comp_var_bcs(["outflow", "outflow", "reflect", "reflect"])
+    rows = [list(vb[0]), list(vb[2]), list(vb[3]), list(vb[0])]
+    U0, U1 = _swe_random_state(nx, ny, 3), _swe_random_state(nx, ny, 4)
+    dx, dy, grav, cfl = 1.0 / nx, 1.0 / ny, 1.0, 0.8
+    for what in ("upload", "dx"):
+        s = device.DeviceState(dev, nx, ny, ng, rows)
+        s.upload(U0)
+        pol = DtPolicy(1.e30)
+        s.swe_evolve(dx, dy, grav, 1, "Roe", cfl, pol, 3, fast_math=0)
+        dx2 = dx
+        if what == "upload":
+            s.upload(U1)
+            Ustart = U1
+        else:
+            Ustart, dx2 = s.download(), 0.5 * dx
+        polb = DtPolicy(1.e30)
+        polb.t, polb.n, polb.dt_old = pol.t, pol.n, pol.dt_old
+        d2 = list(s.swe_evolve(dx2, dy, grav, 1, "Roe", cfl, pol, 3, fast_math=0))
+        sf = device.DeviceState(dev, nx, ny, ng, rows)
+        sf.upload(Ustart)
+        df = list(sf.swe_evolve(dx2, dy, grav, 1, "Roe", cfl, polb, 3, fast_math=0))
+        assert d2 == df, (what, d2, df)
+        assert np.array_equal(s.download()[ng:-ng, ng:-ng], sf.download()[ng:-ng, ng:-ng])
+
+
 def test_pyro_swe_run_sim_batches_steps(api, golden):
     """Pyro("swe").run_sim() hands batches of steps to the device (evolve_many): same dt
     sequence end and state as single steps"""
