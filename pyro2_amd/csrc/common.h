@@ -198,6 +198,7 @@ struct StepScalars {
     int steps;                           // steps that advanced, this call
     int dead;                            // an invalid state was met: nothing runs any more
     double min0;                         // the CFL minimum the call starts from where the last call left it (device-side runs)
+    double keep0;                        // decomposed runs: 1 if this rank kept it, min-reduced over the ranks before it is used
 };
 
 // The driver's compute_timestep (simulation_null.py:222-244) for a run that advances on the

@@ -374,10 +374,21 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
     // the CFL minimum of the state as handed over: the one the last step of the previous call left, where
     // nothing has touched the state since (what pyrohip_comp_dt answers from as well) -- a pass over the
     // whole array otherwise (1.55 ms at 16384^2, 0.14 ms at 4096^2 per call)
-    const bool min_cached = cfl_min_cached(s, 0, p->gamma, p->dx, p->dy) && (!c->global_cfl || s->cfl_is_global);
+    bool min_cached = cfl_min_cached(s, 0, p->gamma, p->dx, p->dy) && (!c->global_cfl || s->cfl_is_global);
     H.min0 = min_cached ? s->next_cfl_min : 0.0;
+    H.keep0 = min_cached ? 1.0 : 0.0;
     PYRO_CHECK_HIP(hipMemcpyAsync(s->d_scal, &H, sizeof(H), hipMemcpyHostToDevice, c->stream));
     PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));      // H is on this stack frame
+    if (c->global_cfl && c->comm != nullptr) {
+        // decomposed run: all ranks keep their (global) minimum or none does -- a rank whose slab was written
+        // since must reduce its array, and the others' kept minimum still counts that slab's OLD cells.  One
+        // small all-reduce + read-back per call instead of a pass over the slab (0.9 ms at 2048 x 16384)
+        PYRO_TRY(comm_allreduce_min_device(c, &s->d_scal->keep0));
+        PYRO_CHECK_HIP(hipMemcpyAsync(c->reduce_host, &s->d_scal->keep0, sizeof(double), hipMemcpyDeviceToHost,
+                                      c->stream));
+        PYRO_CHECK_HIP(hipStreamSynchronize(c->stream));
+        min_cached = ((double *)c->reduce_host)[0] == 1.0;
+    }
     PYRO_CHECK_HIP(hipMemsetAsync(s->d_flag, 0, sizeof(int), c->stream));
     const bool wave = !sphf && ((p->kernel_set == 2) ||
                                 (p->kernel_set == -1 && wave_kernel_pays_ctu(s->g, p)));
@@ -464,12 +475,10 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
                 rc = pyrohip_fill_bc(s, -1);
         }
         if (rc) break;
-        if (first && min_cached) {
-            dmin = &d_scal0->min0;
-            first = false;
-        }
         if (first) {   // CFL minimum of the state as handed over (full array, ghost cells filled)
-            if (sphf)
+            if (min_cached)
+                dmin = &d_scal0->min0;      // (... the one the previous call's last step left)
+            else if (sphf)
                 rc = p->fast_math ? fastm::comp_cfl_min_device_sph(s, p, &dmin)
                                   : exact::comp_cfl_min_device_sph(s, p, &dmin);
             else
@@ -480,7 +489,8 @@ int pyrohip_comp_evolve(pyrohip_state *s, const pyrohip_comp_params *p, double c
             // first step of a call (found by running four ranks on one GPU: the slabs far from
             // the blast started every call with their own, larger dt; with two ranks the two
             // local minima are equal by symmetry and nothing showed)
-            if (c->global_cfl) {
+            // (a kept minimum is the global one already: every rank kept it, see above)
+            if (c->global_cfl && !min_cached) {
                 rc = comm_allreduce_min_device(c, const_cast<double *>(dmin));
                 if (rc) break;
                 s->cfl_is_global = true;
