@@ -713,7 +713,9 @@ def _mg_vcycles(ctx, device, nx, cycles):
     m.zero(L, 0)
     m.set(L, 1, rhs)
     m.init_rhs_norm()
-    m.solve(rtol=0.0, max_cycles=2)     # warm-up
+    # warm-up: ~50 ms of V-cycles (the clock after the host-side set-up: tools/mg_warm.py; 2 cycles when
+    # the caller asks for a token run)
+    m.solve(rtol=0.0, max_cycles=2 if cycles < 5 else (80 if nx >= 2048 else 250))
     m.zero(L, 0)
     ctx.sync()
     t0 = time.perf_counter()
@@ -870,7 +872,7 @@ def bench_pyro_driver(ctx, device, bare, n_=lambda n, lo=32: n, k_=lambda k, few
         k_(100), k_(5), (SEDOV_BYTES_PER_CELL, "64 B per cell update (SURVEY 8(d))"),
         bare_ms=bare.get("sedov_4096"))
     leg("advection_smooth_2048", "advection", "smooth",
-        {"mesh.nx": n_(2048), "mesh.ny": n_(2048), "particles.do_particles": 0}, k_(768, 6), k_(48, 6),
+        {"mesh.nx": n_(2048), "mesh.ny": n_(2048), "particles.do_particles": 0}, k_(768, 6), k_(3072, 6),
         (ADV_BYTES_PER_CELL, "16 B per cell update"), bare_ms=bare.get("advection"),
         note="inputs.smooth carries 100 tracer particles (host-side NumPy, two grid-sized velocity "
              "arrays per call): switched off here, the leg times the grid update")
@@ -1384,10 +1386,16 @@ def main():
                     leg("sedov_8192", lambda: sedov_size_leg(args, dist, ctx, device, defaults, n_(8192), k_(40)))
                 leg("sedov_small_grids", lambda: bench_small_grids(
                     ctx, device, sizes=(64, 256, 512) if D == 1 else (32, 64), steps=k_(400)))
-                leg("advection", lambda: bench_advection(ctx, device, nx=n_(2048), steps=k_(600, 6), warmup=k_(30),
+                # (~50 ms of untimed steps in front of the memory-bound legs: after the host-side set-up of a
+                # leg the GPU's clock takes tens of ms of work to come back up -- tools/adv_warm.py, mg_warm.py:
+                # advection 2048^2 17.7 / 17.4 / 16.7 / 15.7 us per step after 6 / 60 / 600 / 3000 untimed steps,
+                # 8192^2 0.197 -> 0.165 ms, a 4096^2 V-cycle 0.719 -> 0.681 ms; a run of thousands of steps
+                # sees the warm figure.  The FP64-bound Sedov legs go the other way under sustained load
+                # (profiles/r06_sedov4096_by_launch.txt) and keep their windows.)
+                leg("advection", lambda: bench_advection(ctx, device, nx=n_(2048), steps=k_(600, 6), warmup=k_(3000, 6),
                                                          fast_math=defaults["fast_math"]))
                 leg("advection_8192", lambda: bench_advection(ctx, device, nx=n_(8192), steps=k_(60, 6),
-                                                              warmup=k_(6), fast_math=defaults["fast_math"]))
+                                                              warmup=k_(300, 6), fast_math=defaults["fast_math"]))
                 leg("multigrid", lambda: bench_mg(ctx, device, nx=n_(4096), cycles=k_(10), small_sizes=D == 1))
                 leg("incompressible", lambda: bench_incompressible(ctx, device, nx=n_(2048), steps=k_(5, 1)))
                 bare = {"sedov_4096": (also.get("sedov_4096") or {}).get("ms_per_step"),
