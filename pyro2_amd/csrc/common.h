@@ -99,6 +99,10 @@ struct pyrohip_ctx {
     int nranks = 1, rank = 0;
     bool global_cfl = false;  // all-reduce the step kernels' CFL minimum on the device
     int num_cus = 0;
+    // one-round launches of the row-marching kernels: the two wavefronts of a SIMD tell each other how many
+    // rows they have left (comp_wave.hip: wave_prio_feedback); [SIMD of the chip][wavefront slot], tagged per launch
+    pyro::DevBuf prio_board;
+    unsigned launch_seq = 0;
 };
 
 namespace pyro {

@@ -239,6 +239,13 @@ __device__ __forceinline__ void st_put(double *st, int s, const Cons &U)
 // SRC = false: an instance without the source-term blocks (gravity, heating) for runs that have none --
 // skipped at run time they still cost registers whose pending loads force a full vmcnt wait where their
 // paths join the row's work: 31.7 -> 32.3 Gcell/s at 16384^2 (round 6)
+#if defined(PYRO_WAVE_TIMELINE) && PYRO_FAST && !defined(PYRO_EMU)
+// developer build (tools/wave_timeline.py): every wavefront of k_ctu_wave leaves (start, end) on the
+// 100 MHz constant clock, its hardware id and its unit in a device array read back by
+// pyrohip_debug_wave_timeline -- where does a one-round launch lose the time between the average
+// wavefront's life and the kernel's?
+__device__ unsigned long long g_wave_timeline[4 * 65536];
+#endif
 template <int SOLVER, bool STD, bool MOL = false, bool ONE = false, bool RKF = false, bool SRC = true,
           int FINT = -1>   // SOLVER, STD as k_ctu_fused
 __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *__restrict__ Uin,
@@ -263,11 +270,20 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     const int per = (P.nunits + 7) / 8;
     const int unit = ((int)blockIdx.x % 8) * per + (int)blockIdx.x / 8;
     if (unit >= P.nunits) return;
-    const int cb = unit % P.ncb, sb = P.sb_first + (unit / P.ncb) * P.sb_step;
-    const int i0 = g.ilo + sb * P.L;                       // strip rows [i0, i1)
+    // (units behind the ncb x nsb regular ones: the extra strip of the column strips [0, n_extra) -- a launch
+    // that fits the resident slots in one round is cut into exactly as many strips as there are slots,
+    // wave_extra_units below)
+    const int nreg = P.ncb * P.nsb;
+    const int cb = unit < nreg ? unit % P.ncb : unit - nreg;
+    const int sb = unit < nreg ? P.sb_first + (unit / P.ncb) * P.sb_step : P.nsb;
+    int i0 = g.ilo + sb * P.L;                             // strip rows [i0, i1)
     // (the last strip runs to the end of the grid: it may be up to ng - 1 rows longer
     // than L, so that no strip is shorter than the ghost width -- comp_step_wave_ex)
-    const int i1 = (sb == P.nsb - 1) ? g.ihi + 1 : i0 + P.L;
+    int i1 = (sb == P.nsb - 1) ? g.ihi + 1 : i0 + P.L;
+    if (cb < P.n_extra) {      // nsb + 1 strips of equal length (to a row)
+        i0 = g.ilo + (int)((long)sb * g.nx / (P.nsb + 1));
+        i1 = g.ilo + (int)((long)(sb + 1) * g.nx / (P.nsb + 1));
+    }
     const int j = g.jlo + cb * WOUT - 4 + l;               // this lane's column
     const int jc = (j < g.qy) ? j : g.qy - 1;              // ragged last strip: clamp, unused
     const bool jin = (j >= g.jlo && j <= g.jhi);
@@ -316,9 +332,23 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         active = S->active != 0;
     }
     // the wavefront's CFL minimum (in every lane) and its positivity flag at the end
+#if defined(PYRO_WAVE_TIMELINE) && PYRO_FAST && !defined(PYRO_EMU)
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     auto finish = [&](double cfl, bool bad) {
         if (bad) atomicOr(flag, ONE ? (2 << (P.pol_m & 1)) : 1);
         if (l != 0) return;
+#if defined(PYRO_WAVE_TIMELINE) && PYRO_FAST && !defined(PYRO_EMU)
+        if (unit < 65536) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_wave_timeline[4 * unit] = tl_t0;
+            g_wave_timeline[4 * unit + 1] = __builtin_amdgcn_s_memrealtime();
+            g_wave_timeline[4 * unit + 2] = ((unsigned long long)xcc << 32) | hwid;
+            g_wave_timeline[4 * unit + 3] = ((unsigned long long)sb << 32) | (unsigned)cb;
+        }
+#endif
         if (ONE)
             atomicMin(P.pol->slots + (size_t)(P.pol_m % 3) * kPolSetWords + (size_t)(unit % kPolSlots) * kPolStride,
                       (unsigned long long)__double_as_longlong(cfl));
@@ -535,9 +565,43 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     unsigned hw_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
     const int wslot = (int)(hw_id & 1u);
+    // Round 6, second half: the turns by phase are blind -- each wavefront counts its OWN rows, the two
+    // drift apart and the better duty changes with the strip length (tools/wave_timeline.py, 4096^2: the
+    // second wavefront ends 90 us before the first with seven eighths, 80 us after it with four, together with
+    // five; 3072^2 wants seven).  With a board (P.prio_board: one word per SIMD and slot in device memory, the
+    // two wavefronts of a SIMD sit on one XCD = one L2) each tells the other how many rows it has left, a row
+    // late, and the one with more rows left takes the priority: the pair ends together whatever the strips.
+    const bool prio_fb = P.prio_board != nullptr;
+    int *prio_mine = nullptr, *prio_other = nullptr;
+    int prio_seen = 0;
+    if (prio_fb) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        int *const pair = P.prio_board + 2 * (int)(((xcc & 15u) << 12) | ((hw_id >> 4) & 0xfffu));   // (SIMD, CU, SH, SE)
+        prio_mine = pair + wslot;
+        prio_other = pair + (wslot ^ 1);
+    }
+    // (the word goes out and the other one is asked for BEHIND the request of the next row: loads return in
+    // order, in front of it a miss of this word would hold up the row; workgroup scope -- sc0: through the
+    // CU's cache to the XCD's L2, the two wavefronts share both)
+    auto prio_publish = [&](int k) {
+        if (!prio_fb) return;
+        __hip_atomic_store(prio_mine, (P.prio_tag << 16) | (i1 + 3 - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        prio_seen = __hip_atomic_load(prio_other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+#else
+    auto prio_publish = [](int) {};
 #endif
     for (int k = i0 - 4; k <= i1 + 3; k++) {
 #if !defined(PYRO_EMU)
+        if (prio_fb) {
+            // (the word asked for an iteration ago: complete with the row that arrived since)
+            const int seen = __builtin_amdgcn_readfirstlane(prio_seen);
+            const int left = i1 + 3 - k;
+            const int other_left = ((seen >> 16) == P.prio_tag) ? (seen & 0xffff) : left;
+            if (left > other_left) __builtin_amdgcn_s_setprio(1);
+            else if (left < other_left) __builtin_amdgcn_s_setprio(0);
+        } else
         if (P.prio_duty > 0) {
             const int phase = ((k - i0) >> PYRO_WAVE_PRIO_SHIFT) & 7;
             if (wslot ? (phase < P.prio_duty) : (phase >= P.prio_duty)) __builtin_amdgcn_s_setprio(1);
@@ -573,6 +637,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
             if (!DELAY) {
             Upre = loadU(k + 1);
             Kpre = loadK(k + 1);
+            prio_publish(k);
             }
             const bool interior = row_in(k) && jin;
             // (RKF: the stage state is a temporary of the step -- nothing to keep the floor in)
@@ -598,6 +663,7 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
                 }
                 Ucx = loadU(k - 4);                 // (in front of the next row's request: its wait leaves that one out)
                 Upre = loadU(k + 1);
+                prio_publish(k);
                 STAGE_FENCE();
             }
         }
@@ -1027,12 +1093,38 @@ static int wave_rows(int nx, int ncb, int slots)
 // eighths -- 3072^2 0.389 -> 0.374 ms, 4096^2 0.639 -> 0.623 with 7, 0.651 with 8 --, the 38-row strips of
 // 2048^2 with six: 0.193 vs 0.195 / 0.201 with 5 / 7; the method-of-lines launches pass L = 0 and keep six:
 // an RK4 step at 4096^2 took 2.20 ms with seven against 2.13)
+#if defined(PYRO_WAVE_PRIO_DUTY_FORCE)      // (developer A/B: tools/wave_timeline.py)
+static int wave_prio_duty(int nwaves, int slots, int) { return nwaves <= 2 * slots ? PYRO_WAVE_PRIO_DUTY_FORCE : 0; }
+#else
 static int wave_prio_duty(int nwaves, int slots, int L) { return nwaves <= 2 * slots ? (L >= 64 ? 7 : 6) : 0; }
+#endif
 
 // the launch geometry of a step on an nx x ny slab: column strips, rows per strip, row strips
 // (a last strip shorter than the ghost width joins its predecessor: the boundary strips of a
 // slab must hold the ng rows the neighbour receives as its halo), and whether the first and
 // the last strip can go first with the halo exchange beside the interior ones
+// the rows-left board of the SIMD pairs for a launch whose wavefronts take turns (prio_duty > 0): 2^16 SIMD
+// numbers (XCC, SE, SH, CU, SIMD fields of the hardware id) x 2 slots, zeroed once, tagged per launch
+#if !defined(PYRO_WAVE_NO_FEEDBACK)
+static int wave_prio_feedback(pyrohip_ctx *c, FP &P)
+{
+    P.prio_board = nullptr;
+    if (P.prio_duty <= 0) return 0;
+#if !defined(PYRO_EMU)
+    const size_t bytes = (size_t)2 * 65536 * sizeof(int);
+    if (c->prio_board.bytes < bytes) {
+        PYRO_TRY(c->prio_board.ensure(bytes));
+        PYRO_CHECK_HIP(hipMemsetAsync(c->prio_board.p, 0, bytes, c->stream));
+    }
+    c->launch_seq = (c->launch_seq % 32767u) + 1u;      // 1 .. 32767: never the zeroed board's 0
+    P.prio_board = (int *)c->prio_board.p;
+    P.prio_tag = (int)c->launch_seq;
+#endif
+    return 0;
+}
+#else
+static int wave_prio_feedback(pyrohip_ctx *, FP &P) { P.prio_board = nullptr; return 0; }
+#endif
 struct WaveGeom { int ncb, L, nsb, overlap; };
 static WaveGeom wave_geometry(int nx, int ny, int ng, int cus, int march_rows)
 {
@@ -1045,6 +1137,21 @@ static WaveGeom wave_geometry(int nx, int ny, int ng, int cus, int march_rows)
     w.overlap = (w.nsb >= 3 && w.L >= ng) ? 1 : 0;
     return w;
 }
+// One-round launches: a SIMD that holds ONE wavefront gets little out of it (4096^2, 74 x 27 = 1998 strips on
+// 2048 slots: the 50 wavefronts without a partner lived 638 us, the paired ones 535 each -- tools/wave_timeline.py
+// -- and the launch lasts as long as its last wavefront).  So the first n_extra column strips are cut into
+// nsb + 1 row strips instead of nsb: as many strips as slots.  Single domain only (a slab's strips are
+// its protocol), not with a strip length the caller chose.
+#if !defined(PYRO_WAVE_NO_EXTRA)
+static int wave_extra_units(const WaveGeom &w, int nx, int slots, int march_rows)
+{
+    const int nreg = w.ncb * w.nsb;
+    if (march_rows > 0 || w.nsb < 2 || nreg >= slots || nx / (w.nsb + 1) < 8) return 0;
+    return slots - nreg < w.ncb ? slots - nreg : w.ncb;
+}
+#else
+static int wave_extra_units(const WaveGeom &, int, int, int) { return 0; }
+#endif
 #if !PYRO_FAST
 // (for callers that want to know before they launch: bench.py's scaling line, the tests of
 // the decomposed runs)  out: ncb, L, nsb, overlap, wavefronts, resident slots
@@ -1071,11 +1178,12 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
     P.L = wg.L;
     const int nsb = wg.nsb;
     P.nsb = nsb;
-    const int nwg = P.ncb * nsb;
     // slab of a decomposed run with the halo communicator: EVERY step posts the
     // exchange of its new boundary rows (overlapped when the strips allow it), so the
     // protocol does not depend on this rank's geometry
     const bool post = s->nb_set && comm_can_overlap(s);
+    P.n_extra = (s->nb_set || post) ? 0 : wave_extra_units(wg, g.nx, 4 * PYRO_WAVE_MINW * cus, p->march_rows);
+    const int nwg = P.ncb * nsb + P.n_extra;
     PYRO_TRY(c->reduce.ensure((nwg + kMinStageBlocks + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
     using KernelT = void (*)(const double *, double *, Geom, FP, int *, double *,
@@ -1132,6 +1240,7 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
     }
     P.nunits = nwg;
     P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus, P.L);
+    PYRO_TRY(wave_prio_feedback(c, P));
     if (S && s->pol_next && !post) {
         // this launch is the whole step (pyrohip_comp_evolve): ghost cells read through the
         // boundary rules, the dt policy of the next step run by the last wavefront to finish
@@ -1192,7 +1301,8 @@ int comp_rk_rhs_wave(pyrohip_state *s, const pyrohip_comp_params *p, pyrohip_sta
     const int cus = c->num_cus > 0 ? c->num_cus : 256;
     const WaveGeom wg = wave_geometry(g.nx, g.ny, g.ng, cus, p->march_rows);
     P.ncb = wg.ncb; P.L = wg.L; P.nsb = wg.nsb;
-    const int nwg = P.ncb * wg.nsb;
+    P.n_extra = s->nb_set ? 0 : wave_extra_units(wg, g.nx, 4 * PYRO_WAVE_MINW * cus, p->march_rows);
+    const int nwg = P.ncb * wg.nsb + P.n_extra;
     PYRO_TRY(c->reduce.ensure((nwg + kMinStageBlocks + 2) * sizeof(double)));
     using KernelT = void (*)(const double *, double *, Geom, FP, int *, double *,
                              const StepScalars *);
@@ -1204,6 +1314,7 @@ int comp_rk_rhs_wave(pyrohip_state *s, const pyrohip_comp_params *p, pyrohip_sta
     const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
     P.nunits = nwg;
     P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus, 0);
+    // (no rows-left board for the method-of-lines launches: measured, an RK4 step at 4096^2 2.20 ms with it, 2.14 without)
     PYRO_LAUNCH(c, "k_ctu_wave_mol", kernels[solver][std_rec], dim3(8 * ((nwg + 7) / 8)), dim3(64), WLDS_BYTES,
                 (const double *)Uin, Uout, g, P, s->d_flag, (double *)c->reduce.p, nullptr);
     PYRO_CHECK_HIP(hipGetLastError());
@@ -1242,7 +1353,8 @@ int comp_rk_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, pyrohip_st
     const int cus = c->num_cus > 0 ? c->num_cus : 256;
     const WaveGeom wg = wave_geometry(g.nx, g.ny, g.ng, cus, p->march_rows);
     P.ncb = wg.ncb; P.L = wg.L; P.nsb = wg.nsb;
-    const int nwg = P.ncb * wg.nsb;
+    P.n_extra = s->nb_set ? 0 : wave_extra_units(wg, g.nx, 4 * PYRO_WAVE_MINW * cus, p->march_rows);
+    const int nwg = P.ncb * wg.nsb + P.n_extra;
     PYRO_TRY(c->reduce.ensure((nwg + kMinStageBlocks + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
     using KernelT = void (*)(const double *, double *, Geom, FP, int *, double *, const StepScalars *);
@@ -1270,6 +1382,7 @@ int comp_rk_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, pyrohip_st
     const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
     P.nunits = nwg;
     P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus, 0);
+    // (no rows-left board for the method-of-lines launches: measured, an RK4 step at 4096^2 2.20 ms with it, 2.14 without)
     const dim3 grid(8 * ((nwg + 7) / 8)), block(64);
     // stage 0: the state itself, ghost cells filled in memory (they stay the state's "stale"
     // ghost cells after the step, like the reference's), density floor in place
@@ -1316,3 +1429,12 @@ int comp_rk_step_wave(pyrohip_state *s, const pyrohip_comp_params *p, pyrohip_st
 
 }  // namespace PYRO_NS
 }  // namespace pyro
+
+#if defined(PYRO_WAVE_TIMELINE) && PYRO_FAST && !defined(PYRO_EMU)
+extern "C" int pyrohip_debug_wave_timeline(unsigned long long *out, int nunits)
+{
+    if (!out || nunits < 1 || nunits > 65536) return -1;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pyro::PYRO_NS::g_wave_timeline),
+                                    (size_t)nunits * 4 * sizeof(unsigned long long));
+}
+#endif

@@ -330,6 +330,7 @@ int pyrohip_shutdown(pyrohip_ctx *c)
     pyrohip_comm_destroy(c);
     c->staging.release();
     c->reduce.release();
+    c->prio_board.release();
     if (c->reduce_host) (void)hipHostFree(c->reduce_host);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);

@@ -27,6 +27,9 @@ struct FP {   // kernel parameters
     int nunits;               // ... (column block, strip) pairs of this launch
     int prio_duty;            // ... eighths of the time the second wavefront of a SIMD has priority (0: age decides)
     int sb_first, sb_step;    // ... strip of workgroup b: sb_first + (b / ncb) * sb_step
+    int n_extra;              // ... column strips [0, n_extra) are cut into nsb + 1 row strips (one-round launches: every slot filled)
+    int *prio_board;          // ... rows-left board of the SIMD pairs (nullptr: priority turns by prio_duty) and this launch's tag
+    int prio_tag;
     // tile kernel: the ghost fill folded into the loads (pyrohip_comp_params.fuse_fill):
     // row / column maps of the boundary rules (identity without) and, per variable and
     // side, whether the ghost value changes sign (bit 4 n + side)

@@ -14,7 +14,7 @@ from pyro2_amd.pyro_sim import Pyro   # noqa: E402
 what = sys.argv[1] if len(sys.argv) > 1 else "swe"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 cfg = {"swe": ("swe", "dam", "inputs.dam.x", 4096, "swe_evolve"),
-       "rk": ("compressible_rk", "sedov", None, 4096, "comp_rk_evolve"),
+       "rk": ("compressible_rk", "sedov", None, int(os.environ.get("NX", "4096")), "comp_rk_evolve"),
        "sph": ("compressible", "sedov", "inputs.sedov.spherical", 2048, "comp_evolve")}[what]
 ctx = device.Context(0)
 device.Context._default = ctx
