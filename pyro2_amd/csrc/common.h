@@ -334,6 +334,30 @@ struct pyrohip_state {
     bool stages_valid = false;   // swe: the work planes hold the stages of the LAST step (staged set)
 };
 
+// the rows-left board of the SIMD pairs for a row-marching launch whose wavefronts all sit on the chip at once or in
+// two rounds (comp_wave.hip: the one with more rows left takes the priority): 2^16 SIMD numbers (XCC, SE, SH, CU,
+// SIMD fields of the hardware id) x 2 slots, zeroed once, tagged per launch (1 .. 32767: never the zeroed board's 0)
+inline int prio_board_acquire(pyrohip_ctx *c, int **board, int *tag)
+{
+    const size_t bytes = (size_t)2 * 65536 * sizeof(int);
+    if (c->prio_board.bytes < bytes) {
+        PYRO_TRY(c->prio_board.ensure(bytes));
+        PYRO_CHECK_HIP(hipMemsetAsync(c->prio_board.p, 0, bytes, c->stream));
+    }
+    c->launch_seq = (c->launch_seq % 32767u) + 1u;
+    *board = (int *)c->prio_board.p;
+    *tag = (int)c->launch_seq;
+    return 0;
+}
+// one-round launches: as many strips as wavefront slots -- the first n_extra of the ncb column strips are cut into
+// nsb + 1 row strips of equal length instead of nsb (a SIMD left with ONE wavefront gets little out of it and
+// the launch lasts as long as its last wavefront: tools/wave_timeline.py)
+inline int wave_fill_extra(int ncb, int nsb, int nx, int slots)
+{
+    const int nreg = ncb * nsb;
+    if (nsb < 2 || nreg >= slots || nx / (nsb + 1) < 8) return 0;
+    return slots - nreg < ncb ? slots - nreg : ncb;
+}
 // the CFL minimum the last step of a device-side run left still describes the state: same kind of
 // quantity, same (gamma | g, dx, dy), nothing has written the state since (every writer resets it)
 inline bool cfl_min_cached(const pyrohip_state *s, int kind, double a, double dx, double dy)

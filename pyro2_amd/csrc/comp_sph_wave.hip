@@ -111,7 +111,9 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
     const int per = (P.nunits + 7) / 8;
     const int unit = pyro_uniform(((int)blockIdx.x % 8) * per + (int)blockIdx.x / 8);
     if (unit >= P.nunits) return;
-    const int cb = pyro_uniform(unit % P.ncb), sb = pyro_uniform(unit / P.ncb);
+    const int nreg = P.ncb * P.nsb;      // (units behind: the extra strip of the column strips [0, n_extra): comp_wave.hip)
+    const int cb = pyro_uniform(unit < nreg ? unit % P.ncb : unit - nreg);
+    const int sb = pyro_uniform(unit < nreg ? unit / P.ncb : P.nsb);
     double dt = P.dt;
     if (S) {
         if (!S->active) {      // past tmax / after an invalid state: nothing happens
@@ -120,8 +122,12 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
         }
         dt = S->dt;
     }
-    const int i0 = g.ilo + sb * P.L;
-    const int i1 = (sb == P.nsb - 1) ? g.ihi + 1 : i0 + P.L;
+    int i0 = g.ilo + sb * P.L;
+    int i1 = (sb == P.nsb - 1) ? g.ihi + 1 : i0 + P.L;
+    if (cb < P.n_extra) {      // nsb + 1 strips of equal length (to a row)
+        i0 = g.ilo + (int)((long)sb * g.nx / (P.nsb + 1));
+        i1 = g.ilo + (int)((long)(sb + 1) * g.nx / (P.nsb + 1));
+    }
     const int j = g.jlo + cb * SWOUT - 4 + l;
     const int jc = (j < g.qy) ? j : g.qy - 1;              // ragged last strip: clamped, unused
     const int jpc = (jc + 1 < g.qy) ? jc + 1 : jc;
@@ -236,9 +242,34 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
     unsigned hw_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
     const int wslot = (int)(hw_id & 1u);
+    // (comp_wave.hip: the two wavefronts of a SIMD tell each other their rows left, the one behind takes the priority)
+    const bool prio_fb = P.prio_board != nullptr;
+    int *prio_mine = nullptr, *prio_other = nullptr;
+    int prio_seen = 0;
+    if (prio_fb) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        int *const pair = P.prio_board + 2 * (int)(((xcc & 15u) << 12) | ((hw_id >> 4) & 0xfffu));
+        prio_mine = pair + wslot;
+        prio_other = pair + (wslot ^ 1);
+    }
+    auto prio_publish = [&](int k) {      // (behind the request of the next row)
+        if (!prio_fb) return;
+        __hip_atomic_store(prio_mine, (P.prio_tag << 16) | (i1 + 3 - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        prio_seen = __hip_atomic_load(prio_other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+#else
+    auto prio_publish = [](int) {};
 #endif
     for (int k = i0 - 4; k <= i1 + 3; k++) {
 #if !defined(PYRO_EMU)
+        if (prio_fb) {
+            const int seen = __builtin_amdgcn_readfirstlane(prio_seen);
+            const int left = i1 + 3 - k;
+            const int other_left = ((seen >> 16) == P.prio_tag) ? (seen & 0xffff) : left;
+            if (left > other_left) __builtin_amdgcn_s_setprio(1);
+            else if (left < other_left) __builtin_amdgcn_s_setprio(0);
+        } else
         if (P.prio_duty > 0) {
             const int phase = ((k - i0) >> 1) & 7;
             if (wslot ? (phase < P.prio_duty) : (phase >= P.prio_duty)) __builtin_amdgcn_s_setprio(1);
@@ -259,7 +290,7 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
         // ---- row k arrives: primitives
         {
             Cons U = Upre;
-            if (!SPHW_DELAY) Upre = loadU(k + 1);
+            if (!SPHW_DELAY) { Upre = loadU(k + 1); prio_publish(k); }
             const bool interior = row_in(k) && jin;
             if (interior) U.d = fmax(U.d, P.small_dens);
             bool ok;
@@ -274,6 +305,7 @@ __global__ __launch_bounds__(64, 2) void k_sph_wave(const double *__restrict__ U
                 if (k - 1 >= i0 + 4 && jout) store_row(Upend, k - 5);      // the update iteration k-1 made
                 Ucx = loadU(k - 4);                 // (in front of the next row's request: its wait leaves that one out)
                 Upre = loadU(k + 1);
+                prio_publish(k);
                 SPHW_FENCE();
             }
         }
@@ -627,8 +659,15 @@ int comp_step_wave_sph_ex(pyrohip_state *s, const pyrohip_comp_params *p, double
     if (p->march_rows > 0) P.L = p->march_rows < g.nx ? p->march_rows : g.nx;
     P.nsb = (g.nx + P.L - 1) / P.L;
     if (P.nsb > 1 && g.nx - (P.nsb - 1) * P.L < g.ng) P.nsb--;
-    P.nunits = P.ncb * P.nsb;
+    // (one round: as many strips as wavefront slots; the pairs of the SIMDs told their rows left: comp_wave.hip)
+#if !defined(PYRO_SPHW_NO_EXTRA)
+    P.n_extra = p->march_rows > 0 ? 0 : wave_fill_extra(P.ncb, P.nsb, g.nx, 8 * cus);
+#endif
+    P.nunits = P.ncb * P.nsb + P.n_extra;
     P.prio_duty = (P.nunits <= 2 * 8 * cus) ? 5 : 0;
+#if !defined(PYRO_EMU) && !defined(PYRO_SPHW_NO_FEEDBACK)
+    if (P.prio_duty > 0) PYRO_TRY(prio_board_acquire(c, &P.prio_board, &P.prio_tag));
+#endif
     PYRO_TRY(c->reduce.ensure((P.nunits + kMinStageBlocks + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
     using KernelT = void (*)(const double *, double *, Geom, FP, SphG, int *, double *, const StepScalars *);

@@ -1111,14 +1111,7 @@ static int wave_prio_feedback(pyrohip_ctx *c, FP &P)
     P.prio_board = nullptr;
     if (P.prio_duty <= 0) return 0;
 #if !defined(PYRO_EMU)
-    const size_t bytes = (size_t)2 * 65536 * sizeof(int);
-    if (c->prio_board.bytes < bytes) {
-        PYRO_TRY(c->prio_board.ensure(bytes));
-        PYRO_CHECK_HIP(hipMemsetAsync(c->prio_board.p, 0, bytes, c->stream));
-    }
-    c->launch_seq = (c->launch_seq % 32767u) + 1u;      // 1 .. 32767: never the zeroed board's 0
-    P.prio_board = (int *)c->prio_board.p;
-    P.prio_tag = (int)c->launch_seq;
+    PYRO_TRY(prio_board_acquire(c, &P.prio_board, &P.prio_tag));
 #endif
     return 0;
 }
@@ -1145,9 +1138,7 @@ static WaveGeom wave_geometry(int nx, int ny, int ng, int cus, int march_rows)
 #if !defined(PYRO_WAVE_NO_EXTRA)
 static int wave_extra_units(const WaveGeom &w, int nx, int slots, int march_rows)
 {
-    const int nreg = w.ncb * w.nsb;
-    if (march_rows > 0 || w.nsb < 2 || nreg >= slots || nx / (w.nsb + 1) < 8) return 0;
-    return slots - nreg < w.ncb ? slots - nreg : w.ncb;
+    return march_rows > 0 ? 0 : wave_fill_extra(w.ncb, w.nsb, nx, slots);
 }
 #else
 static int wave_extra_units(const WaveGeom &, int, int, int) { return 0; }

@@ -543,6 +543,9 @@ struct SWW {
     int limiter;
     int ncb, L, nunits;
     int prio_duty;      // eighths of the time the second wavefront of a SIMD holds the priority (0: age decides)
+    int nsb, n_extra;   // row strips; column strips [0, n_extra) are cut into nsb + 1 (common.h: wave_fill_extra)
+    int *prio_board;    // rows-left board of the SIMD pairs (comp_wave.hip; nullptr: turns by prio_duty) and the launch's tag
+    int prio_tag;
 };
 
 #if !defined(PYRO_EMU)
@@ -606,9 +609,15 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
         P.dt = S->dt;
     }
     double amax = 0.0, bmax = 0.0;      // running maxima of |u| + c, |v| + c over the cells updated
-    const int cb = pyro_uniform(unit % P.ncb), sb = pyro_uniform(unit / P.ncb);
-    const int i0 = g.ilo + sb * P.L;                        // rows [i0, i1)
-    const int i1 = (i0 + P.L < g.ihi + 1) ? i0 + P.L : g.ihi + 1;
+    const int nreg = P.ncb * P.nsb;      // (units behind: the extra strip of the column strips [0, n_extra))
+    const int cb = pyro_uniform(unit < nreg ? unit % P.ncb : unit - nreg);
+    const int sb = pyro_uniform(unit < nreg ? unit / P.ncb : P.nsb);
+    int i0 = g.ilo + sb * P.L;                              // rows [i0, i1)
+    int i1 = (i0 + P.L < g.ihi + 1) ? i0 + P.L : g.ihi + 1;
+    if (cb < P.n_extra) {      // nsb + 1 strips of equal length (to a row)
+        i0 = g.ilo + (int)((long)sb * g.nx / (P.nsb + 1));
+        i1 = g.ilo + (int)((long)(sb + 1) * g.nx / (P.nsb + 1));
+    }
     const int j = g.jlo - SWW_REACH + cb * SWW_OUT + l;
     const int jc = j < 0 ? 0 : (j < g.qy ? j : g.qy - 1);
     const bool jout = l >= SWW_REACH && l < SWW_REACH + SWW_OUT && j >= g.jlo && j <= g.jhi;
@@ -681,9 +690,34 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
     unsigned hw_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
     const int wslot = (int)(hw_id & 1u);
+    // (comp_wave.hip: the two wavefronts of a SIMD tell each other their rows left, the one behind takes the priority)
+    const bool prio_fb = P.prio_board != nullptr;
+    int *prio_mine = nullptr, *prio_other = nullptr;
+    int prio_seen = 0;
+    if (prio_fb) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        int *const pair = P.prio_board + 2 * (int)(((xcc & 15u) << 12) | ((hw_id >> 4) & 0xfffu));
+        prio_mine = pair + wslot;
+        prio_other = pair + (wslot ^ 1);
+    }
+    auto prio_publish = [&](int k) {      // (behind the request of the next row)
+        if (!prio_fb) return;
+        __hip_atomic_store(prio_mine, (P.prio_tag << 16) | (i1 + 2 - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        prio_seen = __hip_atomic_load(prio_other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+#else
+    auto prio_publish = [](int) {};
 #endif
     for (int k = i0 - 3; k <= i1 + 2; k++) {
 #if !defined(PYRO_EMU)
+        if (prio_fb) {
+            const int seen = __builtin_amdgcn_readfirstlane(prio_seen);
+            const int left = i1 + 2 - k;
+            const int other_left = ((seen >> 16) == P.prio_tag) ? (seen & 0xffff) : left;
+            if (left > other_left) __builtin_amdgcn_s_setprio(1);
+            else if (left < other_left) __builtin_amdgcn_s_setprio(0);
+        } else
         if (P.prio_duty > 0) {     // the two wavefronts of a SIMD take turns at the priority (comp_wave.hip)
             const int phase = ((k - i0) >> 1) & 7;
             if (wslot ? (phase < P.prio_duty) : (phase >= P.prio_duty)) __builtin_amdgcn_s_setprio(1);
@@ -701,6 +735,7 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
         if (!SWW_DELAY) {
         Upre = loadU(k + 1);
         Urep = loadU(k - 2);
+        prio_publish(k);
         }
         q[4][0] = Uk.a[0];
         q[4][1] = sw_vel(Uk.a[1], Uk.a[0]);
@@ -714,6 +749,7 @@ __global__ __launch_bounds__(64, 2) void k_sw_wave(const double *__restrict__ Ui
             if (k - 1 - 2 >= i0 + 1 && jout) store_row(Upend, k - 4);      // the update iteration k-1 made (row c-1 = k-4)
             Uold = loadU(k - 3);                 // (in front of the next row's request: its wait leaves that one out)
             Upre = loadU(k + 1);
+            prio_publish(k);
             SWW_FENCE();
         }
         const int c = k - 2;                 // window row 2
@@ -826,6 +862,12 @@ static int sww_rows(int nx, int ncb, int cus)
     return best;
 }
 
+#if !defined(PYRO_SWW_NO_EXTRA)
+static int sww_fill_extra(int ncb, int nsb, int nx, int slots) { return wave_fill_extra(ncb, nsb, nx, slots); }
+#else
+static int sww_fill_extra(int, int, int, int) { return 0; }
+#endif
+
 // ghost frame of the four planes from one buffer to the other (1-d grid: 2 ng blocks of
 // columns for the ghost rows, then row blocks for the ghost columns)
 __global__ __launch_bounds__(256) void k_sw_copy_frame(const double *__restrict__ src,
@@ -866,14 +908,21 @@ int swe_step_wave(pyrohip_state *s, double dx, double dy, double grav, int limit
         PYRO_CHECK_HIP(hipMalloc((void **)&s->alt_base, n * sizeof(double)));
         PYRO_CHECK_HIP(hipMemsetAsync(s->alt_base, 0, n * sizeof(double), c->stream));
     }
-    SWW P{dx, dy, dt, grav, limiter, 0, 0, 0, 0};
+    SWW P{dx, dy, dt, grav, limiter, 0, 0, 0, 0, 0, 0, nullptr, 0};
+    const int slots = 8 * (c->num_cus > 0 ? c->num_cus : 256);
     P.ncb = (g.ny + SWW_OUT - 1) / SWW_OUT;
     P.L = sww_rows(g.nx, P.ncb, c->num_cus > 0 ? c->num_cus : 256);
-    P.nunits = P.ncb * ((g.nx + P.L - 1) / P.L);
+    P.nsb = (g.nx + P.L - 1) / P.L;
+    P.n_extra = sww_fill_extra(P.ncb, P.nsb, g.nx, slots);
+    P.nunits = P.ncb * P.nsb + P.n_extra;
     if (nparts) *nparts = P.nunits;
     {
-        // one round of resident wavefronts: the pair of a SIMD takes turns at the priority and ends together
-        P.prio_duty = (P.nunits <= 8 * (c->num_cus > 0 ? c->num_cus : 256)) ? 6 : 0;
+        // one round of resident wavefronts: the pair of a SIMD ends together -- the one with more rows left
+        // takes the priority (GPU; comp_wave.hip), turns by phase otherwise
+        P.prio_duty = (P.nunits <= slots) ? 6 : 0;
+#if !defined(PYRO_EMU) && !defined(PYRO_SWW_NO_FEEDBACK)
+        if (P.prio_duty > 0) PYRO_TRY(prio_board_acquire(c, &P.prio_board, &P.prio_tag));
+#endif
     }
     double *Uout = s->alt_base + geom_lead(g);
     const dim3 grid(8 * ((P.nunits + 7) / 8)), block(64);
@@ -905,7 +954,8 @@ int swe_wave_units(const Geom &g, int cus)
 {
     const int ncb = (g.ny + SWW_OUT - 1) / SWW_OUT;
     const int L = sww_rows(g.nx, ncb, cus > 0 ? cus : 256);
-    return ncb * ((g.nx + L - 1) / L);
+    const int nsb = (g.nx + L - 1) / L;
+    return ncb * nsb + sww_fill_extra(ncb, nsb, g.nx, 8 * (cus > 0 ? cus : 256));
 }
 #endif
 
