@@ -247,7 +247,7 @@ __device__ __forceinline__ void st_put(double *st, int s, const Cons &U)
 __device__ unsigned long long g_wave_timeline[4 * 65536];
 #endif
 template <int SOLVER, bool STD, bool MOL = false, bool ONE = false, bool RKF = false, bool SRC = true,
-          int FINT = -1>   // SOLVER, STD as k_ctu_fused
+          int FINT = -1, bool FB = false>   // SOLVER, STD as k_ctu_fused
 __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *__restrict__ Uin,
                                                                  double *__restrict__ Uout, Geom g,
                                                                  FP P, int *__restrict__ flag,
@@ -571,7 +571,9 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     // five; 3072^2 wants seven).  With a board (P.prio_board: one word per SIMD and slot in device memory, the
     // two wavefronts of a SIMD sit on one XCD = one L2) each tells the other how many rows it has left, a row
     // late, and the one with more rows left takes the priority: the pair ends together whatever the strips.
-    const bool prio_fb = P.prio_board != nullptr;
+    // (FB: instances of their own -- the launches of many rounds, the headline's, keep the code they had; the
+    // method-of-lines instances have no register for it)
+    const bool prio_fb = FB && !MOL && P.prio_board != nullptr;
     int *prio_mine = nullptr, *prio_other = nullptr;
     int prio_seen = 0;
     if (prio_fb) {
@@ -1189,10 +1191,25 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         {k_ctu_wave<1, false, false, false, false, false>, k_ctu_wave<1, true, false, false, false, false>},
         {k_ctu_wave<2, false, false, false, false, false>, k_ctu_wave<2, true, false, false, false, false>}};
     const KernelT (*kernels)[2] = P.have_src ? kernels_src : kernels_nosrc;
+#if !defined(PYRO_EMU) && !defined(PYRO_WAVE_NO_FEEDBACK)
+    // ... with the rows-left board of the SIMD pairs (launches of one or two rounds)
+    static const KernelT kernels_src_fb[3][2] = {
+        {k_ctu_wave<0, false, false, false, false, true, -1, true>, k_ctu_wave<0, true, false, false, false, true, -1, true>},
+        {k_ctu_wave<1, false, false, false, false, true, -1, true>, k_ctu_wave<1, true, false, false, false, true, -1, true>},
+        {k_ctu_wave<2, false, false, false, false, true, -1, true>, k_ctu_wave<2, true, false, false, false, true, -1, true>}};
+    static const KernelT kernels_nosrc_fb[3][2] = {
+        {k_ctu_wave<0, false, false, false, false, false, -1, true>, k_ctu_wave<0, true, false, false, false, false, -1, true>},
+        {k_ctu_wave<1, false, false, false, false, false, -1, true>, k_ctu_wave<1, true, false, false, false, false, -1, true>},
+        {k_ctu_wave<2, false, false, false, false, false, -1, true>, k_ctu_wave<2, true, false, false, false, false, -1, true>}};
+    const KernelT (*kernels_fb)[2] = P.have_src ? kernels_src_fb : kernels_nosrc_fb;
+#else
+    const KernelT (*kernels_fb)[2] = kernels;
+#endif
 #else
     // (the bit-faithful build keeps ONE instance: without the source blocks its register allocation
     // comes out worse -- 15.8 -> 16.4 ms per step at 16384^2)
     const KernelT (*kernels)[2] = kernels_src;
+    const KernelT (*kernels_fb)[2] = kernels_src;      // (... and the turns by phase)
 #endif
     const int solver = (p->riemann == 1 || p->riemann == 2) ? p->riemann : 0;
     const int std_rec = (p->limiter == 2 && p->use_flattening) ? 1 : 0;
@@ -1256,8 +1273,8 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         s->halo_pending = false;
         return 0;
     }
-    PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((nwg + 7) / 8)), dim3(64), WLDS_BYTES,
-                (const double *)Uin, Uout, g, P, s->d_flag, part, S);
+    PYRO_LAUNCH(c, "k_ctu_wave", (P.prio_board ? kernels_fb : kernels)[solver][std_rec], dim3(8 * ((nwg + 7) / 8)),
+                dim3(64), WLDS_BYTES, (const double *)Uin, Uout, g, P, s->d_flag, part, S);
     if (post) {        // too few strips to overlap: the exchange follows the whole update
         if (!s->frame_prefilled) fused_copy_frame(s);
         PYRO_TRY(comm_post_halo(s, Uout));
