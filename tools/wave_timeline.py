@@ -54,6 +54,12 @@ def by(name, key):
     print(name + ": " + "  ".join(f"{k}:{life[key == k].mean():.0f}/{end[key == k].mean():.0f}" for k in ks))
 
 
+span = end.max()
+print("wavefronts alive at span - t: " + "  ".join(
+    f"{t:.0f} us: {int(np.sum((start <= span - t) & (end > span - t)))}" for t in (800, 600, 400, 300, 200, 150, 100, 50, 20)
+    if t < span))
+print(f"wavefront-time lost to the drain (slots not held between the last dispatch and the end): "
+      f"{np.sum(span - end[end > start.max()]) / len(np.unique(hw | (xcc << 20))) :.1f} us per SIMD slot pair")
 print("(mean life / mean end time, us)")
 by("xcc", xcc)
 by("wave slot", wave_id)
