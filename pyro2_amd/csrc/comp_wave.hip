@@ -268,7 +268,15 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     // that share apron rows and the cache lines at a column cut meet in ONE L2 at about the
     // same time (the launch pads the grid to a multiple of 8)
     const int per = (P.nunits + 7) / 8;
-    const int unit = ((int)blockIdx.x % 8) * per + (int)blockIdx.x / 8;
+    int unit = ((int)blockIdx.x % 8) * per + (int)blockIdx.x / 8;
+    if (P.n_short > 0) {
+        // (many rounds: every XCD's queue ends with its share of the short strips -- wave_short_tail below)
+        const int NL = P.ncb * (P.nsb - P.n_short), NS = P.ncb * P.n_short;
+        const int perL = (NL + 7) / 8, perS = (NS + 7) / 8;
+        const int x = (int)blockIdx.x % 8, r = (int)blockIdx.x / 8;
+        if (r < perL) unit = (x * perL + r < NL) ? x * perL + r : P.nunits;
+        else unit = (x * perS + r - perL < NS) ? NL + x * perS + r - perL : P.nunits;
+    }
     if (unit >= P.nunits) return;
     // (units behind the ncb x nsb regular ones: the extra strip of the column strips [0, n_extra) -- a launch
     // that fits the resident slots in one round is cut into exactly as many strips as there are slots,
@@ -283,6 +291,10 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     if (cb < P.n_extra) {      // nsb + 1 strips of equal length (to a row)
         i0 = g.ilo + (int)((long)sb * g.nx / (P.nsb + 1));
         i1 = g.ilo + (int)((long)(sb + 1) * g.nx / (P.nsb + 1));
+    }
+    if (P.n_short > 0 && sb >= P.nsb - P.n_short) {      // a short strip at the end of the grid
+        i0 = g.ilo + (P.nsb - P.n_short) * P.L + (sb - (P.nsb - P.n_short)) * P.Ls;
+        i1 = (sb == P.nsb - 1) ? g.ihi + 1 : i0 + P.Ls;
     }
     const int j = g.jlo + cb * WOUT - 4 + l;               // this lane's column
     const int jc = (j < g.qy) ? j : g.qy - 1;              // ragged last strip: clamp, unused
@@ -1145,6 +1157,41 @@ static int wave_extra_units(const WaveGeom &w, int nx, int slots, int march_rows
 #else
 static int wave_extra_units(const WaveGeom &, int, int, int) { return 0; }
 #endif
+// Many-round launches: the slots empty over the last strip's life (16384^2: 1815 / 1319 / 737 / 486 of 2048 wavefronts
+// alive 400 / 300 / 200 / 100 us before the end of an 8.4 ms launch, tools/wave_timeline.py: ~2.7 % of the launch, 3.5 % at
+// 8192^2).  So the row strips of the last round's worth of units are cut in two, and every XCD's queue of units ends
+// with its share of them (the kernel's unit numbering): the drain lasts a short strip's life.  Single domain,
+// launches of >= 4 rounds.  -> number of short strips (0: none), *Ls their length,
+// *nsb_long the long ones in front
+#if !defined(PYRO_WAVE_NO_SHORT_TAIL)
+static int wave_short_tail(const WaveGeom &w, int nx, int slots, int march_rows, int *Ls, int *nsb_long)
+{
+    (void)march_rows;
+    if ((long)w.ncb * w.nsb < 4L * slots || w.L < 16) return 0;
+    // (measured, Gcell/s with halves / thirds / quarters: 16384^2 (126-row strips) 31.95 / 32.00 / 32.12, 8192^2 (59 rows)
+    // 30.10 / 30.07 / 29.99, 6144^2 28.4 / 28.35 / 28.07; without the tail 31.75 / 29.7 / 27.65; a region of half a
+    // round of units 31.81 / 29.85 / 27.85, of a round and a half 31.97 / 30.02 / 28.20: short strips of about 30 rows)
+#ifndef PYRO_WAVE_TAIL_DIV
+#define PYRO_WAVE_TAIL_DIV (w.L >= 100 ? 4 : 2)
+#endif
+#ifndef PYRO_WAVE_TAIL_ROUNDS_X2
+#define PYRO_WAVE_TAIL_ROUNDS_X2 2
+#endif
+    const int nr1 = (slots + w.ncb - 1) / w.ncb;           // row strips of one round of units
+    if (w.nsb < 4 * nr1) return 0;
+    const int nr = (nr1 * PYRO_WAVE_TAIL_ROUNDS_X2 + 1) / 2;
+    const int nl = w.nsb - nr;
+    const int rows = nx - nl * w.L;                        // rows of the short region (>= 1: nsb strips cover nx)
+    const int ls = (w.L + PYRO_WAVE_TAIL_DIV - 1) / PYRO_WAVE_TAIL_DIV;
+    int ns = (rows + ls - 1) / ls;
+    if (ns > 1 && rows - (ns - 1) * ls < 4) ns--;          // (a last strip of < 4 rows joins its predecessor)
+    if (rows < 8 || ns < 1) return 0;
+    *Ls = ls; *nsb_long = nl;
+    return ns;
+}
+#else
+static int wave_short_tail(const WaveGeom &, int, int, int, int *, int *) { return 0; }
+#endif
 #if !PYRO_FAST
 // (for callers that want to know before they launch: bench.py's scaling line, the tests of
 // the decomposed runs)  out: ncb, L, nsb, overlap, wavefronts, resident slots
@@ -1176,7 +1223,11 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
     // protocol does not depend on this rank's geometry
     const bool post = s->nb_set && comm_can_overlap(s);
     P.n_extra = (s->nb_set || post) ? 0 : wave_extra_units(wg, g.nx, 4 * PYRO_WAVE_MINW * cus, p->march_rows);
-    const int nwg = P.ncb * nsb + P.n_extra;
+    int nsb_long = nsb;
+    if (!s->nb_set && !post && !(S && s->pol_next))
+        P.n_short = wave_short_tail(wg, g.nx, 4 * PYRO_WAVE_MINW * cus, p->march_rows, &P.Ls, &nsb_long);
+    if (P.n_short > 0) P.nsb = nsb_long + P.n_short;
+    const int nwg = P.ncb * P.nsb + P.n_extra;
     PYRO_TRY(c->reduce.ensure((nwg + kMinStageBlocks + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
     using KernelT = void (*)(const double *, double *, Geom, FP, int *, double *,
@@ -1273,7 +1324,10 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         s->halo_pending = false;
         return 0;
     }
-    PYRO_LAUNCH(c, "k_ctu_wave", (P.prio_board ? kernels_fb : kernels)[solver][std_rec], dim3(8 * ((nwg + 7) / 8)),
+    // (short tail: the grid holds the eight queues of long units, then the eight of short ones)
+    const int nblocks = P.n_short > 0 ? 8 * ((P.ncb * (P.nsb - P.n_short) + 7) / 8 + (P.ncb * P.n_short + 7) / 8)
+                                      : 8 * ((nwg + 7) / 8);
+    PYRO_LAUNCH(c, "k_ctu_wave", (P.prio_board ? kernels_fb : kernels)[solver][std_rec], dim3(nblocks),
                 dim3(64), WLDS_BYTES, (const double *)Uin, Uout, g, P, s->d_flag, part, S);
     if (post) {        // too few strips to overlap: the exchange follows the whole update
         if (!s->frame_prefilled) fused_copy_frame(s);

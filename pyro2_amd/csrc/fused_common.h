@@ -28,6 +28,8 @@ struct FP {   // kernel parameters
     int prio_duty;            // ... eighths of the time the second wavefront of a SIMD has priority (0: age decides)
     int sb_first, sb_step;    // ... strip of workgroup b: sb_first + (b / ncb) * sb_step
     int n_extra;              // ... column strips [0, n_extra) are cut into nsb + 1 row strips (one-round launches: every slot filled)
+    int n_short, Ls;          // ... many-round launches: the LAST n_short of the nsb row strips are short ones (Ls rows), dealt to the
+                              //     ends of the eight XCD queues: the slots drain over a short strip's life (comp_wave.hip)
     int *prio_board;          // ... rows-left board of the SIMD pairs (nullptr: priority turns by prio_duty) and this launch's tag
     int prio_tag;
     // tile kernel: the ghost fill folded into the loads (pyrohip_comp_params.fuse_fill):

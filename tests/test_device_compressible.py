@@ -1580,6 +1580,37 @@ def test_rk_evolve_on_device_equals_single_steps(dev, method):
         res.append((d1,))
 
 
+@pytest.mark.parametrize("fast", [0, 1])
+def test_comp_wave_short_tail_of_a_many_round_launch(dev, fast):
+    """launches of four and more rounds of resident wavefronts cut the row strips of their last round's worth of
+    units in two and deal them to the ends of the eight XCD queues (comp_wave.hip: wave_short_tail).  The emulated
+    device has 32 wavefront slots: 512 x 224 cells in 16-row strips are 4 column x 32 row strips = four rounds -> 24
+    long + 16 short row strips.  Three steps (host-stepped and on the device) against the tile kernel: every cell
+    updated exactly once, bit for bit in the bit-faithful build (the contracted one computes a cell the same way
+    whatever strip it sits in: the two kernels differ by their algebra, 1e-10)"""
+    if dev.kind == "hip":
+        pytest.skip("a 512 x 224 grid is one round on this device (the bench-size tests cover its many-round launches)")
+    nx, ny, ng = 512, 224, 4
+    meta = [nx, ny, ng, 1.0 / nx, 1.0 / ny, 1.4, 2, 1, 0.75, 0.85, 0.33, 0.1, 0.0, 0.8]
+    bcs = ["outflow", "reflect", "periodic", "periodic"]
+    U0 = _rk_random_state(nx, ny, 11)
+    ref, dref, _ = device_comp_run(dev, U0, meta, bcs, 1.0, 3, kernel_set=1, fast_math=fast)
+    got, dgot, _ = device_comp_run(dev, U0, meta, bcs, 1.0, 3, kernel_set=2, march_rows=16, fast_math=fast)
+    P, cfl = dev_params(meta, kernel_set=2, march_rows=16, fast_math=fast)
+    s = comp_state(dev, nx, ny, bcs)
+    s.upload(U0)
+    pol = DtPolicy(1.0)
+    dts = list(s.comp_evolve(P, cfl, pol, 3))
+    onb = s.download()
+    if fast == 0:
+        assert list(dgot) == list(dref) == dts
+        assert np.array_equal(got[ng:-ng, ng:-ng], ref[ng:-ng, ng:-ng])
+        assert np.array_equal(onb[ng:-ng, ng:-ng], ref[ng:-ng, ng:-ng])
+    else:
+        assert elementwise_err(got[ng:-ng, ng:-ng], ref[ng:-ng, ng:-ng], comp_floors(ref[ng:-ng, ng:-ng])) <= 1e-10
+        assert np.array_equal(onb[ng:-ng, ng:-ng], got[ng:-ng, ng:-ng])
+
+
 @pytest.mark.parametrize("solver", ["ctu_tile", "ctu_wave", "rk"])
 def test_evolve_starts_from_the_cached_minimum_only_for_an_untouched_state(dev, solver):
     """a device-side run starts from the CFL minimum the previous call's last step left (no pass over the
