@@ -767,7 +767,7 @@ int fused_prepare(pyrohip_state *s, const pyrohip_comp_params *p, double dt, FP 
     P.ntj = P.ntiles = 0;
     P.L = P.ncb = P.nsb = P.nunits = 0;
     P.prio_duty = 0;
-    P.sb_first = 0; P.sb_step = 1; P.n_extra = 0; P.n_short = 0; P.Ls = 0; P.prio_board = nullptr; P.prio_tag = 0;
+    P.sb_first = 0; P.sb_step = 1; P.n_extra = 0; P.n_short = 0; P.Ls = 0; P.n_tail = 0; P.units_short = 0; P.prio_board = nullptr; P.prio_tag = 0;
     P.mr = bc_map(g.ilo, g.ihi, g.ng, 0, 0, false);      // identity (tile kernel: fused_fill_maps)
     P.mc = P.mr;
     P.odd = 0;

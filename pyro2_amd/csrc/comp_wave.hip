@@ -269,9 +269,9 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
     // same time (the launch pads the grid to a multiple of 8)
     const int per = (P.nunits + 7) / 8;
     int unit = ((int)blockIdx.x % 8) * per + (int)blockIdx.x / 8;
-    if (P.n_short > 0) {
+    if (P.units_short > 0) {
         // (many rounds: every XCD's queue ends with its share of the short strips -- wave_short_tail below)
-        const int NL = P.ncb * (P.nsb - P.n_short), NS = P.ncb * P.n_short;
+        const int NL = P.nunits - P.units_short, NS = P.units_short;
         const int perL = (NL + 7) / 8, perS = (NS + 7) / 8;
         const int x = (int)blockIdx.x % 8, r = (int)blockIdx.x / 8;
         if (r < perL) unit = (x * perL + r < NL) ? x * perL + r : P.nunits;
@@ -292,9 +292,12 @@ __global__ __launch_bounds__(64, PYRO_WAVE_MINW) void k_ctu_wave(const double *_
         i0 = g.ilo + (int)((long)sb * g.nx / (P.nsb + 1));
         i1 = g.ilo + (int)((long)(sb + 1) * g.nx / (P.nsb + 1));
     }
-    if (P.n_short > 0 && sb >= P.nsb - P.n_short) {      // a short strip at the end of the grid
-        i0 = g.ilo + (P.nsb - P.n_short) * P.L + (sb - (P.nsb - P.n_short)) * P.Ls;
-        i1 = (sb == P.nsb - 1) ? g.ihi + 1 : i0 + P.Ls;
+    if (P.n_short > 0 && sb >= P.nsb - P.n_short - P.n_tail) {
+        // long strips, then n_short short ones, then n_tail long ones (a slab's last boundary strip)
+        const int nl = P.nsb - P.n_short - P.n_tail;
+        if (sb < nl + P.n_short) { i0 = g.ilo + nl * P.L + (sb - nl) * P.Ls; i1 = i0 + P.Ls; }
+        else { i0 = g.ilo + nl * P.L + P.n_short * P.Ls + (sb - nl - P.n_short) * P.L; i1 = i0 + P.L; }
+        if (sb == P.nsb - 1) i1 = g.ihi + 1;
     }
     const int j = g.jlo + cb * WOUT - 4 + l;               // this lane's column
     const int jc = (j < g.qy) ? j : g.qy - 1;              // ragged last strip: clamp, unused
@@ -1226,7 +1229,27 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
     int nsb_long = nsb;
     if (!s->nb_set && !post && !(S && s->pol_next))
         P.n_short = wave_short_tail(wg, g.nx, 4 * PYRO_WAVE_MINW * cus, p->march_rows, &P.Ls, &nsb_long);
-    if (P.n_short > 0) P.nsb = nsb_long + P.n_short;
+    if (P.n_short > 0) { P.nsb = nsb_long + P.n_short; P.units_short = P.ncb * P.n_short; }
+#if !defined(PYRO_WAVE_NO_SLAB_TAIL)
+    // (a slab with the boundary strips on the halo stream: the interior launch ends with short strips too -- the
+    // row strips in front of the last boundary strip, which keeps its rows; strip lengths that divide only)
+    int slab_short = 0;
+    if (post && wg.overlap) {
+        int ls = 0, nl1 = 0;
+        const int ns1 = wave_short_tail(wg, g.nx, 4 * PYRO_WAVE_MINW * cus, 0, &ls, &nl1);
+        const int div = ls > 0 ? (P.L + ls - 1) / ls : 0;
+        const int nr = nsb - nl1;                          // (row strips of one round of units: wave_short_tail)
+        if (ns1 > 0 && div >= 2 && P.L % div == 0 && nsb - nr - 1 >= 2) {
+            P.Ls = P.L / div;
+            P.n_short = nr * div;
+            P.n_tail = 1;
+            P.nsb = nsb + nr * (div - 1);
+            slab_short = P.ncb * P.n_short;
+        }
+    }
+#else
+    const int slab_short = 0;
+#endif
     const int nwg = P.ncb * P.nsb + P.n_extra;
     PYRO_TRY(c->reduce.ensure((nwg + kMinStageBlocks + 2) * sizeof(double)));
     double *part = (double *)c->reduce.p;
@@ -1277,16 +1300,20 @@ int comp_step_wave_ex(pyrohip_state *s, const pyrohip_comp_params *p, double dt,
         s->frame_prefilled = false;
         hipStream_t bs = nullptr;
         PYRO_TRY(comm_fork_boundary(s, &bs));
-        P.sb_first = 0; P.sb_step = nsb - 1;
+        P.sb_first = 0; P.sb_step = P.nsb - 1;
         P.nunits = 2 * P.ncb;
+        P.units_short = 0;
         P.prio_duty = 0;               // (the pair of a SIMD may belong to the other launch)
         PYRO_LAUNCH_ON(c, bs, "k_ctu_wave_boundary", kernels[solver][std_rec], dim3(8 * ((P.nunits + 7) / 8)),
                        dim3(64), WLDS_BYTES, (const double *)Uin, Uout, g, P, s->d_flag, part, S);
         PYRO_TRY(comm_post_halo_here(s, Uout));
         P.sb_first = 1; P.sb_step = 1;
-        P.nunits = (nsb - 2) * P.ncb;
+        P.nunits = (P.nsb - 2) * P.ncb;
+        P.units_short = slab_short;
         P.prio_duty = wave_prio_duty(nwg, 4 * PYRO_WAVE_MINW * cus, P.L);
-        PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(8 * ((P.nunits + 7) / 8)), dim3(64),
+        const int nblk = slab_short > 0 ? 8 * ((P.nunits - slab_short + 7) / 8 + (slab_short + 7) / 8)
+                                        : 8 * ((P.nunits + 7) / 8);
+        PYRO_LAUNCH(c, "k_ctu_wave", kernels[solver][std_rec], dim3(nblk), dim3(64),
                     WLDS_BYTES, (const double *)Uin, Uout, g, P, s->d_flag, part, S);
         PYRO_TRY(comm_join_boundary(s));       // the minimum below reads the boundary strips' partials
         const double *dmin;

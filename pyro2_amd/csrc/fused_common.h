@@ -30,6 +30,7 @@ struct FP {   // kernel parameters
     int n_extra;              // ... column strips [0, n_extra) are cut into nsb + 1 row strips (one-round launches: every slot filled)
     int n_short, Ls;          // ... many-round launches: the LAST n_short of the nsb row strips are short ones (Ls rows), dealt to the
                               //     ends of the eight XCD queues: the slots drain over a short strip's life (comp_wave.hip)
+    int n_tail, units_short;  // ... long strips BEHIND the short ones (a slab's last boundary strip: 1); short units of THIS launch (0: plain dealing)
     int *prio_board;          // ... rows-left board of the SIMD pairs (nullptr: priority turns by prio_duty) and this launch's tag
     int prio_tag;
     // tile kernel: the ghost fill folded into the loads (pyrohip_comp_params.fuse_fill):

@@ -63,6 +63,64 @@ def test_rccl_step_with_device_side_dt_allreduce(hip):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fast", [0, 1])
+def test_rccl_overlapped_slab_short_strips_at_the_end_of_the_interior(hip, fast):
+    """a slab whose launch is four and more rounds of wavefronts ends its INTERIOR launch with short strips (the
+    row strips in front of the last boundary strip cut in two, dealt to the ends of the XCD queues:
+    comp_wave.hip).  1792 x 4096 cells in 16-row strips = 74 x 112 = 8288 wavefronts on 2048 slots -> 83 long
+    row strips, 56 short ones, the last boundary strip.  Both x neighbours the rank itself = the periodic
+    single-domain run (which cuts ITS last strips short another way): 3 steps, host-stepped and enqueued on
+    the device, bit for bit in both builds (a cell is computed the same way whatever strip it sits in)"""
+    from pyro2_amd.decomp import DtPolicy
+    try:
+        hip.comm_init(1, 0, device.Context.comm_unique_id())
+    except Exception:
+        pass
+    hip.comm_set_global_dt(False)
+    nx, ny, ng = 1792, 4096, 4
+    rng = np.random.default_rng(5)
+    x = (np.arange(nx + 2 * ng)[:, None] - ng + 0.5) / nx
+    y = (np.arange(ny + 2 * ng)[None, :] - ng + 0.5) / ny
+    full = np.zeros((nx + 2 * ng, ny + 2 * ng, 4))
+    a = rng.uniform(0.05, 0.2, 6)
+    rho = 1.0 + a[0] * np.sin(2 * np.pi * x) * np.cos(4 * np.pi * y) + a[1] * np.cos(6 * np.pi * x)
+    u = a[2] * np.sin(4 * np.pi * x) + a[3] * np.cos(2 * np.pi * y)
+    v = a[4] * np.cos(2 * np.pi * x) * np.sin(2 * np.pi * y)
+    pr = 1.0 + a[5] * np.cos(2 * np.pi * x) * np.sin(6 * np.pi * y)
+    full[..., 0] = rho
+    full[..., 2] = rho * u
+    full[..., 3] = rho * v
+    full[..., 1] = pr / 0.4 + 0.5 * rho * (u * u + v * v)
+    P = device.make_comp_params(1.0 / nx, 1.0 / ny, fast_math=fast, kernel_set=2, march_rows=16)
+
+    def run(mode, on_device):
+        bx = "periodic" if mode == "periodic" else "halo"
+        s = device.DeviceState(hip, nx, ny, ng, [[bx, bx, "outflow", "outflow"]] * 4)
+        s.upload(full)
+        if mode == "overlap":
+            s.set_neighbours(0, 0)
+        pol, dts = DtPolicy(0.1), []
+        if on_device:
+            dts = list(s.comp_evolve(P, 0.8, pol, 3))
+        else:
+            for _ in range(3):
+                if mode != "periodic":
+                    s.halo_exchange(0, 0)
+                s.fill_bc()
+                dt = pol(s.comp_dt(P, 0.8))
+                s.comp_step(P, dt)
+                pol.advance(dt)
+                dts.append(dt)
+        return s.download()[ng:-ng, ng:-ng], dts
+
+    ref, dref = run("periodic", False)
+    for on_device in (False, True):
+        U, d = run("overlap", on_device)
+        assert d == dref, on_device
+        assert np.array_equal(U, ref), on_device
+
+
+@pytest.mark.gpu
 def test_rccl_overlapped_halo_self_neighbour(hip):
     """the overlapped exchange (boundary strips first, halos of the NEW state on the
     halo stream / second communicator beside the interior strips, next step only
